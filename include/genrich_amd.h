@@ -1,0 +1,174 @@
+/*
+ * genrich_amd.h -- C ABI of the MI355X-native Genrich hot path.
+ *
+ * The reference (jsh58/Genrich v0.6.2) is a monolith with no plugin/FFI
+ * interface; this header is the drop-in boundary cut where its data narrows
+ * (SURVEY.md section 8b).  Every entry point names the reference code it
+ * replaces (file:line into Genrich.c / Genrich.h).  Plain C types only: no
+ * torch, no HIP types.  Handle based, not thread-safe (the reference is
+ * single-threaded, README.md:535).
+ *
+ * Call order for one run (mirrors runProgram, Genrich.c:5386-5607):
+ *
+ *   gx_create -> gx_set_chroms
+ *   for each replicate:
+ *     gx_sample_begin(ctx, 0, save) ; gx_push_events* ; gx_sample_end   (treatment)
+ *     either  gx_sample_begin(ctx, 1, NULL) ; gx_push_events* ; gx_sample_end   (control)
+ *     or      gx_sample_no_control
+ *     gx_pvalues
+ *   gx_find_peaks -> gx_get_peaks / gx_get_intervals
+ *   gx_destroy
+ */
+#ifndef GENRICH_AMD_H
+#define GENRICH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GX_SKIP (-1.0f) /* Genrich.h:27  SKIP: statistic of an excluded (-E) region */
+
+/* Status codes.  0 = success; negative values map 1:1 onto the reference's
+ * errCode enum (Genrich.h:97-106) so a host can print the identical
+ * "Error! <msg>" text (Genrich.c:78-81) and exit(1). */
+enum gx_status {
+  GX_OK = 0,
+  GX_ERR_MEM = -1,      /* ERRMEM    "Cannot allocate memory" */
+  GX_ERR_GEN = -2,      /* ERRGEN    "No analyzable genome (length=0)"           Genrich.c:1828 */
+  GX_ERR_EXPT = -3,     /* ERREXPT   "Experimental sample has no analyzable fragments" :2292 */
+  GX_ERR_PILE = -4,     /* ERRPILE   "Invalid pileup value (< 0)"                :1921,1969 */
+  GX_ERR_POS = -5,      /* ERRPOS    ": read aligned beyond reference end"       :2531 */
+  GX_ERR_ALNS = -6,     /* ERRALNS   "Disallowed number of alignments"           :2402,2485 */
+  GX_ERR_ARR = -7,      /* ERRARR / ERRARRC / "finishes at %f (not 0.0)"         :2144,2276,2153,2284 */
+  GX_ERR_PVAL = -8,     /* ERRPVAL / genome-length mismatch                      :344,377 */
+  GX_ERR_DF = -9,       /* ERRDF     "Invalid df in pchisq()"                    :556 */
+  GX_ERR_ORDER = -10,   /* API called out of order / bad argument */
+  GX_ERR_DEVICE = -11,  /* HIP runtime failure (message via gx_last_error) */
+  GX_ERR_OVERFLOW = -12 /* a per-base difference reached the int16 range at which the
+                           reference starts skipping alignments (Genrich.c:2558-2573);
+                           that order-dependent behaviour is not reproduced */
+};
+
+/* One alignment-derived interval AFTER saveInterval's clamping
+ * (Genrich.c:2522-2544): 0 <= start < len(chrom), start <= end <= len.
+ * weight = 1/count, count in {1,2,3,4,5,6,8,10} (Genrich.c:2576-2583,
+ * addFrac 2311, subFrac 2412). */
+typedef struct gx_event {
+  uint32_t chrom; /* index into the table given to gx_set_chroms */
+  uint32_t start;
+  uint32_t end;
+  uint32_t count;
+} gx_event;
+
+/* Peak-calling parameters: the tail of runProgram's argument list
+ * (Genrich.c:5390-5395) after getArgs' conversions (5796-5817). */
+typedef struct gx_params {
+  float thr;           /* minPQval = -log10f(-p or -q value)           Genrich.c:5817 */
+  int32_t qval_opt;    /* 1: significance on q-values (-q)             :5790 */
+  float min_auc;       /* -a, DEFAUC 200.0f                            Genrich.h:31 */
+  int32_t min_len;     /* -l, DEFMINLEN 0 */
+  int32_t max_gap;     /* -g, DEFMAXGAP 100 */
+  int32_t device;      /* HIP device ordinal (ignored by the CPU oracle) */
+  uint64_t genome_len; /* -L, 0 = compute from the chromosome table    :1819,1091 */
+} gx_params;
+
+/* One called peak = the arguments of printPeak (Genrich.c:885-887). */
+typedef struct gx_peak {
+  uint32_t chrom;
+  uint32_t start;
+  uint32_t end;
+  uint32_t summit; /* offset of the summit from start (narrowPeak column 10) */
+  float auc;       /* signal (column 7) */
+  float p;         /* summit -log10 p (column 8) */
+  float q;         /* summit -log10 q (column 9) or GX_SKIP without -q */
+} gx_peak;
+
+typedef struct gx_ctx gx_ctx;
+
+/* ---- life cycle ------------------------------------------------------- */
+
+int gx_create(gx_ctx** ctx, const gx_params* params);
+void gx_destroy(gx_ctx* ctx);
+const char* gx_last_error(const gx_ctx* ctx);
+const char* gx_strerror(int status); /* the reference's errMsg text, Genrich.h:107-154 */
+
+/* Chromosome table in header order = output order (saveChrom, Genrich.c:4220-4270).
+ * skip[i]   : chromosome listed in -e (Chrom.skip, :4243).
+ * bed[i]    : merged, sorted -E coordinates as start/end pairs (Chrom.bed, saveXBed :1144);
+ *             bed_len[i] = number of coordinates (even). bed/bed_len may be NULL. */
+int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip,
+                  const uint32_t* const* bed, const int32_t* bed_len);
+
+/* ---- per-sample event stream (replaces saveInterval's accumulate step,
+ *      Genrich.c:2546-2583, and the re-zeroing of diff arrays, :5503-5510) ---- */
+
+/* is_ctrl = 0: start the treatment file of the next replicate; save[i] = chromosome
+ * appears in this treatment file's header (Chrom.save, :4230-4244, reset :5463).
+ * is_ctrl = 1: start the matching control file (save must be NULL). */
+int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save);
+
+/* Host-resident events; copied before return (caller keeps ownership). */
+int gx_push_events(gx_ctx* ctx, const gx_event* events, size_t n);
+
+/* Events already resident in device memory (HIP path only; the pointer must stay
+ * valid until gx_sample_end). */
+int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n);
+
+/* Treatment: == savePileupExpt (Genrich.c:2168-2295), returns fragLen.
+ * Control : == savePileupCtrl (:2052-2161), returns lambda and factor.
+ * Any out pointer may be NULL. */
+int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor);
+
+/* == savePileupNoCtrl (Genrich.c:1883-1896): missing or "null" control. */
+int gx_sample_no_control(gx_ctx* ctx, float* lambda);
+
+/* == savePval (Genrich.c:1720-1794) for the current replicate; closes the replicate. */
+int gx_pvalues(gx_ctx* ctx);
+
+/* ---- genome-wide statistics and peaks (replaces findPeaks, Genrich.c:1076-1137:
+ *      combinePval 612, computeQval 352, callPeaks 977) ---- */
+
+int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* peak_bp);
+
+/* Copies min(cap, n_peaks) peaks, chromosome-table order then position. */
+int gx_get_peaks(gx_ctx* ctx, gx_peak* out, size_t cap);
+
+/* Interval arrays for host-side -f / -k formatting (printLog 808, printPile 1697).
+ * which: replicate index r (0..n-1) = that replicate's p-value intervals,
+ *        GX_IV_FINAL = the intervals peaks were called on (combined when n > 1).
+ * Arrays (any may be NULL) receive n_iv entries: end[], expt[] and ctrl[] pileups
+ * (only meaningful for a single replicate, as in the reference), p[], q[]. */
+#define GX_IV_FINAL (-1)
+int gx_interval_count(gx_ctx* ctx, int which, int chrom, size_t* n_iv);
+int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* end,
+                     float* expt, float* ctrl, float* p, float* q);
+
+/* ---- multi-GPU hooks: chromosomes are sharded across ranks; the
+ *      three genome-wide quantities are exchanged through host-supplied callbacks
+ *      (RCCL via torch.distributed in bench.py; a no-op on one GPU). ---- */
+
+/* Sum `n` int64 values over all ranks in place (fragLen / ctrlFrag fixed-point parts,
+ * genome length).  buf is host memory. */
+typedef int (*gx_allreduce_i64_fn)(int64_t* buf, size_t n, void* user);
+/* Gather variable-length tables: every rank contributes n_local 16-byte records
+ * {uint32 key, uint32 pad, uint64 bp}; the callback returns a malloc'd concatenation of
+ * all ranks' records in *out / *n_out (freed by the library with free()).
+ * With dev = 1 the buffers are device pointers and the callback must not free them. */
+typedef int (*gx_allgather_tab_fn)(const void* local, size_t n_local, void** out,
+                                   size_t* n_out, void* user);
+int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce,
+                       gx_allgather_tab_fn allgather, void* user);
+
+/* ---- introspection used by bench.py / tests ---- */
+
+/* Per-phase device times (ms, HIP events on the library's stream) of the last
+ * gx_* call sequence; names are NUL-separated in *names. Returns count. */
+int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENRICH_AMD_H */

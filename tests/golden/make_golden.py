@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the UNMODIFIED reference
+(oracle/_ref/Genrich, built by oracle/Makefile from /root/reference) on small synthetic
+SAM files.  Run in the build container only:  python tests/golden/make_golden.py
+
+Per case the fixture holds DATA only:
+  case.json          chromosome table, -e/-E, per-replicate `save` flags, parameters, the
+                     scalars the reference printed under -v (lambda, factor, genome length,
+                     peak count / bp)
+  events.bed.gz      the reference's own -b output = the post-clamp event list
+                     (chr start end name_count_[E|C]_sample; Genrich.c:2497-2508)
+  out.narrowPeak.gz, out.log.gz (-f), out.pile.gz (-k)   the reference's outputs
+The SAM inputs are regenerated from tests/synth.py and are not committed.
+"""
+import gzip
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "Genrich")
+
+
+def merged_bed(regions, clen):
+    """saveXBed's sort + clamp + merge (Genrich.c:1144-1206) for one chromosome."""
+    iv = sorted([list(r) for r in regions if r[0] < clen], key=lambda r: r[0])
+    out = []
+    for s, e in iv:
+        e = min(e, clen)
+        if out and s <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], e)
+        else:
+            out.append([s, e])
+    return [c for r in out for c in r]
+
+
+def multimap_reads(lens, n_reads, seed):
+    """Reads with 1..12 equally scored alignments (exercises counts 2,3,4,5,6,8,10 and the
+    7 / 9 / >10 subsampling, Genrich.c:3145-3146)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rows = []
+    for _ in range(n_reads):
+        k = int(rng.integers(1, 13))
+        for _a in range(k):
+            c = int(rng.integers(0, len(lens)))
+            fl = int(100 + rng.integers(0, 150))
+            s = int(rng.integers(0, lens[c] - fl))
+            # pull most of the alignments towards a few hot spots so peaks exist
+            if rng.random() < 0.75:
+                s = int(min(max(0, (s // 10000) * 10000 + 5000 + rng.integers(-60, 60)), lens[c] - fl))
+            rows.append((c, s, s + fl, k))
+    return np.array(rows, dtype=synth.EVENT_DTYPE)
+
+
+def mf(lens, n, seed, peak_every=8000, tower_every=30000, **kw):
+    """Strongly enriched stream so that the tiny genomes still yield peaks and q < 1."""
+    if kw.get("uniform_only"):
+        return synth.make_fragments(lens, n, seed, **kw)
+    return synth.make_fragments(lens, n, seed, peak_every, tower_every, frac_peak=0.4,
+                                frac_tower=0.3, **kw)
+
+
+def cases():
+    L1 = [60_000]
+    yield dict(
+        name="basic", names=["chrA"], args=[],
+        reps=[dict(t=(["chrA"], L1, mf(L1, 3000, 11)), c=None)])
+
+    L2 = [40_000, 25_000]
+    N2 = ["chr1", "chr2"]
+    yield dict(
+        name="ctrl_q", names=N2, args=["-q", "0.3", "-a", "20"],
+        reps=[dict(t=(N2, L2, mf(L2, 3000, 21)),
+                   c=(N2, L2, mf(L2, 2500, 22, uniform_only=True)))])
+
+    yield dict(
+        name="multimap", names=N2, args=["-p", "0.05", "-a", "5", "-g", "50"],
+        reps=[dict(t=(N2, L2, multimap_reads(L2, 1200, 31)),
+                   c=(N2, L2, multimap_reads(L2, 600, 32)))])
+
+    yield dict(
+        name="atac", names=N2, args=["-j", "-a", "50"],
+        reps=[dict(t=(N2, L2, mf(L2, 2500, 41)), c=None)])
+
+    yield dict(
+        name="atac_odd", names=N2, args=["-j", "-d", "151", "-q", "0.5", "-a", "10", "-l", "40"],
+        reps=[dict(t=(N2, L2, mf(L2, 2500, 42, min_len=30)),
+                   c=(N2, L2, mf(L2, 2000, 43, uniform_only=True)))])
+
+    yield dict(
+        name="reps3", names=N2, args=["-q", "0.2", "-a", "30"],
+        reps=[dict(t=(N2, L2, mf(L2, 2000, 51)),
+                   c=(N2, L2, mf(L2, 2000, 52, uniform_only=True))),
+              dict(t=(N2, L2, mf(L2, 2200, 53)), c="null"),
+              dict(t=(N2, L2, mf(L2, 1800, 55)),
+                   c=(N2, L2, mf(L2, 1500, 56, uniform_only=True)))])
+
+    # three replicates, p-value mode, one replicate lacks chr2 (NULL padding, 1735-1750)
+    yield dict(
+        name="reps3_p_missing", names=N2, args=["-a", "100"],
+        reps=[dict(t=(N2, L2, mf(L2, 2000, 61)), c=None),
+              dict(t=(N2[:1], L2[:1], mf(L2[:1], 1500, 62)), c=None),
+              dict(t=(N2, L2, mf(L2, 1800, 63)), c=None)])
+
+    L3 = [30_000, 20_000, 8_000]
+    N3 = ["chr1", "chr2", "chrX"]
+    yield dict(
+        name="bedx", names=N3, args=["-e", "chrX", "-a", "40", "-q", "0.2"],
+        bed=[("chr1", 0, 1500), ("chr1", 9000, 9800), ("chr1", 9500, 11000),
+             ("chr1", 29000, 31000), ("chr2", 5000, 5001), ("chr2", 19990, 20000),
+             ("chr2", 25000, 26000)],
+        reps=[dict(t=(N3, L3, mf(L3, 3000, 71)),
+                   c=(N3, L3, mf(L3, 2500, 72, uniform_only=True)))])
+
+    yield dict(
+        name="bedx_noctrl", names=N3, args=["-a", "40"],
+        bed=[("chr1", 0, 1500), ("chr1", 12000, 13000), ("chr2", 19000, 20000)],
+        reps=[dict(t=(N3, L3, mf(L3, 3000, 73)), c=None)])
+
+    # chrC appears only in the control header (save = false, Genrich.c:4244); chr2 has
+    # treatment reads but no control reads
+    NC = ["chr1", "chr2", "chrC"]
+    LC = [30_000, 20_000, 10_000]
+    ctrl = mf(LC, 2500, 82, uniform_only=True)
+    ctrl = ctrl[ctrl["chrom"] != 1]
+    yield dict(
+        name="ctrl_only_chrom", names=NC, args=["-a", "40", "-L", "45000"],
+        reps=[dict(t=(NC[:2], LC[:2], mf(LC[:2], 2500, 81)),
+                   c=(NC, LC, ctrl))])
+
+    # -X: no peak calling, just the -f log (logIntervals, Genrich.c:837)
+    yield dict(
+        name="nopeaks_log", names=N2, args=["-X", "-q", "0.05"],
+        reps=[dict(t=(N2, L2, mf(L2, 1500, 91)), c=None),
+              dict(t=(N2, L2, mf(L2, 1500, 92)), c=None)])
+
+
+def gz_copy(src, dst):
+    with open(src, "rb") as f, gzip.GzipFile(dst, "wb", mtime=0) as g:
+        shutil.copyfileobj(f, g)
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/Genrich missing: run `make -C oracle` in the build container")
+    for case in cases():
+        out_dir = os.path.join(HERE, case["name"])
+        os.makedirs(out_dir, exist_ok=True)
+        tmp = os.path.join("/tmp/genrich_golden", case["name"])
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        tfiles, cfiles = [], []
+        chrom_order, chrom_len = [], {}
+        saves = []
+
+        def seen(names, lens):
+            for n, l in zip(names, lens):
+                if n not in chrom_len:
+                    chrom_order.append(n)
+                    chrom_len[n] = l
+
+        for r, rep in enumerate(case["reps"]):
+            names, lens, ev = rep["t"]
+            p = os.path.join(tmp, f"t{r}.sam")
+            synth.write_sam(p, names, lens, ev, name_prefix=f"t{r}_")
+            tfiles.append(p)
+            seen(names, lens)
+            saves.append(list(names))
+            if rep["c"] is None:
+                cfiles.append(None)
+            elif rep["c"] == "null":
+                cfiles.append("null")
+            else:
+                names, lens, ev = rep["c"]
+                p = os.path.join(tmp, f"c{r}.sam")
+                synth.write_sam(p, names, lens, ev, name_prefix=f"c{r}_")
+                cfiles.append(p)
+                seen(names, lens)
+        args = [REF, "-t", ",".join(tfiles), "-v",
+                "-f", os.path.join(tmp, "out.log"), "-k", os.path.join(tmp, "out.pile"),
+                "-b", os.path.join(tmp, "events.bed")]
+        if "-X" not in case["args"]:
+            args += ["-o", os.path.join(tmp, "out.narrowPeak")]
+        if any(c is not None for c in cfiles):
+            args += ["-c", ",".join(c if c else "null" for c in cfiles)]
+        if case.get("bed"):
+            bp = os.path.join(tmp, "x.bed")
+            with open(bp, "w") as f:
+                for c, s, e in case["bed"]:
+                    f.write(f"{c}\t{s}\t{e}\n")
+            args += ["-E", bp]
+        args += case["args"]
+        res = subprocess.run(args, capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.exit(f"{case['name']}: reference failed:\n{res.stderr}")
+        err = res.stderr
+        skip = []
+        if "-e" in case["args"]:
+            skip = case["args"][case["args"].index("-e") + 1].split(",")
+        beds = {}
+        for n in chrom_order:
+            regs = [(s, e) for c, s, e in case.get("bed", []) if c == n]
+            beds[n] = merged_bed(regs, chrom_len[n]) if n not in skip else []
+        meta = dict(
+            name=case["name"], args=case["args"],
+            chroms=[dict(name=n, len=chrom_len[n], skip=n in skip, bed=beds[n]) for n in chrom_order],
+            replicates=[dict(save=[n in s for n in chrom_order],
+                             control=(None if c is None else ("null" if c == "null" else "file")),
+                             expt_name=os.path.basename(t),
+                             ctrl_name=(None if c is None else os.path.basename(c)))
+                        for s, c, t in zip(saves, cfiles, tfiles)],
+            ref_lambda=[float(v) for v in re.findall(r"Background pileup value: ([0-9.]+)", err)],
+            ref_factor=[float(v) for v in re.findall(r"Scaling factor for control pileup: ([0-9.]+)", err)],
+            ref_genome_len=[int(v) for v in re.findall(r"Genome length: (\d+)bp", err)],
+            ref_peaks=[[int(a), int(b)] for a, b in re.findall(r"Peaks identified: (\d+) \((\d+)bp\)", err)],
+            tmp_prefix=tmp + "/",
+        )
+        with open(os.path.join(out_dir, "case.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        for fn in ("events.bed", "out.narrowPeak", "out.log", "out.pile"):
+            src = os.path.join(tmp, fn)
+            if os.path.exists(src):
+                gz_copy(src, os.path.join(out_dir, fn + ".gz"))
+        n_np = sum(1 for _ in open(os.path.join(tmp, "out.narrowPeak"))) if "-X" not in case["args"] else 0
+        print(f"{case['name']:18s} peaks={n_np:4d} lambda={meta['ref_lambda']} factor={meta['ref_factor']}")
+        shutil.rmtree(tmp)
+
+
+if __name__ == "__main__":
+    main()
