@@ -1,0 +1,757 @@
+// gx_api.hip -- C ABI (include/genrich_amd.h) over the HIP kernels.  Host code here only
+// sizes buffers, launches kernels on one stream and moves scalars; every per-base /
+// per-interval computation of the hot path runs on the device.  There is no CPU fallback:
+// a missing device or a failed launch is reported as GX_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gx_stats.h"
+
+using namespace gx;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Pileup {  // run-length pileup of one sample (treatment or control)
+  DevBuf ivEnd, ivV, tileIvOff, chromIvOff;
+  u32 nIv = 0;
+};
+
+struct PArray {  // p-value intervals of one replicate (or the Fisher combination)
+  DevBuf end, p, expt, ctrl, chromOff, q;
+  u32 n = 0;
+  bool hasPiles = false;  // expt/ctrl filled (single-replicate logging)
+  float ctrlConst = 0.0f; // control value when ctrl is not materialised (no -E, no control file)
+  bool ctrlIsConst = false;
+  std::vector<uint8_t> present;  // per chromosome: p-values exist (pval[n] != NULL)
+};
+
+struct Phase {
+  std::string name;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct gx_ctx {
+  gx_params par{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // chromosome table
+  std::vector<uint32_t> len;
+  std::vector<uint8_t> skip, save, owned;
+  std::vector<std::vector<uint32_t>> bed;
+  std::vector<DChrom> hChrom;
+  u32 nChrom = 0, nTiles = 0;
+  int sbShift = 0;
+  u32 nSB = 0;
+  DevBuf dChrom, dTileChrom;
+  // per-sample state
+  int phase = 0;  // 0 idle, 1 treatment open, 2 treatment done, 3 control open, 4 control done
+  int sample = 0;
+  DevBuf evBuf;
+  size_t evCount = 0;
+  struct Seg { const gx_event* p; size_t n; };
+  std::vector<Seg> segs;
+  DevBuf recsA, recsB, sbHist, sbOff, sbCursor, sbChunkOff, tileCnt, tileWsum, tileOff, tileCursor,
+      tileCarry, lb, misc, dScal, dStatus;
+  Pileup expt, ctrl;
+  Scalars hScal{};
+  std::vector<PArray> reps;
+  int finalIdx = -1;
+  // BH
+  DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp;
+  // sweep
+  DevBuf swChrom, swStart, swEnd, swP, swQ, swSig, cand, valid, peaks, lb2;
+  std::vector<gx_peak> hPeaks;
+  uint64_t genomeLenUsed = 0, peakBP = 0;
+  // collectives
+  int rank = 0, world = 1;
+  gx_allreduce_i64_fn allreduce = nullptr;
+  gx_allgather_tab_fn allgather = nullptr;
+  void* user = nullptr;
+  // timing
+  std::vector<Phase> phases;
+  std::vector<float> phaseMs;
+  std::string phaseNames;
+};
+
+#define HIPCHECK(x)                                                                      \
+  do {                                                                                   \
+    hipError_t e__ = (x);                                                                \
+    if (e__ != hipSuccess) {                                                             \
+      ctx->err = std::string(#x) + ": " + hipGetErrorString(e__);                        \
+      return GX_ERR_DEVICE;                                                              \
+    }                                                                                    \
+  } while (0)
+
+namespace {
+
+// misc device words (u32 indices into ctx->misc)
+enum { M_TICKET = 0, M_NIV = 1, M_TICKET2 = 2, M_SWCOUNT = 3, M_NPEAKS = 4, M_BHCOUNT = 5, M_ALLONE = 6,
+       M_PEAKBP = 8 /* u64 */, M_GENOME = 10 /* u64 */, M_WORDS = 16 };
+
+void phase_begin(gx_ctx* ctx, const char* name) {
+  Phase ph;
+  ph.name = name;
+  (void)hipEventCreate(&ph.a);
+  (void)hipEventCreate(&ph.b);
+  (void)hipEventRecord(ph.a, ctx->stream);
+  ctx->phases.push_back(ph);
+}
+void phase_end(gx_ctx* ctx) { (void)hipEventRecord(ctx->phases.back().b, ctx->stream); }
+
+int status_to_rc(gx_ctx* ctx, u32 st) {
+  if (!st) return GX_OK;
+  struct { u32 bit; int rc; const char* msg; } tab[] = {
+      {ST_BAD_CHROM, GX_ERR_ORDER, "event on an unknown chromosome"},
+      {ST_BAD_POS, GX_ERR_POS, ": read aligned beyond reference end"},
+      {ST_BAD_COUNT, GX_ERR_ALNS, "Disallowed number of alignments"},
+      {ST_NEG_PILE, GX_ERR_PILE, "Invalid pileup value (< 0)"},
+      {ST_NO_FRAGS, GX_ERR_EXPT, "Experimental sample has no analyzable fragments"},
+      {ST_SAT16, GX_ERR_OVERFLOW, "per-base difference beyond the reference's int16 range"},
+      {ST_LOOKBACK, GX_ERR_DEVICE, "look-back spin limit reached"},
+      {ST_HASH_FULL, GX_ERR_DEVICE, "p-value table full"},
+      {ST_BAD_DF, GX_ERR_DF, "Invalid df in pchisq()"},
+  };
+  for (auto& t : tab)
+    if (st & t.bit) {
+      ctx->err = t.msg;
+      return t.rc;
+    }
+  ctx->err = "unknown device status";
+  return GX_ERR_DEVICE;
+}
+
+int read_status(gx_ctx* ctx) {
+  u32 st = 0;
+  HIPCHECK(hipMemcpyAsync(&st, ctx->dStatus.p, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  return status_to_rc(ctx, st);
+}
+
+uint64_t genome_len_for(const gx_ctx* ctx, const std::vector<uint8_t>& present) {
+  // calcLambda 1819-1827 / findPeaks 1091-1101
+  uint64_t g = 0;
+  for (u32 i = 0; i < ctx->nChrom; i++)
+    if (!ctx->skip[i] && present[i]) {
+      g += ctx->len[i];
+      for (size_t j = 0; j + 1 < ctx->bed[i].size(); j += 2) g -= ctx->bed[i][j + 1] - ctx->bed[i][j];
+    }
+  return g;
+}
+
+int upload_chroms(gx_ctx* ctx) {
+  for (u32 i = 0; i < ctx->nChrom; i++)
+    ctx->hChrom[i].flags = (ctx->skip[i] ? CH_SKIP : 0) | (ctx->save[i] ? CH_SAVE : 0) | (ctx->owned[i] ? CH_OWNED : 0);
+  HIPCHECK(hipMemcpyAsync(ctx->dChrom.p, ctx->hChrom.data(), ctx->nChrom * sizeof(DChrom), hipMemcpyHostToDevice,
+                          ctx->stream));
+  return GX_OK;
+}
+
+// events -> tile-bucketed endpoint records -> run-length pileup + exact fragLen accumulators
+int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
+  // host-pushed events are staged in evBuf; device-resident segments are used in place
+  std::vector<gx_ctx::Seg> segs;
+  if (ctx->evCount) segs.push_back({ctx->evBuf.as<gx_event>(), ctx->evCount});
+  for (auto& sg : ctx->segs) segs.push_back(sg);
+  size_t n = 0;
+  for (auto& sg : segs) n += sg.n;
+  if (2 * n >= 0xFFFFFFFFull) {
+    ctx->err = "too many events in one sample for 32-bit record offsets";
+    return GX_ERR_MEM;
+  }
+  const u32 nRec = (u32)(2 * n);
+  const u32 nTiles = ctx->nTiles, nSB = ctx->nSB, nChrom = ctx->nChrom;
+  hipStream_t s = ctx->stream;
+  HIPCHECK(ctx->recsA.ensure((size_t)nRec * 8 + 16));
+  HIPCHECK(ctx->recsB.ensure((size_t)nRec * 8 + 16));
+  HIPCHECK(ctx->tileCnt.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->tileWsum.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->tileOff.ensure((size_t)(nTiles + 2) * 4));
+  HIPCHECK(ctx->tileCursor.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 1) * 8));
+  // an interval closes at every base with a non-zero difference (<= one per record) plus one per chromosome
+  const size_t ivCap = (size_t)nRec + nChrom + 16;
+  HIPCHECK(out.ivEnd.ensure(ivCap * 4));
+  HIPCHECK(out.ivV.ensure(ivCap * 4));
+  HIPCHECK(out.tileIvOff.ensure((size_t)(nTiles + 2) * 4));
+  HIPCHECK(out.chromIvOff.ensure((size_t)(nChrom + 2) * 4));
+
+  phase_begin(ctx, isCtrl ? "c.convert" : "t.convert");
+  HIPCHECK(hipMemsetAsync(ctx->sbHist.p, 0, MAX_BINS * 4, s));
+  HIPCHECK(hipMemsetAsync(ctx->tileCnt.p, 0, (size_t)(nTiles + 1) * 4, s));
+  HIPCHECK(hipMemsetAsync(ctx->tileWsum.p, 0, (size_t)(nTiles + 1) * 4, s));
+  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 1) * 8, s));
+  HIPCHECK(hipMemsetAsync(ctx->misc.as<u32>() + M_TICKET, 0, 8, s));  // ticket + nIv
+  size_t off = 0;
+  for (auto& seg : segs) {
+    if (!seg.n) continue;
+    u32 blocks = (u32)std::min<size_t>((seg.n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_convert, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
+                       ctx->sbShift, nSB, ctx->recsA.as<u64>() + 2 * off, ctx->sbHist.as<u32>(), ctx->dStatus.as<u32>());
+    off += seg.n;
+  }
+  phase_end(ctx);
+
+  phase_begin(ctx, isCtrl ? "c.bucket" : "t.bucket");
+  hipLaunchKernelGGL(k_scan_sb, dim3(1), dim3(1024), 0, s, ctx->sbHist.as<u32>(), nSB, (u32)SC_CHUNK, ctx->sbOff.as<u32>(),
+                     ctx->sbCursor.as<u32>(), ctx->sbChunkOff.as<u32>());
+  const u32 chunks1 = (nRec + SC_CHUNK - 1) / SC_CHUNK;
+  if (chunks1) {
+    hipLaunchKernelGGL(k_scatter<1>, dim3(chunks1), dim3(SC_NT), 0, s, ctx->recsA.as<u64>(), ctx->recsB.as<u64>(),
+                       ctx->sbOff.as<u32>() + nSB /* total */, (const u32*)nullptr, 0u, ctx->sbShift, nSB,
+                       ctx->sbCursor.as<u32>());
+    const u32 chunks2 = chunks1 + nSB;  // upper bound on sum of ceil(count / CHUNK)
+    hipLaunchKernelGGL(k_hist2, dim3(chunks2), dim3(SC_NT), 0, s, ctx->recsB.as<u64>(), ctx->sbOff.as<u32>(),
+                       ctx->sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>(),
+                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, ctx->tileOff.as<u32>(),
+                       ctx->tileCursor.as<u32>(), ctx->tileCarry.as<int>());
+    hipLaunchKernelGGL(k_scatter<2>, dim3(chunks2), dim3(SC_NT), 0, s, ctx->recsB.as<u64>(), ctx->recsA.as<u64>(),
+                       ctx->sbOff.as<u32>(), ctx->sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, nSB,
+                       ctx->tileCursor.as<u32>());
+  } else {
+    HIPCHECK(hipMemsetAsync(ctx->tileOff.p, 0, (size_t)(nTiles + 2) * 4, s));
+    HIPCHECK(hipMemsetAsync(ctx->tileCarry.p, 0, (size_t)(nTiles + 1) * 4, s));
+  }
+  phase_end(ctx);
+
+  phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");
+  TileOut to{out.ivEnd.as<u32>(), out.ivV.as<int>(), out.tileIvOff.as<u32>(), out.chromIvOff.as<u32>(),
+             ctx->misc.as<u32>() + M_NIV};
+  const size_t ldsBytes = (size_t)(TL_PAD + 64) * 4;
+  hipLaunchKernelGGL(k_tile, dim3(nTiles), dim3(TL_NT), ldsBytes, s, ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(),
+                     ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, nChrom,
+                     ctx->misc.as<u32>() + M_TICKET, ctx->lb.as<u64>(), to, ctx->dStatus.as<u32>());
+  hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
+                     ctx->misc.as<u32>() + M_NIV);
+  phase_end(ctx);
+
+  phase_begin(ctx, isCtrl ? "c.fraglen" : "t.fraglen");
+  Scalars* ds = ctx->dScal.as<Scalars>();
+  long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
+  HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
+  hipLaunchKernelGGL(k_fraglen, dim3(2048), dim3(256), 0, s, out.ivEnd.as<u32>(), out.ivV.as<int>(),
+                     out.chromIvOff.as<u32>(), nChrom, ctx->misc.as<u32>() + M_NIV, acc, ctx->dStatus.as<u32>());
+  phase_end(ctx);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(&out.nIv, ctx->misc.as<u32>() + M_NIV, 4, hipMemcpyDeviceToHost, s));
+  return GX_OK;
+}
+
+// fragLen / ctrlFrag partial sums -> (all ranks) -> lambda, factor
+int finish_scalars(gx_ctx* ctx, int isCtrl) {
+  hipStream_t s = ctx->stream;
+  Scalars* ds = ctx->dScal.as<Scalars>();
+  if (ctx->world > 1 && ctx->allreduce) {
+    long long acc[2];
+    long long* dacc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
+    HIPCHECK(hipMemcpyAsync(acc, dacc, 16, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    int64_t buf[2] = {acc[0], acc[1]};
+    if (ctx->allreduce(buf, 2, ctx->user)) {
+      ctx->err = "allreduce callback failed";
+      return GX_ERR_DEVICE;
+    }
+    acc[0] = buf[0];
+    acc[1] = buf[1];
+    HIPCHECK(hipMemcpyAsync(dacc, acc, 16, hipMemcpyHostToDevice, s));
+  }
+  hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>());
+  HIPCHECK(hipMemcpyAsync(&ctx->hScal, ds, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+  return read_status(ctx);
+}
+
+}  // namespace
+
+// ================================ C ABI ==================================================
+
+extern "C" {
+
+const char* gx_strerror(int status) {
+  switch (status) {
+    case GX_OK: return "";
+    case GX_ERR_MEM: return "Cannot allocate memory";
+    case GX_ERR_GEN: return "No analyzable genome (length=0)";
+    case GX_ERR_EXPT: return "Experimental sample has no analyzable fragments";
+    case GX_ERR_PILE: return "Invalid pileup value (< 0)";
+    case GX_ERR_POS: return ": read aligned beyond reference end";
+    case GX_ERR_ALNS: return "Disallowed number of alignments";
+    case GX_ERR_ARR: return "Failure creating experimental pileup";
+    case GX_ERR_PVAL: return "Failure collecting p-values";
+    case GX_ERR_DF: return "Invalid df in pchisq()";
+    case GX_ERR_ORDER: return "API called out of order";
+    case GX_ERR_DEVICE: return "HIP device failure";
+    case GX_ERR_OVERFLOW: return "per-base difference beyond the reference's int16 range";
+    default: return "Unknown error";
+  }
+}
+
+int gx_create(gx_ctx** out, const gx_params* par) {
+  if (!out || !par) return GX_ERR_ORDER;
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= par->device) {
+    fprintf(stderr, "genrich_amd: no HIP device %d (found %d) -- there is no CPU fallback\n", par->device, nd);
+    return GX_ERR_DEVICE;
+  }
+  gx_ctx* ctx = new gx_ctx();
+  ctx->par = *par;
+  ctx->device = par->device;
+  *out = ctx;
+  HIPCHECK(hipSetDevice(ctx->device));
+  HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIPCHECK(ctx->misc.ensure(M_WORDS * 4));
+  HIPCHECK(ctx->dScal.ensure(sizeof(Scalars)));
+  HIPCHECK(ctx->dStatus.ensure(64));
+  HIPCHECK(ctx->sbHist.ensure(MAX_BINS * 4));
+  HIPCHECK(ctx->sbOff.ensure((MAX_BINS + 2) * 4));
+  HIPCHECK(ctx->sbCursor.ensure((MAX_BINS + 2) * 4));
+  HIPCHECK(ctx->sbChunkOff.ensure((MAX_BINS + 2) * 4));
+  HIPCHECK(hipMemsetAsync(ctx->misc.p, 0, M_WORDS * 4, ctx->stream));
+  HIPCHECK(hipMemsetAsync(ctx->dScal.p, 0, sizeof(Scalars), ctx->stream));
+  HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (TL_PAD + 64) * 4));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  return GX_OK;
+}
+
+void gx_destroy(gx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& ph : ctx->phases) {
+    (void)hipEventDestroy(ph.a);
+    (void)hipEventDestroy(ph.b);
+  }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* gx_last_error(const gx_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip, const uint32_t* const* bed,
+                  const int32_t* bed_len) {
+  if (!ctx || n <= 0 || !len) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  ctx->nChrom = (u32)n;
+  ctx->len.assign(len, len + n);
+  ctx->skip.assign(n, 0);
+  ctx->save.assign(n, 1);
+  ctx->owned.assign(n, 1);
+  ctx->bed.assign(n, {});
+  for (int i = 0; i < n; i++) {
+    ctx->skip[i] = skip && skip[i];
+    if (bed && bed_len && bed_len[i] > 0 && !ctx->skip[i]) ctx->bed[i].assign(bed[i], bed[i] + bed_len[i]);
+  }
+  ctx->hChrom.assign(n, DChrom{});
+  std::vector<u32> tileChrom;
+  u32 t = 0;
+  for (int i = 0; i < n; i++) {
+    DChrom& c = ctx->hChrom[i];
+    c.len = len[i];
+    if (ctx->skip[i] || len[i] == 0) {
+      c.tileBase = NULL_TILE;
+      c.nTiles = 0;
+      continue;
+    }
+    c.tileBase = t;
+    c.nTiles = (u32)(((uint64_t)len[i] + TILE - 1) >> TB);
+    for (u32 k = 0; k < c.nTiles; k++) tileChrom.push_back((u32)i);
+    t += c.nTiles;
+  }
+  ctx->nTiles = t;
+  if (t == 0) {
+    ctx->err = "No analyzable genome (length=0)";
+    return GX_ERR_GEN;
+  }
+  int lg = 0;
+  while ((1u << lg) < t) lg++;
+  ctx->sbShift = std::min(11, (lg + 1) / 2);
+  while (((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1 > (u32)MAX_BINS) ctx->sbShift++;
+  if ((1u << ctx->sbShift) > (u32)MAX_BINS) {
+    ctx->err = "genome too large for the two-level tile sort";
+    return GX_ERR_MEM;
+  }
+  ctx->nSB = ((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1;  // + the null bucket
+  HIPCHECK(ctx->dChrom.ensure((size_t)n * sizeof(DChrom)));
+  HIPCHECK(ctx->dTileChrom.ensure((size_t)t * 4));
+  HIPCHECK(hipMemcpyAsync(ctx->dTileChrom.p, tileChrom.data(), (size_t)t * 4, hipMemcpyHostToDevice, ctx->stream));
+  int rc = upload_chroms(ctx);
+  if (rc) return rc;
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  return GX_OK;
+}
+
+int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce, gx_allgather_tab_fn allgather,
+                       void* user) {
+  if (!ctx || world < 1 || rank < 0 || rank >= world) return GX_ERR_ORDER;
+  ctx->rank = rank;
+  ctx->world = world;
+  ctx->allreduce = allreduce;
+  ctx->allgather = allgather;
+  ctx->user = user;
+  return GX_OK;
+}
+
+int gx_set_owned(gx_ctx* ctx, const uint8_t* owned) {
+  if (!ctx || !owned || ctx->nChrom == 0) return GX_ERR_ORDER;
+  ctx->owned.assign(owned, owned + ctx->nChrom);
+  int rc = upload_chroms(ctx);
+  if (rc) return rc;
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  return GX_OK;
+}
+
+int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
+  if (!ctx || ctx->nChrom == 0) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (!is_ctrl) {
+    if (ctx->phase != 0) return GX_ERR_ORDER;
+    for (u32 i = 0; i < ctx->nChrom; i++) ctx->save[i] = save ? (save[i] != 0) : 1;
+    int rc = upload_chroms(ctx);
+    if (rc) return rc;
+    uint64_t g = ctx->par.genome_len ? ctx->par.genome_len : genome_len_for(ctx, ctx->save);
+    if (!g) {
+      ctx->err = "No analyzable genome (length=0)";
+      return GX_ERR_GEN;  // calcLambda 1828
+    }
+    Scalars z{};
+    z.genomeLen = g;
+    ctx->hScal = z;
+    HIPCHECK(hipMemcpyAsync(ctx->dScal.p, &ctx->hScal, sizeof(Scalars), hipMemcpyHostToDevice, ctx->stream));
+    for (auto& ph : ctx->phases) {
+      (void)hipEventDestroy(ph.a);
+      (void)hipEventDestroy(ph.b);
+    }
+    ctx->phases.clear();
+    ctx->phase = 1;
+  } else {
+    if (ctx->phase != 2) return GX_ERR_ORDER;
+    ctx->phase = 3;
+  }
+  ctx->segs.clear();
+  ctx->evCount = 0;
+  return GX_OK;
+}
+
+int gx_push_events(gx_ctx* ctx, const gx_event* events, size_t n) {
+  if (!ctx || (ctx->phase != 1 && ctx->phase != 3)) return GX_ERR_ORDER;
+  if (!n) return GX_OK;
+  HIPCHECK(hipSetDevice(ctx->device));
+  // host events are staged contiguously in one device buffer (grown geometrically)
+  size_t need = (ctx->evCount + n) * sizeof(gx_event);
+  if (need > ctx->evBuf.cap) {
+    DevBuf nb;
+    HIPCHECK(nb.ensure(std::max(need, ctx->evBuf.cap * 2)));
+    if (ctx->evCount)
+      HIPCHECK(hipMemcpyAsync(nb.p, ctx->evBuf.p, ctx->evCount * sizeof(gx_event), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    ctx->evBuf = std::move(nb);
+  }
+  HIPCHECK(hipMemcpyAsync(ctx->evBuf.as<gx_event>() + ctx->evCount, events, n * sizeof(gx_event), hipMemcpyHostToDevice,
+                          ctx->stream));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffer on return
+  ctx->evCount += n;
+  return GX_OK;
+}
+
+int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n) {
+  if (!ctx || (ctx->phase != 1 && ctx->phase != 3)) return GX_ERR_ORDER;
+  if (n) ctx->segs.push_back({d_events, n});
+  return GX_OK;
+}
+
+int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor) {
+  if (!ctx) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (ctx->phase == 1) {
+    int rc = build_pileup(ctx, ctx->expt, 0);
+    if (rc) return rc;
+    rc = finish_scalars(ctx, 0);
+    if (rc) return rc;
+    ctx->phase = 2;
+  } else if (ctx->phase == 3) {
+    int rc = build_pileup(ctx, ctx->ctrl, 1);
+    if (rc) return rc;
+    rc = finish_scalars(ctx, 1);
+    if (rc) return rc;
+    ctx->phase = 4;
+    ctx->err = "control samples are not implemented yet";
+    return GX_ERR_ORDER;
+  } else
+    return GX_ERR_ORDER;
+  if (frag_len) *frag_len = ctx->hScal.fragLen;
+  if (lambda) *lambda = ctx->hScal.lambda;
+  if (factor) *factor = ctx->hScal.factor;
+  return GX_OK;
+}
+
+int gx_sample_no_control(gx_ctx* ctx, float* lambda) {
+  if (!ctx || ctx->phase != 2) return GX_ERR_ORDER;
+  if (lambda) *lambda = ctx->hScal.lambda;  // computed with fragLen (calcLambda 1831)
+  ctx->phase = 5;
+  return GX_OK;
+}
+
+int gx_pvalues(gx_ctx* ctx) {
+  if (!ctx || (ctx->phase != 4 && ctx->phase != 5)) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  PArray pa;
+  pa.present.assign(ctx->nChrom, 0);
+  for (u32 i = 0; i < ctx->nChrom; i++) pa.present[i] = !ctx->skip[i] && ctx->save[i];
+  if (ctx->phase == 5) {
+    // no control: the p-intervals are the treatment intervals
+    const u32 n = ctx->expt.nIv;
+    pa.n = n;
+    HIPCHECK(pa.p.ensure((size_t)n * 4 + 16));
+    HIPCHECK(pa.expt.ensure((size_t)n * 4 + 16));
+    phase_begin(ctx, "pval");
+    hipLaunchKernelGGL(k_pval_const, dim3(std::max(1u, std::min((n + 255) / 256, 4096u))), dim3(256), 0, s,
+                       ctx->expt.ivV.as<int>(), ctx->misc.as<u32>() + M_NIV, ctx->dScal.as<Scalars>(), pa.p.as<float>(),
+                       pa.expt.as<float>(), ctx->dStatus.as<u32>());
+    phase_end(ctx);
+    HIPCHECK(hipGetLastError());
+    pa.end = std::move(ctx->expt.ivEnd);
+    pa.chromOff = std::move(ctx->expt.chromIvOff);
+    pa.hasPiles = true;
+    pa.ctrlIsConst = true;
+    pa.ctrlConst = ctx->hScal.lambda;
+  } else {
+    ctx->err = "control samples are not implemented yet";
+    return GX_ERR_ORDER;
+  }
+  ctx->reps.push_back(std::move(pa));
+  ctx->sample++;
+  ctx->phase = 0;
+  return GX_OK;
+}
+
+int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* peak_bp) {
+  if (!ctx || ctx->phase != 0 || ctx->sample < 1) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  if (ctx->sample > 1) {
+    ctx->err = "replicates are not implemented yet";
+    return GX_ERR_ORDER;
+  }
+  ctx->finalIdx = (int)ctx->reps.size() - 1;
+  PArray& fa = ctx->reps[ctx->finalIdx];
+  const u32 n = fa.n, nChrom = ctx->nChrom;
+  u32* misc = ctx->misc.as<u32>();
+  // genome length (findPeaks 1091-1101)
+  uint64_t g = ctx->par.genome_len;
+  const bool genomeOpt = g == 0;
+  if (genomeOpt) g = genome_len_for(ctx, fa.present);
+  ctx->genomeLenUsed = g;
+  HIPCHECK(hipMemcpyAsync(misc + M_GENOME, &g, 8, hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(misc + M_NIV, &n, 4, hipMemcpyHostToDevice, s));
+  const u32 gridIv = std::max(1u, std::min((n + 255) / 256, 4096u));
+
+  if (ctx->par.qval_opt) {
+    phase_begin(ctx, "bh");
+    const u32 cap = 1u << 22;
+    HIPCHECK(ctx->bhKeys.ensure((size_t)cap * 4));
+    HIPCHECK(ctx->bhLens.ensure((size_t)cap * 8));
+    HIPCHECK(ctx->bhQ.ensure((size_t)cap * 4));
+    HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)cap * 4, s));
+    HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)cap * 8, s));
+    HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
+    hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
+                       fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV,
+                       ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->dStatus.as<u32>());
+    // occupied slots -> (key, slot), then sort by key
+    HIPCHECK(ctx->bhOutKeys.ensure((size_t)cap * 4));
+    HIPCHECK(ctx->bhOutSlot.ensure((size_t)cap * 4));
+    hipLaunchKernelGGL(k_bh_compact, dim3(1024), dim3(256), 0, s, ctx->bhKeys.as<u32>(), cap, ctx->bhOutKeys.as<u32>(),
+                       ctx->bhOutSlot.as<u32>(), misc + M_BHCOUNT);
+    u32 D = 0;
+    HIPCHECK(hipMemcpyAsync(&D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (D) {
+      HIPCHECK(ctx->bhSortKeys.ensure((size_t)D * 4));
+      HIPCHECK(ctx->bhSortSlot.ensure((size_t)D * 4));
+      HIPCHECK(ctx->bhRaw.ensure((size_t)D * 4));
+      size_t tmpBytes = 0;
+      HIPCHECK(rocprim::radix_sort_pairs(nullptr, tmpBytes, ctx->bhOutKeys.as<u32>(), ctx->bhSortKeys.as<u32>(),
+                                         ctx->bhOutSlot.as<u32>(), ctx->bhSortSlot.as<u32>(), D, 0, 32, s));
+      HIPCHECK(ctx->bhTmp.ensure(tmpBytes + 16));
+      HIPCHECK(rocprim::radix_sort_pairs(ctx->bhTmp.p, tmpBytes, ctx->bhOutKeys.as<u32>(), ctx->bhSortKeys.as<u32>(),
+                                         ctx->bhOutSlot.as<u32>(), ctx->bhSortSlot.as<u32>(), D, 0, 32, s));
+      hipLaunchKernelGGL(k_qtable, dim3(1), dim3(1024), 0, s, ctx->bhSortKeys.as<u32>(), ctx->bhSortSlot.as<u32>(),
+                         ctx->bhLens.as<u64>(), D, reinterpret_cast<const u64*>(misc + M_GENOME), ctx->bhQ.as<float>(),
+                         ctx->bhRaw.as<float>(), misc + M_ALLONE);
+    }
+    HIPCHECK(fa.q.ensure((size_t)n * 4 + 16));
+    hipLaunchKernelGGL(k_qlookup, dim3(gridIv), dim3(256), 0, s, fa.p.as<float>(), misc + M_NIV, ctx->bhKeys.as<u32>(),
+                       ctx->bhQ.as<float>(), cap - 1, fa.q.as<float>());
+    phase_end(ctx);
+    HIPCHECK(hipGetLastError());
+  }
+
+  // peak sweep
+  phase_begin(ctx, "sweep");
+  const size_t mCap = (size_t)n + 16;
+  HIPCHECK(ctx->swChrom.ensure(mCap * 4));
+  HIPCHECK(ctx->swStart.ensure(mCap * 4));
+  HIPCHECK(ctx->swEnd.ensure(mCap * 4));
+  HIPCHECK(ctx->swP.ensure(mCap * 4));
+  HIPCHECK(ctx->swQ.ensure(mCap * 4));
+  HIPCHECK(ctx->swSig.ensure(mCap * 4));
+  const u32 nBlocks = (n + SW_CHUNK - 1) / SW_CHUNK;
+  HIPCHECK(ctx->lb2.ensure((size_t)(nBlocks + 1) * 8));
+  HIPCHECK(hipMemsetAsync(ctx->lb2.p, 0, (size_t)(nBlocks + 1) * 8, s));
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 12, s));  // ticket2, swcount, npeaks
+  HIPCHECK(hipMemsetAsync(misc + M_PEAKBP, 0, 8, s));
+  SweepList L{ctx->swChrom.as<u32>(), ctx->swStart.as<u32>(), ctx->swEnd.as<u32>(), ctx->swP.as<float>(),
+              ctx->swQ.as<float>(), ctx->swSig.as<u32>(), misc + M_SWCOUNT};
+  if (nBlocks)
+    hipLaunchKernelGGL(k_sweep_compact, dim3(nBlocks), dim3(SW_NT), 0, s, fa.end.as<u32>(), fa.p.as<float>(),
+                       ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr, fa.chromOff.as<u32>(), nChrom,
+                       misc + M_NIV, ctx->par.thr, misc + M_TICKET2, ctx->lb2.as<u64>(), L, ctx->dStatus.as<u32>());
+  u32 M = 0;
+  HIPCHECK(hipMemcpyAsync(&M, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  u32 nPeaks = 0;
+  ctx->peakBP = 0;
+  if (M) {
+    HIPCHECK(ctx->cand.ensure((size_t)M * sizeof(gx_peak)));
+    HIPCHECK(ctx->valid.ensure((size_t)M * 4));
+    HIPCHECK(ctx->peaks.ensure((size_t)M * sizeof(gx_peak)));
+    hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((M + 255) / 256, 2048u))), dim3(256), 0, s, L,
+                       ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->par.max_gap, ctx->cand.as<gx_peak>(),
+                       ctx->valid.as<u32>());
+    hipLaunchKernelGGL(k_peak_compact, dim3(1), dim3(1024), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
+                       misc + M_SWCOUNT, ctx->peaks.as<gx_peak>(), misc + M_NPEAKS,
+                       reinterpret_cast<u64*>(misc + M_PEAKBP));
+    HIPCHECK(hipMemcpyAsync(&nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&ctx->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+  }
+  ctx->hPeaks.resize(nPeaks);
+  if (nPeaks)
+    HIPCHECK(hipMemcpyAsync(ctx->hPeaks.data(), ctx->peaks.p, (size_t)nPeaks * sizeof(gx_peak), hipMemcpyDeviceToHost, s));
+  phase_end(ctx);
+  int rc = read_status(ctx);
+  if (rc) return rc;
+  if (n_peaks) *n_peaks = nPeaks;
+  if (genome_len) *genome_len = g;
+  if (peak_bp) *peak_bp = ctx->peakBP;
+  return GX_OK;
+}
+
+int gx_get_peaks(gx_ctx* ctx, gx_peak* out, size_t cap) {
+  if (!ctx || !out) return GX_ERR_ORDER;
+  size_t n = std::min(cap, ctx->hPeaks.size());
+  memcpy(out, ctx->hPeaks.data(), n * sizeof(gx_peak));
+  return GX_OK;
+}
+
+static const PArray* which_array(gx_ctx* ctx, int which, int chrom, u32* lo, u32* hi) {
+  if (chrom < 0 || (u32)chrom >= ctx->nChrom) return nullptr;
+  int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
+  if (w < 0 || w >= (int)ctx->reps.size()) return nullptr;
+  const PArray& pa = ctx->reps[w];
+  if (!pa.present[chrom]) return nullptr;
+  u32 off[2];
+  if (hipMemcpy(off, pa.chromOff.as<u32>() + chrom, 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+  *lo = off[0];
+  *hi = off[1];
+  return &pa;
+}
+
+int gx_interval_count(gx_ctx* ctx, int which, int chrom, size_t* n_iv) {
+  if (!ctx || !n_iv) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  u32 lo = 0, hi = 0;
+  const PArray* pa = which_array(ctx, which, chrom, &lo, &hi);
+  *n_iv = pa ? hi - lo : 0;
+  return GX_OK;
+}
+
+int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* end, float* expt, float* ctrl, float* p,
+                     float* q) {
+  if (!ctx) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  u32 lo = 0, hi = 0;
+  const PArray* pa = which_array(ctx, which, chrom, &lo, &hi);
+  if (!pa) return GX_OK;
+  size_t n = std::min<size_t>(cap, hi - lo);
+  if (!n) return GX_OK;
+  if (end) HIPCHECK(hipMemcpy(end, pa->end.as<u32>() + lo, n * 4, hipMemcpyDeviceToHost));
+  if (p) HIPCHECK(hipMemcpy(p, pa->p.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));
+  if (expt) {
+    if (pa->hasPiles) HIPCHECK(hipMemcpy(expt, pa->expt.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));
+    else std::fill(expt, expt + n, 0.0f);
+  }
+  if (ctrl) {
+    if (pa->hasPiles && !pa->ctrlIsConst) HIPCHECK(hipMemcpy(ctrl, pa->ctrl.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));
+    else std::fill(ctrl, ctrl + n, pa->ctrlIsConst ? pa->ctrlConst : 0.0f);
+  }
+  if (q) {
+    if (pa->q.p && ctx->par.qval_opt) HIPCHECK(hipMemcpy(q, pa->q.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));
+    else std::fill(q, q + n, GX_SKIP);
+  }
+  return GX_OK;
+}
+
+int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->phaseMs.clear();
+  ctx->phaseNames.clear();
+  for (auto& ph : ctx->phases) {
+    float t = 0;
+    (void)hipEventElapsedTime(&t, ph.a, ph.b);
+    ctx->phaseMs.push_back(t);
+    ctx->phaseNames += ph.name;
+    ctx->phaseNames.push_back('\0');
+  }
+  if (names) *names = ctx->phaseNames.c_str();
+  if (ms) *ms = ctx->phaseMs.data();
+  return (int)ctx->phases.size();
+}
+
+}  // extern "C"

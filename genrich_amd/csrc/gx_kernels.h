@@ -1,0 +1,613 @@
+// gx_kernels.h -- hand-written HIP kernels of the Genrich hot path for gfx950 (CDNA4).
+//
+// Data layout:
+//   * every analysed chromosome is cut into tiles of TILE = 2^TB bases; a tile belongs to
+//     one chromosome.  The reference's per-base difference array (Diff, Genrich.h:178-181;
+//     written by saveInterval, Genrich.c:2575-2583) never exists in HBM: each tile's slice
+//     lives in LDS for the lifetime of one workgroup.
+//   * an alignment interval becomes two 8-byte endpoint records
+//       [63:32] tile   [31:8] offset in tile   [7:0] signed weight in 1/120 units
+//     which a two-level bucket sort (super-bucket, then tile) groups by tile.
+//   * pileups leave the tile kernel as run-length intervals (end, V120) exactly where the
+//     reference breaks them (savePileupExpt, Genrich.c:2239-2273): V120 is the exact pileup
+//     in 1/120 units, from which getVal's float is re-materialised when needed.
+// No MFMA anywhere: there is no dense contraction in this workload.  All cross-workgroup
+// accumulation is integer (atomics / fixed point), so results are run-to-run identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gx_math.h"
+#include "../../include/genrich_amd.h"
+
+namespace gx {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+constexpr int TB = 14;                 // tile bits
+constexpr int TILE = 1 << TB;          // bases per tile
+constexpr u32 NULL_TILE = 0xFFFFFFFFu; // dropped endpoint
+constexpr int MAX_BINS = 2048;         // bins of one bucket-sort level
+
+// device status bits (checked by the host at every sync point)
+enum : u32 {
+  ST_BAD_CHROM = 1u,     // event on an unknown chromosome
+  ST_BAD_POS = 2u,       // start >= chromosome length      (ERRPOS, Genrich.c:2531)
+  ST_BAD_COUNT = 4u,     // count not in {1,2,3,4,5,6,8,10}  (ERRALNS, :2402)
+  ST_NEG_PILE = 8u,      // negative pileup                  (ERRPILE, :1921)
+  ST_SAT16 = 16u,        // |per-base difference| reached the reference's int16 range (:2558)
+  ST_LOOKBACK = 32u,     // decoupled look-back spin limit hit (internal)
+  ST_HASH_FULL = 64u,    // p-value table overflow (internal)
+  ST_NO_FRAGS = 128u,    // fragLen == 0                     (ERREXPT, :2292)
+  ST_BAD_DF = 256u,      // more than 200 replicates         (ERRDF, :556)
+};
+
+struct DChrom {
+  u32 len;
+  u32 tileBase;  // first tile of this chromosome (NULL_TILE when it has none)
+  u32 nTiles;
+  u32 flags;     // bit0 skip (-e), bit1 save (this replicate), bit2 owned by this rank
+};
+constexpr u32 CH_SKIP = 1, CH_SAVE = 2, CH_OWNED = 4;
+
+__device__ __forceinline__ bool chrom_active(const DChrom& c) {
+  return (c.flags & (CH_SKIP | CH_SAVE | CH_OWNED)) == (CH_SAVE | CH_OWNED) && c.tileBase != NULL_TILE;
+}
+
+// ---- small block-level helpers (wave = 64 lanes) ------------------------------------
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += o;
+  }
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// exclusive block scan; `scratch` holds one T per wave (+1); returns exclusive prefix and the
+// block total.  All threads must call it.
+template <typename T, int NT>
+__device__ __forceinline__ T block_excl_scan(T v, T* scratch, T* total) {
+  constexpr int NW = NT / 64;
+  T inc = wave_incl_scan(v);
+  int w = threadIdx.x >> 6;
+  if (lane_id() == 63) scratch[w] = inc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    T x = threadIdx.x < NW ? scratch[threadIdx.x] : T(0);
+    T xi = wave_incl_scan(x);
+    if (threadIdx.x < NW) scratch[threadIdx.x] = xi - x;
+    if (threadIdx.x == NW - 1) scratch[NW] = xi;
+  }
+  __syncthreads();
+  T res = inc - v + scratch[w];
+  *total = scratch[NW];
+  __syncthreads();
+  return res;
+}
+
+// ---- 1. events -> endpoint records ------------------------------------------------------
+// Replaces the accumulate step of saveInterval (Genrich.c:2546-2583): instead of a
+// read-modify-write on diff[start] / diff[end], emit (+w at start) and (-w at end).
+// An end at the chromosome length never influences a base < len and is dropped.
+// Also builds the level-1 (super-bucket) histogram.
+__global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev, u32 n,
+                                                 const DChrom* __restrict__ chroms, u32 nChrom,
+                                                 int sbShift, u32 nSB, u64* __restrict__ recs,
+                                                 u32* __restrict__ sbHist, u32* __restrict__ st) {
+  __shared__ u32 hist[MAX_BINS];
+  for (int i = threadIdx.x; i < (int)nSB; i += 256) hist[i] = 0;
+  __syncthreads();
+  u32 bad = 0;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    uint4 e = reinterpret_cast<const uint4*>(ev)[i];  // chrom, start, end, count
+    u64 r0 = (u64)NULL_TILE << 32, r1 = r0;
+    int w = 0;
+    switch (e.w) {
+      case 1: w = 120; break;
+      case 2: w = 60; break;
+      case 3: w = 40; break;
+      case 4: w = 30; break;
+      case 5: w = 24; break;
+      case 6: w = 20; break;
+      case 8: w = 15; break;
+      case 10: w = 12; break;
+      default: bad |= ST_BAD_COUNT;
+    }
+    if (e.x >= nChrom)
+      bad |= ST_BAD_CHROM;
+    else if (w) {
+      DChrom c = chroms[e.x];
+      if (chrom_active(c)) {
+        if (e.y >= c.len)
+          bad |= ST_BAD_POS;
+        else {
+          u32 end = e.z > c.len ? c.len : e.z;
+          if (end > e.y) {  // an empty interval adds and removes the same weight
+            r0 = ((u64)(c.tileBase + (e.y >> TB)) << 32) | ((u64)(e.y & (TILE - 1)) << 8) |
+                 (u64)(uint8_t)(int8_t)w;
+            if (end < c.len)
+              r1 = ((u64)(c.tileBase + (end >> TB)) << 32) | ((u64)(end & (TILE - 1)) << 8) |
+                   (u64)(uint8_t)(int8_t)(-w);
+          }
+        }
+      }
+    }
+    reinterpret_cast<ulonglong2*>(recs)[i] = make_ulonglong2(r0, r1);
+    u32 t0 = (u32)(r0 >> 32), t1 = (u32)(r1 >> 32);
+    atomicAdd(&hist[t0 == NULL_TILE ? nSB - 1 : t0 >> sbShift], 1u);
+    atomicAdd(&hist[t1 == NULL_TILE ? nSB - 1 : t1 >> sbShift], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)nSB; i += 256)
+    if (hist[i]) atomicAdd(&sbHist[i], hist[i]);
+  if (bad) atomicOr(st, bad);
+}
+
+// ---- 2. tiny single-block scans ----------------------------------------------------------
+// super-bucket histogram -> offsets, cursors and the level-2 chunk table
+__global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist, u32 nSB, u32 chunk,
+                                                  u32* __restrict__ sbOff, u32* __restrict__ sbCursor,
+                                                  u32* __restrict__ sbChunkOff) {
+  __shared__ u32 scratch[20];
+  // nSB <= MAX_BINS = 2 * 1024: two items per thread
+  u32 i0 = threadIdx.x * 2, i1 = i0 + 1;
+  u32 a = i0 < nSB ? sbHist[i0] : 0, b = i1 < nSB ? sbHist[i1] : 0;
+  u32 tot;
+  u32 ex = block_excl_scan<u32, 1024>(a + b, scratch, &tot);
+  if (i0 < nSB) { sbOff[i0] = ex; sbCursor[i0] = ex; }
+  if (i1 < nSB) { sbOff[i1] = ex + a; sbCursor[i1] = ex + a; }
+  if (threadIdx.x == 0) sbOff[nSB] = tot;
+  // chunks per super-bucket (the last, null, bucket gets none)
+  u32 ca = (i0 + 1 < nSB) ? (a + chunk - 1) / chunk : 0, cb = (i1 + 1 < nSB) ? (b + chunk - 1) / chunk : 0;
+  u32 ctot;
+  u32 cex = block_excl_scan<u32, 1024>(ca + cb, scratch, &ctot);
+  if (i0 < nSB) sbChunkOff[i0] = cex;
+  if (i1 < nSB) sbChunkOff[i1] = cex + ca;
+  if (threadIdx.x == 0) sbChunkOff[nSB] = ctot;
+}
+
+// per-tile record counts -> offsets + cursors; per-tile weight sums -> carry-in of each tile
+// (running pileup at the tile's first base = sum of all weights in earlier tiles of the
+// same chromosome).  Single workgroup, 8 tiles per thread per round.
+constexpr int ST_ITEMS = 8;
+__global__ __launch_bounds__(1024) void k_scan_tiles(const u32* __restrict__ tileCnt,
+                                                     const int* __restrict__ tileWsum,
+                                                     const u32* __restrict__ tileChrom,
+                                                     const DChrom* __restrict__ chroms, u32 nTiles,
+                                                     u32* __restrict__ tileOff, u32* __restrict__ tileCursor,
+                                                     int* __restrict__ tileCarry) {
+  __shared__ u32 scratch[20];
+  __shared__ int iscratch[20];
+  u32 baseCnt = 0;
+  int baseW = 0;
+  for (u32 t0 = 0; t0 < nTiles; t0 += 1024 * ST_ITEMS) {
+    u32 tb = t0 + threadIdx.x * ST_ITEMS;
+    u32 c[ST_ITEMS];
+    int w[ST_ITEMS];
+    u32 cs = 0;
+    int ws = 0;
+#pragma unroll
+    for (int k = 0; k < ST_ITEMS; k++) {
+      u32 t = tb + k;
+      c[k] = t < nTiles ? tileCnt[t] : 0;
+      w[k] = t < nTiles ? tileWsum[t] : 0;
+      cs += c[k];
+      ws += w[k];
+    }
+    u32 ctot;
+    int wtot;
+    u32 cex = baseCnt + block_excl_scan<u32, 1024>(cs, scratch, &ctot);
+    int wex = baseW + block_excl_scan<int, 1024>(ws, iscratch, &wtot);
+#pragma unroll
+    for (int k = 0; k < ST_ITEMS; k++) {
+      u32 t = tb + k;
+      if (t < nTiles) {
+        tileOff[t] = cex;
+        tileCursor[t] = cex;
+        tileCarry[t] = wex;  // genome-wide prefix; made per-chromosome below
+      }
+      cex += c[k];
+      wex += w[k];
+    }
+    baseCnt += ctot;
+    baseW += wtot;
+  }
+  if (threadIdx.x == 0) tileOff[nTiles] = baseCnt;
+  __syncthreads();
+  // subtract the prefix at the chromosome's first tile: non-first tiles read it here ...
+  for (u32 t = threadIdx.x; t < nTiles; t += 1024) {
+    u32 first = chroms[tileChrom[t]].tileBase;
+    if (t != first) tileCarry[t] -= tileCarry[first];
+  }
+  __syncthreads();
+  // ... and the first tiles are reset afterwards
+  for (u32 t = threadIdx.x; t < nTiles; t += 1024)
+    if (t == chroms[tileChrom[t]].tileBase) tileCarry[t] = 0;
+}
+
+// ---- 3. bucket scatter (both levels) -------------------------------------------------------
+// One workgroup takes CHUNK records of one segment, ranks them per bin with LDS atomics,
+// reserves a run per (workgroup, bin) with one global atomic, sorts the chunk in LDS and
+// writes bin-contiguous runs.  Order inside a bin is arbitrary: every consumer is a
+// commutative integer sum.
+constexpr int SC_NT = 256;
+constexpr int SC_ITEMS = 16;
+constexpr int SC_CHUNK = SC_NT * SC_ITEMS;  // 4096 records
+
+template <int LEVEL>
+__device__ __forceinline__ u32 bin_of(u64 r, int sbShift, u32 nBins, u32 segTileBase) {
+  u32 t = (u32)(r >> 32);
+  if (LEVEL == 1) return t == NULL_TILE ? nBins - 1 : t >> sbShift;
+  return t - segTileBase;
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ in, u64* __restrict__ out,
+                                                   const u32* __restrict__ segOff,
+                                                   const u32* __restrict__ chunkOff, u32 nSeg,
+                                                   int sbShift, u32 nBinsL1, u32* __restrict__ cursor) {
+  __shared__ u32 hist[MAX_BINS];
+  __shared__ u32 start[MAX_BINS];
+  __shared__ u32 base[MAX_BINS];
+  __shared__ u64 stage[SC_CHUNK];
+  __shared__ u32 scratch[8];
+  u32 seg = 0, chunkInSeg = blockIdx.x, begin, end, nBins, segTileBase = 0;
+  if (LEVEL == 1) {
+    begin = blockIdx.x * SC_CHUNK;
+    end = segOff[0];  // total
+    if (begin >= end) return;
+    end = min(end, begin + SC_CHUNK);
+    nBins = nBinsL1;
+  } else {
+    if (blockIdx.x >= chunkOff[nSeg]) return;
+    u32 lo = 0, hi = nSeg;  // last seg with chunkOff[seg] <= blockIdx.x
+    while (hi - lo > 1) {
+      u32 mid = (lo + hi) >> 1;
+      if (chunkOff[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    seg = lo;
+    chunkInSeg = blockIdx.x - chunkOff[seg];
+    begin = segOff[seg] + chunkInSeg * SC_CHUNK;
+    end = min(segOff[seg + 1], begin + SC_CHUNK);
+    nBins = 1u << sbShift;
+    segTileBase = seg << sbShift;
+  }
+  for (int i = threadIdx.x; i < (int)nBins; i += SC_NT) hist[i] = 0;
+  __syncthreads();
+  u64 r[SC_ITEMS];
+  u32 rk[SC_ITEMS];
+#pragma unroll
+  for (int k = 0; k < SC_ITEMS; k++) {
+    u32 idx = begin + k * SC_NT + threadIdx.x;
+    if (idx < end) {
+      r[k] = in[idx];
+      rk[k] = atomicAdd(&hist[bin_of<LEVEL>(r[k], sbShift, nBins, segTileBase)], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of hist -> start; reserve global runs
+  u32 carry = 0;
+  for (u32 b0 = 0; b0 < nBins; b0 += SC_NT) {
+    u32 b = b0 + threadIdx.x;
+    u32 c = b < nBins ? hist[b] : 0;
+    u32 tot;
+    u32 ex = block_excl_scan<u32, SC_NT>(c, scratch, &tot);
+    if (b < nBins) {
+      start[b] = carry + ex;
+      if (c) base[b] = atomicAdd(&cursor[LEVEL == 1 ? b : segTileBase + b], c);
+    }
+    carry += tot;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SC_ITEMS; k++) {
+    u32 idx = begin + k * SC_NT + threadIdx.x;
+    if (idx < end) stage[start[bin_of<LEVEL>(r[k], sbShift, nBins, segTileBase)] + rk[k]] = r[k];
+  }
+  __syncthreads();
+  u32 cnt = end - begin;
+  for (u32 i = threadIdx.x; i < cnt; i += SC_NT) {
+    u64 v = stage[i];
+    u32 b = bin_of<LEVEL>(v, sbShift, nBins, segTileBase);
+    out[base[b] + (i - start[b])] = v;
+  }
+}
+
+// level-2 histogram: records and signed weight per tile
+__global__ __launch_bounds__(SC_NT) void k_hist2(const u64* __restrict__ in, const u32* __restrict__ segOff,
+                                                 const u32* __restrict__ chunkOff, u32 nSeg, int sbShift,
+                                                 u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
+  __shared__ u32 hist[MAX_BINS];
+  __shared__ int wsum[MAX_BINS];
+  if (blockIdx.x >= chunkOff[nSeg]) return;
+  u32 lo = 0, hi = nSeg;
+  while (hi - lo > 1) {
+    u32 mid = (lo + hi) >> 1;
+    if (chunkOff[mid] <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  u32 seg = lo;
+  u32 begin = segOff[seg] + (blockIdx.x - chunkOff[seg]) * SC_CHUNK;
+  u32 end = min(segOff[seg + 1], begin + SC_CHUNK);
+  u32 nBins = 1u << sbShift, segTileBase = seg << sbShift;
+  for (int i = threadIdx.x; i < (int)nBins; i += SC_NT) { hist[i] = 0; wsum[i] = 0; }
+  __syncthreads();
+  for (u32 idx = begin + threadIdx.x; idx < end; idx += SC_NT) {
+    u64 r = in[idx];
+    u32 b = (u32)(r >> 32) - segTileBase;
+    atomicAdd(&hist[b], 1u);
+    atomicAdd(&wsum[b], (int)(int8_t)(r & 0xFF));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)nBins; i += SC_NT)
+    if (hist[i]) {
+      atomicAdd(&tileCnt[segTileBase + i], hist[i]);
+      atomicAdd(&tileWsum[segTileBase + i], wsum[i]);
+    }
+}
+
+
+// ---- decoupled look-back (single-pass chained scan across workgroups) ------------------------
+// lb[i] is one 8-byte granule {flag:2, value:62}: 0 = nothing yet, AGG = this block's own
+// aggregate, INC = inclusive prefix through this block.  The value and its flag travel in ONE
+// relaxed agent-scope 8-byte store / load, so no fence is needed (the data is the flag).
+// Block ids must be handed out by an atomic ticket so that a block only ever waits on blocks
+// that have already started.  Call from the first wave (64 lanes) only; returns the exclusive
+// prefix of `aggregate` over blocks [0, id) in every lane.  lb must be zeroed before launch.
+constexpr u64 LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_MASK = (1ull << 62) - 1;
+constexpr u32 LB_SPIN_LIMIT = 4000000;
+
+__device__ __forceinline__ u64 lookback_excl(u64* lb, u32 id, u64 aggregate, u32* st) {
+  u64 excl = 0;
+  if (id > 0) {
+    if (lane_id() == 0)
+      __hip_atomic_store(&lb[id], LB_AGG | aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int look = (int)id - 1;
+    u32 spins = 0;
+    bool done = false;
+    while (!done) {
+      int idx = look - lane_id();  // lane 0 = nearest predecessor
+      u64 v = idx >= 0 ? __hip_atomic_load(&lb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : LB_INC;   // virtual block -1: inclusive prefix 0
+      u64 flag = v >> 62;
+      u64 invalidMask = __ballot(flag == 0);
+      u64 incMask = __ballot(flag == 2);
+      int firstInvalid = invalidMask ? __builtin_ctzll(invalidMask) : 64;
+      int firstInc = incMask ? __builtin_ctzll(incMask) : 64;
+      if (firstInc < firstInvalid) {
+        excl += wave_sum(lane_id() <= firstInc ? (v & LB_MASK) : 0ull);
+        done = true;
+      } else if (firstInvalid > 0) {
+        excl += wave_sum(lane_id() < firstInvalid ? (v & LB_MASK) : 0ull);
+        look -= firstInvalid;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > LB_SPIN_LIMIT) {
+          if (lane_id() == 0) atomicOr(st, ST_LOOKBACK);
+          done = true;
+        }
+      }
+    }
+  }
+  if (lane_id() == 0)
+    __hip_atomic_store(&lb[id], LB_INC | (excl + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
+// lazily re-seeking cursor: which chromosome owns interval i of an array laid out by
+// chromIvOff[nChrom+1]?  A binary search runs only when i leaves the current range.
+struct ChromCursor {
+  u32 c = 0, lo = 0, hi = 0;
+  __device__ __forceinline__ void seek(const u32* __restrict__ off, u32 nChrom, u32 i) {
+    if (i >= lo && i < hi) return;
+    u32 a = 0, b = nChrom;  // last c with off[c] <= i  (empty ranges share an offset: take the last)
+    while (b - a > 1) {
+      u32 mid = (a + b) >> 1;
+      if (off[mid] <= i) a = mid; else b = mid;
+    }
+    c = a;
+    lo = off[a];
+    hi = off[a + 1];
+  }
+};
+
+// ---- 4. the tile kernel: LDS difference array -> prefix sum -> run-length pileup -----------
+// Replaces savePileupExpt's two per-base passes (Genrich.c:2197-2273; and the per-base walk
+// of calcFactor/savePileupCtrl for a control).  One workgroup owns one tile:
+//   zero the LDS slice; add every endpoint record of the tile (ds_add, integer);
+//   blocked prefix sum (32 bases per thread, wave shuffles + one cross-wave step);
+//   a base j >= 1 with a non-zero difference closes the interval [.., j) whose value is the
+//   prefix BEFORE j (:2241-2251); the chromosome's last tile also closes [.., len) (:2268).
+// The output position of a tile's intervals is a prefix sum over tiles, obtained in the same
+// launch by a decoupled look-back over 8-byte {flag, value} granules (one relaxed agent-scope
+// store/load each; tickets are handed out by an atomic so a tile only waits on tiles that
+// have already started).
+constexpr int TL_NT = 512;
+constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
+constexpr int TL_PAD = TILE + TILE / 32;          // +1 dword per 32: conflict-free blocked reads
+struct TileOut {
+  u32* ivEnd;       // interval end (chromosome coordinate)
+  int* ivV;         // pileup in 1/120 units
+  u32* tileIvOff;   // [nTiles+1] first interval of each tile
+  u32* chromIvOff;  // [nChrom+1] first interval of each chromosome
+  u32* nIv;         // total
+};
+
+__global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
+                                                   const u32* __restrict__ tileOff,
+                                                   const int* __restrict__ tileCarry,
+                                                   const u32* __restrict__ tileChrom,
+                                                   const DChrom* __restrict__ chroms, u32 nTiles,
+                                                   u32 nChrom, u32* __restrict__ ticket,
+                                                   u64* __restrict__ lb, TileOut out,
+                                                   u32* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  int* delta = lds;                        // TL_PAD ints
+  int* scr = lds + TL_PAD;                 // [0..15] scan scratch, [16] ticket, [17] output base
+  if (threadIdx.x == 0) scr[16] = (int)atomicAdd(ticket, 1u);
+  // zero the slice (16 B per lane)
+  for (int i = threadIdx.x * 4; i < TL_PAD; i += TL_NT * 4)
+    *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  const u32 t = (u32)scr[16];
+  if (t >= nTiles) return;
+  const u32 ci = tileChrom[t];
+  const DChrom c = chroms[ci];
+  const bool active = chrom_active(c);
+  const u32 tl = t - c.tileBase;
+  const u32 pos0 = tl << TB;
+  const bool lastTile = tl + 1 == c.nTiles;
+  // accumulate this tile's endpoint records
+  const u32 rb = tileOff[t], re = tileOff[t + 1];
+  for (u32 i = rb + threadIdx.x; i < re; i += TL_NT) {
+    u64 r = recs[i];
+    u32 off = (u32)(r >> 8) & (TILE - 1);
+    atomicAdd(&delta[off + (off >> 5)], (int)(int8_t)(r & 0xFF));
+  }
+  __syncthreads();
+  // blocked read: thread i owns bases [32 i, 32 i + 32)
+  int d[TL_EPT];
+  int sum = 0;
+  u32 cnt = 0;
+  const int lbase = threadIdx.x * 33;
+  u32 sat = 0;
+#pragma unroll
+  for (int k = 0; k < TL_EPT; k++) {
+    d[k] = delta[lbase + k];
+    sum += d[k];
+    cnt += (d[k] != 0) && (pos0 + threadIdx.x * TL_EPT + k != 0);
+    sat |= (u32)(d[k] >= 32767 * GX_UNIT) | (u32)(d[k] <= -32768 * GX_UNIT);
+  }
+  if (lastTile && threadIdx.x == TL_NT - 1 && active) cnt += 1;  // closing interval [.., len)
+  if (!active) cnt = 0;
+  int sumTot;
+  u32 cntTot;
+  int exSum = block_excl_scan<int, TL_NT>(sum, scr, &sumTot);
+  u32 exCnt = block_excl_scan<u32, TL_NT>(cnt, reinterpret_cast<u32*>(scr), &cntTot);
+  // output position of this tile = exclusive prefix of interval counts over earlier tiles
+  if (threadIdx.x < 64) {
+    u64 excl = lookback_excl(lb, t, (u64)cntTot, st);
+    if (threadIdx.x == 0) {
+      scr[17] = (int)(u32)excl;
+      out.tileIvOff[t] = (u32)excl;
+      if (tl == 0) out.chromIvOff[ci] = (u32)excl;
+      if (t == nTiles - 1) {
+        out.tileIvOff[nTiles] = (u32)(excl + cntTot);
+        *out.nIv = (u32)(excl + cntTot);
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  // emit
+  int run = tileCarry[t] + exSum;
+  u32 o = (u32)scr[17] + exCnt;
+  u32 neg = 0;
+#pragma unroll
+  for (int k = 0; k < TL_EPT; k++) {
+    u32 p = pos0 + threadIdx.x * TL_EPT + k;
+    if (d[k] != 0 && p != 0) {
+      out.ivEnd[o] = p;
+      out.ivV[o] = run;
+      o++;
+    }
+    run += d[k];
+    neg |= (u32)(run < 0);
+  }
+  if (lastTile && threadIdx.x == TL_NT - 1) {
+    out.ivEnd[o] = c.len;
+    out.ivV[o] = run;
+  }
+  u32 bad = (neg ? ST_NEG_PILE : 0) | (sat ? ST_SAT16 : 0);
+  if (bad) atomicOr(st, bad);
+}
+
+// chromosome table epilogue of the tile kernel: chromIvOff for chromosomes without tiles
+// (inactive ones get an empty range) -- single thread, nChrom is small.
+__global__ void k_fix_chrom_off(const DChrom* __restrict__ chroms, u32 nChrom, u32* __restrict__ chromIvOff,
+                                const u32* __restrict__ nIv) {
+  if (threadIdx.x || blockIdx.x) return;
+  u32 next = *nIv;
+  chromIvOff[nChrom] = next;
+  for (int c = (int)nChrom - 1; c >= 0; c--) {
+    if (chroms[c].tileBase == NULL_TILE)
+      chromIvOff[c] = next;
+    else
+      next = chromIvOff[c];
+  }
+}
+
+// ---- 5. fragLen: sum over intervals of (float)(len * val), accumulated exactly ------------
+// savePileupExpt 2246/2271, calcFactor 2018/2038: `fragLen += (j - start) * val` is a float
+// product added into a double.  Every product is a multiple of 2^-27 (val >= 1/10 when
+// non-zero), so the sum is accumulated exactly in two int64 (integer part, fraction * 2^27):
+// deterministic for any launch geometry or rank count, and equal to the reference's double
+// sum whenever that sum is exact (always, for unit weights).
+__global__ __launch_bounds__(256) void k_fraglen(const u32* __restrict__ ivEnd, const int* __restrict__ ivV,
+                                                 const u32* __restrict__ chromIvOff, u32 nChrom,
+                                                 const u32* __restrict__ nIvPtr,
+                                                 long long* __restrict__ acc, u32* __restrict__ st) {
+  const u32 nIv = *nIvPtr;
+  long long hi = 0, lo = 0;
+  u32 neg = 0;
+  ChromCursor cur;
+  const u32 per = (nIv + gridDim.x - 1) / gridDim.x;  // blocked: one contiguous range per workgroup
+  const u32 b0 = blockIdx.x * per, b1 = min(nIv, b0 + per);
+  for (u32 i = b0 + threadIdx.x; i < b1; i += 256) {
+    int v = ivV[i];
+    if (v == 0) continue;
+    u32 e = ivEnd[i];
+    cur.seek(chromIvOff, nChrom, i);
+    u32 s = i == cur.lo ? 0 : ivEnd[i - 1];
+    bool ng;
+    float val = getval(v, &ng);
+    neg |= ng;
+    float term = (float)(e - s) * val;
+    float fl = floorf(term);
+    hi += (long long)fl;
+    lo += (long long)((term - fl) * 134217728.0f);
+  }
+  hi = wave_sum(hi);
+  lo = wave_sum(lo);
+  if (lane_id() == 0) {
+    if (hi) atomicAdd((u64*)&acc[0], (u64)hi);
+    if (lo) atomicAdd((u64*)&acc[1], (u64)lo);
+  }
+  if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// scalars of one replicate, kept on the device so no host round trip sits between kernels
+struct Scalars {
+  long long fragAcc[2];  // treatment fragLen: integer part, fraction * 2^27
+  long long ctrlAcc[2];  // control
+  double fragLen;
+  double ctrlFrag;
+  float lambda;
+  float factor;
+  u64 genomeLen;
+};
+
+__global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (!isCtrl) {
+    s->fragLen = (double)s->fragAcc[0] + (double)s->fragAcc[1] * (1.0 / 134217728.0);
+    if (s->fragLen == 0.0) atomicOr(st, ST_NO_FRAGS);
+  } else {
+    s->ctrlFrag = (double)s->ctrlAcc[0] + (double)s->ctrlAcc[1] * (1.0 / 134217728.0);
+    s->factor = s->ctrlFrag == 0.0 ? 1.0f : (float)(s->fragLen / s->ctrlFrag);  // calcFactor 2043-2045
+  }
+  s->lambda = (float)(s->fragLen / (double)s->genomeLen);  // calcLambda 1831
+}
+
+}  // namespace gx

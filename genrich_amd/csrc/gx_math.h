@@ -1,0 +1,232 @@
+// gx_math.h -- scalar device math of the Genrich hot path (gfx950).
+//
+// Pileup values are exact integers in units of 1/120 ("V120"); the float the reference
+// would hold is re-materialised by gx_getval exactly as getVal does (Genrich.c:1902-1907).
+// p-values are double math rounded once to float (calcPval, Genrich.c:1628-1653); the
+// device uses OCML's double log/exp/log1p (<= 1-2 ulp), so the float result equals the
+// host-libm one unless the double lands within ~1e-16 of a float rounding boundary.
+// Compile with -ffp-contract=off: the reference is built without FMA contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#define GX_UNIT 120
+#define GX_SKIPF (-1.0f)
+
+namespace gx {
+
+// residue mod 120 -> packed (eighths | sixths<<4 | tenths<<8) with 15e+20s+12t == r (mod 120),
+// e<8, s<3, t<5 (a bijection; frac bit layout of the reference: Genrich.c:2299-2305).
+// mod 3: 15e+20s+12t = 2s ; mod 5: = 2t ; mod 8: = 7e + 4(s+t).
+__device__ __forceinline__ uint32_t est_of_residue(int r) {
+  uint32_t s = (uint32_t)(r * 2) % 3u;
+  uint32_t t = (uint32_t)(r * 3) % 5u;
+  uint32_t e = (7u * ((uint32_t)r + 4u * (s + t))) & 7u;
+  return e | (s << 4) | (t << 8);
+}
+
+// getVal (1902-1907) of the canonical (cov, e, s, t) state of the exact sum v/120.
+// *neg is set when the canonical integer part is negative (updateVal's ERRPILE, 1921/1969).
+__device__ __forceinline__ float getval(int32_t v, bool* neg) {
+  int32_t q = v / GX_UNIT, r = v - q * GX_UNIT;
+  if (r < 0) { r += GX_UNIT; q -= 1; }
+  if (r == 0) { *neg = q < 0; return (float)q; }
+  uint32_t est = est_of_residue(r);
+  int e = est & 15, s = (est >> 4) & 15, t = est >> 8;
+  int32_t cov = q - (15 * e + 20 * s + 12 * t - r) / GX_UNIT;
+  *neg = cov < 0;
+  return (float)cov + ((float)e / 8.0f) + ((float)s / 6.0f) + ((float)t / 10.0f);
+}
+
+// ---- log-normal -log10 p : calcPval (1628-1653), plnorm (1617), pnorm (1509-1607) ----
+
+__device__ __forceinline__ double do_del(double y, double temp, bool lower) {  // 1497-1503
+  double xsq = trunc(y * 16) / 16;
+  double del = (y - xsq) * (y + xsq);
+  if (lower) return log1p(-exp((-xsq * xsq - del) / 2.0) * temp);
+  return (-xsq * xsq - del) / 2.0 + log(temp);
+}
+
+__device__ inline double pnorm_upper_log(double x) {
+  const double a0 = 2.2352520354606839287, a1 = 161.02823106855587881,
+               a2 = 1067.6894854603709582, a3 = 18154.981253343561249,
+               a4 = 0.065682337918207449113;
+  const double b0 = 47.20258190468824187, b1 = 976.09855173777669322,
+               b2 = 10260.932208618978205, b3 = 45507.789335026729956;
+  const double c[9] = {0.39894151208813466764, 8.8831497943883759412, 93.506656132177855979,
+                       597.27027639480026226,  2494.5375852903726711, 6848.1904505362823326,
+                       11602.651437647350124,  9842.7148383839780218, 1.0765576773720192317e-8};
+  const double d[8] = {22.266688044328115691, 235.38790178262499861, 1519.377599407554805,
+                       6485.558298266760755,  18615.571640885098091, 34900.952721145977266,
+                       38912.003286093271411, 19685.429676859990727};
+  const double p[6] = {0.21589853405795699,   0.1274011611602473639,   0.022235277870649807,
+                       0.001421619193227893466, 2.9112874951168792e-5, 0.02307344176494017303};
+  const double q[5] = {1.28426009614491121, 0.468238212480865118, 0.0659881378689285515,
+                       0.00378239633202758244, 7.29751555083966205e-5};
+  double y = fabs(x), num, den, t;
+  if (y <= 0.67448975) {
+    if (y > DBL_EPSILON * 0.5) {
+      double xsq = x * x;
+      num = a4 * xsq;
+      den = xsq;
+      num = (num + a0) * xsq; den = (den + b0) * xsq;
+      num = (num + a1) * xsq; den = (den + b1) * xsq;
+      num = (num + a2) * xsq; den = (den + b2) * xsq;
+      t = x * (num + a3) / (den + b3);
+    } else
+      t = x * a3 / b3;
+    return log(0.5 - t);
+  }
+  if (y <= sqrt(32.0)) {
+    num = c[8] * y;
+    den = y;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      num = (num + c[i]) * y;
+      den = (den + d[i]) * y;
+    }
+    t = (num + c[7]) / (den + d[7]);
+    return do_del(y, t, x <= 0.0);
+  }
+  if (y < 1e170) {
+    double xsq = 1.0 / (x * x);
+    num = p[5] * xsq;
+    den = xsq;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      num = (num + p[i]) * xsq;
+      den = (den + q[i]) * xsq;
+    }
+    t = xsq * (num + p[4]) / (den + q[4]);
+    t = (1 / sqrt(2 * 3.14159265358979323846) - t) / y;
+    return do_del(x, t, x <= 0.0);
+  }
+  return -0.0;
+}
+
+// meanlog / sdlog of the null for control value mu (1637-1648)
+__device__ __forceinline__ void lnorm_params(float ctrl, double* meanlog, double* sdlog) {
+  double mu = ctrl;
+  if (mu > 7.0) {
+    double sd = 10.0 * log10(mu);
+    mu *= mu;
+    sd *= sd;
+    *meanlog = log(mu / sqrt(sd + mu));
+    *sdlog = sqrt(log1p(sd / mu));
+  } else {
+    *meanlog = log(mu) - 0.445999019652555; /* LOGSQRT, Genrich.h:52 */
+    *sdlog = 0.944456478248262;             /* SQRTLOG, Genrich.h:53 */
+  }
+}
+
+__device__ __forceinline__ float pval_given(float expt, double meanlog, double sdlog) {
+  double pv;
+  if (sdlog == 0.0)
+    pv = (double)expt < meanlog ? 0.0 : (double)FLT_MAX;
+  else
+    pv = -pnorm_upper_log((log((double)expt) - meanlog) / sdlog) / 2.30258509299404568402;
+  return pv > (double)FLT_MAX ? FLT_MAX : (float)pv;
+}
+
+__device__ inline float calc_pval(float expt, float ctrl) {
+  if (ctrl == GX_SKIPF) return GX_SKIPF;
+  if (ctrl == 0.0f) return expt == 0.0f ? 0.0f : FLT_MAX;
+  if (expt == 0.0f) return 0.0f;
+  double ml, sl;
+  lnorm_params(ctrl, &ml, &sl);
+  return pval_given(expt, ml, sl);
+}
+
+// ---- chi-squared upper tail, log scale: pchisq (555-559) and helpers (407-545) ----
+
+__device__ __forceinline__ double log1_exp(double x) {  // R_Log1_Exp, 407
+  return x > -0.693147180559945309417 ? log(-expm1(x)) : log1p(-exp(x));
+}
+
+__device__ inline double bd0(double x, double np) {  // 412-430
+  if (fabs(x - np) < 0.1 * (x + np)) {
+    double v = (x - np) / (x + np);
+    double s = (x - np) * v;
+    if (fabs(s) < DBL_MIN) return s;
+    double ej = 2 * x * v;
+    v = v * v;
+    for (int j = 1; j < 1000; j++) {
+      ej *= v;
+      double s1 = s + ej / ((j << 1) + 1);
+      if (s1 == s) return s1;
+      s = s1;
+    }
+  }
+  return x * log(x / np) + np - x;
+}
+
+__device__ inline double stirlerr(double n) {  // 436-469
+  const double sferr[16] = {0.0,
+                            0.0810614667953272582196702,
+                            0.0413406959554092940938221,
+                            0.02767792568499833914878929,
+                            0.02079067210376509311152277,
+                            0.01664469118982119216319487,
+                            0.01387612882307074799874573,
+                            0.01189670994589177009505572,
+                            0.010411265261972096497478567,
+                            0.009255462182712732917728637,
+                            0.008330563433362871256469318,
+                            0.007573675487951840794972024,
+                            0.006942840107209529865664152,
+                            0.006408994188004207068439631,
+                            0.005951370112758847735624416,
+                            0.005554733551962801371038690};
+  const double S0 = 1.0 / 12, S1 = 1.0 / 360, S2 = 1.0 / 1260, S3 = 1.0 / 1680, S4 = 1.0 / 1188;
+  double nn = n * n;
+  if (n > 80.0) return (S0 - (S1 - S2 / nn) / nn) / n;
+  if (n > 35.0) return (S0 - (S1 - (S2 - S3 / nn) / nn) / nn) / n;
+  if (n > 15.0) return (S0 - (S1 - (S2 - (S3 - S4 / nn) / nn) / nn) / nn) / n;
+  return sferr[(int)n];
+}
+
+__device__ inline double dpois_log(double x, double lambda) {  // 474-477
+  return -0.5 * log(2.0 * 3.14159265358979323846 * x) - stirlerr(x) - bd0(x, lambda);
+}
+
+__device__ inline double pgamma_upper_log(double x, double alph) {  // 528-545
+  if (x < 1) {  // pgamma_smallx 509-522
+    double sum = 0.0, c = alph, n = 0.0, term;
+    do {
+      n++;
+      c *= -x / n;
+      term = c / (alph + n);
+      sum += term;
+    } while (fabs(term) > DBL_EPSILON * fabs(sum));
+    double lf2 = alph * log(x) - lgamma(alph + 1);
+    return log1_exp(log1p(sum) + lf2);
+  }
+  if (x <= alph - 1) {  // pd_upper_series 482-491
+    double a = alph, term = x / a, sum = term;
+    do {
+      a++;
+      term *= x / a;
+      sum += term;
+    } while (term > sum * DBL_EPSILON);
+    return log1_exp(log(sum) + dpois_log(alph - 1, x));
+  }
+  double y = alph - 1, term = 1, sum = 0;  // pd_lower_series 496-504
+  while (y >= 1 && term > sum * DBL_EPSILON) {
+    term *= y / x;
+    sum += term;
+    y--;
+  }
+  return log1p(sum) + dpois_log(alph - 1, x);
+}
+
+// multPval's tail (577-582): sum of -log10 p over df/2 replicates -> combined -log10 p
+__device__ inline float fisher_combine(double sum, int df) {
+  if (df == 0) return GX_SKIPF;
+  if (df == 2 || sum == 0.0) return (float)sum;
+  double p = -pgamma_upper_log((2.0 * sum / 0.434294481903251827651) / 2.0, df / 2.0) /
+             2.30258509299404568402;
+  return p > (double)FLT_MAX ? FLT_MAX : (float)p;
+}
+
+}  // namespace gx

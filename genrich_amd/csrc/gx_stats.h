@@ -1,0 +1,363 @@
+// gx_stats.h -- p-values, Benjamini-Hochberg q-values and the peak sweep on run-length
+// intervals (gfx950).  Interval arrays are laid out chromosome after chromosome; chromOff
+// [nChrom+1] gives each chromosome's range, so an interval's start is the previous end or 0.
+#pragma once
+#include "gx_kernels.h"
+
+namespace gx {
+
+// ---- p-values, no control: savePileupNoCtrl + savePval (Genrich.c:1883-1896, 1720-1794) ----
+// The control pileup is the constant lambda, so the p-intervals are the treatment intervals.
+__global__ __launch_bounds__(256) void k_pval_const(const int* __restrict__ ivV, const u32* __restrict__ nIvPtr,
+                                                    const Scalars* __restrict__ sc, float* __restrict__ pOut,
+                                                    float* __restrict__ exptOut, u32* __restrict__ st) {
+  const u32 n = *nIvPtr;
+  const float lambda = sc->lambda;
+  double ml = 0, sl = 1;
+  if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
+  u32 neg = 0;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    bool ng;
+    float val = getval(ivV[i], &ng);
+    neg |= ng;
+    float p;
+    if (lambda == 0.0f)
+      p = val == 0.0f ? 0.0f : FLT_MAX;  // calcPval 1631-1632
+    else
+      p = val == 0.0f ? 0.0f : pval_given(val, ml, sl);
+    pOut[i] = p;
+    if (exptOut) exptOut[i] = val;
+  }
+  if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// ---- Benjamini-Hochberg: computeQval (352-401) / saveQval (212-250) -----------------------
+// hashPval (300-327): genome-wide multiset {distinct float p -> total bp}.  Keys are the
+// float's bits (p >= +0, so unsigned bit order == numeric order; -0 is folded into +0 as C's
+// == does, 282).  Each workgroup first aggregates into an LDS table so the global table sees
+// one atomic per (workgroup, distinct value).
+constexpr u32 EMPTY_KEY = 0xFFFFFFFFu;  // a NaN pattern: never a p-value
+constexpr int BH_LT = 2048;             // LDS table entries
+constexpr int BH_LPROBE = 8;
+
+__device__ __forceinline__ u32 bh_hash(u32 k) {
+  k *= 2654435761u;
+  return k ^ (k >> 15);
+}
+
+__device__ __forceinline__ void bh_global_add(u32* __restrict__ gKeys, u64* __restrict__ gLens, u32 capMask,
+                                              u32 key, u64 len, u32* st) {
+  u32 h = bh_hash(key) & capMask;
+  for (u32 probe = 0; probe <= capMask; probe++) {
+    u32 old = gKeys[h];
+    if (old != key) {
+      if (old != EMPTY_KEY) { h = (h + 1) & capMask; continue; }
+      old = atomicCAS(&gKeys[h], EMPTY_KEY, key);
+      if (old != EMPTY_KEY && old != key) { h = (h + 1) & capMask; continue; }
+    }
+    atomicAdd(&gLens[h], len);
+    return;
+  }
+  atomicOr(st, ST_HASH_FULL);
+}
+
+__global__ __launch_bounds__(256) void k_bh_hist(const u32* __restrict__ end, const float* __restrict__ p,
+                                                 const u32* __restrict__ chromOff, u32 nChrom,
+                                                 const u32* __restrict__ nPtr, u32* __restrict__ gKeys,
+                                                 u64* __restrict__ gLens, u32 capMask, u32* __restrict__ st) {
+  __shared__ u32 lk[BH_LT];
+  __shared__ u64 ll[BH_LT];
+  for (int i = threadIdx.x; i < BH_LT; i += 256) { lk[i] = EMPTY_KEY; ll[i] = 0; }
+  __syncthreads();
+  const u32 n = *nPtr;
+  const u32 per = (n + gridDim.x - 1) / gridDim.x;
+  const u32 b0 = blockIdx.x * per, b1 = min(n, b0 + per);
+  ChromCursor cur;
+  for (u32 i = b0 + threadIdx.x; i < b1; i += 256) {
+    float pv = p[i];
+    if (pv == GX_SKIPF) continue;  // 319
+    cur.seek(chromOff, nChrom, i);
+    u32 s = i == cur.lo ? 0 : end[i - 1];
+    u64 len = end[i] - s;
+    u32 key = pv == 0.0f ? 0u : __float_as_uint(pv);
+    u32 h = bh_hash(key) & (BH_LT - 1);
+    bool placed = false;
+    for (int probe = 0; probe < BH_LPROBE && !placed; probe++) {
+      u32 old = lk[h];
+      if (old != key) {
+        if (old == EMPTY_KEY) old = atomicCAS(&lk[h], EMPTY_KEY, key);
+        if (old != EMPTY_KEY && old != key) { h = (h + 1) & (BH_LT - 1); continue; }
+      }
+      atomicAdd(&ll[h], len);
+      placed = true;
+    }
+    if (!placed) bh_global_add(gKeys, gLens, capMask, key, len, st);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < BH_LT; i += 256)
+    if (lk[i] != EMPTY_KEY) bh_global_add(gKeys, gLens, capMask, lk[i], ll[i], st);
+}
+
+// occupied slots -> (key, slot) pairs, arbitrary order (sorted afterwards)
+__global__ __launch_bounds__(256) void k_bh_compact(const u32* __restrict__ gKeys, u32 cap, u32* __restrict__ outKeys,
+                                                    u32* __restrict__ outSlot, u32* __restrict__ counter) {
+  for (u32 s = blockIdx.x * 256 + threadIdx.x; s < cap; s += gridDim.x * 256) {
+    u32 k = gKeys[s];
+    if (k != EMPTY_KEY) {
+      u32 j = atomicAdd(counter, 1u);
+      outKeys[j] = k;
+      outSlot[j] = s;
+    }
+  }
+}
+
+// insert (key, bp) pairs gathered from other ranks
+__global__ __launch_bounds__(256) void k_bh_insert(const u32* __restrict__ keys, const u64* __restrict__ lens, u32 n,
+                                                   u32* __restrict__ gKeys, u64* __restrict__ gLens, u32 capMask,
+                                                   u32* __restrict__ st) {
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    bh_global_add(gKeys, gLens, capMask, keys[i], lens[i], st);
+}
+
+// float log10 as the host's libm evaluates it (saveQval 221, 226 call log10f).
+__device__ __forceinline__ float log10f_host(float x) { return (float)log10((double)x); }
+
+// saveQval 219-229 on the sorted table (ascending p): from the most significant value down,
+//   raw_i = p_i + logN + log10f(k_i),  k_i = 1 + bp with strictly larger p   (float adds, left to right)
+//   q_i = max(min(raw_i, q_{i+1}), 0) = max(min_{j>=i} raw_j, 0)               (suffix minimum: exact)
+// Single workgroup; each thread owns a contiguous run of the REVERSED order.
+template <typename T, int NT, typename Op>
+__device__ __forceinline__ T block_excl_scan_op(T v, T identity, T* scratch, Op op) {
+  constexpr int NW = NT / 64;
+  T inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(inc, d, 64);
+    if (lane_id() >= d) inc = op(o, inc);
+  }
+  int w = threadIdx.x >> 6;
+  if (lane_id() == 63) scratch[w] = inc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    T x = threadIdx.x < NW ? scratch[threadIdx.x] : identity;
+    T xi = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      T o = __shfl_up(xi, d, 64);
+      if (lane_id() >= d) xi = op(o, xi);
+    }
+    T xe = __shfl_up(xi, 1, 64);
+    if (threadIdx.x == 0) xe = identity;
+    if (threadIdx.x < NW) scratch[threadIdx.x] = xe;
+  }
+  __syncthreads();
+  T prev = __shfl_up(inc, 1, 64);
+  if (lane_id() == 0) prev = identity;
+  T res = op(scratch[w], prev);
+  __syncthreads();
+  return res;
+}
+
+struct OpAddU64 { __device__ u64 operator()(u64 a, u64 b) const { return a + b; } };
+struct OpMinF { __device__ float operator()(float a, float b) const { return a < b ? a : b; } };
+
+__global__ __launch_bounds__(1024) void k_qtable(const u32* __restrict__ keys, const u32* __restrict__ slots,
+                                                 const u64* __restrict__ gLens, u32 D, const u64* __restrict__ genomeLenPtr,
+                                                 float* __restrict__ qOfSlot, float* __restrict__ raw /* scratch [D] */,
+                                                 u32* __restrict__ allOne) {
+  __shared__ u64 s64[20];
+  __shared__ float sf[20];
+  const float logN = -log10f_host((float)*genomeLenPtr);
+  const u32 per = (D + 1023) / 1024;
+  const u32 r0 = min(D, threadIdx.x * per), r1 = min(D, r0 + per);  // reversed indices [r0, r1)
+  u64 sum = 0;
+  for (u32 r = r0; r < r1; r++) sum += gLens[slots[D - 1 - r]];
+  u64 k = 1 + block_excl_scan_op<u64, 1024>(sum, 0ull, s64, OpAddU64());
+  float mn = FLT_MAX;
+  for (u32 r = r0; r < r1; r++) {
+    u32 i = D - 1 - r;
+    float pv = __uint_as_float(keys[i]);
+    float rw = pv + logN + log10f_host((float)k);
+    raw[i] = rw;
+    mn = rw < mn ? rw : mn;
+    k += gLens[slots[i]];
+  }
+  float run = block_excl_scan_op<float, 1024>(mn, FLT_MAX, sf, OpMinF());
+  for (u32 r = r0; r < r1; r++) {
+    u32 i = D - 1 - r;
+    float rw = raw[i];
+    run = rw < run ? rw : run;
+    float q = run > 0.0f ? run : 0.0f;
+    qOfSlot[slots[i]] = q;
+    if (r == 0 && allOne) *allOne = q == 0.0f;  // "All q-values are 1" (245)
+  }
+}
+
+// per interval: q = table[p] (lookup 196-206), SKIP stays SKIP (237-238)
+__global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, const u32* __restrict__ nPtr,
+                                                 const u32* __restrict__ gKeys, const float* __restrict__ qOfSlot,
+                                                 u32 capMask, float* __restrict__ q) {
+  const u32 n = *nPtr;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float pv = p[i];
+    if (pv == GX_SKIPF) { q[i] = GX_SKIPF; continue; }
+    u32 key = pv == 0.0f ? 0u : __float_as_uint(pv);
+    u32 h = bh_hash(key) & capMask;
+    while (gKeys[h] != key) h = (h + 1) & capMask;  // every p was inserted
+    q[i] = qOfSlot[h];
+  }
+}
+
+// ---- peak sweep: callPeaks (977-1069) ---------------------------------------------------------
+// Only significant intervals (pq > thr, strict, 1015) and SKIP intervals matter: two significant
+// intervals belong to one candidate iff no SKIP interval lies between them and
+// start_next - end_prev <= maxGap (1031-1032).  Pass 1 compacts those intervals in order
+// (single pass, decoupled look-back); pass 2 marks candidate heads; pass 3 walks each candidate
+// sequentially so the float AUC is summed in the reference's order (950).
+struct SweepList {
+  u32* chrom;
+  u32* start;
+  u32* end;
+  float* p;
+  float* q;
+  u32* sig;   // 1 significant, 0 SKIP marker
+  u32* count; // number of entries
+};
+
+constexpr int SW_NT = 256;
+constexpr int SW_ITEMS = 8;
+constexpr int SW_CHUNK = SW_NT * SW_ITEMS;
+
+__global__ __launch_bounds__(SW_NT) void k_sweep_compact(const u32* __restrict__ end, const float* __restrict__ p,
+                                                         const float* __restrict__ q, const u32* __restrict__ chromOff,
+                                                         u32 nChrom, const u32* __restrict__ nPtr, float thr,
+                                                         u32* __restrict__ ticket, u64* __restrict__ lb, SweepList out,
+                                                         u32* __restrict__ st) {
+  __shared__ u32 scratch[8];
+  __shared__ u32 s_id, s_base;
+  if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const u32 id = s_id;
+  const u32 n = *nPtr;
+  const u32 nBlocks = (n + SW_CHUNK - 1) / SW_CHUNK;
+  if (id >= nBlocks) return;
+  const u32 i0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  float pv[SW_ITEMS], qv[SW_ITEMS];
+  u32 keep = 0, cnt = 0;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++) {
+    u32 i = i0 + k;
+    if (i < n) {
+      pv[k] = p[i];
+      qv[k] = q ? q[i] : GX_SKIPF;
+      float pq = q ? qv[k] : pv[k];
+      if (pq > thr || pq == GX_SKIPF) { keep |= 1u << k; cnt++; }
+    }
+  }
+  u32 tot;
+  u32 ex = block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
+  if (threadIdx.x < 64) {
+    u64 excl = lookback_excl(lb, id, (u64)tot, st);
+    if (threadIdx.x == 0) {
+      s_base = (u32)excl;
+      if (id == nBlocks - 1) *out.count = (u32)(excl + tot);
+    }
+  }
+  __syncthreads();
+  if (!keep) return;
+  u32 o = s_base + ex;
+  ChromCursor cur;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++)
+    if (keep & (1u << k)) {
+      u32 i = i0 + k;
+      cur.seek(chromOff, nChrom, i);
+      float pq = q ? qv[k] : pv[k];
+      out.chrom[o] = cur.c;
+      out.start[o] = i == cur.lo ? 0 : end[i - 1];
+      out.end[o] = end[i];
+      out.p[o] = pv[k];
+      out.q[o] = qv[k];
+      out.sig[o] = pq == GX_SKIPF ? 0u : 1u;
+      o++;
+    }
+}
+
+// head of a candidate: first significant interval after a SKIP, a chromosome change, or a gap
+// wider than maxGap
+__device__ __forceinline__ bool sweep_is_head(const SweepList& L, u32 j, int maxGap) {
+  if (j == 0 || !L.sig[j - 1] || L.chrom[j - 1] != L.chrom[j]) return true;
+  long long gap = (long long)L.start[j] - (long long)L.end[j - 1];
+  return gap != 0 && gap > (long long)maxGap;
+}
+
+// one thread per candidate: updatePeak (943-970) over its intervals in order, then checkPeak (916-927)
+__global__ __launch_bounds__(256) void k_peak_walk(SweepList L, float thr, float minAUC, int minLen, int maxGap,
+                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  const u32 M = *L.count;
+  for (u32 j = blockIdx.x * 256 + threadIdx.x; j < M; j += gridDim.x * 256) {
+    valid[j] = 0;
+    if (!L.sig[j] || !sweep_is_head(L, j, maxGap)) continue;
+    const bool qOpt = L.q[j] != GX_SKIPF;
+    float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
+    u32 summitPos = 0, summitLen = 0;
+    const u32 peakStart = L.start[j];
+    u32 peakEnd = 0;
+    for (u32 k = j; k < M; k++) {
+      if (k > j && (!L.sig[k] || sweep_is_head(L, k, maxGap))) break;
+      u32 s = L.start[k], e = L.end[k], len = e - s;
+      float pq = qOpt ? L.q[k] : L.p[k];
+      auc += (float)len * (pq - thr);  // 950: float product, float running sum, in order
+      peakEnd = e;
+      if (pq > summitVal) {
+        summitVal = pq;
+        sp = L.p[k];
+        sq = L.q[k];
+        summitPos = (u32)(((u64)e + s) / 2 - peakStart);
+        summitLen = len;
+      } else if (pq == summitVal && len > summitLen) {
+        summitPos = (u32)(((u64)e + s) / 2 - peakStart);
+        summitLen = len;
+      }
+    }
+    if (auc >= minAUC && (long long)peakEnd - (long long)peakStart >= (long long)minLen) {
+      gx_peak pk;
+      pk.chrom = L.chrom[j];
+      pk.start = peakStart;
+      pk.end = peakEnd;
+      pk.summit = summitPos;
+      pk.auc = auc;
+      pk.p = sp;
+      pk.q = sq;
+      cand[j] = pk;
+      valid[j] = 1;
+    }
+  }
+}
+
+// ordered compaction of the valid candidates (single workgroup: the list is short)
+__global__ __launch_bounds__(1024) void k_peak_compact(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
+                                                       const u32* __restrict__ mPtr, gx_peak* __restrict__ peaks,
+                                                       u32* __restrict__ nPeaks, u64* __restrict__ peakBP) {
+  __shared__ u32 scratch[20];
+  const u32 M = *mPtr;
+  u32 base = 0;
+  u64 bp = 0;
+  for (u32 j0 = 0; j0 < M; j0 += 1024) {
+    u32 j = j0 + threadIdx.x;
+    u32 v = j < M ? valid[j] : 0;
+    u32 tot;
+    u32 ex = block_excl_scan<u32, 1024>(v, scratch, &tot);
+    if (v) {
+      gx_peak pk = cand[j];
+      peaks[base + ex] = pk;
+      bp += pk.end - pk.start;
+    }
+    base += tot;
+  }
+  bp = wave_sum(bp);
+  if (lane_id() == 0 && bp) atomicAdd(peakBP, bp);
+  if (threadIdx.x == 0) *nPeaks = base;
+}
+
+}  // namespace gx

@@ -1,0 +1,207 @@
+"""ctypes binding of include/genrich_amd.h (the drop-in boundary of the hot path)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgenrich_amd.so")
+
+EVENT_DTYPE = np.dtype([("chrom", "<u4"), ("start", "<u4"), ("end", "<u4"), ("count", "<u4")])
+PEAK_DTYPE = np.dtype(
+    [("chrom", "<u4"), ("start", "<u4"), ("end", "<u4"), ("summit", "<u4"),
+     ("auc", "<f4"), ("p", "<f4"), ("q", "<f4")]
+)
+GX_IV_FINAL = -1
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.c_size_t, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p),
+                           C.POINTER(C.c_size_t), C.c_void_p)
+
+
+class GxParams(C.Structure):
+    """gx_params: the peak-calling tail of runProgram's arguments (Genrich.c:5390-5395)."""
+    _fields_ = [
+        ("thr", C.c_float), ("qval_opt", C.c_int32), ("min_auc", C.c_float),
+        ("min_len", C.c_int32), ("max_gap", C.c_int32), ("device", C.c_int32),
+        ("genome_len", C.c_uint64),
+    ]
+
+
+_libm = C.CDLL("libm.so.6")
+_libm.log10f.restype = C.c_float
+_libm.log10f.argtypes = [C.c_float]
+
+
+def minus_log10f(x: float) -> float:
+    """getArgs: pqvalue = -log10f(pqvalue) (Genrich.c:5817), with the host's libm."""
+    return float(-_libm.log10f(C.c_float(x)))
+
+
+_lib = None
+
+_SIGS = {
+    "gx_create": [C.POINTER(C.c_void_p), C.POINTER(GxParams)],
+    "gx_destroy": [C.c_void_p],
+    "gx_set_chroms": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "gx_set_owned": [C.c_void_p, C.c_void_p],
+    "gx_set_collectives": [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p],
+    "gx_sample_begin": [C.c_void_p, C.c_int, C.c_void_p],
+    "gx_push_events": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_push_events_device": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_sample_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float)],
+    "gx_sample_no_control": [C.c_void_p, C.POINTER(C.c_float)],
+    "gx_pvalues": [C.c_void_p],
+    "gx_find_peaks": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "gx_get_peaks": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_interval_count": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
+    "gx_get_intervals": [C.c_void_p, C.c_int, C.c_int, C.c_size_t] + [C.c_void_p] * 5,
+    "gx_phase_times": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float))],
+}
+
+
+def load_library(path: str = LIB_PATH):
+    """Load libgenrich_amd.so and declare every entry point of include/genrich_amd.h.
+    Raises if the library or a symbol is missing -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = None if name == "gx_destroy" else C.c_int
+    lib.gx_last_error.restype = C.c_char_p
+    lib.gx_last_error.argtypes = [C.c_void_p]
+    lib.gx_strerror.restype = C.c_char_p
+    lib.gx_strerror.argtypes = [C.c_int]
+    _lib = lib
+    return lib
+
+
+class Genrich:
+    """One run of the hot path on one GPU: the call order of runProgram (Genrich.c:5386-5607)."""
+
+    def __init__(self, params: GxParams):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.lib.gx_create(C.byref(self.ctx), C.byref(params))
+        if rc != 0:
+            msg = self.lib.gx_last_error(self.ctx).decode() if self.ctx else ""
+            raise RuntimeError(f"gx_create failed ({rc}): {self.lib.gx_strerror(rc).decode()} {msg}")
+        self._keep = []
+        self.n_peaks = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"genrich_amd error {rc}: {self.lib.gx_strerror(rc).decode()} "
+                               f"[{self.lib.gx_last_error(self.ctx).decode()}]")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.gx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_chroms(self, lens, skip=None, beds=None):
+        n = len(lens)
+        self.n_chrom = n
+        lens_a = np.ascontiguousarray(lens, dtype=np.uint32)
+        skip_a = np.ascontiguousarray(skip if skip is not None else np.zeros(n), dtype=np.uint8)
+        bed_ptrs = (C.POINTER(C.c_uint32) * n)()
+        bed_len = np.zeros(n, dtype=np.int32)
+        keep = []
+        if beds is not None:
+            for i, b in enumerate(beds):
+                arr = np.ascontiguousarray(b, dtype=np.uint32).ravel()
+                keep.append(arr)
+                bed_len[i] = arr.size
+                bed_ptrs[i] = arr.ctypes.data_as(C.POINTER(C.c_uint32))
+        self._keep.append((lens_a, skip_a, keep, bed_len, bed_ptrs))
+        self._check(self.lib.gx_set_chroms(
+            self.ctx, n, lens_a.ctypes.data, skip_a.ctypes.data,
+            C.cast(bed_ptrs, C.c_void_p) if beds is not None else None,
+            bed_len.ctypes.data if beds is not None else None))
+
+    def set_owned(self, owned):
+        a = np.ascontiguousarray(owned, dtype=np.uint8)
+        self._check(self.lib.gx_set_owned(self.ctx, a.ctypes.data))
+
+    def set_collectives(self, rank, world, allreduce, allgather):
+        self._cb = (ALLREDUCE_FN(allreduce), ALLGATHER_FN(allgather))
+        self._check(self.lib.gx_set_collectives(self.ctx, rank, world, self._cb[0], self._cb[1], None))
+
+    def sample_begin(self, is_ctrl, save=None):
+        sp = None
+        if save is not None:
+            sa = np.ascontiguousarray(save, dtype=np.uint8)
+            self._keep.append(sa)
+            sp = sa.ctypes.data
+        self._check(self.lib.gx_sample_begin(self.ctx, int(is_ctrl), sp))
+
+    def push_events(self, ev):
+        ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+        self._check(self.lib.gx_push_events(self.ctx, ev.ctypes.data, len(ev)))
+
+    def push_events_device(self, dev_ptr: int, n: int):
+        """Events already resident in HBM (e.g. a torch tensor's data_ptr())."""
+        self._check(self.lib.gx_push_events_device(self.ctx, C.c_void_p(dev_ptr), n))
+
+    def sample_end(self):
+        frag, lam, fac = C.c_double(0), C.c_float(0), C.c_float(0)
+        self._check(self.lib.gx_sample_end(self.ctx, C.byref(frag), C.byref(lam), C.byref(fac)))
+        return frag.value, lam.value, fac.value
+
+    def sample_no_control(self):
+        lam = C.c_float(0)
+        self._check(self.lib.gx_sample_no_control(self.ctx, C.byref(lam)))
+        return lam.value
+
+    def pvalues(self):
+        self._check(self.lib.gx_pvalues(self.ctx))
+
+    def find_peaks(self):
+        n, g, bp = C.c_size_t(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.gx_find_peaks(self.ctx, C.byref(n), C.byref(g), C.byref(bp)))
+        self.n_peaks, self.genome_len, self.peak_bp = n.value, g.value, bp.value
+        return n.value, g.value, bp.value
+
+    def get_peaks(self):
+        out = np.zeros(self.n_peaks, dtype=PEAK_DTYPE)
+        if self.n_peaks:
+            self._check(self.lib.gx_get_peaks(self.ctx, out.ctypes.data, self.n_peaks))
+        return out
+
+    def get_intervals(self, which, chrom):
+        n = C.c_size_t(0)
+        self._check(self.lib.gx_interval_count(self.ctx, int(which), int(chrom), C.byref(n)))
+        n = n.value
+        end = np.zeros(n, dtype=np.uint32)
+        cols = {k: np.zeros(n, dtype=np.float32) for k in ("expt", "ctrl", "p", "q")}
+        if n:
+            self._check(self.lib.gx_get_intervals(
+                self.ctx, int(which), int(chrom), n, end.ctypes.data,
+                *[cols[k].ctypes.data for k in ("expt", "ctrl", "p", "q")]))
+        return end, cols
+
+    def phase_times(self):
+        names = C.c_char_p()
+        ms = C.POINTER(C.c_float)()
+        k = self.lib.gx_phase_times(self.ctx, C.byref(names), C.byref(ms))
+        out = []
+        # names are NUL-separated: walk the buffer
+        addr = C.cast(names, C.c_void_p).value
+        for i in range(k):
+            s = C.string_at(addr)
+            out.append((s.decode(), ms[i]))
+            addr += len(s) + 1
+        return out

@@ -161,6 +161,9 @@ typedef int (*gx_allgather_tab_fn)(const void* local, size_t n_local, void** out
                                    size_t* n_out, void* user);
 int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce,
                        gx_allgather_tab_fn allgather, void* user);
+/* owned[i] = 1: this rank computes chromosome i (default: all).  The full table still goes to
+ * gx_set_chroms on every rank, so genome lengths and output order are global. */
+int gx_set_owned(gx_ctx* ctx, const uint8_t* owned);
 
 /* ---- introspection used by bench.py / tests ---- */
 
