@@ -106,6 +106,8 @@ struct gx_ctx {
   gx_allreduce_i64_fn allreduce = nullptr;
   gx_allgather_tab_fn allgather = nullptr;
   void* user = nullptr;
+  // recycled device buffers (gx_reset keeps allocations alive across runs)
+  std::vector<DevBuf> pool;
   // timing
   std::vector<Phase> phases;
   std::vector<float> phaseMs;
@@ -122,6 +124,24 @@ struct gx_ctx {
   } while (0)
 
 namespace {
+
+// buffer of at least `bytes`, recycled from the context's pool when possible
+hipError_t pooled(gx_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (b.cap >= bytes) return hipSuccess;
+  if (b.p) ctx->pool.push_back(std::move(b));
+  int best = -1;
+  for (int i = 0; i < (int)ctx->pool.size(); i++)
+    if (ctx->pool[i].cap >= bytes && (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap)) best = i;
+  if (best >= 0) {
+    b = std::move(ctx->pool[best]);
+    ctx->pool.erase(ctx->pool.begin() + best);
+    return hipSuccess;
+  }
+  return b.ensure(bytes);
+}
+void recycle(gx_ctx* ctx, DevBuf& b) {
+  if (b.p) ctx->pool.push_back(std::move(b));
+}
 
 // misc device words (u32 indices into ctx->misc)
 enum { M_TICKET = 0, M_NIV = 1, M_TICKET2 = 2, M_SWCOUNT = 3, M_NPEAKS = 4, M_BHCOUNT = 5, M_ALLONE = 6,
@@ -210,10 +230,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 1) * 8));
   // an interval closes at every base with a non-zero difference (<= one per record) plus one per chromosome
   const size_t ivCap = (size_t)nRec + nChrom + 16;
-  HIPCHECK(out.ivEnd.ensure(ivCap * 4));
-  HIPCHECK(out.ivV.ensure(ivCap * 4));
-  HIPCHECK(out.tileIvOff.ensure((size_t)(nTiles + 2) * 4));
-  HIPCHECK(out.chromIvOff.ensure((size_t)(nChrom + 2) * 4));
+  HIPCHECK(pooled(ctx, out.ivEnd, ivCap * 4));
+  HIPCHECK(pooled(ctx, out.ivV, ivCap * 4));
+  HIPCHECK(pooled(ctx, out.tileIvOff, (size_t)(nTiles + 2) * 4));
+  HIPCHECK(pooled(ctx, out.chromIvOff, (size_t)(nChrom + 2) * 4));
 
   phase_begin(ctx, isCtrl ? "c.convert" : "t.convert");
   HIPCHECK(hipMemsetAsync(ctx->sbHist.p, 0, MAX_BINS * 4, s));
@@ -441,6 +461,25 @@ int gx_set_owned(gx_ctx* ctx, const uint8_t* owned) {
   return GX_OK;
 }
 
+int gx_reset(gx_ctx* ctx) {
+  if (!ctx) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  for (auto& pa : ctx->reps) {
+    recycle(ctx, pa.end); recycle(ctx, pa.p); recycle(ctx, pa.expt); recycle(ctx, pa.ctrl);
+    recycle(ctx, pa.chromOff); recycle(ctx, pa.q);
+  }
+  ctx->reps.clear();
+  ctx->sample = 0;
+  ctx->phase = 0;
+  ctx->finalIdx = -1;
+  ctx->segs.clear();
+  ctx->evCount = 0;
+  ctx->hPeaks.clear();
+  HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
+  return GX_OK;
+}
+
 int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
   if (!ctx || ctx->nChrom == 0) return GX_ERR_ORDER;
   HIPCHECK(hipSetDevice(ctx->device));
@@ -543,8 +582,8 @@ int gx_pvalues(gx_ctx* ctx) {
     // no control: the p-intervals are the treatment intervals
     const u32 n = ctx->expt.nIv;
     pa.n = n;
-    HIPCHECK(pa.p.ensure((size_t)n * 4 + 16));
-    HIPCHECK(pa.expt.ensure((size_t)n * 4 + 16));
+    HIPCHECK(pooled(ctx, pa.p, (size_t)n * 4 + 16));
+    HIPCHECK(pooled(ctx, pa.expt, (size_t)n * 4 + 16));
     phase_begin(ctx, "pval");
     hipLaunchKernelGGL(k_pval_const, dim3(std::max(1u, std::min((n + 255) / 256, 4096u))), dim3(256), 0, s,
                        ctx->expt.ivV.as<int>(), ctx->misc.as<u32>() + M_NIV, ctx->dScal.as<Scalars>(), pa.p.as<float>(),
@@ -621,7 +660,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                          ctx->bhLens.as<u64>(), D, reinterpret_cast<const u64*>(misc + M_GENOME), ctx->bhQ.as<float>(),
                          ctx->bhRaw.as<float>(), misc + M_ALLONE);
     }
-    HIPCHECK(fa.q.ensure((size_t)n * 4 + 16));
+    HIPCHECK(pooled(ctx, fa.q, (size_t)n * 4 + 16));
     hipLaunchKernelGGL(k_qlookup, dim3(gridIv), dim3(256), 0, s, fa.p.as<float>(), misc + M_NIV, ctx->bhKeys.as<u32>(),
                        ctx->bhQ.as<float>(), cap - 1, fa.q.as<float>());
     phase_end(ctx);
@@ -733,6 +772,14 @@ int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* en
     if (pa->q.p && ctx->par.qval_opt) HIPCHECK(hipMemcpy(q, pa->q.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));
     else std::fill(q, q + n, GX_SKIP);
   }
+  return GX_OK;
+}
+
+int gx_total_intervals(gx_ctx* ctx, int which, size_t* n_iv) {
+  if (!ctx || !n_iv) return GX_ERR_ORDER;
+  int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
+  if (w < 0 || w >= (int)ctx->reps.size()) return GX_ERR_ORDER;
+  *n_iv = ctx->reps[w].n;
   return GX_OK;
 }
 

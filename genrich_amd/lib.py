@@ -45,6 +45,7 @@ _lib = None
 _SIGS = {
     "gx_create": [C.POINTER(C.c_void_p), C.POINTER(GxParams)],
     "gx_destroy": [C.c_void_p],
+    "gx_reset": [C.c_void_p],
     "gx_set_chroms": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "gx_set_owned": [C.c_void_p, C.c_void_p],
     "gx_set_collectives": [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p],
@@ -56,6 +57,7 @@ _SIGS = {
     "gx_pvalues": [C.c_void_p],
     "gx_find_peaks": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "gx_get_peaks": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_total_intervals": [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)],
     "gx_interval_count": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
     "gx_get_intervals": [C.c_void_p, C.c_int, C.c_int, C.c_size_t] + [C.c_void_p] * 5,
     "gx_phase_times": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float))],
@@ -132,6 +134,9 @@ class Genrich:
             C.cast(bed_ptrs, C.c_void_p) if beds is not None else None,
             bed_len.ctypes.data if beds is not None else None))
 
+    def reset(self):
+        self._check(self.lib.gx_reset(self.ctx))
+
     def set_owned(self, owned):
         a = np.ascontiguousarray(owned, dtype=np.uint8)
         self._check(self.lib.gx_set_owned(self.ctx, a.ctypes.data))
@@ -192,6 +197,11 @@ class Genrich:
                 self.ctx, int(which), int(chrom), n, end.ctypes.data,
                 *[cols[k].ctypes.data for k in ("expt", "ctrl", "p", "q")]))
         return end, cols
+
+    def interval_total(self, which=GX_IV_FINAL):
+        n = C.c_size_t(0)
+        self._check(self.lib.gx_total_intervals(self.ctx, int(which), C.byref(n)))
+        return n.value
 
     def phase_times(self):
         names = C.c_char_p()

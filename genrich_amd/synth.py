@@ -1,0 +1,154 @@
+"""Deterministic synthetic fragment streams shaped like the workloads of BASELINE.json.
+
+Used by the tests, by tests/golden/make_golden.py (which also renders them as SAM text
+for the reference binary) and by bench.py.  Pure numpy; the same seed always gives the
+same stream.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# hg38 primary contigs, chr1..22, X, Y, M
+HG38_LENS = [
+    248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973,
+    145138636, 138394717, 133797422, 135086622, 133275309, 114364328, 107043718,
+    101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983,
+    50818468, 156040895, 57227415, 16569,
+]
+HG38_NAMES = [f"chr{i}" for i in range(1, 23)] + ["chrX", "chrY", "chrM"]
+
+EVENT_DTYPE = np.dtype(
+    [("chrom", "<u4"), ("start", "<u4"), ("end", "<u4"), ("count", "<u4")]
+)
+
+
+def make_fragments(
+    lens,
+    n_frag,
+    seed,
+    peak_every=50_000,
+    tower_every=5_000_000,
+    frac_peak=0.31,
+    frac_tower=0.02,
+    uniform_only=False,
+    min_len=100,
+):
+    """Fragments (chrom, start, end) on chromosomes of the given lengths.
+
+    Shape follows SURVEY.md 8(d): chromosome chosen in proportion to its length;
+    fragment length = min_len + U[0,100) + U[0,100) (triangular); 67 % uniform positions,
+    31 % within +-150 bp of a peak centre every `peak_every` bp, 2 % in towers every
+    `tower_every` bp.  Returns a structured array with count = 1.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens = np.asarray(lens, dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    g = rng.integers(0, cum[-1], size=n_frag, dtype=np.int64)
+    chrom = np.searchsorted(cum, g, side="right") - 1
+    pos = g - cum[chrom]
+    flen = min_len + rng.integers(0, 100, size=n_frag) + rng.integers(0, 100, size=n_frag)
+    if not uniform_only:
+        u = rng.random(n_frag)
+        jitter = rng.integers(-150, 151, size=n_frag)
+        is_peak = u < frac_peak
+        is_tower = (u >= frac_peak) & (u < frac_peak + frac_tower)
+        centre_p = (pos // peak_every) * peak_every + peak_every // 2
+        centre_t = (pos // tower_every) * tower_every + tower_every // 2
+        pos = np.where(is_peak, centre_p + jitter - flen // 2, pos)
+        pos = np.where(is_tower, centre_t + jitter // 3 - flen // 2, pos)
+    clen = lens[chrom]
+    flen = np.minimum(flen, clen)  # tiny chromosomes
+    pos = np.clip(pos, 0, clen - flen)
+    ev = np.empty(n_frag, dtype=EVENT_DTYPE)
+    ev["chrom"] = chrom
+    ev["start"] = pos
+    ev["end"] = pos + flen
+    ev["count"] = 1
+    return ev
+
+
+def add_multimap(ev, lens, frac, seed):
+    """Replace a fraction of fragments by k equally-scored copies (k in 2,3,4,5,6,8,10) at
+    random loci with weight 1/k (the -s fractional-pileup path, Genrich.c:3122-3176)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens = np.asarray(lens, dtype=np.int64)
+    n = len(ev)
+    pick = rng.random(n) < frac
+    keep = ev[~pick]
+    multi = ev[pick]
+    ks = rng.choice(np.array([2, 3, 4, 5, 6, 8, 10]), size=len(multi))
+    rep = np.repeat(np.arange(len(multi)), ks)
+    out = multi[rep].copy()
+    out["count"] = np.repeat(ks, ks)
+    flen = (out["end"] - out["start"]).astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    g = rng.integers(0, cum[-1], size=len(out), dtype=np.int64)
+    chrom = np.searchsorted(cum, g, side="right") - 1
+    pos = g - cum[chrom]
+    clen = lens[chrom]
+    flen = np.minimum(flen, clen)
+    pos = np.clip(pos, 0, clen - flen)
+    # the first copy of each read stays where it was
+    first = np.concatenate([[True], rep[1:] != rep[:-1]])
+    out["chrom"] = np.where(first, out["chrom"], chrom)
+    out["start"] = np.where(first, out["start"], pos)
+    out["end"] = np.where(first, out["end"], pos + flen)
+    fix = out["end"] > lens[out["chrom"]]
+    out["end"] = np.where(fix, lens[out["chrom"]], out["end"])
+    return np.concatenate([keep, out])
+
+
+def atac_events(ev, lens, d=100, adj=True):
+    """ATAC-seq mode geometry (saveFragAtac, Genrich.c:2728-2749; -d halves 5796-5797):
+    each fragment becomes one or two cut-site intervals, clamped like saveInterval."""
+    lens = np.asarray(lens, dtype=np.int64)
+    len3 = int(np.float32(d) / np.float32(2.0) + np.float32(0.5))
+    len5 = d // 2
+    s = ev["start"].astype(np.int64)
+    e = ev["end"].astype(np.int64)
+    if adj:
+        s = s + 5
+        e = e - 5
+    one = (s + len3) >= (e - len3)
+    clen = lens[ev["chrom"]]
+
+    def clamp(a, b, c):
+        a = np.maximum(a, 0)
+        b = np.minimum(b, c)
+        return a, b
+
+    a1, b1 = clamp(s - len5, np.where(one, e + len5, s + len3), clen)
+    a2, b2 = clamp(e - len3, e + len5, clen)
+    first = np.empty(len(ev), dtype=EVENT_DTYPE)
+    first["chrom"], first["start"], first["end"], first["count"] = ev["chrom"], a1, b1, ev["count"]
+    second = np.empty(int((~one).sum()), dtype=EVENT_DTYPE)
+    m = ~one
+    second["chrom"], second["start"], second["end"], second["count"] = (
+        ev["chrom"][m], a2[m], b2[m], ev["count"][m])
+    out = np.concatenate([first, second])
+    return out[out["start"] < lens[out["chrom"]]]
+
+
+def write_sam(path, names, lens, ev, read_len=50, name_prefix="r"):
+    """Render fragments as queryname-grouped paired SAM records (flags 99/147, +256 for the
+    2nd..kth alignment of a multimapped read; consecutive events with count = k > 1 are the
+    k alignments of one read, as add_multimap lays them out)."""
+    with open(path, "w") as f:
+        f.write("@HD\tVN:1.0\tSO:queryname\n")
+        for n, l in zip(names, lens):
+            f.write(f"@SQ\tSN:{n}\tLN:{l}\n")
+        i = 0
+        rid = 0
+        n = len(ev)
+        while i < n:
+            k = int(ev["count"][i])
+            for a in range(k):
+                c, s, e = int(ev["chrom"][i + a]), int(ev["start"][i + a]), int(ev["end"][i + a])
+                rl = min(read_len, e - s)
+                sec = 256 if a else 0
+                p1, p2 = s + 1, e - rl + 1
+                nm = f"{name_prefix}{rid}"
+                f.write(f"{nm}\t{99 + sec}\t{names[c]}\t{p1}\t30\t{rl}M\t=\t{p2}\t{e - s}\t*\t*\tAS:i:0\n")
+                f.write(f"{nm}\t{147 + sec}\t{names[c]}\t{p2}\t30\t{rl}M\t=\t{p1}\t{-(e - s)}\t*\t*\tAS:i:0\n")
+            i += k
+            rid += 1

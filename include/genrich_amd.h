@@ -92,6 +92,9 @@ typedef struct gx_ctx gx_ctx;
 
 int gx_create(gx_ctx** ctx, const gx_params* params);
 void gx_destroy(gx_ctx* ctx);
+/* Forget all replicates and results but keep the chromosome table and device buffers
+ * (a fresh run without re-allocating; what the reference does by exiting the process). */
+int gx_reset(gx_ctx* ctx);
 const char* gx_last_error(const gx_ctx* ctx);
 const char* gx_strerror(int status); /* the reference's errMsg text, Genrich.h:107-154 */
 
@@ -143,6 +146,7 @@ int gx_get_peaks(gx_ctx* ctx, gx_peak* out, size_t cap);
  * (only meaningful for a single replicate, as in the reference), p[], q[]. */
 #define GX_IV_FINAL (-1)
 int gx_interval_count(gx_ctx* ctx, int which, int chrom, size_t* n_iv);
+int gx_total_intervals(gx_ctx* ctx, int which, size_t* n_iv); /* over all chromosomes */
 int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* end,
                      float* expt, float* ctrl, float* p, float* q);
 

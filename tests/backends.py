@@ -8,39 +8,19 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libgenrich_oracle.so")
 REF_BIN = os.path.join(ORACLE_DIR, "_ref", "Genrich")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libgenrich_ref.so")
 
-EVENT_DTYPE = np.dtype([("chrom", "<u4"), ("start", "<u4"), ("end", "<u4"), ("count", "<u4")])
-PEAK_DTYPE = np.dtype(
-    [("chrom", "<u4"), ("start", "<u4"), ("end", "<u4"), ("summit", "<u4"),
-     ("auc", "<f4"), ("p", "<f4"), ("q", "<f4")]
-)
-
-
-class GxParams(C.Structure):
-    _fields_ = [
-        ("thr", C.c_float), ("qval_opt", C.c_int32), ("min_auc", C.c_float),
-        ("min_len", C.c_int32), ("max_gap", C.c_int32), ("device", C.c_int32),
-        ("genome_len", C.c_uint64),
-    ]
-
-
-_libm = C.CDLL("libm.so.6")
-_libm.log10f.restype = C.c_float
-_libm.log10f.argtypes = [C.c_float]
-
-
-def minus_log10f(x: float) -> float:
-    """getArgs' `pqvalue = -log10f(pqvalue)` (Genrich.c:5817): the host's libm log10f
-    (numpy's float32 log10 rounds differently, e.g. for 0.01f)."""
-    return float(-_libm.log10f(C.c_float(x)))
+# shared POD definitions come from the product's binding of include/genrich_amd.h
+from genrich_amd.lib import EVENT_DTYPE, PEAK_DTYPE, GxParams, minus_log10f  # noqa: E402,F401
 
 
 def make_params(pq=0.01, qval=False, min_auc=200.0, min_len=0, max_gap=100, genome_len=0,
