@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "gx_stats.h"
+#include "gx_merge.h"
 
 using namespace gx;
 
@@ -53,7 +53,7 @@ struct Pileup {  // run-length pileup of one sample (treatment or control)
 };
 
 struct PArray {  // p-value intervals of one replicate (or the Fisher combination)
-  DevBuf end, p, expt, ctrl, chromOff, q;
+  DevBuf end, p, expt, ctrl, chromOff, tileOff, q, dPresent;
   u32 n = 0;
   bool hasPiles = false;  // expt/ctrl filled (single-replicate logging)
   float ctrlConst = 0.0f; // control value when ctrl is not materialised (no -E, no control file)
@@ -98,7 +98,7 @@ struct gx_ctx {
   // BH
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp;
   // sweep
-  DevBuf swChrom, swStart, swEnd, swP, swQ, swSig, cand, valid, peaks, lb2;
+  DevBuf swChrom, swStart, swEnd, swP, swQ, swSig, cand, valid, peaks, lb2, headPos;
   std::vector<gx_peak> hPeaks;
   uint64_t genomeLenUsed = 0, peakBP = 0;
   // collectives
@@ -145,7 +145,8 @@ void recycle(gx_ctx* ctx, DevBuf& b) {
 
 // misc device words (u32 indices into ctx->misc)
 enum { M_TICKET = 0, M_NIV = 1, M_TICKET2 = 2, M_SWCOUNT = 3, M_NPEAKS = 4, M_BHCOUNT = 5, M_ALLONE = 6,
-       M_PEAKBP = 8 /* u64 */, M_GENOME = 10 /* u64 */, M_WORDS = 16 };
+       M_PEAKBP = 8 /* u64 */, M_GENOME = 10 /* u64 */, M_TICKET3 = 12, M_TICKET4 = 13, M_NHEADS = 14,
+       M_NMERGED = 15, M_WORDS = 32 };
 
 void phase_begin(gx_ctx* ctx, const char* name) {
   Phase ph;
@@ -467,7 +468,7 @@ int gx_reset(gx_ctx* ctx) {
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   for (auto& pa : ctx->reps) {
     recycle(ctx, pa.end); recycle(ctx, pa.p); recycle(ctx, pa.expt); recycle(ctx, pa.ctrl);
-    recycle(ctx, pa.chromOff); recycle(ctx, pa.q);
+    recycle(ctx, pa.chromOff); recycle(ctx, pa.q); recycle(ctx, pa.tileOff); recycle(ctx, pa.dPresent);
   }
   ctx->reps.clear();
   ctx->sample = 0;
@@ -554,8 +555,6 @@ int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor) {
     rc = finish_scalars(ctx, 1);
     if (rc) return rc;
     ctx->phase = 4;
-    ctx->err = "control samples are not implemented yet";
-    return GX_ERR_ORDER;
   } else
     return GX_ERR_ORDER;
   if (frag_len) *frag_len = ctx->hScal.fragLen;
@@ -592,12 +591,44 @@ int gx_pvalues(gx_ctx* ctx) {
     HIPCHECK(hipGetLastError());
     pa.end = std::move(ctx->expt.ivEnd);
     pa.chromOff = std::move(ctx->expt.chromIvOff);
+    pa.tileOff = std::move(ctx->expt.tileIvOff);
     pa.hasPiles = true;
     pa.ctrlIsConst = true;
     pa.ctrlConst = ctx->hScal.lambda;
   } else {
-    ctx->err = "control samples are not implemented yet";
-    return GX_ERR_ORDER;
+    // treatment + control: tile-local union of breakpoints (savePval 1768-1791)
+    const u32 nTiles = ctx->nTiles, nChrom = ctx->nChrom;
+    const size_t cap = (size_t)ctx->expt.nIv + ctx->ctrl.nIv + 16;
+    HIPCHECK(pooled(ctx, pa.end, cap * 4));
+    HIPCHECK(pooled(ctx, pa.expt, cap * 4));
+    HIPCHECK(pooled(ctx, pa.ctrl, cap * 4));
+    HIPCHECK(pooled(ctx, pa.p, cap * 4));
+    HIPCHECK(pooled(ctx, pa.tileOff, (size_t)(nTiles + 2) * 4));
+    HIPCHECK(pooled(ctx, pa.chromOff, (size_t)(nChrom + 2) * 4));
+    u32* misc = ctx->misc.as<u32>();
+    phase_begin(ctx, "merge");
+    HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 1) * 8, s));
+    HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
+    RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>()};
+    RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>()};
+    Merge2Out mo{pa.end.as<u32>(), pa.expt.as<float>(), pa.ctrl.as<float>(), pa.tileOff.as<u32>(),
+                 pa.chromOff.as<u32>(), misc + M_NMERGED};
+    hipLaunchKernelGGL(k_merge2, dim3(std::min(nTiles, 2048u)), dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(),
+                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, misc + M_TICKET, ctx->lb.as<u64>(), mo,
+                       ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, pa.chromOff.as<u32>(),
+                       misc + M_NMERGED);
+    phase_end(ctx);
+    phase_begin(ctx, "pval");
+    hipLaunchKernelGGL(k_pval_pairs, dim3(4096), dim3(256), 0, s, pa.expt.as<float>(), pa.ctrl.as<float>(),
+                       misc + M_NMERGED, pa.p.as<float>());
+    phase_end(ctx);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(&pa.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
+    int rc = read_status(ctx);
+    if (rc) return rc;
+    pa.hasPiles = true;
+    pa.ctrlIsConst = false;
   }
   ctx->reps.push_back(std::move(pa));
   ctx->sample++;
@@ -609,14 +640,54 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   if (!ctx || ctx->phase != 0 || ctx->sample < 1) return GX_ERR_ORDER;
   HIPCHECK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  if (ctx->sample > 1) {
-    ctx->err = "replicates are not implemented yet";
-    return GX_ERR_ORDER;
+  u32* misc = ctx->misc.as<u32>();
+  if (ctx->sample > 1 && (int)ctx->reps.size() == ctx->sample) {
+    // combinePval (612-667): union of all replicates' breakpoints, Fisher's method per interval
+    const int nr = ctx->sample;
+    if (nr > MAX_REPS) {
+      ctx->err = "more than 32 replicates are not supported";
+      return GX_ERR_DF;
+    }
+    const u32 nTiles = ctx->nTiles, nChrom = ctx->nChrom;
+    PArray comb;
+    comb.present.assign(nChrom, 0);
+    size_t cap = nChrom + 16;
+    RepSet S{};
+    S.n = nr;
+    for (int r = 0; r < nr; r++) {
+      PArray& pa = ctx->reps[r];
+      HIPCHECK(pooled(ctx, pa.dPresent, nChrom + 16));
+      HIPCHECK(hipMemcpyAsync(pa.dPresent.p, pa.present.data(), nChrom, hipMemcpyHostToDevice, s));
+      for (u32 i = 0; i < nChrom; i++) comb.present[i] |= pa.present[i];
+      cap += pa.n;
+      S.r[r] = RepIn{pa.end.as<u32>(), pa.p.as<float>(), pa.tileOff.as<u32>(), pa.dPresent.as<uint8_t>()};
+    }
+    HIPCHECK(pooled(ctx, comb.end, cap * 4));
+    HIPCHECK(pooled(ctx, comb.p, cap * 4));
+    HIPCHECK(pooled(ctx, comb.tileOff, (size_t)(nTiles + 2) * 4));
+    HIPCHECK(pooled(ctx, comb.chromOff, (size_t)(nChrom + 2) * 4));
+    phase_begin(ctx, "fisher");
+    HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 1) * 8, s));
+    HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
+    MergeNOut mo{comb.end.as<u32>(), comb.p.as<float>(), comb.tileOff.as<u32>(), comb.chromOff.as<u32>(),
+                 misc + M_NMERGED};
+    const size_t lds = (size_t)nr * MG_WORDS * 4;
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, 2048u)), dim3(MG_NT), lds, s, S, ctx->dTileChrom.as<u32>(),
+                       ctx->dChrom.as<DChrom>(), nTiles, misc + M_TICKET, ctx->lb.as<u64>(), mo, ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, comb.chromOff.as<u32>(),
+                       misc + M_NMERGED);
+    phase_end(ctx);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(&comb.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
+    int rc = read_status(ctx);
+    if (rc) return rc;
+    ctx->reps.push_back(std::move(comb));
   }
   ctx->finalIdx = (int)ctx->reps.size() - 1;
   PArray& fa = ctx->reps[ctx->finalIdx];
   const u32 n = fa.n, nChrom = ctx->nChrom;
-  u32* misc = ctx->misc.as<u32>();
   // genome length (findPeaks 1091-1101)
   uint64_t g = ctx->par.genome_len;
   const bool genomeOpt = g == 0;
@@ -669,39 +740,62 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
 
   // peak sweep
   phase_begin(ctx, "sweep");
-  const size_t mCap = (size_t)n + 16;
-  HIPCHECK(ctx->swChrom.ensure(mCap * 4));
-  HIPCHECK(ctx->swStart.ensure(mCap * 4));
-  HIPCHECK(ctx->swEnd.ensure(mCap * 4));
-  HIPCHECK(ctx->swP.ensure(mCap * 4));
-  HIPCHECK(ctx->swQ.ensure(mCap * 4));
-  HIPCHECK(ctx->swSig.ensure(mCap * 4));
-  const u32 nBlocks = (n + SW_CHUNK - 1) / SW_CHUNK;
-  HIPCHECK(ctx->lb2.ensure((size_t)(nBlocks + 1) * 8));
-  HIPCHECK(hipMemsetAsync(ctx->lb2.p, 0, (size_t)(nBlocks + 1) * 8, s));
+  const u32 nChunks = (n + SW_CHUNK - 1) / SW_CHUNK;
+  // three look-back arrays: compact (<= nChunks), heads (<= nChunks), peaks (<= M/256 + 1, M <= n)
+  const size_t lbWords = (size_t)nChunks * 2 + (size_t)n / SW_NT + 8;
+  HIPCHECK(ctx->lb2.ensure(lbWords * 8));
+  HIPCHECK(hipMemsetAsync(ctx->lb2.p, 0, lbWords * 8, s));
   HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 12, s));  // ticket2, swcount, npeaks
   HIPCHECK(hipMemsetAsync(misc + M_PEAKBP, 0, 8, s));
-  SweepList L{ctx->swChrom.as<u32>(), ctx->swStart.as<u32>(), ctx->swEnd.as<u32>(), ctx->swP.as<float>(),
-              ctx->swQ.as<float>(), ctx->swSig.as<u32>(), misc + M_SWCOUNT};
-  if (nBlocks)
-    hipLaunchKernelGGL(k_sweep_compact, dim3(nBlocks), dim3(SW_NT), 0, s, fa.end.as<u32>(), fa.p.as<float>(),
-                       ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr, fa.chromOff.as<u32>(), nChrom,
-                       misc + M_NIV, ctx->par.thr, misc + M_TICKET2, ctx->lb2.as<u64>(), L, ctx->dStatus.as<u32>());
-  u32 M = 0;
-  HIPCHECK(hipMemcpyAsync(&M, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
-  u32 nPeaks = 0;
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET3, 0, 12, s));  // ticket3, ticket4, nheads
+  // entries kept by the compaction are a small fraction of the intervals; start from a guess and
+  // regrow in the (rare) case the device reports more
+  size_t mCap = std::max<size_t>(ctx->swChrom.cap / 4, (size_t)n / 8 + 1024);
+  u32 M = 0, nPeaks = 0;
   ctx->peakBP = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    HIPCHECK(ctx->swChrom.ensure(mCap * 4));
+    HIPCHECK(ctx->swStart.ensure(mCap * 4));
+    HIPCHECK(ctx->swEnd.ensure(mCap * 4));
+    HIPCHECK(ctx->swP.ensure(mCap * 4));
+    HIPCHECK(ctx->swQ.ensure(mCap * 4));
+    HIPCHECK(ctx->swSig.ensure(mCap * 4));
+    mCap = ctx->swChrom.cap / 4;
+    SweepList L{ctx->swChrom.as<u32>(), ctx->swStart.as<u32>(), ctx->swEnd.as<u32>(), ctx->swP.as<float>(),
+                ctx->swQ.as<float>(), ctx->swSig.as<u32>(), misc + M_SWCOUNT};
+    // count first (cap = 0 writes nothing) would cost a second pass; instead the kernel bounds its
+    // writes by the capacity and always reports the true count
+    hipLaunchKernelGGL(k_sweep_compact, dim3(std::max(1u, std::min(nChunks, 1024u))), dim3(SW_NT), 0, s,
+                       fa.end.as<u32>(), fa.p.as<float>(), ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr,
+                       fa.chromOff.as<u32>(), nChrom, misc + M_NIV, ctx->par.thr, misc + M_TICKET2, ctx->lb2.as<u64>(), L,
+                       (u32)std::min<size_t>(mCap, 0xFFFFFFFFu), ctx->dStatus.as<u32>());
+    HIPCHECK(hipMemcpyAsync(&M, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (M <= mCap) break;
+    mCap = (size_t)M + M / 8 + 1024;  // redo with room for everything
+    HIPCHECK(hipMemsetAsync(ctx->lb2.p, 0, lbWords * 8, s));
+    HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 8, s));
+  }
   if (M) {
+    SweepList L{ctx->swChrom.as<u32>(), ctx->swStart.as<u32>(), ctx->swEnd.as<u32>(), ctx->swP.as<float>(),
+                ctx->swQ.as<float>(), ctx->swSig.as<u32>(), misc + M_SWCOUNT};
+    // heads <= significant entries; candidates and peaks <= heads
+    HIPCHECK(ctx->headPos.ensure((size_t)M * 4 + 16));
     HIPCHECK(ctx->cand.ensure((size_t)M * sizeof(gx_peak)));
-    HIPCHECK(ctx->valid.ensure((size_t)M * 4));
+    HIPCHECK(ctx->valid.ensure((size_t)M * 4 + 16));
     HIPCHECK(ctx->peaks.ensure((size_t)M * sizeof(gx_peak)));
-    hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((M + 255) / 256, 2048u))), dim3(256), 0, s, L,
-                       ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->par.max_gap, ctx->cand.as<gx_peak>(),
-                       ctx->valid.as<u32>());
-    hipLaunchKernelGGL(k_peak_compact, dim3(1), dim3(1024), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
-                       misc + M_SWCOUNT, ctx->peaks.as<gx_peak>(), misc + M_NPEAKS,
-                       reinterpret_cast<u64*>(misc + M_PEAKBP));
+    u64* lbHeads = ctx->lb2.as<u64>() + nChunks;
+    u64* lbPeaks = ctx->lb2.as<u64>() + 2 * (size_t)nChunks;
+    const u32 mChunks = (M + SW_CHUNK - 1) / SW_CHUNK;
+    hipLaunchKernelGGL(k_sweep_heads, dim3(std::min(mChunks, 1024u)), dim3(SW_NT), 0, s, L, ctx->par.max_gap,
+                       misc + M_TICKET3, lbHeads, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((M + 3) / 4, 4096u))), dim3(256), 0, s, L,
+                       ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
+                       ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
+    hipLaunchKernelGGL(k_peak_compact, dim3(std::max(1u, std::min((M + SW_NT - 1) / SW_NT, 1024u))), dim3(SW_NT), 0, s,
+                       ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(), misc + M_NHEADS, misc + M_TICKET4, lbPeaks,
+                       ctx->peaks.as<gx_peak>(), misc + M_NPEAKS, reinterpret_cast<u64*>(misc + M_PEAKBP),
+                       ctx->dStatus.as<u32>());
     HIPCHECK(hipMemcpyAsync(&nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(&ctx->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));

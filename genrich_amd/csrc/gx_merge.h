@@ -1,0 +1,277 @@
+// gx_merge.h -- interval merges done tile by tile with LDS bitmaps (gfx950).
+//
+//  k_merge2 : savePval's two-pointer merge of the treatment and control pileups
+//             (Genrich.c:1768-1791) together with savePileupCtrl's value rule
+//             net = max(factor * val, lambda) and its "break only where net changes"
+//             run-length rule (2107-2127).
+//  k_mergeN : combinePval's union of all replicates' breakpoints (612-667) + multPval (567-583).
+//
+// Both run-length inputs were produced tile by tile, so "the intervals that end inside tile t"
+// are a contiguous slice [tileOff[t], tileOff[t+1]).  A tile's breakpoints are set as bits of a
+// 2^TB-bit LDS bitmap per input; the union is a bitwise OR; an input's covering interval at
+// a union breakpoint j is slice_begin + popcount(bits before j).  Output positions again come
+// from the decoupled look-back.
+#pragma once
+#include "gx_stats.h"
+
+namespace gx {
+
+constexpr int MG_NT = 256;
+constexpr int MG_WORDS = TILE / 32;        // 512 bitmap words per input
+constexpr int MG_WPT = MG_WORDS / MG_NT;   // 2 consecutive words per thread
+
+struct RleIn {   // run-length pileup from k_tile
+  const u32* end;
+  const int* v;
+  const u32* tileOff;
+};
+
+struct Merge2Out {
+  u32* end;
+  float* expt;
+  float* ctrl;
+  u32* tileOff;   // [nTiles+1]
+  u32* chromOff;  // [nChrom+1]
+  u32* n;
+};
+
+__device__ __forceinline__ float ctrl_net(int v, float factor, float lambda, bool* neg) {
+  float val = factor * getval(v, neg);  // 2107 / 2118: float product
+  return val > lambda ? val : lambda;   // MAX(val, lambda)
+}
+
+__global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalars* __restrict__ sc,
+                                                  const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+                                                  u32 nTiles, u32* __restrict__ ticket, u64* __restrict__ lb,
+                                                  Merge2Out out, u32* __restrict__ st) {
+  __shared__ u32 bmA[MG_WORDS], bmB[MG_WORDS], bmC[MG_WORDS];
+  __shared__ u32 scratch[8];
+  __shared__ u32 s_id, s_base;
+  const float factor = sc->factor, lambda = sc->lambda;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
+    for (int i = threadIdx.x; i < MG_WORDS; i += MG_NT) { bmA[i] = 0; bmB[i] = 0; bmC[i] = 0; }
+    __syncthreads();
+    const u32 t = s_id;
+    if (t >= nTiles) return;
+    const u32 ci = tileChrom[t];
+    const DChrom c = chroms[ci];
+    const bool active = chrom_active(c);
+    const u32 tl = t - c.tileBase, pos0 = tl << TB;
+    const bool lastTile = tl + 1 == c.nTiles;
+    u32 a0 = A.tileOff[t], a1 = A.tileOff[t + 1], b0 = B.tileOff[t], b1 = B.tileOff[t + 1];
+    if (!active) { a1 = a0; b1 = b0; }
+    const u32 a1c = (lastTile && a1 > a0) ? a1 - 1 : a1;  // the chromosome-closing interval is handled apart
+    const u32 b1c = (lastTile && b1 > b0) ? b1 - 1 : b1;
+    u32 neg = 0;
+    for (u32 i = a0 + threadIdx.x; i < a1c; i += MG_NT) {
+      u32 off = A.end[i] - pos0;
+      atomicOr(&bmA[off >> 5], 1u << (off & 31));
+    }
+    for (u32 i = b0 + threadIdx.x; i < b1c; i += MG_NT) {
+      u32 off = B.end[i] - pos0;
+      bool ng1, ng2;
+      float here = ctrl_net(B.v[i], factor, lambda, &ng1);
+      float next = ctrl_net(B.v[i + 1], factor, lambda, &ng2);  // i + 1 exists: at least the closing interval
+      neg |= ng1 | ng2;
+      atomicOr(&bmC[off >> 5], 1u << (off & 31));
+      if (here != next) atomicOr(&bmB[off >> 5], 1u << (off & 31));  // 2122: net != MAX(val, lambda)
+    }
+    __syncthreads();
+    u32 wU[MG_WPT], wA[MG_WPT], wC[MG_WPT];
+    u32 cU = 0, cA = 0, cC = 0;
+#pragma unroll
+    for (int k = 0; k < MG_WPT; k++) {
+      int w = threadIdx.x * MG_WPT + k;
+      wA[k] = bmA[w];
+      wC[k] = bmC[w];
+      wU[k] = wA[k] | bmB[w];
+      cU += __popc(wU[k]);
+      cA += __popc(wA[k]);
+      cC += __popc(wC[k]);
+    }
+    u32 tU, tA, tC;
+    u32 exU = block_excl_scan<u32, MG_NT>(cU, scratch, &tU);
+    u32 exA = block_excl_scan<u32, MG_NT>(cA, scratch, &tA);
+    u32 exC = block_excl_scan<u32, MG_NT>(cC, scratch, &tC);
+    const u32 tileCount = active ? tU + (lastTile ? 1u : 0u) : 0u;
+    if (threadIdx.x < 64) {
+      u64 excl = lookback_excl(lb, t, (u64)tileCount, st);
+      if (threadIdx.x == 0) {
+        s_base = (u32)excl;
+        out.tileOff[t] = (u32)excl;
+        if (tl == 0) out.chromOff[ci] = (u32)excl;
+        if (t == nTiles - 1) {
+          out.tileOff[nTiles] = (u32)(excl + tileCount);
+          *out.n = (u32)(excl + tileCount);
+        }
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    u32 o = s_base + exU;
+#pragma unroll
+    for (int k = 0; k < MG_WPT; k++) {
+      u32 bits = wU[k];
+      while (bits) {
+        int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        u32 below = (1u << b) - 1;
+        u32 ia = a0 + exA + __popc(wA[k] & below);
+        u32 ic = b0 + exC + __popc(wC[k] & below);
+        bool ng1, ng2;
+        out.end[o] = pos0 + (threadIdx.x * MG_WPT + k) * 32 + b;
+        out.expt[o] = getval(A.v[ia], &ng1);
+        out.ctrl[o] = ctrl_net(B.v[ic], factor, lambda, &ng2);
+        neg |= ng1 | ng2;
+        o++;
+      }
+      exA += __popc(wA[k]);
+      exC += __popc(wC[k]);
+    }
+    if (lastTile && threadIdx.x == 0) {  // 1779-1788 at the chromosome end: both pileups close at len
+      bool ng1, ng2;
+      u32 oc = s_base + tU;
+      out.end[oc] = c.len;
+      out.expt[oc] = getval(A.v[a1 - 1], &ng1);
+      out.ctrl[oc] = ctrl_net(B.v[b1 - 1], factor, lambda, &ng2);
+      neg |= ng1 | ng2;
+    }
+    if (neg) atomicOr(st, ST_NEG_PILE);
+  }
+}
+
+// p-values of (treatment, control) pairs: calcPval (1628-1653), elementwise
+__global__ __launch_bounds__(256) void k_pval_pairs(const float* __restrict__ expt, const float* __restrict__ ctrl,
+                                                    const u32* __restrict__ nPtr, float* __restrict__ p) {
+  const u32 n = *nPtr;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = calc_pval(expt[i], ctrl[i]);
+}
+
+// ---- Fisher combination over replicates ---------------------------------------------------------
+constexpr int MAX_REPS = 32;
+
+struct RepIn {
+  const u32* end;
+  const float* p;
+  const u32* tileOff;
+  const uint8_t* present;  // per chromosome: this replicate has p-values there (pval[j] != NULL)
+};
+struct RepSet {
+  RepIn r[MAX_REPS];
+  int n;
+};
+struct MergeNOut {
+  u32* end;
+  float* p;
+  u32* tileOff;
+  u32* chromOff;
+  u32* n;
+};
+
+__global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restrict__ tileChrom,
+                                                  const DChrom* __restrict__ chroms, u32 nTiles,
+                                                  u32* __restrict__ ticket, u64* __restrict__ lb, MergeNOut out,
+                                                  u32* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) u32 bm[];  // S.n bitmaps of MG_WORDS words
+  __shared__ u32 scratch[8];
+  __shared__ u32 s_id, s_base;
+  const int n = S.n;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
+    for (int i = threadIdx.x; i < n * MG_WORDS; i += MG_NT) bm[i] = 0;
+    __syncthreads();
+    const u32 t = s_id;
+    if (t >= nTiles) return;
+    const u32 ci = tileChrom[t];
+    const DChrom c = chroms[ci];
+    const u32 tl = t - c.tileBase, pos0 = tl << TB;
+    const bool lastTile = tl + 1 == c.nTiles;
+    bool any = false;
+    for (int r = 0; r < n; r++) {
+      if (!S.r[r].present[ci]) continue;
+      any = true;
+      u32 a0 = S.r[r].tileOff[t], a1 = S.r[r].tileOff[t + 1];
+      u32 a1c = (lastTile && a1 > a0) ? a1 - 1 : a1;
+      for (u32 i = a0 + threadIdx.x; i < a1c; i += MG_NT) {
+        u32 off = S.r[r].end[i] - pos0;
+        atomicOr(&bm[r * MG_WORDS + (off >> 5)], 1u << (off & 31));
+      }
+    }
+    __syncthreads();
+    u32 wU[MG_WPT] = {0, 0};
+    u32 cU = 0;
+#pragma unroll
+    for (int k = 0; k < MG_WPT; k++) {
+      int w = threadIdx.x * MG_WPT + k;
+      for (int r = 0; r < n; r++) wU[k] |= bm[r * MG_WORDS + w];
+      cU += __popc(wU[k]);
+    }
+    u32 tU;
+    u32 exU = block_excl_scan<u32, MG_NT>(cU, scratch, &tU);
+    // per replicate: intervals ending before this thread's first word (rank base)
+    u32 exR[MAX_REPS];
+    for (int r = 0; r < n; r++) {
+      u32 cr = 0;
+#pragma unroll
+      for (int k = 0; k < MG_WPT; k++) cr += __popc(bm[r * MG_WORDS + threadIdx.x * MG_WPT + k]);
+      u32 tr;
+      exR[r] = block_excl_scan<u32, MG_NT>(cr, scratch, &tr);
+    }
+    const u32 tileCount = any ? tU + (lastTile ? 1u : 0u) : 0u;
+    if (threadIdx.x < 64) {
+      u64 excl = lookback_excl(lb, t, (u64)tileCount, st);
+      if (threadIdx.x == 0) {
+        s_base = (u32)excl;
+        out.tileOff[t] = (u32)excl;
+        if (tl == 0) out.chromOff[ci] = (u32)excl;
+        if (t == nTiles - 1) {
+          out.tileOff[nTiles] = (u32)(excl + tileCount);
+          *out.n = (u32)(excl + tileCount);
+        }
+      }
+    }
+    __syncthreads();
+    if (!any) continue;
+    u32 o = s_base + exU;
+#pragma unroll
+    for (int k = 0; k < MG_WPT; k++) {
+      const int w = threadIdx.x * MG_WPT + k;
+      u32 bits = wU[k];
+      while (bits) {
+        int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        u32 below = (1u << b) - 1;
+        double sum = 0.0;
+        int df = 0;
+        for (int r = 0; r < n; r++) {  // multPval 570-574, replicate order
+          if (!S.r[r].present[ci]) continue;
+          u32 idx = S.r[r].tileOff[t] + exR[r] + __popc(bm[r * MG_WORDS + w] & below);
+          float pv = S.r[r].p[idx];
+          if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
+        }
+        if (df > 400) atomicOr(st, ST_BAD_DF);
+        out.end[o] = pos0 + w * 32 + b;
+        out.p[o] = fisher_combine(sum, df);
+        o++;
+      }
+      for (int r = 0; r < n; r++) exR[r] += __popc(bm[r * MG_WORDS + w]);
+    }
+    if (lastTile && threadIdx.x == 0) {
+      double sum = 0.0;
+      int df = 0;
+      for (int r = 0; r < n; r++) {
+        if (!S.r[r].present[ci]) continue;
+        float pv = S.r[r].p[S.r[r].tileOff[t + 1] - 1];
+        if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
+      }
+      u32 oc = s_base + tU;
+      out.end[oc] = c.len;
+      out.p[oc] = fisher_combine(sum, df);
+    }
+  }
+}
+
+}  // namespace gx

@@ -211,9 +211,15 @@ __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, co
 // ---- peak sweep: callPeaks (977-1069) ---------------------------------------------------------
 // Only significant intervals (pq > thr, strict, 1015) and SKIP intervals matter: two significant
 // intervals belong to one candidate iff no SKIP interval lies between them and
-// start_next - end_prev <= maxGap (1031-1032).  Pass 1 compacts those intervals in order
-// (single pass, decoupled look-back); pass 2 marks candidate heads; pass 3 walks each candidate
-// sequentially so the float AUC is summed in the reference's order (950).
+// start_next - end_prev <= maxGap (1031-1032).
+//   pass 1  k_sweep_compact : ordered compaction of {significant, SKIP} intervals (look-back)
+//   pass 2  k_sweep_heads   : ordered list of candidate heads (look-back)
+//   pass 3  k_peak_walk     : one wavefront per candidate; the float AUC is summed strictly in
+//                             interval order (950) -- lanes load and form the products in
+//                             parallel, the additions are replayed serially through shuffles
+//   pass 4  k_peak_compact  : ordered compaction of the candidates passing checkPeak (916-927)
+// All four are persistent kernels that pull chunks by atomic ticket, so no list length ever
+// has to travel to the host between them.
 struct SweepList {
   u32* chrom;
   u32* start;
@@ -232,132 +238,233 @@ __global__ __launch_bounds__(SW_NT) void k_sweep_compact(const u32* __restrict__
                                                          const float* __restrict__ q, const u32* __restrict__ chromOff,
                                                          u32 nChrom, const u32* __restrict__ nPtr, float thr,
                                                          u32* __restrict__ ticket, u64* __restrict__ lb, SweepList out,
-                                                         u32* __restrict__ st) {
+                                                         u32 cap, u32* __restrict__ st) {
   __shared__ u32 scratch[8];
   __shared__ u32 s_id, s_base;
-  if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
-  __syncthreads();
-  const u32 id = s_id;
   const u32 n = *nPtr;
-  const u32 nBlocks = (n + SW_CHUNK - 1) / SW_CHUNK;
-  if (id >= nBlocks) return;
-  const u32 i0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
-  float pv[SW_ITEMS], qv[SW_ITEMS];
-  u32 keep = 0, cnt = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++) {
-    u32 i = i0 + k;
-    if (i < n) {
-      pv[k] = p[i];
-      qv[k] = q ? q[i] : GX_SKIPF;
-      float pq = q ? qv[k] : pv[k];
-      if (pq > thr || pq == GX_SKIPF) { keep |= 1u << k; cnt++; }
-    }
+  const u32 nChunks = (n + SW_CHUNK - 1) / SW_CHUNK;
+  if (nChunks == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out.count = 0;
+    return;
   }
-  u32 tot;
-  u32 ex = block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
-  if (threadIdx.x < 64) {
-    u64 excl = lookback_excl(lb, id, (u64)tot, st);
-    if (threadIdx.x == 0) {
-      s_base = (u32)excl;
-      if (id == nBlocks - 1) *out.count = (u32)(excl + tot);
-    }
-  }
-  __syncthreads();
-  if (!keep) return;
-  u32 o = s_base + ex;
-  ChromCursor cur;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const u32 id = s_id;
+    if (id >= nChunks) return;
+    const u32 i0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
+    float pv[SW_ITEMS], qv[SW_ITEMS];
+    u32 keep = 0, cnt = 0;
 #pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++)
-    if (keep & (1u << k)) {
+    for (int k = 0; k < SW_ITEMS; k++) {
       u32 i = i0 + k;
-      cur.seek(chromOff, nChrom, i);
-      float pq = q ? qv[k] : pv[k];
-      out.chrom[o] = cur.c;
-      out.start[o] = i == cur.lo ? 0 : end[i - 1];
-      out.end[o] = end[i];
-      out.p[o] = pv[k];
-      out.q[o] = qv[k];
-      out.sig[o] = pq == GX_SKIPF ? 0u : 1u;
-      o++;
+      if (i < n) {
+        pv[k] = p[i];
+        qv[k] = q ? q[i] : GX_SKIPF;
+        float pq = q ? qv[k] : pv[k];
+        if (pq > thr || pq == GX_SKIPF) { keep |= 1u << k; cnt++; }
+      }
     }
+    u32 tot;
+    u32 ex = block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
+    if (threadIdx.x < 64) {
+      u64 excl = lookback_excl(lb, id, (u64)tot, st);
+      if (threadIdx.x == 0) {
+        s_base = (u32)excl;
+        if (id == nChunks - 1) *out.count = (u32)(excl + tot);
+      }
+    }
+    __syncthreads();
+    if (!keep) continue;
+    u32 o = s_base + ex;
+    ChromCursor cur;
+#pragma unroll
+    for (int k = 0; k < SW_ITEMS; k++)
+      if ((keep & (1u << k)) && o < cap) {  // the true count is reported even when the list is full
+        u32 i = i0 + k;
+        cur.seek(chromOff, nChrom, i);
+        float pq = q ? qv[k] : pv[k];
+        out.chrom[o] = cur.c;
+        out.start[o] = i == cur.lo ? 0 : end[i - 1];
+        out.end[o] = end[i];
+        out.p[o] = pv[k];
+        out.q[o] = qv[k];
+        out.sig[o] = pq == GX_SKIPF ? 0u : 1u;
+        o++;
+      }
+  }
 }
 
-// head of a candidate: first significant interval after a SKIP, a chromosome change, or a gap
-// wider than maxGap
+// head of a candidate: a significant interval that follows a SKIP marker, a chromosome
+// change, or a gap wider than maxGap
 __device__ __forceinline__ bool sweep_is_head(const SweepList& L, u32 j, int maxGap) {
+  if (!L.sig[j]) return false;
   if (j == 0 || !L.sig[j - 1] || L.chrom[j - 1] != L.chrom[j]) return true;
   long long gap = (long long)L.start[j] - (long long)L.end[j - 1];
   return gap != 0 && gap > (long long)maxGap;
 }
 
-// one thread per candidate: updatePeak (943-970) over its intervals in order, then checkPeak (916-927)
-__global__ __launch_bounds__(256) void k_peak_walk(SweepList L, float thr, float minAUC, int minLen, int maxGap,
-                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+__global__ __launch_bounds__(SW_NT) void k_sweep_heads(SweepList L, int maxGap, u32* __restrict__ ticket,
+                                                       u64* __restrict__ lb, u32* __restrict__ headPos,
+                                                       u32* __restrict__ nHeads, u32* __restrict__ st) {
+  __shared__ u32 scratch[8];
+  __shared__ u32 s_id, s_base;
   const u32 M = *L.count;
-  for (u32 j = blockIdx.x * 256 + threadIdx.x; j < M; j += gridDim.x * 256) {
-    valid[j] = 0;
-    if (!L.sig[j] || !sweep_is_head(L, j, maxGap)) continue;
-    const bool qOpt = L.q[j] != GX_SKIPF;
-    float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
-    u32 summitPos = 0, summitLen = 0;
-    const u32 peakStart = L.start[j];
-    u32 peakEnd = 0;
-    for (u32 k = j; k < M; k++) {
-      if (k > j && (!L.sig[k] || sweep_is_head(L, k, maxGap))) break;
-      u32 s = L.start[k], e = L.end[k], len = e - s;
-      float pq = qOpt ? L.q[k] : L.p[k];
-      auc += (float)len * (pq - thr);  // 950: float product, float running sum, in order
-      peakEnd = e;
-      if (pq > summitVal) {
-        summitVal = pq;
-        sp = L.p[k];
-        sq = L.q[k];
-        summitPos = (u32)(((u64)e + s) / 2 - peakStart);
-        summitLen = len;
-      } else if (pq == summitVal && len > summitLen) {
-        summitPos = (u32)(((u64)e + s) / 2 - peakStart);
-        summitLen = len;
+  const u32 nChunks = (M + SW_CHUNK - 1) / SW_CHUNK;
+  if (nChunks == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nHeads = 0;
+    return;
+  }
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const u32 id = s_id;
+    if (id >= nChunks) return;
+    const u32 j0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
+    u32 keep = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SW_ITEMS; k++) {
+      u32 j = j0 + k;
+      if (j < M && sweep_is_head(L, j, maxGap)) { keep |= 1u << k; cnt++; }
+    }
+    u32 tot;
+    u32 ex = block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
+    if (threadIdx.x < 64) {
+      u64 excl = lookback_excl(lb, id, (u64)tot, st);
+      if (threadIdx.x == 0) {
+        s_base = (u32)excl;
+        if (id == nChunks - 1) *nHeads = (u32)(excl + tot);
       }
     }
-    if (auc >= minAUC && (long long)peakEnd - (long long)peakStart >= (long long)minLen) {
-      gx_peak pk;
-      pk.chrom = L.chrom[j];
-      pk.start = peakStart;
-      pk.end = peakEnd;
-      pk.summit = summitPos;
-      pk.auc = auc;
-      pk.p = sp;
-      pk.q = sq;
-      cand[j] = pk;
-      valid[j] = 1;
+    __syncthreads();
+    u32 o = s_base + ex;
+#pragma unroll
+    for (int k = 0; k < SW_ITEMS; k++)
+      if (keep & (1u << k)) headPos[o++] = j0 + k;
+  }
+}
+
+// one wavefront per candidate: updatePeak (943-970) over its intervals, then checkPeak (916-927)
+__global__ __launch_bounds__(256) void k_peak_walk(SweepList L, const u32* __restrict__ headPos,
+                                                   const u32* __restrict__ nHeads, float thr, float minAUC, int minLen,
+                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  const u32 M = *L.count, H = *nHeads;
+  const u32 wavesPerGrid = gridDim.x * 4;
+  const int lane = lane_id();
+  for (u32 h = blockIdx.x * 4 + (threadIdx.x >> 6); h < H; h += wavesPerGrid) {
+    const u32 j0 = headPos[h];
+    const u32 jEnd = h + 1 < H ? headPos[h + 1] : M;  // members are [j0, first non-significant or jEnd)
+    const bool qOpt = L.q[j0] != GX_SKIPF;
+    const u32 peakStart = L.start[j0];
+    float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
+    u32 summitPos = 0, summitLen = 0, peakEnd = 0;
+    for (u32 base = j0; base < jEnd; base += 64) {
+      u32 k = base + lane;
+      bool in = k < jEnd && L.sig[k];
+      u64 inMask = __ballot(in);
+      // members are a prefix: stop at the first lane that is not one
+      int nIn = (~inMask) ? __builtin_ctzll(~inMask) : 64;
+      float term = 0.0f, pq = -2.0f, pv = 0.0f, qv = 0.0f;
+      u32 s = 0, e = 0;
+      if (lane < nIn) {
+        s = L.start[k];
+        e = L.end[k];
+        pv = L.p[k];
+        qv = L.q[k];
+        pq = qOpt ? qv : pv;
+        term = (float)(e - s) * (pq - thr);  // 949-950: float product ...
+      }
+      for (int l = 0; l < nIn; l++) auc += __shfl(term, l, 64);  // ... float running sum, in order
+      // summit of this chunk: max pq, earliest lane (956-961)
+      float mx = pq;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+      if (nIn > 0) {
+        u64 atMax = __ballot(lane < nIn && pq == mx);
+        int firstMax = __builtin_ctzll(atMax);
+        // among the lanes at the maximum: first one with the greatest length (962-968)
+        u32 len = (lane < nIn && pq == mx) ? e - s : 0;
+        u32 ml = len;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ml = max(ml, (u32)__shfl_xor((int)ml, d, 64));
+        u64 atLen = __ballot(lane < nIn && pq == mx && len == ml);
+        int firstLen = __builtin_ctzll(atLen);
+        u32 cPos = (u32)(((u64)__shfl((int)e, firstLen, 64) + (u32)__shfl((int)s, firstLen, 64)) / 2 - peakStart);
+        if (mx > summitVal) {
+          summitVal = mx;
+          sp = __shfl(pv, firstMax, 64);
+          sq = __shfl(qv, firstMax, 64);
+          summitPos = cPos;
+          summitLen = ml;
+        } else if (mx == summitVal && ml > summitLen) {
+          summitPos = cPos;
+          summitLen = ml;
+        }
+        peakEnd = (u32)__shfl((int)e, nIn - 1, 64);
+      }
+      if (nIn < 64) break;
+    }
+    if (lane == 0) {
+      bool ok = auc >= minAUC && (long long)peakEnd - (long long)peakStart >= (long long)minLen;
+      valid[h] = ok;
+      if (ok) {
+        gx_peak pk;
+        pk.chrom = L.chrom[j0];
+        pk.start = peakStart;
+        pk.end = peakEnd;
+        pk.summit = summitPos;
+        pk.auc = auc;
+        pk.p = sp;
+        pk.q = sq;
+        cand[h] = pk;
+      }
     }
   }
 }
 
-// ordered compaction of the valid candidates (single workgroup: the list is short)
-__global__ __launch_bounds__(1024) void k_peak_compact(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
-                                                       const u32* __restrict__ mPtr, gx_peak* __restrict__ peaks,
-                                                       u32* __restrict__ nPeaks, u64* __restrict__ peakBP) {
-  __shared__ u32 scratch[20];
-  const u32 M = *mPtr;
-  u32 base = 0;
+// ordered compaction of the candidates that passed checkPeak
+__global__ __launch_bounds__(SW_NT) void k_peak_compact(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
+                                                        const u32* __restrict__ nHeads, u32* __restrict__ ticket,
+                                                        u64* __restrict__ lb, gx_peak* __restrict__ peaks,
+                                                        u32* __restrict__ nPeaks, u64* __restrict__ peakBP,
+                                                        u32* __restrict__ st) {
+  __shared__ u32 scratch[8];
+  __shared__ u32 s_id, s_base;
+  const u32 H = *nHeads;
+  const u32 nChunks = (H + SW_NT - 1) / SW_NT;
+  if (nChunks == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nPeaks = 0;
+    return;
+  }
   u64 bp = 0;
-  for (u32 j0 = 0; j0 < M; j0 += 1024) {
-    u32 j = j0 + threadIdx.x;
-    u32 v = j < M ? valid[j] : 0;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const u32 id = s_id;
+    if (id >= nChunks) break;
+    u32 h = id * SW_NT + threadIdx.x;
+    u32 v = h < H ? valid[h] : 0;
     u32 tot;
-    u32 ex = block_excl_scan<u32, 1024>(v, scratch, &tot);
+    u32 ex = block_excl_scan<u32, SW_NT>(v, scratch, &tot);
+    if (threadIdx.x < 64) {
+      u64 excl = lookback_excl(lb, id, (u64)tot, st);
+      if (threadIdx.x == 0) {
+        s_base = (u32)excl;
+        if (id == nChunks - 1) *nPeaks = (u32)(excl + tot);
+      }
+    }
+    __syncthreads();
     if (v) {
-      gx_peak pk = cand[j];
-      peaks[base + ex] = pk;
+      gx_peak pk = cand[h];
+      peaks[s_base + ex] = pk;
       bp += pk.end - pk.start;
     }
-    base += tot;
   }
   bp = wave_sum(bp);
   if (lane_id() == 0 && bp) atomicAdd(peakBP, bp);
-  if (threadIdx.x == 0) *nPeaks = base;
 }
 
 }  // namespace gx
