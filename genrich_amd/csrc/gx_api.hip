@@ -869,6 +869,22 @@ int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* en
   return GX_OK;
 }
 
+int gx_selftest(gx_ctx* ctx, int what, const float* a, const float* b, float* out, size_t n) {
+  if (!ctx || !a || !out || !n) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  DevBuf da, db, dout;
+  HIPCHECK(da.ensure(n * 4));
+  HIPCHECK(db.ensure(n * 4));
+  HIPCHECK(dout.ensure(n * 4));
+  HIPCHECK(hipMemcpy(da.p, a, n * 4, hipMemcpyHostToDevice));
+  if (b) HIPCHECK(hipMemcpy(db.p, b, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest, dim3(1024), dim3(256), 0, ctx->stream, what, da.as<float>(), db.as<float>(),
+                     dout.as<float>(), (u32)n);
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  HIPCHECK(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+  return GX_OK;
+}
+
 int gx_total_intervals(gx_ctx* ctx, int which, size_t* n_iv) {
   if (!ctx || !n_iv) return GX_ERR_ORDER;
   int w = which == GX_IV_FINAL ? ctx->finalIdx : which;

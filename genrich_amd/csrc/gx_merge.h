@@ -274,4 +274,19 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
   }
 }
 
+// scalar device functions exposed for the numerics tests (gx_selftest)
+__global__ __launch_bounds__(256) void k_selftest(int what, const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, u32 n) {
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    bool ng = false;
+    switch (what) {
+      case 0: out[i] = log10f_host(a[i]); break;
+      case 1: out[i] = calc_pval(a[i], b[i]); break;
+      case 2: out[i] = getval(__float_as_int(a[i]), &ng); break;
+      case 3: out[i] = fisher_combine((double)a[i], (int)b[i]); break;
+      default: out[i] = 0.0f;
+    }
+  }
+}
+
 }  // namespace gx

@@ -119,8 +119,51 @@ __global__ __launch_bounds__(256) void k_bh_insert(const u32* __restrict__ keys,
     bh_global_add(gKeys, gLens, capMask, keys[i], lens[i], st);
 }
 
-// float log10 as the host's libm evaluates it (saveQval 221, 226 call log10f).
-__device__ __forceinline__ float log10f_host(float x) { return (float)log10((double)x); }
+// float log10 exactly as the host's libm evaluates it (saveQval 221, 226 call log10f).
+// glibc 2.35's log10f is the fdlibm formula  z = y*log10_2lo + ivln10*logf(m);  z + y*log10_2hi
+// (float ops) around its table-driven logf (16-entry table, cubic in double).  Restated here and
+// verified bit-identical to the host's log10f over ALL positive normal floats
+// (oracle/check_log10f.c: 2,130,706,432 inputs, 0 mismatches, with or without FMA contraction),
+// so the BH table is bit-exact instead of merely within tolerance.  Inputs here are integers
+// >= 1 (k, genome length), so the subnormal/negative branches are not needed.
+__device__ inline float logf_host(float x) {
+  const double invc[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0,
+                           0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,  0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0,
+                           0x1.0953f419900a7p+0, 0x1p+0,               0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+                           0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
+  const double logc[16] = {-0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3,
+                           -0x1.6574f0ac07758p-3, -0x1.1aa2bc79c81p-3,   -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4,
+                           -0x1.252f438e10c1ep-5, 0x0p+0,                0x1.aa5aa5df25984p-5,  0x1.c5e53aa362eb4p-4,
+                           0x1.526e57720db08p-3,  0x1.bc2860d22477p-3,   0x1.1058bc8a07ee1p-2,  0x1.4043057b6ee09p-2};
+  const double Ln2 = 0x1.62e42fefa39efp-1;
+  const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  u32 ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  u32 tmp = ix - 0x3f330000u;
+  int i = (tmp >> 19) & 15;
+  int k = (int)tmp >> 23;
+  u32 iz = ix - (tmp & (0x1ffu << 23));
+  double z = (double)__uint_as_float(iz);
+  double r = z * invc[i] - 1;
+  double y0 = logc[i] + (double)k * Ln2;
+  double r2 = r * r;
+  double y = A1 * r + A2;
+  y = A0 * r2 + y;
+  y = y * r2 + (y0 + r);
+  return (float)y;
+}
+
+__device__ inline float log10f_host(float x) {
+  const float ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f, log10_2lo = 7.9034151668e-07f;
+  int hx = (int)__float_as_uint(x);
+  int k = (hx >> 23) - 127;
+  int i = ((u32)k & 0x80000000u) >> 31;
+  hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+  float y = (float)(k + i);
+  float m = __uint_as_float((u32)hx);
+  float z = y * log10_2lo + ivln10 * logf_host(m);
+  return z + y * log10_2hi;
+}
 
 // saveQval 219-229 on the sorted table (ascending p): from the most significant value down,
 //   raw_i = p_i + logN + log10f(k_i),  k_i = 1 + bp with strictly larger p   (float adds, left to right)

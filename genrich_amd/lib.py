@@ -60,6 +60,7 @@ _SIGS = {
     "gx_total_intervals": [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)],
     "gx_interval_count": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
     "gx_get_intervals": [C.c_void_p, C.c_int, C.c_int, C.c_size_t] + [C.c_void_p] * 5,
+    "gx_selftest": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_phase_times": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float))],
 }
 
@@ -197,6 +198,16 @@ class Genrich:
                 self.ctx, int(which), int(chrom), n, end.ctypes.data,
                 *[cols[k].ctypes.data for k in ("expt", "ctrl", "p", "q")]))
         return end, cols
+
+    def selftest(self, what, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.zeros_like(a)
+        bp = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            bp = b.ctypes.data
+        self._check(self.lib.gx_selftest(self.ctx, int(what), a.ctypes.data, bp, out.ctypes.data, a.size))
+        return out
 
     def interval_total(self, which=GX_IV_FINAL):
         n = C.c_size_t(0)

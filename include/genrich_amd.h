@@ -175,6 +175,13 @@ int gx_set_owned(gx_ctx* ctx, const uint8_t* owned);
  * gx_* call sequence; names are NUL-separated in *names. Returns count. */
 int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
 
+/* Evaluate one scalar device function on n inputs (numerics tests):
+ * what 0: log10f as the host libm computes it (saveQval 221/226)   out = f(a)
+ *      1: calcPval(expt = a, ctrl = b)          (Genrich.c:1628)
+ *      2: getVal of the exact pileup whose int32 bits are in a (1/120 units, :1902)
+ *      3: multPval's combination of sum = a over df = b (567-583) */
+int gx_selftest(gx_ctx* ctx, int what, const float* a, const float* b, float* out, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,7 @@ def assert_same_run(o, h, so, sh, case, tol=1e-5):
         if co is not None:
             assert np.float32(co).tobytes() == np.float32(ch).tobytes(), ("factor", co, ch)
     assert o.genome_len == h.genome_len
-    nbit = 0
+    nbit = {"p": 0, "q": 0}
     nrep = len(case["replicates"])
     whiches = [-1] + (list(range(nrep)) if nrep > 1 else [])
     for which, c in [(w, c) for w in whiches for c in range(len(case["lens"]))]:
@@ -48,7 +48,7 @@ def assert_same_run(o, h, so, sh, case, tol=1e-5):
             assert np.array_equal(fin, np.isfinite(b) & (np.abs(b) < 1e30))
             assert np.all(np.abs(a[fin] - b[fin]) <= tol * np.maximum(1.0, np.abs(a[fin]))), k
             assert np.array_equal(co[k][~fin], chh[k][~fin])
-            nbit += int((co[k].view(np.uint32) != chh[k].view(np.uint32)).sum())
+            nbit[k] += int((co[k].view(np.uint32) != chh[k].view(np.uint32)).sum())
     po, ph = o.get_peaks(), h.get_peaks()
     assert len(po) == len(ph), (len(po), len(ph))
     for f in ("chrom", "start", "end", "summit"):
@@ -68,7 +68,7 @@ def test_golden_case(name):
     meta, case, params, names = G.load_case(name)
     o, h, so, sh = run_both(case, params)
     nbit = assert_same_run(o, h, so, sh, case)
-    assert nbit == 0, f"{nbit} p/q values differ in their last bits from the host-libm oracle"
+    assert nbit == {"p": 0, "q": 0}, f"{nbit} p/q values differ in their last bits from the host-libm oracle"
     if meta["ref_peaks"]:
         assert h.n_peaks == meta["ref_peaks"][0][0]
 
@@ -128,3 +128,52 @@ def test_random_three_replicates():
     o, h, so, sh = run_both(case, params)
     assert_same_run(o, h, so, sh, case)
     assert h.n_peaks > 0
+
+
+# ---- scalar device functions against the host ---------------------------------------------
+
+def test_device_log10f_is_the_hosts():
+    """saveQval's log10f (Genrich.c:221, 226): the device restatement must equal the host libm
+    bit for bit (k and the genome length are integers >= 1)."""
+    h = hip_backend(B.make_params())
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.arange(1, 200_001), rng.integers(1, 2**32, 300_000),
+                        rng.integers(1, 2**62, 100_000)]).astype(np.float32)
+    got = h.selftest(0, x)
+    import ctypes as C
+    want = np.array([B._libm.log10f(C.c_float(v)) for v in x[:60_000]], dtype=np.float32)
+    assert np.array_equal(got[:60_000].view(np.uint32), want.view(np.uint32))
+    # the rest against numpy's double log10 rounded once (differs from libm only on hard cases)
+    ref = np.log10(x.astype(np.float64)).astype(np.float32)
+    assert np.max(np.abs(got.astype(np.float64) - ref)) < 2e-6
+
+
+def test_device_calc_pval_vs_oracle():
+    """calcPval on a grid of (treatment, control) values: within 1e-5 everywhere and bit-equal
+    to the host-libm oracle except where the double result sits on a float rounding boundary."""
+    h = hip_backend(B.make_params())
+    lib = B.Oracle.lib()
+    rng = np.random.default_rng(2)
+    n = 200_000
+    expt = (rng.integers(0, 60_000, n) / 120.0).astype(np.float32)
+    ctrl = np.where(rng.random(n) < 0.5, rng.random(n) * 7.5, rng.random(n) * 60).astype(np.float32)
+    ctrl[:10] = [0, -1, 7, 7.0000005, 1e-30, 6.9999995, 3, 3, 3, 3]
+    expt[:10] = [5, 5, 0, 1, 1, 1, 0, 1e6, 3e38, 1e-3]
+    got = h.selftest(1, expt, ctrl)
+    want = np.array([lib.gxo_calc_pval(float(e), float(c)) for e, c in zip(expt, ctrl)], dtype=np.float32)
+    fin = np.abs(want) < 1e30
+    assert np.array_equal(got[~fin], want[~fin])
+    assert np.all(np.abs(got[fin].astype(np.float64) - want[fin]) <= 1e-5 * np.maximum(1, np.abs(want[fin])))
+    nbad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    assert nbad <= 2, f"{nbad} of {n} p-values differ in the last bit"
+
+
+def test_device_getval_all_residues():
+    h = hip_backend(B.make_params())
+    lib = B.Oracle.lib()
+    import ctypes as C
+    v = np.concatenate([np.arange(0, 120 * 40), np.arange(120 * 5000, 120 * 5000 + 360)]).astype(np.int32)
+    got = h.selftest(2, v.view(np.float32))
+    neg = C.c_int(0)
+    want = np.array([lib.gxo_getval(int(x), C.byref(neg)) for x in v], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
