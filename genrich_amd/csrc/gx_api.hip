@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unistd.h>
 
 #include "gx_merge.h"
 
@@ -148,6 +149,22 @@ enum { M_TICKET = 0, M_NIV = 1, M_TICKET2 = 2, M_SWCOUNT = 3, M_NPEAKS = 4, M_BH
        M_PEAKBP = 8 /* u64 */, M_GENOME = 10 /* u64 */, M_TICKET3 = 12, M_TICKET4 = 13, M_NHEADS = 14,
        M_NMERGED = 15, M_WORDS = 32 };
 
+// GX_DEBUG=1: synchronise after every launch and say which kernel it was (hang / fault triage)
+int dbg_sync(gx_ctx* ctx, const char* what) {
+  static const bool on = getenv("GX_DEBUG") != nullptr;
+  if (!on) return GX_OK;
+  fprintf(stderr, "[gx] %s ...", what);
+  fflush(stderr);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+  fflush(stderr);
+  if (e != hipSuccess) {
+    ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+    return GX_ERR_DEVICE;
+  }
+  return GX_OK;
+}
+
 void phase_begin(gx_ctx* ctx, const char* name) {
   Phase ph;
   ph.name = name;
@@ -248,6 +265,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     u32 blocks = (u32)std::min<size_t>((seg.n + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(k_convert, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
                        ctx->sbShift, nSB, ctx->recsA.as<u64>() + 2 * off, ctx->sbHist.as<u32>(), ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_convert")) return rc__;
     off += seg.n;
   }
   phase_end(ctx);
@@ -255,20 +273,25 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   phase_begin(ctx, isCtrl ? "c.bucket" : "t.bucket");
   hipLaunchKernelGGL(k_scan_sb, dim3(1), dim3(1024), 0, s, ctx->sbHist.as<u32>(), nSB, (u32)SC_CHUNK, ctx->sbOff.as<u32>(),
                      ctx->sbCursor.as<u32>(), ctx->sbChunkOff.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_scan_sb")) return rc__;
   const u32 chunks1 = (nRec + SC_CHUNK - 1) / SC_CHUNK;
   if (chunks1) {
     hipLaunchKernelGGL(k_scatter<1>, dim3(chunks1), dim3(SC_NT), 0, s, ctx->recsA.as<u64>(), ctx->recsB.as<u64>(),
                        ctx->sbOff.as<u32>() + nSB /* total */, (const u32*)nullptr, 0u, ctx->sbShift, nSB,
                        ctx->sbCursor.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_scatter<1>")) return rc__;
     const u32 chunks2 = chunks1 + nSB;  // upper bound on sum of ceil(count / CHUNK)
     hipLaunchKernelGGL(k_hist2, dim3(chunks2), dim3(SC_NT), 0, s, ctx->recsB.as<u64>(), ctx->sbOff.as<u32>(),
                        ctx->sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>());
+  if (int rc__ = dbg_sync(ctx, "k_hist2")) return rc__;
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>(),
                        ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, ctx->tileOff.as<u32>(),
                        ctx->tileCursor.as<u32>(), ctx->tileCarry.as<int>());
+  if (int rc__ = dbg_sync(ctx, "k_scan_tiles")) return rc__;
     hipLaunchKernelGGL(k_scatter<2>, dim3(chunks2), dim3(SC_NT), 0, s, ctx->recsB.as<u64>(), ctx->recsA.as<u64>(),
                        ctx->sbOff.as<u32>(), ctx->sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, nSB,
                        ctx->tileCursor.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_scatter<2>")) return rc__;
   } else {
     HIPCHECK(hipMemsetAsync(ctx->tileOff.p, 0, (size_t)(nTiles + 2) * 4, s));
     HIPCHECK(hipMemsetAsync(ctx->tileCarry.p, 0, (size_t)(nTiles + 1) * 4, s));
@@ -282,8 +305,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   hipLaunchKernelGGL(k_tile, dim3(nTiles), dim3(TL_NT), ldsBytes, s, ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(),
                      ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, nChrom,
                      ctx->misc.as<u32>() + M_TICKET, ctx->lb.as<u64>(), to, ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
                      ctx->misc.as<u32>() + M_NIV);
+  if (int rc__ = dbg_sync(ctx, "k_fix_chrom_off")) return rc__;
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.fraglen" : "t.fraglen");
@@ -292,6 +317,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
   hipLaunchKernelGGL(k_fraglen, dim3(2048), dim3(256), 0, s, out.ivEnd.as<u32>(), out.ivV.as<int>(),
                      out.chromIvOff.as<u32>(), nChrom, ctx->misc.as<u32>() + M_NIV, acc, ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_fraglen")) return rc__;
   phase_end(ctx);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(&out.nIv, ctx->misc.as<u32>() + M_NIV, 4, hipMemcpyDeviceToHost, s));
@@ -317,6 +343,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     HIPCHECK(hipMemcpyAsync(dacc, acc, 16, hipMemcpyHostToDevice, s));
   }
   hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
   HIPCHECK(hipMemcpyAsync(&ctx->hScal, ds, sizeof(Scalars), hipMemcpyDeviceToHost, s));
   return read_status(ctx);
 }
@@ -587,6 +614,7 @@ int gx_pvalues(gx_ctx* ctx) {
     hipLaunchKernelGGL(k_pval_const, dim3(std::max(1u, std::min((n + 255) / 256, 4096u))), dim3(256), 0, s,
                        ctx->expt.ivV.as<int>(), ctx->misc.as<u32>() + M_NIV, ctx->dScal.as<Scalars>(), pa.p.as<float>(),
                        pa.expt.as<float>(), ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_pval_const")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     pa.end = std::move(ctx->expt.ivEnd);
@@ -616,12 +644,15 @@ int gx_pvalues(gx_ctx* ctx) {
     hipLaunchKernelGGL(k_merge2, dim3(std::min(nTiles, 2048u)), dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(),
                        ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, misc + M_TICKET, ctx->lb.as<u64>(), mo,
                        ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_merge2")) return rc__;
     hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, pa.chromOff.as<u32>(),
                        misc + M_NMERGED);
+  if (int rc__ = dbg_sync(ctx, "k_fix_chrom_off")) return rc__;
     phase_end(ctx);
     phase_begin(ctx, "pval");
     hipLaunchKernelGGL(k_pval_pairs, dim3(4096), dim3(256), 0, s, pa.expt.as<float>(), pa.ctrl.as<float>(),
                        misc + M_NMERGED, pa.p.as<float>());
+  if (int rc__ = dbg_sync(ctx, "k_pval_pairs")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(&pa.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
@@ -676,8 +707,10 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                                  (int)lds));
     hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, 2048u)), dim3(MG_NT), lds, s, S, ctx->dTileChrom.as<u32>(),
                        ctx->dChrom.as<DChrom>(), nTiles, misc + M_TICKET, ctx->lb.as<u64>(), mo, ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
     hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, comb.chromOff.as<u32>(),
                        misc + M_NMERGED);
+  if (int rc__ = dbg_sync(ctx, "k_fix_chrom_off")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(&comb.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
@@ -709,11 +742,13 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
                        fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV,
                        ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
     // occupied slots -> (key, slot), then sort by key
     HIPCHECK(ctx->bhOutKeys.ensure((size_t)cap * 4));
     HIPCHECK(ctx->bhOutSlot.ensure((size_t)cap * 4));
     hipLaunchKernelGGL(k_bh_compact, dim3(1024), dim3(256), 0, s, ctx->bhKeys.as<u32>(), cap, ctx->bhOutKeys.as<u32>(),
                        ctx->bhOutSlot.as<u32>(), misc + M_BHCOUNT);
+  if (int rc__ = dbg_sync(ctx, "k_bh_compact")) return rc__;
     u32 D = 0;
     HIPCHECK(hipMemcpyAsync(&D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
@@ -730,10 +765,12 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       hipLaunchKernelGGL(k_qtable, dim3(1), dim3(1024), 0, s, ctx->bhSortKeys.as<u32>(), ctx->bhSortSlot.as<u32>(),
                          ctx->bhLens.as<u64>(), D, reinterpret_cast<const u64*>(misc + M_GENOME), ctx->bhQ.as<float>(),
                          ctx->bhRaw.as<float>(), misc + M_ALLONE);
+  if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     }
     HIPCHECK(pooled(ctx, fa.q, (size_t)n * 4 + 16));
     hipLaunchKernelGGL(k_qlookup, dim3(gridIv), dim3(256), 0, s, fa.p.as<float>(), misc + M_NIV, ctx->bhKeys.as<u32>(),
                        ctx->bhQ.as<float>(), cap - 1, fa.q.as<float>());
+  if (int rc__ = dbg_sync(ctx, "k_qlookup")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
   }
@@ -769,6 +806,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                        fa.end.as<u32>(), fa.p.as<float>(), ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr,
                        fa.chromOff.as<u32>(), nChrom, misc + M_NIV, ctx->par.thr, misc + M_TICKET2, ctx->lb2.as<u64>(), L,
                        (u32)std::min<size_t>(mCap, 0xFFFFFFFFu), ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_sweep_compact")) return rc__;
     HIPCHECK(hipMemcpyAsync(&M, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     if (M <= mCap) break;
@@ -789,13 +827,16 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     const u32 mChunks = (M + SW_CHUNK - 1) / SW_CHUNK;
     hipLaunchKernelGGL(k_sweep_heads, dim3(std::min(mChunks, 1024u)), dim3(SW_NT), 0, s, L, ctx->par.max_gap,
                        misc + M_TICKET3, lbHeads, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_sweep_heads")) return rc__;
     hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((M + 3) / 4, 4096u))), dim3(256), 0, s, L,
                        ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
                        ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_peak_walk")) return rc__;
     hipLaunchKernelGGL(k_peak_compact, dim3(std::max(1u, std::min((M + SW_NT - 1) / SW_NT, 1024u))), dim3(SW_NT), 0, s,
                        ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(), misc + M_NHEADS, misc + M_TICKET4, lbPeaks,
                        ctx->peaks.as<gx_peak>(), misc + M_NPEAKS, reinterpret_cast<u64*>(misc + M_PEAKBP),
                        ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_peak_compact")) return rc__;
     HIPCHECK(hipMemcpyAsync(&nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(&ctx->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
@@ -880,6 +921,7 @@ int gx_selftest(gx_ctx* ctx, int what, const float* a, const float* b, float* ou
   if (b) HIPCHECK(hipMemcpy(db.p, b, n * 4, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_selftest, dim3(1024), dim3(256), 0, ctx->stream, what, da.as<float>(), db.as<float>(),
                      dout.as<float>(), (u32)n);
+  if (int rc__ = dbg_sync(ctx, "k_selftest")) return rc__;
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   HIPCHECK(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
   return GX_OK;

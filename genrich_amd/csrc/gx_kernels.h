@@ -366,7 +366,7 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const u64* __restrict__ in, con
 // that have already started.  Call from the first wave (64 lanes) only; returns the exclusive
 // prefix of `aggregate` over blocks [0, id) in every lane.  lb must be zeroed before launch.
 constexpr u64 LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_MASK = (1ull << 62) - 1;
-constexpr u32 LB_SPIN_LIMIT = 4000000;
+constexpr u32 LB_SPIN_LIMIT = 2000000;  // ~ seconds; a timed-out launch is reported, never silent
 
 __device__ __forceinline__ u64 lookback_excl(u64* lb, u32 id, u64 aggregate, u32* st) {
   u64 excl = 0;
@@ -393,7 +393,13 @@ __device__ __forceinline__ u64 lookback_excl(u64* lb, u32 id, u64 aggregate, u32
         look -= firstInvalid;
       } else {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > LB_SPIN_LIMIT) {
+        ++spins;
+        // give up when this wave has waited too long, or as soon as any other wave has
+        // (so one failure cannot cascade into a launch that spins for minutes)
+        bool abort_ = spins > LB_SPIN_LIMIT;
+        if (!abort_ && (spins & 1023u) == 0)
+          abort_ = (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_LOOKBACK) != 0;
+        if (abort_) {
           if (lane_id() == 0) atomicOr(st, ST_LOOKBACK);
           done = true;
         }

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
       }
     }
     __syncthreads();
-    if (!active) continue;
+    if (active) {  // block-uniform; kept as a guarded region so no branch ever targets a barrier
     u32 o = s_base + exU;
 #pragma unroll
     for (int k = 0; k < MG_WPT; k++) {
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
       out.expt[oc] = getval(A.v[a1 - 1], &ng1);
       out.ctrl[oc] = ctrl_net(B.v[b1 - 1], factor, lambda, &ng2);
       neg |= ng1 | ng2;
+    }
     }
     if (neg) atomicOr(st, ST_NEG_PILE);
   }
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
       }
     }
     __syncthreads();
-    if (!any) continue;
+    if (any) {  // block-uniform
     u32 o = s_base + exU;
 #pragma unroll
     for (int k = 0; k < MG_WPT; k++) {
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
       u32 oc = s_base + tU;
       out.end[oc] = c.len;
       out.p[oc] = fisher_combine(sum, df);
+    }
     }
   }
 }

@@ -319,7 +319,8 @@ __global__ __launch_bounds__(SW_NT) void k_sweep_compact(const u32* __restrict__
       }
     }
     __syncthreads();
-    if (!keep) continue;
+    // NOTE: no divergent `continue` here -- lanes that branch back to the barrier at the loop top
+    // separately from their wave-mates make the wave arrive twice (observed hang on gfx950).
     u32 o = s_base + ex;
     ChromCursor cur;
 #pragma unroll
