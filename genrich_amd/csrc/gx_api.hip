@@ -107,6 +107,7 @@ struct gx_ctx {
   gx_allreduce_i64_fn allreduce = nullptr;
   gx_allgather_tab_fn allgather = nullptr;
   void* user = nullptr;
+  int numCU = 0, resTile = 0, resMerge = 0, resSweep = 0;  // co-resident workgroups per kernel class
   // recycled device buffers (gx_reset keeps allocations alive across runs)
   std::vector<DevBuf> pool;
   // timing
@@ -284,9 +285,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     hipLaunchKernelGGL(k_hist2, dim3(chunks2), dim3(SC_NT), 0, s, ctx->recsB.as<u64>(), ctx->sbOff.as<u32>(),
                        ctx->sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>());
   if (int rc__ = dbg_sync(ctx, "k_hist2")) return rc__;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>(),
-                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, ctx->tileOff.as<u32>(),
-                       ctx->tileCursor.as<u32>(), ctx->tileCarry.as<int>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(std::min<u32>((nTiles + STL_CHUNK - 1) / STL_CHUNK, (u32)ctx->resSweep)),
+                       dim3(STL_NT), 0, s, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>(), nTiles, ctx->lb.as<u64>(),
+                       ctx->tileOff.as<u32>(), ctx->tileCursor.as<u32>(), ctx->tileCarry.as<int>(), ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_scan_tiles")) return rc__;
     hipLaunchKernelGGL(k_scatter<2>, dim3(chunks2), dim3(SC_NT), 0, s, ctx->recsB.as<u64>(), ctx->recsA.as<u64>(),
                        ctx->sbOff.as<u32>(), ctx->sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, nSB,
@@ -301,10 +302,11 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");
   TileOut to{out.ivEnd.as<u32>(), out.ivV.as<int>(), out.tileIvOff.as<u32>(), out.chromIvOff.as<u32>(),
              ctx->misc.as<u32>() + M_NIV};
-  const size_t ldsBytes = (size_t)(TL_PAD + 64) * 4;
-  hipLaunchKernelGGL(k_tile, dim3(nTiles), dim3(TL_NT), ldsBytes, s, ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(),
-                     ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, nChrom,
-                     ctx->misc.as<u32>() + M_TICKET, ctx->lb.as<u64>(), to, ctx->dStatus.as<u32>());
+  const size_t ldsBytes = (size_t)(TL_PAD + TL_SCR) * 4;
+  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 1) * 8, s));  // k_scan_tiles used the first entries
+  hipLaunchKernelGGL(k_tile, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s,
+                     ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
+                     ctx->dChrom.as<DChrom>(), nTiles, ctx->lb.as<u64>(), to, ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
                      ctx->misc.as<u32>() + M_NIV);
@@ -397,7 +399,20 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   HIPCHECK(hipMemsetAsync(ctx->dScal.p, 0, sizeof(Scalars), ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
   HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (TL_PAD + 64) * 4));
+                               (TL_PAD + TL_SCR) * 4));
+  {
+    // persistent kernels: the grid must not exceed what is co-resident (look-back forward progress)
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, ctx->device));
+    ctx->numCU = prop.multiProcessorCount;
+    int nb = 0;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile, TL_NT, (TL_PAD + TL_SCR) * 4));
+    ctx->resTile = std::max(1, nb) * ctx->numCU;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_merge2, MG_NT, 0));
+    ctx->resMerge = std::max(1, std::min(nb, 4)) * ctx->numCU;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sweep_compact, SW_NT, 0));
+    ctx->resSweep = std::max(1, std::min(nb, 4)) * ctx->numCU;
+  }
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   return GX_OK;
 }
@@ -641,9 +656,9 @@ int gx_pvalues(gx_ctx* ctx) {
     RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>()};
     Merge2Out mo{pa.end.as<u32>(), pa.expt.as<float>(), pa.ctrl.as<float>(), pa.tileOff.as<u32>(),
                  pa.chromOff.as<u32>(), misc + M_NMERGED};
-    hipLaunchKernelGGL(k_merge2, dim3(std::min(nTiles, 2048u)), dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(),
-                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, misc + M_TICKET, ctx->lb.as<u64>(), mo,
-                       ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_merge2, dim3(std::min(nTiles, (u32)ctx->resMerge)), dim3(MG_NT), 0, s, A, Bc,
+                       ctx->dScal.as<Scalars>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles,
+                       ctx->lb.as<u64>(), mo, ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_merge2")) return rc__;
     hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, pa.chromOff.as<u32>(),
                        misc + M_NMERGED);
@@ -705,8 +720,11 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     const size_t lds = (size_t)nr * MG_WORDS * 4;
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
-    hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, 2048u)), dim3(MG_NT), lds, s, S, ctx->dTileChrom.as<u32>(),
-                       ctx->dChrom.as<DChrom>(), nTiles, misc + M_TICKET, ctx->lb.as<u64>(), mo, ctx->dStatus.as<u32>());
+    int nbN = 0;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbN, k_mergeN, MG_NT, lds));
+    hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(std::max(1, std::min(nbN, 4)) * ctx->numCU))), dim3(MG_NT),
+                       lds, s, S, ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, ctx->lb.as<u64>(), mo,
+                       ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
     hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, comb.chromOff.as<u32>(),
                        misc + M_NMERGED);
@@ -802,9 +820,9 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                 ctx->swQ.as<float>(), ctx->swSig.as<u32>(), misc + M_SWCOUNT};
     // count first (cap = 0 writes nothing) would cost a second pass; instead the kernel bounds its
     // writes by the capacity and always reports the true count
-    hipLaunchKernelGGL(k_sweep_compact, dim3(std::max(1u, std::min(nChunks, 1024u))), dim3(SW_NT), 0, s,
+    hipLaunchKernelGGL(k_sweep_compact, dim3(std::max(1u, std::min(nChunks, (u32)ctx->resSweep))), dim3(SW_NT), 0, s,
                        fa.end.as<u32>(), fa.p.as<float>(), ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr,
-                       fa.chromOff.as<u32>(), nChrom, misc + M_NIV, ctx->par.thr, misc + M_TICKET2, ctx->lb2.as<u64>(), L,
+                       fa.chromOff.as<u32>(), nChrom, misc + M_NIV, ctx->par.thr, ctx->lb2.as<u64>(), L,
                        (u32)std::min<size_t>(mCap, 0xFFFFFFFFu), ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_sweep_compact")) return rc__;
     HIPCHECK(hipMemcpyAsync(&M, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
@@ -825,15 +843,15 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     u64* lbHeads = ctx->lb2.as<u64>() + nChunks;
     u64* lbPeaks = ctx->lb2.as<u64>() + 2 * (size_t)nChunks;
     const u32 mChunks = (M + SW_CHUNK - 1) / SW_CHUNK;
-    hipLaunchKernelGGL(k_sweep_heads, dim3(std::min(mChunks, 1024u)), dim3(SW_NT), 0, s, L, ctx->par.max_gap,
-                       misc + M_TICKET3, lbHeads, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_sweep_heads, dim3(std::min(mChunks, (u32)ctx->resSweep)), dim3(SW_NT), 0, s, L, ctx->par.max_gap,
+                       lbHeads, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_sweep_heads")) return rc__;
     hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((M + 3) / 4, 4096u))), dim3(256), 0, s, L,
                        ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
                        ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_peak_walk")) return rc__;
-    hipLaunchKernelGGL(k_peak_compact, dim3(std::max(1u, std::min((M + SW_NT - 1) / SW_NT, 1024u))), dim3(SW_NT), 0, s,
-                       ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(), misc + M_NHEADS, misc + M_TICKET4, lbPeaks,
+    hipLaunchKernelGGL(k_peak_compact, dim3(std::max(1u, std::min((M + SW_NT - 1) / SW_NT, (u32)ctx->resSweep))),
+                       dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(), misc + M_NHEADS, lbPeaks,
                        ctx->peaks.as<gx_peak>(), misc + M_NPEAKS, reinterpret_cast<u64*>(misc + M_PEAKBP),
                        ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_peak_compact")) return rc__;

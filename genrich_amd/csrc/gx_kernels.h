@@ -58,14 +58,33 @@ __device__ __forceinline__ bool chrom_active(const DChrom& c) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// 64-lane inclusive add-scan in 7 DPP adds (no LDS crossbar traffic): rows of 16 lanes are
+// scanned with row_shr 1/2/3/4/8, then row_bcast:15 / row_bcast:31 carry the row totals across
+// the wave (gfx9 DPP controls; lanes without a source read `old` = 0).
+__device__ __forceinline__ int dpp_scan_add(int v) {
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, false);  // row_shr:3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xe, false);  // row_shr:4, banks 1-3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xc, false);  // row_shr:8, banks 2-3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return x;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_incl_scan(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return (T)dpp_scan_add((int)v);
+  } else {
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    T o = __shfl_up(v, d, 64);
-    if (lane_id() >= d) v += o;
+    for (int d = 1; d < 64; d <<= 1) {
+      T o = __shfl_up(v, d, 64);
+      if (lane_id() >= d) v += o;
+    }
+    return v;
   }
-  return v;
 }
 
 template <typename T>
@@ -96,6 +115,81 @@ __device__ __forceinline__ T block_excl_scan(T v, T* scratch, T* total) {
   __syncthreads();
   return res;
 }
+
+// ---- decoupled look-back (single-pass chained scan across workgroups) ------------------------
+// lb[i] is one 8-byte granule {flag:2, value:62}: 0 = nothing yet, AGG = this block's own
+// aggregate, INC = inclusive prefix through this block.  The value and its flag travel in ONE
+// relaxed agent-scope 8-byte store / load, so no fence is needed (the data is the flag).
+// Forward progress: every launch that uses this is a PERSISTENT kernel whose workgroups are all
+// co-resident (grid <= occupancy x CUs, computed by the host) and take work items round-robin
+// (item = blockIdx.x + round * gridDim.x), so an item only ever waits on items that a resident
+// workgroup is processing or has finished -- without a per-item ticket atomic (one contended
+// word hands out only ~90 tickets/us on MI355X, i.e. > 2 ms for hg38's 188,507 tiles).  Every
+// spin is bounded (ST_LOOKBACK).  Call from the first wave (64 lanes) only; returns the
+// exclusive prefix of `aggregate` over items [0, id) in every lane.  lb zeroed before launch.
+constexpr u64 LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_MASK = (1ull << 62) - 1;
+constexpr u32 LB_SPIN_LIMIT = 2000000;  // ~ seconds; a timed-out launch is reported, never silent
+
+__device__ __forceinline__ u64 lookback_excl(u64* lb, u32 id, u64 aggregate, u32* st) {
+  u64 excl = 0;
+  if (id > 0) {
+    if (lane_id() == 0)
+      __hip_atomic_store(&lb[id], LB_AGG | (aggregate & LB_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int look = (int)id - 1;
+    u32 spins = 0;
+    bool done = false;
+    while (!done) {
+      int idx = look - lane_id();  // lane 0 = nearest predecessor
+      u64 v = idx >= 0 ? __hip_atomic_load(&lb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : LB_INC;   // virtual block -1: inclusive prefix 0
+      u64 flag = v >> 62;
+      u64 invalidMask = __ballot(flag == 0);
+      u64 incMask = __ballot(flag == 2);
+      int firstInvalid = invalidMask ? __builtin_ctzll(invalidMask) : 64;
+      int firstInc = incMask ? __builtin_ctzll(incMask) : 64;
+      if (firstInc < firstInvalid) {
+        excl += wave_sum(lane_id() <= firstInc ? (v & LB_MASK) : 0ull);
+        done = true;
+      } else if (firstInvalid > 0) {
+        excl += wave_sum(lane_id() < firstInvalid ? (v & LB_MASK) : 0ull);
+        look -= firstInvalid;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        // give up when this wave has waited too long, or as soon as any other wave has
+        // (so one failure cannot cascade into a launch that spins for minutes)
+        bool abort_ = spins > LB_SPIN_LIMIT;
+        if (!abort_ && (spins & 1023u) == 0)
+          abort_ = (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_LOOKBACK) != 0;
+        if (abort_) {
+          if (lane_id() == 0) atomicOr(st, ST_LOOKBACK);
+          done = true;
+        }
+      }
+    }
+  }
+  excl &= LB_MASK;  // packed multi-field values rely on modular arithmetic inside the 62 bits
+  if (lane_id() == 0)
+    __hip_atomic_store(&lb[id], LB_INC | ((excl + aggregate) & LB_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
+// lazily re-seeking cursor: which chromosome owns interval i of an array laid out by
+// chromIvOff[nChrom+1]?  A binary search runs only when i leaves the current range.
+struct ChromCursor {
+  u32 c = 0, lo = 0, hi = 0;
+  __device__ __forceinline__ void seek(const u32* __restrict__ off, u32 nChrom, u32 i) {
+    if (i >= lo && i < hi) return;
+    u32 a = 0, b = nChrom;  // last c with off[c] <= i  (empty ranges share an offset: take the last)
+    while (b - a > 1) {
+      u32 mid = (a + b) >> 1;
+      if (off[mid] <= i) a = mid; else b = mid;
+    }
+    c = a;
+    lo = off[a];
+    hi = off[a + 1];
+  }
+};
 
 // ---- 1. events -> endpoint records ------------------------------------------------------
 // Replaces the accumulate step of saveInterval (Genrich.c:2546-2583): instead of a
@@ -178,28 +272,28 @@ __global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist
   if (threadIdx.x == 0) sbChunkOff[nSB] = ctot;
 }
 
-// per-tile record counts -> offsets + cursors; per-tile weight sums -> carry-in of each tile
-// (running pileup at the tile's first base = sum of all weights in earlier tiles of the
-// same chromosome).  Single workgroup, 8 tiles per thread per round.
-constexpr int ST_ITEMS = 8;
-__global__ __launch_bounds__(1024) void k_scan_tiles(const u32* __restrict__ tileCnt,
-                                                     const int* __restrict__ tileWsum,
-                                                     const u32* __restrict__ tileChrom,
-                                                     const DChrom* __restrict__ chroms, u32 nTiles,
-                                                     u32* __restrict__ tileOff, u32* __restrict__ tileCursor,
-                                                     int* __restrict__ tileCarry) {
-  __shared__ u32 scratch[20];
-  __shared__ int iscratch[20];
-  u32 baseCnt = 0;
-  int baseW = 0;
-  for (u32 t0 = 0; t0 < nTiles; t0 += 1024 * ST_ITEMS) {
-    u32 tb = t0 + threadIdx.x * ST_ITEMS;
-    u32 c[ST_ITEMS];
-    int w[ST_ITEMS];
+// per-tile record counts -> offsets + cursors, per-tile weight sums -> genome-wide prefix
+// (tilePrefW; the carry-in of a tile is tilePrefW[t] - tilePrefW[first tile of its chromosome]).
+// Persistent multi-workgroup chained scan, 2048 tiles per item.
+constexpr int STL_NT = 256;
+constexpr int STL_ITEMS = 8;
+constexpr int STL_CHUNK = STL_NT * STL_ITEMS;
+__global__ __launch_bounds__(STL_NT) void k_scan_tiles(const u32* __restrict__ tileCnt, const int* __restrict__ tileWsum,
+                                                       u32 nTiles, u64* __restrict__ lb, u32* __restrict__ tileOff,
+                                                       u32* __restrict__ tileCursor, int* __restrict__ tilePrefW,
+                                                       u32* __restrict__ st) {
+  __shared__ u32 scratch[8];
+  __shared__ int iscratch[8];
+  __shared__ u64 s_base;
+  const u32 nChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
+    const u32 tb = id * STL_CHUNK + threadIdx.x * STL_ITEMS;
+    u32 c[STL_ITEMS];
+    int w[STL_ITEMS];
     u32 cs = 0;
     int ws = 0;
 #pragma unroll
-    for (int k = 0; k < ST_ITEMS; k++) {
+    for (int k = 0; k < STL_ITEMS; k++) {
       u32 t = tb + k;
       c[k] = t < nTiles ? tileCnt[t] : 0;
       w[k] = t < nTiles ? tileWsum[t] : 0;
@@ -208,33 +302,35 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const u32* __restrict__ til
     }
     u32 ctot;
     int wtot;
-    u32 cex = baseCnt + block_excl_scan<u32, 1024>(cs, scratch, &ctot);
-    int wex = baseW + block_excl_scan<int, 1024>(ws, iscratch, &wtot);
+    u32 cex = block_excl_scan<u32, STL_NT>(cs, scratch, &ctot);
+    int wex = block_excl_scan<int, STL_NT>(ws, iscratch, &wtot);
+    if (threadIdx.x < 64) {
+      // one granule carries both prefixes: records in the low 32 bits, weight (mod 2^30) in the
+      // next 30.  A chunk's weight sum may be negative, but every PREFIX is a pileup value at a
+      // tile boundary (>= 0, < 2^30 in 1/120 units), so modular sums reproduce it exactly.
+      u64 agg = (u64)ctot | ((u64)((u32)wtot & 0x3FFFFFFFu) << 32);
+      u64 excl = lookback_excl(lb, id, agg, st);
+      if (threadIdx.x == 0) {
+        s_base = excl;
+        if (id == nChunks - 1) tileOff[nTiles] = (u32)excl + ctot;
+      }
+    }
+    __syncthreads();
+    cex += (u32)s_base;
+    wex = (int)(((u32)wex + (u32)(s_base >> 32)) & 0x3FFFFFFFu);
 #pragma unroll
-    for (int k = 0; k < ST_ITEMS; k++) {
+    for (int k = 0; k < STL_ITEMS; k++) {
       u32 t = tb + k;
       if (t < nTiles) {
         tileOff[t] = cex;
         tileCursor[t] = cex;
-        tileCarry[t] = wex;  // genome-wide prefix; made per-chromosome below
+        tilePrefW[t] = wex;
       }
       cex += c[k];
-      wex += w[k];
+      wex = (int)(((u32)wex + (u32)w[k]) & 0x3FFFFFFFu);
     }
-    baseCnt += ctot;
-    baseW += wtot;
+    __syncthreads();
   }
-  if (threadIdx.x == 0) tileOff[nTiles] = baseCnt;
-  __syncthreads();
-  // subtract the prefix at the chromosome's first tile: non-first tiles read it here ...
-  for (u32 t = threadIdx.x; t < nTiles; t += 1024) {
-    u32 first = chroms[tileChrom[t]].tileBase;
-    if (t != first) tileCarry[t] -= tileCarry[first];
-  }
-  __syncthreads();
-  // ... and the first tiles are reset afterwards
-  for (u32 t = threadIdx.x; t < nTiles; t += 1024)
-    if (t == chroms[tileChrom[t]].tileBase) tileCarry[t] = 0;
 }
 
 // ---- 3. bucket scatter (both levels) -------------------------------------------------------
@@ -358,76 +454,6 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const u64* __restrict__ in, con
 }
 
 
-// ---- decoupled look-back (single-pass chained scan across workgroups) ------------------------
-// lb[i] is one 8-byte granule {flag:2, value:62}: 0 = nothing yet, AGG = this block's own
-// aggregate, INC = inclusive prefix through this block.  The value and its flag travel in ONE
-// relaxed agent-scope 8-byte store / load, so no fence is needed (the data is the flag).
-// Block ids must be handed out by an atomic ticket so that a block only ever waits on blocks
-// that have already started.  Call from the first wave (64 lanes) only; returns the exclusive
-// prefix of `aggregate` over blocks [0, id) in every lane.  lb must be zeroed before launch.
-constexpr u64 LB_AGG = 1ull << 62, LB_INC = 2ull << 62, LB_MASK = (1ull << 62) - 1;
-constexpr u32 LB_SPIN_LIMIT = 2000000;  // ~ seconds; a timed-out launch is reported, never silent
-
-__device__ __forceinline__ u64 lookback_excl(u64* lb, u32 id, u64 aggregate, u32* st) {
-  u64 excl = 0;
-  if (id > 0) {
-    if (lane_id() == 0)
-      __hip_atomic_store(&lb[id], LB_AGG | aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int look = (int)id - 1;
-    u32 spins = 0;
-    bool done = false;
-    while (!done) {
-      int idx = look - lane_id();  // lane 0 = nearest predecessor
-      u64 v = idx >= 0 ? __hip_atomic_load(&lb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : LB_INC;   // virtual block -1: inclusive prefix 0
-      u64 flag = v >> 62;
-      u64 invalidMask = __ballot(flag == 0);
-      u64 incMask = __ballot(flag == 2);
-      int firstInvalid = invalidMask ? __builtin_ctzll(invalidMask) : 64;
-      int firstInc = incMask ? __builtin_ctzll(incMask) : 64;
-      if (firstInc < firstInvalid) {
-        excl += wave_sum(lane_id() <= firstInc ? (v & LB_MASK) : 0ull);
-        done = true;
-      } else if (firstInvalid > 0) {
-        excl += wave_sum(lane_id() < firstInvalid ? (v & LB_MASK) : 0ull);
-        look -= firstInvalid;
-      } else {
-        __builtin_amdgcn_s_sleep(1);
-        ++spins;
-        // give up when this wave has waited too long, or as soon as any other wave has
-        // (so one failure cannot cascade into a launch that spins for minutes)
-        bool abort_ = spins > LB_SPIN_LIMIT;
-        if (!abort_ && (spins & 1023u) == 0)
-          abort_ = (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_LOOKBACK) != 0;
-        if (abort_) {
-          if (lane_id() == 0) atomicOr(st, ST_LOOKBACK);
-          done = true;
-        }
-      }
-    }
-  }
-  if (lane_id() == 0)
-    __hip_atomic_store(&lb[id], LB_INC | (excl + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return excl;
-}
-
-// lazily re-seeking cursor: which chromosome owns interval i of an array laid out by
-// chromIvOff[nChrom+1]?  A binary search runs only when i leaves the current range.
-struct ChromCursor {
-  u32 c = 0, lo = 0, hi = 0;
-  __device__ __forceinline__ void seek(const u32* __restrict__ off, u32 nChrom, u32 i) {
-    if (i >= lo && i < hi) return;
-    u32 a = 0, b = nChrom;  // last c with off[c] <= i  (empty ranges share an offset: take the last)
-    while (b - a > 1) {
-      u32 mid = (a + b) >> 1;
-      if (off[mid] <= i) a = mid; else b = mid;
-    }
-    c = a;
-    lo = off[a];
-    hi = off[a + 1];
-  }
-};
-
 // ---- 4. the tile kernel: LDS difference array -> prefix sum -> run-length pileup -----------
 // Replaces savePileupExpt's two per-base passes (Genrich.c:2197-2273; and the per-base walk
 // of calcFactor/savePileupCtrl for a control).  One workgroup owns one tile:
@@ -437,11 +463,13 @@ struct ChromCursor {
 //   prefix BEFORE j (:2241-2251); the chromosome's last tile also closes [.., len) (:2268).
 // The output position of a tile's intervals is a prefix sum over tiles, obtained in the same
 // launch by a decoupled look-back over 8-byte {flag, value} granules (one relaxed agent-scope
-// store/load each; tickets are handed out by an atomic so a tile only waits on tiles that
-// have already started).
+// store/load each).  Persistent: workgroup b handles tiles b, b + gridDim, b + 2 gridDim, ...
 constexpr int TL_NT = 512;
+constexpr int TL_NW = TL_NT / 64;
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
 constexpr int TL_PAD = TILE + TILE / 32;          // +1 dword per 32: conflict-free blocked reads
+constexpr int TL_SCR = 64;                        // scratch ints after the slice
+
 struct TileOut {
   u32* ivEnd;       // interval end (chromosome coordinate)
   int* ivV;         // pileup in 1/120 units
@@ -452,90 +480,97 @@ struct TileOut {
 
 __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
                                                    const u32* __restrict__ tileOff,
-                                                   const int* __restrict__ tileCarry,
+                                                   const int* __restrict__ tilePrefW,
                                                    const u32* __restrict__ tileChrom,
                                                    const DChrom* __restrict__ chroms, u32 nTiles,
-                                                   u32 nChrom, u32* __restrict__ ticket,
                                                    u64* __restrict__ lb, TileOut out,
                                                    u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
-  int* delta = lds;                        // TL_PAD ints
-  int* scr = lds + TL_PAD;                 // [0..15] scan scratch, [16] ticket, [17] output base
-  if (threadIdx.x == 0) scr[16] = (int)atomicAdd(ticket, 1u);
-  // zero the slice (16 B per lane)
-  for (int i = threadIdx.x * 4; i < TL_PAD; i += TL_NT * 4)
-    *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
-  __syncthreads();
-  const u32 t = (u32)scr[16];
-  if (t >= nTiles) return;
-  const u32 ci = tileChrom[t];
-  const DChrom c = chroms[ci];
-  const bool active = chrom_active(c);
-  const u32 tl = t - c.tileBase;
-  const u32 pos0 = tl << TB;
-  const bool lastTile = tl + 1 == c.nTiles;
-  // accumulate this tile's endpoint records
-  const u32 rb = tileOff[t], re = tileOff[t + 1];
-  for (u32 i = rb + threadIdx.x; i < re; i += TL_NT) {
-    u64 r = recs[i];
-    u32 off = (u32)(r >> 8) & (TILE - 1);
-    atomicAdd(&delta[off + (off >> 5)], (int)(int8_t)(r & 0xFF));
-  }
-  __syncthreads();
-  // blocked read: thread i owns bases [32 i, 32 i + 32)
-  int d[TL_EPT];
-  int sum = 0;
-  u32 cnt = 0;
-  const int lbase = threadIdx.x * 33;
-  u32 sat = 0;
+  int* delta = lds;                        // TL_PAD ints (no static LDS: keeps the base 16-B aligned)
+  int* scr = lds + TL_PAD;                 // [0..8] sums, [16..24] counts, [32] output base
+  const int wv = threadIdx.x >> 6;
+  u32 bad = 0;
+  for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {
+    // zero the slice (16 B per lane)
+    for (int i = threadIdx.x * 4; i < TL_PAD; i += TL_NT * 4)
+      *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
+    const u32 ci = tileChrom[t];
+    const DChrom c = chroms[ci];
+    const bool active = chrom_active(c);
+    const u32 tl = t - c.tileBase;
+    const u32 pos0 = tl << TB;
+    const bool lastTile = tl + 1 == c.nTiles;
+    const u32 rb = tileOff[t], re = tileOff[t + 1];
+    const int carry = tilePrefW[t] - tilePrefW[c.tileBase];
+    __syncthreads();
+    // accumulate this tile's endpoint records
+    for (u32 i = rb + threadIdx.x; i < re; i += TL_NT) {
+      u64 r = recs[i];
+      u32 off = (u32)(r >> 8) & (TILE - 1);
+      atomicAdd(&delta[off + (off >> 5)], (int)(int8_t)(r & 0xFF));
+    }
+    __syncthreads();
+    // blocked read: thread i owns bases [32 i, 32 i + 32)
+    int d[TL_EPT];
+    int sum = 0;
+    u32 cnt = 0, sat = 0;
+    const int lbase = threadIdx.x * 33;
 #pragma unroll
-  for (int k = 0; k < TL_EPT; k++) {
-    d[k] = delta[lbase + k];
-    sum += d[k];
-    cnt += (d[k] != 0) && (pos0 + threadIdx.x * TL_EPT + k != 0);
-    sat |= (u32)(d[k] >= 32767 * GX_UNIT) | (u32)(d[k] <= -32768 * GX_UNIT);
-  }
-  if (lastTile && threadIdx.x == TL_NT - 1 && active) cnt += 1;  // closing interval [.., len)
-  if (!active) cnt = 0;
-  int sumTot;
-  u32 cntTot;
-  int exSum = block_excl_scan<int, TL_NT>(sum, scr, &sumTot);
-  u32 exCnt = block_excl_scan<u32, TL_NT>(cnt, reinterpret_cast<u32*>(scr), &cntTot);
-  // output position of this tile = exclusive prefix of interval counts over earlier tiles
-  if (threadIdx.x < 64) {
-    u64 excl = lookback_excl(lb, t, (u64)cntTot, st);
-    if (threadIdx.x == 0) {
-      scr[17] = (int)(u32)excl;
-      out.tileIvOff[t] = (u32)excl;
-      if (tl == 0) out.chromIvOff[ci] = (u32)excl;
-      if (t == nTiles - 1) {
-        out.tileIvOff[nTiles] = (u32)(excl + cntTot);
-        *out.nIv = (u32)(excl + cntTot);
+    for (int k = 0; k < TL_EPT; k++) {
+      d[k] = delta[lbase + k];
+      sum += d[k];
+      cnt += (d[k] != 0) && (pos0 + threadIdx.x * TL_EPT + k != 0);
+      sat |= (u32)(d[k] >= 32767 * GX_UNIT) | (u32)(d[k] <= -32768 * GX_UNIT);
+    }
+    if (lastTile && threadIdx.x == TL_NT - 1) cnt += 1;  // closing interval [.., len)
+    if (!active) cnt = 0;
+    // fused block scan of (sum, cnt): two DPP wave scans, one cross-wave step
+    const int incS = dpp_scan_add(sum);
+    const u32 incC = (u32)dpp_scan_add((int)cnt);
+    if (lane_id() == 63) { scr[wv] = incS; scr[16 + wv] = (int)incC; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      int xs = threadIdx.x < TL_NW ? scr[threadIdx.x] : 0;
+      int xc = threadIdx.x < TL_NW ? scr[16 + threadIdx.x] : 0;
+      int is = dpp_scan_add(xs), ic = dpp_scan_add(xc);
+      if (threadIdx.x < TL_NW) { scr[threadIdx.x] = is - xs; scr[16 + threadIdx.x] = ic - xc; }
+      const u32 cntTot = (u32)__shfl(ic, TL_NW - 1, 64);
+      // output position of this tile = exclusive prefix of interval counts over earlier tiles
+      u64 excl = lookback_excl(lb, t, (u64)cntTot, st);
+      if (threadIdx.x == 0) {
+        scr[32] = (int)(u32)excl;
+        out.tileIvOff[t] = (u32)excl;
+        if (tl == 0) out.chromIvOff[ci] = (u32)excl;
+        if (t == nTiles - 1) {
+          out.tileIvOff[nTiles] = (u32)(excl + cntTot);
+          *out.nIv = (u32)(excl + cntTot);
+        }
       }
     }
-  }
-  __syncthreads();
-  if (!active) return;
-  // emit
-  int run = tileCarry[t] + exSum;
-  u32 o = (u32)scr[17] + exCnt;
-  u32 neg = 0;
+    __syncthreads();
+    if (active) {  // block-uniform
+      int run = carry + (incS - sum) + scr[wv];
+      u32 o = (u32)scr[32] + (incC - cnt) + (u32)scr[16 + wv];
+      u32 neg = 0;
 #pragma unroll
-  for (int k = 0; k < TL_EPT; k++) {
-    u32 p = pos0 + threadIdx.x * TL_EPT + k;
-    if (d[k] != 0 && p != 0) {
-      out.ivEnd[o] = p;
-      out.ivV[o] = run;
-      o++;
+      for (int k = 0; k < TL_EPT; k++) {
+        u32 p = pos0 + threadIdx.x * TL_EPT + k;
+        if (d[k] != 0 && p != 0) {
+          out.ivEnd[o] = p;
+          out.ivV[o] = run;
+          o++;
+        }
+        run += d[k];
+        neg |= (u32)(run < 0);
+      }
+      if (lastTile && threadIdx.x == TL_NT - 1) {
+        out.ivEnd[o] = c.len;
+        out.ivV[o] = run;
+      }
+      bad |= (neg ? ST_NEG_PILE : 0) | (sat ? ST_SAT16 : 0);
     }
-    run += d[k];
-    neg |= (u32)(run < 0);
+    __syncthreads();  // scr and the slice are reused by the next tile
   }
-  if (lastTile && threadIdx.x == TL_NT - 1) {
-    out.ivEnd[o] = c.len;
-    out.ivV[o] = run;
-  }
-  u32 bad = (neg ? ST_NEG_PILE : 0) | (sat ? ST_SAT16 : 0);
   if (bad) atomicOr(st, bad);
 }
 

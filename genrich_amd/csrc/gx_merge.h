@@ -42,19 +42,16 @@ __device__ __forceinline__ float ctrl_net(int v, float factor, float lambda, boo
 
 __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalars* __restrict__ sc,
                                                   const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
-                                                  u32 nTiles, u32* __restrict__ ticket, u64* __restrict__ lb,
+                                                  u32 nTiles, u64* __restrict__ lb,
                                                   Merge2Out out, u32* __restrict__ st) {
   __shared__ u32 bmA[MG_WORDS], bmB[MG_WORDS], bmC[MG_WORDS];
   __shared__ u32 scratch[8];
-  __shared__ u32 s_id, s_base;
+  __shared__ u32 s_base;
   const float factor = sc->factor, lambda = sc->lambda;
-  for (;;) {
+  for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {  // persistent, round-robin (see lookback_excl)
     __syncthreads();
-    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
     for (int i = threadIdx.x; i < MG_WORDS; i += MG_NT) { bmA[i] = 0; bmB[i] = 0; bmC[i] = 0; }
     __syncthreads();
-    const u32 t = s_id;
-    if (t >= nTiles) return;
     const u32 ci = tileChrom[t];
     const DChrom c = chroms[ci];
     const bool active = chrom_active(c);
@@ -173,19 +170,16 @@ struct MergeNOut {
 
 __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restrict__ tileChrom,
                                                   const DChrom* __restrict__ chroms, u32 nTiles,
-                                                  u32* __restrict__ ticket, u64* __restrict__ lb, MergeNOut out,
+                                                  u64* __restrict__ lb, MergeNOut out,
                                                   u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) u32 bm[];  // S.n bitmaps of MG_WORDS words
   __shared__ u32 scratch[8];
-  __shared__ u32 s_id, s_base;
+  __shared__ u32 s_base;
   const int n = S.n;
-  for (;;) {
+  for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {  // persistent, round-robin
     __syncthreads();
-    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
     for (int i = threadIdx.x; i < n * MG_WORDS; i += MG_NT) bm[i] = 0;
     __syncthreads();
-    const u32 t = s_id;
-    if (t >= nTiles) return;
     const u32 ci = tileChrom[t];
     const DChrom c = chroms[ci];
     const u32 tl = t - c.tileBase, pos0 = tl << TB;

@@ -280,22 +280,18 @@ constexpr int SW_CHUNK = SW_NT * SW_ITEMS;
 __global__ __launch_bounds__(SW_NT) void k_sweep_compact(const u32* __restrict__ end, const float* __restrict__ p,
                                                          const float* __restrict__ q, const u32* __restrict__ chromOff,
                                                          u32 nChrom, const u32* __restrict__ nPtr, float thr,
-                                                         u32* __restrict__ ticket, u64* __restrict__ lb, SweepList out,
+                                                         u64* __restrict__ lb, SweepList out,
                                                          u32 cap, u32* __restrict__ st) {
   __shared__ u32 scratch[8];
-  __shared__ u32 s_id, s_base;
+  __shared__ u32 s_base;
   const u32 n = *nPtr;
   const u32 nChunks = (n + SW_CHUNK - 1) / SW_CHUNK;
   if (nChunks == 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *out.count = 0;
     return;
   }
-  for (;;) {
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {  // persistent, round-robin
     __syncthreads();
-    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const u32 id = s_id;
-    if (id >= nChunks) return;
     const u32 i0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
     float pv[SW_ITEMS], qv[SW_ITEMS];
     u32 keep = 0, cnt = 0;
@@ -349,23 +345,19 @@ __device__ __forceinline__ bool sweep_is_head(const SweepList& L, u32 j, int max
   return gap != 0 && gap > (long long)maxGap;
 }
 
-__global__ __launch_bounds__(SW_NT) void k_sweep_heads(SweepList L, int maxGap, u32* __restrict__ ticket,
+__global__ __launch_bounds__(SW_NT) void k_sweep_heads(SweepList L, int maxGap,
                                                        u64* __restrict__ lb, u32* __restrict__ headPos,
                                                        u32* __restrict__ nHeads, u32* __restrict__ st) {
   __shared__ u32 scratch[8];
-  __shared__ u32 s_id, s_base;
+  __shared__ u32 s_base;
   const u32 M = *L.count;
   const u32 nChunks = (M + SW_CHUNK - 1) / SW_CHUNK;
   if (nChunks == 0) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *nHeads = 0;
     return;
   }
-  for (;;) {
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
     __syncthreads();
-    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const u32 id = s_id;
-    if (id >= nChunks) return;
     const u32 j0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
     u32 keep = 0, cnt = 0;
 #pragma unroll
@@ -470,12 +462,12 @@ __global__ __launch_bounds__(256) void k_peak_walk(SweepList L, const u32* __res
 
 // ordered compaction of the candidates that passed checkPeak
 __global__ __launch_bounds__(SW_NT) void k_peak_compact(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
-                                                        const u32* __restrict__ nHeads, u32* __restrict__ ticket,
+                                                        const u32* __restrict__ nHeads,
                                                         u64* __restrict__ lb, gx_peak* __restrict__ peaks,
                                                         u32* __restrict__ nPeaks, u64* __restrict__ peakBP,
                                                         u32* __restrict__ st) {
   __shared__ u32 scratch[8];
-  __shared__ u32 s_id, s_base;
+  __shared__ u32 s_base;
   const u32 H = *nHeads;
   const u32 nChunks = (H + SW_NT - 1) / SW_NT;
   if (nChunks == 0) {
@@ -483,12 +475,8 @@ __global__ __launch_bounds__(SW_NT) void k_peak_compact(const gx_peak* __restric
     return;
   }
   u64 bp = 0;
-  for (;;) {
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
     __syncthreads();
-    if (threadIdx.x == 0) s_id = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const u32 id = s_id;
-    if (id >= nChunks) break;
     u32 h = id * SW_NT + threadIdx.x;
     u32 v = h < H ? valid[h] : 0;
     u32 tot;
