@@ -91,12 +91,13 @@ struct gx_ctx {
   struct Seg { const gx_event* p; size_t n; };
   std::vector<Seg> segs;
   DevBuf recsA, recsB, sbHist, sbOff, sbCursor, sbChunkOff, tileCnt, tileWsum, tileOff, tileCursor,
-      tileCarry, lb, misc, dScal, dStatus;
+      tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};
   std::vector<PArray> reps;
   int finalIdx = -1;
   // BH
+  DevBuf pvLut;
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp;
   // sweep
   DevBuf swChrom, swStart, swEnd, swP, swQ, swSig, cand, valid, peaks, lb2, headPos;
@@ -246,7 +247,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(ctx->tileOff.ensure((size_t)(nTiles + 2) * 4));
   HIPCHECK(ctx->tileCursor.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
-  HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 1) * 8));
+  HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 8) * 8));
   // an interval closes at every base with a non-zero difference (<= one per record) plus one per chromosome
   const size_t ivCap = (size_t)nRec + nChrom + 16;
   HIPCHECK(pooled(ctx, out.ivEnd, ivCap * 4));
@@ -300,26 +301,40 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");
-  TileOut to{out.ivEnd.as<u32>(), out.ivV.as<int>(), out.tileIvOff.as<u32>(), out.chromIvOff.as<u32>(),
-             ctx->misc.as<u32>() + M_NIV};
+  const size_t looseCap = (size_t)nRec + nTiles + 16;  // slot of tile t starts at tileOff[t] + t
+  HIPCHECK(ctx->looseEnd.ensure(looseCap * 4));
+  HIPCHECK(ctx->looseV.ensure(looseCap * 4));
+  HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->tileLastEnd.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->tilePrevEnd.ensure((size_t)(nTiles + 1) * 4));
+  TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>()};
   const size_t ldsBytes = (size_t)(TL_PAD + TL_SCR) * 4;
-  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 1) * 8, s));  // k_scan_tiles used the first entries
   hipLaunchKernelGGL(k_tile, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s,
                      ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
-                     ctx->dChrom.as<DChrom>(), nTiles, ctx->lb.as<u64>(), to, ctx->dStatus.as<u32>());
+                     ctx->dChrom.as<DChrom>(), nTiles, to, ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
+  phase_end(ctx);
+
+  phase_begin(ctx, isCtrl ? "c.pack" : "t.pack");
+  const u32 ivChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(2 * ivChunks + 2) * 8, s));
+  IvScanOut so{out.tileIvOff.as<u32>(), ctx->tilePrevEnd.as<u32>(), out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV};
+  hipLaunchKernelGGL(k_scan_iv, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
+                     ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
+                     ctx->dChrom.as<DChrom>(), nTiles, ctx->lb.as<u64>(), ctx->lb.as<u64>() + ivChunks + 1, so,
+                     ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_scan_iv")) return rc__;
   hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
                      ctx->misc.as<u32>() + M_NIV);
   if (int rc__ = dbg_sync(ctx, "k_fix_chrom_off")) return rc__;
-  phase_end(ctx);
-
-  phase_begin(ctx, isCtrl ? "c.fraglen" : "t.fraglen");
   Scalars* ds = ctx->dScal.as<Scalars>();
   long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
   HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
-  hipLaunchKernelGGL(k_fraglen, dim3(2048), dim3(256), 0, s, out.ivEnd.as<u32>(), out.ivV.as<int>(),
-                     out.chromIvOff.as<u32>(), nChrom, ctx->misc.as<u32>() + M_NIV, acc, ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_fraglen")) return rc__;
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileOff.as<u32>(), out.tileIvOff.as<u32>(),
+             ctx->tilePrevEnd.as<u32>()};
+  hipLaunchKernelGGL(k_pack, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, pin, nTiles,
+                     out.ivEnd.as<u32>(), out.ivV.as<int>(), acc, ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_pack")) return rc__;
   phase_end(ctx);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(&out.nIv, ctx->misc.as<u32>() + M_NIV, 4, hipMemcpyDeviceToHost, s));
@@ -410,7 +425,7 @@ int gx_create(gx_ctx** out, const gx_params* par) {
     ctx->resTile = std::max(1, nb) * ctx->numCU;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_merge2, MG_NT, 0));
     ctx->resMerge = std::max(1, std::min(nb, 4)) * ctx->numCU;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_sweep_compact, SW_NT, 0));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scan_iv, STL_NT, 0));
     ctx->resSweep = std::max(1, std::min(nb, 4)) * ctx->numCU;
   }
   HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -626,9 +641,11 @@ int gx_pvalues(gx_ctx* ctx) {
     HIPCHECK(pooled(ctx, pa.p, (size_t)n * 4 + 16));
     HIPCHECK(pooled(ctx, pa.expt, (size_t)n * 4 + 16));
     phase_begin(ctx, "pval");
-    hipLaunchKernelGGL(k_pval_const, dim3(std::max(1u, std::min((n + 255) / 256, 4096u))), dim3(256), 0, s,
-                       ctx->expt.ivV.as<int>(), ctx->misc.as<u32>() + M_NIV, ctx->dScal.as<Scalars>(), pa.p.as<float>(),
-                       pa.expt.as<float>(), ctx->dStatus.as<u32>());
+    HIPCHECK(ctx->pvLut.ensure((size_t)PV_LUT * 4));
+    hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>());
+    hipLaunchKernelGGL(k_pval_const, dim3(std::max(1u, std::min((n + 255) / 256, 8192u))), dim3(256), 0, s,
+                       ctx->expt.ivV.as<int>(), ctx->misc.as<u32>() + M_NIV, ctx->dScal.as<Scalars>(),
+                       ctx->pvLut.as<float>(), pa.p.as<float>(), pa.expt.as<float>(), ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_pval_const")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
@@ -796,65 +813,60 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   // peak sweep
   phase_begin(ctx, "sweep");
   const u32 nChunks = (n + SW_CHUNK - 1) / SW_CHUNK;
-  // three look-back arrays: compact (<= nChunks), heads (<= nChunks), peaks (<= M/256 + 1, M <= n)
-  const size_t lbWords = (size_t)nChunks * 2 + (size_t)n / SW_NT + 8;
-  HIPCHECK(ctx->lb2.ensure(lbWords * 8));
-  HIPCHECK(hipMemsetAsync(ctx->lb2.p, 0, lbWords * 8, s));
-  HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 12, s));  // ticket2, swcount, npeaks
+  // chunk count / offset scratch: one region per compaction (intervals, list entries, heads)
+  HIPCHECK(ctx->lb2.ensure(((size_t)nChunks * 6 + 64) * 4));
+  u32* cnt1 = ctx->lb2.as<u32>();
+  u32* off1 = cnt1 + nChunks + 8;
+  u32* cnt2 = off1 + nChunks + 8;
+  u32* off2 = cnt2 + nChunks + 8;
+  u32* cnt3 = off2 + nChunks + 8;
+  u32* off3 = cnt3 + nChunks + 8;
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 12, s));  // (unused), swcount, npeaks
   HIPCHECK(hipMemsetAsync(misc + M_PEAKBP, 0, 8, s));
-  HIPCHECK(hipMemsetAsync(misc + M_TICKET3, 0, 12, s));  // ticket3, ticket4, nheads
-  // entries kept by the compaction are a small fraction of the intervals; start from a guess and
-  // regrow in the (rare) case the device reports more
-  size_t mCap = std::max<size_t>(ctx->swChrom.cap / 4, (size_t)n / 8 + 1024);
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET3, 0, 12, s));  // (unused), (unused), nheads
+  const float* qPtr = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
   u32 M = 0, nPeaks = 0;
   ctx->peakBP = 0;
-  for (int attempt = 0; attempt < 2; attempt++) {
+  if (nChunks) {
+    hipLaunchKernelGGL(k_sweep_count, dim3(nChunks), dim3(SW_NT), 0, s, fa.p.as<float>(), qPtr, misc + M_NIV,
+                       ctx->par.thr, cnt1);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt1, (const u32*)nullptr, nChunks, (u32)SW_CHUNK, off1,
+                       misc + M_SWCOUNT);
+    HIPCHECK(hipMemcpyAsync(&M, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));  // the list is sized exactly (it is ~1-2 % of the intervals)
+  }
+  if (M) {
+    const size_t mCap = (size_t)M + 16;
     HIPCHECK(ctx->swChrom.ensure(mCap * 4));
     HIPCHECK(ctx->swStart.ensure(mCap * 4));
     HIPCHECK(ctx->swEnd.ensure(mCap * 4));
     HIPCHECK(ctx->swP.ensure(mCap * 4));
     HIPCHECK(ctx->swQ.ensure(mCap * 4));
     HIPCHECK(ctx->swSig.ensure(mCap * 4));
-    mCap = ctx->swChrom.cap / 4;
     SweepList L{ctx->swChrom.as<u32>(), ctx->swStart.as<u32>(), ctx->swEnd.as<u32>(), ctx->swP.as<float>(),
                 ctx->swQ.as<float>(), ctx->swSig.as<u32>(), misc + M_SWCOUNT};
-    // count first (cap = 0 writes nothing) would cost a second pass; instead the kernel bounds its
-    // writes by the capacity and always reports the true count
-    hipLaunchKernelGGL(k_sweep_compact, dim3(std::max(1u, std::min(nChunks, (u32)ctx->resSweep))), dim3(SW_NT), 0, s,
-                       fa.end.as<u32>(), fa.p.as<float>(), ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr,
-                       fa.chromOff.as<u32>(), nChrom, misc + M_NIV, ctx->par.thr, ctx->lb2.as<u64>(), L,
-                       (u32)std::min<size_t>(mCap, 0xFFFFFFFFu), ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_sweep_compact")) return rc__;
-    HIPCHECK(hipMemcpyAsync(&M, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    if (M <= mCap) break;
-    mCap = (size_t)M + M / 8 + 1024;  // redo with room for everything
-    HIPCHECK(hipMemsetAsync(ctx->lb2.p, 0, lbWords * 8, s));
-    HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 8, s));
-  }
-  if (M) {
-    SweepList L{ctx->swChrom.as<u32>(), ctx->swStart.as<u32>(), ctx->swEnd.as<u32>(), ctx->swP.as<float>(),
-                ctx->swQ.as<float>(), ctx->swSig.as<u32>(), misc + M_SWCOUNT};
-    // heads <= significant entries; candidates and peaks <= heads
+    hipLaunchKernelGGL(k_sweep_write, dim3(nChunks), dim3(SW_NT), 0, s, fa.end.as<u32>(), fa.p.as<float>(), qPtr,
+                       fa.chromOff.as<u32>(), nChrom, misc + M_NIV, ctx->par.thr, off1, L);
+    // heads <= list entries; candidates and peaks <= heads
     HIPCHECK(ctx->headPos.ensure((size_t)M * 4 + 16));
     HIPCHECK(ctx->cand.ensure((size_t)M * sizeof(gx_peak)));
     HIPCHECK(ctx->valid.ensure((size_t)M * 4 + 16));
     HIPCHECK(ctx->peaks.ensure((size_t)M * sizeof(gx_peak)));
-    u64* lbHeads = ctx->lb2.as<u64>() + nChunks;
-    u64* lbPeaks = ctx->lb2.as<u64>() + 2 * (size_t)nChunks;
     const u32 mChunks = (M + SW_CHUNK - 1) / SW_CHUNK;
-    hipLaunchKernelGGL(k_sweep_heads, dim3(std::min(mChunks, (u32)ctx->resSweep)), dim3(SW_NT), 0, s, L, ctx->par.max_gap,
-                       lbHeads, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_sweep_heads")) return rc__;
-    hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((M + 3) / 4, 4096u))), dim3(256), 0, s, L,
+    hipLaunchKernelGGL(k_heads_count, dim3(mChunks), dim3(SW_NT), 0, s, L, ctx->par.max_gap, cnt2);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt2, (const u32*)nullptr, mChunks, (u32)SW_CHUNK, off2,
+                       misc + M_NHEADS);
+    hipLaunchKernelGGL(k_heads_write, dim3(mChunks), dim3(SW_NT), 0, s, L, ctx->par.max_gap, off2, ctx->headPos.as<u32>());
+    hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((M + 3) / 4, 8192u))), dim3(256), 0, s, L,
                        ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
                        ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_peak_walk")) return rc__;
-    hipLaunchKernelGGL(k_peak_compact, dim3(std::max(1u, std::min((M + SW_NT - 1) / SW_NT, (u32)ctx->resSweep))),
-                       dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(), misc + M_NHEADS, lbPeaks,
-                       ctx->peaks.as<gx_peak>(), misc + M_NPEAKS, reinterpret_cast<u64*>(misc + M_PEAKBP),
-                       ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_peak_compact")) return rc__;
+    // heads H <= M: chunk arrays sized by M's chunk count; kernels bound themselves by *nHeads
+    hipLaunchKernelGGL(k_peaks_count, dim3(mChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt3, misc + M_NHEADS, mChunks, (u32)SW_CHUNK, off3,
+                       misc + M_NPEAKS);
+    hipLaunchKernelGGL(k_peaks_write, dim3(mChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
+                       misc + M_NHEADS, off3, ctx->peaks.as<gx_peak>(), reinterpret_cast<u64*>(misc + M_PEAKBP));
+    if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
     HIPCHECK(hipMemcpyAsync(&nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(&ctx->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));

@@ -456,14 +456,17 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const u64* __restrict__ in, con
 
 // ---- 4. the tile kernel: LDS difference array -> prefix sum -> run-length pileup -----------
 // Replaces savePileupExpt's two per-base passes (Genrich.c:2197-2273; and the per-base walk
-// of calcFactor/savePileupCtrl for a control).  One workgroup owns one tile:
+// of calcFactor/savePileupCtrl for a control).  One workgroup owns one tile at a time:
 //   zero the LDS slice; add every endpoint record of the tile (ds_add, integer);
-//   blocked prefix sum (32 bases per thread, wave shuffles + one cross-wave step);
+//   blocked prefix sum (32 bases per thread, DPP wave scans + one cross-wave step);
 //   a base j >= 1 with a non-zero difference closes the interval [.., j) whose value is the
 //   prefix BEFORE j (:2241-2251); the chromosome's last tile also closes [.., len) (:2268).
-// The output position of a tile's intervals is a prefix sum over tiles, obtained in the same
-// launch by a decoupled look-back over 8-byte {flag, value} granules (one relaxed agent-scope
-// store/load each).  Persistent: workgroup b handles tiles b, b + gridDim, b + 2 gridDim, ...
+// No inter-workgroup dependency: a tile writes its intervals into its own slot of a LOOSE
+// array (slot t starts at tileOff[t] + t: a tile cannot close more intervals than it has
+// endpoint records, plus the chromosome-closing one) and reports how many it wrote.
+// k_scan_iv then turns the counts into tight offsets and k_pack packs the slots.  (A fused
+// decoupled look-back was measured first: with ~512 resident tiles the look-back distance made
+// it latency-bound at ~10 us per tile.)
 constexpr int TL_NT = 512;
 constexpr int TL_NW = TL_NT / 64;
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
@@ -471,11 +474,10 @@ constexpr int TL_PAD = TILE + TILE / 32;          // +1 dword per 32: conflict-f
 constexpr int TL_SCR = 64;                        // scratch ints after the slice
 
 struct TileOut {
-  u32* ivEnd;       // interval end (chromosome coordinate)
-  int* ivV;         // pileup in 1/120 units
-  u32* tileIvOff;   // [nTiles+1] first interval of each tile
-  u32* chromIvOff;  // [nChrom+1] first interval of each chromosome
-  u32* nIv;         // total
+  u32* looseEnd;    // interval end (chromosome coordinate), loose slots
+  int* looseV;      // pileup in 1/120 units
+  u32* tileCount;   // [nTiles] intervals written by each tile
+  u32* tileLastEnd; // [nTiles] end of the tile's last interval (valid when tileCount > 0)
 };
 
 __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
@@ -483,11 +485,10 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
                                                    const int* __restrict__ tilePrefW,
                                                    const u32* __restrict__ tileChrom,
                                                    const DChrom* __restrict__ chroms, u32 nTiles,
-                                                   u64* __restrict__ lb, TileOut out,
-                                                   u32* __restrict__ st) {
+                                                   TileOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
   int* delta = lds;                        // TL_PAD ints (no static LDS: keeps the base 16-B aligned)
-  int* scr = lds + TL_PAD;                 // [0..8] sums, [16..24] counts, [32] output base
+  int* scr = lds + TL_PAD;                 // [0..8] sums, [16..24] counts
   const int wv = threadIdx.x >> 6;
   u32 bad = 0;
   for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {
@@ -522,60 +523,244 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
       cnt += (d[k] != 0) && (pos0 + threadIdx.x * TL_EPT + k != 0);
       sat |= (u32)(d[k] >= 32767 * GX_UNIT) | (u32)(d[k] <= -32768 * GX_UNIT);
     }
-    if (lastTile && threadIdx.x == TL_NT - 1) cnt += 1;  // closing interval [.., len)
     if (!active) cnt = 0;
     // fused block scan of (sum, cnt): two DPP wave scans, one cross-wave step
     const int incS = dpp_scan_add(sum);
     const u32 incC = (u32)dpp_scan_add((int)cnt);
     if (lane_id() == 63) { scr[wv] = incS; scr[16 + wv] = (int)incC; }
     __syncthreads();
-    if (threadIdx.x < 64) {
-      int xs = threadIdx.x < TL_NW ? scr[threadIdx.x] : 0;
-      int xc = threadIdx.x < TL_NW ? scr[16 + threadIdx.x] : 0;
-      int is = dpp_scan_add(xs), ic = dpp_scan_add(xc);
-      if (threadIdx.x < TL_NW) { scr[threadIdx.x] = is - xs; scr[16 + threadIdx.x] = ic - xc; }
-      const u32 cntTot = (u32)__shfl(ic, TL_NW - 1, 64);
-      // output position of this tile = exclusive prefix of interval counts over earlier tiles
-      u64 excl = lookback_excl(lb, t, (u64)cntTot, st);
-      if (threadIdx.x == 0) {
-        scr[32] = (int)(u32)excl;
-        out.tileIvOff[t] = (u32)excl;
-        if (tl == 0) out.chromIvOff[ci] = (u32)excl;
-        if (t == nTiles - 1) {
-          out.tileIvOff[nTiles] = (u32)(excl + cntTot);
-          *out.nIv = (u32)(excl + cntTot);
-        }
-      }
+    int preS = 0;
+    u32 preC = 0, totC = 0;
+#pragma unroll
+    for (int w = 0; w < TL_NW; w++) {  // 8 waves: every thread sums the wave totals it needs
+      int ws = scr[w];
+      u32 wc = (u32)scr[16 + w];
+      if (w < wv) { preS += ws; preC += wc; }
+      totC += wc;
     }
-    __syncthreads();
     if (active) {  // block-uniform
-      int run = carry + (incS - sum) + scr[wv];
-      u32 o = (u32)scr[32] + (incC - cnt) + (u32)scr[16 + wv];
-      u32 neg = 0;
+      int run = carry + preS + (incS - sum);
+      const u32 o0 = rb + t + preC + (incC - cnt);
+      const u32 totFinal = totC + (lastTile ? 1u : 0u);
+      u32 o = o0, neg = 0, lastEnd = 0;
 #pragma unroll
       for (int k = 0; k < TL_EPT; k++) {
         u32 p = pos0 + threadIdx.x * TL_EPT + k;
         if (d[k] != 0 && p != 0) {
-          out.ivEnd[o] = p;
-          out.ivV[o] = run;
+          out.looseEnd[o] = p;
+          out.looseV[o] = run;
+          lastEnd = p;
           o++;
         }
         run += d[k];
         neg |= (u32)(run < 0);
       }
-      if (lastTile && threadIdx.x == TL_NT - 1) {
-        out.ivEnd[o] = c.len;
-        out.ivV[o] = run;
+      if (lastTile && threadIdx.x == TL_NT - 1) {  // closing interval [.., len)
+        out.looseEnd[o] = c.len;
+        out.looseV[o] = run;
+        lastEnd = c.len;
+        o++;
       }
+      if (o != o0 && o == rb + t + totFinal) out.tileLastEnd[t] = lastEnd;  // wrote the tile's last interval
+      if (threadIdx.x == 0) out.tileCount[t] = totFinal;
       bad |= (neg ? ST_NEG_PILE : 0) | (sat ? ST_SAT16 : 0);
+    } else if (threadIdx.x == 0) {
+      out.tileCount[t] = 0;
     }
     __syncthreads();  // scr and the slice are reused by the next tile
   }
   if (bad) atomicOr(st, bad);
 }
 
-// chromosome table epilogue of the tile kernel: chromIvOff for chromosomes without tiles
-// (inactive ones get an empty range) -- single thread, nChrom is small.
+// tile interval counts -> tight offsets (sum scan) and, per tile, the end of the last interval
+// that precedes it on the same chromosome (max scan over (chromosome, end) keys).  Persistent
+// multi-workgroup chained scan, 2048 tiles per item; also fills chromIvOff for tiled
+// chromosomes and the total.
+__device__ __forceinline__ u64 lookback_excl_max(u64* lb, u32 id, u64 aggregate, u32* st) {
+  // same protocol as lookback_excl with max instead of +
+  u64 excl = 0;
+  if (id > 0) {
+    if (lane_id() == 0)
+      __hip_atomic_store(&lb[id], LB_AGG | (aggregate & LB_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int look = (int)id - 1;
+    u32 spins = 0;
+    bool done = false;
+    while (!done) {
+      int idx = look - lane_id();
+      u64 v = idx >= 0 ? __hip_atomic_load(&lb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_INC;
+      u64 flag = v >> 62;
+      u64 invalidMask = __ballot(flag == 0);
+      u64 incMask = __ballot(flag == 2);
+      int firstInvalid = invalidMask ? __builtin_ctzll(invalidMask) : 64;
+      int firstInc = incMask ? __builtin_ctzll(incMask) : 64;
+      int take = firstInc < firstInvalid ? firstInc + 1 : firstInvalid;
+      if (take > 0) {
+        u64 m = lane_id() < take ? (v & LB_MASK) : 0ull;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          u64 o = __shfl_xor(m, d, 64);
+          m = o > m ? o : m;
+        }
+        excl = m > excl ? m : excl;
+        if (firstInc < firstInvalid) done = true; else look -= firstInvalid;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        bool abort_ = spins > LB_SPIN_LIMIT;
+        if (!abort_ && (spins & 1023u) == 0)
+          abort_ = (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_LOOKBACK) != 0;
+        if (abort_) {
+          if (lane_id() == 0) atomicOr(st, ST_LOOKBACK);
+          done = true;
+        }
+      }
+    }
+  }
+  u64 inc = aggregate > excl ? aggregate : excl;
+  if (lane_id() == 0)
+    __hip_atomic_store(&lb[id], LB_INC | (inc & LB_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
+struct IvScanOut {
+  u32* tileIvOff;   // [nTiles+1]
+  u32* tilePrevEnd; // [nTiles] start of the tile's first interval
+  u32* chromIvOff;  // [nChrom+1] (entries of chromosomes without tiles are filled by k_fix_chrom_off)
+  u32* nIv;
+};
+
+__global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
+                                                    const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+                                                    u32 nTiles, u64* __restrict__ lbSum, u64* __restrict__ lbMax,
+                                                    IvScanOut out, u32* __restrict__ st) {
+  __shared__ u32 scratch[8];
+  __shared__ u64 s64[8];
+  __shared__ u64 s_sum, s_max;
+  const u32 nChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
+    const u32 tb = id * STL_CHUNK + threadIdx.x * STL_ITEMS;
+    u32 c[STL_ITEMS];
+    u64 key[STL_ITEMS];
+    u32 cs = 0;
+    u64 km = 0;
+#pragma unroll
+    for (int k = 0; k < STL_ITEMS; k++) {
+      u32 t = tb + k;
+      c[k] = t < nTiles ? tileCount[t] : 0;
+      // key of a tile with intervals: (chromosome + 1, last end); 0 otherwise
+      key[k] = c[k] ? (((u64)(tileChrom[t] + 1) << 32) | tileLastEnd[t]) : 0ull;
+      cs += c[k];
+      km = key[k] > km ? key[k] : km;
+    }
+    u32 ctot;
+    u32 cex = block_excl_scan<u32, STL_NT>(cs, scratch, &ctot);
+    // exclusive max scan across the workgroup (shuffles: 64-bit keys)
+    u64 inc = km;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      u64 o = __shfl_up(inc, d, 64);
+      if (lane_id() >= d && o > inc) inc = o;
+    }
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 63) s64[wv] = inc;
+    __syncthreads();
+    u64 kex = __shfl_up(inc, 1, 64);
+    if (lane_id() == 0) kex = 0;
+    u64 ktot = 0;
+    for (int w = 0; w < STL_NT / 64; w++) {
+      u64 x = s64[w];
+      if (w < wv && x > kex) kex = x;
+      if (x > ktot) ktot = x;
+    }
+    if (threadIdx.x < 64) {
+      u64 es = lookback_excl(lbSum, id, (u64)ctot, st);
+      u64 em = lookback_excl_max(lbMax, id, ktot, st);
+      if (threadIdx.x == 0) {
+        s_sum = es;
+        s_max = em;
+        if (id == nChunks - 1) {
+          out.tileIvOff[nTiles] = (u32)es + ctot;
+          *out.nIv = (u32)es + ctot;
+        }
+      }
+    }
+    __syncthreads();
+    cex += (u32)s_sum;
+    if (s_max > kex) kex = s_max;
+#pragma unroll
+    for (int k = 0; k < STL_ITEMS; k++) {
+      u32 t = tb + k;
+      if (t < nTiles) {
+        u32 ci = tileChrom[t];
+        out.tileIvOff[t] = cex;
+        out.tilePrevEnd[t] = (u32)(kex >> 32) == ci + 1 ? (u32)kex : 0u;
+        if (t == chroms[ci].tileBase) out.chromIvOff[ci] = cex;
+      }
+      cex += c[k];
+      if (key[k] > kex) kex = key[k];
+    }
+    __syncthreads();
+  }
+}
+
+// loose slots -> tight arrays, and fragLen on the way.
+// savePileupExpt 2246/2271, calcFactor 2018/2038: `fragLen += (j - start) * val` is a float
+// product added into a double.  Every product is a multiple of 2^-27 (val >= 1/10 when
+// non-zero), so the sum is accumulated exactly in two int64 (integer part, fraction * 2^27):
+// deterministic for any launch geometry or rank count, and equal to the reference's double
+// sum whenever that sum is exact (always, for unit weights).
+struct PackIn {
+  const u32* looseEnd;
+  const int* looseV;
+  const u32* tileOff;      // record offsets (loose slot of tile t starts at tileOff[t] + t)
+  const u32* tileIvOff;
+  const u32* tilePrevEnd;
+};
+
+__global__ __launch_bounds__(256) void k_pack(PackIn in, u32 nTiles, u32* __restrict__ ivEnd, int* __restrict__ ivV,
+                                              long long* __restrict__ acc, u32* __restrict__ st) {
+  long long hi = 0, lo = 0;
+  u32 neg = 0;
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  // one wavefront per tile (a tile holds a few hundred intervals)
+  for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
+    const u32 src = in.tileOff[t] + t, dst = in.tileIvOff[t], n = in.tileIvOff[t + 1] - dst;
+    u32 prevEnd = in.tilePrevEnd[t];
+    for (u32 b = 0; b < n; b += 64) {
+      u32 i = b + lane;
+      u32 e = 0;
+      int v = 0;
+      if (i < n) {
+        e = in.looseEnd[src + i];
+        v = in.looseV[src + i];
+        ivEnd[dst + i] = e;
+        ivV[dst + i] = v;
+      }
+      u32 s = __shfl_up(e, 1, 64);
+      if (lane == 0) s = prevEnd;
+      prevEnd = __shfl(e, 63, 64);
+      if (i < n && v != 0) {
+        bool ng;
+        float val = getval(v, &ng);
+        neg |= ng;
+        float term = (float)(e - s) * val;
+        float fl = floorf(term);
+        hi += (long long)fl;
+        lo += (long long)((term - fl) * 134217728.0f);
+      }
+    }
+  }
+  hi = wave_sum(hi);
+  lo = wave_sum(lo);
+  if (lane == 0) {
+    if (hi) atomicAdd((u64*)&acc[0], (u64)hi);
+    if (lo) atomicAdd((u64*)&acc[1], (u64)lo);
+  }
+  if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// chromosome table epilogue: chromIvOff for chromosomes without tiles (inactive ones get an
+// empty range) -- single thread, nChrom is small.
 __global__ void k_fix_chrom_off(const DChrom* __restrict__ chroms, u32 nChrom, u32* __restrict__ chromIvOff,
                                 const u32* __restrict__ nIv) {
   if (threadIdx.x || blockIdx.x) return;
@@ -587,45 +772,6 @@ __global__ void k_fix_chrom_off(const DChrom* __restrict__ chroms, u32 nChrom, u
     else
       next = chromIvOff[c];
   }
-}
-
-// ---- 5. fragLen: sum over intervals of (float)(len * val), accumulated exactly ------------
-// savePileupExpt 2246/2271, calcFactor 2018/2038: `fragLen += (j - start) * val` is a float
-// product added into a double.  Every product is a multiple of 2^-27 (val >= 1/10 when
-// non-zero), so the sum is accumulated exactly in two int64 (integer part, fraction * 2^27):
-// deterministic for any launch geometry or rank count, and equal to the reference's double
-// sum whenever that sum is exact (always, for unit weights).
-__global__ __launch_bounds__(256) void k_fraglen(const u32* __restrict__ ivEnd, const int* __restrict__ ivV,
-                                                 const u32* __restrict__ chromIvOff, u32 nChrom,
-                                                 const u32* __restrict__ nIvPtr,
-                                                 long long* __restrict__ acc, u32* __restrict__ st) {
-  const u32 nIv = *nIvPtr;
-  long long hi = 0, lo = 0;
-  u32 neg = 0;
-  ChromCursor cur;
-  const u32 per = (nIv + gridDim.x - 1) / gridDim.x;  // blocked: one contiguous range per workgroup
-  const u32 b0 = blockIdx.x * per, b1 = min(nIv, b0 + per);
-  for (u32 i = b0 + threadIdx.x; i < b1; i += 256) {
-    int v = ivV[i];
-    if (v == 0) continue;
-    u32 e = ivEnd[i];
-    cur.seek(chromIvOff, nChrom, i);
-    u32 s = i == cur.lo ? 0 : ivEnd[i - 1];
-    bool ng;
-    float val = getval(v, &ng);
-    neg |= ng;
-    float term = (float)(e - s) * val;
-    float fl = floorf(term);
-    hi += (long long)fl;
-    lo += (long long)((term - fl) * 134217728.0f);
-  }
-  hi = wave_sum(hi);
-  lo = wave_sum(lo);
-  if (lane_id() == 0) {
-    if (hi) atomicAdd((u64*)&acc[0], (u64)hi);
-    if (lo) atomicAdd((u64*)&acc[1], (u64)lo);
-  }
-  if (neg) atomicOr(st, ST_NEG_PILE);
 }
 
 // scalars of one replicate, kept on the device so no host round trip sits between kernels

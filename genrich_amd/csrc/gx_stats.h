@@ -8,23 +8,49 @@ namespace gx {
 
 // ---- p-values, no control: savePileupNoCtrl + savePval (Genrich.c:1883-1896, 1720-1794) ----
 // The control pileup is the constant lambda, so the p-intervals are the treatment intervals.
+// With a constant control the p-value is a function of the exact pileup V alone, so it is
+// tabulated once per replicate for V < PV_LUT (pileups up to ~2184x; a 1 MiB table that stays in
+// L2) by the very same double-precision routine, and looked up per interval; larger V are
+// computed directly.  Same bits either way.
+constexpr u32 PV_LUT = 1u << 18;
+
+__device__ __forceinline__ float pval_of_v(int v, float lambda, double ml, double sl, float* valOut, bool* neg) {
+  float val = getval(v, neg);
+  *valOut = val;
+  if (lambda == 0.0f) return val == 0.0f ? 0.0f : FLT_MAX;  // calcPval 1631-1632
+  return val == 0.0f ? 0.0f : pval_given(val, ml, sl);
+}
+
+__global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc, float* __restrict__ lutP) {
+  const float lambda = sc->lambda;
+  double ml = 0, sl = 1;
+  if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
+  for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += gridDim.x * 256) {
+    float val;
+    bool ng;
+    lutP[v] = pval_of_v((int)v, lambda, ml, sl, &val, &ng);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_pval_const(const int* __restrict__ ivV, const u32* __restrict__ nIvPtr,
-                                                    const Scalars* __restrict__ sc, float* __restrict__ pOut,
-                                                    float* __restrict__ exptOut, u32* __restrict__ st) {
+                                                    const Scalars* __restrict__ sc, const float* __restrict__ lutP,
+                                                    float* __restrict__ pOut, float* __restrict__ exptOut,
+                                                    u32* __restrict__ st) {
   const u32 n = *nIvPtr;
   const float lambda = sc->lambda;
   double ml = 0, sl = 1;
   if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
   u32 neg = 0;
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int v = ivV[i];
     bool ng;
-    float val = getval(ivV[i], &ng);
+    float val, p;
+    if ((u32)v < PV_LUT) {
+      val = getval(v, &ng);
+      p = lutP[v];
+    } else
+      p = pval_of_v(v, lambda, ml, sl, &val, &ng);
     neg |= ng;
-    float p;
-    if (lambda == 0.0f)
-      p = val == 0.0f ? 0.0f : FLT_MAX;  // calcPval 1631-1632
-    else
-      p = val == 0.0f ? 0.0f : pval_given(val, ml, sl);
     pOut[i] = p;
     if (exptOut) exptOut[i] = val;
   }
@@ -255,14 +281,14 @@ __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, co
 // Only significant intervals (pq > thr, strict, 1015) and SKIP intervals matter: two significant
 // intervals belong to one candidate iff no SKIP interval lies between them and
 // start_next - end_prev <= maxGap (1031-1032).
-//   pass 1  k_sweep_compact : ordered compaction of {significant, SKIP} intervals (look-back)
-//   pass 2  k_sweep_heads   : ordered list of candidate heads (look-back)
+//   pass 1  k_sweep_count / k_sweep_write : ordered compaction of {significant, SKIP} intervals
+//   pass 2  k_heads_count / k_heads_write : ordered list of candidate heads
 //   pass 3  k_peak_walk     : one wavefront per candidate; the float AUC is summed strictly in
 //                             interval order (950) -- lanes load and form the products in
 //                             parallel, the additions are replayed serially through shuffles
-//   pass 4  k_peak_compact  : ordered compaction of the candidates passing checkPeak (916-927)
-// All four are persistent kernels that pull chunks by atomic ticket, so no list length ever
-// has to travel to the host between them.
+//   pass 4  k_peaks_count / k_peaks_write : ordered compaction of the candidates passing checkPeak (916-927)
+// Ordered compactions are count -> k_scan_small (chunk counts) -> write; list lengths stay on the
+// device (kernels read them through pointers), only the final peak count travels to the host.
 struct SweepList {
   u32* chrom;
   u32* start;
@@ -277,63 +303,88 @@ constexpr int SW_NT = 256;
 constexpr int SW_ITEMS = 8;
 constexpr int SW_CHUNK = SW_NT * SW_ITEMS;
 
-__global__ __launch_bounds__(SW_NT) void k_sweep_compact(const u32* __restrict__ end, const float* __restrict__ p,
-                                                         const float* __restrict__ q, const u32* __restrict__ chromOff,
-                                                         u32 nChrom, const u32* __restrict__ nPtr, float thr,
-                                                         u64* __restrict__ lb, SweepList out,
-                                                         u32 cap, u32* __restrict__ st) {
-  __shared__ u32 scratch[8];
-  __shared__ u32 s_base;
+// exclusive scan of a short u32 array (chunk counts) by one workgroup; total -> *total
+__global__ __launch_bounds__(1024) void k_scan_small(const u32* __restrict__ in, const u32* __restrict__ nPtr, u32 nMax,
+                                                     u32 chunk, u32* __restrict__ out, u32* __restrict__ total) {
+  __shared__ u32 scratch[20];
+  // n items = ceil(*nPtr / chunk) when nPtr is given (a device-side count), else nMax
+  u32 n = nPtr ? (*nPtr + chunk - 1) / chunk : nMax;
+  if (n > nMax) n = nMax;
+  const u32 per = (n + 1023) / 1024;
+  const u32 i0 = min(n, threadIdx.x * per), i1 = min(n, i0 + per);
+  u32 sum = 0;
+  for (u32 i = i0; i < i1; i++) sum += in[i];
+  u32 tot;
+  u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
+  for (u32 i = i0; i < i1; i++) {
+    u32 v = in[i];
+    out[i] = ex;
+    ex += v;
+  }
+  if (threadIdx.x == 0) *total = tot;
+}
+
+// pass 1a: how many {significant, SKIP} intervals per chunk of 2048
+__global__ __launch_bounds__(SW_NT) void k_sweep_count(const float* __restrict__ p, const float* __restrict__ q,
+                                                       const u32* __restrict__ nPtr, float thr, u32* __restrict__ chunkCnt) {
+  __shared__ u32 s_cnt[SW_NT / 64];
   const u32 n = *nPtr;
-  const u32 nChunks = (n + SW_CHUNK - 1) / SW_CHUNK;
-  if (nChunks == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *out.count = 0;
-    return;
-  }
-  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {  // persistent, round-robin
-    __syncthreads();
-    const u32 i0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
-    float pv[SW_ITEMS], qv[SW_ITEMS];
-    u32 keep = 0, cnt = 0;
+  const u32 i0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  if (blockIdx.x * SW_CHUNK >= n) return;
+  const float* pq = q ? q : p;
+  u32 cnt = 0;
 #pragma unroll
-    for (int k = 0; k < SW_ITEMS; k++) {
+  for (int k = 0; k < SW_ITEMS; k++) {
+    u32 i = i0 + k;
+    if (i < n) {
+      float v = pq[i];
+      cnt += (v > thr || v == GX_SKIPF);
+    }
+  }
+  cnt = wave_sum(cnt);
+  if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// pass 1b: ordered write of those intervals
+__global__ __launch_bounds__(SW_NT) void k_sweep_write(const u32* __restrict__ end, const float* __restrict__ p,
+                                                       const float* __restrict__ q, const u32* __restrict__ chromOff,
+                                                       u32 nChrom, const u32* __restrict__ nPtr, float thr,
+                                                       const u32* __restrict__ chunkOff, SweepList out) {
+  __shared__ u32 scratch[8];
+  const u32 n = *nPtr;
+  if (blockIdx.x * SW_CHUNK >= n) return;
+  const u32 i0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  float pv[SW_ITEMS], qv[SW_ITEMS];
+  u32 keep = 0, cnt = 0;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++) {
+    u32 i = i0 + k;
+    if (i < n) {
+      pv[k] = p[i];
+      qv[k] = q ? q[i] : GX_SKIPF;
+      float pq = q ? qv[k] : pv[k];
+      if (pq > thr || pq == GX_SKIPF) { keep |= 1u << k; cnt++; }
+    }
+  }
+  u32 tot;
+  u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
+  ChromCursor cur;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++)
+    if (keep & (1u << k)) {
       u32 i = i0 + k;
-      if (i < n) {
-        pv[k] = p[i];
-        qv[k] = q ? q[i] : GX_SKIPF;
-        float pq = q ? qv[k] : pv[k];
-        if (pq > thr || pq == GX_SKIPF) { keep |= 1u << k; cnt++; }
-      }
+      cur.seek(chromOff, nChrom, i);
+      float pq = q ? qv[k] : pv[k];
+      out.chrom[o] = cur.c;
+      out.start[o] = i == cur.lo ? 0 : end[i - 1];
+      out.end[o] = end[i];
+      out.p[o] = pv[k];
+      out.q[o] = qv[k];
+      out.sig[o] = pq == GX_SKIPF ? 0u : 1u;
+      o++;
     }
-    u32 tot;
-    u32 ex = block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
-    if (threadIdx.x < 64) {
-      u64 excl = lookback_excl(lb, id, (u64)tot, st);
-      if (threadIdx.x == 0) {
-        s_base = (u32)excl;
-        if (id == nChunks - 1) *out.count = (u32)(excl + tot);
-      }
-    }
-    __syncthreads();
-    // NOTE: no divergent `continue` here -- lanes that branch back to the barrier at the loop top
-    // separately from their wave-mates make the wave arrive twice (observed hang on gfx950).
-    u32 o = s_base + ex;
-    ChromCursor cur;
-#pragma unroll
-    for (int k = 0; k < SW_ITEMS; k++)
-      if ((keep & (1u << k)) && o < cap) {  // the true count is reported even when the list is full
-        u32 i = i0 + k;
-        cur.seek(chromOff, nChrom, i);
-        float pq = q ? qv[k] : pv[k];
-        out.chrom[o] = cur.c;
-        out.start[o] = i == cur.lo ? 0 : end[i - 1];
-        out.end[o] = end[i];
-        out.p[o] = pv[k];
-        out.q[o] = qv[k];
-        out.sig[o] = pq == GX_SKIPF ? 0u : 1u;
-        o++;
-      }
-  }
 }
 
 // head of a candidate: a significant interval that follows a SKIP marker, a chromosome
@@ -345,41 +396,41 @@ __device__ __forceinline__ bool sweep_is_head(const SweepList& L, u32 j, int max
   return gap != 0 && gap > (long long)maxGap;
 }
 
-__global__ __launch_bounds__(SW_NT) void k_sweep_heads(SweepList L, int maxGap,
-                                                       u64* __restrict__ lb, u32* __restrict__ headPos,
-                                                       u32* __restrict__ nHeads, u32* __restrict__ st) {
-  __shared__ u32 scratch[8];
-  __shared__ u32 s_base;
+// pass 2a / 2b: count and write candidate heads (list positions), chunked like pass 1
+__global__ __launch_bounds__(SW_NT) void k_heads_count(SweepList L, int maxGap, u32* __restrict__ chunkCnt) {
+  __shared__ u32 s_cnt[SW_NT / 64];
   const u32 M = *L.count;
-  const u32 nChunks = (M + SW_CHUNK - 1) / SW_CHUNK;
-  if (nChunks == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *nHeads = 0;
-    return;
-  }
-  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
-    __syncthreads();
-    const u32 j0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
-    u32 keep = 0, cnt = 0;
+  if (blockIdx.x * SW_CHUNK >= M) return;
+  const u32 j0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  u32 cnt = 0;
 #pragma unroll
-    for (int k = 0; k < SW_ITEMS; k++) {
-      u32 j = j0 + k;
-      if (j < M && sweep_is_head(L, j, maxGap)) { keep |= 1u << k; cnt++; }
-    }
-    u32 tot;
-    u32 ex = block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
-    if (threadIdx.x < 64) {
-      u64 excl = lookback_excl(lb, id, (u64)tot, st);
-      if (threadIdx.x == 0) {
-        s_base = (u32)excl;
-        if (id == nChunks - 1) *nHeads = (u32)(excl + tot);
-      }
-    }
-    __syncthreads();
-    u32 o = s_base + ex;
-#pragma unroll
-    for (int k = 0; k < SW_ITEMS; k++)
-      if (keep & (1u << k)) headPos[o++] = j0 + k;
+  for (int k = 0; k < SW_ITEMS; k++) {
+    u32 j = j0 + k;
+    if (j < M) cnt += sweep_is_head(L, j, maxGap);
   }
+  cnt = wave_sum(cnt);
+  if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(SW_NT) void k_heads_write(SweepList L, int maxGap, const u32* __restrict__ chunkOff,
+                                                       u32* __restrict__ headPos) {
+  __shared__ u32 scratch[8];
+  const u32 M = *L.count;
+  if (blockIdx.x * SW_CHUNK >= M) return;
+  const u32 j0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  u32 keep = 0, cnt = 0;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++) {
+    u32 j = j0 + k;
+    if (j < M && sweep_is_head(L, j, maxGap)) { keep |= 1u << k; cnt++; }
+  }
+  u32 tot;
+  u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++)
+    if (keep & (1u << k)) headPos[o++] = j0 + k;
 }
 
 // one wavefront per candidate: updatePeak (943-970) over its intervals, then checkPeak (916-927)
@@ -460,41 +511,44 @@ __global__ __launch_bounds__(256) void k_peak_walk(SweepList L, const u32* __res
   }
 }
 
-// ordered compaction of the candidates that passed checkPeak
-__global__ __launch_bounds__(SW_NT) void k_peak_compact(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
-                                                        const u32* __restrict__ nHeads,
-                                                        u64* __restrict__ lb, gx_peak* __restrict__ peaks,
-                                                        u32* __restrict__ nPeaks, u64* __restrict__ peakBP,
-                                                        u32* __restrict__ st) {
-  __shared__ u32 scratch[8];
-  __shared__ u32 s_base;
+// pass 4: ordered compaction of the candidates that passed checkPeak (chunks of 2048 heads)
+__global__ __launch_bounds__(SW_NT) void k_peaks_count(const u32* __restrict__ valid, const u32* __restrict__ nHeads,
+                                                       u32* __restrict__ chunkCnt) {
+  __shared__ u32 s_cnt[SW_NT / 64];
   const u32 H = *nHeads;
-  const u32 nChunks = (H + SW_NT - 1) / SW_NT;
-  if (nChunks == 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *nPeaks = 0;
-    return;
-  }
+  if (blockIdx.x * SW_CHUNK >= H) return;
+  const u32 h0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  u32 cnt = 0;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++)
+    if (h0 + k < H) cnt += valid[h0 + k];
+  cnt = wave_sum(cnt);
+  if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(SW_NT) void k_peaks_write(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
+                                                       const u32* __restrict__ nHeads, const u32* __restrict__ chunkOff,
+                                                       gx_peak* __restrict__ peaks, u64* __restrict__ peakBP) {
+  __shared__ u32 scratch[8];
+  const u32 H = *nHeads;
+  if (blockIdx.x * SW_CHUNK >= H) return;
+  const u32 h0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  u32 keep = 0, cnt = 0;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++)
+    if (h0 + k < H && valid[h0 + k]) { keep |= 1u << k; cnt++; }
+  u32 tot;
+  u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
   u64 bp = 0;
-  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
-    __syncthreads();
-    u32 h = id * SW_NT + threadIdx.x;
-    u32 v = h < H ? valid[h] : 0;
-    u32 tot;
-    u32 ex = block_excl_scan<u32, SW_NT>(v, scratch, &tot);
-    if (threadIdx.x < 64) {
-      u64 excl = lookback_excl(lb, id, (u64)tot, st);
-      if (threadIdx.x == 0) {
-        s_base = (u32)excl;
-        if (id == nChunks - 1) *nPeaks = (u32)(excl + tot);
-      }
-    }
-    __syncthreads();
-    if (v) {
-      gx_peak pk = cand[h];
-      peaks[s_base + ex] = pk;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++)
+    if (keep & (1u << k)) {
+      gx_peak pk = cand[h0 + k];
+      peaks[o++] = pk;
       bp += pk.end - pk.start;
     }
-  }
   bp = wave_sum(bp);
   if (lane_id() == 0 && bp) atomicAdd(peakBP, bp);
 }
