@@ -82,7 +82,9 @@ struct gx_ctx {
   u32 nChrom = 0, nTiles = 0;
   int sbShift = 0;
   u32 nSB = 0;
-  DevBuf dChrom, dTileChrom;
+  DevBuf dChrom, dTileChrom, dBedTileOff, dBedEdge, dTileSave0;
+  bool hasBed = false;
+  size_t nBedEdges = 0;
   // per-sample state
   int phase = 0;  // 0 idle, 1 treatment open, 2 treatment done, 3 control open, 4 control done
   int sample = 0;
@@ -249,7 +251,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 8) * 8));
   // an interval closes at every base with a non-zero difference (<= one per record) plus one per chromosome
-  const size_t ivCap = (size_t)nRec + nChrom + 16;
+  const size_t ivCap = (size_t)nRec + nChrom + ctx->nBedEdges + 16;
   HIPCHECK(pooled(ctx, out.ivEnd, ivCap * 4));
   HIPCHECK(pooled(ctx, out.ivV, ivCap * 4));
   HIPCHECK(pooled(ctx, out.tileIvOff, (size_t)(nTiles + 2) * 4));
@@ -301,7 +303,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");
-  const size_t looseCap = (size_t)nRec + nTiles + 16;  // slot of tile t starts at tileOff[t] + t
+  const size_t looseCap = (size_t)nRec + nTiles + ctx->nBedEdges + 16;  // slot t: tileOff[t] + t (+ edges before)
   HIPCHECK(ctx->looseEnd.ensure(looseCap * 4));
   HIPCHECK(ctx->looseV.ensure(looseCap * 4));
   HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
@@ -309,9 +311,15 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(ctx->tilePrevEnd.ensure((size_t)(nTiles + 1) * 4));
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>()};
   const size_t ldsBytes = (size_t)(TL_PAD + TL_SCR) * 4;
-  hipLaunchKernelGGL(k_tile, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s,
-                     ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
-                     ctx->dChrom.as<DChrom>(), nTiles, to, ctx->dStatus.as<u32>());
+  BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
+  if (ctx->hasBed)
+    hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s,
+                       ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
+                       ctx->dChrom.as<DChrom>(), nTiles, bin, to, ctx->dStatus.as<u32>());
+  else
+    hipLaunchKernelGGL(k_tile<false>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s,
+                       ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
+                       ctx->dChrom.as<DChrom>(), nTiles, bin, to, ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   phase_end(ctx);
 
@@ -330,7 +338,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   Scalars* ds = ctx->dScal.as<Scalars>();
   long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
   HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
-  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileOff.as<u32>(), out.tileIvOff.as<u32>(),
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileOff.as<u32>(),
+             ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, out.tileIvOff.as<u32>(),
              ctx->tilePrevEnd.as<u32>()};
   hipLaunchKernelGGL(k_pack, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, pin, nTiles,
                      out.ivEnd.as<u32>(), out.ivV.as<int>(), acc, ctx->dStatus.as<u32>());
@@ -413,7 +422,9 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   HIPCHECK(hipMemsetAsync(ctx->misc.p, 0, M_WORDS * 4, ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dScal.p, 0, sizeof(Scalars), ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
-  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (TL_PAD + TL_SCR) * 4));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (TL_PAD + TL_SCR) * 4));
   {
     // persistent kernels: the grid must not exceed what is co-resident (look-back forward progress)
@@ -421,7 +432,7 @@ int gx_create(gx_ctx** out, const gx_params* par) {
     HIPCHECK(hipGetDeviceProperties(&prop, ctx->device));
     ctx->numCU = prop.multiProcessorCount;
     int nb = 0;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile, TL_NT, (TL_PAD + TL_SCR) * 4));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true>, TL_NT, (TL_PAD + TL_SCR) * 4));
     ctx->resTile = std::max(1, nb) * ctx->numCU;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_merge2, MG_NT, 0));
     ctx->resMerge = std::max(1, std::min(nb, 4)) * ctx->numCU;
@@ -490,6 +501,38 @@ int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip, 
     return GX_ERR_MEM;
   }
   ctx->nSB = ((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1;  // + the null bucket
+  // -E edges per tile (Genrich.c:2185-2195: a region starting at 0 only flips the initial state)
+  {
+    std::vector<u32> bedOff(t + 1, 0), edges;
+    std::vector<uint8_t> save0(t, 1);
+    ctx->hasBed = false;
+    for (int i = 0; i < n; i++) {
+      const DChrom& c = ctx->hChrom[i];
+      if (c.tileBase == NULL_TILE) continue;
+      const std::vector<uint32_t>& b = ctx->bed[i];
+      if (!b.empty()) ctx->hasBed = true;
+      bool state = b.empty() || b[0] != 0;
+      size_t k = (!b.empty() && b[0] == 0) ? 1 : 0;
+      for (u32 tl = 0; tl < c.nTiles; tl++) {
+        const uint64_t lo = (uint64_t)tl << TB, hi = lo + TILE;
+        save0[c.tileBase + tl] = state;
+        bedOff[c.tileBase + tl] = (u32)edges.size();
+        while (k < b.size() && b[k] < hi && b[k] < c.len) {
+          edges.push_back((u32)(b[k] - lo));
+          state = !state;
+          k++;
+        }
+      }
+    }
+    bedOff[t] = (u32)edges.size();
+    ctx->nBedEdges = edges.size();
+    HIPCHECK(ctx->dBedTileOff.ensure((size_t)(t + 1) * 4));
+    HIPCHECK(ctx->dBedEdge.ensure(edges.size() * 4 + 16));
+    HIPCHECK(ctx->dTileSave0.ensure((size_t)t + 16));
+    HIPCHECK(hipMemcpy(ctx->dBedTileOff.p, bedOff.data(), (size_t)(t + 1) * 4, hipMemcpyHostToDevice));
+    if (!edges.empty()) HIPCHECK(hipMemcpy(ctx->dBedEdge.p, edges.data(), edges.size() * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dTileSave0.p, save0.data(), (size_t)t, hipMemcpyHostToDevice));
+  }
   HIPCHECK(ctx->dChrom.ensure((size_t)n * sizeof(DChrom)));
   HIPCHECK(ctx->dTileChrom.ensure((size_t)t * 4));
   HIPCHECK(hipMemcpyAsync(ctx->dTileChrom.p, tileChrom.data(), (size_t)t * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -640,12 +683,14 @@ int gx_pvalues(gx_ctx* ctx) {
     pa.n = n;
     HIPCHECK(pooled(ctx, pa.p, (size_t)n * 4 + 16));
     HIPCHECK(pooled(ctx, pa.expt, (size_t)n * 4 + 16));
+    if (ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)n * 4 + 16));
     phase_begin(ctx, "pval");
     HIPCHECK(ctx->pvLut.ensure((size_t)PV_LUT * 4));
     hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>());
     hipLaunchKernelGGL(k_pval_const, dim3(std::max(1u, std::min((n + 255) / 256, 8192u))), dim3(256), 0, s,
                        ctx->expt.ivV.as<int>(), ctx->misc.as<u32>() + M_NIV, ctx->dScal.as<Scalars>(),
-                       ctx->pvLut.as<float>(), pa.p.as<float>(), pa.expt.as<float>(), ctx->dStatus.as<u32>());
+                       ctx->pvLut.as<float>(), pa.p.as<float>(), pa.expt.as<float>(),
+                       ctx->hasBed ? pa.ctrl.as<float>() : (float*)nullptr, ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_pval_const")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
@@ -653,7 +698,7 @@ int gx_pvalues(gx_ctx* ctx) {
     pa.chromOff = std::move(ctx->expt.chromIvOff);
     pa.tileOff = std::move(ctx->expt.tileIvOff);
     pa.hasPiles = true;
-    pa.ctrlIsConst = true;
+    pa.ctrlIsConst = !ctx->hasBed;
     pa.ctrlConst = ctx->hScal.lambda;
   } else {
     // treatment + control: tile-local union of breakpoints (savePval 1768-1791)

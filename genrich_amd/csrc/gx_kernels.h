@@ -471,7 +471,18 @@ constexpr int TL_NT = 512;
 constexpr int TL_NW = TL_NT / 64;
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
 constexpr int TL_PAD = TILE + TILE / 32;          // +1 dword per 32: conflict-free blocked reads
-constexpr int TL_SCR = 64;                        // scratch ints after the slice
+constexpr int TL_SCR = 64 + TILE / 32;            // scratch ints after the slice (+ the -E edge bitmap)
+constexpr int V_MARK = (int)0x80000000;           // "pileup" of an interval inside an excluded (-E) region
+
+// -E support (Genrich.c:2185-2263): bed edges are breakpoints whatever the difference array
+// holds, breakpoints inside an excluded region are suppressed, and intervals there carry
+// V_MARK (treatment value 0.0f, control SKIP).  Edges of a tile come as a CSR list built on
+// the host; tileSave0 is the `save` state in effect at the tile's first base.
+struct BedIn {
+  const u32* bedTileOff;  // [nTiles+1]
+  const u32* bedEdge;     // tile-local offsets
+  const uint8_t* tileSave0;
+};
 
 struct TileOut {
   u32* looseEnd;    // interval end (chromosome coordinate), loose slots
@@ -480,15 +491,17 @@ struct TileOut {
   u32* tileLastEnd; // [nTiles] end of the tile's last interval (valid when tileCount > 0)
 };
 
+template <bool BED>
 __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
                                                    const u32* __restrict__ tileOff,
                                                    const int* __restrict__ tilePrefW,
                                                    const u32* __restrict__ tileChrom,
                                                    const DChrom* __restrict__ chroms, u32 nTiles,
-                                                   TileOut out, u32* __restrict__ st) {
+                                                   BedIn bed, TileOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
   int* delta = lds;                        // TL_PAD ints (no static LDS: keeps the base 16-B aligned)
-  int* scr = lds + TL_PAD;                 // [0..8] sums, [16..24] counts
+  int* scr = lds + TL_PAD;                 // [0..8] sums, [16..24] counts, [32..40] edge counts
+  u32* eb = reinterpret_cast<u32*>(scr + 64);  // -E edge bitmap: word i = bases of thread i
   const int wv = threadIdx.x >> 6;
   u32 bad = 0;
   for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {
@@ -503,6 +516,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
     const bool lastTile = tl + 1 == c.nTiles;
     const u32 rb = tileOff[t], re = tileOff[t + 1];
     const int carry = tilePrefW[t] - tilePrefW[c.tileBase];
+    if (BED) eb[threadIdx.x] = 0;
     __syncthreads();
     // accumulate this tile's endpoint records
     for (u32 i = rb + threadIdx.x; i < re; i += TL_NT) {
@@ -510,7 +524,28 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
       u32 off = (u32)(r >> 8) & (TILE - 1);
       atomicAdd(&delta[off + (off >> 5)], (int)(int8_t)(r & 0xFF));
     }
+    if (BED)
+      for (u32 i = bed.bedTileOff[t] + threadIdx.x; i < bed.bedTileOff[t + 1]; i += TL_NT) {
+        u32 off = bed.bedEdge[i];
+        atomicOr(&eb[off >> 5], 1u << (off & 31));
+      }
     __syncthreads();
+    // -E: `save` state at this thread's first base = tile state ^ parity(edges before it)
+    u32 ew = 0;
+    bool save = true;
+    if (BED) {
+      ew = eb[threadIdx.x];
+      const int pe = __popc(ew);
+      const int incE = dpp_scan_add(pe);
+      if (lane_id() == 63) scr[32 + wv] = incE;
+      __syncthreads();
+      int preE = incE - pe;
+#pragma unroll
+      for (int w = 0; w < TL_NW; w++)
+        if (w < wv) preE += scr[32 + w];
+      save = ((bed.tileSave0[t] != 0) ^ ((preE & 1) != 0));
+    }
+    const bool save0 = save;
     // blocked read: thread i owns bases [32 i, 32 i + 32)
     int d[TL_EPT];
     int sum = 0;
@@ -520,7 +555,9 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
     for (int k = 0; k < TL_EPT; k++) {
       d[k] = delta[lbase + k];
       sum += d[k];
-      cnt += (d[k] != 0) && (pos0 + threadIdx.x * TL_EPT + k != 0);
+      const bool edge = BED && ((ew >> k) & 1u);
+      cnt += (edge || (save && d[k] != 0)) && (pos0 + threadIdx.x * TL_EPT + k != 0);  // 2241
+      if (edge) save = !save;                                                           // 2258-2263
       sat |= (u32)(d[k] >= 32767 * GX_UNIT) | (u32)(d[k] <= -32768 * GX_UNIT);
     }
     if (!active) cnt = 0;
@@ -540,28 +577,32 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
     }
     if (active) {  // block-uniform
       int run = carry + preS + (incS - sum);
-      const u32 o0 = rb + t + preC + (incC - cnt);
+      const u32 slot = rb + t + (BED ? bed.bedTileOff[t] : 0u);  // a tile closes <= records + edges + 1 intervals
+      const u32 o0 = slot + preC + (incC - cnt);
       const u32 totFinal = totC + (lastTile ? 1u : 0u);
       u32 o = o0, neg = 0, lastEnd = 0;
+      save = save0;
 #pragma unroll
       for (int k = 0; k < TL_EPT; k++) {
         u32 p = pos0 + threadIdx.x * TL_EPT + k;
-        if (d[k] != 0 && p != 0) {
+        const bool edge = BED && ((ew >> k) & 1u);
+        if ((edge || (save && d[k] != 0)) && p != 0) {
           out.looseEnd[o] = p;
-          out.looseV[o] = run;
+          out.looseV[o] = save ? run : V_MARK;  // 2244-2248
           lastEnd = p;
           o++;
         }
+        if (edge) save = !save;
         run += d[k];
         neg |= (u32)(run < 0);
       }
       if (lastTile && threadIdx.x == TL_NT - 1) {  // closing interval [.., len)
         out.looseEnd[o] = c.len;
-        out.looseV[o] = run;
+        out.looseV[o] = save ? run : V_MARK;
         lastEnd = c.len;
         o++;
       }
-      if (o != o0 && o == rb + t + totFinal) out.tileLastEnd[t] = lastEnd;  // wrote the tile's last interval
+      if (o != o0 && o == slot + totFinal) out.tileLastEnd[t] = lastEnd;  // wrote the tile's last interval
       if (threadIdx.x == 0) out.tileCount[t] = totFinal;
       bad |= (neg ? ST_NEG_PILE : 0) | (sat ? ST_SAT16 : 0);
     } else if (threadIdx.x == 0) {
@@ -712,7 +753,8 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
 struct PackIn {
   const u32* looseEnd;
   const int* looseV;
-  const u32* tileOff;      // record offsets (loose slot of tile t starts at tileOff[t] + t)
+  const u32* tileOff;      // record offsets (loose slot of tile t starts at tileOff[t] + t [+ bedTileOff[t]])
+  const u32* bedTileOff;   // nullptr without -E
   const u32* tileIvOff;
   const u32* tilePrevEnd;
 };
@@ -724,7 +766,8 @@ __global__ __launch_bounds__(256) void k_pack(PackIn in, u32 nTiles, u32* __rest
   const int wv = threadIdx.x >> 6, lane = lane_id();
   // one wavefront per tile (a tile holds a few hundred intervals)
   for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
-    const u32 src = in.tileOff[t] + t, dst = in.tileIvOff[t], n = in.tileIvOff[t + 1] - dst;
+    const u32 src = in.tileOff[t] + t + (in.bedTileOff ? in.bedTileOff[t] : 0u), dst = in.tileIvOff[t],
+              n = in.tileIvOff[t + 1] - dst;
     u32 prevEnd = in.tilePrevEnd[t];
     for (u32 b = 0; b < n; b += 64) {
       u32 i = b + lane;
@@ -739,7 +782,7 @@ __global__ __launch_bounds__(256) void k_pack(PackIn in, u32 nTiles, u32* __rest
       u32 s = __shfl_up(e, 1, 64);
       if (lane == 0) s = prevEnd;
       prevEnd = __shfl(e, 63, 64);
-      if (i < n && v != 0) {
+      if (i < n && v != 0 && v != V_MARK) {
         bool ng;
         float val = getval(v, &ng);
         neg |= ng;

@@ -35,7 +35,13 @@ struct Merge2Out {
   u32* n;
 };
 
+__device__ __forceinline__ float expt_val(int v, bool* neg) {
+  if (v == V_MARK) { *neg = false; return 0.0f; }  // excluded region: 2248 / 2273
+  return getval(v, neg);
+}
+
 __device__ __forceinline__ float ctrl_net(int v, float factor, float lambda, bool* neg) {
+  if (v == V_MARK) { *neg = false; return GX_SKIPF; }  // excluded region: 2124 / 2141
   float val = factor * getval(v, neg);  // 2107 / 2118: float product
   return val > lambda ? val : lambda;   // MAX(val, lambda)
 }
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
         u32 ic = b0 + exC + __popc(wC[k] & below);
         bool ng1, ng2;
         out.end[o] = pos0 + (threadIdx.x * MG_WPT + k) * 32 + b;
-        out.expt[o] = getval(A.v[ia], &ng1);
+        out.expt[o] = expt_val(A.v[ia], &ng1);
         out.ctrl[o] = ctrl_net(B.v[ic], factor, lambda, &ng2);
         neg |= ng1 | ng2;
         o++;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
       bool ng1, ng2;
       u32 oc = s_base + tU;
       out.end[oc] = c.len;
-      out.expt[oc] = getval(A.v[a1 - 1], &ng1);
+      out.expt[oc] = expt_val(A.v[a1 - 1], &ng1);
       out.ctrl[oc] = ctrl_net(B.v[b1 - 1], factor, lambda, &ng2);
       neg |= ng1 | ng2;
     }

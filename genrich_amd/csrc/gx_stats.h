@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
 __global__ __launch_bounds__(256) void k_pval_const(const int* __restrict__ ivV, const u32* __restrict__ nIvPtr,
                                                     const Scalars* __restrict__ sc, const float* __restrict__ lutP,
                                                     float* __restrict__ pOut, float* __restrict__ exptOut,
-                                                    u32* __restrict__ st) {
+                                                    float* __restrict__ ctrlOut, u32* __restrict__ st) {
   const u32 n = *nIvPtr;
   const float lambda = sc->lambda;
   double ml = 0, sl = 1;
@@ -43,9 +43,12 @@ __global__ __launch_bounds__(256) void k_pval_const(const int* __restrict__ ivV,
   u32 neg = 0;
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int v = ivV[i];
-    bool ng;
+    bool ng = false;
     float val, p;
-    if ((u32)v < PV_LUT) {
+    if (v == V_MARK) {  // inside an excluded region: treatment 0.0f (2248), control SKIP (1871) -> p SKIP (1629)
+      val = 0.0f;
+      p = GX_SKIPF;
+    } else if ((u32)v < PV_LUT) {
       val = getval(v, &ng);
       p = lutP[v];
     } else
@@ -53,6 +56,7 @@ __global__ __launch_bounds__(256) void k_pval_const(const int* __restrict__ ivV,
     neg |= ng;
     pOut[i] = p;
     if (exptOut) exptOut[i] = val;
+    if (ctrlOut) ctrlOut[i] = v == V_MARK ? GX_SKIPF : lambda;
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
 }

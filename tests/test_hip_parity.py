@@ -61,7 +61,7 @@ def assert_same_run(o, h, so, sh, case, tol=1e-5):
 
 
 SUPPORTED = ["basic", "atac", "ctrl_q", "multimap", "atac_odd", "reps3", "reps3_p_missing",
-             "ctrl_only_chrom", "nopeaks_log"]
+             "ctrl_only_chrom", "nopeaks_log", "bedx", "bedx_noctrl"]
 
 
 @pytest.mark.parametrize("name", SUPPORTED)
