@@ -10,7 +10,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gx_api.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("gx_kernels.h", "gx_stats.h", "gx_math.h")] + [
+EMIT = os.path.join(HERE, "csrc", "gx_emit.cpp")
+DEPS = [SRC, EMIT] + [os.path.join(HERE, "csrc", f) for f in ("gx_kernels.h", "gx_stats.h", "gx_merge.h", "gx_math.h")] + [
     os.path.join(os.path.dirname(HERE), "include", "genrich_amd.h")]
 LIB = os.path.join(HERE, "libgenrich_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -27,7 +28,7 @@ def needs_build() -> bool:
 
 def build(force: bool = False) -> str:
     if force or needs_build():
-        subprocess.check_call([HIPCC] + FLAGS + [SRC, "-o", LIB])
+        subprocess.check_call([HIPCC] + FLAGS + [SRC, EMIT, "-o", LIB])
     return LIB
 
 

@@ -928,6 +928,12 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   return GX_OK;
 }
 
+int gx_peak_count(gx_ctx* ctx, size_t* n) {
+  if (!ctx || !n) return GX_ERR_ORDER;
+  *n = ctx->hPeaks.size();
+  return GX_OK;
+}
+
 int gx_get_peaks(gx_ctx* ctx, gx_peak* out, size_t cap) {
   if (!ctx || !out) return GX_ERR_ORDER;
   size_t n = std::min(cap, ctx->hPeaks.size());

@@ -57,6 +57,10 @@ _SIGS = {
     "gx_pvalues": [C.c_void_p],
     "gx_find_peaks": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "gx_get_peaks": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_peak_count": [C.c_void_p, C.POINTER(C.c_size_t)],
+    "gx_write_narrowpeak_path": [C.c_void_p, C.c_void_p, C.c_char_p],
+    "gx_write_pile_path": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int],
+    "gx_write_log_path": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_char_p],
     "gx_total_intervals": [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)],
     "gx_interval_count": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
     "gx_get_intervals": [C.c_void_p, C.c_int, C.c_int, C.c_size_t] + [C.c_void_p] * 5,
@@ -198,6 +202,24 @@ class Genrich:
                 self.ctx, int(which), int(chrom), n, end.ctypes.data,
                 *[cols[k].ctypes.data for k in ("expt", "ctrl", "p", "q")]))
         return end, cols
+
+    # -- text emitters (gx_emit.cpp) ----------------------------------------------------
+    def _names(self, names):
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        self._keep.append(arr)
+        return C.cast(arr, C.c_void_p)
+
+    def write_narrowpeak(self, names, path):
+        self._check(self.lib.gx_write_narrowpeak_path(self.ctx, self._names(names), path.encode()))
+
+    def write_pile(self, rep, names, expt_name, ctrl_name, path, append=False):
+        self._check(self.lib.gx_write_pile_path(
+            self.ctx, rep, self._names(names), len(names), expt_name.encode(),
+            ctrl_name.encode() if ctrl_name else None, path.encode(), int(append)))
+
+    def write_log(self, n_rep, names, qval_opt, peaks_opt, thr, path):
+        self._check(self.lib.gx_write_log_path(self.ctx, n_rep, self._names(names), len(names), int(qval_opt),
+                                               int(peaks_opt), float(thr), path.encode()))
 
     def selftest(self, what, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float32)

@@ -137,6 +137,7 @@ int gx_pvalues(gx_ctx* ctx);
 int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* peak_bp);
 
 /* Copies min(cap, n_peaks) peaks, chromosome-table order then position. */
+int gx_peak_count(gx_ctx* ctx, size_t* n_peaks);
 int gx_get_peaks(gx_ctx* ctx, gx_peak* out, size_t cap);
 
 /* Interval arrays for host-side -f / -k formatting (printLog 808, printPile 1697).
@@ -149,6 +150,24 @@ int gx_interval_count(gx_ctx* ctx, int which, int chrom, size_t* n_iv);
 int gx_total_intervals(gx_ctx* ctx, int which, size_t* n_iv); /* over all chromosomes */
 int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* end,
                      float* expt, float* ctrl, float* p, float* q);
+
+/* ---- host-side text emitters of the drop-in surface (gx_emit.cpp); byte format of the
+ *      reference's printf calls.  names[i] = chromosome names in table order. ---- */
+#include <stdio.h>
+/* -o  ENCODE narrowPeak: printPeak, Genrich.c:885-909 */
+int gx_write_narrowpeak(gx_ctx* ctx, const char* const* names, FILE* out);
+/* -k  pileup log of replicate rep: printPileHeader 1680-1691, printPile 1697-1715 */
+int gx_write_pile(gx_ctx* ctx, int rep, const char* const* names, int n_chrom, const char* expt_name,
+                  const char* ctrl_name, FILE* out);
+/* -f  bedgraph-ish log: printLogHeader 674-717, printInterval 770-803, printIntervalN 724-763;
+ *     peaks_opt = 0 is -X (logIntervals 837-878) */
+int gx_write_log(gx_ctx* ctx, int n_rep, const char* const* names, int n_chrom, int qval_opt, int peaks_opt,
+                 float thr, FILE* out);
+int gx_write_narrowpeak_path(gx_ctx* ctx, const char* const* names, const char* path);
+int gx_write_pile_path(gx_ctx* ctx, int rep, const char* const* names, int n_chrom, const char* expt_name,
+                       const char* ctrl_name, const char* path, int append);
+int gx_write_log_path(gx_ctx* ctx, int n_rep, const char* const* names, int n_chrom, int qval_opt, int peaks_opt,
+                      float thr, const char* path);
 
 /* ---- multi-GPU hooks: chromosomes are sharded across ranks; the
  *      three genome-wide quantities are exchanged through host-supplied callbacks

@@ -74,6 +74,28 @@ def test_golden_case(name):
         assert h.n_peaks == meta["ref_peaks"][0][0]
 
 
+@pytest.mark.parametrize("name", G.case_names())
+def test_golden_text_outputs_byte_identical(name, tmp_path):
+    """narrowPeak / -f / -k text produced from the HIP path (gx_emit.cpp over the C ABI) must be
+    byte-identical to the files the reference itself wrote (tests/golden/<case>/out.*)."""
+    meta, case, params, names = G.load_case(name)
+    h = hip_backend(params)
+    B.run_case(h, case)
+    nrep = len(case["replicates"])
+    pile = str(tmp_path / "pile")
+    for r, rm in enumerate(meta["replicates"]):
+        cname = None if rm["control"] is None else (
+            "null" if rm["control"] == "null" else meta["tmp_prefix"] + rm["ctrl_name"])
+        h.write_pile(r, names, meta["tmp_prefix"] + rm["expt_name"], cname, pile, append=r > 0)
+    peaks_opt = "-X" not in meta["args"]
+    h.write_log(nrep, names, params.qval_opt, peaks_opt, params.thr, str(tmp_path / "log"))
+    assert open(pile, "rb").read() == G.read_gz(name, "out.pile")
+    assert open(tmp_path / "log", "rb").read() == G.read_gz(name, "out.log")
+    if peaks_opt:
+        h.write_narrowpeak(names, str(tmp_path / "np"))
+        assert open(tmp_path / "np", "rb").read() == G.read_gz(name, "out.narrowPeak")
+
+
 @pytest.mark.parametrize("qval", [False, True])
 def test_random_treatment_only(qval):
     lens = [300_000, 70_001, 16_384, 16_385, 5]
