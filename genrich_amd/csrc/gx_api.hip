@@ -832,6 +832,49 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     u32 D = 0;
     HIPCHECK(hipMemcpyAsync(&D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (ctx->world > 1 && ctx->allgather) {
+      // every rank contributes its {p bits, bp} pairs; all ranks rebuild the same genome-wide table
+      // (hashPval 300-327 runs over all chromosomes)
+      struct Rec { u32 key, pad; u64 bp; };
+      std::vector<u32> hk(D), hs(D);
+      std::vector<u64> hl((size_t)cap);
+      if (D) {
+        HIPCHECK(hipMemcpy(hk.data(), ctx->bhOutKeys.p, (size_t)D * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(hs.data(), ctx->bhOutSlot.p, (size_t)D * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(hl.data(), ctx->bhLens.p, (size_t)cap * 8, hipMemcpyDeviceToHost));
+      }
+      std::vector<Rec> mine(D);
+      for (u32 i = 0; i < D; i++) mine[i] = Rec{hk[i], 0u, hl[hs[i]]};
+      void* all = nullptr;
+      size_t nAll = 0;
+      if (ctx->allgather(mine.data(), D, &all, &nAll, ctx->user)) {
+        ctx->err = "allgather callback failed";
+        return GX_ERR_DEVICE;
+      }
+      std::vector<u32> ak(nAll);
+      std::vector<u64> al(nAll);
+      const Rec* ar = static_cast<const Rec*>(all);
+      for (size_t i = 0; i < nAll; i++) { ak[i] = ar[i].key; al[i] = ar[i].bp; }
+      free(all);
+      HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)cap * 4, s));
+      HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)cap * 8, s));
+      HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
+      if (nAll) {
+        DevBuf dk, dl;
+        HIPCHECK(dk.ensure(nAll * 4));
+        HIPCHECK(dl.ensure(nAll * 8));
+        HIPCHECK(hipMemcpyAsync(dk.p, ak.data(), nAll * 4, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync(dl.p, al.data(), nAll * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_bh_insert, dim3(std::max<u32>(1, std::min<size_t>((nAll + 255) / 256, 1024))), dim3(256), 0,
+                           s, dk.as<u32>(), dl.as<u64>(), (u32)nAll, ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(),
+                           cap - 1, ctx->dStatus.as<u32>());
+        HIPCHECK(hipStreamSynchronize(s));
+      }
+      hipLaunchKernelGGL(k_bh_compact, dim3(1024), dim3(256), 0, s, ctx->bhKeys.as<u32>(), cap,
+                         ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), misc + M_BHCOUNT);
+      HIPCHECK(hipMemcpyAsync(&D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+    }
     if (D) {
       HIPCHECK(ctx->bhSortKeys.ensure((size_t)D * 4));
       HIPCHECK(ctx->bhSortSlot.ensure((size_t)D * 4));
