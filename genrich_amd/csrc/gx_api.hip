@@ -102,7 +102,7 @@ struct gx_ctx {
   DevBuf pvLut;
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp;
   // sweep
-  DevBuf swChrom, swStart, swEnd, swP, swQ, swSig, cand, valid, peaks, lb2, headPos;
+  DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos;
   std::vector<gx_peak> hPeaks;
   uint64_t genomeLenUsed = 0, peakBP = 0;
   // collectives
@@ -900,64 +900,72 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
 
   // peak sweep
   phase_begin(ctx, "sweep");
-  const u32 nChunks = (n + SW_CHUNK - 1) / SW_CHUNK;
-  // chunk count / offset scratch: one region per compaction (intervals, list entries, heads)
-  HIPCHECK(ctx->lb2.ensure(((size_t)nChunks * 6 + 64) * 4));
-  u32* cnt1 = ctx->lb2.as<u32>();
-  u32* off1 = cnt1 + nChunks + 8;
-  u32* cnt2 = off1 + nChunks + 8;
-  u32* off2 = cnt2 + nChunks + 8;
-  u32* cnt3 = off2 + nChunks + 8;
-  u32* off3 = cnt3 + nChunks + 8;
-  HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 12, s));  // (unused), swcount, npeaks
+  const u32 nWords = (n + 63) / 64;
+  const u32 wChunks = (nWords + SW_CHUNK - 1) / SW_CHUNK;
+  // three bit masks + chunk count/offset scratch
+  HIPCHECK(ctx->swMask.ensure((size_t)(nWords + 2) * 8 * 3));
+  HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, (size_t)(nWords + 2) * 8 * 3, s));
+  SweepMasks SM{ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + (nWords + 2), ctx->swMask.as<u64>() + 2 * (size_t)(nWords + 2),
+                nWords};
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 12, s));  // nruns(ends), nruns, npeaks
   HIPCHECK(hipMemsetAsync(misc + M_PEAKBP, 0, 8, s));
-  HIPCHECK(hipMemsetAsync(misc + M_TICKET3, 0, 12, s));  // (unused), (unused), nheads
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET3, 0, 12, s));  // -, -, ncands
   const float* qPtr = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
-  u32 M = 0, nPeaks = 0;
+  u32 R = 0, nPeaks = 0;
   ctx->peakBP = 0;
-  if (nChunks) {
-    hipLaunchKernelGGL(k_sweep_count, dim3(nChunks), dim3(SW_NT), 0, s, fa.p.as<float>(), qPtr, misc + M_NIV,
-                       ctx->par.thr, cnt1);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt1, (const u32*)nullptr, nChunks, (u32)SW_CHUNK, off1,
+  if (nWords) {
+    HIPCHECK(ctx->lb2.ensure(((size_t)wChunks * 4 + 64) * 4));
+    u32* cntS = ctx->lb2.as<u32>();
+    u32* offS = cntS + wChunks + 8;
+    u32* cntE = offS + wChunks + 8;
+    u32* offE = cntE + wChunks + 8;
+    hipLaunchKernelGGL(k_brk_mask, dim3((nChrom + 255) / 256), dim3(256), 0, s, fa.chromOff.as<u32>(), nChrom, SM.brk);
+    hipLaunchKernelGGL(k_sig_mask, dim3(std::max(1u, std::min((nWords + 3) / 4, 8192u))), dim3(256), 0, s, fa.p.as<float>(),
+                       qPtr, misc + M_NIV, ctx->par.thr, SM);
+    hipLaunchKernelGGL(k_runs_count, dim3(wChunks), dim3(SW_NT), 0, s, SM, cntS, cntE);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cntS, (const u32*)nullptr, wChunks, (u32)SW_CHUNK, offS,
                        misc + M_SWCOUNT);
-    HIPCHECK(hipMemcpyAsync(&M, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));  // the list is sized exactly (it is ~1-2 % of the intervals)
-  }
-  if (M) {
-    const size_t mCap = (size_t)M + 16;
-    HIPCHECK(ctx->swChrom.ensure(mCap * 4));
-    HIPCHECK(ctx->swStart.ensure(mCap * 4));
-    HIPCHECK(ctx->swEnd.ensure(mCap * 4));
-    HIPCHECK(ctx->swP.ensure(mCap * 4));
-    HIPCHECK(ctx->swQ.ensure(mCap * 4));
-    HIPCHECK(ctx->swSig.ensure(mCap * 4));
-    SweepList L{ctx->swChrom.as<u32>(), ctx->swStart.as<u32>(), ctx->swEnd.as<u32>(), ctx->swP.as<float>(),
-                ctx->swQ.as<float>(), ctx->swSig.as<u32>(), misc + M_SWCOUNT};
-    hipLaunchKernelGGL(k_sweep_write, dim3(nChunks), dim3(SW_NT), 0, s, fa.end.as<u32>(), fa.p.as<float>(), qPtr,
-                       fa.chromOff.as<u32>(), nChrom, misc + M_NIV, ctx->par.thr, off1, L);
-    // heads <= list entries; candidates and peaks <= heads
-    HIPCHECK(ctx->headPos.ensure((size_t)M * 4 + 16));
-    HIPCHECK(ctx->cand.ensure((size_t)M * sizeof(gx_peak)));
-    HIPCHECK(ctx->valid.ensure((size_t)M * 4 + 16));
-    HIPCHECK(ctx->peaks.ensure((size_t)M * sizeof(gx_peak)));
-    const u32 mChunks = (M + SW_CHUNK - 1) / SW_CHUNK;
-    hipLaunchKernelGGL(k_heads_count, dim3(mChunks), dim3(SW_NT), 0, s, L, ctx->par.max_gap, cnt2);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt2, (const u32*)nullptr, mChunks, (u32)SW_CHUNK, off2,
-                       misc + M_NHEADS);
-    hipLaunchKernelGGL(k_heads_write, dim3(mChunks), dim3(SW_NT), 0, s, L, ctx->par.max_gap, off2, ctx->headPos.as<u32>());
-    hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((M + 3) / 4, 8192u))), dim3(256), 0, s, L,
-                       ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
-                       ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
-    // heads H <= M: chunk arrays sized by M's chunk count; kernels bound themselves by *nHeads
-    hipLaunchKernelGGL(k_peaks_count, dim3(mChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt3, misc + M_NHEADS, mChunks, (u32)SW_CHUNK, off3,
-                       misc + M_NPEAKS);
-    hipLaunchKernelGGL(k_peaks_write, dim3(mChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
-                       misc + M_NHEADS, off3, ctx->peaks.as<gx_peak>(), reinterpret_cast<u64*>(misc + M_PEAKBP));
-    if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
-    HIPCHECK(hipMemcpyAsync(&nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(&ctx->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cntE, (const u32*)nullptr, wChunks, (u32)SW_CHUNK, offE,
+                       misc + M_TICKET2);
+    HIPCHECK(hipMemcpyAsync(&R, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));  // run / candidate arrays are sized exactly
+    if (R) {
+      HIPCHECK(ctx->swStart.ensure((size_t)R * 4 + 16));
+      HIPCHECK(ctx->swEnd.ensure((size_t)R * 4 + 16));
+      HIPCHECK(ctx->headPos.ensure((size_t)R * 4 + 16));
+      HIPCHECK(ctx->cand.ensure((size_t)R * sizeof(gx_peak)));
+      HIPCHECK(ctx->valid.ensure((size_t)R * 4 + 16));
+      HIPCHECK(ctx->peaks.ensure((size_t)R * sizeof(gx_peak)));
+      const u32 rChunks = (R + SW_CHUNK - 1) / SW_CHUNK;
+      HIPCHECK(ctx->swChrom.ensure(((size_t)rChunks * 4 + 64) * 4));
+      u32* cnt2 = ctx->swChrom.as<u32>();
+      u32* off2 = cnt2 + rChunks + 8;
+      u32* cnt3 = off2 + rChunks + 8;
+      u32* off3 = cnt3 + rChunks + 8;
+      u32* runStart = ctx->swStart.as<u32>();
+      u32* runEnd = ctx->swEnd.as<u32>();
+      hipLaunchKernelGGL(k_runs_write, dim3(wChunks), dim3(SW_NT), 0, s, SM, offS, offE, runStart, runEnd);
+      hipLaunchKernelGGL(k_cands_count, dim3(rChunks), dim3(SW_NT), 0, s, SM, fa.end.as<u32>(), runStart, runEnd,
+                         misc + M_SWCOUNT, ctx->par.max_gap, cnt2);
+      hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt2, (const u32*)nullptr, rChunks, (u32)SW_CHUNK, off2,
+                         misc + M_NHEADS);
+      hipLaunchKernelGGL(k_cands_write, dim3(rChunks), dim3(SW_NT), 0, s, SM, fa.end.as<u32>(), runStart, runEnd,
+                         misc + M_SWCOUNT, ctx->par.max_gap, off2, ctx->headPos.as<u32>());
+      hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((R + 3) / 4, 8192u))), dim3(256), 0, s, SM,
+                         fa.end.as<u32>(), fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom, runStart, runEnd,
+                         misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc,
+                         ctx->par.min_len, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
+      // candidates C <= R: chunk arrays sized by R's chunk count; kernels bound themselves by *nCands
+      hipLaunchKernelGGL(k_peaks_count, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
+      hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt3, misc + M_NHEADS, rChunks, (u32)SW_CHUNK, off3,
+                         misc + M_NPEAKS);
+      hipLaunchKernelGGL(k_peaks_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
+                         misc + M_NHEADS, off3, ctx->peaks.as<gx_peak>(), reinterpret_cast<u64*>(misc + M_PEAKBP));
+      if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
+      HIPCHECK(hipMemcpyAsync(&nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipMemcpyAsync(&ctx->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+    }
   }
   ctx->hPeaks.resize(nPeaks);
   if (nPeaks)

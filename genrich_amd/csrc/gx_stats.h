@@ -282,30 +282,23 @@ __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, co
 }
 
 // ---- peak sweep: callPeaks (977-1069) ---------------------------------------------------------
-// Only significant intervals (pq > thr, strict, 1015) and SKIP intervals matter: two significant
-// intervals belong to one candidate iff no SKIP interval lies between them and
-// start_next - end_prev <= maxGap (1031-1032).
-//   pass 1  k_sweep_count / k_sweep_write : ordered compaction of {significant, SKIP} intervals
-//   pass 2  k_heads_count / k_heads_write : ordered list of candidate heads
-//   pass 3  k_peak_walk     : one wavefront per candidate; the float AUC is summed strictly in
-//                             interval order (950) -- lanes load and form the products in
-//                             parallel, the additions are replayed serially through shuffles
-//   pass 4  k_peaks_count / k_peaks_write : ordered compaction of the candidates passing checkPeak (916-927)
-// Ordered compactions are count -> k_scan_small (chunk counts) -> write; list lengths stay on the
-// device (kernels read them through pointers), only the final peak count travels to the host.
-struct SweepList {
-  u32* chrom;
-  u32* start;
-  u32* end;
-  float* p;
-  float* q;
-  u32* sig;   // 1 significant, 0 SKIP marker
-  u32* count; // number of entries
-};
-
+// A candidate peak is a maximal chain of significant intervals (pq > thr, strict, 1015) in which
+// consecutive members are separated by less than... precisely: two significant intervals belong
+// to one candidate iff they are on the same chromosome, no SKIP interval lies between them and
+// start_next - end_prev <= maxGap (1031-1032).  More than half of all intervals can be
+// significant (peaks are dense in breakpoints), so nothing per-interval is materialised beyond
+// three bit masks (significant / SKIP / first-of-chromosome, 1 bit per interval each, L2-resident):
+//   k_sig_mask     pq[] -> bit masks                                   (the only full-length read)
+//   k_runs_*       maximal runs of adjacent significant intervals: count -> k_scan_small -> write
+//   k_cands_*      a run opens a new candidate unless it links to the previous run
+//   k_peak_walk    one wavefront per candidate over the ORIGINAL arrays; the float AUC is summed
+//                  strictly in interval order (950): lanes form the products in parallel, the
+//                  additions are replayed serially through shuffles
+//   k_peaks_*      ordered compaction of the candidates passing checkPeak (916-927)
+// List lengths stay on the device (kernels read them through pointers).
 constexpr int SW_NT = 256;
 constexpr int SW_ITEMS = 8;
-constexpr int SW_CHUNK = SW_NT * SW_ITEMS;
+constexpr int SW_CHUNK = SW_NT * SW_ITEMS;  // items per workgroup in the chunked compactions
 
 // exclusive scan of a short u32 array (chunk counts) by one workgroup; total -> *total
 __global__ __launch_bounds__(1024) void k_scan_small(const u32* __restrict__ in, const u32* __restrict__ nPtr, u32 nMax,
@@ -328,161 +321,218 @@ __global__ __launch_bounds__(1024) void k_scan_small(const u32* __restrict__ in,
   if (threadIdx.x == 0) *total = tot;
 }
 
-// pass 1a: how many {significant, SKIP} intervals per chunk of 2048
-__global__ __launch_bounds__(SW_NT) void k_sweep_count(const float* __restrict__ p, const float* __restrict__ q,
-                                                       const u32* __restrict__ nPtr, float thr, u32* __restrict__ chunkCnt) {
-  __shared__ u32 s_cnt[SW_NT / 64];
+struct SweepMasks {
+  u64* sig;   // bit i: interval i is significant
+  u64* skip;  // bit i: interval i is a SKIP (-E) interval
+  u64* brk;   // bit i: interval i is the first of its chromosome
+  u32 nWords; // (n + 63) / 64, n known on the host
+};
+
+// bit i of brk for every non-empty chromosome range start (masks are zeroed by the host)
+__global__ void k_brk_mask(const u32* __restrict__ chromOff, u32 nChrom, u64* __restrict__ brk) {
+  for (u32 c = blockIdx.x * blockDim.x + threadIdx.x; c < nChrom; c += gridDim.x * blockDim.x) {
+    u32 a = chromOff[c], b = chromOff[c + 1];
+    if (b > a) atomicOr(&brk[a >> 6], 1ull << (a & 63));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sig_mask(const float* __restrict__ p, const float* __restrict__ q,
+                                                  const u32* __restrict__ nPtr, float thr, SweepMasks M) {
   const u32 n = *nPtr;
-  const u32 i0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
-  if (blockIdx.x * SW_CHUNK >= n) return;
   const float* pq = q ? q : p;
-  u32 cnt = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++) {
-    u32 i = i0 + k;
-    if (i < n) {
-      float v = pq[i];
-      cnt += (v > thr || v == GX_SKIPF);
+  const u32 nw = (n + 63) >> 6;
+  for (u32 w = blockIdx.x * 4 + (threadIdx.x >> 6); w < nw; w += gridDim.x * 4) {
+    u32 i = (w << 6) + lane_id();
+    float v = i < n ? pq[i] : 0.0f;
+    u64 sg = __ballot(i < n && v > thr);
+    u64 sk = __ballot(i < n && v == GX_SKIPF);
+    if (lane_id() == 0) {
+      M.sig[w] = sg;
+      M.skip[w] = sk;
     }
   }
-  cnt = wave_sum(cnt);
-  if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// pass 1b: ordered write of those intervals
-__global__ __launch_bounds__(SW_NT) void k_sweep_write(const u32* __restrict__ end, const float* __restrict__ p,
-                                                       const float* __restrict__ q, const u32* __restrict__ chromOff,
-                                                       u32 nChrom, const u32* __restrict__ nPtr, float thr,
-                                                       const u32* __restrict__ chunkOff, SweepList out) {
-  __shared__ u32 scratch[8];
-  const u32 n = *nPtr;
-  if (blockIdx.x * SW_CHUNK >= n) return;
-  const u32 i0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
-  float pv[SW_ITEMS], qv[SW_ITEMS];
-  u32 keep = 0, cnt = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++) {
-    u32 i = i0 + k;
-    if (i < n) {
-      pv[k] = p[i];
-      qv[k] = q ? q[i] : GX_SKIPF;
-      float pq = q ? qv[k] : pv[k];
-      if (pq > thr || pq == GX_SKIPF) { keep |= 1u << k; cnt++; }
-    }
-  }
-  u32 tot;
-  u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
-  ChromCursor cur;
+// run starts / ends of word w: a run starts at a significant interval whose predecessor is not
+// significant or which is the first of its chromosome; it ends symmetrically
+__device__ __forceinline__ void run_bits(const SweepMasks& M, u32 w, u64* starts, u64* ends) {
+  const u64 sg = M.sig[w], bk = M.brk[w];
+  const u64 prevBit = w ? M.sig[w - 1] >> 63 : 0ull;
+  const u64 nextBit = w + 1 < M.nWords ? M.sig[w + 1] & 1ull : 0ull;
+  const u64 nextBrk = w + 1 < M.nWords ? M.brk[w + 1] & 1ull : 0ull;
+  *starts = sg & (~((sg << 1) | prevBit) | bk);
+  *ends = sg & (~((sg >> 1) | (nextBit << 63)) | ((bk >> 1) | (nextBrk << 63)));
+}
+
+// count run starts and ends per chunk of 2048 words (one word per thread x 8)
+__global__ __launch_bounds__(SW_NT) void k_runs_count(SweepMasks M, u32* __restrict__ cntS, u32* __restrict__ cntE) {
+  __shared__ u32 s_a[SW_NT / 64], s_b[SW_NT / 64];
+  const u32 w0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  u32 a = 0, b = 0;
 #pragma unroll
   for (int k = 0; k < SW_ITEMS; k++)
-    if (keep & (1u << k)) {
-      u32 i = i0 + k;
-      cur.seek(chromOff, nChrom, i);
-      float pq = q ? qv[k] : pv[k];
-      out.chrom[o] = cur.c;
-      out.start[o] = i == cur.lo ? 0 : end[i - 1];
-      out.end[o] = end[i];
-      out.p[o] = pv[k];
-      out.q[o] = qv[k];
-      out.sig[o] = pq == GX_SKIPF ? 0u : 1u;
-      o++;
+    if (w0 + k < M.nWords) {
+      u64 st, en;
+      run_bits(M, w0 + k, &st, &en);
+      a += __popcll(st);
+      b += __popcll(en);
     }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (lane_id() == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cntS[blockIdx.x] = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+    cntE[blockIdx.x] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+  }
 }
 
-// head of a candidate: a significant interval that follows a SKIP marker, a chromosome
-// change, or a gap wider than maxGap
-__device__ __forceinline__ bool sweep_is_head(const SweepList& L, u32 j, int maxGap) {
-  if (!L.sig[j]) return false;
-  if (j == 0 || !L.sig[j - 1] || L.chrom[j - 1] != L.chrom[j]) return true;
-  long long gap = (long long)L.start[j] - (long long)L.end[j - 1];
-  return gap != 0 && gap > (long long)maxGap;
+__global__ __launch_bounds__(SW_NT) void k_runs_write(SweepMasks M, const u32* __restrict__ offS, const u32* __restrict__ offE,
+                                                      u32* __restrict__ runStart, u32* __restrict__ runEnd) {
+  __shared__ u32 scratch[8];
+  const u32 w0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  u64 st[SW_ITEMS], en[SW_ITEMS];
+  u32 a = 0, b = 0;
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++) {
+    st[k] = 0;
+    en[k] = 0;
+    if (w0 + k < M.nWords) run_bits(M, w0 + k, &st[k], &en[k]);
+    a += __popcll(st[k]);
+    b += __popcll(en[k]);
+  }
+  u32 tot;
+  u32 oa = offS[blockIdx.x] + block_excl_scan<u32, SW_NT>(a, scratch, &tot);
+  u32 ob = offE[blockIdx.x] + block_excl_scan<u32, SW_NT>(b, scratch, &tot);
+#pragma unroll
+  for (int k = 0; k < SW_ITEMS; k++) {
+    u64 x = st[k];
+    while (x) {
+      int bit = __builtin_ctzll(x);
+      x &= x - 1;
+      runStart[oa++] = ((w0 + k) << 6) + bit;
+    }
+    x = en[k];
+    while (x) {
+      int bit = __builtin_ctzll(x);
+      x &= x - 1;
+      runEnd[ob++] = ((w0 + k) << 6) + bit;
+    }
+  }
 }
 
-// pass 2a / 2b: count and write candidate heads (list positions), chunked like pass 1
-__global__ __launch_bounds__(SW_NT) void k_heads_count(SweepList L, int maxGap, u32* __restrict__ chunkCnt) {
+// any bit of mask set in the interval-index range [lo, hi) ?
+__device__ __forceinline__ bool any_bit(const u64* __restrict__ mask, u32 lo, u32 hi) {
+  if (lo >= hi) return false;
+  u32 w0 = lo >> 6, w1 = (hi - 1) >> 6;
+  for (u32 w = w0; w <= w1; w++) {
+    u64 m = mask[w];
+    if (w == w0) m &= ~0ull << (lo & 63);
+    if (w == w1 && ((hi & 63) != 0)) m &= (1ull << (hi & 63)) - 1;
+    if (m) return true;
+  }
+  return false;
+}
+
+// run r opens a new candidate unless it links to run r-1 (same chromosome, no SKIP between,
+// start - previous end <= maxGap)
+__device__ __forceinline__ bool run_is_head(const SweepMasks& M, const u32* __restrict__ end,
+                                            const u32* __restrict__ runStart, const u32* __restrict__ runEnd, u32 r,
+                                            int maxGap) {
+  if (r == 0) return true;
+  const u32 a = runEnd[r - 1], s = runStart[r];       // a < s
+  if ((M.brk[s >> 6] >> (s & 63)) & 1ull) return true;  // first interval of a chromosome
+  const long long gap = (long long)end[s - 1] - (long long)end[a];  // start(s) - end(a); same chromosome unless a brk lies between
+  if (gap != 0 && gap > (long long)maxGap) return true;
+  // few intervals lie between linked runs (each is >= 1 bp): scan the masks
+  if (any_bit(M.brk, a + 1, s + 1)) return true;
+  if (any_bit(M.skip, a + 1, s)) return true;
+  return false;
+}
+
+__global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u32* __restrict__ end,
+                                                       const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
+                                                       const u32* __restrict__ nRuns, int maxGap, u32* __restrict__ chunkCnt) {
   __shared__ u32 s_cnt[SW_NT / 64];
-  const u32 M = *L.count;
-  if (blockIdx.x * SW_CHUNK >= M) return;
-  const u32 j0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  const u32 R = *nRuns;
+  if (blockIdx.x * SW_CHUNK >= R) return;
+  const u32 r0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
   u32 cnt = 0;
 #pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++) {
-    u32 j = j0 + k;
-    if (j < M) cnt += sweep_is_head(L, j, maxGap);
-  }
+  for (int k = 0; k < SW_ITEMS; k++)
+    if (r0 + k < R) cnt += run_is_head(M, end, runStart, runEnd, r0 + k, maxGap);
   cnt = wave_sum(cnt);
   if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-__global__ __launch_bounds__(SW_NT) void k_heads_write(SweepList L, int maxGap, const u32* __restrict__ chunkOff,
-                                                       u32* __restrict__ headPos) {
+__global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u32* __restrict__ end,
+                                                       const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
+                                                       const u32* __restrict__ nRuns, int maxGap,
+                                                       const u32* __restrict__ chunkOff, u32* __restrict__ candRun) {
   __shared__ u32 scratch[8];
-  const u32 M = *L.count;
-  if (blockIdx.x * SW_CHUNK >= M) return;
-  const u32 j0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  const u32 R = *nRuns;
+  if (blockIdx.x * SW_CHUNK >= R) return;
+  const u32 r0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
   u32 keep = 0, cnt = 0;
 #pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++) {
-    u32 j = j0 + k;
-    if (j < M && sweep_is_head(L, j, maxGap)) { keep |= 1u << k; cnt++; }
-  }
+  for (int k = 0; k < SW_ITEMS; k++)
+    if (r0 + k < R && run_is_head(M, end, runStart, runEnd, r0 + k, maxGap)) { keep |= 1u << k; cnt++; }
   u32 tot;
   u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
 #pragma unroll
   for (int k = 0; k < SW_ITEMS; k++)
-    if (keep & (1u << k)) headPos[o++] = j0 + k;
+    if (keep & (1u << k)) candRun[o++] = r0 + k;
 }
 
 // one wavefront per candidate: updatePeak (943-970) over its intervals, then checkPeak (916-927)
-__global__ __launch_bounds__(256) void k_peak_walk(SweepList L, const u32* __restrict__ headPos,
-                                                   const u32* __restrict__ nHeads, float thr, float minAUC, int minLen,
+__global__ __launch_bounds__(256) void k_peak_walk(SweepMasks M, const u32* __restrict__ end, const float* __restrict__ p,
+                                                   const float* __restrict__ q, const u32* __restrict__ chromOff, u32 nChrom,
+                                                   const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
+                                                   const u32* __restrict__ nRuns, const u32* __restrict__ candRun,
+                                                   const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
                                                    gx_peak* __restrict__ cand, u32* __restrict__ valid) {
-  const u32 M = *L.count, H = *nHeads;
+  const u32 R = *nRuns, C = *nCands;
   const u32 wavesPerGrid = gridDim.x * 4;
   const int lane = lane_id();
-  for (u32 h = blockIdx.x * 4 + (threadIdx.x >> 6); h < H; h += wavesPerGrid) {
-    const u32 j0 = headPos[h];
-    const u32 jEnd = h + 1 < H ? headPos[h + 1] : M;  // members are [j0, first non-significant or jEnd)
-    const bool qOpt = L.q[j0] != GX_SKIPF;
-    const u32 peakStart = L.start[j0];
+  for (u32 c = blockIdx.x * 4 + (threadIdx.x >> 6); c < C; c += wavesPerGrid) {
+    const u32 rFirst = candRun[c], rLast = (c + 1 < C ? candRun[c + 1] : R) - 1;
+    const u32 i0 = runStart[rFirst], i1 = runEnd[rLast];  // interval span [i0, i1], both significant
+    const bool atChromStart = (M.brk[i0 >> 6] >> (i0 & 63)) & 1ull;
+    const u32 peakStart = atChromStart ? 0u : end[i0 - 1];
     float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
-    u32 summitPos = 0, summitLen = 0, peakEnd = 0;
-    for (u32 base = j0; base < jEnd; base += 64) {
-      u32 k = base + lane;
-      bool in = k < jEnd && L.sig[k];
-      u64 inMask = __ballot(in);
-      // members are a prefix: stop at the first lane that is not one
-      int nIn = (~inMask) ? __builtin_ctzll(~inMask) : 64;
-      float term = 0.0f, pq = -2.0f, pv = 0.0f, qv = 0.0f;
+    u32 summitPos = 0, summitLen = 0;
+    for (u32 base = i0; base <= i1; base += 64) {
+      const u32 i = base + lane;
+      const bool in = i <= i1;
+      float pv = 0.0f, qv = GX_SKIPF, pq = -2.0f, term = 0.0f;
       u32 s = 0, e = 0;
-      if (lane < nIn) {
-        s = L.start[k];
-        e = L.end[k];
-        pv = L.p[k];
-        qv = L.q[k];
-        pq = qOpt ? qv : pv;
-        term = (float)(e - s) * (pq - thr);  // 949-950: float product ...
+      if (in) {
+        e = end[i];
+        s = i == i0 ? peakStart : end[i - 1];
+        pv = p[i];
+        if (q) qv = q[i];
+        pq = q ? qv : pv;
       }
-      for (int l = 0; l < nIn; l++) auc += __shfl(term, l, 64);  // ... float running sum, in order
-      // summit of this chunk: max pq, earliest lane (956-961)
-      float mx = pq;
+      const bool sg = in && pq > thr;       // non-significant intervals inside the span only fill gaps
+      if (!sg) pq = -2.0f; else term = (float)(e - s) * (pq - thr);  // 949-950: float product ...
+      u64 sgMask = __ballot(sg);
+      for (u64 m = sgMask; m; m &= m - 1) auc += __shfl(term, __builtin_ctzll(m), 64);  // ... summed in order
+      if (sgMask) {
+        // summit of this chunk: maximum pq, earliest lane (956-961); among the lanes at the maximum
+        // the first one with the greatest length (962-968)
+        float mx = pq;
 #pragma unroll
-      for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-      if (nIn > 0) {
-        u64 atMax = __ballot(lane < nIn && pq == mx);
-        int firstMax = __builtin_ctzll(atMax);
-        // among the lanes at the maximum: first one with the greatest length (962-968)
-        u32 len = (lane < nIn && pq == mx) ? e - s : 0;
+        for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        const u64 atMax = __ballot(sg && pq == mx);
+        const int firstMax = __builtin_ctzll(atMax);
+        const u32 len = (sg && pq == mx) ? e - s : 0;
         u32 ml = len;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) ml = max(ml, (u32)__shfl_xor((int)ml, d, 64));
-        u64 atLen = __ballot(lane < nIn && pq == mx && len == ml);
-        int firstLen = __builtin_ctzll(atLen);
-        u32 cPos = (u32)(((u64)__shfl((int)e, firstLen, 64) + (u32)__shfl((int)s, firstLen, 64)) / 2 - peakStart);
+        const int firstLen = __builtin_ctzll(__ballot(sg && pq == mx && len == ml));
+        const u32 cPos = (u32)(((u64)(u32)__shfl((int)e, firstLen, 64) + (u32)__shfl((int)s, firstLen, 64)) / 2 - peakStart);
         if (mx > summitVal) {
           summitVal = mx;
           sp = __shfl(pv, firstMax, 64);
@@ -493,23 +543,24 @@ __global__ __launch_bounds__(256) void k_peak_walk(SweepList L, const u32* __res
           summitPos = cPos;
           summitLen = ml;
         }
-        peakEnd = (u32)__shfl((int)e, nIn - 1, 64);
       }
-      if (nIn < 64) break;
     }
     if (lane == 0) {
+      const u32 peakEnd = end[i1];
       bool ok = auc >= minAUC && (long long)peakEnd - (long long)peakStart >= (long long)minLen;
-      valid[h] = ok;
+      valid[c] = ok;
       if (ok) {
+        ChromCursor cur;
+        cur.seek(chromOff, nChrom, i0);
         gx_peak pk;
-        pk.chrom = L.chrom[j0];
+        pk.chrom = cur.c;
         pk.start = peakStart;
         pk.end = peakEnd;
         pk.summit = summitPos;
         pk.auc = auc;
         pk.p = sp;
         pk.q = sq;
-        cand[h] = pk;
+        cand[c] = pk;
       }
     }
   }
