@@ -310,7 +310,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(ctx->tileLastEnd.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tilePrevEnd.ensure((size_t)(nTiles + 1) * 4));
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>()};
-  const size_t ldsBytes = (size_t)(TL_PAD + TL_SCR) * 4;
+  const size_t ldsBytes = (size_t)TL_LDS * 4;
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
   if (ctx->hasBed)
     hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s,
@@ -423,16 +423,16 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   HIPCHECK(hipMemsetAsync(ctx->dScal.p, 0, sizeof(Scalars), ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
   HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (TL_PAD + TL_SCR) * 4));
+                               TL_LDS * 4));
   HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (TL_PAD + TL_SCR) * 4));
+                               TL_LDS * 4));
   {
     // persistent kernels: the grid must not exceed what is co-resident (look-back forward progress)
     hipDeviceProp_t prop;
     HIPCHECK(hipGetDeviceProperties(&prop, ctx->device));
     ctx->numCU = prop.multiProcessorCount;
     int nb = 0;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true>, TL_NT, (TL_PAD + TL_SCR) * 4));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true>, TL_NT, TL_LDS * 4));
     ctx->resTile = std::max(1, nb) * ctx->numCU;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_merge2, MG_NT, 0));
     ctx->resMerge = std::max(1, std::min(nb, 4)) * ctx->numCU;

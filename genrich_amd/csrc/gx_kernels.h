@@ -470,8 +470,7 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const u64* __restrict__ in, con
 constexpr int TL_NT = 512;
 constexpr int TL_NW = TL_NT / 64;
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
-constexpr int TL_PAD = TILE + TILE / 32;          // +1 dword per 32: conflict-free blocked reads
-constexpr int TL_SCR = 64 + TILE / 32;            // scratch ints after the slice (+ the -E edge bitmap)
+constexpr int TL_LDS = TILE + 64 + 2 * (TILE / 32); // ints: slice, scan scratch, occupancy + -E edge bitmaps
 constexpr int V_MARK = (int)0x80000000;           // "pileup" of an interval inside an excluded (-E) region
 
 // -E support (Genrich.c:2185-2263): bed edges are breakpoints whatever the difference array
@@ -498,16 +497,21 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
                                                    const u32* __restrict__ tileChrom,
                                                    const DChrom* __restrict__ chroms, u32 nTiles,
                                                    BedIn bed, TileOut out, u32* __restrict__ st) {
+  // LDS: the tile's slice of the difference array (one int per base) plus an occupancy bitmap
+  // (one bit per base).  Only bases that received a record are ever read back or cleared, so a
+  // tile costs O(records) LDS traffic instead of O(TILE): at config 2 ~1,060 of the 16,384 bases
+  // of a tile are touched.  The slice is all-zero whenever a tile starts (each tile clears what it
+  // touched).
   extern __shared__ __attribute__((aligned(16))) int lds[];
-  int* delta = lds;                        // TL_PAD ints (no static LDS: keeps the base 16-B aligned)
-  int* scr = lds + TL_PAD;                 // [0..8] sums, [16..24] counts, [32..40] edge counts
-  u32* eb = reinterpret_cast<u32*>(scr + 64);  // -E edge bitmap: word i = bases of thread i
+  int* delta = lds;                            // TILE ints
+  int* scr = lds + TILE;                       // [0..8] sums, [16..24] counts, [32..40] edge counts
+  u32* occ = reinterpret_cast<u32*>(scr + 64); // TILE/32 words: word i = bases of thread i
+  u32* eb = occ + TILE / 32;                   // -E edge bitmap, same shape
   const int wv = threadIdx.x >> 6;
   u32 bad = 0;
+  for (int i = threadIdx.x * 4; i < TILE; i += TL_NT * 4)
+    *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
   for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {
-    // zero the slice (16 B per lane)
-    for (int i = threadIdx.x * 4; i < TL_PAD; i += TL_NT * 4)
-      *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
     const u32 ci = tileChrom[t];
     const DChrom c = chroms[ci];
     const bool active = chrom_active(c);
@@ -516,13 +520,15 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
     const bool lastTile = tl + 1 == c.nTiles;
     const u32 rb = tileOff[t], re = tileOff[t + 1];
     const int carry = tilePrefW[t] - tilePrefW[c.tileBase];
+    occ[threadIdx.x] = 0;
     if (BED) eb[threadIdx.x] = 0;
     __syncthreads();
     // accumulate this tile's endpoint records
     for (u32 i = rb + threadIdx.x; i < re; i += TL_NT) {
       u64 r = recs[i];
       u32 off = (u32)(r >> 8) & (TILE - 1);
-      atomicAdd(&delta[off + (off >> 5)], (int)(int8_t)(r & 0xFF));
+      atomicAdd(&delta[off], (int)(int8_t)(r & 0xFF));
+      atomicOr(&occ[off >> 5], 1u << (off & 31));
     }
     if (BED)
       for (u32 i = bed.bedTileOff[t] + threadIdx.x; i < bed.bedTileOff[t + 1]; i += TL_NT) {
@@ -530,11 +536,11 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
         atomicOr(&eb[off >> 5], 1u << (off & 31));
       }
     __syncthreads();
-    // -E: `save` state at this thread's first base = tile state ^ parity(edges before it)
-    u32 ew = 0;
+    // thread i owns bases [32 i, 32 i + 32): pass 1 over its touched bases (and -E edges)
+    const u32 ow = occ[threadIdx.x];
+    const u32 ew = BED ? eb[threadIdx.x] : 0u;
     bool save = true;
-    if (BED) {
-      ew = eb[threadIdx.x];
+    if (BED) {  // `save` state at this thread's first base = tile state ^ parity(edges before it)
       const int pe = __popc(ew);
       const int incE = dpp_scan_add(pe);
       if (lane_id() == 63) scr[32 + wv] = incE;
@@ -546,19 +552,17 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
       save = ((bed.tileSave0[t] != 0) ^ ((preE & 1) != 0));
     }
     const bool save0 = save;
-    // blocked read: thread i owns bases [32 i, 32 i + 32)
-    int d[TL_EPT];
+    const int lbase = threadIdx.x * 32;
     int sum = 0;
     u32 cnt = 0, sat = 0;
-    const int lbase = threadIdx.x * 33;
-#pragma unroll
-    for (int k = 0; k < TL_EPT; k++) {
-      d[k] = delta[lbase + k];
-      sum += d[k];
+    for (u32 m = ow | ew; m; m &= m - 1) {
+      const int k = __builtin_ctz(m);
+      const int d = delta[lbase + k];
       const bool edge = BED && ((ew >> k) & 1u);
-      cnt += (edge || (save && d[k] != 0)) && (pos0 + threadIdx.x * TL_EPT + k != 0);  // 2241
-      if (edge) save = !save;                                                           // 2258-2263
-      sat |= (u32)(d[k] >= 32767 * GX_UNIT) | (u32)(d[k] <= -32768 * GX_UNIT);
+      sum += d;
+      cnt += (edge || (save && d != 0)) && (pos0 + lbase + k != 0);  // 2241
+      if (edge) save = !save;                                         // 2258-2263
+      sat |= (u32)(d >= 32767 * GX_UNIT) | (u32)(d <= -32768 * GX_UNIT);
     }
     if (!active) cnt = 0;
     // fused block scan of (sum, cnt): two DPP wave scans, one cross-wave step
@@ -575,27 +579,30 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
       if (w < wv) { preS += ws; preC += wc; }
       totC += wc;
     }
-    if (active) {  // block-uniform
-      int run = carry + preS + (incS - sum);
-      const u32 slot = rb + t + (BED ? bed.bedTileOff[t] : 0u);  // a tile closes <= records + edges + 1 intervals
-      const u32 o0 = slot + preC + (incC - cnt);
-      const u32 totFinal = totC + (lastTile ? 1u : 0u);
-      u32 o = o0, neg = 0, lastEnd = 0;
-      save = save0;
-#pragma unroll
-      for (int k = 0; k < TL_EPT; k++) {
-        u32 p = pos0 + threadIdx.x * TL_EPT + k;
-        const bool edge = BED && ((ew >> k) & 1u);
-        if ((edge || (save && d[k] != 0)) && p != 0) {
-          out.looseEnd[o] = p;
-          out.looseV[o] = save ? run : V_MARK;  // 2244-2248
-          lastEnd = p;
-          o++;
-        }
-        if (edge) save = !save;
-        run += d[k];
-        neg |= (u32)(run < 0);
+    // pass 2: emit, and clear what was touched
+    int run = carry + preS + (incS - sum);
+    const u32 slot = rb + t + (BED ? bed.bedTileOff[t] : 0u);  // a tile closes <= records + edges + 1 intervals
+    const u32 o0 = slot + preC + (incC - cnt);
+    const u32 totFinal = active ? totC + (lastTile ? 1u : 0u) : 0u;
+    u32 o = o0, neg = 0, lastEnd = 0;
+    save = save0;
+    for (u32 m = ow | ew; m; m &= m - 1) {
+      const int k = __builtin_ctz(m);
+      const int d = delta[lbase + k];
+      const u32 p = pos0 + lbase + k;
+      const bool edge = BED && ((ew >> k) & 1u);
+      if (active && (edge || (save && d != 0)) && p != 0) {
+        out.looseEnd[o] = p;
+        out.looseV[o] = save ? run : V_MARK;  // 2244-2248
+        lastEnd = p;
+        o++;
       }
+      if (edge) save = !save;
+      run += d;
+      neg |= (u32)(run < 0);
+      if (d != 0) delta[lbase + k] = 0;
+    }
+    if (active) {  // block-uniform
       if (lastTile && threadIdx.x == TL_NT - 1) {  // closing interval [.., len)
         out.looseEnd[o] = c.len;
         out.looseV[o] = save ? run : V_MARK;
@@ -603,12 +610,10 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
         o++;
       }
       if (o != o0 && o == slot + totFinal) out.tileLastEnd[t] = lastEnd;  // wrote the tile's last interval
-      if (threadIdx.x == 0) out.tileCount[t] = totFinal;
       bad |= (neg ? ST_NEG_PILE : 0) | (sat ? ST_SAT16 : 0);
-    } else if (threadIdx.x == 0) {
-      out.tileCount[t] = 0;
     }
-    __syncthreads();  // scr and the slice are reused by the next tile
+    if (threadIdx.x == 0) out.tileCount[t] = totFinal;
+    __syncthreads();  // scr, occ and the slice are reused by the next tile
   }
   if (bad) atomicOr(st, bad);
 }
