@@ -92,8 +92,13 @@ struct gx_ctx {
   size_t evCount = 0;
   struct Seg { const gx_event* p; size_t n; };
   std::vector<Seg> segs;
-  DevBuf recsA, recsB, sbHist, sbOff, sbCursor, sbChunkOff, tileCnt, tileWsum, tileOff, tileCursor,
-      tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
+  struct Stream {  // one record stream of the bucket sort
+    DevBuf a, b, sbHist, sbOff, sbCursor, sbChunkOff;
+    u32 chunks2 = 0;
+  };
+  Stream str[3];  // S (start keys), E (end keys), F (fractional records)
+  DevBuf tileCnt[3], tileOff[3], tileCursor[3];
+  DevBuf tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};
   std::vector<PArray> reps;
@@ -227,6 +232,32 @@ int upload_chroms(gx_ctx* ctx) {
   return GX_OK;
 }
 
+// one record stream of the bucket sort (S / E: 4-byte keys, F: 8-byte records)
+template <typename R>
+int sort_stream(gx_ctx* ctx, gx_ctx::Stream& st, u32 nRec, int q) {
+  hipStream_t s = ctx->stream;
+  const u32 nSB = ctx->nSB, nTiles = ctx->nTiles;
+  constexpr u32 CHUNK = SC_NT * ScCfg<R>::ITEMS;
+  hipLaunchKernelGGL(k_scan_sb, dim3(1), dim3(1024), 0, s, st.sbHist.as<u32>(), nSB, CHUNK, st.sbOff.as<u32>(),
+                     st.sbCursor.as<u32>(), st.sbChunkOff.as<u32>());
+  const u32 chunks1 = (nRec + CHUNK - 1) / CHUNK;
+  hipLaunchKernelGGL((k_scatter<1, R>), dim3(chunks1), dim3(SC_NT), 0, s, st.a.as<R>(), st.b.as<R>(),
+                     st.sbOff.as<u32>() + nSB /* total */, (const u32*)nullptr, 0u, ctx->sbShift, nSB, st.sbCursor.as<u32>());
+  st.chunks2 = chunks1 + nSB;  // upper bound on sum of ceil(count / CHUNK)
+  hipLaunchKernelGGL((k_hist2<R>), dim3(st.chunks2), dim3(SC_NT), 0, s, st.b.as<R>(), st.sbOff.as<u32>(),
+                     st.sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, ctx->tileCnt[q].as<u32>(), ctx->tileWsum.as<int>());
+  (void)nTiles;
+  return dbg_sync(ctx, "sort_stream level 1");
+}
+
+template <typename R>
+int sort_stream2(gx_ctx* ctx, gx_ctx::Stream& st, int q) {
+  hipLaunchKernelGGL((k_scatter<2, R>), dim3(st.chunks2), dim3(SC_NT), 0, ctx->stream, st.b.as<R>(), st.a.as<R>(),
+                     st.sbOff.as<u32>(), st.sbChunkOff.as<u32>(), ctx->nSB - 1, ctx->sbShift, ctx->nSB,
+                     ctx->tileCursor[q].as<u32>());
+  return dbg_sync(ctx, "sort_stream level 2");
+}
+
 // events -> tile-bucketed endpoint records -> run-length pileup + exact fragLen accumulators
 int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // host-pushed events are staged in evBuf; device-resident segments are used in place
@@ -239,71 +270,104 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     ctx->err = "too many events in one sample for 32-bit record offsets";
     return GX_ERR_MEM;
   }
-  const u32 nRec = (u32)(2 * n);
+  const u32 nEv = (u32)n;
   const u32 nTiles = ctx->nTiles, nSB = ctx->nSB, nChrom = ctx->nChrom;
+  const bool unit32 = nTiles < MAX_TILES32;  // tile id + offset fit a 4-byte key
   hipStream_t s = ctx->stream;
-  HIPCHECK(ctx->recsA.ensure((size_t)nRec * 8 + 16));
-  HIPCHECK(ctx->recsB.ensure((size_t)nRec * 8 + 16));
-  HIPCHECK(ctx->tileCnt.ensure((size_t)(nTiles + 1) * 4));
+  gx_ctx::Stream& SS = ctx->str[0];
+  gx_ctx::Stream& SE = ctx->str[1];
+  gx_ctx::Stream& SF = ctx->str[2];
+  if (unit32) {
+    HIPCHECK(SS.a.ensure((size_t)nEv * 4 + 16));
+    HIPCHECK(SS.b.ensure((size_t)nEv * 4 + 16));
+    HIPCHECK(SE.a.ensure((size_t)nEv * 4 + 16));
+    HIPCHECK(SE.b.ensure((size_t)nEv * 4 + 16));
+  }
+  HIPCHECK(SF.a.ensure((size_t)nEv * 16 + 16));  // worst case: every event fractional
+  for (int q = 0; q < 3; q++) {
+    gx_ctx::Stream& st = ctx->str[q];
+    HIPCHECK(st.sbHist.ensure(MAX_BINS * 4));
+    HIPCHECK(st.sbOff.ensure((MAX_BINS + 2) * 4));
+    HIPCHECK(st.sbCursor.ensure((MAX_BINS + 2) * 4));
+    HIPCHECK(st.sbChunkOff.ensure((MAX_BINS + 2) * 4));
+    HIPCHECK(ctx->tileCnt[q].ensure((size_t)(nTiles + 1) * 4));
+    HIPCHECK(ctx->tileOff[q].ensure((size_t)(nTiles + 2) * 4));
+    HIPCHECK(ctx->tileCursor[q].ensure((size_t)(nTiles + 1) * 4));
+    HIPCHECK(hipMemsetAsync(st.sbHist.p, 0, MAX_BINS * 4, s));
+    HIPCHECK(hipMemsetAsync(ctx->tileCnt[q].p, 0, (size_t)(nTiles + 1) * 4, s));
+  }
   HIPCHECK(ctx->tileWsum.ensure((size_t)(nTiles + 1) * 4));
-  HIPCHECK(ctx->tileOff.ensure((size_t)(nTiles + 2) * 4));
-  HIPCHECK(ctx->tileCursor.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
-  HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 8) * 8));
-  // an interval closes at every base with a non-zero difference (<= one per record) plus one per chromosome
-  const size_t ivCap = (size_t)nRec + nChrom + ctx->nBedEdges + 16;
+  HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 64) * 8));
+  // an interval closes at every base with a non-zero difference (<= one per record), at every -E edge,
+  // plus one per chromosome
+  const size_t ivCap = (size_t)2 * nEv + nChrom + ctx->nBedEdges + 16;
   HIPCHECK(pooled(ctx, out.ivEnd, ivCap * 4));
   HIPCHECK(pooled(ctx, out.ivV, ivCap * 4));
   HIPCHECK(pooled(ctx, out.tileIvOff, (size_t)(nTiles + 2) * 4));
   HIPCHECK(pooled(ctx, out.chromIvOff, (size_t)(nChrom + 2) * 4));
 
   phase_begin(ctx, isCtrl ? "c.convert" : "t.convert");
-  HIPCHECK(hipMemsetAsync(ctx->sbHist.p, 0, MAX_BINS * 4, s));
-  HIPCHECK(hipMemsetAsync(ctx->tileCnt.p, 0, (size_t)(nTiles + 1) * 4, s));
   HIPCHECK(hipMemsetAsync(ctx->tileWsum.p, 0, (size_t)(nTiles + 1) * 4, s));
-  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 1) * 8, s));
-  HIPCHECK(hipMemsetAsync(ctx->misc.as<u32>() + M_TICKET, 0, 8, s));  // ticket + nIv
+  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 64) * 8, s));
+  HIPCHECK(hipMemsetAsync(ctx->misc.as<u32>() + M_TICKET, 0, 8, s));  // nF + nIv
+  ConvertOut co{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), ctx->misc.as<u32>() + M_TICKET, SS.sbHist.as<u32>(),
+                SE.sbHist.as<u32>()};
   size_t off = 0;
   for (auto& seg : segs) {
     if (!seg.n) continue;
     u32 blocks = (u32)std::min<size_t>((seg.n + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_convert, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
-                       ctx->sbShift, nSB, ctx->recsA.as<u64>() + 2 * off, ctx->sbHist.as<u32>(), ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_convert")) return rc__;
+    if (unit32)
+      hipLaunchKernelGGL(k_convert<true>, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, (u32)off, ctx->dChrom.as<DChrom>(),
+                         nChrom, ctx->sbShift, nSB, co, ctx->dStatus.as<u32>());
+    else
+      hipLaunchKernelGGL(k_convert<false>, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, (u32)off,
+                         ctx->dChrom.as<DChrom>(), nChrom, ctx->sbShift, nSB, co, ctx->dStatus.as<u32>());
     off += seg.n;
+  }
+  if (int rc__ = dbg_sync(ctx, "k_convert")) return rc__;
+  u32 nF = 2 * nEv;
+  if (unit32) {  // how many fractional records were appended (0 for ordinary data)
+    HIPCHECK(hipMemcpyAsync(&nF, ctx->misc.as<u32>() + M_TICKET, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
   }
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.bucket" : "t.bucket");
-  hipLaunchKernelGGL(k_scan_sb, dim3(1), dim3(1024), 0, s, ctx->sbHist.as<u32>(), nSB, (u32)SC_CHUNK, ctx->sbOff.as<u32>(),
-                     ctx->sbCursor.as<u32>(), ctx->sbChunkOff.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_scan_sb")) return rc__;
-  const u32 chunks1 = (nRec + SC_CHUNK - 1) / SC_CHUNK;
-  if (chunks1) {
-    hipLaunchKernelGGL(k_scatter<1>, dim3(chunks1), dim3(SC_NT), 0, s, ctx->recsA.as<u64>(), ctx->recsB.as<u64>(),
-                       ctx->sbOff.as<u32>() + nSB /* total */, (const u32*)nullptr, 0u, ctx->sbShift, nSB,
-                       ctx->sbCursor.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_scatter<1>")) return rc__;
-    const u32 chunks2 = chunks1 + nSB;  // upper bound on sum of ceil(count / CHUNK)
-    hipLaunchKernelGGL(k_hist2, dim3(chunks2), dim3(SC_NT), 0, s, ctx->recsB.as<u64>(), ctx->sbOff.as<u32>(),
-                       ctx->sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>());
-  if (int rc__ = dbg_sync(ctx, "k_hist2")) return rc__;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(std::min<u32>((nTiles + STL_CHUNK - 1) / STL_CHUNK, (u32)ctx->resSweep)),
-                       dim3(STL_NT), 0, s, ctx->tileCnt.as<u32>(), ctx->tileWsum.as<int>(), nTiles, ctx->lb.as<u64>(),
-                       ctx->tileOff.as<u32>(), ctx->tileCursor.as<u32>(), ctx->tileCarry.as<int>(), ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_scan_tiles")) return rc__;
-    hipLaunchKernelGGL(k_scatter<2>, dim3(chunks2), dim3(SC_NT), 0, s, ctx->recsB.as<u64>(), ctx->recsA.as<u64>(),
-                       ctx->sbOff.as<u32>(), ctx->sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, nSB,
-                       ctx->tileCursor.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_scatter<2>")) return rc__;
-  } else {
-    HIPCHECK(hipMemsetAsync(ctx->tileOff.p, 0, (size_t)(nTiles + 2) * 4, s));
-    HIPCHECK(hipMemsetAsync(ctx->tileCarry.p, 0, (size_t)(nTiles + 1) * 4, s));
+  if (nF) {
+    HIPCHECK(SF.b.ensure((size_t)nF * 8 + 16));
+    hipLaunchKernelGGL((k_hist1<u64>), dim3(std::max(1u, std::min((nF + 255) / 256, 4096u))), dim3(256), 0, s, SF.a.as<u64>(),
+                       nF, ctx->sbShift, nSB, SF.sbHist.as<u32>());
   }
+  if (unit32 && nEv) {
+    if (int rc = sort_stream<u32>(ctx, SS, nEv, 0)) return rc;
+    if (int rc = sort_stream<u32>(ctx, SE, nEv, 1)) return rc;
+  }
+  if (nF)
+    if (int rc = sort_stream<u64>(ctx, SF, nF, 2)) return rc;
+  TileTabs tt{};
+  for (int q = 0; q < 3; q++) {
+    tt.cnt[q] = ctx->tileCnt[q].as<u32>();
+    tt.off[q] = ctx->tileOff[q].as<u32>();
+    tt.cursor[q] = ctx->tileCursor[q].as<u32>();
+  }
+  tt.wsumF = ctx->tileWsum.as<int>();
+  tt.prefW = ctx->tileCarry.as<int>();
+  const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s, tt, nTiles,
+                     ctx->lb.as<u64>(), ctx->lb.as<u64>() + tChunks + 2, ctx->lb.as<u64>() + 2 * (tChunks + 2),
+                     ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_scan_tiles")) return rc__;
+  if (unit32 && nEv) {
+    if (int rc = sort_stream2<u32>(ctx, SS, 0)) return rc;
+    if (int rc = sort_stream2<u32>(ctx, SE, 1)) return rc;
+  }
+  if (nF)
+    if (int rc = sort_stream2<u64>(ctx, SF, 2)) return rc;
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");
-  const size_t looseCap = (size_t)nRec + nTiles + ctx->nBedEdges + 16;  // slot t: tileOff[t] + t (+ edges before)
+  const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
   HIPCHECK(ctx->looseEnd.ensure(looseCap * 4));
   HIPCHECK(ctx->looseV.ensure(looseCap * 4));
   HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
@@ -312,14 +376,16 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>()};
   const size_t ldsBytes = (size_t)TL_LDS * 4;
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
+  TileIn tin{SS.a.as<u32>(), ctx->tileOff[0].as<u32>(), SE.a.as<u32>(), ctx->tileOff[1].as<u32>(), SF.a.as<u64>(),
+             ctx->tileOff[2].as<u32>()};
   if (ctx->hasBed)
-    hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s,
-                       ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
-                       ctx->dChrom.as<DChrom>(), nTiles, bin, to, ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin,
+                       ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, bin, to,
+                       ctx->dStatus.as<u32>());
   else
-    hipLaunchKernelGGL(k_tile<false>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s,
-                       ctx->recsA.as<u64>(), ctx->tileOff.as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
-                       ctx->dChrom.as<DChrom>(), nTiles, bin, to, ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_tile<false>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin,
+                       ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, bin, to,
+                       ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   phase_end(ctx);
 
@@ -338,8 +404,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   Scalars* ds = ctx->dScal.as<Scalars>();
   long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
   HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
-  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileOff.as<u32>(),
-             ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, out.tileIvOff.as<u32>(),
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileOff[0].as<u32>(), ctx->tileOff[1].as<u32>(),
+             ctx->tileOff[2].as<u32>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, out.tileIvOff.as<u32>(),
              ctx->tilePrevEnd.as<u32>()};
   hipLaunchKernelGGL(k_pack, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, pin, nTiles,
                      out.ivEnd.as<u32>(), out.ivV.as<int>(), acc, ctx->dStatus.as<u32>());
@@ -415,10 +481,6 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   HIPCHECK(ctx->misc.ensure(M_WORDS * 4));
   HIPCHECK(ctx->dScal.ensure(sizeof(Scalars)));
   HIPCHECK(ctx->dStatus.ensure(64));
-  HIPCHECK(ctx->sbHist.ensure(MAX_BINS * 4));
-  HIPCHECK(ctx->sbOff.ensure((MAX_BINS + 2) * 4));
-  HIPCHECK(ctx->sbCursor.ensure((MAX_BINS + 2) * 4));
-  HIPCHECK(ctx->sbChunkOff.ensure((MAX_BINS + 2) * 4));
   HIPCHECK(hipMemsetAsync(ctx->misc.p, 0, M_WORDS * 4, ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dScal.p, 0, sizeof(Scalars), ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));

@@ -195,18 +195,50 @@ struct ChromCursor {
 // Replaces the accumulate step of saveInterval (Genrich.c:2546-2583): instead of a
 // read-modify-write on diff[start] / diff[end], emit (+w at start) and (-w at end).
 // An end at the chromosome length never influences a base < len and is dropped.
-// Also builds the level-1 (super-bucket) histogram.
-__global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev, u32 n,
+//
+// Three record streams feed the bucket sort:
+//   S, E : 4-byte keys  [31:TB] tile  [TB-1:0] offset  for the starts / ends of unit-weight
+//          (count == 1) intervals -- sign and weight are implied by the stream, which halves
+//          the sort traffic of the common case.  One slot per event (NULL32 when unused).
+//   F    : 8-byte records  [63:32] tile  [31:8] offset  [7:0] signed weight (1/120 units) for
+//          multimapped (fractional) intervals, appended compactly; also carries everything when
+//          the genome has too many tiles for a 4-byte key.
+constexpr u32 NULL32 = 0xFFFFFFFFu;
+constexpr u32 MAX_TILES32 = (1u << (32 - TB)) - 1;  // tile ids representable in a 4-byte key
+
+template <typename R> struct RecT;
+template <> struct RecT<u64> {
+  static __device__ __forceinline__ u32 tile(u64 r) { return (u32)(r >> 32); }
+};
+template <> struct RecT<u32> {
+  static __device__ __forceinline__ u32 tile(u32 r) { return r == NULL32 ? NULL_TILE : r >> TB; }
+};
+
+__device__ __forceinline__ u64 make_rec64(u32 tile, u32 off, int w) {
+  return ((u64)tile << 32) | ((u64)off << 8) | (u64)(uint8_t)(int8_t)w;
+}
+
+struct ConvertOut {
+  u32* S;       // [n] start keys
+  u32* E;       // [n] end keys
+  u64* F;       // fractional / fallback records
+  u32* nF;      // number of F records (appended in pairs)
+  u32* histS;   // level-1 histograms [nSB]
+  u32* histE;
+};
+
+template <bool UNIT32>
+__global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev, u32 n, u32 evBase,
                                                  const DChrom* __restrict__ chroms, u32 nChrom,
-                                                 int sbShift, u32 nSB, u64* __restrict__ recs,
-                                                 u32* __restrict__ sbHist, u32* __restrict__ st) {
-  __shared__ u32 hist[MAX_BINS];
-  for (int i = threadIdx.x; i < (int)nSB; i += 256) hist[i] = 0;
-  __syncthreads();
+                                                 int sbShift, u32 nSB, ConvertOut out, u32* __restrict__ st) {
+  __shared__ u32 hS[MAX_BINS], hE[MAX_BINS];
+  if (UNIT32) {
+    for (int i = threadIdx.x; i < (int)nSB; i += 256) { hS[i] = 0; hE[i] = 0; }
+    __syncthreads();
+  }
   u32 bad = 0;
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     uint4 e = reinterpret_cast<const uint4*>(ev)[i];  // chrom, start, end, count
-    u64 r0 = (u64)NULL_TILE << 32, r1 = r0;
     int w = 0;
     switch (e.w) {
       case 1: w = 120; break;
@@ -219,6 +251,7 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
       case 10: w = 12; break;
       default: bad |= ST_BAD_COUNT;
     }
+    u32 t0 = NULL_TILE, t1 = NULL_TILE, o0 = 0, o1 = 0;
     if (e.x >= nChrom)
       bad |= ST_BAD_CHROM;
     else if (w) {
@@ -229,27 +262,61 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
         else {
           u32 end = e.z > c.len ? c.len : e.z;
           if (end > e.y) {  // an empty interval adds and removes the same weight
-            r0 = ((u64)(c.tileBase + (e.y >> TB)) << 32) | ((u64)(e.y & (TILE - 1)) << 8) |
-                 (u64)(uint8_t)(int8_t)w;
-            if (end < c.len)
-              r1 = ((u64)(c.tileBase + (end >> TB)) << 32) | ((u64)(end & (TILE - 1)) << 8) |
-                   (u64)(uint8_t)(int8_t)(-w);
+            t0 = c.tileBase + (e.y >> TB);
+            o0 = e.y & (TILE - 1);
+            if (end < c.len) {
+              t1 = c.tileBase + (end >> TB);
+              o1 = end & (TILE - 1);
+            }
           }
         }
       }
     }
-    reinterpret_cast<ulonglong2*>(recs)[i] = make_ulonglong2(r0, r1);
-    u32 t0 = (u32)(r0 >> 32), t1 = (u32)(r1 >> 32);
-    atomicAdd(&hist[t0 == NULL_TILE ? nSB - 1 : t0 >> sbShift], 1u);
-    atomicAdd(&hist[t1 == NULL_TILE ? nSB - 1 : t1 >> sbShift], 1u);
+    const bool unit = UNIT32 && w == 120;
+    if (UNIT32) {
+      u32 ks = unit && t0 != NULL_TILE ? (t0 << TB) | o0 : NULL32;
+      u32 ke = unit && t1 != NULL_TILE ? (t1 << TB) | o1 : NULL32;
+      out.S[evBase + i] = ks;
+      out.E[evBase + i] = ke;
+      atomicAdd(&hS[ks == NULL32 ? nSB - 1 : t0 >> sbShift], 1u);
+      atomicAdd(&hE[ke == NULL32 ? nSB - 1 : t1 >> sbShift], 1u);
+    }
+    if (!unit && t0 != NULL_TILE) {
+      u32 pos = UNIT32 ? atomicAdd(out.nF, 2u) : 2 * (evBase + i);
+      out.F[pos] = make_rec64(t0, o0, w);
+      out.F[pos + 1] = t1 != NULL_TILE ? make_rec64(t1, o1, -w) : (u64)NULL_TILE << 32;
+    } else if (!UNIT32) {
+      out.F[2 * (evBase + i)] = (u64)NULL_TILE << 32;
+      out.F[2 * (evBase + i) + 1] = (u64)NULL_TILE << 32;
+    }
+  }
+  if (UNIT32) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)nSB; i += 256) {
+      if (hS[i]) atomicAdd(&out.histS[i], hS[i]);
+      if (hE[i]) atomicAdd(&out.histE[i], hE[i]);
+    }
+  }
+  if (bad) atomicOr(st, bad);
+}
+
+// level-1 histogram of an already materialised stream (the F records)
+template <typename R>
+__global__ __launch_bounds__(256) void k_hist1(const R* __restrict__ in, u32 n, int sbShift, u32 nSB,
+                                               u32* __restrict__ sbHist) {
+  __shared__ u32 hist[MAX_BINS];
+  for (int i = threadIdx.x; i < (int)nSB; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    u32 t = RecT<R>::tile(in[i]);
+    atomicAdd(&hist[t == NULL_TILE ? nSB - 1 : t >> sbShift], 1u);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < (int)nSB; i += 256)
     if (hist[i]) atomicAdd(&sbHist[i], hist[i]);
-  if (bad) atomicOr(st, bad);
 }
 
-// ---- 2. tiny single-block scans ----------------------------------------------------------
+// ---- 2. tiny scans ------------------------------------------------------------------------
 // super-bucket histogram -> offsets, cursors and the level-2 chunk table
 __global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist, u32 nSB, u32 chunk,
                                                   u32* __restrict__ sbOff, u32* __restrict__ sbCursor,
@@ -272,99 +339,131 @@ __global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist
   if (threadIdx.x == 0) sbChunkOff[nSB] = ctot;
 }
 
-// per-tile record counts -> offsets + cursors, per-tile weight sums -> genome-wide prefix
-// (tilePrefW; the carry-in of a tile is tilePrefW[t] - tilePrefW[first tile of its chromosome]).
-// Persistent multi-workgroup chained scan, 2048 tiles per item.
+// per-tile record counts of the three streams -> offsets + cursors; per-tile weight -> genome-wide
+// prefix tilePrefW (the carry-in of a tile is tilePrefW[t] - tilePrefW[first tile of its
+// chromosome]); weight of a tile = 120 (#S - #E) + sum of its F weights.
+// Persistent multi-workgroup chained scan (one look-back per stream), 2048 tiles per item.
 constexpr int STL_NT = 256;
 constexpr int STL_ITEMS = 8;
 constexpr int STL_CHUNK = STL_NT * STL_ITEMS;
-__global__ __launch_bounds__(STL_NT) void k_scan_tiles(const u32* __restrict__ tileCnt, const int* __restrict__ tileWsum,
-                                                       u32 nTiles, u64* __restrict__ lb, u32* __restrict__ tileOff,
-                                                       u32* __restrict__ tileCursor, int* __restrict__ tilePrefW,
+
+struct TileTabs {
+  const u32* cnt[3];   // S, E, F record counts per tile (F may be nullptr)
+  const int* wsumF;    // sum of F weights per tile (nullptr without F)
+  u32* off[3];         // [nTiles+1]
+  u32* cursor[3];
+  int* prefW;          // [nTiles]
+};
+
+__global__ __launch_bounds__(STL_NT) void k_scan_tiles(TileTabs T, u32 nTiles, u64* __restrict__ lb0,
+                                                       u64* __restrict__ lb1, u64* __restrict__ lb2,
                                                        u32* __restrict__ st) {
   __shared__ u32 scratch[8];
-  __shared__ int iscratch[8];
-  __shared__ u64 s_base;
+  __shared__ u64 s_base[3];
   const u32 nChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  u64* lbs[3] = {lb0, lb1, lb2};
   for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
     const u32 tb = id * STL_CHUNK + threadIdx.x * STL_ITEMS;
-    u32 c[STL_ITEMS];
+    u32 c[3][STL_ITEMS];
     int w[STL_ITEMS];
-    u32 cs = 0;
+    u32 cs[3] = {0, 0, 0};
     int ws = 0;
 #pragma unroll
     for (int k = 0; k < STL_ITEMS; k++) {
       u32 t = tb + k;
-      c[k] = t < nTiles ? tileCnt[t] : 0;
-      w[k] = t < nTiles ? tileWsum[t] : 0;
-      cs += c[k];
+      bool ok = t < nTiles;
+      c[0][k] = ok ? T.cnt[0][t] : 0;
+      c[1][k] = ok ? T.cnt[1][t] : 0;
+      c[2][k] = ok && T.cnt[2] ? T.cnt[2][t] : 0;
+      w[k] = 120 * ((int)c[0][k] - (int)c[1][k]) + (ok && T.wsumF ? T.wsumF[t] : 0);
+      cs[0] += c[0][k];
+      cs[1] += c[1][k];
+      cs[2] += c[2][k];
       ws += w[k];
     }
-    u32 ctot;
+    u32 tot[3];
+    u32 ex[3];
     int wtot;
-    u32 cex = block_excl_scan<u32, STL_NT>(cs, scratch, &ctot);
-    int wex = block_excl_scan<int, STL_NT>(ws, iscratch, &wtot);
+    for (int q = 0; q < 3; q++) ex[q] = block_excl_scan<u32, STL_NT>(cs[q], scratch, &tot[q]);
+    int wex = block_excl_scan<int, STL_NT>(ws, reinterpret_cast<int*>(scratch), &wtot);
     if (threadIdx.x < 64) {
-      // one granule carries both prefixes: records in the low 32 bits, weight (mod 2^30) in the
-      // next 30.  A chunk's weight sum may be negative, but every PREFIX is a pileup value at a
-      // tile boundary (>= 0, < 2^30 in 1/120 units), so modular sums reproduce it exactly.
-      u64 agg = (u64)ctot | ((u64)((u32)wtot & 0x3FFFFFFFu) << 32);
-      u64 excl = lookback_excl(lb, id, agg, st);
+      // stream 0's granule also carries the weight prefix (mod 2^30) in bits 32..61.  A chunk's
+      // weight sum may be negative, but every PREFIX is a pileup value at a tile boundary
+      // (>= 0, < 2^30 in 1/120 units), so modular sums reproduce it exactly.
+      u64 agg0 = (u64)tot[0] | ((u64)((u32)wtot & 0x3FFFFFFFu) << 32);
+      u64 e0 = lookback_excl(lbs[0], id, agg0, st);
+      u64 e1 = lookback_excl(lbs[1], id, (u64)tot[1], st);
+      u64 e2 = lookback_excl(lbs[2], id, (u64)tot[2], st);
       if (threadIdx.x == 0) {
-        s_base = excl;
-        if (id == nChunks - 1) tileOff[nTiles] = (u32)excl + ctot;
+        s_base[0] = e0;
+        s_base[1] = e1;
+        s_base[2] = e2;
+        if (id == nChunks - 1) {
+          T.off[0][nTiles] = (u32)e0 + tot[0];
+          T.off[1][nTiles] = (u32)e1 + tot[1];
+          T.off[2][nTiles] = (u32)e2 + tot[2];
+        }
       }
     }
     __syncthreads();
-    cex += (u32)s_base;
-    wex = (int)(((u32)wex + (u32)(s_base >> 32)) & 0x3FFFFFFFu);
+    ex[0] += (u32)s_base[0];
+    ex[1] += (u32)s_base[1];
+    ex[2] += (u32)s_base[2];
+    wex = (int)(((u32)wex + (u32)(s_base[0] >> 32)) & 0x3FFFFFFFu);
 #pragma unroll
     for (int k = 0; k < STL_ITEMS; k++) {
       u32 t = tb + k;
       if (t < nTiles) {
-        tileOff[t] = cex;
-        tileCursor[t] = cex;
-        tilePrefW[t] = wex;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          T.off[q][t] = ex[q];
+          T.cursor[q][t] = ex[q];
+        }
+        T.prefW[t] = wex;
       }
-      cex += c[k];
+      ex[0] += c[0][k];
+      ex[1] += c[1][k];
+      ex[2] += c[2][k];
       wex = (int)(((u32)wex + (u32)w[k]) & 0x3FFFFFFFu);
     }
     __syncthreads();
   }
 }
 
-// ---- 3. bucket scatter (both levels) -------------------------------------------------------
+// ---- 3. bucket scatter (both levels, either record width) -----------------------------------
 // One workgroup takes CHUNK records of one segment, ranks them per bin with LDS atomics,
 // reserves a run per (workgroup, bin) with one global atomic, sorts the chunk in LDS and
 // writes bin-contiguous runs.  Order inside a bin is arbitrary: every consumer is a
 // commutative integer sum.
 constexpr int SC_NT = 256;
-constexpr int SC_ITEMS = 16;
-constexpr int SC_CHUNK = SC_NT * SC_ITEMS;  // 4096 records
+template <typename R> struct ScCfg { static constexpr int ITEMS = 16; };   // 4096 x 8 B = 32 KiB staged
+template <> struct ScCfg<u32> { static constexpr int ITEMS = 32; };       // 8192 x 4 B = 32 KiB staged
 
-template <int LEVEL>
-__device__ __forceinline__ u32 bin_of(u64 r, int sbShift, u32 nBins, u32 segTileBase) {
-  u32 t = (u32)(r >> 32);
+template <int LEVEL, typename R>
+__device__ __forceinline__ u32 bin_of(R r, int sbShift, u32 nBins, u32 segTileBase) {
+  u32 t = RecT<R>::tile(r);
   if (LEVEL == 1) return t == NULL_TILE ? nBins - 1 : t >> sbShift;
   return t - segTileBase;
 }
 
-template <int LEVEL>
-__global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ in, u64* __restrict__ out,
+template <int LEVEL, typename R>
+__global__ __launch_bounds__(SC_NT) void k_scatter(const R* __restrict__ in, R* __restrict__ out,
                                                    const u32* __restrict__ segOff,
                                                    const u32* __restrict__ chunkOff, u32 nSeg,
                                                    int sbShift, u32 nBinsL1, u32* __restrict__ cursor) {
+  constexpr int ITEMS = ScCfg<R>::ITEMS;
+  constexpr int CHUNK = SC_NT * ITEMS;
   __shared__ u32 hist[MAX_BINS];
   __shared__ u32 start[MAX_BINS];
   __shared__ u32 base[MAX_BINS];
-  __shared__ u64 stage[SC_CHUNK];
+  __shared__ R stage[CHUNK];
   __shared__ u32 scratch[8];
   u32 seg = 0, chunkInSeg = blockIdx.x, begin, end, nBins, segTileBase = 0;
   if (LEVEL == 1) {
-    begin = blockIdx.x * SC_CHUNK;
+    begin = blockIdx.x * CHUNK;
     end = segOff[0];  // total
     if (begin >= end) return;
-    end = min(end, begin + SC_CHUNK);
+    end = min(end, begin + CHUNK);
     nBins = nBinsL1;
   } else {
     if (blockIdx.x >= chunkOff[nSeg]) return;
@@ -375,21 +474,21 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ in, u
     }
     seg = lo;
     chunkInSeg = blockIdx.x - chunkOff[seg];
-    begin = segOff[seg] + chunkInSeg * SC_CHUNK;
-    end = min(segOff[seg + 1], begin + SC_CHUNK);
+    begin = segOff[seg] + chunkInSeg * CHUNK;
+    end = min(segOff[seg + 1], begin + CHUNK);
     nBins = 1u << sbShift;
     segTileBase = seg << sbShift;
   }
   for (int i = threadIdx.x; i < (int)nBins; i += SC_NT) hist[i] = 0;
   __syncthreads();
-  u64 r[SC_ITEMS];
-  u32 rk[SC_ITEMS];
+  R r[ITEMS];
+  u32 rk[ITEMS];
 #pragma unroll
-  for (int k = 0; k < SC_ITEMS; k++) {
+  for (int k = 0; k < ITEMS; k++) {
     u32 idx = begin + k * SC_NT + threadIdx.x;
     if (idx < end) {
       r[k] = in[idx];
-      rk[k] = atomicAdd(&hist[bin_of<LEVEL>(r[k], sbShift, nBins, segTileBase)], 1u);
+      rk[k] = atomicAdd(&hist[bin_of<LEVEL, R>(r[k], sbShift, nBins, segTileBase)], 1u);
     }
   }
   __syncthreads();
@@ -408,23 +507,25 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const u64* __restrict__ in, u
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < SC_ITEMS; k++) {
+  for (int k = 0; k < ITEMS; k++) {
     u32 idx = begin + k * SC_NT + threadIdx.x;
-    if (idx < end) stage[start[bin_of<LEVEL>(r[k], sbShift, nBins, segTileBase)] + rk[k]] = r[k];
+    if (idx < end) stage[start[bin_of<LEVEL, R>(r[k], sbShift, nBins, segTileBase)] + rk[k]] = r[k];
   }
   __syncthreads();
   u32 cnt = end - begin;
   for (u32 i = threadIdx.x; i < cnt; i += SC_NT) {
-    u64 v = stage[i];
-    u32 b = bin_of<LEVEL>(v, sbShift, nBins, segTileBase);
+    R v = stage[i];
+    u32 b = bin_of<LEVEL, R>(v, sbShift, nBins, segTileBase);
     out[base[b] + (i - start[b])] = v;
   }
 }
 
-// level-2 histogram: records and signed weight per tile
-__global__ __launch_bounds__(SC_NT) void k_hist2(const u64* __restrict__ in, const u32* __restrict__ segOff,
+// level-2 histogram: records (and, for F, signed weight) per tile
+template <typename R>
+__global__ __launch_bounds__(SC_NT) void k_hist2(const R* __restrict__ in, const u32* __restrict__ segOff,
                                                  const u32* __restrict__ chunkOff, u32 nSeg, int sbShift,
                                                  u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
+  constexpr int CHUNK = SC_NT * ScCfg<R>::ITEMS;
   __shared__ u32 hist[MAX_BINS];
   __shared__ int wsum[MAX_BINS];
   if (blockIdx.x >= chunkOff[nSeg]) return;
@@ -434,25 +535,24 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const u64* __restrict__ in, con
     if (chunkOff[mid] <= blockIdx.x) lo = mid; else hi = mid;
   }
   u32 seg = lo;
-  u32 begin = segOff[seg] + (blockIdx.x - chunkOff[seg]) * SC_CHUNK;
-  u32 end = min(segOff[seg + 1], begin + SC_CHUNK);
+  u32 begin = segOff[seg] + (blockIdx.x - chunkOff[seg]) * CHUNK;
+  u32 end = min(segOff[seg + 1], begin + CHUNK);
   u32 nBins = 1u << sbShift, segTileBase = seg << sbShift;
   for (int i = threadIdx.x; i < (int)nBins; i += SC_NT) { hist[i] = 0; wsum[i] = 0; }
   __syncthreads();
   for (u32 idx = begin + threadIdx.x; idx < end; idx += SC_NT) {
-    u64 r = in[idx];
-    u32 b = (u32)(r >> 32) - segTileBase;
+    R r = in[idx];
+    u32 b = RecT<R>::tile(r) - segTileBase;
     atomicAdd(&hist[b], 1u);
-    atomicAdd(&wsum[b], (int)(int8_t)(r & 0xFF));
+    if (sizeof(R) == 8) atomicAdd(&wsum[b], (int)(int8_t)((u64)r & 0xFF));
   }
   __syncthreads();
   for (int i = threadIdx.x; i < (int)nBins; i += SC_NT)
     if (hist[i]) {
       atomicAdd(&tileCnt[segTileBase + i], hist[i]);
-      atomicAdd(&tileWsum[segTileBase + i], wsum[i]);
+      if (sizeof(R) == 8) atomicAdd(&tileWsum[segTileBase + i], wsum[i]);
     }
 }
-
 
 // ---- 4. the tile kernel: LDS difference array -> prefix sum -> run-length pileup -----------
 // Replaces savePileupExpt's two per-base passes (Genrich.c:2197-2273; and the per-base walk
@@ -490,9 +590,14 @@ struct TileOut {
   u32* tileLastEnd; // [nTiles] end of the tile's last interval (valid when tileCount > 0)
 };
 
+struct TileIn {
+  const u32* S;  const u32* offS;   // start keys, bucketed by tile; [nTiles+1] offsets
+  const u32* E;  const u32* offE;   // end keys
+  const u64* F;  const u32* offF;   // fractional records
+};
+
 template <bool BED>
-__global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
-                                                   const u32* __restrict__ tileOff,
+__global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in,
                                                    const int* __restrict__ tilePrefW,
                                                    const u32* __restrict__ tileChrom,
                                                    const DChrom* __restrict__ chroms, u32 nTiles,
@@ -518,14 +623,27 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(const u64* __restrict__ recs,
     const u32 tl = t - c.tileBase;
     const u32 pos0 = tl << TB;
     const bool lastTile = tl + 1 == c.nTiles;
-    const u32 rb = tileOff[t], re = tileOff[t + 1];
+    const u32 sb = in.offS[t], se = in.offS[t + 1], eb0 = in.offE[t], ee = in.offE[t + 1];
+    const u32 fb = in.offF[t], fe = in.offF[t + 1];
+    const u32 rb = sb + eb0 + fb;  // records before this tile, all streams
     const int carry = tilePrefW[t] - tilePrefW[c.tileBase];
     occ[threadIdx.x] = 0;
     if (BED) eb[threadIdx.x] = 0;
     __syncthreads();
-    // accumulate this tile's endpoint records
-    for (u32 i = rb + threadIdx.x; i < re; i += TL_NT) {
-      u64 r = recs[i];
+    // accumulate this tile's endpoints: +1 per start, -1 per end (unit weight = 120), then the
+    // fractional records with their own signed weight
+    for (u32 i = sb + threadIdx.x; i < se; i += TL_NT) {
+      u32 off = in.S[i] & (TILE - 1);
+      atomicAdd(&delta[off], GX_UNIT);
+      atomicOr(&occ[off >> 5], 1u << (off & 31));
+    }
+    for (u32 i = eb0 + threadIdx.x; i < ee; i += TL_NT) {
+      u32 off = in.E[i] & (TILE - 1);
+      atomicAdd(&delta[off], -GX_UNIT);
+      atomicOr(&occ[off >> 5], 1u << (off & 31));
+    }
+    for (u32 i = fb + threadIdx.x; i < fe; i += TL_NT) {
+      u64 r = in.F[i];
       u32 off = (u32)(r >> 8) & (TILE - 1);
       atomicAdd(&delta[off], (int)(int8_t)(r & 0xFF));
       atomicOr(&occ[off >> 5], 1u << (off & 31));
@@ -758,7 +876,9 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
 struct PackIn {
   const u32* looseEnd;
   const int* looseV;
-  const u32* tileOff;      // record offsets (loose slot of tile t starts at tileOff[t] + t [+ bedTileOff[t]])
+  const u32* offS;         // record offsets of the three streams: the loose slot of tile t starts at
+  const u32* offE;         //   offS[t] + offE[t] + offF[t] + t [+ bedTileOff[t]]
+  const u32* offF;
   const u32* bedTileOff;   // nullptr without -E
   const u32* tileIvOff;
   const u32* tilePrevEnd;
@@ -771,7 +891,7 @@ __global__ __launch_bounds__(256) void k_pack(PackIn in, u32 nTiles, u32* __rest
   const int wv = threadIdx.x >> 6, lane = lane_id();
   // one wavefront per tile (a tile holds a few hundred intervals)
   for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
-    const u32 src = in.tileOff[t] + t + (in.bedTileOff ? in.bedTileOff[t] : 0u), dst = in.tileIvOff[t],
+    const u32 src = in.offS[t] + in.offE[t] + in.offF[t] + t + (in.bedTileOff ? in.bedTileOff[t] : 0u), dst = in.tileIvOff[t],
               n = in.tileIvOff[t + 1] - dst;
     u32 prevEnd = in.tilePrevEnd[t];
     for (u32 b = 0; b < n; b += 64) {
