@@ -98,7 +98,7 @@ struct gx_ctx {
   };
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3], tileCursor[3];
-  DevBuf tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
+  DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};
   std::vector<PArray> reps;
@@ -376,16 +376,18 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>()};
   const size_t ldsBytes = (size_t)TL_LDS * 4;
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
-  TileIn tin{SS.a.as<u32>(), ctx->tileOff[0].as<u32>(), SE.a.as<u32>(), ctx->tileOff[1].as<u32>(), SF.a.as<u64>(),
-             ctx->tileOff[2].as<u32>()};
+  HIPCHECK(ctx->tileMeta.ensure((size_t)(nTiles + 1) * sizeof(TileMeta)));
+  hipLaunchKernelGGL(k_tile_meta, dim3((nTiles + 255) / 256), dim3(256), 0, s, ctx->tileOff[0].as<u32>(),
+                     ctx->tileOff[1].as<u32>(), ctx->tileOff[2].as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
+                     ctx->dChrom.as<DChrom>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, nTiles,
+                     ctx->tileMeta.as<TileMeta>());
+  TileIn tin{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
   if (ctx->hasBed)
-    hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin,
-                       ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, bin, to,
-                       ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin, nTiles,
+                       bin, to, ctx->dStatus.as<u32>());
   else
-    hipLaunchKernelGGL(k_tile<false>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin,
-                       ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, bin, to,
-                       ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_tile<false>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin, nTiles,
+                       bin, to, ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   phase_end(ctx);
 
@@ -404,8 +406,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   Scalars* ds = ctx->dScal.as<Scalars>();
   long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
   HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
-  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileOff[0].as<u32>(), ctx->tileOff[1].as<u32>(),
-             ctx->tileOff[2].as<u32>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, out.tileIvOff.as<u32>(),
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), out.tileIvOff.as<u32>(),
              ctx->tilePrevEnd.as<u32>()};
   hipLaunchKernelGGL(k_pack, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, pin, nTiles,
                      out.ivEnd.as<u32>(), out.ivV.as<int>(), acc, ctx->dStatus.as<u32>());

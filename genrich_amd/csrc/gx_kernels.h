@@ -435,9 +435,9 @@ __global__ __launch_bounds__(STL_NT) void k_scan_tiles(TileTabs T, u32 nTiles, u
 // reserves a run per (workgroup, bin) with one global atomic, sorts the chunk in LDS and
 // writes bin-contiguous runs.  Order inside a bin is arbitrary: every consumer is a
 // commutative integer sum.
-constexpr int SC_NT = 256;
-template <typename R> struct ScCfg { static constexpr int ITEMS = 16; };   // 4096 x 8 B = 32 KiB staged
-template <> struct ScCfg<u32> { static constexpr int ITEMS = 32; };       // 8192 x 4 B = 32 KiB staged
+constexpr int SC_NT = 1024;  // 16 waves per workgroup: the kernel is latency-, not bandwidth-bound
+template <typename R> struct ScCfg { static constexpr int ITEMS = 4; };    // 4096 x 8 B = 32 KiB staged
+template <> struct ScCfg<u32> { static constexpr int ITEMS = 8; };        // 8192 x 4 B = 32 KiB staged
 
 template <int LEVEL, typename R>
 __device__ __forceinline__ u32 bin_of(R r, int sbShift, u32 nBins, u32 segTileBase) {
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const R* __restrict__ in, R* 
   __shared__ u32 start[MAX_BINS];
   __shared__ u32 base[MAX_BINS];
   __shared__ R stage[CHUNK];
-  __shared__ u32 scratch[8];
+  __shared__ u32 scratch[20];
   u32 seg = 0, chunkInSeg = blockIdx.x, begin, end, nBins, segTileBase = 0;
   if (LEVEL == 1) {
     begin = blockIdx.x * CHUNK;
@@ -590,18 +590,49 @@ struct TileOut {
   u32* tileLastEnd; // [nTiles] end of the tile's last interval (valid when tileCount > 0)
 };
 
-struct TileIn {
-  const u32* S;  const u32* offS;   // start keys, bucketed by tile; [nTiles+1] offsets
-  const u32* E;  const u32* offE;   // end keys
-  const u64* F;  const u32* offF;   // fractional records
+// everything k_tile needs to know about a tile in one 48-byte record, so the persistent loop can
+// prefetch the next tile's descriptor without a dependent-load chain (tileChrom -> chroms -> prefW)
+struct __attribute__((aligned(16))) TileMeta {
+  u32 sb, eb, fb, nS;     // record ranges of the three streams
+  u32 nE, nF;
+  int carry;              // pileup (1/120 units) at the tile's first base
+  u32 ci;                 // chromosome
+  u32 pos0, len;          // first base of the tile, chromosome length
+  u32 flags;              // bit0 active, bit1 last tile of the chromosome
+  u32 slot;               // first loose output slot
 };
 
+struct TileIn {
+  const u32* S;  const u32* E;  const u64* F;   // the three record streams, bucketed by tile
+  const TileMeta* meta;
+};
+
+__global__ __launch_bounds__(256) void k_tile_meta(const u32* __restrict__ offS, const u32* __restrict__ offE,
+                                                   const u32* __restrict__ offF, const int* __restrict__ prefW,
+                                                   const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+                                                   const u32* __restrict__ bedTileOff, u32 nTiles,
+                                                   TileMeta* __restrict__ meta) {
+  for (u32 t = blockIdx.x * 256 + threadIdx.x; t < nTiles; t += gridDim.x * 256) {
+    const u32 ci = tileChrom[t];
+    const DChrom c = chroms[ci];
+    TileMeta m;
+    m.sb = offS[t]; m.nS = offS[t + 1] - m.sb;
+    m.eb = offE[t]; m.nE = offE[t + 1] - m.eb;
+    m.fb = offF[t]; m.nF = offF[t + 1] - m.fb;
+    m.carry = prefW[t] - prefW[c.tileBase];
+    m.ci = ci;
+    const u32 tl = t - c.tileBase;
+    m.pos0 = tl << TB;
+    m.len = c.len;
+    m.flags = (chrom_active(c) ? 1u : 0u) | (tl + 1 == c.nTiles ? 2u : 0u);
+    m.slot = m.sb + m.eb + m.fb + t + (bedTileOff ? bedTileOff[t] : 0u);  // <= records + edges + 1 intervals per tile
+    meta[t] = m;
+  }
+}
+
 template <bool BED>
-__global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in,
-                                                   const int* __restrict__ tilePrefW,
-                                                   const u32* __restrict__ tileChrom,
-                                                   const DChrom* __restrict__ chroms, u32 nTiles,
-                                                   BedIn bed, TileOut out, u32* __restrict__ st) {
+__global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn bed, TileOut out,
+                                                   u32* __restrict__ st) {
   // LDS: the tile's slice of the difference array (one int per base) plus an occupancy bitmap
   // (one bit per base).  Only bases that received a record are ever read back or cleared, so a
   // tile costs O(records) LDS traffic instead of O(TILE): at config 2 ~1,060 of the 16,384 bases
@@ -616,17 +647,15 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in,
   u32 bad = 0;
   for (int i = threadIdx.x * 4; i < TILE; i += TL_NT * 4)
     *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
+  TileMeta cur = blockIdx.x < nTiles ? in.meta[blockIdx.x] : TileMeta{};
   for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {
-    const u32 ci = tileChrom[t];
-    const DChrom c = chroms[ci];
-    const bool active = chrom_active(c);
-    const u32 tl = t - c.tileBase;
-    const u32 pos0 = tl << TB;
-    const bool lastTile = tl + 1 == c.nTiles;
-    const u32 sb = in.offS[t], se = in.offS[t + 1], eb0 = in.offE[t], ee = in.offE[t + 1];
-    const u32 fb = in.offF[t], fe = in.offF[t + 1];
-    const u32 rb = sb + eb0 + fb;  // records before this tile, all streams
-    const int carry = tilePrefW[t] - tilePrefW[c.tileBase];
+    const TileMeta m = cur;
+    if (t + gridDim.x < nTiles) cur = in.meta[t + gridDim.x];  // prefetch: in flight while this tile is processed
+    const bool active = m.flags & 1u;
+    const u32 pos0 = m.pos0;
+    const bool lastTile = (m.flags & 2u) != 0;
+    const u32 sb = m.sb, se = m.sb + m.nS, eb0 = m.eb, ee = m.eb + m.nE, fb = m.fb, fe = m.fb + m.nF;
+    const int carry = m.carry;
     occ[threadIdx.x] = 0;
     if (BED) eb[threadIdx.x] = 0;
     __syncthreads();
@@ -699,7 +728,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in,
     }
     // pass 2: emit, and clear what was touched
     int run = carry + preS + (incS - sum);
-    const u32 slot = rb + t + (BED ? bed.bedTileOff[t] : 0u);  // a tile closes <= records + edges + 1 intervals
+    const u32 slot = m.slot;
     const u32 o0 = slot + preC + (incC - cnt);
     const u32 totFinal = active ? totC + (lastTile ? 1u : 0u) : 0u;
     u32 o = o0, neg = 0, lastEnd = 0;
@@ -722,9 +751,9 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in,
     }
     if (active) {  // block-uniform
       if (lastTile && threadIdx.x == TL_NT - 1) {  // closing interval [.., len)
-        out.looseEnd[o] = c.len;
+        out.looseEnd[o] = m.len;
         out.looseV[o] = save ? run : V_MARK;
-        lastEnd = c.len;
+        lastEnd = m.len;
         o++;
       }
       if (o != o0 && o == slot + totFinal) out.tileLastEnd[t] = lastEnd;  // wrote the tile's last interval
@@ -876,10 +905,7 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
 struct PackIn {
   const u32* looseEnd;
   const int* looseV;
-  const u32* offS;         // record offsets of the three streams: the loose slot of tile t starts at
-  const u32* offE;         //   offS[t] + offE[t] + offF[t] + t [+ bedTileOff[t]]
-  const u32* offF;
-  const u32* bedTileOff;   // nullptr without -E
+  const TileMeta* meta;    // .slot = first loose slot of the tile
   const u32* tileIvOff;
   const u32* tilePrevEnd;
 };
@@ -891,7 +917,7 @@ __global__ __launch_bounds__(256) void k_pack(PackIn in, u32 nTiles, u32* __rest
   const int wv = threadIdx.x >> 6, lane = lane_id();
   // one wavefront per tile (a tile holds a few hundred intervals)
   for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
-    const u32 src = in.offS[t] + in.offE[t] + in.offF[t] + t + (in.bedTileOff ? in.bedTileOff[t] : 0u), dst = in.tileIvOff[t],
+    const u32 src = in.meta[t].slot, dst = in.tileIvOff[t],
               n = in.tileIvOff[t + 1] - dst;
     u32 prevEnd = in.tilePrevEnd[t];
     for (u32 b = 0; b < n; b += 64) {
