@@ -647,10 +647,23 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
   u32 bad = 0;
   for (int i = threadIdx.x * 4; i < TILE; i += TL_NT * 4)
     *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
-  TileMeta cur = blockIdx.x < nTiles ? in.meta[blockIdx.x] : TileMeta{};
-  for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {
-    const TileMeta m = cur;
-    if (t + gridDim.x < nTiles) cur = in.meta[t + gridDim.x];  // prefetch: in flight while this tile is processed
+  // software pipeline over this workgroup's tiles: descriptors are loaded two tiles ahead and the
+  // first TL_NT start / end keys of the next tile one tile ahead, so their HBM/L2 latency overlaps
+  // the current tile instead of stalling every wave at the top of each iteration
+  const u32 G = gridDim.x;
+  TileMeta m1 = blockIdx.x < nTiles ? in.meta[blockIdx.x] : TileMeta{};
+  TileMeta m2 = blockIdx.x + G < nTiles ? in.meta[blockIdx.x + G] : TileMeta{};
+  u32 ks1 = threadIdx.x < m1.nS ? in.S[m1.sb + threadIdx.x] : 0u;
+  u32 ke1 = threadIdx.x < m1.nE ? in.E[m1.eb + threadIdx.x] : 0u;
+  for (u32 t = blockIdx.x; t < nTiles; t += G) {
+    const TileMeta m = m1;
+    const u32 ks0 = ks1, ke0 = ke1;
+    m1 = m2;
+    if (t + 2 * G < nTiles) m2 = in.meta[t + 2 * G];
+    if (t + G < nTiles) {
+      ks1 = threadIdx.x < m1.nS ? in.S[m1.sb + threadIdx.x] : 0u;
+      ke1 = threadIdx.x < m1.nE ? in.E[m1.eb + threadIdx.x] : 0u;
+    }
     const bool active = m.flags & 1u;
     const u32 pos0 = m.pos0;
     const bool lastTile = (m.flags & 2u) != 0;
@@ -661,12 +674,22 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     __syncthreads();
     // accumulate this tile's endpoints: +1 per start, -1 per end (unit weight = 120), then the
     // fractional records with their own signed weight
-    for (u32 i = sb + threadIdx.x; i < se; i += TL_NT) {
+    if (threadIdx.x < m.nS) {
+      u32 off = ks0 & (TILE - 1);
+      atomicAdd(&delta[off], GX_UNIT);
+      atomicOr(&occ[off >> 5], 1u << (off & 31));
+    }
+    if (threadIdx.x < m.nE) {
+      u32 off = ke0 & (TILE - 1);
+      atomicAdd(&delta[off], -GX_UNIT);
+      atomicOr(&occ[off >> 5], 1u << (off & 31));
+    }
+    for (u32 i = sb + TL_NT + threadIdx.x; i < se; i += TL_NT) {
       u32 off = in.S[i] & (TILE - 1);
       atomicAdd(&delta[off], GX_UNIT);
       atomicOr(&occ[off >> 5], 1u << (off & 31));
     }
-    for (u32 i = eb0 + threadIdx.x; i < ee; i += TL_NT) {
+    for (u32 i = eb0 + TL_NT + threadIdx.x; i < ee; i += TL_NT) {
       u32 off = in.E[i] & (TILE - 1);
       atomicAdd(&delta[off], -GX_UNIT);
       atomicOr(&occ[off >> 5], 1u << (off & 31));
