@@ -364,9 +364,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   if (nF)
     if (int rc = sort_stream2<u64>(ctx, SF, 2)) return rc;
-  phase_end(ctx);
-
-  phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");
   const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
   HIPCHECK(ctx->looseEnd.ensure(looseCap * 4));
   HIPCHECK(ctx->looseV.ensure(looseCap * 4));
@@ -381,6 +378,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
                      ctx->tileOff[1].as<u32>(), ctx->tileOff[2].as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
                      ctx->dChrom.as<DChrom>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, nTiles,
                      ctx->tileMeta.as<TileMeta>());
+  phase_end(ctx);
+
+  phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");  // k_tile alone: the dominant kernel (bench.py's roofline)
   TileIn tin{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
   if (ctx->hasBed)
     hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin, nTiles,
