@@ -26,9 +26,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
 
 
+HOST_SRC = os.path.join(HERE, "host", "genrich_amd.cpp")
+HOST_BIN = os.path.join(HERE, "genrich-amd")
+
+
+def build_host(force: bool = False) -> str:
+    """The command-line host program (C++, g++): SAM/BAM ingest + options over the C ABI."""
+    if force or not os.path.exists(HOST_BIN) or os.path.getmtime(HOST_BIN) < max(
+            os.path.getmtime(HOST_SRC), os.path.getmtime(LIB)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", HOST_SRC, "-o", HOST_BIN, "-L" + HERE,
+                               "-lgenrich_amd", "-lz", "-Wl,-rpath,$ORIGIN"])
+    return HOST_BIN
+
+
 def build(force: bool = False) -> str:
     if force or needs_build():
         subprocess.check_call([HIPCC] + FLAGS + [SRC, EMIT, "-o", LIB])
+    build_host(force)
     return LIB
 
 

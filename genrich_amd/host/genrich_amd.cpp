@@ -1,0 +1,1067 @@
+// genrich_amd.cpp -- host program: the Genrich command line over the MI355X hot path.
+//
+// Everything upstream of the C ABI stays on the CPU, as north_star prescribes: option handling
+// (getArgs, Genrich.c:5718-5827), SAM / BAM reading (readSAM 4468, readBAM 4983), pairing of
+// alignments into fragments (parseAlign 4141, processAlns 3187), multimap weighting
+// (processPair 3122, processSingle 3019), interval geometry (saveFragment 2754, saveFragAtac
+// 2728, saveUnpair 2689, processAvgExt 2614) and saveInterval's clamping / -b line (2516-2591).
+// Each alignment-derived interval becomes one gx_event; pileups, p/q-values and peaks come
+// from libgenrich_amd.so; text output is gx_emit.cpp.  Written from the behaviour described in
+// SURVEY.md Appendix A, not transliterated from the reference.
+//
+// Not implemented here (the reference options are recognised and rejected with a message):
+//   -r / -R  PCR-duplicate removal (Genrich.c:2776-2977, 3267-4042)
+//   -P       peak calling from a -f log (callPeaksLog, 1277-1488)
+//
+// Extra long option (diagnostics, never needed for normal use):
+//   --events-only   parse and write the -b file without touching a GPU
+#include <getopt.h>
+#include <zlib.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/genrich_amd.h"
+
+#define VERSION "0.6.2-amd"
+#define MAX_ALNS 128  // Genrich.h:17 (also the length of stored read names)
+static const float NOSCORE = -FLT_MAX;
+
+namespace {
+
+[[noreturn]] void die(const std::string& msg, const char* tail) {  // error(), Genrich.c:78-81
+  fprintf(stderr, "Error! %s%s\n", msg.c_str(), tail);
+  exit(EXIT_FAILURE);
+}
+
+int getInt(const char* s) {  // 102-108
+  char* end;
+  long v = strtol(s, &end, 10);
+  if (*end != '\0') die(s, ": cannot convert to int");
+  return (int)v;
+}
+long getLong(const char* s) {
+  char* end;
+  long v = strtol(s, &end, 10);
+  if (*end != '\0') die(s, ": cannot convert to int");
+  return v;
+}
+float getFloat(const char* s) {  // 90-96
+  char* end;
+  float v = strtof(s, &end);
+  if (*end != '\0') die(s, ": cannot convert to float");
+  return v;
+}
+
+// ---- output files: plain or gzip (-z), printf-style ---------------------------------------
+struct Out {
+  FILE* f = nullptr;
+  gzFile gz = nullptr;
+  std::string name;
+};
+
+ssize_t gzCookieWrite(void* c, const char* buf, size_t n) { return gzwrite((gzFile)c, buf, (unsigned)n) ? (ssize_t)n : 0; }
+int gzCookieClose(void* c) { return gzclose((gzFile)c) == Z_OK ? 0 : -1; }
+
+Out openWrite(const char* path, bool gzOut) {  // openWrite, 5076-5102
+  Out o;
+  if (path[0] == '-' && strlen(path) > 1) die(path, ": output filename cannot start with '-'");
+  bool isStdout = !strcmp(path, "-");
+  o.name = path;
+  if (gzOut) {
+    if (!isStdout && (o.name.size() < 3 || o.name.compare(o.name.size() - 3, 3, ".gz"))) o.name += ".gz";
+    gzFile g = isStdout ? gzdopen(fileno(stdout), "wb") : gzopen(o.name.c_str(), "w");
+    if (!g) die(o.name, ": cannot open file for writing");
+    cookie_io_functions_t io = {nullptr, gzCookieWrite, nullptr, gzCookieClose};
+    o.f = fopencookie(g, "w", io);
+    o.gz = g;
+  } else
+    o.f = isStdout ? stdout : fopen(path, "w");
+  if (!o.f) die(o.name, ": cannot open file for writing");
+  return o;
+}
+void closeOut(Out& o) {
+  if (o.f && o.f != stdout && fclose(o.f)) die(o.name, ": cannot close file");
+  if (o.f == stdout) fflush(stdout);
+  o.f = nullptr;
+}
+
+// ---- chromosome table (saveChrom 4220-4270, saveXBed 1144-1206) -----------------------------
+struct Chrom {
+  std::string name;
+  uint32_t len = 0;
+  bool skip = false, save = false;
+  std::vector<uint32_t> bed;  // merged start/end pairs
+};
+struct BedRec { std::string name; uint32_t pos[2]; };
+
+struct Opts {
+  const char *inFile = nullptr, *ctrlFile = nullptr, *outFile = nullptr, *logFile = nullptr, *pileFile = nullptr,
+             *bedFile = nullptr, *xFile = nullptr, *dupsFile = nullptr, *xchrom = nullptr;
+  uint64_t genomeLen = 0;
+  int extend = 0, minMapQ = 0, minLen = 0, maxGap = 100, atacLen5 = 100, atacLen3 = 0;
+  float asDiff = 0.0f, pqvalue = 0.01f, minAUC = 200.0f;
+  bool singleOpt = false, extendOpt = false, avgExtOpt = false, atacOpt = false, atacAdj = true, gzOut = false,
+       qvalOpt = false, dupsOpt = false, peaksOpt = true, peaksOnly = false, sortOpt = true, verbose = false,
+       eventsOnly = false;
+  int device = 0;
+};
+
+struct State {
+  Opts o;
+  std::vector<Chrom> chrom;
+  std::vector<std::string> xchr;
+  std::vector<BedRec> xbed;
+  gx_ctx* gx = nullptr;
+  bool tableFrozen = false;  // the device already holds the chromosome table
+  bool sampleOpen = false;   // gx_sample_begin done for the file being read
+  std::vector<gx_event> buf;
+  Out bed;
+  bool bedOpt = false;
+  bool ctrl = false;
+  int sample = 0;
+  uint64_t errCount = 0;
+};
+
+void check(State& S, int rc) {
+  if (rc == GX_OK) return;
+  std::string detail = S.gx ? gx_last_error(S.gx) : "";
+  die(detail.empty() ? std::string(gx_strerror(rc)) : detail, "");
+}
+
+void mergeBed(Chrom& c, const std::vector<BedRec>& xbed, bool verbose) {
+  std::vector<std::pair<uint32_t, uint32_t>> iv;
+  for (const BedRec& b : xbed)
+    if (b.name == c.name) {
+      if (b.pos[0] >= c.len) {
+        if (verbose) {
+          fprintf(stderr, "Warning! BED interval (%s, %d - %d) ignored\n", b.name.c_str(), b.pos[0], b.pos[1]);
+          fprintf(stderr, "  - located off end of reference %s (length %d)\n", c.name.c_str(), c.len);
+        }
+        continue;
+      }
+      // insertion before the first interval whose start is >= this start (1165-1175)
+      size_t j = 0;
+      while (j < iv.size() && b.pos[0] > iv[j].first) j++;
+      iv.insert(iv.begin() + j, {b.pos[0], b.pos[1]});
+    }
+  std::vector<std::pair<uint32_t, uint32_t>> out;
+  for (auto& p : iv) {
+    if (p.second > c.len) {
+      if (verbose) {
+        fprintf(stderr, "Warning! BED interval (%s, %d - %d) extends ", c.name.c_str(), p.first, p.second);
+        fprintf(stderr, "past end of ref.\n  - edited to (%s, %d - %d)\n", c.name.c_str(), p.first, c.len);
+      }
+      p.second = c.len;
+    }
+    if (!out.empty() && p.first <= out.back().second) {
+      if (p.second > out.back().second) out.back().second = p.second;
+    } else
+      out.push_back(p);
+  }
+  for (auto& p : out) {
+    c.bed.push_back(p.first);
+    c.bed.push_back(p.second);
+  }
+}
+
+int saveChrom(State& S, const char* name, uint32_t len) {
+  for (size_t i = 0; i < S.chrom.size(); i++)
+    if (S.chrom[i].name == name) {
+      if (S.chrom[i].len != len) die(name, ": reference sequence has different lengths in BAM/SAM files");
+      if (!S.ctrl) S.chrom[i].save = true;
+      return (int)i;
+    }
+  if (S.tableFrozen)  // all headers are pre-scanned; only an input read from stdin can get here
+    die(name, ": reference sequence first seen after the chromosome table was sent to the device");
+  Chrom c;
+  c.name = name;
+  c.len = len;
+  for (auto& x : S.xchr)
+    if (x == name) c.skip = true;
+  c.save = !S.ctrl;  // do not save if ref in ctrl sample only
+  if (!c.skip) mergeBed(c, S.xbed, S.o.verbose);
+  S.chrom.push_back(c);
+  return (int)S.chrom.size() - 1;
+}
+
+// ---- saveInterval (2516-2591): clamp, event, -b line ----------------------------------------
+uint32_t saveInterval(State& S, int ci, int64_t start, int64_t end, const char* qname, uint8_t count) {
+  Chrom& c = S.chrom[ci];
+  if (start < 0) {
+    if (S.o.verbose) {
+      if (S.errCount < MAX_ALNS)
+        fprintf(stderr, "Warning! Read %s prevented from extending below 0 on %s\n", qname, c.name.c_str());
+      S.errCount++;
+    }
+    start = 0;
+  }
+  if (start >= c.len) {
+    char msg[512];
+    snprintf(msg, sizeof msg, "Read %s, ref. %s", qname, c.name.c_str());
+    die(msg, ": read aligned beyond reference end");
+  }
+  if (end > c.len) {
+    if (S.o.verbose) {
+      if (S.errCount < MAX_ALNS)
+        fprintf(stderr, "Warning! Read %s prevented from extending past %d on %s\n", qname, c.len, c.name.c_str());
+      S.errCount++;
+    }
+    end = c.len;
+  }
+  S.buf.push_back(gx_event{(uint32_t)ci, (uint32_t)start, (uint32_t)end, count});
+  if (S.buf.size() >= (1u << 20)) {
+    if (S.gx && S.sampleOpen) check(S, gx_push_events(S.gx, S.buf.data(), S.buf.size()));
+    if (!S.gx || S.sampleOpen) S.buf.clear();  // --events-only keeps nothing
+  }
+  if (S.bedOpt)
+    fprintf(S.bed.f, "%s\t%ld\t%ld\t%s_%d_%c_%d\n", c.name.c_str(), (long)start, (long)end, qname, count,
+            S.ctrl ? 'C' : 'E', S.sample);
+  return (uint32_t)(end - start);
+}
+
+// ---- alignments of one read name -------------------------------------------------------------
+struct Aln {
+  uint32_t pos[2];
+  float score;
+  bool primary, paired, full, first, strand;
+  int chrom;
+};
+struct Unpair { int chrom; uint32_t pos[2]; bool strand; uint8_t count; std::string name; };
+
+struct Counts {
+  uint64_t count = 0, unmapped = 0, paired = 0, single = 0, orphan = 0, pairedPr = 0, singlePr = 0, supp = 0,
+           skipped = 0, lowMapQ = 0, secPair = 0, secSingle = 0;
+  double totalLen = 0.0;
+};
+
+uint32_t saveFragment(State& S, const char* qname, const Aln& a, uint8_t count) {  // 2754-2774, 2728-2749
+  uint32_t start = a.pos[0], end = a.pos[1];
+  if (start > end) std::swap(start, end);
+  if (!S.o.atacOpt) return saveInterval(S, a.chrom, start, end, qname, count);
+  if (S.o.atacAdj) { start += 5; end += (uint32_t)-5; }
+  if (start + S.o.atacLen3 >= (uint32_t)(int)(end - S.o.atacLen3))
+    return saveInterval(S, a.chrom, (int)(start - S.o.atacLen5), (int64_t)end + S.o.atacLen5, qname, count);
+  return saveInterval(S, a.chrom, (int)(start - S.o.atacLen5), (int64_t)start + S.o.atacLen3, qname, count) +
+         saveInterval(S, a.chrom, (int)(end - S.o.atacLen3), (int64_t)end + S.o.atacLen5, qname, count);
+}
+
+void saveUnpair(State& S, const char* qname, Aln& a, uint8_t count) {  // 2689-2721
+  const Opts& o = S.o;
+  if (o.extendOpt) {
+    if (a.strand) saveInterval(S, a.chrom, a.pos[0], (int64_t)a.pos[0] + o.extend, qname, count);
+    else saveInterval(S, a.chrom, (int)(a.pos[1] - o.extend), a.pos[1], qname, count);
+  } else if (o.atacOpt) {
+    if (a.strand) {
+      if (o.atacAdj) a.pos[0] += 5;
+      saveInterval(S, a.chrom, (int)(a.pos[0] - o.atacLen5), (int64_t)a.pos[0] + o.atacLen3, qname, count);
+    } else {
+      if (o.atacAdj) a.pos[1] += (uint32_t)-5;
+      saveInterval(S, a.chrom, (int)(a.pos[1] - o.atacLen3), (int64_t)a.pos[1] + o.atacLen5, qname, count);
+    }
+  } else
+    saveInterval(S, a.chrom, a.pos[0], a.pos[1], qname, count);
+}
+
+bool usable(const State& S, const Aln& a) { return S.chrom[a.chrom].save && !S.chrom[a.chrom].skip; }
+
+// new minimum score so that the number of kept alignments is one of 1,2,3,4,5,6,8,10 (2985, 3089)
+void subsample(const std::vector<float>& scoresDesc, uint8_t& count, float& score) {
+  count = count > 10 ? 10 : count - 1;
+  score = scoresDesc[count - 1];
+}
+
+int processPair(State& S, const char* qname, std::vector<Aln>& aln, Counts& C, float score) {  // 3122-3176
+  if (score != NOSCORE) score -= S.o.asDiff;
+  auto ok = [&](const Aln& a) { return a.paired && a.full && a.score >= score && usable(S, a); };
+  uint8_t count = 0;
+  for (auto& a : aln) count += ok(a);
+  if (!count) return 0;
+  if (count > 10 || count == 7 || count == 9) {
+    std::vector<float> sc;
+    for (auto& a : aln)
+      if (ok(a)) {  // stable insertion, descending
+        size_t j = 0;
+        while (j < sc.size() && !(a.score > sc[j])) j++;
+        sc.insert(sc.begin() + j, a.score);
+      }
+    subsample(sc, count, score);
+  }
+  uint64_t fragLen = 0;
+  uint8_t saved = 0;
+  for (auto& a : aln)
+    if (ok(a)) {
+      fragLen += saveFragment(S, qname, a, count);
+      if (++saved == count) break;  // in case of AS ties
+    }
+  C.totalLen += (double)fragLen / count;
+  return 1;
+}
+
+int processSingle(State& S, const char* qname, std::vector<Aln>& aln, std::vector<Unpair>& unpair, float score,
+                  bool first) {  // 3019-3083
+  if (score != NOSCORE) score -= S.o.asDiff;
+  auto ok = [&](const Aln& a) { return !a.paired && a.first == first && a.score >= score && usable(S, a); };
+  uint8_t count = 0;
+  for (auto& a : aln) count += ok(a);
+  if (!count) return 0;
+  if (count > 10 || count == 7 || count == 9) {
+    std::vector<float> sc;
+    for (auto& a : aln)
+      if (ok(a)) {
+        size_t j = 0;
+        while (j < sc.size() && !(a.score > sc[j])) j++;
+        sc.insert(sc.begin() + j, a.score);
+      }
+    subsample(sc, count, score);
+  }
+  uint8_t saved = 0;
+  for (auto& a : aln)
+    if (ok(a)) {
+      if (S.o.avgExtOpt)
+        unpair.push_back(Unpair{a.chrom, {a.pos[0], a.pos[1]}, a.strand, count, qname});
+      else
+        saveUnpair(S, qname, a, count);
+      if (++saved == count) break;
+    }
+  return 1;
+}
+
+void processAlns(State& S, const char* qname, std::vector<Aln>& aln, std::vector<Unpair>& unpair, Counts& C) {  // 3187-3265
+  float scorePr = NOSCORE, scoreR1 = NOSCORE, scoreR2 = NOSCORE;
+  bool pair = false, singleR1 = false, singleR2 = false;
+  for (auto& a : aln) {
+    if (a.paired) {
+      if (a.full) {
+        if (!pair || scorePr < a.score) scorePr = a.score;
+        pair = true;
+      } else
+        C.orphan++;
+    } else if (S.o.singleOpt && !pair) {
+      if (a.first && scoreR1 <= a.score) { scoreR1 = a.score; singleR1 = true; }
+      else if (!a.first && scoreR2 <= a.score) { scoreR2 = a.score; singleR2 = true; }
+    }
+  }
+  if (pair)
+    C.pairedPr += processPair(S, qname, aln, C, scorePr);
+  else if (S.o.singleOpt) {
+    if (singleR1) C.singlePr += processSingle(S, qname, aln, unpair, scoreR1, true);
+    if (singleR2) C.singlePr += processSingle(S, qname, aln, unpair, scoreR2, false);
+  }
+}
+
+// parseAlign (4141-4212); returns false when the per-read alignment limit is hit
+bool parseAlign(State& S, std::vector<Aln>& aln, uint16_t flag, int ci, uint32_t pos, int length, uint32_t pnext,
+                Counts& C, float score) {
+  if (flag & 0x1) {
+    if ((flag & 0xC0) == 0xC0) die("", "Linear template with >2 reads -- not allowed");
+    if (!(flag & 0xC0)) die("", "Unknown index of paired alignment");
+  }
+  const Chrom& ch = S.chrom[ci];
+  const uint32_t end5 = (flag & 0x10) ? pos + length : pos;  // 5' end of a reverse read = pos + refLen
+  if ((flag & 0x3) == 0x3) {
+    if (ch.skip || !ch.save) C.skipped++;
+    else {
+      C.paired++;
+      if (flag & 0x100) C.secPair++;
+    }
+    for (auto& a : aln)
+      if (a.paired && !a.full && a.chrom == ci &&
+          ((flag & 0x40) ? (!a.first && a.pos[0] == pos) : (a.first && a.pos[1] == pos)) &&
+          ((flag & 0x100) ? !a.primary : a.primary)) {
+        if (flag & 0x40) a.pos[0] = end5; else a.pos[1] = end5;  // updatePairedAln 4049
+        if (score == NOSCORE) a.score = NOSCORE;
+        else if (a.score != NOSCORE) a.score += score;
+        a.full = true;
+        return true;
+      }
+    if (aln.size() == MAX_ALNS) return false;
+    Aln a{};
+    a.chrom = ci;
+    a.score = score;
+    a.primary = !(flag & 0x100);
+    a.full = false;
+    a.paired = true;
+    if (flag & 0x40) { a.pos[0] = end5; a.pos[1] = pnext; a.first = true; }
+    else { a.pos[0] = pnext; a.pos[1] = end5; a.first = false; }
+    aln.push_back(a);
+    return true;
+  }
+  if (ch.skip || !ch.save) C.skipped++;
+  else {
+    C.single++;
+    if (flag & 0x100) C.secSingle++;
+  }
+  if (S.o.singleOpt) {
+    if (aln.size() == MAX_ALNS) return false;
+    Aln a{};
+    a.chrom = ci;
+    a.score = score;
+    a.primary = !(flag & 0x100);
+    a.paired = false;
+    a.strand = !(flag & 0x10);
+    a.first = flag & 0x40;
+    a.pos[0] = pos;
+    a.pos[1] = pos + length;
+    aln.push_back(a);
+  }
+  return true;
+}
+
+// ---- input: one gz-transparent byte stream (plain, gzip or BGZF) ------------------------------
+struct In {
+  gzFile gz = nullptr;
+  std::string name;
+};
+In openRead(const char* path) {
+  In in;
+  in.name = path;
+  in.gz = !strcmp(path, "-") ? gzdopen(fileno(stdin), "rb") : gzopen(path, "rb");
+  if (!in.gz) die(path, ": cannot open file for reading");
+  gzbuffer(in.gz, 1 << 20);
+  return in;
+}
+
+// distance to the 3' end from a SAM CIGAR (parseCigar 4408, calcDist 4451)
+int calcDist(const char* qname, const char* seq, const char* cigar) {
+  int length = strcmp(seq, "*") ? (int)strlen(seq) : 0;
+  int offset = 0;
+  if (strcmp(cigar, "*")) {
+    int len = 0;
+    const char* p = cigar;
+    while (*p) {
+      char* e;
+      long n = strtol(p, &e, 10);
+      if (e == p && (*p < '0' || *p > '9')) n = 0;  // an op without a number counts as 0
+      char op = *e;
+      if (!op) break;
+      switch (op) {
+        case 'M': case '=': case 'X': len += (int)n; break;
+        case 'I': case 'S': len += (int)n; offset -= (int)n; break;
+        case 'D': offset += (int)n; break;
+        case 'N': case 'H': case 'P': break;
+        default: {
+          char msg[4] = "' '";
+          msg[1] = op;
+          die(msg, ": unknown Op in CIGAR");
+        }
+      }
+      p = e + 1;
+    }
+    if (!length) length = len;
+    else if (length != len) die(qname, ": mismatch between sequence length and CIGAR");
+  } else if (!length)
+    die(qname, ": no sequence information (SEQ or CIGAR)");
+  return length + offset;
+}
+
+float samScore(char* extra) {  // getScore 4383-4402
+  if (!extra) return NOSCORE;
+  for (char* f = strtok(extra, "\t"); f; f = strtok(nullptr, "\t"))
+    if (!strncmp(f, "AS:", 3)) {
+      char* v = strchr(f + 3, ':');
+      if (!v) return NOSCORE;
+      char* nl = strchr(v + 1, '\n');
+      if (nl) *nl = '\0';
+      return getFloat(v + 1);
+    }
+  return NOSCORE;
+}
+
+void headerLine(State& S, char* line) {  // checkHeader 4307-4342
+  size_t n = strlen(line);
+  while (n && (line[n - 1] == '\n' || line[n - 1] == '\r')) line[--n] = '\0';
+  std::vector<char*> f;
+  for (char* t = strtok(line, "\t"); t; t = strtok(nullptr, "\t")) f.push_back(t);
+  if (f.empty()) return;
+  if (!strcmp(f[0], "@HD")) {
+    const char* order = nullptr;
+    for (size_t i = 1; i < f.size(); i++)
+      if (!strncmp(f[i], "SO:", 3)) order = f[i] + 3;
+    if (S.o.sortOpt && (!order || strcmp(order, "queryname")))
+      die("", "SAM/BAM file not sorted by queryname (samtools sort -n)");
+  } else if (!strcmp(f[0], "@SQ")) {
+    const char *name = nullptr, *len = nullptr;
+    for (size_t i = 1; i < f.size(); i++) {
+      if (!strncmp(f[i], "SN:", 3)) name = f[i] + 3;
+      else if (!strncmp(f[i], "LN:", 3)) len = f[i] + 3;
+    }
+    if (name && len) saveChrom(S, name, (uint32_t)getInt(len));
+  }
+}
+
+int findChrom(State& S, const char* rname) {
+  for (size_t i = 0; i < S.chrom.size(); i++)
+    if (S.chrom[i].name == rname) return (int)i;
+  die(rname, ": cannot find reference sequence name in SAM header");
+}
+
+// the header of the current file is complete: open the sample on the device
+void openSample(State& S) {
+  if (S.sampleOpen) return;
+  S.sampleOpen = true;
+  if (!S.gx) return;
+  std::vector<uint8_t> save(S.chrom.size());
+  for (size_t k = 0; k < S.chrom.size(); k++) save[k] = S.chrom[k].save;
+  check(S, gx_sample_begin(S.gx, S.ctrl ? 1 : 0, S.ctrl ? nullptr : save.data()));
+}
+
+struct ReadSet {
+  std::string name;
+  std::vector<Aln> aln;
+  std::vector<Unpair> unpair;
+  bool have = false;
+};
+
+void flushSet(State& S, ReadSet& rs, Counts& C) {
+  if (rs.have) processAlns(S, rs.name.c_str(), rs.aln, rs.unpair, C);
+  rs.aln.clear();
+}
+
+// one alignment record, format independent (the tail of readSAM's / parseBAM's loop)
+void record(State& S, ReadSet& rs, Counts& C, const char* qname, uint16_t flag, int ci, uint32_t pos, uint8_t mapq,
+            int length, uint32_t pnext, float score) {
+  if (mapq < S.o.minMapQ) { C.lowMapQ++; return; }
+  openSample(S);  // the header is complete once the first record arrives
+  if (!rs.have || rs.name != qname) {
+    flushSet(S, rs, C);
+    rs.have = true;
+    rs.name.assign(qname, strnlen(qname, MAX_ALNS));  // strncpy(readName, qname, MAX_ALNS)
+  }
+  if (!parseAlign(S, rs.aln, flag, ci, pos, length, pnext, C, score) && S.o.verbose)
+    fprintf(stderr, "Warning! Read %s has more than %d alignments\n", qname, MAX_ALNS);
+}
+
+void finishFile(State& S, ReadSet& rs, Counts& C) {  // the tail of readSAM / parseBAM
+  flushSet(S, rs, C);
+  if (S.o.avgExtOpt) {  // processAvgExt 2614-2647
+    int avgLen = 0;
+    if (!C.pairedPr) {
+      if (S.o.verbose) {
+        fprintf(stderr, "Warning! No paired alignments to calculate avg frag ");
+        fprintf(stderr, "length --\n  Printing unpaired alignments \"as is\"\n");
+      }
+    } else
+      avgLen = (int)(C.totalLen / C.pairedPr + 0.5);
+    for (auto& u : rs.unpair) {
+      if (!avgLen) saveInterval(S, u.chrom, u.pos[0], u.pos[1], u.name.c_str(), u.count);
+      else if (u.strand) saveInterval(S, u.chrom, u.pos[0], (int64_t)u.pos[0] + avgLen, u.name.c_str(), u.count);
+      else saveInterval(S, u.chrom, (int)(u.pos[1] - avgLen), u.pos[1], u.name.c_str(), u.count);
+    }
+    rs.unpair.clear();
+  }
+}
+
+uint64_t readSAM(State& S, In& in, char* first, Counts& C) {
+  std::vector<char> line(65520);
+  ReadSet rs;
+  bool pastHeader = false;
+  bool useFirst = first != nullptr;
+  for (;;) {
+    char* l;
+    if (useFirst) { l = first; useFirst = false; }
+    else if (!(l = gzgets(in.gz, line.data(), (int)line.size()))) break;
+    if (l[0] == '@') {
+      if (pastHeader) die(l, ": misplaced SAM header line");
+      headerLine(S, l);
+      continue;
+    }
+    pastHeader = true;
+    // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [extra]
+    char* fld[12] = {nullptr};
+    char* p = l;
+    int nf = 0;
+    for (; nf < 11; nf++) {
+      fld[nf] = p;
+      char* t = strchr(p, '\t');
+      if (!t) {
+        size_t n = strlen(p);
+        while (n && (p[n - 1] == '\n' || p[n - 1] == '\r')) p[--n] = '\0';
+        nf++;
+        p = nullptr;
+        break;
+      }
+      *t = '\0';
+      p = t + 1;
+    }
+    if (nf < 11) die(fld[0] ? fld[0] : "", ": poorly formatted SAM/BAM record");
+    char* extra = p;  // may be null
+    const char* qname = fld[0];
+    C.count++;
+    uint16_t flag = (uint16_t)getInt(fld[1]);
+    if (flag & 0x4) { C.unmapped++; continue; }
+    if (!strcmp(qname, "*") || !strcmp(fld[2], "*")) die(qname, ": poorly formatted SAM/BAM record");
+    if (flag & 0xE00) { C.supp++; continue; }
+    int ci = findChrom(S, fld[2]);
+    uint32_t pos = (uint32_t)(getInt(fld[3]) - 1), pnext = (uint32_t)(getInt(fld[7]) - 1);
+    uint8_t mapq = (uint8_t)getInt(fld[4]);
+    if (mapq < S.o.minMapQ) { C.lowMapQ++; continue; }
+    int length = calcDist(qname, fld[9], fld[5]);
+    float score = samScore(extra);
+    record(S, rs, C, qname, flag, ci, pos, mapq, length, pnext, score);
+  }
+  finishFile(S, rs, C);
+  return C.count;
+}
+
+// ---- BAM (readBAM 4983-5068, parseBAM 4826-4977, getBAMscore 4751) -----------------------------
+bool gzReadAll(gzFile g, void* dst, size_t n) { return n == 0 || gzread(g, dst, (unsigned)n) == (int)n; }
+int32_t rdI32(gzFile g, bool must) {
+  uint8_t b[4];
+  int k = gzread(g, b, 4);
+  if (k == 0 && !must) return -1;  // clean EOF between records
+  if (k != 4) die("", "Cannot parse BAM file");
+  return (int32_t)(b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24));
+}
+
+float bamScore(const uint8_t* p, const uint8_t* end) {
+  while (p + 3 <= end) {
+    const bool isAS = p[0] == 'A' && p[1] == 'S';
+    const char ty = (char)p[2];
+    p += 3;
+    auto need = [&](size_t n) { if (p + n > end) die("", "Poorly formatted BAM auxiliary field"); };
+    switch (ty) {
+      case 'A': case 'c': case 'C': need(1); if (isAS && ty != 'A') return ty == 'c' ? (float)(int8_t)p[0] : (float)p[0]; p += 1; break;
+      case 's': case 'S': { need(2); uint16_t v = (uint16_t)(p[0] | (p[1] << 8)); if (isAS) return ty == 's' ? (float)(int16_t)v : (float)v; p += 2; break; }
+      case 'i': case 'I': { need(4); uint32_t v = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); if (isAS) return ty == 'i' ? (float)(int32_t)v : (float)v; p += 4; break; }
+      case 'f': { need(4); float f; memcpy(&f, p, 4); if (isAS) return f; p += 4; break; }
+      case 'Z': case 'H': while (p < end && *p) p++; p++; break;
+      case 'B': {
+        need(5);
+        char st = (char)p[0];
+        uint32_t cnt = p[1] | (p[2] << 8) | (p[3] << 16) | ((uint32_t)p[4] << 24);
+        size_t w = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+        p += 5 + (size_t)cnt * w;
+        break;
+      }
+      default: {
+        char msg[4] = "' '";
+        msg[1] = ty;
+        die(msg, ": unknown value type in BAM auxiliary field");
+      }
+    }
+  }
+  return NOSCORE;
+}
+
+uint64_t readBAM(State& S, In& in, Counts& C) {
+  gzFile g = in.gz;
+  int32_t l_text = rdI32(g, true);
+  std::vector<char> text((size_t)l_text + 1, 0);
+  if (!gzReadAll(g, text.data(), (size_t)l_text)) die("", "Cannot parse BAM file");
+  {  // first header line: @HD with the sort order
+    std::string firstLine(text.data(), strcspn(text.data(), "\n"));
+    std::vector<char> tmp(firstLine.begin(), firstLine.end());
+    tmp.push_back('\0');
+    char* tag = strtok(tmp.data(), "\t");
+    if (!tag || strcmp(tag, "@HD")) die("", "Cannot parse BAM file");
+    const char* order = nullptr;
+    for (char* f = strtok(nullptr, "\t"); f; f = strtok(nullptr, "\t"))
+      if (!strncmp(f, "SO:", 3)) order = f + 3;
+    if (S.o.sortOpt && (!order || strcmp(order, "queryname")))
+      die("", "SAM/BAM file not sorted by queryname (samtools sort -n)");
+  }
+  int32_t n_ref = rdI32(g, true);
+  std::vector<int> idx((size_t)std::max(0, n_ref));
+  for (int i = 0; i < n_ref; i++) {
+    int32_t len = rdI32(g, true);
+    if (len < 1 || len > 65520) die("", "Cannot parse BAM file");
+    std::vector<char> nm((size_t)len);
+    if (!gzReadAll(g, nm.data(), (size_t)len) || nm[len - 1] != '\0') die("", "Cannot parse BAM file");
+    idx[i] = saveChrom(S, nm.data(), (uint32_t)rdI32(g, true));
+  }
+  ReadSet rs;
+  std::vector<uint8_t> blk;
+  for (;;) {
+    int32_t bs = rdI32(g, false);
+    if (bs < 0) break;
+    if (bs < 32) die("", "Cannot parse BAM file");
+    blk.resize((size_t)bs);
+    if (!gzReadAll(g, blk.data(), (size_t)bs)) die("", "Cannot parse BAM file");
+    auto i32 = [&](size_t o) { return (int32_t)(blk[o] | (blk[o + 1] << 8) | (blk[o + 2] << 16) | ((uint32_t)blk[o + 3] << 24)); };
+    auto u16 = [&](size_t o) { return (uint16_t)(blk[o] | (blk[o + 1] << 8)); };
+    const int32_t refID = i32(0), pos = i32(4);
+    const uint8_t l_read_name = blk[8], mapq = blk[9];
+    const uint16_t n_cigar = u16(12), flag = u16(14);
+    const int32_t l_seq = i32(16), next_pos = i32(24);
+    size_t off = 32;
+    if (off + l_read_name > blk.size()) die("", "Cannot parse BAM file");
+    const char* qname = (const char*)&blk[off];
+    off += l_read_name;
+    const size_t cigOff = off;
+    off += (size_t)n_cigar * 4 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if (off > blk.size()) die("", "Cannot parse BAM file");
+    C.count++;
+    if (flag & 0x4) { C.unmapped++; continue; }
+    if (!strcmp(qname, "*") || refID < 0 || refID >= n_ref || pos < 0) die(qname, ": poorly formatted SAM/BAM record");
+    if (flag & 0xE00) { C.supp++; continue; }
+    if (mapq < S.o.minMapQ) { C.lowMapQ++; continue; }
+    int length = l_seq, offset = 0;  // calcDistBAM: CIGAR ops consume as in parseCigar
+    if (n_cigar) {
+      int len = 0;
+      for (int k = 0; k < n_cigar; k++) {
+        uint32_t c = (uint32_t)i32(cigOff + 4 * (size_t)k);
+        int n = (int)(c >> 4), op = (int)(c & 15);
+        switch (op) {
+          case 0: case 7: case 8: len += n; break;       // M = X
+          case 1: case 4: len += n; offset -= n; break;  // I S
+          case 2: offset += n; break;                    // D
+          case 3: case 5: case 6: break;                 // N H P
+          default: die("", ": unknown Op in CIGAR");
+        }
+      }
+      if (!length) length = len;
+      else if (length != len) die(qname, ": mismatch between sequence length and CIGAR");
+    } else if (!length)
+      die(qname, ": no sequence information (SEQ or CIGAR)");
+    float score = bamScore(blk.data() + off, blk.data() + blk.size());
+    record(S, rs, C, qname, flag, idx[refID], (uint32_t)pos, mapq, length + offset, (uint32_t)next_pos, score);
+  }
+  finishFile(S, rs, C);
+  return C.count;
+}
+
+// ---- -v accounting (logCounts 5295-5374) -------------------------------------------------------
+void logCounts(const State& S, const Counts& C, bool bam) {
+  const Opts& o = S.o;
+  if (S.errCount > MAX_ALNS) fprintf(stderr, "(another %ld warning messages suppressed)\n", (long)(S.errCount - MAX_ALNS));
+  double avgLen = C.pairedPr ? C.totalLen / C.pairedPr : 0.0;
+  fprintf(stderr, "  %s records analyzed: %11ld\n", bam ? "BAM" : "SAM", (long)C.count);
+  if (C.unmapped) fprintf(stderr, "    Unmapped:           %11ld\n", (long)C.unmapped);
+  if (C.supp) fprintf(stderr, "    Supp./dups/lowQual: %11ld\n", (long)C.supp);
+  if (C.skipped) {
+    fprintf(stderr, "    To skipped refs:    %11ld\n", (long)C.skipped);
+    fprintf(stderr, "      (");
+    bool first = true;
+    for (auto& c : S.chrom)
+      if (c.skip || !c.save) {
+        fprintf(stderr, "%s%s", first ? "" : ",", c.name.c_str());
+        first = false;
+      }
+    fprintf(stderr, ")\n");
+  }
+  if (C.lowMapQ) fprintf(stderr, "    MAPQ < %-2d:          %11ld\n", o.minMapQ, (long)C.lowMapQ);
+  fprintf(stderr, "    Paired alignments:  %11ld\n", (long)C.paired);
+  if (C.secPair) fprintf(stderr, "      secondary alns:   %11ld\n", (long)C.secPair);
+  if (C.orphan) fprintf(stderr, "      \"orphan\" alns:    %11ld\t** Warning! **\n", (long)C.orphan);
+  fprintf(stderr, "    Unpaired alignments:%11ld\n", (long)C.single);
+  if (C.secSingle) fprintf(stderr, "      secondary alns:   %11ld\n", (long)C.secSingle);
+  fprintf(stderr, "  Fragments analyzed:   %11ld\n", (long)(C.singlePr + C.pairedPr));
+  fprintf(stderr, "    Full fragments:     %11ld\n", (long)C.pairedPr);
+  if (C.pairedPr && !o.atacOpt) fprintf(stderr, "      (avg. length: %.1fbp)\n", avgLen);
+  if (o.singleOpt) {
+    fprintf(stderr, "    Half fragments:     %11ld\n", (long)C.singlePr);
+    if (C.singlePr) {
+      fprintf(stderr, "      (from unpaired alns");
+      if (o.extendOpt) fprintf(stderr, ", extended to %dbp", o.extend);
+      else if (o.avgExtOpt && C.pairedPr) fprintf(stderr, ", extended to %dbp", (int)(avgLen + 0.5));
+      fprintf(stderr, ")\n");
+    }
+  }
+  if (o.atacOpt) {
+    fprintf(stderr, "    ATAC-seq cut sites: %11ld\n", (long)(2 * C.pairedPr + C.singlePr));
+    fprintf(stderr, "      (expanded to length %dbp)\n", o.atacLen5 + o.atacLen3);
+  }
+}
+
+// header pre-scan: the chromosome table must be complete (in the order the reference would build
+// it: first appearance over t1, c1, t2, c2, ...) before anything is sent to the device
+void scanHeader(State& S, const char* filename, bool ctrl) {
+  if (!strcmp(filename, "-")) return;
+  In in = openRead(filename);
+  S.ctrl = ctrl;
+  char magic[4];
+  int got = gzread(in.gz, magic, 4);
+  if (got == 4 && !memcmp(magic, "BAM\1", 4)) {
+    int32_t l_text = rdI32(in.gz, true);
+    if (gzseek(in.gz, l_text, SEEK_CUR) == -1) die("", "Cannot parse BAM file");
+    int32_t n_ref = rdI32(in.gz, true);
+    for (int i = 0; i < n_ref; i++) {
+      int32_t len = rdI32(in.gz, true);
+      if (len < 1 || len > 65520) die("", "Cannot parse BAM file");
+      std::vector<char> nm((size_t)len);
+      if (!gzReadAll(in.gz, nm.data(), (size_t)len)) die("", "Cannot parse BAM file");
+      saveChrom(S, nm.data(), (uint32_t)rdI32(in.gz, true));
+    }
+  } else {
+    std::vector<char> line(65520);
+    memcpy(line.data(), magic, (size_t)std::max(0, got));
+    line[std::max(0, got)] = '\0';
+    bool first = true;
+    for (;;) {
+      char* l = line.data();
+      if (first) {
+        first = false;
+        if (got > 0 && !memchr(magic, '\n', (size_t)got) && !gzgets(in.gz, l + got, (int)line.size() - got)) l[got] = '\0';
+      } else if (!gzgets(in.gz, l, (int)line.size()))
+        break;
+      if (l[0] != '@') break;
+      const bool sortSave = S.o.sortOpt;
+      S.o.sortOpt = false;  // the sort-order check belongs to the real pass
+      headerLine(S, l);
+      S.o.sortOpt = sortSave;
+    }
+  }
+  gzclose(in.gz);
+}
+
+void sendChroms(State& S) {
+  S.tableFrozen = true;
+  if (!S.gx) return;
+  size_t n = S.chrom.size();
+  if (!n) die("", "No analyzable genome (length=0)");
+  std::vector<uint32_t> len(n);
+  std::vector<uint8_t> skip(n);
+  std::vector<const uint32_t*> bed(n);
+  std::vector<int32_t> bedLen(n);
+  for (size_t i = 0; i < n; i++) {
+    len[i] = S.chrom[i].len;
+    skip[i] = S.chrom[i].skip;
+    bed[i] = S.chrom[i].bed.data();
+    bedLen[i] = (int32_t)S.chrom[i].bed.size();
+  }
+  check(S, gx_set_chroms(S.gx, (int)n, len.data(), skip.data(), bed.data(), bedLen.data()));
+}
+
+void loadBED(State& S, const char* files) {  // loadBED 5187-5238
+  std::string list(files);
+  std::vector<char> line(65520);
+  for (char* fn = strtok(list.data(), ", "); fn; fn = strtok(nullptr, ", ")) {
+    In in = openRead(fn);
+    while (gzgets(in.gz, line.data(), (int)line.size())) {
+      std::string orig(line.data());
+      char* name = strtok(line.data(), "\t");
+      char* a = name ? strtok(nullptr, "\t") : nullptr;
+      char* b = a ? strtok(nullptr, "\t\n") : nullptr;
+      if (!name || !a || !b) die(orig, ": poorly formatted BED record");
+      int p0 = getInt(a), p1 = getInt(b);
+      if (p1 <= p0 || p0 < 0 || p1 < 0) {
+        char msg[512];
+        snprintf(msg, sizeof msg, "%s, %d - %d", name, p0, p1);
+        die(msg, ": poorly formatted BED record");
+      }
+      S.xbed.push_back(BedRec{name, {(uint32_t)p0, (uint32_t)p1}});
+    }
+    gzclose(in.gz);
+  }
+}
+
+void usage() {
+  fprintf(stderr,
+          "Usage: genrich-amd  -t <file>  -o <file>  [optional arguments]\n"
+          "  (same options as Genrich v0.6.2: -t -c -o -f -k -b -z -y -w -x -j -d -D -e -E -m -s\n"
+          "   -p -q -a -l -g -X -S -L -v -V; -r/-R/-P are not implemented in this build)\n");
+  exit(EXIT_FAILURE);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  State S;
+  Opts& o = S.o;
+  static struct option longOpts[] = {{"help", no_argument, nullptr, 'h'},
+                                     {"verbose", no_argument, nullptr, 'v'},
+                                     {"version", no_argument, nullptr, 'V'},
+                                     {"events-only", no_argument, nullptr, 1000},
+                                     {"device", required_argument, nullptr, 1001},
+                                     {nullptr, 0, nullptr, 0}};
+  int c;
+  while ((c = getopt_long(argc, argv, "ht:c:o:f:k:b:zyw:xjd:De:E:m:s:p:q:a:l:g:rR:XPSL:vV", longOpts, nullptr)) != -1)
+    switch (c) {
+      case 't': o.inFile = optarg; break;
+      case 'c': o.ctrlFile = optarg; break;
+      case 'o': o.outFile = optarg; break;
+      case 'f': o.logFile = optarg; break;
+      case 'k': o.pileFile = optarg; break;
+      case 'b': o.bedFile = optarg; break;
+      case 'z': o.gzOut = true; break;
+      case 'y': o.singleOpt = true; break;
+      case 'w': o.extend = getInt(optarg); o.extendOpt = true; break;
+      case 'x': o.avgExtOpt = true; break;
+      case 'j': o.atacOpt = true; break;
+      case 'd': o.atacLen5 = getInt(optarg); break;
+      case 'D': o.atacAdj = false; break;
+      case 'e': o.xchrom = optarg; break;
+      case 'E': o.xFile = optarg; break;
+      case 'm': o.minMapQ = getInt(optarg); break;
+      case 's': o.asDiff = getFloat(optarg); break;
+      case 'p': o.pqvalue = getFloat(optarg); break;
+      case 'q': o.pqvalue = getFloat(optarg); o.qvalOpt = true; break;
+      case 'a': o.minAUC = getFloat(optarg); break;
+      case 'l': o.minLen = getInt(optarg); break;
+      case 'g': o.maxGap = getInt(optarg); break;
+      case 'r': o.dupsOpt = true; break;
+      case 'R': o.dupsFile = optarg; break;
+      case 'X': o.peaksOpt = false; break;
+      case 'P': o.peaksOnly = true; break;
+      case 'S': o.sortOpt = false; break;
+      case 'L': o.genomeLen = (uint64_t)getLong(optarg); break;
+      case 'v': o.verbose = true; break;
+      case 'V': fprintf(stderr, "genrich-amd, version %s (Genrich 0.6.2 hot path on MI355X)\n", VERSION); exit(EXIT_FAILURE);
+      case 1000: o.eventsOnly = true; break;
+      case 1001: o.device = getInt(optarg); break;
+      case 'h': usage();
+      default: exit(EXIT_FAILURE);
+    }
+  if (optind < argc) die(argv[optind], ": unknown command-line argument");
+  if ((o.peaksOpt && !o.outFile && !o.eventsOnly) || (o.peaksOnly && !o.logFile) || (!o.peaksOnly && !o.inFile)) {
+    fprintf(stderr, "Error! Need input/output files\n");
+    usage();
+  }
+  if (o.dupsOpt) die("", "-r (PCR duplicate removal) is not implemented in genrich-amd");
+  if (o.peaksOnly) die("", "-P (peak calling from a log file) is not implemented in genrich-amd");
+  if (o.avgExtOpt) { o.singleOpt = true; o.extendOpt = false; }
+  if (o.extendOpt) {
+    o.singleOpt = true;
+    if (o.extend <= 0) die("", "Extension length must be > 0");
+  }
+  if (o.atacOpt) {
+    o.avgExtOpt = o.extendOpt = false;
+    if (o.atacLen5 <= 0) die("", "ATAC-seq interval length must be > 0");
+    o.atacLen3 = (int)(o.atacLen5 / 2.0f + 0.5f);
+    o.atacLen5 /= 2;
+  }
+  if (o.minLen < 0) die("", "Minimum peak length must be >= 0");
+  if (o.minAUC < 0.0f) die("", "Minimum AUC must be >= 0.0");
+  if (o.asDiff < 0.0f) die("", "Secondary alignment score threshold must be >= 0.0");
+  if (o.xchrom) {
+    std::string list(o.xchrom);
+    for (char* t = strtok(list.data(), ", "); t; t = strtok(nullptr, ", ")) S.xchr.push_back(t);
+  }
+  if (o.pqvalue <= 0.0f || o.pqvalue > 1.0f) die("", "p-/q-value must be in (0,1]");
+  const float thr = -log10f(o.pqvalue);
+
+  if (o.bedFile) { S.bed = openWrite(o.bedFile, o.gzOut); S.bedOpt = true; }
+  if (o.xFile) loadBED(S, o.xFile);
+  if (!o.eventsOnly) {
+    gx_params par{};
+    par.thr = thr;
+    par.qval_opt = o.qvalOpt;
+    par.min_auc = o.minAUC;
+    par.min_len = o.minLen;
+    par.max_gap = o.maxGap;
+    par.device = o.device;
+    par.genome_len = o.genomeLen;
+    int rc = gx_create(&S.gx, &par);
+    if (rc) die(S.gx ? gx_last_error(S.gx) : gx_strerror(rc), "");
+  }
+
+  // loop over the comma-separated treatment / control lists (runProgram 5455-5585)
+  std::string tList(o.inFile), cList(o.ctrlFile ? o.ctrlFile : "");
+  std::vector<std::string> tFiles, cFiles;
+  for (char* t = strtok(tList.data(), ", "); t; t = strtok(nullptr, ", ")) tFiles.push_back(t);
+  for (char* t = strtok(cList.data(), ", "); t; t = strtok(nullptr, ", ")) cFiles.push_back(t);
+  for (size_t r = 0; r < tFiles.size(); r++) {  // pre-scan of every header, reference order
+    scanHeader(S, tFiles[r].c_str(), false);
+    if (o.ctrlFile && r < cFiles.size() && cFiles[r] != "null") scanHeader(S, cFiles[r].c_str(), true);
+  }
+  sendChroms(S);
+  for (size_t r = 0; r < tFiles.size(); r++) {
+    for (auto& ch : S.chrom) ch.save = false;
+    const char* ctrlName = !o.ctrlFile ? nullptr : (r < cFiles.size() ? cFiles[r].c_str() : nullptr);
+    for (int i = 0; i < 2; i++) {
+      const char* filename = i ? ctrlName : tFiles[r].c_str();
+      if (i && filename && !strcmp(filename, "null")) filename = nullptr;
+      if (i && !filename) {
+        if (o.verbose) fprintf(stderr, "- control file #%d not provided -\n", S.sample);
+        float lambda = 0;
+        if (S.gx) check(S, gx_sample_no_control(S.gx, &lambda));
+        if (o.verbose && S.gx) fprintf(stderr, "  Background pileup value: %f\n", lambda);
+        break;
+      }
+      S.ctrl = i;
+      S.sampleOpen = false;
+      S.errCount = 0;
+      S.buf.clear();
+      In in = openRead(filename);
+      // BAM or SAM?  (checkBAM 5107: the decompressed stream starts with "BAM\1")
+      char magic[4] = {0};
+      int got = gzread(in.gz, magic, 4);
+      bool bam = got == 4 && !memcmp(magic, "BAM\1", 4);
+      if (o.verbose) fprintf(stderr, "Processing %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
+      Counts C;
+      if (bam)
+        readBAM(S, in, C);
+      else if (got <= 0)
+        readSAM(S, in, nullptr, C);
+      else {
+        // hand the 4 sniffed bytes back as the beginning of the first line
+        std::vector<char> firstLine(65520);
+        memcpy(firstLine.data(), magic, (size_t)got);
+        firstLine[got] = '\0';
+        if (!memchr(magic, '\n', (size_t)got)) {
+          if (!gzgets(in.gz, firstLine.data() + got, (int)firstLine.size() - got)) firstLine[got] = '\0';
+        } else
+          die(filename, ": poorly formatted SAM/BAM record");
+        readSAM(S, in, firstLine.data(), C);
+      }
+      gzclose(in.gz);
+      openSample(S);  // a file without a single usable record still opens (and closes) its sample
+      if (S.gx && !S.buf.empty()) check(S, gx_push_events(S.gx, S.buf.data(), S.buf.size()));
+      S.buf.clear();
+      if (o.verbose) logCounts(S, C, bam);
+      if (S.gx) {
+        double fragLen = 0;
+        float lambda = 0, factor = 0;
+        check(S, gx_sample_end(S.gx, &fragLen, &lambda, &factor));
+        if (i && o.verbose) {
+          fprintf(stderr, "  Background pileup value: %f\n", lambda);
+          fprintf(stderr, "  Scaling factor for control pileup: %f\n", factor);
+          if (factor > 5.0f) fprintf(stderr, "  ** Warning! Large scaling may mask true signal **\n");
+        }
+      }
+    }
+    if (S.gx) check(S, gx_pvalues(S.gx));
+    S.sample++;
+  }
+  if (S.bedOpt) closeOut(S.bed);
+  if (o.eventsOnly) return EXIT_SUCCESS;
+
+  size_t nPeaks = 0;
+  uint64_t genomeLen = 0, peakBP = 0;
+  check(S, gx_find_peaks(S.gx, &nPeaks, &genomeLen, &peakBP));
+  if (o.verbose) {  // findPeaks 1103-1117, 1130-1132
+    if (o.peaksOpt) {
+      fprintf(stderr, "Peak-calling parameters:\n");
+      fprintf(stderr, "  Genome length: %ldbp\n", (long)genomeLen);
+      fprintf(stderr, "  Significance threshold: -log(%c) > %.3f\n", o.qvalOpt ? 'q' : 'p', thr);
+      fprintf(stderr, "  Min. AUC: %.3f\n", o.minAUC);
+      if (o.minLen) fprintf(stderr, "  Min. peak length: %dbp\n", o.minLen);
+      fprintf(stderr, "  Max. gap between sites: %dbp\n", o.maxGap);
+    } else {
+      fprintf(stderr, "- peak-calling skipped -\n");
+      fprintf(stderr, "  Genome length: %ldbp\n", (long)genomeLen);
+    }
+  }
+  std::vector<const char*> names;
+  for (auto& ch : S.chrom) names.push_back(ch.name.c_str());
+  const int nChrom = (int)names.size();
+  if (o.pileFile) {
+    Out pile = openWrite(o.pileFile, o.gzOut);
+    for (int r = 0; r < S.sample; r++) {
+      const char* cn = !o.ctrlFile ? nullptr : ((size_t)r < cFiles.size() ? cFiles[r].c_str() : nullptr);
+      check(S, gx_write_pile(S.gx, r, names.data(), nChrom, tFiles[r].c_str(), cn, pile.f));
+    }
+    closeOut(pile);
+  }
+  if (o.peaksOpt) {
+    Out out = openWrite(o.outFile, o.gzOut);
+    check(S, gx_write_narrowpeak(S.gx, names.data(), out.f));
+    closeOut(out);
+    if (o.verbose) fprintf(stderr, "Peaks identified: %d (%ldbp)\n", (int)nPeaks, (long)peakBP);
+  }
+  if (o.logFile) {
+    Out log = openWrite(o.logFile, o.gzOut);
+    check(S, gx_write_log(S.gx, S.sample, names.data(), nChrom, o.qvalOpt, o.peaksOpt, thr, log.f));
+    closeOut(log);
+  }
+  gx_destroy(S.gx);
+  return EXIT_SUCCESS;
+}

@@ -1,0 +1,96 @@
+"""The host program genrich_amd/genrich-amd (C++): option handling, SAM ingest and interval
+geometry are checked on the CPU against the reference's own -b event lists (golden fixtures);
+the full command line (SAM in -> narrowPeak / -f / -k out) is checked on the GPU."""
+import gzip
+import importlib.util
+import os
+import subprocess
+
+import pytest
+
+import golden_cases as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cases():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G.GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return {c["name"]: c for c in mg.cases()}, mg
+
+
+def _write_inputs(case, mg, tmp):
+    """Regenerate the synthetic SAM inputs of a golden case (deterministic) under the same
+    path prefix the fixture was made with, so that the -k header lines match byte for byte."""
+    import synth
+    os.makedirs(tmp, exist_ok=True)
+    tf, cf = [], []
+    for r, rep in enumerate(case["reps"]):
+        names, lens, ev = rep["t"]
+        p = os.path.join(tmp, f"t{r}.sam")
+        synth.write_sam(p, names, lens, ev, name_prefix=f"t{r}_")
+        tf.append(p)
+        if rep["c"] is None:
+            cf.append(None)
+        elif rep["c"] == "null":
+            cf.append("null")
+        else:
+            names, lens, ev = rep["c"]
+            p = os.path.join(tmp, f"c{r}.sam")
+            synth.write_sam(p, names, lens, ev, name_prefix=f"c{r}_")
+            cf.append(p)
+    args = ["-t", ",".join(tf)]
+    if any(c is not None for c in cf):
+        args += ["-c", ",".join(c if c else "null" for c in cf)]
+    if case.get("bed"):
+        bp = os.path.join(tmp, "x.bed")
+        with open(bp, "w") as f:
+            for c, s, e in case["bed"]:
+                f.write(f"{c}\t{s}\t{e}\n")
+        args += ["-E", bp]
+    return args + case["args"]
+
+
+def _binary():
+    from genrich_amd import build
+    build.build()
+    return build.HOST_BIN
+
+
+@pytest.mark.parametrize("name", G.case_names())
+def test_cli_event_stream_matches_reference(name, tmp_path):
+    cases, mg = _cases()
+    case = cases[name]
+    args = _write_inputs(case, mg, str(tmp_path / "in"))
+    bed = str(tmp_path / "events.bed")
+    a = [x for x in args if x != "-X"]
+    res = subprocess.run([_binary(), "--events-only", "-b", bed] + a, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", G.case_names())
+def test_cli_outputs_byte_identical(name):
+    """Whole command line on the GPU box: the same files the reference wrote."""
+    cases, mg = _cases()
+    case = cases[name]
+    meta, _, _, _ = G.load_case(name)
+    tmp = meta["tmp_prefix"].rstrip("/")  # same input paths as when the fixture was made
+    args = _write_inputs(case, mg, tmp)
+    out = os.path.join(tmp, "cli_out")
+    cmd = [_binary(), "-v", "-f", out + ".log", "-k", out + ".pile", "-b", out + ".bed"] + args
+    if "-X" not in case["args"]:
+        cmd += ["-o", out + ".narrowPeak"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert open(out + ".bed", "rb").read() == G.read_gz(name, "events.bed")
+    assert open(out + ".pile", "rb").read() == G.read_gz(name, "out.pile")
+    assert open(out + ".log", "rb").read() == G.read_gz(name, "out.log")
+    if "-X" not in case["args"]:
+        assert open(out + ".narrowPeak", "rb").read() == G.read_gz(name, "out.narrowPeak")
+    lam = [f"{v:f}" for v in meta["ref_lambda"]]
+    assert [l.split(": ")[1] for l in res.stderr.splitlines() if "Background pileup value" in l] == lam
+    if meta["ref_peaks"]:
+        assert f"Peaks identified: {meta['ref_peaks'][0][0]} ({meta['ref_peaks'][0][1]}bp)" in res.stderr
