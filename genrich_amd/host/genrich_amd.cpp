@@ -9,9 +9,9 @@
 // from libgenrich_amd.so; text output is gx_emit.cpp.  Written from the behaviour described in
 // SURVEY.md Appendix A, not transliterated from the reference.
 //
-// Not implemented here (the reference options are recognised and rejected with a message):
+// -P (peak calling from a -f log, callPeaksLog 1277-1488) is text processing and runs on the host.
+// Not implemented here (the reference option is recognised and rejected with a message):
 //   -r / -R  PCR-duplicate removal (Genrich.c:2776-2977, 3267-4042)
-//   -P       peak calling from a -f log (callPeaksLog, 1277-1488)
 //
 // Extra long option (diagnostics, never needed for normal use):
 //   --events-only   parse and write the -b file without touching a GPU
@@ -853,11 +853,169 @@ void loadBED(State& S, const char* files) {  // loadBED 5187-5238
   }
 }
 
+// ---- -P: call peaks from a bedgraph-ish -f log (findPeaksOnly 5243, callPeaksLog 1277-1488) -------
+// Host-only by nature (it re-parses text); the sweep is the same state machine as callPeaks,
+// applied to the 6-decimal values of the log, with new -e / -E exclusions cutting intervals.
+struct PeakState {
+  float auc = 0.0f, summitVal = -1.0f, summitP = -1.0f, summitQ = -1.0f;
+  int64_t peakStart = -1, peakEnd = -1;
+  uint32_t summitPos = 0, summitLen = 0;
+  void reset() { peakStart = -1; summitVal = -1.0f; summitLen = 0; auc = 0.0f; }            // resetVars 932
+  void update(uint32_t start, uint32_t end, float pq, float thr, float pv, float qv) {     // updatePeak 943
+    uint32_t len = end - start;
+    auc += len * (pq - thr);
+    if (peakStart == -1) peakStart = start;
+    peakEnd = end;
+    if (pq > summitVal) {
+      summitVal = pq; summitP = pv; summitQ = qv;
+      summitPos = (uint32_t)((end + start) / 2 - peakStart);
+      summitLen = len;
+    } else if (pq == summitVal && len > summitLen) {
+      summitPos = (uint32_t)((end + start) / 2 - peakStart);
+      summitLen = len;
+    }
+  }
+};
+
+void peaksOnly(State& S, float thr) {
+  const Opts& o = S.o;
+  In in = openRead(o.logFile);
+  Out out = openWrite(o.outFile, o.gzOut);
+  if (o.verbose) fprintf(stderr, "Peak-calling from log file: %s\n", o.logFile);
+  std::vector<char> line(65520);
+  // header: the LAST -log(p) / -log(q) columns (getIdx 1224-1246)
+  if (!gzgets(in.gz, line.data(), (int)line.size())) die("<header>", ": cannot find field in header of bedgraph-ish log file");
+  int idxP = -1, idxQ = -1, nf = 0;
+  for (char* f = strtok(line.data(), "\t\n"); f; f = strtok(nullptr, "\t\n"), nf++) {
+    if (!strncmp(f, "-log(p)", 7)) idxP = nf;
+    else if (!strncmp(f, "-log(q)", 7)) idxQ = nf;
+  }
+  if (idxP == -1) die("-log(p)", ": cannot find field in header of bedgraph-ish log file");
+  if (o.qvalOpt && idxQ == -1) die("-log(q)", ": cannot find field in header of bedgraph-ish log file");
+  const int idx = o.qvalOpt ? idxQ : idxP;
+
+  int count = 0;
+  uint64_t peakBP = 0, genomeLen = o.genomeLen;
+  const bool genomeOpt = genomeLen == 0;
+  PeakState P;
+  std::string prev, chrName;
+  bool skip = false, save = true, warn = false;
+  Chrom cur;
+  size_t bedIdx = 0;
+  uint32_t bedPos = UINT32_MAX;
+  auto check = [&](const std::string& name) {  // checkPeak 916 + printPeak 885
+    if (P.peakStart != -1 && P.auc >= o.minAUC && P.peakEnd - P.peakStart >= o.minLen) {
+      float sc = 1000.0f * P.auc / (P.peakEnd - P.peakStart) + 0.5f;
+      unsigned int u = (unsigned int)(long long)sc;
+      fprintf(out.f, "%s\t%ld\t%ld\tpeak_%d\t%d\t.\t%f\t%f", name.c_str(), (long)P.peakStart, (long)P.peakEnd, count,
+              u < 1000u ? u : 1000u, P.auc, P.summitP);
+      if (P.summitQ == GX_SKIP) fprintf(out.f, "\t-1\t%d\n", P.summitPos);
+      else fprintf(out.f, "\t%f\t%d\n", P.summitQ, P.summitPos);
+      peakBP += (uint64_t)(P.peakEnd - P.peakStart);
+      count++;
+    }
+  };
+  auto nextBed = [&]() { bedIdx++; bedPos = bedIdx < cur.bed.size() ? cur.bed[bedIdx] : UINT32_MAX; };
+  while (gzgets(in.gz, line.data(), (int)line.size())) {
+    // loadBDG 1252-1272
+    char *chr = nullptr, *pStat = nullptr, *qStat = nullptr;
+    uint32_t start = 0, end = 0;
+    char* f = strtok(line.data(), "\t\n");
+    for (int i = 0; i <= idx; i++) {
+      if (!f) die("", "Poorly formatted bedgraph-ish log record");
+      if (i == 0) chr = f;
+      else if (i == 1) start = (uint32_t)getInt(f);
+      else if (i == 2) end = (uint32_t)getInt(f);
+      else if (i == idxP) pStat = f;
+      else if (i == idxQ) qStat = f;
+      f = strtok(nullptr, "\t\n");
+    }
+    if (prev != chr) {  // new chromosome, 1321-1356
+      check(prev);
+      P.reset();
+      skip = false;
+      for (auto& x : S.xchr)
+        if (x == chr) skip = true;
+      if (o.verbose && skip) {
+        fprintf(stderr, "Warning! Skipping chromosome %s --\n  ", chr);
+        fprintf(stderr, "Reads aligning to it were used in the background");
+        fprintf(stderr, " pileup calculation,\n  and its length was included");
+        fprintf(stderr, " in the genome length %scalculation\n", o.qvalOpt ? "(and q-value) " : "");
+      }
+      cur = Chrom();
+      cur.name = chr;
+      cur.len = UINT32_MAX;  // coordinates cannot be validated here (1344)
+      if (!skip) {
+        mergeBed(cur, S.xbed, o.verbose);
+        bedIdx = 0;
+        bedPos = cur.bed.empty() ? UINT32_MAX : cur.bed[0];
+        save = true;
+      }
+      prev = chr;
+    }
+    chrName = chr;
+    if (skip) continue;
+    const char* stat = o.qvalOpt ? qStat : pStat;
+    if (!strcmp(stat, "NA")) {  // skipped region of the original run
+      check(chrName);
+      P.reset();
+      continue;
+    }
+    const float pq = getFloat(stat);
+    const float pv = o.qvalOpt ? getFloat(pStat) : pq, qv = o.qvalOpt ? pq : GX_SKIP;
+    if (bedPos == start) {  // 1376-1390
+      if (save) { check(chrName); P.reset(); }
+      save = !save;
+      nextBed();
+    }
+    uint32_t subStart = start;
+    while (bedPos > start && bedPos < end) {  // new -E edges inside the interval, 1395-1425
+      if (save) {
+        if (pq > thr) P.update(subStart, bedPos, pq, thr, pv, qv);
+        check(chrName);
+        P.reset();
+        if (genomeOpt) genomeLen += bedPos - subStart;
+      } else
+        warn = true;
+      subStart = bedPos;
+      save = !save;
+      nextBed();
+    }
+    if (!save) { warn = true; continue; }
+    start = subStart;
+    if (genomeOpt) genomeLen += end - start;
+    if (pq > thr)
+      P.update(start, end, pq, thr, pv, qv);
+    else if ((int64_t)end - P.peakEnd > o.maxGap) {
+      check(chrName);
+      P.reset();
+    }
+  }
+  check(chrName);
+  if (o.verbose) {
+    if (warn) {
+      fprintf(stderr, "Warning! Skipping given BED regions --\n  ");
+      fprintf(stderr, "Reads aligning to them were used in the background");
+      fprintf(stderr, " pileup calculation,\n  and the lengths were included");
+      fprintf(stderr, " in the genome length %scalculation\n", o.qvalOpt ? "(and q-value) " : "");
+    }
+    fprintf(stderr, "Peak-calling parameters:\n");
+    fprintf(stderr, "  Genome length: %ldbp\n", (long)genomeLen);
+    fprintf(stderr, "  Significance threshold: -log(%c) > %.3f\n", o.qvalOpt ? 'q' : 'p', thr);
+    fprintf(stderr, "  Min. AUC: %.3f\n", o.minAUC);
+    if (o.minLen) fprintf(stderr, "  Min. peak length: %dbp\n", o.minLen);
+    fprintf(stderr, "  Max. gap between sites: %dbp\n", o.maxGap);
+    fprintf(stderr, "Peaks identified: %d (%ldbp)\n", count, (long)peakBP);
+  }
+  gzclose(in.gz);
+  closeOut(out);
+}
+
 void usage() {
   fprintf(stderr,
           "Usage: genrich-amd  -t <file>  -o <file>  [optional arguments]\n"
           "  (same options as Genrich v0.6.2: -t -c -o -f -k -b -z -y -w -x -j -d -D -e -E -m -s\n"
-          "   -p -q -a -l -g -X -S -L -v -V; -r/-R/-P are not implemented in this build)\n");
+          "   -p -q -a -l -g -X -P -S -L -v -V; -r/-R are not implemented in this build)\n");
   exit(EXIT_FAILURE);
 }
 
@@ -916,7 +1074,6 @@ int main(int argc, char** argv) {
     usage();
   }
   if (o.dupsOpt) die("", "-r (PCR duplicate removal) is not implemented in genrich-amd");
-  if (o.peaksOnly) die("", "-P (peak calling from a log file) is not implemented in genrich-amd");
   if (o.avgExtOpt) { o.singleOpt = true; o.extendOpt = false; }
   if (o.extendOpt) {
     o.singleOpt = true;
@@ -938,8 +1095,12 @@ int main(int argc, char** argv) {
   if (o.pqvalue <= 0.0f || o.pqvalue > 1.0f) die("", "p-/q-value must be in (0,1]");
   const float thr = -log10f(o.pqvalue);
 
-  if (o.bedFile) { S.bed = openWrite(o.bedFile, o.gzOut); S.bedOpt = true; }
   if (o.xFile) loadBED(S, o.xFile);
+  if (o.peaksOnly) {  // runProgram 5398-5403
+    peaksOnly(S, thr);
+    return EXIT_SUCCESS;
+  }
+  if (o.bedFile) { S.bed = openWrite(o.bedFile, o.gzOut); S.bedOpt = true; }
   if (!o.eventsOnly) {
     gx_params par{};
     par.thr = thr;

@@ -24,6 +24,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth  # noqa: E402
 
@@ -144,6 +145,15 @@ def cases():
               dict(t=(N2, L2, mf(L2, 1500, 92)), c=None)])
 
 
+# -P re-calls on the -f log of a case (callPeaksLog, Genrich.c:1277-1488): new thresholds, new -e / -E
+P_RUNS = {
+    "ctrl_q": [dict(args=["-q", "0.4", "-a", "15"]), dict(args=["-p", "0.001", "-a", "10", "-g", "20", "-l", "50"])],
+    "reps3": [dict(args=["-p", "0.01", "-a", "50"]), dict(args=["-q", "0.3", "-a", "5", "-e", "chr2"])],
+    "bedx": [dict(args=["-q", "0.25", "-a", "30"], bed=[("chr1", 3000, 3400), ("chr1", 12000, 12345), ("chr2", 0, 777)])],
+    "basic": [dict(args=["-a", "100", "-L", "1000"], bed=[("chrA", 12500, 12520)])],
+}
+
+
 def gz_copy(src, dst):
     with open(src, "rb") as f, gzip.GzipFile(dst, "wb", mtime=0) as g:
         shutil.copyfileobj(f, g)
@@ -230,6 +240,23 @@ def main():
             src = os.path.join(tmp, fn)
             if os.path.exists(src):
                 gz_copy(src, os.path.join(out_dir, fn + ".gz"))
+        p_meta = []
+        for k, pr in enumerate(P_RUNS.get(case["name"], [])):
+            pargs = [REF, "-P", "-f", os.path.join(tmp, "out.log"), "-o", os.path.join(tmp, f"out.P{k}.narrowPeak")] + pr["args"]
+            if pr.get("bed"):
+                bp = os.path.join(tmp, f"xP{k}.bed")
+                with open(bp, "w") as f:
+                    for c, s_, e in pr["bed"]:
+                        f.write(f"{c}\t{s_}\t{e}\n")
+                pargs += ["-E", bp]
+            r2 = subprocess.run(pargs, capture_output=True, text=True)
+            if r2.returncode != 0:
+                sys.exit(f"{case['name']}: reference -P failed:\n{r2.stderr}")
+            gz_copy(os.path.join(tmp, f"out.P{k}.narrowPeak"), os.path.join(out_dir, f"out.P{k}.narrowPeak.gz"))
+            p_meta.append(dict(args=pr["args"], bed=pr.get("bed", [])))
+        meta["p_runs"] = p_meta
+        with open(os.path.join(out_dir, "case.json"), "w") as f:
+            json.dump(meta, f, indent=1)
         n_np = sum(1 for _ in open(os.path.join(tmp, "out.narrowPeak"))) if "-X" not in case["args"] else 0
         print(f"{case['name']:18s} peaks={n_np:4d} lambda={meta['ref_lambda']} factor={meta['ref_factor']}")
         shutil.rmtree(tmp)

@@ -94,3 +94,31 @@ def test_cli_outputs_byte_identical(name):
     assert [l.split(": ")[1] for l in res.stderr.splitlines() if "Background pileup value" in l] == lam
     if meta["ref_peaks"]:
         assert f"Peaks identified: {meta['ref_peaks'][0][0]} ({meta['ref_peaks'][0][1]}bp)" in res.stderr
+
+
+def _p_runs():
+    import json
+    out = []
+    for name in G.case_names():
+        meta = json.load(open(os.path.join(G.GOLDEN, name, "case.json")))
+        for k, pr in enumerate(meta.get("p_runs", [])):
+            out.append((name, k, pr))
+    return out
+
+
+@pytest.mark.parametrize("name,k,pr", _p_runs())
+def test_cli_peaks_from_log(name, k, pr, tmp_path):
+    """-P: re-calling peaks from the reference's own -f log must reproduce the reference's -P output."""
+    log = str(tmp_path / "in.log")
+    with open(log, "wb") as f:
+        f.write(G.read_gz(name, "out.log"))
+    args = [_binary(), "-P", "-f", log, "-o", str(tmp_path / "np")] + pr["args"]
+    if pr["bed"]:
+        bp = str(tmp_path / "x.bed")
+        with open(bp, "w") as f:
+            for c, s, e in pr["bed"]:
+                f.write(f"{c}\t{s}\t{e}\n")
+        args += ["-E", bp]
+    res = subprocess.run(args, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert open(tmp_path / "np", "rb").read() == G.read_gz(name, f"out.P{k}.narrowPeak")
