@@ -152,3 +152,68 @@ def write_sam(path, names, lens, ev, read_len=50, name_prefix="r"):
                 f.write(f"{nm}\t{147 + sec}\t{names[c]}\t{p2}\t30\t{rl}M\t=\t{p1}\t{-(e - s)}\t*\t*\tAS:i:0\n")
             i += k
             rid += 1
+
+
+def write_sam_mixed(path, names, lens, ev, seed, read_len=50, name_prefix="m", frac_single=0.3, bam=False):
+    """Queryname-grouped SAM (or BAM when bam=True) with a mix of proper pairs and unpaired
+    alignments (forward / reverse), varying MAPQ, a few unmapped, supplementary and secondary
+    records, soft clips and deletions in the CIGAR: exercises -y / -w / -x / -m and the record
+    filters of readSAM / parseBAM (Genrich.c:4531-4559, 4891-4911)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    recs = []  # (qname, flag, chrom, pos0, mapq, cigar ops [(n, op)], pnext0, tlen, AS or None)
+    for i in range(len(ev)):
+        c, s, e = int(ev["chrom"][i]), int(ev["start"][i]), int(ev["end"][i])
+        nm = f"{name_prefix}{i}"
+        rl = min(read_len, e - s)
+        mapq = int(rng.integers(0, 45))
+        u = rng.random()
+        if u < frac_single:
+            rev = rng.random() < 0.5
+            ops = [(rl, "M")]
+            if rng.random() < 0.3 and rl > 20:
+                ops = [(5, "S"), (rl - 15, "M"), (3, "D"), (10, "M")]
+            pos = s if not rev else max(0, e - rl)
+            flag = (16 if rev else 0) | (64 if rng.random() < 0.5 else 128 if rng.random() < 0.5 else 0)
+            if flag & 0xC0:
+                flag |= 1 | 8  # paired in sequencing, mate unmapped
+            recs.append((nm, flag, c, pos, mapq, ops, -1, 0, int(rng.integers(-30, 1))))
+        else:
+            p1, p2 = s, e - rl
+            recs.append((nm, 99, c, p1, mapq, [(rl, "M")], p2, e - s, 0))
+            recs.append((nm, 147, c, p2, mapq, [(rl, "M")], p1, -(e - s), 0))
+        if rng.random() < 0.03:
+            recs.append((nm + "u", 4, 0, 0, 0, [], -1, 0, None))        # unmapped
+        if rng.random() < 0.03:
+            recs.append((nm + "s", 2048, c, s, 30, [(rl, "M")], -1, 0, 0))  # supplementary
+    if not bam:
+        with open(path, "w") as f:
+            f.write("@HD\tVN:1.0\tSO:queryname\n")
+            for n, l in zip(names, lens):
+                f.write(f"@SQ\tSN:{n}\tLN:{l}\n")
+            for nm, flag, c, pos, mapq, ops, pn, tlen, sc in recs:
+                cigar = "".join(f"{n}{o}" for n, o in ops) or "*"
+                rn = "*" if flag & 4 else names[c]
+                extra = f"\tNM:i:0\tAS:i:{sc}" if sc is not None else ""
+                f.write(f"{nm}\t{flag}\t{rn}\t{0 if flag & 4 else pos + 1}\t{mapq}\t{cigar}\t"
+                        f"{'=' if pn >= 0 else '*'}\t{pn + 1}\t{tlen}\t*\t*{extra}\n")
+        return
+    import gzip
+    import struct
+    raw = bytearray()
+    text = "@HD\tVN:1.0\tSO:queryname\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(names, lens))
+    raw += b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(names))
+    for n, l in zip(names, lens):
+        raw += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    opcode = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
+    for nm, flag, c, pos, mapq, ops, pn, tlen, sc in recs:
+        lseq = sum(n for n, o in ops if o in "MIS=X")
+        cig = b"".join(struct.pack("<I", (n << 4) | opcode[o]) for n, o in ops)
+        aux = b""
+        if sc is not None:
+            aux = b"NMC\0" + (b"ASc" + struct.pack("<b", sc) if -128 <= sc < 128 else b"ASi" + struct.pack("<i", sc))
+        body = struct.pack("<iiBBHHHiiii", -1 if flag & 4 else c, -1 if flag & 4 else pos, len(nm) + 1, mapq, 0,
+                           len(ops), flag, lseq, c if pn >= 0 else -1, pn, tlen)
+        body += nm.encode() + b"\0" + cig + b"\0" * ((lseq + 1) // 2) + b"\xff" * lseq + aux
+        raw += struct.pack("<i", len(body)) + body
+    with gzip.GzipFile(path, "wb", mtime=0) as g:
+        g.write(bytes(raw))

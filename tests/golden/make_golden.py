@@ -138,6 +138,14 @@ def cases():
         reps=[dict(t=(NC[:2], LC[:2], mf(LC[:2], 2500, 81)),
                    c=(NC, LC, ctrl))])
 
+    # unpaired alignments: -y (as is), -w (fixed extension), -x (average fragment length), with a MAPQ
+    # filter and assorted records the reader must skip; the same stream also as BAM input
+    for nm, extra in (("unpaired_y", ["-y"]), ("unpaired_w", ["-w", "150", "-m", "10"]), ("unpaired_x", ["-x"]),
+                      ("unpaired_bam_atac", ["-y", "-j", "-D", "-d", "80"])):
+        yield dict(
+            name=nm, names=N2, args=extra + ["-a", "20"], mixed=dict(seed=7, bam=nm.endswith("bam_atac")),
+            reps=[dict(t=(N2, L2, mf(L2, 2500, 95)), c=(N2, L2, mf(L2, 2000, 96, uniform_only=True)))])
+
     # -X: no peak calling, just the -f log (logIntervals, Genrich.c:837)
     yield dict(
         name="nopeaks_log", names=N2, args=["-X", "-q", "0.05"],
@@ -180,8 +188,13 @@ def main():
 
         for r, rep in enumerate(case["reps"]):
             names, lens, ev = rep["t"]
-            p = os.path.join(tmp, f"t{r}.sam")
-            synth.write_sam(p, names, lens, ev, name_prefix=f"t{r}_")
+            mixed = case.get("mixed")
+            ext = "bam" if mixed and mixed["bam"] else "sam"
+            p = os.path.join(tmp, f"t{r}.{ext}")
+            if mixed:
+                synth.write_sam_mixed(p, names, lens, ev, mixed["seed"], name_prefix=f"t{r}_", bam=mixed["bam"])
+            else:
+                synth.write_sam(p, names, lens, ev, name_prefix=f"t{r}_")
             tfiles.append(p)
             seen(names, lens)
             saves.append(list(names))
@@ -191,8 +204,11 @@ def main():
                 cfiles.append("null")
             else:
                 names, lens, ev = rep["c"]
-                p = os.path.join(tmp, f"c{r}.sam")
-                synth.write_sam(p, names, lens, ev, name_prefix=f"c{r}_")
+                p = os.path.join(tmp, f"c{r}.{ext}")
+                if mixed:
+                    synth.write_sam_mixed(p, names, lens, ev, mixed["seed"] + 1, name_prefix=f"c{r}_", bam=mixed["bam"])
+                else:
+                    synth.write_sam(p, names, lens, ev, name_prefix=f"c{r}_")
                 cfiles.append(p)
                 seen(names, lens)
         args = [REF, "-t", ",".join(tfiles), "-v",

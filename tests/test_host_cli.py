@@ -28,8 +28,13 @@ def _write_inputs(case, mg, tmp):
     tf, cf = [], []
     for r, rep in enumerate(case["reps"]):
         names, lens, ev = rep["t"]
-        p = os.path.join(tmp, f"t{r}.sam")
-        synth.write_sam(p, names, lens, ev, name_prefix=f"t{r}_")
+        mixed = case.get("mixed")
+        ext = "bam" if mixed and mixed["bam"] else "sam"
+        p = os.path.join(tmp, f"t{r}.{ext}")
+        if mixed:
+            synth.write_sam_mixed(p, names, lens, ev, mixed["seed"], name_prefix=f"t{r}_", bam=mixed["bam"])
+        else:
+            synth.write_sam(p, names, lens, ev, name_prefix=f"t{r}_")
         tf.append(p)
         if rep["c"] is None:
             cf.append(None)
@@ -37,8 +42,11 @@ def _write_inputs(case, mg, tmp):
             cf.append("null")
         else:
             names, lens, ev = rep["c"]
-            p = os.path.join(tmp, f"c{r}.sam")
-            synth.write_sam(p, names, lens, ev, name_prefix=f"c{r}_")
+            p = os.path.join(tmp, f"c{r}.{ext}")
+            if mixed:
+                synth.write_sam_mixed(p, names, lens, ev, mixed["seed"] + 1, name_prefix=f"c{r}_", bam=mixed["bam"])
+            else:
+                synth.write_sam(p, names, lens, ev, name_prefix=f"c{r}_")
             cf.append(p)
     args = ["-t", ",".join(tf)]
     if any(c is not None for c in cf):
