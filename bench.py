@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frags", type=int, default=50_000_000)
     ap.add_argument("--qval", action="store_true", help="-q 0.05 instead of -p 0.01")
+    ap.add_argument("--control", action="store_true",
+                    help="add a 50M-fragment uniform control (configs[2] shape; not the headline metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-chroms", type=int, default=12)
     args = ap.parse_args()
@@ -92,6 +94,11 @@ def main():
     owned = np.array([o == rank for o in owner], dtype=np.uint8)
     mine = ev_all[owned[ev_all["chrom"]].astype(bool)] if world > 1 else ev_all
     d_ev = torch.from_numpy(mine.view(np.uint32).reshape(-1, 4).copy()).to(dev)
+    d_ct = None
+    if args.control:
+        ct_all = synth.make_fragments(lens, args.frags, seed=2, uniform_only=True)
+        ct = ct_all[owned[ct_all["chrom"]].astype(bool)] if world > 1 else ct_all
+        d_ct = torch.from_numpy(ct.view(np.uint32).reshape(-1, 4).copy()).to(dev)
     torch.cuda.synchronize()
 
     params = GxParams(minus_log10f(0.05 if args.qval else 0.01), int(args.qval), 200.0, 0, 100, local, 0)
@@ -107,7 +114,12 @@ def main():
         gx.sample_begin(0, None)
         gx.push_events_device(d_ev.data_ptr(), d_ev.shape[0])
         gx.sample_end()
-        gx.sample_no_control()
+        if d_ct is not None:
+            gx.sample_begin(1, None)
+            gx.push_events_device(d_ct.data_ptr(), d_ct.shape[0])
+            gx.sample_end()
+        else:
+            gx.sample_no_control()
         gx.pvalues()
         return gx.find_peaks()
 
@@ -171,7 +183,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"hg38 25 contigs ({G} bp), {args.frags} paired fragments, treatment only, "
-                            + ("-q 0.05" if args.qval else "-p 0.01") + " (BASELINE.json configs[1])",
+                            + ("-q 0.05" if args.qval else "-p 0.01")
+                            + (" + 50M-fragment control (configs[2] shape)" if args.control else " (BASELINE.json configs[1])"),
                 "parallelism": f"chromosome-sharded x{world}",
                 "peaks": n_peaks,
             },

@@ -24,7 +24,7 @@ namespace gx {
 typedef unsigned long long u64;
 typedef uint32_t u32;
 
-constexpr int TB = 14;                 // tile bits
+constexpr int TB = 13;                 // tile bits
 constexpr int TILE = 1 << TB;          // bases per tile
 constexpr u32 NULL_TILE = 0xFFFFFFFFu; // dropped endpoint
 constexpr int MAX_BINS = 2048;         // bins of one bucket-sort level
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const R* __restrict__ in, const
 // k_scan_iv then turns the counts into tight offsets and k_pack packs the slots.  (A fused
 // decoupled look-back was measured first: with ~512 resident tiles the look-back distance made
 // it latency-bound at ~10 us per tile.)
-constexpr int TL_NT = 512;
+constexpr int TL_NT = 256;
 constexpr int TL_NW = TL_NT / 64;
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
 constexpr int TL_LDS = TILE + 64 + 2 * (TILE / 32); // ints: slice, scan scratch, occupancy + -E edge bitmaps

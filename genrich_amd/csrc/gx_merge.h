@@ -16,7 +16,8 @@
 
 namespace gx {
 
-constexpr int MG_NT = 256;
+constexpr int MG_WORDS_ = TILE / 32;
+constexpr int MG_NT = MG_WORDS_ < 256 ? MG_WORDS_ : 256;
 constexpr int MG_WORDS = TILE / 32;        // 512 bitmap words per input
 constexpr int MG_WPT = MG_WORDS / MG_NT;   // 2 consecutive words per thread
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
       }
     }
     __syncthreads();
-    u32 wU[MG_WPT] = {0, 0};
+    u32 wU[MG_WPT] = {};
     u32 cU = 0;
 #pragma unroll
     for (int k = 0; k < MG_WPT; k++) {
