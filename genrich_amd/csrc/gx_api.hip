@@ -98,6 +98,7 @@ struct gx_ctx {
   };
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3], tileCursor[3];
+  DevBuf looseC, pairLogE, pairCtab;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};
@@ -115,7 +116,7 @@ struct gx_ctx {
   gx_allreduce_i64_fn allreduce = nullptr;
   gx_allgather_tab_fn allgather = nullptr;
   void* user = nullptr;
-  int numCU = 0, resTile = 0, resMerge = 0, resSweep = 0;  // co-resident workgroups per kernel class
+  int numCU = 0, resTile = 0, resSweep = 0;  // co-resident workgroups per kernel class
   // recycled device buffers (gx_reset keeps allocations alive across runs)
   std::vector<DevBuf> pool;
   // timing
@@ -497,8 +498,6 @@ int gx_create(gx_ctx** out, const gx_params* par) {
     int nb = 0;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true>, TL_NT, TL_LDS * 4));
     ctx->resTile = std::max(1, nb) * ctx->numCU;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_merge2, MG_NT, 0));
-    ctx->resMerge = std::max(1, std::min(nb, 4)) * ctx->numCU;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scan_iv, STL_NT, 0));
     ctx->resSweep = std::max(1, std::min(nb, 4)) * ctx->numCU;
   }
@@ -773,26 +772,42 @@ int gx_pvalues(gx_ctx* ctx) {
     HIPCHECK(pooled(ctx, pa.p, cap * 4));
     HIPCHECK(pooled(ctx, pa.tileOff, (size_t)(nTiles + 2) * 4));
     HIPCHECK(pooled(ctx, pa.chromOff, (size_t)(nChrom + 2) * 4));
+    // loose slots reuse the tile kernel's loose buffers (+ one more int array)
+    HIPCHECK(ctx->looseEnd.ensure(cap * 4));
+    HIPCHECK(ctx->looseV.ensure(cap * 4));
+    HIPCHECK(ctx->looseC.ensure(cap * 4));
+    HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
+    HIPCHECK(ctx->pairLogE.ensure((size_t)PAIR_LUT * 8));
+    HIPCHECK(ctx->pairCtab.ensure((size_t)PAIR_LUT * sizeof(CtrlEntry)));
     u32* misc = ctx->misc.as<u32>();
     phase_begin(ctx, "merge");
-    HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 1) * 8, s));
-    HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
     RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>()};
     RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>()};
-    Merge2Out mo{pa.end.as<u32>(), pa.expt.as<float>(), pa.ctrl.as<float>(), pa.tileOff.as<u32>(),
-                 pa.chromOff.as<u32>(), misc + M_NMERGED};
-    hipLaunchKernelGGL(k_merge2, dim3(std::min(nTiles, (u32)ctx->resMerge)), dim3(MG_NT), 0, s, A, Bc,
-                       ctx->dScal.as<Scalars>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles,
-                       ctx->lb.as<u64>(), mo, ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_merge2")) return rc__;
+    Merge2Out mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->tileIvCount.as<u32>()};
+    hipLaunchKernelGGL(k_merge2, dim3(std::min(nTiles, (u32)(8 * ctx->numCU))), dim3(MG_NT), 0, s, A, Bc,
+                       ctx->dScal.as<Scalars>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo,
+                       ctx->dStatus.as<u32>());
+    if (int rc__ = dbg_sync(ctx, "k_merge2")) return rc__;
+    const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+    HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));
+    hipLaunchKernelGGL(k_scan_counts, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
+                       ctx->tileIvCount.as<u32>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles,
+                       ctx->lb.as<u64>(), pa.tileOff.as<u32>(), pa.chromOff.as<u32>(), misc + M_NMERGED,
+                       ctx->dStatus.as<u32>());
     hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, pa.chromOff.as<u32>(),
                        misc + M_NMERGED);
-  if (int rc__ = dbg_sync(ctx, "k_fix_chrom_off")) return rc__;
+    if (int rc__ = dbg_sync(ctx, "k_scan_counts")) return rc__;
     phase_end(ctx);
     phase_begin(ctx, "pval");
-    hipLaunchKernelGGL(k_pval_pairs, dim3(4096), dim3(256), 0, s, pa.expt.as<float>(), pa.ctrl.as<float>(),
-                       misc + M_NMERGED, pa.p.as<float>());
-  if (int rc__ = dbg_sync(ctx, "k_pval_pairs")) return rc__;
+    hipLaunchKernelGGL(k_pair_tabs, dim3(PAIR_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(),
+                       ctx->pairLogE.as<double>(), ctx->pairCtab.as<CtrlEntry>());
+    PackPairsIn ppi{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->expt.tileIvOff.as<u32>(),
+                    ctx->ctrl.tileIvOff.as<u32>(), pa.tileOff.as<u32>()};
+    hipLaunchKernelGGL(k_pack_pairs, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, ppi, nTiles,
+                       ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(), ctx->pairCtab.as<CtrlEntry>(),
+                       pa.end.as<u32>(), pa.expt.as<float>(), pa.ctrl.as<float>(), pa.p.as<float>(),
+                       ctx->dStatus.as<u32>());
+    if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(&pa.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));

@@ -27,13 +27,11 @@ struct RleIn {   // run-length pileup from k_tile
   const u32* tileOff;
 };
 
-struct Merge2Out {
+struct Merge2Out {   // loose slots: tile t writes at A.tileOff[t] + B.tileOff[t] (a union is never longer)
   u32* end;
-  float* expt;
-  float* ctrl;
-  u32* tileOff;   // [nTiles+1]
-  u32* chromOff;  // [nChrom+1]
-  u32* n;
+  int* exptV;        // treatment pileup (1/120 units, V_MARK inside -E regions)
+  int* ctrlV;        // control pileup of the covering control interval
+  u32* tileCount;    // [nTiles]
 };
 
 __device__ __forceinline__ float expt_val(int v, bool* neg) {
@@ -47,15 +45,15 @@ __device__ __forceinline__ float ctrl_net(int v, float factor, float lambda, boo
   return val > lambda ? val : lambda;   // MAX(val, lambda)
 }
 
+// No inter-workgroup dependency (like k_tile): counts go to k_scan_counts, packing to k_pack_pairs.
 __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalars* __restrict__ sc,
                                                   const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
-                                                  u32 nTiles, u64* __restrict__ lb,
-                                                  Merge2Out out, u32* __restrict__ st) {
+                                                  u32 nTiles, Merge2Out out, u32* __restrict__ st) {
   __shared__ u32 bmA[MG_WORDS], bmB[MG_WORDS], bmC[MG_WORDS];
   __shared__ u32 scratch[8];
-  __shared__ u32 s_base;
   const float factor = sc->factor, lambda = sc->lambda;
-  for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {  // persistent, round-robin (see lookback_excl)
+  u32 neg = 0;
+  for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {
     __syncthreads();
     for (int i = threadIdx.x; i < MG_WORDS; i += MG_NT) { bmA[i] = 0; bmB[i] = 0; bmC[i] = 0; }
     __syncthreads();
@@ -65,10 +63,10 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
     const u32 tl = t - c.tileBase, pos0 = tl << TB;
     const bool lastTile = tl + 1 == c.nTiles;
     u32 a0 = A.tileOff[t], a1 = A.tileOff[t + 1], b0 = B.tileOff[t], b1 = B.tileOff[t + 1];
+    const u32 slot = a0 + b0;
     if (!active) { a1 = a0; b1 = b0; }
     const u32 a1c = (lastTile && a1 > a0) ? a1 - 1 : a1;  // the chromosome-closing interval is handled apart
     const u32 b1c = (lastTile && b1 > b0) ? b1 - 1 : b1;
-    u32 neg = 0;
     for (u32 i = a0 + threadIdx.x; i < a1c; i += MG_NT) {
       u32 off = A.end[i] - pos0;
       atomicOr(&bmA[off >> 5], 1u << (off & 31));
@@ -99,59 +97,164 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
     u32 exU = block_excl_scan<u32, MG_NT>(cU, scratch, &tU);
     u32 exA = block_excl_scan<u32, MG_NT>(cA, scratch, &tA);
     u32 exC = block_excl_scan<u32, MG_NT>(cC, scratch, &tC);
-    const u32 tileCount = active ? tU + (lastTile ? 1u : 0u) : 0u;
+    if (threadIdx.x == 0) out.tileCount[t] = active ? tU + (lastTile ? 1u : 0u) : 0u;
+    if (active) {  // block-uniform
+      u32 o = slot + exU;
+#pragma unroll
+      for (int k = 0; k < MG_WPT; k++) {
+        u32 bits = wU[k];
+        while (bits) {
+          int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          u32 below = (1u << b) - 1;
+          out.end[o] = pos0 + (threadIdx.x * MG_WPT + k) * 32 + b;
+          out.exptV[o] = A.v[a0 + exA + __popc(wA[k] & below)];
+          out.ctrlV[o] = B.v[b0 + exC + __popc(wC[k] & below)];
+          o++;
+        }
+        exA += __popc(wA[k]);
+        exC += __popc(wC[k]);
+      }
+      if (lastTile && threadIdx.x == 0) {  // 1779-1788 at the chromosome end: both pileups close at len
+        u32 oc = slot + tU;
+        out.end[oc] = c.len;
+        out.exptV[oc] = A.v[a1 - 1];
+        out.ctrlV[oc] = B.v[b1 - 1];
+      }
+    }
+  }
+  if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// counts per tile -> offsets (sum scan), chromosome offsets and the total
+__global__ __launch_bounds__(STL_NT) void k_scan_counts(const u32* __restrict__ tileCount, const u32* __restrict__ tileChrom,
+                                                        const DChrom* __restrict__ chroms, u32 nTiles, u64* __restrict__ lb,
+                                                        u32* __restrict__ tileOff, u32* __restrict__ chromOff,
+                                                        u32* __restrict__ nOut, u32* __restrict__ st) {
+  __shared__ u32 scratch[8];
+  __shared__ u32 s_base;
+  const u32 nChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
+    const u32 tb = id * STL_CHUNK + threadIdx.x * STL_ITEMS;
+    u32 c[STL_ITEMS];
+    u32 cs = 0;
+#pragma unroll
+    for (int k = 0; k < STL_ITEMS; k++) {
+      c[k] = tb + k < nTiles ? tileCount[tb + k] : 0;
+      cs += c[k];
+    }
+    u32 ctot;
+    u32 cex = block_excl_scan<u32, STL_NT>(cs, scratch, &ctot);
     if (threadIdx.x < 64) {
-      u64 excl = lookback_excl(lb, t, (u64)tileCount, st);
+      u64 es = lookback_excl(lb, id, (u64)ctot, st);
       if (threadIdx.x == 0) {
-        s_base = (u32)excl;
-        out.tileOff[t] = (u32)excl;
-        if (tl == 0) out.chromOff[ci] = (u32)excl;
-        if (t == nTiles - 1) {
-          out.tileOff[nTiles] = (u32)(excl + tileCount);
-          *out.n = (u32)(excl + tileCount);
+        s_base = (u32)es;
+        if (id == nChunks - 1) {
+          tileOff[nTiles] = (u32)es + ctot;
+          *nOut = (u32)es + ctot;
         }
       }
     }
     __syncthreads();
-    if (active) {  // block-uniform; kept as a guarded region so no branch ever targets a barrier
-    u32 o = s_base + exU;
+    cex += s_base;
 #pragma unroll
-    for (int k = 0; k < MG_WPT; k++) {
-      u32 bits = wU[k];
-      while (bits) {
-        int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        u32 below = (1u << b) - 1;
-        u32 ia = a0 + exA + __popc(wA[k] & below);
-        u32 ic = b0 + exC + __popc(wC[k] & below);
-        bool ng1, ng2;
-        out.end[o] = pos0 + (threadIdx.x * MG_WPT + k) * 32 + b;
-        out.expt[o] = expt_val(A.v[ia], &ng1);
-        out.ctrl[o] = ctrl_net(B.v[ic], factor, lambda, &ng2);
-        neg |= ng1 | ng2;
-        o++;
+    for (int k = 0; k < STL_ITEMS; k++) {
+      u32 t = tb + k;
+      if (t < nTiles) {
+        tileOff[t] = cex;
+        if (t == chroms[tileChrom[t]].tileBase) chromOff[tileChrom[t]] = cex;
       }
-      exA += __popc(wA[k]);
-      exC += __popc(wC[k]);
+      cex += c[k];
     }
-    if (lastTile && threadIdx.x == 0) {  // 1779-1788 at the chromosome end: both pileups close at len
-      bool ng1, ng2;
-      u32 oc = s_base + tU;
-      out.end[oc] = c.len;
-      out.expt[oc] = expt_val(A.v[a1 - 1], &ng1);
-      out.ctrl[oc] = ctrl_net(B.v[b1 - 1], factor, lambda, &ng2);
-      neg |= ng1 | ng2;
-    }
-    }
-    if (neg) atomicOr(st, ST_NEG_PILE);
+    __syncthreads();
   }
 }
 
-// p-values of (treatment, control) pairs: calcPval (1628-1653), elementwise
-__global__ __launch_bounds__(256) void k_pval_pairs(const float* __restrict__ expt, const float* __restrict__ ctrl,
-                                                    const u32* __restrict__ nPtr, float* __restrict__ p) {
-  const u32 n = *nPtr;
-  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = calc_pval(expt[i], ctrl[i]);
+// p-values of (treatment, control) pairs, calcPval (1628-1653), through two tables indexed by the
+// exact pileups (both take few distinct values): log(treatment value), and for the control its
+// clamped value with the log-normal parameters (1637-1648).  Same double-precision operations
+// as the direct evaluation, so the same bits; pileups beyond the tables are computed directly.
+constexpr u32 PAIR_LUT = 1u << 16;
+struct CtrlEntry { double ml, sl; float net; float pad; };
+
+__global__ __launch_bounds__(256) void k_pair_tabs(const Scalars* __restrict__ sc, double* __restrict__ logE,
+                                                   CtrlEntry* __restrict__ ctab) {
+  const float factor = sc->factor, lambda = sc->lambda;
+  for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PAIR_LUT; v += gridDim.x * 256) {
+    bool ng;
+    float e = getval((int)v, &ng);
+    logE[v] = e > 0.0f ? log((double)e) : 0.0;
+    CtrlEntry c;
+    c.net = ctrl_net((int)v, factor, lambda, &ng);
+    c.ml = 0;
+    c.sl = 1;
+    c.pad = 0;
+    if (c.net > 0.0f) lnorm_params(c.net, &c.ml, &c.sl);
+    ctab[v] = c;
+  }
+}
+
+__device__ __forceinline__ float pval_pair(int ev, int cv, float* exptOut, float* ctrlOut, float factor, float lambda,
+                                           const double* __restrict__ logE, const CtrlEntry* __restrict__ ctab, bool* neg) {
+  bool n1 = false, n2 = false;
+  const float expt = expt_val(ev, &n1);
+  float ctrl;
+  double ml, sl;
+  if ((u32)cv < PAIR_LUT) {
+    CtrlEntry c = ctab[cv];
+    ctrl = c.net; ml = c.ml; sl = c.sl;
+  } else {
+    ctrl = ctrl_net(cv, factor, lambda, &n2);
+    ml = 0; sl = 1;
+    if (ctrl > 0.0f) lnorm_params(ctrl, &ml, &sl);
+  }
+  *neg = n1 | n2;
+  *exptOut = expt;
+  *ctrlOut = ctrl;
+  if (ctrl == GX_SKIPF) return GX_SKIPF;
+  if (ctrl == 0.0f) return expt == 0.0f ? 0.0f : FLT_MAX;
+  if (expt == 0.0f) return 0.0f;
+  const double le = (u32)ev < PAIR_LUT ? logE[ev] : log((double)expt);
+  double pv;
+  if (sl == 0.0)
+    pv = (double)expt < ml ? 0.0 : (double)FLT_MAX;
+  else
+    pv = -pnorm_upper_log((le - ml) / sl) / 2.30258509299404568402;
+  return pv > (double)FLT_MAX ? FLT_MAX : (float)pv;
+}
+
+struct PackPairsIn {
+  const u32* looseEnd;
+  const int* looseE;
+  const int* looseC;
+  const u32* slotA;    // A.tileOff
+  const u32* slotB;    // B.tileOff
+  const u32* tileOff;  // tight offsets
+};
+
+// loose slots -> tight (end, expt, ctrl, p); one wavefront per tile
+__global__ __launch_bounds__(256) void k_pack_pairs(PackPairsIn in, u32 nTiles, const Scalars* __restrict__ sc,
+                                                    const double* __restrict__ logE, const CtrlEntry* __restrict__ ctab,
+                                                    u32* __restrict__ end, float* __restrict__ expt,
+                                                    float* __restrict__ ctrl, float* __restrict__ p,
+                                                    u32* __restrict__ st) {
+  const float factor = sc->factor, lambda = sc->lambda;
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  u32 neg = 0;
+  for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
+    const u32 src = in.slotA[t] + in.slotB[t], dst = in.tileOff[t], n = in.tileOff[t + 1] - dst;
+    for (u32 i = lane; i < n; i += 64) {
+      bool ng;
+      float e, c;
+      float pv = pval_pair(in.looseE[src + i], in.looseC[src + i], &e, &c, factor, lambda, logE, ctab, &ng);
+      neg |= ng;
+      end[dst + i] = in.looseEnd[src + i];
+      expt[dst + i] = e;
+      ctrl[dst + i] = c;
+      p[dst + i] = pv;
+    }
+  }
+  if (neg) atomicOr(st, ST_NEG_PILE);
 }
 
 // ---- Fisher combination over replicates ---------------------------------------------------------
