@@ -853,22 +853,28 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     HIPCHECK(pooled(ctx, comb.tileOff, (size_t)(nTiles + 2) * 4));
     HIPCHECK(pooled(ctx, comb.chromOff, (size_t)(nChrom + 2) * 4));
     phase_begin(ctx, "fisher");
-    HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 1) * 8, s));
-    HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
-    MergeNOut mo{comb.end.as<u32>(), comb.p.as<float>(), comb.tileOff.as<u32>(), comb.chromOff.as<u32>(),
-                 misc + M_NMERGED};
+    HIPCHECK(ctx->looseEnd.ensure(cap * 4));
+    HIPCHECK(ctx->looseV.ensure(cap * 4));
+    HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
+    MergeNOut mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<float>(), ctx->tileIvCount.as<u32>()};
     const size_t lds = (size_t)nr * MG_WORDS * 4;
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
-    int nbN = 0;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbN, k_mergeN, MG_NT, lds));
-    hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(std::max(1, std::min(nbN, 4)) * ctx->numCU))), dim3(MG_NT),
-                       lds, s, S, ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, ctx->lb.as<u64>(), mo,
+    hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(4 * ctx->numCU))), dim3(MG_NT), lds, s, S,
+                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>());
+    if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
+    const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+    HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));
+    hipLaunchKernelGGL(k_scan_counts, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
+                       ctx->tileIvCount.as<u32>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles,
+                       ctx->lb.as<u64>(), comb.tileOff.as<u32>(), comb.chromOff.as<u32>(), misc + M_NMERGED,
                        ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
     hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, comb.chromOff.as<u32>(),
                        misc + M_NMERGED);
-  if (int rc__ = dbg_sync(ctx, "k_fix_chrom_off")) return rc__;
+    hipLaunchKernelGGL(k_pack_ep, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, S,
+                       ctx->looseEnd.as<u32>(), ctx->looseV.as<float>(), comb.tileOff.as<u32>(), nTiles, comb.end.as<u32>(),
+                       comb.p.as<float>());
+    if (int rc__ = dbg_sync(ctx, "k_pack_ep")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(&comb.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));

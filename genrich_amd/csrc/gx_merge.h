@@ -270,21 +270,17 @@ struct RepSet {
   RepIn r[MAX_REPS];
   int n;
 };
-struct MergeNOut {
+struct MergeNOut {   // loose slots: tile t writes at sum_r tileOff_r[t]
   u32* end;
   float* p;
-  u32* tileOff;
-  u32* chromOff;
-  u32* n;
+  u32* tileCount;
 };
 
 __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restrict__ tileChrom,
                                                   const DChrom* __restrict__ chroms, u32 nTiles,
-                                                  u64* __restrict__ lb, MergeNOut out,
-                                                  u32* __restrict__ st) {
+                                                  MergeNOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) u32 bm[];  // S.n bitmaps of MG_WORDS words
   __shared__ u32 scratch[8];
-  __shared__ u32 s_base;
   const int n = S.n;
   for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {  // persistent, round-robin
     __syncthreads();
@@ -325,22 +321,11 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
       u32 tr;
       exR[r] = block_excl_scan<u32, MG_NT>(cr, scratch, &tr);
     }
-    const u32 tileCount = any ? tU + (lastTile ? 1u : 0u) : 0u;
-    if (threadIdx.x < 64) {
-      u64 excl = lookback_excl(lb, t, (u64)tileCount, st);
-      if (threadIdx.x == 0) {
-        s_base = (u32)excl;
-        out.tileOff[t] = (u32)excl;
-        if (tl == 0) out.chromOff[ci] = (u32)excl;
-        if (t == nTiles - 1) {
-          out.tileOff[nTiles] = (u32)(excl + tileCount);
-          *out.n = (u32)(excl + tileCount);
-        }
-      }
-    }
-    __syncthreads();
+    u32 slot = 0;
+    for (int r = 0; r < n; r++) slot += S.r[r].tileOff[t];
+    if (threadIdx.x == 0) out.tileCount[t] = any ? tU + (lastTile ? 1u : 0u) : 0u;
     if (any) {  // block-uniform
-    u32 o = s_base + exU;
+    u32 o = slot + exU;
 #pragma unroll
     for (int k = 0; k < MG_WPT; k++) {
       const int w = threadIdx.x * MG_WPT + k;
@@ -372,10 +357,26 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
         float pv = S.r[r].p[S.r[r].tileOff[t + 1] - 1];
         if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
       }
-      u32 oc = s_base + tU;
+      u32 oc = slot + tU;
       out.end[oc] = c.len;
       out.p[oc] = fisher_combine(sum, df);
     }
+    }
+  }
+}
+
+// loose (end, p) slots of k_mergeN -> tight arrays; one wavefront per tile
+__global__ __launch_bounds__(256) void k_pack_ep(RepSet S, const u32* __restrict__ looseEnd, const float* __restrict__ looseP,
+                                                 const u32* __restrict__ tileOff, u32 nTiles, u32* __restrict__ end,
+                                                 float* __restrict__ p) {
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
+    u32 src = 0;
+    for (int r = 0; r < S.n; r++) src += S.r[r].tileOff[t];
+    const u32 dst = tileOff[t], n = tileOff[t + 1] - dst;
+    for (u32 i = lane; i < n; i += 64) {
+      end[dst + i] = looseEnd[src + i];
+      p[dst + i] = looseP[src + i];
     }
   }
 }
