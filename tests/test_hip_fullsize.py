@@ -1,0 +1,123 @@
+"""GPU, BASELINE.json's full size (hg38, 50 M fragments, configs[1]): size-independent properties
+that need no oracle, plus oracle parity on a mid-size slice (chr19..chrM, ~400 Mbp)."""
+import numpy as np
+import pytest
+
+import backends as B
+import synth
+
+pytestmark = pytest.mark.gpu
+
+LENS = synth.HG38_LENS
+
+
+@pytest.fixture(scope="module")
+def full_run():
+    import genrich_amd
+    ev = synth.make_fragments(LENS, 50_000_000, seed=1)
+    gx = genrich_amd.Genrich(B.make_params(pq=0.01))
+    gx.set_chroms(LENS)
+    gx.sample_begin(0, None)
+    gx.push_events(ev)
+    frag, _, _ = gx.sample_end()
+    lam = gx.sample_no_control()
+    gx.pvalues()
+    gx.find_peaks()
+    return ev, gx, frag, lam
+
+
+def test_fraglen_is_the_sum_of_fragment_lengths(full_run):
+    """Linearity: sum over intervals of len * pileup == sum over fragments of their length (exact
+    for unit weights), and lambda is its float quotient by the genome length (calcLambda 1831)."""
+    ev, gx, frag, lam = full_run
+    want = int((ev["end"].astype(np.int64) - ev["start"].astype(np.int64)).sum())
+    assert frag == float(want)
+    assert gx.genome_len == sum(LENS)
+    assert np.float32(lam) == np.float32(want / sum(LENS))
+
+
+def test_intervals_partition_every_chromosome(full_run):
+    ev, gx, _, _ = full_run
+    total = 0
+    for c in (0, 7, 20, 23, 24):
+        end, cols = gx.get_intervals(-1, c)
+        assert end[-1] == LENS[c]
+        assert np.all(np.diff(end.astype(np.int64)) > 0), "interval ends must be strictly increasing"
+        # run-length property: adjacent intervals never carry the same pileup (2241: break only where the difference != 0)
+        assert np.all(cols["expt"][1:] != cols["expt"][:-1])
+        # number of intervals = distinct positions with a non-zero net difference (+1 closing)
+        sel = ev[ev["chrom"] == c]
+        pos = np.concatenate([sel["start"], sel["end"]]).astype(np.int64)
+        w = np.concatenate([np.ones(len(sel), np.int64), -np.ones(len(sel), np.int64)])
+        order = np.argsort(pos, kind="stable")
+        pos, w = pos[order], w[order]
+        first = np.concatenate([[True], pos[1:] != pos[:-1]])
+        net = np.add.reduceat(w, np.flatnonzero(first))
+        upos = pos[first]
+        nbreak = int(((net != 0) & (upos > 0) & (upos < LENS[c])).sum())
+        assert len(end) == nbreak + 1
+        # pileup checksum: sum(len * cov) on this chromosome == bases covered by its fragments
+        lens_iv = np.diff(np.concatenate([[0], end.astype(np.int64)]))
+        assert int(round(float((lens_iv * cols["expt"].astype(np.float64)).sum()))) == int(
+            (np.minimum(sel["end"], LENS[c]).astype(np.int64) - sel["start"]).sum())
+        total += len(end)
+    assert total > 0
+
+
+def test_peaks_are_ordered_separated_and_above_threshold(full_run):
+    _, gx, _, _ = full_run
+    pk = gx.get_peaks()
+    assert len(pk) > 50_000
+    key = pk["chrom"].astype(np.int64) * (1 << 32) + pk["start"]
+    assert np.all(np.diff(key) > 0), "peaks must be in chromosome-table order, then by position"
+    same = pk["chrom"][1:] == pk["chrom"][:-1]
+    gap = pk["start"][1:].astype(np.int64) - pk["end"][:-1].astype(np.int64)
+    assert np.all(gap[same] > 100), "two peaks closer than maxGap would have been one candidate"
+    assert np.all(pk["auc"] >= 200.0) and np.all(pk["p"] > 2.0)
+    assert np.all(pk["end"] > pk["start"]) and np.all(pk["summit"] < pk["end"] - pk["start"])
+    assert gx.peak_bp == int((pk["end"].astype(np.int64) - pk["start"]).sum())
+
+
+def test_rerun_is_bit_identical(full_run):
+    """Determinism: integer atomics and ordered float sums only -> the same bytes every run."""
+    import genrich_amd
+    ev, gx, frag, lam = full_run
+    first = gx.get_peaks().tobytes()
+    g2 = genrich_amd.Genrich(B.make_params(pq=0.01))
+    g2.set_chroms(LENS)
+    g2.sample_begin(0, None)
+    for part in np.array_split(ev[::-1], 7):  # different order and batching of the same events
+        g2.push_events(part)
+    f2, _, _ = g2.sample_end()
+    l2 = g2.sample_no_control()
+    g2.pvalues()
+    g2.find_peaks()
+    assert (f2, l2) == (frag, lam)
+    assert g2.get_peaks().tobytes() == first
+
+
+def test_midsize_slice_against_oracle():
+    """chr19, chr20, chr21, chr22, chrY, chrM of the same generator (~280 Mbp, 4.5 M fragments):
+    the oracle finishes in seconds; intervals and peaks must agree exactly."""
+    import genrich_amd
+    sub = [LENS[i] for i in (18, 19, 20, 21, 23, 24)]
+    ev = synth.make_fragments(sub, 4_500_000, seed=3)
+    case = dict(lens=sub, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    params = B.make_params(pq=0.01)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = genrich_amd.Genrich(params)
+    sh = B.run_case(h, case)
+    assert so[0][0] == sh[0][0] and np.float32(so[0][1]) == np.float32(sh[0][1])
+    po, ph = o.get_peaks(), h.get_peaks()
+    assert len(po) == len(ph) > 1000
+    for f in ("chrom", "start", "end", "summit"):
+        assert np.array_equal(po[f], ph[f]), f
+    assert np.array_equal(po["auc"].view(np.uint32), ph["auc"].view(np.uint32)), "AUC must be bit-identical"
+    assert np.allclose(po["p"], ph["p"], rtol=1e-5)
+    for c in (0, 5):
+        eo, co = o.get_intervals(-1, c)
+        eh, ch = h.get_intervals(-1, c)
+        assert np.array_equal(eo, eh)
+        assert np.array_equal(co["expt"].view(np.uint32), ch["expt"].view(np.uint32))
+        assert np.all(np.abs(co["p"].astype(np.float64) - ch["p"]) <= 1e-5 * np.maximum(1, co["p"]))
