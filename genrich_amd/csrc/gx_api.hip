@@ -273,7 +273,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   const u32 nEv = (u32)n;
   const u32 nTiles = ctx->nTiles, nSB = ctx->nSB, nChrom = ctx->nChrom;
-  const bool unit32 = nTiles < MAX_TILES32;  // tile id + offset fit a 4-byte key
+  // tile id + offset fit a 4-byte key (GX_FORCE_REC64=1 forces the wide-record path: used by the tests,
+  // since only a genome beyond 4.29 Gbp takes it naturally)
+  static const bool forceWide = getenv("GX_FORCE_REC64") != nullptr;
+  const bool unit32 = nTiles < MAX_TILES32 && !forceWide;
   hipStream_t s = ctx->stream;
   gx_ctx::Stream& SS = ctx->str[0];
   gx_ctx::Stream& SE = ctx->str[1];

@@ -200,3 +200,46 @@ def test_device_getval_all_residues():
     neg = C.c_int(0)
     want = np.array([lib.gxo_getval(int(x), C.byref(neg)) for x in v], dtype=np.float32)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_pileups_beyond_the_lookup_tables():
+    """Towers deeper than the p-value tables (2^18 / 2^16 in 1/120 units = 2184x / 546x): the
+    direct evaluation must give the same bits as the tabulated one."""
+    lens = [60_000, 30_000]
+    base = synth.make_fragments(lens, 6_000, 17, peak_every=10_000, tower_every=40_000)
+    tower = np.array([(0, 20_000 + (i % 7), 20_200 + (i % 11), 1) for i in range(3_000)]
+                     + [(1, 5_000, 5_300, 1)] * 700, dtype=B.EVENT_DTYPE)
+    tr = np.concatenate([base, tower])
+    ct = np.concatenate([synth.make_fragments(lens, 5_000, 18, uniform_only=True),
+                         np.array([(0, 20_050, 20_150, 1)] * 900, dtype=B.EVENT_DTYPE)])
+    for ctrl in (None, ct):
+        case = dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=ctrl)])
+        params = B.make_params(pq=0.05, qval=ctrl is not None, min_auc=20.0)
+        o, h, so, sh = run_both(case, params)
+        assert_same_run(o, h, so, sh, case)
+        e, cols = h.get_intervals(-1, 0)
+        assert cols["expt"].max() > 2500
+
+
+def test_wide_record_path(tmp_path):
+    """Genomes with more tiles than a 4-byte key can address route every event through the
+    8-byte record stream; GX_FORCE_REC64 forces that path on small inputs."""
+    import subprocess
+    import sys
+    import os
+    code = (
+        "import sys; sys.path.insert(0, 'tests'); sys.path.insert(0, '.');\n"
+        "import numpy as np, backends as B, golden_cases as G, genrich_amd\n"
+        "for name in ('ctrl_q', 'multimap', 'bedx'):\n"
+        "    meta, case, params, names = G.load_case(name)\n"
+        "    o = B.Oracle(params); B.run_case(o, case)\n"
+        "    h = genrich_amd.Genrich(params); B.run_case(h, case)\n"
+        "    assert o.get_peaks().tobytes() == h.get_peaks().tobytes(), name\n"
+        "    for c in range(len(case['lens'])):\n"
+        "        eo, co = o.get_intervals(-1, c); eh, ch = h.get_intervals(-1, c)\n"
+        "        assert np.array_equal(eo, eh) and np.array_equal(co['p'].view(np.uint32), ch['p'].view(np.uint32)), name\n"
+        "print('wide ok')\n")
+    env = dict(os.environ, GX_FORCE_REC64="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert res.returncode == 0 and "wide ok" in res.stdout, res.stderr[-2000:]
