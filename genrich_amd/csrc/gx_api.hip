@@ -51,6 +51,7 @@ struct DevBuf {
 struct Pileup {  // run-length pileup of one sample (treatment or control)
   DevBuf ivEnd, ivV, tileIvOff, chromIvOff;
   u32 nIv = 0;
+  bool packed = false;  // ivEnd / ivV filled (otherwise the intervals still sit in the loose slots)
 };
 
 struct PArray {  // p-value intervals of one replicate (or the Fisher combination)
@@ -73,6 +74,8 @@ struct gx_ctx {
   gx_params par{};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;   // small read-backs that must not stall the main stream
+  hipEvent_t sideEv = nullptr;
   std::string err;
   // chromosome table
   std::vector<uint32_t> len;
@@ -98,7 +101,7 @@ struct gx_ctx {
   };
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3], tileCursor[3];
-  DevBuf looseC, pairLogE, pairCtab;
+  DevBuf looseC, pairLogE, pairCtab, fragSum, tileDeep, fragList;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};
@@ -260,6 +263,20 @@ int sort_stream2(gx_ctx* ctx, gx_ctx::Stream& st, int q) {
 }
 
 // events -> tile-bucketed endpoint records -> run-length pileup + exact fragLen accumulators
+// loose slots -> tight (end, V) arrays of a pileup (only needed ahead of a control merge)
+int pack_pileup(gx_ctx* ctx, Pileup& P) {
+  if (P.packed) return GX_OK;
+  hipStream_t s = ctx->stream;
+  const u32 nTiles = ctx->nTiles;
+  HIPCHECK(pooled(ctx, P.ivV, P.ivEnd.cap));
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), P.tileIvOff.as<u32>()};
+  hipLaunchKernelGGL(k_pack, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s, pin, nTiles,
+                     P.ivEnd.as<u32>(), P.ivV.as<int>());
+  if (int rc__ = dbg_sync(ctx, "k_pack")) return rc__;
+  P.packed = true;
+  return GX_OK;
+}
+
 int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // host-pushed events are staged in evBuf; device-resident segments are used in place
   std::vector<gx_ctx::Seg> segs;
@@ -307,7 +324,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // plus one per chromosome
   const size_t ivCap = (size_t)2 * nEv + nChrom + ctx->nBedEdges + 16;
   HIPCHECK(pooled(ctx, out.ivEnd, ivCap * 4));
-  HIPCHECK(pooled(ctx, out.ivV, ivCap * 4));
   HIPCHECK(pooled(ctx, out.tileIvOff, (size_t)(nTiles + 2) * 4));
   HIPCHECK(pooled(ctx, out.chromIvOff, (size_t)(nChrom + 2) * 4));
 
@@ -315,8 +331,18 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(hipMemsetAsync(ctx->tileWsum.p, 0, (size_t)(nTiles + 1) * 4, s));
   HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 64) * 8, s));
   HIPCHECK(hipMemsetAsync(ctx->misc.as<u32>() + M_TICKET, 0, 8, s));  // nF + nIv
+  // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
+  static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
+  HIPCHECK(ctx->fragSum.ensure(sizeof(FragFix)));
+  HIPCHECK(ctx->tileDeep.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(hipMemsetAsync(ctx->fragSum.p, 0, sizeof(FragFix), s));
+  HIPCHECK(hipMemsetAsync(ctx->tileDeep.p, 0, (size_t)(nTiles + 1) * 4, s));
+  FragFix* ff = ctx->fragSum.as<FragFix>();
+  u32* slowFrag = &ff->slow;
+  if (ctx->hasBed || !unit32 || forceSlowFrag) HIPCHECK(hipMemsetAsync(slowFrag, 1, 4, s));
   ConvertOut co{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), ctx->misc.as<u32>() + M_TICKET, SS.sbHist.as<u32>(),
-                SE.sbHist.as<u32>()};
+                SE.sbHist.as<u32>(), ff->fragSum, slowFrag};
   size_t off = 0;
   for (auto& seg : segs) {
     if (!seg.n) continue;
@@ -331,24 +357,26 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   if (int rc__ = dbg_sync(ctx, "k_convert")) return rc__;
   u32 nF = 2 * nEv;
-  if (unit32) {  // how many fractional records were appended (0 for ordinary data)
-    HIPCHECK(hipMemcpyAsync(&nF, ctx->misc.as<u32>() + M_TICKET, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+  if (unit32) {  // how many fractional records were appended (0 for ordinary data): read on the side
+                 // stream while the main stream starts bucketing the unit-weight keys
+    HIPCHECK(hipEventRecord(ctx->sideEv, s));
+    HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->sideEv, 0));
+    HIPCHECK(hipMemcpyAsync(&nF, ctx->misc.as<u32>() + M_TICKET, 4, hipMemcpyDeviceToHost, ctx->side));
   }
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.bucket" : "t.bucket");
-  if (nF) {
-    HIPCHECK(SF.b.ensure((size_t)nF * 8 + 16));
-    hipLaunchKernelGGL((k_hist1<u64>), dim3(std::max(1u, std::min((nF + 255) / 256, 4096u))), dim3(256), 0, s, SF.a.as<u64>(),
-                       nF, ctx->sbShift, nSB, SF.sbHist.as<u32>());
-  }
   if (unit32 && nEv) {
     if (int rc = sort_stream<u32>(ctx, SS, nEv, 0)) return rc;
     if (int rc = sort_stream<u32>(ctx, SE, nEv, 1)) return rc;
   }
-  if (nF)
+  if (unit32) HIPCHECK(hipStreamSynchronize(ctx->side));
+  if (nF) {
+    HIPCHECK(SF.b.ensure((size_t)nF * 8 + 16));
+    hipLaunchKernelGGL((k_hist1<u64>), dim3(std::max(1u, std::min((nF + 255) / 256, 4096u))), dim3(256), 0, s, SF.a.as<u64>(),
+                       nF, ctx->sbShift, nSB, SF.sbHist.as<u32>());
     if (int rc = sort_stream<u64>(ctx, SF, nF, 2)) return rc;
+  }
   TileTabs tt{};
   for (int q = 0; q < 3; q++) {
     tt.cnt[q] = ctx->tileCnt[q].as<u32>();
@@ -374,7 +402,11 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tileLastEnd.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tilePrevEnd.ensure((size_t)(nTiles + 1) * 4));
-  TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>()};
+  Scalars* ds = ctx->dScal.as<Scalars>();
+  long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
+  HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
+  TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(),
+             ctx->tileDeep.as<u32>()};
   const size_t ldsBytes = (size_t)TL_LDS * 4;
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
   HIPCHECK(ctx->tileMeta.ensure((size_t)(nTiles + 1) * sizeof(TileMeta)));
@@ -407,14 +439,26 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
                      ctx->misc.as<u32>() + M_NIV);
   if (int rc__ = dbg_sync(ctx, "k_fix_chrom_off")) return rc__;
-  Scalars* ds = ctx->dScal.as<Scalars>();
-  long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
-  HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
-  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), out.tileIvOff.as<u32>(),
-             ctx->tilePrevEnd.as<u32>()};
-  hipLaunchKernelGGL(k_pack, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, pin, nTiles,
-                     out.ivEnd.as<u32>(), out.ivV.as<int>(), acc, ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_pack")) return rc__;
+  {
+    const u32* lE = ctx->looseEnd.as<u32>();
+    const int* lV = ctx->looseV.as<int>();
+    const TileMeta* tm = ctx->tileMeta.as<TileMeta>();
+    const u32* tOff = out.tileIvOff.as<u32>();
+    const u32* tPrev = ctx->tilePrevEnd.as<u32>();
+    hipLaunchKernelGGL(k_frag_fix1, dim3((nTiles + 255) / 256), dim3(256), 0, s, lE, lV, tm, tOff, tPrev,
+                       ctx->tileDeep.as<u32>(), nTiles, ff, ctx->fragList.as<u32>());
+    hipLaunchKernelGGL(k_frag_fix2, dim3(std::max(1u, std::min((nTiles + 3) / 4, 1024u))), dim3(256), 0, s, lE, lV, tm, tOff,
+                       tPrev, ff, ctx->fragList.as<u32>());
+    hipLaunchKernelGGL(k_frag, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, lE, lV, tm, tOff, tPrev,
+                       nTiles, ff, acc);
+    hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ff, acc);
+  }
+  if (int rc__ = dbg_sync(ctx, "k_frag")) return rc__;
+  out.packed = false;
+  if (isCtrl) {  // a control is always merged against the treatment: tight arrays needed
+    int rc = pack_pileup(ctx, out);
+    if (rc) return rc;
+  }
   phase_end(ctx);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(&out.nIv, ctx->misc.as<u32>() + M_NIV, 4, hipMemcpyDeviceToHost, s));
@@ -483,6 +527,8 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   *out = ctx;
   HIPCHECK(hipSetDevice(ctx->device));
   HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIPCHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  HIPCHECK(hipEventCreateWithFlags(&ctx->sideEv, hipEventDisableTiming));
   HIPCHECK(ctx->misc.ensure(M_WORDS * 4));
   HIPCHECK(ctx->dScal.ensure(sizeof(Scalars)));
   HIPCHECK(ctx->dStatus.ensure(64));
@@ -517,6 +563,8 @@ void gx_destroy(gx_ctx* ctx) {
     (void)hipEventDestroy(ph.b);
   }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->sideEv) (void)hipEventDestroy(ctx->sideEv);
   delete ctx;
 }
 
@@ -671,6 +719,8 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
     ctx->phase = 1;
   } else {
     if (ctx->phase != 2) return GX_ERR_ORDER;
+    int rc = pack_pileup(ctx, ctx->expt);  // the control's tiles are about to reuse the loose slots
+    if (rc) return rc;
     ctx->phase = 3;
   }
   ctx->segs.clear();
@@ -752,11 +802,12 @@ int gx_pvalues(gx_ctx* ctx) {
     phase_begin(ctx, "pval");
     HIPCHECK(ctx->pvLut.ensure((size_t)PV_LUT * 4));
     hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>());
-    hipLaunchKernelGGL(k_pval_const, dim3(std::max(1u, std::min((n + 255) / 256, 8192u))), dim3(256), 0, s,
-                       ctx->expt.ivV.as<int>(), ctx->misc.as<u32>() + M_NIV, ctx->dScal.as<Scalars>(),
-                       ctx->pvLut.as<float>(), pa.p.as<float>(), pa.expt.as<float>(),
-                       ctx->hasBed ? pa.ctrl.as<float>() : (float*)nullptr, ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_pval_const")) return rc__;
+    PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>()};
+    hipLaunchKernelGGL(k_pack_pval, dim3(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s, pin,
+                       ctx->nTiles, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(),
+                       pa.p.as<float>(), pa.expt.as<float>(), ctx->hasBed ? pa.ctrl.as<float>() : (float*)nullptr,
+                       ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     pa.end = std::move(ctx->expt.ivEnd);

@@ -218,6 +218,8 @@ __device__ __forceinline__ u64 make_rec64(u32 tile, u32 off, int w) {
   return ((u64)tile << 32) | ((u64)off << 8) | (u64)(uint8_t)(int8_t)w;
 }
 
+constexpr int FRAG_SLOTS = 64;  // partial sums of the closed form of fragLen (see k_frag)
+
 struct ConvertOut {
   u32* S;       // [n] start keys
   u32* E;       // [n] end keys
@@ -225,6 +227,8 @@ struct ConvertOut {
   u32* nF;      // number of F records (appended in pairs)
   u32* histS;   // level-1 histograms [nSB]
   u32* histE;
+  u64* fragSum; // [FRAG_SLOTS] sum of the clamped lengths of the fragments kept (see k_frag)
+  u32* slowFrag;
 };
 
 template <bool UNIT32>
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
     for (int i = threadIdx.x; i < (int)nSB; i += 256) { hS[i] = 0; hE[i] = 0; }
     __syncthreads();
   }
-  u32 bad = 0;
+  u32 bad = 0, frac = 0;
+  u64 covered = 0;
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     uint4 e = reinterpret_cast<const uint4*>(ev)[i];  // chrom, start, end, count
     int w = 0;
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
         else {
           u32 end = e.z > c.len ? c.len : e.z;
           if (end > e.y) {  // an empty interval adds and removes the same weight
+            covered += end - e.y;
             t0 = c.tileBase + (e.y >> TB);
             o0 = e.y & (TILE - 1);
             if (end < c.len) {
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
       atomicAdd(&hE[ke == NULL32 ? nSB - 1 : t1 >> sbShift], 1u);
     }
     if (!unit && t0 != NULL_TILE) {
+      frac = 1;
       u32 pos = UNIT32 ? atomicAdd(out.nF, 2u) : 2 * (evBase + i);
       out.F[pos] = make_rec64(t0, o0, w);
       out.F[pos + 1] = t1 != NULL_TILE ? make_rec64(t1, o1, -w) : (u64)NULL_TILE << 32;
@@ -298,6 +305,9 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
     }
   }
   if (bad) atomicOr(st, bad);
+  if (frac) atomicOr(out.slowFrag, 1u);
+  covered = wave_sum(covered);
+  if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 4 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
 }
 
 // level-1 histogram of an already materialised stream (the F records)
@@ -571,6 +581,7 @@ constexpr int TL_NT = 256;
 constexpr int TL_NW = TL_NT / 64;
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
 constexpr int TL_LDS = TILE + 64 + 2 * (TILE / 32); // ints: slice, scan scratch, occupancy + -E edge bitmaps
+constexpr int FRAG_FAST_MAXV = ((1 << 24) / (2 * TILE)) * GX_UNIT;  // len < 2 TILE and V below this: len * val < 2^24
 constexpr int V_MARK = (int)0x80000000;           // "pileup" of an interval inside an excluded (-E) region
 
 // -E support (Genrich.c:2185-2263): bed edges are breakpoints whatever the difference array
@@ -588,7 +599,23 @@ struct TileOut {
   int* looseV;      // pileup in 1/120 units
   u32* tileCount;   // [nTiles] intervals written by each tile
   u32* tileLastEnd; // [nTiles] end of the tile's last interval (valid when tileCount > 0)
+  u32* tileDeep;    // [nTiles] pre-zeroed; set when a pileup of the tile reaches FRAG_FAST_MAXV (see k_frag)
 };
+
+// savePileupExpt 2246/2271, calcFactor 2018/2038: `fragLen += (j - start) * val` is a float
+// product added into a double.  Every product is a multiple of 2^-27 (val >= 1/10 when
+// non-zero), so the sum is accumulated exactly in two int64 (integer part, fraction * 2^27):
+// deterministic for any launch geometry or rank count, and equal to the reference's double
+// sum whenever that sum is exact (always, for unit weights).
+__device__ __forceinline__ void frag_term(u32 len, int v, long long& hi, long long& lo) {
+  if (v != 0 && v != V_MARK) {
+    bool ng;
+    const float term = (float)len * getval(v, &ng);
+    const float fl = floorf(term);
+    hi += (long long)fl;
+    lo += (long long)((term - fl) * 134217728.0f);
+  }
+}
 
 // everything k_tile needs to know about a tile in one 48-byte record, so the persistent loop can
 // prefetch the next tile's descriptor without a dependent-load chain (tileChrom -> chroms -> prefW)
@@ -755,6 +782,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     const u32 o0 = slot + preC + (incC - cnt);
     const u32 totFinal = active ? totC + (lastTile ? 1u : 0u) : 0u;
     u32 o = o0, neg = 0, lastEnd = 0;
+    u32 big = threadIdx.x == 0 && carry >= FRAG_FAST_MAXV;
     save = save0;
     for (u32 m = ow | ew; m; m &= m - 1) {
       const int k = __builtin_ctz(m);
@@ -770,6 +798,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
       if (edge) save = !save;
       run += d;
       neg |= (u32)(run < 0);
+      big |= (u32)(run >= FRAG_FAST_MAXV);
       if (d != 0) delta[lbase + k] = 0;
     }
     if (active) {  // block-uniform
@@ -781,6 +810,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
       }
       if (o != o0 && o == slot + totFinal) out.tileLastEnd[t] = lastEnd;  // wrote the tile's last interval
       bad |= (neg ? ST_NEG_PILE : 0) | (sat ? ST_SAT16 : 0);
+      if (big) atomicOr(&out.tileDeep[t], 1u);  // rare
     }
     if (threadIdx.x == 0) out.tileCount[t] = totFinal;
     __syncthreads();  // scr, occ and the slice are reused by the next tile
@@ -919,52 +949,106 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
   }
 }
 
-// loose slots -> tight arrays, and fragLen on the way.
-// savePileupExpt 2246/2271, calcFactor 2018/2038: `fragLen += (j - start) * val` is a float
-// product added into a double.  Every product is a multiple of 2^-27 (val >= 1/10 when
-// non-zero), so the sum is accumulated exactly in two int64 (integer part, fraction * 2^27):
-// deterministic for any launch geometry or rank count, and equal to the reference's double
-// sum whenever that sum is exact (always, for unit weights).
-struct PackIn {
-  const u32* looseEnd;
-  const int* looseV;
-  const TileMeta* meta;    // .slot = first loose slot of the tile
-  const u32* tileIvOff;
-  const u32* tilePrevEnd;
+// fragLen.  savePileupExpt adds (float)len * val per interval into a double.  With unit weights
+// only (no fractional records, no -E regions) val is an integer, and a product below 2^24 is
+// exact, so the sum over such intervals is the number of covered (base, fragment) pairs: the sum
+// of the clamped fragment lengths, which k_convert accumulates for free ("closed form").  Only
+// intervals with len * val >= 2^24 can round, and they are easy to find:
+//   * val >= 2^24 / (2 TILE): k_tile marks the tiles in which the pileup gets that deep;
+//   * otherwise len >= 2 TILE: the interval starts before its tile does, so it is the tile's first.
+// k_frag_fix1 looks at every tile's first interval and lists the deep tiles, k_frag_fix2 walks
+// the listed tiles; both add (rounded product - exact product), an integer, to a correction.
+// Everything else (fractional weights, -E, wide records) takes the general path k_frag, which
+// walks every interval and accumulates exactly in (integer, fraction * 2^27) form.
+struct FragFix {
+  u64 fragSum[FRAG_SLOTS];  // closed form partial sums
+  u32 slow;                 // general path wanted
+  u32 nList;
+  long long corr;
 };
 
-__global__ __launch_bounds__(256) void k_pack(PackIn in, u32 nTiles, u32* __restrict__ ivEnd, int* __restrict__ ivV,
-                                              long long* __restrict__ acc, u32* __restrict__ st) {
-  long long hi = 0, lo = 0;
-  u32 neg = 0;
+__device__ __forceinline__ long long frag_corr(u32 len, int v) {
+  if (v <= 0) return 0;  // V_MARK never occurs on this path
+  const u32 cnt = (u32)v / GX_UNIT;
+  const float term = (float)len * (float)cnt;  // what getval returns for a whole pileup
+  return (long long)term - (long long)((u64)len * cnt);
+}
+
+__global__ __launch_bounds__(256) void k_frag_fix1(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
+                                                   const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
+                                                   const u32* __restrict__ tilePrevEnd, const u32* __restrict__ tileDeep,
+                                                   u32 nTiles, FragFix* __restrict__ ff, u32* __restrict__ list) {
+  if (ff->slow) return;
+  long long c = 0;
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t < nTiles && tileIvOff[t + 1] != tileIvOff[t]) {
+    if (tileDeep[t])
+      list[atomicAdd(&ff->nList, 1u)] = t;
+    else {
+      const u32 slot = meta[t].slot;
+      const u32 len = looseEnd[slot] - tilePrevEnd[t];
+      if (len >= 2 * TILE) c = frag_corr(len, looseV[slot]);
+    }
+  }
+  if (__ballot(c != 0)) {
+    c = wave_sum(c);
+    if (lane_id() == 0) atomicAdd((u64*)&ff->corr, (u64)c);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_frag_fix2(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
+                                                   const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
+                                                   const u32* __restrict__ tilePrevEnd, FragFix* __restrict__ ff,
+                                                   const u32* __restrict__ list) {
+  if (ff->slow) return;
+  const u32 nList = ff->nList;
+  long long c = 0;
   const int wv = threadIdx.x >> 6, lane = lane_id();
-  // one wavefront per tile (a tile holds a few hundred intervals)
-  for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
-    const u32 src = in.meta[t].slot, dst = in.tileIvOff[t],
-              n = in.tileIvOff[t + 1] - dst;
-    u32 prevEnd = in.tilePrevEnd[t];
+  for (u32 li = blockIdx.x * 4 + wv; li < nList; li += gridDim.x * 4) {
+    const u32 t = list[li];
+    const u32 src = meta[t].slot, n = tileIvOff[t + 1] - tileIvOff[t];
+    u32 prevEnd = tilePrevEnd[t];
     for (u32 b = 0; b < n; b += 64) {
-      u32 i = b + lane;
+      const u32 i = b + lane;
       u32 e = 0;
       int v = 0;
       if (i < n) {
-        e = in.looseEnd[src + i];
-        v = in.looseV[src + i];
-        ivEnd[dst + i] = e;
-        ivV[dst + i] = v;
+        e = looseEnd[src + i];
+        v = looseV[src + i];
       }
       u32 s = __shfl_up(e, 1, 64);
       if (lane == 0) s = prevEnd;
       prevEnd = __shfl(e, 63, 64);
-      if (i < n && v != 0 && v != V_MARK) {
-        bool ng;
-        float val = getval(v, &ng);
-        neg |= ng;
-        float term = (float)(e - s) * val;
-        float fl = floorf(term);
-        hi += (long long)fl;
-        lo += (long long)((term - fl) * 134217728.0f);
+      if (i < n) c += frag_corr(e - s, v);
+    }
+  }
+  c = wave_sum(c);
+  if (lane == 0 && c) atomicAdd((u64*)&ff->corr, (u64)c);
+}
+
+// general path: one wavefront per tile walks the tile's loose slots (read only)
+__global__ __launch_bounds__(256) void k_frag(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
+                                              const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
+                                              const u32* __restrict__ tilePrevEnd, u32 nTiles,
+                                              const FragFix* __restrict__ ff, long long* __restrict__ acc) {
+  if (ff->slow == 0) return;
+  long long hi = 0, lo = 0;
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
+    const u32 src = meta[t].slot, n = tileIvOff[t + 1] - tileIvOff[t];
+    u32 prevEnd = tilePrevEnd[t];
+    for (u32 b = 0; b < n; b += 64) {
+      const u32 i = b + lane;
+      u32 e = 0;
+      int v = 0;
+      if (i < n) {
+        e = looseEnd[src + i];
+        v = looseV[src + i];
       }
+      u32 s = __shfl_up(e, 1, 64);
+      if (lane == 0) s = prevEnd;
+      prevEnd = __shfl(e, 63, 64);
+      if (i < n) frag_term(e - s, v, hi, lo);
     }
   }
   hi = wave_sum(hi);
@@ -973,7 +1057,58 @@ __global__ __launch_bounds__(256) void k_pack(PackIn in, u32 nTiles, u32* __rest
     if (hi) atomicAdd((u64*)&acc[0], (u64)hi);
     if (lo) atomicAdd((u64*)&acc[1], (u64)lo);
   }
-  if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// loose slots -> tight arrays (needed when a control pileup is merged against this one)
+struct PackIn {
+  const u32* looseEnd;
+  const int* looseV;
+  const TileMeta* meta;    // .slot = first loose slot of the tile
+  const u32* tileIvOff;
+};
+
+__global__ __launch_bounds__(256) void k_pack(PackIn in, u32 nTiles, u32* __restrict__ ivEnd, int* __restrict__ ivV) {
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  // one wavefront per tile (a tile holds a few hundred intervals); four independent pairs of
+  // loads per lane and the next tile's header in flight: the shape is latency-bound
+  const u32 stride = gridDim.x * 4;
+  u32 t = blockIdx.x * 4 + wv;
+  u32 src1 = 0, dst1 = 0, n1 = 0;
+  if (t < nTiles) {
+    src1 = in.meta[t].slot;
+    dst1 = in.tileIvOff[t];
+    n1 = in.tileIvOff[t + 1] - dst1;
+  }
+  for (; t < nTiles; t += stride) {
+    const u32 src = src1, dst = dst1, n = n1;
+    if (t + stride < nTiles) {
+      src1 = in.meta[t + stride].slot;
+      dst1 = in.tileIvOff[t + stride];
+      n1 = in.tileIvOff[t + stride + 1] - dst1;
+    }
+    for (u32 b = 0; b < n; b += 256) {
+      u32 e[4];
+      int v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 i = b + k * 64 + lane;
+        e[k] = 0;
+        v[k] = 0;
+        if (i < n) {
+          e[k] = in.looseEnd[src + i];
+          v[k] = in.looseV[src + i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 i = b + k * 64 + lane;
+        if (i < n) {
+          ivEnd[dst + i] = e[k];
+          ivV[dst + i] = v[k];
+        }
+      }
+    }
+  }
 }
 
 // chromosome table epilogue: chromIvOff for chromosomes without tiles (inactive ones get an
@@ -1001,6 +1136,15 @@ struct Scalars {
   float factor;
   u64 genomeLen;
 };
+
+// closed form or general path -> the (integer, fraction * 2^27) accumulator pair
+__global__ void k_frag_select(const FragFix* __restrict__ ff, long long* __restrict__ acc) {
+  if (threadIdx.x || blockIdx.x || ff->slow) return;
+  u64 t = 0;
+  for (int i = 0; i < FRAG_SLOTS; i++) t += ff->fragSum[i];
+  acc[0] = (long long)t + ff->corr;
+  acc[1] = 0;
+}
 
 __global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st) {
   if (threadIdx.x || blockIdx.x) return;

@@ -32,31 +32,78 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
   }
 }
 
-__global__ __launch_bounds__(256) void k_pval_const(const int* __restrict__ ivV, const u32* __restrict__ nIvPtr,
-                                                    const Scalars* __restrict__ sc, const float* __restrict__ lutP,
-                                                    float* __restrict__ pOut, float* __restrict__ exptOut,
-                                                    float* __restrict__ ctrlOut, u32* __restrict__ st) {
-  const u32 n = *nIvPtr;
+// p-values against a constant control (no control sample), straight from the tile kernel's
+// loose slots: one wavefront per tile moves the tile's intervals to their tight position and
+// scores them on the way, so the packed (end, V) pair never makes a round trip through HBM.
+// Latency, not bandwidth, bounds this shape (a few hundred intervals per tile): every lane keeps
+// PP_UNROLL independent (end, V) loads in flight, the next tile's header is fetched while the
+// current one is processed, and the hot head of the p-value table lives in LDS (a 64-lane gather
+// from L1 costs one cache line per lane).
+constexpr int PP_UNROLL = 4;
+constexpr int PP_LUT = 4096;  // V < 4096: pileups below 34
+
+__global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const Scalars* __restrict__ sc,
+                                                   const float* __restrict__ lutP, u32* __restrict__ ivEnd,
+                                                   float* __restrict__ pOut, float* __restrict__ exptOut,
+                                                   float* __restrict__ ctrlOut, u32* __restrict__ st) {
+  __shared__ float hot[PP_LUT];
+  for (int i = threadIdx.x; i < PP_LUT; i += 256) hot[i] = lutP[i];
+  __syncthreads();
   const float lambda = sc->lambda;
   double ml = 0, sl = 1;
   if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
   u32 neg = 0;
-  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int v = ivV[i];
-    bool ng = false;
-    float val, p;
-    if (v == V_MARK) {  // inside an excluded region: treatment 0.0f (2248), control SKIP (1871) -> p SKIP (1629)
-      val = 0.0f;
-      p = GX_SKIPF;
-    } else if ((u32)v < PV_LUT) {
-      val = getval(v, &ng);
-      p = lutP[v];
-    } else
-      p = pval_of_v(v, lambda, ml, sl, &val, &ng);
-    neg |= ng;
-    pOut[i] = p;
-    if (exptOut) exptOut[i] = val;
-    if (ctrlOut) ctrlOut[i] = v == V_MARK ? GX_SKIPF : lambda;
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const u32 stride = gridDim.x * 4;
+  u32 t = blockIdx.x * 4 + wv;
+  u32 src1 = 0, dst1 = 0, n1 = 0;
+  if (t < nTiles) {
+    src1 = in.meta[t].slot;
+    dst1 = in.tileIvOff[t];
+    n1 = in.tileIvOff[t + 1] - dst1;
+  }
+  for (; t < nTiles; t += stride) {
+    const u32 src = src1, dst = dst1, n = n1;
+    if (t + stride < nTiles) {
+      src1 = in.meta[t + stride].slot;
+      dst1 = in.tileIvOff[t + stride];
+      n1 = in.tileIvOff[t + stride + 1] - dst1;
+    }
+    for (u32 b = 0; b < n; b += 64 * PP_UNROLL) {
+      u32 e[PP_UNROLL];
+      int v[PP_UNROLL];
+#pragma unroll
+      for (int k = 0; k < PP_UNROLL; k++) {
+        const u32 i = b + k * 64 + lane;
+        e[k] = 0;
+        v[k] = 0;
+        if (i < n) {
+          e[k] = in.looseEnd[src + i];
+          v[k] = in.looseV[src + i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PP_UNROLL; k++) {
+        const u32 i = b + k * 64 + lane;
+        if (i < n) {
+          bool ng = false;
+          float val, p;
+          if (v[k] == V_MARK) {  // inside an excluded region: treatment 0.0f (2248), control SKIP (1871) -> p SKIP (1629)
+            val = 0.0f;
+            p = GX_SKIPF;
+          } else if ((u32)v[k] < PV_LUT) {
+            val = getval(v[k], &ng);
+            p = (u32)v[k] < PP_LUT ? hot[v[k]] : lutP[v[k]];
+          } else
+            p = pval_of_v(v[k], lambda, ml, sl, &val, &ng);
+          neg |= ng;
+          ivEnd[dst + i] = e[k];
+          pOut[dst + i] = p;
+          exptOut[dst + i] = val;
+          if (ctrlOut) ctrlOut[dst + i] = v[k] == V_MARK ? GX_SKIPF : lambda;
+        }
+      }
+    }
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
 }

@@ -243,3 +243,42 @@ def test_wide_record_path(tmp_path):
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert res.returncode == 0 and "wide ok" in res.stdout, res.stderr[-2000:]
+
+
+def test_fraglen_closed_form_guards():
+    """fragLen is normally the closed form (sum of fragment lengths, k_convert) plus a correction
+    for the few intervals whose float product len * val rounds: covered stretches longer than two
+    tiles (3 x 6,000,001 = 18,000,003 is not a float) and deep pileups (20,001 x 999)."""
+    lens = [300_000, 9_000_000]
+    long3 = np.array([(1, 1_000_000, 7_000_001, 1)] * 3, dtype=B.EVENT_DTYPE)  # nothing else on chrom 1
+    bg = synth.make_fragments(lens[:1], 4000, seed=3)
+    deep = np.array([(0, 100_000, 100_150, 1)] * 1500 + [(1, 8_000_000, 8_000_999, 1)] * 20_001, dtype=B.EVENT_DTYPE)
+    for extra in (long3, deep, np.concatenate([long3, deep])):
+        tr = np.concatenate([bg, extra])
+        case = dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=bg)])
+        o, h, so, sh = run_both(case, B.make_params(pq=0.01, min_auc=20.0))
+        assert_same_run(o, h, so, sh, case)
+        closed = float((tr["end"].astype(np.int64) - tr["start"]).sum())
+        assert so[0][0] != closed  # the correction, not luck: the reference's rounded sum is not the closed form
+
+
+def test_fraglen_general_path_on_unit_data():
+    """GX_FORCE_SLOWFRAG routes ordinary unit-weight data through the per-interval walk: same
+    fragLen / lambda / peaks as the oracle (and hence as the closed form)."""
+    import subprocess
+    import sys
+    import os
+    code = (
+        "import sys; sys.path.insert(0, 'tests'); sys.path.insert(0, '.');\n"
+        "import numpy as np, backends as B, golden_cases as G, genrich_amd\n"
+        "for name in ('basic', 'ctrl_q', 'atac'):\n"
+        "    meta, case, params, names = G.load_case(name)\n"
+        "    o = B.Oracle(params); so = B.run_case(o, case)\n"
+        "    h = genrich_amd.Genrich(params); sh = B.run_case(h, case)\n"
+        "    assert [x[0] for x in so] == [x[0] for x in sh], (name, so, sh)\n"
+        "    assert o.get_peaks().tobytes() == h.get_peaks().tobytes(), name\n"
+        "print('slow ok')\n")
+    env = dict(os.environ, GX_FORCE_SLOWFRAG="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert res.returncode == 0 and "slow ok" in res.stdout, res.stderr[-2000:]
