@@ -26,16 +26,23 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), own(o.own) { o.p = nullptr; o.cap = 0; o.own = true; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+    if (this != &o) { release(); p = o.p; cap = o.cap; own = o.own; o.p = nullptr; o.cap = 0; o.own = true; }
     return *this;
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && own) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    own = true;
+  }
+  void view(void* ptr, size_t bytes) {  // non-owning window into another allocation
+    release();
+    p = ptr;
+    cap = bytes;
+    own = false;
   }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
@@ -46,6 +53,7 @@ struct DevBuf {
     return e;
   }
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+  bool own = true;
 };
 
 struct Pileup {  // run-length pileup of one sample (treatment or control)
@@ -74,6 +82,8 @@ struct gx_ctx {
   gx_params par{};
   int device = 0;
   hipStream_t stream = nullptr;
+  int maskIdx = -1;             // reps[] entry whose sig / skip masks sit in swMask (k_pack_pval)
+  u32 maskN = 0;
   hipStream_t side = nullptr;   // small read-backs that must not stall the main stream
   hipEvent_t sideEv = nullptr;
   std::string err;
@@ -101,7 +111,7 @@ struct gx_ctx {
   };
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3], tileCursor[3];
-  DevBuf looseC, pairLogE, pairCtab, fragSum, tileDeep, fragList;
+  DevBuf looseC, pairLogE, pairCtab, fragSum, tileDeep, fragList, zeroArena;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};
@@ -111,7 +121,7 @@ struct gx_ctx {
   DevBuf pvLut;
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp;
   // sweep
-  DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos;
+  DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
   std::vector<gx_peak> hPeaks;
   uint64_t genomeLenUsed = 0, peakBP = 0;
   // collectives
@@ -158,9 +168,10 @@ void recycle(gx_ctx* ctx, DevBuf& b) {
 }
 
 // misc device words (u32 indices into ctx->misc)
-enum { M_TICKET = 0, M_NIV = 1, M_TICKET2 = 2, M_SWCOUNT = 3, M_NPEAKS = 4, M_BHCOUNT = 5, M_ALLONE = 6,
-       M_PEAKBP = 8 /* u64 */, M_GENOME = 10 /* u64 */, M_TICKET3 = 12, M_TICKET4 = 13, M_NHEADS = 14,
-       M_NMERGED = 15, M_WORDS = 32 };
+enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_GENOME = 10 /* u64 */, M_NMERGED = 15,
+       // the sweep's counters are contiguous: one memset clears them
+       M_TICKET2 = 16, M_SWCOUNT = 17, M_NPEAKS = 18, M_TICKET3 = 19, M_TICKET4 = 20, M_NHEADS = 21, M_PEAKBP = 22 /* u64 */,
+       M_SWEEP_FIRST = 16, M_SWEEP_WORDS = 8, M_WORDS = 32 };
 
 // GX_DEBUG=1: synchronise after every launch and say which kernel it was (hang / fault triage)
 int dbg_sync(gx_ctx* ctx, const char* what) {
@@ -247,19 +258,14 @@ int sort_stream(gx_ctx* ctx, gx_ctx::Stream& st, u32 nRec, int q) {
   const u32 chunks1 = (nRec + CHUNK - 1) / CHUNK;
   hipLaunchKernelGGL((k_scatter<1, R>), dim3(chunks1), dim3(SC_NT), 0, s, st.a.as<R>(), st.b.as<R>(),
                      st.sbOff.as<u32>() + nSB /* total */, (const u32*)nullptr, 0u, ctx->sbShift, nSB, st.sbCursor.as<u32>());
-  st.chunks2 = chunks1 + nSB;  // upper bound on sum of ceil(count / CHUNK)
-  hipLaunchKernelGGL((k_hist2<R>), dim3(st.chunks2), dim3(SC_NT), 0, s, st.b.as<R>(), st.sbOff.as<u32>(),
-                     st.sbChunkOff.as<u32>(), nSB - 1, ctx->sbShift, ctx->tileCnt[q].as<u32>(), ctx->tileWsum.as<int>());
-  (void)nTiles;
-  return dbg_sync(ctx, "sort_stream level 1");
-}
-
-template <typename R>
-int sort_stream2(gx_ctx* ctx, gx_ctx::Stream& st, int q) {
-  hipLaunchKernelGGL((k_scatter<2, R>), dim3(st.chunks2), dim3(SC_NT), 0, ctx->stream, st.b.as<R>(), st.a.as<R>(),
-                     st.sbOff.as<u32>(), st.sbChunkOff.as<u32>(), ctx->nSB - 1, ctx->sbShift, ctx->nSB,
-                     ctx->tileCursor[q].as<u32>());
-  return dbg_sync(ctx, "sort_stream level 2");
+  // level 2: one workgroup per super-bucket (the last level-1 bin holds the records without a tile)
+  const size_t lds2 = b2_lds_bytes<R>(1u << ctx->sbShift);
+  if (lds2 > 64 * 1024)
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds2));
+  hipLaunchKernelGGL((k_bucket2<R>), dim3(std::max(1u, nSB - 1)), dim3(B2_NT), lds2, s, st.b.as<R>(), st.a.as<R>(),
+                     st.sbOff.as<u32>(), nSB - 1, ctx->sbShift, nTiles, ctx->tileCnt[q].as<u32>(), ctx->tileWsum.as<int>());
+  return dbg_sync(ctx, "sort_stream");
 }
 
 // events -> tile-bucketed endpoint records -> run-length pileup + exact fragLen accumulators
@@ -305,19 +311,31 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     HIPCHECK(SE.b.ensure((size_t)nEv * 4 + 16));
   }
   HIPCHECK(SF.a.ensure((size_t)nEv * 16 + 16));  // worst case: every event fractional
+  // everything that must start at zero lives in one arena: one memset per sample instead of eleven
+  {
+    const size_t tileBytes = ((size_t)(nTiles + 1) * 4 + 255) & ~(size_t)255;
+    const size_t histBytes = MAX_BINS * 4;
+    const size_t ffBytes = (sizeof(FragFix) + 255) & ~(size_t)255;
+    const size_t total = ffBytes + 3 * histBytes + 5 * tileBytes;
+    HIPCHECK(ctx->zeroArena.ensure(total));
+    char* base = ctx->zeroArena.as<char>();
+    ctx->fragSum.view(base, ffBytes);
+    base += ffBytes;
+    for (int q = 0; q < 3; q++, base += histBytes) ctx->str[q].sbHist.view(base, histBytes);
+    for (int q = 0; q < 3; q++, base += tileBytes) ctx->tileCnt[q].view(base, tileBytes);
+    ctx->tileWsum.view(base, tileBytes);
+    base += tileBytes;
+    ctx->tileDeep.view(base, tileBytes);
+    HIPCHECK(hipMemsetAsync(ctx->zeroArena.p, 0, total, s));
+  }
   for (int q = 0; q < 3; q++) {
     gx_ctx::Stream& st = ctx->str[q];
-    HIPCHECK(st.sbHist.ensure(MAX_BINS * 4));
     HIPCHECK(st.sbOff.ensure((MAX_BINS + 2) * 4));
     HIPCHECK(st.sbCursor.ensure((MAX_BINS + 2) * 4));
     HIPCHECK(st.sbChunkOff.ensure((MAX_BINS + 2) * 4));
-    HIPCHECK(ctx->tileCnt[q].ensure((size_t)(nTiles + 1) * 4));
     HIPCHECK(ctx->tileOff[q].ensure((size_t)(nTiles + 2) * 4));
     HIPCHECK(ctx->tileCursor[q].ensure((size_t)(nTiles + 1) * 4));
-    HIPCHECK(hipMemsetAsync(st.sbHist.p, 0, MAX_BINS * 4, s));
-    HIPCHECK(hipMemsetAsync(ctx->tileCnt[q].p, 0, (size_t)(nTiles + 1) * 4, s));
   }
-  HIPCHECK(ctx->tileWsum.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 64) * 8));
   // an interval closes at every base with a non-zero difference (<= one per record), at every -E edge,
@@ -328,20 +346,15 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(pooled(ctx, out.chromIvOff, (size_t)(nChrom + 2) * 4));
 
   phase_begin(ctx, isCtrl ? "c.convert" : "t.convert");
-  HIPCHECK(hipMemsetAsync(ctx->tileWsum.p, 0, (size_t)(nTiles + 1) * 4, s));
-  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(nTiles + 64) * 8, s));
-  HIPCHECK(hipMemsetAsync(ctx->misc.as<u32>() + M_TICKET, 0, 8, s));  // nF + nIv
+  const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)3 * (tChunks + 2) * 8, s));  // k_scan_tiles' three look-back arrays
   // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
   static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
-  HIPCHECK(ctx->fragSum.ensure(sizeof(FragFix)));
-  HIPCHECK(ctx->tileDeep.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
-  HIPCHECK(hipMemsetAsync(ctx->fragSum.p, 0, sizeof(FragFix), s));
-  HIPCHECK(hipMemsetAsync(ctx->tileDeep.p, 0, (size_t)(nTiles + 1) * 4, s));
   FragFix* ff = ctx->fragSum.as<FragFix>();
   u32* slowFrag = &ff->slow;
   if (ctx->hasBed || !unit32 || forceSlowFrag) HIPCHECK(hipMemsetAsync(slowFrag, 1, 4, s));
-  ConvertOut co{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), ctx->misc.as<u32>() + M_TICKET, SS.sbHist.as<u32>(),
+  ConvertOut co{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), &ff->nF, SS.sbHist.as<u32>(),
                 SE.sbHist.as<u32>(), ff->fragSum, slowFrag};
   size_t off = 0;
   for (auto& seg : segs) {
@@ -361,7 +374,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
                  // stream while the main stream starts bucketing the unit-weight keys
     HIPCHECK(hipEventRecord(ctx->sideEv, s));
     HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->sideEv, 0));
-    HIPCHECK(hipMemcpyAsync(&nF, ctx->misc.as<u32>() + M_TICKET, 4, hipMemcpyDeviceToHost, ctx->side));
+    HIPCHECK(hipMemcpyAsync(&nF, &ff->nF, 4, hipMemcpyDeviceToHost, ctx->side));
   }
   phase_end(ctx);
 
@@ -385,17 +398,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   tt.wsumF = ctx->tileWsum.as<int>();
   tt.prefW = ctx->tileCarry.as<int>();
-  const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
   hipLaunchKernelGGL(k_scan_tiles, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s, tt, nTiles,
                      ctx->lb.as<u64>(), ctx->lb.as<u64>() + tChunks + 2, ctx->lb.as<u64>() + 2 * (tChunks + 2),
                      ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_scan_tiles")) return rc__;
-  if (unit32 && nEv) {
-    if (int rc = sort_stream2<u32>(ctx, SS, 0)) return rc;
-    if (int rc = sort_stream2<u32>(ctx, SE, 1)) return rc;
-  }
-  if (nF)
-    if (int rc = sort_stream2<u64>(ctx, SF, 2)) return rc;
   const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
   HIPCHECK(ctx->looseEnd.ensure(looseCap * 4));
   HIPCHECK(ctx->looseV.ensure(looseCap * 4));
@@ -403,8 +409,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(ctx->tileLastEnd.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tilePrevEnd.ensure((size_t)(nTiles + 1) * 4));
   Scalars* ds = ctx->dScal.as<Scalars>();
-  long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
-  HIPCHECK(hipMemsetAsync(acc, 0, 16, s));
+  long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;  // zero since gx_sample_begin(treatment)
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(),
              ctx->tileDeep.as<u32>()};
   const size_t ldsBytes = (size_t)TL_LDS * 4;
@@ -445,8 +450,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     const TileMeta* tm = ctx->tileMeta.as<TileMeta>();
     const u32* tOff = out.tileIvOff.as<u32>();
     const u32* tPrev = ctx->tilePrevEnd.as<u32>();
+    hipLaunchKernelGGL(k_deep_list, dim3((nTiles + 255) / 256), dim3(256), 0, s, ctx->tileDeep.as<u32>(), tOff, nTiles, ff,
+                       ctx->fragList.as<u32>());
     hipLaunchKernelGGL(k_frag_fix1, dim3((nTiles + 255) / 256), dim3(256), 0, s, lE, lV, tm, tOff, tPrev,
-                       ctx->tileDeep.as<u32>(), nTiles, ff, ctx->fragList.as<u32>());
+                       ctx->tileDeep.as<u32>(), nTiles, ff);
     hipLaunchKernelGGL(k_frag_fix2, dim3(std::max(1u, std::min((nTiles + 3) / 4, 1024u))), dim3(256), 0, s, lE, lV, tm, tOff,
                        tPrev, ff, ctx->fragList.as<u32>());
     hipLaunchKernelGGL(k_frag, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, lE, lV, tm, tOff, tPrev,
@@ -803,11 +810,26 @@ int gx_pvalues(gx_ctx* ctx) {
     HIPCHECK(ctx->pvLut.ensure((size_t)PV_LUT * 4));
     hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>());
     PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>()};
+    // p-mode: the sweep's significance / skip masks are filled on the way (gx_find_peaks reuses them
+    // when this replicate turns out to be the only one)
+    u64 *sigM = nullptr, *skipM = nullptr;
+    ctx->maskIdx = -1;
+    if (!ctx->par.qval_opt) {
+      const u32 nWords = (n + 63) / 64;
+      HIPCHECK(ctx->swMask.ensure((size_t)(nWords + 2) * 8 * 3));
+      HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, (size_t)(nWords + 2) * 8 * 3, s));
+      sigM = ctx->swMask.as<u64>();
+      skipM = sigM + (nWords + 2);
+      ctx->maskIdx = (int)ctx->reps.size();
+      ctx->maskN = n;
+    }
     hipLaunchKernelGGL(k_pack_pval, dim3(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s, pin,
                        ctx->nTiles, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(),
                        pa.p.as<float>(), pa.expt.as<float>(), ctx->hasBed ? pa.ctrl.as<float>() : (float*)nullptr,
-                       ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
+                       ctx->par.thr, sigM, skipM, ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_pval_deep, dim3(256), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(),
+                       ctx->dScal.as<Scalars>(), pa.p.as<float>(), ctx->par.thr, sigM);
+    if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     pa.end = std::move(ctx->expt.ivEnd);
@@ -1041,13 +1063,16 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   const u32 nWords = (n + 63) / 64;
   const u32 wChunks = (nWords + SW_CHUNK - 1) / SW_CHUNK;
   // three bit masks + chunk count/offset scratch
+  const bool haveMasks = !ctx->par.qval_opt && ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;  // from k_pack_pval
   HIPCHECK(ctx->swMask.ensure((size_t)(nWords + 2) * 8 * 3));
-  HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, (size_t)(nWords + 2) * 8 * 3, s));
+  if (haveMasks)
+    HIPCHECK(hipMemsetAsync(ctx->swMask.as<u64>() + 2 * (size_t)(nWords + 2), 0, (size_t)(nWords + 2) * 8, s));
+  else
+    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, (size_t)(nWords + 2) * 8 * 3, s));
+  ctx->maskIdx = -1;
   SweepMasks SM{ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + (nWords + 2), ctx->swMask.as<u64>() + 2 * (size_t)(nWords + 2),
                 nWords};
-  HIPCHECK(hipMemsetAsync(misc + M_TICKET2, 0, 12, s));  // nruns(ends), nruns, npeaks
-  HIPCHECK(hipMemsetAsync(misc + M_PEAKBP, 0, 8, s));
-  HIPCHECK(hipMemsetAsync(misc + M_TICKET3, 0, 12, s));  // -, -, ncands
+  HIPCHECK(hipMemsetAsync(misc + M_SWEEP_FIRST, 0, M_SWEEP_WORDS * 4, s));  // run / candidate / peak counters, peak bp
   const float* qPtr = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
   u32 R = 0, nPeaks = 0;
   ctx->peakBP = 0;
@@ -1058,8 +1083,9 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     u32* cntE = offS + wChunks + 8;
     u32* offE = cntE + wChunks + 8;
     hipLaunchKernelGGL(k_brk_mask, dim3((nChrom + 255) / 256), dim3(256), 0, s, fa.chromOff.as<u32>(), nChrom, SM.brk);
-    hipLaunchKernelGGL(k_sig_mask, dim3(std::max(1u, std::min((nWords + 3) / 4, 8192u))), dim3(256), 0, s, fa.p.as<float>(),
-                       qPtr, misc + M_NIV, ctx->par.thr, SM);
+    if (!haveMasks)
+      hipLaunchKernelGGL(k_sig_mask, dim3(std::max(1u, std::min((nWords + 15) / 16, 4096u))), dim3(256), 0, s, fa.p.as<float>(),
+                         qPtr, misc + M_NIV, ctx->par.thr, SM);
     hipLaunchKernelGGL(k_runs_count, dim3(wChunks), dim3(SW_NT), 0, s, SM, cntS, cntE);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cntS, (const u32*)nullptr, wChunks, (u32)SW_CHUNK, offS,
                        misc + M_SWCOUNT);
@@ -1089,10 +1115,19 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                          misc + M_NHEADS);
       hipLaunchKernelGGL(k_cands_write, dim3(rChunks), dim3(SW_NT), 0, s, SM, fa.end.as<u32>(), runStart, runEnd,
                          misc + M_SWCOUNT, ctx->par.max_gap, off2, ctx->headPos.as<u32>());
-      hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((R + 3) / 4, 8192u))), dim3(256), 0, s, SM,
-                         fa.end.as<u32>(), fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom, runStart, runEnd,
-                         misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc,
-                         ctx->par.min_len, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
+      HIPCHECK(ctx->candHdr.ensure((size_t)R * sizeof(uint4)));
+      HIPCHECK(ctx->longList.ensure((size_t)R * 4 + 16));
+      hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((R + 255) / 256, 4096u))), dim3(256), 0, s, SM, fa.end.as<u32>(),
+                         runStart, runEnd, misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->candHdr.as<uint4>(),
+                         ctx->longList.as<u32>(), misc + M_TICKET3);
+      hipLaunchKernelGGL(k_peak_short, dim3(std::max(1u, std::min((R + 255) / 256, 8192u))), dim3(256), 0, s,
+                         ctx->candHdr.as<uint4>(), fa.end.as<u32>(), fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom,
+                         misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),
+                         ctx->valid.as<u32>());
+      hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((R + 3) / 4, (u32)(2 * ctx->numCU)))), dim3(256), 0, s,
+                         ctx->candHdr.as<uint4>(), fa.end.as<u32>(), fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom,
+                         ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
+                         ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
       // candidates C <= R: chunk arrays sized by R's chunk count; kernels bound themselves by *nCands
       hipLaunchKernelGGL(k_peaks_count, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
       hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt3, misc + M_NHEADS, rChunks, (u32)SW_CHUNK, off3,

@@ -564,6 +564,119 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const R* __restrict__ in, const
     }
 }
 
+// level 2 in one kernel: a workgroup owns one whole super-bucket, so the per-tile histogram, its
+// scan and the scatter cursors all live in LDS -- no global atomics, no separate histogram pass,
+// and the tile counts are plain stores.  Pass 1 streams the super-bucket and counts (records
+// per tile, and for F the signed weight); pass 2 streams it again (it was just read: L2 /
+// Infinity Cache) in chunks that are ranked and sorted in LDS and written as tile-contiguous runs.
+constexpr int B2_NT = 1024;  // a super-bucket is a serial job: many threads keep it short
+template <typename R>
+__host__ __device__ constexpr size_t b2_lds_bytes(u32 nBins) {
+  return (size_t)B2_NT * ScCfg<R>::ITEMS * sizeof(R) + (size_t)(4 * nBins + 32) * 4;
+}
+
+template <typename R>
+__global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* __restrict__ out,
+                                                   const u32* __restrict__ segOff, u32 nSeg, int sbShift, u32 nTiles,
+                                                   u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
+  constexpr int ITEMS = ScCfg<R>::ITEMS;
+  constexpr int CHUNK = B2_NT * ITEMS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
+  const u32 nBins = 1u << sbShift;
+  R* stage = reinterpret_cast<R*>(b2_lds);
+  u32* hist = reinterpret_cast<u32*>(stage + CHUNK);  // pass 1: records per tile; pass 2: records per tile of the chunk
+  u32* start = hist + nBins;                          // pass 1: weight sums;      pass 2: chunk-local run starts
+  u32* cursor = start + nBins;                        // next output position of every tile
+  u32* base = cursor + nBins;                         // pass 2: output position of the chunk's run
+  u32* scratch = base + nBins;
+  for (u32 seg = blockIdx.x; seg < nSeg; seg += gridDim.x) {
+    const u32 begin = segOff[seg], end = segOff[seg + 1], segTileBase = seg << sbShift;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; start[i] = 0; }
+    __syncthreads();
+    for (u32 i0 = begin; i0 < end; i0 += CHUNK) {
+      R r[ITEMS];
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u32 idx = i0 + k * B2_NT + threadIdx.x;
+        if (idx < end) r[k] = in[idx];
+      }
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u32 idx = i0 + k * B2_NT + threadIdx.x;
+        if (idx < end) {
+          const u32 b = RecT<R>::tile(r[k]) - segTileBase;
+          atomicAdd(&hist[b], 1u);
+          if (sizeof(R) == 8) atomicAdd(&start[b], (u32)(int)(int8_t)((u64)r[k] & 0xFF));
+        }
+      }
+    }
+    __syncthreads();
+    u32 carry = begin;
+    for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
+      const u32 b = b0 + threadIdx.x;
+      const u32 c = b < nBins ? hist[b] : 0;
+      u32 tot;
+      const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
+      if (b < nBins) {
+        cursor[b] = carry + ex;
+        hist[b] = 0;                     // pass 2 starts from an empty chunk histogram
+        if (segTileBase + b < nTiles) {  // (the last super-bucket may be short of tiles)
+          tileCnt[segTileBase + b] = c;
+          if (sizeof(R) == 8) tileWsum[segTileBase + b] += (int)start[b];  // the slot is this workgroup's alone
+        }
+      }
+      carry += tot;
+    }
+    __syncthreads();
+    for (u32 i0 = begin; i0 < end; i0 += CHUNK) {
+      const u32 cEnd = min(end, i0 + CHUNK);
+      R r[ITEMS];
+      u32 rk[ITEMS];
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u32 idx = i0 + k * B2_NT + threadIdx.x;
+        if (idx < cEnd) r[k] = in[idx];
+      }
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u32 idx = i0 + k * B2_NT + threadIdx.x;
+        if (idx < cEnd) rk[k] = atomicAdd(&hist[RecT<R>::tile(r[k]) - segTileBase], 1u);
+      }
+      __syncthreads();  // (also: every thread has left the previous chunk's write loop)
+      // each bin's owner: chunk-local run start, the run's output position, cursor advance, and
+      // the histogram reset for the next chunk
+      u32 lc = 0;
+      for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
+        const u32 b = b0 + threadIdx.x;
+        const u32 c = b < nBins ? hist[b] : 0;
+        u32 tot;
+        const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
+        if (b < nBins) {
+          start[b] = lc + ex;
+          base[b] = cursor[b];
+          cursor[b] += c;
+          hist[b] = 0;
+        }
+        lc += tot;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        const u32 idx = i0 + k * B2_NT + threadIdx.x;
+        if (idx < cEnd) stage[start[RecT<R>::tile(r[k]) - segTileBase] + rk[k]] = r[k];
+      }
+      __syncthreads();
+      const u32 cnt = cEnd - i0;
+      for (u32 i = threadIdx.x; i < cnt; i += B2_NT) {
+        const R v = stage[i];
+        const u32 b = RecT<R>::tile(v) - segTileBase;
+        out[base[b] + (i - start[b])] = v;
+      }
+    }
+  }
+}
+
 // ---- 4. the tile kernel: LDS difference array -> prefix sum -> run-length pileup -----------
 // Replaces savePileupExpt's two per-base passes (Genrich.c:2197-2273; and the per-base walk
 // of calcFactor/savePileupCtrl for a control).  One workgroup owns one tile at a time:
@@ -579,6 +692,7 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const R* __restrict__ in, const
 // it latency-bound at ~10 us per tile.)
 constexpr int TL_NT = 256;
 constexpr int TL_NW = TL_NT / 64;
+constexpr int TL_REG = 4;                         // touched bases per thread held in registers
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
 constexpr int TL_LDS = TILE + 64 + 2 * (TILE / 32); // ints: slice, scan scratch, occupancy + -E edge bitmaps
 constexpr int FRAG_FAST_MAXV = ((1 << 24) / (2 * TILE)) * GX_UNIT;  // len < 2 TILE and V below this: len * val < 2^24
@@ -674,31 +788,40 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
   u32 bad = 0;
   for (int i = threadIdx.x * 4; i < TILE; i += TL_NT * 4)
     *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
+  occ[threadIdx.x] = 0;
+  eb[threadIdx.x] = 0;
+  __syncthreads();
   // software pipeline over this workgroup's tiles: descriptors are loaded two tiles ahead and the
   // first TL_NT start / end keys of the next tile one tile ahead, so their HBM/L2 latency overlaps
   // the current tile instead of stalling every wave at the top of each iteration
   const u32 G = gridDim.x;
   TileMeta m1 = blockIdx.x < nTiles ? in.meta[blockIdx.x] : TileMeta{};
   TileMeta m2 = blockIdx.x + G < nTiles ? in.meta[blockIdx.x + G] : TileMeta{};
+  TileMeta m3 = blockIdx.x + 2 * G < nTiles ? in.meta[blockIdx.x + 2 * G] : TileMeta{};
   u32 ks1 = threadIdx.x < m1.nS ? in.S[m1.sb + threadIdx.x] : 0u;
   u32 ke1 = threadIdx.x < m1.nE ? in.E[m1.eb + threadIdx.x] : 0u;
+  u32 ks2 = threadIdx.x < m2.nS ? in.S[m2.sb + threadIdx.x] : 0u;
+  u32 ke2 = threadIdx.x < m2.nE ? in.E[m2.eb + threadIdx.x] : 0u;
   for (u32 t = blockIdx.x; t < nTiles; t += G) {
+    // (a tile takes about a microsecond, an HBM round trip several: keys two tiles ahead,
+    // descriptors three)
     const TileMeta m = m1;
     const u32 ks0 = ks1, ke0 = ke1;
     m1 = m2;
-    if (t + 2 * G < nTiles) m2 = in.meta[t + 2 * G];
-    if (t + G < nTiles) {
-      ks1 = threadIdx.x < m1.nS ? in.S[m1.sb + threadIdx.x] : 0u;
-      ke1 = threadIdx.x < m1.nE ? in.E[m1.eb + threadIdx.x] : 0u;
+    ks1 = ks2;
+    ke1 = ke2;
+    m2 = m3;
+    if (t + 3 * G < nTiles) m3 = in.meta[t + 3 * G];
+    if (t + 2 * G < nTiles) {
+      ks2 = threadIdx.x < m2.nS ? in.S[m2.sb + threadIdx.x] : 0u;
+      ke2 = threadIdx.x < m2.nE ? in.E[m2.eb + threadIdx.x] : 0u;
     }
     const bool active = m.flags & 1u;
     const u32 pos0 = m.pos0;
     const bool lastTile = (m.flags & 2u) != 0;
     const u32 sb = m.sb, se = m.sb + m.nS, eb0 = m.eb, ee = m.eb + m.nE, fb = m.fb, fe = m.fb + m.nF;
     const int carry = m.carry;
-    occ[threadIdx.x] = 0;
-    if (BED) eb[threadIdx.x] = 0;
-    __syncthreads();
+    // (occ / eb words are zero here: each thread clears its word as soon as it has read it)
     // accumulate this tile's endpoints: +1 per start, -1 per end (unit weight = 120), then the
     // fractional records with their own signed weight
     if (threadIdx.x < m.nS) {
@@ -736,6 +859,8 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     // thread i owns bases [32 i, 32 i + 32): pass 1 over its touched bases (and -E edges)
     const u32 ow = occ[threadIdx.x];
     const u32 ew = BED ? eb[threadIdx.x] : 0u;
+    occ[threadIdx.x] = 0;  // own word, next touched after the barrier that ends this tile
+    if (BED) eb[threadIdx.x] = 0;
     bool save = true;
     if (BED) {  // `save` state at this thread's first base = tile state ^ parity(edges before it)
       const int pe = __popc(ew);
@@ -752,15 +877,37 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     const int lbase = threadIdx.x * 32;
     int sum = 0;
     u32 cnt = 0, sat = 0;
-    for (u32 m = ow | ew; m; m &= m - 1) {
+    // The first TL_REG touched bases of the thread are fetched from LDS in one batch and kept in
+    // registers for both passes (a dependent LDS round trip per base and pass is what this kernel
+    // would otherwise wait for); their slots are cleared at once.  Further bases -- rare -- loop.
+    int kk[TL_REG], dk[TL_REG];
+    u32 mrest = ow | ew;
+#pragma unroll
+    for (int j = 0; j < TL_REG; j++) {
+      kk[j] = mrest ? __builtin_ctz(mrest) : -1;
+      dk[j] = mrest ? delta[lbase + kk[j]] : 0;
+      mrest &= mrest - 1;
+    }
+#define GX_P1_STEP(K, D)                                                        \
+  {                                                                            \
+    const bool edge = BED && ((ew >> (K)) & 1u);                               \
+    sum += (D);                                                                \
+    cnt += (edge || (save && (D) != 0)) && (pos0 + lbase + (K) != 0); /* 2241 */ \
+    if (edge) save = !save;                                       /* 2258-2263 */ \
+    sat |= (u32)((D) >= 32767 * GX_UNIT) | (u32)((D) <= -32768 * GX_UNIT);     \
+  }
+#pragma unroll
+    for (int j = 0; j < TL_REG; j++)
+      if (kk[j] >= 0) {
+        GX_P1_STEP(kk[j], dk[j]);
+        if (dk[j] != 0) delta[lbase + kk[j]] = 0;
+      }
+    for (u32 m = mrest; m; m &= m - 1) {
       const int k = __builtin_ctz(m);
       const int d = delta[lbase + k];
-      const bool edge = BED && ((ew >> k) & 1u);
-      sum += d;
-      cnt += (edge || (save && d != 0)) && (pos0 + lbase + k != 0);  // 2241
-      if (edge) save = !save;                                         // 2258-2263
-      sat |= (u32)(d >= 32767 * GX_UNIT) | (u32)(d <= -32768 * GX_UNIT);
+      GX_P1_STEP(k, d);
     }
+#undef GX_P1_STEP
     if (!active) cnt = 0;
     // fused block scan of (sum, cnt): two DPP wave scans, one cross-wave step
     const int incS = dpp_scan_add(sum);
@@ -784,23 +931,31 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     u32 o = o0, neg = 0, lastEnd = 0;
     u32 big = threadIdx.x == 0 && carry >= FRAG_FAST_MAXV;
     save = save0;
-    for (u32 m = ow | ew; m; m &= m - 1) {
+#define GX_P2_STEP(K, D)                                                \
+  {                                                                    \
+    const u32 p = pos0 + lbase + (K);                                  \
+    const bool edge = BED && ((ew >> (K)) & 1u);                       \
+    if (active && (edge || (save && (D) != 0)) && p != 0) {            \
+      out.looseEnd[o] = p;                                             \
+      out.looseV[o] = save ? run : V_MARK; /* 2244-2248 */             \
+      lastEnd = p;                                                     \
+      o++;                                                             \
+    }                                                                  \
+    if (edge) save = !save;                                            \
+    run += (D);                                                        \
+    neg |= (u32)(run < 0);                                             \
+    big |= (u32)(run >= FRAG_FAST_MAXV);                               \
+  }
+#pragma unroll
+    for (int j = 0; j < TL_REG; j++)
+      if (kk[j] >= 0) GX_P2_STEP(kk[j], dk[j]);
+    for (u32 m = mrest; m; m &= m - 1) {
       const int k = __builtin_ctz(m);
       const int d = delta[lbase + k];
-      const u32 p = pos0 + lbase + k;
-      const bool edge = BED && ((ew >> k) & 1u);
-      if (active && (edge || (save && d != 0)) && p != 0) {
-        out.looseEnd[o] = p;
-        out.looseV[o] = save ? run : V_MARK;  // 2244-2248
-        lastEnd = p;
-        o++;
-      }
-      if (edge) save = !save;
-      run += d;
-      neg |= (u32)(run < 0);
-      big |= (u32)(run >= FRAG_FAST_MAXV);
+      GX_P2_STEP(k, d);
       if (d != 0) delta[lbase + k] = 0;
     }
+#undef GX_P2_STEP
     if (active) {  // block-uniform
       if (lastTile && threadIdx.x == TL_NT - 1) {  // closing interval [.., len)
         out.looseEnd[o] = m.len;
@@ -956,8 +1111,8 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
 // intervals with len * val >= 2^24 can round, and they are easy to find:
 //   * val >= 2^24 / (2 TILE): k_tile marks the tiles in which the pileup gets that deep;
 //   * otherwise len >= 2 TILE: the interval starts before its tile does, so it is the tile's first.
-// k_frag_fix1 looks at every tile's first interval and lists the deep tiles, k_frag_fix2 walks
-// the listed tiles; both add (rounded product - exact product), an integer, to a correction.
+// k_frag_fix1 looks at every other tile's first interval, k_frag_fix2 walks the deep tiles
+// (k_deep_list); both add (rounded product - exact product), an integer, to a correction.
 // Everything else (fractional weights, -E, wide records) takes the general path k_frag, which
 // walks every interval and accumulates exactly in (integer, fraction * 2^27) form.
 struct FragFix {
@@ -965,6 +1120,8 @@ struct FragFix {
   u32 slow;                 // general path wanted
   u32 nList;
   long long corr;
+  u32 nF;                   // fractional records appended by k_convert (not fragLen's, but zeroed with it)
+  u32 pad_;
 };
 
 __device__ __forceinline__ long long frag_corr(u32 len, int v) {
@@ -974,21 +1131,24 @@ __device__ __forceinline__ long long frag_corr(u32 len, int v) {
   return (long long)term - (long long)((u64)len * cnt);
 }
 
+// the tiles k_tile marked deep (and that hold intervals), as a list: walked by k_frag_fix2 and k_pval_deep
+__global__ __launch_bounds__(256) void k_deep_list(const u32* __restrict__ tileDeep, const u32* __restrict__ tileIvOff,
+                                                   u32 nTiles, FragFix* __restrict__ ff, u32* __restrict__ list) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t < nTiles && tileDeep[t] && tileIvOff[t + 1] != tileIvOff[t]) list[atomicAdd(&ff->nList, 1u)] = t;
+}
+
 __global__ __launch_bounds__(256) void k_frag_fix1(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
                                                    const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
                                                    const u32* __restrict__ tilePrevEnd, const u32* __restrict__ tileDeep,
-                                                   u32 nTiles, FragFix* __restrict__ ff, u32* __restrict__ list) {
+                                                   u32 nTiles, FragFix* __restrict__ ff) {
   if (ff->slow) return;
   long long c = 0;
   const u32 t = blockIdx.x * 256 + threadIdx.x;
-  if (t < nTiles && tileIvOff[t + 1] != tileIvOff[t]) {
-    if (tileDeep[t])
-      list[atomicAdd(&ff->nList, 1u)] = t;
-    else {
-      const u32 slot = meta[t].slot;
-      const u32 len = looseEnd[slot] - tilePrevEnd[t];
-      if (len >= 2 * TILE) c = frag_corr(len, looseV[slot]);
-    }
+  if (t < nTiles && tileIvOff[t + 1] != tileIvOff[t] && !tileDeep[t]) {
+    const u32 slot = meta[t].slot;
+    const u32 len = looseEnd[slot] - tilePrevEnd[t];
+    if (len >= 2 * TILE) c = frag_corr(len, looseV[slot]);
   }
   if (__ballot(c != 0)) {
     c = wave_sum(c);

@@ -39,73 +39,145 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
 // PP_UNROLL independent (end, V) loads in flight, the next tile's header is fetched while the
 // current one is processed, and the hot head of the p-value table lives in LDS (a 64-lane gather
 // from L1 costs one cache line per lane).
-constexpr int PP_UNROLL = 4;
-constexpr int PP_LUT = 4096;  // V < 4096: pileups below 34
+constexpr int PP_UNROLL = 4;   // 256 intervals of a tile in flight per wavefront
+constexpr int PP_HOT = 1024;   // whole pileups below this have their p-value in LDS
 
 __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const Scalars* __restrict__ sc,
                                                    const float* __restrict__ lutP, u32* __restrict__ ivEnd,
                                                    float* __restrict__ pOut, float* __restrict__ exptOut,
-                                                   float* __restrict__ ctrlOut, u32* __restrict__ st) {
-  __shared__ float hot[PP_LUT];
-  for (int i = threadIdx.x; i < PP_LUT; i += 256) hot[i] = lutP[i];
+                                                   float* __restrict__ ctrlOut, float thr, u64* __restrict__ sigMask,
+                                                   u64* __restrict__ skipMask, u32* __restrict__ st) {
+  __shared__ float hot[PP_HOT];  // indexed by the whole pileup c = V / 120 (consecutive banks, unlike V itself)
+  for (int i = threadIdx.x; i < PP_HOT; i += 256) hot[i] = lutP[i * GX_UNIT];
   __syncthreads();
   const float lambda = sc->lambda;
-  double ml = 0, sl = 1;
-  if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
   u32 neg = 0;
   const int wv = threadIdx.x >> 6, lane = lane_id();
   const u32 stride = gridDim.x * 4;
+  // two-deep software pipeline per wavefront: headers (slot, offset, count) of tile k+2 and the
+  // first 64 * PP_UNROLL (end, V) pairs of tile k+1 are in flight while tile k is scored
   u32 t = blockIdx.x * 4 + wv;
-  u32 src1 = 0, dst1 = 0, n1 = 0;
+  u32 src1 = 0, dst1 = 0, n1 = 0, src2 = 0, dst2 = 0, n2 = 0;
+  u32 e1[PP_UNROLL];
+  int v1[PP_UNROLL];
+#pragma unroll
+  for (int k = 0; k < PP_UNROLL; k++) { e1[k] = 0; v1[k] = 0; }
   if (t < nTiles) {
     src1 = in.meta[t].slot;
     dst1 = in.tileIvOff[t];
     n1 = in.tileIvOff[t + 1] - dst1;
+#pragma unroll
+    for (int k = 0; k < PP_UNROLL; k++)
+      if (k * 64 + lane < n1) {
+        e1[k] = in.looseEnd[src1 + k * 64 + lane];
+        v1[k] = in.looseV[src1 + k * 64 + lane];
+      }
+  }
+  if (t + stride < nTiles) {
+    src2 = in.meta[t + stride].slot;
+    dst2 = in.tileIvOff[t + stride];
+    n2 = in.tileIvOff[t + stride + 1] - dst2;
   }
   for (; t < nTiles; t += stride) {
     const u32 src = src1, dst = dst1, n = n1;
-    if (t + stride < nTiles) {
-      src1 = in.meta[t + stride].slot;
-      dst1 = in.tileIvOff[t + stride];
-      n1 = in.tileIvOff[t + stride + 1] - dst1;
+    u32 e[PP_UNROLL];
+    int v[PP_UNROLL];
+#pragma unroll
+    for (int k = 0; k < PP_UNROLL; k++) { e[k] = e1[k]; v[k] = v1[k]; }
+    src1 = src2; dst1 = dst2; n1 = t + stride < nTiles ? n2 : 0u;
+#pragma unroll
+    for (int k = 0; k < PP_UNROLL; k++)
+      if (k * 64 + lane < n1) {
+        e1[k] = in.looseEnd[src1 + k * 64 + lane];
+        v1[k] = in.looseV[src1 + k * 64 + lane];
+      }
+    if (t + 2 * stride < nTiles) {
+      src2 = in.meta[t + 2 * stride].slot;
+      dst2 = in.tileIvOff[t + 2 * stride];
+      n2 = in.tileIvOff[t + 2 * stride + 1] - dst2;
     }
     for (u32 b = 0; b < n; b += 64 * PP_UNROLL) {
-      u32 e[PP_UNROLL];
-      int v[PP_UNROLL];
+      if (b) {  // beyond the pipelined first batch (dense tiles)
 #pragma unroll
-      for (int k = 0; k < PP_UNROLL; k++) {
-        const u32 i = b + k * 64 + lane;
-        e[k] = 0;
-        v[k] = 0;
-        if (i < n) {
-          e[k] = in.looseEnd[src + i];
-          v[k] = in.looseV[src + i];
+        for (int k = 0; k < PP_UNROLL; k++) {
+          const u32 i = b + k * 64 + lane;
+          if (i < n) {
+            e[k] = in.looseEnd[src + i];
+            v[k] = in.looseV[src + i];
+          }
         }
       }
 #pragma unroll
       for (int k = 0; k < PP_UNROLL; k++) {
         const u32 i = b + k * 64 + lane;
+        float p = 0.0f;
         if (i < n) {
           bool ng = false;
-          float val, p;
+          float val;
           if (v[k] == V_MARK) {  // inside an excluded region: treatment 0.0f (2248), control SKIP (1871) -> p SKIP (1629)
             val = 0.0f;
             p = GX_SKIPF;
-          } else if ((u32)v[k] < PV_LUT) {
-            val = getval(v[k], &ng);
-            p = (u32)v[k] < PP_LUT ? hot[v[k]] : lutP[v[k]];
-          } else
-            p = pval_of_v(v[k], lambda, ml, sl, &val, &ng);
+          } else {
+            // pileups beyond the table (>= 2184) are scored by k_pval_deep: the double-precision
+            // math would cost this kernel half its occupancy
+            const u32 c = __umulhi((u32)v[k], 0x88888889u) >> 6;  // V / 120 for V >= 0
+            if (v[k] >= 0 && c * GX_UNIT == (u32)v[k] && c < PP_HOT) {  // a whole pileup: getval is (float)c
+              val = (float)c;
+              p = hot[c];
+            } else {
+              val = getval(v[k], &ng);
+              p = (u32)v[k] < PV_LUT ? lutP[v[k]] : 0.0f;
+            }
+          }
           neg |= ng;
           ivEnd[dst + i] = e[k];
           pOut[dst + i] = p;
           exptOut[dst + i] = val;
           if (ctrlOut) ctrlOut[dst + i] = v[k] == V_MARK ? GX_SKIPF : lambda;
         }
+        if (sigMask) {  // the sweep's significance / skip bit masks, while p is at hand (pre-zeroed words)
+          const u64 sg = __ballot(p > thr), sk = __ballot(p == GX_SKIPF);
+          if ((sg | sk) && lane == 0) {
+            const u32 pos = dst + b + k * 64, w = pos >> 6, sh = pos & 63;
+            if (sg) {
+              atomicOr((unsigned long long*)&sigMask[w], (unsigned long long)(sg << sh));
+              if (sh && (sg >> (64 - sh))) atomicOr((unsigned long long*)&sigMask[w + 1], (unsigned long long)(sg >> (64 - sh)));
+            }
+            if (sk) {
+              atomicOr((unsigned long long*)&skipMask[w], (unsigned long long)(sk << sh));
+              if (sh && (sk >> (64 - sh))) atomicOr((unsigned long long*)&skipMask[w + 1], (unsigned long long)(sk >> (64 - sh)));
+            }
+          }
+        }
       }
     }
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// the intervals of the deep tiles whose pileup lies beyond the table
+__global__ __launch_bounds__(256) void k_pval_deep(PackIn in, const FragFix* __restrict__ ff, const u32* __restrict__ list,
+                                                   const Scalars* __restrict__ sc, float* __restrict__ pOut, float thr,
+                                                   u64* __restrict__ sigMask) {
+  const u32 nList = ff->nList;
+  const float lambda = sc->lambda;
+  double ml = 0, sl = 1;
+  if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  for (u32 li = blockIdx.x * 4 + wv; li < nList; li += gridDim.x * 4) {
+    const u32 t = list[li];
+    const u32 src = in.meta[t].slot, dst = in.tileIvOff[t], n = in.tileIvOff[t + 1] - dst;
+    for (u32 i = lane; i < n; i += 64) {
+      const int v = in.looseV[src + i];
+      if (v != V_MARK && (u32)v >= PV_LUT) {
+        float val;
+        bool ng;
+        const float p = pval_of_v(v, lambda, ml, sl, &val, &ng);
+        pOut[dst + i] = p;
+        if (sigMask && p > thr) atomicOr((unsigned long long*)&sigMask[(dst + i) >> 6], 1ull << ((dst + i) & 63));
+      }
+    }
+  }
 }
 
 // ---- Benjamini-Hochberg: computeQval (352-401) / saveQval (212-250) -----------------------
@@ -388,14 +460,22 @@ __global__ __launch_bounds__(256) void k_sig_mask(const float* __restrict__ p, c
   const u32 n = *nPtr;
   const float* pq = q ? q : p;
   const u32 nw = (n + 63) >> 6;
-  for (u32 w = blockIdx.x * 4 + (threadIdx.x >> 6); w < nw; w += gridDim.x * 4) {
-    u32 i = (w << 6) + lane_id();
-    float v = i < n ? pq[i] : 0.0f;
-    u64 sg = __ballot(i < n && v > thr);
-    u64 sk = __ballot(i < n && v == GX_SKIPF);
-    if (lane_id() == 0) {
-      M.sig[w] = sg;
-      M.skip[w] = sk;
+  // four words per wave and iteration: a single 4-byte load per lane in flight reaches ~2.5 TB/s
+  for (u32 w0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; w0 < nw; w0 += gridDim.x * 16) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 i = ((w0 + k) << 6) + lane_id();
+      v[k] = i < n ? pq[i] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u64 sg = __ballot(v[k] > thr);
+      const u64 sk = __ballot(v[k] == GX_SKIPF);
+      if (lane_id() == 0 && w0 + k < nw) {
+        M.sig[w0 + k] = sg;
+        M.skip[w0 + k] = sk;
+      }
     }
   }
 }
@@ -533,21 +613,120 @@ __global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u32* 
     if (keep & (1u << k)) candRun[o++] = r0 + k;
 }
 
-// one wavefront per candidate: updatePeak (943-970) over its intervals, then checkPeak (916-927)
-__global__ __launch_bounds__(256) void k_peak_walk(SweepMasks M, const u32* __restrict__ end, const float* __restrict__ p,
-                                                   const float* __restrict__ q, const u32* __restrict__ chromOff, u32 nChrom,
-                                                   const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
-                                                   const u32* __restrict__ nRuns, const u32* __restrict__ candRun,
-                                                   const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
-                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+constexpr u32 PK_SHORT = 1024;
+
+// candidate -> {first interval, last interval, start coordinate}: one thread per candidate, so the
+// chain candRun -> runStart/runEnd -> end[] is walked by all candidates at once instead of once
+// per wavefront in k_peak_walk
+__global__ __launch_bounds__(256) void k_cand_hdr(SweepMasks M, const u32* __restrict__ end,
+                                                  const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
+                                                  const u32* __restrict__ nRuns, const u32* __restrict__ candRun,
+                                                  const u32* __restrict__ nCands, uint4* __restrict__ hdr,
+                                                  u32* __restrict__ longList, u32* __restrict__ nLong) {
   const u32 R = *nRuns, C = *nCands;
-  const u32 wavesPerGrid = gridDim.x * 4;
-  const int lane = lane_id();
-  for (u32 c = blockIdx.x * 4 + (threadIdx.x >> 6); c < C; c += wavesPerGrid) {
+  for (u32 c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
     const u32 rFirst = candRun[c], rLast = (c + 1 < C ? candRun[c + 1] : R) - 1;
     const u32 i0 = runStart[rFirst], i1 = runEnd[rLast];  // interval span [i0, i1], both significant
     const bool atChromStart = (M.brk[i0 >> 6] >> (i0 & 63)) & 1ull;
-    const u32 peakStart = atChromStart ? 0u : end[i0 - 1];
+    hdr[c] = make_uint4(i0, i1, atChromStart ? 0u : end[i0 - 1], end[i1]);
+    if (i1 - i0 >= PK_SHORT) longList[atomicAdd(nLong, 1u)] = c;  // walked by a whole wavefront (k_peak_walk)
+  }
+}
+
+__device__ __forceinline__ void peak_finish(u32 c, const uint4 h, float auc, u32 summitPos, float sp, float sq,
+                                            float minAUC, int minLen, const u32* __restrict__ chromOff, u32 nChrom,
+                                            gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  const u32 peakStart = h.z, peakEnd = h.w;
+  const bool ok = auc >= minAUC && (long long)peakEnd - (long long)peakStart >= (long long)minLen;  // checkPeak 916-927
+  valid[c] = ok;
+  if (ok) {
+    ChromCursor cur;
+    cur.seek(chromOff, nChrom, h.x);
+    gx_peak pk;
+    pk.chrom = cur.c;
+    pk.start = peakStart;
+    pk.end = peakEnd;
+    pk.summit = summitPos;
+    pk.auc = auc;
+    pk.p = sp;
+    pk.q = sq;
+    cand[c] = pk;
+  }
+}
+
+// updatePeak (943-970) for one interval [s, e) with p / q values pv / qv
+struct PeakAcc {
+  float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
+  u32 summitPos = 0, summitLen = 0, s = 0, origin = 0;
+  __device__ __forceinline__ void step(u32 e, float pv, float qv, bool useQ, float thr) {
+    const float pq = useQ ? qv : pv;
+    if (pq > thr) {  // non-significant intervals inside the span only fill gaps
+      auc += (float)(e - s) * (pq - thr);  // 949-950: float product, summed in order
+      const u32 len = e - s;
+      if (pq > summitVal) {               // 956-961
+        summitVal = pq;
+        sp = pv;
+        sq = qv;
+        summitPos = (u32)(((u64)e + s) / 2 - origin);
+        summitLen = len;
+      } else if (pq == summitVal && len > summitLen) {  // 962-968
+        summitPos = (u32)(((u64)e + s) / 2 - origin);
+        summitLen = len;
+      }
+    }
+    s = e;
+  }
+};
+
+// candidates of up to PK_SHORT intervals (all but pathological ones): one thread each, a plain
+// in-order loop like updatePeak itself; every candidate of the genome is in flight at once.  The
+// body of the loop reads four intervals per 16-byte load: a 64-lane gather costs the texture
+// unit one cycle per lane whatever the width.
+__global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hdr, const u32* __restrict__ end,
+                                                    const float* __restrict__ p, const float* __restrict__ q,
+                                                    const u32* __restrict__ chromOff, u32 nChrom,
+                                                    const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
+                                                    gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  const u32 C = *nCands;
+  const bool useQ = q != nullptr;
+  for (u32 c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+    const uint4 h = hdr[c];
+    const u32 i0 = h.x, i1 = h.y;
+    if (i1 - i0 >= PK_SHORT) continue;
+    PeakAcc a;
+    a.s = h.z;
+    a.origin = h.z;
+    u32 i = i0;
+    for (; i <= i1 && (i & 3u); i++) a.step(end[i], p[i], useQ ? q[i] : GX_SKIPF, useQ, thr);
+    for (; i + 3 <= i1; i += 4) {
+      const uint4 e4 = *reinterpret_cast<const uint4*>(end + i);
+      const float4 p4 = *reinterpret_cast<const float4*>(p + i);
+      float4 q4 = make_float4(GX_SKIPF, GX_SKIPF, GX_SKIPF, GX_SKIPF);
+      if (useQ) q4 = *reinterpret_cast<const float4*>(q + i);
+      a.step(e4.x, p4.x, q4.x, useQ, thr);
+      a.step(e4.y, p4.y, q4.y, useQ, thr);
+      a.step(e4.z, p4.z, q4.z, useQ, thr);
+      a.step(e4.w, p4.w, q4.w, useQ, thr);
+    }
+    for (; i <= i1; i++) a.step(end[i], p[i], useQ ? q[i] : GX_SKIPF, useQ, thr);
+    peak_finish(c, h, a.auc, a.summitPos, a.sp, a.sq, minAUC, minLen, chromOff, nChrom, cand, valid);
+  }
+}
+
+// one wavefront per candidate: updatePeak (943-970) over its intervals, then checkPeak (916-927)
+__global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr, const u32* __restrict__ end,
+                                                   const float* __restrict__ p, const float* __restrict__ q,
+                                                   const u32* __restrict__ chromOff, u32 nChrom,
+                                                   const u32* __restrict__ longList, const u32* __restrict__ nLong,
+                                                   float thr, float minAUC, int minLen,
+                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  const u32 L = *nLong;
+  const u32 wavesPerGrid = gridDim.x * 4;
+  const int lane = lane_id();
+  for (u32 li = blockIdx.x * 4 + (threadIdx.x >> 6); li < L; li += wavesPerGrid) {
+    const u32 c = longList[li];
+    const uint4 h = hdr[c];
+    const u32 i0 = h.x, i1 = h.y, peakStart = h.z;
     float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
     u32 summitPos = 0, summitLen = 0;
     for (u32 base = i0; base <= i1; base += 64) {
@@ -565,7 +744,10 @@ __global__ __launch_bounds__(256) void k_peak_walk(SweepMasks M, const u32* __re
       const bool sg = in && pq > thr;       // non-significant intervals inside the span only fill gaps
       if (!sg) pq = -2.0f; else term = (float)(e - s) * (pq - thr);  // 949-950: float product ...
       u64 sgMask = __ballot(sg);
-      for (u64 m = sgMask; m; m &= m - 1) auc += __shfl(term, __builtin_ctzll(m), 64);  // ... summed in order
+      if (sgMask) {  // ... summed in lane order; the other lanes hold +0.0f, which changes nothing
+#pragma unroll
+        for (int k = 0; k < 64; k++) auc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), k));
+      }
       if (sgMask) {
         // summit of this chunk: maximum pq, earliest lane (956-961); among the lanes at the maximum
         // the first one with the greatest length (962-968)
@@ -592,24 +774,7 @@ __global__ __launch_bounds__(256) void k_peak_walk(SweepMasks M, const u32* __re
         }
       }
     }
-    if (lane == 0) {
-      const u32 peakEnd = end[i1];
-      bool ok = auc >= minAUC && (long long)peakEnd - (long long)peakStart >= (long long)minLen;
-      valid[c] = ok;
-      if (ok) {
-        ChromCursor cur;
-        cur.seek(chromOff, nChrom, i0);
-        gx_peak pk;
-        pk.chrom = cur.c;
-        pk.start = peakStart;
-        pk.end = peakEnd;
-        pk.summit = summitPos;
-        pk.auc = auc;
-        pk.p = sp;
-        pk.q = sq;
-        cand[c] = pk;
-      }
-    }
+    if (lane == 0) peak_finish(c, h, auc, summitPos, sp, sq, minAUC, minLen, chromOff, nChrom, cand, valid);
   }
 }
 

@@ -282,3 +282,23 @@ def test_fraglen_general_path_on_unit_data():
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert res.returncode == 0 and "slow ok" in res.stdout, res.stderr[-2000:]
+
+
+def test_giant_candidate_takes_the_wavefront_walk():
+    """A peak of several thousand intervals is walked by a whole wavefront (k_peak_walk); ordinary
+    ones by one thread each (k_peak_short).  Same in-order float AUC either way."""
+    rng = np.random.default_rng(11)
+    lens = [2_000_000]
+    bg = synth.make_fragments(lens, 15_000, seed=5)
+    st = rng.integers(500_000, 560_000, 40_000).astype(np.uint32)
+    ln = rng.integers(150, 400, 40_000).astype(np.uint32)
+    big = np.zeros(len(st), dtype=B.EVENT_DTYPE)
+    big["chrom"], big["start"], big["end"], big["count"] = 0, st, st + ln, 1
+    case = dict(lens=lens, replicates=[dict(save=None, treat=np.concatenate([bg, big]), ctrl=None)])
+    o, h, so, sh = run_both(case, B.make_params(pq=0.01, min_auc=20.0))
+    assert_same_run(o, h, so, sh, case)
+    pk = h.get_peaks()
+    e, _ = h.get_intervals(-1, 0)
+    widest = max(np.searchsorted(e, q["end"]) - np.searchsorted(e, q["start"]) for q in pk)
+    assert widest > 1024, widest
+    assert np.array_equal(o.get_peaks()["auc"].view(np.uint32), pk["auc"].view(np.uint32))
