@@ -259,10 +259,9 @@ int sort_stream(gx_ctx* ctx, gx_ctx::Stream& st, u32 nRec, int q) {
   hipLaunchKernelGGL((k_scatter<1, R>), dim3(chunks1), dim3(SC_NT), 0, s, st.a.as<R>(), st.b.as<R>(),
                      st.sbOff.as<u32>() + nSB /* total */, (const u32*)nullptr, 0u, ctx->sbShift, nSB, st.sbCursor.as<u32>());
   // level 2: one workgroup per super-bucket (the last level-1 bin holds the records without a tile)
-  const size_t lds2 = b2_lds_bytes<R>(1u << ctx->sbShift);
-  if (lds2 > 64 * 1024)
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds2));
+  const size_t lds2 = b2_lds_bytes(1u << ctx->sbShift);
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds2));
   hipLaunchKernelGGL((k_bucket2<R>), dim3(std::max(1u, nSB - 1)), dim3(B2_NT), lds2, s, st.b.as<R>(), st.a.as<R>(),
                      st.sbOff.as<u32>(), nSB - 1, ctx->sbShift, nTiles, ctx->tileCnt[q].as<u32>(), ctx->tileWsum.as<int>());
   return dbg_sync(ctx, "sort_stream");
@@ -614,7 +613,11 @@ int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip, 
   }
   int lg = 0;
   while ((1u << lg) < t) lg++;
-  ctx->sbShift = std::min(11, (lg + 1) / 2);
+  // tiles per super-bucket: the level-1 scatter wants few bins (long runs per bin and chunk), the level-2
+  // kernel many super-buckets (one workgroup each); GX_SBSHIFT overrides for experiments
+  // (hg38, 377 K tiles: 2^9 tiles per super-bucket measured best of 2^8 / 2^9 / 2^10)
+  ctx->sbShift = std::min(11, lg / 2);
+  if (const char* e = getenv("GX_SBSHIFT")) ctx->sbShift = std::max(0, std::min(11, atoi(e)));
   while (((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1 > (u32)MAX_BINS) ctx->sbShift++;
   if ((1u << ctx->sbShift) > (u32)MAX_BINS) {
     ctx->err = "genome too large for the two-level tile sort";

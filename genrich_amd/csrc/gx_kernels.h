@@ -332,21 +332,35 @@ __global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist
                                                   u32* __restrict__ sbOff, u32* __restrict__ sbCursor,
                                                   u32* __restrict__ sbChunkOff) {
   __shared__ u32 scratch[20];
-  // nSB <= MAX_BINS = 2 * 1024: two items per thread
-  u32 i0 = threadIdx.x * 2, i1 = i0 + 1;
-  u32 a = i0 < nSB ? sbHist[i0] : 0, b = i1 < nSB ? sbHist[i1] : 0;
-  u32 tot;
-  u32 ex = block_excl_scan<u32, 1024>(a + b, scratch, &tot);
-  if (i0 < nSB) { sbOff[i0] = ex; sbCursor[i0] = ex; }
-  if (i1 < nSB) { sbOff[i1] = ex + a; sbCursor[i1] = ex + a; }
-  if (threadIdx.x == 0) sbOff[nSB] = tot;
-  // chunks per super-bucket (the last, null, bucket gets none)
-  u32 ca = (i0 + 1 < nSB) ? (a + chunk - 1) / chunk : 0, cb = (i1 + 1 < nSB) ? (b + chunk - 1) / chunk : 0;
-  u32 ctot;
-  u32 cex = block_excl_scan<u32, 1024>(ca + cb, scratch, &ctot);
-  if (i0 < nSB) sbChunkOff[i0] = cex;
-  if (i1 < nSB) sbChunkOff[i1] = cex + ca;
-  if (threadIdx.x == 0) sbChunkOff[nSB] = ctot;
+  // nSB <= MAX_BINS: MAX_BINS / 1024 consecutive items per thread
+  constexpr int PER = MAX_BINS / 1024;
+  u32 v[PER], c[PER], sum = 0, csum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const u32 i = threadIdx.x * PER + k;
+    v[k] = i < nSB ? sbHist[i] : 0;
+    c[k] = i + 1 < nSB ? (v[k] + chunk - 1) / chunk : 0;  // chunks per super-bucket (the last, null, bucket gets none)
+    sum += v[k];
+    csum += c[k];
+  }
+  u32 tot, ctot;
+  u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
+  u32 cex = block_excl_scan<u32, 1024>(csum, scratch, &ctot);
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const u32 i = threadIdx.x * PER + k;
+    if (i < nSB) {
+      sbOff[i] = ex;
+      sbCursor[i] = ex;
+      sbChunkOff[i] = cex;
+    }
+    ex += v[k];
+    cex += c[k];
+  }
+  if (threadIdx.x == 0) {
+    sbOff[nSB] = tot;
+    sbChunkOff[nSB] = ctot;
+  }
 }
 
 // per-tile record counts of the three streams -> offsets + cursors; per-tile weight -> genome-wide
@@ -569,11 +583,16 @@ __global__ __launch_bounds__(SC_NT) void k_hist2(const R* __restrict__ in, const
 // and the tile counts are plain stores.  Pass 1 streams the super-bucket and counts (records
 // per tile, and for F the signed weight); pass 2 streams it again (it was just read: L2 /
 // Infinity Cache) in chunks that are ranked and sorted in LDS and written as tile-contiguous runs.
-constexpr int B2_NT = 1024;  // a super-bucket is a serial job: many threads keep it short
-template <typename R>
-__host__ __device__ constexpr size_t b2_lds_bytes(u32 nBins) {
-  return (size_t)B2_NT * ScCfg<R>::ITEMS * sizeof(R) + (size_t)(4 * nBins + 32) * 4;
+constexpr int B2_NT = 1024;
+constexpr int B2_STAGE_BYTES = 128 * 1024;  // a whole super-bucket is sorted in LDS when it fits (it usually does)
+constexpr int B2_LDS_MAX = 160 * 1024;
+__host__ __device__ constexpr u32 b2_table_bytes(u32 nBins) { return (4 * nBins + 32) * 4; }
+// stage bytes: 128 KiB unless the per-tile tables of a very large genome need the room
+__host__ __device__ constexpr u32 b2_stage_bytes(u32 nBins) {
+  return b2_table_bytes(nBins) + B2_STAGE_BYTES <= B2_LDS_MAX ? (u32)B2_STAGE_BYTES
+                                                               : ((B2_LDS_MAX - b2_table_bytes(nBins)) & ~16383u);
 }
+__host__ __device__ constexpr size_t b2_lds_bytes(u32 nBins) { return (size_t)b2_stage_bytes(nBins) + b2_table_bytes(nBins); }
 
 template <typename R>
 __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* __restrict__ out,
@@ -581,16 +600,71 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* 
                                                    u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
   constexpr int ITEMS = ScCfg<R>::ITEMS;
   constexpr int CHUNK = B2_NT * ITEMS;
+  constexpr int FITEMS = B2_STAGE_BYTES / (int)sizeof(R) / B2_NT;  // records per thread on the one-pass path
+  static_assert((u32)FITEMS * B2_NT <= 65536, "ranks are packed in 16 bits");
   extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
   const u32 nBins = 1u << sbShift;
+  const u32 stageBytes = b2_stage_bytes(nBins);
+  const u32 FCAP = stageBytes / (u32)sizeof(R);
   R* stage = reinterpret_cast<R*>(b2_lds);
-  u32* hist = reinterpret_cast<u32*>(stage + CHUNK);  // pass 1: records per tile; pass 2: records per tile of the chunk
-  u32* start = hist + nBins;                          // pass 1: weight sums;      pass 2: chunk-local run starts
-  u32* cursor = start + nBins;                        // next output position of every tile
-  u32* base = cursor + nBins;                         // pass 2: output position of the chunk's run
+  u32* hist = reinterpret_cast<u32*>(b2_lds + stageBytes);  // records per tile (of the chunk, in the chunked pass 2)
+  u32* start = hist + nBins;                                    // run starts (pass 1 of the chunked path: weight sums)
+  u32* cursor = start + nBins;                                  // chunked path: next output position of every tile
+  u32* base = cursor + nBins;                                   // chunked path: output position of the chunk's run
   u32* scratch = base + nBins;
   for (u32 seg = blockIdx.x; seg < nSeg; seg += gridDim.x) {
     const u32 begin = segOff[seg], end = segOff[seg + 1], segTileBase = seg << sbShift;
+    if (end - begin <= FCAP) {
+      // one pass: every record is read once into registers, ranked, sorted in LDS and written back
+      // as one contiguous, fully coalesced stream (each output line is written exactly once)
+      __syncthreads();
+      for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; cursor[i] = 0; }
+      __syncthreads();
+      R r[FITEMS];
+      u32 rk[FITEMS / 2];  // ranks are below FCAP <= 2^16: two per register
+#pragma unroll
+      for (int k = 0; k < FITEMS / 2; k++) rk[k] = 0;
+#pragma unroll
+      for (int k = 0; k < FITEMS; k++) {
+        const u32 idx = begin + k * B2_NT + threadIdx.x;
+        if (idx < end) r[k] = in[idx];
+      }
+#pragma unroll
+      for (int k = 0; k < FITEMS; k++) {
+        const u32 idx = begin + k * B2_NT + threadIdx.x;
+        if (idx < end) {
+          const u32 b = RecT<R>::tile(r[k]) - segTileBase;
+          rk[k >> 1] |= atomicAdd(&hist[b], 1u) << (16 * (k & 1));
+          if (sizeof(R) == 8) atomicAdd(&cursor[b], (u32)(int)(int8_t)((u64)r[k] & 0xFF));
+        }
+      }
+      __syncthreads();
+      u32 carry = 0;
+      for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
+        const u32 b = b0 + threadIdx.x;
+        const u32 c = b < nBins ? hist[b] : 0;
+        u32 tot;
+        const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
+        if (b < nBins) {
+          start[b] = carry + ex;
+          if (segTileBase + b < nTiles) {  // (the last super-bucket may be short of tiles)
+            tileCnt[segTileBase + b] = c;
+            if (sizeof(R) == 8) tileWsum[segTileBase + b] += (int)cursor[b];  // the slot is this workgroup's alone
+          }
+        }
+        carry += tot;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < FITEMS; k++) {
+        const u32 idx = begin + k * B2_NT + threadIdx.x;
+        if (idx < end) stage[start[RecT<R>::tile(r[k]) - segTileBase] + ((rk[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)] = r[k];
+      }
+      __syncthreads();
+      const u32 cnt = end - begin;
+      for (u32 i = threadIdx.x; i < cnt; i += B2_NT) out[begin + i] = stage[i];
+    } else {
+    // chunked two-pass path for a super-bucket that does not fit (a pile-up of records in one place)
     __syncthreads();
     for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; start[i] = 0; }
     __syncthreads();
@@ -674,6 +748,7 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* 
         out[base[b] + (i - start[b])] = v;
       }
     }
+    }  // chunked path
   }
 }
 

@@ -302,3 +302,19 @@ def test_giant_candidate_takes_the_wavefront_walk():
     widest = max(np.searchsorted(e, q["end"]) - np.searchsorted(e, q["start"]) for q in pk)
     assert widest > 1024, widest
     assert np.array_equal(o.get_peaks()["auc"].view(np.uint32), pk["auc"].view(np.uint32))
+
+
+def test_crowded_tile_takes_the_chunked_bucket_path():
+    """More endpoint records in one super-bucket than the one-pass LDS sort holds (32,768): the
+    level-2 bucket kernel falls back to its chunked two-pass path."""
+    rng = np.random.default_rng(13)
+    lens = [400_000]
+    bg = synth.make_fragments(lens, 3000, seed=7)
+    st = rng.integers(100_000, 104_000, 70_000).astype(np.uint32)
+    ln = rng.integers(100, 200, 70_000).astype(np.uint32)
+    crowd = np.zeros(len(st), dtype=B.EVENT_DTYPE)
+    crowd["chrom"], crowd["start"], crowd["end"], crowd["count"] = 0, st, st + ln, 1
+    case = dict(lens=lens, replicates=[dict(save=None, treat=np.concatenate([bg, crowd]), ctrl=bg)])
+    o, h, so, sh = run_both(case, B.make_params(pq=0.01, min_auc=20.0))
+    assert_same_run(o, h, so, sh, case)
+    assert h.n_peaks >= 1
