@@ -84,6 +84,7 @@ struct gx_ctx {
   hipStream_t stream = nullptr;
   int maskIdx = -1;             // reps[] entry whose sig / skip masks sit in swMask (k_pack_pval)
   u32 maskN = 0;
+  size_t maskStride = 0;        // words between the sig / skip / brk masks in swMask
   hipStream_t side = nullptr;   // small read-backs that must not stall the main stream
   hipEvent_t sideEv = nullptr;
   std::string err;
@@ -111,7 +112,7 @@ struct gx_ctx {
   };
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3], tileCursor[3];
-  DevBuf looseC, pairLogE, pairCtab, fragSum, tileDeep, fragList, zeroArena;
+  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};
@@ -825,6 +826,7 @@ int gx_pvalues(gx_ctx* ctx) {
       skipM = sigM + (nWords + 2);
       ctx->maskIdx = (int)ctx->reps.size();
       ctx->maskN = n;
+      ctx->maskStride = nWords + 2;
     }
     hipLaunchKernelGGL(k_pack_pval, dim3(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s, pin,
                        ctx->nTiles, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(),
@@ -863,9 +865,9 @@ int gx_pvalues(gx_ctx* ctx) {
     RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>()};
     RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>()};
     Merge2Out mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->tileIvCount.as<u32>()};
+    // (ctx->tileMeta still holds the control build's descriptors: pos0 / len / flags do not depend on the sample)
     hipLaunchKernelGGL(k_merge2, dim3(std::min(nTiles, (u32)(8 * ctx->numCU))), dim3(MG_NT), 0, s, A, Bc,
-                       ctx->dScal.as<Scalars>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo,
-                       ctx->dStatus.as<u32>());
+                       ctx->dScal.as<Scalars>(), ctx->tileMeta.as<TileMeta>(), nTiles, mo, ctx->dStatus.as<u32>());
     if (int rc__ = dbg_sync(ctx, "k_merge2")) return rc__;
     const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
     HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));
@@ -882,16 +884,39 @@ int gx_pvalues(gx_ctx* ctx) {
                        ctx->pairLogE.as<double>(), ctx->pairCtab.as<CtrlEntry>());
     PackPairsIn ppi{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->expt.tileIvOff.as<u32>(),
                     ctx->ctrl.tileIvOff.as<u32>(), pa.tileOff.as<u32>()};
-    hipLaunchKernelGGL(k_pack_pairs, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, ppi, nTiles,
-                       ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(), ctx->pairCtab.as<CtrlEntry>(),
-                       pa.end.as<u32>(), pa.expt.as<float>(), pa.ctrl.as<float>(), pa.p.as<float>(),
-                       ctx->dStatus.as<u32>());
+    HIPCHECK(ctx->pairP2d.ensure((size_t)PT_N * PT_N * 4));
+    HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
+    hipLaunchKernelGGL(k_pair_tab2d, dim3(PT_N * PT_N / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(),
+                       ctx->pairLogE.as<double>(), ctx->pairCtab.as<CtrlEntry>(), ctx->pairP2d.as<float>());
+    // p-mode: the sweep's masks are filled on the way (the interval count is only bounded here, so the
+    // masks are laid out for the bound and gx_find_peaks is told the stride)
+    u64 *sigM = nullptr, *skipM = nullptr;
+    ctx->maskIdx = -1;
+    if (!ctx->par.qval_opt) {
+      const size_t stride = (cap + 63) / 64 + 2;
+      HIPCHECK(ctx->swMask.ensure(stride * 8 * 3));
+      HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, stride * 8 * 3, s));
+      sigM = ctx->swMask.as<u64>();
+      skipM = sigM + stride;
+      ctx->maskIdx = (int)ctx->reps.size();
+      ctx->maskStride = stride;
+    }
+    HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
+    hipLaunchKernelGGL(k_pack_pairs, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s, ppi,
+                       nTiles, ctx->pairCtab.as<CtrlEntry>(), ctx->pairP2d.as<float>(), pa.end.as<u32>(),
+                       pa.expt.as<float>(), pa.ctrl.as<float>(), pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                       ctx->fragList.as<u32>(), misc + M_TICKET);
+    hipLaunchKernelGGL(k_pack_pairs_full, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(4 * ctx->numCU)))), dim3(256), 0, s,
+                       ppi, ctx->fragList.as<u32>(), misc + M_TICKET, ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(),
+                       ctx->pairCtab.as<CtrlEntry>(), pa.expt.as<float>(), pa.ctrl.as<float>(), pa.p.as<float>(),
+                       ctx->par.thr, sigM, skipM, ctx->dStatus.as<u32>());
     if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(&pa.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
     int rc = read_status(ctx);
     if (rc) return rc;
+    ctx->maskN = pa.n;
     pa.hasPiles = true;
     pa.ctrlIsConst = false;
   }
@@ -1066,15 +1091,15 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   const u32 nWords = (n + 63) / 64;
   const u32 wChunks = (nWords + SW_CHUNK - 1) / SW_CHUNK;
   // three bit masks + chunk count/offset scratch
-  const bool haveMasks = !ctx->par.qval_opt && ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;  // from k_pack_pval
-  HIPCHECK(ctx->swMask.ensure((size_t)(nWords + 2) * 8 * 3));
+  const bool haveMasks = !ctx->par.qval_opt && ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;  // from the pack kernels
+  const size_t mStride = haveMasks ? ctx->maskStride : (size_t)nWords + 2;
+  HIPCHECK(ctx->swMask.ensure(mStride * 8 * 3));
   if (haveMasks)
-    HIPCHECK(hipMemsetAsync(ctx->swMask.as<u64>() + 2 * (size_t)(nWords + 2), 0, (size_t)(nWords + 2) * 8, s));
+    HIPCHECK(hipMemsetAsync(ctx->swMask.as<u64>() + 2 * mStride, 0, mStride * 8, s));
   else
-    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, (size_t)(nWords + 2) * 8 * 3, s));
+    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, mStride * 8 * 3, s));
   ctx->maskIdx = -1;
-  SweepMasks SM{ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + (nWords + 2), ctx->swMask.as<u64>() + 2 * (size_t)(nWords + 2),
-                nWords};
+  SweepMasks SM{ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + mStride, ctx->swMask.as<u64>() + 2 * mStride, nWords};
   HIPCHECK(hipMemsetAsync(misc + M_SWEEP_FIRST, 0, M_SWEEP_WORDS * 4, s));  // run / candidate / peak counters, peak bp
   const float* qPtr = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
   u32 R = 0, nPeaks = 0;

@@ -46,82 +46,134 @@ __device__ __forceinline__ float ctrl_net(int v, float factor, float lambda, boo
 }
 
 // No inter-workgroup dependency (like k_tile): counts go to k_scan_counts, packing to k_pack_pairs.
+// Per tile the work is small (a few hundred breakpoints) and the kernel is bound by the chain of
+// dependent loads, so, as in k_tile, tile headers are fetched two tiles ahead and the first MG_NT
+// intervals of both inputs one tile ahead; the pileup values of the tile's intervals are staged
+// in LDS so that the emit loop does no dependent global gather.
+constexpr int MG_CAP = 1024;  // intervals per input and tile whose values are staged in LDS
+
+struct MergeHdr {
+  u32 a0, a1c, a1, b0, b1c, b1, pos0, len, flags;  // flags: 1 active, 2 last tile of its chromosome
+};
+
+__device__ __forceinline__ MergeHdr merge_hdr(const RleIn& A, const RleIn& B, const TileMeta* __restrict__ meta, u32 t) {
+  MergeHdr h;
+  const TileMeta m = meta[t];
+  h.pos0 = m.pos0;
+  h.len = m.len;
+  h.flags = m.flags & 3u;
+  h.a0 = A.tileOff[t];
+  h.a1 = A.tileOff[t + 1];
+  h.b0 = B.tileOff[t];
+  h.b1 = B.tileOff[t + 1];
+  if (!(h.flags & 1u)) { h.a1 = h.a0; h.b1 = h.b0; }
+  const bool lastTile = h.flags & 2u;
+  h.a1c = (lastTile && h.a1 > h.a0) ? h.a1 - 1 : h.a1;  // the chromosome-closing interval is handled apart
+  h.b1c = (lastTile && h.b1 > h.b0) ? h.b1 - 1 : h.b1;
+  return h;
+}
+
 __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalars* __restrict__ sc,
-                                                  const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
-                                                  u32 nTiles, Merge2Out out, u32* __restrict__ st) {
+                                                  const TileMeta* __restrict__ meta, u32 nTiles, Merge2Out out,
+                                                  u32* __restrict__ st) {
   __shared__ u32 bmA[MG_WORDS], bmB[MG_WORDS], bmC[MG_WORDS];
-  __shared__ u32 scratch[8];
+  __shared__ u64 scratch64[8];
+  __shared__ int sA[MG_CAP + 1], sC[MG_CAP + 1];
+  static_assert(MG_WPT == 1, "one bitmap word per thread");
   const float factor = sc->factor, lambda = sc->lambda;
   u32 neg = 0;
-  for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < MG_WORDS; i += MG_NT) { bmA[i] = 0; bmB[i] = 0; bmC[i] = 0; }
-    __syncthreads();
-    const u32 ci = tileChrom[t];
-    const DChrom c = chroms[ci];
-    const bool active = chrom_active(c);
-    const u32 tl = t - c.tileBase, pos0 = tl << TB;
-    const bool lastTile = tl + 1 == c.nTiles;
-    u32 a0 = A.tileOff[t], a1 = A.tileOff[t + 1], b0 = B.tileOff[t], b1 = B.tileOff[t + 1];
-    const u32 slot = a0 + b0;
-    if (!active) { a1 = a0; b1 = b0; }
-    const u32 a1c = (lastTile && a1 > a0) ? a1 - 1 : a1;  // the chromosome-closing interval is handled apart
-    const u32 b1c = (lastTile && b1 > b0) ? b1 - 1 : b1;
-    for (u32 i = a0 + threadIdx.x; i < a1c; i += MG_NT) {
-      u32 off = A.end[i] - pos0;
-      atomicOr(&bmA[off >> 5], 1u << (off & 31));
+  const u32 G = gridDim.x;
+  bmA[threadIdx.x] = 0;
+  bmB[threadIdx.x] = 0;
+  bmC[threadIdx.x] = 0;
+  MergeHdr h1{}, h2{};
+  if (blockIdx.x < nTiles) h1 = merge_hdr(A, B, meta, blockIdx.x);
+  if (blockIdx.x + G < nTiles) h2 = merge_hdr(A, B, meta, blockIdx.x + G);
+  u32 eA1 = 0, eB1 = 0;
+  int vA1 = 0, vB1 = 0, vBn1 = 0;
+  if (h1.a0 + threadIdx.x < h1.a1c) { eA1 = A.end[h1.a0 + threadIdx.x]; vA1 = A.v[h1.a0 + threadIdx.x]; }
+  if (h1.b0 + threadIdx.x < h1.b1c) {
+    eB1 = B.end[h1.b0 + threadIdx.x];
+    vB1 = B.v[h1.b0 + threadIdx.x];
+    vBn1 = B.v[h1.b0 + threadIdx.x + 1];
+  }
+  __syncthreads();
+  for (u32 t = blockIdx.x; t < nTiles; t += G) {
+    const MergeHdr h = h1;
+    const u32 eA0 = eA1, eB0 = eB1;
+    const int vA0 = vA1, vB0 = vB1, vBn0 = vBn1;
+    h1 = h2;
+    if (t + G < nTiles) {
+      if (h1.a0 + threadIdx.x < h1.a1c) { eA1 = A.end[h1.a0 + threadIdx.x]; vA1 = A.v[h1.a0 + threadIdx.x]; }
+      if (h1.b0 + threadIdx.x < h1.b1c) {
+        eB1 = B.end[h1.b0 + threadIdx.x];
+        vB1 = B.v[h1.b0 + threadIdx.x];
+        vBn1 = B.v[h1.b0 + threadIdx.x + 1];  // exists: at least the closing interval follows
+      }
     }
-    for (u32 i = b0 + threadIdx.x; i < b1c; i += MG_NT) {
-      u32 off = B.end[i] - pos0;
+    if (t + 2 * G < nTiles) h2 = merge_hdr(A, B, meta, t + 2 * G);
+    const bool active = h.flags & 1u, lastTile = h.flags & 2u;
+    const u32 a0 = h.a0, b0 = h.b0, pos0 = h.pos0;
+    const u32 nA = h.a1c - a0, nB = h.b1c - b0;
+    const bool staged = nA <= MG_CAP && nB <= MG_CAP;  // block-uniform
+    // (bitmap words are zero here: each thread clears its words as soon as it has read them)
+    for (u32 j = threadIdx.x; j < nA; j += MG_NT) {
+      const u32 e = j < MG_NT ? eA0 : A.end[a0 + j];
+      const int v = j < MG_NT ? vA0 : A.v[a0 + j];
+      const u32 off = e - pos0;
+      atomicOr(&bmA[off >> 5], 1u << (off & 31));
+      if (staged) sA[j] = v;
+    }
+    for (u32 j = threadIdx.x; j < nB; j += MG_NT) {
+      const u32 e = j < MG_NT ? eB0 : B.end[b0 + j];
+      const int v = j < MG_NT ? vB0 : B.v[b0 + j];
+      const int vn = j < MG_NT ? vBn0 : B.v[b0 + j + 1];
+      const u32 off = e - pos0;
       bool ng1, ng2;
-      float here = ctrl_net(B.v[i], factor, lambda, &ng1);
-      float next = ctrl_net(B.v[i + 1], factor, lambda, &ng2);  // i + 1 exists: at least the closing interval
+      const float here = ctrl_net(v, factor, lambda, &ng1);
+      const float next = ctrl_net(vn, factor, lambda, &ng2);
       neg |= ng1 | ng2;
       atomicOr(&bmC[off >> 5], 1u << (off & 31));
       if (here != next) atomicOr(&bmB[off >> 5], 1u << (off & 31));  // 2122: net != MAX(val, lambda)
+      if (staged) sC[j] = v;
+    }
+    if (active && staged && threadIdx.x == 0) {  // the interval that covers what follows the tile's last breakpoint
+      sA[nA] = A.v[h.a1c];
+      sC[nB] = B.v[h.b1c];
     }
     __syncthreads();
-    u32 wU[MG_WPT], wA[MG_WPT], wC[MG_WPT];
-    u32 cU = 0, cA = 0, cC = 0;
-#pragma unroll
-    for (int k = 0; k < MG_WPT; k++) {
-      int w = threadIdx.x * MG_WPT + k;
-      wA[k] = bmA[w];
-      wC[k] = bmC[w];
-      wU[k] = wA[k] | bmB[w];
-      cU += __popc(wU[k]);
-      cA += __popc(wA[k]);
-      cC += __popc(wC[k]);
-    }
-    u32 tU, tA, tC;
-    u32 exU = block_excl_scan<u32, MG_NT>(cU, scratch, &tU);
-    u32 exA = block_excl_scan<u32, MG_NT>(cA, scratch, &tA);
-    u32 exC = block_excl_scan<u32, MG_NT>(cC, scratch, &tC);
+    const u32 wA = bmA[threadIdx.x], wC = bmC[threadIdx.x], wU = wA | bmB[threadIdx.x];
+    bmA[threadIdx.x] = 0;
+    bmB[threadIdx.x] = 0;
+    bmC[threadIdx.x] = 0;
+    const u32 cU = __popc(wU), cA = __popc(wA), cC = __popc(wC);
+    // one scan for the three counts (each total <= TILE + 1 < 2^16)
+    u64 tot3;
+    const u64 ex3 = block_excl_scan<u64, MG_NT>((u64)cU | ((u64)cA << 16) | ((u64)cC << 32), scratch64, &tot3);
+    const u32 tU = (u32)tot3 & 0xFFFFu;
+    const u32 exU = (u32)ex3 & 0xFFFFu, exA = (u32)(ex3 >> 16) & 0xFFFFu, exC = (u32)(ex3 >> 32) & 0xFFFFu;
+    const u32 slot = a0 + b0;
     if (threadIdx.x == 0) out.tileCount[t] = active ? tU + (lastTile ? 1u : 0u) : 0u;
     if (active) {  // block-uniform
       u32 o = slot + exU;
-#pragma unroll
-      for (int k = 0; k < MG_WPT; k++) {
-        u32 bits = wU[k];
-        while (bits) {
-          int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          u32 below = (1u << b) - 1;
-          out.end[o] = pos0 + (threadIdx.x * MG_WPT + k) * 32 + b;
-          out.exptV[o] = A.v[a0 + exA + __popc(wA[k] & below)];
-          out.ctrlV[o] = B.v[b0 + exC + __popc(wC[k] & below)];
-          o++;
-        }
-        exA += __popc(wA[k]);
-        exC += __popc(wC[k]);
+      for (u32 bits = wU; bits; bits &= bits - 1) {
+        const int b = __ffs(bits) - 1;
+        const u32 below = (1u << b) - 1;
+        const u32 ia = exA + __popc(wA & below), ic = exC + __popc(wC & below);
+        out.end[o] = pos0 + threadIdx.x * 32 + b;
+        out.exptV[o] = staged ? sA[ia] : A.v[a0 + ia];
+        out.ctrlV[o] = staged ? sC[ic] : B.v[b0 + ic];
+        o++;
       }
       if (lastTile && threadIdx.x == 0) {  // 1779-1788 at the chromosome end: both pileups close at len
-        u32 oc = slot + tU;
-        out.end[oc] = c.len;
-        out.exptV[oc] = A.v[a1 - 1];
-        out.ctrlV[oc] = B.v[b1 - 1];
+        const u32 oc = slot + tU;
+        out.end[oc] = h.len;
+        out.exptV[oc] = A.v[h.a1 - 1];
+        out.ctrlV[oc] = B.v[h.b1 - 1];
       }
     }
+    // (block_excl_scan ends with a barrier after the scratch reads; the staged values are read above)
+    __syncthreads();
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
 }
@@ -232,26 +284,135 @@ struct PackPairsIn {
   const u32* tileOff;  // tight offsets
 };
 
-// loose slots -> tight (end, expt, ctrl, p); one wavefront per tile
-__global__ __launch_bounds__(256) void k_pack_pairs(PackPairsIn in, u32 nTiles, const Scalars* __restrict__ sc,
-                                                    const double* __restrict__ logE, const CtrlEntry* __restrict__ ctab,
-                                                    u32* __restrict__ end, float* __restrict__ expt,
-                                                    float* __restrict__ ctrl, float* __restrict__ p,
-                                                    u32* __restrict__ st) {
+// Whole pileups (no fractional part) below PT_N on both sides -- nearly every interval of an
+// ordinary run -- have their p-value in a PT_N x PT_N table built once per replicate by the same
+// routine; the corner PT_HOT x PT_HOT of it and the control's net values sit in LDS.
+constexpr u32 PT_N = 256, PT_HOT = 64;
+
+__global__ __launch_bounds__(256) void k_pair_tab2d(const Scalars* __restrict__ sc, const double* __restrict__ logE,
+                                                    const CtrlEntry* __restrict__ ctab, float* __restrict__ p2d) {
+  const float factor = sc->factor, lambda = sc->lambda;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < PT_N * PT_N; i += gridDim.x * 256) {
+    float e, c;
+    bool ng;
+    p2d[i] = pval_pair((int)((i / PT_N) * GX_UNIT), (int)((i % PT_N) * GX_UNIT), &e, &c, factor, lambda, logE, ctab, &ng);
+  }
+}
+
+// loose slots -> tight (end, expt, ctrl, p); one wavefront per tile.  Table look-ups only: a tile
+// holding any other pair of values is put on a list and redone by k_pack_pairs_full (whose
+// double-precision path would cost this kernel most of its occupancy).
+__global__ __launch_bounds__(256) void k_pack_pairs(PackPairsIn in, u32 nTiles, const CtrlEntry* __restrict__ ctab,
+                                                    const float* __restrict__ p2d, u32* __restrict__ end,
+                                                    float* __restrict__ expt, float* __restrict__ ctrl,
+                                                    float* __restrict__ p, float thr, u64* __restrict__ sigMask,
+                                                    u64* __restrict__ skipMask, u32* __restrict__ heavyList,
+                                                    u32* __restrict__ nHeavy) {
+  __shared__ float hot[PT_HOT * PT_HOT];
+  __shared__ float net[PT_N];
+  for (int i = threadIdx.x; i < (int)(PT_HOT * PT_HOT); i += 256) hot[i] = p2d[(i / PT_HOT) * PT_N + (i % PT_HOT)];
+  for (int i = threadIdx.x; i < (int)PT_N; i += 256) net[i] = ctab[i * GX_UNIT].net;
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const u32 stride = gridDim.x * 4;
+  u32 t = blockIdx.x * 4 + wv;
+  u32 src1 = 0, dst1 = 0, n1 = 0;
+  if (t < nTiles) {
+    src1 = in.slotA[t] + in.slotB[t];
+    dst1 = in.tileOff[t];
+    n1 = in.tileOff[t + 1] - dst1;
+  }
+  for (; t < nTiles; t += stride) {
+    const u32 src = src1, dst = dst1, n = n1;
+    if (t + stride < nTiles) {
+      src1 = in.slotA[t + stride] + in.slotB[t + stride];
+      dst1 = in.tileOff[t + stride];
+      n1 = in.tileOff[t + stride + 1] - dst1;
+    }
+    bool miss = false;
+    for (u32 b = 0; b < n; b += 256) {
+      u32 e[4];
+      int ev[4], cv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 i = b + k * 64 + lane;
+        e[k] = 0; ev[k] = 0; cv[k] = 0;
+        if (i < n) {
+          e[k] = in.looseEnd[src + i];
+          ev[k] = in.looseE[src + i];
+          cv[k] = in.looseC[src + i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 i = b + k * 64 + lane;
+        float pv = 0.0f;
+        if (i < n) {
+          float ef = 0.0f, cf = GX_SKIPF;
+          if (ev[k] == V_MARK || cv[k] == V_MARK) {
+            // inside an excluded region both pileups carry the mark: treatment 0, control and p SKIP
+            // (pairs with a single mark do not occur; the full kernel decides them anyway)
+            if (ev[k] == V_MARK && cv[k] == V_MARK) pv = GX_SKIPF; else miss = true;
+          } else {
+            const u32 ec = __umulhi((u32)ev[k], 0x88888889u) >> 6, cc = __umulhi((u32)cv[k], 0x88888889u) >> 6;
+            if (ev[k] >= 0 && cv[k] >= 0 && ec < PT_N && cc < PT_N && ec * GX_UNIT == (u32)ev[k] && cc * GX_UNIT == (u32)cv[k]) {
+              ef = (float)ec;
+              cf = net[cc];
+              pv = (ec < PT_HOT && cc < PT_HOT) ? hot[ec * PT_HOT + cc] : p2d[ec * PT_N + cc];
+            } else
+              miss = true;
+          }
+          end[dst + i] = e[k];
+          expt[dst + i] = ef;
+          ctrl[dst + i] = cf;
+          p[dst + i] = pv;
+        }
+        if (sigMask) {  // the sweep's masks while p is at hand (pre-zeroed words; a redone tile ORs its own bits in)
+          const u64 sg = __ballot(pv > thr), sk = __ballot(pv == GX_SKIPF);
+          if ((sg | sk) && lane == 0) {
+            const u32 pos = dst + b + k * 64, w = pos >> 6, sh = pos & 63;
+            if (sg) {
+              atomicOr((unsigned long long*)&sigMask[w], (unsigned long long)(sg << sh));
+              if (sh && (sg >> (64 - sh))) atomicOr((unsigned long long*)&sigMask[w + 1], (unsigned long long)(sg >> (64 - sh)));
+            }
+            if (sk) {
+              atomicOr((unsigned long long*)&skipMask[w], (unsigned long long)(sk << sh));
+              if (sh && (sk >> (64 - sh))) atomicOr((unsigned long long*)&skipMask[w + 1], (unsigned long long)(sk >> (64 - sh)));
+            }
+          }
+        }
+      }
+    }
+    if (__ballot(miss) && lane == 0) heavyList[atomicAdd(nHeavy, 1u)] = t;
+  }
+}
+
+// the listed tiles again, every pair evaluated in full (fractional pileups, very deep ones)
+__global__ __launch_bounds__(256) void k_pack_pairs_full(PackPairsIn in, const u32* __restrict__ heavyList,
+                                                         const u32* __restrict__ nHeavy, const Scalars* __restrict__ sc,
+                                                         const double* __restrict__ logE, const CtrlEntry* __restrict__ ctab,
+                                                         float* __restrict__ expt, float* __restrict__ ctrl,
+                                                         float* __restrict__ p, float thr, u64* __restrict__ sigMask,
+                                                         u64* __restrict__ skipMask, u32* __restrict__ st) {
   const float factor = sc->factor, lambda = sc->lambda;
   const int wv = threadIdx.x >> 6, lane = lane_id();
+  const u32 nH = *nHeavy;
   u32 neg = 0;
-  for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
+  for (u32 li = blockIdx.x * 4 + wv; li < nH; li += gridDim.x * 4) {
+    const u32 t = heavyList[li];
     const u32 src = in.slotA[t] + in.slotB[t], dst = in.tileOff[t], n = in.tileOff[t + 1] - dst;
     for (u32 i = lane; i < n; i += 64) {
       bool ng;
       float e, c;
-      float pv = pval_pair(in.looseE[src + i], in.looseC[src + i], &e, &c, factor, lambda, logE, ctab, &ng);
+      const float pv = pval_pair(in.looseE[src + i], in.looseC[src + i], &e, &c, factor, lambda, logE, ctab, &ng);
       neg |= ng;
-      end[dst + i] = in.looseEnd[src + i];
       expt[dst + i] = e;
       ctrl[dst + i] = c;
       p[dst + i] = pv;
+      if (sigMask) {  // the light pass saw p = 0 for the pairs it skipped: only bits to add
+        if (pv > thr) atomicOr((unsigned long long*)&sigMask[(dst + i) >> 6], 1ull << ((dst + i) & 63));
+        if (pv == GX_SKIPF) atomicOr((unsigned long long*)&skipMask[(dst + i) >> 6], 1ull << ((dst + i) & 63));
+      }
     }
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
