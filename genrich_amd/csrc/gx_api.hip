@@ -56,6 +56,34 @@ struct DevBuf {
   bool own = true;
 };
 
+// Small device -> host read-backs land in one pinned block: a copy into pageable memory is staged and
+// blocks the caller, a copy into pinned memory is an ordinary asynchronous packet.
+struct HostMail {
+  Scalars scal;
+  long long acc[2];
+  uint64_t peakBP, genome;
+  u32 nF, nIv, status, R, nPeaks, nMerged, D, n;
+};
+
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+};
+
 struct Pileup {  // run-length pileup of one sample (treatment or control)
   DevBuf ivEnd, ivV, tileIvOff, chromIvOff;
   u32 nIv = 0;
@@ -115,7 +143,7 @@ struct gx_ctx {
   DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
-  Scalars hScal{};
+  Scalars hScal{};  // host copy of the device scalars (refreshed from the mail block)
   std::vector<PArray> reps;
   int finalIdx = -1;
   // BH
@@ -123,7 +151,11 @@ struct gx_ctx {
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp;
   // sweep
   DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
-  std::vector<gx_peak> hPeaks;
+  PinnedBuf hPeaks;             // the peak list on the host (pinned: the read-back is asynchronous)
+  size_t nHostPeaks = 0;
+  u32* nIvTarget = nullptr;
+  PinnedBuf mailBuf;
+  HostMail* mail = nullptr;
   uint64_t genomeLenUsed = 0, peakBP = 0;
   // collectives
   int rank = 0, world = 1;
@@ -135,6 +167,7 @@ struct gx_ctx {
   std::vector<DevBuf> pool;
   // timing
   std::vector<Phase> phases;
+  size_t nPhases = 0;
   std::vector<float> phaseMs;
   std::string phaseNames;
 };
@@ -190,15 +223,19 @@ int dbg_sync(gx_ctx* ctx, const char* what) {
   return GX_OK;
 }
 
+// phase timers: the event pairs are created once and reused run after run
 void phase_begin(gx_ctx* ctx, const char* name) {
-  Phase ph;
+  if (ctx->nPhases == ctx->phases.size()) {
+    Phase ph;
+    (void)hipEventCreate(&ph.a);
+    (void)hipEventCreate(&ph.b);
+    ctx->phases.push_back(ph);
+  }
+  Phase& ph = ctx->phases[ctx->nPhases++];
   ph.name = name;
-  (void)hipEventCreate(&ph.a);
-  (void)hipEventCreate(&ph.b);
   (void)hipEventRecord(ph.a, ctx->stream);
-  ctx->phases.push_back(ph);
 }
-void phase_end(gx_ctx* ctx) { (void)hipEventRecord(ctx->phases.back().b, ctx->stream); }
+void phase_end(gx_ctx* ctx) { (void)hipEventRecord(ctx->phases[ctx->nPhases - 1].b, ctx->stream); }
 
 int status_to_rc(gx_ctx* ctx, u32 st) {
   if (!st) return GX_OK;
@@ -223,10 +260,9 @@ int status_to_rc(gx_ctx* ctx, u32 st) {
 }
 
 int read_status(gx_ctx* ctx) {
-  u32 st = 0;
-  HIPCHECK(hipMemcpyAsync(&st, ctx->dStatus.p, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(hipMemcpyAsync(&ctx->mail->status, ctx->dStatus.p, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(hipStreamSynchronize(ctx->stream));
-  return status_to_rc(ctx, st);
+  return status_to_rc(ctx, ctx->mail->status);
 }
 
 uint64_t genome_len_for(const gx_ctx* ctx, const std::vector<uint8_t>& present) {
@@ -359,7 +395,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   size_t off = 0;
   for (auto& seg : segs) {
     if (!seg.n) continue;
-    u32 blocks = (u32)std::min<size_t>((seg.n + 255) / 256, 256 * 16);
+    // every workgroup flushes its two LDS histograms with global atomics: at least 8 K events each
+    u32 blocks = (u32)std::max<size_t>(1, std::min<size_t>((seg.n + 8191) / 8192, 256 * 16));
     if (unit32)
       hipLaunchKernelGGL(k_convert<true>, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, (u32)off, ctx->dChrom.as<DChrom>(),
                          nChrom, ctx->sbShift, nSB, co, ctx->dStatus.as<u32>());
@@ -374,7 +411,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
                  // stream while the main stream starts bucketing the unit-weight keys
     HIPCHECK(hipEventRecord(ctx->sideEv, s));
     HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->sideEv, 0));
-    HIPCHECK(hipMemcpyAsync(&nF, &ff->nF, 4, hipMemcpyDeviceToHost, ctx->side));
+    HIPCHECK(hipMemcpyAsync(&ctx->mail->nF, &ff->nF, 4, hipMemcpyDeviceToHost, ctx->side));
   }
   phase_end(ctx);
 
@@ -383,7 +420,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     if (int rc = sort_stream<u32>(ctx, SS, nEv, 0)) return rc;
     if (int rc = sort_stream<u32>(ctx, SE, nEv, 1)) return rc;
   }
-  if (unit32) HIPCHECK(hipStreamSynchronize(ctx->side));
+  if (unit32) {
+    HIPCHECK(hipStreamSynchronize(ctx->side));
+    nF = ctx->mail->nF;
+  }
   if (nF) {
     HIPCHECK(SF.b.ensure((size_t)nF * 8 + 16));
     hipLaunchKernelGGL((k_hist1<u64>), dim3(std::max(1u, std::min((nF + 255) / 256, 4096u))), dim3(256), 0, s, SF.a.as<u64>(),
@@ -468,7 +508,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   phase_end(ctx);
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipMemcpyAsync(&out.nIv, ctx->misc.as<u32>() + M_NIV, 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipMemcpyAsync(&ctx->mail->nIv, ctx->misc.as<u32>() + M_NIV, 4, hipMemcpyDeviceToHost, s));
+  ctx->nIvTarget = &out.nIv;  // filled from the mail block once finish_scalars has synchronised
   return GX_OK;
 }
 
@@ -477,7 +518,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
   hipStream_t s = ctx->stream;
   Scalars* ds = ctx->dScal.as<Scalars>();
   if (ctx->world > 1 && ctx->allreduce) {
-    long long acc[2];
+    long long* acc = ctx->mail->acc;
     long long* dacc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
     HIPCHECK(hipMemcpyAsync(acc, dacc, 16, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
@@ -492,8 +533,100 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
   }
   hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
-  HIPCHECK(hipMemcpyAsync(&ctx->hScal, ds, sizeof(Scalars), hipMemcpyDeviceToHost, s));
-  return read_status(ctx);
+  HIPCHECK(hipMemcpyAsync(&ctx->mail->scal, ds, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+  int rc = read_status(ctx);
+  ctx->hScal = ctx->mail->scal;
+  if (ctx->nIvTarget) *ctx->nIvTarget = ctx->mail->nIv;
+  ctx->nIvTarget = nullptr;
+  return rc;
+}
+
+// tile space, super-buckets, -E edge lists and the chromosome table for the chromosomes this
+// context works on: not skipped (-e), not empty, and owned by this rank (gx_set_owned)
+int layout_tiles(gx_ctx* ctx) {
+  const int n = (int)ctx->nChrom;
+  const std::vector<uint32_t>& len = ctx->len;
+  ctx->hChrom.assign(n, DChrom{});
+  std::vector<u32> tileChrom;
+  u32 t = 0;
+  for (int i = 0; i < n; i++) {
+    DChrom& c = ctx->hChrom[i];
+    c.len = len[i];
+    if (ctx->skip[i] || !ctx->owned[i] || len[i] == 0) {
+      c.tileBase = NULL_TILE;
+      c.nTiles = 0;
+      continue;
+    }
+    c.tileBase = t;
+    c.nTiles = (u32)(((uint64_t)len[i] + TILE - 1) >> TB);
+    for (u32 k = 0; k < c.nTiles; k++) tileChrom.push_back((u32)i);
+    t += c.nTiles;
+  }
+  if (t == 0) {
+    // a rank that owns nothing still needs a (dormant) tile space: the first analyzable chromosome's
+    for (int i = 0; i < n && t == 0; i++)
+      if (!ctx->skip[i] && len[i] != 0) {
+        DChrom& c = ctx->hChrom[i];
+        c.tileBase = 0;
+        c.nTiles = (u32)(((uint64_t)len[i] + TILE - 1) >> TB);
+        tileChrom.assign(c.nTiles, (u32)i);
+        t = c.nTiles;
+      }
+  }
+  ctx->nTiles = t;
+  if (t == 0) {
+    ctx->err = "No analyzable genome (length=0)";
+    return GX_ERR_GEN;
+  }
+  int lg = 0;
+  while ((1u << lg) < t) lg++;
+  // tiles per super-bucket: the level-1 scatter wants few bins (long runs per bin and chunk), the level-2
+  // kernel many super-buckets (one workgroup each); GX_SBSHIFT overrides for experiments
+  // (hg38, 377 K tiles: 2^9 tiles per super-bucket measured best of 2^8 / 2^9 / 2^10)
+  ctx->sbShift = std::min(11, lg / 2);
+  if (const char* e = getenv("GX_SBSHIFT")) ctx->sbShift = std::max(0, std::min(11, atoi(e)));
+  while (((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1 > (u32)MAX_BINS) ctx->sbShift++;
+  if ((1u << ctx->sbShift) > (u32)MAX_BINS) {
+    ctx->err = "genome too large for the two-level tile sort";
+    return GX_ERR_MEM;
+  }
+  ctx->nSB = ((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1;  // + the null bucket
+  // -E edges per tile (Genrich.c:2185-2195: a region starting at 0 only flips the initial state)
+  {
+    std::vector<u32> bedOff(t + 1, 0), edges;
+    std::vector<uint8_t> save0(t, 1);
+    ctx->hasBed = false;
+    for (int i = 0; i < n; i++) {
+      const DChrom& c = ctx->hChrom[i];
+      if (c.tileBase == NULL_TILE) continue;
+      const std::vector<uint32_t>& b = ctx->bed[i];
+      if (!b.empty()) ctx->hasBed = true;
+      bool state = b.empty() || b[0] != 0;
+      size_t k = (!b.empty() && b[0] == 0) ? 1 : 0;
+      for (u32 tl = 0; tl < c.nTiles; tl++) {
+        const uint64_t lo = (uint64_t)tl << TB, hi = lo + TILE;
+        save0[c.tileBase + tl] = state;
+        bedOff[c.tileBase + tl] = (u32)edges.size();
+        while (k < b.size() && b[k] < hi && b[k] < c.len) {
+          edges.push_back((u32)(b[k] - lo));
+          state = !state;
+          k++;
+        }
+      }
+    }
+    bedOff[t] = (u32)edges.size();
+    ctx->nBedEdges = edges.size();
+    HIPCHECK(ctx->dBedTileOff.ensure((size_t)(t + 1) * 4));
+    HIPCHECK(ctx->dBedEdge.ensure(edges.size() * 4 + 16));
+    HIPCHECK(ctx->dTileSave0.ensure((size_t)t + 16));
+    HIPCHECK(hipMemcpy(ctx->dBedTileOff.p, bedOff.data(), (size_t)(t + 1) * 4, hipMemcpyHostToDevice));
+    if (!edges.empty()) HIPCHECK(hipMemcpy(ctx->dBedEdge.p, edges.data(), edges.size() * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dTileSave0.p, save0.data(), (size_t)t, hipMemcpyHostToDevice));
+  }
+  HIPCHECK(ctx->dChrom.ensure((size_t)n * sizeof(DChrom)));
+  HIPCHECK(ctx->dTileChrom.ensure((size_t)t * 4));
+  HIPCHECK(hipMemcpyAsync(ctx->dTileChrom.p, tileChrom.data(), (size_t)t * 4, hipMemcpyHostToDevice, ctx->stream));
+  return upload_chroms(ctx);
 }
 
 }  // namespace
@@ -534,6 +667,9 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   *out = ctx;
   HIPCHECK(hipSetDevice(ctx->device));
   HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIPCHECK(ctx->mailBuf.ensure(sizeof(HostMail)));
+  ctx->mail = static_cast<HostMail*>(ctx->mailBuf.p);
+  memset(ctx->mail, 0, sizeof(HostMail));
   HIPCHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
   HIPCHECK(hipEventCreateWithFlags(&ctx->sideEv, hipEventDisableTiming));
   HIPCHECK(ctx->misc.ensure(M_WORDS * 4));
@@ -591,76 +727,7 @@ int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip, 
     ctx->skip[i] = skip && skip[i];
     if (bed && bed_len && bed_len[i] > 0 && !ctx->skip[i]) ctx->bed[i].assign(bed[i], bed[i] + bed_len[i]);
   }
-  ctx->hChrom.assign(n, DChrom{});
-  std::vector<u32> tileChrom;
-  u32 t = 0;
-  for (int i = 0; i < n; i++) {
-    DChrom& c = ctx->hChrom[i];
-    c.len = len[i];
-    if (ctx->skip[i] || len[i] == 0) {
-      c.tileBase = NULL_TILE;
-      c.nTiles = 0;
-      continue;
-    }
-    c.tileBase = t;
-    c.nTiles = (u32)(((uint64_t)len[i] + TILE - 1) >> TB);
-    for (u32 k = 0; k < c.nTiles; k++) tileChrom.push_back((u32)i);
-    t += c.nTiles;
-  }
-  ctx->nTiles = t;
-  if (t == 0) {
-    ctx->err = "No analyzable genome (length=0)";
-    return GX_ERR_GEN;
-  }
-  int lg = 0;
-  while ((1u << lg) < t) lg++;
-  // tiles per super-bucket: the level-1 scatter wants few bins (long runs per bin and chunk), the level-2
-  // kernel many super-buckets (one workgroup each); GX_SBSHIFT overrides for experiments
-  // (hg38, 377 K tiles: 2^9 tiles per super-bucket measured best of 2^8 / 2^9 / 2^10)
-  ctx->sbShift = std::min(11, lg / 2);
-  if (const char* e = getenv("GX_SBSHIFT")) ctx->sbShift = std::max(0, std::min(11, atoi(e)));
-  while (((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1 > (u32)MAX_BINS) ctx->sbShift++;
-  if ((1u << ctx->sbShift) > (u32)MAX_BINS) {
-    ctx->err = "genome too large for the two-level tile sort";
-    return GX_ERR_MEM;
-  }
-  ctx->nSB = ((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1;  // + the null bucket
-  // -E edges per tile (Genrich.c:2185-2195: a region starting at 0 only flips the initial state)
-  {
-    std::vector<u32> bedOff(t + 1, 0), edges;
-    std::vector<uint8_t> save0(t, 1);
-    ctx->hasBed = false;
-    for (int i = 0; i < n; i++) {
-      const DChrom& c = ctx->hChrom[i];
-      if (c.tileBase == NULL_TILE) continue;
-      const std::vector<uint32_t>& b = ctx->bed[i];
-      if (!b.empty()) ctx->hasBed = true;
-      bool state = b.empty() || b[0] != 0;
-      size_t k = (!b.empty() && b[0] == 0) ? 1 : 0;
-      for (u32 tl = 0; tl < c.nTiles; tl++) {
-        const uint64_t lo = (uint64_t)tl << TB, hi = lo + TILE;
-        save0[c.tileBase + tl] = state;
-        bedOff[c.tileBase + tl] = (u32)edges.size();
-        while (k < b.size() && b[k] < hi && b[k] < c.len) {
-          edges.push_back((u32)(b[k] - lo));
-          state = !state;
-          k++;
-        }
-      }
-    }
-    bedOff[t] = (u32)edges.size();
-    ctx->nBedEdges = edges.size();
-    HIPCHECK(ctx->dBedTileOff.ensure((size_t)(t + 1) * 4));
-    HIPCHECK(ctx->dBedEdge.ensure(edges.size() * 4 + 16));
-    HIPCHECK(ctx->dTileSave0.ensure((size_t)t + 16));
-    HIPCHECK(hipMemcpy(ctx->dBedTileOff.p, bedOff.data(), (size_t)(t + 1) * 4, hipMemcpyHostToDevice));
-    if (!edges.empty()) HIPCHECK(hipMemcpy(ctx->dBedEdge.p, edges.data(), edges.size() * 4, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->dTileSave0.p, save0.data(), (size_t)t, hipMemcpyHostToDevice));
-  }
-  HIPCHECK(ctx->dChrom.ensure((size_t)n * sizeof(DChrom)));
-  HIPCHECK(ctx->dTileChrom.ensure((size_t)t * 4));
-  HIPCHECK(hipMemcpyAsync(ctx->dTileChrom.p, tileChrom.data(), (size_t)t * 4, hipMemcpyHostToDevice, ctx->stream));
-  int rc = upload_chroms(ctx);
+  int rc = layout_tiles(ctx);
   if (rc) return rc;
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   return GX_OK;
@@ -679,8 +746,9 @@ int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn all
 
 int gx_set_owned(gx_ctx* ctx, const uint8_t* owned) {
   if (!ctx || !owned || ctx->nChrom == 0) return GX_ERR_ORDER;
+  if (ctx->phase != 0 || ctx->sample != 0) return GX_ERR_ORDER;  // the tile space changes: between runs only
   ctx->owned.assign(owned, owned + ctx->nChrom);
-  int rc = upload_chroms(ctx);
+  int rc = layout_tiles(ctx);
   if (rc) return rc;
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   return GX_OK;
@@ -700,7 +768,7 @@ int gx_reset(gx_ctx* ctx) {
   ctx->finalIdx = -1;
   ctx->segs.clear();
   ctx->evCount = 0;
-  ctx->hPeaks.clear();
+  ctx->nHostPeaks = 0;
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
   return GX_OK;
 }
@@ -722,11 +790,7 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
     z.genomeLen = g;
     ctx->hScal = z;
     HIPCHECK(hipMemcpyAsync(ctx->dScal.p, &ctx->hScal, sizeof(Scalars), hipMemcpyHostToDevice, ctx->stream));
-    for (auto& ph : ctx->phases) {
-      (void)hipEventDestroy(ph.a);
-      (void)hipEventDestroy(ph.b);
-    }
-    ctx->phases.clear();
+    ctx->nPhases = 0;
     ctx->phase = 1;
   } else {
     if (ctx->phase != 2) return GX_ERR_ORDER;
@@ -913,9 +977,10 @@ int gx_pvalues(gx_ctx* ctx) {
     if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(&pa.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&ctx->mail->nMerged, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
     int rc = read_status(ctx);
     if (rc) return rc;
+    pa.n = ctx->mail->nMerged;
     ctx->maskN = pa.n;
     pa.hasPiles = true;
     pa.ctrlIsConst = false;
@@ -981,9 +1046,10 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     if (int rc__ = dbg_sync(ctx, "k_pack_ep")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(&comb.n, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&ctx->mail->nMerged, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
     int rc = read_status(ctx);
     if (rc) return rc;
+    comb.n = ctx->mail->nMerged;
     ctx->reps.push_back(std::move(comb));
   }
   ctx->finalIdx = (int)ctx->reps.size() - 1;
@@ -994,8 +1060,10 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   const bool genomeOpt = g == 0;
   if (genomeOpt) g = genome_len_for(ctx, fa.present);
   ctx->genomeLenUsed = g;
-  HIPCHECK(hipMemcpyAsync(misc + M_GENOME, &g, 8, hipMemcpyHostToDevice, s));
-  HIPCHECK(hipMemcpyAsync(misc + M_NIV, &n, 4, hipMemcpyHostToDevice, s));
+  ctx->mail->genome = g;
+  ctx->mail->n = n;
+  HIPCHECK(hipMemcpyAsync(misc + M_GENOME, &ctx->mail->genome, 8, hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(misc + M_NIV, &ctx->mail->n, 4, hipMemcpyHostToDevice, s));
   const u32 gridIv = std::max(1u, std::min((n + 255) / 256, 4096u));
 
   if (ctx->par.qval_opt) {
@@ -1017,9 +1085,9 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     hipLaunchKernelGGL(k_bh_compact, dim3(1024), dim3(256), 0, s, ctx->bhKeys.as<u32>(), cap, ctx->bhOutKeys.as<u32>(),
                        ctx->bhOutSlot.as<u32>(), misc + M_BHCOUNT);
   if (int rc__ = dbg_sync(ctx, "k_bh_compact")) return rc__;
-    u32 D = 0;
-    HIPCHECK(hipMemcpyAsync(&D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    u32 D = ctx->mail->D;
     if (ctx->world > 1 && ctx->allgather) {
       // every rank contributes its {p bits, bp} pairs; all ranks rebuild the same genome-wide table
       // (hashPval 300-327 runs over all chromosomes)
@@ -1060,8 +1128,9 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       }
       hipLaunchKernelGGL(k_bh_compact, dim3(1024), dim3(256), 0, s, ctx->bhKeys.as<u32>(), cap,
                          ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), misc + M_BHCOUNT);
-      HIPCHECK(hipMemcpyAsync(&D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
       HIPCHECK(hipStreamSynchronize(s));
+      D = ctx->mail->D;
     }
     if (D) {
       HIPCHECK(ctx->bhSortKeys.ensure((size_t)D * 4));
@@ -1103,6 +1172,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   HIPCHECK(hipMemsetAsync(misc + M_SWEEP_FIRST, 0, M_SWEEP_WORDS * 4, s));  // run / candidate / peak counters, peak bp
   const float* qPtr = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
   u32 R = 0, nPeaks = 0;
+  bool haveStatus = false;
   ctx->peakBP = 0;
   if (nWords) {
     HIPCHECK(ctx->lb2.ensure(((size_t)wChunks * 4 + 64) * 4));
@@ -1119,8 +1189,9 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                        misc + M_SWCOUNT);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cntE, (const u32*)nullptr, wChunks, (u32)SW_CHUNK, offE,
                        misc + M_TICKET2);
-    HIPCHECK(hipMemcpyAsync(&R, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&ctx->mail->R, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));  // run / candidate arrays are sized exactly
+    R = ctx->mail->R;
     if (R) {
       HIPCHECK(ctx->swStart.ensure((size_t)R * 4 + 16));
       HIPCHECK(ctx->swEnd.ensure((size_t)R * 4 + 16));
@@ -1163,16 +1234,27 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       hipLaunchKernelGGL(k_peaks_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
                          misc + M_NHEADS, off3, ctx->peaks.as<gx_peak>(), reinterpret_cast<u64*>(misc + M_PEAKBP));
       if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
-      HIPCHECK(hipMemcpyAsync(&nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipMemcpyAsync(&ctx->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
+      // peak count, peak bp and the status word in one round trip
+      HIPCHECK(hipMemcpyAsync(&ctx->mail->nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipMemcpyAsync(&ctx->mail->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipMemcpyAsync(&ctx->mail->status, ctx->dStatus.p, 4, hipMemcpyDeviceToHost, s));
       HIPCHECK(hipStreamSynchronize(s));
+      nPeaks = ctx->mail->nPeaks;
+      ctx->peakBP = ctx->mail->peakBP;
+      haveStatus = true;
     }
   }
-  ctx->hPeaks.resize(nPeaks);
+  HIPCHECK(ctx->hPeaks.ensure((size_t)nPeaks * sizeof(gx_peak) + 16));
+  ctx->nHostPeaks = nPeaks;
   if (nPeaks)
-    HIPCHECK(hipMemcpyAsync(ctx->hPeaks.data(), ctx->peaks.p, (size_t)nPeaks * sizeof(gx_peak), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->hPeaks.p, ctx->peaks.p, (size_t)nPeaks * sizeof(gx_peak), hipMemcpyDeviceToHost, s));
   phase_end(ctx);
-  int rc = read_status(ctx);
+  int rc;
+  if (haveStatus) {
+    HIPCHECK(hipStreamSynchronize(s));
+    rc = status_to_rc(ctx, ctx->mail->status);
+  } else
+    rc = read_status(ctx);
   if (rc) return rc;
   if (n_peaks) *n_peaks = nPeaks;
   if (genome_len) *genome_len = g;
@@ -1182,14 +1264,14 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
 
 int gx_peak_count(gx_ctx* ctx, size_t* n) {
   if (!ctx || !n) return GX_ERR_ORDER;
-  *n = ctx->hPeaks.size();
+  *n = ctx->nHostPeaks;
   return GX_OK;
 }
 
 int gx_get_peaks(gx_ctx* ctx, gx_peak* out, size_t cap) {
   if (!ctx || !out) return GX_ERR_ORDER;
-  size_t n = std::min(cap, ctx->hPeaks.size());
-  memcpy(out, ctx->hPeaks.data(), n * sizeof(gx_peak));
+  size_t n = std::min(cap, ctx->nHostPeaks);
+  if (n) memcpy(out, ctx->hPeaks.p, n * sizeof(gx_peak));
   return GX_OK;
 }
 
@@ -1274,7 +1356,8 @@ int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->phaseMs.clear();
   ctx->phaseNames.clear();
-  for (auto& ph : ctx->phases) {
+  for (size_t i = 0; i < ctx->nPhases; i++) {
+    Phase& ph = ctx->phases[i];
     float t = 0;
     (void)hipEventElapsedTime(&t, ph.a, ph.b);
     ctx->phaseMs.push_back(t);
@@ -1283,7 +1366,7 @@ int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms) {
   }
   if (names) *names = ctx->phaseNames.c_str();
   if (ms) *ms = ctx->phaseMs.data();
-  return (int)ctx->phases.size();
+  return (int)ctx->nPhases;
 }
 
 }  // extern "C"

@@ -698,6 +698,25 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
     a.origin = h.z;
     u32 i = i0;
     for (; i <= i1 && (i & 3u); i++) a.step(end[i], p[i], useQ ? q[i] : GX_SKIPF, useQ, thr);
+    // twelve intervals per round trip (three independent 16-byte loads per array), then four
+    for (; i + 11 <= i1; i += 12) {
+      uint4 e4[3];
+      float4 p4[3], q4[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        e4[k] = *reinterpret_cast<const uint4*>(end + i + 4 * k);
+        p4[k] = *reinterpret_cast<const float4*>(p + i + 4 * k);
+        q4[k] = make_float4(GX_SKIPF, GX_SKIPF, GX_SKIPF, GX_SKIPF);
+        if (useQ) q4[k] = *reinterpret_cast<const float4*>(q + i + 4 * k);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        a.step(e4[k].x, p4[k].x, q4[k].x, useQ, thr);
+        a.step(e4[k].y, p4[k].y, q4[k].y, useQ, thr);
+        a.step(e4[k].z, p4[k].z, q4[k].z, useQ, thr);
+        a.step(e4[k].w, p4[k].w, q4[k].w, useQ, thr);
+      }
+    }
     for (; i + 3 <= i1; i += 4) {
       const uint4 e4 = *reinterpret_cast<const uint4*>(end + i);
       const float4 p4 = *reinterpret_cast<const float4*>(p + i);
