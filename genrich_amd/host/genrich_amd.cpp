@@ -9,9 +9,8 @@
 // from libgenrich_amd.so; text output is gx_emit.cpp.  Written from the behaviour described in
 // SURVEY.md Appendix A, not transliterated from the reference.
 //
-// -P (peak calling from a -f log, callPeaksLog 1277-1488) is text processing and runs on the host.
-// Not implemented here (the reference option is recognised and rejected with a message):
-//   -r / -R  PCR-duplicate removal (Genrich.c:2776-2977, 3267-4042)
+// -P (peak calling from a -f log, callPeaksLog 1277-1488) is text processing and runs on the host,
+// and so does -r / -R (PCR-duplicate removal, Genrich.c:2776-2977 and 3267-4042).
 //
 // Extra long option (diagnostics, never needed for normal use):
 //   --events-only   parse and write the -b file without touching a GPU
@@ -25,7 +24,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/genrich_amd.h"
@@ -125,6 +127,8 @@ struct State {
   std::vector<gx_event> buf;
   Out bed;
   bool bedOpt = false;
+  Out dups;               // -R: log of the reads removed as PCR duplicates
+  bool dupsVerb = false;
   bool ctrl = false;
   int sample = 0;
   uint64_t errCount = 0;
@@ -239,6 +243,7 @@ struct Unpair { int chrom; uint32_t pos[2]; bool strand; uint8_t count; std::str
 struct Counts {
   uint64_t count = 0, unmapped = 0, paired = 0, single = 0, orphan = 0, pairedPr = 0, singlePr = 0, supp = 0,
            skipped = 0, lowMapQ = 0, secPair = 0, secSingle = 0;
+  uint64_t countPr = 0, dupsPr = 0, countDc = 0, dupsDc = 0, countSn = 0, dupsSn = 0;  // -r
   double totalLen = 0.0;
 };
 
@@ -334,7 +339,65 @@ int processSingle(State& S, const char* qname, std::vector<Aln>& aln, std::vecto
   return 1;
 }
 
-void processAlns(State& S, const char* qname, std::vector<Aln>& aln, std::vector<Unpair>& unpair, Counts& C) {  // 3187-3265
+// ---- -r: alignment sets kept until the end of the file (saveAlns 2942-2977) --------------------
+struct DRead {
+  std::string name;
+  uint16_t qual = 0;            // sum of the base qualities (both mates for pairs / discordant pairs)
+  bool first = false;           // singleton: which mate
+  float score = NOSCORE, scoreR2 = NOSCORE;
+  std::vector<Aln> aln, alnR2;  // alnR2: the R2 alignments of a discordant pair
+};
+struct DupReads { std::vector<DRead> pr, dc, sn; };
+
+// copyAlns 2815-2851: the unpaired alignments of one mate within the score window
+void copyAlns(const State& S, const std::vector<Aln>& aln, float score, bool first, std::vector<Aln>& dest) {
+  if (score != NOSCORE) score -= S.o.asDiff;
+  for (auto& a : aln)
+    if (!a.paired && a.first == first && a.score >= score) dest.push_back(a);
+}
+
+void saveAlns(const State& S, const char* qname, const std::vector<Aln>& aln, bool pair, bool singleR1, bool singleR2,
+              float scorePr, float scoreR1, float scoreR2, uint16_t qualR1, uint16_t qualR2, DupReads& D) {
+  auto sumq = [](uint16_t a, uint16_t b) { return (uint16_t)std::min<int>((int)a + (int)b, UINT16_MAX); };
+  if (pair) {  // saveAlnsPair 2890-2935: positions ordered
+    DRead r;
+    r.name = qname;
+    r.qual = sumq(qualR1, qualR2);
+    r.score = scorePr;
+    float score = scorePr;
+    if (score != NOSCORE) score -= S.o.asDiff;
+    for (auto& a : aln)
+      if (a.paired && a.full && a.score >= score) {
+        Aln b = a;
+        if (b.pos[0] > b.pos[1]) std::swap(b.pos[0], b.pos[1]);
+        r.aln.push_back(b);
+      }
+    D.pr.push_back(std::move(r));
+  } else if (S.o.singleOpt) {
+    if (singleR1 && singleR2) {  // both mates aligned, not as a proper pair (saveAlnsDiscord 2874)
+      DRead r;
+      r.name = qname;
+      r.first = true;
+      r.score = scoreR1;
+      r.scoreR2 = scoreR2;
+      copyAlns(S, aln, scoreR1, true, r.aln);
+      copyAlns(S, aln, scoreR2, false, r.alnR2);
+      r.qual = sumq(qualR1, qualR2);
+      D.dc.push_back(std::move(r));
+    } else if (singleR1 || singleR2) {  // saveAlnsSingle 2856
+      DRead r;
+      r.name = qname;
+      r.first = singleR1;
+      r.score = singleR1 ? scoreR1 : scoreR2;
+      r.qual = singleR1 ? qualR1 : qualR2;
+      copyAlns(S, aln, r.score, r.first, r.aln);
+      D.sn.push_back(std::move(r));
+    }
+  }
+}
+
+void processAlns(State& S, const char* qname, std::vector<Aln>& aln, std::vector<Unpair>& unpair, Counts& C,
+                 uint16_t qualR1, uint16_t qualR2, DupReads& D) {  // 3187-3265
   float scorePr = NOSCORE, scoreR1 = NOSCORE, scoreR2 = NOSCORE;
   bool pair = false, singleR1 = false, singleR2 = false;
   for (auto& a : aln) {
@@ -349,12 +412,172 @@ void processAlns(State& S, const char* qname, std::vector<Aln>& aln, std::vector
       else if (!a.first && scoreR2 <= a.score) { scoreR2 = a.score; singleR2 = true; }
     }
   }
-  if (pair)
+  if (S.o.dupsOpt)
+    saveAlns(S, qname, aln, pair, singleR1, singleR2, scorePr, scoreR1, scoreR2, qualR1, qualR2, D);
+  else if (pair)
     C.pairedPr += processPair(S, qname, aln, C, scorePr);
   else if (S.o.singleOpt) {
     if (singleR1) C.singlePr += processSingle(S, qname, aln, unpair, scoreR1, true);
     if (singleR2) C.singlePr += processSingle(S, qname, aln, unpair, scoreR2, false);
   }
+}
+
+// ---- -r: PCR duplicates (findDups 3949-4042) ---------------------------------------------------
+// Sets are visited from the highest base-quality sum down (a stable order, sortReads 3362); a set
+// is a duplicate when any of its alignments matches one already kept: proper pairs by (chrom,
+// both 5' ends), discordant pairs by both ends with their strands in either order, singletons by
+// (chrom, 5' end, strand) -- against kept singletons and against both ends of every kept pair.
+// Only membership matters, so ordered maps stand in for the reference's chained hash tables.
+struct KeyPr { int chrom; uint32_t p0, p1; bool operator<(const KeyPr& o) const { return std::tie(chrom, p0, p1) < std::tie(o.chrom, o.p0, o.p1); } };
+struct KeySn { int chrom; uint32_t pos; bool strand; bool operator<(const KeySn& o) const { return std::tie(chrom, pos, strand) < std::tie(o.chrom, o.pos, o.strand); } };
+struct KeyDc {
+  int c0, c1; uint32_t p0, p1; bool s0, s1;
+  bool operator<(const KeyDc& o) const { return std::tie(c0, c1, p0, p1, s0, s1) < std::tie(o.c0, o.c1, o.p0, o.p1, o.s0, o.s1); }
+};
+
+void dupLine(State& S, const char* fmt, ...) {
+  char buf[2 * MAX_ALNS + 4096];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  fputs(buf, S.dups.f);
+}
+
+void findDups(State& S, DupReads& D, Counts& C) {
+  const bool verb = S.dupsVerb;
+  std::map<KeySn, std::string> tabSn;
+  const bool useSn = S.o.singleOpt && !D.sn.empty();  // the singleton table exists only when there are singletons
+  auto addSn = [&](int chrom, uint32_t pos, bool strand, const std::string& name) {  // checkAndAdd 3514
+    tabSn.emplace(KeySn{chrom, pos, strand}, verb ? name : std::string());
+  };
+  auto order = [](const std::vector<DRead>& v) {
+    std::vector<uint32_t> o(v.size());
+    for (uint32_t i = 0; i < o.size(); i++) o[i] = i;
+    std::stable_sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) { return v[a].qual > v[b].qual; });
+    return o;
+  };
+
+  {  // properly paired sets (findDupsPr 3616)
+    std::map<KeyPr, std::string> tab;
+    for (uint32_t i : order(D.pr)) {
+      DRead& r = D.pr[i];
+      bool dup = false;
+      for (auto& a : r.aln) {
+        auto it = tab.find(KeyPr{a.chrom, a.pos[0], a.pos[1]});
+        if (it != tab.end()) {
+          if (verb) dupLine(S, "%s\t%s:%d-%d\t%s\tpaired\n", r.name.c_str(), S.chrom[a.chrom].name.c_str(), a.pos[0], a.pos[1], it->second.c_str());
+          dup = true;
+          break;
+        }
+      }
+      if (dup) C.dupsPr++;
+      else {
+        for (auto& a : r.aln) {
+          tab.emplace(KeyPr{a.chrom, a.pos[0], a.pos[1]}, verb ? r.name : std::string());
+          if (useSn) {
+            addSn(a.chrom, a.pos[0], true, r.name);
+            addSn(a.chrom, a.pos[1], false, r.name);
+          }
+        }
+        C.pairedPr += processPair(S, r.name.c_str(), r.aln, C, r.score);
+      }
+      C.countPr++;
+    }
+    D.pr.clear();
+    D.pr.shrink_to_fit();
+  }
+  if (!S.o.singleOpt) return;
+
+  // with -x the average fragment length of the kept pairs becomes the extension (3990-3996)
+  const Opts saved = S.o;
+  if (S.o.avgExtOpt) {
+    int extend = 0;
+    if (!C.pairedPr) {
+      if (S.o.verbose) {
+        fprintf(stderr, "Warning! No paired alignments to calculate avg frag ");
+        fprintf(stderr, "length --\n  Printing unpaired alignments \"as is\"\n");
+      }
+    } else
+      extend = (int)(C.totalLen / C.pairedPr + 0.5);
+    S.o.extend = extend;
+    if (extend) S.o.extendOpt = true;
+    S.o.avgExtOpt = false;
+  }
+  std::vector<Unpair> none;
+
+  {  // discordant sets (findDupsDc 3761): every R1 x R2 combination, either order
+    std::map<KeyDc, std::string> tab;
+    auto end5 = [](const Aln& a) { return a.strand ? a.pos[0] : a.pos[1]; };
+    for (uint32_t i : order(D.dc)) {
+      DRead& r = D.dc[i];
+      bool dup = false;
+      for (size_t k = 0; k < r.aln.size() && !dup; k++) {
+        const Aln& a = r.aln[k];
+        const uint32_t pos = end5(a);
+        for (size_t j = 0; j < r.alnR2.size() && !dup; j++) {
+          const Aln& b = r.alnR2[j];
+          const uint32_t pos1 = end5(b);
+          auto it = tab.find(KeyDc{a.chrom, b.chrom, pos, pos1, a.strand, b.strand});
+          if (it != tab.end()) {
+            if (verb) dupLine(S, "%s\t%s:%d,%c;%s:%d,%c\t%s\tdiscordant\n", r.name.c_str(), S.chrom[a.chrom].name.c_str(), pos,
+                              a.strand ? '+' : '-', S.chrom[b.chrom].name.c_str(), pos1, b.strand ? '+' : '-', it->second.c_str());
+            dup = true;
+            break;
+          }
+          it = tab.find(KeyDc{b.chrom, a.chrom, pos1, pos, b.strand, a.strand});
+          if (it != tab.end()) {
+            if (verb) dupLine(S, "%s\t%s:%d,%c;%s:%d,%c\t%s\tdiscordant\n", r.name.c_str(), S.chrom[b.chrom].name.c_str(), pos1,
+                              b.strand ? '+' : '-', S.chrom[a.chrom].name.c_str(), pos, a.strand ? '+' : '-', it->second.c_str());
+            dup = true;
+          }
+        }
+      }
+      if (dup) C.dupsDc++;
+      else {
+        for (size_t k = 0; k < r.aln.size(); k++)
+          for (size_t j = 0; j < r.alnR2.size(); j++) {
+            const Aln &a = r.aln[k], &b = r.alnR2[j];
+            tab.emplace(KeyDc{a.chrom, b.chrom, end5(a), end5(b), a.strand, b.strand}, verb ? r.name : std::string());
+            if (useSn) {
+              if (!j) addSn(a.chrom, end5(a), a.strand, r.name);
+              if (!k) addSn(b.chrom, end5(b), b.strand, r.name);
+            }
+          }
+        C.singlePr += processSingle(S, r.name.c_str(), r.aln, none, r.score, true);
+        C.singlePr += processSingle(S, r.name.c_str(), r.alnR2, none, r.scoreR2, false);
+      }
+      C.countDc++;
+    }
+    D.dc.clear();
+    D.dc.shrink_to_fit();
+  }
+
+  {  // singletons (findDupsSn 3886): the table already holds the ends of the kept pairs
+    auto end5 = [](const Aln& a) { return a.strand ? a.pos[0] : a.pos[1]; };
+    for (uint32_t i : order(D.sn)) {
+      DRead& r = D.sn[i];
+      bool dup = false;
+      for (auto& a : r.aln) {
+        auto it = tabSn.find(KeySn{a.chrom, end5(a), a.strand});
+        if (it != tabSn.end()) {
+          if (verb) dupLine(S, "%s\t%s:%d,%c\t%s\tsingle\n", r.name.c_str(), S.chrom[a.chrom].name.c_str(), end5(a),
+                            a.strand ? '+' : '-', it->second.c_str());
+          dup = true;
+          break;
+        }
+      }
+      if (dup) C.dupsSn++;
+      else {
+        for (auto& a : r.aln) tabSn.emplace(KeySn{a.chrom, end5(a), a.strand}, verb ? r.name : std::string());
+        C.singlePr += processSingle(S, r.name.c_str(), r.aln, none, r.score, r.first);
+      }
+      C.countSn++;
+    }
+    D.sn.clear();
+    D.sn.shrink_to_fit();
+  }
+  S.o = saved;
 }
 
 // parseAlign (4141-4212); returns false when the per-read alignment limit is hit
@@ -518,16 +741,27 @@ struct ReadSet {
   std::vector<Aln> aln;
   std::vector<Unpair> unpair;
   bool have = false;
+  uint16_t qualR1 = 0, qualR2 = 0;  // -r: base-quality sums of the two mates of the current read
+  DupReads dup;                     // -r: every alignment set of the file
 };
 
 void flushSet(State& S, ReadSet& rs, Counts& C) {
-  if (rs.have) processAlns(S, rs.name.c_str(), rs.aln, rs.unpair, C);
+  if (rs.have) processAlns(S, rs.name.c_str(), rs.aln, rs.unpair, C, rs.qualR1, rs.qualR2, rs.dup);
   rs.aln.clear();
+  rs.qualR1 = rs.qualR2 = 0;
+}
+
+// sumQual 4127-4134, bug for bug: `qual[0] == 0xFF` compares a (signed) char with 255 and never
+// holds, so a BAM record without qualities (all 0xFF = -1) sums to -len and wraps
+uint16_t sumQual(const char* qual, int len, int offset) {
+  int sum = 0;
+  for (int i = 0; i < len; i++) sum += (int)(signed char)qual[i] - offset;
+  return sum > UINT16_MAX ? UINT16_MAX : (uint16_t)sum;
 }
 
 // one alignment record, format independent (the tail of readSAM's / parseBAM's loop)
 void record(State& S, ReadSet& rs, Counts& C, const char* qname, uint16_t flag, int ci, uint32_t pos, uint8_t mapq,
-            int length, uint32_t pnext, float score) {
+            int length, uint32_t pnext, float score, const char* qual, int qualLen, int qualOffset) {
   if (mapq < S.o.minMapQ) { C.lowMapQ++; return; }
   openSample(S);  // the header is complete once the first record arrives
   if (!rs.have || rs.name != qname) {
@@ -535,12 +769,21 @@ void record(State& S, ReadSet& rs, Counts& C, const char* qname, uint16_t flag, 
     rs.have = true;
     rs.name.assign(qname, strnlen(qname, MAX_ALNS));  // strncpy(readName, qname, MAX_ALNS)
   }
+  if (S.o.dupsOpt && !(((flag & 0x1) && ((flag & 0xC0) == 0xC0 || !(flag & 0xC0))))) {  // parseAlign 4155-4164
+    uint16_t& q = (flag & 0x40) ? rs.qualR1 : rs.qualR2;
+    const bool star = qualLen >= 1 && qual[0] == '*' && (qualLen == 1 || qual[1] == '\0');  // strcmp(qual, "*")
+    if (!q && !star) q = sumQual(qual, qualLen, qualOffset);
+  }
   if (!parseAlign(S, rs.aln, flag, ci, pos, length, pnext, C, score) && S.o.verbose)
     fprintf(stderr, "Warning! Read %s has more than %d alignments\n", qname, MAX_ALNS);
 }
 
 void finishFile(State& S, ReadSet& rs, Counts& C) {  // the tail of readSAM / parseBAM
   flushSet(S, rs, C);
+  if (S.o.dupsOpt) {
+    findDups(S, rs.dup, C);
+    return;
+  }
   if (S.o.avgExtOpt) {  // processAvgExt 2614-2647
     int avgLen = 0;
     if (!C.pairedPr) {
@@ -605,7 +848,7 @@ uint64_t readSAM(State& S, In& in, char* first, Counts& C) {
     if (mapq < S.o.minMapQ) { C.lowMapQ++; continue; }
     int length = calcDist(qname, fld[9], fld[5]);
     float score = samScore(extra);
-    record(S, rs, C, qname, flag, ci, pos, mapq, length, pnext, score);
+    record(S, rs, C, qname, flag, ci, pos, mapq, length, pnext, score, fld[10], (int)strlen(fld[10]), 33);
   }
   finishFile(S, rs, C);
   return C.count;
@@ -622,7 +865,10 @@ int32_t rdI32(gzFile g, bool must) {
 }
 
 float bamScore(const uint8_t* p, const uint8_t* end) {
-  while (p + 3 <= end) {
+  // getBAMscore 4751: the scan stops once fewer than five bytes remain (`while (i < len - 4)`), so a
+  // one-byte-valued tag at the very end of the record is never looked at -- kept as is
+  const uint8_t* stop = end - 4;
+  while (p < stop) {
     const bool isAS = p[0] == 'A' && p[1] == 'S';
     const char ty = (char)p[2];
     p += 3;
@@ -722,7 +968,8 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     } else if (!length)
       die(qname, ": no sequence information (SEQ or CIGAR)");
     float score = bamScore(blk.data() + off, blk.data() + blk.size());
-    record(S, rs, C, qname, flag, idx[refID], (uint32_t)pos, mapq, length + offset, (uint32_t)next_pos, score);
+    record(S, rs, C, qname, flag, idx[refID], (uint32_t)pos, mapq, length + offset, (uint32_t)next_pos, score,
+           (const char*)blk.data() + off - (size_t)l_seq, l_seq, 0);
   }
   finishFile(S, rs, C);
   return C.count;
@@ -753,6 +1000,17 @@ void logCounts(const State& S, const Counts& C, bool bam) {
   if (C.orphan) fprintf(stderr, "      \"orphan\" alns:    %11ld\t** Warning! **\n", (long)C.orphan);
   fprintf(stderr, "    Unpaired alignments:%11ld\n", (long)C.single);
   if (C.secSingle) fprintf(stderr, "      secondary alns:   %11ld\n", (long)C.secSingle);
+  if (o.dupsOpt) {
+    fprintf(stderr, "  PCR duplicates --\n");
+    fprintf(stderr, "    Paired aln sets:    %11ld\n", (long)C.countPr);
+    fprintf(stderr, "      duplicates:       %11ld (%.1f%%)\n", (long)C.dupsPr, C.countPr ? 100.0f * C.dupsPr / C.countPr : 0.0f);
+    if (o.singleOpt) {
+      fprintf(stderr, "    Discordant aln sets:%11ld\n", (long)C.countDc);
+      fprintf(stderr, "      duplicates:       %11ld (%.1f%%)\n", (long)C.dupsDc, C.countDc ? 100.0f * C.dupsDc / C.countDc : 0.0f);
+      fprintf(stderr, "    Singleton aln sets: %11ld\n", (long)C.countSn);
+      fprintf(stderr, "      duplicates:       %11ld (%.1f%%)\n", (long)C.dupsSn, C.countSn ? 100.0f * C.dupsSn / C.countSn : 0.0f);
+    }
+  }
   fprintf(stderr, "  Fragments analyzed:   %11ld\n", (long)(C.singlePr + C.pairedPr));
   fprintf(stderr, "    Full fragments:     %11ld\n", (long)C.pairedPr);
   if (C.pairedPr && !o.atacOpt) fprintf(stderr, "      (avg. length: %.1fbp)\n", avgLen);
@@ -1015,7 +1273,7 @@ void usage() {
   fprintf(stderr,
           "Usage: genrich-amd  -t <file>  -o <file>  [optional arguments]\n"
           "  (same options as Genrich v0.6.2: -t -c -o -f -k -b -z -y -w -x -j -d -D -e -E -m -s\n"
-          "   -p -q -a -l -g -X -P -S -L -v -V; -r/-R are not implemented in this build)\n");
+          "   -r -R -p -q -a -l -g -X -P -S -L -v -V)\n");
   exit(EXIT_FAILURE);
 }
 
@@ -1073,7 +1331,6 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Error! Need input/output files\n");
     usage();
   }
-  if (o.dupsOpt) die("", "-r (PCR duplicate removal) is not implemented in genrich-amd");
   if (o.avgExtOpt) { o.singleOpt = true; o.extendOpt = false; }
   if (o.extendOpt) {
     o.singleOpt = true;
@@ -1101,6 +1358,7 @@ int main(int argc, char** argv) {
     return EXIT_SUCCESS;
   }
   if (o.bedFile) { S.bed = openWrite(o.bedFile, o.gzOut); S.bedOpt = true; }
+  if (o.dupsOpt && o.dupsFile) { S.dups = openWrite(o.dupsFile, o.gzOut); S.dupsVerb = true; }  // 5411-5415
   if (!o.eventsOnly) {
     gx_params par{};
     par.thr = thr;
@@ -1147,6 +1405,7 @@ int main(int argc, char** argv) {
       int got = gzread(in.gz, magic, 4);
       bool bam = got == 4 && !memcmp(magic, "BAM\1", 4);
       if (o.verbose) fprintf(stderr, "Processing %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
+      if (S.dupsVerb) fprintf(S.dups.f, "# %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
       Counts C;
       if (bam)
         readBAM(S, in, C);
@@ -1183,6 +1442,7 @@ int main(int argc, char** argv) {
     S.sample++;
   }
   if (S.bedOpt) closeOut(S.bed);
+  if (S.dupsVerb) closeOut(S.dups);
   if (o.eventsOnly) return EXIT_SUCCESS;
 
   size_t nPeaks = 0;

@@ -217,3 +217,84 @@ def write_sam_mixed(path, names, lens, ev, seed, read_len=50, name_prefix="m", f
         raw += struct.pack("<i", len(body)) + body
     with gzip.GzipFile(path, "wb", mtime=0) as g:
         g.write(bytes(raw))
+
+
+def write_sam_dups(path, names, lens, ev, seed, read_len=50, name_prefix="d", bam=False):
+    """Queryname-grouped SAM / BAM for -r (PCR-duplicate removal, Genrich.c:3267-4042): proper
+    pairs, singletons (mate unmapped), discordant pairs (both mates aligned, not as a proper
+    pair, possibly on two chromosomes) and multi-mapped pairs with secondary alignments; about a
+    quarter of the templates reuse the coordinates of an earlier one (the duplicates); base
+    qualities vary per read (they decide which copy is kept) and a few reads carry none."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    recs = []  # (qname, flag, chrom, pos0, mapq, rl, rnext chrom or -1, pnext0, tlen, AS, qual array or None)
+    used, used_dc = [], []
+
+    def quals(rl):
+        if rng.random() < 0.05:
+            return None
+        return rng.integers(int(rng.integers(2, 30)), 41, rl).astype(np.uint8)
+
+    for i in range(len(ev)):
+        c, s, e = int(ev["chrom"][i]), int(ev["start"][i]), int(ev["end"][i])
+        if used and rng.random() < 0.25:
+            c, s, e = used[int(rng.integers(0, len(used)))]
+        used.append((c, s, e))
+        nm = f"{name_prefix}{i}"
+        rl = min(read_len, e - s)
+        kind = rng.choice(["pair", "pair", "pair", "single", "discord", "multi"])
+        mapq = 30
+        if kind == "pair" or kind == "multi":
+            recs.append((nm, 99, c, s, mapq, rl, c, e - rl, e - s, -2, quals(rl)))
+            recs.append((nm, 147, c, e - rl, mapq, rl, c, s, -(e - s), -3, quals(rl)))
+            if kind == "multi":  # a secondary pair elsewhere on the chromosome, slightly worse score
+                d = int(rng.integers(300, 2000))
+                s2 = s + d if e + d < lens[c] else max(0, s - d)
+                e2 = s2 + (e - s)
+                recs.append((nm, 99 | 256, c, s2, mapq, rl, c, e2 - rl, e - s, -4, None))
+                recs.append((nm, 147 | 256, c, e2 - rl, mapq, rl, c, s2, -(e - s), -4, None))
+        elif kind == "single":
+            rev = rng.random() < 0.5
+            first = rng.random() < 0.5
+            flag = 1 | 8 | (64 if first else 128) | (16 if rev else 0)
+            recs.append((nm, flag, c, e - rl if rev else s, mapq, rl, -1, -1, 0, -1, quals(rl)))
+        else:  # discordant: both mates aligned on their own
+            if used_dc and rng.random() < 0.3:  # an earlier discordant template again, sometimes with the mates swapped
+                c1, p1, r1rev, c2, p2, r2rev = used_dc[int(rng.integers(0, len(used_dc)))]
+                if rng.random() < 0.5:
+                    c1, p1, r1rev, c2, p2, r2rev = c2, p2, r2rev, c1, p1, r1rev
+            else:
+                c2 = int(rng.integers(0, len(lens)))
+                p2 = int(rng.integers(0, max(1, lens[c2] - read_len)))
+                r1rev, r2rev = bool(rng.random() < 0.5), bool(rng.random() < 0.5)
+                c1, p1 = c, (e - rl if r1rev else s)
+            used_dc.append((c1, p1, r1rev, c2, p2, r2rev))
+            rl = min(read_len, lens[c1] - p1, lens[c2] - p2)
+            recs.append((nm, 1 | 64 | (16 if r1rev else 0) | (32 if r2rev else 0), c1, p1, mapq, rl, c2, p2, 0, -1, quals(rl)))
+            recs.append((nm, 1 | 128 | (16 if r2rev else 0) | (32 if r1rev else 0), c2, p2, mapq, rl, c1, p1, 0, -2, quals(rl)))
+    if not bam:
+        with open(path, "w") as f:
+            f.write("@HD\tVN:1.0\tSO:queryname\n")
+            for n, l in zip(names, lens):
+                f.write(f"@SQ\tSN:{n}\tLN:{l}\n")
+            for nm, flag, c, pos, mapq, rl, rn, pn, tlen, sc, q in recs:
+                rnext = "*" if rn < 0 else ("=" if rn == c else names[rn])
+                qs = "*" if q is None else "".join(chr(33 + int(v)) for v in q)
+                f.write(f"{nm}\t{flag}\t{names[c]}\t{pos + 1}\t{mapq}\t{rl}M\t{rnext}\t{pn + 1}\t{tlen}\t"
+                        f"{'A' * rl}\t{qs}\tNM:i:0\tAS:i:{sc}\n")
+        return
+    import gzip
+    import struct
+    raw = bytearray()
+    text = "@HD\tVN:1.0\tSO:queryname\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(names, lens))
+    raw += b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(names))
+    for n, l in zip(names, lens):
+        raw += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    for nm, flag, c, pos, mapq, rl, rn, pn, tlen, sc, q in recs:
+        cig = struct.pack("<I", (rl << 4) | 0)
+        aux = b"NMC\0" + b"ASc" + struct.pack("<b", sc)
+        body = struct.pack("<iiBBHHHiiii", c, pos, len(nm) + 1, mapq, 0, 1, flag, rl, rn, pn, tlen)
+        qb = b"\xff" * rl if q is None else bytes(q.tolist())
+        body += nm.encode() + b"\0" + cig + b"\x11" * ((rl + 1) // 2) + qb + aux
+        raw += struct.pack("<i", len(body)) + body
+    with gzip.GzipFile(path, "wb", mtime=0) as g:
+        g.write(bytes(raw))

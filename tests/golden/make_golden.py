@@ -146,6 +146,13 @@ def cases():
             name=nm, names=N2, args=extra + ["-a", "20"], mixed=dict(seed=7, bam=nm.endswith("bam_atac")),
             reps=[dict(t=(N2, L2, mf(L2, 2500, 95)), c=(N2, L2, mf(L2, 2000, 96, uniform_only=True)))])
 
+    # -r / -R: PCR-duplicate removal -- pairs only; with unpaired alignments kept (-y); BAM input with -x
+    for nm, extra, isbam in (("dups_pairs", ["-r"], False), ("dups_y", ["-r", "-y", "-s", "1.5"], False),
+                             ("dups_x_bam", ["-r", "-x"], True)):
+        yield dict(
+            name=nm, names=N2, args=extra + ["-a", "20"], mixed=dict(seed=21, bam=isbam, writer="dups"),
+            reps=[dict(t=(N2, L2, mf(L2, 2500, 97)), c=(N2, L2, mf(L2, 2000, 98, uniform_only=True)))])
+
     # -X: no peak calling, just the -f log (logIntervals, Genrich.c:837)
     yield dict(
         name="nopeaks_log", names=N2, args=["-X", "-q", "0.05"],
@@ -160,6 +167,16 @@ P_RUNS = {
     "bedx": [dict(args=["-q", "0.25", "-a", "30"], bed=[("chr1", 3000, 3400), ("chr1", 12000, 12345), ("chr2", 0, 777)])],
     "basic": [dict(args=["-a", "100", "-L", "1000"], bed=[("chrA", 12500, 12520)])],
 }
+
+
+def write_input(path, names, lens, ev, mixed, seed_off, prefix):
+    """The synthetic SAM / BAM input of one sample, by the writer the case asks for."""
+    if mixed and mixed.get("writer") == "dups":
+        synth.write_sam_dups(path, names, lens, ev, mixed["seed"] + seed_off, name_prefix=prefix, bam=mixed["bam"])
+    elif mixed:
+        synth.write_sam_mixed(path, names, lens, ev, mixed["seed"] + seed_off, name_prefix=prefix, bam=mixed["bam"])
+    else:
+        synth.write_sam(path, names, lens, ev, name_prefix=prefix)
 
 
 def gz_copy(src, dst):
@@ -191,10 +208,7 @@ def main():
             mixed = case.get("mixed")
             ext = "bam" if mixed and mixed["bam"] else "sam"
             p = os.path.join(tmp, f"t{r}.{ext}")
-            if mixed:
-                synth.write_sam_mixed(p, names, lens, ev, mixed["seed"], name_prefix=f"t{r}_", bam=mixed["bam"])
-            else:
-                synth.write_sam(p, names, lens, ev, name_prefix=f"t{r}_")
+            write_input(p, names, lens, ev, mixed, 0, f"t{r}_")
             tfiles.append(p)
             seen(names, lens)
             saves.append(list(names))
@@ -205,10 +219,7 @@ def main():
             else:
                 names, lens, ev = rep["c"]
                 p = os.path.join(tmp, f"c{r}.{ext}")
-                if mixed:
-                    synth.write_sam_mixed(p, names, lens, ev, mixed["seed"] + 1, name_prefix=f"c{r}_", bam=mixed["bam"])
-                else:
-                    synth.write_sam(p, names, lens, ev, name_prefix=f"c{r}_")
+                write_input(p, names, lens, ev, mixed, 1, f"c{r}_")
                 cfiles.append(p)
                 seen(names, lens)
         args = [REF, "-t", ",".join(tfiles), "-v",
@@ -225,6 +236,8 @@ def main():
                     f.write(f"{c}\t{s}\t{e}\n")
             args += ["-E", bp]
         args += case["args"]
+        if "-r" in case["args"]:
+            args += ["-R", os.path.join(tmp, "out.dups")]
         res = subprocess.run(args, capture_output=True, text=True)
         if res.returncode != 0:
             sys.exit(f"{case['name']}: reference failed:\n{res.stderr}")
@@ -249,10 +262,11 @@ def main():
             ref_genome_len=[int(v) for v in re.findall(r"Genome length: (\d+)bp", err)],
             ref_peaks=[[int(a), int(b)] for a, b in re.findall(r"Peaks identified: (\d+) \((\d+)bp\)", err)],
             tmp_prefix=tmp + "/",
+            ref_dups=[l.strip() for l in err.splitlines() if "aln sets:" in l or "duplicates:" in l],
         )
         with open(os.path.join(out_dir, "case.json"), "w") as f:
             json.dump(meta, f, indent=1)
-        for fn in ("events.bed", "out.narrowPeak", "out.log", "out.pile"):
+        for fn in ("events.bed", "out.narrowPeak", "out.log", "out.pile", "out.dups"):
             src = os.path.join(tmp, fn)
             if os.path.exists(src):
                 gz_copy(src, os.path.join(out_dir, fn + ".gz"))

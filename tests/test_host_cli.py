@@ -31,10 +31,7 @@ def _write_inputs(case, mg, tmp):
         mixed = case.get("mixed")
         ext = "bam" if mixed and mixed["bam"] else "sam"
         p = os.path.join(tmp, f"t{r}.{ext}")
-        if mixed:
-            synth.write_sam_mixed(p, names, lens, ev, mixed["seed"], name_prefix=f"t{r}_", bam=mixed["bam"])
-        else:
-            synth.write_sam(p, names, lens, ev, name_prefix=f"t{r}_")
+        mg.write_input(p, names, lens, ev, mixed, 0, f"t{r}_")
         tf.append(p)
         if rep["c"] is None:
             cf.append(None)
@@ -43,10 +40,7 @@ def _write_inputs(case, mg, tmp):
         else:
             names, lens, ev = rep["c"]
             p = os.path.join(tmp, f"c{r}.{ext}")
-            if mixed:
-                synth.write_sam_mixed(p, names, lens, ev, mixed["seed"] + 1, name_prefix=f"c{r}_", bam=mixed["bam"])
-            else:
-                synth.write_sam(p, names, lens, ev, name_prefix=f"c{r}_")
+            mg.write_input(p, names, lens, ev, mixed, 1, f"c{r}_")
             cf.append(p)
     args = ["-t", ",".join(tf)]
     if any(c is not None for c in cf):
@@ -73,9 +67,18 @@ def test_cli_event_stream_matches_reference(name, tmp_path):
     args = _write_inputs(case, mg, str(tmp_path / "in"))
     bed = str(tmp_path / "events.bed")
     a = [x for x in args if x != "-X"]
+    dups = str(tmp_path / "dups.txt")
+    if "-r" in a:  # -R: the log of removed PCR duplicates (file names in its '#' lines differ by directory)
+        a += ["-R", dups, "-v"]
     res = subprocess.run([_binary(), "--events-only", "-b", bed] + a, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
+    if "-r" in a:
+        strip = lambda txt: [l if not l.startswith("#") else l.rsplit("/", 1)[0].rsplit(" ", 1)[0] for l in txt.splitlines()]
+        assert strip(open(dups).read()) == strip(G.read_gz(name, "out.dups").decode())
+        meta, _, _, _ = G.load_case(name)
+        got = [l.strip() for l in res.stderr.splitlines() if "aln sets:" in l or "duplicates:" in l]
+        assert got == meta["ref_dups"]
 
 
 @pytest.mark.gpu
@@ -89,6 +92,8 @@ def test_cli_outputs_byte_identical(name):
     args = _write_inputs(case, mg, tmp)
     out = os.path.join(tmp, "cli_out")
     cmd = [_binary(), "-v", "-f", out + ".log", "-k", out + ".pile", "-b", out + ".bed"] + args
+    if "-r" in args:
+        cmd += ["-R", out + ".dups"]
     if "-X" not in case["args"]:
         cmd += ["-o", out + ".narrowPeak"]
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -98,6 +103,8 @@ def test_cli_outputs_byte_identical(name):
     assert open(out + ".log", "rb").read() == G.read_gz(name, "out.log")
     if "-X" not in case["args"]:
         assert open(out + ".narrowPeak", "rb").read() == G.read_gz(name, "out.narrowPeak")
+    if "-r" in args:
+        assert open(out + ".dups", "rb").read() == G.read_gz(name, "out.dups")
     lam = [f"{v:f}" for v in meta["ref_lambda"]]
     assert [l.split(": ")[1] for l in res.stderr.splitlines() if "Background pileup value" in l] == lam
     if meta["ref_peaks"]:
