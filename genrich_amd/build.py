@@ -32,9 +32,9 @@ HOST_BIN = os.path.join(HERE, "genrich-amd")
 
 def build_host(force: bool = False) -> str:
     """The command-line host program (C++, g++): SAM/BAM ingest + options over the C ABI."""
-    if force or not os.path.exists(HOST_BIN) or os.path.getmtime(HOST_BIN) < max(
-            os.path.getmtime(HOST_SRC), os.path.getmtime(LIB)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", HOST_SRC, "-o", HOST_BIN, "-L" + HERE,
+    deps = [HOST_SRC, os.path.join(os.path.dirname(HOST_SRC), "bgzf_reader.h"), LIB]
+    if force or not os.path.exists(HOST_BIN) or os.path.getmtime(HOST_BIN) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", HOST_SRC, "-o", HOST_BIN, "-L" + HERE,
                                "-lgenrich_amd", "-lz", "-Wl,-rpath,$ORIGIN"])
     return HOST_BIN
 

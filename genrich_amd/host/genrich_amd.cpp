@@ -12,8 +12,9 @@
 // -P (peak calling from a -f log, callPeaksLog 1277-1488) is text processing and runs on the host,
 // and so does -r / -R (PCR-duplicate removal, Genrich.c:2776-2977 and 3267-4042).
 //
-// Extra long option (diagnostics, never needed for normal use):
-//   --events-only   parse and write the -b file without touching a GPU
+// Extra long options:
+//   --threads N     threads that inflate BGZF (BAM, bgzip-ped SAM) input; default min(8, cores)
+//   --events-only   parse and write the -b file without touching a GPU (diagnostics)
 #include <getopt.h>
 #include <zlib.h>
 
@@ -31,6 +32,7 @@
 #include <vector>
 
 #include "../../include/genrich_amd.h"
+#include "bgzf_reader.h"
 
 #define VERSION "0.6.2-amd"
 #define MAX_ALNS 128  // Genrich.h:17 (also the length of stored read names)
@@ -639,17 +641,14 @@ bool parseAlign(State& S, std::vector<Aln>& aln, uint16_t flag, int ci, uint32_t
 }
 
 // ---- input: one gz-transparent byte stream (plain, gzip or BGZF) ------------------------------
-struct In {
-  gzFile gz = nullptr;
-  std::string name;
-};
-In openRead(const char* path) {
-  In in;
-  in.name = path;
-  in.gz = !strcmp(path, "-") ? gzdopen(fileno(stdin), "rb") : gzopen(path, "rb");
-  if (!in.gz) die(path, ": cannot open file for reading");
-  gzbuffer(in.gz, 1 << 20);
-  return in;
+// (BGZF members are inflated by a pool of threads, bgzf_reader.h; everything else through zlib's gz*)
+typedef gxhost::Input In;
+int g_threads = 1;
+void openRead(In& in, const char* path) {
+  if (!in.open(path, g_threads)) die(path, ": cannot open file for reading");
+}
+void checkIn(In& in) {
+  if (!in.error().empty()) die(in.name(), (": " + in.error()).c_str());
 }
 
 // distance to the 3' end from a SAM CIGAR (parseCigar 4408, calcDist 4451)
@@ -810,7 +809,7 @@ uint64_t readSAM(State& S, In& in, char* first, Counts& C) {
   for (;;) {
     char* l;
     if (useFirst) { l = first; useFirst = false; }
-    else if (!(l = gzgets(in.gz, line.data(), (int)line.size()))) break;
+    else if (!(l = in.gets(line.data(), (int)line.size()))) break;
     if (l[0] == '@') {
       if (pastHeader) die(l, ": misplaced SAM header line");
       headerLine(S, l);
@@ -855,10 +854,10 @@ uint64_t readSAM(State& S, In& in, char* first, Counts& C) {
 }
 
 // ---- BAM (readBAM 4983-5068, parseBAM 4826-4977, getBAMscore 4751) -----------------------------
-bool gzReadAll(gzFile g, void* dst, size_t n) { return n == 0 || gzread(g, dst, (unsigned)n) == (int)n; }
-int32_t rdI32(gzFile g, bool must) {
+bool gzReadAll(In& g, void* dst, size_t n) { return n == 0 || g.read(dst, n) == n; }
+int32_t rdI32(In& g, bool must) {
   uint8_t b[4];
-  int k = gzread(g, b, 4);
+  int k = (int)g.read(b, 4);
   if (k == 0 && !must) return -1;  // clean EOF between records
   if (k != 4) die("", "Cannot parse BAM file");
   return (int32_t)(b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24));
@@ -898,7 +897,7 @@ float bamScore(const uint8_t* p, const uint8_t* end) {
 }
 
 uint64_t readBAM(State& S, In& in, Counts& C) {
-  gzFile g = in.gz;
+  In& g = in;
   int32_t l_text = rdI32(g, true);
   std::vector<char> text((size_t)l_text + 1, 0);
   if (!gzReadAll(g, text.data(), (size_t)l_text)) die("", "Cannot parse BAM file");
@@ -1033,20 +1032,21 @@ void logCounts(const State& S, const Counts& C, bool bam) {
 // it: first appearance over t1, c1, t2, c2, ...) before anything is sent to the device
 void scanHeader(State& S, const char* filename, bool ctrl) {
   if (!strcmp(filename, "-")) return;
-  In in = openRead(filename);
+  In in;
+  openRead(in, filename);
   S.ctrl = ctrl;
   char magic[4];
-  int got = gzread(in.gz, magic, 4);
+  int got = (int)in.read(magic, 4);
   if (got == 4 && !memcmp(magic, "BAM\1", 4)) {
-    int32_t l_text = rdI32(in.gz, true);
-    if (gzseek(in.gz, l_text, SEEK_CUR) == -1) die("", "Cannot parse BAM file");
-    int32_t n_ref = rdI32(in.gz, true);
+    int32_t l_text = rdI32(in, true);
+    if (!in.skip((size_t)l_text)) die("", "Cannot parse BAM file");
+    int32_t n_ref = rdI32(in, true);
     for (int i = 0; i < n_ref; i++) {
-      int32_t len = rdI32(in.gz, true);
+      int32_t len = rdI32(in, true);
       if (len < 1 || len > 65520) die("", "Cannot parse BAM file");
       std::vector<char> nm((size_t)len);
-      if (!gzReadAll(in.gz, nm.data(), (size_t)len)) die("", "Cannot parse BAM file");
-      saveChrom(S, nm.data(), (uint32_t)rdI32(in.gz, true));
+      if (!gzReadAll(in, nm.data(), (size_t)len)) die("", "Cannot parse BAM file");
+      saveChrom(S, nm.data(), (uint32_t)rdI32(in, true));
     }
   } else {
     std::vector<char> line(65520);
@@ -1057,8 +1057,8 @@ void scanHeader(State& S, const char* filename, bool ctrl) {
       char* l = line.data();
       if (first) {
         first = false;
-        if (got > 0 && !memchr(magic, '\n', (size_t)got) && !gzgets(in.gz, l + got, (int)line.size() - got)) l[got] = '\0';
-      } else if (!gzgets(in.gz, l, (int)line.size()))
+        if (got > 0 && !memchr(magic, '\n', (size_t)got) && !in.gets(l + got, (int)line.size() - got)) l[got] = '\0';
+      } else if (!in.gets(l, (int)line.size()))
         break;
       if (l[0] != '@') break;
       const bool sortSave = S.o.sortOpt;
@@ -1067,7 +1067,8 @@ void scanHeader(State& S, const char* filename, bool ctrl) {
       S.o.sortOpt = sortSave;
     }
   }
-  gzclose(in.gz);
+  checkIn(in);
+  in.close();
 }
 
 void sendChroms(State& S) {
@@ -1092,8 +1093,9 @@ void loadBED(State& S, const char* files) {  // loadBED 5187-5238
   std::string list(files);
   std::vector<char> line(65520);
   for (char* fn = strtok(list.data(), ", "); fn; fn = strtok(nullptr, ", ")) {
-    In in = openRead(fn);
-    while (gzgets(in.gz, line.data(), (int)line.size())) {
+    In in;
+  openRead(in, fn);
+    while (in.gets(line.data(), (int)line.size())) {
       std::string orig(line.data());
       char* name = strtok(line.data(), "\t");
       char* a = name ? strtok(nullptr, "\t") : nullptr;
@@ -1107,7 +1109,8 @@ void loadBED(State& S, const char* files) {  // loadBED 5187-5238
       }
       S.xbed.push_back(BedRec{name, {(uint32_t)p0, (uint32_t)p1}});
     }
-    gzclose(in.gz);
+    checkIn(in);
+  in.close();
   }
 }
 
@@ -1137,12 +1140,13 @@ struct PeakState {
 
 void peaksOnly(State& S, float thr) {
   const Opts& o = S.o;
-  In in = openRead(o.logFile);
+  In in;
+  openRead(in, o.logFile);
   Out out = openWrite(o.outFile, o.gzOut);
   if (o.verbose) fprintf(stderr, "Peak-calling from log file: %s\n", o.logFile);
   std::vector<char> line(65520);
   // header: the LAST -log(p) / -log(q) columns (getIdx 1224-1246)
-  if (!gzgets(in.gz, line.data(), (int)line.size())) die("<header>", ": cannot find field in header of bedgraph-ish log file");
+  if (!in.gets(line.data(), (int)line.size())) die("<header>", ": cannot find field in header of bedgraph-ish log file");
   int idxP = -1, idxQ = -1, nf = 0;
   for (char* f = strtok(line.data(), "\t\n"); f; f = strtok(nullptr, "\t\n"), nf++) {
     if (!strncmp(f, "-log(p)", 7)) idxP = nf;
@@ -1174,7 +1178,7 @@ void peaksOnly(State& S, float thr) {
     }
   };
   auto nextBed = [&]() { bedIdx++; bedPos = bedIdx < cur.bed.size() ? cur.bed[bedIdx] : UINT32_MAX; };
-  while (gzgets(in.gz, line.data(), (int)line.size())) {
+  while (in.gets(line.data(), (int)line.size())) {
     // loadBDG 1252-1272
     char *chr = nullptr, *pStat = nullptr, *qStat = nullptr;
     uint32_t start = 0, end = 0;
@@ -1265,7 +1269,8 @@ void peaksOnly(State& S, float thr) {
     fprintf(stderr, "  Max. gap between sites: %dbp\n", o.maxGap);
     fprintf(stderr, "Peaks identified: %d (%ldbp)\n", count, (long)peakBP);
   }
-  gzclose(in.gz);
+  checkIn(in);
+  in.close();
   closeOut(out);
 }
 
@@ -1287,7 +1292,13 @@ int main(int argc, char** argv) {
                                      {"version", no_argument, nullptr, 'V'},
                                      {"events-only", no_argument, nullptr, 1000},
                                      {"device", required_argument, nullptr, 1001},
+                                     {"threads", required_argument, nullptr, 1002},
                                      {nullptr, 0, nullptr, 0}};
+  {  // BGZF inflate threads: --threads N, else GENRICH_THREADS, else up to 8 of the machine's cores
+    const char* e = getenv("GENRICH_THREADS");
+    unsigned hw = std::thread::hardware_concurrency();
+    g_threads = e ? atoi(e) : (int)std::min(8u, hw ? hw : 1u);
+  }
   int c;
   while ((c = getopt_long(argc, argv, "ht:c:o:f:k:b:zyw:xjd:De:E:m:s:p:q:a:l:g:rR:XPSL:vV", longOpts, nullptr)) != -1)
     switch (c) {
@@ -1323,6 +1334,7 @@ int main(int argc, char** argv) {
       case 'V': fprintf(stderr, "genrich-amd, version %s (Genrich 0.6.2 hot path on MI355X)\n", VERSION); exit(EXIT_FAILURE);
       case 1000: o.eventsOnly = true; break;
       case 1001: o.device = getInt(optarg); break;
+      case 1002: g_threads = getInt(optarg); break;
       case 'h': usage();
       default: exit(EXIT_FAILURE);
     }
@@ -1399,10 +1411,11 @@ int main(int argc, char** argv) {
       S.sampleOpen = false;
       S.errCount = 0;
       S.buf.clear();
-      In in = openRead(filename);
+      In in;
+  openRead(in, filename);
       // BAM or SAM?  (checkBAM 5107: the decompressed stream starts with "BAM\1")
       char magic[4] = {0};
-      int got = gzread(in.gz, magic, 4);
+      int got = (int)in.read(magic, 4);
       bool bam = got == 4 && !memcmp(magic, "BAM\1", 4);
       if (o.verbose) fprintf(stderr, "Processing %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
       if (S.dupsVerb) fprintf(S.dups.f, "# %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
@@ -1417,12 +1430,13 @@ int main(int argc, char** argv) {
         memcpy(firstLine.data(), magic, (size_t)got);
         firstLine[got] = '\0';
         if (!memchr(magic, '\n', (size_t)got)) {
-          if (!gzgets(in.gz, firstLine.data() + got, (int)firstLine.size() - got)) firstLine[got] = '\0';
+          if (!in.gets(firstLine.data() + got, (int)firstLine.size() - got)) firstLine[got] = '\0';
         } else
           die(filename, ": poorly formatted SAM/BAM record");
         readSAM(S, in, firstLine.data(), C);
       }
-      gzclose(in.gz);
+      checkIn(in);
+  in.close();
       openSample(S);  // a file without a single usable record still opens (and closes) its sample
       if (S.gx && !S.buf.empty()) check(S, gx_push_events(S.gx, S.buf.data(), S.buf.size()));
       S.buf.clear();

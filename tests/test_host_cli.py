@@ -137,3 +137,53 @@ def test_cli_peaks_from_log(name, k, pr, tmp_path):
     res = subprocess.run(args, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert open(tmp_path / "np", "rb").read() == G.read_gz(name, f"out.P{k}.narrowPeak")
+
+
+def _bgzf(data, block=30_000):
+    """BGZF (SAM spec 4.1): independent gzip members of < 64 KiB with a 'BC' extra field, plus the
+    empty end-of-file member."""
+    import struct
+    import zlib
+    out = bytearray()
+    for off in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if off is None else data[off:off + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = c.compress(chunk) + c.flush()
+        bsize = 18 + len(payload) + 8 - 1
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + payload
+        out += struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+@pytest.mark.parametrize("name", ["unpaired_bam_atac", "dups_x_bam", "ctrl_q"])
+def test_cli_bgzf_input_parallel_inflate(name, tmp_path):
+    """BGZF input (what samtools / bgzip write) is inflated by a thread pool; the event stream must be
+    the one the single-threaded zlib path (and the reference) produce."""
+    cases, mg = _cases()
+    case = cases[name]
+    args = _write_inputs(case, mg, str(tmp_path / "in"))
+    for i, a in enumerate(args):  # re-compress every input file as BGZF
+        for p in (a.split(",") if i and args[i - 1] in ("-t", "-c") else []):
+            if p != "null":
+                raw = open(p, "rb").read()
+                if p.endswith(".bam"):
+                    raw = gzip.decompress(raw)
+                open(p, "wb").write(_bgzf(raw))
+    a = [x for x in args if x != "-X"]
+    for threads in ("4", "1"):
+        bed = str(tmp_path / f"events{threads}.bed")
+        res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-b", bed] + a, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
+
+
+def test_cli_bgzf_corrupt_block_is_an_error(tmp_path):
+    cases, mg = _cases()
+    args = _write_inputs(cases["basic"], mg, str(tmp_path / "in"))
+    p = args[1]
+    z = bytearray(_bgzf(open(p, "rb").read()))
+    z[len(z) // 2] ^= 0x5A
+    open(p, "wb").write(bytes(z))
+    res = subprocess.run([_binary(), "--events-only", "--threads", "4", "-b", str(tmp_path / "e.bed")] + args,
+                         capture_output=True, text=True)
+    assert res.returncode != 0 and "BGZF" in res.stderr
