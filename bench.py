@@ -82,10 +82,21 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # GX_BENCH_BACKEND=gloo is a validation mode for a box with fewer GPUs than ranks: ranks share the
+    # devices round-robin and the (tiny) collectives go through host memory; it is labelled in `config`
+    backend = os.environ.get("GX_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local >= ndev:
+        sys.exit(f"rank {rank}: no GPU {local} on this node ({ndev} visible)")
+    local_dev = local % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     lens = synth.HG38_LENS
     G = int(sum(lens))
@@ -101,11 +112,11 @@ def main():
         d_ct = torch.from_numpy(ct.view(np.uint32).reshape(-1, 4).copy()).to(dev)
     torch.cuda.synchronize()
 
-    params = GxParams(minus_log10f(0.05 if args.qval else 0.01), int(args.qval), 200.0, 0, 100, local, 0)
+    params = GxParams(minus_log10f(0.05 if args.qval else 0.01), int(args.qval), 200.0, 0, 100, local_dev, 0)
     gx = Genrich(params)
     gx.set_chroms(lens)
     if world > 1:
-        coll = Collectives(device=dev)
+        coll = Collectives(device=cdev)
         gx.set_owned(owned)
         gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
 
@@ -140,10 +151,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        npk = torch.tensor([res[0]], dtype=torch.int64, device=dev)
+        npk = torch.tensor([res[0]], dtype=torch.int64, device=cdev)
         dist.all_reduce(npk)
         n_peaks = int(npk.item())
     else:
@@ -185,7 +196,8 @@ def main():
                 "workload": f"hg38 25 contigs ({G} bp), {args.frags} paired fragments, treatment only, "
                             + ("-q 0.05" if args.qval else "-p 0.01")
                             + (" + 50M-fragment control (configs[2] shape)" if args.control else " (BASELINE.json configs[1])"),
-                "parallelism": f"chromosome-sharded x{world}",
+                "parallelism": f"chromosome-sharded x{world}"
+                               + ("" if backend == "nccl" or world == 1 else f" ({backend} validation mode, {ndev} GPU(s))"),
                 "peaks": n_peaks,
             },
             "roofline": {

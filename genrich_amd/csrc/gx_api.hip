@@ -148,7 +148,8 @@ struct gx_ctx {
   int finalIdx = -1;
   // BH
   DevBuf pvLut;
-  DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp;
+  DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp, bhRecs;
+  PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   // sweep
   DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
   PinnedBuf hPeaks;             // the peak list on the host (pinned: the read-back is asynchronous)
@@ -1091,41 +1092,33 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     if (ctx->world > 1 && ctx->allgather) {
       // every rank contributes its {p bits, bp} pairs; all ranks rebuild the same genome-wide table
       // (hashPval 300-327 runs over all chromosomes)
-      struct Rec { u32 key, pad; u64 bp; };
-      std::vector<u32> hk(D), hs(D);
-      std::vector<u64> hl((size_t)cap);
+      HIPCHECK(ctx->bhRecs.ensure((size_t)std::max(D, 1u) * sizeof(BhRec)));
+      HIPCHECK(ctx->hostRecs.ensure((size_t)std::max(D, 1u) * sizeof(BhRec)));
       if (D) {
-        HIPCHECK(hipMemcpy(hk.data(), ctx->bhOutKeys.p, (size_t)D * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(hs.data(), ctx->bhOutSlot.p, (size_t)D * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(hl.data(), ctx->bhLens.p, (size_t)cap * 8, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k_bh_pack, dim3(std::max(1u, std::min((D + 255) / 256, 1024u))), dim3(256), 0, s,
+                           ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), ctx->bhLens.as<u64>(), D,
+                           ctx->bhRecs.as<BhRec>());
+        HIPCHECK(hipMemcpyAsync(ctx->hostRecs.p, ctx->bhRecs.p, (size_t)D * sizeof(BhRec), hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
       }
-      std::vector<Rec> mine(D);
-      for (u32 i = 0; i < D; i++) mine[i] = Rec{hk[i], 0u, hl[hs[i]]};
       void* all = nullptr;
       size_t nAll = 0;
-      if (ctx->allgather(mine.data(), D, &all, &nAll, ctx->user)) {
+      if (ctx->allgather(ctx->hostRecs.p, D, &all, &nAll, ctx->user)) {
         ctx->err = "allgather callback failed";
         return GX_ERR_DEVICE;
       }
-      std::vector<u32> ak(nAll);
-      std::vector<u64> al(nAll);
-      const Rec* ar = static_cast<const Rec*>(all);
-      for (size_t i = 0; i < nAll; i++) { ak[i] = ar[i].key; al[i] = ar[i].bp; }
-      free(all);
       HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)cap * 4, s));
       HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)cap * 8, s));
       HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
       if (nAll) {
-        DevBuf dk, dl;
-        HIPCHECK(dk.ensure(nAll * 4));
-        HIPCHECK(dl.ensure(nAll * 8));
-        HIPCHECK(hipMemcpyAsync(dk.p, ak.data(), nAll * 4, hipMemcpyHostToDevice, s));
-        HIPCHECK(hipMemcpyAsync(dl.p, al.data(), nAll * 8, hipMemcpyHostToDevice, s));
+        HIPCHECK(ctx->bhRecs.ensure(nAll * sizeof(BhRec)));
+        HIPCHECK(hipMemcpyAsync(ctx->bhRecs.p, all, nAll * sizeof(BhRec), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_bh_insert, dim3(std::max<u32>(1, std::min<size_t>((nAll + 255) / 256, 1024))), dim3(256), 0,
-                           s, dk.as<u32>(), dl.as<u64>(), (u32)nAll, ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(),
-                           cap - 1, ctx->dStatus.as<u32>());
-        HIPCHECK(hipStreamSynchronize(s));
+                           s, ctx->bhRecs.as<BhRec>(), (u32)nAll, ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1,
+                           ctx->dStatus.as<u32>());
+        HIPCHECK(hipStreamSynchronize(s));  // `all` is read by the copy until here
       }
+      free(all);
       hipLaunchKernelGGL(k_bh_compact, dim3(1024), dim3(256), 0, s, ctx->bhKeys.as<u32>(), cap,
                          ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), misc + M_BHCOUNT);
       HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));

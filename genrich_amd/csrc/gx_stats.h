@@ -260,12 +260,19 @@ __global__ __launch_bounds__(256) void k_bh_compact(const u32* __restrict__ gKey
   }
 }
 
-// insert (key, bp) pairs gathered from other ranks
-__global__ __launch_bounds__(256) void k_bh_insert(const u32* __restrict__ keys, const u64* __restrict__ lens, u32 n,
-                                                   u32* __restrict__ gKeys, u64* __restrict__ gLens, u32 capMask,
-                                                   u32* __restrict__ st) {
+// the exchange format of the multi-GPU BH table: this rank's distinct values as dense records ...
+struct BhRec { u32 key, pad; u64 bp; };
+
+__global__ __launch_bounds__(256) void k_bh_pack(const u32* __restrict__ keys, const u32* __restrict__ slots,
+                                                 const u64* __restrict__ gLens, u32 n, BhRec* __restrict__ out) {
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = BhRec{keys[i], 0u, gLens[slots[i]]};
+}
+
+// ... and the insertion of every rank's records into a fresh table
+__global__ __launch_bounds__(256) void k_bh_insert(const BhRec* __restrict__ recs, u32 n, u32* __restrict__ gKeys,
+                                                   u64* __restrict__ gLens, u32 capMask, u32* __restrict__ st) {
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-    bh_global_add(gKeys, gLens, capMask, keys[i], lens[i], st);
+    bh_global_add(gKeys, gLens, capMask, recs[i].key, recs[i].bp, st);
 }
 
 // float log10 exactly as the host's libm evaluates it (saveQval 221, 226 call log10f).
