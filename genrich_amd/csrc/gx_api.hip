@@ -150,6 +150,7 @@ struct gx_ctx {
   DevBuf pvLut;
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp, bhRecs;
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
+  bool bhDirty = false;         // the BH table was left with entries (an error path): wipe it before use
   // sweep
   DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
   PinnedBuf hPeaks;             // the peak list on the host (pinned: the read-back is asynchronous)
@@ -1070,22 +1071,24 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   if (ctx->par.qval_opt) {
     phase_begin(ctx, "bh");
     const u32 cap = 1u << 22;
+    const bool fresh = ctx->bhKeys.cap < (size_t)cap * 4;
     HIPCHECK(ctx->bhKeys.ensure((size_t)cap * 4));
     HIPCHECK(ctx->bhLens.ensure((size_t)cap * 8));
     HIPCHECK(ctx->bhQ.ensure((size_t)cap * 4));
-    HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)cap * 4, s));
-    HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)cap * 8, s));
-    HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
-    hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
-                       fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV,
-                       ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
-    // occupied slots -> (key, slot), then sort by key
     HIPCHECK(ctx->bhOutKeys.ensure((size_t)cap * 4));
     HIPCHECK(ctx->bhOutSlot.ensure((size_t)cap * 4));
-    hipLaunchKernelGGL(k_bh_compact, dim3(1024), dim3(256), 0, s, ctx->bhKeys.as<u32>(), cap, ctx->bhOutKeys.as<u32>(),
-                       ctx->bhOutSlot.as<u32>(), misc + M_BHCOUNT);
-  if (int rc__ = dbg_sync(ctx, "k_bh_compact")) return rc__;
+    if (fresh || ctx->bhDirty) {  // normally the table comes back clean from the previous call (k_bh_clear)
+      HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)cap * 4, s));
+      HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)cap * 8, s));
+    }
+    ctx->bhDirty = true;
+    HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
+    BhTable T{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
+              misc + M_BHCOUNT};
+    hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
+                       fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
+                       ctx->dStatus.as<u32>());
+  if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
     HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     u32 D = ctx->mail->D;
@@ -1107,20 +1110,16 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
         ctx->err = "allgather callback failed";
         return GX_ERR_DEVICE;
       }
-      HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)cap * 4, s));
-      HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)cap * 8, s));
+      hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);  // this rank's own entries out, everybody's in
       HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
       if (nAll) {
         HIPCHECK(ctx->bhRecs.ensure(nAll * sizeof(BhRec)));
         HIPCHECK(hipMemcpyAsync(ctx->bhRecs.p, all, nAll * sizeof(BhRec), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_bh_insert, dim3(std::max<u32>(1, std::min<size_t>((nAll + 255) / 256, 1024))), dim3(256), 0,
-                           s, ctx->bhRecs.as<BhRec>(), (u32)nAll, ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1,
-                           ctx->dStatus.as<u32>());
+                           s, ctx->bhRecs.as<BhRec>(), (u32)nAll, T, ctx->dStatus.as<u32>());
         HIPCHECK(hipStreamSynchronize(s));  // `all` is read by the copy until here
       }
       free(all);
-      hipLaunchKernelGGL(k_bh_compact, dim3(1024), dim3(256), 0, s, ctx->bhKeys.as<u32>(), cap,
-                         ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), misc + M_BHCOUNT);
       HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
       HIPCHECK(hipStreamSynchronize(s));
       D = ctx->mail->D;
@@ -1141,8 +1140,19 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     }
     HIPCHECK(pooled(ctx, fa.q, (size_t)n * 4 + 16));
-    hipLaunchKernelGGL(k_qlookup, dim3(gridIv), dim3(256), 0, s, fa.p.as<float>(), misc + M_NIV, ctx->bhKeys.as<u32>(),
-                       ctx->bhQ.as<float>(), cap - 1, fa.q.as<float>());
+    {  // q-values and, on the way, the sweep's significance / SKIP masks
+      const size_t stride = (size_t)((n + 63) / 64) + 2;
+      HIPCHECK(ctx->swMask.ensure(stride * 8 * 3));
+      HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, stride * 8 * 3, s));
+      ctx->maskIdx = ctx->finalIdx;
+      ctx->maskN = n;
+      ctx->maskStride = stride;
+      hipLaunchKernelGGL(k_qlookup, dim3(std::max(1u, std::min((n + 4095) / 4096, 4096u))), dim3(256), 0, s, fa.p.as<float>(),
+                         misc + M_NIV, ctx->bhKeys.as<u32>(), ctx->bhQ.as<float>(), cap - 1, fa.q.as<float>(), ctx->par.thr,
+                         ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride);
+    }
+    hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+    ctx->bhDirty = false;
   if (int rc__ = dbg_sync(ctx, "k_qlookup")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
@@ -1153,7 +1163,8 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   const u32 nWords = (n + 63) / 64;
   const u32 wChunks = (nWords + SW_CHUNK - 1) / SW_CHUNK;
   // three bit masks + chunk count/offset scratch
-  const bool haveMasks = !ctx->par.qval_opt && ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;  // from the pack kernels
+  // the masks were filled by the pack kernels (p mode, one replicate) or by k_qlookup (q mode)
+  const bool haveMasks = ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;
   const size_t mStride = haveMasks ? ctx->maskStride : (size_t)nWords + 2;
   HIPCHECK(ctx->swMask.ensure(mStride * 8 * 3));
   if (haveMasks)

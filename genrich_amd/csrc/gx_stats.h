@@ -194,26 +194,49 @@ __device__ __forceinline__ u32 bh_hash(u32 k) {
   return k ^ (k >> 15);
 }
 
-__device__ __forceinline__ void bh_global_add(u32* __restrict__ gKeys, u64* __restrict__ gLens, u32 capMask,
-                                              u32 key, u64 len, u32* st) {
-  u32 h = bh_hash(key) & capMask;
-  for (u32 probe = 0; probe <= capMask; probe++) {
-    u32 old = gKeys[h];
+// the global table plus the list of its occupied slots: whoever claims a slot appends (key, slot),
+// so that neither finding the distinct values nor cleaning up afterwards has to scan the table
+struct BhTable {
+  u32* keys;      // [cap] EMPTY_KEY when free
+  u64* lens;      // [cap] bp
+  u32 capMask;
+  u32* outKeys;   // [<= cap] claimed keys, arbitrary order (sorted afterwards)
+  u32* outSlot;
+  u32* counter;
+};
+
+__device__ __forceinline__ void bh_global_add(const BhTable& T, u32 key, u64 len, u32* st) {
+  u32 h = bh_hash(key) & T.capMask;
+  for (u32 probe = 0; probe <= T.capMask; probe++) {
+    u32 old = T.keys[h];
     if (old != key) {
-      if (old != EMPTY_KEY) { h = (h + 1) & capMask; continue; }
-      old = atomicCAS(&gKeys[h], EMPTY_KEY, key);
-      if (old != EMPTY_KEY && old != key) { h = (h + 1) & capMask; continue; }
+      if (old != EMPTY_KEY) { h = (h + 1) & T.capMask; continue; }
+      old = atomicCAS(&T.keys[h], EMPTY_KEY, key);
+      if (old == EMPTY_KEY) {  // this thread claimed the slot
+        const u32 j = atomicAdd(T.counter, 1u);
+        T.outKeys[j] = key;
+        T.outSlot[j] = h;
+      } else if (old != key) { h = (h + 1) & T.capMask; continue; }
     }
-    atomicAdd(&gLens[h], len);
+    atomicAdd(&T.lens[h], len);
     return;
   }
   atomicOr(st, ST_HASH_FULL);
 }
 
+// frees the claimed slots again (the table is handed back clean instead of being wiped per call)
+__global__ __launch_bounds__(256) void k_bh_clear(BhTable T) {
+  const u32 n = *T.counter;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const u32 h = T.outSlot[i];
+    T.keys[h] = EMPTY_KEY;
+    T.lens[h] = 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bh_hist(const u32* __restrict__ end, const float* __restrict__ p,
                                                  const u32* __restrict__ chromOff, u32 nChrom,
-                                                 const u32* __restrict__ nPtr, u32* __restrict__ gKeys,
-                                                 u64* __restrict__ gLens, u32 capMask, u32* __restrict__ st) {
+                                                 const u32* __restrict__ nPtr, BhTable T, u32* __restrict__ st) {
   __shared__ u32 lk[BH_LT];
   __shared__ u64 ll[BH_LT];
   for (int i = threadIdx.x; i < BH_LT; i += 256) { lk[i] = EMPTY_KEY; ll[i] = 0; }
@@ -222,42 +245,48 @@ __global__ __launch_bounds__(256) void k_bh_hist(const u32* __restrict__ end, co
   const u32 per = (n + gridDim.x - 1) / gridDim.x;
   const u32 b0 = blockIdx.x * per, b1 = min(n, b0 + per);
   ChromCursor cur;
-  for (u32 i = b0 + threadIdx.x; i < b1; i += 256) {
-    float pv = p[i];
-    if (pv == GX_SKIPF) continue;  // 319
-    cur.seek(chromOff, nChrom, i);
-    u32 s = i == cur.lo ? 0 : end[i - 1];
-    u64 len = end[i] - s;
-    u32 key = pv == 0.0f ? 0u : __float_as_uint(pv);
-    u32 h = bh_hash(key) & (BH_LT - 1);
-    bool placed = false;
-    for (int probe = 0; probe < BH_LPROBE && !placed; probe++) {
-      u32 old = lk[h];
-      if (old != key) {
-        if (old == EMPTY_KEY) old = atomicCAS(&lk[h], EMPTY_KEY, key);
-        if (old != EMPTY_KEY && old != key) { h = (h + 1) & (BH_LT - 1); continue; }
+  for (u32 i0 = b0 + threadIdx.x; i0 < b1; i0 += 4 * 256) {  // four intervals per thread in flight
+    float pv4[4];
+    u32 e4[4], s4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 i = i0 + k * 256;
+      pv4[k] = GX_SKIPF;
+      e4[k] = 0;
+      s4[k] = 0;
+      if (i < b1) {
+        pv4[k] = p[i];
+        e4[k] = end[i];
+        s4[k] = i ? end[i - 1] : 0u;
       }
-      atomicAdd(&ll[h], len);
-      placed = true;
     }
-    if (!placed) bh_global_add(gKeys, gLens, capMask, key, len, st);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 i = i0 + k * 256;
+      const float pv = pv4[k];
+      if (i < b1 && pv != GX_SKIPF) {  // 319
+        cur.seek(chromOff, nChrom, i);
+        const u32 s = i == cur.lo ? 0u : s4[k];
+        const u64 len = e4[k] - s;
+        const u32 key = pv == 0.0f ? 0u : __float_as_uint(pv);
+        u32 h = bh_hash(key) & (BH_LT - 1);
+        bool placed = false;
+        for (int probe = 0; probe < BH_LPROBE && !placed; probe++) {
+          u32 old = lk[h];
+          if (old != key) {
+            if (old == EMPTY_KEY) old = atomicCAS(&lk[h], EMPTY_KEY, key);
+            if (old != EMPTY_KEY && old != key) { h = (h + 1) & (BH_LT - 1); continue; }
+          }
+          atomicAdd(&ll[h], len);
+          placed = true;
+        }
+        if (!placed) bh_global_add(T, key, len, st);
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < BH_LT; i += 256)
-    if (lk[i] != EMPTY_KEY) bh_global_add(gKeys, gLens, capMask, lk[i], ll[i], st);
-}
-
-// occupied slots -> (key, slot) pairs, arbitrary order (sorted afterwards)
-__global__ __launch_bounds__(256) void k_bh_compact(const u32* __restrict__ gKeys, u32 cap, u32* __restrict__ outKeys,
-                                                    u32* __restrict__ outSlot, u32* __restrict__ counter) {
-  for (u32 s = blockIdx.x * 256 + threadIdx.x; s < cap; s += gridDim.x * 256) {
-    u32 k = gKeys[s];
-    if (k != EMPTY_KEY) {
-      u32 j = atomicAdd(counter, 1u);
-      outKeys[j] = k;
-      outSlot[j] = s;
-    }
-  }
+    if (lk[i] != EMPTY_KEY) bh_global_add(T, lk[i], ll[i], st);
 }
 
 // the exchange format of the multi-GPU BH table: this rank's distinct values as dense records ...
@@ -269,10 +298,8 @@ __global__ __launch_bounds__(256) void k_bh_pack(const u32* __restrict__ keys, c
 }
 
 // ... and the insertion of every rank's records into a fresh table
-__global__ __launch_bounds__(256) void k_bh_insert(const BhRec* __restrict__ recs, u32 n, u32* __restrict__ gKeys,
-                                                   u64* __restrict__ gLens, u32 capMask, u32* __restrict__ st) {
-  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-    bh_global_add(gKeys, gLens, capMask, recs[i].key, recs[i].bp, st);
+__global__ __launch_bounds__(256) void k_bh_insert(const BhRec* __restrict__ recs, u32 n, BhTable T, u32* __restrict__ st) {
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) bh_global_add(T, recs[i].key, recs[i].bp, st);
 }
 
 // float log10 exactly as the host's libm evaluates it (saveQval 221, 226 call log10f).
@@ -392,18 +419,43 @@ __global__ __launch_bounds__(1024) void k_qtable(const u32* __restrict__ keys, c
   }
 }
 
-// per interval: q = table[p] (lookup 196-206), SKIP stays SKIP (237-238)
+// per interval: q = table[p] (lookup 196-206), SKIP stays SKIP (237-238); the sweep's significance /
+// SKIP masks are written on the way (whole words: one wavefront per 64 intervals, four words per
+// iteration so that four loads per lane are in flight)
 __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, const u32* __restrict__ nPtr,
                                                  const u32* __restrict__ gKeys, const float* __restrict__ qOfSlot,
-                                                 u32 capMask, float* __restrict__ q) {
+                                                 u32 capMask, float* __restrict__ q, float thr, u64* __restrict__ sigMask,
+                                                 u64* __restrict__ skipMask) {
   const u32 n = *nPtr;
-  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    float pv = p[i];
-    if (pv == GX_SKIPF) { q[i] = GX_SKIPF; continue; }
-    u32 key = pv == 0.0f ? 0u : __float_as_uint(pv);
-    u32 h = bh_hash(key) & capMask;
-    while (gKeys[h] != key) h = (h + 1) & capMask;  // every p was inserted
-    q[i] = qOfSlot[h];
+  const u32 nw = (n + 63) >> 6;
+  for (u32 w0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; w0 < nw; w0 += gridDim.x * 16) {
+    float pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 i = ((w0 + k) << 6) + lane_id();
+      pv[k] = i < n ? p[i] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 i = ((w0 + k) << 6) + lane_id();
+      float qv = 0.0f;
+      if (i < n) {
+        if (pv[k] == GX_SKIPF)
+          qv = GX_SKIPF;
+        else {
+          const u32 key = pv[k] == 0.0f ? 0u : __float_as_uint(pv[k]);
+          u32 h = bh_hash(key) & capMask;
+          while (gKeys[h] != key) h = (h + 1) & capMask;  // every p was inserted
+          qv = qOfSlot[h];
+        }
+        q[i] = qv;
+      }
+      const u64 sg = __ballot(i < n && qv > thr), sk = __ballot(i < n && qv == GX_SKIPF);
+      if (lane_id() == 0 && w0 + k < nw) {
+        sigMask[w0 + k] = sg;
+        skipMask[w0 + k] = sk;
+      }
+    }
   }
 }
 
