@@ -135,11 +135,10 @@ struct gx_ctx {
   struct Seg { const gx_event* p; size_t n; };
   std::vector<Seg> segs;
   struct Stream {  // one record stream of the bucket sort
-    DevBuf a, b, sbHist, sbOff, sbCursor, sbChunkOff;
-    u32 chunks2 = 0;
+    DevBuf a, b, sbHist, sbOff, sbCursor;
   };
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
-  DevBuf tileCnt[3], tileOff[3], tileCursor[3];
+  DevBuf tileCnt[3], tileOff[3];
   DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
@@ -292,11 +291,11 @@ int sort_stream(gx_ctx* ctx, gx_ctx::Stream& st, u32 nRec, int q) {
   hipStream_t s = ctx->stream;
   const u32 nSB = ctx->nSB, nTiles = ctx->nTiles;
   constexpr u32 CHUNK = SC_NT * ScCfg<R>::ITEMS;
-  hipLaunchKernelGGL(k_scan_sb, dim3(1), dim3(1024), 0, s, st.sbHist.as<u32>(), nSB, CHUNK, st.sbOff.as<u32>(),
-                     st.sbCursor.as<u32>(), st.sbChunkOff.as<u32>());
+  hipLaunchKernelGGL(k_scan_sb, dim3(1), dim3(1024), 0, s, st.sbHist.as<u32>(), nSB, st.sbOff.as<u32>(),
+                     st.sbCursor.as<u32>());
   const u32 chunks1 = (nRec + CHUNK - 1) / CHUNK;
-  hipLaunchKernelGGL((k_scatter<1, R>), dim3(chunks1), dim3(SC_NT), 0, s, st.a.as<R>(), st.b.as<R>(),
-                     st.sbOff.as<u32>() + nSB /* total */, (const u32*)nullptr, 0u, ctx->sbShift, nSB, st.sbCursor.as<u32>());
+  hipLaunchKernelGGL((k_scatter1<R>), dim3(chunks1), dim3(SC_NT), 0, s, st.a.as<R>(), st.b.as<R>(),
+                     st.sbOff.as<u32>() + nSB /* total */, ctx->sbShift, nSB, st.sbCursor.as<u32>());
   // level 2: one workgroup per super-bucket (the last level-1 bin holds the records without a tile)
   const size_t lds2 = b2_lds_bytes(1u << ctx->sbShift);
   HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -306,7 +305,6 @@ int sort_stream(gx_ctx* ctx, gx_ctx::Stream& st, u32 nRec, int q) {
   return dbg_sync(ctx, "sort_stream");
 }
 
-// events -> tile-bucketed endpoint records -> run-length pileup + exact fragLen accumulators
 // loose slots -> tight (end, V) arrays of a pileup (only needed ahead of a control merge)
 int pack_pileup(gx_ctx* ctx, Pileup& P) {
   if (P.packed) return GX_OK;
@@ -321,6 +319,7 @@ int pack_pileup(gx_ctx* ctx, Pileup& P) {
   return GX_OK;
 }
 
+// events -> tile-bucketed endpoint records -> run-length pileup (loose slots + offsets) and fragLen
 int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // host-pushed events are staged in evBuf; device-resident segments are used in place
   std::vector<gx_ctx::Seg> segs;
@@ -370,9 +369,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     gx_ctx::Stream& st = ctx->str[q];
     HIPCHECK(st.sbOff.ensure((MAX_BINS + 2) * 4));
     HIPCHECK(st.sbCursor.ensure((MAX_BINS + 2) * 4));
-    HIPCHECK(st.sbChunkOff.ensure((MAX_BINS + 2) * 4));
     HIPCHECK(ctx->tileOff[q].ensure((size_t)(nTiles + 2) * 4));
-    HIPCHECK(ctx->tileCursor[q].ensure((size_t)(nTiles + 1) * 4));
   }
   HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 64) * 8));
@@ -436,7 +433,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   for (int q = 0; q < 3; q++) {
     tt.cnt[q] = ctx->tileCnt[q].as<u32>();
     tt.off[q] = ctx->tileOff[q].as<u32>();
-    tt.cursor[q] = ctx->tileCursor[q].as<u32>();
   }
   tt.wsumF = ctx->tileWsum.as<int>();
   tt.prefW = ctx->tileCarry.as<int>();
@@ -1066,7 +1062,6 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   ctx->mail->n = n;
   HIPCHECK(hipMemcpyAsync(misc + M_GENOME, &ctx->mail->genome, 8, hipMemcpyHostToDevice, s));
   HIPCHECK(hipMemcpyAsync(misc + M_NIV, &ctx->mail->n, 4, hipMemcpyHostToDevice, s));
-  const u32 gridIv = std::max(1u, std::min((n + 255) / 256, 4096u));
 
   if (ctx->par.qval_opt) {
     phase_begin(ctx, "bh");

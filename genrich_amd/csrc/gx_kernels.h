@@ -327,43 +327,34 @@ __global__ __launch_bounds__(256) void k_hist1(const R* __restrict__ in, u32 n, 
 }
 
 // ---- 2. tiny scans ------------------------------------------------------------------------
-// super-bucket histogram -> offsets, cursors and the level-2 chunk table
-__global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist, u32 nSB, u32 chunk,
-                                                  u32* __restrict__ sbOff, u32* __restrict__ sbCursor,
-                                                  u32* __restrict__ sbChunkOff) {
+// super-bucket histogram -> offsets and scatter cursors
+__global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist, u32 nSB, u32* __restrict__ sbOff,
+                                                  u32* __restrict__ sbCursor) {
   __shared__ u32 scratch[20];
   // nSB <= MAX_BINS: MAX_BINS / 1024 consecutive items per thread
   constexpr int PER = MAX_BINS / 1024;
-  u32 v[PER], c[PER], sum = 0, csum = 0;
+  u32 v[PER], sum = 0;
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const u32 i = threadIdx.x * PER + k;
     v[k] = i < nSB ? sbHist[i] : 0;
-    c[k] = i + 1 < nSB ? (v[k] + chunk - 1) / chunk : 0;  // chunks per super-bucket (the last, null, bucket gets none)
     sum += v[k];
-    csum += c[k];
   }
-  u32 tot, ctot;
+  u32 tot;
   u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
-  u32 cex = block_excl_scan<u32, 1024>(csum, scratch, &ctot);
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const u32 i = threadIdx.x * PER + k;
     if (i < nSB) {
       sbOff[i] = ex;
       sbCursor[i] = ex;
-      sbChunkOff[i] = cex;
     }
     ex += v[k];
-    cex += c[k];
   }
-  if (threadIdx.x == 0) {
-    sbOff[nSB] = tot;
-    sbChunkOff[nSB] = ctot;
-  }
+  if (threadIdx.x == 0) sbOff[nSB] = tot;
 }
 
-// per-tile record counts of the three streams -> offsets + cursors; per-tile weight -> genome-wide
+// per-tile record counts of the three streams -> offsets; per-tile weight -> genome-wide
 // prefix tilePrefW (the carry-in of a tile is tilePrefW[t] - tilePrefW[first tile of its
 // chromosome]); weight of a tile = 120 (#S - #E) + sum of its F weights.
 // Persistent multi-workgroup chained scan (one look-back per stream), 2048 tiles per item.
@@ -375,7 +366,6 @@ struct TileTabs {
   const u32* cnt[3];   // S, E, F record counts per tile (F may be nullptr)
   const int* wsumF;    // sum of F weights per tile (nullptr without F)
   u32* off[3];         // [nTiles+1]
-  u32* cursor[3];
   int* prefW;          // [nTiles]
 };
 
@@ -441,7 +431,6 @@ __global__ __launch_bounds__(STL_NT) void k_scan_tiles(TileTabs T, u32 nTiles, u
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           T.off[q][t] = ex[q];
-          T.cursor[q][t] = ex[q];
         }
         T.prefW[t] = wex;
       }
@@ -463,18 +452,17 @@ constexpr int SC_NT = 1024;  // 16 waves per workgroup: the kernel is latency-, 
 template <typename R> struct ScCfg { static constexpr int ITEMS = 4; };    // 4096 x 8 B = 32 KiB staged
 template <> struct ScCfg<u32> { static constexpr int ITEMS = 8; };        // 8192 x 4 B = 32 KiB staged
 
-template <int LEVEL, typename R>
-__device__ __forceinline__ u32 bin_of(R r, int sbShift, u32 nBins, u32 segTileBase) {
-  u32 t = RecT<R>::tile(r);
-  if (LEVEL == 1) return t == NULL_TILE ? nBins - 1 : t >> sbShift;
-  return t - segTileBase;
+template <typename R>
+__device__ __forceinline__ u32 sb_of(R r, int sbShift, u32 nBins) {  // records without a tile go to the last bin
+  const u32 t = RecT<R>::tile(r);
+  return t == NULL_TILE ? nBins - 1 : t >> sbShift;
 }
 
-template <int LEVEL, typename R>
-__global__ __launch_bounds__(SC_NT) void k_scatter(const R* __restrict__ in, R* __restrict__ out,
-                                                   const u32* __restrict__ segOff,
-                                                   const u32* __restrict__ chunkOff, u32 nSeg,
-                                                   int sbShift, u32 nBinsL1, u32* __restrict__ cursor) {
+// level 1: records -> super-buckets
+template <typename R>
+__global__ __launch_bounds__(SC_NT) void k_scatter1(const R* __restrict__ in, R* __restrict__ out,
+                                                    const u32* __restrict__ total, int sbShift, u32 nBins,
+                                                    u32* __restrict__ cursor) {
   constexpr int ITEMS = ScCfg<R>::ITEMS;
   constexpr int CHUNK = SC_NT * ITEMS;
   __shared__ u32 hist[MAX_BINS];
@@ -482,27 +470,10 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const R* __restrict__ in, R* 
   __shared__ u32 base[MAX_BINS];
   __shared__ R stage[CHUNK];
   __shared__ u32 scratch[20];
-  u32 seg = 0, chunkInSeg = blockIdx.x, begin, end, nBins, segTileBase = 0;
-  if (LEVEL == 1) {
-    begin = blockIdx.x * CHUNK;
-    end = segOff[0];  // total
-    if (begin >= end) return;
-    end = min(end, begin + CHUNK);
-    nBins = nBinsL1;
-  } else {
-    if (blockIdx.x >= chunkOff[nSeg]) return;
-    u32 lo = 0, hi = nSeg;  // last seg with chunkOff[seg] <= blockIdx.x
-    while (hi - lo > 1) {
-      u32 mid = (lo + hi) >> 1;
-      if (chunkOff[mid] <= blockIdx.x) lo = mid; else hi = mid;
-    }
-    seg = lo;
-    chunkInSeg = blockIdx.x - chunkOff[seg];
-    begin = segOff[seg] + chunkInSeg * CHUNK;
-    end = min(segOff[seg + 1], begin + CHUNK);
-    nBins = 1u << sbShift;
-    segTileBase = seg << sbShift;
-  }
+  const u32 begin = blockIdx.x * CHUNK;
+  u32 end = *total;
+  if (begin >= end) return;
+  end = min(end, begin + CHUNK);
   for (int i = threadIdx.x; i < (int)nBins; i += SC_NT) hist[i] = 0;
   __syncthreads();
   R r[ITEMS];
@@ -512,7 +483,7 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const R* __restrict__ in, R* 
     u32 idx = begin + k * SC_NT + threadIdx.x;
     if (idx < end) {
       r[k] = in[idx];
-      rk[k] = atomicAdd(&hist[bin_of<LEVEL, R>(r[k], sbShift, nBins, segTileBase)], 1u);
+      rk[k] = atomicAdd(&hist[sb_of<R>(r[k], sbShift, nBins)], 1u);
     }
   }
   __syncthreads();
@@ -525,7 +496,7 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const R* __restrict__ in, R* 
     u32 ex = block_excl_scan<u32, SC_NT>(c, scratch, &tot);
     if (b < nBins) {
       start[b] = carry + ex;
-      if (c) base[b] = atomicAdd(&cursor[LEVEL == 1 ? b : segTileBase + b], c);
+      if (c) base[b] = atomicAdd(&cursor[b], c);
     }
     carry += tot;
   }
@@ -533,49 +504,15 @@ __global__ __launch_bounds__(SC_NT) void k_scatter(const R* __restrict__ in, R* 
 #pragma unroll
   for (int k = 0; k < ITEMS; k++) {
     u32 idx = begin + k * SC_NT + threadIdx.x;
-    if (idx < end) stage[start[bin_of<LEVEL, R>(r[k], sbShift, nBins, segTileBase)] + rk[k]] = r[k];
+    if (idx < end) stage[start[sb_of<R>(r[k], sbShift, nBins)] + rk[k]] = r[k];
   }
   __syncthreads();
   u32 cnt = end - begin;
   for (u32 i = threadIdx.x; i < cnt; i += SC_NT) {
     R v = stage[i];
-    u32 b = bin_of<LEVEL, R>(v, sbShift, nBins, segTileBase);
+    u32 b = sb_of<R>(v, sbShift, nBins);
     out[base[b] + (i - start[b])] = v;
   }
-}
-
-// level-2 histogram: records (and, for F, signed weight) per tile
-template <typename R>
-__global__ __launch_bounds__(SC_NT) void k_hist2(const R* __restrict__ in, const u32* __restrict__ segOff,
-                                                 const u32* __restrict__ chunkOff, u32 nSeg, int sbShift,
-                                                 u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
-  constexpr int CHUNK = SC_NT * ScCfg<R>::ITEMS;
-  __shared__ u32 hist[MAX_BINS];
-  __shared__ int wsum[MAX_BINS];
-  if (blockIdx.x >= chunkOff[nSeg]) return;
-  u32 lo = 0, hi = nSeg;
-  while (hi - lo > 1) {
-    u32 mid = (lo + hi) >> 1;
-    if (chunkOff[mid] <= blockIdx.x) lo = mid; else hi = mid;
-  }
-  u32 seg = lo;
-  u32 begin = segOff[seg] + (blockIdx.x - chunkOff[seg]) * CHUNK;
-  u32 end = min(segOff[seg + 1], begin + CHUNK);
-  u32 nBins = 1u << sbShift, segTileBase = seg << sbShift;
-  for (int i = threadIdx.x; i < (int)nBins; i += SC_NT) { hist[i] = 0; wsum[i] = 0; }
-  __syncthreads();
-  for (u32 idx = begin + threadIdx.x; idx < end; idx += SC_NT) {
-    R r = in[idx];
-    u32 b = RecT<R>::tile(r) - segTileBase;
-    atomicAdd(&hist[b], 1u);
-    if (sizeof(R) == 8) atomicAdd(&wsum[b], (int)(int8_t)((u64)r & 0xFF));
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < (int)nBins; i += SC_NT)
-    if (hist[i]) {
-      atomicAdd(&tileCnt[segTileBase + i], hist[i]);
-      if (sizeof(R) == 8) atomicAdd(&tileWsum[segTileBase + i], wsum[i]);
-    }
 }
 
 // level 2 in one kernel: a workgroup owns one whole super-bucket, so the per-tile histogram, its
