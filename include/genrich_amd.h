@@ -178,14 +178,16 @@ int gx_write_log_path(gx_ctx* ctx, int n_rep, const char* const* names, int n_ch
 typedef int (*gx_allreduce_i64_fn)(int64_t* buf, size_t n, void* user);
 /* Gather variable-length tables: every rank contributes n_local 16-byte records
  * {uint32 key, uint32 pad, uint64 bp}; the callback returns a malloc'd concatenation of
- * all ranks' records in *out / *n_out (freed by the library with free()).
- * With dev = 1 the buffers are device pointers and the callback must not free them. */
+ * all ranks' records in *out / *n_out (freed by the library with free()).  `local` is host
+ * memory owned by the library. */
 typedef int (*gx_allgather_tab_fn)(const void* local, size_t n_local, void** out,
                                    size_t* n_out, void* user);
 int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce,
                        gx_allgather_tab_fn allgather, void* user);
 /* owned[i] = 1: this rank computes chromosome i (default: all).  The full table still goes to
- * gx_set_chroms on every rank, so genome lengths and output order are global. */
+ * gx_set_chroms on every rank, so genome lengths and output order are global; device work and
+ * memory are laid out for the owned chromosomes only.  Call after gx_set_chroms and before the
+ * first gx_sample_begin (or right after gx_reset): GX_ERR_ORDER otherwise. */
 int gx_set_owned(gx_ctx* ctx, const uint8_t* owned);
 
 /* ---- introspection used by bench.py / tests ---- */
