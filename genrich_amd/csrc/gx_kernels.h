@@ -24,7 +24,10 @@ namespace gx {
 typedef unsigned long long u64;
 typedef uint32_t u32;
 
-constexpr int TB = 13;                 // tile bits
+#ifndef GX_TB
+#define GX_TB 12  // 4,096-base tiles measured best of 2^11 / 2^12 / 2^13 (compile-time knob: -DGX_TB=13)
+#endif
+constexpr int TB = GX_TB;              // tile bits
 constexpr int TILE = 1 << TB;          // bases per tile
 constexpr u32 NULL_TILE = 0xFFFFFFFFu; // dropped endpoint
 constexpr int MAX_BINS = 2048;         // bins of one bucket-sort level
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* 
 // k_scan_iv then turns the counts into tight offsets and k_pack packs the slots.  (A fused
 // decoupled look-back was measured first: with ~512 resident tiles the look-back distance made
 // it latency-bound at ~10 us per tile.)
-constexpr int TL_NT = 256;
+constexpr int TL_NT = TILE / 32;  // one thread per 32 bases (= one bitmap word)
 constexpr int TL_NW = TL_NT / 64;
 constexpr int TL_REG = 4;                         // touched bases per thread held in registers
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread

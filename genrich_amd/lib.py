@@ -69,7 +69,7 @@ _SIGS = {
 }
 
 
-def load_library(path: str = LIB_PATH):
+def load_library(path: str = os.environ.get("GENRICH_AMD_LIB", LIB_PATH)):
     """Load libgenrich_amd.so and declare every entry point of include/genrich_amd.h.
     Raises if the library or a symbol is missing -- there is no fallback path."""
     global _lib
