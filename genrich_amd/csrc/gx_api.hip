@@ -297,10 +297,11 @@ int sort_stream(gx_ctx* ctx, gx_ctx::Stream& st, u32 nRec, int q) {
   hipLaunchKernelGGL((k_scatter1<R>), dim3(chunks1), dim3(SC_NT), 0, s, st.a.as<R>(), st.b.as<R>(),
                      st.sbOff.as<u32>() + nSB /* total */, ctx->sbShift, nSB, st.sbCursor.as<u32>());
   // level 2: one workgroup per super-bucket (the last level-1 bin holds the records without a tile)
-  const size_t lds2 = b2_lds_bytes(1u << ctx->sbShift);
+  const size_t lds2 = b2_lds_bytes<R>(1u << ctx->sbShift);
   HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds2));
-  hipLaunchKernelGGL((k_bucket2<R>), dim3(std::max(1u, nSB - 1)), dim3(B2_NT), lds2, s, st.b.as<R>(), st.a.as<R>(),
+  hipLaunchKernelGGL((k_bucket2<R>), dim3(std::max(1u, nSB - 1)), dim3(B2_NT), lds2, s, st.b.as<R>(),
+                     st.a.as<typename B2Out<R>::type>(),
                      st.sbOff.as<u32>(), nSB - 1, ctx->sbShift, nTiles, ctx->tileCnt[q].as<u32>(), ctx->tileWsum.as<int>());
   return dbg_sync(ctx, "sort_stream");
 }
@@ -460,7 +461,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");  // k_tile alone: the dominant kernel (bench.py's roofline)
-  TileIn tin{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
+  TileIn tin{SS.a.as<uint16_t>(), SE.a.as<uint16_t>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
   if (ctx->hasBed)
     hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin, nTiles,
                        bin, to, ctx->dStatus.as<u32>());
@@ -578,10 +579,10 @@ int layout_tiles(gx_ctx* ctx) {
   }
   int lg = 0;
   while ((1u << lg) < t) lg++;
-  // tiles per super-bucket: the level-1 scatter wants few bins (long runs per bin and chunk), the level-2
-  // kernel many super-buckets (one workgroup each); GX_SBSHIFT overrides for experiments
-  // (hg38, 377 K tiles: 2^9 tiles per super-bucket measured best of 2^8 / 2^9 / 2^10)
-  ctx->sbShift = std::min(11, lg / 2);
+  // tiles per super-bucket: the level-1 scatter wants few bins (long runs per bin and chunk); level 2 wants
+  // a super-bucket's keys to fit its one-pass LDS sort (45 K keys: ~2^9 tiles at hg38 / 50 M fragments) and
+  // enough super-buckets for every CU; GX_SBSHIFT overrides for experiments
+  ctx->sbShift = std::min(11, std::max(0, (lg - 1) / 2));
   if (const char* e = getenv("GX_SBSHIFT")) ctx->sbShift = std::max(0, std::min(11, atoi(e)));
   while (((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1 > (u32)MAX_BINS) ctx->sbShift++;
   if ((1u << ctx->sbShift) > (u32)MAX_BINS) {

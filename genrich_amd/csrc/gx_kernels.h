@@ -524,46 +524,58 @@ __global__ __launch_bounds__(SC_NT) void k_scatter1(const R* __restrict__ in, R*
 // per tile, and for F the signed weight); pass 2 streams it again (it was just read: L2 /
 // Infinity Cache) in chunks that are ranked and sorted in LDS and written as tile-contiguous runs.
 constexpr int B2_NT = 1024;
-constexpr int B2_STAGE_BYTES = 128 * 1024;  // a whole super-bucket is sorted in LDS when it fits (it usually does)
+// What leaves level 2: for the 4-byte key streams only the offset inside the tile (2 bytes; the
+// tile is implied by the record's position and the per-tile offsets), for F the record as it is.
+template <typename R> struct B2Out { typedef R type; };
+template <> struct B2Out<u32> { typedef uint16_t type; };
+static_assert(TB <= 16, "tile offsets are stored in 16 bits");
+// one-pass path: records of a super-bucket held in registers (FITEMS per thread) and sorted in LDS
+template <typename R> struct B2Cfg { static constexpr int FITEMS = 16; };     // 16 K x 8 B staged
+template <> struct B2Cfg<u32> { static constexpr int FITEMS = 40; };          // 40 K x 2 B staged
 constexpr int B2_LDS_MAX = 160 * 1024;
 __host__ __device__ constexpr u32 b2_table_bytes(u32 nBins) { return (4 * nBins + 32) * 4; }
-// stage bytes: 128 KiB unless the per-tile tables of a very large genome need the room
-__host__ __device__ constexpr u32 b2_stage_bytes(u32 nBins) {
-  return b2_table_bytes(nBins) + B2_STAGE_BYTES <= B2_LDS_MAX ? (u32)B2_STAGE_BYTES
-                                                               : ((B2_LDS_MAX - b2_table_bytes(nBins)) & ~16383u);
+template <typename R>
+__host__ __device__ constexpr u32 b2_stage_bytes() {
+  // the larger of: one-pass staging (output elements), one chunk of the two-pass path (records)
+  return (u32)B2_NT * (u32)(B2Cfg<R>::FITEMS * sizeof(typename B2Out<R>::type) > ScCfg<R>::ITEMS * sizeof(R)
+                                ? B2Cfg<R>::FITEMS * sizeof(typename B2Out<R>::type)
+                                : ScCfg<R>::ITEMS * sizeof(R));
 }
-__host__ __device__ constexpr size_t b2_lds_bytes(u32 nBins) { return (size_t)b2_stage_bytes(nBins) + b2_table_bytes(nBins); }
+template <typename R>
+__host__ __device__ constexpr size_t b2_lds_bytes(u32 nBins) { return (size_t)b2_stage_bytes<R>() + b2_table_bytes(nBins); }
 
 template <typename R>
-__global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* __restrict__ out,
+__global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, typename B2Out<R>::type* __restrict__ out,
                                                    const u32* __restrict__ segOff, u32 nSeg, int sbShift, u32 nTiles,
                                                    u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
+  typedef typename B2Out<R>::type O;
   constexpr int ITEMS = ScCfg<R>::ITEMS;
   constexpr int CHUNK = B2_NT * ITEMS;
-  constexpr int FITEMS = B2_STAGE_BYTES / (int)sizeof(R) / B2_NT;  // records per thread on the one-pass path
-  static_assert((u32)FITEMS * B2_NT <= 65536, "ranks are packed in 16 bits");
+  constexpr int FITEMS = B2Cfg<R>::FITEMS;  // records per thread on the one-pass path
+  constexpr u32 FCAP = (u32)FITEMS * B2_NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
   const u32 nBins = 1u << sbShift;
-  const u32 stageBytes = b2_stage_bytes(nBins);
-  const u32 FCAP = stageBytes / (u32)sizeof(R);
-  R* stage = reinterpret_cast<R*>(b2_lds);
+  constexpr u32 stageBytes = b2_stage_bytes<R>();
+  R* stage = reinterpret_cast<R*>(b2_lds);    // two-pass path: one chunk of records
+  O* stageO = reinterpret_cast<O*>(b2_lds);   // one-pass path: the whole super-bucket, as it will be written
   u32* hist = reinterpret_cast<u32*>(b2_lds + stageBytes);  // records per tile (of the chunk, in the chunked pass 2)
   u32* start = hist + nBins;                                    // run starts (pass 1 of the chunked path: weight sums)
   u32* cursor = start + nBins;                                  // chunked path: next output position of every tile
   u32* base = cursor + nBins;                                   // chunked path: output position of the chunk's run
   u32* scratch = base + nBins;
+  auto outOf = [](R r) -> O {
+    if constexpr (sizeof(R) == 4) return (O)((u32)r & (TILE - 1)); else return r;
+  };
   for (u32 seg = blockIdx.x; seg < nSeg; seg += gridDim.x) {
     const u32 begin = segOff[seg], end = segOff[seg + 1], segTileBase = seg << sbShift;
     if (end - begin <= FCAP) {
-      // one pass: every record is read once into registers, ranked, sorted in LDS and written back
-      // as one contiguous, fully coalesced stream (each output line is written exactly once)
+      // one pass: every record is read once into registers, counted, then placed in LDS by a second
+      // round of LDS atomics on per-tile cursors, and written back as one contiguous, fully coalesced
+      // stream (each output line is written exactly once)
       __syncthreads();
-      for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; cursor[i] = 0; }
+      for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; base[i] = 0; }
       __syncthreads();
       R r[FITEMS];
-      u32 rk[FITEMS / 2];  // ranks are below FCAP <= 2^16: two per register
-#pragma unroll
-      for (int k = 0; k < FITEMS / 2; k++) rk[k] = 0;
 #pragma unroll
       for (int k = 0; k < FITEMS; k++) {
         const u32 idx = begin + k * B2_NT + threadIdx.x;
@@ -574,8 +586,8 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* 
         const u32 idx = begin + k * B2_NT + threadIdx.x;
         if (idx < end) {
           const u32 b = RecT<R>::tile(r[k]) - segTileBase;
-          rk[k >> 1] |= atomicAdd(&hist[b], 1u) << (16 * (k & 1));
-          if (sizeof(R) == 8) atomicAdd(&cursor[b], (u32)(int)(int8_t)((u64)r[k] & 0xFF));
+          atomicAdd(&hist[b], 1u);
+          if (sizeof(R) == 8) atomicAdd(&base[b], (u32)(int)(int8_t)((u64)r[k] & 0xFF));
         }
       }
       __syncthreads();
@@ -586,10 +598,10 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* 
         u32 tot;
         const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
         if (b < nBins) {
-          start[b] = carry + ex;
+          cursor[b] = carry + ex;
           if (segTileBase + b < nTiles) {  // (the last super-bucket may be short of tiles)
             tileCnt[segTileBase + b] = c;
-            if (sizeof(R) == 8) tileWsum[segTileBase + b] += (int)cursor[b];  // the slot is this workgroup's alone
+            if (sizeof(R) == 8) tileWsum[segTileBase + b] += (int)base[b];  // the slot is this workgroup's alone
           }
         }
         carry += tot;
@@ -598,11 +610,11 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* 
 #pragma unroll
       for (int k = 0; k < FITEMS; k++) {
         const u32 idx = begin + k * B2_NT + threadIdx.x;
-        if (idx < end) stage[start[RecT<R>::tile(r[k]) - segTileBase] + ((rk[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)] = r[k];
+        if (idx < end) stageO[atomicAdd(&cursor[RecT<R>::tile(r[k]) - segTileBase], 1u)] = outOf(r[k]);
       }
       __syncthreads();
       const u32 cnt = end - begin;
-      for (u32 i = threadIdx.x; i < cnt; i += B2_NT) out[begin + i] = stage[i];
+      for (u32 i = threadIdx.x; i < cnt; i += B2_NT) out[begin + i] = stageO[i];
     } else {
     // chunked two-pass path for a super-bucket that does not fit (a pile-up of records in one place)
     __syncthreads();
@@ -685,7 +697,7 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, R* 
       for (u32 i = threadIdx.x; i < cnt; i += B2_NT) {
         const R v = stage[i];
         const u32 b = RecT<R>::tile(v) - segTileBase;
-        out[base[b] + (i - start[b])] = v;
+        out[base[b] + (i - start[b])] = outOf(v);
       }
     }
     }  // chunked path
@@ -759,7 +771,8 @@ struct __attribute__((aligned(16))) TileMeta {
 };
 
 struct TileIn {
-  const u32* S;  const u32* E;  const u64* F;   // the three record streams, bucketed by tile
+  const uint16_t* S;  const uint16_t* E;  // start / end offsets inside the tile, bucketed by tile
+  const u64* F;                           // fractional-weight records
   const TileMeta* meta;
 };
 
@@ -840,22 +853,22 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     // accumulate this tile's endpoints: +1 per start, -1 per end (unit weight = 120), then the
     // fractional records with their own signed weight
     if (threadIdx.x < m.nS) {
-      u32 off = ks0 & (TILE - 1);
+      u32 off = ks0;
       atomicAdd(&delta[off], GX_UNIT);
       atomicOr(&occ[off >> 5], 1u << (off & 31));
     }
     if (threadIdx.x < m.nE) {
-      u32 off = ke0 & (TILE - 1);
+      u32 off = ke0;
       atomicAdd(&delta[off], -GX_UNIT);
       atomicOr(&occ[off >> 5], 1u << (off & 31));
     }
     for (u32 i = sb + TL_NT + threadIdx.x; i < se; i += TL_NT) {
-      u32 off = in.S[i] & (TILE - 1);
+      u32 off = in.S[i];
       atomicAdd(&delta[off], GX_UNIT);
       atomicOr(&occ[off >> 5], 1u << (off & 31));
     }
     for (u32 i = eb0 + TL_NT + threadIdx.x; i < ee; i += TL_NT) {
-      u32 off = in.E[i] & (TILE - 1);
+      u32 off = in.E[i];
       atomicAdd(&delta[off], -GX_UNIT);
       atomicOr(&occ[off >> 5], 1u << (off & 31));
     }
