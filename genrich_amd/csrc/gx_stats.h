@@ -54,56 +54,71 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
   u32 neg = 0;
   const int wv = threadIdx.x >> 6, lane = lane_id();
   const u32 stride = gridDim.x * 4;
-  // two-deep software pipeline per wavefront: headers (slot, offset, count) of tile k+2 and the
-  // first 64 * PP_UNROLL (end, V) pairs of tile k+1 are in flight while tile k is scored
-  u32 t = blockIdx.x * 4 + wv;
-  u32 src1 = 0, dst1 = 0, n1 = 0, src2 = 0, dst2 = 0, n2 = 0;
+  // A wavefront works on a pair of consecutive tiles at a time (their intervals are contiguous in
+  // the tight arrays; a 4,096-base tile alone holds ~110 intervals, too few for 64 x PP_UNROLL
+  // lanes).  Two-deep software pipeline: headers of pair k+2 and the first 64 * PP_UNROLL (end, V)
+  // values of pair k+1 are in flight while pair k is scored.
+  struct Hdr { u32 s0, s1, n0, n, dst; };
+  const u32 nUnits = (nTiles + 1) / 2;
+  auto loadHdr = [&](u32 u) {
+    Hdr h;
+    const u32 t0 = 2 * u;
+    h.s0 = in.meta[t0].slot;
+    h.dst = in.tileIvOff[t0];
+    const u32 mid = in.tileIvOff[t0 + 1];
+    h.n0 = mid - h.dst;
+    h.s1 = 0;
+    h.n = h.n0;
+    if (t0 + 1 < nTiles) {
+      h.s1 = in.meta[t0 + 1].slot;
+      h.n = in.tileIvOff[t0 + 2] - h.dst;
+    }
+    return h;
+  };
+  auto srcOf = [](const Hdr& h, u32 i) { return i < h.n0 ? h.s0 + i : h.s1 + (i - h.n0); };
+  u32 u = blockIdx.x * 4 + wv;
+  Hdr h1{0, 0, 0, 0, 0}, h2{0, 0, 0, 0, 0};
   u32 e1[PP_UNROLL];
   int v1[PP_UNROLL];
 #pragma unroll
   for (int k = 0; k < PP_UNROLL; k++) { e1[k] = 0; v1[k] = 0; }
-  if (t < nTiles) {
-    src1 = in.meta[t].slot;
-    dst1 = in.tileIvOff[t];
-    n1 = in.tileIvOff[t + 1] - dst1;
+  if (u < nUnits) {
+    h1 = loadHdr(u);
 #pragma unroll
     for (int k = 0; k < PP_UNROLL; k++)
-      if (k * 64 + lane < n1) {
-        e1[k] = in.looseEnd[src1 + k * 64 + lane];
-        v1[k] = in.looseV[src1 + k * 64 + lane];
+      if (k * 64 + lane < h1.n) {
+        const u32 si = srcOf(h1, k * 64 + lane);
+        e1[k] = in.looseEnd[si];
+        v1[k] = in.looseV[si];
       }
   }
-  if (t + stride < nTiles) {
-    src2 = in.meta[t + stride].slot;
-    dst2 = in.tileIvOff[t + stride];
-    n2 = in.tileIvOff[t + stride + 1] - dst2;
-  }
-  for (; t < nTiles; t += stride) {
-    const u32 src = src1, dst = dst1, n = n1;
+  if (u + stride < nUnits) h2 = loadHdr(u + stride);
+  for (; u < nUnits; u += stride) {
+    const Hdr h = h1;
+    const u32 dst = h.dst, n = h.n;
     u32 e[PP_UNROLL];
     int v[PP_UNROLL];
 #pragma unroll
     for (int k = 0; k < PP_UNROLL; k++) { e[k] = e1[k]; v[k] = v1[k]; }
-    src1 = src2; dst1 = dst2; n1 = t + stride < nTiles ? n2 : 0u;
+    h1 = h2;
+    if (!(u + stride < nUnits)) h1.n = 0;
 #pragma unroll
     for (int k = 0; k < PP_UNROLL; k++)
-      if (k * 64 + lane < n1) {
-        e1[k] = in.looseEnd[src1 + k * 64 + lane];
-        v1[k] = in.looseV[src1 + k * 64 + lane];
+      if (k * 64 + lane < h1.n) {
+        const u32 si = srcOf(h1, k * 64 + lane);
+        e1[k] = in.looseEnd[si];
+        v1[k] = in.looseV[si];
       }
-    if (t + 2 * stride < nTiles) {
-      src2 = in.meta[t + 2 * stride].slot;
-      dst2 = in.tileIvOff[t + 2 * stride];
-      n2 = in.tileIvOff[t + 2 * stride + 1] - dst2;
-    }
+    if (u + 2 * stride < nUnits) h2 = loadHdr(u + 2 * stride);
     for (u32 b = 0; b < n; b += 64 * PP_UNROLL) {
       if (b) {  // beyond the pipelined first batch (dense tiles)
 #pragma unroll
         for (int k = 0; k < PP_UNROLL; k++) {
           const u32 i = b + k * 64 + lane;
           if (i < n) {
-            e[k] = in.looseEnd[src + i];
-            v[k] = in.looseV[src + i];
+            const u32 si = srcOf(h, i);
+            e[k] = in.looseEnd[si];
+            v[k] = in.looseV[si];
           }
         }
       }
@@ -673,6 +688,7 @@ __global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u32* 
 }
 
 constexpr u32 PK_SHORT = 1024;
+constexpr int PK_LOADS = 8;
 
 // candidate -> {first interval, last interval, start coordinate}: one thread per candidate, so the
 // chain candRun -> runStart/runEnd -> end[] is walked by all candidates at once instead of once
@@ -738,9 +754,9 @@ struct PeakAcc {
 };
 
 // candidates of up to PK_SHORT intervals (all but pathological ones): one thread each, a plain
-// in-order loop like updatePeak itself; every candidate of the genome is in flight at once.  The
-// body of the loop reads four intervals per 16-byte load: a 64-lane gather costs the texture
-// unit one cycle per lane whatever the width.
+// in-order loop like updatePeak itself; every candidate of the genome is in flight at once.  Loads
+// are 16 bytes wide (a 64-lane gather costs the texture unit one cycle per lane whatever the width)
+// and PK_LOADS of them per array are in flight: the kernel is a chain of memory round trips.
 __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hdr, const u32* __restrict__ end,
                                                     const float* __restrict__ p, const float* __restrict__ q,
                                                     const u32* __restrict__ chromOff, u32 nChrom,
@@ -755,38 +771,31 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
     PeakAcc a;
     a.s = h.z;
     a.origin = h.z;
-    u32 i = i0;
-    for (; i <= i1 && (i & 3u); i++) a.step(end[i], p[i], useQ ? q[i] : GX_SKIPF, useQ, thr);
-    // twelve intervals per round trip (three independent 16-byte loads per array), then four
-    for (; i + 11 <= i1; i += 12) {
-      uint4 e4[3];
-      float4 p4[3], q4[3];
+    // PK_LOADS aligned 16-byte loads per array in flight (32 intervals per round trip); elements
+    // outside [i0, i1] in the first / last load are skipped (the arrays are padded by 16 bytes)
+    for (u32 b = i0 & ~3u; b <= i1; b += 4 * PK_LOADS) {
+      uint4 e4[PK_LOADS];
+      float4 p4[PK_LOADS], q4[PK_LOADS];
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        e4[k] = *reinterpret_cast<const uint4*>(end + i + 4 * k);
-        p4[k] = *reinterpret_cast<const float4*>(p + i + 4 * k);
+      for (int k = 0; k < PK_LOADS; k++) {
+        e4[k] = make_uint4(0, 0, 0, 0);
+        p4[k] = make_float4(0, 0, 0, 0);
         q4[k] = make_float4(GX_SKIPF, GX_SKIPF, GX_SKIPF, GX_SKIPF);
-        if (useQ) q4[k] = *reinterpret_cast<const float4*>(q + i + 4 * k);
+        if (b + 4 * k <= i1) {
+          e4[k] = *reinterpret_cast<const uint4*>(end + b + 4 * k);
+          p4[k] = *reinterpret_cast<const float4*>(p + b + 4 * k);
+          if (useQ) q4[k] = *reinterpret_cast<const float4*>(q + b + 4 * k);
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        a.step(e4[k].x, p4[k].x, q4[k].x, useQ, thr);
-        a.step(e4[k].y, p4[k].y, q4[k].y, useQ, thr);
-        a.step(e4[k].z, p4[k].z, q4[k].z, useQ, thr);
-        a.step(e4[k].w, p4[k].w, q4[k].w, useQ, thr);
+      for (int k = 0; k < PK_LOADS; k++) {
+        const u32 j = b + 4 * k;
+        if (j >= i0 && j <= i1) a.step(e4[k].x, p4[k].x, q4[k].x, useQ, thr);
+        if (j + 1 >= i0 && j + 1 <= i1) a.step(e4[k].y, p4[k].y, q4[k].y, useQ, thr);
+        if (j + 2 >= i0 && j + 2 <= i1) a.step(e4[k].z, p4[k].z, q4[k].z, useQ, thr);
+        if (j + 3 >= i0 && j + 3 <= i1) a.step(e4[k].w, p4[k].w, q4[k].w, useQ, thr);
       }
     }
-    for (; i + 3 <= i1; i += 4) {
-      const uint4 e4 = *reinterpret_cast<const uint4*>(end + i);
-      const float4 p4 = *reinterpret_cast<const float4*>(p + i);
-      float4 q4 = make_float4(GX_SKIPF, GX_SKIPF, GX_SKIPF, GX_SKIPF);
-      if (useQ) q4 = *reinterpret_cast<const float4*>(q + i);
-      a.step(e4.x, p4.x, q4.x, useQ, thr);
-      a.step(e4.y, p4.y, q4.y, useQ, thr);
-      a.step(e4.z, p4.z, q4.z, useQ, thr);
-      a.step(e4.w, p4.w, q4.w, useQ, thr);
-    }
-    for (; i <= i1; i++) a.step(end[i], p[i], useQ ? q[i] : GX_SKIPF, useQ, thr);
     peak_finish(c, h, a.auc, a.summitPos, a.sp, a.sq, minAUC, minLen, chromOff, nChrom, cand, valid);
   }
 }
