@@ -223,12 +223,27 @@ __device__ __forceinline__ u64 make_rec64(u32 tile, u32 off, int w) {
 
 constexpr int FRAG_SLOTS = 64;  // partial sums of the closed form of fragLen (see k_frag)
 
+// Level 1 of the bucket sort works on chunks of the key arrays (one workgroup of k_scatter1 each),
+// and reserves its output runs per (XCD, super-bucket): workgroups are dealt to the 8 XCDs
+// round-robin, each XCD has its own L2, and a 128-byte line completed by short runs from several
+// XCDs costs ~1.5x the time of one completed within a single L2 (tools/bw_probe3.hip: 232 vs
+// 154 us for this shape).  So the level-1 histograms are kept per chunk-index-mod-8, which is the
+// XCD that will scatter the chunk (if the dispatch order differs, only speed is affected).
+constexpr int NXCD = 8;
+// logical index of a workgroup such that consecutive logical indices sit on one XCD: the grid's
+// first NXCD * (G / NXCD) workgroups are regrouped, a remainder keeps its index
+__device__ __forceinline__ u32 xcd_local_block(u32 b, u32 G) {
+  const u32 per = G / NXCD, full = per * NXCD;
+  return b < full ? (b % NXCD) * per + b / NXCD : b;
+}
+constexpr int L1_CHUNK32 = 8192, L1_CHUNK64 = 4096;  // records per level-1 chunk (4- / 8-byte records)
+
 struct ConvertOut {
   u32* S;       // [n] start keys
   u32* E;       // [n] end keys
   u64* F;       // fractional / fallback records
   u32* nF;      // number of F records (appended in pairs)
-  u32* histS;   // level-1 histograms [nSB]
+  u32* histS;   // level-1 histograms [NXCD][nSB]
   u32* histE;
   u64* fragSum; // [FRAG_SLOTS] sum of the clamped lengths of the fragments kept (see k_frag)
   u32* slowFrag;
@@ -245,7 +260,13 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
   }
   u32 bad = 0, frac = 0;
   u64 covered = 0;
-  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  // a workgroup takes whole level-1 chunks of the key arrays (chunk ids congruent to blockIdx.x
+  // modulo the grid, which is a multiple of NXCD: all its chunks belong to one XCD class)
+  const u32 g0 = evBase, g1 = evBase + n;
+  const u32 cFirst = g0 / L1_CHUNK32, cLast = (g1 - 1) / L1_CHUNK32;
+  for (u32 c = cFirst + (blockIdx.x + gridDim.x - cFirst % gridDim.x) % gridDim.x; c <= cLast; c += gridDim.x)
+  for (u32 g = max(c * L1_CHUNK32, g0) + threadIdx.x, gEnd = min((c + 1) * (u32)L1_CHUNK32, g1); g < gEnd; g += 256) {
+    const u32 i = g - evBase;
     uint4 e = reinterpret_cast<const uint4*>(ev)[i];  // chrom, start, end, count
     int w = 0;
     switch (e.w) {
@@ -302,9 +323,10 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
   }
   if (UNIT32) {
     __syncthreads();
+    const u32 x = blockIdx.x % NXCD;
     for (int i = threadIdx.x; i < (int)nSB; i += 256) {
-      if (hS[i]) atomicAdd(&out.histS[i], hS[i]);
-      if (hE[i]) atomicAdd(&out.histE[i], hE[i]);
+      if (hS[i]) atomicAdd(&out.histS[x * nSB + i], hS[i]);
+      if (hE[i]) atomicAdd(&out.histE[x * nSB + i], hE[i]);
     }
   }
   if (bad) atomicOr(st, bad);
@@ -313,24 +335,28 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
   if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 4 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
 }
 
-// level-1 histogram of an already materialised stream (the F records)
+// level-1 histogram of an already materialised stream (the F records), same chunk / XCD rule
 template <typename R>
 __global__ __launch_bounds__(256) void k_hist1(const R* __restrict__ in, u32 n, int sbShift, u32 nSB,
                                                u32* __restrict__ sbHist) {
+  constexpr u32 CH = sizeof(R) == 4 ? L1_CHUNK32 : L1_CHUNK64;
   __shared__ u32 hist[MAX_BINS];
   for (int i = threadIdx.x; i < (int)nSB; i += 256) hist[i] = 0;
   __syncthreads();
-  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    u32 t = RecT<R>::tile(in[i]);
-    atomicAdd(&hist[t == NULL_TILE ? nSB - 1 : t >> sbShift], 1u);
-  }
+  for (u32 c = blockIdx.x; c * CH < n; c += gridDim.x)
+    for (u32 i = c * CH + threadIdx.x, iEnd = min((c + 1) * CH, n); i < iEnd; i += 256) {
+      u32 t = RecT<R>::tile(in[i]);
+      atomicAdd(&hist[t == NULL_TILE ? nSB - 1 : t >> sbShift], 1u);
+    }
   __syncthreads();
+  const u32 x = blockIdx.x % NXCD;
   for (int i = threadIdx.x; i < (int)nSB; i += 256)
-    if (hist[i]) atomicAdd(&sbHist[i], hist[i]);
+    if (hist[i]) atomicAdd(&sbHist[x * nSB + i], hist[i]);
 }
 
 // ---- 2. tiny scans ------------------------------------------------------------------------
-// super-bucket histogram -> offsets and scatter cursors
+// super-bucket histograms [NXCD][nSB] -> super-bucket offsets and the scatter cursors [NXCD][nSB]:
+// inside a super-bucket the XCD classes follow each other, so it stays one contiguous range
 __global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist, u32 nSB, u32* __restrict__ sbOff,
                                                   u32* __restrict__ sbCursor) {
   __shared__ u32 scratch[20];
@@ -340,7 +366,9 @@ __global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const u32 i = threadIdx.x * PER + k;
-    v[k] = i < nSB ? sbHist[i] : 0;
+    v[k] = 0;
+    if (i < nSB)
+      for (int x = 0; x < NXCD; x++) v[k] += sbHist[x * nSB + i];
     sum += v[k];
   }
   u32 tot;
@@ -350,7 +378,11 @@ __global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist
     const u32 i = threadIdx.x * PER + k;
     if (i < nSB) {
       sbOff[i] = ex;
-      sbCursor[i] = ex;
+      u32 o = ex;
+      for (int x = 0; x < NXCD; x++) {
+        sbCursor[x * nSB + i] = o;
+        o += sbHist[x * nSB + i];
+      }
     }
     ex += v[k];
   }
@@ -468,11 +500,13 @@ __global__ __launch_bounds__(SC_NT) void k_scatter1(const R* __restrict__ in, R*
                                                     u32* __restrict__ cursor) {
   constexpr int ITEMS = ScCfg<R>::ITEMS;
   constexpr int CHUNK = SC_NT * ITEMS;
+  static_assert(CHUNK == (sizeof(R) == 4 ? L1_CHUNK32 : L1_CHUNK64), "the histograms were taken per chunk of this size");
   __shared__ u32 hist[MAX_BINS];
   __shared__ u32 start[MAX_BINS];
   __shared__ u32 base[MAX_BINS];
   __shared__ R stage[CHUNK];
   __shared__ u32 scratch[20];
+  cursor += (blockIdx.x % NXCD) * nBins;  // this chunk's XCD class
   const u32 begin = blockIdx.x * CHUNK;
   u32 end = *total;
   if (begin >= end) return;
@@ -490,18 +524,20 @@ __global__ __launch_bounds__(SC_NT) void k_scatter1(const R* __restrict__ in, R*
     }
   }
   __syncthreads();
-  // exclusive scan of hist -> start; reserve global runs
-  u32 carry = 0;
-  for (u32 b0 = 0; b0 < nBins; b0 += SC_NT) {
-    u32 b = b0 + threadIdx.x;
-    u32 c = b < nBins ? hist[b] : 0;
+  // Thread t owns bins t and t + SC_NT (MAX_BINS = 2 SC_NT).  Its two run reservations (global
+  // atomics) are issued first and stay in flight during the scan; the two counts (<= CHUNK < 2^16
+  // each, so are their sums) share one 32-bit block scan.
+  static_assert(MAX_BINS == 2 * SC_NT && CHUNK < 65536, "two bins per thread, 16-bit packed counts");
+  {
+    const u32 b0 = threadIdx.x, b1 = threadIdx.x + SC_NT;
+    const u32 c0 = b0 < nBins ? hist[b0] : 0, c1 = b1 < nBins ? hist[b1] : 0;
+    u32 g0 = 0, g1 = 0;
+    if (c0) g0 = atomicAdd(&cursor[b0], c0);
+    if (c1) g1 = atomicAdd(&cursor[b1], c1);
     u32 tot;
-    u32 ex = block_excl_scan<u32, SC_NT>(c, scratch, &tot);
-    if (b < nBins) {
-      start[b] = carry + ex;
-      if (c) base[b] = atomicAdd(&cursor[b], c);
-    }
-    carry += tot;
+    const u32 ex = block_excl_scan<u32, SC_NT>(c0 | (c1 << 16), scratch, &tot);
+    if (b0 < nBins) { start[b0] = ex & 0xFFFFu; base[b0] = g0; }
+    if (b1 < nBins) { start[b1] = (tot & 0xFFFFu) + (ex >> 16); base[b1] = g1; }
   }
   __syncthreads();
 #pragma unroll
@@ -823,14 +859,18 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
   // first TL_NT start / end keys of the next tile one tile ahead, so their HBM/L2 latency overlaps
   // the current tile instead of stalling every wave at the top of each iteration
   const u32 G = gridDim.x;
-  TileMeta m1 = blockIdx.x < nTiles ? in.meta[blockIdx.x] : TileMeta{};
-  TileMeta m2 = blockIdx.x + G < nTiles ? in.meta[blockIdx.x + G] : TileMeta{};
-  TileMeta m3 = blockIdx.x + 2 * G < nTiles ? in.meta[blockIdx.x + 2 * G] : TileMeta{};
+  // neighbouring tiles write neighbouring loose slots: give them to workgroups of the same XCD
+  // (workgroups are dealt to the XCDs round-robin), so that the cache lines two tiles share are
+  // completed inside one L2
+  const u32 lb = xcd_local_block(blockIdx.x, G);
+  TileMeta m1 = lb < nTiles ? in.meta[lb] : TileMeta{};
+  TileMeta m2 = lb + G < nTiles ? in.meta[lb + G] : TileMeta{};
+  TileMeta m3 = lb + 2 * G < nTiles ? in.meta[lb + 2 * G] : TileMeta{};
   u32 ks1 = threadIdx.x < m1.nS ? in.S[m1.sb + threadIdx.x] : 0u;
   u32 ke1 = threadIdx.x < m1.nE ? in.E[m1.eb + threadIdx.x] : 0u;
   u32 ks2 = threadIdx.x < m2.nS ? in.S[m2.sb + threadIdx.x] : 0u;
   u32 ke2 = threadIdx.x < m2.nE ? in.E[m2.eb + threadIdx.x] : 0u;
-  for (u32 t = blockIdx.x; t < nTiles; t += G) {
+  for (u32 t = lb; t < nTiles; t += G) {
     // (a tile takes about a microsecond, an HBM round trip several: keys two tiles ahead,
     // descriptors three)
     const TileMeta m = m1;

@@ -86,9 +86,10 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
   bmA[threadIdx.x] = 0;
   bmB[threadIdx.x] = 0;
   bmC[threadIdx.x] = 0;
+  const u32 lb = xcd_local_block(blockIdx.x, G);  // neighbouring tiles (neighbouring loose slots) on one XCD
   MergeHdr h1{}, h2{};
-  if (blockIdx.x < nTiles) h1 = merge_hdr(A, B, meta, blockIdx.x);
-  if (blockIdx.x + G < nTiles) h2 = merge_hdr(A, B, meta, blockIdx.x + G);
+  if (lb < nTiles) h1 = merge_hdr(A, B, meta, lb);
+  if (lb + G < nTiles) h2 = merge_hdr(A, B, meta, lb + G);
   u32 eA1 = 0, eB1 = 0;
   int vA1 = 0, vB1 = 0, vBn1 = 0;
   if (h1.a0 + threadIdx.x < h1.a1c) { eA1 = A.end[h1.a0 + threadIdx.x]; vA1 = A.v[h1.a0 + threadIdx.x]; }
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
     vBn1 = B.v[h1.b0 + threadIdx.x + 1];
   }
   __syncthreads();
-  for (u32 t = blockIdx.x; t < nTiles; t += G) {
+  for (u32 t = lb; t < nTiles; t += G) {
     const MergeHdr h = h1;
     const u32 eA0 = eA1, eB0 = eB1;
     const int vA0 = vA1, vB0 = vB1, vBn0 = vBn1;
