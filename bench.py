@@ -115,6 +115,9 @@ def main():
     params = GxParams(minus_log10f(0.05 if args.qval else 0.01), int(args.qval), 200.0, 0, 100, local_dev, 0)
     gx = Genrich(params)
     gx.set_chroms(lens)
+    # events -> peaks: the pileup floats of the intervals are only read by the -f / -k emitters, which this
+    # run does not use (the command-line host keeps them exactly when -f or -k is given)
+    gx.set_keep_pileups(bool(os.environ.get("GX_BENCH_KEEP_PILEUPS")))
     if world > 1:
         coll = Collectives(device=cdev)
         gx.set_owned(owned)

@@ -94,6 +94,7 @@ struct PArray {  // p-value intervals of one replicate (or the Fisher combinatio
   DevBuf end, p, expt, ctrl, chromOff, tileOff, q, dPresent;
   u32 n = 0;
   bool hasPiles = false;  // expt/ctrl filled (single-replicate logging)
+  bool pilesDropped = false;  // ... deliberately not (gx_set_keep_pileups(0))
   float ctrlConst = 0.0f; // control value when ctrl is not materialised (no -E, no control file)
   bool ctrlIsConst = false;
   std::vector<uint8_t> present;  // per chromosome: p-values exist (pval[n] != NULL)
@@ -110,6 +111,7 @@ struct gx_ctx {
   gx_params par{};
   int device = 0;
   hipStream_t stream = nullptr;
+  bool keepPiles = true;        // materialise the pileup floats of the p-value intervals
   int maskIdx = -1;             // reps[] entry whose sig / skip masks sit in swMask (k_pack_pval)
   u32 maskN = 0;
   size_t maskStride = 0;        // words between the sig / skip / brk masks in swMask
@@ -352,7 +354,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // everything that must start at zero lives in one arena: one memset per sample instead of eleven
   {
     const size_t tileBytes = ((size_t)(nTiles + 1) * 4 + 255) & ~(size_t)255;
-    const size_t histBytes = MAX_BINS * 4;
+    const size_t histBytes = (size_t)NXCD * MAX_BINS * 4;
     const size_t ffBytes = (sizeof(FragFix) + 255) & ~(size_t)255;
     const size_t total = ffBytes + 3 * histBytes + 5 * tileBytes;
     HIPCHECK(ctx->zeroArena.ensure(total));
@@ -369,7 +371,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   for (int q = 0; q < 3; q++) {
     gx_ctx::Stream& st = ctx->str[q];
     HIPCHECK(st.sbOff.ensure((MAX_BINS + 2) * 4));
-    HIPCHECK(st.sbCursor.ensure((MAX_BINS + 2) * 4));
+    HIPCHECK(st.sbCursor.ensure((size_t)NXCD * (MAX_BINS + 2) * 4));
     HIPCHECK(ctx->tileOff[q].ensure((size_t)(nTiles + 2) * 4));
   }
   HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
@@ -395,8 +397,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   size_t off = 0;
   for (auto& seg : segs) {
     if (!seg.n) continue;
-    // every workgroup flushes its two LDS histograms with global atomics: at least 8 K events each
-    u32 blocks = (u32)std::max<size_t>(1, std::min<size_t>((seg.n + 8191) / 8192, 256 * 16));
+    // whole level-1 chunks per workgroup, grid a multiple of NXCD (see k_convert)
+    u32 blocks = (u32)std::max<size_t>(NXCD, std::min<size_t>(((seg.n + L1_CHUNK32 - 1) / L1_CHUNK32 + NXCD - 1) / NXCD * NXCD,
+                                                             256 * 16));
     if (unit32)
       hipLaunchKernelGGL(k_convert<true>, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, (u32)off, ctx->dChrom.as<DChrom>(),
                          nChrom, ctx->sbShift, nSB, co, ctx->dStatus.as<u32>());
@@ -426,7 +429,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   if (nF) {
     HIPCHECK(SF.b.ensure((size_t)nF * 8 + 16));
-    hipLaunchKernelGGL((k_hist1<u64>), dim3(std::max(1u, std::min((nF + 255) / 256, 4096u))), dim3(256), 0, s, SF.a.as<u64>(),
+    hipLaunchKernelGGL((k_hist1<u64>), dim3(std::max<u32>(NXCD, std::min((nF + L1_CHUNK64 - 1) / L1_CHUNK64 / NXCD * NXCD + NXCD, 4096u))),
+                       dim3(256), 0, s, SF.a.as<u64>(),
                        nF, ctx->sbShift, nSB, SF.sbHist.as<u32>());
     if (int rc = sort_stream<u64>(ctx, SF, nF, 2)) return rc;
   }
@@ -743,6 +747,12 @@ int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn all
   return GX_OK;
 }
 
+int gx_set_keep_pileups(gx_ctx* ctx, int keep) {
+  if (!ctx) return GX_ERR_ORDER;
+  ctx->keepPiles = keep != 0;
+  return GX_OK;
+}
+
 int gx_set_owned(gx_ctx* ctx, const uint8_t* owned) {
   if (!ctx || !owned || ctx->nChrom == 0) return GX_ERR_ORDER;
   if (ctx->phase != 0 || ctx->sample != 0) return GX_ERR_ORDER;  // the tile space changes: between runs only
@@ -870,9 +880,10 @@ int gx_pvalues(gx_ctx* ctx) {
     // no control: the p-intervals are the treatment intervals
     const u32 n = ctx->expt.nIv;
     pa.n = n;
+    const bool keep = ctx->keepPiles;
     HIPCHECK(pooled(ctx, pa.p, (size_t)n * 4 + 16));
-    HIPCHECK(pooled(ctx, pa.expt, (size_t)n * 4 + 16));
-    if (ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)n * 4 + 16));
+    if (keep) HIPCHECK(pooled(ctx, pa.expt, (size_t)n * 4 + 16));
+    if (keep && ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)n * 4 + 16));
     phase_begin(ctx, "pval");
     HIPCHECK(ctx->pvLut.ensure((size_t)PV_LUT * 4));
     hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>());
@@ -891,10 +902,21 @@ int gx_pvalues(gx_ctx* ctx) {
       ctx->maskN = n;
       ctx->maskStride = nWords + 2;
     }
-    hipLaunchKernelGGL(k_pack_pval, dim3(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s, pin,
-                       ctx->nTiles, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(),
-                       pa.p.as<float>(), pa.expt.as<float>(), ctx->hasBed ? pa.ctrl.as<float>() : (float*)nullptr,
-                       ctx->par.thr, sigM, skipM, ctx->dStatus.as<u32>());
+    {
+      const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+      const bool ctl = keep && ctx->hasBed, msk = sigM != nullptr;
+#define GX_LAUNCH_PACK_PVAL(K, C, M)                                                                                    \
+  hipLaunchKernelGGL((k_pack_pval<K, C, M>), grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),          \
+                     ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(), pa.p.as<float>(), pa.expt.as<float>(),           \
+                     pa.ctrl.as<float>(), ctx->par.thr, sigM, skipM, ctx->dStatus.as<u32>())
+      if (keep) {
+        if (ctl) { if (msk) GX_LAUNCH_PACK_PVAL(true, true, true); else GX_LAUNCH_PACK_PVAL(true, true, false); }
+        else { if (msk) GX_LAUNCH_PACK_PVAL(true, false, true); else GX_LAUNCH_PACK_PVAL(true, false, false); }
+      } else {
+        if (msk) GX_LAUNCH_PACK_PVAL(false, false, true); else GX_LAUNCH_PACK_PVAL(false, false, false);
+      }
+#undef GX_LAUNCH_PACK_PVAL
+    }
     hipLaunchKernelGGL(k_pval_deep, dim3(256), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(),
                        ctx->dScal.as<Scalars>(), pa.p.as<float>(), ctx->par.thr, sigM);
     if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
@@ -903,7 +925,8 @@ int gx_pvalues(gx_ctx* ctx) {
     pa.end = std::move(ctx->expt.ivEnd);
     pa.chromOff = std::move(ctx->expt.chromIvOff);
     pa.tileOff = std::move(ctx->expt.tileIvOff);
-    pa.hasPiles = true;
+    pa.hasPiles = keep;
+    pa.pilesDropped = !keep;
     pa.ctrlIsConst = !ctx->hasBed;
     pa.ctrlConst = ctx->hScal.lambda;
   } else {
@@ -911,8 +934,11 @@ int gx_pvalues(gx_ctx* ctx) {
     const u32 nTiles = ctx->nTiles, nChrom = ctx->nChrom;
     const size_t cap = (size_t)ctx->expt.nIv + ctx->ctrl.nIv + 16;
     HIPCHECK(pooled(ctx, pa.end, cap * 4));
-    HIPCHECK(pooled(ctx, pa.expt, cap * 4));
-    HIPCHECK(pooled(ctx, pa.ctrl, cap * 4));
+    const bool keep = ctx->keepPiles;
+    if (keep) {
+      HIPCHECK(pooled(ctx, pa.expt, cap * 4));
+      HIPCHECK(pooled(ctx, pa.ctrl, cap * 4));
+    }
     HIPCHECK(pooled(ctx, pa.p, cap * 4));
     HIPCHECK(pooled(ctx, pa.tileOff, (size_t)(nTiles + 2) * 4));
     HIPCHECK(pooled(ctx, pa.chromOff, (size_t)(nChrom + 2) * 4));
@@ -965,14 +991,22 @@ int gx_pvalues(gx_ctx* ctx) {
       ctx->maskStride = stride;
     }
     HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
-    hipLaunchKernelGGL(k_pack_pairs, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s, ppi,
-                       nTiles, ctx->pairCtab.as<CtrlEntry>(), ctx->pairP2d.as<float>(), pa.end.as<u32>(),
-                       pa.expt.as<float>(), pa.ctrl.as<float>(), pa.p.as<float>(), ctx->par.thr, sigM, skipM,
-                       ctx->fragList.as<u32>(), misc + M_TICKET);
+    {
+      const dim3 grid(std::max(1u, std::min((nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+      const bool msk = sigM != nullptr;
+#define GX_LAUNCH_PACK_PAIRS(K, M)                                                                                     \
+  hipLaunchKernelGGL((k_pack_pairs<K, M>), grid, dim3(256), 0, s, ppi, nTiles, ctx->pairCtab.as<CtrlEntry>(),           \
+                     ctx->pairP2d.as<float>(), pa.end.as<u32>(), pa.expt.as<float>(), pa.ctrl.as<float>(),              \
+                     pa.p.as<float>(), ctx->par.thr, sigM, skipM, ctx->fragList.as<u32>(), misc + M_TICKET)
+      if (keep) { if (msk) GX_LAUNCH_PACK_PAIRS(true, true); else GX_LAUNCH_PACK_PAIRS(true, false); }
+      else { if (msk) GX_LAUNCH_PACK_PAIRS(false, true); else GX_LAUNCH_PACK_PAIRS(false, false); }
+#undef GX_LAUNCH_PACK_PAIRS
+    }
     hipLaunchKernelGGL(k_pack_pairs_full, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(4 * ctx->numCU)))), dim3(256), 0, s,
                        ppi, ctx->fragList.as<u32>(), misc + M_TICKET, ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(),
-                       ctx->pairCtab.as<CtrlEntry>(), pa.expt.as<float>(), pa.ctrl.as<float>(), pa.p.as<float>(),
-                       ctx->par.thr, sigM, skipM, ctx->dStatus.as<u32>());
+                       ctx->pairCtab.as<CtrlEntry>(), keep ? pa.expt.as<float>() : (float*)nullptr,
+                       keep ? pa.ctrl.as<float>() : (float*)nullptr, pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                       ctx->dStatus.as<u32>());
     if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
@@ -981,7 +1015,8 @@ int gx_pvalues(gx_ctx* ctx) {
     if (rc) return rc;
     pa.n = ctx->mail->nMerged;
     ctx->maskN = pa.n;
-    pa.hasPiles = true;
+    pa.hasPiles = keep;
+    pa.pilesDropped = !keep;
     pa.ctrlIsConst = false;
   }
   ctx->reps.push_back(std::move(pa));
@@ -1219,10 +1254,15 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((R + 255) / 256, 4096u))), dim3(256), 0, s, SM, fa.end.as<u32>(),
                          runStart, runEnd, misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->candHdr.as<uint4>(),
                          ctx->longList.as<u32>(), misc + M_TICKET3);
-      hipLaunchKernelGGL(k_peak_short, dim3(std::max(1u, std::min((R + 255) / 256, 8192u))), dim3(256), 0, s,
-                         ctx->candHdr.as<uint4>(), fa.end.as<u32>(), fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom,
-                         misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),
-                         ctx->valid.as<u32>());
+      {
+        const dim3 grid(std::max(1u, std::min((R + 255) / 256, 8192u)));
+#define GX_LAUNCH_PEAK_SHORT(Q)                                                                                          \
+  hipLaunchKernelGGL((k_peak_short<Q>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), fa.end.as<u32>(),                 \
+                     fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom, misc + M_NHEADS, ctx->par.thr,                \
+                     ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>())
+        if (qPtr) GX_LAUNCH_PEAK_SHORT(true); else GX_LAUNCH_PEAK_SHORT(false);
+#undef GX_LAUNCH_PEAK_SHORT
+      }
       hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((R + 3) / 4, (u32)(2 * ctx->numCU)))), dim3(256), 0, s,
                          ctx->candHdr.as<uint4>(), fa.end.as<u32>(), fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom,
                          ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
@@ -1307,6 +1347,10 @@ int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* en
   const PArray* pa = which_array(ctx, which, chrom, &lo, &hi);
   if (!pa) return GX_OK;
   size_t n = std::min<size_t>(cap, hi - lo);
+  if ((expt || ctrl) && pa->pilesDropped) {
+    ctx->err = "the pileup values were not kept (gx_set_keep_pileups)";
+    return GX_ERR_ORDER;
+  }
   if (!n) return GX_OK;
   if (end) HIPCHECK(hipMemcpy(end, pa->end.as<u32>() + lo, n * 4, hipMemcpyDeviceToHost));
   if (p) HIPCHECK(hipMemcpy(p, pa->p.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));

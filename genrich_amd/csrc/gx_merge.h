@@ -118,17 +118,14 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
     const u32 nA = h.a1c - a0, nB = h.b1c - b0;
     const bool staged = nA <= MG_CAP && nB <= MG_CAP;  // block-uniform
     // (bitmap words are zero here: each thread clears its words as soon as it has read them)
-    for (u32 j = threadIdx.x; j < nA; j += MG_NT) {
-      const u32 e = j < MG_NT ? eA0 : A.end[a0 + j];
-      const int v = j < MG_NT ? vA0 : A.v[a0 + j];
+    // (the prefetched first MG_NT intervals of each input come from registers, the rest -- dense
+    // tiles only -- from memory: two pieces of straight code, not a select inside one loop)
+    auto addA = [&](u32 j, u32 e, int v) {
       const u32 off = e - pos0;
       atomicOr(&bmA[off >> 5], 1u << (off & 31));
       if (staged) sA[j] = v;
-    }
-    for (u32 j = threadIdx.x; j < nB; j += MG_NT) {
-      const u32 e = j < MG_NT ? eB0 : B.end[b0 + j];
-      const int v = j < MG_NT ? vB0 : B.v[b0 + j];
-      const int vn = j < MG_NT ? vBn0 : B.v[b0 + j + 1];
+    };
+    auto addB = [&](u32 j, u32 e, int v, int vn) {
       const u32 off = e - pos0;
       bool ng1, ng2;
       const float here = ctrl_net(v, factor, lambda, &ng1);
@@ -137,7 +134,11 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
       atomicOr(&bmC[off >> 5], 1u << (off & 31));
       if (here != next) atomicOr(&bmB[off >> 5], 1u << (off & 31));  // 2122: net != MAX(val, lambda)
       if (staged) sC[j] = v;
-    }
+    };
+    if (threadIdx.x < nA) addA(threadIdx.x, eA0, vA0);
+    for (u32 j = threadIdx.x + MG_NT; j < nA; j += MG_NT) addA(j, A.end[a0 + j], A.v[a0 + j]);
+    if (threadIdx.x < nB) addB(threadIdx.x, eB0, vB0, vBn0);
+    for (u32 j = threadIdx.x + MG_NT; j < nB; j += MG_NT) addB(j, B.end[b0 + j], B.v[b0 + j], B.v[b0 + j + 1]);
     if (active && staged && threadIdx.x == 0) {  // the interval that covers what follows the tile's last breakpoint
       sA[nA] = A.v[h.a1c];
       sC[nB] = B.v[h.b1c];
@@ -157,14 +158,24 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
     if (threadIdx.x == 0) out.tileCount[t] = active ? tU + (lastTile ? 1u : 0u) : 0u;
     if (active) {  // block-uniform
       u32 o = slot + exU;
-      for (u32 bits = wU; bits; bits &= bits - 1) {
-        const int b = __ffs(bits) - 1;
-        const u32 below = (1u << b) - 1;
-        const u32 ia = exA + __popc(wA & below), ic = exC + __popc(wC & below);
-        out.end[o] = pos0 + threadIdx.x * 32 + b;
-        out.exptV[o] = staged ? sA[ia] : A.v[a0 + ia];
-        out.ctrlV[o] = staged ? sC[ic] : B.v[b0 + ic];
-        o++;
+      if (staged) {  // (two loops, not a select inside one: the choice is per tile)
+        for (u32 bits = wU; bits; bits &= bits - 1) {
+          const int b = __ffs(bits) - 1;
+          const u32 below = (1u << b) - 1;
+          out.end[o] = pos0 + threadIdx.x * 32 + b;
+          out.exptV[o] = sA[exA + __popc(wA & below)];
+          out.ctrlV[o] = sC[exC + __popc(wC & below)];
+          o++;
+        }
+      } else {
+        for (u32 bits = wU; bits; bits &= bits - 1) {
+          const int b = __ffs(bits) - 1;
+          const u32 below = (1u << b) - 1;
+          out.end[o] = pos0 + threadIdx.x * 32 + b;
+          out.exptV[o] = A.v[a0 + exA + __popc(wA & below)];
+          out.ctrlV[o] = B.v[b0 + exC + __popc(wC & below)];
+          o++;
+        }
       }
       if (lastTile && threadIdx.x == 0) {  // 1779-1788 at the chromosome end: both pileups close at len
         const u32 oc = slot + tU;
@@ -303,6 +314,8 @@ __global__ __launch_bounds__(256) void k_pair_tab2d(const Scalars* __restrict__ 
 // loose slots -> tight (end, expt, ctrl, p); one wavefront per tile.  Table look-ups only: a tile
 // holding any other pair of values is put on a list and redone by k_pack_pairs_full (whose
 // double-precision path would cost this kernel most of its occupancy).
+// (KEEP / MASKS are compile-time for the same reason as in k_pack_pval)
+template <bool KEEP, bool MASKS>
 __global__ __launch_bounds__(256) void k_pack_pairs(PackPairsIn in, u32 nTiles, const CtrlEntry* __restrict__ ctab,
                                                     const float* __restrict__ p2d, u32* __restrict__ end,
                                                     float* __restrict__ expt, float* __restrict__ ctrl,
@@ -364,11 +377,13 @@ __global__ __launch_bounds__(256) void k_pack_pairs(PackPairsIn in, u32 nTiles, 
               miss = true;
           }
           end[dst + i] = e[k];
-          expt[dst + i] = ef;
-          ctrl[dst + i] = cf;
+          if (KEEP) {  // (otherwise the pileup floats are not kept, gx_set_keep_pileups)
+            expt[dst + i] = ef;
+            ctrl[dst + i] = cf;
+          }
           p[dst + i] = pv;
         }
-        if (sigMask) {  // the sweep's masks while p is at hand (pre-zeroed words; a redone tile ORs its own bits in)
+        if (MASKS) {  // the sweep's masks while p is at hand (pre-zeroed words; a redone tile ORs its own bits in)
           const u64 sg = __ballot(pv > thr), sk = __ballot(pv == GX_SKIPF);
           if ((sg | sk) && lane == 0) {
             const u32 pos = dst + b + k * 64, w = pos >> 6, sh = pos & 63;
@@ -407,8 +422,10 @@ __global__ __launch_bounds__(256) void k_pack_pairs_full(PackPairsIn in, const u
       float e, c;
       const float pv = pval_pair(in.looseE[src + i], in.looseC[src + i], &e, &c, factor, lambda, logE, ctab, &ng);
       neg |= ng;
-      expt[dst + i] = e;
-      ctrl[dst + i] = c;
+      if (expt) {
+        expt[dst + i] = e;
+        ctrl[dst + i] = c;
+      }
       p[dst + i] = pv;
       if (sigMask) {  // the light pass saw p = 0 for the pairs it skipped: only bits to add
         if (pv > thr) atomicOr((unsigned long long*)&sigMask[(dst + i) >> 6], 1ull << ((dst + i) & 63));

@@ -42,6 +42,10 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
 constexpr int PP_UNROLL = 4;   // 256 intervals of a tile in flight per wavefront
 constexpr int PP_HOT = 1024;   // whole pileups below this have their p-value in LDS
 
+// KEEP / CTRL / MASKS: whether the pileup floats, the control column (-E runs) and the sweep masks
+// are written.  Compile-time on purpose: with the same choices as run-time null checks on the
+// output pointers the compiler schedules the stores of the hot loop 35 % slower (measured).
+template <bool KEEP, bool CTRL, bool MASKS>
 __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const Scalars* __restrict__ sc,
                                                    const float* __restrict__ lutP, u32* __restrict__ ivEnd,
                                                    float* __restrict__ pOut, float* __restrict__ exptOut,
@@ -110,18 +114,8 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
         v1[k] = in.looseV[si];
       }
     if (u + 2 * stride < nUnits) h2 = loadHdr(u + 2 * stride);
-    for (u32 b = 0; b < n; b += 64 * PP_UNROLL) {
-      if (b) {  // beyond the pipelined first batch (dense tiles)
-#pragma unroll
-        for (int k = 0; k < PP_UNROLL; k++) {
-          const u32 i = b + k * 64 + lane;
-          if (i < n) {
-            const u32 si = srcOf(h, i);
-            e[k] = in.looseEnd[si];
-            v[k] = in.looseV[si];
-          }
-        }
-      }
+    // score one batch of 64 * PP_UNROLL intervals starting at b (values already in e / v)
+    auto scoreBatch = [&](u32 b, const u32 (&e)[PP_UNROLL], const int (&v)[PP_UNROLL]) {
 #pragma unroll
       for (int k = 0; k < PP_UNROLL; k++) {
         const u32 i = b + k * 64 + lane;
@@ -147,10 +141,10 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
           neg |= ng;
           ivEnd[dst + i] = e[k];
           pOut[dst + i] = p;
-          exptOut[dst + i] = val;
-          if (ctrlOut) ctrlOut[dst + i] = v[k] == V_MARK ? GX_SKIPF : lambda;
+          if (KEEP) exptOut[dst + i] = val;
+          if (KEEP && CTRL) ctrlOut[dst + i] = v[k] == V_MARK ? GX_SKIPF : lambda;
         }
-        if (sigMask) {  // the sweep's significance / skip bit masks, while p is at hand (pre-zeroed words)
+        if (MASKS) {  // the sweep's significance / skip bit masks, while p is at hand (pre-zeroed words)
           const u64 sg = __ballot(p > thr), sk = __ballot(p == GX_SKIPF);
           if ((sg | sk) && lane == 0) {
             const u32 pos = dst + b + k * 64, w = pos >> 6, sh = pos & 63;
@@ -165,6 +159,26 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
           }
         }
       }
+    };
+    // (the pipelined first batch and the reloaded later ones -- dense tiles only -- are separate
+    // pieces of code: a select between register and memory sources inside one loop costs the
+    // load / store scheduling of the whole loop)
+    scoreBatch(0, e, v);
+    for (u32 b = 64 * PP_UNROLL; b < n; b += 64 * PP_UNROLL) {
+      u32 e2[PP_UNROLL];
+      int v2[PP_UNROLL];
+#pragma unroll
+      for (int k = 0; k < PP_UNROLL; k++) {
+        const u32 i = b + k * 64 + lane;
+        e2[k] = 0;
+        v2[k] = 0;
+        if (i < n) {
+          const u32 si = srcOf(h, i);
+          e2[k] = in.looseEnd[si];
+          v2[k] = in.looseV[si];
+        }
+      }
+      scoreBatch(b, e2, v2);
     }
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
@@ -757,13 +771,14 @@ struct PeakAcc {
 // in-order loop like updatePeak itself; every candidate of the genome is in flight at once.  Loads
 // are 16 bytes wide (a 64-lane gather costs the texture unit one cycle per lane whatever the width)
 // and PK_LOADS of them per array are in flight: the kernel is a chain of memory round trips.
+template <bool USEQ>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
 __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hdr, const u32* __restrict__ end,
                                                     const float* __restrict__ p, const float* __restrict__ q,
                                                     const u32* __restrict__ chromOff, u32 nChrom,
                                                     const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
                                                     gx_peak* __restrict__ cand, u32* __restrict__ valid) {
   const u32 C = *nCands;
-  const bool useQ = q != nullptr;
+  constexpr bool useQ = USEQ;
   for (u32 c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
     const uint4 h = hdr[c];
     const u32 i0 = h.x, i1 = h.y;

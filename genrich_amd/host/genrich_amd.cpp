@@ -1382,6 +1382,7 @@ int main(int argc, char** argv) {
     par.genome_len = o.genomeLen;
     int rc = gx_create(&S.gx, &par);
     if (rc) die(S.gx ? gx_last_error(S.gx) : gx_strerror(rc), "");
+    check(S, gx_set_keep_pileups(S.gx, o.logFile || o.pileFile));  // only -f / -k print pileup values
   }
 
   // loop over the comma-separated treatment / control lists (runProgram 5455-5585)

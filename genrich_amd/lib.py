@@ -48,6 +48,7 @@ _SIGS = {
     "gx_reset": [C.c_void_p],
     "gx_set_chroms": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "gx_set_owned": [C.c_void_p, C.c_void_p],
+    "gx_set_keep_pileups": [C.c_void_p, C.c_int],
     "gx_set_collectives": [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p],
     "gx_sample_begin": [C.c_void_p, C.c_int, C.c_void_p],
     "gx_push_events": [C.c_void_p, C.c_void_p, C.c_size_t],
@@ -142,6 +143,11 @@ class Genrich:
     def reset(self):
         self._check(self.lib.gx_reset(self.ctx))
 
+    def set_keep_pileups(self, keep):
+        """keep=False: the pileup floats of the p-value intervals (only the -f / -k emitters read them)
+        are not materialised."""
+        self._check(self.lib.gx_set_keep_pileups(self.ctx, int(bool(keep))))
+
     def set_owned(self, owned):
         a = np.ascontiguousarray(owned, dtype=np.uint8)
         self._check(self.lib.gx_set_owned(self.ctx, a.ctypes.data))
@@ -191,7 +197,9 @@ class Genrich:
             self._check(self.lib.gx_get_peaks(self.ctx, out.ctypes.data, self.n_peaks))
         return out
 
-    def get_intervals(self, which, chrom):
+    def get_intervals(self, which, chrom, piles=True):
+        """(ends, {"expt", "ctrl", "p", "q"}) of one chromosome; piles=False leaves the pileup
+        columns out (the only choice after set_keep_pileups(False))."""
         n = C.c_size_t(0)
         self._check(self.lib.gx_interval_count(self.ctx, int(which), int(chrom), C.byref(n)))
         n = n.value
@@ -200,7 +208,7 @@ class Genrich:
         if n:
             self._check(self.lib.gx_get_intervals(
                 self.ctx, int(which), int(chrom), n, end.ctypes.data,
-                *[cols[k].ctypes.data for k in ("expt", "ctrl", "p", "q")]))
+                *[cols[k].ctypes.data if piles or k in ("p", "q") else None for k in ("expt", "ctrl", "p", "q")]))
         return end, cols
 
     # -- text emitters (gx_emit.cpp) ----------------------------------------------------

@@ -190,6 +190,12 @@ int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn all
  * first gx_sample_begin (or right after gx_reset): GX_ERR_ORDER otherwise. */
 int gx_set_owned(gx_ctx* ctx, const uint8_t* owned);
 
+/* keep = 0: the treatment / control pileup floats of the p-value intervals are not written to
+ * device memory (they are only ever read by gx_get_intervals, i.e. by the -f / -k emitters, which
+ * then fail with GX_ERR_ORDER); interval ends, p and q are unaffected.  Default 1.  The reference
+ * always keeps them (Pileup arrays, Genrich.h:208-214) and prints them only with -f / -k. */
+int gx_set_keep_pileups(gx_ctx* ctx, int keep);
+
 /* ---- introspection used by bench.py / tests ---- */
 
 /* Per-phase device times (ms, HIP events on the library's stream) of the last

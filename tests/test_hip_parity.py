@@ -318,3 +318,24 @@ def test_crowded_tile_takes_the_chunked_bucket_path():
     o, h, so, sh = run_both(case, B.make_params(pq=0.01, min_auc=20.0))
     assert_same_run(o, h, so, sh, case)
     assert h.n_peaks >= 1
+
+
+@pytest.mark.parametrize("name", ["basic", "ctrl_q", "bedx"])
+def test_without_pileup_floats(name):
+    """gx_set_keep_pileups(0): interval ends, p, q and peaks are what they are with the pileup
+    floats kept; asking for the pileups is an error, not a silent zero."""
+    meta, case, params, names = G.load_case(name)
+    full = hip_backend(params)
+    B.run_case(full, case)
+    lean = hip_backend(params)
+    lean.set_keep_pileups(False)
+    B.run_case(lean, case)
+    assert full.get_peaks().tobytes() == lean.get_peaks().tobytes()
+    for c in range(len(case["lens"])):
+        ef, cf = full.get_intervals(-1, c)
+        el, cl = lean.get_intervals(-1, c, piles=False)
+        assert np.array_equal(ef, el)
+        assert np.array_equal(cf["p"].view(np.uint32), cl["p"].view(np.uint32))
+        assert np.array_equal(cf["q"].view(np.uint32), cl["q"].view(np.uint32))
+    with pytest.raises(RuntimeError):
+        lean.get_intervals(-1, 0)
