@@ -339,3 +339,21 @@ def test_without_pileup_floats(name):
         assert np.array_equal(cf["q"].view(np.uint32), cl["q"].view(np.uint32))
     with pytest.raises(RuntimeError):
         lean.get_intervals(-1, 0)
+
+
+def test_thousands_of_small_contigs():
+    """An assembly with alternate / unplaced contigs: 2,500 chromosomes, many shorter than one tile,
+    some without any read, some skipped (-e)."""
+    rng = np.random.default_rng(17)
+    lens = [int(x) for x in rng.integers(300, 30_000, 2500)]
+    lens[7] = 1  # a one-base contig
+    ev = synth.make_fragments(lens, 400_000, seed=9)
+    ev = ev[(ev["chrom"] % 11) != 3]  # contigs without reads
+    ct = synth.make_fragments(lens, 300_000, seed=10, uniform_only=True)
+    skip = [(i % 97) == 5 for i in range(len(lens))]
+    case = dict(lens=lens, skip=skip, replicates=[dict(save=None, treat=ev, ctrl=ct)])
+    for qval in (False, True):
+        params = B.make_params(pq=0.05 if qval else 0.01, qval=qval, min_auc=10.0)
+        o, h, so, sh = run_both(case, params)
+        assert_same_run(o, h, so, sh, case)
+        assert qval or h.n_peaks > 1000
