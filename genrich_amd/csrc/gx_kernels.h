@@ -750,7 +750,8 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, typ
 // No inter-workgroup dependency: a tile writes its intervals into its own slot of a LOOSE
 // array (slot t starts at tileOff[t] + t: a tile cannot close more intervals than it has
 // endpoint records, plus the chromosome-closing one) and reports how many it wrote.
-// k_scan_iv then turns the counts into tight offsets and k_pack packs the slots.  (A fused
+// k_scan_iv then turns the counts into tight offsets and the pack kernels (k_pack_pval, or k_pack
+// ahead of a control merge) move the slots to their tight place.  (A fused
 // decoupled look-back was measured first: with ~512 resident tiles the look-back distance made
 // it latency-bound at ~10 us per tile.)
 constexpr int TL_NT = TILE / 32;  // one thread per 32 bases (= one bitmap word)
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
                                                    u32* __restrict__ st) {
   // LDS: the tile's slice of the difference array (one int per base) plus an occupancy bitmap
   // (one bit per base).  Only bases that received a record are ever read back or cleared, so a
-  // tile costs O(records) LDS traffic instead of O(TILE): at config 2 ~1,060 of the 16,384 bases
+  // tile costs O(records) LDS traffic instead of O(TILE): at config 2 ~130 of the 4,096 bases
   // of a tile are touched.  The slice is all-zero whenever a tile starts (each tile clears what it
   // touched).
   extern __shared__ __attribute__((aligned(16))) int lds[];
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     int preS = 0;
     u32 preC = 0, totC = 0;
 #pragma unroll
-    for (int w = 0; w < TL_NW; w++) {  // 8 waves: every thread sums the wave totals it needs
+    for (int w = 0; w < TL_NW; w++) {  // every thread sums the (few) wave totals it needs
       int ws = scr[w];
       u32 wc = (u32)scr[16 + w];
       if (w < wv) { preS += ws; preC += wc; }
