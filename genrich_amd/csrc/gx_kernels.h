@@ -5,9 +5,11 @@
 //     one chromosome.  The reference's per-base difference array (Diff, Genrich.h:178-181;
 //     written by saveInterval, Genrich.c:2575-2583) never exists in HBM: each tile's slice
 //     lives in LDS for the lifetime of one workgroup.
-//   * an alignment interval becomes two 8-byte endpoint records
-//       [63:32] tile   [31:8] offset in tile   [7:0] signed weight in 1/120 units
-//     which a two-level bucket sort (super-bucket, then tile) groups by tile.
+//   * an alignment interval of unit weight becomes a 4-byte start key and a 4-byte end key
+//       [31:TB] tile   [TB-1:0] offset in tile
+//     (sign and weight implied by the stream; 16-bit offsets after the sort), one of fractional
+//     weight two 8-byte records  [63:32] tile  [31:8] offset  [7:0] signed weight in 1/120 units;
+//     a two-level bucket sort (super-bucket, then tile) groups them by tile.
 //   * pileups leave the tile kernel as run-length intervals (end, V120) exactly where the
 //     reference breaks them (savePileupExpt, Genrich.c:2239-2273): V120 is the exact pileup
 //     in 1/120 units, from which getVal's float is re-materialised when needed.

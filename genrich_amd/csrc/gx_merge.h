@@ -9,8 +9,8 @@
 // Both run-length inputs were produced tile by tile, so "the intervals that end inside tile t"
 // are a contiguous slice [tileOff[t], tileOff[t+1]).  A tile's breakpoints are set as bits of a
 // 2^TB-bit LDS bitmap per input; the union is a bitwise OR; an input's covering interval at
-// a union breakpoint j is slice_begin + popcount(bits before j).  Output positions again come
-// from the decoupled look-back.
+// a union breakpoint j is slice_begin + popcount(bits before j).  Like k_tile, a tile writes into
+// its own loose slot and reports a count; k_scan_counts and the pack kernels make the result tight.
 #pragma once
 #include "gx_stats.h"
 
