@@ -357,3 +357,28 @@ def test_thousands_of_small_contigs():
         o, h, so, sh = run_both(case, params)
         assert_same_run(o, h, so, sh, case)
         assert qval or h.n_peaks > 1000
+
+
+@pytest.mark.parametrize("name", ["basic", "atac", "bedx_noctrl"])
+def test_q_values_without_control(name):
+    """-q on a control-less replicate (the BH table over a p array that came from the pack kernel)."""
+    meta, case, _, names = G.load_case(name)
+    params = B.make_params(pq=0.2, qval=True, min_auc=5.0)
+    o, h, so, sh = run_both(case, params)
+    nbit = assert_same_run(o, h, so, sh, case)
+    assert nbit == {"p": 0, "q": 0}
+    qs = np.concatenate([h.get_intervals(-1, c)[1]["q"] for c in range(len(case["lens"]))])
+    assert len(np.unique(qs)) > 3
+
+
+def test_q_values_without_control_deep_and_fractional():
+    """... with fractional pileups (-s) and pileups beyond the p-value table."""
+    lens = [300_000]
+    bg = synth.make_fragments(lens, 6000, seed=21)
+    mm = synth.add_multimap(bg, lens, 0.3, seed=22)
+    deep = np.array([(0, 150_000, 150_200, 1)] * 2600, dtype=B.EVENT_DTYPE)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=np.concatenate([mm, deep]), ctrl=None)])
+    o, h, so, sh = run_both(case, B.make_params(pq=0.2, qval=True, min_auc=5.0))
+    assert_same_run(o, h, so, sh, case)
+    e, cols = h.get_intervals(-1, 0)
+    assert cols["expt"].max() > 2500 and (cols["expt"] % 1 != 0).any()
