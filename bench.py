@@ -218,10 +218,11 @@ def main():
                 "algorithmic_bytes": alg_bytes,
                 "launch_ms": t_tile * 1e3,
                 "traffic_gbs": (traffic / t_tile / 1e9) if (traffic and t_tile > 0) else None,
+                "traffic_frac_of_peak": (traffic / t_tile / 1e9 / HBM_PEAK_GBS) if (traffic and t_tile > 0) else None,
                 "note": "algorithmic bytes = 8 B/base (clear + scan of the dense difference array) + 16 B/event "
                         "+ 8 B/interval, SURVEY 8(d); k_tile keeps that array in LDS, so its real HBM traffic "
-                        "(`traffic`, PMC; `traffic_gbs` = traffic / launch time) is ~20x smaller and `frac` can exceed 1: "
-                        "the kernel is LDS-latency / issue-bound, not HBM-bound",
+                        "(`traffic`, PMC; `traffic_gbs` = traffic / launch time, `traffic_frac_of_peak` = that over 8 TB/s) "
+                        "is ~25x smaller and `frac` can exceed 1: the kernel is VALU-issue / LDS-latency bound, not HBM-bound",
             },
             "phases_ms": phases,
             "whole_path_hbm_frac": ((8.0 * G + 16.0 * 2 * args.frags + 52.0 * iv0) / (dt / args.steps) / 1e9)
