@@ -382,3 +382,43 @@ def test_q_values_without_control_deep_and_fractional():
     assert_same_run(o, h, so, sh, case)
     e, cols = h.get_intervals(-1, 0)
     assert cols["expt"].max() > 2500 and (cols["expt"] % 1 != 0).any()
+
+
+def test_events_from_several_host_and_device_segments():
+    """One sample fed in pieces: host pushes and device-resident segments of odd sizes (the level-1
+    chunk bookkeeping of k_convert runs over the concatenation)."""
+    torch = pytest.importorskip("torch")
+    lens = [3_000_000, 1_500_000]
+    ev = synth.make_fragments(lens, 60_000, seed=31)
+    ct = synth.make_fragments(lens, 50_000, seed=32, uniform_only=True)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=ct)])
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    h.set_chroms(lens)
+
+    def feed(events):
+        cuts = [0, 9_001, 9_001 + 8_192, 30_011, len(events)]
+        keep = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            part = events[a:b]
+            if (a // 7) % 2 == 0:
+                h.push_events(part)
+            else:
+                t = torch.from_numpy(part.view(np.uint32).reshape(-1, 4).copy()).cuda()
+                keep.append(t)  # must stay alive until the sample is closed
+                h.push_events_device(t.data_ptr(), t.shape[0])
+        return keep
+
+    h.sample_begin(0, None)
+    k1 = feed(ev)
+    frag, _, _ = h.sample_end()
+    h.sample_begin(1, None)
+    k2 = feed(ct)
+    _, lam, fac = h.sample_end()
+    h.pvalues()
+    h.find_peaks()
+    del k1, k2
+    assert_same_run(o, h, so, [(frag, lam, fac)], case)
+    assert h.n_peaks > 0
