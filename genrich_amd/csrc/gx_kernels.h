@@ -967,12 +967,27 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     if (edge) save = !save;                                       /* 2258-2263 */ \
     sat |= (u32)((D) >= 32767 * GX_UNIT) | (u32)((D) <= -32768 * GX_UNIT);     \
   }
+    if constexpr (!BED) {
+      // Without -E edges the register-held steps need no branches: an absent entry carries d = 0,
+      // which adds nothing, counts nothing and needs no clearing.  (Base 0 of a chromosome is the
+      // one position whose difference does not close an interval, 2241.)
 #pragma unroll
-    for (int j = 0; j < TL_REG; j++)
-      if (kk[j] >= 0) {
-        GX_P1_STEP(kk[j], dk[j]);
-        if (dk[j] != 0) delta[lbase + kk[j]] = 0;
+      for (int j = 0; j < TL_REG; j++) {
+        const int d = dk[j];
+        sum += d;
+        cnt += (u32)(d != 0);
+        sat |= (u32)(d >= 32767 * GX_UNIT) | (u32)(d <= -32768 * GX_UNIT);
+        if (d != 0) delta[lbase + kk[j]] = 0;
       }
+      if (pos0 + lbase == 0 && kk[0] == 0 && dk[0] != 0) cnt -= 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < TL_REG; j++)
+        if (kk[j] >= 0) {
+          GX_P1_STEP(kk[j], dk[j]);
+          if (dk[j] != 0) delta[lbase + kk[j]] = 0;
+        }
+    }
     for (u32 m = mrest; m; m &= m - 1) {
       const int k = __builtin_ctz(m);
       const int d = delta[lbase + k];
@@ -1017,9 +1032,26 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     neg |= (u32)(run < 0);                                             \
     big |= (u32)(run >= FRAG_FAST_MAXV);                               \
   }
+    if constexpr (!BED) {
 #pragma unroll
-    for (int j = 0; j < TL_REG; j++)
-      if (kk[j] >= 0) GX_P2_STEP(kk[j], dk[j]);
+      for (int j = 0; j < TL_REG; j++) {  // (d = 0 for an absent entry: nothing emitted, run unchanged)
+        const int d = dk[j];
+        const u32 p = pos0 + lbase + kk[j];
+        if (active && d != 0 && p != 0) {
+          out.looseEnd[o] = p;
+          out.looseV[o] = run;
+          lastEnd = p;
+          o++;
+        }
+        run += d;
+        neg |= (u32)(run < 0);
+        big |= (u32)(run >= FRAG_FAST_MAXV);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TL_REG; j++)
+        if (kk[j] >= 0) GX_P2_STEP(kk[j], dk[j]);
+    }
     for (u32 m = mrest; m; m &= m - 1) {
       const int k = __builtin_ctz(m);
       const int d = delta[lbase + k];

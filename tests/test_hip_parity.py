@@ -387,7 +387,13 @@ def test_q_values_without_control_deep_and_fractional():
 def test_events_from_several_host_and_device_segments():
     """One sample fed in pieces: host pushes and device-resident segments of odd sizes (the level-1
     chunk bookkeeping of k_convert runs over the concatenation)."""
-    torch = pytest.importorskip("torch")
+    import ctypes as C
+    # plain HIP runtime calls -- through the very runtime instance the library under test is linked
+    # to (a process may hold a second copy, e.g. the one bundled with torch)
+    hip_backend(B.make_params(pq=0.01)).close()
+    paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+    rocm = [q for q in paths if "/torch/" not in q] or paths
+    hip = C.CDLL(rocm[0])
     lens = [3_000_000, 1_500_000]
     ev = synth.make_fragments(lens, 60_000, seed=31)
     ct = synth.make_fragments(lens, 50_000, seed=32, uniform_only=True)
@@ -406,9 +412,12 @@ def test_events_from_several_host_and_device_segments():
             if (a // 7) % 2 == 0:
                 h.push_events(part)
             else:
-                t = torch.from_numpy(part.view(np.uint32).reshape(-1, 4).copy()).cuda()
-                keep.append(t)  # must stay alive until the sample is closed
-                h.push_events_device(t.data_ptr(), t.shape[0])
+                raw = np.ascontiguousarray(part).tobytes()
+                ptr = C.c_void_p()
+                assert hip.hipMalloc(C.byref(ptr), C.c_size_t(len(raw))) == 0
+                assert hip.hipMemcpy(ptr, raw, C.c_size_t(len(raw)), 1) == 0  # synchronous host -> device
+                keep.append(ptr)  # must stay allocated until the sample is closed
+                h.push_events_device(ptr.value, len(part))
         return keep
 
     h.sample_begin(0, None)
@@ -419,6 +428,7 @@ def test_events_from_several_host_and_device_segments():
     _, lam, fac = h.sample_end()
     h.pvalues()
     h.find_peaks()
-    del k1, k2
+    for ptr in k1 + k2:
+        hip.hipFree(ptr)
     assert_same_run(o, h, so, [(frag, lam, fac)], case)
     assert h.n_peaks > 0
