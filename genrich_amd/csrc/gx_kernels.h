@@ -758,7 +758,10 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, typ
 // it latency-bound at ~10 us per tile.)
 constexpr int TL_NT = TILE / 32;  // one thread per 32 bases (= one bitmap word)
 constexpr int TL_NW = TL_NT / 64;
-constexpr int TL_REG = 4;                         // touched bases per thread held in registers
+#ifndef GX_TL_REG
+#define GX_TL_REG 4
+#endif
+constexpr int TL_REG = GX_TL_REG;                 // touched bases per thread held in registers
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
 constexpr int TL_LDS = TILE + 64 + 2 * (TILE / 32); // ints: slice, scan scratch, occupancy + -E edge bitmaps
 constexpr int FRAG_FAST_MAXV = ((1 << 24) / (2 * TILE)) * GX_UNIT;  // len < 2 TILE and V below this: len * val < 2^24
