@@ -1,0 +1,74 @@
+"""Build container only (needs oracle/_ref/Genrich): random SAM / BAM inputs and option sets; the
+host program (--events-only, no GPU needed) against the unmodified reference: -b event stream, -R
+duplicate log and the -v accounting must be identical.  usage: fuzz_host_vs_reference.py SEED0 SEED1"""
+import sys, os, subprocess, random, gzip
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from genrich_amd import synth
+REF=os.path.join(ROOT, 'oracle', '_ref', 'Genrich'); BIN=os.path.join(ROOT, 'genrich_amd', 'genrich-amd')
+N2=["chr1","chr2","chrM"]; 
+def one(seed):
+    rng=random.Random(seed)
+    L=[rng.randint(20_000,60_000), rng.randint(10_000,40_000), rng.randint(2_000,8_000)]
+    d=f"/tmp/fuzz/c{seed}"; os.makedirs(d,exist_ok=True)
+    ev=synth.make_fragments(L, rng.randint(300,3000), seed=seed)
+    ct=synth.make_fragments(L, rng.randint(300,3000), seed=seed+1, uniform_only=True)
+    writer=rng.choice(["mixed","dups","plain"]); bam=rng.random()<0.4 and writer!="plain"
+    ext="bam" if bam else "sam"
+    def wr(p,e,s,pre):
+        if writer=="mixed": synth.write_sam_mixed(p,N2,L,e,s,name_prefix=pre,bam=bam)
+        elif writer=="dups": synth.write_sam_dups(p,N2,L,e,s,name_prefix=pre,bam=bam)
+        else: synth.write_sam(p,N2,L,e,name_prefix=pre)
+    t=f"{d}/t.{ext}"; c=f"{d}/c.{ext}"; wr(t,ev,seed,"t_"); wr(c,ct,seed+7,"c_")
+    args=["-t",t]
+    if rng.random()<0.7: args+=["-c",c]
+    single=rng.choice([None,"-y","-w","-x"])
+    if single=="-w": args+=["-w",str(rng.randint(50,400))]
+    elif single: args+=[single]
+    if rng.random()<0.3:
+        args+=["-j"]
+        if rng.random()<0.5: args+=["-d",str(rng.randint(20,200))]
+        if rng.random()<0.5: args+=["-D"]
+    if rng.random()<0.4: args+=["-m",str(rng.randint(1,40))]
+    if rng.random()<0.4: args+=["-s",str(rng.choice([0.5,1,2,5,20]))]
+    dups = rng.random()<0.5
+    if dups: args+=["-r"]
+    if rng.random()<0.3: args+=["-e",rng.choice(["chrM","chr2","chrM,chr2"])]
+    if rng.random()<0.3:
+        bp=f"{d}/x.bed"
+        with open(bp,"w") as f:
+            for _ in range(rng.randint(1,5)):
+                ci=rng.randrange(3); s=rng.randint(0,L[ci]-10); e=min(L[ci], s+rng.randint(1,3000)); f.write(f"{N2[ci]}\t{s}\t{e}\n")
+        args+=["-E",bp]
+    ra=[REF]+args+["-b",f"{d}/ref.bed","-o",f"{d}/ref.np","-v"]+(["-R",f"{d}/ref.dups"] if dups else [])
+    ha=[BIN,"--events-only"]+args+["-b",f"{d}/hip.bed","-v"]+(["-R",f"{d}/hip.dups"] if dups else [])
+    r=subprocess.run(ra,capture_output=True,text=True); h=subprocess.run(ha,capture_output=True,text=True)
+    # the reference may fail legitimately (e.g. no fragments): then both must fail
+    if r.returncode!=0 and ("no analyzable fragments" in r.stderr or "Experimental sample" in r.stderr):
+        subprocess.run(["rm","-rf",d]); return None   # the reference stops after the treatment file; the events-only host goes on
+    if r.returncode!=0 or h.returncode!=0:
+        # events-only host stops before the statistics: compare only when the reference got past ingest
+        if "Experimental sample" in r.stderr or "No analyzable" in r.stderr or "peak" in r.stderr.lower():
+            pass
+        elif r.returncode!=h.returncode:
+            return f"seed {seed}: rc ref={r.returncode} hip={h.returncode}\n{' '.join(args)}\nREF: {r.stderr[-300:]}\nHIP: {h.stderr[-300:]}"
+    if os.path.exists(f"{d}/ref.bed") and os.path.exists(f"{d}/hip.bed"):
+        if open(f"{d}/ref.bed","rb").read()!=open(f"{d}/hip.bed","rb").read():
+            return f"seed {seed}: -b differs: {' '.join(args)}"
+    if dups and os.path.exists(f"{d}/ref.dups") and open(f"{d}/ref.dups","rb").read()!=open(f"{d}/hip.dups","rb").read():
+        return f"seed {seed}: -R differs: {' '.join(args)}"
+    # verbose accounting lines (up to the point the host stops)
+    def acct(txt): return [l for l in txt.splitlines() if l.startswith("  ") or l.startswith("Processing") or "Warning" in l]
+    ra_,ha_=acct(r.stderr),acct(h.stderr)
+    ra_=[l for l in ra_ if "Background" not in l and "Scaling" not in l and "Genome length" not in l]
+    if ra_[:len(ha_)]!=ha_: 
+        import difflib
+        return f"seed {seed}: -v differs: {' '.join(args)}\n"+"\n".join(list(difflib.unified_diff(ra_,ha_,lineterm=''))[:20])
+    subprocess.run(["rm","-rf",d])
+    return None
+bad=0
+for seed in range(int(sys.argv[1]),int(sys.argv[2])):
+    m=one(seed)
+    if m: print(m); bad+=1
+print("done, failures:",bad)
