@@ -432,3 +432,57 @@ def test_events_from_several_host_and_device_segments():
         hip.hipFree(ptr)
     assert_same_run(o, h, so, [(frag, lam, fac)], case)
     assert h.n_peaks > 0
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    nch = int(rng.integers(1, 6))
+    lens = [int(x) for x in rng.integers(500, 120_000, nch)]
+    skip = [bool(rng.random() < 0.15) for _ in lens]
+    if all(skip):
+        skip[0] = False
+    beds = []
+    for L, sk in zip(lens, skip):
+        regs = []
+        if not sk and rng.random() < 0.3:
+            for _ in range(int(rng.integers(1, 4))):
+                s = int(rng.integers(0, max(1, L - 5)))
+                regs.append((s, min(L, s + int(rng.integers(1, 3000)))))
+        regs.sort()
+        merged = []
+        for s, e in regs:  # merged, clipped, as saveXBed leaves them (Genrich.c:1144-1206)
+            if merged and s <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], e)
+            else:
+                merged.append([s, e])
+        beds.append([v for r in merged for v in r])
+    reps = []
+    for r in range(int(rng.choice([1, 1, 2, 3]))):
+        n = int(rng.integers(200, 6000))
+        tr = synth.make_fragments(lens, n, seed=seed * 7 + r, frac_peak=0.4, frac_tower=0.2)
+        if rng.random() < 0.3:
+            tr = synth.add_multimap(tr, lens, 0.25, seed=seed + 11)
+        ct = None
+        if rng.random() < 0.5:
+            ct = synth.make_fragments(lens, int(rng.integers(200, 6000)), seed=seed * 7 + 3 + r, uniform_only=True)
+        reps.append(dict(save=None, treat=tr, ctrl=ct))
+    qval = bool(rng.random() < 0.5)
+    params = B.make_params(pq=float(rng.choice([0.3, 0.1, 0.05])) if qval else float(rng.choice([0.05, 0.01, 0.001])),
+                           qval=qval, min_auc=float(rng.choice([1, 10, 50])), min_len=int(rng.choice([0, 0, 80])),
+                           max_gap=int(rng.choice([0, 100, 250])))
+    return dict(lens=lens, skip=skip, beds=beds, replicates=reps), params
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_runs_against_oracle(block):
+    """40 random runs: 1-5 chromosomes (some skipped, some with -E regions), 1-3 replicates with or
+    without control, multimapping, -p / -q, assorted -a / -l / -g."""
+    for seed in range(block * 10, block * 10 + 10):
+        case, params = _random_case(1000 + seed)
+        try:
+            o, h, so, sh = run_both(case, params)
+        except RuntimeError as ex:  # both must refuse the same inputs (e.g. a sample without fragments)
+            with pytest.raises(RuntimeError):
+                B.run_case(B.Oracle(params), case)
+            continue
+        assert_same_run(o, h, so, sh, case)
