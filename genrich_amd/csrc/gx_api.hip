@@ -141,7 +141,7 @@ struct gx_ctx {
   };
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3];
-  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena;
+  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};  // host copy of the device scalars (refreshed from the mail block)
@@ -389,11 +389,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
   static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
   HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->endAtLen.ensure((size_t)(nChrom + 1) * 4));
+  HIPCHECK(hipMemsetAsync(ctx->endAtLen.p, 0, (size_t)(nChrom + 1) * 4, s));
   FragFix* ff = ctx->fragSum.as<FragFix>();
   u32* slowFrag = &ff->slow;
   if (ctx->hasBed || !unit32 || forceSlowFrag) HIPCHECK(hipMemsetAsync(slowFrag, 1, 4, s));
   ConvertOut co{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), &ff->nF, SS.sbHist.as<u32>(),
-                SE.sbHist.as<u32>(), ff->fragSum, slowFrag};
+                SE.sbHist.as<u32>(), ff->fragSum, slowFrag, ctx->endAtLen.as<u32>()};
   size_t off = 0;
   for (auto& seg : segs) {
     if (!seg.n) continue;

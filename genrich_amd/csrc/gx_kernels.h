@@ -249,6 +249,7 @@ struct ConvertOut {
   u32* histE;
   u64* fragSum; // [FRAG_SLOTS] sum of the clamped lengths of the fragments kept (see k_frag)
   u32* slowFrag;
+  u32* endAtLen; // [nChrom] weight of the events that end at (or beyond) the chromosome's end
 };
 
 template <bool UNIT32>
@@ -299,6 +300,10 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
             if (end < c.len) {
               t1 = c.tileBase + (end >> TB);
               o1 = end & (TILE - 1);
+            } else if (atomicAdd(&out.endAtLen[e.x], (u32)w) + (u32)w >= 32768u * GX_UNIT) {
+              // the reference's diff has an entry at `len` too, and its int16 saturates there like
+              // anywhere else (2565-2573): same policy as inside the chromosome (ST_SAT16, k_tile)
+              bad |= ST_SAT16;
             }
           }
         }

@@ -486,3 +486,24 @@ def test_random_runs_against_oracle(block):
                 B.run_case(B.Oracle(params), case)
             continue
         assert_same_run(o, h, so, sh, case)
+
+
+def test_saturation_at_the_chromosome_end_is_reported():
+    """The reference's int16 difference array has an entry at `len` as well: once 32,768 alignments
+    end there it silently skips further ones (Genrich.c:2565-2573).  That order-dependent behaviour is
+    not reproduced anywhere; like inside a chromosome, the input is refused with GX_ERR_OVERFLOW."""
+    lens = [50_000]
+    n = 33_000
+    st = np.random.default_rng(3).integers(49_000, 49_900, n).astype(np.uint32)
+    ev = np.zeros(n, dtype=B.EVENT_DTYPE)
+    ev["chrom"], ev["start"], ev["end"], ev["count"] = 0, st, 50_000, 1
+    h = hip_backend(B.make_params(pq=0.01))
+    h.set_chroms(lens)
+    h.sample_begin(0, None)
+    h.push_events(ev)
+    with pytest.raises(RuntimeError, match="int16"):
+        h.sample_end()
+    # one fewer than the limit is fine and matches the oracle (which has skipped nothing yet)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev[:32_767], ctrl=None)])
+    o, h2, so, sh = run_both(case, B.make_params(pq=0.01))
+    assert_same_run(o, h2, so, sh, case)
