@@ -437,10 +437,11 @@ def test_events_from_several_host_and_device_segments():
     assert h.n_peaks > 0
 
 
-def _random_case(seed):
+def _random_case(seed, scale=1):
+    """scale > 1: the same mix on chromosomes / samples `scale` times larger (tools/fuzz_hip_vs_oracle.py)"""
     rng = np.random.default_rng(seed)
     nch = int(rng.integers(1, 6))
-    lens = [int(x) for x in rng.integers(500, 120_000, nch)]
+    lens = [int(x) for x in rng.integers(500 * scale, 120_000 * scale, nch)]
     skip = [bool(rng.random() < 0.15) for _ in lens]
     if all(skip):
         skip[0] = False
@@ -450,7 +451,7 @@ def _random_case(seed):
         if not sk and rng.random() < 0.3:
             for _ in range(int(rng.integers(1, 4))):
                 s = int(rng.integers(0, max(1, L - 5)))
-                regs.append((s, min(L, s + int(rng.integers(1, 3000)))))
+                regs.append((s, min(L, s + int(rng.integers(1, 3000 * scale)))))
         regs.sort()
         merged = []
         for s, e in regs:  # merged, clipped, as saveXBed leaves them (Genrich.c:1144-1206)
@@ -461,13 +462,13 @@ def _random_case(seed):
         beds.append([v for r in merged for v in r])
     reps = []
     for r in range(int(rng.choice([1, 1, 2, 3]))):
-        n = int(rng.integers(200, 6000))
+        n = int(rng.integers(200 * scale, 6000 * scale))
         tr = synth.make_fragments(lens, n, seed=seed * 7 + r, frac_peak=0.4, frac_tower=0.2)
         if rng.random() < 0.3:
             tr = synth.add_multimap(tr, lens, 0.25, seed=seed + 11)
         ct = None
         if rng.random() < 0.5:
-            ct = synth.make_fragments(lens, int(rng.integers(200, 6000)), seed=seed * 7 + 3 + r, uniform_only=True)
+            ct = synth.make_fragments(lens, int(rng.integers(200 * scale, 6000 * scale)), seed=seed * 7 + 3 + r, uniform_only=True)
         reps.append(dict(save=None, treat=tr, ctrl=ct))
     qval = bool(rng.random() < 0.5)
     params = B.make_params(pq=float(rng.choice([0.3, 0.1, 0.05])) if qval else float(rng.choice([0.05, 0.01, 0.001])),

@@ -3,6 +3,8 @@ usage: fuzz_hip_vs_oracle.py SEED0 SEED1 [--mid]
 
 default: the generator of tests/test_hip_parity.py::test_random_runs_against_oracle (small runs)
 --mid:   1-4 chromosomes of 0.2-6 Mbases, 0.1-0.9 M fragments (deep towers, multimapping, control)
+--x50:   the default generator (skipped chromosomes, -E regions, replicates, -p / -q, -a / -l / -g) with
+         chromosomes and samples 50 times larger
 
 An input the library refuses for int16 saturation (the reference's skips there
 depend on the order of the alignments and are not reproduced) is counted separately, not compared."""
@@ -38,7 +40,7 @@ def mid_case(seed):
 mid = "--mid" in sys.argv
 bad = refused = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
-    case, params = mid_case(seed) if mid else T._random_case(seed)
+    case, params = mid_case(seed) if mid else T._random_case(seed, 50 if "--x50" in sys.argv else 1)
     try:
         o, h, so, sh = T.run_both(case, params)
         T.assert_same_run(o, h, so, sh, case)
