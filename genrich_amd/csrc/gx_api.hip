@@ -141,7 +141,7 @@ struct gx_ctx {
   };
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3];
-  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen;
+  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, nWide, wideList;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};  // host copy of the device scalars (refreshed from the mail block)
@@ -165,7 +165,7 @@ struct gx_ctx {
   gx_allreduce_i64_fn allreduce = nullptr;
   gx_allgather_tab_fn allgather = nullptr;
   void* user = nullptr;
-  int numCU = 0, resTile = 0, resSweep = 0;  // co-resident workgroups per kernel class
+  int numCU = 0, resTile = 0, resTileHalf = 0, resSweep = 0;  // co-resident workgroups per kernel class
   // recycled device buffers (gx_reset keeps allocations alive across runs)
   std::vector<DevBuf> pool;
   // timing
@@ -356,11 +356,16 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     const size_t tileBytes = ((size_t)(nTiles + 1) * 4 + 255) & ~(size_t)255;
     const size_t histBytes = (size_t)NXCD * MAX_BINS * 4;
     const size_t ffBytes = (sizeof(FragFix) + 255) & ~(size_t)255;
-    const size_t total = ffBytes + 3 * histBytes + 5 * tileBytes;
+    const size_t endBytes = ((size_t)(nChrom + 1) * 4 + 255) & ~(size_t)255;
+    const size_t total = ffBytes + 256 + endBytes + 3 * histBytes + 5 * tileBytes;
     HIPCHECK(ctx->zeroArena.ensure(total));
     char* base = ctx->zeroArena.as<char>();
     ctx->fragSum.view(base, ffBytes);
     base += ffBytes;
+    ctx->nWide.view(base, 256);
+    base += 256;
+    ctx->endAtLen.view(base, endBytes);
+    base += endBytes;
     for (int q = 0; q < 3; q++, base += histBytes) ctx->str[q].sbHist.view(base, histBytes);
     for (int q = 0; q < 3; q++, base += tileBytes) ctx->tileCnt[q].view(base, tileBytes);
     ctx->tileWsum.view(base, tileBytes);
@@ -389,8 +394,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
   static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
   HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
-  HIPCHECK(ctx->endAtLen.ensure((size_t)(nChrom + 1) * 4));
-  HIPCHECK(hipMemsetAsync(ctx->endAtLen.p, 0, (size_t)(nChrom + 1) * 4, s));
   FragFix* ff = ctx->fragSum.as<FragFix>();
   u32* slowFrag = &ff->slow;
   if (ctx->hasBed || !unit32 || forceSlowFrag) HIPCHECK(hipMemsetAsync(slowFrag, 1, 4, s));
@@ -457,23 +460,33 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;  // zero since gx_sample_begin(treatment)
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(),
              ctx->tileDeep.as<u32>()};
-  const size_t ldsBytes = (size_t)TL_LDS * 4;
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
   HIPCHECK(ctx->tileMeta.ensure((size_t)(nTiles + 1) * sizeof(TileMeta)));
+  HIPCHECK(ctx->wideList.ensure((size_t)(nTiles + 1) * 4));
   hipLaunchKernelGGL(k_tile_meta, dim3((nTiles + 255) / 256), dim3(256), 0, s, ctx->tileOff[0].as<u32>(),
                      ctx->tileOff[1].as<u32>(), ctx->tileOff[2].as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
                      ctx->dChrom.as<DChrom>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, nTiles,
-                     ctx->tileMeta.as<TileMeta>());
+                     ctx->tileMeta.as<TileMeta>(), ctx->wideList.as<u32>(), ctx->nWide.as<u32>());
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");  // k_tile alone: the dominant kernel (bench.py's roofline)
   TileIn tin{SS.a.as<uint16_t>(), SE.a.as<uint16_t>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
-  if (ctx->hasBed)
-    hipLaunchKernelGGL(k_tile<true>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin, nTiles,
-                       bin, to, ctx->dStatus.as<u32>());
-  else
-    hipLaunchKernelGGL(k_tile<false>, dim3(std::min<u32>(nTiles, (u32)ctx->resTile)), dim3(TL_NT), ldsBytes, s, tin, nTiles,
-                       bin, to, ctx->dStatus.as<u32>());
+  // narrow tiles with 16-bit LDS counters (twice the tiles in flight), then the wide ones from their list
+  // (whose length stays on the device: an empty list costs one idle launch)
+  const u32* wl = ctx->wideList.as<u32>();
+  const u32* nw = ctx->nWide.as<u32>();
+  const dim3 gHalf(std::min<u32>(nTiles, (u32)ctx->resTileHalf)), gWide(std::min<u32>(nTiles, (u32)ctx->resTile));
+  if (ctx->hasBed) {
+    hipLaunchKernelGGL((k_tile<true, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
+                       ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL((k_tile<true, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
+                       ctx->dStatus.as<u32>());
+  } else {
+    hipLaunchKernelGGL((k_tile<false, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
+                       ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL((k_tile<false, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
+                       ctx->dStatus.as<u32>());
+  }
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   phase_end(ctx);
 
@@ -683,18 +696,21 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   HIPCHECK(hipMemsetAsync(ctx->misc.p, 0, M_WORDS * 4, ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dScal.p, 0, sizeof(Scalars), ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
-  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               TL_LDS * 4));
-  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               TL_LDS * 4));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<true, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS * 4));
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<false, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS * 4));
   {
     // persistent kernels: the grid must not exceed what is co-resident (look-back forward progress)
     hipDeviceProp_t prop;
     HIPCHECK(hipGetDeviceProperties(&prop, ctx->device));
     ctx->numCU = prop.multiProcessorCount;
     int nb = 0;
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true>, TL_NT, TL_LDS * 4));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true, false>, TL_NT, TL_LDS * 4));
     ctx->resTile = std::max(1, nb) * ctx->numCU;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true, true>, TL_NT, TL_LDS_HALF * 4));
+    ctx->resTileHalf = std::max(1, nb) * ctx->numCU;
+    if (getenv("GX_DEBUG")) fprintf(stderr, "k_tile workgroups: half %d, wide %d\n", ctx->resTileHalf, ctx->resTile);
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scan_iv, STL_NT, 0));
     ctx->resSweep = std::max(1, std::min(nb, 4)) * ctx->numCU;
   }

@@ -769,6 +769,14 @@ constexpr int TL_NW = TL_NT / 64;
 constexpr int TL_REG = GX_TL_REG;                 // touched bases per thread held in registers
 constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
 constexpr int TL_LDS = TILE + 64 + 2 * (TILE / 32); // ints: slice, scan scratch, occupancy + -E edge bitmaps
+// k_tile<.., HALF = true> packs the differences of two neighbouring bases into one LDS word as 16-bit
+// counts of unit-weight records (word = 65536 * odd base + even base as one integer sum, so borrows
+// between the halves undo themselves on decoding): half the LDS per tile = twice the tiles in
+// flight on a CU, which is what bounds this kernel.  Tiles that could overflow a half (>= 32767
+// records in a stream) or that hold fractional records are "wide" and go through the 32-bit variant.
+constexpr int TL_LDS_HALF = TILE / 2 + 64 + 2 * (TILE / 32);
+constexpr u32 TL_HALF_MAX = 32767;                // records per stream at which a tile turns wide
+constexpr u32 TM_ACTIVE = 1u, TM_LAST = 2u, TM_WIDE = 4u;  // TileMeta::flags
 constexpr int FRAG_FAST_MAXV = ((1 << 24) / (2 * TILE)) * GX_UNIT;  // len < 2 TILE and V below this: len * val < 2^24
 constexpr int V_MARK = (int)0x80000000;           // "pileup" of an interval inside an excluded (-E) region
 
@@ -827,8 +835,13 @@ __global__ __launch_bounds__(256) void k_tile_meta(const u32* __restrict__ offS,
                                                    const u32* __restrict__ offF, const int* __restrict__ prefW,
                                                    const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
                                                    const u32* __restrict__ bedTileOff, u32 nTiles,
-                                                   TileMeta* __restrict__ meta) {
-  for (u32 t = blockIdx.x * 256 + threadIdx.x; t < nTiles; t += gridDim.x * 256) {
+                                                   TileMeta* __restrict__ meta, u32* __restrict__ wideList,
+                                                   u32* __restrict__ nWide) {
+  // (the grid covers the tiles exactly once: every wavefront reaches the ballot below together)
+  for (u32 t0 = blockIdx.x * 256; t0 < nTiles; t0 += gridDim.x * 256) {
+    const u32 t = t0 + threadIdx.x;
+    bool wide = false;
+    if (t < nTiles) {
     const u32 ci = tileChrom[t];
     const DChrom c = chroms[ci];
     TileMeta m;
@@ -840,14 +853,34 @@ __global__ __launch_bounds__(256) void k_tile_meta(const u32* __restrict__ offS,
     const u32 tl = t - c.tileBase;
     m.pos0 = tl << TB;
     m.len = c.len;
-    m.flags = (chrom_active(c) ? 1u : 0u) | (tl + 1 == c.nTiles ? 2u : 0u);
+    wide = m.nF != 0 || m.nS >= TL_HALF_MAX || m.nE >= TL_HALF_MAX;
+    m.flags = (chrom_active(c) ? TM_ACTIVE : 0u) | (tl + 1 == c.nTiles ? TM_LAST : 0u) | (wide ? TM_WIDE : 0u);
     m.slot = m.sb + m.eb + m.fb + t + (bedTileOff ? bedTileOff[t] : 0u);  // <= records + edges + 1 intervals per tile
     meta[t] = m;
+    }
+    // the wide tiles, as a list for k_tile<.., false> (one reservation per wavefront, ascending inside it)
+    const u64 wm = __ballot(wide);
+    if (wm) {
+      u32 base = 0;
+      if (lane_id() == 0) base = atomicAdd(nWide, (u32)__popcll(wm));
+      base = __shfl(base, 0, 64);
+      if (wide) wideList[base + __popcll(wm & ((1ull << lane_id()) - 1ull))] = t;
+    }
   }
 }
 
-template <bool BED>
-__global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn bed, TileOut out,
+template <bool HALF>
+__device__ __forceinline__ int tile_diff(const int* delta, int base) {  // difference at a base of the tile, 1/120 units
+  if constexpr (!HALF) return delta[base];
+  const int w = delta[base >> 1];
+  const int lo = (int)(short)w;
+  return ((base & 1) ? (w - lo) >> 16 : lo) * GX_UNIT;
+}
+
+// HALF: all tiles except the wide ones.  !HALF: the tiles of wideList (nItems = *nWide).
+template <bool BED, bool HALF>
+__global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const u32* __restrict__ wideList,
+                                                   const u32* __restrict__ nWide, BedIn bed, TileOut out,
                                                    u32* __restrict__ st) {
   // LDS: the tile's slice of the difference array (one int per base) plus an occupancy bitmap
   // (one bit per base).  Only bases that received a record are ever read back or cleared, so a
@@ -855,13 +888,14 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
   // of a tile are touched.  The slice is all-zero whenever a tile starts (each tile clears what it
   // touched).
   extern __shared__ __attribute__((aligned(16))) int lds[];
-  int* delta = lds;                            // TILE ints
-  int* scr = lds + TILE;                       // [0..8] sums, [16..24] counts, [32..40] edge counts
+  constexpr int SLICE = HALF ? TILE / 2 : TILE;
+  int* delta = lds;                            // SLICE ints
+  int* scr = lds + SLICE;                      // [0..8] sums, [16..24] counts, [32..40] edge counts
   u32* occ = reinterpret_cast<u32*>(scr + 64); // TILE/32 words: word i = bases of thread i
   u32* eb = occ + TILE / 32;                   // -E edge bitmap, same shape
   const int wv = threadIdx.x >> 6;
   u32 bad = 0;
-  for (int i = threadIdx.x * 4; i < TILE; i += TL_NT * 4)
+  for (int i = threadIdx.x * 4; i < SLICE; i += TL_NT * 4)
     *reinterpret_cast<int4*>(delta + i) = make_int4(0, 0, 0, 0);
   occ[threadIdx.x] = 0;
   eb[threadIdx.x] = 0;
@@ -874,61 +908,64 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
   // (workgroups are dealt to the XCDs round-robin), so that the cache lines two tiles share are
   // completed inside one L2
   const u32 lb = xcd_local_block(blockIdx.x, G);
-  TileMeta m1 = lb < nTiles ? in.meta[lb] : TileMeta{};
-  TileMeta m2 = lb + G < nTiles ? in.meta[lb + G] : TileMeta{};
-  TileMeta m3 = lb + 2 * G < nTiles ? in.meta[lb + 2 * G] : TileMeta{};
-  u32 ks1 = threadIdx.x < m1.nS ? in.S[m1.sb + threadIdx.x] : 0u;
-  u32 ke1 = threadIdx.x < m1.nE ? in.E[m1.eb + threadIdx.x] : 0u;
-  u32 ks2 = threadIdx.x < m2.nS ? in.S[m2.sb + threadIdx.x] : 0u;
-  u32 ke2 = threadIdx.x < m2.nE ? in.E[m2.eb + threadIdx.x] : 0u;
-  for (u32 t = lb; t < nTiles; t += G) {
+  const u32 nItems = HALF ? nTiles : *nWide;
+  auto tileAt = [&](u32 i) -> u32 { return i < nItems ? (HALF ? i : wideList[i]) : 0u; };
+  // (a wide tile's keys are not for the HALF kernel: it skips the tile)
+  auto keyOf = [&](const uint16_t* K, u32 kb, u32 nk, u32 flags) -> u32 {
+    return threadIdx.x < nk && !(HALF && (flags & TM_WIDE)) ? K[kb + threadIdx.x] : 0u;
+  };
+  u32 t1 = tileAt(lb), t2 = tileAt(lb + G), t3 = tileAt(lb + 2 * G), t4 = tileAt(lb + 3 * G);
+  TileMeta m1 = lb < nItems ? in.meta[t1] : TileMeta{};
+  TileMeta m2 = lb + G < nItems ? in.meta[t2] : TileMeta{};
+  TileMeta m3 = lb + 2 * G < nItems ? in.meta[t3] : TileMeta{};
+  u32 ks1 = keyOf(in.S, m1.sb, m1.nS, m1.flags), ke1 = keyOf(in.E, m1.eb, m1.nE, m1.flags);
+  u32 ks2 = keyOf(in.S, m2.sb, m2.nS, m2.flags), ke2 = keyOf(in.E, m2.eb, m2.nE, m2.flags);
+  for (u32 i = lb; i < nItems; i += G) {
     // (a tile takes about a microsecond, an HBM round trip several: keys two tiles ahead,
-    // descriptors three)
+    // descriptors three, the list of wide tiles four)
+    const u32 t = t1;
     const TileMeta m = m1;
     const u32 ks0 = ks1, ke0 = ke1;
+    t1 = t2;
+    t2 = t3;
+    t3 = t4;
+    t4 = tileAt(i + 4 * G);
     m1 = m2;
     ks1 = ks2;
     ke1 = ke2;
     m2 = m3;
-    if (t + 3 * G < nTiles) m3 = in.meta[t + 3 * G];
-    if (t + 2 * G < nTiles) {
-      ks2 = threadIdx.x < m2.nS ? in.S[m2.sb + threadIdx.x] : 0u;
-      ke2 = threadIdx.x < m2.nE ? in.E[m2.eb + threadIdx.x] : 0u;
+    if (i + 3 * G < nItems) m3 = in.meta[t3];
+    if (i + 2 * G < nItems) {
+      ks2 = keyOf(in.S, m2.sb, m2.nS, m2.flags);
+      ke2 = keyOf(in.E, m2.eb, m2.nE, m2.flags);
     }
-    const bool active = m.flags & 1u;
+    if (HALF && (m.flags & TM_WIDE)) continue;  // block-uniform
+    const bool active = m.flags & TM_ACTIVE;
     const u32 pos0 = m.pos0;
-    const bool lastTile = (m.flags & 2u) != 0;
+    const bool lastTile = (m.flags & TM_LAST) != 0;
     const u32 sb = m.sb, se = m.sb + m.nS, eb0 = m.eb, ee = m.eb + m.nE, fb = m.fb, fe = m.fb + m.nF;
     const int carry = m.carry;
     // (occ / eb words are zero here: each thread clears its word as soon as it has read it)
     // accumulate this tile's endpoints: +1 per start, -1 per end (unit weight = 120), then the
     // fractional records with their own signed weight
-    if (threadIdx.x < m.nS) {
-      u32 off = ks0;
-      atomicAdd(&delta[off], GX_UNIT);
+    auto add = [&](u32 off, int sign) {
+      if constexpr (HALF)
+        atomicAdd(&delta[off >> 1], (off & 1) ? sign * 65536 : sign);
+      else
+        atomicAdd(&delta[off], sign * GX_UNIT);
       atomicOr(&occ[off >> 5], 1u << (off & 31));
-    }
-    if (threadIdx.x < m.nE) {
-      u32 off = ke0;
-      atomicAdd(&delta[off], -GX_UNIT);
-      atomicOr(&occ[off >> 5], 1u << (off & 31));
-    }
-    for (u32 i = sb + TL_NT + threadIdx.x; i < se; i += TL_NT) {
-      u32 off = in.S[i];
-      atomicAdd(&delta[off], GX_UNIT);
-      atomicOr(&occ[off >> 5], 1u << (off & 31));
-    }
-    for (u32 i = eb0 + TL_NT + threadIdx.x; i < ee; i += TL_NT) {
-      u32 off = in.E[i];
-      atomicAdd(&delta[off], -GX_UNIT);
-      atomicOr(&occ[off >> 5], 1u << (off & 31));
-    }
-    for (u32 i = fb + threadIdx.x; i < fe; i += TL_NT) {
-      u64 r = in.F[i];
-      u32 off = (u32)(r >> 8) & (TILE - 1);
-      atomicAdd(&delta[off], (int)(int8_t)(r & 0xFF));
-      atomicOr(&occ[off >> 5], 1u << (off & 31));
-    }
+    };
+    if (threadIdx.x < m.nS) add(ks0, 1);
+    if (threadIdx.x < m.nE) add(ke0, -1);
+    for (u32 i = sb + TL_NT + threadIdx.x; i < se; i += TL_NT) add(in.S[i], 1);
+    for (u32 i = eb0 + TL_NT + threadIdx.x; i < ee; i += TL_NT) add(in.E[i], -1);
+    if constexpr (!HALF)
+      for (u32 i = fb + threadIdx.x; i < fe; i += TL_NT) {
+        u64 r = in.F[i];
+        u32 off = (u32)(r >> 8) & (TILE - 1);
+        atomicAdd(&delta[off], (int)(int8_t)(r & 0xFF));
+        atomicOr(&occ[off >> 5], 1u << (off & 31));
+      }
     if (BED)
       for (u32 i = bed.bedTileOff[t] + threadIdx.x; i < bed.bedTileOff[t + 1]; i += TL_NT) {
         u32 off = bed.bedEdge[i];
@@ -964,7 +1001,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
 #pragma unroll
     for (int j = 0; j < TL_REG; j++) {
       kk[j] = mrest ? __builtin_ctz(mrest) : -1;
-      dk[j] = mrest ? delta[lbase + kk[j]] : 0;
+      dk[j] = mrest ? tile_diff<HALF>(delta, lbase + kk[j]) : 0;
       mrest &= mrest - 1;
     }
 #define GX_P1_STEP(K, D)                                                        \
@@ -985,7 +1022,8 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
         sum += d;
         cnt += (u32)(d != 0);
         sat |= (u32)(d >= 32767 * GX_UNIT) | (u32)(d <= -32768 * GX_UNIT);
-        if (d != 0) delta[lbase + kk[j]] = 0;
+        if constexpr (!HALF)
+          if (d != 0) delta[lbase + kk[j]] = 0;
       }
       if (pos0 + lbase == 0 && kk[0] == 0 && dk[0] != 0) cnt -= 1;
     } else {
@@ -993,12 +1031,13 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
       for (int j = 0; j < TL_REG; j++)
         if (kk[j] >= 0) {
           GX_P1_STEP(kk[j], dk[j]);
-          if (dk[j] != 0) delta[lbase + kk[j]] = 0;
+          if constexpr (!HALF)
+            if (dk[j] != 0) delta[lbase + kk[j]] = 0;
         }
     }
     for (u32 m = mrest; m; m &= m - 1) {
       const int k = __builtin_ctz(m);
-      const int d = delta[lbase + k];
+      const int d = tile_diff<HALF>(delta, lbase + k);
       GX_P1_STEP(k, d);
     }
 #undef GX_P1_STEP
@@ -1062,11 +1101,20 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, BedIn 
     }
     for (u32 m = mrest; m; m &= m - 1) {
       const int k = __builtin_ctz(m);
-      const int d = delta[lbase + k];
+      const int d = tile_diff<HALF>(delta, lbase + k);
       GX_P2_STEP(k, d);
-      if (d != 0) delta[lbase + k] = 0;
+      if constexpr (HALF) {  // a word is cleared by the last touched base it holds
+        if ((k & 1) || !((m >> (k + 1)) & 1u)) delta[(lbase + k) >> 1] = 0;
+      } else if (d != 0) {
+        delta[lbase + k] = 0;
+      }
     }
 #undef GX_P2_STEP
+    if constexpr (HALF) {  // (only now: a base of the loop above may share its word with a register-held one)
+#pragma unroll
+      for (int j = 0; j < TL_REG; j++)
+        if (dk[j] != 0) delta[(lbase + kk[j]) >> 1] = 0;
+    }
     if (active) {  // block-uniform
       if (lastTile && threadIdx.x == TL_NT - 1) {  // closing interval [.., len)
         out.looseEnd[o] = m.len;
