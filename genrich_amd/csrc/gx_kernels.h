@@ -877,7 +877,7 @@ __device__ __forceinline__ int tile_diff(const int* delta, int base) {  // diffe
   return ((base & 1) ? (w - lo) >> 16 : lo) * GX_UNIT;
 }
 
-// HALF: all tiles except the wide ones.  !HALF: the tiles of wideList (nItems = *nWide).
+// HALF: all tiles except the wide ones.  !HALF: the tiles of wideList (*nWide of them).
 template <bool BED, bool HALF>
 __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const u32* __restrict__ wideList,
                                                    const u32* __restrict__ nWide, BedIn bed, TileOut out,
@@ -900,46 +900,91 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
   occ[threadIdx.x] = 0;
   eb[threadIdx.x] = 0;
   __syncthreads();
-  // software pipeline over this workgroup's tiles: descriptors are loaded two tiles ahead and the
-  // first TL_NT start / end keys of the next tile one tile ahead, so their HBM/L2 latency overlaps
-  // the current tile instead of stalling every wave at the top of each iteration
+  // Software pipeline over this workgroup's tiles.  On this hardware loads and stores share one
+  // in-order counter (vmcnt), and a wait that follows a data-dependent number of stores can only be
+  // "everything": a prefetch consumed after a tile's stores makes every tile wait for its own stores
+  // to be acknowledged (measured: the kernel ran at the speed of that round trip).  So all
+  // prefetches are issued right after a tile's stores (`issue`) and collected right before the
+  // next tile's stores (`collect`): whatever is waited for is at least most of a tile old.
+  //   top of tile j:  M(j), K(j), M(j+1) in registers;  K(j+1), M(j+2) [, list(j+4)] in flight
+  //   collect (j):    K(j+1), M(j+2) arrived
+  //   issue (j):      K(j+2) (needs M(j+2)), M(j+3) [, list(j+5)]
+  // (M = descriptor, K = the first TL_NT start / end keys, list = entry of wideList.)
   const u32 G = gridDim.x;
   // neighbouring tiles write neighbouring loose slots: give them to workgroups of the same XCD
   // (workgroups are dealt to the XCDs round-robin), so that the cache lines two tiles share are
   // completed inside one L2
   const u32 lb = xcd_local_block(blockIdx.x, G);
-  const u32 nItems = HALF ? nTiles : *nWide;
-  auto tileAt = [&](u32 i) -> u32 { return i < nItems ? (HALF ? i : wideList[i]) : 0u; };
+  // When most tiles are wide (multimapped reads everywhere) the 32-bit kernel takes all of them and
+  // this one none.
+  const u32 nW = *nWide;
+  const bool allWide = nW > nTiles / 2;
+  if (HALF && allWide) return;
+  const u32 nItems = HALF || allWide ? nTiles : nW;
+  struct Raw { uint4 a, b, c; };
+  auto tileAt = [&](u32 i) -> u32 { return i < nItems ? (HALF || allWide ? i : wideList[i]) : 0u; };
+  // (unconditional: past the end tileAt gives tile 0, whose descriptor is loaded and then ignored.  A
+  // conditional load would be followed by register copies, i.e. by a wait for it)
+  auto loadMeta = [&](u32 tile) -> Raw {
+    const uint4* q = reinterpret_cast<const uint4*>(in.meta + tile);
+    return Raw{q[0], q[1], q[2]};
+  };
+  auto uni = [](u32 v) -> u32 { return (u32)__builtin_amdgcn_readfirstlane((int)v); };
+  auto cook = [&](const Raw& r, u32 i) -> TileMeta {  // (the whole workgroup loaded the same descriptor)
+    TileMeta m;
+    m.sb = uni(r.a.x); m.eb = uni(r.a.y); m.fb = uni(r.a.z); m.nS = uni(r.a.w);
+    m.nE = uni(r.b.x); m.nF = uni(r.b.y); m.carry = (int)uni(r.b.z); m.ci = uni(r.b.w);
+    m.pos0 = uni(r.c.x); m.len = uni(r.c.y); m.flags = uni(r.c.z); m.slot = uni(r.c.w);
+    if (i >= nItems) { m.nS = 0; m.nE = 0; m.nF = 0; m.flags = 0; }
+    return m;
+  };
   // (a wide tile's keys are not for the HALF kernel: it skips the tile)
   auto keyOf = [&](const uint16_t* K, u32 kb, u32 nk, u32 flags) -> u32 {
     return threadIdx.x < nk && !(HALF && (flags & TM_WIDE)) ? K[kb + threadIdx.x] : 0u;
   };
-  u32 t1 = tileAt(lb), t2 = tileAt(lb + G), t3 = tileAt(lb + 2 * G), t4 = tileAt(lb + 3 * G);
-  TileMeta m1 = lb < nItems ? in.meta[t1] : TileMeta{};
-  TileMeta m2 = lb + G < nItems ? in.meta[t2] : TileMeta{};
-  TileMeta m3 = lb + 2 * G < nItems ? in.meta[t3] : TileMeta{};
-  u32 ks1 = keyOf(in.S, m1.sb, m1.nS, m1.flags), ke1 = keyOf(in.E, m1.eb, m1.nE, m1.flags);
-  u32 ks2 = keyOf(in.S, m2.sb, m2.nS, m2.flags), ke2 = keyOf(in.E, m2.eb, m2.nE, m2.flags);
+  u32 tC = tileAt(lb), tN = tileAt(lb + G), tF = tileAt(lb + 2 * G), tQ = tileAt(lb + 3 * G), tL = tileAt(lb + 4 * G);
+  u32 tR = 0;
+  TileMeta mC = cook(loadMeta(tC), lb), mN = cook(loadMeta(tN), lb + G), mR{};
+  u32 ksC = keyOf(in.S, mC.sb, mC.nS, mC.flags), keC = keyOf(in.E, mC.eb, mC.nE, mC.flags), ksN = 0, keN = 0;
+  // (arrived before the loop: a register that is pending on the way in gets a wait at its use inside the
+  // loop, which at run time would wait for whatever is in flight in every iteration)
+  asm volatile("" : "+v"(ksC), "+v"(keC), "+v"(tF), "+v"(tQ) :: "memory");
+  u32 ksL = keyOf(in.S, mN.sb, mN.nS, mN.flags), keL = keyOf(in.E, mN.eb, mN.nE, mN.flags);  // in flight
+  Raw rF = loadMeta(tF);                                                                      // in flight
   for (u32 i = lb; i < nItems; i += G) {
-    // (a tile takes about a microsecond, an HBM round trip several: keys two tiles ahead,
-    // descriptors three, the list of wide tiles four)
-    const u32 t = t1;
-    const TileMeta m = m1;
-    const u32 ks0 = ks1, ke0 = ke1;
-    t1 = t2;
-    t2 = t3;
-    t3 = t4;
-    t4 = tileAt(i + 4 * G);
-    m1 = m2;
-    ks1 = ks2;
-    ke1 = ke2;
-    m2 = m3;
-    if (i + 3 * G < nItems) m3 = in.meta[t3];
-    if (i + 2 * G < nItems) {
-      ks2 = keyOf(in.S, m2.sb, m2.nS, m2.flags);
-      ke2 = keyOf(in.E, m2.eb, m2.nE, m2.flags);
+    const u32 t = tC;
+    TileMeta m = mC;
+    if (HALF && (m.flags & TM_WIDE)) {
+      // not this kernel's tile: it passes as an empty, inactive one (one `collect` and one `issue` site
+      // keep the registers with loads in flight free of copies, which would be waits); its count of
+      // zero intervals is overwritten by the kernel that owns it
+      m.nS = 0; m.nE = 0; m.nF = 0; m.flags = 0;
     }
-    if (HALF && (m.flags & TM_WIDE)) continue;  // block-uniform
+    const u32 ks0 = ksC, ke0 = keC;
+    auto collect = [&]() {
+      // (the empty asm is the point where the loads in flight must have arrived, and nothing that
+      // touches memory moves across it)
+      asm volatile("" : "+v"(ksL), "+v"(keL), "+v"(rF.a.x), "+v"(rF.a.y), "+v"(rF.a.z), "+v"(rF.a.w), "+v"(rF.b.x),
+                        "+v"(rF.b.y), "+v"(rF.b.z), "+v"(rF.b.w), "+v"(rF.c.x), "+v"(rF.c.y), "+v"(rF.c.z), "+v"(rF.c.w),
+                        "+v"(tL) :: "memory");
+      ksN = ksL;
+      keN = keL;
+      mR = cook(rF, i + 2 * G);
+      tR = tF;
+    };
+    auto issue = [&]() {
+      // tile j+1 becomes the current one -- first, so that the registers of what has arrived are free
+      // again before the loads are issued (a load into another register would have to be copied at the
+      // loop's back edge: a wait)
+      mC = mN; tC = tN; ksC = ksN; keC = keN;
+      mN = mR; tN = tR;
+      ksL = keyOf(in.S, mN.sb, mN.nS, mN.flags);  // K(j+2)
+      keL = keyOf(in.E, mN.eb, mN.nE, mN.flags);
+      rF = loadMeta(tQ);                          // M(j+3)
+      tF = tQ;
+      tQ = tL;
+      tL = tileAt(i + 5 * G);
+    };
     const bool active = m.flags & TM_ACTIVE;
     const u32 pos0 = m.pos0;
     const bool lastTile = (m.flags & TM_LAST) != 0;
@@ -1056,6 +1101,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
       if (w < wv) { preS += ws; preC += wc; }
       totC += wc;
     }
+    collect();
     // pass 2: emit, and clear what was touched
     int run = carry + preS + (incS - sum);
     const u32 slot = m.slot;
@@ -1127,6 +1173,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
       if (big) atomicOr(&out.tileDeep[t], 1u);  // rare
     }
     if (threadIdx.x == 0) out.tileCount[t] = totFinal;
+    issue();
     __syncthreads();  // scr, occ and the slice are reused by the next tile
   }
   if (bad) atomicOr(st, bad);
