@@ -6,6 +6,8 @@
 // single-threaded parser consumes them in order.  Anything else (plain text, ordinary gzip, stdin)
 // goes through zlib's gz* layer exactly as the reference reads it (openRead 5125).
 #pragma once
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <condition_variable>
@@ -28,23 +30,51 @@ class Input {
   Input& operator=(const Input&) = delete;
   ~Input() { close(); }
 
-  // false: cannot open.  threads <= 1 or not a BGZF file: zlib's own reader
+  // false: cannot open (or empty).  threads <= 1 or not a BGZF file: zlib's own reader
   bool open(const char* path, int threads) {
     name_ = path;
-    if (strcmp(path, "-") && threads > 1) {
+    const bool isStdin = !strcmp(path, "-");
+    if (!isStdin) {
       f_ = fopen(path, "rb");
       if (!f_) return false;
-      if (looksLikeBgzf()) {
+      if (fgetc(f_) == EOF) {  // an empty file counts as one that cannot be opened (openRead 5145-5147)
+        fclose(f_);
+        f_ = nullptr;
+        return false;
+      }
+      rewind(f_);
+      if (threads > 1 && looksLikeBgzf()) {
+        mapFile();
         startWorkers(threads);
         return true;
       }
       fclose(f_);
       f_ = nullptr;
     }
-    gz_ = !strcmp(path, "-") ? gzdopen(fileno(stdin), "rb") : gzopen(path, "rb");
+    gz_ = isStdin ? gzdopen(fileno(stdin), "rb") : gzopen(path, "rb");
     if (!gz_) return false;
     gzbuffer(gz_, 1 << 20);
+    compressed_ = !gzdirect(gz_);
+    if (isStdin && !compressed_) {
+      int c = gzgetc(gz_);
+      if (c < 0) return false;
+      gzungetc(c, gz_);
+    }
     return true;
+  }
+
+  // the stream is gzip-compressed (the reference refuses that on stdin, openRead 5158-5160)
+  bool compressed() const { return compressed_ || f_ != nullptr; }
+
+  // Two-pass reading of a stream that cannot be reopened (stdin): everything handed out while
+  // recording is kept, and replay() puts it back in front of the stream.
+  void record() { recording_ = true; }
+  void replay() {
+    rec_.append(pre_, prePos_, std::string::npos);
+    pre_.swap(rec_);
+    rec_.clear();
+    prePos_ = 0;
+    recording_ = false;
   }
 
   const std::string& name() const { return name_; }
@@ -53,30 +83,76 @@ class Input {
 
   // up to n bytes; fewer only at the end of the stream (or on error: error() is then non-empty)
   size_t read(void* dst, size_t n) {
+    uint8_t* d = static_cast<uint8_t*>(dst);
+    size_t got = 0;
+    if (prePos_ < pre_.size()) {
+      got = std::min(n, pre_.size() - prePos_);
+      memcpy(d, pre_.data() + prePos_, got);
+      prePos_ += got;
+    }
+    if (got < n) got += readStream(d + got, n - got);
+    if (recording_) rec_.append(reinterpret_cast<const char*>(d), got);
+    return got;
+  }
+
+  // like gzgets: at most size-1 characters, through the first newline; nullptr at the end
+  char* gets(char* buf, int size) {
+    if (size <= 1) return nullptr;
+    int got = 0;
+    bool done = false;
+    if (prePos_ < pre_.size()) {
+      const char* p = pre_.data() + prePos_;
+      size_t avail = std::min(pre_.size() - prePos_, (size_t)(size - 1));
+      const void* nl = memchr(p, '\n', avail);
+      size_t k = nl ? (size_t)(static_cast<const char*>(nl) - p) + 1 : avail;
+      memcpy(buf, p, k);
+      prePos_ += k;
+      got = (int)k;
+      buf[got] = '\0';
+      done = nl || got == size - 1;
+    }
+    if (!done && !getsStream(buf + got, size - got) && !got) return nullptr;
+    if (recording_) rec_.append(buf);
+    return buf;
+  }
+
+  bool skip(size_t n) {
+    if (recording_ || prePos_ < pre_.size()) {
+      uint8_t tmp[4096];
+      while (n) {
+        size_t k = std::min(n, sizeof tmp);
+        if (read(tmp, k) != k) return false;
+        n -= k;
+      }
+      return true;
+    }
+    return skipStream(n);
+  }
+
+ private:
+  size_t readStream(uint8_t* d, size_t n) {
     if (gz_) {
-      int k = gzread(gz_, dst, (unsigned)n);
+      int k = gzread(gz_, d, (unsigned)n);
       return k < 0 ? 0 : (size_t)k;
     }
     size_t got = 0;
-    uint8_t* d = static_cast<uint8_t*>(dst);
     while (got < n) {
       if (!ensure()) break;
       size_t k = std::min(n - got, cur_->outLen - pos_);
-      memcpy(d + got, cur_->out.data() + pos_, k);
+      memcpy(d + got, cur_->out.get() + pos_, k);
       pos_ += k;
       got += k;
     }
     return got;
   }
 
-  // like gzgets: at most size-1 characters, through the first newline; nullptr at the end
-  char* gets(char* buf, int size) {
+  char* getsStream(char* buf, int size) {
     if (gz_) return gzgets(gz_, buf, size);
     if (size <= 1) return nullptr;
     int got = 0;
     while (got < size - 1) {
       if (!ensure()) break;
-      const uint8_t* p = cur_->out.data() + pos_;
+      const uint8_t* p = cur_->out.get() + pos_;
       size_t avail = std::min<size_t>(cur_->outLen - pos_, (size_t)(size - 1 - got));
       const void* nl = memchr(p, '\n', avail);
       size_t k = nl ? (size_t)(static_cast<const uint8_t*>(nl) - p) + 1 : avail;
@@ -90,7 +166,7 @@ class Input {
     return buf;
   }
 
-  bool skip(size_t n) {
+  bool skipStream(size_t n) {
     if (gz_) return gzseek(gz_, (z_off_t)n, SEEK_CUR) != -1;
     while (n) {
       if (!ensure()) return false;
@@ -100,6 +176,16 @@ class Input {
     }
     return true;
   }
+
+ public:
+  // Zero-copy access for record-structured input: a pointer to the next n bytes when they lie inside
+  // the current inflated block (nullptr otherwise, or when zlib's gz* reader is in use: the caller then
+  // falls back to read()).  Valid until the bytes have been advance()d over and the next call is made.
+  const uint8_t* peek(size_t n) {
+    if (gz_ || prePos_ < pre_.size() || recording_ || !ensure()) return nullptr;
+    return cur_->outLen - pos_ >= n ? cur_->out.get() + pos_ : nullptr;
+  }
+  void advance(size_t n) { pos_ += n; }
 
   void close() {
     if (gz_) {
@@ -114,21 +200,38 @@ class Input {
       cvWork_.notify_all();
       for (auto& t : workers_) t.join();
       workers_.clear();
+      queue_.clear();
+      todo_.clear();
+      cur_.reset();
+      if (map_) munmap(const_cast<uint8_t*>(map_), mapLen_);
+      map_ = nullptr;
       fclose(f_);
       f_ = nullptr;
-      queue_.clear();
-      cur_.reset();
     }
   }
 
  private:
   struct Block {
-    std::vector<uint8_t> comp;  // deflate payload + crc32 + isize
-    std::vector<uint8_t> out;
+    const uint8_t* comp = nullptr;  // deflate payload + crc32 + isize: inside the mapping, or `own`
+    size_t compLen = 0;
+    std::unique_ptr<uint8_t[]> own;
+    std::unique_ptr<uint8_t[]> out;  // (plain new[]: no zero fill of 64 KiB per block)
     size_t outLen = 0;
     bool done = false;
     std::string err;
   };
+
+  // a regular file is mapped, so that the members go to the workers without a copy; anything that
+  // cannot be mapped is read with fread
+  void mapFile() {
+    struct stat st;
+    if (fstat(fileno(f_), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return;
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f_), 0);
+    if (m == MAP_FAILED) return;
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    map_ = static_cast<const uint8_t*>(m);
+    mapLen_ = (size_t)st.st_size;
+  }
 
   bool looksLikeBgzf() {
     uint8_t h[18];
@@ -143,15 +246,32 @@ class Input {
     for (int i = 0; i < threads; i++) workers_.emplace_back([this] { work(); });
   }
 
-  // read the next member from the file and hand it to the pool; false at the end of the file
+  // take the next member of the file and hand it to the pool; false at the end of the file
   bool enqueue() {
-    uint8_t h[12];
-    size_t k = fread(h, 1, 12, f_);
-    if (k == 0) return false;
-    if (k != 12 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail("not a BGZF block");
+    uint8_t hbuf[12];
+    const uint8_t* h;
+    if (map_) {
+      if (mapPos_ == mapLen_) return false;
+      if (mapLen_ - mapPos_ < 12) return fail("not a BGZF block");
+      h = map_ + mapPos_;
+    } else {
+      size_t k = fread(hbuf, 1, 12, f_);
+      if (k == 0) return false;
+      if (k != 12) return fail("not a BGZF block");
+      h = hbuf;
+    }
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail("not a BGZF block");
     const size_t xlen = h[10] | (h[11] << 8);
-    std::vector<uint8_t> extra(xlen);
-    if (fread(extra.data(), 1, xlen, f_) != xlen) return fail("truncated BGZF block");
+    std::vector<uint8_t> xbuf;
+    const uint8_t* extra;
+    if (map_) {
+      if (mapLen_ - mapPos_ - 12 < xlen) return fail("truncated BGZF block");
+      extra = h + 12;
+    } else {
+      xbuf.resize(xlen);
+      if (fread(xbuf.data(), 1, xlen, f_) != xlen) return fail("truncated BGZF block");
+      extra = xbuf.data();
+    }
     long bsize = -1;
     for (size_t o = 0; o + 4 <= xlen;) {
       const size_t slen = extra[o + 2] | (extra[o + 3] << 8);
@@ -160,8 +280,16 @@ class Input {
     }
     if (bsize < (long)(12 + xlen + 8)) return fail("BGZF block without a size field");
     auto b = std::make_shared<Block>();
-    b->comp.resize((size_t)bsize - 12 - xlen);
-    if (fread(b->comp.data(), 1, b->comp.size(), f_) != b->comp.size()) return fail("truncated BGZF block");
+    b->compLen = (size_t)bsize - 12 - xlen;
+    if (map_) {
+      if (mapLen_ - mapPos_ < (size_t)bsize) return fail("truncated BGZF block");
+      b->comp = h + 12 + xlen;
+      mapPos_ += (size_t)bsize;
+    } else {
+      b->own.reset(new uint8_t[b->compLen]);
+      if (fread(b->own.get(), 1, b->compLen, f_) != b->compLen) return fail("truncated BGZF block");
+      b->comp = b->own.get();
+    }
     {
       std::lock_guard<std::mutex> lk(m_);
       queue_.push_back(b);
@@ -222,29 +350,35 @@ class Input {
   }
 
   static void inflateBlock(Block& b) {
-    if (b.comp.size() < 8) { b.err = "truncated BGZF block"; return; }
-    const uint8_t* tail = b.comp.data() + b.comp.size() - 8;
+    if (b.compLen < 8) { b.err = "truncated BGZF block"; return; }
+    const uint8_t* tail = b.comp + b.compLen - 8;
     const uint32_t crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
     const uint32_t isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
     if (isize > 65536) { b.err = "BGZF block larger than 64 KiB"; return; }
-    b.out.resize(isize ? isize : 1);
+    b.out.reset(new uint8_t[isize ? isize : 1]);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) { b.err = "zlib initialisation failed"; return; }
-    zs.next_in = const_cast<Bytef*>(b.comp.data());
-    zs.avail_in = (uInt)(b.comp.size() - 8);
-    zs.next_out = b.out.data();
+    zs.next_in = const_cast<Bytef*>(b.comp);
+    zs.avail_in = (uInt)(b.compLen - 8);
+    zs.next_out = b.out.get();
     zs.avail_out = (uInt)isize;
     int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
     if (rc != Z_STREAM_END || zs.total_out != isize) { b.err = "corrupt BGZF block"; return; }
-    if (crc32(crc32(0L, Z_NULL, 0), b.out.data(), isize) != crc) { b.err = "BGZF checksum mismatch"; return; }
+    if (crc32(crc32(0L, Z_NULL, 0), b.out.get(), isize) != crc) { b.err = "BGZF checksum mismatch"; return; }
     b.outLen = isize;
+    b.own.reset();
   }
 
   std::string name_, err_;
+  std::string pre_, rec_;  // replay buffer (served first) and the recording that will become one
+  size_t prePos_ = 0;
+  bool recording_ = false, compressed_ = false;
   gzFile gz_ = nullptr;
   FILE* f_ = nullptr;
+  const uint8_t* map_ = nullptr;
+  size_t mapLen_ = 0, mapPos_ = 0;
   std::vector<std::thread> workers_;
   std::mutex m_;
   std::condition_variable cvWork_, cvDone_;

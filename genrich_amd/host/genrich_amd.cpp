@@ -14,6 +14,7 @@
 //
 // Extra long options:
 //   --threads N     threads that inflate BGZF (BAM, bgzip-ped SAM) input; default min(8, cores)
+//   (environment: GENRICH_HOST_PROF=1 prints the CPU time of the parsing thread after the last input)
 //   --events-only   parse and write the -b file without touching a GPU (diagnostics)
 #include <getopt.h>
 #include <zlib.h>
@@ -125,6 +126,7 @@ struct State {
   std::vector<BedRec> xbed;
   gx_ctx* gx = nullptr;
   bool tableFrozen = false;  // the device already holds the chromosome table
+  std::unique_ptr<gxhost::Input> stdinIn;  // '-' can be opened once: its header pre-scan is replayed to the real pass
   bool sampleOpen = false;   // gx_sample_begin done for the file being read
   std::vector<gx_event> buf;
   Out bed;
@@ -923,13 +925,33 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     idx[i] = saveChrom(S, nm.data(), (uint32_t)rdI32(g, true));
   }
   ReadSet rs;
-  std::vector<uint8_t> blk;
+  std::vector<uint8_t> copy;
   for (;;) {
-    int32_t bs = rdI32(g, false);
-    if (bs < 0) break;
-    if (bs < 32) die("", "Cannot parse BAM file");
-    blk.resize((size_t)bs);
-    if (!gzReadAll(g, blk.data(), (size_t)bs)) die("", "Cannot parse BAM file");
+    // a record that lies inside one inflated block is parsed where it is; one that straddles two
+    // blocks (or any record, with zlib's reader) is copied first
+    const uint8_t* blk;
+    size_t blkLen;
+    const uint8_t* p4 = g.peek(4);
+    const uint8_t* whole = nullptr;
+    if (p4) {
+      const int32_t bs = (int32_t)(p4[0] | (p4[1] << 8) | (p4[2] << 16) | ((uint32_t)p4[3] << 24));
+      if (bs < 32) die("", "Cannot parse BAM file");
+      whole = g.peek(4 + (size_t)bs);
+      if (whole) {
+        blk = whole + 4;
+        blkLen = (size_t)bs;
+        g.advance(4 + (size_t)bs);
+      }
+    }
+    if (!whole) {
+      int32_t bs = rdI32(g, false);
+      if (bs < 0) break;
+      if (bs < 32) die("", "Cannot parse BAM file");
+      copy.resize((size_t)bs);
+      if (!gzReadAll(g, copy.data(), (size_t)bs)) die("", "Cannot parse BAM file");
+      blk = copy.data();
+      blkLen = (size_t)bs;
+    }
     auto i32 = [&](size_t o) { return (int32_t)(blk[o] | (blk[o + 1] << 8) | (blk[o + 2] << 16) | ((uint32_t)blk[o + 3] << 24)); };
     auto u16 = [&](size_t o) { return (uint16_t)(blk[o] | (blk[o + 1] << 8)); };
     const int32_t refID = i32(0), pos = i32(4);
@@ -937,12 +959,12 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     const uint16_t n_cigar = u16(12), flag = u16(14);
     const int32_t l_seq = i32(16), next_pos = i32(24);
     size_t off = 32;
-    if (off + l_read_name > blk.size()) die("", "Cannot parse BAM file");
+    if (off + l_read_name > blkLen) die("", "Cannot parse BAM file");
     const char* qname = (const char*)&blk[off];
     off += l_read_name;
     const size_t cigOff = off;
     off += (size_t)n_cigar * 4 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
-    if (off > blk.size()) die("", "Cannot parse BAM file");
+    if (off > blkLen) die("", "Cannot parse BAM file");
     C.count++;
     if (flag & 0x4) { C.unmapped++; continue; }
     if (!strcmp(qname, "*") || refID < 0 || refID >= n_ref || pos < 0) die(qname, ": poorly formatted SAM/BAM record");
@@ -966,9 +988,9 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
       else if (length != len) die(qname, ": mismatch between sequence length and CIGAR");
     } else if (!length)
       die(qname, ": no sequence information (SEQ or CIGAR)");
-    float score = bamScore(blk.data() + off, blk.data() + blk.size());
+    float score = bamScore(blk + off, blk + blkLen);
     record(S, rs, C, qname, flag, idx[refID], (uint32_t)pos, mapq, length + offset, (uint32_t)next_pos, score,
-           (const char*)blk.data() + off - (size_t)l_seq, l_seq, 0);
+           (const char*)blk + off - (size_t)l_seq, l_seq, 0);
   }
   finishFile(S, rs, C);
   return C.count;
@@ -1030,10 +1052,24 @@ void logCounts(const State& S, const Counts& C, bool bam) {
 
 // header pre-scan: the chromosome table must be complete (in the order the reference would build
 // it: first appearance over t1, c1, t2, c2, ...) before anything is sent to the device
+In& openStdin(State& S) {  // openRead 5135-5166 for '-'
+  if (!S.stdinIn) {
+    S.stdinIn.reset(new In);
+    openRead(*S.stdinIn, "-");
+    if (S.stdinIn->compressed()) die("", "Cannot pipe in gzip-compressed file (use zcat instead)");
+  }
+  return *S.stdinIn;
+}
+
 void scanHeader(State& S, const char* filename, bool ctrl) {
-  if (!strcmp(filename, "-")) return;
-  In in;
-  openRead(in, filename);
+  const bool isStdin = !strcmp(filename, "-");
+  if (isStdin && S.stdinIn) return;  // (named twice: the second reading finds it at its end, as in the reference)
+  In file;
+  In& in = isStdin ? openStdin(S) : file;
+  if (isStdin)
+    in.record();
+  else
+    openRead(in, filename);
   S.ctrl = ctrl;
   char magic[4];
   int got = (int)in.read(magic, 4);
@@ -1068,7 +1104,10 @@ void scanHeader(State& S, const char* filename, bool ctrl) {
     }
   }
   checkIn(in);
-  in.close();
+  if (isStdin)
+    in.replay();
+  else
+    in.close();
 }
 
 void sendChroms(State& S) {
@@ -1412,8 +1451,10 @@ int main(int argc, char** argv) {
       S.sampleOpen = false;
       S.errCount = 0;
       S.buf.clear();
-      In in;
-  openRead(in, filename);
+      In file;
+      const bool isStdin = !strcmp(filename, "-");
+      In& in = isStdin ? openStdin(S) : file;
+      if (!isStdin) openRead(in, filename);
       // BAM or SAM?  (checkBAM 5107: the decompressed stream starts with "BAM\1")
       char magic[4] = {0};
       int got = (int)in.read(magic, 4);
@@ -1437,7 +1478,7 @@ int main(int argc, char** argv) {
         readSAM(S, in, firstLine.data(), C);
       }
       checkIn(in);
-  in.close();
+      if (!isStdin) in.close();
       openSample(S);  // a file without a single usable record still opens (and closes) its sample
       if (S.gx && !S.buf.empty()) check(S, gx_push_events(S.gx, S.buf.data(), S.buf.size()));
       S.buf.clear();
@@ -1458,6 +1499,7 @@ int main(int argc, char** argv) {
   }
   if (S.bedOpt) closeOut(S.bed);
   if (S.dupsVerb) closeOut(S.dups);
+  if (getenv("GENRICH_HOST_PROF")) { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); fprintf(stderr, "main thread cpu %.3f s\n", ts.tv_sec + ts.tv_nsec * 1e-9); }
   if (o.eventsOnly) return EXIT_SUCCESS;
 
   size_t nPeaks = 0;

@@ -187,3 +187,37 @@ def test_cli_bgzf_corrupt_block_is_an_error(tmp_path):
     res = subprocess.run([_binary(), "--events-only", "--threads", "4", "-b", str(tmp_path / "e.bed")] + args,
                          capture_output=True, text=True)
     assert res.returncode != 0 and "BGZF" in res.stderr
+
+
+@pytest.mark.parametrize("which", ["-t", "-c"])
+def test_cli_reads_a_sam_stream_from_stdin(which, tmp_path):
+    """`samtools view -h ... | Genrich -t - ...` (openRead 5135: '-' is stdin).  The host needs every
+    header before anything goes to the device, so the part of the stream its header pre-scan consumed
+    is replayed to the real pass; the event stream must be the one the same data gives as a file."""
+    cases, mg = _cases()
+    args = _write_inputs(cases["ctrl_q"], mg, str(tmp_path / "in"))
+    a = [x for x in args if x != "-X"]
+    path = a[a.index(which) + 1]
+    assert "," not in path and path.endswith(".sam")
+    piped = list(a)
+    piped[piped.index(which) + 1] = "-"
+    bed = str(tmp_path / "events.bed")
+    with open(path, "rb") as f:
+        res = subprocess.run([_binary(), "--events-only", "-b", bed] + piped, stdin=f, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert open(bed, "rb").read() == G.read_gz("ctrl_q", "events.bed")
+
+
+def test_cli_refuses_compressed_or_empty_stdin(tmp_path):
+    """openRead 5145-5160: an empty input 'cannot be opened'; gzip data on stdin is an error of its own."""
+    cases, mg = _cases()
+    args = _write_inputs(cases["basic"], mg, str(tmp_path / "in"))
+    z = gzip.compress(open(args[1], "rb").read())
+    res = subprocess.run([_binary(), "--events-only", "-t", "-"], input=z, capture_output=True)
+    assert res.returncode != 0 and b"Cannot pipe in gzip-compressed file" in res.stderr
+    res = subprocess.run([_binary(), "--events-only", "-t", "-"], input=b"", capture_output=True)
+    assert res.returncode != 0 and b"cannot open file for reading" in res.stderr
+    empty = tmp_path / "empty.sam"
+    empty.write_bytes(b"")
+    res = subprocess.run([_binary(), "--events-only", "-t", str(empty)], capture_output=True)
+    assert res.returncode != 0 and b"cannot open file for reading" in res.stderr

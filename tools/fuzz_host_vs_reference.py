@@ -8,6 +8,18 @@ import numpy as np
 from genrich_amd import synth
 REF=os.path.join(ROOT, 'oracle', '_ref', 'Genrich'); BIN=os.path.join(ROOT, 'genrich_amd', 'genrich-amd')
 N2=["chr1","chr2","chrM"]; 
+def bgzf(data, rng):
+    import struct, zlib
+    out=bytearray(); off=0
+    while True:
+        chunk=data[off:off+rng.choice([rng.randint(40,400), rng.randint(400,5000), rng.randint(5000,65000)])]
+        cobj=zlib.compressobj(rng.choice([0,1,6]), zlib.DEFLATED, -15)
+        payload=cobj.compress(chunk)+cobj.flush()
+        out+=b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0"+struct.pack("<H",18+len(payload)+8-1)+payload
+        out+=struct.pack("<II", zlib.crc32(chunk)&0xFFFFFFFF, len(chunk))
+        if not chunk: break
+        off+=len(chunk)
+    return bytes(out)
 def one(seed):
     rng=random.Random(seed)
     L=[rng.randint(20_000,60_000), rng.randint(10_000,40_000), rng.randint(2_000,8_000)]
@@ -21,7 +33,16 @@ def one(seed):
         elif writer=="dups": synth.write_sam_dups(p,N2,L,e,s,name_prefix=pre,bam=bam)
         else: synth.write_sam(p,N2,L,e,name_prefix=pre)
     t=f"{d}/t.{ext}"; c=f"{d}/c.{ext}"; wr(t,ev,seed,"t_"); wr(c,ct,seed+7,"c_")
-    args=["-t",t]
+    threads=[]
+    if rng.random()<0.5:   # BGZF with small random blocks: the host's thread pool, records straddling blocks
+        for p in (t,c):
+            raw=open(p,"rb").read()
+            if bam: raw=gzip.decompress(raw)
+            open(p,"wb").write(bgzf(raw, rng))
+        threads=["--threads",str(rng.randint(2,5))]
+    piped = None
+    if not threads and not bam and rng.random()<0.4: piped = t   # plain SAM text through stdin
+    args=["-t","-" if piped else t]
     if rng.random()<0.7: args+=["-c",c]
     single=rng.choice([None,"-y","-w","-x"])
     if single=="-w": args+=["-w",str(rng.randint(50,400))]
@@ -42,8 +63,8 @@ def one(seed):
                 ci=rng.randrange(3); s=rng.randint(0,L[ci]-10); e=min(L[ci], s+rng.randint(1,3000)); f.write(f"{N2[ci]}\t{s}\t{e}\n")
         args+=["-E",bp]
     ra=[REF]+args+["-b",f"{d}/ref.bed","-o",f"{d}/ref.np","-v"]+(["-R",f"{d}/ref.dups"] if dups else [])
-    ha=[BIN,"--events-only"]+args+["-b",f"{d}/hip.bed","-v"]+(["-R",f"{d}/hip.dups"] if dups else [])
-    r=subprocess.run(ra,capture_output=True,text=True); h=subprocess.run(ha,capture_output=True,text=True)
+    ha=[BIN,"--events-only"]+threads+args+["-b",f"{d}/hip.bed","-v"]+(["-R",f"{d}/hip.dups"] if dups else [])
+    r=subprocess.run(ra,capture_output=True,text=True,stdin=open(piped) if piped else None); h=subprocess.run(ha,capture_output=True,text=True,stdin=open(piped) if piped else None)
     # the reference may fail legitimately (e.g. no fragments): then both must fail
     if r.returncode!=0 and ("no analyzable fragments" in r.stderr or "Experimental sample" in r.stderr):
         subprocess.run(["rm","-rf",d]); return None   # the reference stops after the treatment file; the events-only host goes on
