@@ -187,7 +187,7 @@ int saveChrom(State& S, const char* name, uint32_t len) {
       if (!S.ctrl) S.chrom[i].save = true;
       return (int)i;
     }
-  if (S.tableFrozen)  // all headers are pre-scanned; only an input read from stdin can get here
+  if (S.tableFrozen)  // every header was pre-scanned: this is an @SQ line that follows the first record of its file
     die(name, ": reference sequence first seen after the chromosome table was sent to the device");
   Chrom c;
   c.name = name;
