@@ -1,6 +1,9 @@
 """Build container only (needs oracle/_ref/Genrich): the oracle (CPU restatement) against the
 unmodified reference on random runs (replicates, controls incl. null, -p/-q, -a/-l/-g, -e, -E,
-multimapping): narrowPeak / -f / -k byte for byte.  usage: fuzz_oracle_vs_reference.py SEED0 SEED1"""
+multimapping): narrowPeak / -f / -k byte for byte.  usage: fuzz_oracle_vs_reference.py SEED0 SEED1
+[--saturate]   (--saturate: inputs that drive the reference's int16 difference array into its skip
+rule, Genrich.c:2565-2573 -- > 32,767 starts on one base, ends on one base, ends at the chromosome's
+last position, and ends on the hot start base, in random order)"""
 import sys, os, subprocess, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -69,6 +72,32 @@ def one(seed):
         if open(f"{d}/{a}","rb").read()!=open(f"{d}/{b}","rb").read():
             return f"seed {seed}: {a} differs: {' '.join(args+extra)}"
     subprocess.run(["rm","-rf",d]); return None
+def saturating(seed):
+    rng=np.random.default_rng(seed)
+    L=[20000,8000]; names=N[:2]
+    d=f"/tmp/fuzz/s{seed}"; os.makedirs(d,exist_ok=True)
+    def blk(n,c,s,e):
+        a=np.zeros(n,dtype=B.EVENT_DTYPE); a["chrom"]=c; a["start"]=s; a["end"]=e; a["count"]=1; return a
+    n1,n2,n3,n4=int(rng.integers(33000,42000)),int(rng.integers(33000,42000)),int(rng.integers(33000,40000)),int(rng.integers(1000,20000))
+    ev=np.concatenate([synth.make_fragments(L,2000,seed=seed),
+                       blk(n1,0,5000,5000+rng.integers(100,300,n1)), blk(n2,0,9000-rng.integers(100,300,n2),9000),
+                       blk(n3,1,8000-rng.integers(100,300,n3),8000), blk(n4,0,5000-rng.integers(100,300,n4),5000)])
+    ev=ev[rng.permutation(len(ev))]
+    t=f"{d}/t.sam"; synth.write_sam(t,names,L,ev,name_prefix="t_")
+    run=[REF,"-t",t,"-p","0.01","-a","20","-v","-o",f"{d}/ref.np","-f",f"{d}/ref.log","-k",f"{d}/ref.pile","-b",f"{d}/ev.bed"]
+    r=subprocess.run(run,capture_output=True,text=True)
+    if r.returncode!=0: return f"seed {seed}: reference failed {r.stderr[-200:]}"
+    idx={n:i for i,n in enumerate(names)}; rows=[]
+    for line in open(f"{d}/ev.bed"):
+        c,s,e,nm=line.rstrip("\n").split("\t"); _,cnt,kind,smp=nm.rsplit("_",3); rows.append((idx[c],int(s),int(e),int(cnt)))
+    o=B.Oracle(B.make_params(pq=0.01, qval=False, min_auc=20.0)); o.set_chroms(L,[False,False],[[],[]])
+    o.sample_begin(0,None); o.push_events(np.array(rows,dtype=B.EVENT_DTYPE)); o.sample_end(); o.sample_no_control()
+    o.pvalues_to(f"{d}/or.pile", False, names, t, None)
+    o.find_peaks_to(f"{d}/or.np", f"{d}/or.log", names, True)
+    for a,b in (("ref.np","or.np"),("ref.log","or.log"),("ref.pile","or.pile")):
+        if open(f"{d}/{a}","rb").read()!=open(f"{d}/{b}","rb").read(): return f"seed {seed}: {a} differs (saturating input)"
+    subprocess.run(["rm","-rf",d]); return None
+if "--saturate" in sys.argv: one=saturating
 bad=0
 for seed in range(int(sys.argv[1]),int(sys.argv[2])):
     try: m=one(seed)
