@@ -83,6 +83,18 @@ def saturating(seed):
                        blk(n1,0,5000,5000+rng.integers(100,300,n1)), blk(n2,0,9000-rng.integers(100,300,n2),9000),
                        blk(n3,1,8000-rng.integers(100,300,n3),8000), blk(n4,0,5000-rng.integers(100,300,n4),5000)])
     ev=ev[rng.permutation(len(ev))]
+    if seed % 2:   # multimapped reads too: k alignments of one read are k consecutive events of count k, one of them on a hot base
+        groups=[]
+        for _ in range(int(rng.integers(5000,30000))):
+            k=int(rng.choice([2,3,4,5,6,8,10])); g=synth.make_fragments(L,k,seed=int(rng.integers(1<<30)),uniform_only=True); g["count"]=k
+            hot=int(rng.integers(3))
+            if hot==0: g[0]["chrom"],g[0]["start"],g[0]["end"]=0,5000,5000+int(rng.integers(100,300))
+            elif hot==1: g[0]["chrom"],g[0]["end"]=0,9000; g[0]["start"]=9000-int(rng.integers(100,300))
+            groups.append(g)
+        # groups go in between the unit events, each group contiguous
+        cut=np.sort(rng.integers(0,len(ev)+1,len(groups))); pieces=[]; last=0
+        for c,g in zip(cut,groups): pieces+= [ev[last:c], g]; last=c
+        ev=np.concatenate(pieces+[ev[last:]])
     t=f"{d}/t.sam"; synth.write_sam(t,names,L,ev,name_prefix="t_")
     run=[REF,"-t",t,"-p","0.01","-a","20","-v","-o",f"{d}/ref.np","-f",f"{d}/ref.log","-k",f"{d}/ref.pile","-b",f"{d}/ev.bed"]
     r=subprocess.run(run,capture_output=True,text=True)
