@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include "gx_merge.h"
+#include "gx_saturate.h"
 
 using namespace gx;
 
@@ -849,6 +850,11 @@ int gx_push_events(gx_ctx* ctx, const gx_event* events, size_t n) {
   HIPCHECK(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffer on return
   ctx->evCount += n;
   return GX_OK;
+}
+
+long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, const uint32_t* len, uint8_t* keep) {
+  if ((!events && n) || (!keep && n) || n_chrom < 0 || (!len && n_chrom)) return GX_ERR_ORDER;
+  return gxsat::filter(events, n, n_chrom, len, keep);
 }
 
 int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n) {
