@@ -47,9 +47,8 @@ enum gx_status {
   GX_ERR_DF = -9,       /* ERRDF     "Invalid df in pchisq()"                    :556 */
   GX_ERR_ORDER = -10,   /* API called out of order / bad argument */
   GX_ERR_DEVICE = -11,  /* HIP runtime failure (message via gx_last_error) */
-  GX_ERR_OVERFLOW = -12 /* a per-base difference reached the int16 range at which the
-                           reference starts skipping alignments (Genrich.c:2558-2573);
-                           that order-dependent behaviour is not reproduced */
+  GX_ERR_OVERFLOW = -12 /* (not returned any more: the reference's int16 saturation skips,
+                           Genrich.c:2558-2573, are reproduced -- see gx_filter_saturation) */
 };
 
 /* One alignment-derived interval AFTER saveInterval's clamping
