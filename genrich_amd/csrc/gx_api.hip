@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include "gx_merge.h"
+#include "gx_saturate.h"
 
 using namespace gx;
 
@@ -62,7 +63,7 @@ struct HostMail {
   Scalars scal;
   long long acc[2];
   uint64_t peakBP, genome;
-  u32 nF, nIv, status, R, nPeaks, nMerged, D, n;
+  u32 nF, nIv, status, R, nPeaks, nMerged, D, n, hot;
 };
 
 struct PinnedBuf {
@@ -151,6 +152,7 @@ struct gx_ctx {
   DevBuf pvLut;
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp, bhRecs;
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
+  bool satDone = false;         // this sample's events already went through the saturation filter
   bool bhDirty = false;         // the BH table was left with entries (an error path): wipe it before use
   // sweep
   DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
@@ -398,7 +400,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   u32* slowFrag = &ff->slow;
   if (ctx->hasBed || !unit32 || forceSlowFrag) HIPCHECK(hipMemsetAsync(slowFrag, 1, 4, s));
   ConvertOut co{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), &ff->nF, SS.sbHist.as<u32>(),
-                SE.sbHist.as<u32>(), ff->fragSum, slowFrag, ctx->endAtLen.as<u32>()};
+                SE.sbHist.as<u32>(), ff->fragSum, slowFrag, ctx->endAtLen.as<u32>(), ctx->nWide.as<u32>() + 1};
   size_t off = 0;
   for (auto& seg : segs) {
     if (!seg.n) continue;
@@ -489,6 +491,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   phase_end(ctx);
+  // (word 1 of the nWide block: the "a base can reach the int16 limits" flag, also set by k_convert)
+  hipLaunchKernelGGL(k_hot_check, dim3(std::min<u32>(nTiles, 256u)), dim3(256), 0, s, tin, wl, nw, ctx->nWide.as<u32>() + 1);
+  if (int rc__ = dbg_sync(ctx, "k_hot_check")) return rc__;
+  HIPCHECK(hipMemcpyAsync(&ctx->mail->hot, ctx->nWide.as<u32>() + 1, 4, hipMemcpyDeviceToHost, s));
 
   phase_begin(ctx, isCtrl ? "c.pack" : "t.pack");
   const u32 ivChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
@@ -531,6 +537,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   return GX_OK;
 }
 
+constexpr int RETRY_SATURATED = 1;  // (internal) finish_scalars: filter the events and build the sample again
+
 // fragLen / ctrlFrag partial sums -> (all ranks) -> lambda, factor
 int finish_scalars(gx_ctx* ctx, int isCtrl) {
   hipStream_t s = ctx->stream;
@@ -540,6 +548,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     long long* dacc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
     HIPCHECK(hipMemcpyAsync(acc, dacc, 16, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (ctx->mail->hot && !ctx->satDone) return RETRY_SATURATED;  // before this rank enters the collective
     int64_t buf[2] = {acc[0], acc[1]};
     if (ctx->allreduce(buf, 2, ctx->user)) {
       ctx->err = "allreduce callback failed";
@@ -553,9 +562,64 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
   if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
   HIPCHECK(hipMemcpyAsync(&ctx->mail->scal, ds, sizeof(Scalars), hipMemcpyDeviceToHost, s));
   int rc = read_status(ctx);
+  if (ctx->mail->hot && !ctx->satDone) return RETRY_SATURATED;
   ctx->hScal = ctx->mail->scal;
   if (ctx->nIvTarget) *ctx->nIvTarget = ctx->mail->nIv;
   ctx->nIvTarget = nullptr;
+  return rc;
+}
+
+// The sample holds a base that can reach the reference's int16 limits: bring the events to the host,
+// drop the ones saveInterval would drop (gx_saturate.h) and stage what is left for a second build.
+int drop_saturated(gx_ctx* ctx, int isCtrl) {
+  hipStream_t s = ctx->stream;
+  size_t total = ctx->evCount;
+  for (auto& sg : ctx->segs) total += sg.n;
+  std::vector<gx_event> all(total);
+  size_t at = 0;
+  if (ctx->evCount) {
+    HIPCHECK(hipMemcpyAsync(all.data(), ctx->evBuf.p, ctx->evCount * sizeof(gx_event), hipMemcpyDeviceToHost, s));
+    at = ctx->evCount;
+  }
+  for (auto& sg : ctx->segs) {
+    if (sg.n) HIPCHECK(hipMemcpyAsync(all.data() + at, sg.p, sg.n * sizeof(gx_event), hipMemcpyDeviceToHost, s));
+    at += sg.n;
+  }
+  HIPCHECK(hipStreamSynchronize(s));
+  // only the chromosomes this context works on (the others' events are ignored by k_convert too)
+  std::vector<uint32_t> len(ctx->nChrom);
+  for (u32 i = 0; i < ctx->nChrom; i++) len[i] = ctx->hChrom[i].tileBase == NULL_TILE ? 0u : ctx->len[i];
+  std::vector<uint8_t> keep(total);
+  const long long dropped = gxsat::filter(all.data(), total, (int)ctx->nChrom, len.data(), keep.data());
+  size_t kept = 0;
+  if (dropped > 0) {
+    for (size_t i = 0; i < total; i++)
+      if (keep[i]) all[kept++] = all[i];
+  } else
+    kept = total;
+  // (also when nothing was dropped: the second build must not see the caller's segments twice)
+  HIPCHECK(ctx->evBuf.ensure(std::max<size_t>(kept, 1) * sizeof(gx_event)));
+  if (kept) HIPCHECK(hipMemcpyAsync(ctx->evBuf.p, all.data(), kept * sizeof(gx_event), hipMemcpyHostToDevice, s));
+  HIPCHECK(hipStreamSynchronize(s));  // `all` goes out of scope
+  ctx->evCount = kept;
+  ctx->segs.clear();
+  ctx->satDone = true;
+  // what the first build left behind: its status bits and its contribution to fragLen / ctrlFrag
+  Scalars* ds = ctx->dScal.as<Scalars>();
+  HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, s));
+  HIPCHECK(hipMemsetAsync(isCtrl ? ds->ctrlAcc : ds->fragAcc, 0, 16, s));
+  return GX_OK;
+}
+
+int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
+  int rc = build_pileup(ctx, P, isCtrl);
+  if (rc) return rc;
+  rc = finish_scalars(ctx, isCtrl);
+  if (rc == RETRY_SATURATED) {
+    if ((rc = drop_saturated(ctx, isCtrl))) return rc;
+    if ((rc = build_pileup(ctx, P, isCtrl))) return rc;
+    rc = finish_scalars(ctx, isCtrl);
+  }
   return rc;
 }
 
@@ -827,6 +891,7 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
   }
   ctx->segs.clear();
   ctx->evCount = 0;
+  ctx->satDone = false;
   return GX_OK;
 }
 
@@ -851,6 +916,11 @@ int gx_push_events(gx_ctx* ctx, const gx_event* events, size_t n) {
   return GX_OK;
 }
 
+long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, const uint32_t* len, uint8_t* keep) {
+  if ((!events && n) || (!keep && n) || n_chrom < 0 || (!len && n_chrom)) return GX_ERR_ORDER;
+  return gxsat::filter(events, n, n_chrom, len, keep);
+}
+
 int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n) {
   if (!ctx || (ctx->phase != 1 && ctx->phase != 3)) return GX_ERR_ORDER;
   if (n) ctx->segs.push_back({d_events, n});
@@ -861,15 +931,11 @@ int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor) {
   if (!ctx) return GX_ERR_ORDER;
   HIPCHECK(hipSetDevice(ctx->device));
   if (ctx->phase == 1) {
-    int rc = build_pileup(ctx, ctx->expt, 0);
-    if (rc) return rc;
-    rc = finish_scalars(ctx, 0);
+    int rc = close_sample(ctx, ctx->expt, 0);
     if (rc) return rc;
     ctx->phase = 2;
   } else if (ctx->phase == 3) {
-    int rc = build_pileup(ctx, ctx->ctrl, 1);
-    if (rc) return rc;
-    rc = finish_scalars(ctx, 1);
+    int rc = close_sample(ctx, ctx->ctrl, 1);
     if (rc) return rc;
     ctx->phase = 4;
   } else

@@ -208,6 +208,8 @@ struct ChromCursor {
 //   F    : 8-byte records  [63:32] tile  [31:8] offset  [7:0] signed weight (1/120 units) for
 //          multimapped (fractional) intervals, appended compactly; also carries everything when
 //          the genome has too many tiles for a 4-byte key.
+// weight (1/120 units) of starts, or of ends, below which a base cannot reach the reference's int16 limits
+constexpr u32 HOT16 = 32766u * GX_UNIT;
 constexpr u32 NULL32 = 0xFFFFFFFFu;
 constexpr u32 MAX_TILES32 = (1u << (32 - TB)) - 1;  // tile ids representable in a 4-byte key
 
@@ -250,6 +252,7 @@ struct ConvertOut {
   u64* fragSum; // [FRAG_SLOTS] sum of the clamped lengths of the fragments kept (see k_frag)
   u32* slowFrag;
   u32* endAtLen; // [nChrom] weight of the events that end at (or beyond) the chromosome's end
+  u32* hot;      // set when a base can reach the reference's int16 limits (see k_hot_check)
 };
 
 template <bool UNIT32>
@@ -300,10 +303,10 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
             if (end < c.len) {
               t1 = c.tileBase + (end >> TB);
               o1 = end & (TILE - 1);
-            } else if (atomicAdd(&out.endAtLen[e.x], (u32)w) + (u32)w >= 32768u * GX_UNIT) {
+            } else if (atomicAdd(&out.endAtLen[e.x], (u32)w) + (u32)w >= HOT16) {
               // the reference's diff has an entry at `len` too, and its int16 saturates there like
-              // anywhere else (2565-2573): same policy as inside the chromosome (ST_SAT16, k_tile)
-              bad |= ST_SAT16;
+              // anywhere else (2565-2573): these ends have no record, so they are counted here
+              atomicOr(out.hot, 1u);
             }
           }
         }
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
     const bool save0 = save;
     const int lbase = threadIdx.x * 32;
     int sum = 0;
-    u32 cnt = 0, sat = 0;
+    u32 cnt = 0;
     // The first TL_REG touched bases of the thread are fetched from LDS in one batch and kept in
     // registers for both passes (a dependent LDS round trip per base and pass is what this kernel
     // would otherwise wait for); their slots are cleared at once.  Further bases -- rare -- loop.
@@ -1055,7 +1058,6 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
     sum += (D);                                                                \
     cnt += (edge || (save && (D) != 0)) && (pos0 + lbase + (K) != 0); /* 2241 */ \
     if (edge) save = !save;                                       /* 2258-2263 */ \
-    sat |= (u32)((D) >= 32767 * GX_UNIT) | (u32)((D) <= -32768 * GX_UNIT);     \
   }
     if constexpr (!BED) {
       // Without -E edges the register-held steps need no branches: an absent entry carries d = 0,
@@ -1066,7 +1068,6 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
         const int d = dk[j];
         sum += d;
         cnt += (u32)(d != 0);
-        sat |= (u32)(d >= 32767 * GX_UNIT) | (u32)(d <= -32768 * GX_UNIT);
         if constexpr (!HALF)
           if (d != 0) delta[lbase + kk[j]] = 0;
       }
@@ -1169,7 +1170,7 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
         o++;
       }
       if (o != o0 && o == slot + totFinal) out.tileLastEnd[t] = lastEnd;  // wrote the tile's last interval
-      bad |= (neg ? ST_NEG_PILE : 0) | (sat ? ST_SAT16 : 0);
+      bad |= neg ? ST_NEG_PILE : 0;
       if (big) atomicOr(&out.tileDeep[t], 1u);  // rare
     }
     if (threadIdx.x == 0) out.tileCount[t] = totFinal;
@@ -1177,6 +1178,38 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
     __syncthreads();  // scr, occ and the slice are reused by the next tile
   }
   if (bad) atomicOr(st, bad);
+}
+
+// Can any base reach the reference's int16 limits (Genrich.c:2558-2573: an alignment is dropped when
+// diff[start] holds INT16_MAX or diff[end] INT16_MIN)?  That takes >= 32,767 unit weights starting,
+// or ending, on one base, so only a tile that is wide by count can hold such a base.  Starts and ends
+// are summed apart: the running value in the reference's input order can hit a limit while the net
+// difference k_tile sees stays small.  The answer is one flag; which alignments are dropped depends
+// on their order and is decided on the host (gx_saturate.h), which then rebuilds the sample.
+__global__ __launch_bounds__(256) void k_hot_check(TileIn in, const u32* __restrict__ wideList,
+                                                   const u32* __restrict__ nWide, u32* __restrict__ hot) {
+  __shared__ u32 ws[TILE], we[TILE];
+  const u32 nW = *nWide;
+  for (u32 i = blockIdx.x; i < nW; i += gridDim.x) {
+    const TileMeta m = in.meta[wideList[i]];
+    if (!(m.flags & TM_ACTIVE)) continue;  // block-uniform
+    if ((u64)m.nS + m.nF < HOT16 / GX_UNIT && (u64)m.nE + m.nF < HOT16 / GX_UNIT) continue;
+    for (int j = threadIdx.x; j < TILE; j += 256) { ws[j] = 0; we[j] = 0; }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < m.nS; j += 256) atomicAdd(&ws[in.S[m.sb + j]], (u32)GX_UNIT);
+    for (u32 j = threadIdx.x; j < m.nE; j += 256) atomicAdd(&we[in.E[m.eb + j]], (u32)GX_UNIT);
+    for (u32 j = threadIdx.x; j < m.nF; j += 256) {
+      const u64 r = in.F[m.fb + j];
+      const int w = (int)(int8_t)(r & 0xFF);
+      const u32 off = (u32)(r >> 8) & (TILE - 1);
+      if (w > 0) atomicAdd(&ws[off], (u32)w); else atomicAdd(&we[off], (u32)(-w));
+    }
+    __syncthreads();
+    bool h = false;
+    for (int j = threadIdx.x; j < TILE; j += 256) h |= ws[j] >= HOT16 || we[j] >= HOT16;
+    if (h) atomicOr(hot, 1u);
+    __syncthreads();
+  }
 }
 
 // tile interval counts -> tight offsets (sum scan) and, per tile, the end of the last interval

@@ -87,8 +87,24 @@ def load_library(path: str = os.environ.get("GENRICH_AMD_LIB", LIB_PATH)):
     lib.gx_last_error.argtypes = [C.c_void_p]
     lib.gx_strerror.restype = C.c_char_p
     lib.gx_strerror.argtypes = [C.c_int]
+    lib.gx_filter_saturation.restype = C.c_longlong
+    lib.gx_filter_saturation.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
+
+
+def filter_saturation(events, lens):
+    """keep flags (uint8) for `events` under the reference's int16 saturation rule (Genrich.c:2558-2573);
+    host-only, needs no GPU."""
+    import numpy as np
+    lib = load_library()
+    ev = np.ascontiguousarray(events)
+    ln = np.ascontiguousarray(lens, dtype=np.uint32)
+    keep = np.ones(len(ev), dtype=np.uint8)
+    rc = lib.gx_filter_saturation(ev.ctypes.data, len(ev), len(ln), ln.ctypes.data, keep.ctypes.data)
+    if rc < 0:
+        raise RuntimeError(f"gx_filter_saturation: {rc}")
+    return keep, int(rc)
 
 
 class Genrich:

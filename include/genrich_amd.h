@@ -47,9 +47,8 @@ enum gx_status {
   GX_ERR_DF = -9,       /* ERRDF     "Invalid df in pchisq()"                    :556 */
   GX_ERR_ORDER = -10,   /* API called out of order / bad argument */
   GX_ERR_DEVICE = -11,  /* HIP runtime failure (message via gx_last_error) */
-  GX_ERR_OVERFLOW = -12 /* a per-base difference reached the int16 range at which the
-                           reference starts skipping alignments (Genrich.c:2558-2573);
-                           that order-dependent behaviour is not reproduced */
+  GX_ERR_OVERFLOW = -12 /* (not returned any more: the reference's int16 saturation skips,
+                           Genrich.c:2558-2573, are reproduced -- see gx_filter_saturation) */
 };
 
 /* One alignment-derived interval AFTER saveInterval's clamping
@@ -119,6 +118,14 @@ int gx_push_events(gx_ctx* ctx, const gx_event* events, size_t n);
 /* Events already resident in device memory (HIP path only; the pointer must stay
  * valid until gx_sample_end). */
 int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n);
+
+/* The reference's int16 saturation rule (Genrich.c:2558-2573): saveInterval drops an alignment
+ * when the int16 part of diff[start] already holds INT16_MAX or that of diff[end] INT16_MIN, which
+ * depends on the order of the alignments.  keep[i] = 0 for the events (in input order, as for
+ * gx_push_events; lengths as for gx_set_chroms) that it would drop, 1 otherwise.  Host-only: no
+ * context, no device.  gx_sample_end applies the same rule itself when the device finds a base
+ * that can saturate at all.  Returns the number of events dropped, or a negative gx_status. */
+long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, const uint32_t* len, uint8_t* keep);
 
 /* Treatment: == savePileupExpt (Genrich.c:2168-2295), returns fragLen.
  * Control : == savePileupCtrl (:2052-2161), returns lambda and factor.
