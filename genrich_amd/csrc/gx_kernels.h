@@ -40,7 +40,7 @@ enum : u32 {
   ST_BAD_POS = 2u,       // start >= chromosome length      (ERRPOS, Genrich.c:2531)
   ST_BAD_COUNT = 4u,     // count not in {1,2,3,4,5,6,8,10}  (ERRALNS, :2402)
   ST_NEG_PILE = 8u,      // negative pileup                  (ERRPILE, :1921)
-  ST_SAT16 = 16u,        // |per-base difference| reached the reference's int16 range (:2558)
+  ST_SAT16 = 16u,        // (unused since the reference's int16 saturation skips are reproduced: k_hot_check)
   ST_LOOKBACK = 32u,     // decoupled look-back spin limit hit (internal)
   ST_HASH_FULL = 64u,    // p-value table overflow (internal)
   ST_NO_FRAGS = 128u,    // fragLen == 0                     (ERREXPT, :2292)
