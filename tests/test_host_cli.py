@@ -155,6 +155,24 @@ def _bgzf(data, block=30_000):
     return bytes(out)
 
 
+@pytest.mark.parametrize("block", [37, 4099])
+def test_cli_bgzf_records_straddling_blocks(block, tmp_path):
+    """BAM records are parsed in place when they lie inside one inflated block and copied when they
+    straddle blocks: with 37-byte blocks every record (and most 4-byte length fields) is split."""
+    cases, mg = _cases()
+    name = "dups_x_bam"
+    args = _write_inputs(cases[name], mg, str(tmp_path / "in"))
+    for i, a in enumerate(args):
+        for p in (a.split(",") if i and args[i - 1] in ("-t", "-c") else []):
+            if p != "null":
+                open(p, "wb").write(_bgzf(gzip.decompress(open(p, "rb").read()), block=block))
+    a = [x for x in args if x != "-X"]
+    bed = str(tmp_path / "events.bed")
+    res = subprocess.run([_binary(), "--events-only", "--threads", "3", "-b", bed] + a, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
+
+
 @pytest.mark.parametrize("name", ["unpaired_bam_atac", "dups_x_bam", "ctrl_q"])
 def test_cli_bgzf_input_parallel_inflate(name, tmp_path):
     """BGZF input (what samtools / bgzip write) is inflated by a thread pool; the event stream must be
