@@ -1052,6 +1052,19 @@ void logCounts(const State& S, const Counts& C, bool bam) {
 
 // header pre-scan: the chromosome table must be complete (in the order the reference would build
 // it: first appearance over t1, c1, t2, c2, ...) before anything is sent to the device
+// BAM or SAM?  checkBAM (5107-5125) looks at the first characters of a gzip-compressed input only:
+// "BAM\1" is BAM; the end of the stream -- or, `char m = gzgetc()` being signed, a 0xFF byte -- before a
+// character that differs from the magic is "cannot open file for reading".  Uncompressed input is SAM.
+bool sniffBam(In& in, char magic[4], int& got) {
+  got = (int)in.read(magic, 4);
+  if (!in.compressed()) return false;
+  for (int i = 0; i < 4; i++) {
+    if (i >= got || (unsigned char)magic[i] == 0xFF) die("", ": cannot open file for reading");
+    if (magic[i] != "BAM\1"[i]) return false;
+  }
+  return true;
+}
+
 In& openStdin(State& S) {  // openRead 5135-5166 for '-'
   if (!S.stdinIn) {
     S.stdinIn.reset(new In);
@@ -1072,8 +1085,8 @@ void scanHeader(State& S, const char* filename, bool ctrl) {
     openRead(in, filename);
   S.ctrl = ctrl;
   char magic[4];
-  int got = (int)in.read(magic, 4);
-  if (got == 4 && !memcmp(magic, "BAM\1", 4)) {
+  int got = 0;
+  if (sniffBam(in, magic, got)) {
     int32_t l_text = rdI32(in, true);
     if (!in.skip((size_t)l_text)) die("", "Cannot parse BAM file");
     int32_t n_ref = rdI32(in, true);
@@ -1457,8 +1470,8 @@ int main(int argc, char** argv) {
       if (!isStdin) openRead(in, filename);
       // BAM or SAM?  (checkBAM 5107: the decompressed stream starts with "BAM\1")
       char magic[4] = {0};
-      int got = (int)in.read(magic, 4);
-      bool bam = got == 4 && !memcmp(magic, "BAM\1", 4);
+      int got = 0;
+      const bool bam = sniffBam(in, magic, got);
       if (o.verbose) fprintf(stderr, "Processing %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
       if (S.dupsVerb) fprintf(S.dups.f, "# %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
       Counts C;

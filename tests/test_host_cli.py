@@ -165,7 +165,8 @@ def test_cli_bgzf_records_straddling_blocks(block, tmp_path):
     for i, a in enumerate(args):
         for p in (a.split(",") if i and args[i - 1] in ("-t", "-c") else []):
             if p != "null":
-                open(p, "wb").write(_bgzf(gzip.decompress(open(p, "rb").read()), block=block))
+                raw = gzip.decompress(open(p, "rb").read())
+                open(p, "wb").write(_bgzf(raw, block=block))
     a = [x for x in args if x != "-X"]
     bed = str(tmp_path / "events.bed")
     res = subprocess.run([_binary(), "--events-only", "--threads", "3", "-b", bed] + a, capture_output=True, text=True)
@@ -239,3 +240,10 @@ def test_cli_refuses_compressed_or_empty_stdin(tmp_path):
     empty.write_bytes(b"")
     res = subprocess.run([_binary(), "--events-only", "-t", str(empty)], capture_output=True)
     assert res.returncode != 0 and b"cannot open file for reading" in res.stderr
+    # checkBAM 5107-5125: a compressed input that ends inside the "BAM\1" magic (or holds nothing at all)
+    for content in (b"", b"BA"):
+        for wrap in (gzip.compress, _bgzf):
+            z = tmp_path / "short.gz"
+            z.write_bytes(wrap(content))
+            res = subprocess.run([_binary(), "--events-only", "--threads", "2", "-t", str(z)], capture_output=True)
+            assert res.returncode != 0 and b"Error! : cannot open file for reading" in res.stderr
