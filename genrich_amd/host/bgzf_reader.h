@@ -77,6 +77,13 @@ class Input {
     recording_ = false;
   }
 
+  // hand back the n bytes that the last read() delivered (a format sniff)
+  void unread(const void* p, size_t n) {
+    pre_.replace(0, prePos_, static_cast<const char*>(p), n);
+    prePos_ = 0;
+    if (recording_) rec_.resize(rec_.size() - std::min(n, rec_.size()));
+  }
+
   const std::string& name() const { return name_; }
   const std::string& error() const { return err_; }
   bool parallel() const { return f_ != nullptr; }

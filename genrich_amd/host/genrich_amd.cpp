@@ -687,37 +687,49 @@ int calcDist(const char* qname, const char* seq, const char* cigar) {
 }
 
 float samScore(char* extra) {  // getScore 4383-4402
+  // fields on TAB; inside a field the tokens between colons (strtok: a run of colons is one separator).
+  // The first field whose first token is "AS" decides: its third token is the score, whatever the second
+  // (the type) says; without a third token there is no score.
   if (!extra) return NOSCORE;
-  for (char* f = strtok(extra, "\t"); f; f = strtok(nullptr, "\t"))
-    if (!strncmp(f, "AS:", 3)) {
-      char* v = strchr(f + 3, ':');
-      if (!v) return NOSCORE;
-      char* nl = strchr(v + 1, '\n');
-      if (nl) *nl = '\0';
-      return getFloat(v + 1);
+  char* endF = nullptr;
+  for (char* f = strtok_r(extra, "\t", &endF); f; f = strtok_r(nullptr, "\t", &endF)) {
+    char* endT = nullptr;
+    char* tag = strtok_r(f, ":", &endT);
+    if (tag && !strcmp(tag, "AS")) {
+      if (!strtok_r(nullptr, ":", &endT)) return NOSCORE;
+      char* v = strtok_r(nullptr, ":", &endT);
+      return v ? getFloat(v) : NOSCORE;
     }
+  }
   return NOSCORE;
 }
 
-void headerLine(State& S, char* line) {  // checkHeader 4307-4342
-  size_t n = strlen(line);
-  while (n && (line[n - 1] == '\n' || line[n - 1] == '\r')) line[--n] = '\0';
-  std::vector<char*> f;
-  for (char* t = strtok(line, "\t"); t; t = strtok(nullptr, "\t")) f.push_back(t);
-  if (f.empty()) return;
-  if (!strcmp(f[0], "@HD")) {
-    const char* order = nullptr;
-    for (size_t i = 1; i < f.size(); i++)
-      if (!strncmp(f[i], "SO:", 3)) order = f[i] + 3;
+void headerLine(State& S, char* line) {  // checkHeader 4307-4342, loadChrom 4275-4299
+  // as the reference cuts it up: strtok on TAB, so the last token of the line still carries its '\n' -- a
+  // bare "@HD\n" or "@SQ\n" is therefore not recognised -- and only the values of SO: / SN: / LN: are cut at
+  // the line feed (a carriage return stays)
+  auto cut = [](char* v) {
+    if (v) v[strcspn(v, "\n")] = '\0';
+  };
+  char* tag = strtok(line, "\t");
+  if (!tag) return;
+  if (!strcmp(tag, "@HD")) {
+    char* order = nullptr;
+    for (char* f = strtok(nullptr, "\t"); f; f = strtok(nullptr, "\t"))
+      if (!strncmp(f, "SO:", 3)) order = f + 3;
+    cut(order);
     if (S.o.sortOpt && (!order || strcmp(order, "queryname")))
       die("", "SAM/BAM file not sorted by queryname (samtools sort -n)");
-  } else if (!strcmp(f[0], "@SQ")) {
-    const char *name = nullptr, *len = nullptr;
-    for (size_t i = 1; i < f.size(); i++) {
-      if (!strncmp(f[i], "SN:", 3)) name = f[i] + 3;
-      else if (!strncmp(f[i], "LN:", 3)) len = f[i] + 3;
+  } else if (!strcmp(tag, "@SQ")) {
+    char *name = nullptr, *len = nullptr;
+    for (char* f = strtok(nullptr, "\t"); f; f = strtok(nullptr, "\t")) {
+      if (!strncmp(f, "SN:", 3)) name = f + 3;
+      else if (!strncmp(f, "LN:", 3)) len = f + 3;
     }
-    if (name && len) saveChrom(S, name, (uint32_t)getInt(len));
+    if (!name || !len) return;
+    cut(name);
+    cut(len);
+    saveChrom(S, name, (uint32_t)getInt(len));
   }
 }
 
@@ -818,34 +830,41 @@ uint64_t readSAM(State& S, In& in, char* first, Counts& C) {
       continue;
     }
     pastHeader = true;
-    // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [extra]
+    // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [extra], cut up as the reference does
+    // (readSAM 4524-4530, loadFields 4350-4377): strtok on TAB -- so a run of tabs is one separator, and
+    // the last field of a line keeps its line end -- with the integer fields converted (getInt: the whole
+    // token must be a number) as they are met, QUAL included in that order of events.
+    char* save = nullptr;
+    char* qname = strtok_r(l, "\t", &save);
+    if (!qname) die(l, ": poorly formatted SAM/BAM record");
     char* fld[12] = {nullptr};
-    char* p = l;
-    int nf = 0;
-    for (; nf < 11; nf++) {
-      fld[nf] = p;
-      char* t = strchr(p, '\t');
-      if (!t) {
-        size_t n = strlen(p);
-        while (n && (p[n - 1] == '\n' || p[n - 1] == '\r')) p[--n] = '\0';
-        nf++;
-        p = nullptr;
+    fld[0] = qname;
+    uint16_t flag = 0;
+    uint32_t pos = 0, pnext = 0;
+    uint8_t mapq = 0;
+    char* extra = nullptr;
+    int nf = 1;
+    for (char* f = strtok_r(nullptr, "\t", &save); f; f = strtok_r(nullptr, "\t", &save)) {
+      fld[nf] = f;
+      switch (nf) {
+        case 1: flag = (uint16_t)getInt(f); break;
+        case 3: pos = (uint32_t)(getInt(f) - 1); break;
+        case 4: mapq = (uint8_t)getInt(f); break;
+        case 7: pnext = (uint32_t)(getInt(f) - 1); break;
+        case 8: (void)getInt(f); break;  // TLEN: converted, then ignored
+        default: break;
+      }
+      if (++nf == 11) {
+        extra = strtok_r(nullptr, "\n", &save);
         break;
       }
-      *t = '\0';
-      p = t + 1;
     }
-    if (nf < 11) die(fld[0] ? fld[0] : "", ": poorly formatted SAM/BAM record");
-    char* extra = p;  // may be null
-    const char* qname = fld[0];
+    if (nf < 11) die(qname, ": poorly formatted SAM/BAM record");
     C.count++;
-    uint16_t flag = (uint16_t)getInt(fld[1]);
     if (flag & 0x4) { C.unmapped++; continue; }
     if (!strcmp(qname, "*") || !strcmp(fld[2], "*")) die(qname, ": poorly formatted SAM/BAM record");
     if (flag & 0xE00) { C.supp++; continue; }
     int ci = findChrom(S, fld[2]);
-    uint32_t pos = (uint32_t)(getInt(fld[3]) - 1), pnext = (uint32_t)(getInt(fld[7]) - 1);
-    uint8_t mapq = (uint8_t)getInt(fld[4]);
     if (mapq < S.o.minMapQ) { C.lowMapQ++; continue; }
     int length = calcDist(qname, fld[9], fld[5]);
     float score = samScore(extra);
@@ -857,11 +876,15 @@ uint64_t readSAM(State& S, In& in, char* first, Counts& C) {
 
 // ---- BAM (readBAM 4983-5068, parseBAM 4826-4977, getBAMscore 4751) -----------------------------
 bool gzReadAll(In& g, void* dst, size_t n) { return n == 0 || g.read(dst, n) == n; }
+// readInt32 4628-4640.  Without `must`, the end of the stream -- between records or inside the length
+// field -- returns EOF (-1); so does a length field that holds -1, which the reference cannot tell apart.
 int32_t rdI32(In& g, bool must) {
   uint8_t b[4];
   int k = (int)g.read(b, 4);
-  if (k == 0 && !must) return -1;  // clean EOF between records
-  if (k != 4) die("", "Cannot parse BAM file");
+  if (k != 4) {
+    if (!must) return -1;
+    die("", "Cannot parse BAM file");
+  }
   return (int32_t)(b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24));
 }
 
@@ -874,17 +897,32 @@ float bamScore(const uint8_t* p, const uint8_t* end) {
     const char ty = (char)p[2];
     p += 3;
     auto need = [&](size_t n) { if (p + n > end) die("", "Poorly formatted BAM auxiliary field"); };
+    if (isAS && ty != 'c' && ty != 'C' && ty != 's' && ty != 'S' && ty != 'i' && ty != 'I') {
+      char msg[4] = "' '";  // (an alignment score of another type -- 'A', 'f', ... -- is an error, 4782-4786)
+      msg[1] = ty;
+      die(msg, ": unknown value type in BAM auxiliary field");
+    }
     switch (ty) {
-      case 'A': case 'c': case 'C': need(1); if (isAS && ty != 'A') return ty == 'c' ? (float)(int8_t)p[0] : (float)p[0]; p += 1; break;
+      case 'A': case 'c': case 'C': need(1); if (isAS) return ty == 'c' ? (float)(int8_t)p[0] : (float)p[0]; p += 1; break;
       case 's': case 'S': { need(2); uint16_t v = (uint16_t)(p[0] | (p[1] << 8)); if (isAS) return ty == 's' ? (float)(int16_t)v : (float)v; p += 2; break; }
       case 'i': case 'I': { need(4); uint32_t v = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); if (isAS) return ty == 'i' ? (float)(int32_t)v : (float)v; p += 4; break; }
-      case 'f': { need(4); float f; memcpy(&f, p, 4); if (isAS) return f; p += 4; break; }
+      case 'f': need(4); p += 4; break;
       case 'Z': case 'H': while (p < end && *p) p++; p++; break;
-      case 'B': {
+      case 'B': {  // arrayLen 4712-4731
         need(5);
         char st = (char)p[0];
+        size_t w;
+        switch (st) {
+          case 'c': case 'C': w = 1; break;
+          case 's': case 'S': w = 2; break;
+          case 'i': case 'I': case 'f': w = 4; break;
+          default: {
+            char msg[4] = "' '";
+            msg[1] = st;
+            die(msg, ": unknown value type in BAM auxiliary field");
+          }
+        }
         uint32_t cnt = p[1] | (p[2] << 8) | (p[3] << 16) | ((uint32_t)p[4] << 24);
-        size_t w = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
         p += 5 + (size_t)cnt * w;
         break;
       }
@@ -935,7 +973,8 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     const uint8_t* whole = nullptr;
     if (p4) {
       const int32_t bs = (int32_t)(p4[0] | (p4[1] << 8) | (p4[2] << 16) | ((uint32_t)p4[3] << 24));
-      if (bs < 32) die("", "Cannot parse BAM file");
+      if (bs == -1) break;  // (see rdI32)
+      if (bs < 32) die("", "Cannot parse BAM file");  // (a negative size passes the reference's unsigned test and fails its end-of-block test, 4870 / 4885)
       whole = g.peek(4 + (size_t)bs);
       if (whole) {
         blk = whole + 4;
@@ -945,7 +984,7 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     }
     if (!whole) {
       int32_t bs = rdI32(g, false);
-      if (bs < 0) break;
+      if (bs == -1) break;
       if (bs < 32) die("", "Cannot parse BAM file");
       copy.resize((size_t)bs);
       if (!gzReadAll(g, copy.data(), (size_t)bs)) die("", "Cannot parse BAM file");
@@ -954,43 +993,39 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     }
     auto i32 = [&](size_t o) { return (int32_t)(blk[o] | (blk[o + 1] << 8) | (blk[o + 2] << 16) | ((uint32_t)blk[o + 3] << 24)); };
     auto u16 = [&](size_t o) { return (uint16_t)(blk[o] | (blk[o + 1] << 8)); };
+    // loadBAMfields 4660-4688: the name length is a signed byte, and only the end of the last field is
+    // checked against the block (4885).  (Offsets that leave the block on the way are an error here; the
+    // reference reads whatever its line buffer holds there.)
     const int32_t refID = i32(0), pos = i32(4);
-    const uint8_t l_read_name = blk[8], mapq = blk[9];
+    const int l_read_name = (int8_t)blk[8];
+    const uint8_t mapq = blk[9];
     const uint16_t n_cigar = u16(12), flag = u16(14);
     const int32_t l_seq = i32(16), next_pos = i32(24);
-    size_t off = 32;
-    if (off + l_read_name > blkLen) die("", "Cannot parse BAM file");
-    const char* qname = (const char*)&blk[off];
-    off += l_read_name;
-    const size_t cigOff = off;
-    off += (size_t)n_cigar * 4 + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
-    if (off > blkLen) die("", "Cannot parse BAM file");
+    const long long nameOff = 32, cigOff = nameOff + l_read_name, seqOff = cigOff + 4LL * n_cigar,
+                    qualOff = seqOff + (l_seq + 1) / 2, auxOff = qualOff + l_seq;
+    if (auxOff > (long long)blkLen) die("", "Cannot parse BAM file");
+    if (cigOff < 32 || seqOff > (long long)blkLen || qualOff < 32 || qualOff > (long long)blkLen || auxOff < 32 ||
+        !memchr(blk + nameOff, '\0', blkLen - (size_t)nameOff))
+      die("", "Cannot parse BAM file");
+    const char* qname = (const char*)&blk[nameOff];
+    const size_t off = (size_t)auxOff;
     C.count++;
     if (flag & 0x4) { C.unmapped++; continue; }
     if (!strcmp(qname, "*") || refID < 0 || refID >= n_ref || pos < 0) die(qname, ": poorly formatted SAM/BAM record");
     if (flag & 0xE00) { C.supp++; continue; }
     if (mapq < S.o.minMapQ) { C.lowMapQ++; continue; }
-    int length = l_seq, offset = 0;  // calcDistBAM: CIGAR ops consume as in parseCigar
-    if (n_cigar) {
-      int len = 0;
-      for (int k = 0; k < n_cigar; k++) {
-        uint32_t c = (uint32_t)i32(cigOff + 4 * (size_t)k);
-        int n = (int)(c >> 4), op = (int)(c & 15);
-        switch (op) {
-          case 0: case 7: case 8: len += n; break;       // M = X
-          case 1: case 4: len += n; offset -= n; break;  // I S
-          case 2: offset += n; break;                    // D
-          case 3: case 5: case 6: break;                 // N H P
-          default: die("", ": unknown Op in CIGAR");
-        }
-      }
-      if (!length) length = len;
-      else if (length != len) die(qname, ": mismatch between sequence length and CIGAR");
-    } else if (!length)
-      die(qname, ": no sequence information (SEQ or CIGAR)");
+    // calcDistBAM 4694-4706: the distance to the 3' end is l_seq - I - S + D, with no check of the CIGAR
+    // against the sequence (unlike calcDist for SAM) -- also when SEQ is absent (l_seq = 0)
+    int length = l_seq;
+    for (int k = 0; k < n_cigar; k++) {
+      const uint32_t c = (uint32_t)i32((size_t)cigOff + 4 * (size_t)k);
+      const int op = (int)(c & 15);
+      if (op == 1 || op == 4) length -= (int)(c >> 4);
+      else if (op == 2) length += (int)(c >> 4);
+    }
     float score = bamScore(blk + off, blk + blkLen);
-    record(S, rs, C, qname, flag, idx[refID], (uint32_t)pos, mapq, length + offset, (uint32_t)next_pos, score,
-           (const char*)blk + off - (size_t)l_seq, l_seq, 0);
+    record(S, rs, C, qname, flag, idx[refID], (uint32_t)pos, mapq, length, (uint32_t)next_pos, score,
+           (const char*)blk + qualOff, l_seq, 0);
   }
   finishFile(S, rs, C);
   return C.count;
@@ -1060,7 +1095,11 @@ bool sniffBam(In& in, char magic[4], int& got) {
   if (!in.compressed()) return false;
   for (int i = 0; i < 4; i++) {
     if (i >= got || (unsigned char)magic[i] == 0xFF) die("", ": cannot open file for reading");
-    if (magic[i] != "BAM\1"[i]) return false;
+    if (magic[i] != "BAM\1"[i]) {
+      // (the reference pushes the character back with gzungetc, which refuses a negative `char`)
+      if ((signed char)magic[i] < 0) die("", "Failure in ungetc() call");
+      return false;
+    }
   }
   return true;
 }
@@ -1098,17 +1137,9 @@ void scanHeader(State& S, const char* filename, bool ctrl) {
       saveChrom(S, nm.data(), (uint32_t)rdI32(in, true));
     }
   } else {
+    in.unread(magic, (size_t)std::max(0, got));
     std::vector<char> line(65520);
-    memcpy(line.data(), magic, (size_t)std::max(0, got));
-    line[std::max(0, got)] = '\0';
-    bool first = true;
-    for (;;) {
-      char* l = line.data();
-      if (first) {
-        first = false;
-        if (got > 0 && !memchr(magic, '\n', (size_t)got) && !in.gets(l + got, (int)line.size() - got)) l[got] = '\0';
-      } else if (!in.gets(l, (int)line.size()))
-        break;
+    while (char* l = in.gets(line.data(), (int)line.size())) {
       if (l[0] != '@') break;
       const bool sortSave = S.o.sortOpt;
       S.o.sortOpt = false;  // the sort-order check belongs to the real pass
@@ -1477,18 +1508,9 @@ int main(int argc, char** argv) {
       Counts C;
       if (bam)
         readBAM(S, in, C);
-      else if (got <= 0)
-        readSAM(S, in, nullptr, C);
       else {
-        // hand the 4 sniffed bytes back as the beginning of the first line
-        std::vector<char> firstLine(65520);
-        memcpy(firstLine.data(), magic, (size_t)got);
-        firstLine[got] = '\0';
-        if (!memchr(magic, '\n', (size_t)got)) {
-          if (!in.gets(firstLine.data() + got, (int)firstLine.size() - got)) firstLine[got] = '\0';
-        } else
-          die(filename, ": poorly formatted SAM/BAM record");
-        readSAM(S, in, firstLine.data(), C);
+        in.unread(magic, (size_t)std::max(0, got));  // the sniffed bytes are the beginning of the first line
+        readSAM(S, in, nullptr, C);
       }
       checkIn(in);
       if (!isStdin) in.close();

@@ -219,13 +219,18 @@ def write_sam_mixed(path, names, lens, ev, seed, read_len=50, name_prefix="m", f
         g.write(bytes(raw))
 
 
-def write_sam_dups(path, names, lens, ev, seed, read_len=50, name_prefix="d", bam=False):
+def write_sam_dups(path, names, lens, ev, seed, read_len=50, name_prefix="d", bam=False, quirks=0.0):
     """Queryname-grouped SAM / BAM for -r (PCR-duplicate removal, Genrich.c:3267-4042): proper
     pairs, singletons (mate unmapped), discordant pairs (both mates aligned, not as a proper
     pair, possibly on two chromosomes) and multi-mapped pairs with secondary alignments; about a
     quarter of the templates reuse the coordinates of an earlier one (the duplicates); base
-    qualities vary per read (they decide which copy is kept) and a few reads carry none."""
+    qualities vary per read (they decide which copy is kept) and a few reads carry none.
+    quirks > 0: that share of the records comes in forms that are valid but unusual and that the
+    reference treats in its own way -- SAM without optional fields (QUAL is then the last token of the
+    line and keeps its line feed, loadFields 4350), SAM / BAM without SEQ (calcDistBAM 4694 takes l_seq = 0
+    at face value, calcDist falls back to the CIGAR) and soft-clipped CIGARs."""
     rng = np.random.Generator(np.random.PCG64(seed))
+    qrng = np.random.Generator(np.random.PCG64(seed + 9999))  # (its own stream: quirks = 0 writes what it always wrote)
     recs = []  # (qname, flag, chrom, pos0, mapq, rl, rnext chrom or -1, pnext0, tlen, AS, qual array or None)
     used, used_dc = [], []
 
@@ -279,8 +284,17 @@ def write_sam_dups(path, names, lens, ev, seed, read_len=50, name_prefix="d", ba
             for nm, flag, c, pos, mapq, rl, rn, pn, tlen, sc, q in recs:
                 rnext = "*" if rn < 0 else ("=" if rn == c else names[rn])
                 qs = "*" if q is None else "".join(chr(33 + int(v)) for v in q)
-                f.write(f"{nm}\t{flag}\t{names[c]}\t{pos + 1}\t{mapq}\t{rl}M\t{rnext}\t{pn + 1}\t{tlen}\t"
-                        f"{'A' * rl}\t{qs}\tNM:i:0\tAS:i:{sc}\n")
+                seq, cigar, tags = "A" * rl, f"{rl}M", f"\tNM:i:0\tAS:i:{sc}"
+                if quirks:
+                    u = qrng.random(3)
+                    if u[0] < quirks:
+                        tags = ""
+                    if u[1] < quirks:
+                        seq = "*"
+                    if u[2] < quirks and rl > 12:
+                        cigar = f"4S{rl - 4}M"
+                f.write(f"{nm}\t{flag}\t{names[c]}\t{pos + 1}\t{mapq}\t{cigar}\t{rnext}\t{pn + 1}\t{tlen}\t"
+                        f"{seq}\t{qs}{tags}\n")
         return
     import gzip
     import struct
@@ -292,9 +306,18 @@ def write_sam_dups(path, names, lens, ev, seed, read_len=50, name_prefix="d", ba
     for nm, flag, c, pos, mapq, rl, rn, pn, tlen, sc, q in recs:
         cig = struct.pack("<I", (rl << 4) | 0)
         aux = b"NMC\0" + b"ASc" + struct.pack("<b", sc)
-        body = struct.pack("<iiBBHHHiiii", c, pos, len(nm) + 1, mapq, 0, 1, flag, rl, rn, pn, tlen)
-        qb = b"\xff" * rl if q is None else bytes(q.tolist())
-        body += nm.encode() + b"\0" + cig + b"\x11" * ((rl + 1) // 2) + qb + aux
+        ncig, lseq = 1, rl
+        if quirks:
+            u = qrng.random(3)
+            if u[0] < quirks:
+                aux = b""
+            if u[2] < quirks and rl > 12:
+                cig, ncig = struct.pack("<II", (4 << 4) | 4, ((rl - 4) << 4) | 0), 2
+            if u[1] < quirks:
+                lseq = 0
+        body = struct.pack("<iiBBHHHiiii", c, pos, len(nm) + 1, mapq, 0, ncig, flag, lseq, rn, pn, tlen)
+        qb = b"\xff" * lseq if q is None else bytes(q.tolist())[:lseq]
+        body += nm.encode() + b"\0" + cig + b"\x11" * ((lseq + 1) // 2) + qb + aux
         raw += struct.pack("<i", len(body)) + body
     with gzip.GzipFile(path, "wb", mtime=0) as g:
         g.write(bytes(raw))

@@ -153,6 +153,15 @@ def cases():
             name=nm, names=N2, args=extra + ["-a", "20"], mixed=dict(seed=21, bam=isbam, writer="dups"),
             reps=[dict(t=(N2, L2, mf(L2, 2500, 97)), c=(N2, L2, mf(L2, 2000, 98, uniform_only=True)))])
 
+    # valid but unusual records: SAM lines without optional fields (QUAL keeps its line feed), records
+    # without SEQ (the BAM reader takes l_seq = 0 at face value), soft clips -- with -r, where qualities count
+    # (the BAM case keeps to proper pairs: on an unpaired reverse read without SEQ the reference's own
+    # arithmetic ends in "Invalid pileup value (< 0)")
+    for nm, extra, isbam in (("quirks_sam", ["-r", "-y"], False), ("quirks_bam", ["-r"], True)):
+        yield dict(
+            name=nm, names=N2, args=extra + ["-a", "20"], mixed=dict(seed=33, bam=isbam, writer="dups", quirks=0.3),
+            reps=[dict(t=(N2, L2, mf(L2, 2000, 101)), c=(N2, L2, mf(L2, 1500, 102, uniform_only=True)))])
+
     # -X: no peak calling, just the -f log (logIntervals, Genrich.c:837)
     yield dict(
         name="nopeaks_log", names=N2, args=["-X", "-q", "0.05"],
@@ -172,7 +181,8 @@ P_RUNS = {
 def write_input(path, names, lens, ev, mixed, seed_off, prefix):
     """The synthetic SAM / BAM input of one sample, by the writer the case asks for."""
     if mixed and mixed.get("writer") == "dups":
-        synth.write_sam_dups(path, names, lens, ev, mixed["seed"] + seed_off, name_prefix=prefix, bam=mixed["bam"])
+        synth.write_sam_dups(path, names, lens, ev, mixed["seed"] + seed_off, name_prefix=prefix, bam=mixed["bam"],
+                             quirks=mixed.get("quirks", 0.0))
     elif mixed:
         synth.write_sam_mixed(path, names, lens, ev, mixed["seed"] + seed_off, name_prefix=prefix, bam=mixed["bam"])
     else:

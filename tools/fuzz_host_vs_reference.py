@@ -28,9 +28,10 @@ def one(seed):
     ct=synth.make_fragments(L, rng.randint(300,3000), seed=seed+1, uniform_only=True)
     writer=rng.choice(["mixed","dups","plain"]); bam=rng.random()<0.4 and writer!="plain"
     ext="bam" if bam else "sam"
+    quirks=rng.choice([0.0,0.0,0.25])   # records without optional fields / without SEQ, soft clips
     def wr(p,e,s,pre):
         if writer=="mixed": synth.write_sam_mixed(p,N2,L,e,s,name_prefix=pre,bam=bam)
-        elif writer=="dups": synth.write_sam_dups(p,N2,L,e,s,name_prefix=pre,bam=bam)
+        elif writer=="dups": synth.write_sam_dups(p,N2,L,e,s,name_prefix=pre,bam=bam,quirks=quirks)
         else: synth.write_sam(p,N2,L,e,name_prefix=pre)
     t=f"{d}/t.{ext}"; c=f"{d}/c.{ext}"; wr(t,ev,seed,"t_"); wr(c,ct,seed+7,"c_")
     threads=[]
@@ -70,19 +71,25 @@ def one(seed):
         subprocess.run(["rm","-rf",d]); return None   # the reference stops after the treatment file; the events-only host goes on
     if r.returncode!=0 or h.returncode!=0:
         # events-only host stops before the statistics: compare only when the reference got past ingest
-        if "Experimental sample" in r.stderr or "No analyzable" in r.stderr or "peak" in r.stderr.lower():
+        if "Experimental sample" in r.stderr or "No analyzable" in r.stderr or "peak" in r.stderr.lower() or "Invalid pileup" in r.stderr:
             pass
         elif r.returncode!=h.returncode:
             return f"seed {seed}: rc ref={r.returncode} hip={h.returncode}\n{' '.join(args)}\nREF: {r.stderr[-300:]}\nHIP: {h.stderr[-300:]}"
     if os.path.exists(f"{d}/ref.bed") and os.path.exists(f"{d}/hip.bed"):
-        if open(f"{d}/ref.bed","rb").read()!=open(f"{d}/hip.bed","rb").read():
+        rb,hb=open(f"{d}/ref.bed","rb").read(),open(f"{d}/hip.bed","rb").read()
+        # (a reference that stopped in its statistics has written the events up to that point only)
+        if (rb!=hb) if r.returncode==0 else (not hb.startswith(rb[:rb.rfind(b"\n")+1])):
             return f"seed {seed}: -b differs: {' '.join(args)}"
-    if dups and os.path.exists(f"{d}/ref.dups") and open(f"{d}/ref.dups","rb").read()!=open(f"{d}/hip.dups","rb").read():
-        return f"seed {seed}: -R differs: {' '.join(args)}"
+    if dups and os.path.exists(f"{d}/ref.dups"):
+        rd,hd=open(f"{d}/ref.dups","rb").read(),open(f"{d}/hip.dups","rb").read()
+        if (rd!=hd) if r.returncode==0 else (not hd.startswith(rd[:rd.rfind(b"\n")+1])):
+            return f"seed {seed}: -R differs: {' '.join(args)}"
     # verbose accounting lines (up to the point the host stops)
     def acct(txt): return [l for l in txt.splitlines() if l.startswith("  ") or l.startswith("Processing") or "Warning" in l]
     ra_,ha_=acct(r.stderr),acct(h.stderr)
     ra_=[l for l in ra_ if "Background" not in l and "Scaling" not in l and "Genome length" not in l]
+    if r.returncode!=0:   # the reference stopped in its statistics: its log ends there
+        ra_=[l for l in ra_ if "internal error" not in l]; ha_=ha_[:len(ra_)]
     if ra_[:len(ha_)]!=ha_: 
         import difflib
         return f"seed {seed}: -v differs: {' '.join(args)}\n"+"\n".join(list(difflib.unified_diff(ra_,ha_,lineterm=''))[:20])
