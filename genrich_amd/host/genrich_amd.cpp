@@ -1179,12 +1179,16 @@ void loadBED(State& S, const char* files) {  // loadBED 5187-5238
     In in;
   openRead(in, fn);
     while (in.gets(line.data(), (int)line.size())) {
-      std::string orig(line.data());
+      // in the reference's order (5203-5213): a field is converted as soon as it has been cut off, and a
+      // missing one is reported with what strtok has left of the line, i.e. the name
       char* name = strtok(line.data(), "\t");
-      char* a = name ? strtok(nullptr, "\t") : nullptr;
-      char* b = a ? strtok(nullptr, "\t\n") : nullptr;
-      if (!name || !a || !b) die(orig, ": poorly formatted BED record");
-      int p0 = getInt(a), p1 = getInt(b);
+      if (!name) die(line.data(), ": poorly formatted BED record");
+      char* a = strtok(nullptr, "\t");
+      if (!a) die(line.data(), ": poorly formatted BED record");
+      const int p0 = getInt(a);
+      char* b = strtok(nullptr, "\t\n");
+      if (!b) die(line.data(), ": poorly formatted BED record");
+      const int p1 = getInt(b);
       if (p1 <= p0 || p0 < 0 || p1 < 0) {
         char msg[512];
         snprintf(msg, sizeof msg, "%s, %d - %d", name, p0, p1);
