@@ -936,23 +936,27 @@ float bamScore(const uint8_t* p, const uint8_t* end) {
   return NOSCORE;
 }
 
+// the text part of a BAM header (readBAM 5007-5031): only its first line is looked at -- it must be an @HD
+// line, and with the sort-order check on, one that says SO:queryname
+void bamHeaderText(State& S, In& g) {
+  int32_t l_text = rdI32(g, true);
+  std::vector<char> text((size_t)std::max(0, l_text) + 1, 0);
+  if (l_text > 0 && !gzReadAll(g, text.data(), (size_t)l_text)) die("", "Cannot parse BAM file");
+  std::string firstLine(text.data(), strcspn(text.data(), "\n"));
+  std::vector<char> tmp(firstLine.begin(), firstLine.end());
+  tmp.push_back('\0');
+  char* tag = strtok(tmp.data(), "\t");
+  if (!tag || strcmp(tag, "@HD")) die("", "Cannot parse BAM file");
+  const char* order = nullptr;
+  for (char* f = strtok(nullptr, "\t"); f; f = strtok(nullptr, "\t"))
+    if (!strncmp(f, "SO:", 3)) order = f + 3;
+  if (S.o.sortOpt && (!order || strcmp(order, "queryname")))
+    die("", "SAM/BAM file not sorted by queryname (samtools sort -n)");
+}
+
 uint64_t readBAM(State& S, In& in, Counts& C) {
   In& g = in;
-  int32_t l_text = rdI32(g, true);
-  std::vector<char> text((size_t)l_text + 1, 0);
-  if (!gzReadAll(g, text.data(), (size_t)l_text)) die("", "Cannot parse BAM file");
-  {  // first header line: @HD with the sort order
-    std::string firstLine(text.data(), strcspn(text.data(), "\n"));
-    std::vector<char> tmp(firstLine.begin(), firstLine.end());
-    tmp.push_back('\0');
-    char* tag = strtok(tmp.data(), "\t");
-    if (!tag || strcmp(tag, "@HD")) die("", "Cannot parse BAM file");
-    const char* order = nullptr;
-    for (char* f = strtok(nullptr, "\t"); f; f = strtok(nullptr, "\t"))
-      if (!strncmp(f, "SO:", 3)) order = f + 3;
-    if (S.o.sortOpt && (!order || strcmp(order, "queryname")))
-      die("", "SAM/BAM file not sorted by queryname (samtools sort -n)");
-  }
+  bamHeaderText(S, g);
   int32_t n_ref = rdI32(g, true);
   std::vector<int> idx((size_t)std::max(0, n_ref));
   for (int i = 0; i < n_ref; i++) {
@@ -1126,8 +1130,7 @@ void scanHeader(State& S, const char* filename, bool ctrl) {
   char magic[4];
   int got = 0;
   if (sniffBam(in, magic, got)) {
-    int32_t l_text = rdI32(in, true);
-    if (!in.skip((size_t)l_text)) die("", "Cannot parse BAM file");
+    bamHeaderText(S, in);
     int32_t n_ref = rdI32(in, true);
     for (int i = 0; i < n_ref; i++) {
       int32_t len = rdI32(in, true);
