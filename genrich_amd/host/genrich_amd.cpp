@@ -1314,7 +1314,9 @@ void peaksOnly(State& S, float thr) {
       continue;
     }
     const float pq = getFloat(stat);
-    const float pv = o.qvalOpt ? getFloat(pStat) : pq, qv = o.qvalOpt ? pq : GX_SKIP;
+    // (with -q the p-value column is converted only where a significant stretch needs it, 1402 / 1452)
+    auto pvNow = [&]() { return o.qvalOpt ? getFloat(pStat) : pq; };
+    const float qv = o.qvalOpt ? pq : GX_SKIP;
     if (bedPos == start) {  // 1376-1390
       if (save) { check(chrName); P.reset(); }
       save = !save;
@@ -1323,7 +1325,7 @@ void peaksOnly(State& S, float thr) {
     uint32_t subStart = start;
     while (bedPos > start && bedPos < end) {  // new -E edges inside the interval, 1395-1425
       if (save) {
-        if (pq > thr) P.update(subStart, bedPos, pq, thr, pv, qv);
+        if (pq > thr) P.update(subStart, bedPos, pq, thr, pvNow(), qv);
         check(chrName);
         P.reset();
         if (genomeOpt) genomeLen += bedPos - subStart;
@@ -1337,7 +1339,7 @@ void peaksOnly(State& S, float thr) {
     start = subStart;
     if (genomeOpt) genomeLen += end - start;
     if (pq > thr)
-      P.update(start, end, pq, thr, pv, qv);
+      P.update(start, end, pq, thr, pvNow(), qv);
     else if ((int64_t)end - P.peakEnd > o.maxGap) {
       check(chrName);
       P.reset();
