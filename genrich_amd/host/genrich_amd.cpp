@@ -1124,8 +1124,8 @@ void scanHeader(State& S, const char* filename, bool ctrl) {
   In& in = isStdin ? openStdin(S) : file;
   if (isStdin)
     in.record();
-  else
-    openRead(in, filename);
+  else if (!in.open(filename, g_threads))
+    return;  // reported when the real pass gets to this file, where the reference would find out
   S.ctrl = ctrl;
   char magic[4];
   int got = 0;
