@@ -20,17 +20,66 @@ def bgzf(data, rng):
         if not chunk: break
         off+=len(chunk)
     return bytes(out)
+def write_wild(path, names, lens, seed, nreads, prefix):
+    """Syntactically valid SAM with alignment sets of every shape: 1-6 alignments per read name (now and then
+    more than the reference's 128-alignment buffer), free combinations of the paired / proper / mate-unmapped /
+    strand / first / last / secondary flags, mates that point at each other or nowhere, any chromosome,
+    assorted CIGARs, scores present or not, SEQ / QUAL present or '*'."""
+    rng=random.Random(seed)
+    cigars=["50M","20M2D30M","5S45M","45M5S","10M3I37M","25M100N25M","5H50M","50=","30M2X18M","1M","3S20M2D20M7S"]
+    qlen={"50M":50,"20M2D30M":50,"5S45M":50,"45M5S":50,"10M3I37M":50,"25M100N25M":50,"5H50M":50,"50=":50,"30M2X18M":50,"1M":1,"3S20M2D20M7S":50}
+    with open(path,"w") as f:
+        f.write("@HD\tVN:1.0\tSO:queryname\n")
+        for n,l in zip(names,lens): f.write(f"@SQ\tSN:{n}\tLN:{l}\n")
+        for i in range(nreads):
+            nm=f"{prefix}{i}"
+            k=rng.choice([1,1,2,2,2,3,4,6]) if rng.random()>0.01 else rng.randint(125,135)
+            alns=[]
+            for a in range(k):
+                c=rng.randrange(len(names)); pos=rng.randint(1,max(1,lens[c]-60))
+                alns.append([c,pos])
+            npair=0
+            if rng.random()<0.6:     # the set begins with one or two coherent proper pairs (the second one secondary)
+                for sec in ([0] if rng.random()<0.6 else [0,256]):
+                    c=rng.randrange(len(names)); p1=rng.randint(1,max(1,lens[c]-400)); p2=p1+rng.randint(0,300)
+                    sc=rng.randint(-30,0)
+                    order=[(99|sec,p1,p2),(147|sec,p2,p1)]
+                    if rng.random()<0.3: order.reverse()
+                    for fl,pa,pb in order:
+                        tg=[f"AS:i:{sc+rng.choice([0,0,-1])}"] if rng.random()<0.9 else []
+                        f.write("\t".join([nm,str(fl),names[c],str(pa),str(rng.choice([0,10,30,42])),"50M","=",str(pb),"0","A"*50,"I"*50]+tg)+"\n")
+                    npair+=1
+            for a,(c,pos) in enumerate(alns if not npair or rng.random()<0.5 else []):
+                flag=0
+                for bit,pr in ((1,0.8),(2,0.6),(8,0.15),(16,0.5),(32,0.5),(256,0.3),(4,0.03),(2048,0.03),(1024,0.02)):
+                    if rng.random()<pr: flag|=bit
+                if flag&1: flag|=rng.choice([64,128])          # (neither or both: the reference stops with an error)
+                elif rng.random()<0.3: flag|=rng.choice([64,128,192])
+                if rng.random()<0.6 and len(alns)>1:   # mate = another alignment of the set
+                    m=alns[rng.randrange(len(alns))]; rnext="=" if m[0]==c else names[m[0]]; pnext=m[1]
+                else:
+                    rnext=rng.choice(["*","=",names[rng.randrange(len(names))]]); pnext=rng.randint(0,lens[c])
+                cg=rng.choice(cigars)
+                if rng.random()<0.15: seq,qual="*","*"
+                else:
+                    seq="A"*qlen[cg]; qual="".join(chr(33+rng.randint(2,40)) for _ in range(qlen[cg])) if rng.random()<0.8 else "*"
+                tags=[]
+                if rng.random()<0.85: tags.append(f"AS:i:{rng.randint(-40,0)}")
+                if rng.random()<0.5: tags.insert(rng.randrange(len(tags)+1),"NM:i:1")
+                if rng.random()<0.2: tags.append("YS:i:-3")
+                f.write("\t".join([nm,str(flag),names[c],str(pos),str(rng.choice([0,1,10,30,42])),cg,rnext,str(pnext),str(rng.randint(-500,500)),seq,qual]+tags)+"\n")
 def one(seed):
     rng=random.Random(seed)
     L=[rng.randint(20_000,60_000), rng.randint(10_000,40_000), rng.randint(2_000,8_000)]
     d=f"/tmp/fuzz/c{seed}"; os.makedirs(d,exist_ok=True)
     ev=synth.make_fragments(L, rng.randint(300,3000), seed=seed)
     ct=synth.make_fragments(L, rng.randint(300,3000), seed=seed+1, uniform_only=True)
-    writer=rng.choice(["mixed","dups","plain"]); bam=rng.random()<0.4 and writer!="plain"
+    writer=rng.choice(["mixed","dups","plain"]) if "--wild" not in sys.argv else "wild"; bam=rng.random()<0.4 and writer not in ("plain","wild")
     ext="bam" if bam else "sam"
     quirks=rng.choice([0.0,0.0,0.25])   # records without optional fields / without SEQ, soft clips
     def wr(p,e,s,pre):
         if writer=="mixed": synth.write_sam_mixed(p,N2,L,e,s,name_prefix=pre,bam=bam)
+        elif writer=="wild": write_wild(p,N2,L,s,rng.randint(100,800),pre)
         elif writer=="dups": synth.write_sam_dups(p,N2,L,e,s,name_prefix=pre,bam=bam,quirks=quirks)
         else: synth.write_sam(p,N2,L,e,name_prefix=pre)
     t=f"{d}/t.{ext}"; c=f"{d}/c.{ext}"; wr(t,ev,seed,"t_"); wr(c,ct,seed+7,"c_")
