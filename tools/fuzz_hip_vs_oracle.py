@@ -3,6 +3,8 @@ usage: fuzz_hip_vs_oracle.py SEED0 SEED1 [--mid]
 
 default: the generator of tests/test_hip_parity.py::test_random_runs_against_oracle (small runs)
 --mid:   1-4 chromosomes of 0.2-6 Mbases, 0.1-0.9 M fragments (deep towers, multimapping, control)
+--extreme: thresholds at and beyond their ends (-p / -q of 1, 0.999, 1e-30, 1e-300; -a 0, 1e6; -g 0,
+         100000; -l 100000) on top of whichever generator is chosen
 --x50:   the default generator (skipped chromosomes, -E regions, replicates, -p / -q, -a / -l / -g) with
          chromosomes and samples 50 times larger
 
@@ -41,6 +43,12 @@ mid = "--mid" in sys.argv
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     case, params = mid_case(seed) if mid else T._random_case(seed, 50 if "--x50" in sys.argv else 1)
+    if "--extreme" in sys.argv:
+        r = np.random.default_rng(seed + 77)
+        qv = bool(r.random() < 0.5)
+        params = B.make_params(pq=float(r.choice([1, 0.999, 1e-30, 1e-300, 0.05])), qval=qv,
+                               min_auc=float(r.choice([0, 0.001, 1e6, 20])), min_len=int(r.choice([0, 100000])),
+                               max_gap=int(r.choice([0, 100, 100000])))
     try:
         o, h, so, sh = T.run_both(case, params)
         T.assert_same_run(o, h, so, sh, case)

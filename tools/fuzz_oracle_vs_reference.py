@@ -31,11 +31,11 @@ def one(seed):
     args=["-t",",".join(tf)]
     if any(cf): args+=["-c",",".join(c if c else "null" for c in cf)]
     extra=[]
-    if rng.random()<0.5: extra+=["-q",str(rng.choice([0.05,0.2,0.5]))]
-    else: extra+=["-p",str(rng.choice([0.01,0.05,0.001]))]
-    extra+=["-a",str(rng.choice([5,20,50,200]))]
-    if rng.random()<0.3: extra+=["-l",str(rng.randint(0,200))]
-    if rng.random()<0.3: extra+=["-g",str(rng.randint(0,300))]
+    if rng.random()<0.5: extra+=["-q",str(rng.choice([0.05,0.2,0.5,1,0.999,1e-30]))]
+    else: extra+=["-p",str(rng.choice([0.01,0.05,0.001,1,0.999,1e-30,1e-300]))]
+    extra+=["-a",str(rng.choice([5,20,50,200,0,0.001,1e6]))]
+    if rng.random()<0.3: extra+=["-l",str(rng.choice([rng.randint(0,200),100000]))]
+    if rng.random()<0.3: extra+=["-g",str(rng.choice([rng.randint(0,300),0,100000]))]
     if rng.random()<0.3: extra+=["-e",rng.choice(["chr3","chr2"])]
     bed=[]
     if rng.random()<0.35:
