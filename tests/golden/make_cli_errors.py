@@ -1,0 +1,61 @@
+"""Build container only (needs oracle/_ref/Genrich): a table of small damaged or unusual SAM inputs with
+what the reference makes of them -- exit status, its `Error!` line, and the -b event stream when it gets
+that far.  Written to tests/golden/cli_errors.json.gz; replayed against the host program by
+tests/test_host_cli.py::test_cli_damaged_sam_as_the_reference.  Data only: the inputs are synthetic, the
+expected values are the reference's output.  usage: python tests/golden/make_cli_errors.py"""
+import gzip, json, os, random, subprocess, sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from genrich_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "Genrich")
+N2 = ["chr1", "chr2"]
+L = [9000, 5000]
+
+
+def load_mutator():
+    src = open(os.path.join(ROOT, "tools", "fuzz_host_malformed.py")).read().split("def one(seed):")[0]
+    ns = {"__file__": os.path.join(ROOT, "tools", "fuzz_host_malformed.py")}
+    exec(compile(src, "fuzz_host_malformed", "exec"), ns)
+    return ns["mutate_sam"]
+
+
+def main():
+    mutate_sam = load_mutator()
+    out = []
+    tmp = "/tmp/genrich_cli_errors"
+    os.makedirs(tmp, exist_ok=True)
+    seen = set()
+    for seed in range(400):
+        rng = random.Random(seed)
+        ev = synth.make_fragments(L, 12, seed=seed)
+        p = os.path.join(tmp, "t.sam")
+        (synth.write_sam_mixed if seed % 2 else synth.write_sam_dups)(p, N2, L, ev, seed, name_prefix="t_")
+        text, kind = mutate_sam(open(p).read(), rng)
+        open(p, "w").write(text)
+        args = rng.choice([[], ["-y"], ["-r"], ["-y", "-r"], ["-x"]])
+        bed = os.path.join(tmp, "ref.bed")
+        if os.path.exists(bed):
+            os.remove(bed)
+        r = subprocess.run([REF, "-t", p] + args + ["-b", bed, "-o", "/dev/null"], capture_output=True, text=True, errors="replace")
+        if r.returncode not in (0, 1):
+            continue
+        err = next((l for l in r.stderr.splitlines() if l.startswith("Error!")), "")
+        late = any(k in err for k in ("no analyzable fragments", "Experimental sample", "peak", "No analyzable", "Invalid pileup"))
+        key = (kind, err.split(":")[-1], tuple(args))
+        if key in seen and kind != "none":
+            continue
+        seen.add(key)
+        out.append(dict(kind=kind, args=args, sam=text, rc=0 if (late or r.returncode == 0) else 1, error="" if late else err,
+                        events=open(bed).read() if os.path.exists(bed) and (late or r.returncode == 0) else None))
+        if len(out) >= 90:
+            break
+    with gzip.GzipFile(os.path.join(HERE, "cli_errors.json.gz"), "wb", mtime=0) as g:
+        g.write(json.dumps(out, indent=0).encode())
+    print(len(out), "cases;", sum(1 for c in out if c["rc"]), "failing")
+
+
+main()

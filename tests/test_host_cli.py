@@ -247,3 +247,29 @@ def test_cli_refuses_compressed_or_empty_stdin(tmp_path):
             z.write_bytes(wrap(content))
             res = subprocess.run([_binary(), "--events-only", "--threads", "2", "-t", str(z)], capture_output=True)
             assert res.returncode != 0 and b"Error! : cannot open file for reading" in res.stderr
+
+
+def test_cli_damaged_sam_as_the_reference(tmp_path):
+    """90 small SAM inputs with a field dropped or emptied, a non-numeric value, a broken CIGAR or tag, a
+    changed or misplaced header line, a truncation ... and what the reference made of each (its exit status,
+    its `Error!` line, its -b stream): tests/golden/cli_errors.json.gz, written by make_cli_errors.py from the
+    reference binary.  The host program must cut the lines up, convert and complain in the same order."""
+    import json
+    cases = json.loads(gzip.open(os.path.join(G.GOLDEN, "cli_errors.json.gz")).read())
+    assert len(cases) >= 80
+    sam = tmp_path / "t.sam"
+    bed = tmp_path / "e.bed"
+    for k, c in enumerate(cases):
+        sam.write_text(c["sam"])
+        if bed.exists():
+            bed.unlink()
+        res = subprocess.run([_binary(), "--events-only", "-t", str(sam), "-b", str(bed)] + c["args"],
+                             capture_output=True, text=True, errors="replace")
+        what = f"case {k} ({c['kind']}, {' '.join(c['args'])})"
+        err = next((l for l in res.stderr.splitlines() if l.startswith("Error!")), "")
+        if c["rc"]:
+            assert res.returncode != 0 and err == c["error"], f"{what}: {err!r} instead of {c['error']!r}"
+        else:
+            assert res.returncode == 0, f"{what}: {err}"
+            if c["events"] is not None:
+                assert bed.read_text() == c["events"], what
