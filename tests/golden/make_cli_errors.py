@@ -20,11 +20,11 @@ def load_mutator():
     src = open(os.path.join(ROOT, "tools", "fuzz_host_malformed.py")).read().split("def one(seed):")[0]
     ns = {"__file__": os.path.join(ROOT, "tools", "fuzz_host_malformed.py")}
     exec(compile(src, "fuzz_host_malformed", "exec"), ns)
-    return ns["mutate_sam"]
+    return ns["mutate_sam"], ns["mutate_bam"]
 
 
 def main():
-    mutate_sam = load_mutator()
+    mutate_sam, mutate_bam = load_mutator()
     out = []
     tmp = "/tmp/genrich_cli_errors"
     os.makedirs(tmp, exist_ok=True)
@@ -53,9 +53,40 @@ def main():
                         events=open(bed).read() if os.path.exists(bed) and (late or r.returncode == 0) else None))
         if len(out) >= 90:
             break
+    nsam = len(out)
+    import base64
+    for seed in range(1000, 3000):   # the same for BAM: truncations and single flipped bits
+        rng = random.Random(seed)
+        ev = synth.make_fragments(L, 12, seed=seed)
+        p = os.path.join(tmp, "t.bam")
+        (synth.write_sam_mixed if seed % 2 else synth.write_sam_dups)(p, N2, L, ev, seed, name_prefix="t_", bam=True)
+        data, kind = mutate_bam(gzip.decompress(open(p, "rb").read()), rng)
+        z = gzip.compress(data, mtime=0)
+        open(p, "wb").write(z)
+        args = rng.choice([[], ["-y"], ["-r"], ["-y", "-r"], ["-x"]])
+        bed = os.path.join(tmp, "ref.bed")
+        if os.path.exists(bed):
+            os.remove(bed)
+        r = subprocess.run([REF, "-t", p] + args + ["-b", bed, "-o", "/dev/null"], capture_output=True, text=True, errors="replace")
+        if r.returncode not in (0, 1):
+            continue
+        # (not the inputs on which the reference reads outside its buffer: a negative l_seq, a name length >= 128)
+        err = next((l for l in r.stderr.splitlines() if l.startswith("Error!")), "")
+        late = any(k in err for k in ("no analyzable fragments", "Experimental sample", "peak", "No analyzable", "Invalid pileup"))
+        key = ("bam", kind, err.split(":")[-1], tuple(args))
+        if r.returncode == 0 or late:
+            key += (seed % 6,)
+        if key in seen:
+            continue
+        seen.add(key)
+        out.append(dict(kind="bam " + kind, args=args, bam=base64.b64encode(z).decode(), rc=0 if (late or r.returncode == 0) else 1,
+                        error="" if late else err,
+                        events=open(bed, errors="replace").read() if os.path.exists(bed) and (late or r.returncode == 0) else None))
+        if len(out) >= nsam + 60:
+            break
     with gzip.GzipFile(os.path.join(HERE, "cli_errors.json.gz"), "wb", mtime=0) as g:
         g.write(json.dumps(out, indent=0).encode())
-    print(len(out), "cases;", sum(1 for c in out if c["rc"]), "failing")
+    print(len(out), "cases;", sum(1 for c in out if c["rc"]), "failing;", len(out) - nsam, "BAM")
 
 
 main()

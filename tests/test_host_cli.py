@@ -250,17 +250,23 @@ def test_cli_refuses_compressed_or_empty_stdin(tmp_path):
 
 
 def test_cli_damaged_sam_as_the_reference(tmp_path):
-    """90 small SAM inputs with a field dropped or emptied, a non-numeric value, a broken CIGAR or tag, a
-    changed or misplaced header line, a truncation ... and what the reference made of each (its exit status,
+    """Small SAM inputs with a field dropped or emptied, a non-numeric value, a broken CIGAR or tag, a changed
+    or misplaced header line, a truncation ..., BAM inputs truncated or with one bit flipped, and what the
+    reference made of each (its exit status,
     its `Error!` line, its -b stream): tests/golden/cli_errors.json.gz, written by make_cli_errors.py from the
     reference binary.  The host program must cut the lines up, convert and complain in the same order."""
     import json
     cases = json.loads(gzip.open(os.path.join(G.GOLDEN, "cli_errors.json.gz")).read())
     assert len(cases) >= 80
-    sam = tmp_path / "t.sam"
+    import base64
     bed = tmp_path / "e.bed"
     for k, c in enumerate(cases):
-        sam.write_text(c["sam"])
+        if "bam" in c:
+            sam = tmp_path / "t.bam"
+            sam.write_bytes(base64.b64decode(c["bam"]))
+        else:
+            sam = tmp_path / "t.sam"
+            sam.write_text(c["sam"])
         if bed.exists():
             bed.unlink()
         res = subprocess.run([_binary(), "--events-only", "-t", str(sam), "-b", str(bed)] + c["args"],
@@ -272,4 +278,4 @@ def test_cli_damaged_sam_as_the_reference(tmp_path):
         else:
             assert res.returncode == 0, f"{what}: {err}"
             if c["events"] is not None:
-                assert bed.read_text() == c["events"], what
+                assert bed.read_text(errors="replace") == c["events"], what
