@@ -20,7 +20,7 @@ def bgzf(data, rng):
         if not chunk: break
         off+=len(chunk)
     return bytes(out)
-def write_wild(path, names, lens, seed, nreads, prefix):
+def write_wild(path, names, lens, seed, nreads, prefix, bam=False):
     """Syntactically valid SAM with alignment sets of every shape: 1-6 alignments per read name (now and then
     more than the reference's 128-alignment buffer), free combinations of the paired / proper / mate-unmapped /
     strand / first / last / secondary flags, mates that point at each other or nowhere, any chromosome,
@@ -28,7 +28,9 @@ def write_wild(path, names, lens, seed, nreads, prefix):
     rng=random.Random(seed)
     cigars=["50M","20M2D30M","5S45M","45M5S","10M3I37M","25M100N25M","5H50M","50=","30M2X18M","1M","3S20M2D20M7S"]
     qlen={"50M":50,"20M2D30M":50,"5S45M":50,"45M5S":50,"10M3I37M":50,"25M100N25M":50,"5H50M":50,"50=":50,"30M2X18M":50,"1M":1,"3S20M2D20M7S":50}
-    with open(path,"w") as f:
+    import io
+    f=io.StringIO()
+    if True:
         f.write("@HD\tVN:1.0\tSO:queryname\n")
         for n,l in zip(names,lens): f.write(f"@SQ\tSN:{n}\tLN:{l}\n")
         for i in range(nreads):
@@ -68,18 +70,46 @@ def write_wild(path, names, lens, seed, nreads, prefix):
                 if rng.random()<0.5: tags.insert(rng.randrange(len(tags)+1),"NM:i:1")
                 if rng.random()<0.2: tags.append("YS:i:-3")
                 f.write("\t".join([nm,str(flag),names[c],str(pos),str(rng.choice([0,1,10,30,42])),cg,rnext,str(pnext),str(rng.randint(-500,500)),seq,qual]+tags)+"\n")
+    if bam: open(path,"wb").write(sam_to_bam(f.getvalue(),names))
+    else: open(path,"w").write(f.getvalue())
+def sam_to_bam(text, names):
+    """the records of write_wild as BAM (integer tags as one signed / unsigned byte when they fit)"""
+    import struct, re
+    hdr="".join(l+"\n" for l in text.split("\n") if l.startswith("@"))
+    raw=bytearray(b"BAM\1"+struct.pack("<i",len(hdr))+hdr.encode()+struct.pack("<i",len(names)))
+    lens={}
+    for l in hdr.split("\n"):
+        if l.startswith("@SQ"):
+            d=dict(x.split(":",1) for x in l.split("\t")[1:]); lens[d["SN"]]=int(d["LN"])
+    for n in names: raw+=struct.pack("<i",len(n)+1)+n.encode()+b"\0"+struct.pack("<i",lens[n])
+    idx={n:i for i,n in enumerate(names)}; ops="MIDNSHP=X"
+    for l in text.split("\n"):
+        if not l or l.startswith("@"): continue
+        q,flag,rn,pos,mapq,cg,rnext,pnext,tlen,seq,qual,*tags=l.split("\t")
+        cig=b"".join(struct.pack("<I",(int(n)<<4)|ops.index(o)) for n,o in re.findall(r"(\d+)([MIDNSHP=X])",cg))
+        lseq=0 if seq=="*" else len(seq)
+        sq=b"\x11"*((lseq+1)//2); ql=(b"\xff"*lseq) if qual=="*" else bytes(ord(c)-33 for c in qual)
+        aux=b""
+        for t in tags:
+            tg,ty,v=t.split(":"); v=int(v)
+            aux+=tg.encode()+((b"c"+struct.pack("<b",v)) if -128<=v<0 else (b"C"+struct.pack("<B",v)) if 0<=v<256 else (b"i"+struct.pack("<i",v)))
+        nref=idx[rn] if rnext=="=" else (idx[rnext] if rnext in idx else -1)
+        body=struct.pack("<iiBBHHHiiii",idx[rn],int(pos)-1,len(q)+1,int(mapq),0,len(cig)//4,int(flag),lseq,nref,int(pnext)-1,int(tlen))
+        body+=q.encode()+b"\0"+cig+sq+ql+aux
+        raw+=struct.pack("<i",len(body))+body
+    return gzip.compress(bytes(raw))
 def one(seed):
     rng=random.Random(seed)
     L=[rng.randint(20_000,60_000), rng.randint(10_000,40_000), rng.randint(2_000,8_000)]
     d=f"/tmp/fuzz/c{seed}"; os.makedirs(d,exist_ok=True)
     ev=synth.make_fragments(L, rng.randint(300,3000), seed=seed)
     ct=synth.make_fragments(L, rng.randint(300,3000), seed=seed+1, uniform_only=True)
-    writer=rng.choice(["mixed","dups","plain"]) if "--wild" not in sys.argv else "wild"; bam=rng.random()<0.4 and writer not in ("plain","wild")
+    writer=rng.choice(["mixed","dups","plain"]) if "--wild" not in sys.argv else "wild"; bam=rng.random()<0.4 and writer!="plain"
     ext="bam" if bam else "sam"
     quirks=rng.choice([0.0,0.0,0.25])   # records without optional fields / without SEQ, soft clips
     def wr(p,e,s,pre):
         if writer=="mixed": synth.write_sam_mixed(p,N2,L,e,s,name_prefix=pre,bam=bam)
-        elif writer=="wild": write_wild(p,N2,L,s,rng.randint(100,800),pre)
+        elif writer=="wild": write_wild(p,N2,L,s,rng.randint(100,800),pre,bam=bam)
         elif writer=="dups": synth.write_sam_dups(p,N2,L,e,s,name_prefix=pre,bam=bam,quirks=quirks)
         else: synth.write_sam(p,N2,L,e,name_prefix=pre)
     t=f"{d}/t.{ext}"; c=f"{d}/c.{ext}"; wr(t,ev,seed,"t_"); wr(c,ct,seed+7,"c_")
