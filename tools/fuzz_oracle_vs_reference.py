@@ -17,15 +17,17 @@ N=["chr1","chr2","chr3"]
 def one(seed):
     rng=random.Random(seed)
     L=[rng.randint(30_000,90_000), rng.randint(10_000,50_000), rng.randint(3_000,12_000)]
+    scale=40 if "--mid" in sys.argv else 1      # --mid: chromosomes of Mbases, 10^5 fragments per sample
+    L=[x*scale for x in L]
     d=f"/tmp/fuzz/o{seed}"; os.makedirs(d,exist_ok=True)
     nrep=rng.choice([1,1,1,2,3])
     tf,cf,reps=[],[],[]
     for r in range(nrep):
-        ev=synth.make_fragments(L, rng.randint(800,4000), seed=seed*10+r, frac_peak=0.4, frac_tower=0.2) if True else None
+        ev=synth.make_fragments(L, rng.randint(800,4000)*scale, seed=seed*10+r, frac_peak=0.4, frac_tower=0.2)
         if rng.random()<0.3: ev=synth.add_multimap(ev,L,rng.choice([0.1,0.3]),seed=seed+3)
         t=f"{d}/t{r}.sam"; synth.write_sam(t,N,L,ev,name_prefix=f"t{r}_"); tf.append(t)
         if rng.random()<0.6:
-            ct=synth.make_fragments(L, rng.randint(800,4000), seed=seed*10+5+r, uniform_only=True)
+            ct=synth.make_fragments(L, rng.randint(800,4000)*scale, seed=seed*10+5+r, uniform_only=True)
             c=f"{d}/c{r}.sam"; synth.write_sam(c,N,L,ct,name_prefix=f"c{r}_"); cf.append(c)
         else: cf.append(None)
     args=["-t",",".join(tf)]
