@@ -251,29 +251,32 @@ struct Counts {
   double totalLen = 0.0;
 };
 
+// (positions are uint32_t in the reference and its sums with the extension / ATAC lengths wrap in 32 bits
+// before they reach saveInterval's int64_t parameters; a position can be "negative" -- wrapped -- when the
+// BAM reader made it from a record without SEQ)
 uint32_t saveFragment(State& S, const char* qname, const Aln& a, uint8_t count) {  // 2754-2774, 2728-2749
   uint32_t start = a.pos[0], end = a.pos[1];
   if (start > end) std::swap(start, end);
   if (!S.o.atacOpt) return saveInterval(S, a.chrom, start, end, qname, count);
   if (S.o.atacAdj) { start += 5; end += (uint32_t)-5; }
   if (start + S.o.atacLen3 >= (uint32_t)(int)(end - S.o.atacLen3))
-    return saveInterval(S, a.chrom, (int)(start - S.o.atacLen5), (int64_t)end + S.o.atacLen5, qname, count);
-  return saveInterval(S, a.chrom, (int)(start - S.o.atacLen5), (int64_t)start + S.o.atacLen3, qname, count) +
-         saveInterval(S, a.chrom, (int)(end - S.o.atacLen3), (int64_t)end + S.o.atacLen5, qname, count);
+    return saveInterval(S, a.chrom, (int)(start - S.o.atacLen5), (uint32_t)(end + S.o.atacLen5), qname, count);
+  return saveInterval(S, a.chrom, (int)(start - S.o.atacLen5), (uint32_t)(start + S.o.atacLen3), qname, count) +
+         saveInterval(S, a.chrom, (int)(end - S.o.atacLen3), (uint32_t)(end + S.o.atacLen5), qname, count);
 }
 
 void saveUnpair(State& S, const char* qname, Aln& a, uint8_t count) {  // 2689-2721
   const Opts& o = S.o;
   if (o.extendOpt) {
-    if (a.strand) saveInterval(S, a.chrom, a.pos[0], (int64_t)a.pos[0] + o.extend, qname, count);
+    if (a.strand) saveInterval(S, a.chrom, a.pos[0], (uint32_t)(a.pos[0] + o.extend), qname, count);
     else saveInterval(S, a.chrom, (int)(a.pos[1] - o.extend), a.pos[1], qname, count);
   } else if (o.atacOpt) {
     if (a.strand) {
       if (o.atacAdj) a.pos[0] += 5;
-      saveInterval(S, a.chrom, (int)(a.pos[0] - o.atacLen5), (int64_t)a.pos[0] + o.atacLen3, qname, count);
+      saveInterval(S, a.chrom, (int)(a.pos[0] - o.atacLen5), (uint32_t)(a.pos[0] + o.atacLen3), qname, count);
     } else {
       if (o.atacAdj) a.pos[1] += (uint32_t)-5;
-      saveInterval(S, a.chrom, (int)(a.pos[1] - o.atacLen3), (int64_t)a.pos[1] + o.atacLen5, qname, count);
+      saveInterval(S, a.chrom, (int)(a.pos[1] - o.atacLen3), (uint32_t)(a.pos[1] + o.atacLen5), qname, count);
     }
   } else
     saveInterval(S, a.chrom, a.pos[0], a.pos[1], qname, count);
@@ -808,7 +811,7 @@ void finishFile(State& S, ReadSet& rs, Counts& C) {  // the tail of readSAM / pa
       avgLen = (int)(C.totalLen / C.pairedPr + 0.5);
     for (auto& u : rs.unpair) {
       if (!avgLen) saveInterval(S, u.chrom, u.pos[0], u.pos[1], u.name.c_str(), u.count);
-      else if (u.strand) saveInterval(S, u.chrom, u.pos[0], (int64_t)u.pos[0] + avgLen, u.name.c_str(), u.count);
+      else if (u.strand) saveInterval(S, u.chrom, u.pos[0], (uint32_t)(u.pos[0] + avgLen), u.name.c_str(), u.count);
       else saveInterval(S, u.chrom, (int)(u.pos[1] - avgLen), u.pos[1], u.name.c_str(), u.count);
     }
     rs.unpair.clear();

@@ -84,9 +84,37 @@ def main():
                         events=open(bed, errors="replace").read() if os.path.exists(bed) and (late or r.returncode == 0) else None))
         if len(out) >= nsam + 60:
             break
+    # valid BAM with alignment sets of every shape, some records without SEQ (tools/fuzz_host_vs_reference.py
+    # --wild), under the options that extend or shift unpaired alignments: positions that wrapped in the
+    # reference's 32-bit arithmetic must wrap here
+    wsrc = open(os.path.join(ROOT, "tools", "fuzz_host_vs_reference.py")).read().split("def one(seed):")[0]
+    wns = {"__file__": os.path.join(ROOT, "tools", "fuzz_host_vs_reference.py")}
+    sys.argv = [sys.argv[0], "0", "0"]
+    exec(compile(wsrc, "fuzz_host_vs_reference", "exec"), wns)
+    nbefore = len(out)
+    for seed in range(5000, 5400):
+        rng = random.Random(seed)
+        p = os.path.join(tmp, "t.bam")
+        wns["write_wild"](p, N2, L, seed, 25, "w_", bam=True)
+        args = rng.choice([["-y"], ["-w", str(rng.randint(50, 400))], ["-y", "-j"], ["-w", "399", "-j", "-s", "1", "-r"], ["-x"],
+                           ["-y", "-j", "-d", "183", "-D"]])
+        bed = os.path.join(tmp, "ref.bed")
+        if os.path.exists(bed):
+            os.remove(bed)
+        r = subprocess.run([REF, "-t", p] + args + ["-b", bed, "-o", "/dev/null"], capture_output=True, text=True, errors="replace")
+        if r.returncode not in (0, 1):
+            continue
+        err = next((l for l in r.stderr.splitlines() if l.startswith("Error!")), "")
+        late = any(k in err for k in ("no analyzable fragments", "Experimental sample", "peak", "No analyzable", "Invalid pileup"))
+        if r.returncode != 0 and not late:
+            continue
+        out.append(dict(kind="bam wild", args=args, bam=base64.b64encode(open(p, "rb").read()).decode(), rc=0, error="",
+                        events=open(bed, errors="replace").read()))
+        if len(out) >= nbefore + 12:
+            break
     with gzip.GzipFile(os.path.join(HERE, "cli_errors.json.gz"), "wb", mtime=0) as g:
         g.write(json.dumps(out, indent=0).encode())
-    print(len(out), "cases;", sum(1 for c in out if c["rc"]), "failing;", len(out) - nsam, "BAM")
+    print(len(out), "cases;", sum(1 for c in out if c["rc"]), "failing;", nbefore - nsam, "damaged BAM;", len(out) - nbefore, "wild BAM")
 
 
 main()
