@@ -1181,7 +1181,8 @@ void sendChroms(State& S) {
 void loadBED(State& S, const char* files) {  // loadBED 5187-5238
   std::string list(files);
   std::vector<char> line(65520);
-  for (char* fn = strtok(list.data(), ", "); fn; fn = strtok(nullptr, ", ")) {
+  char* endFn = nullptr;  // (strtok_r as in the reference: the lines are cut up with strtok inside the loop)
+  for (char* fn = strtok_r(list.data(), ", ", &endFn); fn; fn = strtok_r(nullptr, ", ", &endFn)) {
     In in;
   openRead(in, fn);
     while (in.gets(line.data(), (int)line.size())) {

@@ -279,3 +279,18 @@ def test_cli_damaged_sam_as_the_reference(tmp_path):
             assert res.returncode == 0, f"{what}: {err}"
             if c["events"] is not None:
                 assert bed.read_text(errors="replace") == c["events"], what
+
+
+def test_cli_several_bed_files(tmp_path):
+    """-E takes a comma-separated list (loadBED 5187-5238); the names are walked with strtok_r because every
+    line of a file is cut up with strtok."""
+    cases, mg = _cases()
+    args = _write_inputs(cases["basic"], mg, str(tmp_path / "in"))
+    a, b = tmp_path / "a.bed", tmp_path / "b.bed"
+    a.write_text("chrA\t100\t900\tname\t0\t+\nchrA\t5000\t5100\n")
+    b.write_text("chrA\t20000\t20500\n")
+    bed = tmp_path / "e.bed"
+    res = subprocess.run([_binary(), "--events-only", "-b", str(bed), "-E", f"{a},{b}"] + [x for x in args if x != "-X"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert open(bed, "rb").read() == G.read_gz("basic", "events.bed")
