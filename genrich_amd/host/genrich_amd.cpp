@@ -957,9 +957,9 @@ void bamHeaderText(State& S, In& g) {
     die("", "SAM/BAM file not sorted by queryname (samtools sort -n)");
 }
 
-uint64_t readBAM(State& S, In& in, Counts& C) {
-  In& g = in;
-  bamHeaderText(S, g);
+// the reference table of a BAM header (readBAM, Genrich.c:5038-5049): n_ref x {l_name, name (NUL-terminated), l_ref};
+// one parser for the header pre-scan and the real pass, so neither hands saveChrom an unterminated name
+std::vector<int> bamRefTable(State& S, In& g) {
   int32_t n_ref = rdI32(g, true);
   std::vector<int> idx((size_t)std::max(0, n_ref));
   for (int i = 0; i < n_ref; i++) {
@@ -969,6 +969,14 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     if (!gzReadAll(g, nm.data(), (size_t)len) || nm[len - 1] != '\0') die("", "Cannot parse BAM file");
     idx[i] = saveChrom(S, nm.data(), (uint32_t)rdI32(g, true));
   }
+  return idx;
+}
+
+uint64_t readBAM(State& S, In& in, Counts& C) {
+  In& g = in;
+  bamHeaderText(S, g);
+  std::vector<int> idx = bamRefTable(S, g);
+  const int32_t n_ref = (int32_t)idx.size();
   ReadSet rs;
   std::vector<uint8_t> copy;
   for (;;) {
@@ -1134,14 +1142,7 @@ void scanHeader(State& S, const char* filename, bool ctrl) {
   int got = 0;
   if (sniffBam(in, magic, got)) {
     bamHeaderText(S, in);
-    int32_t n_ref = rdI32(in, true);
-    for (int i = 0; i < n_ref; i++) {
-      int32_t len = rdI32(in, true);
-      if (len < 1 || len > 65520) die("", "Cannot parse BAM file");
-      std::vector<char> nm((size_t)len);
-      if (!gzReadAll(in, nm.data(), (size_t)len)) die("", "Cannot parse BAM file");
-      saveChrom(S, nm.data(), (uint32_t)rdI32(in, true));
-    }
+    bamRefTable(S, in);
   } else {
     in.unread(magic, (size_t)std::max(0, got));
     std::vector<char> line(65520);

@@ -294,3 +294,16 @@ def test_cli_several_bed_files(tmp_path):
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert open(bed, "rb").read() == G.read_gz("basic", "events.bed")
+
+
+def test_cli_bam_reference_name_without_nul(tmp_path):
+    """A BAM whose reference name lacks its NUL terminator is "Cannot parse BAM file" in the header
+    pre-scan too (it used to reach saveChrom as an unterminated C string)."""
+    import struct
+    hdr = b"@HD\tVN:1.0\tSO:queryname\n"
+    for gz in (gzip.compress, _bgzf):
+        raw = b"BAM\1" + struct.pack("<i", len(hdr)) + hdr + struct.pack("<i", 1) + struct.pack("<i", 4) + b"chrA" + struct.pack("<i", 1000)
+        p = str(tmp_path / f"bad_{gz.__name__}.bam")
+        open(p, "wb").write(gz(raw))
+        res = subprocess.run([_binary(), "--events-only", "-t", p, "-b", str(tmp_path / "e.bed")], capture_output=True, text=True)
+        assert res.returncode == 1 and "Cannot parse BAM file" in res.stderr, res.stderr
