@@ -296,8 +296,12 @@ __global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev
           bad |= ST_BAD_POS;
         else {
           u32 end = e.z > c.len ? c.len : e.z;
-          if (end > e.y) {  // an empty interval adds and removes the same weight
-            covered += end - e.y;
+          // (an empty interval adds and removes the same weight.  One that ends before it starts -- the
+          // reference's BAM reader makes them from reverse reads without SEQ -- is counted like any other:
+          // +w at its start, -w at its end, a negative length towards fragLen; the pileup between the two
+          // goes down, and below zero that is the reference's "Invalid pileup value")
+          if (end != e.y) {
+            covered += (u64)((long long)end - (long long)e.y);
             t0 = c.tileBase + (e.y >> TB);
             o0 = e.y & (TILE - 1);
             if (end < c.len) {

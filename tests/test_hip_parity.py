@@ -545,3 +545,31 @@ def test_saturation_only_at_the_chromosome_end():
         case = dict(lens=lens, replicates=[dict(save=None, treat=ev[:m], ctrl=None)])
         o, h, so, sh = run_both(case, B.make_params(pq=0.01))
         assert_same_run(o, h, so, sh, case)
+
+
+def test_intervals_that_end_before_they_start():
+    """saveInterval adds +w at start and -w at end whatever their order (the reference's BAM reader produces
+    such intervals from reverse reads without SEQ).  Covered by other fragments the run goes through, with
+    the pileup lowered between end and start; uncovered it stops with "Invalid pileup value (< 0)"."""
+    lens = [30_000]
+    bg = synth.make_fragments(lens, 4000, seed=5)
+    rng = np.random.default_rng(6)
+    deep = np.zeros(3000, dtype=B.EVENT_DTYPE)   # a plateau over [10000, 12000)
+    deep["chrom"], deep["start"], deep["end"], deep["count"] = 0, 10_000 - rng.integers(0, 50, 3000), 12_000 + rng.integers(0, 50, 3000), 1
+    back = np.zeros(200, dtype=B.EVENT_DTYPE)     # 200 intervals running backwards inside the plateau
+    st = rng.integers(10_600, 11_900, 200)
+    back["chrom"], back["start"], back["end"], back["count"] = 0, st, st - rng.integers(1, 500, 200), 1
+    ev = np.concatenate([bg, deep, back])
+    ev = ev[rng.permutation(len(ev))]
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    o, h, so, sh = run_both(case, B.make_params(pq=0.01, min_auc=20.0))
+    assert_same_run(o, h, so, sh, case)
+    lone = np.zeros(1, dtype=B.EVENT_DTYPE)   # nothing else on its chromosome
+    lone["chrom"], lone["start"], lone["end"], lone["count"] = 1, 3_000, 2_900, 1
+    for backend in (B.Oracle, hip_backend):
+        b = backend(B.make_params(pq=0.01))
+        b.set_chroms(lens + [5_000])
+        b.sample_begin(0, None)
+        b.push_events(np.concatenate([bg[:50], lone]))
+        with pytest.raises(RuntimeError, match="Invalid pileup"):
+            b.sample_end()
