@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "gx_math.h"
 #include "../../include/genrich_amd.h"
 
@@ -768,13 +769,24 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, typ
 // ahead of a control merge) move the slots to their tight place.  (A fused
 // decoupled look-back was measured first: with ~512 resident tiles the look-back distance made
 // it latency-bound at ~10 us per tile.)
-constexpr int TL_NT = TILE / 32;  // one thread per 32 bases (= one bitmap word)
+#ifndef GX_TL_EPT
+#define GX_TL_EPT 32
+#endif
+constexpr int TL_EPT = GX_TL_EPT;                 // bases per thread (= one occupancy word): 32, or 64 for one wavefront per 2^12-base tile
+static_assert(TL_EPT == 32 || TL_EPT == 64, "the occupancy word is 32 or 64 bits");
+constexpr int TL_NT = TILE / TL_EPT;
 constexpr int TL_NW = TL_NT / 64;
+static_assert(TL_NT % 64 == 0, "whole wavefronts");
 #ifndef GX_TL_REG
-#define GX_TL_REG 4
+#define GX_TL_REG (GX_TL_EPT == 64 ? 6 : 4)
 #endif
 constexpr int TL_REG = GX_TL_REG;                 // touched bases per thread held in registers
-constexpr int TL_EPT = TILE / TL_NT;              // 32 bases per thread
+constexpr int TL_KPT = (TL_NT >= 128 ? 1 : 128 / TL_NT);  // prefetched keys per thread and stream (128 per tile)
+using occ_t = std::conditional<TL_EPT == 64, unsigned long long, u32>::type;
+__device__ __forceinline__ int occ_ctz(u32 v) { return __builtin_ctz(v); }
+__device__ __forceinline__ int occ_ctz(unsigned long long v) { return __builtin_ctzll(v); }
+__device__ __forceinline__ int occ_popc(u32 v) { return __popc(v); }
+__device__ __forceinline__ int occ_popc(unsigned long long v) { return __popcll(v); }
 constexpr int TL_LDS = TILE + 64 + 2 * (TILE / 32); // ints: slice, scan scratch, occupancy + -E edge bitmaps
 // k_tile<.., HALF = true> packs the differences of two neighbouring bases into one LDS word as 16-bit
 // counts of unit-weight records (word = 65536 * odd base + even base as one integer sum, so borrows
@@ -898,8 +910,8 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
   constexpr int SLICE = HALF ? TILE / 2 : TILE;
   int* delta = lds;                            // SLICE ints
   int* scr = lds + SLICE;                      // [0..8] sums, [16..24] counts, [32..40] edge counts
-  u32* occ = reinterpret_cast<u32*>(scr + 64); // TILE/32 words: word i = bases of thread i
-  u32* eb = occ + TILE / 32;                   // -E edge bitmap, same shape
+  occ_t* occ = reinterpret_cast<occ_t*>(scr + 64);  // one word per thread: bit k = base k of the thread's TL_EPT
+  occ_t* eb = occ + TL_NT;                          // -E edge bitmap, same shape
   const int wv = threadIdx.x >> 6;
   u32 bad = 0;
   for (int i = threadIdx.x * 4; i < SLICE; i += TL_NT * 4)
@@ -946,17 +958,25 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
     return m;
   };
   // (a wide tile's keys are not for the HALF kernel: it skips the tile)
-  auto keyOf = [&](const uint16_t* K, u32 kb, u32 nk, u32 flags) -> u32 {
-    return threadIdx.x < nk && !(HALF && (flags & TM_WIDE)) ? K[kb + threadIdx.x] : 0u;
+  struct Keys { u32 v[TL_KPT]; };
+  auto keyOf = [&](const uint16_t* K, u32 kb, u32 nk, u32 flags) -> Keys {
+    Keys r;
+#pragma unroll
+    for (int q = 0; q < TL_KPT; q++) {
+      const u32 ix = threadIdx.x + q * TL_NT;
+      r.v[q] = ix < nk && !(HALF && (flags & TM_WIDE)) ? K[kb + ix] : 0u;
+    }
+    return r;
   };
   u32 tC = tileAt(lb), tN = tileAt(lb + G), tF = tileAt(lb + 2 * G), tQ = tileAt(lb + 3 * G), tL = tileAt(lb + 4 * G);
   u32 tR = 0;
   TileMeta mC = cook(loadMeta(tC), lb), mN = cook(loadMeta(tN), lb + G), mR{};
-  u32 ksC = keyOf(in.S, mC.sb, mC.nS, mC.flags), keC = keyOf(in.E, mC.eb, mC.nE, mC.flags), ksN = 0, keN = 0;
+  Keys ksC = keyOf(in.S, mC.sb, mC.nS, mC.flags), keC = keyOf(in.E, mC.eb, mC.nE, mC.flags), ksN{}, keN{};
   // (arrived before the loop: a register that is pending on the way in gets a wait at its use inside the
   // loop, which at run time would wait for whatever is in flight in every iteration)
-  asm volatile("" : "+v"(ksC), "+v"(keC), "+v"(tF), "+v"(tQ) :: "memory");
-  u32 ksL = keyOf(in.S, mN.sb, mN.nS, mN.flags), keL = keyOf(in.E, mN.eb, mN.nE, mN.flags);  // in flight
+  asm volatile("" : "+v"(ksC.v[0]), "+v"(keC.v[0]), "+v"(tF), "+v"(tQ) :: "memory");
+  if constexpr (TL_KPT > 1) asm volatile("" : "+v"(ksC.v[TL_KPT - 1]), "+v"(keC.v[TL_KPT - 1]) :: "memory");
+  Keys ksL = keyOf(in.S, mN.sb, mN.nS, mN.flags), keL = keyOf(in.E, mN.eb, mN.nE, mN.flags);  // in flight
   Raw rF = loadMeta(tF);                                                                      // in flight
   for (u32 i = lb; i < nItems; i += G) {
     const u32 t = tC;
@@ -967,11 +987,12 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
       // zero intervals is overwritten by the kernel that owns it
       m.nS = 0; m.nE = 0; m.nF = 0; m.flags = 0;
     }
-    const u32 ks0 = ksC, ke0 = keC;
+    const Keys ks0 = ksC, ke0 = keC;
     auto collect = [&]() {
       // (the empty asm is the point where the loads in flight must have arrived, and nothing that
       // touches memory moves across it)
-      asm volatile("" : "+v"(ksL), "+v"(keL), "+v"(rF.a.x), "+v"(rF.a.y), "+v"(rF.a.z), "+v"(rF.a.w), "+v"(rF.b.x),
+      if constexpr (TL_KPT > 1) asm volatile("" : "+v"(ksL.v[TL_KPT - 1]), "+v"(keL.v[TL_KPT - 1]) :: "memory");
+      asm volatile("" : "+v"(ksL.v[0]), "+v"(keL.v[0]), "+v"(rF.a.x), "+v"(rF.a.y), "+v"(rF.a.z), "+v"(rF.a.w), "+v"(rF.b.x),
                         "+v"(rF.b.y), "+v"(rF.b.z), "+v"(rF.b.w), "+v"(rF.c.x), "+v"(rF.c.y), "+v"(rF.c.z), "+v"(rF.c.w),
                         "+v"(tL) :: "memory");
       ksN = ksL;
@@ -1005,33 +1026,36 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
         atomicAdd(&delta[off >> 1], (off & 1) ? sign * 65536 : sign);
       else
         atomicAdd(&delta[off], sign * GX_UNIT);
-      atomicOr(&occ[off >> 5], 1u << (off & 31));
+      atomicOr(&occ[off / TL_EPT], (occ_t)1 << (off % TL_EPT));
     };
-    if (threadIdx.x < m.nS) add(ks0, 1);
-    if (threadIdx.x < m.nE) add(ke0, -1);
-    for (u32 i = sb + TL_NT + threadIdx.x; i < se; i += TL_NT) add(in.S[i], 1);
-    for (u32 i = eb0 + TL_NT + threadIdx.x; i < ee; i += TL_NT) add(in.E[i], -1);
+#pragma unroll
+    for (int q = 0; q < TL_KPT; q++) {
+      if (threadIdx.x + q * TL_NT < m.nS) add(ks0.v[q], 1);
+      if (threadIdx.x + q * TL_NT < m.nE) add(ke0.v[q], -1);
+    }
+    for (u32 i = sb + TL_KPT * TL_NT + threadIdx.x; i < se; i += TL_NT) add(in.S[i], 1);
+    for (u32 i = eb0 + TL_KPT * TL_NT + threadIdx.x; i < ee; i += TL_NT) add(in.E[i], -1);
     if constexpr (!HALF)
       for (u32 i = fb + threadIdx.x; i < fe; i += TL_NT) {
         u64 r = in.F[i];
         u32 off = (u32)(r >> 8) & (TILE - 1);
         atomicAdd(&delta[off], (int)(int8_t)(r & 0xFF));
-        atomicOr(&occ[off >> 5], 1u << (off & 31));
+        atomicOr(&occ[off / TL_EPT], (occ_t)1 << (off % TL_EPT));
       }
     if (BED)
       for (u32 i = bed.bedTileOff[t] + threadIdx.x; i < bed.bedTileOff[t + 1]; i += TL_NT) {
         u32 off = bed.bedEdge[i];
-        atomicOr(&eb[off >> 5], 1u << (off & 31));
+        atomicOr(&eb[off / TL_EPT], (occ_t)1 << (off % TL_EPT));
       }
     __syncthreads();
     // thread i owns bases [32 i, 32 i + 32): pass 1 over its touched bases (and -E edges)
-    const u32 ow = occ[threadIdx.x];
-    const u32 ew = BED ? eb[threadIdx.x] : 0u;
+    const occ_t ow = occ[threadIdx.x];
+    const occ_t ew = BED ? eb[threadIdx.x] : (occ_t)0;
     occ[threadIdx.x] = 0;  // own word, next touched after the barrier that ends this tile
     if (BED) eb[threadIdx.x] = 0;
     bool save = true;
     if (BED) {  // `save` state at this thread's first base = tile state ^ parity(edges before it)
-      const int pe = __popc(ew);
+      const int pe = occ_popc(ew);
       const int incE = dpp_scan_add(pe);
       if (lane_id() == 63) scr[32 + wv] = incE;
       __syncthreads();
@@ -1042,17 +1066,17 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
       save = ((bed.tileSave0[t] != 0) ^ ((preE & 1) != 0));
     }
     const bool save0 = save;
-    const int lbase = threadIdx.x * 32;
+    const int lbase = threadIdx.x * TL_EPT;
     int sum = 0;
     u32 cnt = 0;
     // The first TL_REG touched bases of the thread are fetched from LDS in one batch and kept in
     // registers for both passes (a dependent LDS round trip per base and pass is what this kernel
     // would otherwise wait for); their slots are cleared at once.  Further bases -- rare -- loop.
     int kk[TL_REG], dk[TL_REG];
-    u32 mrest = ow | ew;
+    occ_t mrest = ow | ew;
 #pragma unroll
     for (int j = 0; j < TL_REG; j++) {
-      kk[j] = mrest ? __builtin_ctz(mrest) : -1;
+      kk[j] = mrest ? occ_ctz(mrest) : -1;
       dk[j] = mrest ? tile_diff<HALF>(delta, lbase + kk[j]) : 0;
       mrest &= mrest - 1;
     }
@@ -1085,8 +1109,8 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
             if (dk[j] != 0) delta[lbase + kk[j]] = 0;
         }
     }
-    for (u32 m = mrest; m; m &= m - 1) {
-      const int k = __builtin_ctz(m);
+    for (occ_t m = mrest; m; m &= m - 1) {
+      const int k = occ_ctz(m);
       const int d = tile_diff<HALF>(delta, lbase + k);
       GX_P1_STEP(k, d);
     }
@@ -1150,12 +1174,12 @@ __global__ __launch_bounds__(TL_NT, 2) void k_tile(TileIn in, u32 nTiles, const 
       for (int j = 0; j < TL_REG; j++)
         if (kk[j] >= 0) GX_P2_STEP(kk[j], dk[j]);
     }
-    for (u32 m = mrest; m; m &= m - 1) {
-      const int k = __builtin_ctz(m);
+    for (occ_t m = mrest; m; m &= m - 1) {
+      const int k = occ_ctz(m);
       const int d = tile_diff<HALF>(delta, lbase + k);
       GX_P2_STEP(k, d);
       if constexpr (HALF) {  // a word is cleared by the last touched base it holds
-        if ((k & 1) || !((m >> (k + 1)) & 1u)) delta[(lbase + k) >> 1] = 0;
+        if ((k & 1) || !((m >> (k + 1)) & 1)) delta[(lbase + k) >> 1] = 0;
       } else if (d != 0) {
         delta[lbase + k] = 0;
       }
