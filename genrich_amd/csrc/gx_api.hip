@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include "gx_merge.h"
+#include "gx_rccl.h"
 #include "gx_saturate.h"
 
 using namespace gx;
@@ -64,6 +65,8 @@ struct HostMail {
   long long acc[2];
   uint64_t peakBP, genome;
   u32 nF, nIv, status, R, nPeaks, nMerged, D, n, hot;
+  long long coll[4];   // this rank's / all ranks' {fragLen parts, saturation flag}
+  u32 counts[64];      // BH records per rank (all-gather)
 };
 
 struct PinnedBuf {
@@ -149,7 +152,9 @@ struct gx_ctx {
   std::vector<PArray> reps;
   int finalIdx = -1;
   // BH
-  DevBuf pvLut;
+  DevBuf pvLut, dRisk, dDeep;
+  PinnedBuf riskHost;           // count + records of the risky p-values, as read back / as sent with the host's values
+  bool pairTabsReady = false;   // the control's p-value tables were built when its sample was closed
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp, bhRecs;
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
@@ -167,6 +172,9 @@ struct gx_ctx {
   gx_allreduce_i64_fn allreduce = nullptr;
   gx_allgather_tab_fn allgather = nullptr;
   void* user = nullptr;
+  ncclComm_t comm = nullptr;    // the library's own collectives (gx_set_rccl): RCCL on device buffers, on `stream`
+  bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
+  DevBuf dColl, dCounts, dGather;
   int numCU = 0, resTile = 0, resTileHalf = 0, resSweep = 0;  // co-resident workgroups per kernel class
   // recycled device buffers (gx_reset keeps allocations alive across runs)
   std::vector<DevBuf> pool;
@@ -268,6 +276,60 @@ int read_status(gx_ctx* ctx) {
   HIPCHECK(hipMemcpyAsync(&ctx->mail->status, ctx->dStatus.p, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   return status_to_rc(ctx, ctx->mail->status);
+}
+
+// ---- risky p-values (gx_math.h round_checked; gx_kernels.h RiskBuf) --------------------------------
+// risk_queue: ahead of a synchronisation the host needs anyway, ask for the list's count and first records.
+// risk_apply: after it, evaluate the listed values with the host's libm and send them back (k_risk_apply).
+int risk_queue(gx_ctx* ctx) {
+  HIPCHECK(hipMemcpyAsync(ctx->riskHost.p, ctx->dRisk.p, 32 + RISK_PREFIX * sizeof(RiskRec), hipMemcpyDeviceToHost, ctx->stream));
+  return GX_OK;
+}
+
+struct RiskHostIn { const float* a; const float* b; };  // RK_SELF: the caller's inputs
+
+float risk_host_value(const gx_ctx* ctx, const RiskRec& r, const RiskHostIn& in) {
+  const float lambda = ctx->hScal.lambda, factor = ctx->hScal.factor;
+  bool ng = false, rk = false;
+  switch (r.kind) {
+    case RK_LUT:
+    case RK_DEEP: return calc_pval(getval((int)r.a, &ng), lambda, &rk);  // no control: the control value is lambda
+    case RK_TAB2D:
+      return calc_pval((float)(r.a / PT_N), ctrl_net((int)((r.a % PT_N) * GX_UNIT), factor, lambda, &ng), &rk);
+    case RK_PAIR: return calc_pval(expt_val((int)r.b, &ng), ctrl_net((int)r.c, factor, lambda, &ng), &rk);
+    case RK_FISHER: return fisher_combine(r.x, (int)r.c, &rk);
+    case RK_SELF:
+      if (r.b == 1) return calc_pval(in.a[r.a], in.b[r.a], &rk);
+      if (r.b == 3) return fisher_combine((double)in.a[r.a], (int)in.b[r.a], &rk);
+      return 0.0f;
+    default: return 0.0f;
+  }
+}
+
+int risk_apply(gx_ctx* ctx, RiskTargets T, RiskHostIn in = RiskHostIn{nullptr, nullptr}) {
+  RiskBuf* hb = static_cast<RiskBuf*>(ctx->riskHost.p);
+  const u32 n = hb->count;
+  if (!n) return GX_OK;
+  hipStream_t s = ctx->stream;
+  if (n > RISK_CAP) {
+    HIPCHECK(hipMemsetAsync(ctx->dRisk.p, 0, 4, s));
+    ctx->err = "more p-values next to a float rounding boundary than the list holds";
+    return GX_ERR_DEVICE;
+  }
+  if (n > RISK_PREFIX) {  // (rare: the count and the first records came with the synchronisation already paid for)
+    HIPCHECK(hipMemcpyAsync(hb->rec + RISK_PREFIX, ctx->dRisk.as<RiskBuf>()->rec + RISK_PREFIX,
+                            (size_t)(n - RISK_PREFIX) * sizeof(RiskRec), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+  }
+  for (u32 i = 0; i < n; i++) hb->rec[i].pnew = risk_host_value(ctx, hb->rec[i], in);
+  // (the pinned records stay untouched until the next risk_queue, which follows a synchronisation)
+  HIPCHECK(hipMemcpyAsync(ctx->dRisk.as<RiskBuf>()->rec, hb->rec, (size_t)n * sizeof(RiskRec), hipMemcpyHostToDevice, s));
+  T.lutP = ctx->pvLut.as<float>();
+  T.p2d = ctx->pairP2d.as<float>();
+  T.deep = ctx->dDeep.as<DeepTab>();
+  hipLaunchKernelGGL(k_risk_apply, dim3(1), dim3(256), 0, s, ctx->dRisk.as<RiskBuf>(), n, T);
+  hb->count = 0;
+  return dbg_sync(ctx, "k_risk_apply");
 }
 
 uint64_t genome_len_for(const gx_ctx* ctx, const std::vector<uint8_t>& present) {
@@ -522,7 +584,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
                        tPrev, ff, ctx->fragList.as<u32>());
     hipLaunchKernelGGL(k_frag, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, lE, lV, tm, tOff, tPrev,
                        nTiles, ff, acc);
-    hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ff, acc);
+    hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ff, acc,
+                       ctx->world > 1 || ctx->forceColl ? ctx->dColl.as<long long>() : (long long*)nullptr,
+                       ctx->nWide.as<u32>() + 1);
   }
   if (int rc__ = dbg_sync(ctx, "k_frag")) return rc__;
   out.packed = false;
@@ -543,30 +607,64 @@ constexpr int RETRY_SATURATED = 1;  // (internal) finish_scalars: filter the eve
 int finish_scalars(gx_ctx* ctx, int isCtrl) {
   hipStream_t s = ctx->stream;
   Scalars* ds = ctx->dScal.as<Scalars>();
-  if (ctx->world > 1 && ctx->allreduce) {
-    long long* acc = ctx->mail->acc;
-    long long* dacc = isCtrl ? ds->ctrlAcc : ds->fragAcc;
-    HIPCHECK(hipMemcpyAsync(acc, dacc, 16, hipMemcpyDeviceToHost, s));
+  const bool multi = ctx->world > 1 || ctx->forceColl;
+  long long* dcoll = multi ? ctx->dColl.as<long long>() : nullptr;
+  if (multi && ctx->comm) {
+    // RCCL on the device words, in stream order: no host hop.  The third word sums the ranks' saturation
+    // flags, so that every rank learns from the one synchronisation below whether the sums are final.
+    const gxrccl::Api* api = gxrccl::load(&ctx->err);
+    if (!api) return GX_ERR_DEVICE;
+    ncclResult_t r = api->allReduce(dcoll, dcoll, 3, ncclInt64, ncclSum, ctx->comm, s);
+    if (r != ncclSuccess) {
+      ctx->err = std::string("ncclAllReduce: ") + api->getErrorString(r);
+      return GX_ERR_DEVICE;
+    }
+  } else if (multi && ctx->allreduce) {
+    long long* acc = ctx->mail->coll;
+    HIPCHECK(hipMemcpyAsync(acc, dcoll, 24, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    if (ctx->mail->hot && !ctx->satDone) return RETRY_SATURATED;  // before this rank enters the collective
-    int64_t buf[2] = {acc[0], acc[1]};
-    if (ctx->allreduce(buf, 2, ctx->user)) {
+    int64_t buf[3] = {acc[0], acc[1], acc[2]};
+    if (ctx->allreduce(buf, 3, ctx->user)) {
       ctx->err = "allreduce callback failed";
       return GX_ERR_DEVICE;
     }
     acc[0] = buf[0];
     acc[1] = buf[1];
-    HIPCHECK(hipMemcpyAsync(dacc, acc, 16, hipMemcpyHostToDevice, s));
+    acc[2] = buf[2];
+    HIPCHECK(hipMemcpyAsync(dcoll, acc, 24, hipMemcpyHostToDevice, s));
+  } else if (multi) {
+    ctx->err = "several ranks but no collectives (gx_set_rccl / gx_set_collectives)";
+    return GX_ERR_ORDER;
   }
-  hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>());
+  if (multi) HIPCHECK(hipMemcpyAsync(&ctx->mail->coll[2], dcoll + 2, 8, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>(), (const long long*)dcoll);
   if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
+  // lambda (and with a control the factor) is final: build the p-value tables now, so that the values the
+  // host has to re-evaluate (risky ones) travel with the synchronisation that returns the scalars
+  if (!isCtrl) {
+    hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ds, ctx->pvLut.as<float>(), ctx->dRisk.as<RiskBuf>(),
+                       ctx->dDeep.as<DeepTab>());
+    PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>()};
+    hipLaunchKernelGGL(k_deep_risky, dim3(64), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(), ds,
+                       ctx->dRisk.as<RiskBuf>());
+  } else {
+    hipLaunchKernelGGL(k_pair_tabs, dim3(PAIR_LUT / 256), dim3(256), 0, s, ds, ctx->pairLogE.as<double>(),
+                       ctx->pairCtab.as<CtrlEntry>());
+    hipLaunchKernelGGL(k_pair_tab2d, dim3(PT_N * PT_N / 256), dim3(256), 0, s, ds, ctx->pairLogE.as<double>(),
+                       ctx->pairCtab.as<CtrlEntry>(), ctx->pairP2d.as<float>(), ctx->dRisk.as<RiskBuf>());
+    ctx->pairTabsReady = true;
+  }
+  if (int rc__ = dbg_sync(ctx, "p-value tables")) return rc__;
   HIPCHECK(hipMemcpyAsync(&ctx->mail->scal, ds, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+  if (int rc__ = risk_queue(ctx)) return rc__;
   int rc = read_status(ctx);
-  if (ctx->mail->hot && !ctx->satDone) return RETRY_SATURATED;
   ctx->hScal = ctx->mail->scal;
+  const int rcRisk = risk_apply(ctx, RiskTargets{});
+  // (with several ranks: if any of them has to rebuild its sample, all go round again with it)
+  if ((multi ? ctx->mail->coll[2] != 0 : ctx->mail->hot != 0) && !ctx->satDone) return RETRY_SATURATED;
   if (ctx->nIvTarget) *ctx->nIvTarget = ctx->mail->nIv;
   ctx->nIvTarget = nullptr;
-  return rc;
+  return rc ? rc : rcRisk;
 }
 
 // The sample holds a base that can reach the reference's int16 limits: bring the events to the host,
@@ -757,6 +855,18 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   HIPCHECK(ctx->misc.ensure(M_WORDS * 4));
   HIPCHECK(ctx->dScal.ensure(sizeof(Scalars)));
   HIPCHECK(ctx->dStatus.ensure(64));
+  // p-value tables and the list of risky values: fixed sizes, built while a sample is closed
+  HIPCHECK(ctx->pvLut.ensure((size_t)PV_LUT * 4));
+  HIPCHECK(ctx->pairLogE.ensure((size_t)PAIR_LUT * 8));
+  HIPCHECK(ctx->pairCtab.ensure((size_t)PAIR_LUT * sizeof(CtrlEntry)));
+  HIPCHECK(ctx->pairP2d.ensure((size_t)PT_N * PT_N * 4));
+  HIPCHECK(ctx->dColl.ensure(64));
+  HIPCHECK(ctx->dRisk.ensure(sizeof(RiskBuf)));
+  HIPCHECK(ctx->dDeep.ensure(sizeof(DeepTab)));
+  HIPCHECK(ctx->riskHost.ensure(sizeof(RiskBuf)));
+  memset(ctx->riskHost.p, 0, 32);
+  HIPCHECK(hipMemsetAsync(ctx->dRisk.p, 0, 32, ctx->stream));
+  HIPCHECK(hipMemsetAsync(ctx->dDeep.p, 0, sizeof(DeepTab), ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->misc.p, 0, M_WORDS * 4, ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dScal.p, 0, sizeof(Scalars), ctx->stream));
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
@@ -786,6 +896,10 @@ void gx_destroy(gx_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) {
+    if (const gxrccl::Api* api = gxrccl::load(nullptr)) (void)api->commDestroy(ctx->comm);
+    ctx->comm = nullptr;
+  }
   for (auto& ph : ctx->phases) {
     (void)hipEventDestroy(ph.a);
     (void)hipEventDestroy(ph.b);
@@ -826,6 +940,44 @@ int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn all
   ctx->allreduce = allreduce;
   ctx->allgather = allgather;
   ctx->user = user;
+  ctx->forceColl = getenv("GX_FORCE_COLL") != nullptr;
+  return GX_OK;
+}
+
+int gx_rccl_unique_id(void* out, size_t cap) {
+  if (!out || cap < sizeof(ncclUniqueId)) return GX_ERR_ORDER;
+  std::string err;
+  const gxrccl::Api* api = gxrccl::load(&err);
+  if (!api) {
+    fprintf(stderr, "genrich_amd: %s\n", err.c_str());
+    return GX_ERR_DEVICE;
+  }
+  ncclUniqueId id;
+  if (api->getUniqueId(&id) != ncclSuccess) return GX_ERR_DEVICE;
+  memcpy(out, &id, sizeof id);
+  return GX_OK;
+}
+
+int gx_set_rccl(gx_ctx* ctx, int rank, int world, const void* unique_id) {
+  if (!ctx || !unique_id || world < 1 || rank < 0 || rank >= world || world > 64) return GX_ERR_ORDER;
+  const gxrccl::Api* api = gxrccl::load(&ctx->err);
+  if (!api) return GX_ERR_DEVICE;
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (ctx->comm) {
+    (void)api->commDestroy(ctx->comm);
+    ctx->comm = nullptr;
+  }
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof id);
+  ncclResult_t r = api->commInitRank(&ctx->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    ctx->err = std::string("ncclCommInitRank: ") + api->getErrorString(r);
+    ctx->comm = nullptr;
+    return GX_ERR_DEVICE;
+  }
+  ctx->rank = rank;
+  ctx->world = world;
+  ctx->forceColl = getenv("GX_FORCE_COLL") != nullptr;
   return GX_OK;
 }
 
@@ -969,8 +1121,7 @@ int gx_pvalues(gx_ctx* ctx) {
     if (keep) HIPCHECK(pooled(ctx, pa.expt, (size_t)n * 4 + 16));
     if (keep && ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)n * 4 + 16));
     phase_begin(ctx, "pval");
-    HIPCHECK(ctx->pvLut.ensure((size_t)PV_LUT * 4));
-    hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>());
+    // (the table p(V) was built when the treatment sample was closed: finish_scalars)
     PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>()};
     // p-mode: the sweep's significance / skip masks are filled on the way (gx_find_peaks reuses them
     // when this replicate turns out to be the only one)
@@ -1002,7 +1153,7 @@ int gx_pvalues(gx_ctx* ctx) {
 #undef GX_LAUNCH_PACK_PVAL
     }
     hipLaunchKernelGGL(k_pval_deep, dim3(256), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(),
-                       ctx->dScal.as<Scalars>(), pa.p.as<float>(), ctx->par.thr, sigM);
+                       ctx->dScal.as<Scalars>(), ctx->dDeep.as<DeepTab>(), pa.p.as<float>(), ctx->par.thr, sigM);
     if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
@@ -1031,8 +1182,6 @@ int gx_pvalues(gx_ctx* ctx) {
     HIPCHECK(ctx->looseV.ensure(cap * 4));
     HIPCHECK(ctx->looseC.ensure(cap * 4));
     HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
-    HIPCHECK(ctx->pairLogE.ensure((size_t)PAIR_LUT * 8));
-    HIPCHECK(ctx->pairCtab.ensure((size_t)PAIR_LUT * sizeof(CtrlEntry)));
     u32* misc = ctx->misc.as<u32>();
     phase_begin(ctx, "merge");
     RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>()};
@@ -1053,14 +1202,11 @@ int gx_pvalues(gx_ctx* ctx) {
     if (int rc__ = dbg_sync(ctx, "k_scan_counts")) return rc__;
     phase_end(ctx);
     phase_begin(ctx, "pval");
-    hipLaunchKernelGGL(k_pair_tabs, dim3(PAIR_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(),
-                       ctx->pairLogE.as<double>(), ctx->pairCtab.as<CtrlEntry>());
+    // (the control's tables -- log(treatment), control parameters, p of whole pileup pairs -- were built when
+    // its sample was closed: finish_scalars)
     PackPairsIn ppi{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->expt.tileIvOff.as<u32>(),
                     ctx->ctrl.tileIvOff.as<u32>(), pa.tileOff.as<u32>()};
-    HIPCHECK(ctx->pairP2d.ensure((size_t)PT_N * PT_N * 4));
     HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
-    hipLaunchKernelGGL(k_pair_tab2d, dim3(PT_N * PT_N / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(),
-                       ctx->pairLogE.as<double>(), ctx->pairCtab.as<CtrlEntry>(), ctx->pairP2d.as<float>());
     // p-mode: the sweep's masks are filled on the way (the interval count is only bounded here, so the
     // masks are laid out for the bound and gx_find_peaks is told the stride)
     u64 *sigM = nullptr, *skipM = nullptr;
@@ -1090,12 +1236,21 @@ int gx_pvalues(gx_ctx* ctx) {
                        ppi, ctx->fragList.as<u32>(), misc + M_TICKET, ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(),
                        ctx->pairCtab.as<CtrlEntry>(), keep ? pa.expt.as<float>() : (float*)nullptr,
                        keep ? pa.ctrl.as<float>() : (float*)nullptr, pa.p.as<float>(), ctx->par.thr, sigM, skipM,
-                       ctx->dStatus.as<u32>());
+                       ctx->dStatus.as<u32>(), ctx->dRisk.as<RiskBuf>());
     if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(&ctx->mail->nMerged, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
+    if (int rc__ = risk_queue(ctx)) return rc__;
     int rc = read_status(ctx);
+    {
+      RiskTargets T{};
+      T.pairP = pa.p.as<float>();
+      T.sigMask = sigM;
+      T.thr = ctx->par.thr;
+      const int rcRisk = risk_apply(ctx, T);
+      if (!rc) rc = rcRisk;
+    }
     if (rc) return rc;
     pa.n = ctx->mail->nMerged;
     ctx->maskN = pa.n;
@@ -1148,7 +1303,8 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
     hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(4 * ctx->numCU))), dim3(MG_NT), lds, s, S,
-                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>());
+                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
+                       ctx->dRisk.as<RiskBuf>());
     if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
     const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
     HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));
@@ -1165,7 +1321,15 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(&ctx->mail->nMerged, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
+    if (int rc__ = risk_queue(ctx)) return rc__;
     int rc = read_status(ctx);
+    {
+      RiskTargets T{};
+      T.fisherP = comb.p.as<float>();
+      T.fisherTileOff = comb.tileOff.as<u32>();
+      const int rcRisk = risk_apply(ctx, T);
+      if (!rc) rc = rcRisk;
+    }
     if (rc) return rc;
     comb.n = ctx->mail->nMerged;
     ctx->reps.push_back(std::move(comb));
@@ -1204,12 +1368,45 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                        fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
                        ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
+    const bool multi = ctx->world > 1 || ctx->forceColl;
+    u32 D = 0;
+    if (multi && ctx->comm) {
+      // every rank contributes its {p bits, bp} pairs; all ranks rebuild the same genome-wide table
+      // (hashPval 300-327 runs over all chromosomes).  RCCL on device buffers: the counts first (the
+      // host needs their maximum to size the exchange), then the records, padded to that maximum.
+      const gxrccl::Api* api = gxrccl::load(&ctx->err);
+      if (!api) return GX_ERR_DEVICE;
+      const u32 W = (u32)ctx->world;
+      if (W > 64) { ctx->err = "more than 64 ranks"; return GX_ERR_ORDER; }
+      HIPCHECK(ctx->dCounts.ensure(64 * 4));
+      ncclResult_t r = api->allGather(misc + M_BHCOUNT, ctx->dCounts.p, 1, ncclUint32, ctx->comm, s);
+      if (r != ncclSuccess) { ctx->err = std::string("ncclAllGather: ") + api->getErrorString(r); return GX_ERR_DEVICE; }
+      HIPCHECK(hipMemcpyAsync(ctx->mail->counts, ctx->dCounts.p, W * 4, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      u32 maxD = 1;
+      for (u32 k = 0; k < W; k++) maxD = std::max(maxD, ctx->mail->counts[k]);
+      const u32 Dl = ctx->mail->counts[ctx->rank];
+      HIPCHECK(ctx->bhRecs.ensure((size_t)maxD * sizeof(BhRec)));
+      HIPCHECK(ctx->dGather.ensure((size_t)maxD * W * sizeof(BhRec)));
+      if (Dl)
+        hipLaunchKernelGGL(k_bh_pack, dim3(std::max(1u, std::min((Dl + 255) / 256, 1024u))), dim3(256), 0, s,
+                           ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), ctx->bhLens.as<u64>(), Dl,
+                           ctx->bhRecs.as<BhRec>());
+      r = api->allGather(ctx->bhRecs.p, ctx->dGather.p, (size_t)maxD * 2, ncclUint64, ctx->comm, s);
+      if (r != ncclSuccess) { ctx->err = std::string("ncclAllGather: ") + api->getErrorString(r); return GX_ERR_DEVICE; }
+      hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);  // this rank's own entries out, everybody's in
+      HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
+      hipLaunchKernelGGL(k_bh_insert_gathered, dim3(std::max(1u, std::min((maxD + 255) / 256, 256u)), std::min(W, 64u)), dim3(256),
+                         0, s, ctx->dGather.as<BhRec>(), ctx->dCounts.as<u32>(), W, maxD, T, ctx->dStatus.as<u32>());
+      HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      D = ctx->mail->D;
+    } else {
     HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    u32 D = ctx->mail->D;
-    if (ctx->world > 1 && ctx->allgather) {
-      // every rank contributes its {p bits, bp} pairs; all ranks rebuild the same genome-wide table
-      // (hashPval 300-327 runs over all chromosomes)
+    D = ctx->mail->D;
+    if (multi && ctx->allgather) {
+      // the same exchange through the host program's callback (validation mode of the tests / bench.py)
       HIPCHECK(ctx->bhRecs.ensure((size_t)std::max(D, 1u) * sizeof(BhRec)));
       HIPCHECK(ctx->hostRecs.ensure((size_t)std::max(D, 1u) * sizeof(BhRec)));
       if (D) {
@@ -1238,6 +1435,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
       HIPCHECK(hipStreamSynchronize(s));
       D = ctx->mail->D;
+    }
     }
     if (D) {
       HIPCHECK(ctx->bhSortKeys.ensure((size_t)D * 4));
@@ -1453,20 +1651,56 @@ int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* en
   return GX_OK;
 }
 
-int gx_selftest(gx_ctx* ctx, int what, const float* a, const float* b, float* out, size_t n) {
-  if (!ctx || !a || !out || !n) return GX_ERR_ORDER;
+int gx_selftest2(gx_ctx* ctx, int what, const float* a, const float* b, float* out, double* out_double, size_t n,
+                 size_t* n_risky) {
+  if (!ctx || !a || !out || !n || n > 0xFFFFFFFFull) return GX_ERR_ORDER;
   HIPCHECK(hipSetDevice(ctx->device));
-  DevBuf da, db, dout;
+  DevBuf da, db, dout, ddbl;
   HIPCHECK(da.ensure(n * 4));
   HIPCHECK(db.ensure(n * 4));
   HIPCHECK(dout.ensure(n * 4));
+  if (out_double) HIPCHECK(ddbl.ensure(n * 8));
   HIPCHECK(hipMemcpy(da.p, a, n * 4, hipMemcpyHostToDevice));
   if (b) HIPCHECK(hipMemcpy(db.p, b, n * 4, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_selftest, dim3(1024), dim3(256), 0, ctx->stream, what, da.as<float>(), db.as<float>(),
-                     dout.as<float>(), (u32)n);
+                     dout.as<float>(), ddbl.as<double>(), (u32)n, ctx->dRisk.as<RiskBuf>());
   if (int rc__ = dbg_sync(ctx, "k_selftest")) return rc__;
+  if (int rc__ = risk_queue(ctx)) return rc__;
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  if (n_risky) *n_risky = static_cast<RiskBuf*>(ctx->riskHost.p)->count;
+  RiskTargets T{};
+  T.selfOut = dout.as<float>();
+  if (int rc__ = risk_apply(ctx, T, RiskHostIn{a, b})) return rc__;
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   HIPCHECK(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+  if (out_double) HIPCHECK(hipMemcpy(out_double, ddbl.p, n * 8, hipMemcpyDeviceToHost));
+  return GX_OK;
+}
+
+int gx_selftest(gx_ctx* ctx, int what, const float* a, const float* b, float* out, size_t n) {
+  return gx_selftest2(ctx, what, a, b, out, nullptr, n, nullptr);
+}
+
+// the same scalar routines compiled for the host (what 1: calcPval, 3: multPval's tail): what the library
+// evaluates risky values with, i.e. with this machine's libm; no context, no device
+int gx_selftest_host(int what, const float* a, const float* b, float* out, double* out_double, size_t n) {
+  if (!a || !b || !out || (what != 1 && what != 3)) return GX_ERR_ORDER;
+  for (size_t i = 0; i < n; i++) {
+    bool rk = false;
+    double d = 0.0;
+    if (what == 1) {
+      out[i] = calc_pval(a[i], b[i], &rk);
+      if (a[i] > 0.0f && b[i] > 0.0f) {
+        double ml, sl;
+        lnorm_params(b[i], &ml, &sl);
+        d = pval_double(a[i], log((double)a[i]), ml, sl);
+      }
+    } else {
+      out[i] = fisher_combine((double)a[i], (int)b[i], &rk);
+      if ((int)b[i] > 2 && a[i] != 0.0f) d = fisher_double((double)a[i], (int)b[i]);
+    }
+    if (out_double) out_double[i] = d;
+  }
   return GX_OK;
 }
 

@@ -48,6 +48,33 @@ enum : u32 {
   ST_BAD_DF = 256u,      // more than 200 replicates         (ERRDF, :556)
 };
 
+// ---- "risky" p-values (gx_math.h: round_checked) ------------------------------------------------
+// Every kernel that rounds a p-value to float appends the few results that lie next to a float
+// rounding boundary to this list; at the next point where the host synchronises anyway it
+// re-evaluates them with the host's libm (the same __host__ __device__ routines) and k_risk_apply
+// writes the values back.  What a record refers to depends on its kind.
+enum : u32 {
+  RK_LUT = 1,    // a = V: entry of the no-control table p(V)
+  RK_DEEP = 2,   // a = V: a pileup beyond that table (k_pval_deep)
+  RK_TAB2D = 3,  // a = index into the PT_N x PT_N table of whole (treatment, control) pileups
+  RK_PAIR = 4,   // a = interval, b / c = exact treatment / control pileups (k_pack_pairs_full)
+  RK_FISHER = 5, // a = tile, b = interval within the tile, c = df, x = sum of -log10 p (k_mergeN)
+  RK_SELF = 6,   // a = index, b = function (gx_selftest)
+};
+struct RiskRec { u32 kind, a, b, c; double x; float pnew; u32 pad; };
+constexpr u32 RISK_CAP = 16384, RISK_PREFIX = 64;  // records kept / records the host reads with the count
+struct RiskBuf { u32 count; u32 pad[7]; RiskRec rec[RISK_CAP]; };
+static_assert(sizeof(RiskRec) == 32 && sizeof(RiskBuf) == 32 + 32 * RISK_CAP, "layout shared with the host");
+
+__device__ __forceinline__ void risk_add(RiskBuf* rb, u32 kind, u32 a, u32 b, u32 c, double x) {
+  const u32 j = atomicAdd(&rb->count, 1u);  // (beyond RISK_CAP only the count grows: the host reports it)
+  if (j < RISK_CAP) rb->rec[j] = RiskRec{kind, a, b, c, x, 0.0f, 0u};
+}
+
+// values of pileups beyond the no-control table that the host re-evaluated (RK_DEEP)
+constexpr u32 DEEP_TAB = 64;
+struct DeepTab { u32 n; u32 pad; int v[DEEP_TAB]; float p[DEEP_TAB]; };
+
 struct DChrom {
   u32 len;
   u32 tileBase;  // first tile of this chromosome (NULL_TILE when it has none)
@@ -1564,17 +1591,32 @@ struct Scalars {
   u64 genomeLen;
 };
 
-// closed form or general path -> the (integer, fraction * 2^27) accumulator pair
-__global__ void k_frag_select(const FragFix* __restrict__ ff, long long* __restrict__ acc) {
-  if (threadIdx.x || blockIdx.x || ff->slow) return;
-  u64 t = 0;
-  for (int i = 0; i < FRAG_SLOTS; i++) t += ff->fragSum[i];
-  acc[0] = (long long)t + ff->corr;
-  acc[1] = 0;
+// closed form or general path -> the (integer, fraction * 2^27) accumulator pair; with several ranks
+// also this rank's contribution to the all-reduce: the pair and its "a base can saturate" flag (every
+// rank must learn whether any rank has to rebuild its sample before the sums mean anything)
+__global__ void k_frag_select(const FragFix* __restrict__ ff, long long* __restrict__ acc, long long* __restrict__ coll,
+                              const u32* __restrict__ hot) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (!ff->slow) {
+    u64 t = 0;
+    for (int i = 0; i < FRAG_SLOTS; i++) t += ff->fragSum[i];
+    acc[0] = (long long)t + ff->corr;
+    acc[1] = 0;
+  }
+  if (coll) {
+    coll[0] = acc[0];
+    coll[1] = acc[1];
+    coll[2] = *hot ? 1 : 0;
+  }
 }
 
-__global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st) {
+__global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st, const long long* __restrict__ coll) {
   if (threadIdx.x || blockIdx.x) return;
+  long long* acc = isCtrl ? s->ctrlAcc : s->fragAcc;
+  if (coll) {  // the sums over all ranks
+    acc[0] = coll[0];
+    acc[1] = coll[1];
+  }
   if (!isCtrl) {
     s->fragLen = (double)s->fragAcc[0] + (double)s->fragAcc[1] * (1.0 / 134217728.0);
     if (s->fragLen == 0.0) atomicOr(st, ST_NO_FRAGS);

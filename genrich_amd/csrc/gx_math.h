@@ -2,24 +2,32 @@
 //
 // Pileup values are exact integers in units of 1/120 ("V120"); the float the reference
 // would hold is re-materialised by gx_getval exactly as getVal does (Genrich.c:1902-1907).
-// p-values are double math rounded once to float (calcPval, Genrich.c:1628-1653); the
-// device uses OCML's double log/exp/log1p (<= 1-2 ulp), so the float result equals the
-// host-libm one unless the double lands within ~1e-16 of a float rounding boundary.
-// Compile with -ffp-contract=off: the reference is built without FMA contraction.
+// p-values are double math rounded once to float (calcPval, Genrich.c:1628-1653).  The device
+// uses OCML's double log/exp/log1p, the reference the host's libm; the two agree to a few ulp of
+// the DOUBLE, so the float differs only when the double lies next to a float rounding boundary.
+// round_checked() detects exactly that (distance to the boundary below RISK_B of the value, far
+// above any libm difference): such a value is "risky", goes on a list, and is re-evaluated by the
+// very same routines compiled for the host (every function here is __host__ __device__), i.e. with
+// the libm the reference itself would call on this machine.  A handful per run; all others are
+// bit-identical by the error bound.  Compile with -ffp-contract=off: the reference is built
+// without FMA contraction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
 
+#include <math.h>
+
 #define GX_UNIT 120
 #define GX_SKIPF (-1.0f)
+#define GX_HD __host__ __device__
 
 namespace gx {
 
 // residue mod 120 -> packed (eighths | sixths<<4 | tenths<<8) with 15e+20s+12t == r (mod 120),
 // e<8, s<3, t<5 (a bijection; frac bit layout of the reference: Genrich.c:2299-2305).
 // mod 3: 15e+20s+12t = 2s ; mod 5: = 2t ; mod 8: = 7e + 4(s+t).
-__device__ __forceinline__ uint32_t est_of_residue(int r) {
+GX_HD __forceinline__ uint32_t est_of_residue(int r) {
   uint32_t s = (uint32_t)(r * 2) % 3u;
   uint32_t t = (uint32_t)(r * 3) % 5u;
   uint32_t e = (7u * ((uint32_t)r + 4u * (s + t))) & 7u;
@@ -28,7 +36,7 @@ __device__ __forceinline__ uint32_t est_of_residue(int r) {
 
 // getVal (1902-1907) of the canonical (cov, e, s, t) state of the exact sum v/120.
 // *neg is set when the canonical integer part is negative (updateVal's ERRPILE, 1921/1969).
-__device__ __forceinline__ float getval(int32_t v, bool* neg) {
+GX_HD __forceinline__ float getval(int32_t v, bool* neg) {
   int32_t q = v / GX_UNIT, r = v - q * GX_UNIT;
   if (r < 0) { r += GX_UNIT; q -= 1; }
   if (r == 0) { *neg = q < 0; return (float)q; }
@@ -39,16 +47,41 @@ __device__ __forceinline__ float getval(int32_t v, bool* neg) {
   return (float)cov + ((float)e / 8.0f) + ((float)s / 6.0f) + ((float)t / 10.0f);
 }
 
+// ---- the one rounding of a p-value: double -> float, with the "risky" test ----------------------
+// Device and host evaluate the same IEEE operations around different libm calls (<= ~1.5 ulp of the
+// double apart per call); through calcPval / pchisq that propagates to a relative difference of at
+// most a few 1e-14 in the double result.  A result whose distance to the
+// nearest float rounding boundary (the midpoint of two neighbouring floats) is below RISK_B of its
+// value is not rounded here but flagged: RISK_B = 2^-40 = 9.1e-13 leaves a factor of >= 30, and the
+// numerics tests measure the actual double-level difference against it.  About 2 * RISK_B / 2^-24
+// = 3e-5 of all values are flagged.
+#define GX_RISK_B 0x1p-40
+
+GX_HD __forceinline__ float bits_float(uint32_t u) { union { uint32_t u; float f; } x; x.u = u; return x.f; }
+GX_HD __forceinline__ uint32_t float_bits(float f) { union { uint32_t u; float f; } x; x.f = f; return x.u; }
+
+GX_HD inline float round_checked(double pv, bool* risky) {  // |pv| <= FLT_MAX
+  const float f = (float)pv;
+  const double a = fabs(pv), fd = fabs((double)f);  // rounding is symmetric: work on magnitudes
+  const double err = fabs(a - fd);                  // exact
+  const uint32_t b = float_bits(f) & 0x7FFFFFFFu;
+  // the neighbouring float on pv's side (beyond zero lies the smallest subnormal of the other sign)
+  const double nb = a >= fd ? (double)bits_float(b + 1u) : (b ? (double)bits_float(b - 1u) : -1.401298464324817e-45);
+  const double half = 0.5 * fabs(nb - fd);  // (an infinite neighbour gives an infinite distance)
+  if (half - err < a * GX_RISK_B) *risky = true;
+  return f;
+}
+
 // ---- log-normal -log10 p : calcPval (1628-1653), plnorm (1617), pnorm (1509-1607) ----
 
-__device__ __forceinline__ double do_del(double y, double temp, bool lower) {  // 1497-1503
+GX_HD __forceinline__ double do_del(double y, double temp, bool lower) {  // 1497-1503
   double xsq = trunc(y * 16) / 16;
   double del = (y - xsq) * (y + xsq);
   if (lower) return log1p(-exp((-xsq * xsq - del) / 2.0) * temp);
   return (-xsq * xsq - del) / 2.0 + log(temp);
 }
 
-__device__ inline double pnorm_upper_log(double x) {
+GX_HD inline double pnorm_upper_log(double x) {
   const double a0 = 2.2352520354606839287, a1 = 161.02823106855587881,
                a2 = 1067.6894854603709582, a3 = 18154.981253343561249,
                a4 = 0.065682337918207449113;
@@ -106,7 +139,7 @@ __device__ inline double pnorm_upper_log(double x) {
 }
 
 // meanlog / sdlog of the null for control value mu (1637-1648)
-__device__ __forceinline__ void lnorm_params(float ctrl, double* meanlog, double* sdlog) {
+GX_HD __forceinline__ void lnorm_params(float ctrl, double* meanlog, double* sdlog) {
   double mu = ctrl;
   if (mu > 7.0) {
     double sd = 10.0 * log10(mu);
@@ -120,31 +153,50 @@ __device__ __forceinline__ void lnorm_params(float ctrl, double* meanlog, double
   }
 }
 
-__device__ __forceinline__ float pval_given(float expt, double meanlog, double sdlog) {
-  double pv;
-  if (sdlog == 0.0)
-    pv = (double)expt < meanlog ? 0.0 : (double)FLT_MAX;
-  else
-    pv = -pnorm_upper_log((log((double)expt) - meanlog) / sdlog) / 2.30258509299404568402;
-  return pv > (double)FLT_MAX ? FLT_MAX : (float)pv;
+// the double the reference rounds (1651-1652), from log(expt) and the control's parameters
+GX_HD __forceinline__ double pval_double(float expt, double logExpt, double meanlog, double sdlog) {
+  if (sdlog == 0.0) return (double)expt < meanlog ? 0.0 : (double)FLT_MAX;
+  return -pnorm_upper_log((logExpt - meanlog) / sdlog) / 2.30258509299404568402;
 }
 
-__device__ inline float calc_pval(float expt, float ctrl) {
+GX_HD __forceinline__ float pval_round(double pv, bool* risky) {
+  return pv > (double)FLT_MAX ? FLT_MAX : round_checked(pv, risky);
+}
+
+GX_HD __forceinline__ float pval_given(float expt, double meanlog, double sdlog, bool* risky) {
+  return pval_round(pval_double(expt, log((double)expt), meanlog, sdlog), risky);
+}
+
+GX_HD inline float calc_pval(float expt, float ctrl, bool* risky) {
   if (ctrl == GX_SKIPF) return GX_SKIPF;
   if (ctrl == 0.0f) return expt == 0.0f ? 0.0f : FLT_MAX;
   if (expt == 0.0f) return 0.0f;
   double ml, sl;
   lnorm_params(ctrl, &ml, &sl);
-  return pval_given(expt, ml, sl);
+  return pval_given(expt, ml, sl, risky);
+}
+
+// the pileup floats of the two samples of a p-interval from their exact values (1/120 units; V_MARK
+// inside an excluded -E region)
+#define GX_V_MARK ((int32_t)0x80000000)
+GX_HD __forceinline__ float expt_val(int v, bool* neg) {
+  if (v == GX_V_MARK) { *neg = false; return 0.0f; }  // excluded region: 2248 / 2273
+  return getval(v, neg);
+}
+
+GX_HD __forceinline__ float ctrl_net(int v, float factor, float lambda, bool* neg) {
+  if (v == GX_V_MARK) { *neg = false; return GX_SKIPF; }  // excluded region: 2124 / 2141
+  float val = factor * getval(v, neg);  // 2107 / 2118: float product
+  return val > lambda ? val : lambda;   // MAX(val, lambda)
 }
 
 // ---- chi-squared upper tail, log scale: pchisq (555-559) and helpers (407-545) ----
 
-__device__ __forceinline__ double log1_exp(double x) {  // R_Log1_Exp, 407
+GX_HD __forceinline__ double log1_exp(double x) {  // R_Log1_Exp, 407
   return x > -0.693147180559945309417 ? log(-expm1(x)) : log1p(-exp(x));
 }
 
-__device__ inline double bd0(double x, double np) {  // 412-430
+GX_HD inline double bd0(double x, double np) {  // 412-430
   if (fabs(x - np) < 0.1 * (x + np)) {
     double v = (x - np) / (x + np);
     double s = (x - np) * v;
@@ -161,7 +213,7 @@ __device__ inline double bd0(double x, double np) {  // 412-430
   return x * log(x / np) + np - x;
 }
 
-__device__ inline double stirlerr(double n) {  // 436-469
+GX_HD inline double stirlerr(double n) {  // 436-469
   const double sferr[16] = {0.0,
                             0.0810614667953272582196702,
                             0.0413406959554092940938221,
@@ -186,11 +238,11 @@ __device__ inline double stirlerr(double n) {  // 436-469
   return sferr[(int)n];
 }
 
-__device__ inline double dpois_log(double x, double lambda) {  // 474-477
+GX_HD inline double dpois_log(double x, double lambda) {  // 474-477
   return -0.5 * log(2.0 * 3.14159265358979323846 * x) - stirlerr(x) - bd0(x, lambda);
 }
 
-__device__ inline double pgamma_upper_log(double x, double alph) {  // 528-545
+GX_HD inline double pgamma_upper_log(double x, double alph) {  // 528-545
   if (x < 1) {  // pgamma_smallx 509-522
     double sum = 0.0, c = alph, n = 0.0, term;
     do {
@@ -221,12 +273,14 @@ __device__ inline double pgamma_upper_log(double x, double alph) {  // 528-545
 }
 
 // multPval's tail (577-582): sum of -log10 p over df/2 replicates -> combined -log10 p
-__device__ inline float fisher_combine(double sum, int df) {
+GX_HD inline double fisher_double(double sum, int df) {
+  return -pgamma_upper_log((2.0 * sum / 0.434294481903251827651) / 2.0, df / 2.0) / 2.30258509299404568402;
+}
+
+GX_HD inline float fisher_combine(double sum, int df, bool* risky) {
   if (df == 0) return GX_SKIPF;
   if (df == 2 || sum == 0.0) return (float)sum;
-  double p = -pgamma_upper_log((2.0 * sum / 0.434294481903251827651) / 2.0, df / 2.0) /
-             2.30258509299404568402;
-  return p > (double)FLT_MAX ? FLT_MAX : (float)p;
+  return pval_round(fisher_double(sum, df), risky);
 }
 
 }  // namespace gx

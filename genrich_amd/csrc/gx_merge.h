@@ -34,16 +34,7 @@ struct Merge2Out {   // loose slots: tile t writes at A.tileOff[t] + B.tileOff[t
   u32* tileCount;    // [nTiles]
 };
 
-__device__ __forceinline__ float expt_val(int v, bool* neg) {
-  if (v == V_MARK) { *neg = false; return 0.0f; }  // excluded region: 2248 / 2273
-  return getval(v, neg);
-}
-
-__device__ __forceinline__ float ctrl_net(int v, float factor, float lambda, bool* neg) {
-  if (v == V_MARK) { *neg = false; return GX_SKIPF; }  // excluded region: 2124 / 2141
-  float val = factor * getval(v, neg);  // 2107 / 2118: float product
-  return val > lambda ? val : lambda;   // MAX(val, lambda)
-}
+// (expt_val / ctrl_net: the two pileup floats of a p-interval, gx_math.h)
 
 // No inter-workgroup dependency (like k_tile): counts go to k_scan_counts, packing to k_pack_pairs.
 // Per tile the work is small (a few hundred breakpoints) and the kernel is bound by the chain of
@@ -259,7 +250,8 @@ __global__ __launch_bounds__(256) void k_pair_tabs(const Scalars* __restrict__ s
 }
 
 __device__ __forceinline__ float pval_pair(int ev, int cv, float* exptOut, float* ctrlOut, float factor, float lambda,
-                                           const double* __restrict__ logE, const CtrlEntry* __restrict__ ctab, bool* neg) {
+                                           const double* __restrict__ logE, const CtrlEntry* __restrict__ ctab, bool* neg,
+                                           bool* risky) {
   bool n1 = false, n2 = false;
   const float expt = expt_val(ev, &n1);
   float ctrl;
@@ -279,12 +271,7 @@ __device__ __forceinline__ float pval_pair(int ev, int cv, float* exptOut, float
   if (ctrl == 0.0f) return expt == 0.0f ? 0.0f : FLT_MAX;
   if (expt == 0.0f) return 0.0f;
   const double le = (u32)ev < PAIR_LUT ? logE[ev] : log((double)expt);
-  double pv;
-  if (sl == 0.0)
-    pv = (double)expt < ml ? 0.0 : (double)FLT_MAX;
-  else
-    pv = -pnorm_upper_log((le - ml) / sl) / 2.30258509299404568402;
-  return pv > (double)FLT_MAX ? FLT_MAX : (float)pv;
+  return pval_round(pval_double(expt, le, ml, sl), risky);
 }
 
 struct PackPairsIn {
@@ -302,12 +289,15 @@ struct PackPairsIn {
 constexpr u32 PT_N = 256, PT_HOT = 64;
 
 __global__ __launch_bounds__(256) void k_pair_tab2d(const Scalars* __restrict__ sc, const double* __restrict__ logE,
-                                                    const CtrlEntry* __restrict__ ctab, float* __restrict__ p2d) {
+                                                    const CtrlEntry* __restrict__ ctab, float* __restrict__ p2d,
+                                                    RiskBuf* __restrict__ risk) {
   const float factor = sc->factor, lambda = sc->lambda;
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < PT_N * PT_N; i += gridDim.x * 256) {
     float e, c;
-    bool ng;
-    p2d[i] = pval_pair((int)((i / PT_N) * GX_UNIT), (int)((i % PT_N) * GX_UNIT), &e, &c, factor, lambda, logE, ctab, &ng);
+    bool ng, risky = false;
+    p2d[i] = pval_pair((int)((i / PT_N) * GX_UNIT), (int)((i % PT_N) * GX_UNIT), &e, &c, factor, lambda, logE, ctab, &ng,
+                       &risky);
+    if (risky) risk_add(risk, RK_TAB2D, i, 0, 0, 0.0);
   }
 }
 
@@ -409,7 +399,8 @@ __global__ __launch_bounds__(256) void k_pack_pairs_full(PackPairsIn in, const u
                                                          const double* __restrict__ logE, const CtrlEntry* __restrict__ ctab,
                                                          float* __restrict__ expt, float* __restrict__ ctrl,
                                                          float* __restrict__ p, float thr, u64* __restrict__ sigMask,
-                                                         u64* __restrict__ skipMask, u32* __restrict__ st) {
+                                                         u64* __restrict__ skipMask, u32* __restrict__ st,
+                                                         RiskBuf* __restrict__ risk) {
   const float factor = sc->factor, lambda = sc->lambda;
   const int wv = threadIdx.x >> 6, lane = lane_id();
   const u32 nH = *nHeavy;
@@ -418,9 +409,11 @@ __global__ __launch_bounds__(256) void k_pack_pairs_full(PackPairsIn in, const u
     const u32 t = heavyList[li];
     const u32 src = in.slotA[t] + in.slotB[t], dst = in.tileOff[t], n = in.tileOff[t + 1] - dst;
     for (u32 i = lane; i < n; i += 64) {
-      bool ng;
+      bool ng, risky = false;
       float e, c;
-      const float pv = pval_pair(in.looseE[src + i], in.looseC[src + i], &e, &c, factor, lambda, logE, ctab, &ng);
+      const int ev = in.looseE[src + i], cv = in.looseC[src + i];
+      const float pv = pval_pair(ev, cv, &e, &c, factor, lambda, logE, ctab, &ng, &risky);
+      if (risky) risk_add(risk, RK_PAIR, dst + i, (u32)ev, (u32)cv, 0.0);
       neg |= ng;
       if (expt) {
         expt[dst + i] = e;
@@ -457,7 +450,7 @@ struct MergeNOut {   // loose slots: tile t writes at sum_r tileOff_r[t]
 
 __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restrict__ tileChrom,
                                                   const DChrom* __restrict__ chroms, u32 nTiles,
-                                                  MergeNOut out, u32* __restrict__ st) {
+                                                  MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk) {
   extern __shared__ __attribute__((aligned(16))) u32 bm[];  // S.n bitmaps of MG_WORDS words
   __shared__ u32 scratch[8];
   const int n = S.n;
@@ -523,7 +516,9 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
         }
         if (df > 400) atomicOr(st, ST_BAD_DF);
         out.end[o] = pos0 + w * 32 + b;
-        out.p[o] = fisher_combine(sum, df);
+        bool risky = false;
+        out.p[o] = fisher_combine(sum, df, &risky);
+        if (risky) risk_add(risk, RK_FISHER, t, o - slot, (u32)df, sum);
         o++;
       }
       for (int r = 0; r < n; r++) exR[r] += __popc(bm[r * MG_WORDS + w]);
@@ -538,7 +533,9 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
       }
       u32 oc = slot + tU;
       out.end[oc] = c.len;
-      out.p[oc] = fisher_combine(sum, df);
+      bool risky = false;
+      out.p[oc] = fisher_combine(sum, df, &risky);
+      if (risky) risk_add(risk, RK_FISHER, t, tU, (u32)df, sum);
     }
     }
   }
@@ -560,19 +557,75 @@ __global__ __launch_bounds__(256) void k_pack_ep(RepSet S, const u32* __restrict
   }
 }
 
-// scalar device functions exposed for the numerics tests (gx_selftest)
+// scalar device functions exposed for the numerics tests (gx_selftest); risky p-values go on the list
+// like everywhere else, and `dbl` (optional) receives the double before its rounding to float
 __global__ __launch_bounds__(256) void k_selftest(int what, const float* __restrict__ a, const float* __restrict__ b,
-                                                  float* __restrict__ out, u32 n) {
+                                                  float* __restrict__ out, double* __restrict__ dbl, u32 n,
+                                                  RiskBuf* __restrict__ risk) {
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    bool ng = false;
+    bool ng = false, risky = false;
+    double d = 0.0;
     switch (what) {
       case 0: out[i] = log10f_host(a[i]); break;
-      case 1: out[i] = calc_pval(a[i], b[i]); break;
+      case 1:
+        out[i] = calc_pval(a[i], b[i], &risky);
+        if (dbl && a[i] > 0.0f && b[i] > 0.0f) {
+          double ml, sl;
+          lnorm_params(b[i], &ml, &sl);
+          d = pval_double(a[i], log((double)a[i]), ml, sl);
+        }
+        break;
       case 2: out[i] = getval(__float_as_int(a[i]), &ng); break;
-      case 3: out[i] = fisher_combine((double)a[i], (int)b[i]); break;
+      case 3:
+        out[i] = fisher_combine((double)a[i], (int)b[i], &risky);
+        if (dbl && (int)b[i] > 2 && a[i] != 0.0f) d = fisher_double((double)a[i], (int)b[i]);
+        break;
       default: out[i] = 0.0f;
     }
+    if (dbl) dbl[i] = d;
+    if (risky) risk_add(risk, RK_SELF, i, (u32)what, 0, 0.0);
   }
+}
+
+// the host's values for the listed results, written where each kind lives (one workgroup: the list is short)
+struct RiskTargets {
+  float* lutP;
+  float* p2d;
+  DeepTab* deep;
+  float* pairP;          // RK_PAIR: p-array of the replicate being closed
+  u64* sigMask;          // ... and its significance mask (p mode), or nullptr
+  float thr;
+  float* fisherP;        // RK_FISHER: tight p of the combination
+  const u32* fisherTileOff;
+  float* selfOut;
+};
+
+__global__ __launch_bounds__(256) void k_risk_apply(RiskBuf* __restrict__ rb, u32 n, RiskTargets T) {
+  for (u32 i = threadIdx.x; i < n; i += 256) {
+    const RiskRec r = rb->rec[i];
+    switch (r.kind) {
+      case RK_LUT: T.lutP[r.a] = r.pnew; break;
+      case RK_TAB2D: T.p2d[r.a] = r.pnew; break;
+      case RK_DEEP: {
+        const u32 j = atomicAdd(&T.deep->n, 1u);
+        if (j < DEEP_TAB) { T.deep->v[j] = (int)r.a; T.deep->p[j] = r.pnew; }
+        break;
+      }
+      case RK_PAIR:
+        T.pairP[r.a] = r.pnew;
+        if (T.sigMask) {
+          const unsigned long long bit = 1ull << (r.a & 63);
+          if (r.pnew > T.thr) atomicOr((unsigned long long*)&T.sigMask[r.a >> 6], bit);
+          else atomicAnd((unsigned long long*)&T.sigMask[r.a >> 6], ~bit);
+        }
+        break;
+      case RK_FISHER: T.fisherP[T.fisherTileOff[r.a] + r.b] = r.pnew; break;
+      case RK_SELF: T.selfOut[r.a] = r.pnew; break;
+      default: break;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) rb->count = 0;  // the list starts empty for the next producer
 }
 
 }  // namespace gx

@@ -1,0 +1,63 @@
+// gx_rccl.h -- the library's own collectives: RCCL over xGMI on device buffers, on the library's stream.
+//
+// Chromosomes shard across GPUs (the reference's per-chromosome loops Genrich.c:2172, 1729,
+// 987), so the hot path needs three tiny genome-wide exchanges and nothing else:
+//   1. fragLen / ctrlFrag (calcLambda 1817, calcFactor 1980): all-reduce of 2 x int64 fixed-point parts;
+//   2. the BH table (hashPval 300-327 runs over all chromosomes): all-gather of {p bits, bp} records;
+//   3. the peak list: gathered by the host program (peak_N numbering, 986 / 925).
+// librccl is opened at run time, so a single-GPU run needs no RCCL at all.  One communicator per
+// context (= per GPU, one process or thread each); the unique id travels by whatever channel the
+// host program has (torch.distributed in bench.py, shared memory between the threads of genrich-amd).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <string>
+
+namespace gxrccl {
+
+struct Api {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclAllReduce) allReduce = nullptr;
+  decltype(&ncclAllGather) allGather = nullptr;
+  decltype(&ncclGetErrorString) getErrorString = nullptr;
+};
+
+inline const Api* load(std::string* err) {
+  static Api api;
+  static bool tried = false;
+  static std::string why;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (api.handle) break;
+    }
+    if (!api.handle) {
+      why = std::string("cannot open librccl: ") + dlerror();
+    } else {
+      api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+      api.commInitRank = reinterpret_cast<decltype(api.commInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+      api.commDestroy = reinterpret_cast<decltype(api.commDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+      api.allReduce = reinterpret_cast<decltype(api.allReduce)>(dlsym(api.handle, "ncclAllReduce"));
+      api.allGather = reinterpret_cast<decltype(api.allGather)>(dlsym(api.handle, "ncclAllGather"));
+      api.getErrorString = reinterpret_cast<decltype(api.getErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+      if (!api.getUniqueId || !api.commInitRank || !api.commDestroy || !api.allReduce || !api.allGather ||
+          !api.getErrorString) {
+        why = "librccl lacks an entry point";
+        api.handle = nullptr;
+      }
+    }
+  }
+  if (!api.handle) {
+    if (err) *err = why;
+    return nullptr;
+  }
+  return &api;
+}
+
+}  // namespace gxrccl

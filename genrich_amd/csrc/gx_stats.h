@@ -14,21 +14,24 @@ namespace gx {
 // computed directly.  Same bits either way.
 constexpr u32 PV_LUT = 1u << 18;
 
-__device__ __forceinline__ float pval_of_v(int v, float lambda, double ml, double sl, float* valOut, bool* neg) {
+__device__ __forceinline__ float pval_of_v(int v, float lambda, double ml, double sl, float* valOut, bool* neg, bool* risky) {
   float val = getval(v, neg);
   *valOut = val;
   if (lambda == 0.0f) return val == 0.0f ? 0.0f : FLT_MAX;  // calcPval 1631-1632
-  return val == 0.0f ? 0.0f : pval_given(val, ml, sl);
+  return val == 0.0f ? 0.0f : pval_given(val, ml, sl, risky);
 }
 
-__global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc, float* __restrict__ lutP) {
+__global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc, float* __restrict__ lutP,
+                                                  RiskBuf* __restrict__ risk, DeepTab* __restrict__ deep) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) deep->n = 0;  // this sample's host-evaluated deep values come later
   const float lambda = sc->lambda;
   double ml = 0, sl = 1;
   if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
   for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += gridDim.x * 256) {
     float val;
-    bool ng;
-    lutP[v] = pval_of_v((int)v, lambda, ml, sl, &val, &ng);
+    bool ng, risky = false;
+    lutP[v] = pval_of_v((int)v, lambda, ml, sl, &val, &ng, &risky);
+    if (risky) risk_add(risk, RK_LUT, v, 0, 0, 0.0);
   }
 }
 
@@ -184,10 +187,34 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
   if (neg) atomicOr(st, ST_NEG_PILE);
 }
 
-// the intervals of the deep tiles whose pileup lies beyond the table
+// the intervals of the deep tiles whose pileup lies beyond the table.  k_deep_risky runs while the
+// sample is closed (the host synchronises there): it evaluates the same intervals and lists the
+// values that are risky; the host's answers come back in `deep`, where k_pval_deep finds them.
+__global__ __launch_bounds__(256) void k_deep_risky(PackIn in, const FragFix* __restrict__ ff, const u32* __restrict__ list,
+                                                    const Scalars* __restrict__ sc, RiskBuf* __restrict__ risk) {
+  const u32 nList = ff->nList;
+  const float lambda = sc->lambda;
+  double ml = 0, sl = 1;
+  if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  for (u32 li = blockIdx.x * 4 + wv; li < nList; li += gridDim.x * 4) {
+    const u32 t = list[li];
+    const u32 src = in.meta[t].slot, n = in.tileIvOff[t + 1] - in.tileIvOff[t];
+    for (u32 i = lane; i < n; i += 64) {
+      const int v = in.looseV[src + i];
+      if (v != V_MARK && (u32)v >= PV_LUT) {
+        float val;
+        bool ng, risky = false;
+        (void)pval_of_v(v, lambda, ml, sl, &val, &ng, &risky);
+        if (risky) risk_add(risk, RK_DEEP, (u32)v, 0, 0, 0.0);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_pval_deep(PackIn in, const FragFix* __restrict__ ff, const u32* __restrict__ list,
-                                                   const Scalars* __restrict__ sc, float* __restrict__ pOut, float thr,
-                                                   u64* __restrict__ sigMask) {
+                                                   const Scalars* __restrict__ sc, const DeepTab* __restrict__ deep,
+                                                   float* __restrict__ pOut, float thr, u64* __restrict__ sigMask) {
   const u32 nList = ff->nList;
   const float lambda = sc->lambda;
   double ml = 0, sl = 1;
@@ -200,8 +227,13 @@ __global__ __launch_bounds__(256) void k_pval_deep(PackIn in, const FragFix* __r
       const int v = in.looseV[src + i];
       if (v != V_MARK && (u32)v >= PV_LUT) {
         float val;
-        bool ng;
-        const float p = pval_of_v(v, lambda, ml, sl, &val, &ng);
+        bool ng, risky = false;
+        float p = pval_of_v(v, lambda, ml, sl, &val, &ng, &risky);
+        if (risky) {  // the host's value (always there: k_deep_risky saw the same interval)
+          const u32 nd = min(deep->n, DEEP_TAB);
+          for (u32 j = 0; j < nd; j++)
+            if (deep->v[j] == v) p = deep->p[j];
+        }
         pOut[dst + i] = p;
         if (sigMask && p > thr) atomicOr((unsigned long long*)&sigMask[(dst + i) >> 6], 1ull << ((dst + i) & 63));
       }
@@ -329,6 +361,16 @@ __global__ __launch_bounds__(256) void k_bh_pack(const u32* __restrict__ keys, c
 // ... and the insertion of every rank's records into a fresh table
 __global__ __launch_bounds__(256) void k_bh_insert(const BhRec* __restrict__ recs, u32 n, BhTable T, u32* __restrict__ st) {
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) bh_global_add(T, recs[i].key, recs[i].bp, st);
+}
+
+// the same from an all-gathered buffer: rank r's records start at r * stride, counts[r] of them
+__global__ __launch_bounds__(256) void k_bh_insert_gathered(const BhRec* __restrict__ recs, const u32* __restrict__ counts,
+                                                            u32 world, u32 stride, BhTable T, u32* __restrict__ st) {
+  for (u32 r = blockIdx.y; r < world; r += gridDim.y) {
+    const u32 n = min(counts[r], stride);
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+      bh_global_add(T, recs[(size_t)r * stride + i].key, recs[(size_t)r * stride + i].bp, st);
+  }
 }
 
 // float log10 exactly as the host's libm evaluates it (saveQval 221, 226 call log10f).

@@ -50,6 +50,8 @@ _SIGS = {
     "gx_set_owned": [C.c_void_p, C.c_void_p],
     "gx_set_keep_pileups": [C.c_void_p, C.c_int],
     "gx_set_collectives": [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p],
+    "gx_rccl_unique_id": [C.c_void_p, C.c_size_t],
+    "gx_set_rccl": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "gx_sample_begin": [C.c_void_p, C.c_int, C.c_void_p],
     "gx_push_events": [C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_push_events_device": [C.c_void_p, C.c_void_p, C.c_size_t],
@@ -66,6 +68,8 @@ _SIGS = {
     "gx_interval_count": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)],
     "gx_get_intervals": [C.c_void_p, C.c_int, C.c_int, C.c_size_t] + [C.c_void_p] * 5,
     "gx_selftest": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_selftest2": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)],
+    "gx_selftest_host": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_phase_times": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float))],
 }
 
@@ -105,6 +109,30 @@ def filter_saturation(events, lens):
     if rc < 0:
         raise RuntimeError(f"gx_filter_saturation: {rc}")
     return keep, int(rc)
+
+
+def rccl_unique_id() -> bytes:
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.gx_rccl_unique_id(buf, 128)
+    if rc:
+        raise RuntimeError(f"gx_rccl_unique_id: {rc}")
+    return buf.raw
+
+
+def selftest_host(what, a, b):
+    """calcPval (what 1) / multPval's tail (what 3) by the host build of the library's routines: returns
+    (float results, the doubles they were rounded from).  Needs no GPU."""
+    import numpy as np
+    lib = load_library()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    out = np.zeros_like(a)
+    dbl = np.zeros(a.size, dtype=np.float64)
+    rc = lib.gx_selftest_host(int(what), a.ctypes.data, b.ctypes.data, out.ctypes.data, dbl.ctypes.data, a.size)
+    if rc:
+        raise RuntimeError(f"gx_selftest_host: {rc}")
+    return out, dbl
 
 
 class Genrich:
@@ -171,6 +199,12 @@ class Genrich:
     def set_collectives(self, rank, world, allreduce, allgather):
         self._cb = (ALLREDUCE_FN(allreduce), ALLGATHER_FN(allgather))
         self._check(self.lib.gx_set_collectives(self.ctx, rank, world, self._cb[0], self._cb[1], None))
+
+    def set_rccl(self, rank, world, unique_id: bytes):
+        """The library's own RCCL communicator (collective over all ranks); unique_id = rccl_unique_id()
+        of one rank, handed to the others by the host program."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.gx_set_rccl(self.ctx, int(rank), int(world), buf))
 
     def sample_begin(self, is_ctrl, save=None):
         sp = None
@@ -254,6 +288,17 @@ class Genrich:
             bp = b.ctypes.data
         self._check(self.lib.gx_selftest(self.ctx, int(what), a.ctypes.data, bp, out.ctypes.data, a.size))
         return out
+
+    def selftest2(self, what, a, b):
+        """selftest plus the doubles before rounding and the number of results the host re-evaluated."""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        out = np.zeros_like(a)
+        dbl = np.zeros(a.size, dtype=np.float64)
+        nr = C.c_size_t(0)
+        self._check(self.lib.gx_selftest2(self.ctx, int(what), a.ctypes.data, b.ctypes.data, out.ctypes.data,
+                                          dbl.ctypes.data, a.size, C.byref(nr)))
+        return out, dbl, nr.value
 
     def interval_total(self, which=GX_IV_FINAL):
         n = C.c_size_t(0)

@@ -180,8 +180,8 @@ int gx_write_log_path(gx_ctx* ctx, int n_rep, const char* const* names, int n_ch
  *      three genome-wide quantities are exchanged through host-supplied callbacks
  *      (RCCL via torch.distributed in bench.py; a no-op on one GPU). ---- */
 
-/* Sum `n` int64 values over all ranks in place (fragLen / ctrlFrag fixed-point parts,
- * genome length).  buf is host memory. */
+/* Sum `n` int64 values over all ranks in place (fragLen / ctrlFrag fixed-point parts and the
+ * ranks' "a base can saturate" flags: n = 3).  buf is host memory. */
 typedef int (*gx_allreduce_i64_fn)(int64_t* buf, size_t n, void* user);
 /* Gather variable-length tables: every rank contributes n_local 16-byte records
  * {uint32 key, uint32 pad, uint64 bp}; the callback returns a malloc'd concatenation of
@@ -191,6 +191,13 @@ typedef int (*gx_allgather_tab_fn)(const void* local, size_t n_local, void** out
                                    size_t* n_out, void* user);
 int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce,
                        gx_allgather_tab_fn allgather, void* user);
+/* The library's own collectives: RCCL over xGMI on device buffers, on the library's stream (no host
+ * hop in the data path).  One rank calls gx_rccl_unique_id and hands the 128 bytes to every rank
+ * by whatever channel the host program has; then every rank calls gx_set_rccl (collective: it
+ * returns when all `world` ranks have called it).  Replaces gx_set_collectives' callbacks, which stay
+ * for host programs without RCCL (the tests' gloo mode).  librccl is opened at run time. */
+int gx_rccl_unique_id(void* out, size_t cap /* >= 128 */);
+int gx_set_rccl(gx_ctx* ctx, int rank, int world, const void* unique_id);
 /* owned[i] = 1: this rank computes chromosome i (default: all).  The full table still goes to
  * gx_set_chroms on every rank, so genome lengths and output order are global; device work and
  * memory are laid out for the owned chromosomes only.  Call after gx_set_chroms and before the
@@ -215,6 +222,14 @@ int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
  *      2: getVal of the exact pileup whose int32 bits are in a (1/120 units, :1902)
  *      3: multPval's combination of sum = a over df = b (567-583) */
 int gx_selftest(gx_ctx* ctx, int what, const float* a, const float* b, float* out, size_t n);
+/* The same, plus (what 1 and 3) the double each result was rounded from in out_double (may be NULL)
+ * and the number of results that lay next to a float rounding boundary and were therefore
+ * re-evaluated with the host's libm ("risky", gx_math.h) in *n_risky (may be NULL). */
+int gx_selftest2(gx_ctx* ctx, int what, const float* a, const float* b, float* out, double* out_double,
+                 size_t n, size_t* n_risky);
+/* what 1 and 3 evaluated by the host build of the same routines (this machine's libm, as the
+ * reference would call it); no context and no device needed. */
+int gx_selftest_host(int what, const float* a, const float* b, float* out, double* out_double, size_t n);
 
 #ifdef __cplusplus
 }

@@ -55,3 +55,29 @@ def test_product_never_references_the_oracle():
                 assert "gxo_" not in txt and "libgenrich_oracle" not in txt, f
                 # mentioning the checker in a comment (e.g. check_log10f.c) is fine; importing is not
                 assert not re.search(r"^\s*(from|import)\s+.*oracle", txt, flags=re.M), f
+
+
+def test_host_build_of_the_p_value_routines_equals_the_oracle():
+    """The library re-evaluates p-values that lie next to a float rounding boundary with the host build of
+    its own routines (gx_math.h is __host__ __device__), i.e. with this machine's libm: those must be
+    the oracle's bits everywhere, or the patched values would not be the reference's."""
+    import numpy as np
+    import backends as B
+    from genrich_amd.lib import selftest_host
+    lib = B.Oracle.lib()
+    rng = np.random.default_rng(12)
+    n = 60_000
+    expt = (rng.integers(0, 400_000, n) / 120.0).astype(np.float32)
+    ctrl = np.where(rng.random(n) < 0.5, rng.random(n) * 7.5, rng.random(n) * 300).astype(np.float32)
+    ctrl[:10] = [0, -1, 7, 7.0000005, 1e-30, 6.9999995, 3, 3, 3, 3]
+    expt[:10] = [5, 5, 0, 1, 1, 1, 0, 1e6, 3e38, 1e-3]
+    got, _ = selftest_host(1, expt, ctrl)
+    want = np.array([lib.gxo_calc_pval(float(e), float(c)) for e, c in zip(expt, ctrl)], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # multPval's tail: pchisq of 2 sum / log10(e) over df = 2 x replicates
+    sums = (rng.random(20_000) * 40).astype(np.float32)
+    dfs = (2 * rng.integers(2, 17, 20_000)).astype(np.float32)
+    got, _ = selftest_host(3, sums, dfs)
+    want = np.array([min(lib.gxo_pchisq(2.0 * float(s) / 0.434294481903251827651, int(d)), 3.4028234663852886e38) if s else 0.0
+                     for s, d in zip(sums, dfs)], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

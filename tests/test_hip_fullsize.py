@@ -1,5 +1,6 @@
 """GPU, BASELINE.json's full size (hg38, 50 M fragments, configs[1]): size-independent properties
-that need no oracle, plus oracle parity on a mid-size slice (chr19..chrM, ~400 Mbp)."""
+that need no oracle, the whole genome against the oracle byte for byte (every contig, every interval,
+every peak), and oracle parity on a mid-size slice of another stream."""
 import numpy as np
 import pytest
 
@@ -78,6 +79,29 @@ def test_peaks_are_ordered_separated_and_above_threshold(full_run):
     assert gx.peak_bp == int((pk["end"].astype(np.int64) - pk["start"]).sum())
 
 
+def test_whole_genome_is_the_oracles_bytes(full_run):
+    """All 25 contigs / 50 M fragments through the HIP path and through the oracle: the peak list must be
+    the same bytes and every chromosome's interval ends, pileups and -log10 p the same bits."""
+    ev, gx, frag, lam = full_run
+    o = B.Oracle(B.make_params(pq=0.01))
+    so = B.run_case(o, dict(lens=LENS, replicates=[dict(save=None, treat=ev, ctrl=None)]))
+    assert so[0][0] == frag and np.float32(so[0][1]).tobytes() == np.float32(lam).tobytes()
+    po, ph = o.get_peaks(), gx.get_peaks()
+    assert len(po) == len(ph) > 50_000
+    assert po.tobytes() == ph.tobytes(), "peak lists differ"
+    assert o.peak_bp == gx.peak_bp
+    total = 0
+    for c in range(len(LENS)):
+        eo, co = o.get_intervals(-1, c)
+        eh, ch = gx.get_intervals(-1, c)
+        assert np.array_equal(eo, eh), f"interval ends differ on contig {c}"
+        assert np.array_equal(co["expt"].view(np.uint32), ch["expt"].view(np.uint32)), f"pileups differ on contig {c}"
+        assert np.array_equal(co["p"].view(np.uint32), ch["p"].view(np.uint32)), f"p-values differ on contig {c}"
+        total += len(eo)
+    assert total == gx.interval_total()
+    o.close()
+
+
 def test_rerun_is_bit_identical(full_run):
     """Determinism: integer atomics and ordered float sums only -> the same bytes every run."""
     import genrich_amd
@@ -114,10 +138,10 @@ def test_midsize_slice_against_oracle():
     for f in ("chrom", "start", "end", "summit"):
         assert np.array_equal(po[f], ph[f]), f
     assert np.array_equal(po["auc"].view(np.uint32), ph["auc"].view(np.uint32)), "AUC must be bit-identical"
-    assert np.allclose(po["p"], ph["p"], rtol=1e-5)
+    assert po.tobytes() == ph.tobytes()
     for c in (0, 5):
         eo, co = o.get_intervals(-1, c)
         eh, ch = h.get_intervals(-1, c)
         assert np.array_equal(eo, eh)
         assert np.array_equal(co["expt"].view(np.uint32), ch["expt"].view(np.uint32))
-        assert np.all(np.abs(co["p"].astype(np.float64) - ch["p"]) <= 1e-5 * np.maximum(1, co["p"]))
+        assert np.array_equal(co["p"].view(np.uint32), ch["p"].view(np.uint32))

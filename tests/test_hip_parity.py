@@ -1,7 +1,7 @@
 """GPU parity: the HIP library (through its C ABI) against the CPU oracle on the same inputs.
-Integer structure (interval ends, pileups, peak coordinates) must be bit-exact; -log10 p/q within
-1e-5 (north_star), and we additionally report/require bit-equality where the libm difference
-cannot matter."""
+Everything must be bit-exact: interval ends, pileups, peak coordinates, and -log10 p / q / AUC too
+(north_star asks for 1e-5; the library re-evaluates with the host's libm the few p-values whose
+double lies next to a float rounding boundary, gx_math.h, so the floats are the reference's)."""
 import numpy as np
 import pytest
 
@@ -58,8 +58,9 @@ def assert_same_run(o, h, so, sh, case, tol=1e-5):
     for f in ("chrom", "start", "end", "summit"):
         assert np.array_equal(po[f], ph[f]), f
     for f in ("auc", "p", "q"):
-        assert np.allclose(po[f], ph[f], rtol=1e-5, atol=1e-5), f
+        assert np.array_equal(po[f].view(np.uint32), ph[f].view(np.uint32)), f
     assert o.peak_bp == h.peak_bp
+    assert nbit == {"p": 0, "q": 0}, f"{nbit} p/q values differ in their last bits from the host-libm oracle"
     return nbit
 
 
@@ -175,23 +176,47 @@ def test_device_log10f_is_the_hosts():
 
 
 def test_device_calc_pval_vs_oracle():
-    """calcPval on a grid of (treatment, control) values: within 1e-5 everywhere and bit-equal
-    to the host-libm oracle except where the double result sits on a float rounding boundary."""
+    """calcPval on a grid of (treatment, control) values: every bit of the host-libm oracle.  The device
+    evaluates in double with its own libm; results next to a float rounding boundary ("risky",
+    gx_math.h RISK_B = 2^-40) are re-evaluated on the host.  The test also measures what that margin
+    rests on: the device's doubles differ from the host's by far less than RISK_B."""
+    from genrich_amd.lib import selftest_host
     h = hip_backend(B.make_params())
     lib = B.Oracle.lib()
     rng = np.random.default_rng(2)
-    n = 200_000
-    expt = (rng.integers(0, 60_000, n) / 120.0).astype(np.float32)
-    ctrl = np.where(rng.random(n) < 0.5, rng.random(n) * 7.5, rng.random(n) * 60).astype(np.float32)
+    n = 400_000
+    expt = (rng.integers(0, 400_000, n) / 120.0).astype(np.float32)
+    ctrl = np.where(rng.random(n) < 0.5, rng.random(n) * 7.5, rng.random(n) * 300).astype(np.float32)
     ctrl[:10] = [0, -1, 7, 7.0000005, 1e-30, 6.9999995, 3, 3, 3, 3]
     expt[:10] = [5, 5, 0, 1, 1, 1, 0, 1e6, 3e38, 1e-3]
-    got = h.selftest(1, expt, ctrl)
-    want = np.array([lib.gxo_calc_pval(float(e), float(c)) for e, c in zip(expt, ctrl)], dtype=np.float32)
-    fin = np.abs(want) < 1e30
-    assert np.array_equal(got[~fin], want[~fin])
-    assert np.all(np.abs(got[fin].astype(np.float64) - want[fin]) <= 1e-5 * np.maximum(1, np.abs(want[fin])))
-    nbad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
-    assert nbad <= 2, f"{nbad} of {n} p-values differ in the last bit"
+    got, dd, nrisky = h.selftest2(1, expt, ctrl)
+    want = np.array([lib.gxo_calc_pval(float(e), float(c)) for e, c in zip(expt[:100_000], ctrl[:100_000])], dtype=np.float32)
+    assert np.array_equal(got[:100_000].view(np.uint32), want.view(np.uint32))
+    hw, hd = selftest_host(1, expt, ctrl)   # (== the oracle: tests/test_abi.py)
+    nbad = int((got.view(np.uint32) != hw.view(np.uint32)).sum())
+    assert nbad == 0, f"{nbad} of {n} p-values differ in the last bit"
+    ok = (hd > 0) & (hd < 1e30)
+    rel = np.abs(dd[ok] - hd[ok]) / hd[ok]
+    print(f"risky: {nrisky} of {n}; max relative device/host difference of the doubles: {rel.max():.3g}")
+    assert rel.max() < 2.0 ** -44, "the device's doubles are too far from the host's for the RISK_B = 2^-40 margin"
+    assert 0 < nrisky < n * 1e-3
+
+
+def test_device_fisher_vs_host():
+    from genrich_amd.lib import selftest_host
+    h = hip_backend(B.make_params())
+    rng = np.random.default_rng(21)
+    n = 200_000
+    sums = (rng.random(n) * 60).astype(np.float32)
+    sums[:1000] = (rng.random(1000) * 0.9).astype(np.float32)
+    dfs = (2 * rng.integers(1, 17, n)).astype(np.float32)
+    got, dd, nrisky = h.selftest2(3, sums, dfs)
+    hw, hd = selftest_host(3, sums, dfs)
+    assert np.array_equal(got.view(np.uint32), hw.view(np.uint32))
+    ok = (hd > 0) & (hd < 1e30)
+    rel = np.abs(dd[ok] - hd[ok]) / hd[ok]
+    print(f"risky: {nrisky} of {n}; max relative device/host difference of the doubles: {rel.max():.3g}")
+    assert rel.max() < 2.0 ** -44
 
 
 def test_device_getval_all_residues():
