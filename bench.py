@@ -1,24 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- genome bases p-scored per second on synthetic hg38 (BASELINE.json configs[1]):
-50 M paired fragments, treatment only, default ChIP-seq mode (-p 0.01).
+"""bench.py -- genome bases p-scored per second on synthetic hg38 (BASELINE.json).
 
-One "step" = one pass of the whole hot path over the whole genome: fragment events already
-resident in HBM -> tile-bucketed endpoint records -> LDS difference arrays / prefix sums ->
-run-length pileup -> lambda -> log-normal -log10 p -> peak sweep -> peak list on the host.
+One "step" = one pass of the whole hot path over the whole genome: fragment events already resident
+in HBM -> tile-bucketed endpoint records -> LDS difference arrays / prefix sums -> run-length pileup
+-> lambda (-> control scaling) -> log-normal -log10 p (-> Fisher over replicates) (-> BH q) -> peak
+sweep -> peak list on the host.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--frags F] [--qval]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5]
+    --config 2  hg38, 50 M paired fragments, treatment only, -p 0.01          (configs[1], the headline; default)
+    --config 3  + a 50 M-fragment uniform control, -q 0.05                    (configs[2])
+    --config 4  ATAC -j -d 100 cut-site intervals + -s multimapping weights   (configs[3])
+    --config 5  3 replicates, Fisher-combined p, global q (-q 0.05)           (configs[4])
   N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-         chromosomes are sharded over ranks (LPT); the only exchanges are the fragLen
-         fixed-point sums (and the p-value table with --qval) -> "scaling": "strong".
+         chromosomes are sharded over ranks (LPT); the only exchanges are the fragLen fixed-point sums
+         and (with -q) the p-value table, done by the library itself with RCCL on device buffers.
+         The genome is fixed, per-GPU work shrinks with N -> "scaling": "strong".
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  Besides the contract's fields:
+  gate          the same workload (or its first chromosomes, see cpu_baseline.sample) through the CPU oracle
+                and through the HIP path: narrowpeak_diff (differing narrowPeak lines; must be 0), max_abs_dp /
+                max_abs_dq over every interval
+  roofline      bound "hbm" for the dominant kernel: achieved = HBM bytes it moves (PMC counters of a separate
+                rocprofv3 run of this very build, profiles/) / its mean duration measured here (HIP events);
+                frac = achieved / 8 TB/s <= 1 by construction; `algorithmic_bytes` = what the sparse formulation
+                must move; `whole_step` the same for the whole path; `issue` = the SQ-counter issue model
+  h2d / e2e     PCIe upload of the events from pinned memory, and a step that starts from pinned host memory
+  cpu_baseline  the oracle (kind "port"), one core, events in memory -> peaks, on the sample named
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,50 +44,155 @@ sys.path.insert(0, ROOT)
 
 from genrich_amd import synth  # noqa: E402
 from genrich_amd.dist import Collectives, lpt_partition  # noqa: E402
-from genrich_amd.lib import GxParams, Genrich, minus_log10f  # noqa: E402
+from genrich_amd.lib import GxParams, Genrich, minus_log10f, rccl_unique_id  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
+CONFIGS = {
+    2: dict(name="configs[1]", desc="treatment only, -p 0.01", qval=False, control=False, atac=False, multimap=False, reps=1,
+            gate_chroms=25),
+    3: dict(name="configs[2]", desc="treatment + 50M-fragment uniform control, -q 0.05", qval=True, control=True, atac=False,
+            multimap=False, reps=1, gate_chroms=8),
+    4: dict(name="configs[3]", desc="ATAC -j -d 100 cut-site intervals, 10 % of fragments multimapped (-s weights 1/k), -p 0.01",
+            qval=False, control=False, atac=True, multimap=True, reps=1, gate_chroms=12),
+    5: dict(name="configs[4]", desc="3 replicates, Fisher-combined p, global -q 0.05", qval=True, control=False, atac=False,
+            multimap=False, reps=3, gate_chroms=6),
+}
 
-def cpu_baseline(ev_all, lens, n_chrom_sample, qval):
-    """Single-threaded CPU restatement (oracle/, kind "port") on the first chromosomes only:
-    events in memory -> peaks, the same span the GPU step covers."""
+
+def source_hash():
+    """Identifies the build the profile files under profiles/ belong to."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "genrich_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_workload(cfg, frags, lens):
+    """[(treatment events, control events or None)] per replicate, SURVEY.md 8(d)."""
+    reps = []
+    seeds = [1, 3, 5, 7, 9][:cfg["reps"]]
+    for sd in seeds:
+        # with a control the treatment needs towers whose q survives the genome-wide correction (SURVEY 8d, config 3)
+        tv = synth.make_fragments(lens, frags, seed=sd, tower_every=50_000_000 if cfg["control"] else 5_000_000)
+        if cfg["multimap"]:
+            tv = synth.add_multimap(tv, lens, 0.10, seed=sd + 10)
+        if cfg["atac"]:
+            tv = synth.atac_events(tv, lens, d=100)
+        cv = synth.make_fragments(lens, frags, seed=sd + 1, uniform_only=True) if cfg["control"] else None
+        reps.append((tv, cv))
+    return reps
+
+
+def subset(reps, n_chrom):
+    out = []
+    for tv, cv in reps:
+        out.append((tv[tv["chrom"] < n_chrom], None if cv is None else cv[cv["chrom"] < n_chrom]))
+    return out
+
+
+def run_backend(be, lens, reps, peaks_to=None):
+    be.set_chroms(lens)
+    t0 = time.perf_counter()
+    for tv, cv in reps:
+        be.sample_begin(0, None)
+        be.push_events(tv)
+        be.sample_end()
+        if cv is not None:
+            be.sample_begin(1, None)
+            be.push_events(cv)
+            be.sample_end()
+        else:
+            be.sample_no_control()
+        be.pvalues()
+    if peaks_to:
+        be.find_peaks_to(peaks_to[0], None, peaks_to[1])  # the oracle's own narrowPeak emitter
+    else:
+        be.find_peaks()
+    return time.perf_counter() - t0
+
+
+def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device):
+    """The oracle (CPU restatement, one core) and the HIP path on the same events: narrowPeak text diff,
+    max |dp| / |dq| over all intervals, and the oracle's rate as the CPU baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import backends as B
 
-    sel = ev_all[ev_all["chrom"] < n_chrom_sample]
-    sub_lens = lens[:n_chrom_sample]
-    o = B.Oracle(B.make_params(pq=0.05 if qval else 0.01, qval=qval))
-    o.set_chroms(sub_lens)
-    t0 = time.perf_counter()
-    o.sample_begin(0, None)
-    o.push_events(sel)
-    o.sample_end()
-    o.sample_no_control()
-    o.pvalues()
-    o.find_peaks()
-    dt = time.perf_counter() - t0
-    bases = float(sum(sub_lens))
+    sub_lens = lens[:n_chrom]
+    sub = subset(reps, n_chrom)
+    names = synth.HG38_NAMES[:n_chrom]
+    par = B.make_params(pq=0.05 if qval else 0.01, qval=qval)
+    td = tempfile.mkdtemp()
+    po, ph = os.path.join(td, "o.narrowPeak"), os.path.join(td, "h.narrowPeak")
+    o = B.Oracle(par)
+    dt = run_backend(o, sub_lens, sub, peaks_to=(po, names))
+    par.device = device
+    h = Genrich(par)
+    run_backend(h, sub_lens, sub)
+    h.write_narrowpeak(names, ph)
+    want, got = open(po, "rb").read(), open(ph, "rb").read()
+    os.remove(po)
+    os.remove(ph)
+    os.rmdir(td)
+    if got == want:
+        ndiff = 0
+    else:
+        a, b = set(got.split(b"\n")), set(want.split(b"\n"))
+        ndiff = max(1, len(a ^ b))
+    dp = dq = 0.0
+    nbits = 0
+    n_iv = 0
+    ends_equal = True
+    for c in range(n_chrom):
+        eo, co = o.get_intervals(-1, c)
+        eh, ch = h.get_intervals(-1, c, piles=False)
+        if len(eo) != len(eh) or not np.array_equal(eo, eh):
+            ends_equal = False
+            continue
+        n_iv += len(eo)
+        for k in ("p",) + (("q",) if qval else ()):
+            a, b = co[k].astype(np.float64), ch[k].astype(np.float64)
+            fin = np.abs(a) < 1e30
+            if fin.any():
+                d = float(np.max(np.abs(a[fin] - b[fin])))
+                if k == "p":
+                    dp = max(dp, d)
+                else:
+                    dq = max(dq, d)
+            nbits += int((co[k].view(np.uint32) != ch[k].view(np.uint32)).sum())
+    bases = float(sum(sub_lens)) * len(sub)
+    n_ev = int(sum(len(t) + (0 if c is None else len(c)) for t, c in sub))
+    gate = dict(narrowpeak_diff=ndiff, peaks_oracle=int(o.n_peaks), peaks_hip=int(h.n_peaks), interval_ends_equal=ends_equal,
+                intervals_compared=n_iv, max_abs_dp=dp, max_abs_dq=dq if qval else None, pq_values_differing_in_bits=nbits,
+                passed=bool(ndiff == 0 and ends_equal and dp <= 1e-5 and dq <= 1e-5))
+    what = "the whole workload" if n_chrom == len(lens) else f"hg38 chr1-chr{n_chrom} of the workload"
+    cpu = dict(value=bases / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
+               sample=f"{what} ({sum(sub_lens)/1e6:.0f} Mbp x {len(sub)} replicate(s), {n_ev} events), events in memory -> "
+                      f"peaks, {dt:.1f} s")
     o.close()
-    return dict(value=bases / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
-                sample=f"hg38 chr1-chr{n_chrom_sample} ({bases/1e6:.0f} Mbp, {len(sel)} fragments), "
-                       f"events in memory -> peaks, {dt:.1f} s")
+    return gate, cpu
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frags", type=int, default=50_000_000)
-    ap.add_argument("--qval", action="store_true", help="-q 0.05 instead of -p 0.01")
-    ap.add_argument("--control", action="store_true",
-                    help="add a 50M-fragment uniform control (configs[2] shape; not the headline metric)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--qval", action="store_true", help="-q 0.05 instead of -p 0.01 (on top of --config)")
+    ap.add_argument("--control", action="store_true", help="add a uniform control (on top of --config)")
     ap.add_argument("--lean", action="store_true",
                     help="do not materialise the pileup floats of the intervals (gx_set_keep_pileups(0))")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-chroms", type=int, default=12)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the gate + cpu_baseline leg")
+    ap.add_argument("--cpu-chroms", type=int, default=0, help="gate / cpu_baseline on the first K chromosomes (0: per config)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the H2D / end-to-end-from-pinned figures")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    cfg["qval"] = cfg["qval"] or args.qval
+    cfg["control"] = cfg["control"] or args.control
 
     import torch
     import torch.distributed as dist
@@ -85,7 +206,7 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
     # GX_BENCH_BACKEND=gloo is a validation mode for a box with fewer GPUs than ranks: ranks share the
-    # devices round-robin and the (tiny) collectives go through host memory; it is labelled in `config`
+    # devices round-robin and the (tiny) collectives go through host callbacks; it is labelled in `config`
     backend = os.environ.get("GX_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     if backend == "nccl" and local >= ndev:
@@ -93,7 +214,7 @@ def main():
     local_dev = local % ndev
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where torch's own collective payloads live
     if world > 1:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -102,42 +223,54 @@ def main():
 
     lens = synth.HG38_LENS
     G = int(sum(lens))
-    ev_all = synth.make_fragments(lens, args.frags, seed=1)
+    reps_all = build_workload(cfg, args.frags, lens)
     owner = lpt_partition(lens, world)
     owned = np.array([o == rank for o in owner], dtype=np.uint8)
-    mine = ev_all[owned[ev_all["chrom"]].astype(bool)] if world > 1 else ev_all
-    d_ev = torch.from_numpy(mine.view(np.uint32).reshape(-1, 4).copy()).to(dev)
-    d_ct = None
-    if args.control:
-        ct_all = synth.make_fragments(lens, args.frags, seed=2, uniform_only=True)
-        ct = ct_all[owned[ct_all["chrom"]].astype(bool)] if world > 1 else ct_all
-        d_ct = torch.from_numpy(ct.view(np.uint32).reshape(-1, 4).copy()).to(dev)
+
+    def mine(ev):
+        if ev is None:
+            return None
+        return ev[owned[ev["chrom"]].astype(bool)] if world > 1 else ev
+
+    def to_dev(ev):
+        return None if ev is None else torch.from_numpy(ev.view(np.uint32).reshape(-1, 4).copy()).to(dev)
+
+    d_reps = [(to_dev(mine(tv)), to_dev(mine(cv))) for tv, cv in reps_all]
     torch.cuda.synchronize()
 
-    params = GxParams(minus_log10f(0.05 if args.qval else 0.01), int(args.qval), 200.0, 0, 100, local_dev, 0)
+    params = GxParams(minus_log10f(0.05 if cfg["qval"] else 0.01), int(cfg["qval"]), 200.0, 0, 100, local_dev, 0)
     gx = Genrich(params)
     gx.set_chroms(lens)
     # By default the whole interval table (end, treatment pileup, p) is materialised, as the reference holds it.
-    # --lean drops the pileup floats, which only the -f / -k emitters read (what the command-line host does
-    # when neither option is given): ~3 % faster, reported as such in `config`.
+    # --lean drops the pileup floats, which only the -f / -k emitters read: reported as such in `config`.
     gx.set_keep_pileups(not args.lean)
+    coll_kind = "none"
     if world > 1:
-        coll = Collectives(device=cdev)
         gx.set_owned(owned)
-        gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
-
-    def step():
-        gx.reset()
-        gx.sample_begin(0, None)
-        gx.push_events_device(d_ev.data_ptr(), d_ev.shape[0])
-        gx.sample_end()
-        if d_ct is not None:
-            gx.sample_begin(1, None)
-            gx.push_events_device(d_ct.data_ptr(), d_ct.shape[0])
-            gx.sample_end()
+        if backend == "nccl":
+            # the library's own RCCL communicator; torch.distributed only carries the 128-byte id (outside the timed region)
+            box = [rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            gx.set_rccl(rank, world, box[0])
+            coll_kind = "RCCL inside the library (device buffers, library stream)"
         else:
-            gx.sample_no_control()
-        gx.pvalues()
+            coll = Collectives(device=cdev)
+            gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
+            coll_kind = f"host callbacks over torch.distributed/{backend} (validation mode)"
+
+    def step(dreps=d_reps):
+        gx.reset()
+        for d_tv, d_cv in dreps:
+            gx.sample_begin(0, None)
+            gx.push_events_device(d_tv.data_ptr(), d_tv.shape[0])
+            gx.sample_end()
+            if d_cv is not None:
+                gx.sample_begin(1, None)
+                gx.push_events_device(d_cv.data_ptr(), d_cv.shape[0])
+                gx.sample_end()
+            else:
+                gx.sample_no_control()
+            gx.pvalues()
         return gx.find_peaks()
 
     def barrier():
@@ -152,7 +285,10 @@ def main():
     phase_acc = {}
     for _ in range(args.steps):
         res = step()
+        seen = {}
         for name, ms in gx.phase_times():
+            seen[name] = seen.get(name, 0.0) + ms
+        for name, ms in seen.items():
             phase_acc.setdefault(name, []).append(ms)
     barrier()
     dt = time.perf_counter() - t0
@@ -167,69 +303,127 @@ def main():
         n_peaks = res[0]
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
+        step_s = dt / args.steps
         phases = {k: float(np.mean(v)) for k, v in phase_acc.items()}
-        # dominant kernel: the tile kernel (LDS difference array + prefix sum + RLE emit).
-        # Algorithmic bytes of the stage it implements, SURVEY.md 8(d): clear + scan of the dense
-        # per-base array (8 B/base), its endpoint records (16 B/event) and the RLE it writes
-        # (8 B/interval).  Rank 0's share of the genome when sharded.
-        g0 = float(sum(l for l, o in zip(lens, owner) if o == 0))
-        e0 = float(d_ev.shape[0])
-        iv0 = float(gx.interval_total()) if hasattr(gx, "interval_total") else 0.0
-        alg_bytes = 8.0 * g0 + 16.0 * e0 + 8.0 * iv0
-        t_tile = phases.get("t.tile", 0.0) * 1e-3
-        achieved = alg_bytes / t_tile / 1e9 if t_tile > 0 else 0.0
-        # HBM bytes actually moved by one k_tile launch: PMC counters from a separate rocprofv3 run
-        # (profiles/r01_traffic.json says how they were collected and corrected); single-GPU workload only
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if world == 1 and args.frags == 50_000_000 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("k_tile", {}).get("hbm_bytes_per_launch")
+        n_rep = len(reps_all)
+        iv0 = float(gx.interval_total())
+        ev_n = float(sum(d_tv.shape[0] + (0 if d_cv is None else d_cv.shape[0]) for d_tv, d_cv in d_reps))
+        # ---- roofline of the dominant kernel (k_tile: LDS difference slices -> run-length pileup) -------------
+        # compulsory HBM bytes of the sparse formulation, per launch: 2 B per endpoint record in (two per event),
+        # a 48 B descriptor per tile, 8 B per interval out + 8 B of per-tile counts
+        n_tiles = sum((l + 4095) // 4096 for l, o in zip(lens, owner) if o == 0)
+        launches = n_rep * (2 if cfg["control"] else 1)   # k_tile runs once per sample (its narrow + wide launch pair)
+        # (the library's phase timers cover the last replicate of a step and gx_find_peaks)
+        tile_ms = (phases.get("t.tile", 0.0) + phases.get("c.tile", 0.0)) / (2 if cfg["control"] else 1)
+        prof = None
+        ppath = os.path.join(ROOT, "profiles", f"r02_counters_config{args.config}.json")
+        if os.path.exists(ppath):
+            prof = json.load(open(ppath))
+            if prof.get("source_hash") != source_hash() or world != 1 or args.frags != 50_000_000 or args.qval or args.control:
+                prof = None  # counters of another build / another workload are not this run's
+        traffic = prof["kernels"]["k_tile"]["hbm_bytes_per_step"] / launches if prof else None
+        alg_tile = (2.0 * 2.0 * ev_n + 8.0 * (iv0 if launches == 1 else 2.0 * ev_n)) / launches + 56.0 * n_tiles
+        used = traffic if traffic else alg_tile
+        achieved = used / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
+        # whole step: events in + final interval table (end, p[, pileup]) + sweep masks out
+        alg_step = 16.0 * ev_n + (12.0 if not args.lean else 8.0) * iv0 + 3.0 * iv0 / 8.0
+        roof = {
+            "bound": "hbm", "kernel": "k_tile", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": tile_ms,
+            "algorithmic_bytes": alg_tile,
+            "traffic_over_algorithmic": (traffic / alg_tile) if traffic else None,
+            "whole_step": {
+                "ms": step_s * 1e3,
+                "algorithmic_bytes": alg_step,
+                "traffic": prof["whole_step"]["hbm_bytes_per_step"] if prof else None,
+                "frac_of_peak": ((prof["whole_step"]["hbm_bytes_per_step"] if prof else alg_step) / step_s / 1e9) / HBM_PEAK_GBS,
+                "traffic_over_algorithmic": (prof["whole_step"]["hbm_bytes_per_step"] / alg_step) if prof else None,
+            },
+            "issue": prof.get("issue") if prof else None,
+            "dense_model": {"bytes": 8.0 * G + 16.0 * ev_n + 52.0 * iv0,
+                            "note": "SURVEY 8(d)'s dense int32-array model; the array lives in LDS here, so this is not HBM traffic"},
+            "note": "achieved = HBM bytes k_tile moves per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of this build, "
+                    "profiles/r02_counters_config*.json; the sparse formulation's compulsory bytes when no counter file matches "
+                    "this build) / its mean duration (HIP events on the library's stream); frac <= 1 by construction",
+        }
         out = {
             "metric": "genome bases p-scored/sec, hg38 50M frags",
-            "value": G / (dt / args.steps) / 1e9,
+            "value": n_rep * G / step_s / 1e9,
             "unit": "Gbases/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int32 pileup (1/120 units) + f64 p-values",
             "data": "synthetic",
             "config": {
-                "workload": f"hg38 25 contigs ({G} bp), {args.frags} paired fragments, treatment only, "
-                            + ("-q 0.05" if args.qval else "-p 0.01")
-                            + (" + 50M-fragment control (configs[2] shape)" if args.control else " (BASELINE.json configs[1])"),
+                "workload": f"hg38 25 contigs ({G} bp), {args.frags} paired fragments x {n_rep} replicate(s), {cfg['desc']} "
+                            f"(BASELINE.json {cfg['name']})",
                 "parallelism": f"chromosome-sharded x{world}"
                                + ("" if backend == "nccl" or world == 1 else f" ({backend} validation mode, {ndev} GPU(s))"),
+                "collectives": coll_kind,
                 "peaks": n_peaks,
+                "intervals": int(iv0),
+                "events_per_step": int(ev_n),
                 "pileup_floats_kept": not args.lean,
+                "source_hash": source_hash(),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_tile",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes": alg_bytes,
-                "launch_ms": t_tile * 1e3,
-                "traffic_gbs": (traffic / t_tile / 1e9) if (traffic and t_tile > 0) else None,
-                "traffic_frac_of_peak": (traffic / t_tile / 1e9 / HBM_PEAK_GBS) if (traffic and t_tile > 0) else None,
-                "note": "algorithmic bytes = 8 B/base (clear + scan of the dense difference array) + 16 B/event "
-                        "+ 8 B/interval, SURVEY 8(d); k_tile keeps that array in LDS, so its real HBM traffic "
-                        "(`traffic`, PMC; `traffic_gbs` = traffic / launch time, `traffic_frac_of_peak` = that over 8 TB/s) "
-                        "is ~25x smaller and `frac` can exceed 1: the kernel is VALU-issue / LDS-latency bound, not HBM-bound",
-            },
+            "roofline": roof,
             "phases_ms": phases,
-            "whole_path_hbm_frac": ((8.0 * G + 16.0 * 2 * args.frags + 52.0 * iv0) / (dt / args.steps) / 1e9)
-            / HBM_PEAK_GBS if world == 1 else None,
         }
+        if world == 1 and not args.no_e2e:
+            # PCIe upload of the events from pinned host memory, and a step that starts there (gx_push_events)
+            pin = [(torch.from_numpy(tv.view(np.uint32).reshape(-1, 4)).pin_memory(),
+                    None if cv is None else torch.from_numpy(cv.view(np.uint32).reshape(-1, 4)).pin_memory()) for tv, cv in reps_all]
+            nbytes = sum(t.numel() * 4 + (0 if c is None else c.numel() * 4) for t, c in pin)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ts = []
+            for _ in range(3):
+                e0.record()
+                for (t, c), (dtv, dcv) in zip(pin, d_reps):
+                    dtv.copy_(t, non_blocking=True)
+                    if c is not None:
+                        dcv.copy_(c, non_blocking=True)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            h2d_ms = float(np.median(ts))
+
+            def step_from_host():
+                gx.reset()
+                for t, c in pin:
+                    gx.sample_begin(0, None)
+                    gx.push_events_ptr(t.data_ptr(), t.shape[0])
+                    gx.sample_end()
+                    if c is not None:
+                        gx.sample_begin(1, None)
+                        gx.push_events_ptr(c.data_ptr(), c.shape[0])
+                        gx.sample_end()
+                    else:
+                        gx.sample_no_control()
+                    gx.pvalues()
+                return gx.find_peaks()
+
+            step_from_host()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step_from_host()
+            torch.cuda.synchronize()
+            e2e_ms = (time.perf_counter() - t1) / 3 * 1e3
+            out["h2d"] = {"ms": h2d_ms, "bytes": nbytes, "gbs": nbytes / h2d_ms / 1e6,
+                          "note": "events from pinned host memory to HBM (outside the timed region of `value`)"}
+            out["e2e_from_pinned"] = {"ms_per_step": e2e_ms, "value": n_rep * G / (e2e_ms * 1e-3) / 1e9, "unit": "Gbases/s",
+                                      "note": "gx_push_events from pinned host memory (chunked upload overlapped with the "
+                                              "first kernel) -> peak list on the host"}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ev_all, lens, args.cpu_chroms, args.qval)
+            k = args.cpu_chroms or cfg["gate_chroms"]
+            gate, cpu = gate_and_cpu_baseline(cfg, lens, reps_all, min(k, len(lens)), cfg["qval"], local_dev)
+            out["gate"] = gate
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -218,6 +218,10 @@ class Genrich:
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
         self._check(self.lib.gx_push_events(self.ctx, ev.ctypes.data, len(ev)))
 
+    def push_events_ptr(self, host_ptr, n):
+        """gx_push_events on a raw host pointer (e.g. pinned memory owned by the caller)."""
+        self._check(self.lib.gx_push_events(self.ctx, C.c_void_p(host_ptr), int(n)))
+
     def push_events_device(self, dev_ptr: int, n: int):
         """Events already resident in HBM (e.g. a torch tensor's data_ptr())."""
         self._check(self.lib.gx_push_events_device(self.ctx, C.c_void_p(dev_ptr), n))

@@ -1,5 +1,9 @@
-"""GPU: the chromosome-sharded path (2 ranks sharing the one GPU of the test box, collectives
-over gloo) must give exactly the single-rank result: same lambda, same peaks, same q-values."""
+"""GPU: the chromosome-sharded path (2 ranks sharing the one GPU of the test box, collectives through
+host callbacks over gloo) must give exactly the single-rank result -- same lambda / factor, same peak
+bytes -- with a control and -q, with fractional weights (ATAC geometry + -s multimapping: the case
+where the fixed-point fragLen all-reduce matters) and with three replicates (Fisher + global q).
+The library's own RCCL path is run with a single rank (two ranks cannot share one GPU under RCCL):
+same code, one-member communicator."""
 import os
 import socket
 
@@ -14,25 +18,43 @@ pytestmark = pytest.mark.gpu
 LENS = [200_000, 150_000, 90_000, 40_000, 16_000]
 
 
-def _case():
-    tr = synth.make_fragments(LENS, 60_000, 5, peak_every=20_000, tower_every=70_000, frac_tower=0.1)
-    ct = synth.make_fragments(LENS, 40_000, 6, uniform_only=True)
-    return tr, ct
+def _scenario(name):
+    """(params, [(treatment, control or None)] per replicate)"""
+    if name == "ctrl_q":
+        tr = synth.make_fragments(LENS, 60_000, 5, peak_every=20_000, tower_every=70_000, frac_tower=0.1)
+        ct = synth.make_fragments(LENS, 40_000, 6, uniform_only=True)
+        return B.make_params(pq=0.2, qval=True, min_auc=20.0), [(tr, ct)]
+    if name == "atac_multimap":
+        tr = synth.make_fragments(LENS, 60_000, 7, peak_every=20_000, tower_every=70_000, frac_tower=0.1)
+        tr = synth.atac_events(synth.add_multimap(tr, LENS, 0.25, seed=8), LENS, d=100)
+        return B.make_params(pq=0.01, min_auc=20.0), [(tr, None)]
+    if name == "reps3_q":
+        reps = [(synth.make_fragments(LENS, 40_000, sd, peak_every=20_000, tower_every=70_000, frac_tower=0.1), None)
+                for sd in (11, 13, 15)]
+        return B.make_params(pq=0.3, qval=True, min_auc=20.0), reps
+    raise KeyError(name)
 
 
-def _run(gx, tr, ct):
-    gx.sample_begin(0, None)
-    gx.push_events(tr)
-    gx.sample_end()
-    gx.sample_begin(1, None)
-    gx.push_events(ct)
-    _, lam, fac = gx.sample_end()
-    gx.pvalues()
+def _run(gx, reps, owned=None):
+    sel = (lambda ev: ev) if owned is None else (lambda ev: ev[owned[ev["chrom"]].astype(bool)])
+    scal = []
+    for tr, ct in reps:
+        gx.sample_begin(0, None)
+        gx.push_events(sel(tr))
+        frag, _, _ = gx.sample_end()
+        if ct is not None:
+            gx.sample_begin(1, None)
+            gx.push_events(sel(ct))
+            _, lam, fac = gx.sample_end()
+        else:
+            lam, fac = gx.sample_no_control(), 1.0
+        gx.pvalues()
+        scal.append((frag, lam, fac))
     gx.find_peaks()
-    return lam, fac, gx.get_peaks()
+    return scal, gx.get_peaks()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, name):
     import torch.distributed as dist
 
     import genrich_amd
@@ -40,33 +62,38 @@ def _worker(rank, world, port, q):
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    tr, ct = _case()
+    params, reps = _scenario(name)
     owner = lpt_partition(LENS, world)
     owned = np.array([o == rank for o in owner], dtype=np.uint8)
-    gx = genrich_amd.Genrich(B.make_params(pq=0.2, qval=True, min_auc=20.0))
+    gx = genrich_amd.Genrich(params)
     gx.set_chroms(LENS)
     gx.set_owned(owned)
     coll = Collectives(device="cpu")
     gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
-    sel = lambda ev: ev[owned[ev["chrom"]].astype(bool)]  # noqa: E731
-    lam, fac, peaks = _run(gx, sel(tr), sel(ct))
-    q.put((rank, lam, fac, peaks.tobytes()))
+    scal, peaks = _run(gx, reps, owned)
+    q.put((rank, scal, peaks.tobytes()))
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank():
+@pytest.mark.parametrize("name", ["ctrl_q", "atac_multimap", "reps3_q"])
+def test_two_ranks_equal_one_rank(name):
     import torch.multiprocessing as mp
 
     import genrich_amd
     from genrich_amd.dist import merge_peaks
     from genrich_amd.lib import PEAK_DTYPE
 
-    tr, ct = _case()
-    gx = genrich_amd.Genrich(B.make_params(pq=0.2, qval=True, min_auc=20.0))
+    params, reps = _scenario(name)
+    gx = genrich_amd.Genrich(params)
     gx.set_chroms(LENS)
-    lam1, fac1, peaks1 = _run(gx, tr, ct)
+    scal1, peaks1 = _run(gx, reps)
     assert len(peaks1) > 0
     gx.close()
+    # ... and the oracle agrees with the single-rank run
+    o = B.Oracle(params)
+    o.set_chroms(LENS)
+    scalo, peakso = _run(o, reps)
+    assert peakso.tobytes() == peaks1.tobytes()
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -74,15 +101,38 @@ def test_two_ranks_equal_one_rank():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, name)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for _, lam, fac, _ in res:
-        assert np.float32(lam).tobytes() == np.float32(lam1).tobytes()
-        assert np.float32(fac).tobytes() == np.float32(fac1).tobytes()
-    merged = merge_peaks([np.frombuffer(r[3], dtype=PEAK_DTYPE) for r in res])
+    for _, scal, _ in res:
+        for (f, lam, fac), (f1, lam1, fac1) in zip(scal, scal1):
+            assert f == f1, "fragLen must be the exact fixed-point sum whatever the number of ranks"
+            assert np.float32(lam).tobytes() == np.float32(lam1).tobytes()
+            assert np.float32(fac).tobytes() == np.float32(fac1).tobytes()
+    merged = merge_peaks([np.frombuffer(r[2], dtype=PEAK_DTYPE) for r in res])
     assert merged.tobytes() == peaks1.tobytes(), "sharded peaks (coordinates, AUC, p, q) differ from the single-rank run"
+
+
+@pytest.mark.parametrize("name", ["ctrl_q", "reps3_q"])
+def test_rccl_path_with_one_rank(name, monkeypatch):
+    """gx_set_rccl + GX_FORCE_COLL=1: the all-reduce of the fragLen words and the all-gather of the BH
+    records run through RCCL on the library's stream (a communicator of one rank) and must change nothing."""
+    import genrich_amd
+    from genrich_amd.lib import rccl_unique_id
+
+    params, reps = _scenario(name)
+    gx = genrich_amd.Genrich(params)
+    gx.set_chroms(LENS)
+    scal1, peaks1 = _run(gx, reps)
+    gx.close()
+    monkeypatch.setenv("GX_FORCE_COLL", "1")
+    g2 = genrich_amd.Genrich(params)
+    g2.set_chroms(LENS)
+    g2.set_rccl(0, 1, rccl_unique_id())
+    scal2, peaks2 = _run(g2, reps)
+    assert scal2 == scal1
+    assert peaks2.tobytes() == peaks1.tobytes()

@@ -598,3 +598,19 @@ def test_intervals_that_end_before_they_start():
         b.push_events(np.concatenate([bg[:50], lone]))
         with pytest.raises(RuntimeError, match="Invalid pileup"):
             b.sample_end()
+
+
+@pytest.mark.parametrize("qval", [False, True])
+def test_atac_geometry_with_multimap_weights(qval):
+    """configs[3]'s combination: ATAC -j -d 100 cut-site intervals (two per fragment, saveFragAtac 2728-2749)
+    carrying -s multimapping weights 1/k, k in {2,3,4,5,6,8,10} (10 % of the fragments): fractional pileups in
+    nearly every tile (all tiles take the 32-bit LDS path), the general fragLen path, and p / q on fractional values."""
+    lens = [9_000_000, 5_000_000, 1_200_000, 16_569]
+    fr = synth.make_fragments(lens, 700_000, 31, peak_every=50_000, tower_every=2_000_000)
+    ev = synth.atac_events(synth.add_multimap(fr, lens, 0.10, seed=32), lens, d=100)
+    assert len(ev) > 1_500_000 and (ev["count"] > 1).sum() > 200_000
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    params = B.make_params(pq=0.05 if qval else 0.01, qval=qval, min_auc=50.0)
+    o, h, so, sh = run_both(case, params)
+    assert_same_run(o, h, so, sh, case)
+    assert h.n_peaks > 50

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 runs of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the tracked summaries
+under profiles/:  <tag>_kernel_stats.txt, <tag>_pmc.txt and r02_counters_config<C>.json (what bench.py's
+`roofline` object reads; it carries the hash of the kernel sources it was measured on).
+
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB = 1024 B): on gfx950 FETCH_SIZE tallies the 128-byte
+requests of coalesced streams at 64 B (MI355X_MICROARCH.md, HBM section; calibrated on k_convert's event
+read in round 1), WRITE_SIZE is 1:1.
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def db_of(d):
+    f = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    return f[0] if f else None
+
+
+def tables(c):
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    return lambda p: next(x for x in tabs if x.startswith(p))
+
+
+def short(name):
+    name = name.split("(")[0].replace("void ", "")
+    for k in ("k_tile", "k_pack_pval", "k_scatter1", "k_convert", "k_bucket2", "k_peak_short", "k_merge2", "k_pack_pairs_full",
+              "k_pack_pairs", "k_pack", "k_mergeN", "k_bh_hist", "k_qlookup", "k_sort_fused", "k_pval_loose"):
+        if k in name:
+            return k
+    return name[:60]
+
+
+def kernel_times(db):
+    c = sqlite3.connect(db)
+    t = tables(c)
+    kd, ks = t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol")
+    agg = {}
+    for name, a, b in c.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id = s.id"):
+        agg.setdefault(name.split("(")[0].replace("void ", ""), []).append(b - a)
+    return agg
+
+
+def pmc_means(db):
+    c = sqlite3.connect(db)
+    t = tables(c)
+    pe, kd, ks, ip = t("rocpd_pmc_event"), t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol"), t("rocpd_info_pmc")
+    agg = {}
+    for name, ctr, v in c.execute(
+            f"select s.kernel_name, i.name, e.value from {pe} e join {kd} d on e.event_id = d.event_id "
+            f"join {ks} s on d.kernel_id = s.id join {ip} i on e.pmc_id = i.id"):
+        agg.setdefault((name.split("(")[0].replace("void ", ""), ctr), []).append(v)
+    return agg
+
+
+def main():
+    tag = sys.argv[1]
+    cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    from bench import source_hash
+    steps = 3  # profile_round.sh: --warmup 1 --steps 2
+    out = {"_how": __doc__.strip().split("\n\n")[1].replace("\n", " "), "tag": tag, "config": cfg, "source_hash": source_hash(),
+           "kernels": {}, "whole_step": {}}
+    # kernel durations
+    db = db_of(os.path.join(src, "trace"))
+    lines = []
+    if db:
+        agg = kernel_times(db)
+        tot = sum(sum(v) for v in agg.values())
+        lines.append(f"{'kernel':60s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+        for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            lines.append(f"{name[:60]:60s} {len(v):6d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} "
+                         f"{max(v)/1e3:10.2f} {100*sum(v)/tot:6.2f}")
+            k = out["kernels"].setdefault(short(name), {})
+            k["us_per_step"] = k.get("us_per_step", 0.0) + sum(v) / 1e3 / steps
+            k["launches_per_step"] = k.get("launches_per_step", 0.0) + len(v) / steps
+        out["whole_step"]["kernel_ms_per_step"] = tot / 1e6 / steps
+        open(os.path.join(ROOT, "profiles", f"{tag}_config{cfg}_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
+    # counters
+    pm = {}
+    for p in ("fetch", "write", "sq1", "sq2"):
+        db = db_of(os.path.join(src, p))
+        if db:
+            pm.update(pmc_means(db))
+    lines = [f"{'kernel':58s} {'counter':22s} {'calls':>6s} {'mean':>18s}"]
+    for (name, ctr), v in sorted(pm.items(), key=lambda kv: (kv[0][1], -sum(kv[1]) / len(kv[1]))):
+        lines.append(f"{name[:58]:58s} {ctr:22s} {len(v):6d} {sum(v)/len(v):18.1f}")
+    open(os.path.join(ROOT, "profiles", f"{tag}_config{cfg}_pmc.txt"), "w").write("\n".join(lines) + "\n")
+    fetch_tot = write_tot = 0.0
+    per = {}
+    for (name, ctr), v in pm.items():
+        per.setdefault(name, {})[ctr] = (sum(v) / len(v), len(v))
+    for name, cs in per.items():
+        k = out["kernels"].setdefault(short(name), {})
+        f = cs.get("FETCH_SIZE", (0, 0))
+        w = cs.get("WRITE_SIZE", (0, 0))
+        fetch_tot += f[0] * f[1]
+        write_tot += w[0] * w[1]
+        if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
+            k["fetch_kb_raw_per_step"] = k.get("fetch_kb_raw_per_step", 0) + f[0] * f[1] / steps
+            k["write_kb_raw_per_step"] = k.get("write_kb_raw_per_step", 0) + w[0] * w[1] / steps
+            k["hbm_bytes_per_step"] = k.get("hbm_bytes_per_step", 0) + (2 * f[0] * f[1] + w[0] * w[1]) * 1024 / steps
+        # SQ counters: totals per step over the template instances of one kernel
+        for c in cs:
+            if c.startswith("SQ_"):
+                k.setdefault("sq", {})
+                k["sq"][c] = k["sq"].get(c, 0.0) + cs[c][0] * cs[c][1] / steps
+    out["whole_step"]["fetch_kb_raw"] = fetch_tot / steps
+    out["whole_step"]["write_kb_raw"] = write_tot / steps
+    out["whole_step"]["hbm_bytes_per_step"] = (2 * fetch_tot + write_tot) * 1024 / steps
+    # issue model of the dominant kernel from the SQ counters (quad-cycle units, MI355X_MICROARCH.md)
+    kt = out["kernels"].get("k_tile", {})
+    sq = kt.get("sq", {})
+    if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_BUSY_CYCLES"):
+        wc = sq["SQ_WAVE_CYCLES"]
+        out["issue"] = {
+            "kernel": "k_tile",
+            "valu_insts_per_wave": sq.get("SQ_INSTS_VALU", 0) / max(1.0, sq.get("SQ_WAVES", 1)),
+            "lds_insts_per_wave": sq.get("SQ_INSTS_LDS", 0) / max(1.0, sq.get("SQ_WAVES", 1)),
+            "active_valu_frac_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+            "active_lds_frac_of_wave_cycles": sq.get("SQ_ACTIVE_INST_LDS", 0) / wc,
+            "wait_any_frac_of_wave_cycles": sq.get("SQ_WAIT_ANY", 0) / wc if "SQ_WAIT_ANY" in sq else None,
+            "wait_inst_any_frac_of_wave_cycles": sq.get("SQ_WAIT_INST_ANY", 0) / wc if "SQ_WAIT_INST_ANY" in sq else None,
+            "wait_inst_lds_frac_of_wave_cycles": sq.get("SQ_WAIT_INST_LDS", 0) / wc,
+            "lds_bank_conflict_frac_of_lds_cycles": (sq.get("SQ_LDS_BANK_CONFLICT", 0) / sq["SQ_LDS_IDX_ACTIVE"])
+            if sq.get("SQ_LDS_IDX_ACTIVE") else None,
+            "raw": sq,
+        }
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"r02_counters_config{cfg}.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (under gpurun): kernel trace + PMC passes of `bench.py --config C`, each in its own
+# rocprofv3 run (counters never share a run with --stats / other trace domains), into gpurun_out/prof_<tag>/.
+#   tools/profile_round.sh <tag> [config]      e.g. tools/profile_round.sh r02a 2
+# Afterwards (anywhere): python tools/make_counters_json.py <tag> [config]  ->  profiles/
+set -u
+tag=$1; cfg=${2:-2}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+cmd="python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu --no-e2e"
+run() {  # name, rocprofv3 options...
+  local name=$1; shift
+  timeout -s KILL 300 rocprofv3 "$@" -d $out/$name -o bench -- $cmd > $out/$name.log 2>&1
+  echo "$name rc=$?"
+}
+run trace --kernel-trace --stats
+run fetch --kernel-trace --pmc FETCH_SIZE
+run write --kernel-trace --pmc WRITE_SIZE
+run sq1 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+run sq2 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+ls -la $out
