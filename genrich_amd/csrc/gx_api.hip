@@ -1526,11 +1526,11 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       u32* runEnd = ctx->swEnd.as<u32>();
       hipLaunchKernelGGL(k_runs_write, dim3(wChunks), dim3(SW_NT), 0, s, SM, offS, offE, runStart, runEnd);
       hipLaunchKernelGGL(k_cands_count, dim3(rChunks), dim3(SW_NT), 0, s, SM, fa.end.as<u32>(), runStart, runEnd,
-                         misc + M_SWCOUNT, ctx->par.max_gap, cnt2);
+                         misc + M_SWCOUNT, ctx->par.max_gap, fa.chromOff.as<u32>(), nChrom, cnt2);
       hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt2, (const u32*)nullptr, rChunks, (u32)SW_CHUNK, off2,
                          misc + M_NHEADS);
       hipLaunchKernelGGL(k_cands_write, dim3(rChunks), dim3(SW_NT), 0, s, SM, fa.end.as<u32>(), runStart, runEnd,
-                         misc + M_SWCOUNT, ctx->par.max_gap, off2, ctx->headPos.as<u32>());
+                         misc + M_SWCOUNT, ctx->par.max_gap, fa.chromOff.as<u32>(), nChrom, off2, ctx->headPos.as<u32>());
       HIPCHECK(ctx->candHdr.ensure((size_t)R * sizeof(uint4)));
       HIPCHECK(ctx->longList.ensure((size_t)R * 4 + 16));
       hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((R + 255) / 256, 4096u))), dim3(256), 0, s, SM, fa.end.as<u32>(),

@@ -10,6 +10,7 @@
 // host program has (torch.distributed in bench.py, shared memory between the threads of genrich-amd).
 #pragma once
 #include <dlfcn.h>
+#include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <string>
@@ -32,9 +33,20 @@ inline const Api* load(std::string* err) {
   static std::string why;
   if (!tried) {
     tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-      api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    // The RCCL that belongs to the HIP runtime this process actually runs on: a Python host may have
+    // loaded PyTorch's bundled ROCm (its own libamdhip64 + librccl) before or after this library, and an
+    // RCCL build only works on the runtime it ships with.  So look next to the loaded libamdhip64 first.
+    std::string beside;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+      beside = info.dli_fname;
+      const size_t slash = beside.rfind('/');
+      beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1);
+    }
+    const std::string names[] = {beside + "librccl.so.1", beside + "librccl.so", "librccl.so.1", "librccl.so",
+                                 "/opt/rocm/lib/librccl.so.1"};
+    for (const std::string& n : names) {
+      api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (api.handle) break;
     }
     if (!api.handle) {

@@ -692,24 +692,30 @@ __device__ __forceinline__ bool any_bit(const u64* __restrict__ mask, u32 lo, u3
 }
 
 // run r opens a new candidate unless it links to run r-1 (same chromosome, no SKIP between,
-// start - previous end <= maxGap)
+// start - previous end <= maxGap).  The chromosome test is a search in the (short) offset table, not a
+// walk over the mask words between the two runs: with few significant intervals (a -q run with a
+// control) consecutive runs lie millions of intervals apart.
 __device__ __forceinline__ bool run_is_head(const SweepMasks& M, const u32* __restrict__ end,
                                             const u32* __restrict__ runStart, const u32* __restrict__ runEnd, u32 r,
-                                            int maxGap) {
+                                            int maxGap, const u32* __restrict__ chromOff, u32 nChrom) {
   if (r == 0) return true;
   const u32 a = runEnd[r - 1], s = runStart[r];       // a < s
   if ((M.brk[s >> 6] >> (s & 63)) & 1ull) return true;  // first interval of a chromosome
-  const long long gap = (long long)end[s - 1] - (long long)end[a];  // start(s) - end(a); same chromosome unless a brk lies between
+  ChromCursor cur;
+  cur.seek(chromOff, nChrom, a);
+  if (s >= cur.hi) return true;                         // another chromosome
+  const long long gap = (long long)end[s - 1] - (long long)end[a];  // start(s) - end(a) on one chromosome: >= 0
   if (gap != 0 && gap > (long long)maxGap) return true;
-  // few intervals lie between linked runs (each is >= 1 bp): scan the masks
-  if (any_bit(M.brk, a + 1, s + 1)) return true;
+  // at most `gap` intervals (each >= 1 bp) lie between linked runs: a short scan
   if (any_bit(M.skip, a + 1, s)) return true;
   return false;
 }
 
 __global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u32* __restrict__ end,
                                                        const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
-                                                       const u32* __restrict__ nRuns, int maxGap, u32* __restrict__ chunkCnt) {
+                                                       const u32* __restrict__ nRuns, int maxGap,
+                                                       const u32* __restrict__ chromOff, u32 nChrom,
+                                                       u32* __restrict__ chunkCnt) {
   __shared__ u32 s_cnt[SW_NT / 64];
   const u32 R = *nRuns;
   if (blockIdx.x * SW_CHUNK >= R) return;
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u32* 
   u32 cnt = 0;
 #pragma unroll
   for (int k = 0; k < SW_ITEMS; k++)
-    if (r0 + k < R) cnt += run_is_head(M, end, runStart, runEnd, r0 + k, maxGap);
+    if (r0 + k < R) cnt += run_is_head(M, end, runStart, runEnd, r0 + k, maxGap, chromOff, nChrom);
   cnt = wave_sum(cnt);
   if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
   __syncthreads();
@@ -727,6 +733,7 @@ __global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u32* 
 __global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u32* __restrict__ end,
                                                        const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
                                                        const u32* __restrict__ nRuns, int maxGap,
+                                                       const u32* __restrict__ chromOff, u32 nChrom,
                                                        const u32* __restrict__ chunkOff, u32* __restrict__ candRun) {
   __shared__ u32 scratch[8];
   const u32 R = *nRuns;
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u32* 
   u32 keep = 0, cnt = 0;
 #pragma unroll
   for (int k = 0; k < SW_ITEMS; k++)
-    if (r0 + k < R && run_is_head(M, end, runStart, runEnd, r0 + k, maxGap)) { keep |= 1u << k; cnt++; }
+    if (r0 + k < R && run_is_head(M, end, runStart, runEnd, r0 + k, maxGap, chromOff, nChrom)) { keep |= 1u << k; cnt++; }
   u32 tot;
   u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
 #pragma unroll

@@ -190,15 +190,15 @@ def test_device_calc_pval_vs_oracle():
     ctrl[:10] = [0, -1, 7, 7.0000005, 1e-30, 6.9999995, 3, 3, 3, 3]
     expt[:10] = [5, 5, 0, 1, 1, 1, 0, 1e6, 3e38, 1e-3]
     got, dd, nrisky = h.selftest2(1, expt, ctrl)
-    want = np.array([lib.gxo_calc_pval(float(e), float(c)) for e, c in zip(expt[:100_000], ctrl[:100_000])], dtype=np.float32)
-    assert np.array_equal(got[:100_000].view(np.uint32), want.view(np.uint32))
     hw, hd = selftest_host(1, expt, ctrl)   # (== the oracle: tests/test_abi.py)
     nbad = int((got.view(np.uint32) != hw.view(np.uint32)).sum())
     assert nbad == 0, f"{nbad} of {n} p-values differ in the last bit"
-    ok = (hd > 0) & (hd < 1e30)
+    want = np.array([lib.gxo_calc_pval(float(e), float(c)) for e, c in zip(expt[:100_000], ctrl[:100_000])], dtype=np.float32)
+    assert np.array_equal(got[:100_000].view(np.uint32), want.view(np.uint32))
+    ok = (hd > 1e-45) & (hd < 1e30)   # results that are not zero as a float
     rel = np.abs(dd[ok] - hd[ok]) / hd[ok]
     print(f"risky: {nrisky} of {n}; max relative device/host difference of the doubles: {rel.max():.3g}")
-    assert rel.max() < 2.0 ** -44, "the device's doubles are too far from the host's for the RISK_B = 2^-40 margin"
+    assert rel.max() < 2.0 ** -41, "the device's doubles are too far from the host's for the RISK_B = 2^-38 margin"
     assert 0 < nrisky < n * 1e-3
 
 
@@ -213,10 +213,10 @@ def test_device_fisher_vs_host():
     got, dd, nrisky = h.selftest2(3, sums, dfs)
     hw, hd = selftest_host(3, sums, dfs)
     assert np.array_equal(got.view(np.uint32), hw.view(np.uint32))
-    ok = (hd > 0) & (hd < 1e30)
+    ok = (hd > 1e-45) & (hd < 1e30)
     rel = np.abs(dd[ok] - hd[ok]) / hd[ok]
     print(f"risky: {nrisky} of {n}; max relative device/host difference of the doubles: {rel.max():.3g}")
-    assert rel.max() < 2.0 ** -44
+    assert rel.max() < 2.0 ** -41
 
 
 def test_device_getval_all_residues():
