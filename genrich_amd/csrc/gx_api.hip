@@ -16,6 +16,8 @@
 
 #include "gx_merge.h"
 #include "gx_rccl.h"
+#include "gx_sort.h"
+#include "gx_tile_fast.h"
 #include "gx_saturate.h"
 
 using namespace gx;
@@ -141,8 +143,10 @@ struct gx_ctx {
   struct Seg { const gx_event* p; size_t n; };
   std::vector<Seg> segs;
   struct Stream {  // one record stream of the bucket sort
-    DevBuf a, b, sbHist, sbOff, sbCursor;
+    DevBuf a, pool, pt, cursor, sbOff;  // level-2 output; level-1 pages, page table, list cursors; super-bucket offsets
   };
+  u32 ptJmax = 16;              // pages per (XCD class, super-bucket) list; grown after ST_PT_FULL
+  DevBuf lbIv;
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3];
   DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, nWide, wideList;
@@ -175,7 +179,7 @@ struct gx_ctx {
   ncclComm_t comm = nullptr;    // the library's own collectives (gx_set_rccl): RCCL on device buffers, on `stream`
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
   DevBuf dColl, dCounts, dGather;
-  int numCU = 0, resTile = 0, resTileHalf = 0, resSweep = 0;  // co-resident workgroups per kernel class
+  int numCU = 0, resTile = 0, resTileHalf = 0, resTileFast = 0, resSweep = 0;  // co-resident workgroups per kernel class
   // recycled device buffers (gx_reset keeps allocations alive across runs)
   std::vector<DevBuf> pool;
   // timing
@@ -253,15 +257,16 @@ void phase_end(gx_ctx* ctx) { (void)hipEventRecord(ctx->phases[ctx->nPhases - 1]
 int status_to_rc(gx_ctx* ctx, u32 st) {
   if (!st) return GX_OK;
   struct { u32 bit; int rc; const char* msg; } tab[] = {
+      {ST_LOOKBACK, GX_ERR_DEVICE, "look-back / page-table spin limit reached"},
       {ST_BAD_CHROM, GX_ERR_ORDER, "event on an unknown chromosome"},
       {ST_BAD_POS, GX_ERR_POS, ": read aligned beyond reference end"},
       {ST_BAD_COUNT, GX_ERR_ALNS, "Disallowed number of alignments"},
       {ST_NEG_PILE, GX_ERR_PILE, "Invalid pileup value (< 0)"},
       {ST_NO_FRAGS, GX_ERR_EXPT, "Experimental sample has no analyzable fragments"},
       {ST_SAT16, GX_ERR_OVERFLOW, "per-base difference beyond the reference's int16 range"},
-      {ST_LOOKBACK, GX_ERR_DEVICE, "look-back spin limit reached"},
       {ST_HASH_FULL, GX_ERR_DEVICE, "p-value table full"},
       {ST_BAD_DF, GX_ERR_DF, "Invalid df in pchisq()"},
+      {ST_PT_FULL, GX_ERR_MEM, "level-1 page table full"},
   };
   for (auto& t : tab)
     if (st & t.bit) {
@@ -351,27 +356,6 @@ int upload_chroms(gx_ctx* ctx) {
   return GX_OK;
 }
 
-// one record stream of the bucket sort (S / E: 4-byte keys, F: 8-byte records)
-template <typename R>
-int sort_stream(gx_ctx* ctx, gx_ctx::Stream& st, u32 nRec, int q) {
-  hipStream_t s = ctx->stream;
-  const u32 nSB = ctx->nSB, nTiles = ctx->nTiles;
-  constexpr u32 CHUNK = SC_NT * ScCfg<R>::ITEMS;
-  hipLaunchKernelGGL(k_scan_sb, dim3(1), dim3(1024), 0, s, st.sbHist.as<u32>(), nSB, st.sbOff.as<u32>(),
-                     st.sbCursor.as<u32>());
-  const u32 chunks1 = (nRec + CHUNK - 1) / CHUNK;
-  hipLaunchKernelGGL((k_scatter1<R>), dim3(chunks1), dim3(SC_NT), 0, s, st.a.as<R>(), st.b.as<R>(),
-                     st.sbOff.as<u32>() + nSB /* total */, ctx->sbShift, nSB, st.sbCursor.as<u32>());
-  // level 2: one workgroup per super-bucket (the last level-1 bin holds the records without a tile)
-  const size_t lds2 = b2_lds_bytes<R>(1u << ctx->sbShift);
-  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds2));
-  hipLaunchKernelGGL((k_bucket2<R>), dim3(std::max(1u, nSB - 1)), dim3(B2_NT), lds2, s, st.b.as<R>(),
-                     st.a.as<typename B2Out<R>::type>(),
-                     st.sbOff.as<u32>(), nSB - 1, ctx->sbShift, nTiles, ctx->tileCnt[q].as<u32>(), ctx->tileWsum.as<int>());
-  return dbg_sync(ctx, "sort_stream");
-}
-
 // loose slots -> tight (end, V) arrays of a pileup (only needed ahead of a control merge)
 int pack_pileup(gx_ctx* ctx, Pileup& P) {
   if (P.packed) return GX_OK;
@@ -408,20 +392,31 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   gx_ctx::Stream& SS = ctx->str[0];
   gx_ctx::Stream& SE = ctx->str[1];
   gx_ctx::Stream& SF = ctx->str[2];
+  const u32 nL1 = nSB - 1;  // level-1 bins = super-buckets (records without a tile are not scattered at all)
+  // level-2 output: 16-bit tile offsets (S, E) / whole records (F), tile-contiguous
   if (unit32) {
-    HIPCHECK(SS.a.ensure((size_t)nEv * 4 + 16));
-    HIPCHECK(SS.b.ensure((size_t)nEv * 4 + 16));
-    HIPCHECK(SE.a.ensure((size_t)nEv * 4 + 16));
-    HIPCHECK(SE.b.ensure((size_t)nEv * 4 + 16));
+    HIPCHECK(SS.a.ensure((size_t)nEv * 2 + 16));
+    HIPCHECK(SE.a.ensure((size_t)nEv * 2 + 16));
   }
   HIPCHECK(SF.a.ensure((size_t)nEv * 16 + 16));  // worst case: every event fractional
-  // everything that must start at zero lives in one arena: one memset per sample instead of eleven
+  // level-1 page pools (gx_sort.h): every record lands in one page of its (XCD class, bin) list
+  const u32 jmax = ctx->ptJmax;
+  u32 poolPages[3];
+  // (page 0: sink; NXCD * nL1 fixed first pages; at most records / page-size further ones)
+  poolPages[0] = poolPages[1] = (u32)(nEv >> PgCfg<u32>::SHIFT) + NXCD * nL1 + 4;
+  poolPages[2] = (u32)(((size_t)2 * nEv) >> PgCfg<u64>::SHIFT) + NXCD * nL1 + 4;
+  for (int q = 0; q < 3; q++) HIPCHECK(ctx->str[q].pool.ensure((size_t)poolPages[q] * PG_BYTES));
+  // everything that must start at zero lives in one arena: one memset per sample
+  const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
   {
-    const size_t tileBytes = ((size_t)(nTiles + 1) * 4 + 255) & ~(size_t)255;
-    const size_t histBytes = (size_t)NXCD * MAX_BINS * 4;
-    const size_t ffBytes = (sizeof(FragFix) + 255) & ~(size_t)255;
-    const size_t endBytes = ((size_t)(nChrom + 1) * 4 + 255) & ~(size_t)255;
-    const size_t total = ffBytes + 256 + endBytes + 3 * histBytes + 5 * tileBytes;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t tileBytes = up((size_t)(nTiles + 1) * 4);
+    const size_t ffBytes = up(sizeof(FragFix));
+    const size_t endBytes = up((size_t)(nChrom + 1) * 4);
+    const size_t curBytes = up((size_t)NXCD * nL1 * 4 + 64);          // cursors + (last word) pages handed out
+    const size_t ptBytes = up((size_t)NXCD * nL1 * jmax * 4);
+    const size_t lbTBytes = up((size_t)3 * (tChunks + 2) * 8), lbIBytes = up((size_t)(2 * tChunks + 4) * 8);
+    const size_t total = ffBytes + 256 + endBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
     HIPCHECK(ctx->zeroArena.ensure(total));
     char* base = ctx->zeroArena.as<char>();
     ctx->fragSum.view(base, ffBytes);
@@ -430,21 +425,27 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     base += 256;
     ctx->endAtLen.view(base, endBytes);
     base += endBytes;
-    for (int q = 0; q < 3; q++, base += histBytes) ctx->str[q].sbHist.view(base, histBytes);
+    for (int q = 0; q < 3; q++) {
+      ctx->str[q].cursor.view(base, curBytes);
+      base += curBytes;
+      ctx->str[q].pt.view(base, ptBytes);
+      base += ptBytes;
+    }
     for (int q = 0; q < 3; q++, base += tileBytes) ctx->tileCnt[q].view(base, tileBytes);
     ctx->tileWsum.view(base, tileBytes);
     base += tileBytes;
     ctx->tileDeep.view(base, tileBytes);
+    base += tileBytes;
+    ctx->lb.view(base, lbTBytes);      // k_scan_tiles' three look-back arrays
+    base += lbTBytes;
+    ctx->lbIv.view(base, lbIBytes);    // k_scan_iv's two
     HIPCHECK(hipMemsetAsync(ctx->zeroArena.p, 0, total, s));
   }
   for (int q = 0; q < 3; q++) {
-    gx_ctx::Stream& st = ctx->str[q];
-    HIPCHECK(st.sbOff.ensure((MAX_BINS + 2) * 4));
-    HIPCHECK(st.sbCursor.ensure((size_t)NXCD * (MAX_BINS + 2) * 4));
+    HIPCHECK(ctx->str[q].sbOff.ensure((MAX_BINS + 2) * 4));
     HIPCHECK(ctx->tileOff[q].ensure((size_t)(nTiles + 2) * 4));
   }
   HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
-  HIPCHECK(ctx->lb.ensure((size_t)(nTiles + 64) * 8));
   // an interval closes at every base with a non-zero difference (<= one per record), at every -E edge,
   // plus one per chromosome
   const size_t ivCap = (size_t)2 * nEv + nChrom + ctx->nBedEdges + 16;
@@ -452,56 +453,66 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   HIPCHECK(pooled(ctx, out.tileIvOff, (size_t)(nTiles + 2) * 4));
   HIPCHECK(pooled(ctx, out.chromIvOff, (size_t)(nChrom + 2) * 4));
 
-  phase_begin(ctx, isCtrl ? "c.convert" : "t.convert");
-  const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
-  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)3 * (tChunks + 2) * 8, s));  // k_scan_tiles' three look-back arrays
+  phase_begin(ctx, isCtrl ? "c.sort1" : "t.sort1");
   // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
   static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
   HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
   FragFix* ff = ctx->fragSum.as<FragFix>();
   u32* slowFrag = &ff->slow;
   if (ctx->hasBed || !unit32 || forceSlowFrag) HIPCHECK(hipMemsetAsync(slowFrag, 1, 4, s));
-  ConvertOut co{SS.a.as<u32>(), SE.a.as<u32>(), SF.a.as<u64>(), &ff->nF, SS.sbHist.as<u32>(),
-                SE.sbHist.as<u32>(), ff->fragSum, slowFrag, ctx->endAtLen.as<u32>(), ctx->nWide.as<u32>() + 1};
-  size_t off = 0;
+  PagedStream PG3[3];
+  for (int q = 0; q < 3; q++) {
+    gx_ctx::Stream& st = ctx->str[q];
+    PG3[q] = PagedStream{st.pool.p, st.pt.as<u32>(), st.cursor.as<u32>(), st.cursor.as<u32>() + NXCD * nL1, jmax, poolPages[q],
+                         NXCD * nL1};
+  }
+  Sort1Out so1{ff->fragSum, slowFrag, ctx->endAtLen.as<u32>(), ctx->nWide.as<u32>() + 1};
   for (auto& seg : segs) {
     if (!seg.n) continue;
-    // whole level-1 chunks per workgroup, grid a multiple of NXCD (see k_convert)
-    u32 blocks = (u32)std::max<size_t>(NXCD, std::min<size_t>(((seg.n + L1_CHUNK32 - 1) / L1_CHUNK32 + NXCD - 1) / NXCD * NXCD,
-                                                             256 * 16));
+    const u32 blocks = (u32)((seg.n + S1_CHUNK - 1) / S1_CHUNK);
     if (unit32)
-      hipLaunchKernelGGL(k_convert<true>, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, (u32)off, ctx->dChrom.as<DChrom>(),
-                         nChrom, ctx->sbShift, nSB, co, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL(k_sort1<true>, dim3(blocks), dim3(S1_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
+                         ctx->sbShift, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
     else
-      hipLaunchKernelGGL(k_convert<false>, dim3(blocks), dim3(256), 0, s, seg.p, (u32)seg.n, (u32)off,
-                         ctx->dChrom.as<DChrom>(), nChrom, ctx->sbShift, nSB, co, ctx->dStatus.as<u32>());
-    off += seg.n;
+      hipLaunchKernelGGL(k_sort1<false>, dim3(blocks), dim3(S1_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
+                         ctx->sbShift, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
   }
-  if (int rc__ = dbg_sync(ctx, "k_convert")) return rc__;
-  u32 nF = 2 * nEv;
-  if (unit32) {  // how many fractional records were appended (0 for ordinary data): read on the side
-                 // stream while the main stream starts bucketing the unit-weight keys
-    HIPCHECK(hipEventRecord(ctx->sideEv, s));
-    HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->sideEv, 0));
-    HIPCHECK(hipMemcpyAsync(&ctx->mail->nF, &ff->nF, 4, hipMemcpyDeviceToHost, ctx->side));
-  }
+  if (int rc__ = dbg_sync(ctx, "k_sort1")) return rc__;
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.bucket" : "t.bucket");
-  if (unit32 && nEv) {
-    if (int rc = sort_stream<u32>(ctx, SS, nEv, 0)) return rc;
-    if (int rc = sort_stream<u32>(ctx, SE, nEv, 1)) return rc;
-  }
-  if (unit32) {
-    HIPCHECK(hipStreamSynchronize(ctx->side));
-    nF = ctx->mail->nF;
-  }
-  if (nF) {
-    HIPCHECK(SF.b.ensure((size_t)nF * 8 + 16));
-    hipLaunchKernelGGL((k_hist1<u64>), dim3(std::max<u32>(NXCD, std::min((nF + L1_CHUNK64 - 1) / L1_CHUNK64 / NXCD * NXCD + NXCD, 4096u))),
-                       dim3(256), 0, s, SF.a.as<u64>(),
-                       nF, ctx->sbShift, nSB, SF.sbHist.as<u32>());
-    if (int rc = sort_stream<u64>(ctx, SF, nF, 2)) return rc;
+  {
+    BinScan bs{{SS.cursor.as<u32>(), SE.cursor.as<u32>(), SF.cursor.as<u32>()}, {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()}};
+    hipLaunchKernelGGL(k_scan_bins, dim3(3), dim3(1024), 0, s, bs, nL1);
+    // level 2: one workgroup per super-bucket
+    const size_t lds32 = b2_lds_bytes<u32>(1u << ctx->sbShift), lds64 = b2_lds_bytes<u64>(1u << ctx->sbShift);
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2p<u32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2p<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+    if (unit32 && nEv) {
+      hipLaunchKernelGGL((k_bucket2p<u32>), dim3(std::max(1u, nL1)), dim3(B2_NT), lds32, s, PG3[0], SS.a.as<uint16_t>(),
+                         SS.sbOff.as<u32>(), nL1, ctx->sbShift, nTiles, ctx->tileCnt[0].as<u32>(), ctx->tileWsum.as<int>());
+      hipLaunchKernelGGL((k_bucket2p<u32>), dim3(std::max(1u, nL1)), dim3(B2_NT), lds32, s, PG3[1], SE.a.as<uint16_t>(),
+                         SE.sbOff.as<u32>(), nL1, ctx->sbShift, nTiles, ctx->tileCnt[1].as<u32>(), ctx->tileWsum.as<int>());
+    }
+    // (the F stream: multimapped reads, or everything beyond 4.29 Gbp; a run without them finds every bin empty)
+    hipLaunchKernelGGL((k_bucket2p<u64>), dim3(std::max(1u, nL1)), dim3(B2_NT), lds64, s, PG3[2], SF.a.as<u64>(),
+                       SF.sbOff.as<u32>(), nL1, ctx->sbShift, nTiles, ctx->tileCnt[2].as<u32>(), ctx->tileWsum.as<int>());
+    if (int rc__ = dbg_sync(ctx, "k_bucket2p")) return rc__;
+    if (getenv("GX_DEBUG_SORT")) {
+      HIPCHECK(hipStreamSynchronize(s));
+      for (int q = 0; q < 3; q++) {
+        std::vector<u32> cur((size_t)NXCD * nL1 + 1), off(nL1 + 1);
+        HIPCHECK(hipMemcpy(cur.data(), ctx->str[q].cursor.p, cur.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(off.data(), ctx->str[q].sbOff.p, off.size() * 4, hipMemcpyDeviceToHost));
+        unsigned long long tot = 0;
+        u32 mx = 0;
+        for (size_t i = 0; i < (size_t)NXCD * nL1; i++) { tot += cur[i]; mx = std::max(mx, cur[i]); }
+        u32 stw = 0;
+        HIPCHECK(hipMemcpy(&stw, ctx->dStatus.p, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[gx sort] stream %d: records %llu (sbOff total %u), longest list %u, pages used %u of %u, status %u\n", q, tot,
+                off[nL1], mx, cur[(size_t)NXCD * nL1], poolPages[q], stw);
+      }
+    }
   }
   TileTabs tt{};
   for (int q = 0; q < 3; q++) {
@@ -545,6 +556,12 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
                        ctx->dStatus.as<u32>());
     hipLaunchKernelGGL((k_tile<true, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
+  } else if (!getenv("GX_TILE_OLD")) {
+    // the common case: one wavefront per narrow tile, work laid out by touched base (gx_tile_fast.h)
+    hipLaunchKernelGGL(k_tile_fast, dim3(std::min<u32>(nTiles, (u32)ctx->resTileFast)), dim3(64), 0, s, tin, nTiles, nw, to,
+                       ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL((k_tile<false, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
+                       ctx->dStatus.as<u32>());
   } else {
     hipLaunchKernelGGL((k_tile<false, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
@@ -560,11 +577,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
 
   phase_begin(ctx, isCtrl ? "c.pack" : "t.pack");
   const u32 ivChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
-  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(2 * ivChunks + 2) * 8, s));
   IvScanOut so{out.tileIvOff.as<u32>(), ctx->tilePrevEnd.as<u32>(), out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV};
   hipLaunchKernelGGL(k_scan_iv, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
                      ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
-                     ctx->dChrom.as<DChrom>(), nTiles, ctx->lb.as<u64>(), ctx->lb.as<u64>() + ivChunks + 1, so,
+                     ctx->dChrom.as<DChrom>(), nTiles, ctx->lbIv.as<u64>(), ctx->lbIv.as<u64>() + ivChunks + 1, so,
                      ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_scan_iv")) return rc__;
   hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
@@ -586,7 +602,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
                        nTiles, ff, acc);
     hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ff, acc,
                        ctx->world > 1 || ctx->forceColl ? ctx->dColl.as<long long>() : (long long*)nullptr,
-                       ctx->nWide.as<u32>() + 1);
+                       ctx->nWide.as<u32>() + 1, ctx->dStatus.as<u32>());
   }
   if (int rc__ = dbg_sync(ctx, "k_frag")) return rc__;
   out.packed = false;
@@ -602,6 +618,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
 }
 
 constexpr int RETRY_SATURATED = 1;  // (internal) finish_scalars: filter the events and build the sample again
+constexpr int RETRY_PT = 2;         // (internal) a level-1 page list overflowed: build again with a longer page table
+constexpr u32 PT_JMAX_CAP = 1u << 20;
 
 // fragLen / ctrlFrag partial sums -> (all ranks) -> lambda, factor
 int finish_scalars(gx_ctx* ctx, int isCtrl) {
@@ -657,11 +675,16 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
   if (int rc__ = dbg_sync(ctx, "p-value tables")) return rc__;
   HIPCHECK(hipMemcpyAsync(&ctx->mail->scal, ds, sizeof(Scalars), hipMemcpyDeviceToHost, s));
   if (int rc__ = risk_queue(ctx)) return rc__;
-  int rc = read_status(ctx);
+  HIPCHECK(hipMemcpyAsync(&ctx->mail->status, ctx->dStatus.p, sizeof(u32), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
   ctx->hScal = ctx->mail->scal;
   const int rcRisk = risk_apply(ctx, RiskTargets{});
   // (with several ranks: if any of them has to rebuild its sample, all go round again with it)
-  if ((multi ? ctx->mail->coll[2] != 0 : ctx->mail->hot != 0) && !ctx->satDone) return RETRY_SATURATED;
+  const long long again = multi ? ctx->mail->coll[2]
+                                : (long long)(ctx->mail->hot ? 1 : 0) + ((ctx->mail->status & ST_PT_FULL) ? 65536 : 0);
+  if (again >= 65536 && ctx->ptJmax < PT_JMAX_CAP) return RETRY_PT;
+  int rc = status_to_rc(ctx, ctx->mail->status);
+  if ((again & 0xFFFF) && !ctx->satDone) return RETRY_SATURATED;
   if (ctx->nIvTarget) *ctx->nIvTarget = ctx->mail->nIv;
   ctx->nIvTarget = nullptr;
   return rc ? rc : rcRisk;
@@ -713,10 +736,24 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
   int rc = build_pileup(ctx, P, isCtrl);
   if (rc) return rc;
   rc = finish_scalars(ctx, isCtrl);
+  while (rc == RETRY_PT) {
+    // a (XCD class, super-bucket) list needed more pages than its table row holds -- reads piled up in one
+    // spot: what the first build left behind goes, the table grows, the sample is built again
+    ctx->ptJmax = std::min(ctx->ptJmax * 16, PT_JMAX_CAP);
+    Scalars* ds = ctx->dScal.as<Scalars>();
+    HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
+    HIPCHECK(hipMemsetAsync(isCtrl ? ds->ctrlAcc : ds->fragAcc, 0, 16, ctx->stream));
+    if ((rc = build_pileup(ctx, P, isCtrl))) return rc;
+    rc = finish_scalars(ctx, isCtrl);
+  }
   if (rc == RETRY_SATURATED) {
     if ((rc = drop_saturated(ctx, isCtrl))) return rc;
     if ((rc = build_pileup(ctx, P, isCtrl))) return rc;
     rc = finish_scalars(ctx, isCtrl);
+    if (rc == RETRY_PT || rc == RETRY_SATURATED) {
+      ctx->err = "sample could not be rebuilt";
+      rc = GX_ERR_DEVICE;
+    }
   }
   return rc;
 }
@@ -884,7 +921,11 @@ int gx_create(gx_ctx** out, const gx_params* par) {
     ctx->resTile = std::max(1, nb) * ctx->numCU;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true, true>, TL_NT, TL_LDS_HALF * 4));
     ctx->resTileHalf = std::max(1, nb) * ctx->numCU;
-    if (getenv("GX_DEBUG")) fprintf(stderr, "k_tile workgroups: half %d, wide %d\n", ctx->resTileHalf, ctx->resTile);
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile_fast, 64, 0));
+    ctx->resTileFast = std::max(1, nb) * ctx->numCU;
+    if (const char* e = getenv("GX_TILE_FAST_WG")) ctx->resTileFast = std::max(1, atoi(e)) * ctx->numCU;
+    if (getenv("GX_DEBUG"))
+      fprintf(stderr, "k_tile workgroups: half %d, wide %d, fast %d\n", ctx->resTileHalf, ctx->resTile, ctx->resTileFast);
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scan_iv, STL_NT, 0));
     ctx->resSweep = std::max(1, std::min(nb, 4)) * ctx->numCU;
   }

@@ -224,7 +224,7 @@ struct ChromCursor {
   }
 };
 
-// ---- 1. events -> endpoint records ------------------------------------------------------
+// ---- 1. events -> endpoint records (the kernels are in gx_sort.h) ---------------------------
 // Replaces the accumulate step of saveInterval (Genrich.c:2546-2583): instead of a
 // read-modify-write on diff[start] / diff[end], emit (+w at start) and (-w at end).
 // An end at the chromosome length never influences a base < len and is dropped.
@@ -232,10 +232,10 @@ struct ChromCursor {
 // Three record streams feed the bucket sort:
 //   S, E : 4-byte keys  [31:TB] tile  [TB-1:0] offset  for the starts / ends of unit-weight
 //          (count == 1) intervals -- sign and weight are implied by the stream, which halves
-//          the sort traffic of the common case.  One slot per event (NULL32 when unused).
+//          the sort traffic of the common case.
 //   F    : 8-byte records  [63:32] tile  [31:8] offset  [7:0] signed weight (1/120 units) for
-//          multimapped (fractional) intervals, appended compactly; also carries everything when
-//          the genome has too many tiles for a 4-byte key.
+//          multimapped (fractional) intervals; also carries everything when the genome has too
+//          many tiles for a 4-byte key.
 // weight (1/120 units) of starts, or of ends, below which a base cannot reach the reference's int16 limits
 constexpr u32 HOT16 = 32766u * GX_UNIT;
 constexpr u32 NULL32 = 0xFFFFFFFFu;
@@ -255,180 +255,17 @@ __device__ __forceinline__ u64 make_rec64(u32 tile, u32 off, int w) {
 
 constexpr int FRAG_SLOTS = 64;  // partial sums of the closed form of fragLen (see k_frag)
 
-// Level 1 of the bucket sort works on chunks of the key arrays (one workgroup of k_scatter1 each),
-// and reserves its output runs per (XCD, super-bucket): workgroups are dealt to the 8 XCDs
-// round-robin, each XCD has its own L2, and a 128-byte line completed by short runs from several
-// XCDs costs ~1.5x the time of one completed within a single L2 (tools/bw_probe3.hip: 232 vs
-// 154 us for this shape).  So the level-1 histograms are kept per chunk-index-mod-8, which is the
-// XCD that will scatter the chunk (if the dispatch order differs, only speed is affected).
+// Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2: a 128-byte line completed
+// by short runs from several XCDs costs ~1.5x the time of one completed within a single L2
+// (tools/bw_probe3.hip: 232 vs 154 us for the level-1 scatter's shape).  Hence one output list per
+// (blockIdx % 8, super-bucket) in level 1 of the bucket sort (if the dispatch order differs, only speed
+// is affected), and the XCD-local tile order of the tile kernels.
 constexpr int NXCD = 8;
 // logical index of a workgroup such that consecutive logical indices sit on one XCD: the grid's
 // first NXCD * (G / NXCD) workgroups are regrouped, a remainder keeps its index
 __device__ __forceinline__ u32 xcd_local_block(u32 b, u32 G) {
   const u32 per = G / NXCD, full = per * NXCD;
   return b < full ? (b % NXCD) * per + b / NXCD : b;
-}
-constexpr int L1_CHUNK32 = 8192, L1_CHUNK64 = 4096;  // records per level-1 chunk (4- / 8-byte records)
-
-struct ConvertOut {
-  u32* S;       // [n] start keys
-  u32* E;       // [n] end keys
-  u64* F;       // fractional / fallback records
-  u32* nF;      // number of F records (appended in pairs)
-  u32* histS;   // level-1 histograms [NXCD][nSB]
-  u32* histE;
-  u64* fragSum; // [FRAG_SLOTS] sum of the clamped lengths of the fragments kept (see k_frag)
-  u32* slowFrag;
-  u32* endAtLen; // [nChrom] weight of the events that end at (or beyond) the chromosome's end
-  u32* hot;      // set when a base can reach the reference's int16 limits (see k_hot_check)
-};
-
-template <bool UNIT32>
-__global__ __launch_bounds__(256) void k_convert(const gx_event* __restrict__ ev, u32 n, u32 evBase,
-                                                 const DChrom* __restrict__ chroms, u32 nChrom,
-                                                 int sbShift, u32 nSB, ConvertOut out, u32* __restrict__ st) {
-  __shared__ u32 hS[MAX_BINS], hE[MAX_BINS];
-  if (UNIT32) {
-    for (int i = threadIdx.x; i < (int)nSB; i += 256) { hS[i] = 0; hE[i] = 0; }
-    __syncthreads();
-  }
-  u32 bad = 0, frac = 0;
-  u64 covered = 0;
-  // a workgroup takes whole level-1 chunks of the key arrays (chunk ids congruent to blockIdx.x
-  // modulo the grid, which is a multiple of NXCD: all its chunks belong to one XCD class)
-  const u32 g0 = evBase, g1 = evBase + n;
-  const u32 cFirst = g0 / L1_CHUNK32, cLast = (g1 - 1) / L1_CHUNK32;
-  for (u32 c = cFirst + (blockIdx.x + gridDim.x - cFirst % gridDim.x) % gridDim.x; c <= cLast; c += gridDim.x)
-  for (u32 g = max(c * L1_CHUNK32, g0) + threadIdx.x, gEnd = min((c + 1) * (u32)L1_CHUNK32, g1); g < gEnd; g += 256) {
-    const u32 i = g - evBase;
-    uint4 e = reinterpret_cast<const uint4*>(ev)[i];  // chrom, start, end, count
-    int w = 0;
-    switch (e.w) {
-      case 1: w = 120; break;
-      case 2: w = 60; break;
-      case 3: w = 40; break;
-      case 4: w = 30; break;
-      case 5: w = 24; break;
-      case 6: w = 20; break;
-      case 8: w = 15; break;
-      case 10: w = 12; break;
-      default: bad |= ST_BAD_COUNT;
-    }
-    u32 t0 = NULL_TILE, t1 = NULL_TILE, o0 = 0, o1 = 0;
-    if (e.x >= nChrom)
-      bad |= ST_BAD_CHROM;
-    else if (w) {
-      DChrom c = chroms[e.x];
-      if (chrom_active(c)) {
-        if (e.y >= c.len)
-          bad |= ST_BAD_POS;
-        else {
-          u32 end = e.z > c.len ? c.len : e.z;
-          // (an empty interval adds and removes the same weight.  One that ends before it starts -- the
-          // reference's BAM reader makes them from reverse reads without SEQ -- is counted like any other:
-          // +w at its start, -w at its end, a negative length towards fragLen; the pileup between the two
-          // goes down, and below zero that is the reference's "Invalid pileup value")
-          if (end != e.y) {
-            covered += (u64)((long long)end - (long long)e.y);
-            t0 = c.tileBase + (e.y >> TB);
-            o0 = e.y & (TILE - 1);
-            if (end < c.len) {
-              t1 = c.tileBase + (end >> TB);
-              o1 = end & (TILE - 1);
-            } else if (atomicAdd(&out.endAtLen[e.x], (u32)w) + (u32)w >= HOT16) {
-              // the reference's diff has an entry at `len` too, and its int16 saturates there like
-              // anywhere else (2565-2573): these ends have no record, so they are counted here
-              atomicOr(out.hot, 1u);
-            }
-          }
-        }
-      }
-    }
-    const bool unit = UNIT32 && w == 120;
-    if (UNIT32) {
-      u32 ks = unit && t0 != NULL_TILE ? (t0 << TB) | o0 : NULL32;
-      u32 ke = unit && t1 != NULL_TILE ? (t1 << TB) | o1 : NULL32;
-      out.S[evBase + i] = ks;
-      out.E[evBase + i] = ke;
-      atomicAdd(&hS[ks == NULL32 ? nSB - 1 : t0 >> sbShift], 1u);
-      atomicAdd(&hE[ke == NULL32 ? nSB - 1 : t1 >> sbShift], 1u);
-    }
-    if (!unit && t0 != NULL_TILE) {
-      frac = 1;
-      u32 pos = UNIT32 ? atomicAdd(out.nF, 2u) : 2 * (evBase + i);
-      out.F[pos] = make_rec64(t0, o0, w);
-      out.F[pos + 1] = t1 != NULL_TILE ? make_rec64(t1, o1, -w) : (u64)NULL_TILE << 32;
-    } else if (!UNIT32) {
-      out.F[2 * (evBase + i)] = (u64)NULL_TILE << 32;
-      out.F[2 * (evBase + i) + 1] = (u64)NULL_TILE << 32;
-    }
-  }
-  if (UNIT32) {
-    __syncthreads();
-    const u32 x = blockIdx.x % NXCD;
-    for (int i = threadIdx.x; i < (int)nSB; i += 256) {
-      if (hS[i]) atomicAdd(&out.histS[x * nSB + i], hS[i]);
-      if (hE[i]) atomicAdd(&out.histE[x * nSB + i], hE[i]);
-    }
-  }
-  if (bad) atomicOr(st, bad);
-  if (frac) atomicOr(out.slowFrag, 1u);
-  covered = wave_sum(covered);
-  if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 4 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
-}
-
-// level-1 histogram of an already materialised stream (the F records), same chunk / XCD rule
-template <typename R>
-__global__ __launch_bounds__(256) void k_hist1(const R* __restrict__ in, u32 n, int sbShift, u32 nSB,
-                                               u32* __restrict__ sbHist) {
-  constexpr u32 CH = sizeof(R) == 4 ? L1_CHUNK32 : L1_CHUNK64;
-  __shared__ u32 hist[MAX_BINS];
-  for (int i = threadIdx.x; i < (int)nSB; i += 256) hist[i] = 0;
-  __syncthreads();
-  for (u32 c = blockIdx.x; c * CH < n; c += gridDim.x)
-    for (u32 i = c * CH + threadIdx.x, iEnd = min((c + 1) * CH, n); i < iEnd; i += 256) {
-      u32 t = RecT<R>::tile(in[i]);
-      atomicAdd(&hist[t == NULL_TILE ? nSB - 1 : t >> sbShift], 1u);
-    }
-  __syncthreads();
-  const u32 x = blockIdx.x % NXCD;
-  for (int i = threadIdx.x; i < (int)nSB; i += 256)
-    if (hist[i]) atomicAdd(&sbHist[x * nSB + i], hist[i]);
-}
-
-// ---- 2. tiny scans ------------------------------------------------------------------------
-// super-bucket histograms [NXCD][nSB] -> super-bucket offsets and the scatter cursors [NXCD][nSB]:
-// inside a super-bucket the XCD classes follow each other, so it stays one contiguous range
-__global__ __launch_bounds__(1024) void k_scan_sb(const u32* __restrict__ sbHist, u32 nSB, u32* __restrict__ sbOff,
-                                                  u32* __restrict__ sbCursor) {
-  __shared__ u32 scratch[20];
-  // nSB <= MAX_BINS: MAX_BINS / 1024 consecutive items per thread
-  constexpr int PER = MAX_BINS / 1024;
-  u32 v[PER], sum = 0;
-#pragma unroll
-  for (int k = 0; k < PER; k++) {
-    const u32 i = threadIdx.x * PER + k;
-    v[k] = 0;
-    if (i < nSB)
-      for (int x = 0; x < NXCD; x++) v[k] += sbHist[x * nSB + i];
-    sum += v[k];
-  }
-  u32 tot;
-  u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
-#pragma unroll
-  for (int k = 0; k < PER; k++) {
-    const u32 i = threadIdx.x * PER + k;
-    if (i < nSB) {
-      sbOff[i] = ex;
-      u32 o = ex;
-      for (int x = 0; x < NXCD; x++) {
-        sbCursor[x * nSB + i] = o;
-        o += sbHist[x * nSB + i];
-      }
-    }
-    ex += v[k];
-  }
-  if (threadIdx.x == 0) sbOff[nSB] = tot;
 }
 
 // per-tile record counts of the three streams -> offsets; per-tile weight -> genome-wide
@@ -529,73 +366,6 @@ constexpr int SC_NT = 1024;  // 16 waves per workgroup: the kernel is latency-, 
 template <typename R> struct ScCfg { static constexpr int ITEMS = 4; };    // 4096 x 8 B = 32 KiB staged
 template <> struct ScCfg<u32> { static constexpr int ITEMS = 8; };        // 8192 x 4 B = 32 KiB staged
 
-template <typename R>
-__device__ __forceinline__ u32 sb_of(R r, int sbShift, u32 nBins) {  // records without a tile go to the last bin
-  const u32 t = RecT<R>::tile(r);
-  return t == NULL_TILE ? nBins - 1 : t >> sbShift;
-}
-
-// level 1: records -> super-buckets
-template <typename R>
-__global__ __launch_bounds__(SC_NT) void k_scatter1(const R* __restrict__ in, R* __restrict__ out,
-                                                    const u32* __restrict__ total, int sbShift, u32 nBins,
-                                                    u32* __restrict__ cursor) {
-  constexpr int ITEMS = ScCfg<R>::ITEMS;
-  constexpr int CHUNK = SC_NT * ITEMS;
-  static_assert(CHUNK == (sizeof(R) == 4 ? L1_CHUNK32 : L1_CHUNK64), "the histograms were taken per chunk of this size");
-  __shared__ u32 hist[MAX_BINS];
-  __shared__ u32 start[MAX_BINS];
-  __shared__ u32 base[MAX_BINS];
-  __shared__ R stage[CHUNK];
-  __shared__ u32 scratch[20];
-  cursor += (blockIdx.x % NXCD) * nBins;  // this chunk's XCD class
-  const u32 begin = blockIdx.x * CHUNK;
-  u32 end = *total;
-  if (begin >= end) return;
-  end = min(end, begin + CHUNK);
-  for (int i = threadIdx.x; i < (int)nBins; i += SC_NT) hist[i] = 0;
-  __syncthreads();
-  R r[ITEMS];
-  u32 rk[ITEMS];
-#pragma unroll
-  for (int k = 0; k < ITEMS; k++) {
-    u32 idx = begin + k * SC_NT + threadIdx.x;
-    if (idx < end) {
-      r[k] = in[idx];
-      rk[k] = atomicAdd(&hist[sb_of<R>(r[k], sbShift, nBins)], 1u);
-    }
-  }
-  __syncthreads();
-  // Thread t owns bins t and t + SC_NT (MAX_BINS = 2 SC_NT).  Its two run reservations (global
-  // atomics) are issued first and stay in flight during the scan; the two counts (<= CHUNK < 2^16
-  // each, so are their sums) share one 32-bit block scan.
-  static_assert(MAX_BINS == 2 * SC_NT && CHUNK < 65536, "two bins per thread, 16-bit packed counts");
-  {
-    const u32 b0 = threadIdx.x, b1 = threadIdx.x + SC_NT;
-    const u32 c0 = b0 < nBins ? hist[b0] : 0, c1 = b1 < nBins ? hist[b1] : 0;
-    u32 g0 = 0, g1 = 0;
-    if (c0) g0 = atomicAdd(&cursor[b0], c0);
-    if (c1) g1 = atomicAdd(&cursor[b1], c1);
-    u32 tot;
-    const u32 ex = block_excl_scan<u32, SC_NT>(c0 | (c1 << 16), scratch, &tot);
-    if (b0 < nBins) { start[b0] = ex & 0xFFFFu; base[b0] = g0; }
-    if (b1 < nBins) { start[b1] = (tot & 0xFFFFu) + (ex >> 16); base[b1] = g1; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < ITEMS; k++) {
-    u32 idx = begin + k * SC_NT + threadIdx.x;
-    if (idx < end) stage[start[sb_of<R>(r[k], sbShift, nBins)] + rk[k]] = r[k];
-  }
-  __syncthreads();
-  u32 cnt = end - begin;
-  for (u32 i = threadIdx.x; i < cnt; i += SC_NT) {
-    R v = stage[i];
-    u32 b = sb_of<R>(v, sbShift, nBins);
-    out[base[b] + (i - start[b])] = v;
-  }
-}
-
 // level 2 in one kernel: a workgroup owns one whole super-bucket, so the per-tile histogram, its
 // scan and the scatter cursors all live in LDS -- no global atomics, no separate histogram pass,
 // and the tile counts are plain stores.  Pass 1 streams the super-bucket and counts (records
@@ -609,7 +379,7 @@ template <> struct B2Out<u32> { typedef uint16_t type; };
 static_assert(TB <= 16, "tile offsets are stored in 16 bits");
 // one-pass path: records of a super-bucket held in registers (FITEMS per thread) and sorted in LDS
 template <typename R> struct B2Cfg { static constexpr int FITEMS = 16; };     // 16 K x 8 B staged
-template <> struct B2Cfg<u32> { static constexpr int FITEMS = 40; };          // 40 K x 2 B staged
+template <> struct B2Cfg<u32> { static constexpr int FITEMS = 48; };          // 48 slots of 1024 keys: up to 48 K x 2 B staged
 constexpr int B2_LDS_MAX = 160 * 1024;
 __host__ __device__ constexpr u32 b2_table_bytes(u32 nBins) { return (4 * nBins + 32) * 4; }
 template <typename R>
@@ -621,166 +391,6 @@ __host__ __device__ constexpr u32 b2_stage_bytes() {
 }
 template <typename R>
 __host__ __device__ constexpr size_t b2_lds_bytes(u32 nBins) { return (size_t)b2_stage_bytes<R>() + b2_table_bytes(nBins); }
-
-template <typename R>
-__global__ __launch_bounds__(B2_NT) void k_bucket2(const R* __restrict__ in, typename B2Out<R>::type* __restrict__ out,
-                                                   const u32* __restrict__ segOff, u32 nSeg, int sbShift, u32 nTiles,
-                                                   u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
-  typedef typename B2Out<R>::type O;
-  constexpr int ITEMS = ScCfg<R>::ITEMS;
-  constexpr int CHUNK = B2_NT * ITEMS;
-  constexpr int FITEMS = B2Cfg<R>::FITEMS;  // records per thread on the one-pass path
-  constexpr u32 FCAP = (u32)FITEMS * B2_NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
-  const u32 nBins = 1u << sbShift;
-  constexpr u32 stageBytes = b2_stage_bytes<R>();
-  R* stage = reinterpret_cast<R*>(b2_lds);    // two-pass path: one chunk of records
-  O* stageO = reinterpret_cast<O*>(b2_lds);   // one-pass path: the whole super-bucket, as it will be written
-  u32* hist = reinterpret_cast<u32*>(b2_lds + stageBytes);  // records per tile (of the chunk, in the chunked pass 2)
-  u32* start = hist + nBins;                                    // run starts (pass 1 of the chunked path: weight sums)
-  u32* cursor = start + nBins;                                  // chunked path: next output position of every tile
-  u32* base = cursor + nBins;                                   // chunked path: output position of the chunk's run
-  u32* scratch = base + nBins;
-  auto outOf = [](R r) -> O {
-    if constexpr (sizeof(R) == 4) return (O)((u32)r & (TILE - 1)); else return r;
-  };
-  for (u32 seg = blockIdx.x; seg < nSeg; seg += gridDim.x) {
-    const u32 begin = segOff[seg], end = segOff[seg + 1], segTileBase = seg << sbShift;
-    if (end - begin <= FCAP) {
-      // one pass: every record is read once into registers, counted, then placed in LDS by a second
-      // round of LDS atomics on per-tile cursors, and written back as one contiguous, fully coalesced
-      // stream (each output line is written exactly once)
-      __syncthreads();
-      for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; base[i] = 0; }
-      __syncthreads();
-      R r[FITEMS];
-#pragma unroll
-      for (int k = 0; k < FITEMS; k++) {
-        const u32 idx = begin + k * B2_NT + threadIdx.x;
-        if (idx < end) r[k] = in[idx];
-      }
-#pragma unroll
-      for (int k = 0; k < FITEMS; k++) {
-        const u32 idx = begin + k * B2_NT + threadIdx.x;
-        if (idx < end) {
-          const u32 b = RecT<R>::tile(r[k]) - segTileBase;
-          atomicAdd(&hist[b], 1u);
-          if (sizeof(R) == 8) atomicAdd(&base[b], (u32)(int)(int8_t)((u64)r[k] & 0xFF));
-        }
-      }
-      __syncthreads();
-      u32 carry = 0;
-      for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
-        const u32 b = b0 + threadIdx.x;
-        const u32 c = b < nBins ? hist[b] : 0;
-        u32 tot;
-        const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
-        if (b < nBins) {
-          cursor[b] = carry + ex;
-          if (segTileBase + b < nTiles) {  // (the last super-bucket may be short of tiles)
-            tileCnt[segTileBase + b] = c;
-            if (sizeof(R) == 8) tileWsum[segTileBase + b] += (int)base[b];  // the slot is this workgroup's alone
-          }
-        }
-        carry += tot;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < FITEMS; k++) {
-        const u32 idx = begin + k * B2_NT + threadIdx.x;
-        if (idx < end) stageO[atomicAdd(&cursor[RecT<R>::tile(r[k]) - segTileBase], 1u)] = outOf(r[k]);
-      }
-      __syncthreads();
-      const u32 cnt = end - begin;
-      for (u32 i = threadIdx.x; i < cnt; i += B2_NT) out[begin + i] = stageO[i];
-    } else {
-    // chunked two-pass path for a super-bucket that does not fit (a pile-up of records in one place)
-    __syncthreads();
-    for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; start[i] = 0; }
-    __syncthreads();
-    for (u32 i0 = begin; i0 < end; i0 += CHUNK) {
-      R r[ITEMS];
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u32 idx = i0 + k * B2_NT + threadIdx.x;
-        if (idx < end) r[k] = in[idx];
-      }
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u32 idx = i0 + k * B2_NT + threadIdx.x;
-        if (idx < end) {
-          const u32 b = RecT<R>::tile(r[k]) - segTileBase;
-          atomicAdd(&hist[b], 1u);
-          if (sizeof(R) == 8) atomicAdd(&start[b], (u32)(int)(int8_t)((u64)r[k] & 0xFF));
-        }
-      }
-    }
-    __syncthreads();
-    u32 carry = begin;
-    for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
-      const u32 b = b0 + threadIdx.x;
-      const u32 c = b < nBins ? hist[b] : 0;
-      u32 tot;
-      const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
-      if (b < nBins) {
-        cursor[b] = carry + ex;
-        hist[b] = 0;                     // pass 2 starts from an empty chunk histogram
-        if (segTileBase + b < nTiles) {  // (the last super-bucket may be short of tiles)
-          tileCnt[segTileBase + b] = c;
-          if (sizeof(R) == 8) tileWsum[segTileBase + b] += (int)start[b];  // the slot is this workgroup's alone
-        }
-      }
-      carry += tot;
-    }
-    __syncthreads();
-    for (u32 i0 = begin; i0 < end; i0 += CHUNK) {
-      const u32 cEnd = min(end, i0 + CHUNK);
-      R r[ITEMS];
-      u32 rk[ITEMS];
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u32 idx = i0 + k * B2_NT + threadIdx.x;
-        if (idx < cEnd) r[k] = in[idx];
-      }
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u32 idx = i0 + k * B2_NT + threadIdx.x;
-        if (idx < cEnd) rk[k] = atomicAdd(&hist[RecT<R>::tile(r[k]) - segTileBase], 1u);
-      }
-      __syncthreads();  // (also: every thread has left the previous chunk's write loop)
-      // each bin's owner: chunk-local run start, the run's output position, cursor advance, and
-      // the histogram reset for the next chunk
-      u32 lc = 0;
-      for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
-        const u32 b = b0 + threadIdx.x;
-        const u32 c = b < nBins ? hist[b] : 0;
-        u32 tot;
-        const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
-        if (b < nBins) {
-          start[b] = lc + ex;
-          base[b] = cursor[b];
-          cursor[b] += c;
-          hist[b] = 0;
-        }
-        lc += tot;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const u32 idx = i0 + k * B2_NT + threadIdx.x;
-        if (idx < cEnd) stage[start[RecT<R>::tile(r[k]) - segTileBase] + rk[k]] = r[k];
-      }
-      __syncthreads();
-      const u32 cnt = cEnd - i0;
-      for (u32 i = threadIdx.x; i < cnt; i += B2_NT) {
-        const R v = stage[i];
-        const u32 b = RecT<R>::tile(v) - segTileBase;
-        out[base[b] + (i - start[b])] = outOf(v);
-      }
-    }
-    }  // chunked path
-  }
-}
 
 // ---- 4. the tile kernel: LDS difference array -> prefix sum -> run-length pileup -----------
 // Replaces savePileupExpt's two per-base passes (Genrich.c:2197-2273; and the per-base walk
@@ -1592,10 +1202,11 @@ struct Scalars {
 };
 
 // closed form or general path -> the (integer, fraction * 2^27) accumulator pair; with several ranks
-// also this rank's contribution to the all-reduce: the pair and its "a base can saturate" flag (every
-// rank must learn whether any rank has to rebuild its sample before the sums mean anything)
+// also this rank's contribution to the all-reduce: the pair and its "build this sample again" flags
+// (every rank must learn whether any rank has to, before the sums mean anything): +1 when a base can
+// reach the reference's int16 limits, +65536 when a level-1 page list overflowed (ST_PT_FULL = 512)
 __global__ void k_frag_select(const FragFix* __restrict__ ff, long long* __restrict__ acc, long long* __restrict__ coll,
-                              const u32* __restrict__ hot) {
+                              const u32* __restrict__ hot, const u32* __restrict__ st) {
   if (threadIdx.x || blockIdx.x) return;
   if (!ff->slow) {
     u64 t = 0;
@@ -1606,7 +1217,7 @@ __global__ void k_frag_select(const FragFix* __restrict__ ff, long long* __restr
   if (coll) {
     coll[0] = acc[0];
     coll[1] = acc[1];
-    coll[2] = *hot ? 1 : 0;
+    coll[2] = (*hot ? 1 : 0) + ((*st & 512u) ? 65536 : 0);
   }
 }
 

@@ -1,0 +1,567 @@
+// gx_sort.h -- events -> endpoint records grouped by super-bucket, in ONE pass over the events.
+//
+// Replaces the accumulate step of saveInterval (Genrich.c:2546-2583: diff[start] += w, diff[end] -= w)
+// together with level 1 of the bucket sort that groups the endpoint records by tile.  Round 1 did this
+// in three passes (k_convert wrote the keys and took per-chunk histograms, k_scan_sb placed the
+// super-buckets, k_scatter1 read the keys again and scattered them: 2.15 GB of HBM traffic for 0.4 GB of
+// keys).  The histogram is only needed to know where a super-bucket starts -- so the super-buckets are
+// not contiguous any more: each is a list of fixed-size PAGES taken from a pool, and a workgroup's run
+// of records for a bin is reserved with one atomic add on the bin's cursor, exactly as before.  The
+// events are read once (16 B each), the keys written once (4 B each): 1.2 GB.
+//
+//   page      8192 4-byte keys or 4096 8-byte records (32 KiB)
+//   cursor    [NXCD][bin]  records reserved so far in the (XCD class, bin) list -- one list per class of
+//             workgroups (blockIdx % 8 = the XCD a workgroup runs on), so the cache lines of a page are
+//             completed inside one L2 (tools/bw_probe3.hip: 1.5x the write rate for short runs)
+//   pt        [NXCD][bin][jmax]  page id + 1 of the list's j-th page, j >= 1 (0: not allocated yet); a list's
+//             first page is fixed (page 1 + list index), so the common reservation needs no table look-up
+// A reservation [o, o + c) (c <= one page) touches one or two pages.  Whoever reserves the FIRST slot of
+// a page allocates it (one atomic add on the pool counter) and publishes its id in pt; a workgroup that
+// needs a page it did not allocate polls pt -- the allocator is a workgroup that is already running and
+// publishes right after its own reservation, so the wait is a memory round trip, bounded like every spin
+// in this library (ST_LOOKBACK).  A list that needs more than jmax pages, or an exhausted pool, sets
+// ST_PT_FULL and the host repeats the sample with a longer table (a pile-up of reads in one spot).
+// Level 2 (k_bucket2p, one workgroup per super-bucket) walks the eight lists of its bin.
+#pragma once
+#include "gx_kernels.h"
+
+namespace gx {
+
+constexpr u32 ST_PT_FULL = 512u;  // page table row / page pool exhausted (internal: the host retries)
+
+template <typename R> struct PgCfg { static constexpr int SHIFT = 12; };   // 4096 x 8 B
+template <> struct PgCfg<u32> { static constexpr int SHIFT = 13; };       // 8192 x 4 B
+constexpr u32 PG_BYTES = 32768;
+
+struct PagedStream {
+  void* pool;       // pages; page 0 is a sink for writes that have nowhere to go after an overflow
+  u32* pt;          // [NXCD][nBins][jmax]
+  u32* cursor;      // [NXCD][nBins]
+  u32* pagesUsed;   // dynamic pages handed out
+  u32 jmax, poolPages;
+  u32 nLists;       // NXCD * nBins: pages 1 .. nLists are the lists' first pages, dynamic ones follow
+};
+
+__device__ __forceinline__ u32 first_page(u32 list) { return 1u + list; }
+
+struct Sort1Out {
+  u64* fragSum;   // [FRAG_SLOTS] sum of the clamped lengths of the fragments kept (closed form of fragLen)
+  u32* slowFrag;  // set when a fractional weight was seen (general fragLen path)
+  u32* endAtLen;  // [nChrom] weight of the events that end at (or beyond) the chromosome's end
+  u32* hot;       // set when a base can reach the reference's int16 limits (see k_hot_check)
+};
+
+// one event -> its two endpoint records.  Returns the weight in 1/120 units (0: nothing to add).
+struct Endpoints { u32 t0, o0, t1, o1; int w; };
+
+// FX: with the side effects of the first conversion (status bits, covered bases, end-of-chromosome weights)
+template <bool FX>
+__device__ __forceinline__ Endpoints convert_event(const uint4 e, const DChrom* __restrict__ chroms, u32 nChrom, const Sort1Out& out,
+                                                   u32& bad, u64& covered) {
+  Endpoints r{NULL_TILE, 0u, NULL_TILE, 0u, 0};
+  int w = 0;
+  switch (e.w) {
+    case 1: w = 120; break;
+    case 2: w = 60; break;
+    case 3: w = 40; break;
+    case 4: w = 30; break;
+    case 5: w = 24; break;
+    case 6: w = 20; break;
+    case 8: w = 15; break;
+    case 10: w = 12; break;
+    default: if (FX) bad |= ST_BAD_COUNT;  // ERRALNS, 2402
+  }
+  if (e.x >= nChrom) {
+    if (FX) bad |= ST_BAD_CHROM;
+    return r;
+  }
+  if (!w) return r;
+  const DChrom c = chroms[e.x];
+  if (!chrom_active(c)) return r;
+  if (e.y >= c.len) {  // ERRPOS, 2531
+    if (FX) bad |= ST_BAD_POS;
+    return r;
+  }
+  const u32 end = e.z > c.len ? c.len : e.z;  // 2536-2544
+  // (an empty interval adds and removes the same weight.  One that ends before it starts -- the reference's
+  // BAM reader makes them from reverse reads without SEQ -- is counted like any other: +w at its start, -w
+  // at its end, a negative length towards fragLen)
+  if (end == e.y) return r;
+  if (FX) covered += (u64)((long long)end - (long long)e.y);
+  r.w = w;
+  r.t0 = c.tileBase + (e.y >> TB);
+  r.o0 = e.y & (TILE - 1);
+  if (end < c.len) {
+    r.t1 = c.tileBase + (end >> TB);
+    r.o1 = end & (TILE - 1);
+  } else if (FX && atomicAdd(&out.endAtLen[e.x], (u32)w) + (u32)w >= HOT16) {
+    // the reference's diff has an entry at `len` too, and its int16 saturates there like anywhere else
+    // (2565-2573): these ends have no record, so they are counted here
+    atomicOr(out.hot, 1u);
+  }
+  return r;
+}
+
+#ifndef GX_S1_NT
+#define GX_S1_NT 1024
+#endif
+constexpr int S1_NT = GX_S1_NT;             // threads per workgroup
+constexpr int S1_CHUNK = 8192;              // events per workgroup
+constexpr int S1_ITEMS = S1_CHUNK / S1_NT;
+constexpr int S1_BPT = MAX_BINS / S1_NT;    // level-1 bins owned by a thread
+static_assert(S1_CHUNK == (1 << PgCfg<u32>::SHIFT), "a chunk's run for one bin never spans more than two pages");
+static_assert(S1_BPT == 2 || S1_BPT == 4, "two or four bins per thread");
+
+struct S1Lds {
+  u32 hist[MAX_BINS];
+  u32 startSplit[MAX_BINS];  // [15:0] start of the bin's run in the staged chunk, [31:16] records of it in its first page
+  u32 base0[MAX_BINS];       // record index (in the pool) of the run's first record
+  u32 base1[MAX_BINS];       // ... of its first record in the second page
+  __attribute__((aligned(8))) u32 scratch[40];
+  u32 count;
+  __attribute__((aligned(16))) unsigned char stage[PG_BYTES];
+};
+
+// the page whose first slot the caller's run holds: allocate and publish
+__device__ __forceinline__ u32 page_alloc(const PagedStream& P, u32* __restrict__ row, u32 j, u32* __restrict__ st) {
+  if (j >= P.jmax) {
+    atomicOr(st, ST_PT_FULL);
+    return 0;
+  }
+  u32 pid = atomicAdd(P.pagesUsed, 1u) + 1u + P.nLists;
+  if (pid >= P.poolPages) {
+    atomicOr(st, ST_PT_FULL);
+    pid = 0;
+  }
+  __hip_atomic_store(&row[j], pid + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return pid;
+}
+
+// a page somebody else allocates: poll its table entry
+__device__ __forceinline__ u32 page_wait(const PagedStream& P, u32* __restrict__ row, u32 j, u32* __restrict__ st) {
+  if (j >= P.jmax) return 0;  // (its allocator has raised ST_PT_FULL)
+  u32 spins = 0;
+  for (;;) {
+    const u32 v = __hip_atomic_load(&row[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v) return v - 1u;
+    __builtin_amdgcn_s_sleep(1);
+    // (every allocator publishes, also after an overflow: only a lost allocator could keep this waiting)
+    if (++spins > LB_SPIN_LIMIT ||
+        ((spins & 1023u) == 0 && (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_LOOKBACK))) {
+      atomicOr(st, ST_LOOKBACK);
+      return 0;
+    }
+  }
+}
+
+// Scatter NR records per thread (NULL tile = none) of the whole workgroup into their bins' page lists.
+template <typename R, int NR>
+__device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStream& P, int sbShift, u32 nBins, S1Lds& L,
+                                              u32* __restrict__ st) {
+  constexpr int SHIFT = PgCfg<R>::SHIFT;
+  constexpr u32 PG = 1u << SHIFT;
+  static_assert((size_t)NR * S1_NT * sizeof(R) <= PG_BYTES && (u32)NR * S1_NT <= PG, "one page holds a workgroup's records");
+  const u32 x = blockIdx.x % NXCD;
+  R* stage = reinterpret_cast<R*>(L.stage);
+  for (int i = threadIdx.x; i < (int)nBins; i += S1_NT) L.hist[i] = 0;
+  __syncthreads();
+  u32 rk[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const u32 t = RecT<R>::tile(rec[k]);
+    rk[k] = t != NULL_TILE ? atomicAdd(&L.hist[t >> sbShift], 1u) : 0u;
+  }
+  __syncthreads();
+  {
+    // thread t owns bins t, t + NT, t + 2 NT ...
+    u32 cq[S1_BPT], liq[S1_BPT], oq[S1_BPT], j0q[S1_BPT], in0q[S1_BPT], split[S1_BPT], base[S1_BPT][2];
+    u32* rowq[S1_BPT];
+    bool need[S1_BPT];
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) {
+      const u32 b = threadIdx.x + q * S1_NT;
+      cq[q] = b < nBins ? L.hist[b] : 0u;
+      liq[q] = x * nBins + b;
+      oq[q] = 0; j0q[q] = 0; in0q[q] = 0; split[q] = 0; base[q][0] = 0; base[q][1] = 0; rowq[q] = nullptr; need[q] = false;
+    }
+    // (all reservations in flight together)
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++)
+      if (cq[q]) oq[q] = atomicAdd(&P.cursor[liq[q]], cq[q]);
+    // Two passes, in this order for every lane of the wavefront: first everything this thread has to
+    // PUBLISH (the pages whose first slot its reservations hold), then the waiting for pages that others
+    // publish.  As one if / else the compiler may run the waiting lanes of a wavefront before its allocating
+    // lanes, and two wavefronts then wait for each other's allocators (seen on MI355X: spin limit).
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) {
+      const u32 c = cq[q];
+      if (c) {
+        const u32 li = liq[q], o = oq[q];
+        u32* row = P.pt + (size_t)li * P.jmax;
+        const u32 j0 = o >> SHIFT, j1 = (o + c - 1) >> SHIFT, in0 = o & (PG - 1);
+        rowq[q] = row;
+        j0q[q] = j0;
+        in0q[q] = in0;
+        split[q] = min(c, PG - in0);
+        if (j1 != j0) base[q][1] = page_alloc(P, row, j1, st) << SHIFT;
+        if (j0 == 0) {  // the list's fixed first page: nothing to look up
+          base[q][0] = (first_page(li) << SHIFT) + in0;
+          if (j1 == j0) base[q][1] = first_page(li) << SHIFT;
+        } else if (in0 == 0) {
+          const u32 p0 = page_alloc(P, row, j0, st);
+          base[q][0] = p0 << SHIFT;
+          if (j1 == j0) base[q][1] = p0 << SHIFT;
+        } else
+          need[q] = true;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++)
+      if (need[q]) {
+        const u32 p0 = page_wait(P, rowq[q], j0q[q], st);
+        base[q][0] = (p0 << SHIFT) + in0q[q];
+      }
+    // one block scan for all of a thread's counts (each total <= 8192 < 2^16): 16-bit fields of one word
+    u64 packed = 0;
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) packed |= (u64)cq[q] << (16 * q);
+    u64 tot;
+    const u64 ex = block_excl_scan<u64, S1_NT>(packed, reinterpret_cast<u64*>(L.scratch), &tot);
+    u32 before = 0;  // records of the lower bin groups
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) {
+      const u32 b = threadIdx.x + q * S1_NT;
+      if (b < nBins) {
+        L.startSplit[b] = (before + (u32)((ex >> (16 * q)) & 0xFFFFu)) | (split[q] << 16);
+        L.base0[b] = base[q][0];
+        L.base1[b] = base[q][1];
+      }
+      before += (u32)((tot >> (16 * q)) & 0xFFFFu);
+    }
+    if (threadIdx.x == 0) L.count = before;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const u32 t = RecT<R>::tile(rec[k]);
+    if (t != NULL_TILE) stage[(L.startSplit[t >> sbShift] & 0xFFFFu) + rk[k]] = rec[k];
+  }
+  __syncthreads();
+  const u32 cnt = L.count;
+  R* pool = reinterpret_cast<R*>(P.pool);
+  for (u32 i = threadIdx.x; i < cnt; i += S1_NT) {
+    const R v = stage[i];
+    const u32 b = RecT<R>::tile(v) >> sbShift;
+    const u32 ss = L.startSplit[b];
+    const u32 r = i - (ss & 0xFFFFu), sp = ss >> 16;
+    pool[r < sp ? L.base0[b] + r : L.base1[b] + (r - sp)] = v;
+  }
+  __syncthreads();
+}
+
+// UNIT32: tile id + offset fit a 4-byte key, so unit-weight events (the common case) go to the S / E streams as
+// bare keys and only multimapped ones (weight 1/k) to F.  Otherwise (a genome beyond 4.29 Gbp) everything is an F record.
+template <bool UNIT32>
+__global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev, u32 n, const DChrom* __restrict__ chroms,
+                                                 u32 nChrom, int sbShift, u32 nBins, PagedStream PS, PagedStream PE,
+                                                 PagedStream PF, Sort1Out out, u32* __restrict__ st) {
+  __shared__ S1Lds L;
+  const u32 begin = blockIdx.x * S1_CHUNK;
+  u32 bad = 0, frac = 0;
+  u64 covered = 0;
+  u32 ks[S1_ITEMS], ke[S1_ITEMS];
+#pragma unroll
+  for (int k = 0; k < S1_ITEMS; k++) {
+    const u32 i = begin + k * S1_NT + threadIdx.x;
+    ks[k] = NULL32;
+    ke[k] = NULL32;
+    if (i < n) {
+      const uint4 e = reinterpret_cast<const uint4*>(ev)[i];  // chrom, start, end, count
+      const Endpoints p = convert_event<true>(e, chroms, nChrom, out, bad, covered);
+      if (p.w) {
+        if (UNIT32 && p.w == GX_UNIT) {
+          ks[k] = (p.t0 << TB) | p.o0;
+          if (p.t1 != NULL_TILE) ke[k] = (p.t1 << TB) | p.o1;
+        } else
+          frac = 1;
+      }
+    }
+  }
+  if (UNIT32) {
+    scatter_paged<u32, S1_ITEMS>(ks, PS, sbShift, nBins, L, st);
+    scatter_paged<u32, S1_ITEMS>(ke, PE, sbShift, nBins, L, st);
+  }
+  // fractional (or wide) records: rare, so the events are converted again (they are in L2) instead of being
+  // kept in registers; two events = up to four records per thread and round
+  if (__syncthreads_or((int)frac)) {
+    constexpr int EPR = S1_ITEMS / 4;  // events per thread and round: a round's records (two per event) fill one page at most
+    for (int k0 = 0; k0 < S1_ITEMS; k0 += EPR) {
+      u64 fr[2 * EPR];
+#pragma unroll
+      for (int q = 0; q < EPR; q++) {
+        const u32 i = begin + (k0 + q) * S1_NT + threadIdx.x;
+        fr[2 * q] = (u64)NULL_TILE << 32;
+        fr[2 * q + 1] = (u64)NULL_TILE << 32;
+        if (i < n) {
+          const uint4 e = reinterpret_cast<const uint4*>(ev)[i];
+          u32 bad2 = 0;
+          u64 cov2 = 0;
+          const Endpoints p = convert_event<false>(e, chroms, nChrom, out, bad2, cov2);
+          if (p.w && !(UNIT32 && p.w == GX_UNIT)) {
+            fr[2 * q] = make_rec64(p.t0, p.o0, p.w);
+            if (p.t1 != NULL_TILE) fr[2 * q + 1] = make_rec64(p.t1, p.o1, -p.w);
+          }
+        }
+      }
+      scatter_paged<u64, 2 * S1_ITEMS / 4>(fr, PF, sbShift, nBins, L, st);
+    }
+  }
+  if (bad) atomicOr(st, bad);
+  if (frac) atomicOr(out.slowFrag, 1u);
+  covered = wave_sum(covered);
+  if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 16 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
+}
+
+// bin totals (over the XCD classes) -> where each super-bucket's records start after level 2; one workgroup per stream
+struct BinScan { const u32* cursor[3]; u32* sbOff[3]; };
+
+__global__ __launch_bounds__(1024) void k_scan_bins(BinScan B, u32 nBins) {
+  __shared__ u32 scratch[20];
+  const u32* cursor = B.cursor[blockIdx.x];
+  u32* sbOff = B.sbOff[blockIdx.x];
+  constexpr int PER = MAX_BINS / 1024;
+  u32 v[PER], sum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const u32 i = threadIdx.x * PER + k;
+    v[k] = 0;
+    if (i < nBins)
+      for (int x = 0; x < NXCD; x++) v[k] += cursor[x * nBins + i];
+    sum += v[k];
+  }
+  u32 tot;
+  u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const u32 i = threadIdx.x * PER + k;
+    if (i < nBins) sbOff[i] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0) sbOff[nBins] = tot;
+}
+
+// ---- level 2 on paged input: one workgroup per super-bucket ---------------------------------------------------
+// As k_bucket2 (gx_kernels.h): per-tile histogram, scan and cursors in LDS, a super-bucket that fits is read
+// once into registers and written back as one contiguous stream of 16-bit tile offsets (or whole F records);
+// a larger one takes the chunked two-pass path.  The difference is where a record comes from: logical index L
+// of the bin = the concatenation of its eight (XCD class) lists, each a chain of pages.
+template <typename R>
+struct BinSrc {
+  const R* pool;
+  const u32* pt;   // rows of this bin: pt + (x * nBins + bin) * jmax
+  u32 nBins, jmax, bin;
+  const u32* pre;  // LDS: pre[x] = records in the lists before list x; pre[NXCD] = total
+  __device__ __forceinline__ R at(u32 Lx) const {
+    u32 x = 0;
+#pragma unroll
+    for (int q = 1; q < NXCD; q++) x += (u32)(Lx >= pre[q]);
+    const u32 off = Lx - pre[x];
+    const u32 j = off >> PgCfg<R>::SHIFT, li = x * nBins + bin;
+    const u32 page = j ? pt[(size_t)li * jmax + j] - 1u : first_page(li);
+    return pool[((size_t)page << PgCfg<R>::SHIFT) + (off & ((1u << PgCfg<R>::SHIFT) - 1u))];
+  }
+};
+
+template <typename R>
+__global__ __launch_bounds__(B2_NT) void k_bucket2p(PagedStream P, typename B2Out<R>::type* __restrict__ out,
+                                                    const u32* __restrict__ segOff, u32 nSeg, int sbShift, u32 nTiles,
+                                                    u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
+  typedef typename B2Out<R>::type O;
+  constexpr int ITEMS = ScCfg<R>::ITEMS;
+  constexpr int CHUNK = B2_NT * ITEMS;
+  constexpr int FITEMS = B2Cfg<R>::FITEMS;
+  constexpr u32 FCAP = (u32)FITEMS * B2_NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
+  __shared__ u32 pre[NXCD + 1];
+  __shared__ u64 slotPtr[B2Cfg<R>::FITEMS];
+  __shared__ u32 slotCnt[B2Cfg<R>::FITEMS];
+  const u32 nBins = 1u << sbShift;   // tiles per super-bucket
+  constexpr u32 stageBytes = b2_stage_bytes<R>();
+  R* stage = reinterpret_cast<R*>(b2_lds);
+  O* stageO = reinterpret_cast<O*>(b2_lds);
+  u32* hist = reinterpret_cast<u32*>(b2_lds + stageBytes);
+  u32* start = hist + nBins;
+  u32* cursor = start + nBins;
+  u32* base = cursor + nBins;
+  u32* scratch = base + nBins;
+  auto outOf = [](R r) -> O {
+    if constexpr (sizeof(R) == 4) return (O)((u32)r & (TILE - 1)); else return r;
+  };
+  for (u32 seg = blockIdx.x; seg < nSeg; seg += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      u32 a = 0;
+      for (int x = 0; x < NXCD; x++) {
+        pre[x] = a;
+        a += P.cursor[x * nSeg + seg];
+      }
+      pre[NXCD] = a;
+    }
+    __syncthreads();
+    const u32 total = pre[NXCD], obase = segOff[seg], segTileBase = seg << sbShift;
+    if (total == 0) {  // (tile counts stay zero: the per-sample arena)
+      continue;
+    }
+    const BinSrc<R> src{reinterpret_cast<const R*>(P.pool), P.pt, nSeg, P.jmax, seg, pre};
+    // One-pass path: the bin is cut into SLOTS of B2_NT consecutive records of one list (a page is a whole
+    // number of slots, so a slot never crosses a page): slot k is read by the whole workgroup, thread i its
+    // i-th record, and everything about where the slot lies is the same for all threads -- one descriptor per
+    // slot in LDS instead of a page-table walk per record.
+    u32 nSlots = 0;
+#pragma unroll
+    for (int x = 0; x < NXCD; x++) nSlots += (pre[x + 1] - pre[x] + B2_NT - 1) / B2_NT;
+    if (nSlots <= (u32)FITEMS) {
+      for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; base[i] = 0; }
+      if (threadIdx.x < FITEMS) {
+        const u32 k = threadIdx.x;
+        u32 x = 0, k0 = 0;
+        for (; x < NXCD; x++) {
+          const u32 ns = (pre[x + 1] - pre[x] + B2_NT - 1) / B2_NT;
+          if (k < k0 + ns) break;
+          k0 += ns;
+        }
+        u64 ptr = 0;
+        u32 cnt = 0;
+        if (x < NXCD) {
+          const u32 off = (k - k0) * B2_NT;
+          const u32 jp = off >> PgCfg<R>::SHIFT, li = x * nSeg + seg;
+          const u32 page = jp ? P.pt[(size_t)li * P.jmax + jp] - 1u : first_page(li);
+          ptr = (u64)(reinterpret_cast<const R*>(P.pool) + ((size_t)page << PgCfg<R>::SHIFT) + (off & ((1u << PgCfg<R>::SHIFT) - 1u)));
+          cnt = min((u32)B2_NT, pre[x + 1] - pre[x] - off);
+        }
+        slotPtr[k] = ptr;
+        slotCnt[k] = cnt;
+      }
+      __syncthreads();
+      R r[FITEMS];
+      static_assert(FITEMS % 8 == 0, "batches of eight");
+#pragma unroll
+      for (int k0 = 0; k0 < FITEMS; k0 += 8) {
+#pragma unroll
+        for (int k = k0; k < k0 + 8; k++)
+          if (threadIdx.x < slotCnt[k]) r[k] = reinterpret_cast<const R*>(slotPtr[k])[threadIdx.x];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < FITEMS; k++) {
+        if (threadIdx.x < slotCnt[k]) {
+          const u32 b = RecT<R>::tile(r[k]) - segTileBase;
+          atomicAdd(&hist[b], 1u);
+          if (sizeof(R) == 8) atomicAdd(&base[b], (u32)(int)(int8_t)((u64)r[k] & 0xFF));
+        }
+      }
+      __syncthreads();
+      u32 carry = 0;
+      for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
+        const u32 b = b0 + threadIdx.x;
+        const u32 c = b < nBins ? hist[b] : 0;
+        u32 tot;
+        const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
+        if (b < nBins) {
+          cursor[b] = carry + ex;
+          if (segTileBase + b < nTiles) {
+            tileCnt[segTileBase + b] = c;
+            if (sizeof(R) == 8) tileWsum[segTileBase + b] += (int)base[b];
+          }
+        }
+        carry += tot;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < FITEMS; k++)
+        if (threadIdx.x < slotCnt[k]) stageO[atomicAdd(&cursor[RecT<R>::tile(r[k]) - segTileBase], 1u)] = outOf(r[k]);
+      __syncthreads();
+      for (u32 i = threadIdx.x; i < total; i += B2_NT) out[obase + i] = stageO[i];
+    } else {
+      // chunked two-pass path for a super-bucket that does not fit (a pile-up of records in one place)
+      for (int i = threadIdx.x; i < (int)nBins; i += B2_NT) { hist[i] = 0; start[i] = 0; }
+      __syncthreads();
+      for (u32 i0 = 0; i0 < total; i0 += CHUNK) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+          const u32 idx = i0 + k * B2_NT + threadIdx.x;
+          if (idx < total) {
+            const R rr = src.at(idx);
+            const u32 b = RecT<R>::tile(rr) - segTileBase;
+            atomicAdd(&hist[b], 1u);
+            if (sizeof(R) == 8) atomicAdd(&start[b], (u32)(int)(int8_t)((u64)rr & 0xFF));
+          }
+        }
+      }
+      __syncthreads();
+      u32 carry = obase;
+      for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
+        const u32 b = b0 + threadIdx.x;
+        const u32 c = b < nBins ? hist[b] : 0;
+        u32 tot;
+        const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
+        if (b < nBins) {
+          cursor[b] = carry + ex;
+          hist[b] = 0;
+          if (segTileBase + b < nTiles) {
+            tileCnt[segTileBase + b] = c;
+            if (sizeof(R) == 8) tileWsum[segTileBase + b] += (int)start[b];
+          }
+        }
+        carry += tot;
+      }
+      __syncthreads();
+      for (u32 i0 = 0; i0 < total; i0 += CHUNK) {
+        const u32 cEnd = min(total, i0 + CHUNK);
+        R r[ITEMS];
+        u32 rk[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+          const u32 idx = i0 + k * B2_NT + threadIdx.x;
+          if (idx < cEnd) r[k] = src.at(idx);
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+          const u32 idx = i0 + k * B2_NT + threadIdx.x;
+          if (idx < cEnd) rk[k] = atomicAdd(&hist[RecT<R>::tile(r[k]) - segTileBase], 1u);
+        }
+        __syncthreads();
+        u32 lc = 0;
+        for (u32 b0 = 0; b0 < nBins; b0 += B2_NT) {
+          const u32 b = b0 + threadIdx.x;
+          const u32 c = b < nBins ? hist[b] : 0;
+          u32 tot;
+          const u32 ex = block_excl_scan<u32, B2_NT>(c, scratch, &tot);
+          if (b < nBins) {
+            start[b] = lc + ex;
+            base[b] = cursor[b];
+            cursor[b] += c;
+            hist[b] = 0;
+          }
+          lc += tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+          const u32 idx = i0 + k * B2_NT + threadIdx.x;
+          if (idx < cEnd) stage[start[RecT<R>::tile(r[k]) - segTileBase] + rk[k]] = r[k];
+        }
+        __syncthreads();
+        const u32 cnt = cEnd - i0;
+        for (u32 i = threadIdx.x; i < cnt; i += B2_NT) {
+          const R v = stage[i];
+          const u32 b = RecT<R>::tile(v) - segTileBase;
+          out[base[b] + (i - start[b])] = outOf(v);
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+}  // namespace gx

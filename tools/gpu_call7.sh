@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+GX_DEBUG_SORT=1 timeout -s KILL 300 python tools/diag_sort.py > gpurun_out/c7_diag.log 2>&1
+cat gpurun_out/c7_diag.log | tail -40

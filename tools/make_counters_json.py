@@ -28,11 +28,16 @@ def tables(c):
 
 
 def short(name):
+    """k_xyz of a mangled gx:: kernel name (template instances share it); anything else as it is."""
+    import re
     name = name.split("(")[0].replace("void ", "")
-    for k in ("k_tile", "k_pack_pval", "k_scatter1", "k_convert", "k_bucket2", "k_peak_short", "k_merge2", "k_pack_pairs_full",
-              "k_pack_pairs", "k_pack", "k_mergeN", "k_bh_hist", "k_qlookup", "k_sort_fused", "k_pval_loose"):
-        if k in name:
-            return k
+    m = re.match(r"_ZN2gx(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        return name[m.end():m.end() + n]
+    m = re.match(r"gx::(k_[A-Za-z0-9_]+)", name)
+    if m:
+        return m.group(1)
     return name[:60]
 
 
@@ -114,12 +119,12 @@ def main():
     out["whole_step"]["write_kb_raw"] = write_tot / steps
     out["whole_step"]["hbm_bytes_per_step"] = (2 * fetch_tot + write_tot) * 1024 / steps
     # issue model of the dominant kernel from the SQ counters (quad-cycle units, MI355X_MICROARCH.md)
-    kt = out["kernels"].get("k_tile", {})
+    kt = out["kernels"].get("k_tile_fast", out["kernels"].get("k_tile", {}))
     sq = kt.get("sq", {})
     if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_BUSY_CYCLES"):
         wc = sq["SQ_WAVE_CYCLES"]
         out["issue"] = {
-            "kernel": "k_tile",
+            "kernel": "k_tile_fast" if "k_tile_fast" in out["kernels"] else "k_tile",
             "valu_insts_per_wave": sq.get("SQ_INSTS_VALU", 0) / max(1.0, sq.get("SQ_WAVES", 1)),
             "lds_insts_per_wave": sq.get("SQ_INSTS_LDS", 0) / max(1.0, sq.get("SQ_WAVES", 1)),
             "active_valu_frac_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU", 0) / wc,
