@@ -52,6 +52,9 @@ struct DevBuf {
     if (bytes <= cap) return hipSuccess;
     release();
     size_t want = bytes + bytes / 8 + 256;
+    static const size_t pad = getenv("GX_ALLOC_PAD") ? (size_t)atoll(getenv("GX_ALLOC_PAD")) : 0;  // (placement experiments)
+    static unsigned seq = 0;
+    if (pad) want += pad * (1 + seq++ % 7);
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;
@@ -73,6 +76,7 @@ struct HostMail {
 
 struct PinnedBuf {
   void* p = nullptr;
+  void* dp = nullptr;  // the same memory as the device sees it (kernels write results straight into it)
   size_t cap = 0;
   PinnedBuf() = default;
   PinnedBuf(const PinnedBuf&) = delete;
@@ -84,8 +88,11 @@ struct PinnedBuf {
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 4 + 4096;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e == hipSuccess) cap = want;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
+    if (e == hipSuccess) {
+      cap = want;
+      e = hipHostGetDevicePointer(&dp, p, 0);
+    }
     return e;
   }
 };
@@ -99,6 +106,9 @@ struct Pileup {  // run-length pileup of one sample (treatment or control)
 struct PArray {  // p-value intervals of one replicate (or the Fisher combination)
   DevBuf end, p, expt, ctrl, chromOff, tileOff, q, dPresent;
   u32 n = 0;
+  bool loose = false;     // no control: the intervals still sit in the tile kernel's loose slots (ctx->looseEnd / looseV);
+                          // the tight table is made when somebody asks for it (materialize_rep)
+  bool pilesPending = false;  // no control: the pileup floats are wanted but not made yet (ensure_piles)
   bool hasPiles = false;  // expt/ctrl filled (single-replicate logging)
   bool pilesDropped = false;  // ... deliberately not (gx_set_keep_pileups(0))
   float ctrlConst = 0.0f; // control value when ctrl is not materialised (no -E, no control file)
@@ -284,10 +294,16 @@ int read_status(gx_ctx* ctx) {
 }
 
 // ---- risky p-values (gx_math.h round_checked; gx_kernels.h RiskBuf) --------------------------------
-// risk_queue: ahead of a synchronisation the host needs anyway, ask for the list's count and first records.
+// mail_sync: at a synchronisation the host needs anyway, the list's count and first records come along.
 // risk_apply: after it, evaluate the listed values with the host's libm and send them back (k_risk_apply).
-int risk_queue(gx_ctx* ctx) {
-  HIPCHECK(hipMemcpyAsync(ctx->riskHost.p, ctx->dRisk.p, 32 + RISK_PREFIX * sizeof(RiskRec), hipMemcpyDeviceToHost, ctx->stream));
+// One small kernel writes everything the host wants to know into pinned memory (scalars, status, flags, the
+// risky list's count and first records), then the stream is synchronised.  Null pointers: not wanted.
+int mail_sync(gx_ctx* ctx, const Scalars* ds, const u32* hot, const u32* nIv, const long long* coll, const u32* extra) {
+  HostMail* dm = static_cast<HostMail*>(ctx->mailBuf.dp);
+  MailOut mo{&dm->scal, &dm->status, &dm->hot, &dm->nIv, &dm->coll[2], &dm->nMerged, static_cast<RiskBuf*>(ctx->riskHost.dp)};
+  hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, ds, ctx->dStatus.as<u32>(), hot, nIv, coll, extra,
+                     ctx->dRisk.as<RiskBuf>(), mo);
+  HIPCHECK(hipStreamSynchronize(ctx->stream));
   return GX_OK;
 }
 
@@ -327,7 +343,7 @@ int risk_apply(gx_ctx* ctx, RiskTargets T, RiskHostIn in = RiskHostIn{nullptr, n
     HIPCHECK(hipStreamSynchronize(s));
   }
   for (u32 i = 0; i < n; i++) hb->rec[i].pnew = risk_host_value(ctx, hb->rec[i], in);
-  // (the pinned records stay untouched until the next risk_queue, which follows a synchronisation)
+  // (the pinned records stay untouched until the next mail_sync)
   HIPCHECK(hipMemcpyAsync(ctx->dRisk.as<RiskBuf>()->rec, hb->rec, (size_t)n * sizeof(RiskRec), hipMemcpyHostToDevice, s));
   T.lutP = ctx->pvLut.as<float>();
   T.p2d = ctx->pairP2d.as<float>();
@@ -573,7 +589,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // (word 1 of the nWide block: the "a base can reach the int16 limits" flag, also set by k_convert)
   hipLaunchKernelGGL(k_hot_check, dim3(std::min<u32>(nTiles, 256u)), dim3(256), 0, s, tin, wl, nw, ctx->nWide.as<u32>() + 1);
   if (int rc__ = dbg_sync(ctx, "k_hot_check")) return rc__;
-  HIPCHECK(hipMemcpyAsync(&ctx->mail->hot, ctx->nWide.as<u32>() + 1, 4, hipMemcpyDeviceToHost, s));
 
   phase_begin(ctx, isCtrl ? "c.pack" : "t.pack");
   const u32 ivChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
@@ -583,26 +598,22 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
                      ctx->dChrom.as<DChrom>(), nTiles, ctx->lbIv.as<u64>(), ctx->lbIv.as<u64>() + ivChunks + 1, so,
                      ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_scan_iv")) return rc__;
-  hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
-                     ctx->misc.as<u32>() + M_NIV);
-  if (int rc__ = dbg_sync(ctx, "k_fix_chrom_off")) return rc__;
   {
     const u32* lE = ctx->looseEnd.as<u32>();
     const int* lV = ctx->looseV.as<int>();
     const TileMeta* tm = ctx->tileMeta.as<TileMeta>();
     const u32* tOff = out.tileIvOff.as<u32>();
     const u32* tPrev = ctx->tilePrevEnd.as<u32>();
-    hipLaunchKernelGGL(k_deep_list, dim3((nTiles + 255) / 256), dim3(256), 0, s, ctx->tileDeep.as<u32>(), tOff, nTiles, ff,
-                       ctx->fragList.as<u32>());
     hipLaunchKernelGGL(k_frag_fix1, dim3((nTiles + 255) / 256), dim3(256), 0, s, lE, lV, tm, tOff, tPrev,
-                       ctx->tileDeep.as<u32>(), nTiles, ff);
-    hipLaunchKernelGGL(k_frag_fix2, dim3(std::max(1u, std::min((nTiles + 3) / 4, 1024u))), dim3(256), 0, s, lE, lV, tm, tOff,
-                       tPrev, ff, ctx->fragList.as<u32>());
-    hipLaunchKernelGGL(k_frag, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, lE, lV, tm, tOff, tPrev,
-                       nTiles, ff, acc);
+                       ctx->tileDeep.as<u32>(), nTiles, ff, ctx->fragList.as<u32>());
+    hipLaunchKernelGGL(k_frag_walk, dim3(std::max(1u, std::min((nTiles + 3) / 4, 4096u))), dim3(256), 0, s, lE, lV, tm, tOff,
+                       tPrev, nTiles, ff, ctx->fragList.as<u32>(), acc);
+    // (single thread: chromosome offsets of the chromosomes without tiles, closed form -> accumulator pair,
+    // this rank's words of the all-reduce)
     hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ff, acc,
                        ctx->world > 1 || ctx->forceColl ? ctx->dColl.as<long long>() : (long long*)nullptr,
-                       ctx->nWide.as<u32>() + 1, ctx->dStatus.as<u32>());
+                       ctx->nWide.as<u32>() + 1, ctx->dStatus.as<u32>(), ctx->dChrom.as<DChrom>(), nChrom,
+                       out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV);
   }
   if (int rc__ = dbg_sync(ctx, "k_frag")) return rc__;
   out.packed = false;
@@ -612,7 +623,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   phase_end(ctx);
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipMemcpyAsync(&ctx->mail->nIv, ctx->misc.as<u32>() + M_NIV, 4, hipMemcpyDeviceToHost, s));
   ctx->nIvTarget = &out.nIv;  // filled from the mail block once finish_scalars has synchronised
   return GX_OK;
 }
@@ -654,7 +664,6 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     ctx->err = "several ranks but no collectives (gx_set_rccl / gx_set_collectives)";
     return GX_ERR_ORDER;
   }
-  if (multi) HIPCHECK(hipMemcpyAsync(&ctx->mail->coll[2], dcoll + 2, 8, hipMemcpyDeviceToHost, s));
   hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>(), (const long long*)dcoll);
   if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
   // lambda (and with a control the factor) is final: build the p-value tables now, so that the values the
@@ -673,10 +682,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     ctx->pairTabsReady = true;
   }
   if (int rc__ = dbg_sync(ctx, "p-value tables")) return rc__;
-  HIPCHECK(hipMemcpyAsync(&ctx->mail->scal, ds, sizeof(Scalars), hipMemcpyDeviceToHost, s));
-  if (int rc__ = risk_queue(ctx)) return rc__;
-  HIPCHECK(hipMemcpyAsync(&ctx->mail->status, ctx->dStatus.p, sizeof(u32), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
+  if (int rc__ = mail_sync(ctx, ds, ctx->nWide.as<u32>() + 1, ctx->misc.as<u32>() + M_NIV, dcoll, nullptr)) return rc__;
   ctx->hScal = ctx->mail->scal;
   const int rcRisk = risk_apply(ctx, RiskTargets{});
   // (with several ranks: if any of them has to rebuild its sample, all go round again with it)
@@ -844,6 +850,188 @@ int layout_tiles(gx_ctx* ctx) {
   HIPCHECK(ctx->dTileChrom.ensure((size_t)t * 4));
   HIPCHECK(hipMemcpyAsync(ctx->dTileChrom.p, tileChrom.data(), (size_t)t * 4, hipMemcpyHostToDevice, ctx->stream));
   return upload_chroms(ctx);
+}
+
+// What the sweep walks: the interval arrays (end, p[, q]) of the final p-array.
+struct SweepSrc {
+  const u32* end = nullptr;
+  const float* p = nullptr;
+  const float* q = nullptr;
+  bool haveMasks = false, hasSkip = true;
+  const u32* chromOff = nullptr;
+  u32 nChrom = 0, nWords = 0;
+  size_t mStride = 0;   // words between the sig / skip / brk masks in swMask
+};
+
+// callPeaks (Genrich.c:977-1069) on bit masks: runs of adjacent significant intervals -> candidates -> in-order AUC.
+// Two synchronisations: the number of runs (the candidate arrays are sized by it), and the end; counts travel through
+// pinned memory written by the kernels themselves, and the peak list is written straight into pinned host memory.
+int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
+  hipStream_t s = ctx->stream;
+  u32* misc = ctx->misc.as<u32>();
+  HostMail* dm = static_cast<HostMail*>(ctx->mailBuf.dp);
+  const u32 nWords = S.nWords, nChrom = S.nChrom;
+  const u32 wChunks = (nWords + SW_CHUNK - 1) / SW_CHUNK;
+  SweepMasks SM{ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + S.mStride, ctx->swMask.as<u64>() + 2 * S.mStride, nWords};
+  u32 R = 0, nPeaks = 0;
+  ctx->peakBP = 0;
+  ctx->nHostPeaks = 0;
+  if (nWords) {
+    HIPCHECK(ctx->lb2.ensure(((size_t)wChunks * 4 + 64) * 4));
+    u32* cntS = ctx->lb2.as<u32>();
+    u32* offS = cntS + wChunks + 8;
+    u32* cntE = offS + wChunks + 8;
+    u32* offE = cntE + wChunks + 8;
+    hipLaunchKernelGGL(k_brk_mask, dim3((nChrom + 255) / 256), dim3(256), 0, s, S.chromOff, nChrom, SM.brk);
+    if (!S.haveMasks)
+      hipLaunchKernelGGL(k_sig_mask, dim3(std::max(1u, std::min((nWords + 15) / 16, 4096u))), dim3(256), 0, s, S.p, S.q,
+                         misc + M_NIV, ctx->par.thr, SM);
+    hipLaunchKernelGGL(k_runs_count, dim3(wChunks), dim3(SW_NT), 0, s, SM, cntS, cntE);
+    {
+      ScanJobs J{{{cntS, nullptr, wChunks, (u32)SW_CHUNK, offS, misc + M_SWCOUNT, &dm->R, misc + M_TICKET3},
+                  {cntE, nullptr, wChunks, (u32)SW_CHUNK, offE, misc + M_TICKET2, nullptr, nullptr}}};
+      hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, s, J);
+    }
+    HIPCHECK(hipStreamSynchronize(s));  // run / candidate arrays are sized exactly
+    R = ctx->mail->R;
+    if (R) {
+      HIPCHECK(ctx->swStart.ensure((size_t)R * 4 + 16));
+      HIPCHECK(ctx->swEnd.ensure((size_t)R * 4 + 16));
+      HIPCHECK(ctx->headPos.ensure((size_t)R * 4 + 16));
+      HIPCHECK(ctx->cand.ensure((size_t)R * sizeof(gx_peak)));
+      HIPCHECK(ctx->valid.ensure((size_t)R * 4 + 16));
+      HIPCHECK(ctx->hPeaks.ensure((size_t)R * sizeof(gx_peak) + 16));  // (at most one peak per run)
+      const u32 rChunks = (R + SW_CHUNK - 1) / SW_CHUNK;
+      HIPCHECK(ctx->swChrom.ensure(((size_t)rChunks * 4 + 64) * 4));
+      u32* cnt2 = ctx->swChrom.as<u32>();
+      u32* off2 = cnt2 + rChunks + 8;
+      u32* cnt3 = off2 + rChunks + 8;
+      u32* off3 = cnt3 + rChunks + 8;
+      u32* runStart = ctx->swStart.as<u32>();
+      u32* runEnd = ctx->swEnd.as<u32>();
+      const u64* skipM = S.hasSkip ? SM.skip : (const u64*)nullptr;
+      hipLaunchKernelGGL(k_runs_write, dim3(wChunks), dim3(SW_NT), 0, s, SM, offS, offE, runStart, runEnd);
+      hipLaunchKernelGGL(k_cands_count, dim3(rChunks), dim3(SW_NT), 0, s, SM, skipM, S.end, runStart, runEnd, misc + M_SWCOUNT,
+                         ctx->par.max_gap, S.chromOff, nChrom, cnt2);
+      {
+        ScanJobs J{{{cnt2, nullptr, rChunks, (u32)SW_CHUNK, off2, misc + M_NHEADS, nullptr, nullptr}, {}}};
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, J);
+      }
+      hipLaunchKernelGGL(k_cands_write, dim3(rChunks), dim3(SW_NT), 0, s, SM, skipM, S.end, runStart, runEnd, misc + M_SWCOUNT,
+                         ctx->par.max_gap, S.chromOff, nChrom, off2, ctx->headPos.as<u32>());
+      HIPCHECK(ctx->candHdr.ensure((size_t)R * sizeof(uint4)));
+      HIPCHECK(ctx->longList.ensure((size_t)R * 4 + 16));
+      hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((R + 255) / 256, 4096u))), dim3(256), 0, s, SM, S.end, runStart,
+                         runEnd, misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->candHdr.as<uint4>(),
+                         ctx->longList.as<u32>(), misc + M_TICKET3);
+      {
+        const dim3 grid(std::max(1u, std::min((R + 255) / 256, 8192u)));
+        const dim3 gridW(std::max(1u, std::min((R + 3) / 4, (u32)(2 * ctx->numCU))));
+#define GX_LAUNCH_PEAK_SHORT(Q)                                                                                          \
+  hipLaunchKernelGGL((k_peak_short<Q>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,     \
+                     misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),             \
+                     ctx->valid.as<u32>())
+        if (S.q) GX_LAUNCH_PEAK_SHORT(true); else GX_LAUNCH_PEAK_SHORT(false);
+#undef GX_LAUNCH_PEAK_SHORT
+        hipLaunchKernelGGL(k_peak_walk, gridW, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,
+                           ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
+                           ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
+      }
+      // candidates C <= R: chunk arrays sized by R's chunk count; kernels bound themselves by *nCands
+      hipLaunchKernelGGL(k_peaks_count, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
+      {
+        ScanJobs J{{{cnt3, misc + M_NHEADS, rChunks, (u32)SW_CHUNK, off3, misc + M_NPEAKS, &dm->nPeaks, nullptr}, {}}};
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, J);
+      }
+      hipLaunchKernelGGL(k_peaks_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
+                         misc + M_NHEADS, off3, static_cast<gx_peak*>(ctx->hPeaks.dp));
+      if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
+    }
+  }
+  // the end: status (and whatever else is pending) through the mail kernel, one synchronisation
+  if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
+  if (R) nPeaks = ctx->mail->nPeaks;
+  ctx->nHostPeaks = nPeaks;
+  const gx_peak* hp = static_cast<const gx_peak*>(ctx->hPeaks.p);
+  uint64_t bp = 0;
+  for (u32 i = 0; i < nPeaks; i++) bp += hp[i].end - hp[i].start;  // peakBP (callPeaks 925)
+  ctx->peakBP = bp;
+  *nPeaksOut = nPeaks;
+  return status_to_rc(ctx, ctx->mail->status);
+}
+
+// Loose slots -> the tight interval table (end, p[, pileups]) of a replicate without control: savePval
+// (Genrich.c:1720-1794) against the constant control lambda.  Needs the sample's loose slots, tile tables and
+// p(V) table, i.e. must run before the next sample is built (gx_sample_begin sees to that).
+int materialize_rep(gx_ctx* ctx, int idx) {
+  PArray& pa = ctx->reps[idx];
+  if (!pa.loose) return GX_OK;
+  hipStream_t s = ctx->stream;
+  const u32 n = pa.n;
+  HIPCHECK(pooled(ctx, pa.p, (size_t)n * 4 + 16));
+  phase_begin(ctx, "pval");
+  // (the table p(V) was built when the treatment sample was closed: finish_scalars)
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), pa.tileOff.as<u32>()};
+  // p-mode: the sweep's significance / skip masks are filled on the way (gx_find_peaks reuses them
+  // when this replicate turns out to be the only one)
+  u64 *sigM = nullptr, *skipM = nullptr;
+  ctx->maskIdx = -1;
+  if (!ctx->par.qval_opt) {
+    const u32 nWords = (n + 63) / 64;
+    HIPCHECK(ctx->swMask.ensure((size_t)(nWords + 2) * 8 * 3));
+    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, (size_t)(nWords + 2) * 8 * 3, s));
+    sigM = ctx->swMask.as<u64>();
+    skipM = sigM + (nWords + 2);
+    ctx->maskIdx = idx;
+    ctx->maskN = n;
+    ctx->maskStride = nWords + 2;
+  }
+  {
+    const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+    if (sigM)
+      hipLaunchKernelGGL((k_pack_pval<true>), grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
+                         ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(), pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                         ctx->dStatus.as<u32>());
+    else
+      hipLaunchKernelGGL((k_pack_pval<false>), grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
+                         ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(), pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                         ctx->dStatus.as<u32>());
+  }
+  hipLaunchKernelGGL(k_pval_deep, dim3(256), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(),
+                     ctx->dScal.as<Scalars>(), ctx->dDeep.as<DeepTab>(), pa.p.as<float>(), ctx->par.thr, sigM);
+  if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
+  phase_end(ctx);
+  HIPCHECK(hipGetLastError());
+  pa.end = std::move(ctx->expt.ivEnd);
+  pa.hasPiles = false;
+  pa.pilesPending = ctx->keepPiles;  // made when somebody asks (ensure_piles), from the exact pileups in the loose slots
+  pa.pilesDropped = !ctx->keepPiles;
+  pa.loose = false;
+  return GX_OK;
+}
+
+// The pileup floats of a no-control replicate (Pileup.cov of the reference: only -f / -k print them): made on
+// request from the exact pileups, while the sample's loose slots are still there.
+int ensure_piles(gx_ctx* ctx, int idx) {
+  PArray& pa = ctx->reps[idx];
+  if (pa.loose)
+    if (int rc = materialize_rep(ctx, idx)) return rc;
+  if (!pa.pilesPending) return GX_OK;
+  hipStream_t s = ctx->stream;
+  HIPCHECK(pooled(ctx, pa.expt, (size_t)pa.n * 4 + 16));
+  if (ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)pa.n * 4 + 16));
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), pa.tileOff.as<u32>()};
+  const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+  if (ctx->hasBed)
+    hipLaunchKernelGGL(k_piles_from_loose<true>, grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
+                       pa.expt.as<float>(), pa.ctrl.as<float>());
+  else
+    hipLaunchKernelGGL(k_piles_from_loose<false>, grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
+                       pa.expt.as<float>(), (float*)nullptr);
+  if (int rc__ = dbg_sync(ctx, "k_piles_from_loose")) return rc__;
+  pa.hasPiles = true;
+  pa.pilesPending = false;
+  return GX_OK;
 }
 
 }  // namespace
@@ -1062,6 +1250,10 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
   HIPCHECK(hipSetDevice(ctx->device));
   if (!is_ctrl) {
     if (ctx->phase != 0) return GX_ERR_ORDER;
+    // (a further replicate: the previous one's loose slots, tile tables and p(V) table are about to be reused)
+    for (size_t r = 0; r < ctx->reps.size(); r++)
+      if (ctx->reps[r].loose || ctx->reps[r].pilesPending)
+        if (int rc = ensure_piles(ctx, (int)r)) return rc;
     for (u32 i = 0; i < ctx->nChrom; i++) ctx->save[i] = save ? (save[i] != 0) : 1;
     int rc = upload_chroms(ctx);
     if (rc) return rc;
@@ -1154,57 +1346,18 @@ int gx_pvalues(gx_ctx* ctx) {
   pa.present.assign(ctx->nChrom, 0);
   for (u32 i = 0; i < ctx->nChrom; i++) pa.present[i] = !ctx->skip[i] && ctx->save[i];
   if (ctx->phase == 5) {
-    // no control: the p-intervals are the treatment intervals
-    const u32 n = ctx->expt.nIv;
-    pa.n = n;
-    const bool keep = ctx->keepPiles;
-    HIPCHECK(pooled(ctx, pa.p, (size_t)n * 4 + 16));
-    if (keep) HIPCHECK(pooled(ctx, pa.expt, (size_t)n * 4 + 16));
-    if (keep && ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)n * 4 + 16));
-    phase_begin(ctx, "pval");
-    // (the table p(V) was built when the treatment sample was closed: finish_scalars)
-    PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>()};
-    // p-mode: the sweep's significance / skip masks are filled on the way (gx_find_peaks reuses them
-    // when this replicate turns out to be the only one)
-    u64 *sigM = nullptr, *skipM = nullptr;
-    ctx->maskIdx = -1;
-    if (!ctx->par.qval_opt) {
-      const u32 nWords = (n + 63) / 64;
-      HIPCHECK(ctx->swMask.ensure((size_t)(nWords + 2) * 8 * 3));
-      HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, (size_t)(nWords + 2) * 8 * 3, s));
-      sigM = ctx->swMask.as<u64>();
-      skipM = sigM + (nWords + 2);
-      ctx->maskIdx = (int)ctx->reps.size();
-      ctx->maskN = n;
-      ctx->maskStride = nWords + 2;
-    }
-    {
-      const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
-      const bool ctl = keep && ctx->hasBed, msk = sigM != nullptr;
-#define GX_LAUNCH_PACK_PVAL(K, C, M)                                                                                    \
-  hipLaunchKernelGGL((k_pack_pval<K, C, M>), grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),          \
-                     ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(), pa.p.as<float>(), pa.expt.as<float>(),           \
-                     pa.ctrl.as<float>(), ctx->par.thr, sigM, skipM, ctx->dStatus.as<u32>())
-      if (keep) {
-        if (ctl) { if (msk) GX_LAUNCH_PACK_PVAL(true, true, true); else GX_LAUNCH_PACK_PVAL(true, true, false); }
-        else { if (msk) GX_LAUNCH_PACK_PVAL(true, false, true); else GX_LAUNCH_PACK_PVAL(true, false, false); }
-      } else {
-        if (msk) GX_LAUNCH_PACK_PVAL(false, false, true); else GX_LAUNCH_PACK_PVAL(false, false, false);
-      }
-#undef GX_LAUNCH_PACK_PVAL
-    }
-    hipLaunchKernelGGL(k_pval_deep, dim3(256), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(),
-                       ctx->dScal.as<Scalars>(), ctx->dDeep.as<DeepTab>(), pa.p.as<float>(), ctx->par.thr, sigM);
-    if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
-    phase_end(ctx);
-    HIPCHECK(hipGetLastError());
-    pa.end = std::move(ctx->expt.ivEnd);
+    // no control: the p-intervals are the treatment intervals, and they stay where the tile kernel left them
+    // (loose slots) until somebody needs the tight table: gx_find_peaks on a single sample with -p does not
+    pa.n = ctx->expt.nIv;
     pa.chromOff = std::move(ctx->expt.chromIvOff);
     pa.tileOff = std::move(ctx->expt.tileIvOff);
-    pa.hasPiles = keep;
-    pa.pilesDropped = !keep;
     pa.ctrlIsConst = !ctx->hasBed;
     pa.ctrlConst = ctx->hScal.lambda;
+    pa.loose = true;
+    ctx->reps.push_back(std::move(pa));
+    ctx->sample++;
+    ctx->phase = 0;
+    return GX_OK;
   } else {
     // treatment + control: tile-local union of breakpoints (savePval 1768-1791)
     const u32 nTiles = ctx->nTiles, nChrom = ctx->nChrom;
@@ -1281,9 +1434,8 @@ int gx_pvalues(gx_ctx* ctx) {
     if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(&ctx->mail->nMerged, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
-    if (int rc__ = risk_queue(ctx)) return rc__;
-    int rc = read_status(ctx);
+    if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_NMERGED)) return rc__;
+    int rc = status_to_rc(ctx, ctx->mail->status);
     {
       RiskTargets T{};
       T.pairP = pa.p.as<float>();
@@ -1310,6 +1462,14 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   HIPCHECK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   u32* misc = ctx->misc.as<u32>();
+  for (size_t r = 0; r < ctx->reps.size(); r++) {
+    if (ctx->reps[r].loose)
+      if (int rc = materialize_rep(ctx, (int)r)) return rc;
+    // (the Fisher combination of several replicates reuses the loose slots: the last replicate's pileup
+    // floats, if wanted, have to be made before)
+    if (ctx->sample > 1 && ctx->reps[r].pilesPending)
+      if (int rc = ensure_piles(ctx, (int)r)) return rc;
+  }
   if (ctx->sample > 1 && (int)ctx->reps.size() == ctx->sample) {
     // combinePval (612-667): union of all replicates' breakpoints, Fisher's method per interval
     const int nr = ctx->sample;
@@ -1361,9 +1521,8 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     if (int rc__ = dbg_sync(ctx, "k_pack_ep")) return rc__;
     phase_end(ctx);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(&ctx->mail->nMerged, misc + M_NMERGED, 4, hipMemcpyDeviceToHost, s));
-    if (int rc__ = risk_queue(ctx)) return rc__;
-    int rc = read_status(ctx);
+    if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_NMERGED)) return rc__;
+    int rc = status_to_rc(ctx, ctx->mail->status);
     {
       RiskTargets T{};
       T.fisherP = comb.p.as<float>();
@@ -1514,111 +1673,28 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
 
   // peak sweep
   phase_begin(ctx, "sweep");
-  const u32 nWords = (n + 63) / 64;
-  const u32 wChunks = (nWords + SW_CHUNK - 1) / SW_CHUNK;
-  // three bit masks + chunk count/offset scratch
-  // the masks were filled by the pack kernels (p mode, one replicate) or by k_qlookup (q mode)
-  const bool haveMasks = ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;
-  const size_t mStride = haveMasks ? ctx->maskStride : (size_t)nWords + 2;
-  HIPCHECK(ctx->swMask.ensure(mStride * 8 * 3));
-  if (haveMasks)
-    HIPCHECK(hipMemsetAsync(ctx->swMask.as<u64>() + 2 * mStride, 0, mStride * 8, s));
-  else
-    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, mStride * 8 * 3, s));
-  ctx->maskIdx = -1;
-  SweepMasks SM{ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + mStride, ctx->swMask.as<u64>() + 2 * mStride, nWords};
-  HIPCHECK(hipMemsetAsync(misc + M_SWEEP_FIRST, 0, M_SWEEP_WORDS * 4, s));  // run / candidate / peak counters, peak bp
-  const float* qPtr = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
-  u32 R = 0, nPeaks = 0;
-  bool haveStatus = false;
-  ctx->peakBP = 0;
-  if (nWords) {
-    HIPCHECK(ctx->lb2.ensure(((size_t)wChunks * 4 + 64) * 4));
-    u32* cntS = ctx->lb2.as<u32>();
-    u32* offS = cntS + wChunks + 8;
-    u32* cntE = offS + wChunks + 8;
-    u32* offE = cntE + wChunks + 8;
-    hipLaunchKernelGGL(k_brk_mask, dim3((nChrom + 255) / 256), dim3(256), 0, s, fa.chromOff.as<u32>(), nChrom, SM.brk);
-    if (!haveMasks)
-      hipLaunchKernelGGL(k_sig_mask, dim3(std::max(1u, std::min((nWords + 15) / 16, 4096u))), dim3(256), 0, s, fa.p.as<float>(),
-                         qPtr, misc + M_NIV, ctx->par.thr, SM);
-    hipLaunchKernelGGL(k_runs_count, dim3(wChunks), dim3(SW_NT), 0, s, SM, cntS, cntE);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cntS, (const u32*)nullptr, wChunks, (u32)SW_CHUNK, offS,
-                       misc + M_SWCOUNT);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cntE, (const u32*)nullptr, wChunks, (u32)SW_CHUNK, offE,
-                       misc + M_TICKET2);
-    HIPCHECK(hipMemcpyAsync(&ctx->mail->R, misc + M_SWCOUNT, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));  // run / candidate arrays are sized exactly
-    R = ctx->mail->R;
-    if (R) {
-      HIPCHECK(ctx->swStart.ensure((size_t)R * 4 + 16));
-      HIPCHECK(ctx->swEnd.ensure((size_t)R * 4 + 16));
-      HIPCHECK(ctx->headPos.ensure((size_t)R * 4 + 16));
-      HIPCHECK(ctx->cand.ensure((size_t)R * sizeof(gx_peak)));
-      HIPCHECK(ctx->valid.ensure((size_t)R * 4 + 16));
-      HIPCHECK(ctx->peaks.ensure((size_t)R * sizeof(gx_peak)));
-      const u32 rChunks = (R + SW_CHUNK - 1) / SW_CHUNK;
-      HIPCHECK(ctx->swChrom.ensure(((size_t)rChunks * 4 + 64) * 4));
-      u32* cnt2 = ctx->swChrom.as<u32>();
-      u32* off2 = cnt2 + rChunks + 8;
-      u32* cnt3 = off2 + rChunks + 8;
-      u32* off3 = cnt3 + rChunks + 8;
-      u32* runStart = ctx->swStart.as<u32>();
-      u32* runEnd = ctx->swEnd.as<u32>();
-      hipLaunchKernelGGL(k_runs_write, dim3(wChunks), dim3(SW_NT), 0, s, SM, offS, offE, runStart, runEnd);
-      hipLaunchKernelGGL(k_cands_count, dim3(rChunks), dim3(SW_NT), 0, s, SM, fa.end.as<u32>(), runStart, runEnd,
-                         misc + M_SWCOUNT, ctx->par.max_gap, fa.chromOff.as<u32>(), nChrom, cnt2);
-      hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt2, (const u32*)nullptr, rChunks, (u32)SW_CHUNK, off2,
-                         misc + M_NHEADS);
-      hipLaunchKernelGGL(k_cands_write, dim3(rChunks), dim3(SW_NT), 0, s, SM, fa.end.as<u32>(), runStart, runEnd,
-                         misc + M_SWCOUNT, ctx->par.max_gap, fa.chromOff.as<u32>(), nChrom, off2, ctx->headPos.as<u32>());
-      HIPCHECK(ctx->candHdr.ensure((size_t)R * sizeof(uint4)));
-      HIPCHECK(ctx->longList.ensure((size_t)R * 4 + 16));
-      hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((R + 255) / 256, 4096u))), dim3(256), 0, s, SM, fa.end.as<u32>(),
-                         runStart, runEnd, misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->candHdr.as<uint4>(),
-                         ctx->longList.as<u32>(), misc + M_TICKET3);
-      {
-        const dim3 grid(std::max(1u, std::min((R + 255) / 256, 8192u)));
-#define GX_LAUNCH_PEAK_SHORT(Q)                                                                                          \
-  hipLaunchKernelGGL((k_peak_short<Q>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), fa.end.as<u32>(),                 \
-                     fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom, misc + M_NHEADS, ctx->par.thr,                \
-                     ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>())
-        if (qPtr) GX_LAUNCH_PEAK_SHORT(true); else GX_LAUNCH_PEAK_SHORT(false);
-#undef GX_LAUNCH_PEAK_SHORT
-      }
-      hipLaunchKernelGGL(k_peak_walk, dim3(std::max(1u, std::min((R + 3) / 4, (u32)(2 * ctx->numCU)))), dim3(256), 0, s,
-                         ctx->candHdr.as<uint4>(), fa.end.as<u32>(), fa.p.as<float>(), qPtr, fa.chromOff.as<u32>(), nChrom,
-                         ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
-                         ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
-      // candidates C <= R: chunk arrays sized by R's chunk count; kernels bound themselves by *nCands
-      hipLaunchKernelGGL(k_peaks_count, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
-      hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, cnt3, misc + M_NHEADS, rChunks, (u32)SW_CHUNK, off3,
-                         misc + M_NPEAKS);
-      hipLaunchKernelGGL(k_peaks_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
-                         misc + M_NHEADS, off3, ctx->peaks.as<gx_peak>(), reinterpret_cast<u64*>(misc + M_PEAKBP));
-      if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
-      // peak count, peak bp and the status word in one round trip
-      HIPCHECK(hipMemcpyAsync(&ctx->mail->nPeaks, misc + M_NPEAKS, 4, hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipMemcpyAsync(&ctx->mail->peakBP, misc + M_PEAKBP, 8, hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipMemcpyAsync(&ctx->mail->status, ctx->dStatus.p, 4, hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipStreamSynchronize(s));
-      nPeaks = ctx->mail->nPeaks;
-      ctx->peakBP = ctx->mail->peakBP;
-      haveStatus = true;
-    }
+  SweepSrc src{};
+  src.nChrom = nChrom;
+  {
+    src.end = fa.end.as<u32>();
+    src.p = fa.p.as<float>();
+    src.q = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
+    src.chromOff = fa.chromOff.as<u32>();
+    src.nWords = (n + 63) / 64;
+    // the masks were filled by the pack kernels (p mode, one replicate) or by k_qlookup (q mode)
+    src.haveMasks = ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;
+    src.mStride = src.haveMasks ? ctx->maskStride : (size_t)src.nWords + 2;
+    src.hasSkip = true;
+    HIPCHECK(ctx->swMask.ensure(src.mStride * 8 * 3));
+    if (src.haveMasks)
+      HIPCHECK(hipMemsetAsync(ctx->swMask.as<u64>() + 2 * src.mStride, 0, src.mStride * 8, s));
+    else
+      HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, src.mStride * 8 * 3, s));
   }
-  HIPCHECK(ctx->hPeaks.ensure((size_t)nPeaks * sizeof(gx_peak) + 16));
-  ctx->nHostPeaks = nPeaks;
-  if (nPeaks)
-    HIPCHECK(hipMemcpyAsync(ctx->hPeaks.p, ctx->peaks.p, (size_t)nPeaks * sizeof(gx_peak), hipMemcpyDeviceToHost, s));
+  ctx->maskIdx = -1;
+  u32 nPeaks = 0;
+  if (int rc = run_sweep(ctx, src, &nPeaks)) return rc;
   phase_end(ctx);
-  int rc;
-  if (haveStatus) {
-    HIPCHECK(hipStreamSynchronize(s));
-    rc = status_to_rc(ctx, ctx->mail->status);
-  } else
-    rc = read_status(ctx);
-  if (rc) return rc;
   if (n_peaks) *n_peaks = nPeaks;
   if (genome_len) *genome_len = g;
   if (peak_bp) *peak_bp = ctx->peakBP;
@@ -1642,6 +1718,7 @@ static const PArray* which_array(gx_ctx* ctx, int which, int chrom, u32* lo, u32
   if (chrom < 0 || (u32)chrom >= ctx->nChrom) return nullptr;
   int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
   if (w < 0 || w >= (int)ctx->reps.size()) return nullptr;
+  if (ctx->reps[w].loose && materialize_rep(ctx, w) != GX_OK) return nullptr;
   const PArray& pa = ctx->reps[w];
   if (!pa.present[chrom]) return nullptr;
   u32 off[2];
@@ -1670,6 +1747,11 @@ int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* en
   const PArray* pa = which_array(ctx, which, chrom, &lo, &hi);
   if (!pa) return GX_OK;
   size_t n = std::min<size_t>(cap, hi - lo);
+  if ((expt || ctrl) && pa->pilesPending) {
+    const int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
+    if (int rc = ensure_piles(ctx, w)) return rc;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+  }
   if ((expt || ctrl) && pa->pilesDropped) {
     ctx->err = "the pileup values were not kept (gx_set_keep_pileups)";
     return GX_ERR_ORDER;
@@ -1706,8 +1788,7 @@ int gx_selftest2(gx_ctx* ctx, int what, const float* a, const float* b, float* o
   hipLaunchKernelGGL(k_selftest, dim3(1024), dim3(256), 0, ctx->stream, what, da.as<float>(), db.as<float>(),
                      dout.as<float>(), ddbl.as<double>(), (u32)n, ctx->dRisk.as<RiskBuf>());
   if (int rc__ = dbg_sync(ctx, "k_selftest")) return rc__;
-  if (int rc__ = risk_queue(ctx)) return rc__;
-  HIPCHECK(hipStreamSynchronize(ctx->stream));
+  if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
   if (n_risky) *n_risky = static_cast<RiskBuf*>(ctx->riskHost.p)->count;
   RiskTargets T{};
   T.selfOut = dout.as<float>();

@@ -1015,9 +1015,9 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
 // intervals with len * val >= 2^24 can round, and they are easy to find:
 //   * val >= 2^24 / (2 TILE): k_tile marks the tiles in which the pileup gets that deep;
 //   * otherwise len >= 2 TILE: the interval starts before its tile does, so it is the tile's first.
-// k_frag_fix1 looks at every other tile's first interval, k_frag_fix2 walks the deep tiles
-// (k_deep_list); both add (rounded product - exact product), an integer, to a correction.
-// Everything else (fractional weights, -E, wide records) takes the general path k_frag, which
+// k_frag_fix1 looks at every other tile's first interval (and lists the deep tiles), k_frag_walk walks
+// the listed ones; both add (rounded product - exact product), an integer, to a correction.
+// Everything else (fractional weights, -E, wide records) takes k_frag_walk's general path, which
 // walks every interval and accumulates exactly in (integer, fraction * 2^27) form.
 struct FragFix {
   u64 fragSum[FRAG_SLOTS];  // closed form partial sums
@@ -1035,24 +1035,23 @@ __device__ __forceinline__ long long frag_corr(u32 len, int v) {
   return (long long)term - (long long)((u64)len * cnt);
 }
 
-// the tiles k_tile marked deep (and that hold intervals), as a list: walked by k_frag_fix2 and k_pval_deep
-__global__ __launch_bounds__(256) void k_deep_list(const u32* __restrict__ tileDeep, const u32* __restrict__ tileIvOff,
-                                                   u32 nTiles, FragFix* __restrict__ ff, u32* __restrict__ list) {
-  const u32 t = blockIdx.x * 256 + threadIdx.x;
-  if (t < nTiles && tileDeep[t] && tileIvOff[t + 1] != tileIvOff[t]) list[atomicAdd(&ff->nList, 1u)] = t;
-}
-
+// One pass over the tiles: a tile k_tile marked deep (and that holds intervals) goes on a list (walked by
+// k_frag_walk and k_pval_deep); of every other tile the first interval is looked at (it may start before
+// its tile: the only place where len >= 2 TILE can hide).
 __global__ __launch_bounds__(256) void k_frag_fix1(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
                                                    const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
                                                    const u32* __restrict__ tilePrevEnd, const u32* __restrict__ tileDeep,
-                                                   u32 nTiles, FragFix* __restrict__ ff) {
-  if (ff->slow) return;
+                                                   u32 nTiles, FragFix* __restrict__ ff, u32* __restrict__ list) {
   long long c = 0;
   const u32 t = blockIdx.x * 256 + threadIdx.x;
-  if (t < nTiles && tileIvOff[t + 1] != tileIvOff[t] && !tileDeep[t]) {
-    const u32 slot = meta[t].slot;
-    const u32 len = looseEnd[slot] - tilePrevEnd[t];
-    if (len >= 2 * TILE) c = frag_corr(len, looseV[slot]);
+  if (t < nTiles && tileIvOff[t + 1] != tileIvOff[t]) {
+    if (tileDeep[t])
+      list[atomicAdd(&ff->nList, 1u)] = t;
+    else if (!ff->slow) {
+      const u32 slot = meta[t].slot;
+      const u32 len = looseEnd[slot] - tilePrevEnd[t];
+      if (len >= 2 * TILE) c = frag_corr(len, looseV[slot]);
+    }
   }
   if (__ballot(c != 0)) {
     c = wave_sum(c);
@@ -1060,16 +1059,19 @@ __global__ __launch_bounds__(256) void k_frag_fix1(const u32* __restrict__ loose
   }
 }
 
-__global__ __launch_bounds__(256) void k_frag_fix2(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
+// One wavefront per tile walks the tile's loose slots (read only).  Closed form: the deep tiles of the list,
+// adding (rounded - exact) products to the correction.  General path (fractional weights, -E, wide
+// records): every tile, accumulating every product exactly in (integer, fraction * 2^27) form.
+__global__ __launch_bounds__(256) void k_frag_walk(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
                                                    const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
-                                                   const u32* __restrict__ tilePrevEnd, FragFix* __restrict__ ff,
-                                                   const u32* __restrict__ list) {
-  if (ff->slow) return;
-  const u32 nList = ff->nList;
-  long long c = 0;
+                                                   const u32* __restrict__ tilePrevEnd, u32 nTiles, FragFix* __restrict__ ff,
+                                                   const u32* __restrict__ list, long long* __restrict__ acc) {
+  const bool slow = ff->slow != 0;
+  const u32 nItems = slow ? nTiles : ff->nList;
+  long long c = 0, hi = 0, lo = 0;
   const int wv = threadIdx.x >> 6, lane = lane_id();
-  for (u32 li = blockIdx.x * 4 + wv; li < nList; li += gridDim.x * 4) {
-    const u32 t = list[li];
+  for (u32 it = blockIdx.x * 4 + wv; it < nItems; it += gridDim.x * 4) {
+    const u32 t = slow ? it : list[it];
     const u32 src = meta[t].slot, n = tileIvOff[t + 1] - tileIvOff[t];
     u32 prevEnd = tilePrevEnd[t];
     for (u32 b = 0; b < n; b += 64) {
@@ -1083,43 +1085,21 @@ __global__ __launch_bounds__(256) void k_frag_fix2(const u32* __restrict__ loose
       u32 s = __shfl_up(e, 1, 64);
       if (lane == 0) s = prevEnd;
       prevEnd = __shfl(e, 63, 64);
-      if (i < n) c += frag_corr(e - s, v);
-    }
-  }
-  c = wave_sum(c);
-  if (lane == 0 && c) atomicAdd((u64*)&ff->corr, (u64)c);
-}
-
-// general path: one wavefront per tile walks the tile's loose slots (read only)
-__global__ __launch_bounds__(256) void k_frag(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
-                                              const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
-                                              const u32* __restrict__ tilePrevEnd, u32 nTiles,
-                                              const FragFix* __restrict__ ff, long long* __restrict__ acc) {
-  if (ff->slow == 0) return;
-  long long hi = 0, lo = 0;
-  const int wv = threadIdx.x >> 6, lane = lane_id();
-  for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
-    const u32 src = meta[t].slot, n = tileIvOff[t + 1] - tileIvOff[t];
-    u32 prevEnd = tilePrevEnd[t];
-    for (u32 b = 0; b < n; b += 64) {
-      const u32 i = b + lane;
-      u32 e = 0;
-      int v = 0;
       if (i < n) {
-        e = looseEnd[src + i];
-        v = looseV[src + i];
+        if (slow) frag_term(e - s, v, hi, lo); else c += frag_corr(e - s, v);
       }
-      u32 s = __shfl_up(e, 1, 64);
-      if (lane == 0) s = prevEnd;
-      prevEnd = __shfl(e, 63, 64);
-      if (i < n) frag_term(e - s, v, hi, lo);
     }
   }
-  hi = wave_sum(hi);
-  lo = wave_sum(lo);
-  if (lane == 0) {
-    if (hi) atomicAdd((u64*)&acc[0], (u64)hi);
-    if (lo) atomicAdd((u64*)&acc[1], (u64)lo);
+  if (slow) {
+    hi = wave_sum(hi);
+    lo = wave_sum(lo);
+    if (lane == 0) {
+      if (hi) atomicAdd((u64*)&acc[0], (u64)hi);
+      if (lo) atomicAdd((u64*)&acc[1], (u64)lo);
+    }
+  } else {
+    c = wave_sum(c);
+    if (lane == 0 && c) atomicAdd((u64*)&ff->corr, (u64)c);
   }
 }
 
@@ -1206,8 +1186,19 @@ struct Scalars {
 // (every rank must learn whether any rank has to, before the sums mean anything): +1 when a base can
 // reach the reference's int16 limits, +65536 when a level-1 page list overflowed (ST_PT_FULL = 512)
 __global__ void k_frag_select(const FragFix* __restrict__ ff, long long* __restrict__ acc, long long* __restrict__ coll,
-                              const u32* __restrict__ hot, const u32* __restrict__ st) {
+                              const u32* __restrict__ hot, const u32* __restrict__ st, const DChrom* __restrict__ chroms,
+                              u32 nChrom, u32* __restrict__ chromIvOff, const u32* __restrict__ nIv) {
   if (threadIdx.x || blockIdx.x) return;
+  {  // chromosome table epilogue (as k_fix_chrom_off): offsets of the chromosomes without tiles
+    u32 next = *nIv;
+    chromIvOff[nChrom] = next;
+    for (int c = (int)nChrom - 1; c >= 0; c--) {
+      if (chroms[c].tileBase == NULL_TILE)
+        chromIvOff[c] = next;
+      else
+        next = chromIvOff[c];
+    }
+  }
   if (!ff->slow) {
     u64 t = 0;
     for (int i = 0; i < FRAG_SLOTS; i++) t += ff->fragSum[i];
@@ -1236,6 +1227,35 @@ __global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st, const long long* 
     s->factor = s->ctrlFrag == 0.0 ? 1.0f : (float)(s->fragLen / s->ctrlFrag);  // calcFactor 2043-2045
   }
   s->lambda = (float)(s->fragLen / (double)s->genomeLen);  // calcLambda 1831
+}
+
+// Everything the host wants to know at a synchronisation point, written by ONE small kernel straight into
+// pinned host memory (instead of one copy launch per word): scalars, status, flags, and the list of risky
+// p-values (its count and first records).
+struct MailOut {
+  Scalars* scal;
+  u32* status;
+  u32* hot;
+  u32* nIv;
+  long long* again;   // the ranks' "build this sample again" flags (several ranks only)
+  u32* extra;         // one more word (interval count of a merge)
+  RiskBuf* risk;
+};
+
+__global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, const u32* __restrict__ st, const u32* __restrict__ hot,
+                                             const u32* __restrict__ nIv, const long long* __restrict__ coll,
+                                             const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, MailOut m) {
+  const u32 n = rb->count;
+  if (threadIdx.x == 0) {
+    if (ds) *m.scal = *ds;
+    *m.status = *st;
+    if (hot) *m.hot = *hot;
+    if (nIv) *m.nIv = *nIv;
+    if (coll) *m.again = coll[2];
+    if (extra) *m.extra = *extra;
+    m.risk->count = n;
+  }
+  if (threadIdx.x < n && threadIdx.x < RISK_PREFIX) m.risk->rec[threadIdx.x] = rb->rec[threadIdx.x];
 }
 
 }  // namespace gx

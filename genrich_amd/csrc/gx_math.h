@@ -47,6 +47,17 @@ GX_HD __forceinline__ float getval(int32_t v, bool* neg) {
   return (float)cov + ((float)e / 8.0f) + ((float)s / 6.0f) + ((float)t / 10.0f);
 }
 
+// updateVal's ERRPILE test alone (1921 / 1969): is the integer part of the canonical (cov, e, s, t) state of
+// the exact pileup v / 120 negative?  (It can be for a small positive fractional pileup: 59/120 = -1 + 7/8 + 2/6 + 2/10 ... .)
+GX_HD __forceinline__ bool getval_neg(int32_t v) {
+  int32_t q = v / GX_UNIT, r = v - q * GX_UNIT;
+  if (r < 0) { r += GX_UNIT; q -= 1; }
+  if (r == 0) return q < 0;
+  const uint32_t est = est_of_residue(r);
+  const int e = est & 15, s = (est >> 4) & 15, t = est >> 8;
+  return q - (15 * e + 20 * s + 12 * t - r) / GX_UNIT < 0;
+}
+
 // ---- the one rounding of a p-value: double -> float, with the "risky" test ----------------------
 // Device and host evaluate the same IEEE operations around different libm calls (<= ~1.5 ulp of the
 // double apart per call); through calcPval / pchisq that propagates to a relative difference of at

@@ -45,19 +45,19 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
 constexpr int PP_UNROLL = 4;   // 256 intervals of a tile in flight per wavefront
 constexpr int PP_HOT = 1024;   // whole pileups below this have their p-value in LDS
 
-// KEEP / CTRL / MASKS: whether the pileup floats, the control column (-E runs) and the sweep masks
-// are written.  Compile-time on purpose: with the same choices as run-time null checks on the
-// output pointers the compiler schedules the stores of the hot loop 35 % slower (measured).
-template <bool KEEP, bool CTRL, bool MASKS>
+// The pileup floats of the intervals (the reference's Pileup.cov, printed by -f / -k only) are NOT written
+// here: they are a function of the exact V that stays in the loose slots, and k_piles_from_loose makes them
+// when somebody asks (gx_get_intervals, a further sample about to reuse the slots).
+// MASKS: whether the sweep masks are written.  Compile-time on purpose: with the same choice as a run-time
+// null check on the output pointers the compiler schedules the stores of the hot loop 35 % slower (measured).
+template <bool MASKS>
 __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const Scalars* __restrict__ sc,
                                                    const float* __restrict__ lutP, u32* __restrict__ ivEnd,
-                                                   float* __restrict__ pOut, float* __restrict__ exptOut,
-                                                   float* __restrict__ ctrlOut, float thr, u64* __restrict__ sigMask,
+                                                   float* __restrict__ pOut, float thr, u64* __restrict__ sigMask,
                                                    u64* __restrict__ skipMask, u32* __restrict__ st) {
   __shared__ float hot[PP_HOT];  // indexed by the whole pileup c = V / 120 (consecutive banks, unlike V itself)
   for (int i = threadIdx.x; i < PP_HOT; i += 256) hot[i] = lutP[i * GX_UNIT];
   __syncthreads();
-  const float lambda = sc->lambda;
   u32 neg = 0;
   const int wv = threadIdx.x >> 6, lane = lane_id();
   const u32 stride = gridDim.x * 4;
@@ -124,28 +124,21 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
         const u32 i = b + k * 64 + lane;
         float p = 0.0f;
         if (i < n) {
-          bool ng = false;
-          float val;
           if (v[k] == V_MARK) {  // inside an excluded region: treatment 0.0f (2248), control SKIP (1871) -> p SKIP (1629)
-            val = 0.0f;
             p = GX_SKIPF;
           } else {
             // pileups beyond the table (>= 2184) are scored by k_pval_deep: the double-precision
             // math would cost this kernel half its occupancy
             const u32 c = __umulhi((u32)v[k], 0x88888889u) >> 6;  // V / 120 for V >= 0
-            if (v[k] >= 0 && c * GX_UNIT == (u32)v[k] && c < PP_HOT) {  // a whole pileup: getval is (float)c
-              val = (float)c;
+            if (v[k] >= 0 && c * GX_UNIT == (u32)v[k] && c < PP_HOT)  // a whole pileup
               p = hot[c];
-            } else {
-              val = getval(v[k], &ng);
+            else {
+              neg |= (u32)getval_neg(v[k]);  // updateVal's ERRPILE (1921)
               p = (u32)v[k] < PV_LUT ? lutP[v[k]] : 0.0f;
             }
           }
-          neg |= ng;
           ivEnd[dst + i] = e[k];
           pOut[dst + i] = p;
-          if (KEEP) exptOut[dst + i] = val;
-          if (KEEP && CTRL) ctrlOut[dst + i] = v[k] == V_MARK ? GX_SKIPF : lambda;
         }
         if (MASKS) {  // the sweep's significance / skip bit masks, while p is at hand (pre-zeroed words)
           const u64 sg = __ballot(p > thr), sk = __ballot(p == GX_SKIPF);
@@ -237,6 +230,25 @@ __global__ __launch_bounds__(256) void k_pval_deep(PackIn in, const FragFix* __r
         pOut[dst + i] = p;
         if (sigMask && p > thr) atomicOr((unsigned long long*)&sigMask[(dst + i) >> 6], 1ull << ((dst + i) & 63));
       }
+    }
+  }
+}
+
+// The pileup floats of a no-control replicate's intervals, on request: treatment value = getVal of the exact
+// pileup (1902-1907; 0.0f inside an excluded region, 2248), control = lambda (SKIP inside one, 1871).  One
+// wavefront per tile, from the loose slots to the tight position.
+template <bool CTRL>
+__global__ __launch_bounds__(256) void k_piles_from_loose(PackIn in, u32 nTiles, const Scalars* __restrict__ sc,
+                                                          float* __restrict__ exptOut, float* __restrict__ ctrlOut) {
+  const float lambda = sc->lambda;
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
+    const u32 src = in.meta[t].slot, dst = in.tileIvOff[t], n = in.tileIvOff[t + 1] - dst;
+    for (u32 i = lane; i < n; i += 64) {
+      const int v = in.looseV[src + i];
+      bool ng;
+      exptOut[dst + i] = v == V_MARK ? 0.0f : getval(v, &ng);
+      if (CTRL) ctrlOut[dst + i] = v == V_MARK ? GX_SKIPF : lambda;
     }
   }
 }
@@ -549,25 +561,41 @@ constexpr int SW_NT = 256;
 constexpr int SW_ITEMS = 8;
 constexpr int SW_CHUNK = SW_NT * SW_ITEMS;  // items per workgroup in the chunked compactions
 
-// exclusive scan of a short u32 array (chunk counts) by one workgroup; total -> *total
-__global__ __launch_bounds__(1024) void k_scan_small(const u32* __restrict__ in, const u32* __restrict__ nPtr, u32 nMax,
-                                                     u32 chunk, u32* __restrict__ out, u32* __restrict__ total) {
+// exclusive scan of a short u32 array (chunk counts) by one workgroup; total -> *total (and, when the host
+// wants it at its next synchronisation, -> *totalHost in pinned memory: no copy launch).  One workgroup per
+// job: the two scans that follow the same kernel share a launch.
+struct ScanJob {
+  const u32* in;
+  const u32* nPtr;   // items = ceil(*nPtr / chunk) when given (a device-side count), else nMax
+  u32 nMax, chunk;
+  u32* out;
+  u32* total;
+  u32* totalHost;    // optional
+  u32* zeroMe;       // optional: a counter the kernels after this one expect at zero
+};
+struct ScanJobs { ScanJob j[2]; };
+
+__global__ __launch_bounds__(1024) void k_scan_small(ScanJobs J) {
   __shared__ u32 scratch[20];
-  // n items = ceil(*nPtr / chunk) when nPtr is given (a device-side count), else nMax
-  u32 n = nPtr ? (*nPtr + chunk - 1) / chunk : nMax;
-  if (n > nMax) n = nMax;
+  const ScanJob& jb = J.j[blockIdx.x];
+  u32 n = jb.nPtr ? (*jb.nPtr + jb.chunk - 1) / jb.chunk : jb.nMax;
+  if (n > jb.nMax) n = jb.nMax;
   const u32 per = (n + 1023) / 1024;
   const u32 i0 = min(n, threadIdx.x * per), i1 = min(n, i0 + per);
   u32 sum = 0;
-  for (u32 i = i0; i < i1; i++) sum += in[i];
+  for (u32 i = i0; i < i1; i++) sum += jb.in[i];
   u32 tot;
   u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
   for (u32 i = i0; i < i1; i++) {
-    u32 v = in[i];
-    out[i] = ex;
+    u32 v = jb.in[i];
+    jb.out[i] = ex;
     ex += v;
   }
-  if (threadIdx.x == 0) *total = tot;
+  if (threadIdx.x == 0) {
+    *jb.total = tot;
+    if (jb.totalHost) *jb.totalHost = tot;
+    if (jb.zeroMe) *jb.zeroMe = 0;
+  }
 }
 
 struct SweepMasks {
@@ -695,7 +723,7 @@ __device__ __forceinline__ bool any_bit(const u64* __restrict__ mask, u32 lo, u3
 // start - previous end <= maxGap).  The chromosome test is a search in the (short) offset table, not a
 // walk over the mask words between the two runs: with few significant intervals (a -q run with a
 // control) consecutive runs lie millions of intervals apart.
-__device__ __forceinline__ bool run_is_head(const SweepMasks& M, const u32* __restrict__ end,
+__device__ __forceinline__ bool run_is_head(const SweepMasks& M, const u64* __restrict__ skipMask, const u32* __restrict__ end,
                                             const u32* __restrict__ runStart, const u32* __restrict__ runEnd, u32 r,
                                             int maxGap, const u32* __restrict__ chromOff, u32 nChrom) {
   if (r == 0) return true;
@@ -707,11 +735,11 @@ __device__ __forceinline__ bool run_is_head(const SweepMasks& M, const u32* __re
   const long long gap = (long long)end[s - 1] - (long long)end[a];  // start(s) - end(a) on one chromosome: >= 0
   if (gap != 0 && gap > (long long)maxGap) return true;
   // at most `gap` intervals (each >= 1 bp) lie between linked runs: a short scan
-  if (any_bit(M.skip, a + 1, s)) return true;
+  if (skipMask && any_bit(skipMask, a + 1, s)) return true;  // (no SKIP intervals without -E regions)
   return false;
 }
 
-__global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u32* __restrict__ end,
+__global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u64* __restrict__ skipMask, const u32* __restrict__ end,
                                                        const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
                                                        const u32* __restrict__ nRuns, int maxGap,
                                                        const u32* __restrict__ chromOff, u32 nChrom,
@@ -723,14 +751,14 @@ __global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u32* 
   u32 cnt = 0;
 #pragma unroll
   for (int k = 0; k < SW_ITEMS; k++)
-    if (r0 + k < R) cnt += run_is_head(M, end, runStart, runEnd, r0 + k, maxGap, chromOff, nChrom);
+    if (r0 + k < R) cnt += run_is_head(M, skipMask, end, runStart, runEnd, r0 + k, maxGap, chromOff, nChrom);
   cnt = wave_sum(cnt);
   if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-__global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u32* __restrict__ end,
+__global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u64* __restrict__ skipMask, const u32* __restrict__ end,
                                                        const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
                                                        const u32* __restrict__ nRuns, int maxGap,
                                                        const u32* __restrict__ chromOff, u32 nChrom,
@@ -742,7 +770,7 @@ __global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u32* 
   u32 keep = 0, cnt = 0;
 #pragma unroll
   for (int k = 0; k < SW_ITEMS; k++)
-    if (r0 + k < R && run_is_head(M, end, runStart, runEnd, r0 + k, maxGap, chromOff, nChrom)) { keep |= 1u << k; cnt++; }
+    if (r0 + k < R && run_is_head(M, skipMask, end, runStart, runEnd, r0 + k, maxGap, chromOff, nChrom)) { keep |= 1u << k; cnt++; }
   u32 tot;
   u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
 #pragma unroll
@@ -948,7 +976,7 @@ __global__ __launch_bounds__(SW_NT) void k_peaks_count(const u32* __restrict__ v
 
 __global__ __launch_bounds__(SW_NT) void k_peaks_write(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
                                                        const u32* __restrict__ nHeads, const u32* __restrict__ chunkOff,
-                                                       gx_peak* __restrict__ peaks, u64* __restrict__ peakBP) {
+                                                       gx_peak* __restrict__ peaks /* pinned host memory */) {
   __shared__ u32 scratch[8];
   const u32 H = *nHeads;
   if (blockIdx.x * SW_CHUNK >= H) return;
@@ -959,16 +987,9 @@ __global__ __launch_bounds__(SW_NT) void k_peaks_write(const gx_peak* __restrict
     if (h0 + k < H && valid[h0 + k]) { keep |= 1u << k; cnt++; }
   u32 tot;
   u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
-  u64 bp = 0;
 #pragma unroll
   for (int k = 0; k < SW_ITEMS; k++)
-    if (keep & (1u << k)) {
-      gx_peak pk = cand[h0 + k];
-      peaks[o++] = pk;
-      bp += pk.end - pk.start;
-    }
-  bp = wave_sum(bp);
-  if (lane_id() == 0 && bp) atomicAdd(peakBP, bp);
+    if (keep & (1u << k)) peaks[o++] = cand[h0 + k];
 }
 
 }  // namespace gx

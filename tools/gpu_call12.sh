@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -s KILL 600 python -m pytest tests/test_hip_parity.py tests/test_hip_multirank.py -m gpu -q --timeout 300 2>&1 | tail -3
+( timeout -s KILL 200 python bench.py --steps 20 --warmup 3 --no-cpu --no-e2e ) > gpurun_out/c12_bench2.json 2> gpurun_out/c12_bench2.err
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/c12_bench*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d["ms_per_step"],3), {k: round(v,3) for k,v in d["phases_ms"].items()}, d["config"]["peaks"])
+    except Exception as e: print(f, "ERR", e, open(f.replace(".json",".err")).read()[-600:])
+PY

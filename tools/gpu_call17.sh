@@ -1,0 +1,15 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/prof_c17
+timeout -s KILL 900 python -m pytest tests -m gpu -q --timeout 600 -x > gpurun_out/c17_pytest.log 2>&1
+grep -E "passed|failed|Error|error" gpurun_out/c17_pytest.log | tail -5
+( timeout -s KILL 200 python bench.py --steps 20 --warmup 3 --no-cpu --no-e2e ) > gpurun_out/c17_bench2.json 2> gpurun_out/c17_bench2.err
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/c17_bench*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d["ms_per_step"],3), {k: round(v,3) for k,v in d["phases_ms"].items()}, d["config"]["peaks"])
+    except Exception as e: print(f, "ERR", e, open("gpurun_out/c17_bench2.err").read()[-500:])
+PY
+export TMPDIR=/tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c17/trace -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu --no-e2e > gpurun_out/prof_c17/trace.log 2>&1
+python profiles/summarize_rocpd.py $(find gpurun_out/prof_c17/trace -name "*.db" | head -1) | head -24
