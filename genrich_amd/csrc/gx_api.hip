@@ -148,10 +148,19 @@ struct gx_ctx {
   // per-sample state
   int phase = 0;  // 0 idle, 1 treatment open, 2 treatment done, 3 control open, 4 control done
   int sample = 0;
-  DevBuf evBuf;
-  size_t evCount = 0;
-  struct Seg { const gx_event* p; size_t n; };
+  // The sample's events, in push order: device-resident segments of the caller (gx_push_events_device) and
+  // pieces of the library's own device chunks, filled from host memory by asynchronous copies on `side`
+  // (`ready` = the copy has arrived: the main stream waits for it before the kernel that reads the piece).
+  struct Seg { const gx_event* p; size_t n; hipEvent_t ready; };
   std::vector<Seg> segs;
+  std::vector<DevBuf> evChunks;   // device chunks of EV_CHUNK events, reused sample after sample
+  size_t evChunkIdx = 0, evChunkFill = 0;
+  PinnedBuf stage[2];             // pinned staging of gx_push_events (the caller's buffer is free on return)
+  hipEvent_t stageFree[2] = {nullptr, nullptr};
+  int stageNext = 0;
+  std::vector<hipEvent_t> evPool; // `ready` events, reused
+  size_t evPoolUsed = 0;
+  DevBuf satBuf;                  // what gx_filter_saturation left of the sample
   struct Stream {  // one record stream of the bucket sort
     DevBuf a, pool, pt, cursor, sbOff;  // level-2 output; level-1 pages, page table, list cursors; super-bucket offsets
   };
@@ -173,6 +182,7 @@ struct gx_ctx {
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
   bool bhDirty = false;         // the BH table was left with entries (an error path): wipe it before use
+  u32 bhCapLog = 22;            // log2 of its slots (grows by 3 after ST_HASH_FULL)
   // sweep
   DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
   PinnedBuf hPeaks;             // the peak list on the host (pinned: the read-back is asynchronous)
@@ -388,10 +398,8 @@ int pack_pileup(gx_ctx* ctx, Pileup& P) {
 
 // events -> tile-bucketed endpoint records -> run-length pileup (loose slots + offsets) and fragLen
 int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
-  // host-pushed events are staged in evBuf; device-resident segments are used in place
-  std::vector<gx_ctx::Seg> segs;
-  if (ctx->evCount) segs.push_back({ctx->evBuf.as<gx_event>(), ctx->evCount});
-  for (auto& sg : ctx->segs) segs.push_back(sg);
+  // (host-pushed events sit in the library's device chunks, device-resident segments are used in place)
+  const std::vector<gx_ctx::Seg>& segs = ctx->segs;
   size_t n = 0;
   for (auto& sg : segs) n += sg.n;
   if (2 * n >= 0xFFFFFFFFull) {
@@ -485,6 +493,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   Sort1Out so1{ff->fragSum, slowFrag, ctx->endAtLen.as<u32>(), ctx->nWide.as<u32>() + 1};
   for (auto& seg : segs) {
     if (!seg.n) continue;
+    // (a piece that is still on its way from the host: the main stream waits for that copy only, so the
+    // scatter of the pieces that have arrived overlaps the upload of the rest)
+    if (seg.ready) HIPCHECK(hipStreamWaitEvent(s, seg.ready, 0));
     const u32 blocks = (u32)((seg.n + S1_CHUNK - 1) / S1_CHUNK);
     if (unit32)
       hipLaunchKernelGGL(k_sort1<true>, dim3(blocks), dim3(S1_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
@@ -700,15 +711,12 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
 // drop the ones saveInterval would drop (gx_saturate.h) and stage what is left for a second build.
 int drop_saturated(gx_ctx* ctx, int isCtrl) {
   hipStream_t s = ctx->stream;
-  size_t total = ctx->evCount;
+  size_t total = 0;
   for (auto& sg : ctx->segs) total += sg.n;
   std::vector<gx_event> all(total);
   size_t at = 0;
-  if (ctx->evCount) {
-    HIPCHECK(hipMemcpyAsync(all.data(), ctx->evBuf.p, ctx->evCount * sizeof(gx_event), hipMemcpyDeviceToHost, s));
-    at = ctx->evCount;
-  }
-  for (auto& sg : ctx->segs) {
+  HIPCHECK(hipStreamSynchronize(ctx->side));  // (the uploads have long arrived: the sample was built once)
+  for (auto& sg : ctx->segs) {  // in push order: the replay depends on it
     if (sg.n) HIPCHECK(hipMemcpyAsync(all.data() + at, sg.p, sg.n * sizeof(gx_event), hipMemcpyDeviceToHost, s));
     at += sg.n;
   }
@@ -725,11 +733,11 @@ int drop_saturated(gx_ctx* ctx, int isCtrl) {
   } else
     kept = total;
   // (also when nothing was dropped: the second build must not see the caller's segments twice)
-  HIPCHECK(ctx->evBuf.ensure(std::max<size_t>(kept, 1) * sizeof(gx_event)));
-  if (kept) HIPCHECK(hipMemcpyAsync(ctx->evBuf.p, all.data(), kept * sizeof(gx_event), hipMemcpyHostToDevice, s));
+  HIPCHECK(ctx->satBuf.ensure(std::max<size_t>(kept, 1) * sizeof(gx_event)));
+  if (kept) HIPCHECK(hipMemcpyAsync(ctx->satBuf.p, all.data(), kept * sizeof(gx_event), hipMemcpyHostToDevice, s));
   HIPCHECK(hipStreamSynchronize(s));  // `all` goes out of scope
-  ctx->evCount = kept;
   ctx->segs.clear();
+  if (kept) ctx->segs.push_back({ctx->satBuf.as<gx_event>(), kept, nullptr});
   ctx->satDone = true;
   // what the first build left behind: its status bits and its contribution to fragLen / ctrlFrag
   Scalars* ds = ctx->dScal.as<Scalars>();
@@ -1069,6 +1077,7 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   gx_ctx* ctx = new gx_ctx();
   ctx->par = *par;
   ctx->device = par->device;
+  if (const char* e = getenv("GX_BH_CAPLOG")) ctx->bhCapLog = (u32)std::max(4, std::min(28, atoi(e)));  // (tests: a tiny first table)
   *out = ctx;
   HIPCHECK(hipSetDevice(ctx->device));
   HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -1136,6 +1145,8 @@ void gx_destroy(gx_ctx* ctx) {
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->sideEv) (void)hipEventDestroy(ctx->sideEv);
+  for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->stageFree) if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 
@@ -1239,7 +1250,7 @@ int gx_reset(gx_ctx* ctx) {
   ctx->phase = 0;
   ctx->finalIdx = -1;
   ctx->segs.clear();
-  ctx->evCount = 0;
+  ctx->evChunkIdx = ctx->evChunkFill = ctx->evPoolUsed = 0;
   ctx->nHostPeaks = 0;
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
   return GX_OK;
@@ -1275,30 +1286,77 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
     ctx->phase = 3;
   }
   ctx->segs.clear();
-  ctx->evCount = 0;
+  ctx->evChunkIdx = ctx->evChunkFill = ctx->evPoolUsed = 0;  // (the previous sample's uploads were consumed: gx_sample_end synchronised)
   ctx->satDone = false;
   return GX_OK;
 }
+
+namespace {
+
+constexpr size_t EV_CHUNK = (size_t)1 << 22;   // events per device chunk (64 MiB)
+constexpr size_t EV_STAGE = (size_t)1 << 20;   // events per pinned staging buffer (16 MiB)
+
+hipEvent_t ready_event(gx_ctx* ctx) {
+  if (ctx->evPoolUsed == ctx->evPool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    ctx->evPool.push_back(e);
+  }
+  return ctx->evPool[ctx->evPoolUsed++];
+}
+
+// Host events -> the library's device chunks, by asynchronous copies on the side stream.  `pinned`: the
+// caller's memory is page-locked and stays untouched until gx_sample_end, so it is the copy's source itself;
+// otherwise the events go through two pinned staging buffers (the caller's buffer is free on return, and the
+// host keeps parsing while a buffer is in flight).  Nothing here waits for a copy to arrive: every piece
+// carries an event that the main stream waits for before the kernel that reads it (build_pileup).
+int push_host(gx_ctx* ctx, const gx_event* events, size_t n, bool pinned) {
+  while (n) {
+    if (ctx->evChunkIdx == ctx->evChunks.size()) ctx->evChunks.emplace_back();
+    DevBuf& chunk = ctx->evChunks[ctx->evChunkIdx];
+    HIPCHECK(chunk.ensure(EV_CHUNK * sizeof(gx_event)));
+    size_t take = std::min(n, EV_CHUNK - ctx->evChunkFill);
+    if (!pinned) take = std::min(take, EV_STAGE);
+    gx_event* dst = chunk.as<gx_event>() + ctx->evChunkFill;
+    const gx_event* src = events;
+    if (!pinned) {
+      const int k = ctx->stageNext;
+      ctx->stageNext ^= 1;
+      HIPCHECK(ctx->stage[k].ensure(EV_STAGE * sizeof(gx_event)));
+      if (!ctx->stageFree[k]) HIPCHECK(hipEventCreateWithFlags(&ctx->stageFree[k], hipEventDisableTiming));
+      else HIPCHECK(hipEventSynchronize(ctx->stageFree[k]));  // its previous upload has left the buffer
+      memcpy(ctx->stage[k].p, events, take * sizeof(gx_event));
+      src = static_cast<const gx_event*>(ctx->stage[k].p);
+      HIPCHECK(hipMemcpyAsync(dst, src, take * sizeof(gx_event), hipMemcpyHostToDevice, ctx->side));
+      HIPCHECK(hipEventRecord(ctx->stageFree[k], ctx->side));
+    } else
+      HIPCHECK(hipMemcpyAsync(dst, src, take * sizeof(gx_event), hipMemcpyHostToDevice, ctx->side));
+    hipEvent_t ev = ready_event(ctx);
+    if (!ev) { ctx->err = "hipEventCreate failed"; return GX_ERR_DEVICE; }
+    HIPCHECK(hipEventRecord(ev, ctx->side));
+    ctx->segs.push_back({dst, take, ev});
+    ctx->evChunkFill += take;
+    if (ctx->evChunkFill == EV_CHUNK) { ctx->evChunkIdx++; ctx->evChunkFill = 0; }
+    events += take;
+    n -= take;
+  }
+  return GX_OK;
+}
+
+}  // namespace
 
 int gx_push_events(gx_ctx* ctx, const gx_event* events, size_t n) {
   if (!ctx || (ctx->phase != 1 && ctx->phase != 3)) return GX_ERR_ORDER;
   if (!n) return GX_OK;
   HIPCHECK(hipSetDevice(ctx->device));
-  // host events are staged contiguously in one device buffer (grown geometrically)
-  size_t need = (ctx->evCount + n) * sizeof(gx_event);
-  if (need > ctx->evBuf.cap) {
-    DevBuf nb;
-    HIPCHECK(nb.ensure(std::max(need, ctx->evBuf.cap * 2)));
-    if (ctx->evCount)
-      HIPCHECK(hipMemcpyAsync(nb.p, ctx->evBuf.p, ctx->evCount * sizeof(gx_event), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
-    ctx->evBuf = std::move(nb);
-  }
-  HIPCHECK(hipMemcpyAsync(ctx->evBuf.as<gx_event>() + ctx->evCount, events, n * sizeof(gx_event), hipMemcpyHostToDevice,
-                          ctx->stream));
-  HIPCHECK(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffer on return
-  ctx->evCount += n;
-  return GX_OK;
+  return push_host(ctx, events, n, false);
+}
+
+int gx_push_events_pinned(gx_ctx* ctx, const gx_event* events, size_t n) {
+  if (!ctx || (ctx->phase != 1 && ctx->phase != 3)) return GX_ERR_ORDER;
+  if (!n) return GX_OK;
+  HIPCHECK(hipSetDevice(ctx->device));
+  return push_host(ctx, events, n, true);
 }
 
 long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, const uint32_t* len, uint8_t* keep) {
@@ -1308,7 +1366,7 @@ long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, co
 
 int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n) {
   if (!ctx || (ctx->phase != 1 && ctx->phase != 3)) return GX_ERR_ORDER;
-  if (n) ctx->segs.push_back({d_events, n});
+  if (n) ctx->segs.push_back({d_events, n, nullptr});
   return GX_OK;
 }
 
@@ -1549,25 +1607,53 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
 
   if (ctx->par.qval_opt) {
     phase_begin(ctx, "bh");
-    const u32 cap = 1u << 22;
-    const bool fresh = ctx->bhKeys.cap < (size_t)cap * 4;
-    HIPCHECK(ctx->bhKeys.ensure((size_t)cap * 4));
-    HIPCHECK(ctx->bhLens.ensure((size_t)cap * 8));
-    HIPCHECK(ctx->bhQ.ensure((size_t)cap * 4));
-    HIPCHECK(ctx->bhOutKeys.ensure((size_t)cap * 4));
-    HIPCHECK(ctx->bhOutSlot.ensure((size_t)cap * 4));
-    if (fresh || ctx->bhDirty) {  // normally the table comes back clean from the previous call (k_bh_clear)
-      HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)cap * 4, s));
-      HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)cap * 8, s));
+    // The table of distinct p-values: open addressing, 2^bhCapLog slots.  It starts at 2^22 (16 MiB of keys: L2 /
+    // Infinity-Cache resident for the per-interval look-ups) and grows by 8x, for good, whenever an insertion
+    // gives up (ST_HASH_FULL: bh_global_add stops after BH_MAX_PROBE steps instead of crawling through a full
+    // table) -- the reference's chained hash (recordPval 277-295) has no limit either.
+    u32 cap = 1u << ctx->bhCapLog;
+    auto bh_table = [&](u32 c) -> int {
+      const bool fresh = ctx->bhKeys.cap < (size_t)c * 4;
+      HIPCHECK(ctx->bhKeys.ensure((size_t)c * 4));
+      HIPCHECK(ctx->bhLens.ensure((size_t)c * 8));
+      HIPCHECK(ctx->bhQ.ensure((size_t)c * 4));
+      HIPCHECK(ctx->bhOutKeys.ensure((size_t)c * 4));
+      HIPCHECK(ctx->bhOutSlot.ensure((size_t)c * 4));
+      if (fresh || ctx->bhDirty) {  // normally the table comes back clean from the previous call (k_bh_clear)
+        HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)c * 4, s));
+        HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)c * 8, s));
+      }
+      ctx->bhDirty = true;
+      return GX_OK;
+    };
+    auto bh_grow = [&]() -> int {
+      if (ctx->bhCapLog >= 28) {
+        ctx->err = "p-value table full";
+        return GX_ERR_MEM;
+      }
+      ctx->bhCapLog += 3;
+      cap = 1u << ctx->bhCapLog;
+      ctx->bhDirty = true;  // (whatever the failed attempt left behind is wiped)
+      return GX_OK;
+    };
+    BhTable T{};
+    u32 Dlocal = 0;
+    for (;;) {
+      if (int rc = bh_table(cap)) return rc;
+      HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
+      T = BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
+                  misc + M_BHCOUNT};
+      hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
+                         fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
+                         ctx->dStatus.as<u32>());
+      if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
+      if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;
+      Dlocal = ctx->mail->nMerged;
+      if (!(ctx->mail->status & ST_HASH_FULL)) break;
+      if (ctx->mail->status != ST_HASH_FULL) return status_to_rc(ctx, ctx->mail->status & ~ST_HASH_FULL);
+      HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 4, s));
+      if (int rc = bh_grow()) return rc;
     }
-    ctx->bhDirty = true;
-    HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
-    BhTable T{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
-              misc + M_BHCOUNT};
-    hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
-                       fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
-                       ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
     const bool multi = ctx->world > 1 || ctx->forceColl;
     u32 D = 0;
     if (multi && ctx->comm) {
@@ -1584,7 +1670,11 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       HIPCHECK(hipMemcpyAsync(ctx->mail->counts, ctx->dCounts.p, W * 4, hipMemcpyDeviceToHost, s));
       HIPCHECK(hipStreamSynchronize(s));
       u32 maxD = 1;
-      for (u32 k = 0; k < W; k++) maxD = std::max(maxD, ctx->mail->counts[k]);
+      size_t sumD = 0;
+      for (u32 k = 0; k < W; k++) {
+        maxD = std::max(maxD, ctx->mail->counts[k]);
+        sumD += ctx->mail->counts[k];
+      }
       const u32 Dl = ctx->mail->counts[ctx->rank];
       HIPCHECK(ctx->bhRecs.ensure((size_t)maxD * sizeof(BhRec)));
       HIPCHECK(ctx->dGather.ensure((size_t)maxD * W * sizeof(BhRec)));
@@ -1594,7 +1684,15 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                            ctx->bhRecs.as<BhRec>());
       r = api->allGather(ctx->bhRecs.p, ctx->dGather.p, (size_t)maxD * 2, ncclUint64, ctx->comm, s);
       if (r != ncclSuccess) { ctx->err = std::string("ncclAllGather: ") + api->getErrorString(r); return GX_ERR_DEVICE; }
-      hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);  // this rank's own entries out, everybody's in
+      // this rank's own entries out, everybody's in -- into a table that holds the union at a load of <= 1/4
+      if (sumD * 4 > cap) {
+        while (sumD * 4 > cap)
+          if (int rc = bh_grow()) return rc;
+        if (int rc = bh_table(cap)) return rc;
+        T = BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
+                    misc + M_BHCOUNT};
+      } else
+        hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
       HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
       hipLaunchKernelGGL(k_bh_insert_gathered, dim3(std::max(1u, std::min((maxD + 255) / 256, 256u)), std::min(W, 64u)), dim3(256),
                          0, s, ctx->dGather.as<BhRec>(), ctx->dCounts.as<u32>(), W, maxD, T, ctx->dStatus.as<u32>());
@@ -1602,9 +1700,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       HIPCHECK(hipStreamSynchronize(s));
       D = ctx->mail->D;
     } else {
-    HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    D = ctx->mail->D;
+    D = Dlocal;
     if (multi && ctx->allgather) {
       // the same exchange through the host program's callback (validation mode of the tests / bench.py)
       HIPCHECK(ctx->bhRecs.ensure((size_t)std::max(D, 1u) * sizeof(BhRec)));
@@ -1622,7 +1718,15 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
         ctx->err = "allgather callback failed";
         return GX_ERR_DEVICE;
       }
-      hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);  // this rank's own entries out, everybody's in
+      // this rank's own entries out, everybody's in -- into a table that holds the union at a load of <= 1/4
+      if (nAll * 4 > cap) {
+        while (nAll * 4 > cap)
+          if (int rc = bh_grow()) { free(all); return rc; }
+        if (int rc = bh_table(cap)) { free(all); return rc; }
+        T = BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
+                    misc + M_BHCOUNT};
+      } else
+        hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
       HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
       if (nAll) {
         HIPCHECK(ctx->bhRecs.ensure(nAll * sizeof(BhRec)));

@@ -278,9 +278,11 @@ struct BhTable {
   u32* counter;
 };
 
+constexpr u32 BH_MAX_PROBE = 4096;  // an insertion that has not found its slot by then reports the table full (the host grows it)
+
 __device__ __forceinline__ void bh_global_add(const BhTable& T, u32 key, u64 len, u32* st) {
   u32 h = bh_hash(key) & T.capMask;
-  for (u32 probe = 0; probe <= T.capMask; probe++) {
+  for (u32 probe = 0; probe <= T.capMask && probe < BH_MAX_PROBE; probe++) {
     u32 old = T.keys[h];
     if (old != key) {
       if (old != EMPTY_KEY) { h = (h + 1) & T.capMask; continue; }

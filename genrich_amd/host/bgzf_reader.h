@@ -248,6 +248,8 @@ class Input {
            h[14] == 2 && h[15] == 0;
   }
 
+  size_t members_ = 0;  // members handed to the pool so far
+
   void startWorkers(int threads) {
     depth_ = (size_t)threads * 4 + 4;
     for (int i = 0; i < threads; i++) workers_.emplace_back([this] { work(); });
@@ -257,17 +259,21 @@ class Input {
   bool enqueue() {
     uint8_t hbuf[12];
     const uint8_t* h;
+    // zlib's gz* reader, through which the reference reads, stops quietly at bytes that do not begin another
+    // gzip member once it has read one (trailing garbage after a valid file): end of stream here too
     if (map_) {
       if (mapPos_ == mapLen_) return false;
-      if (mapLen_ - mapPos_ < 12) return fail("not a BGZF block");
+      if (mapLen_ - mapPos_ < 12) return members_ ? false : fail("not a BGZF block");
       h = map_ + mapPos_;
     } else {
       size_t k = fread(hbuf, 1, 12, f_);
       if (k == 0) return false;
-      if (k != 12) return fail("not a BGZF block");
+      if (k != 12) return members_ ? false : fail("not a BGZF block");
       h = hbuf;
     }
-    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail("not a BGZF block");
+    if (h[0] != 0x1f || h[1] != 0x8b) return members_ ? false : fail("not a BGZF block");
+    if (h[2] != 8 || !(h[3] & 4)) return fail("not a BGZF block");
+    members_++;
     const size_t xlen = h[10] | (h[11] << 8);
     std::vector<uint8_t> xbuf;
     const uint8_t* extra;

@@ -55,6 +55,7 @@ _SIGS = {
     "gx_sample_begin": [C.c_void_p, C.c_int, C.c_void_p],
     "gx_push_events": [C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_push_events_device": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_push_events_pinned": [C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_sample_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "gx_sample_no_control": [C.c_void_p, C.POINTER(C.c_float)],
     "gx_pvalues": [C.c_void_p],
@@ -218,9 +219,11 @@ class Genrich:
         ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
         self._check(self.lib.gx_push_events(self.ctx, ev.ctypes.data, len(ev)))
 
-    def push_events_ptr(self, host_ptr, n):
-        """gx_push_events on a raw host pointer (e.g. pinned memory owned by the caller)."""
-        self._check(self.lib.gx_push_events(self.ctx, C.c_void_p(host_ptr), int(n)))
+    def push_events_ptr(self, host_ptr, n, pinned=False):
+        """gx_push_events on a raw host pointer; pinned=True: page-locked memory that stays untouched until
+        sample_end (gx_push_events_pinned: uploaded in place)."""
+        f = self.lib.gx_push_events_pinned if pinned else self.lib.gx_push_events
+        self._check(f(self.ctx, C.c_void_p(host_ptr), int(n)))
 
     def push_events_device(self, dev_ptr: int, n: int):
         """Events already resident in HBM (e.g. a torch tensor's data_ptr())."""

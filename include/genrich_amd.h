@@ -112,8 +112,15 @@ int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip,
  * is_ctrl = 1: start the matching control file (save must be NULL). */
 int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save);
 
-/* Host-resident events; copied before return (caller keeps ownership). */
+/* Host-resident events; consumed before return (the caller may reuse its buffer at once).  They go through
+ * two pinned staging buffers and asynchronous copies on a side stream: the call does not wait for the
+ * upload, so the host parses the next batch while this one travels, and gx_sample_end starts its first
+ * kernel on the pieces that have arrived while the rest is still on its way. */
 int gx_push_events(gx_ctx* ctx, const gx_event* events, size_t n);
+
+/* The same for a caller whose buffer is page-locked (hipHostMalloc / hipHostRegister) and stays untouched
+ * until gx_sample_end: the upload reads it in place, no staging copy. */
+int gx_push_events_pinned(gx_ctx* ctx, const gx_event* events, size_t n);
 
 /* Events already resident in device memory (HIP path only; the pointer must stay
  * valid until gx_sample_end). */

@@ -614,3 +614,16 @@ def test_atac_geometry_with_multimap_weights(qval):
     o, h, so, sh = run_both(case, params)
     assert_same_run(o, h, so, sh, case)
     assert h.n_peaks > 50
+
+
+def test_bh_table_grows_when_full(monkeypatch):
+    """The table of distinct p-values starts small here (2^6 slots) and must grow until the run's few thousand
+    distinct values fit -- same q-values, same peaks as the oracle."""
+    monkeypatch.setenv("GX_BH_CAPLOG", "6")
+    lens = [400_000, 150_000]
+    tr = synth.make_fragments(lens, 120_000, 41, peak_every=20_000, tower_every=90_000, frac_tower=0.1)
+    ct = synth.make_fragments(lens, 90_000, 42, uniform_only=True)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=ct)])
+    o, h, so, sh = run_both(case, B.make_params(pq=0.2, qval=True, min_auc=20.0))
+    assert_same_run(o, h, so, sh, case)
+    assert h.n_peaks > 0

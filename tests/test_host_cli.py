@@ -307,3 +307,21 @@ def test_cli_bam_reference_name_without_nul(tmp_path):
         open(p, "wb").write(gz(raw))
         res = subprocess.run([_binary(), "--events-only", "-t", p, "-b", str(tmp_path / "e.bed")], capture_output=True, text=True)
         assert res.returncode == 1 and "Cannot parse BAM file" in res.stderr, res.stderr
+
+
+def test_cli_bgzf_trailing_garbage_is_end_of_stream(tmp_path):
+    """Bytes after the last BGZF member that do not begin another gzip member end the stream quietly, as
+    with zlib's reader (through which the reference reads): same events, exit status 0."""
+    cases, mg = _cases()
+    name = "dups_x_bam"
+    args = _write_inputs(cases[name], mg, str(tmp_path / "in"))
+    for i, a in enumerate(args):
+        for p in (a.split(",") if i and args[i - 1] in ("-t", "-c") else []):
+            if p != "null":
+                raw = gzip.decompress(open(p, "rb").read())
+                open(p, "wb").write(_bgzf(raw) + b"trailing bytes that are no gzip member")
+    a = [x for x in args if x != "-X"]
+    bed = str(tmp_path / "events.bed")
+    res = subprocess.run([_binary(), "--events-only", "--threads", "3", "-b", bed] + a, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
