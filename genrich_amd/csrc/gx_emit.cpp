@@ -4,6 +4,7 @@
 //   printPeak       Genrich.c:885-909      printLogHeader 674-717
 //   printInterval   770-803                printIntervalN 724-763
 //   printPileHeader 1680-1691              printPile      1697-1715
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -37,13 +38,24 @@ int fetch(gx_ctx* ctx, int which, int chrom, Iv& iv, bool piles, bool qv) {
 
 extern "C" {
 
-// -o: one line per peak; peak_N numbers the peaks in output order (callPeaks' `count`)
-int gx_write_narrowpeak(gx_ctx* ctx, const char* const* names, FILE* out) {
-  size_t n = 0;
-  int rc = gx_peak_count(ctx, &n);
-  if (rc) return rc;
-  std::vector<gx_peak> pk(n ? n : 1);
-  if (n && (rc = gx_get_peaks(ctx, pk.data(), n))) return rc;
+// -o: one line per peak; peak_N numbers the peaks in output order (callPeaks' `count`).  Several contexts
+// (chromosomes sharded over GPUs): their peak lists are merged into chromosome-table order, then position --
+// the order in which the reference meets them (986, 925).
+int gx_write_narrowpeak_group(gx_ctx* const* ctxs, int n_ctx, const char* const* names, FILE* out) {
+  std::vector<gx_peak> pk;
+  for (int g = 0; g < n_ctx; g++) {
+    size_t k = 0;
+    int rc = gx_peak_count(ctxs[g], &k);
+    if (rc) return rc;
+    const size_t at = pk.size();
+    pk.resize(at + k);
+    if (k && (rc = gx_get_peaks(ctxs[g], pk.data() + at, k))) return rc;
+  }
+  if (n_ctx > 1)
+    std::stable_sort(pk.begin(), pk.end(), [](const gx_peak& a, const gx_peak& b) {
+      return a.chrom != b.chrom ? a.chrom < b.chrom : a.start < b.start;
+    });
+  const size_t n = pk.size();
   for (size_t i = 0; i < n; i++) {
     const gx_peak& k = pk[i];
     long start = (long)k.start, end = (long)k.end;
@@ -61,15 +73,17 @@ int gx_write_narrowpeak(gx_ctx* ctx, const char* const* names, FILE* out) {
   return GX_OK;
 }
 
-// -k for replicate `rep`
-int gx_write_pile(gx_ctx* ctx, int rep, const char* const* names, int n_chrom, const char* expt_name,
-                  const char* ctrl_name, FILE* out) {
+int gx_write_narrowpeak(gx_ctx* ctx, const char* const* names, FILE* out) { return gx_write_narrowpeak_group(&ctx, 1, names, out); }
+
+// -k for replicate `rep` (owner[c] = index into ctxs of the context that computed chromosome c; NULL: ctxs[0])
+int gx_write_pile_group(gx_ctx* const* ctxs, const int* owner, int rep, const char* const* names, int n_chrom,
+                        const char* expt_name, const char* ctrl_name, FILE* out) {
   fprintf(out, "# experimental file: %s; control file: %s\n", expt_name,
           ctrl_name && strcmp(ctrl_name, "null") ? ctrl_name : "NA");
   fprintf(out, "chr\tstart\tend\texperimental\tcontrol\t-log(p)\n");
   Iv iv;
   for (int c = 0; c < n_chrom; c++) {
-    int rc = fetch(ctx, rep, c, iv, true, false);
+    int rc = fetch(ctxs[owner ? owner[c] : 0], rep, c, iv, true, false);
     if (rc) return rc;
     uint32_t start = 0;
     for (size_t m = 0; m < iv.n; m++) {
@@ -83,10 +97,15 @@ int gx_write_pile(gx_ctx* ctx, int rep, const char* const* names, int n_chrom, c
   return GX_OK;
 }
 
+int gx_write_pile(gx_ctx* ctx, int rep, const char* const* names, int n_chrom, const char* expt_name,
+                  const char* ctrl_name, FILE* out) {
+  return gx_write_pile_group(&ctx, nullptr, rep, names, n_chrom, expt_name, ctrl_name, out);
+}
+
 // -f after gx_find_peaks.  n_rep = number of replicates; peaks_opt = 0 for -X (logIntervals 837).
 // thr / qval_opt as given to gx_create.
-int gx_write_log(gx_ctx* ctx, int n_rep, const char* const* names, int n_chrom, int qval_opt, int peaks_opt, float thr,
-                 FILE* out) {
+int gx_write_log_group(gx_ctx* const* ctxs, const int* owner, int n_rep, const char* const* names, int n_chrom, int qval_opt,
+                       int peaks_opt, float thr, FILE* out) {
   const bool multi = n_rep > 1;
   if (multi) {
     fprintf(out, "chr\tstart\tend");
@@ -100,6 +119,7 @@ int gx_write_log(gx_ctx* ctx, int n_rep, const char* const* names, int n_chrom, 
   Iv fin;
   std::vector<Iv> reps(multi ? n_rep : 0);
   for (int c = 0; c < n_chrom; c++) {
+    gx_ctx* ctx = ctxs[owner ? owner[c] : 0];
     int rc = fetch(ctx, GX_IV_FINAL, c, fin, !multi, qval_opt != 0);
     if (rc) return rc;
     if (!fin.n) continue;
@@ -146,6 +166,11 @@ int gx_write_log(gx_ctx* ctx, int n_rep, const char* const* names, int n_chrom, 
 }
 
 // path-taking conveniences for FFI callers without a FILE*
+int gx_write_log(gx_ctx* ctx, int n_rep, const char* const* names, int n_chrom, int qval_opt, int peaks_opt, float thr,
+                 FILE* out) {
+  return gx_write_log_group(&ctx, nullptr, n_rep, names, n_chrom, qval_opt, peaks_opt, thr, out);
+}
+
 int gx_write_narrowpeak_path(gx_ctx* ctx, const char* const* names, const char* path) {
   FILE* f = fopen(path, "w");
   if (!f) return GX_ERR_ORDER;

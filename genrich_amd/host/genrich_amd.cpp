@@ -16,6 +16,11 @@
 //   --threads N     threads that inflate BGZF (BAM, bgzip-ped SAM) input; default min(8, cores)
 //   (environment: GENRICH_HOST_PROF=1 prints the CPU time of the parsing thread after the last input)
 //   --events-only   parse and write the -b file without touching a GPU (diagnostics)
+//   --device N      HIP device ordinal (default 0)
+//   --devices LIST  several GPUs of one node, e.g. 0-7 or 0,2,5: chromosomes are sharded over them by length, one
+//                   library context and one host thread per GPU, RCCL inside the library for the two genome-wide
+//                   exchanges, outputs identical to a single-GPU run (a device named twice, e.g. 0,0, runs the
+//                   same protocol through host callbacks: the test mode for a single GPU)
 #include <getopt.h>
 #include <zlib.h>
 
@@ -30,6 +35,8 @@
 #include <map>
 #include <string>
 #include <tuple>
+#include <pthread.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/genrich_amd.h"
@@ -117,14 +124,70 @@ struct Opts {
        qvalOpt = false, dupsOpt = false, peaksOpt = true, peaksOnly = false, sortOpt = true, verbose = false,
        eventsOnly = false;
   int device = 0;
+  std::vector<int> devices;  // --devices a,b,...: one context per GPU, chromosomes sharded by length
 };
+
+// ---- several GPUs of one node -------------------------------------------------------
+// One library context per device, chromosomes dealt out by longest-processing-time bin packing; every event
+// goes to the context that owns its chromosome; gx_sample_end / gx_pvalues / gx_find_peaks run on one host
+// thread per device because they contain the run's collectives (fragLen sums, the BH table): RCCL inside the
+// library when the devices are distinct, in-process callbacks when a device is named twice (a test on one GPU).
+struct Devs {
+  std::vector<gx_ctx*> ctx;
+  std::vector<int> owner;                       // chromosome -> index into ctx
+  std::vector<std::vector<gx_event>> buf;       // events on their way to each context
+  // in-process collectives (callback mode)
+  pthread_barrier_t bar;
+  bool barInit = false;
+  std::vector<std::vector<int64_t>> red;
+  std::vector<const void*> gatherPtr;
+  std::vector<size_t> gatherN;
+  struct User { Devs* d; int rank; };
+  std::vector<User> users;
+  size_t n() const { return ctx.size(); }
+};
+
+int devsAllreduce(int64_t* buf, size_t n, void* user) {
+  Devs::User* u = static_cast<Devs::User*>(user);
+  Devs& D = *u->d;
+  D.red[u->rank].assign(buf, buf + n);
+  pthread_barrier_wait(&D.bar);
+  for (size_t k = 0; k < n; k++) {
+    int64_t sum = 0;
+    for (size_t r = 0; r < D.n(); r++) sum += D.red[r][k];
+    buf[k] = sum;
+  }
+  pthread_barrier_wait(&D.bar);
+  return 0;
+}
+
+int devsAllgather(const void* local, size_t nLocal, void** out, size_t* nOut, void* user) {
+  Devs::User* u = static_cast<Devs::User*>(user);
+  Devs& D = *u->d;
+  D.gatherPtr[u->rank] = local;
+  D.gatherN[u->rank] = nLocal;
+  pthread_barrier_wait(&D.bar);
+  size_t total = 0;
+  for (size_t r = 0; r < D.n(); r++) total += D.gatherN[r];
+  char* all = static_cast<char*>(malloc(std::max<size_t>(16, total * 16)));
+  size_t at = 0;
+  for (size_t r = 0; r < D.n(); r++) {
+    if (D.gatherN[r]) memcpy(all + at * 16, D.gatherPtr[r], D.gatherN[r] * 16);
+    at += D.gatherN[r];
+  }
+  *out = all;
+  *nOut = total;
+  pthread_barrier_wait(&D.bar);
+  return 0;
+}
 
 struct State {
   Opts o;
   std::vector<Chrom> chrom;
   std::vector<std::string> xchr;
   std::vector<BedRec> xbed;
-  gx_ctx* gx = nullptr;
+  gx_ctx* gx = nullptr;      // the (first) device context; nullptr with --events-only
+  Devs devs;                 // all of them
   bool tableFrozen = false;  // the device already holds the chromosome table
   std::unique_ptr<gxhost::Input> stdinIn;  // '-' can be opened once: its header pre-scan is replayed to the real pass
   bool sampleOpen = false;   // gx_sample_begin done for the file being read
@@ -138,10 +201,40 @@ struct State {
   uint64_t errCount = 0;
 };
 
-void check(State& S, int rc) {
+void check(State& S, int rc, gx_ctx* which = nullptr) {
   if (rc == GX_OK) return;
-  std::string detail = S.gx ? gx_last_error(S.gx) : "";
+  gx_ctx* g = which ? which : S.gx;
+  std::string detail = g ? gx_last_error(g) : "";
   die(detail.empty() ? std::string(gx_strerror(rc)) : detail, "");
+}
+
+// f(context index) on every device context: in place for one, one host thread each for several (the calls
+// that contain collectives must run side by side); the first failure ends the program like any other
+template <typename F>
+void onEachDevice(State& S, F f) {
+  Devs& D = S.devs;
+  if (D.n() == 1) {
+    check(S, f(0), D.ctx[0]);
+    return;
+  }
+  std::vector<int> rc(D.n(), GX_OK);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < D.n(); g++) th.emplace_back([&, g] { rc[g] = f((int)g); });
+  for (auto& t : th) t.join();
+  for (size_t g = 0; g < D.n(); g++) check(S, rc[g], D.ctx[g]);
+}
+
+// the events gathered so far go to the contexts that own their chromosomes
+void flushEvents(State& S) {
+  Devs& D = S.devs;
+  if (D.n() == 1) {
+    if (!S.buf.empty()) check(S, gx_push_events(S.gx, S.buf.data(), S.buf.size()));
+    return;
+  }
+  for (auto& b : D.buf) b.clear();
+  for (const gx_event& e : S.buf) D.buf[D.owner[e.chrom]].push_back(e);
+  for (size_t g = 0; g < D.n(); g++)
+    if (!D.buf[g].empty()) check(S, gx_push_events(D.ctx[g], D.buf[g].data(), D.buf[g].size()), D.ctx[g]);
 }
 
 void mergeBed(Chrom& c, const std::vector<BedRec>& xbed, bool verbose) {
@@ -226,7 +319,7 @@ uint32_t saveInterval(State& S, int ci, int64_t start, int64_t end, const char* 
   }
   S.buf.push_back(gx_event{(uint32_t)ci, (uint32_t)start, (uint32_t)end, count});
   if (S.buf.size() >= (1u << 20)) {
-    if (S.gx && S.sampleOpen) check(S, gx_push_events(S.gx, S.buf.data(), S.buf.size()));
+    if (S.gx && S.sampleOpen) flushEvents(S);
     if (!S.gx || S.sampleOpen) S.buf.clear();  // --events-only keeps nothing
   }
   if (S.bedOpt)
@@ -749,7 +842,7 @@ void openSample(State& S) {
   if (!S.gx) return;
   std::vector<uint8_t> save(S.chrom.size());
   for (size_t k = 0; k < S.chrom.size(); k++) save[k] = S.chrom[k].save;
-  check(S, gx_sample_begin(S.gx, S.ctrl ? 1 : 0, S.ctrl ? nullptr : save.data()));
+  for (gx_ctx* g : S.devs.ctx) check(S, gx_sample_begin(g, S.ctrl ? 1 : 0, S.ctrl ? nullptr : save.data()), g);
 }
 
 struct ReadSet {
@@ -1176,7 +1269,29 @@ void sendChroms(State& S) {
     bed[i] = S.chrom[i].bed.data();
     bedLen[i] = (int32_t)S.chrom[i].bed.size();
   }
-  check(S, gx_set_chroms(S.gx, (int)n, len.data(), skip.data(), bed.data(), bedLen.data()));
+  Devs& D = S.devs;
+  for (gx_ctx* g : D.ctx) check(S, gx_set_chroms(g, (int)n, len.data(), skip.data(), bed.data(), bedLen.data()), g);
+  D.owner.assign(n, 0);
+  if (D.n() > 1) {
+    // longest-processing-time bin packing of the chromosomes by length (the reference's per-chromosome loops,
+    // Genrich.c:2172, 1729, 987, are independent): hg38 over 8 GPUs -> heaviest share 400 of 3088 Mbp
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return len[a] > len[b]; });
+    std::vector<uint64_t> load(D.n(), 0);
+    for (size_t i : order) {
+      size_t best = 0;
+      for (size_t g = 1; g < D.n(); g++)
+        if (load[g] < load[best]) best = g;
+      D.owner[i] = (int)best;
+      load[best] += len[i];
+    }
+    for (size_t g = 0; g < D.n(); g++) {
+      std::vector<uint8_t> owned(n);
+      for (size_t i = 0; i < n; i++) owned[i] = D.owner[i] == (int)g;
+      check(S, gx_set_owned(D.ctx[g], owned.data()), D.ctx[g]);
+    }
+  }
 }
 
 void loadBED(State& S, const char* files) {  // loadBED 5187-5238
@@ -1375,7 +1490,8 @@ void usage() {
   fprintf(stderr,
           "Usage: genrich-amd  -t <file>  -o <file>  [optional arguments]\n"
           "  (same options as Genrich v0.6.2: -t -c -o -f -k -b -z -y -w -x -j -d -D -e -E -m -s\n"
-          "   -r -R -p -q -a -l -g -X -P -S -L -v -V)\n");
+          "   -r -R -p -q -a -l -g -X -P -S -L -v -V)\n"
+          "  --device N | --devices 0-7   GPU(s) to use;  --threads N   BGZF inflate threads\n");
   exit(EXIT_FAILURE);
 }
 
@@ -1389,6 +1505,7 @@ int main(int argc, char** argv) {
                                      {"version", no_argument, nullptr, 'V'},
                                      {"events-only", no_argument, nullptr, 1000},
                                      {"device", required_argument, nullptr, 1001},
+                                     {"devices", required_argument, nullptr, 1003},
                                      {"threads", required_argument, nullptr, 1002},
                                      {nullptr, 0, nullptr, 0}};
   {  // BGZF inflate threads: --threads N, else GENRICH_THREADS, else up to 8 of the machine's cores
@@ -1432,6 +1549,18 @@ int main(int argc, char** argv) {
       case 1000: o.eventsOnly = true; break;
       case 1001: o.device = getInt(optarg); break;
       case 1002: g_threads = getInt(optarg); break;
+      case 1003: {  // --devices 0,1,2 or 0-7
+        std::string list(optarg);
+        for (char* t = strtok(list.data(), ","); t; t = strtok(nullptr, ",")) {
+          const char* dash = strchr(t, '-');
+          if (dash && dash != t) {
+            const int a = atoi(t), b = atoi(dash + 1);
+            for (int d = a; d <= b; d++) o.devices.push_back(d);
+          } else
+            o.devices.push_back(getInt(t));
+        }
+        break;
+      }
       case 'h': usage();
       default: exit(EXIT_FAILURE);
     }
@@ -1477,9 +1606,45 @@ int main(int argc, char** argv) {
     par.max_gap = o.maxGap;
     par.device = o.device;
     par.genome_len = o.genomeLen;
-    int rc = gx_create(&S.gx, &par);
-    if (rc) die(S.gx ? gx_last_error(S.gx) : gx_strerror(rc), "");
-    check(S, gx_set_keep_pileups(S.gx, o.logFile || o.pileFile));  // only -f / -k print pileup values
+    if (o.devices.empty()) o.devices.push_back(o.device);
+    if (o.devices.size() > 64) die("", "at most 64 devices");
+    Devs& D = S.devs;
+    for (int d : o.devices) {
+      par.device = d;
+      gx_ctx* g = nullptr;
+      int rc = gx_create(&g, &par);
+      if (rc) die(g ? gx_last_error(g) : gx_strerror(rc), "");
+      check(S, gx_set_keep_pileups(g, o.logFile || o.pileFile), g);  // only -f / -k print pileup values
+      D.ctx.push_back(g);
+    }
+    S.gx = D.ctx[0];
+    D.buf.resize(D.n());
+    if (D.n() > 1) {
+      const int W = (int)D.n();
+      bool distinct = true;
+      for (int a = 0; a < W; a++)
+        for (int b = a + 1; b < W; b++) distinct = distinct && o.devices[a] != o.devices[b];
+      if (distinct) {
+        // the library's own collectives: one RCCL communicator over the devices (xGMI), joined side by side
+        char id[128];
+        int rc = gx_rccl_unique_id(id, sizeof id);
+        if (rc) die(gx_strerror(rc), "");
+        onEachDevice(S, [&](int g) { return gx_set_rccl(D.ctx[g], g, W, id); });
+      } else {
+        // a device named twice (RCCL wants one rank per GPU): the exchanges go through host callbacks between
+        // the threads -- the library's validation mode, here for tests on a single GPU
+        pthread_barrier_init(&D.bar, nullptr, (unsigned)W);
+        D.barInit = true;
+        D.red.resize(W);
+        D.gatherPtr.assign(W, nullptr);
+        D.gatherN.assign(W, 0);
+        D.users.resize(W);
+        for (int g = 0; g < W; g++) {
+          D.users[g] = Devs::User{&D, g};
+          check(S, gx_set_collectives(D.ctx[g], g, W, devsAllreduce, devsAllgather, &D.users[g]), D.ctx[g]);
+        }
+      }
+    }
   }
 
   // loop over the comma-separated treatment / control lists (runProgram 5455-5585)
@@ -1501,7 +1666,7 @@ int main(int argc, char** argv) {
       if (i && !filename) {
         if (o.verbose) fprintf(stderr, "- control file #%d not provided -\n", S.sample);
         float lambda = 0;
-        if (S.gx) check(S, gx_sample_no_control(S.gx, &lambda));
+        for (gx_ctx* g : S.devs.ctx) check(S, gx_sample_no_control(g, &lambda), g);  // (lambda is genome-wide: the same everywhere)
         if (o.verbose && S.gx) fprintf(stderr, "  Background pileup value: %f\n", lambda);
         break;
       }
@@ -1529,13 +1694,19 @@ int main(int argc, char** argv) {
       checkIn(in);
       if (!isStdin) in.close();
       openSample(S);  // a file without a single usable record still opens (and closes) its sample
-      if (S.gx && !S.buf.empty()) check(S, gx_push_events(S.gx, S.buf.data(), S.buf.size()));
+      if (S.gx) flushEvents(S);
       S.buf.clear();
       if (o.verbose) logCounts(S, C, bam);
       if (S.gx) {
         double fragLen = 0;
         float lambda = 0, factor = 0;
-        check(S, gx_sample_end(S.gx, &fragLen, &lambda, &factor));
+        onEachDevice(S, [&](int g) {
+          double fl = 0;
+          float la = 0, fa = 0;
+          const int rc = gx_sample_end(S.devs.ctx[g], &fl, &la, &fa);
+          if (g == 0) { fragLen = fl; lambda = la; factor = fa; }  // (genome-wide scalars: the same on every device)
+          return rc;
+        });
         if (i && o.verbose) {
           fprintf(stderr, "  Background pileup value: %f\n", lambda);
           fprintf(stderr, "  Scaling factor for control pileup: %f\n", factor);
@@ -1543,7 +1714,7 @@ int main(int argc, char** argv) {
         }
       }
     }
-    if (S.gx) check(S, gx_pvalues(S.gx));
+    if (S.gx) onEachDevice(S, [&](int g) { return gx_pvalues(S.devs.ctx[g]); });
     S.sample++;
   }
   if (S.bedOpt) closeOut(S.bed);
@@ -1553,7 +1724,12 @@ int main(int argc, char** argv) {
 
   size_t nPeaks = 0;
   uint64_t genomeLen = 0, peakBP = 0;
-  check(S, gx_find_peaks(S.gx, &nPeaks, &genomeLen, &peakBP));
+  {
+    std::vector<size_t> np(S.devs.n(), 0);
+    std::vector<uint64_t> bp(S.devs.n(), 0);
+    onEachDevice(S, [&](int g) { return gx_find_peaks(S.devs.ctx[g], &np[g], g == 0 ? &genomeLen : nullptr, &bp[g]); });
+    for (size_t g = 0; g < S.devs.n(); g++) { nPeaks += np[g]; peakBP += bp[g]; }
+  }
   if (o.verbose) {  // findPeaks 1103-1117, 1130-1132
     if (o.peaksOpt) {
       fprintf(stderr, "Peak-calling parameters:\n");
@@ -1574,21 +1750,22 @@ int main(int argc, char** argv) {
     Out pile = openWrite(o.pileFile, o.gzOut);
     for (int r = 0; r < S.sample; r++) {
       const char* cn = !o.ctrlFile ? nullptr : ((size_t)r < cFiles.size() ? cFiles[r].c_str() : nullptr);
-      check(S, gx_write_pile(S.gx, r, names.data(), nChrom, tFiles[r].c_str(), cn, pile.f));
+      check(S, gx_write_pile_group(S.devs.ctx.data(), S.devs.owner.data(), r, names.data(), nChrom, tFiles[r].c_str(), cn, pile.f));
     }
     closeOut(pile);
   }
   if (o.peaksOpt) {
     Out out = openWrite(o.outFile, o.gzOut);
-    check(S, gx_write_narrowpeak(S.gx, names.data(), out.f));
+    check(S, gx_write_narrowpeak_group(S.devs.ctx.data(), (int)S.devs.n(), names.data(), out.f));
     closeOut(out);
     if (o.verbose) fprintf(stderr, "Peaks identified: %d (%ldbp)\n", (int)nPeaks, (long)peakBP);
   }
   if (o.logFile) {
     Out log = openWrite(o.logFile, o.gzOut);
-    check(S, gx_write_log(S.gx, S.sample, names.data(), nChrom, o.qvalOpt, o.peaksOpt, thr, log.f));
+    check(S, gx_write_log_group(S.devs.ctx.data(), S.devs.owner.data(), S.sample, names.data(), nChrom, o.qvalOpt, o.peaksOpt, thr,
+                                log.f));
     closeOut(log);
   }
-  gx_destroy(S.gx);
+  for (gx_ctx* g : S.devs.ctx) gx_destroy(g);
   return EXIT_SUCCESS;
 }

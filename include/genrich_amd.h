@@ -177,6 +177,14 @@ int gx_write_pile(gx_ctx* ctx, int rep, const char* const* names, int n_chrom, c
  *     peaks_opt = 0 is -X (logIntervals 837-878) */
 int gx_write_log(gx_ctx* ctx, int n_rep, const char* const* names, int n_chrom, int qval_opt, int peaks_opt,
                  float thr, FILE* out);
+/* The same for a run whose chromosomes are sharded over several contexts (one per GPU): peaks of all
+ * contexts in chromosome-table order (peak_N numbering, Genrich.c:986, 925); owner[c] = index into ctxs of
+ * the context that computed chromosome c. */
+int gx_write_narrowpeak_group(gx_ctx* const* ctxs, int n_ctx, const char* const* names, FILE* out);
+int gx_write_pile_group(gx_ctx* const* ctxs, const int* owner, int rep, const char* const* names, int n_chrom,
+                        const char* expt_name, const char* ctrl_name, FILE* out);
+int gx_write_log_group(gx_ctx* const* ctxs, const int* owner, int n_rep, const char* const* names, int n_chrom,
+                       int qval_opt, int peaks_opt, float thr, FILE* out);
 int gx_write_narrowpeak_path(gx_ctx* ctx, const char* const* names, const char* path);
 int gx_write_pile_path(gx_ctx* ctx, int rep, const char* const* names, int n_chrom, const char* expt_name,
                        const char* ctrl_name, const char* path, int append);

@@ -325,3 +325,26 @@ def test_cli_bgzf_trailing_garbage_is_end_of_stream(tmp_path):
     res = subprocess.run([_binary(), "--events-only", "--threads", "3", "-b", bed] + a, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ctrl_q", "reps3", "multimap", "bedx", "basic", "ctrl_only_chrom"])
+def test_cli_two_contexts_one_gpu_equal_one(name):
+    """--devices 0,0: two library contexts on the one GPU of the test box, chromosomes sharded between them,
+    the collectives through the host program's in-process callbacks (RCCL wants distinct devices).  All
+    outputs must be the reference's bytes, as with one context."""
+    cases, mg = _cases()
+    case = cases[name]
+    meta, _, _, _ = G.load_case(name)
+    tmp = meta["tmp_prefix"].rstrip("/")  # same input paths as when the fixture was made (the -k header names them)
+    args = _write_inputs(case, mg, tmp)
+    out = os.path.join(tmp, "cli2_out")
+    cmd = [_binary(), "--devices", "0,0", "-f", out + ".log", "-k", out + ".pile"] + args
+    if "-X" not in case["args"]:
+        cmd += ["-o", out + ".narrowPeak"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert open(out + ".pile", "rb").read() == G.read_gz(name, "out.pile")
+    assert open(out + ".log", "rb").read() == G.read_gz(name, "out.log")
+    if "-X" not in case["args"]:
+        assert open(out + ".narrowPeak", "rb").read() == G.read_gz(name, "out.narrowPeak")
