@@ -164,6 +164,7 @@ struct gx_ctx {
   struct Stream {  // one record stream of the bucket sort
     DevBuf a, pool, pt, cursor, sbOff;  // level-2 output; level-1 pages, page table, list cursors; super-bucket offsets
   };
+  size_t b2LdsSet = 0;          // dynamic LDS the level-2 kernel was last configured for
   u32 ptJmax = 16;              // pages per (XCD class, super-bucket) list; grown after ST_PT_FULL
   DevBuf lbIv;
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
@@ -181,6 +182,7 @@ struct gx_ctx {
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp, bhRecs;
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
+  long long satDropped = 0;     // ... which dropped this many of them (gx_saturation_dropped)
   bool bhDirty = false;         // the BH table was left with entries (an error path): wipe it before use
   u32 bhCapLog = 22;            // log2 of its slots (grows by 3 after ST_HASH_FULL)
   // sweep
@@ -512,18 +514,17 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     BinScan bs{{SS.cursor.as<u32>(), SE.cursor.as<u32>(), SF.cursor.as<u32>()}, {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()}};
     hipLaunchKernelGGL(k_scan_bins, dim3(3), dim3(1024), 0, s, bs, nL1);
     // level 2: one workgroup per super-bucket
-    const size_t lds32 = b2_lds_bytes<u32>(1u << ctx->sbShift), lds64 = b2_lds_bytes<u64>(1u << ctx->sbShift);
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2p<u32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2p<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
-    if (unit32 && nEv) {
-      hipLaunchKernelGGL((k_bucket2p<u32>), dim3(std::max(1u, nL1)), dim3(B2_NT), lds32, s, PG3[0], SS.a.as<uint16_t>(),
-                         SS.sbOff.as<u32>(), nL1, ctx->sbShift, nTiles, ctx->tileCnt[0].as<u32>(), ctx->tileWsum.as<int>());
-      hipLaunchKernelGGL((k_bucket2p<u32>), dim3(std::max(1u, nL1)), dim3(B2_NT), lds32, s, PG3[1], SE.a.as<uint16_t>(),
-                         SE.sbOff.as<u32>(), nL1, ctx->sbShift, nTiles, ctx->tileCnt[1].as<u32>(), ctx->tileWsum.as<int>());
+    const size_t lds2 = std::max(b2_lds_bytes<u32>(1u << ctx->sbShift), b2_lds_bytes<u64>(1u << ctx->sbShift));
+    if (ctx->b2LdsSet != lds2) {
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2p), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      ctx->b2LdsSet = lds2;
     }
     // (the F stream: multimapped reads, or everything beyond 4.29 Gbp; a run without them finds every bin empty)
-    hipLaunchKernelGGL((k_bucket2p<u64>), dim3(std::max(1u, nL1)), dim3(B2_NT), lds64, s, PG3[2], SF.a.as<u64>(),
-                       SF.sbOff.as<u32>(), nL1, ctx->sbShift, nTiles, ctx->tileCnt[2].as<u32>(), ctx->tileWsum.as<int>());
+    Bucket2Jobs BJ{{{PG3[0], SS.a.p, SS.sbOff.as<u32>(), ctx->tileCnt[0].as<u32>()},
+                    {PG3[1], SE.a.p, SE.sbOff.as<u32>(), ctx->tileCnt[1].as<u32>()},
+                    {PG3[2], SF.a.p, SF.sbOff.as<u32>(), ctx->tileCnt[2].as<u32>()}}};
+    hipLaunchKernelGGL(k_bucket2p, dim3(std::max(1u, nL1), 3), dim3(B2_NT), lds2, s, BJ, nL1, ctx->sbShift, nTiles,
+                       ctx->tileWsum.as<int>());
     if (int rc__ = dbg_sync(ctx, "k_bucket2p")) return rc__;
     if (getenv("GX_DEBUG_SORT")) {
       HIPCHECK(hipStreamSynchronize(s));
@@ -624,7 +625,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ff, acc,
                        ctx->world > 1 || ctx->forceColl ? ctx->dColl.as<long long>() : (long long*)nullptr,
                        ctx->nWide.as<u32>() + 1, ctx->dStatus.as<u32>(), ctx->dChrom.as<DChrom>(), nChrom,
-                       out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV);
+                       out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV, ds, isCtrl);
   }
   if (int rc__ = dbg_sync(ctx, "k_frag")) return rc__;
   out.packed = false;
@@ -675,16 +676,17 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     ctx->err = "several ranks but no collectives (gx_set_rccl / gx_set_collectives)";
     return GX_ERR_ORDER;
   }
-  hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>(), (const long long*)dcoll);
-  if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
+  if (multi) {  // (one rank: k_frag_select has done it)
+    hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>(), (const long long*)dcoll);
+    if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
+  }
   // lambda (and with a control the factor) is final: build the p-value tables now, so that the values the
   // host has to re-evaluate (risky ones) travel with the synchronisation that returns the scalars
   if (!isCtrl) {
-    hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ds, ctx->pvLut.as<float>(), ctx->dRisk.as<RiskBuf>(),
-                       ctx->dDeep.as<DeepTab>());
     PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>()};
-    hipLaunchKernelGGL(k_deep_risky, dim3(64), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(), ds,
-                       ctx->dRisk.as<RiskBuf>());
+    hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256 + DEEP_BLOCKS), dim3(256), 0, s, ds, ctx->pvLut.as<float>(),
+                       ctx->dRisk.as<RiskBuf>(), ctx->dDeep.as<DeepTab>(), pin, ctx->fragSum.as<FragFix>(),
+                       ctx->fragList.as<u32>());
   } else {
     hipLaunchKernelGGL(k_pair_tabs, dim3(PAIR_LUT / 256), dim3(256), 0, s, ds, ctx->pairLogE.as<double>(),
                        ctx->pairCtab.as<CtrlEntry>());
@@ -726,6 +728,7 @@ int drop_saturated(gx_ctx* ctx, int isCtrl) {
   for (u32 i = 0; i < ctx->nChrom; i++) len[i] = ctx->hChrom[i].tileBase == NULL_TILE ? 0u : ctx->len[i];
   std::vector<uint8_t> keep(total);
   const long long dropped = gxsat::filter(all.data(), total, (int)ctx->nChrom, len.data(), keep.data());
+  ctx->satDropped = dropped > 0 ? dropped : 0;
   size_t kept = 0;
   if (dropped > 0) {
     for (size_t i = 0; i < total; i++)
@@ -1288,6 +1291,7 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
   ctx->segs.clear();
   ctx->evChunkIdx = ctx->evChunkFill = ctx->evPoolUsed = 0;  // (the previous sample's uploads were consumed: gx_sample_end synchronised)
   ctx->satDone = false;
+  ctx->satDropped = 0;
   return GX_OK;
 }
 
@@ -1386,6 +1390,12 @@ int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor) {
   if (frag_len) *frag_len = ctx->hScal.fragLen;
   if (lambda) *lambda = ctx->hScal.lambda;
   if (factor) *factor = ctx->hScal.factor;
+  return GX_OK;
+}
+
+int gx_saturation_dropped(gx_ctx* ctx, long long* n) {
+  if (!ctx || !n) return GX_ERR_ORDER;
+  *n = ctx->satDropped;
   return GX_OK;
 }
 

@@ -1181,13 +1181,32 @@ struct Scalars {
   u64 genomeLen;
 };
 
+// fragLen / ctrlFrag (exact fixed-point parts, summed over all ranks when `coll` is given) -> lambda, factor
+__device__ __forceinline__ void finish_frag(Scalars* s, int isCtrl, u32* st, const long long* __restrict__ coll) {
+  long long* acc = isCtrl ? s->ctrlAcc : s->fragAcc;
+  if (coll) {  // the sums over all ranks
+    acc[0] = coll[0];
+    acc[1] = coll[1];
+  }
+  if (!isCtrl) {
+    s->fragLen = (double)s->fragAcc[0] + (double)s->fragAcc[1] * (1.0 / 134217728.0);
+    if (s->fragLen == 0.0) atomicOr(st, ST_NO_FRAGS);
+  } else {
+    s->ctrlFrag = (double)s->ctrlAcc[0] + (double)s->ctrlAcc[1] * (1.0 / 134217728.0);
+    s->factor = s->ctrlFrag == 0.0 ? 1.0f : (float)(s->fragLen / s->ctrlFrag);  // calcFactor 2043-2045
+  }
+  s->lambda = (float)(s->fragLen / (double)s->genomeLen);  // calcLambda 1831
+}
+
 // closed form or general path -> the (integer, fraction * 2^27) accumulator pair; with several ranks
 // also this rank's contribution to the all-reduce: the pair and its "build this sample again" flags
 // (every rank must learn whether any rank has to, before the sums mean anything): +1 when a base can
 // reach the reference's int16 limits, +65536 when a level-1 page list overflowed (ST_PT_FULL = 512)
-__global__ void k_frag_select(const FragFix* __restrict__ ff, long long* __restrict__ acc, long long* __restrict__ coll,
-                              const u32* __restrict__ hot, const u32* __restrict__ st, const DChrom* __restrict__ chroms,
-                              u32 nChrom, u32* __restrict__ chromIvOff, const u32* __restrict__ nIv) {
+// (acc points into *scal: no __restrict__ on either)
+__global__ void k_frag_select(const FragFix* __restrict__ ff, long long* acc, long long* __restrict__ coll,
+                              const u32* __restrict__ hot, u32* st, const DChrom* __restrict__ chroms,
+                              u32 nChrom, u32* __restrict__ chromIvOff, const u32* __restrict__ nIv, Scalars* scal,
+                              int isCtrl) {
   if (threadIdx.x || blockIdx.x) return;
   {  // chromosome table epilogue (as k_fix_chrom_off): offsets of the chromosomes without tiles
     u32 next = *nIv;
@@ -1209,24 +1228,13 @@ __global__ void k_frag_select(const FragFix* __restrict__ ff, long long* __restr
     coll[0] = acc[0];
     coll[1] = acc[1];
     coll[2] = (*hot ? 1 : 0) + ((*st & 512u) ? 65536 : 0);
-  }
+  } else
+    finish_frag(scal, isCtrl, st, nullptr);  // one rank: the sums are final (otherwise k_finish_frag, after the all-reduce)
 }
 
 __global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st, const long long* __restrict__ coll) {
   if (threadIdx.x || blockIdx.x) return;
-  long long* acc = isCtrl ? s->ctrlAcc : s->fragAcc;
-  if (coll) {  // the sums over all ranks
-    acc[0] = coll[0];
-    acc[1] = coll[1];
-  }
-  if (!isCtrl) {
-    s->fragLen = (double)s->fragAcc[0] + (double)s->fragAcc[1] * (1.0 / 134217728.0);
-    if (s->fragLen == 0.0) atomicOr(st, ST_NO_FRAGS);
-  } else {
-    s->ctrlFrag = (double)s->ctrlAcc[0] + (double)s->ctrlAcc[1] * (1.0 / 134217728.0);
-    s->factor = s->ctrlFrag == 0.0 ? 1.0f : (float)(s->fragLen / s->ctrlFrag);  // calcFactor 2043-2045
-  }
-  s->lambda = (float)(s->fragLen / (double)s->genomeLen);  // calcLambda 1831
+  finish_frag(s, isCtrl, st, coll);
 }
 
 // Everything the host wants to know at a synchronisation point, written by ONE small kernel straight into

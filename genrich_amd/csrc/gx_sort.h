@@ -373,9 +373,9 @@ struct BinSrc {
 };
 
 template <typename R>
-__global__ __launch_bounds__(B2_NT) void k_bucket2p(PagedStream P, typename B2Out<R>::type* __restrict__ out,
-                                                    const u32* __restrict__ segOff, u32 nSeg, int sbShift, u32 nTiles,
-                                                    u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
+__device__ __forceinline__ void bucket2p_body(const PagedStream& P, typename B2Out<R>::type* __restrict__ out,
+                                              const u32* __restrict__ segOff, u32 nSeg, int sbShift, u32 nTiles,
+                                              u32* __restrict__ tileCnt, int* __restrict__ tileWsum) {
   typedef typename B2Out<R>::type O;
   constexpr int ITEMS = ScCfg<R>::ITEMS;
   constexpr int CHUNK = B2_NT * ITEMS;
@@ -562,6 +562,25 @@ __global__ __launch_bounds__(B2_NT) void k_bucket2p(PagedStream P, typename B2Ou
       }
     }
   }
+}
+
+// The three streams of a sample in ONE launch (blockIdx.y: 0 start keys, 1 end keys, 2 fractional records): the
+// workgroups of the next stream start while the last ones of the previous stream finish, and a run without
+// fractional records pays no launch for finding every F bin empty.
+struct Bucket2Job {
+  PagedStream P;
+  void* out;
+  const u32* segOff;
+  u32* tileCnt;
+};
+struct Bucket2Jobs { Bucket2Job j[3]; };
+
+__global__ __launch_bounds__(B2_NT) void k_bucket2p(Bucket2Jobs J, u32 nSeg, int sbShift, u32 nTiles, int* __restrict__ tileWsum) {
+  const Bucket2Job& jb = J.j[blockIdx.y];
+  if (blockIdx.y < 2)
+    bucket2p_body<u32>(jb.P, static_cast<uint16_t*>(jb.out), jb.segOff, nSeg, sbShift, nTiles, jb.tileCnt, tileWsum);
+  else
+    bucket2p_body<u64>(jb.P, static_cast<u64*>(jb.out), jb.segOff, nSeg, sbShift, nTiles, jb.tileCnt, tileWsum);
 }
 
 }  // namespace gx

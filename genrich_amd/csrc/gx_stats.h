@@ -21,13 +21,23 @@ __device__ __forceinline__ float pval_of_v(int v, float lambda, double ml, doubl
   return val == 0.0f ? 0.0f : pval_given(val, ml, sl, risky);
 }
 
+__device__ __forceinline__ void deep_risky_body(PackIn in, const FragFix* __restrict__ ff, const u32* __restrict__ list,
+                                                const Scalars* __restrict__ sc, RiskBuf* __restrict__ risk, u32 block, u32 nBlocks);
+
+// blocks [0, PV_LUT / 256): the table; DEEP_BLOCKS more: the deep tiles' risky values (k_deep_risky's work, same launch)
+constexpr u32 DEEP_BLOCKS = 32;
 __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc, float* __restrict__ lutP,
-                                                  RiskBuf* __restrict__ risk, DeepTab* __restrict__ deep) {
+                                                  RiskBuf* __restrict__ risk, DeepTab* __restrict__ deep, PackIn in,
+                                                  const FragFix* __restrict__ ff, const u32* __restrict__ list) {
   if (blockIdx.x == 0 && threadIdx.x == 0) deep->n = 0;  // this sample's host-evaluated deep values come later
+  if (blockIdx.x >= PV_LUT / 256) {
+    if (in.meta) deep_risky_body(in, ff, list, sc, risk, blockIdx.x - PV_LUT / 256, gridDim.x - PV_LUT / 256);
+    return;
+  }
   const float lambda = sc->lambda;
   double ml = 0, sl = 1;
   if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
-  for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += gridDim.x * 256) {
+  for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += (PV_LUT / 256) * 256) {
     float val;
     bool ng, risky = false;
     lutP[v] = pval_of_v((int)v, lambda, ml, sl, &val, &ng, &risky);
@@ -183,14 +193,14 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
 // the intervals of the deep tiles whose pileup lies beyond the table.  k_deep_risky runs while the
 // sample is closed (the host synchronises there): it evaluates the same intervals and lists the
 // values that are risky; the host's answers come back in `deep`, where k_pval_deep finds them.
-__global__ __launch_bounds__(256) void k_deep_risky(PackIn in, const FragFix* __restrict__ ff, const u32* __restrict__ list,
-                                                    const Scalars* __restrict__ sc, RiskBuf* __restrict__ risk) {
+__device__ __forceinline__ void deep_risky_body(PackIn in, const FragFix* __restrict__ ff, const u32* __restrict__ list,
+                                                const Scalars* __restrict__ sc, RiskBuf* __restrict__ risk, u32 block, u32 nBlocks) {
   const u32 nList = ff->nList;
   const float lambda = sc->lambda;
   double ml = 0, sl = 1;
   if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
   const int wv = threadIdx.x >> 6, lane = lane_id();
-  for (u32 li = blockIdx.x * 4 + wv; li < nList; li += gridDim.x * 4) {
+  for (u32 li = block * 4 + wv; li < nList; li += nBlocks * 4) {
     const u32 t = list[li];
     const u32 src = in.meta[t].slot, n = in.tileIvOff[t + 1] - in.tileIvOff[t];
     for (u32 i = lane; i < n; i += 64) {

@@ -1707,6 +1707,15 @@ int main(int argc, char** argv) {
           if (g == 0) { fragLen = fl; lambda = la; factor = fa; }  // (genome-wide scalars: the same on every device)
           return rc;
         });
+        long long dropped = 0;
+        for (gx_ctx* g : S.devs.ctx) {
+          long long d = 0;
+          check(S, gx_saturation_dropped(g, &d), g);
+          dropped += d;
+        }
+        if (dropped)  // saveInterval 2558-2573 warns read by read (with -v) and leaves them out of -b and of the -x average
+          fprintf(stderr, "Warning! %lld alignments skipped due to overflow / underflow of the reference's 16-bit counters "
+                          "(left out of the pileup as in Genrich; their -b lines and lengths were written before)\n", dropped);
         if (i && o.verbose) {
           fprintf(stderr, "  Background pileup value: %f\n", lambda);
           fprintf(stderr, "  Scaling factor for control pileup: %f\n", factor);

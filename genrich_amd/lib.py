@@ -58,6 +58,7 @@ _SIGS = {
     "gx_push_events_pinned": [C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_sample_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "gx_sample_no_control": [C.c_void_p, C.POINTER(C.c_float)],
+    "gx_saturation_dropped": [C.c_void_p, C.POINTER(C.c_longlong)],
     "gx_pvalues": [C.c_void_p],
     "gx_find_peaks": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "gx_get_peaks": [C.c_void_p, C.c_void_p, C.c_size_t],

@@ -139,6 +139,11 @@ long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, co
  * Any out pointer may be NULL. */
 int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor);
 
+/* How many alignments of the sample just closed (gx_sample_end) the reference's int16 saturation rule dropped
+ * (Genrich.c:2558-2573; normally 0).  The library has dropped them as the reference does; a host program that
+ * printed their -b lines or counted their lengths beforehand can at least say so. */
+int gx_saturation_dropped(gx_ctx* ctx, long long* n);
+
 /* == savePileupNoCtrl (Genrich.c:1883-1896): missing or "null" control. */
 int gx_sample_no_control(gx_ctx* ctx, float* lambda);
 

@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -s KILL 900 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/c22_pytest.log 2>&1
+grep -E "passed|failed|^FAILED" gpurun_out/c22_pytest.log | tail -12
+( timeout -s KILL 300 python bench.py --steps 20 --warmup 3 --no-cpu --no-e2e ) > gpurun_out/c22_bench2.json 2> gpurun_out/c22_bench2.err
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/c22_bench*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d["ms_per_step"],3), {k: round(v,3) for k,v in d["phases_ms"].items()}, d["config"]["peaks"])
+    except Exception as e: print(f, "ERR", e, open("gpurun_out/c22_bench2.err").read()[-500:])
+PY
+timeout -s KILL 120 python tools/host_floor.py 2>&1 | tail -2
