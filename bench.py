@@ -321,14 +321,16 @@ def main():
             prof = json.load(open(ppath))
             if prof.get("source_hash") != source_hash() or world != 1 or args.frags != 50_000_000 or args.qval or args.control:
                 prof = None  # counters of another build / another workload are not this run's
-        traffic = prof["kernels"]["k_tile"]["hbm_bytes_per_step"] / launches if prof else None
+        # (the tile stage = k_tile_fast for the narrow tiles + k_tile for the wide ones, one launch each per sample)
+        traffic = (sum(prof["kernels"].get(k, {}).get("hbm_bytes_per_step", 0.0) for k in ("k_tile_fast", "k_tile")) / launches
+                   if prof else None)
         alg_tile = (2.0 * 2.0 * ev_n + 8.0 * (iv0 if launches == 1 else 2.0 * ev_n)) / launches + 56.0 * n_tiles
         used = traffic if traffic else alg_tile
         achieved = used / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
         # whole step: events in + final interval table (end, p[, pileup]) + sweep masks out
         alg_step = 16.0 * ev_n + (12.0 if not args.lean else 8.0) * iv0 + 3.0 * iv0 / 8.0
         roof = {
-            "bound": "hbm", "kernel": "k_tile", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_tile_fast (+ k_tile for wide tiles)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": tile_ms,
             "algorithmic_bytes": alg_tile,
             "traffic_over_algorithmic": (traffic / alg_tile) if traffic else None,
@@ -342,7 +344,7 @@ def main():
             "issue": prof.get("issue") if prof else None,
             "dense_model": {"bytes": 8.0 * G + 16.0 * ev_n + 52.0 * iv0,
                             "note": "SURVEY 8(d)'s dense int32-array model; the array lives in LDS here, so this is not HBM traffic"},
-            "note": "achieved = HBM bytes k_tile moves per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of this build, "
+            "note": "achieved = HBM bytes the tile stage moves per sample (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of this build, "
                     "profiles/r02_counters_config*.json; the sparse formulation's compulsory bytes when no counter file matches "
                     "this build) / its mean duration (HIP events on the library's stream); frac <= 1 by construction",
         }

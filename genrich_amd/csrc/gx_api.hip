@@ -52,9 +52,6 @@ struct DevBuf {
     if (bytes <= cap) return hipSuccess;
     release();
     size_t want = bytes + bytes / 8 + 256;
-    static const size_t pad = getenv("GX_ALLOC_PAD") ? (size_t)atoll(getenv("GX_ALLOC_PAD")) : 0;  // (placement experiments)
-    static unsigned seq = 0;
-    if (pad) want += pad * (1 + seq++ % 7);
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;

@@ -14,7 +14,7 @@
  * {1,2,3,4,5,6,8,10}, is a multiple of 1/120), with the float value
  * re-materialised exactly as getVal() does.
  *
- * Parity pinning: this restatement is checked (tests/test_oracle_vs_ref.py,
+ * Parity pinning: this restatement is checked (tests/test_oracle.py,
  * run in the build container) against the unmodified reference compiled into
  * oracle/_ref/ and against the committed golden fixtures under tests/golden/
  * that the reference produced (tests/golden/make_golden.py), plus the seven
