@@ -190,6 +190,12 @@ def main():
     ap.add_argument("--cpu-chroms", type=int, default=0, help="gate / cpu_baseline on the first K chromosomes (0: per config)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D / end-to-end-from-pinned figures")
     args = ap.parse_args()
+    # The JSON line must be the only thing on stdout: libraries below Python (RCCL prints a version banner
+    # through C stdio, flushed at exit) write to file descriptor 1, so the real stdout is put aside and
+    # descriptor 1 joins stderr until the line is written.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     cfg = dict(CONFIGS[args.config])
     cfg["qval"] = cfg["qval"] or args.qval
     cfg["control"] = cfg["control"] or args.control
@@ -245,14 +251,39 @@ def main():
     # --lean drops the pileup floats, which only the -f / -k emitters read: reported as such in `config`.
     gx.set_keep_pileups(not args.lean)
     coll_kind = "none"
+    force_rccl = world == 1 and os.environ.get("GX_BENCH_FORCE_RCCL") == "1"   # exercise the RCCL path with one rank
+    if force_rccl:
+        os.environ["GX_FORCE_COLL"] = "1"
+        gx.set_rccl(0, 1, rccl_unique_id())
+        coll_kind = "RCCL inside the library, one-rank communicator (exercise mode)"
     if world > 1:
         gx.set_owned(owned)
         if backend == "nccl":
             # the library's own RCCL communicator; torch.distributed only carries the 128-byte id (outside the timed region)
-            box = [rccl_unique_id() if rank == 0 else None]
+            ok = 1
+            try:
+                box = [rccl_unique_id() if rank == 0 else None]
+            except Exception as e:  # noqa: BLE001
+                box, ok = [None], 0
+                print(f"rank {rank}: {e}", file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
-            gx.set_rccl(rank, world, box[0])
-            coll_kind = "RCCL inside the library (device buffers, library stream)"
+            if box[0] is None:
+                ok = 0
+            else:
+                try:
+                    gx.set_rccl(rank, world, box[0])
+                except Exception as e:  # noqa: BLE001
+                    ok = 0
+                    print(f"rank {rank}: {e}", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                coll_kind = "RCCL inside the library (device buffers, library stream)"
+            else:
+                # some rank could not open the library's communicator: all ranks take the callback route together
+                coll = Collectives(device=cdev)
+                gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
+                coll_kind = "host callbacks over torch.distributed/nccl (the library's own communicator failed)"
         else:
             coll = Collectives(device=cdev)
             gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
@@ -426,7 +457,8 @@ def main():
             gate, cpu = gate_and_cpu_baseline(cfg, lens, reps_all, min(k, len(lens)), cfg["qval"], local_dev)
             out["gate"] = gate
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -1119,7 +1119,7 @@ int gx_create(gx_ctx** out, const gx_params* par) {
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile<true, true>, TL_NT, TL_LDS_HALF * 4));
     ctx->resTileHalf = std::max(1, nb) * ctx->numCU;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile_fast, 64, 0));
-    ctx->resTileFast = std::max(1, nb) * ctx->numCU;
+    ctx->resTileFast = std::max(1, std::min(nb, TF_WG_PER_CU)) * ctx->numCU;
     if (const char* e = getenv("GX_TILE_FAST_WG")) ctx->resTileFast = std::max(1, atoi(e)) * ctx->numCU;
     if (getenv("GX_DEBUG"))
       fprintf(stderr, "k_tile workgroups: half %d, wide %d, fast %d\n", ctx->resTileHalf, ctx->resTile, ctx->resTileFast);
@@ -1175,6 +1175,10 @@ int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip, 
 int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce, gx_allgather_tab_fn allgather,
                        void* user) {
   if (!ctx || world < 1 || rank < 0 || rank >= world) return GX_ERR_ORDER;
+  if (ctx->comm && (allreduce || allgather)) {  // callbacks replace a communicator of gx_set_rccl
+    if (const gxrccl::Api* api = gxrccl::load(nullptr)) (void)api->commDestroy(ctx->comm);
+    ctx->comm = nullptr;
+  }
   ctx->rank = rank;
   ctx->world = world;
   ctx->allreduce = allreduce;
@@ -1565,7 +1569,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     HIPCHECK(ctx->looseV.ensure(cap * 4));
     HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
     MergeNOut mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<float>(), ctx->tileIvCount.as<u32>()};
-    const size_t lds = (size_t)nr * MG_WORDS * 4;
+    const size_t lds = mergeN_lds_bytes((int)nr);
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
     hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(4 * ctx->numCU))), dim3(MG_NT), lds, s, S,

@@ -91,16 +91,16 @@ __device__ __forceinline__ bool chrom_active(const DChrom& c) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-// 64-lane inclusive add-scan in 7 DPP adds (no LDS crossbar traffic): rows of 16 lanes are
-// scanned with row_shr 1/2/3/4/8, then row_bcast:15 / row_bcast:31 carry the row totals across
-// the wave (gfx9 DPP controls; lanes without a source read `old` = 0).
+// 64-lane inclusive add-scan in 6 DPP adds (no LDS crossbar traffic): rows of 16 lanes are scanned
+// Kogge-Stone fashion with row_shr 1/2/4/8 (lanes without a source read 0), then row_bcast:15 /
+// row_bcast:31 carry the row totals across the wave (gfx9 DPP controls).  Each step is x += dpp(x), the
+// form the compiler folds into one v_add_u32_dpp.
 __device__ __forceinline__ int dpp_scan_add(int v) {
   int x = v;
-  x += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-  x += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-  x += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, false);  // row_shr:3
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xe, false);  // row_shr:4, banks 1-3
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xc, false);  // row_shr:8, banks 2-3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
   x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
   return x;

@@ -448,12 +448,47 @@ struct MergeNOut {   // loose slots: tile t writes at sum_r tileOff_r[t]
   u32* tileCount;
 };
 
+// Work layout of k_mergeN.  The union of the replicates' breakpoints comes from per-replicate bitmaps
+// (one word per thread, ranks by block scans), as in k_merge2.  Everything per merged interval is DENSE:
+//   1  the owner of a bitmap word lists its set bits (offL[rank]): no memory access in the bit loop;
+//   2  thread i takes merged interval i: its position in each replicate = intervals before its word
+//      (preR) + set bits below it; gathers the replicates' p, sums them in replicate order (multPval
+//      570-574); no-maths cases (df <= 2, sum 0) are written at once; the others look (sum, df) up in an
+//      LDS cache of earlier results -- p is a deterministic function of the pair -- and the misses are
+//      compacted into a list;
+//   3  the misses are evaluated densely (double-precision series: the expensive part, now only for pairs the
+//      workgroup has not met), written, and entered into the cache (one writer per entry, chosen by an
+//      LDS atomic, so an entry is never torn).  Risky roundings (gx_math.h) are not cached: they go on the
+//      host's list every time.
+// Tiles with more than MN_CAP merged intervals take several rounds.
+constexpr int MN_CAP = 1024;     // merged intervals per round
+constexpr int MN_CACHE = 1024;   // cache entries (16 B)
+struct MnEntry { u32 lo, hi; float p; u32 df; };
+__host__ __device__ constexpr size_t mergeN_lds_bytes(int n) {
+  return (size_t)n * MG_WORDS * 4 + (size_t)n * MG_WORDS * 2 + MN_CAP * 2 /*offL*/ + MN_CAP * 8 /*missSum*/ +
+         MN_CAP * 2 /*missI*/ + MN_CAP /*missDf*/ + MN_CACHE * sizeof(MnEntry) + MN_CACHE * 4 /*owner*/ + 64;
+}
+
 __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restrict__ tileChrom,
                                                   const DChrom* __restrict__ chroms, u32 nTiles,
                                                   MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk) {
-  extern __shared__ __attribute__((aligned(16))) u32 bm[];  // S.n bitmaps of MG_WORDS words
-  __shared__ u32 scratch[8];
+  static_assert(MG_WPT == 1, "one bitmap word per thread");
+  extern __shared__ __attribute__((aligned(16))) u32 dyn[];
   const int n = S.n;
+  // (8-byte items first)
+  double* missSum = reinterpret_cast<double*>(dyn);
+  MnEntry* cache = reinterpret_cast<MnEntry*>(missSum + MN_CAP);
+  u32* owner = reinterpret_cast<u32*>(cache + MN_CACHE);
+  u32* bm = owner + MN_CACHE;                                           // n bitmaps of MG_WORDS words
+  uint16_t* preR = reinterpret_cast<uint16_t*>(bm + n * MG_WORDS);      // [r][w]: intervals of r before word w
+  uint16_t* offL = preR + n * MG_WORDS;                                 // offset of merged interval i of the round
+  uint16_t* missI = offL + MN_CAP;
+  uint8_t* missDf = reinterpret_cast<uint8_t*>(missI + MN_CAP);
+  __shared__ u32 scratch[8];
+  __shared__ u32 nMiss;
+  for (int i = threadIdx.x; i < MN_CACHE * 5; i += MG_NT) reinterpret_cast<u32*>(cache)[i] = 0;  // cache + owner
+  if (threadIdx.x == 0) nMiss = 0;
+  u32 bad = 0;
   for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {  // persistent, round-robin
     __syncthreads();
     for (int i = threadIdx.x; i < n * MG_WORDS; i += MG_NT) bm[i] = 0;
@@ -463,82 +498,119 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
     const u32 tl = t - c.tileBase, pos0 = tl << TB;
     const bool lastTile = tl + 1 == c.nTiles;
     bool any = false;
+    u32 slot = 0;
     for (int r = 0; r < n; r++) {
+      const u32 a0 = S.r[r].tileOff[t];
+      slot += a0;
       if (!S.r[r].present[ci]) continue;
       any = true;
-      u32 a0 = S.r[r].tileOff[t], a1 = S.r[r].tileOff[t + 1];
-      u32 a1c = (lastTile && a1 > a0) ? a1 - 1 : a1;
+      const u32 a1 = S.r[r].tileOff[t + 1];
+      const u32 a1c = (lastTile && a1 > a0) ? a1 - 1 : a1;
       for (u32 i = a0 + threadIdx.x; i < a1c; i += MG_NT) {
-        u32 off = S.r[r].end[i] - pos0;
+        const u32 off = S.r[r].end[i] - pos0;
         atomicOr(&bm[r * MG_WORDS + (off >> 5)], 1u << (off & 31));
       }
     }
     __syncthreads();
-    u32 wU[MG_WPT] = {};
-    u32 cU = 0;
-#pragma unroll
-    for (int k = 0; k < MG_WPT; k++) {
-      int w = threadIdx.x * MG_WPT + k;
-      for (int r = 0; r < n; r++) wU[k] |= bm[r * MG_WORDS + w];
-      cU += __popc(wU[k]);
-    }
+    const int w = threadIdx.x;
+    u32 wU = 0;
+    for (int r = 0; r < n; r++) wU |= bm[r * MG_WORDS + w];
     u32 tU;
-    u32 exU = block_excl_scan<u32, MG_NT>(cU, scratch, &tU);
-    // per replicate: intervals ending before this thread's first word (rank base)
-    u32 exR[MAX_REPS];
-    for (int r = 0; r < n; r++) {
-      u32 cr = 0;
-#pragma unroll
-      for (int k = 0; k < MG_WPT; k++) cr += __popc(bm[r * MG_WORDS + threadIdx.x * MG_WPT + k]);
+    const u32 exU = block_excl_scan<u32, MG_NT>((u32)__popc(wU), scratch, &tU);
+    for (int r = 0; r < n; r++) {  // per replicate: intervals ending before each word
       u32 tr;
-      exR[r] = block_excl_scan<u32, MG_NT>(cr, scratch, &tr);
+      preR[r * MG_WORDS + w] = (uint16_t)block_excl_scan<u32, MG_NT>((u32)__popc(bm[r * MG_WORDS + w]), scratch, &tr);
     }
-    u32 slot = 0;
-    for (int r = 0; r < n; r++) slot += S.r[r].tileOff[t];
     if (threadIdx.x == 0) out.tileCount[t] = any ? tU + (lastTile ? 1u : 0u) : 0u;
-    if (any) {  // block-uniform
-    u32 o = slot + exU;
-#pragma unroll
-    for (int k = 0; k < MG_WPT; k++) {
-      const int w = threadIdx.x * MG_WPT + k;
-      u32 bits = wU[k];
-      while (bits) {
-        int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        u32 below = (1u << b) - 1;
+    if (!any) continue;  // block-uniform
+    for (u32 r0 = 0; r0 < tU; r0 += MN_CAP) {
+      // ---- 1: the merged intervals of this round, by rank ----------------------------------------------------
+      {
+        u32 rank = exU - r0;  // (unsigned: earlier rounds' ranks wrap far beyond MN_CAP)
+        for (u32 bits = wU; bits; bits &= bits - 1, rank++)
+          if (rank < (u32)MN_CAP) offL[rank] = (uint16_t)(w * 32 + __builtin_ctz(bits));
+      }
+      __syncthreads();
+      // ---- 2: gather, sum, classify ---------------------------------------------------------------------------
+      const u32 nC = min((u32)MN_CAP, tU - r0);
+      for (u32 i = threadIdx.x; i < nC; i += MG_NT) {
+        const u32 off = offL[i], ww = off >> 5, below = (1u << (off & 31)) - 1u;
         double sum = 0.0;
         int df = 0;
         for (int r = 0; r < n; r++) {  // multPval 570-574, replicate order
           if (!S.r[r].present[ci]) continue;
-          u32 idx = S.r[r].tileOff[t] + exR[r] + __popc(bm[r * MG_WORDS + w] & below);
-          float pv = S.r[r].p[idx];
+          const u32 idx = S.r[r].tileOff[t] + preR[r * MG_WORDS + ww] + __popc(bm[r * MG_WORDS + ww] & below);
+          const float pv = S.r[r].p[idx];
           if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
         }
-        if (df > 400) atomicOr(st, ST_BAD_DF);
-        out.end[o] = pos0 + w * 32 + b;
-        bool risky = false;
-        out.p[o] = fisher_combine(sum, df, &risky);
-        if (risky) risk_add(risk, RK_FISHER, t, o - slot, (u32)df, sum);
-        o++;
+        if (df > 400) bad |= ST_BAD_DF;
+        const u32 o = slot + r0 + i;
+        out.end[o] = pos0 + off;
+        if (df <= 2 || sum == 0.0) {
+          out.p[o] = df == 0 ? GX_SKIPF : (float)sum;   // fisher_combine's cases without maths
+          continue;
+        }
+        const u32 lo = (u32)__double_as_longlong(sum), hi = (u32)(__double_as_longlong(sum) >> 32);
+        const u32 h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ ((u32)df << 20)) * 0x9E3779B1u) >> (32 - 10);
+        static_assert(MN_CACHE == 1 << 10, "hash width");
+        const MnEntry e = cache[h];
+        if (e.df == (u32)df && e.lo == lo && e.hi == hi) {
+          out.p[o] = e.p;
+          continue;
+        }
+        const u32 j = atomicAdd(&nMiss, 1u);
+        missI[j] = (uint16_t)i;
+        missDf[j] = (uint8_t)df;
+        missSum[j] = sum;
       }
-      for (int r = 0; r < n; r++) exR[r] += __popc(bm[r * MG_WORDS + w]);
+      __syncthreads();
+      // ---- 3: the pairs not met before --------------------------------------------------------------------------
+      const u32 nM = nMiss;
+      for (u32 j0 = 0; j0 < nM; j0 += MG_NT) {  // (block-uniform trip count: barriers inside)
+        const u32 j = j0 + threadIdx.x;
+        bool enter = false;
+        u32 h = 0, lo = 0, hi = 0, df = 0;
+        float pv = 0.0f;
+        if (j < nM) {
+          const double sum = missSum[j];
+          df = missDf[j];
+          bool risky = false;
+          pv = pval_round(fisher_double(sum, (int)df), &risky);
+          const u32 i = missI[j];
+          out.p[slot + r0 + i] = pv;
+          if (risky) risk_add(risk, RK_FISHER, t, r0 + i, df, sum);
+          lo = (u32)__double_as_longlong(sum);
+          hi = (u32)(__double_as_longlong(sum) >> 32);
+          h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ (df << 20)) * 0x9E3779B1u) >> (32 - 10);
+          enter = !risky;
+          if (enter) atomicMax(&owner[h], j + 1);
+        }
+        __syncthreads();
+        if (enter && owner[h] == j + 1) {
+          cache[h] = MnEntry{lo, hi, pv, df};
+          owner[h] = 0;
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) nMiss = 0;
+      __syncthreads();
     }
-    if (lastTile && threadIdx.x == 0) {
+    if (lastTile && threadIdx.x == 0) {  // closing interval [.., len)
       double sum = 0.0;
       int df = 0;
       for (int r = 0; r < n; r++) {
         if (!S.r[r].present[ci]) continue;
-        float pv = S.r[r].p[S.r[r].tileOff[t + 1] - 1];
+        const float pv = S.r[r].p[S.r[r].tileOff[t + 1] - 1];
         if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
       }
-      u32 oc = slot + tU;
+      const u32 oc = slot + tU;
       out.end[oc] = c.len;
       bool risky = false;
       out.p[oc] = fisher_combine(sum, df, &risky);
       if (risky) risk_add(risk, RK_FISHER, t, tU, (u32)df, sum);
     }
-    }
   }
+  if (bad) atomicOr(st, bad);
 }
 
 // loose (end, p) slots of k_mergeN -> tight arrays; one wavefront per tile

@@ -5,41 +5,50 @@
 // the general kernel.
 //
 // Why another kernel.  k_tile is VALU-issue bound (SQ counters, profiles/r02a_*: 554 VALU instructions
-// per tile over its two wavefronts, VALU active on 16 % of the wave cycles x 8 waves per SIMD): every
-// thread owns 32 bases and runs unrolled code for four register-held slots whatever the tile holds,
-// while a tile of config 2 has ~125 touched bases for its 128 threads.  Here ONE wavefront owns a
-// tile and the work is laid out by TOUCHED BASE, not by base range:
-//   A  add the tile's records into the LDS slice (ds_add) and mark the occupancy bitmap (ds_or);
-//   B  every lane owns two bitmap words: popcounts -> DPP scan -> ranks; the touched positions are
-//      written, in position order, as a dense list of 16-bit offsets (LDS);
-//   C  64 list entries per step, one per lane: read the difference, give the slot back (subtract),
-//      DPP scan for the running pileup, ballot / mbcnt for the output rank, coalesced stores of
-//      (end, V120).
-// No barrier between wavefronts, no per-thread serial walk over a fixed number of slots, stores
-// that fill whole lines; a tile costs ~220 VALU instructions.  LDS per tile: 8 KiB slice (two bases
-// per word as signed 16-bit halves of one integer sum, as in k_tile<.., HALF>) + 512 B bitmap +
-// 1 KiB list = 9.5 KiB -> 16 tiles in flight per CU with 16 wavefronts.
+// per tile over its two wavefronts): every thread owns 32 bases and runs unrolled code for four
+// register-held slots whatever the tile holds, while a tile of config 2 has ~125 touched bases for its
+// 128 threads.  Here ONE wavefront owns a tile, the work is laid out by TOUCHED BASE, and the LDS
+// counters are addressed by the touched base's RANK, not by its offset:
+//   A1 mark the occupancy bitmap with the tile's records (ds_or) -- nothing else;
+//   B  every lane owns two bitmap words: popcounts -> DPP scan -> the number of touched bases before
+//      each word (`pre`, 16 bits per word);
+//   A2 every record finds its base's rank, pre[word] + popc(word & bits below), adds its sign to
+//      cnt[rank] and writes its offset to list[rank] (records of one base write the same value): the
+//      position-ordered list of touched bases falls out without any per-lane bit loop;
+//   C  64 list entries per step, one per lane: the difference is cnt[j] (cleared on the way), DPP scan
+//      for the running pileup, ballot / mbcnt for the output rank, coalesced stores of (end, V120).
+// No barrier between wavefronts, no per-thread serial walk, stores that fill whole lines: ~190 VALU
+// instructions per tile.  LDS per tile: 512 B bitmap + 256 B pre + 2 KiB cnt + 1 KiB list = 3.75 KiB.
+// (Round 2's first version kept an 8 KiB slice indexed by offset -- two bases per word -- and built the
+// list with per-lane bit loops: 320 VALU instructions per tile, VALU busy ~80 % of the SIMD cycles, 16
+// tiles per CU: 0.62 ms for config 2's sample where this one takes 0.47 ms.)
+// Workgroups per CU (measured, config 2): 16: 0.59, 20: 0.53, 22: 0.51, 24: 0.47, 26: 0.59, 28: 0.57,
+// 32: 0.51 ms -> 24 (TF_WG_PER_CU).
+// A tile with more than TR_CAP touched bases takes ceil(T / TR_CAP) rounds of A2 + C.
 #pragma once
 #include "gx_kernels.h"
 
 namespace gx {
 
-constexpr int TF_LCAP = 512;                                    // list entries per round (a tile rarely holds more)
-constexpr int TF_WORDS = TILE / 2 + TILE / 32 + TF_LCAP / 2;    // ints of LDS per workgroup
 constexpr int TF_KPL = 2;                                       // prefetched keys per lane and stream (128 per tile)
+constexpr int TF_WG_PER_CU = 24;                                // one-wavefront workgroups per CU (see above)
+constexpr int TR_CAP = 512;
+constexpr int TR_WORDS = TILE / 32 + TILE / 64 + TR_CAP + TR_CAP / 2;
 
 __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u32* __restrict__ nWide, TileOut out,
                                                   u32* __restrict__ st) {
-  __shared__ __attribute__((aligned(16))) int lds[TF_WORDS];
-  int* delta = lds;                                                   // TILE / 2 words: two bases each
-  u32* occ = reinterpret_cast<u32*>(lds + TILE / 2);                  // TILE / 32 words: one bit per base
-  uint16_t* list = reinterpret_cast<uint16_t*>(lds + TILE / 2 + TILE / 32);  // TF_LCAP touched offsets, ascending
+  __shared__ __attribute__((aligned(16))) int lds[TR_WORDS];
+  u32* occ = reinterpret_cast<u32*>(lds);                               // TILE / 32 words: one bit per base
+  u32* pre = reinterpret_cast<u32*>(lds + TILE / 32);                   // [lane]: touched bases before word 2 lane | word 2 lane + 1 << 16
+  const uint16_t* pre16 = reinterpret_cast<const uint16_t*>(pre);       // [word]
+  int* cnt = lds + TILE / 32 + TILE / 64;                               // TR_CAP net record counts, by rank
+  uint16_t* list = reinterpret_cast<uint16_t*>(lds + TILE / 32 + TILE / 64 + TR_CAP);  // TR_CAP offsets, by rank
   const int lane = threadIdx.x;
-  for (int i = lane * 4; i < TILE / 2 + TILE / 32; i += 64 * 4) *reinterpret_cast<int4*>(lds + i) = make_int4(0, 0, 0, 0);
+  for (int i = lane * 4; i < TR_WORDS; i += 64 * 4) *reinterpret_cast<int4*>(lds + i) = make_int4(0, 0, 0, 0);
   __syncthreads();
-  if (*nWide > nTiles / 2) return;  // (most tiles are wide: the general kernel takes them all, as k_tile<.., HALF> has it)
+  if (*nWide > nTiles / 2) return;  // (most tiles are wide: the general kernel takes them all)
   const u32 G = gridDim.x;
-  const u32 lb = xcd_local_block(blockIdx.x, G);  // neighbouring tiles (neighbouring loose slots) on one XCD
+  const u32 lb = xcd_local_block(blockIdx.x, G);
   u32 bad = 0;
   // Software pipeline over this wavefront's tiles, with k_tile's discipline (loads and stores share the
   // in-order vmcnt): prefetches are issued right after a tile's stores and collected right before the
@@ -47,6 +56,8 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
   //   top of tile j:  M(j), K(j), M(j+1) in registers;  K(j+1), M(j+2) in flight
   //   collect (j):    K(j+1), M(j+2) arrived
   //   issue (j):      K(j+2) (needs M(j+2)), M(j+3)
+  // (descriptors through scalar loads -- the constant address space -- were tried: the compiler turns
+  // those whose fields feed vector address arithmetic back into vector loads and waits for them on the spot)
   struct Raw { uint4 a, b, c; };
   struct Keys { u32 v[TF_KPL]; };
   auto tileAt = [&](u32 i) -> u32 { return i < nTiles ? i : 0u; };
@@ -57,8 +68,8 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
   auto uni = [](u32 v) -> u32 { return (u32)__builtin_amdgcn_readfirstlane((int)v); };
   auto cook = [&](const Raw& r, u32 i) -> TileMeta {
     TileMeta m;
-    m.sb = uni(r.a.x); m.eb = uni(r.a.y); m.fb = uni(r.a.z); m.nS = uni(r.a.w);
-    m.nE = uni(r.b.x); m.nF = uni(r.b.y); m.carry = (int)uni(r.b.z); m.ci = uni(r.b.w);
+    m.sb = uni(r.a.x); m.eb = uni(r.a.y); m.fb = 0; m.nS = uni(r.a.w);
+    m.nE = uni(r.b.x); m.nF = 0; m.carry = (int)uni(r.b.z); m.ci = 0;
     m.pos0 = uni(r.c.x); m.len = uni(r.c.y); m.flags = uni(r.c.z); m.slot = uni(r.c.w);
     if (i >= nTiles) { m.nS = 0; m.nE = 0; m.nF = 0; m.flags = 0; }
     return m;
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
     const Keys ks0 = ksC, ke0 = keC;
     auto collect = [&]() {
       asm volatile("" : "+v"(ksL.v[0]), "+v"(ksL.v[1]), "+v"(keL.v[0]), "+v"(keL.v[1]), "+v"(rF.a.x), "+v"(rF.a.y),
-                        "+v"(rF.a.z), "+v"(rF.a.w), "+v"(rF.b.x), "+v"(rF.b.y), "+v"(rF.b.z), "+v"(rF.b.w), "+v"(rF.c.x),
+                        "+v"(rF.a.w), "+v"(rF.b.x), "+v"(rF.b.z), "+v"(rF.c.x),
                         "+v"(rF.c.y), "+v"(rF.c.z), "+v"(rF.c.w) :: "memory");
       ksN = ksL;
       keN = keL;
@@ -107,46 +118,68 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
     const bool lastTile = (m.flags & TM_LAST) != 0;
     const u32 pos0 = m.pos0, slot = m.slot;
     const u32 nS = m.nS, nE = m.nE;
-    // ---- A: records -> LDS slice + occupancy bitmap ------------------------------------------------------------
-    auto add = [&](u32 off, int sign) {
-      atomicAdd(&delta[off >> 1], (off & 1) ? sign * 65536 : sign);
-      atomicOr(&occ[off >> 5], 1u << (off & 31));
-    };
+    // ---- A1: records -> occupancy bitmap -----------------------------------------------------------------------
+    auto mark = [&](u32 off) { atomicOr(&occ[off >> 5], 1u << (off & 31)); };
 #pragma unroll
     for (int q = 0; q < TF_KPL; q++) {
-      if ((u32)lane + q * 64 < nS) add(ks0.v[q], 1);
-      if ((u32)lane + q * 64 < nE) add(ke0.v[q], -1);
+      if ((u32)lane + q * 64 < nS) mark(ks0.v[q]);
+      if ((u32)lane + q * 64 < nE) mark(ke0.v[q]);
     }
-    for (u32 k = TF_KPL * 64 + lane; k < nS; k += 64) add(in.S[m.sb + k], 1);
-    for (u32 k = TF_KPL * 64 + lane; k < nE; k += 64) add(in.E[m.eb + k], -1);
+    for (u32 k = TF_KPL * 64 + lane; k < nS; k += 64) mark(in.S[m.sb + k]);
+    for (u32 k = TF_KPL * 64 + lane; k < nE; k += 64) mark(in.E[m.eb + k]);
     __syncthreads();
-    // ---- B: bitmap -> ranks -> dense list of touched offsets ---------------------------------------------------
+    // ---- B: bitmap -> touched bases before each word -----------------------------------------------------------
     u32 w0 = 0, w1 = 0;
     if (nS + nE) {  // wave-uniform
       const uint2 ww = *reinterpret_cast<const uint2*>(occ + 2 * lane);
       w0 = ww.x;
       w1 = ww.y;
-      *reinterpret_cast<uint2*>(occ + 2 * lane) = make_uint2(0u, 0u);  // own words: the next tile finds them clear
     }
-    const int c = __popc(w0) + __popc(w1);
+    const int c0 = __popc(w0), c = c0 + __popc(w1);
     const int incC = dpp_scan_add(c);
     const u32 exc = (u32)(incC - c);
     const u32 T = (u32)__builtin_amdgcn_readlane(incC, 63);  // touched bases of the tile
+    if (T) pre[lane] = exc | ((exc + (u32)c0) << 16);
     collect();
-    // ---- C: 64 touched bases per step --------------------------------------------------------------------------
     int runBase = m.carry;       // pileup (1/120 units) before the first base not yet processed: wave-uniform
     u32 outCount = 0, lastEnd = 0;
-    u32 neg = 0, big = (u32)(m.carry >= FRAG_FAST_MAXV);
-    for (u32 r0 = 0; r0 < T; r0 += TF_LCAP) {
-      {
-        u32 rank = exc - r0;  // (unsigned: entries of earlier rounds wrap far beyond TF_LCAP)
-        for (u32 b = w0; b; b &= b - 1, rank++)
-          if (rank < (u32)TF_LCAP) list[rank] = (uint16_t)(lane * 64 + __builtin_ctz(b));
-        for (u32 b = w1; b; b &= b - 1, rank++)
-          if (rank < (u32)TF_LCAP) list[rank] = (uint16_t)(lane * 64 + 32 + __builtin_ctz(b));
+    u64 negM = 0, bigM = m.carry >= FRAG_FAST_MAXV ? ~0ull : 0ull;
+    // ---- A2: records -> cnt[rank], list[rank] ------------------------------------------------------------------
+    // rank of a record's base = touched bases before its bitmap word + set bits below it in the word.  The
+    // ranks of the register-held records are computed once, all LDS reads in one batch (lanes without a
+    // record look at offset 0).
+    auto rankOf = [&](u32 off) -> u32 {
+      const u32 wi = off >> 5;
+      return (u32)pre16[wi] + (u32)__popc(occ[wi] & ((1u << (off & 31)) - 1u));
+    };
+    u32 rs[TF_KPL], re[TF_KPL];
+    if (T) {  // wave-uniform
+      __syncthreads();  // `pre` is there
+#pragma unroll
+      for (int q = 0; q < TF_KPL; q++) {
+        rs[q] = rankOf(ks0.v[q]);
+        re[q] = rankOf(ke0.v[q]);
       }
+    }
+    for (u32 r0 = 0; r0 < T; r0 += TR_CAP) {
+      if (r0) __syncthreads();  // the previous round is through with cnt and list
+      auto put = [&](u32 r, u32 off, int sign) {
+        r -= r0;
+        if (r < (u32)TR_CAP) {
+          list[r] = (uint16_t)off;
+          atomicAdd(&cnt[r], sign);
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < TF_KPL; q++) {
+        if ((u32)lane + q * 64 < nS) put(rs[q], ks0.v[q], 1);
+        if ((u32)lane + q * 64 < nE) put(re[q], ke0.v[q], -1);
+      }
+      for (u32 k = TF_KPL * 64 + lane; k < nS; k += 64) { const u32 off = in.S[m.sb + k]; put(rankOf(off), off, 1); }
+      for (u32 k = TF_KPL * 64 + lane; k < nE; k += 64) { const u32 off = in.E[m.eb + k]; put(rankOf(off), off, -1); }
       __syncthreads();
-      const u32 nL = min((u32)TF_LCAP, T - r0);
+      // ---- C: 64 touched bases per step ------------------------------------------------------------------------
+      const u32 nL = min((u32)TR_CAP, T - r0);
       for (u32 j0 = 0; j0 < nL; j0 += 64) {
         const u32 j = j0 + lane;
         const bool valid = j < nL;
@@ -154,16 +187,14 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
         int d = 0;
         if (valid) {
           p = list[j];
-          const int w = delta[p >> 1];
-          const int lo = (int)(short)w;
-          d = (p & 1) ? (w - lo) >> 16 : lo;                              // this base's net count of records
-          if (d != 0) atomicAdd(&delta[p >> 1], (p & 1) ? -(d * 65536) : -d);  // its share of the word goes back to zero
+          d = cnt[j];          // this base's net count of records
+          cnt[j] = 0;          // the next round / tile finds it clear
         }
-        const int d120 = d * GX_UNIT;
+        const int d120 = __mul24(d, GX_UNIT);
         const int incS = dpp_scan_add(d120);
-        const int before = runBase + incS - d120;   // the pileup of the interval that ends at this base (2244)
-        const int after = before + d120;
-        const bool nz = valid && d != 0 && active && (pos0 + p != 0);  // 2241: base 0 closes nothing
+        const int after = runBase + incS;
+        const int before = after - d120;            // the pileup of the interval that ends at this base (2244)
+        const bool nz = d != 0 && active && (pos0 + p != 0);  // 2241: base 0 closes nothing
         const u64 mask = __ballot(nz);
         if (nz) {
           const u32 o = slot + outCount +
@@ -171,16 +202,16 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
           out.looseEnd[o] = pos0 + p;
           out.looseV[o] = before;
         }
-        neg |= (u32)(after < 0);
-        big |= (u32)(after >= FRAG_FAST_MAXV);
+        negM |= __ballot(after < 0);
+        bigM |= __ballot(after >= FRAG_FAST_MAXV);
         runBase += __builtin_amdgcn_readlane(incS, 63);
         if (mask) {  // wave-uniform
           outCount += (u32)__popcll(mask);
           lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(mask));
         }
       }
-      __syncthreads();  // the list is rewritten by the next round
     }
+    if (T) *reinterpret_cast<uint2*>(occ + 2 * lane) = make_uint2(0u, 0u);  // own words: the next tile finds them clear
     u32 total = 0;
     if (active) {  // wave-uniform
       total = outCount + (lastTile ? 1u : 0u);
@@ -192,8 +223,8 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
         }
         if (total) out.tileLastEnd[t] = lastEnd;
       }
-      if (__ballot(neg != 0)) bad |= ST_NEG_PILE;
-      if (__ballot(big != 0) && lane == 0) atomicOr(&out.tileDeep[t], 1u);  // rare
+      if (negM) bad |= ST_NEG_PILE;
+      if (bigM && lane == 0) atomicOr(&out.tileDeep[t], 1u);  // rare
     }
     if (lane == 0) out.tileCount[t] = total;  // (0 for a wide tile: overwritten by the kernel that owns it)
     issue();

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (under gpurun): kernel trace + PMC passes of `bench.py --config C`, each in its own
 # rocprofv3 run (counters never share a run with --stats / other trace domains), into gpurun_out/prof_<tag>/.
-#   tools/profile_round.sh <tag> [config]      e.g. tools/profile_round.sh r02a 2
+#   tools/profile_round.sh <tag> [config]      e.g. tools/profile_round.sh r02a 2     (GX_PROF_PASSES=trace: kernel trace only)
 # Afterwards (anywhere): python tools/make_counters_json.py <tag> [config]  ->  profiles/
 set -u
 tag=$1; cfg=${2:-2}
@@ -15,6 +15,7 @@ run() {  # name, rocprofv3 options...
   echo "$name rc=$?"
 }
 run trace --kernel-trace --stats
+[ "${GX_PROF_PASSES:-all}" = trace ] && { ls -la $out; exit 0; }
 run fetch --kernel-trace --pmc FETCH_SIZE
 run write --kernel-trace --pmc WRITE_SIZE
 run sq1 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
