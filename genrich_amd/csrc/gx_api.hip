@@ -176,7 +176,7 @@ struct gx_ctx {
   DevBuf pvLut, dRisk, dDeep;
   PinnedBuf riskHost;           // count + records of the risky p-values, as read back / as sent with the host's values
   bool pairTabsReady = false;   // the control's p-value tables were built when its sample was closed
-  DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhTmp, bhRecs;
+  DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhDl, bhTmp, bhRecs;
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
   long long satDropped = 0;     // ... which dropped this many of them (gx_saturation_dropped)
@@ -184,6 +184,7 @@ struct gx_ctx {
   u32 bhCapLog = 22;            // log2 of its slots (grows by 3 after ST_HASH_FULL)
   // sweep
   DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
+  DevBuf peaksDev;
   PinnedBuf hPeaks;             // the peak list on the host (pinned: the read-back is asynchronous)
   size_t nHostPeaks = 0;
   u32* nIvTarget = nullptr;
@@ -198,6 +199,9 @@ struct gx_ctx {
   ncclComm_t comm = nullptr;    // the library's own collectives (gx_set_rccl): RCCL on device buffers, on `stream`
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
   DevBuf dColl, dCounts, dGather;
+  int phaseLevel = 0;       // gx_set_phase_timing
+  u64 runCap = 0, runSeen = 0;  // run_sweep: runs its arrays are sized for; runs of the last sweep
+  bool phaseOpen = false;
   int numCU = 0, resTile = 0, resTileHalf = 0, resTileFast = 0, resSweep = 0;  // co-resident workgroups per kernel class
   // recycled device buffers (gx_reset keeps allocations alive across runs)
   std::vector<DevBuf> pool;
@@ -260,7 +264,13 @@ int dbg_sync(gx_ctx* ctx, const char* what) {
 }
 
 // phase timers: the event pairs are created once and reused run after run
+// (an event record costs a ~5 us bubble on the stream: gx_set_phase_timing chooses none / the tile stage / all)
+static bool phase_wanted(const gx_ctx* ctx, const char* name) {
+  return ctx->phaseLevel >= 2 || (ctx->phaseLevel == 1 && name[1] == '.' && strcmp(name + 2, "tile") == 0);
+}
 void phase_begin(gx_ctx* ctx, const char* name) {
+  ctx->phaseOpen = phase_wanted(ctx, name);
+  if (!ctx->phaseOpen) return;
   if (ctx->nPhases == ctx->phases.size()) {
     Phase ph;
     (void)hipEventCreate(&ph.a);
@@ -271,7 +281,10 @@ void phase_begin(gx_ctx* ctx, const char* name) {
   ph.name = name;
   (void)hipEventRecord(ph.a, ctx->stream);
 }
-void phase_end(gx_ctx* ctx) { (void)hipEventRecord(ctx->phases[ctx->nPhases - 1].b, ctx->stream); }
+void phase_end(gx_ctx* ctx) {
+  if (ctx->phaseOpen) (void)hipEventRecord(ctx->phases[ctx->nPhases - 1].b, ctx->stream);
+  ctx->phaseOpen = false;
+}
 
 int status_to_rc(gx_ctx* ctx, u32 st) {
   if (!st) return GX_OK;
@@ -353,11 +366,16 @@ int risk_apply(gx_ctx* ctx, RiskTargets T, RiskHostIn in = RiskHostIn{nullptr, n
   }
   for (u32 i = 0; i < n; i++) hb->rec[i].pnew = risk_host_value(ctx, hb->rec[i], in);
   // (the pinned records stay untouched until the next mail_sync)
-  HIPCHECK(hipMemcpyAsync(ctx->dRisk.as<RiskBuf>()->rec, hb->rec, (size_t)n * sizeof(RiskRec), hipMemcpyHostToDevice, s));
+  // A short list is read by the kernel where it lies (mapped pinned memory): no copy launch.
+  const RiskRec* src = static_cast<const RiskBuf*>(ctx->riskHost.dp)->rec;
+  if (n > RISK_PREFIX) {
+    HIPCHECK(hipMemcpyAsync(ctx->dRisk.as<RiskBuf>()->rec, hb->rec, (size_t)n * sizeof(RiskRec), hipMemcpyHostToDevice, s));
+    src = ctx->dRisk.as<RiskBuf>()->rec;
+  }
   T.lutP = ctx->pvLut.as<float>();
   T.p2d = ctx->pairP2d.as<float>();
   T.deep = ctx->dDeep.as<DeepTab>();
-  hipLaunchKernelGGL(k_risk_apply, dim3(1), dim3(256), 0, s, ctx->dRisk.as<RiskBuf>(), n, T);
+  hipLaunchKernelGGL(k_risk_apply, dim3(1), dim3(256), 0, s, ctx->dRisk.as<RiskBuf>(), src, n, T);
   hb->count = 0;
   return dbg_sync(ctx, "k_risk_apply");
 }
@@ -872,8 +890,10 @@ struct SweepSrc {
 };
 
 // callPeaks (Genrich.c:977-1069) on bit masks: runs of adjacent significant intervals -> candidates -> in-order AUC.
-// Two synchronisations: the number of runs (the candidate arrays are sized by it), and the end; counts travel through
-// pinned memory written by the kernels themselves, and the peak list is written straight into pinned host memory.
+// ONE synchronisation, at the end: the run / candidate arrays are sized by a guess (the largest run count seen so
+// far, with headroom), every kernel reads the counts on the device, the true run count comes back with the mail, and
+// only when it exceeds the guess is the sweep repeated with arrays that fit.  Counts travel through pinned memory
+// written by the kernels themselves, and the peak list is written straight into pinned host memory.
 int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
   hipStream_t s = ctx->stream;
   u32* misc = ctx->misc.as<u32>();
@@ -895,21 +915,20 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
       hipLaunchKernelGGL(k_sig_mask, dim3(std::max(1u, std::min((nWords + 15) / 16, 4096u))), dim3(256), 0, s, S.p, S.q,
                          misc + M_NIV, ctx->par.thr, SM);
     hipLaunchKernelGGL(k_runs_count, dim3(wChunks), dim3(SW_NT), 0, s, SM, cntS, cntE);
-    {
-      ScanJobs J{{{cntS, nullptr, wChunks, (u32)SW_CHUNK, offS, misc + M_SWCOUNT, &dm->R, misc + M_TICKET3},
-                  {cntE, nullptr, wChunks, (u32)SW_CHUNK, offE, misc + M_TICKET2, nullptr, nullptr}}};
-      hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, s, J);
-    }
-    HIPCHECK(hipStreamSynchronize(s));  // run / candidate arrays are sized exactly
-    R = ctx->mail->R;
-    if (R) {
-      HIPCHECK(ctx->swStart.ensure((size_t)R * 4 + 16));
-      HIPCHECK(ctx->swEnd.ensure((size_t)R * 4 + 16));
-      HIPCHECK(ctx->headPos.ensure((size_t)R * 4 + 16));
-      HIPCHECK(ctx->cand.ensure((size_t)R * sizeof(gx_peak)));
-      HIPCHECK(ctx->valid.ensure((size_t)R * 4 + 16));
-      HIPCHECK(ctx->hPeaks.ensure((size_t)R * sizeof(gx_peak) + 16));  // (at most one peak per run)
-      const u32 rChunks = (R + SW_CHUNK - 1) / SW_CHUNK;
+    for (int attempt = 0;; attempt++) {
+      // arrays for `cap` runs (never more runs than intervals)
+      const u32 cap = std::min<u64>(std::max<u64>(ctx->runCap, 1u << 16), (u64)nWords * 64);
+      HIPCHECK(ctx->swStart.ensure((size_t)cap * 4 + 16));
+      HIPCHECK(ctx->swEnd.ensure((size_t)cap * 4 + 16));
+      HIPCHECK(ctx->headPos.ensure((size_t)cap * 4 + 16));
+      HIPCHECK(ctx->cand.ensure((size_t)cap * sizeof(gx_peak)));
+      HIPCHECK(ctx->valid.ensure((size_t)cap * 4 + 16));
+      // (at most one peak per run; never a small allocation -- GX_HPEAKS_MIN: experiment on the mapping granularity)
+      static const size_t hpMin = getenv("GX_HPEAKS_MIN") ? (size_t)atoll(getenv("GX_HPEAKS_MIN")) : 0;
+      HIPCHECK(ctx->hPeaks.ensure(std::max((size_t)cap * sizeof(gx_peak) + 16, hpMin)));
+      HIPCHECK(ctx->candHdr.ensure((size_t)cap * sizeof(uint4)));
+      HIPCHECK(ctx->longList.ensure((size_t)cap * 4 + 16));
+      const u32 rChunks = (cap + RC_CHUNK - 1) / RC_CHUNK;
       HIPCHECK(ctx->swChrom.ensure(((size_t)rChunks * 4 + 64) * 4));
       u32* cnt2 = ctx->swChrom.as<u32>();
       u32* off2 = cnt2 + rChunks + 8;
@@ -918,23 +937,28 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
       u32* runStart = ctx->swStart.as<u32>();
       u32* runEnd = ctx->swEnd.as<u32>();
       const u64* skipM = S.hasSkip ? SM.skip : (const u64*)nullptr;
-      hipLaunchKernelGGL(k_runs_write, dim3(wChunks), dim3(SW_NT), 0, s, SM, offS, offE, runStart, runEnd);
+      {  // run count: the true one to the host, at most `cap` for the kernels
+        ScanJobs J{{{cntS, nullptr, wChunks, (u32)SW_CHUNK, offS, misc + M_SWCOUNT, &dm->R, misc + M_TICKET3, cap},
+                    {cntE, nullptr, wChunks, (u32)SW_CHUNK, offE, misc + M_TICKET2, nullptr, nullptr, 0}}};
+        hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, s, J);
+      }
+      hipLaunchKernelGGL(k_runs_write, dim3(wChunks), dim3(SW_NT), 0, s, SM, offS, offE, runStart, runEnd, cap);
+      // (`valid` holds the runs' "opens a candidate" flags until the peak kernels reuse it per candidate;
+      // workgroups beyond the device-side counts leave at once)
       hipLaunchKernelGGL(k_cands_count, dim3(rChunks), dim3(SW_NT), 0, s, SM, skipM, S.end, runStart, runEnd, misc + M_SWCOUNT,
-                         ctx->par.max_gap, S.chromOff, nChrom, cnt2);
+                         ctx->par.max_gap, S.chromOff, nChrom, ctx->valid.as<u32>(), cnt2);
       {
-        ScanJobs J{{{cnt2, nullptr, rChunks, (u32)SW_CHUNK, off2, misc + M_NHEADS, nullptr, nullptr}, {}}};
+        ScanJobs J{{{cnt2, misc + M_SWCOUNT, rChunks, (u32)RC_CHUNK, off2, misc + M_NHEADS, nullptr, nullptr, 0}, {}}};
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, J);
       }
-      hipLaunchKernelGGL(k_cands_write, dim3(rChunks), dim3(SW_NT), 0, s, SM, skipM, S.end, runStart, runEnd, misc + M_SWCOUNT,
-                         ctx->par.max_gap, S.chromOff, nChrom, off2, ctx->headPos.as<u32>());
-      HIPCHECK(ctx->candHdr.ensure((size_t)R * sizeof(uint4)));
-      HIPCHECK(ctx->longList.ensure((size_t)R * 4 + 16));
-      hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((R + 255) / 256, 4096u))), dim3(256), 0, s, SM, S.end, runStart,
+      hipLaunchKernelGGL(k_cands_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_SWCOUNT, off2,
+                         ctx->headPos.as<u32>());
+      hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((cap + 255) / 256, 4096u))), dim3(256), 0, s, SM, S.end, runStart,
                          runEnd, misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->candHdr.as<uint4>(),
                          ctx->longList.as<u32>(), misc + M_TICKET3);
       {
-        const dim3 grid(std::max(1u, std::min((R + 255) / 256, 8192u)));
-        const dim3 gridW(std::max(1u, std::min((R + 3) / 4, (u32)(2 * ctx->numCU))));
+        const dim3 grid(std::max(1u, std::min((cap + 15) / 16, 16384u)));  // 16 candidates per workgroup and round
+        const dim3 gridW(std::max(1u, std::min((cap + 3) / 4, (u32)(8 * ctx->numCU))));
 #define GX_LAUNCH_PEAK_SHORT(Q)                                                                                          \
   hipLaunchKernelGGL((k_peak_short<Q>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,     \
                      misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),             \
@@ -945,20 +969,38 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
                            ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
                            ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
       }
-      // candidates C <= R: chunk arrays sized by R's chunk count; kernels bound themselves by *nCands
+      // candidates C <= R: chunk arrays sized by the run capacity; kernels bound themselves by *nCands
       hipLaunchKernelGGL(k_peaks_count, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
       {
-        ScanJobs J{{{cnt3, misc + M_NHEADS, rChunks, (u32)SW_CHUNK, off3, misc + M_NPEAKS, &dm->nPeaks, nullptr}, {}}};
+        ScanJobs J{{{cnt3, misc + M_NHEADS, rChunks, (u32)RC_CHUNK, off3, misc + M_NPEAKS, &dm->nPeaks, nullptr, 0}, {}}};
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, J);
       }
+      static const bool peaksViaDevice = getenv("GX_PEAKS_DEVICE") != nullptr;  // (experiment)
+      if (peaksViaDevice) HIPCHECK(ctx->peaksDev.ensure((size_t)cap * sizeof(gx_peak) + 16));
       hipLaunchKernelGGL(k_peaks_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
-                         misc + M_NHEADS, off3, static_cast<gx_peak*>(ctx->hPeaks.dp));
+                         misc + M_NHEADS, off3,
+                         peaksViaDevice ? ctx->peaksDev.as<gx_peak>() : static_cast<gx_peak*>(ctx->hPeaks.dp));
       if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
+      // the end: status, counts (and whatever else is pending) through the mail kernel, one synchronisation
+      if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
+      R = ctx->mail->R;
+      ctx->runSeen = R;
+      if (R <= cap) break;
+      if (attempt >= 2) {
+        ctx->err = "peak sweep: run count changed between attempts";
+        return GX_ERR_DEVICE;
+      }
+      ctx->runCap = (u64)R + R / 4 + 1024;  // the guess was too small: once more, with arrays that fit
     }
+    ctx->runCap = std::max<u64>(ctx->runCap, (u64)R + R / 4 + 1024);
+  } else {
+    if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
   }
-  // the end: status (and whatever else is pending) through the mail kernel, one synchronisation
-  if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
   if (R) nPeaks = ctx->mail->nPeaks;
+  if (nPeaks && getenv("GX_PEAKS_DEVICE")) {
+    HIPCHECK(hipMemcpyAsync(ctx->hPeaks.p, ctx->peaksDev.p, (size_t)nPeaks * sizeof(gx_peak), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+  }
   ctx->nHostPeaks = nPeaks;
   const gx_peak* hp = static_cast<const gx_peak*>(ctx->hPeaks.p);
   uint64_t bp = 0;
@@ -1572,7 +1614,9 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     const size_t lds = mergeN_lds_bytes((int)nr);
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
-    hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(4 * ctx->numCU))), dim3(MG_NT), lds, s, S,
+    int mnBlocks = 0;
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN, MG_NT, lds));
+    hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(std::max(1, mnBlocks) * ctx->numCU))), dim3(MG_NT), lds, s, S,
                        ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
                        ctx->dRisk.as<RiskBuf>());
     if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
@@ -1613,8 +1657,11 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   ctx->genomeLenUsed = g;
   ctx->mail->genome = g;
   ctx->mail->n = n;
-  HIPCHECK(hipMemcpyAsync(misc + M_GENOME, &ctx->mail->genome, 8, hipMemcpyHostToDevice, s));
-  HIPCHECK(hipMemcpyAsync(misc + M_NIV, &ctx->mail->n, 4, hipMemcpyHostToDevice, s));
+  // genome length and interval count for the kernels that read them through pointers (BH, k_sig_mask): one tiny
+  // kernel instead of two copy launches, and none at all when the masks came with the p-values
+  const bool masksReady = ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;
+  if (ctx->par.qval_opt || !masksReady)
+    hipLaunchKernelGGL(k_set_misc, dim3(1), dim3(1), 0, s, misc, (u32)M_NIV, (u32)M_GENOME, (u64)g, n);
 
   if (ctx->par.qval_opt) {
     phase_begin(ctx, "bh");
@@ -1762,9 +1809,23 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       HIPCHECK(ctx->bhTmp.ensure(tmpBytes + 16));
       HIPCHECK(rocprim::radix_sort_pairs(ctx->bhTmp.p, tmpBytes, ctx->bhOutKeys.as<u32>(), ctx->bhSortKeys.as<u32>(),
                                          ctx->bhOutSlot.as<u32>(), ctx->bhSortSlot.as<u32>(), D, 0, 32, s));
-      hipLaunchKernelGGL(k_qtable, dim3(1), dim3(1024), 0, s, ctx->bhSortKeys.as<u32>(), ctx->bhSortSlot.as<u32>(),
-                         ctx->bhLens.as<u64>(), D, reinterpret_cast<const u64*>(misc + M_GENOME), ctx->bhQ.as<float>(),
-                         ctx->bhRaw.as<float>(), misc + M_ALLONE);
+      if (D <= 16384 && !getenv("GX_QT_MULTI")) {
+        hipLaunchKernelGGL(k_qtable, dim3(1), dim3(1024), 0, s, ctx->bhSortKeys.as<u32>(), ctx->bhSortSlot.as<u32>(),
+                           ctx->bhLens.as<u64>(), D, reinterpret_cast<const u64*>(misc + M_GENOME), ctx->bhQ.as<float>(),
+                           ctx->bhRaw.as<float>(), misc + M_ALLONE);
+      } else {  // many distinct values (Fisher-combined replicates): the chunked kernels
+        const u32 nCh = (D + QT_CHUNK - 1) / QT_CHUNK;
+        HIPCHECK(ctx->bhDl.ensure((size_t)D * 8 + (size_t)nCh * 12 + 64));
+        u64* dl = ctx->bhDl.as<u64>();
+        u64* chunkSum = dl + D;
+        float* chunkMin = reinterpret_cast<float*>(chunkSum + nCh);
+        hipLaunchKernelGGL(k_qt_sums, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortSlot.as<u32>(), ctx->bhLens.as<u64>(), D, dl,
+                           chunkSum);
+        hipLaunchKernelGGL(k_qt_raw, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortKeys.as<u32>(), dl, D,
+                           reinterpret_cast<const u64*>(misc + M_GENOME), chunkSum, ctx->bhRaw.as<float>(), chunkMin);
+        hipLaunchKernelGGL(k_qt_apply, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortSlot.as<u32>(), ctx->bhRaw.as<float>(), D,
+                           chunkMin, ctx->bhQ.as<float>(), misc + M_ALLONE);
+      }
   if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     }
     HIPCHECK(pooled(ctx, fa.q, (size_t)n * 4 + 16));
@@ -1801,10 +1862,8 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     src.mStride = src.haveMasks ? ctx->maskStride : (size_t)src.nWords + 2;
     src.hasSkip = true;
     HIPCHECK(ctx->swMask.ensure(src.mStride * 8 * 3));
-    if (src.haveMasks)
-      HIPCHECK(hipMemsetAsync(ctx->swMask.as<u64>() + 2 * src.mStride, 0, src.mStride * 8, s));
-    else
-      HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, src.mStride * 8 * 3, s));
+    // (whoever filled the sig / skip masks zeroed all three: the chromosome-start mask is still clear)
+    if (!src.haveMasks) HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, src.mStride * 8 * 3, s));
   }
   ctx->maskIdx = -1;
   u32 nPeaks = 0;
@@ -1946,6 +2005,12 @@ int gx_total_intervals(gx_ctx* ctx, int which, size_t* n_iv) {
   int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
   if (w < 0 || w >= (int)ctx->reps.size()) return GX_ERR_ORDER;
   *n_iv = ctx->reps[w].n;
+  return GX_OK;
+}
+
+int gx_set_phase_timing(gx_ctx* ctx, int level) {
+  if (!ctx || level < 0 || level > 2) return GX_ERR_ORDER;
+  ctx->phaseLevel = level;
   return GX_OK;
 }
 

@@ -461,8 +461,14 @@ struct MergeNOut {   // loose slots: tile t writes at sum_r tileOff_r[t]
 //      LDS atomic, so an entry is never torn).  Risky roundings (gx_math.h) are not cached: they go on the
 //      host's list every time.
 // Tiles with more than MN_CAP merged intervals take several rounds.
-constexpr int MN_CAP = 1024;     // merged intervals per round
-constexpr int MN_CACHE = 1024;   // cache entries (16 B)
+#ifndef GX_MN_CAP
+#define GX_MN_CAP 512
+#endif
+#ifndef GX_MN_CACHE_LOG
+#define GX_MN_CACHE_LOG 9
+#endif
+constexpr int MN_CAP = GX_MN_CAP;                 // merged intervals per round
+constexpr int MN_CACHE = 1 << GX_MN_CACHE_LOG;    // cache entries (16 B)
 struct MnEntry { u32 lo, hi; float p; u32 df; };
 __host__ __device__ constexpr size_t mergeN_lds_bytes(int n) {
   return (size_t)n * MG_WORDS * 4 + (size_t)n * MG_WORDS * 2 + MN_CAP * 2 /*offL*/ + MN_CAP * 8 /*missSum*/ +
@@ -551,8 +557,7 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
           continue;
         }
         const u32 lo = (u32)__double_as_longlong(sum), hi = (u32)(__double_as_longlong(sum) >> 32);
-        const u32 h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ ((u32)df << 20)) * 0x9E3779B1u) >> (32 - 10);
-        static_assert(MN_CACHE == 1 << 10, "hash width");
+        const u32 h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ ((u32)df << 20)) * 0x9E3779B1u) >> (32 - GX_MN_CACHE_LOG);
         const MnEntry e = cache[h];
         if (e.df == (u32)df && e.lo == lo && e.hi == hi) {
           out.p[o] = e.p;
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
           if (risky) risk_add(risk, RK_FISHER, t, r0 + i, df, sum);
           lo = (u32)__double_as_longlong(sum);
           hi = (u32)(__double_as_longlong(sum) >> 32);
-          h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ (df << 20)) * 0x9E3779B1u) >> (32 - 10);
+          h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ (df << 20)) * 0x9E3779B1u) >> (32 - GX_MN_CACHE_LOG);
           enter = !risky;
           if (enter) atomicMax(&owner[h], j + 1);
         }
@@ -672,9 +677,10 @@ struct RiskTargets {
   float* selfOut;
 };
 
-__global__ __launch_bounds__(256) void k_risk_apply(RiskBuf* __restrict__ rb, u32 n, RiskTargets T) {
+__global__ __launch_bounds__(256) void k_risk_apply(RiskBuf* __restrict__ rb, const RiskRec* __restrict__ recs, u32 n,
+                                                    RiskTargets T) {
   for (u32 i = threadIdx.x; i < n; i += 256) {
-    const RiskRec r = rb->rec[i];
+    const RiskRec r = recs[i];  // (device copy of a long list, or the host's mapped pinned records)
     switch (r.kind) {
       case RK_LUT: T.lutP[r.a] = r.pnew; break;
       case RK_TAB2D: T.p2d[r.a] = r.pnew; break;

@@ -514,6 +514,131 @@ __global__ __launch_bounds__(1024) void k_qtable(const u32* __restrict__ keys, c
   }
 }
 
+// The same table for many distinct values (Fisher-combined replicates give millions): three launches over
+// chunks of QT_CHUNK entries, in reversed order r = D - 1 - i (most significant first).  A chunk's prefix
+// -- base pairs of all more significant values, then the minimum of their raw q -- is the reduction of
+// the earlier chunks' aggregates, which every workgroup forms for itself (D / QT_CHUNK values).
+constexpr int QT_NT = 256, QT_ITEMS = 8, QT_CHUNK = QT_NT * QT_ITEMS;
+
+__global__ __launch_bounds__(QT_NT) void k_qt_sums(const u32* __restrict__ slots, const u64* __restrict__ gLens, u32 D,
+                                                   u64* __restrict__ dl /* [D] by r */, u64* __restrict__ chunkSum) {
+  __shared__ u64 red[QT_NT / 64];
+  const u32 base = blockIdx.x * QT_CHUNK;
+  u64 sum = 0;
+#pragma unroll
+  for (int k = 0; k < QT_ITEMS; k++) {
+    const u32 r = base + k * QT_NT + threadIdx.x;
+    if (r < D) {
+      const u64 v = gLens[slots[D - 1 - r]];
+      dl[r] = v;
+      sum += v;
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 t = 0;
+    for (int w = 0; w < QT_NT / 64; w++) t += red[w];
+    chunkSum[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(QT_NT) void k_qt_raw(const u32* __restrict__ keys, const u64* __restrict__ dl, u32 D,
+                                                  const u64* __restrict__ genomeLenPtr, const u64* __restrict__ chunkSum,
+                                                  float* __restrict__ raw /* [D] by r */, float* __restrict__ chunkMin) {
+  __shared__ u64 s64[QT_NT / 64 + 4];
+  __shared__ float redf[QT_NT / 64];
+  __shared__ u64 pre64;
+  const float logN = -log10f_host((float)*genomeLenPtr);
+  u64 before = 0;  // base pairs of the earlier chunks
+  for (u32 c = threadIdx.x; c < blockIdx.x; c += QT_NT) before += chunkSum[c];
+  before = wave_sum(before);
+  if (lane_id() == 0) s64[threadIdx.x >> 6] = before;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 t = 0;
+    for (int w = 0; w < QT_NT / 64; w++) t += s64[w];
+    pre64 = t;
+  }
+  __syncthreads();
+  const u64 chunkBase = pre64;
+  __syncthreads();
+  const u32 r0 = blockIdx.x * QT_CHUNK + threadIdx.x * QT_ITEMS;  // consecutive entries per thread
+  u64 v[QT_ITEMS], sum = 0;
+#pragma unroll
+  for (int k = 0; k < QT_ITEMS; k++) {
+    v[k] = r0 + k < D ? dl[r0 + k] : 0ull;
+    sum += v[k];
+  }
+  u64 kk = 1 + chunkBase + block_excl_scan_op<u64, QT_NT>(sum, 0ull, s64, OpAddU64());
+  float mn = FLT_MAX;
+#pragma unroll
+  for (int k = 0; k < QT_ITEMS; k++) {
+    if (r0 + k < D) {
+      const float pv = __uint_as_float(keys[D - 1 - (r0 + k)]);
+      const float rw = pv + logN + log10f_host((float)kk);
+      raw[r0 + k] = rw;
+      mn = rw < mn ? rw : mn;
+      kk += v[k];
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const float o = __shfl_xor(mn, d, 64);
+    mn = o < mn ? o : mn;
+  }
+  if (lane_id() == 0) redf[threadIdx.x >> 6] = mn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = FLT_MAX;
+    for (int w = 0; w < QT_NT / 64; w++) t = redf[w] < t ? redf[w] : t;
+    chunkMin[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(QT_NT) void k_qt_apply(const u32* __restrict__ slots, const float* __restrict__ raw, u32 D,
+                                                    const float* __restrict__ chunkMin, float* __restrict__ qOfSlot,
+                                                    u32* __restrict__ allOne) {
+  __shared__ float sf[QT_NT / 64 + 4];
+  __shared__ float redf[QT_NT / 64];
+  __shared__ float preMin;
+  float before = FLT_MAX;  // smallest raw q of the earlier chunks
+  for (u32 c = threadIdx.x; c < blockIdx.x; c += QT_NT) before = chunkMin[c] < before ? chunkMin[c] : before;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const float o = __shfl_xor(before, d, 64);
+    before = o < before ? o : before;
+  }
+  if (lane_id() == 0) redf[threadIdx.x >> 6] = before;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = FLT_MAX;
+    for (int w = 0; w < QT_NT / 64; w++) t = redf[w] < t ? redf[w] : t;
+    preMin = t;
+  }
+  __syncthreads();
+  const float chunkBase = preMin;
+  const u32 r0 = blockIdx.x * QT_CHUNK + threadIdx.x * QT_ITEMS;
+  float rw[QT_ITEMS], mn = FLT_MAX;
+#pragma unroll
+  for (int k = 0; k < QT_ITEMS; k++) {
+    rw[k] = r0 + k < D ? raw[r0 + k] : FLT_MAX;
+    mn = rw[k] < mn ? rw[k] : mn;
+  }
+  float run = block_excl_scan_op<float, QT_NT>(mn, FLT_MAX, sf, OpMinF());
+  run = chunkBase < run ? chunkBase : run;
+#pragma unroll
+  for (int k = 0; k < QT_ITEMS; k++) {
+    if (r0 + k < D) {
+      run = rw[k] < run ? rw[k] : run;
+      const float q = run > 0.0f ? run : 0.0f;
+      qOfSlot[slots[D - 1 - (r0 + k)]] = q;
+      if (r0 + k == 0 && allOne) *allOne = q == 0.0f;  // "All q-values are 1" (245)
+    }
+  }
+}
+
 // per interval: q = table[p] (lookup 196-206), SKIP stays SKIP (237-238); the sweep's significance /
 // SKIP masks are written on the way (whole words: one wavefront per 64 intervals, four words per
 // iteration so that four loads per lane are in flight)
@@ -571,7 +696,10 @@ __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, co
 // List lengths stay on the device (kernels read them through pointers).
 constexpr int SW_NT = 256;
 constexpr int SW_ITEMS = 8;
-constexpr int SW_CHUNK = SW_NT * SW_ITEMS;  // items per workgroup in the chunked compactions
+constexpr int SW_CHUNK = SW_NT * SW_ITEMS;  // mask words per workgroup in the chunked compactions
+// Runs and candidates are few (tens of thousands) and every one costs a chain of dependent loads: one per
+// thread, so the chains of a workgroup run side by side instead of eight in a row.
+constexpr int RC_CHUNK = SW_NT;
 
 // exclusive scan of a short u32 array (chunk counts) by one workgroup; total -> *total (and, when the host
 // wants it at its next synchronisation, -> *totalHost in pinned memory: no copy launch).  One workgroup per
@@ -584,6 +712,7 @@ struct ScanJob {
   u32* total;
   u32* totalHost;    // optional
   u32* zeroMe;       // optional: a counter the kernels after this one expect at zero
+  u32 clamp;         // 0: none; else *total = min(total, clamp) while *totalHost gets the true total (arrays sized by guess)
 };
 struct ScanJobs { ScanJob j[2]; };
 
@@ -604,10 +733,16 @@ __global__ __launch_bounds__(1024) void k_scan_small(ScanJobs J) {
     ex += v;
   }
   if (threadIdx.x == 0) {
-    *jb.total = tot;
+    *jb.total = jb.clamp && tot > jb.clamp ? jb.clamp : tot;
     if (jb.totalHost) *jb.totalHost = tot;
     if (jb.zeroMe) *jb.zeroMe = 0;
   }
+}
+
+// gx_find_peaks' two scalars for the kernels that read them through pointers (M_NIV, M_GENOME of the misc block)
+__global__ void k_set_misc(u32* __restrict__ misc, u32 nivWord, u32 genomeWord, u64 genome, u32 n) {
+  misc[nivWord] = n;
+  *reinterpret_cast<u64*>(misc + genomeWord) = genome;
 }
 
 struct SweepMasks {
@@ -685,7 +820,8 @@ __global__ __launch_bounds__(SW_NT) void k_runs_count(SweepMasks M, u32* __restr
 }
 
 __global__ __launch_bounds__(SW_NT) void k_runs_write(SweepMasks M, const u32* __restrict__ offS, const u32* __restrict__ offE,
-                                                      u32* __restrict__ runStart, u32* __restrict__ runEnd) {
+                                                      u32* __restrict__ runStart, u32* __restrict__ runEnd,
+                                                      u32 cap /* runs the arrays hold (a guess: the host checks the true count) */) {
   __shared__ u32 scratch[8];
   const u32 w0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
   u64 st[SW_ITEMS], en[SW_ITEMS];
@@ -707,13 +843,15 @@ __global__ __launch_bounds__(SW_NT) void k_runs_write(SweepMasks M, const u32* _
     while (x) {
       int bit = __builtin_ctzll(x);
       x &= x - 1;
-      runStart[oa++] = ((w0 + k) << 6) + bit;
+      if (oa < cap) runStart[oa] = ((w0 + k) << 6) + bit;
+      oa++;
     }
     x = en[k];
     while (x) {
       int bit = __builtin_ctzll(x);
       x &= x - 1;
-      runEnd[ob++] = ((w0 + k) << 6) + bit;
+      if (ob < cap) runEnd[ob] = ((w0 + k) << 6) + bit;
+      ob++;
     }
   }
 }
@@ -755,43 +893,43 @@ __global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u64* 
                                                        const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
                                                        const u32* __restrict__ nRuns, int maxGap,
                                                        const u32* __restrict__ chromOff, u32 nChrom,
+                                                       u32* __restrict__ isHead /* [R], for k_cands_write */,
                                                        u32* __restrict__ chunkCnt) {
   __shared__ u32 s_cnt[SW_NT / 64];
   const u32 R = *nRuns;
-  if (blockIdx.x * SW_CHUNK >= R) return;
-  const u32 r0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
+  if (blockIdx.x * RC_CHUNK >= R) return;
+  const u32 r = blockIdx.x * RC_CHUNK + threadIdx.x;
   u32 cnt = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++)
-    if (r0 + k < R) cnt += run_is_head(M, skipMask, end, runStart, runEnd, r0 + k, maxGap, chromOff, nChrom);
+  if (r < R) {
+    cnt = run_is_head(M, skipMask, end, runStart, runEnd, r, maxGap, chromOff, nChrom);
+    isHead[r] = cnt;
+  }
   cnt = wave_sum(cnt);
   if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-__global__ __launch_bounds__(SW_NT) void k_cands_write(SweepMasks M, const u64* __restrict__ skipMask, const u32* __restrict__ end,
-                                                       const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
-                                                       const u32* __restrict__ nRuns, int maxGap,
-                                                       const u32* __restrict__ chromOff, u32 nChrom,
+__global__ __launch_bounds__(SW_NT) void k_cands_write(const u32* __restrict__ isHead, const u32* __restrict__ nRuns,
                                                        const u32* __restrict__ chunkOff, u32* __restrict__ candRun) {
   __shared__ u32 scratch[8];
   const u32 R = *nRuns;
-  if (blockIdx.x * SW_CHUNK >= R) return;
-  const u32 r0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
-  u32 keep = 0, cnt = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++)
-    if (r0 + k < R && run_is_head(M, skipMask, end, runStart, runEnd, r0 + k, maxGap, chromOff, nChrom)) { keep |= 1u << k; cnt++; }
+  if (blockIdx.x * RC_CHUNK >= R) return;
+  const u32 r = blockIdx.x * RC_CHUNK + threadIdx.x;
+  const u32 keep = r < R ? isHead[r] : 0u;
   u32 tot;
-  u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++)
-    if (keep & (1u << k)) candRun[o++] = r0 + k;
+  const u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(keep, scratch, &tot);
+  if (keep) candRun[o] = r;
 }
 
-constexpr u32 PK_SHORT = 1024;
-constexpr int PK_LOADS = 8;
+#ifndef GX_PK_SHORT
+#define GX_PK_SHORT 1024
+#endif
+constexpr u32 PK_SHORT = GX_PK_SHORT;   // longer candidates take a wavefront each (k_peak_walk)
+#ifndef GX_PK_LOADS
+#define GX_PK_LOADS 8
+#endif
+constexpr int PK_LOADS = GX_PK_LOADS;
 
 // candidate -> {first interval, last interval, start coordinate}: one thread per candidate, so the
 // chain candRun -> runStart/runEnd -> end[] is walked by all candidates at once instead of once
@@ -856,10 +994,39 @@ struct PeakAcc {
   }
 };
 
-// candidates of up to PK_SHORT intervals (all but pathological ones): one thread each, a plain
-// in-order loop like updatePeak itself; every candidate of the genome is in flight at once.  Loads
-// are 16 bytes wide (a 64-lane gather costs the texture unit one cycle per lane whatever the width)
-// and PK_LOADS of them per array are in flight: the kernel is a chain of memory round trips.
+// DPP inside a row of 16 lanes: lane K's value for the whole row (gfx90a+ row_share / row_newbcast), and the
+// all-lanes maximum by four rotations.  Register-to-register: no LDS round trip, unlike __shfl.
+template <int K> __device__ __forceinline__ float row_lane(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, false));
+}
+template <int K> struct RowSeqSum {  // acc + v[lane 0] + v[lane 1] + ... + v[lane K], in this order
+  static __device__ __forceinline__ float run(float acc, float v) { return RowSeqSum<K - 1>::run(acc, v) + row_lane<K>(v); }
+};
+template <> struct RowSeqSum<-1> { static __device__ __forceinline__ float run(float acc, float) { return acc; } };
+__device__ __forceinline__ float row_max_f(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));  // row_ror:8
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));
+  return v;
+}
+__device__ __forceinline__ u32 row_max_u(u32 v) {
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));
+  v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));
+  return v;
+}
+
+// candidates of up to PK_SHORT intervals (all but pathological ones): SIXTEEN LANES each -- a DPP row, four
+// candidates per wavefront.  The lanes of a row take 16 consecutive intervals per step: loads, significance
+// test, the float product (949-950) and the summit search run in parallel; only the additions into the AUC
+// are replayed in interval order -- 16 dependent v_add_f32_dpp per step, lane k's product handed to the row
+// by the DPP operand -- so the float sum is updatePeak's.  PK_AHEAD steps of loads are in flight together: a
+// candidate of n intervals costs n / (16 PK_AHEAD) memory round trips, where one thread per candidate
+// (round 1) paid n / 32 round trips AND ran every updatePeak serially (a 1,000-interval candidate held its
+// wavefront for ~100 us, which is what the kernel took).
+constexpr int PK_AHEAD = 4;
 template <bool USEQ>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
 __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hdr, const u32* __restrict__ end,
                                                     const float* __restrict__ p, const float* __restrict__ q,
@@ -867,40 +1034,79 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
                                                     const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
                                                     gx_peak* __restrict__ cand, u32* __restrict__ valid) {
   const u32 C = *nCands;
-  constexpr bool useQ = USEQ;
-  for (u32 c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
-    const uint4 h = hdr[c];
-    const u32 i0 = h.x, i1 = h.y;
-    if (i1 - i0 >= PK_SHORT) continue;
-    PeakAcc a;
-    a.s = h.z;
-    a.origin = h.z;
-    // PK_LOADS aligned 16-byte loads per array in flight (32 intervals per round trip); elements
-    // outside [i0, i1] in the first / last load are skipped (the arrays are padded by 16 bytes)
-    for (u32 b = i0 & ~3u; b <= i1; b += 4 * PK_LOADS) {
-      uint4 e4[PK_LOADS];
-      float4 p4[PK_LOADS], q4[PK_LOADS];
+  const int lane = lane_id(), rowBase = lane & 48, rl = lane & 15;
+  const u32 rowId = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (u32)(lane >> 4);  // 16 rows per workgroup
+  for (u32 c0 = 0; c0 < C; c0 += gridDim.x * 16) {  // (wave-uniform bound: every lane takes part in the shuffles)
+    const u32 c = c0 + rowId;
+    uint4 h = make_uint4(1u, 0u, 0u, 0u);
+    if (c < C) h = hdr[c];
+    const u32 i0 = h.x, i1 = h.y, peakStart = h.z;
+    const bool mine = c < C && i1 - i0 < PK_SHORT;
+    const u32 n = mine ? i1 - i0 + 1 : 0u;
+    u32 steps = (n + 15) >> 4;
+    steps = max(steps, (u32)__shfl_xor((int)steps, 16, 64));
+    steps = max(steps, (u32)__shfl_xor((int)steps, 32, 64));  // the wavefront's longest candidate
+    float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
+    u32 summitPos = 0, summitLen = 0;
+    for (u32 st0 = 0; st0 < steps; st0 += PK_AHEAD) {
+      u32 e[PK_AHEAD], sPrev[PK_AHEAD];
+      float pv[PK_AHEAD], qv[PK_AHEAD];
+      bool in[PK_AHEAD];
 #pragma unroll
-      for (int k = 0; k < PK_LOADS; k++) {
-        e4[k] = make_uint4(0, 0, 0, 0);
-        p4[k] = make_float4(0, 0, 0, 0);
-        q4[k] = make_float4(GX_SKIPF, GX_SKIPF, GX_SKIPF, GX_SKIPF);
-        if (b + 4 * k <= i1) {
-          e4[k] = *reinterpret_cast<const uint4*>(end + b + 4 * k);
-          p4[k] = *reinterpret_cast<const float4*>(p + b + 4 * k);
-          if (useQ) q4[k] = *reinterpret_cast<const float4*>(q + b + 4 * k);
+      for (int a = 0; a < PK_AHEAD; a++) {
+        const u32 i = i0 + (st0 + a) * 16 + rl;
+        in[a] = mine && i <= i1;
+        e[a] = 0; sPrev[a] = 0; pv[a] = 0.0f; qv[a] = GX_SKIPF;
+        if (in[a]) {
+          e[a] = end[i];
+          sPrev[a] = i == i0 ? peakStart : end[i - 1];
+          pv[a] = p[i];
+          if (USEQ) qv[a] = q[i];
         }
       }
 #pragma unroll
-      for (int k = 0; k < PK_LOADS; k++) {
-        const u32 j = b + 4 * k;
-        if (j >= i0 && j <= i1) a.step(e4[k].x, p4[k].x, q4[k].x, useQ, thr);
-        if (j + 1 >= i0 && j + 1 <= i1) a.step(e4[k].y, p4[k].y, q4[k].y, useQ, thr);
-        if (j + 2 >= i0 && j + 2 <= i1) a.step(e4[k].z, p4[k].z, q4[k].z, useQ, thr);
-        if (j + 3 >= i0 && j + 3 <= i1) a.step(e4[k].w, p4[k].w, q4[k].w, useQ, thr);
+      for (int a = 0; a < PK_AHEAD; a++) {
+        if (st0 + a >= steps) break;  // wave-uniform
+        float pq = USEQ ? qv[a] : pv[a];
+        const bool sg = in[a] && pq > thr;  // non-significant intervals inside the span only fill gaps
+        float term = 0.0f;
+        if (sg) term = (float)(e[a] - sPrev[a]) * (pq - thr);  // 949-950: float product ...
+        else pq = -2.0f;
+        const u64 wSg = __ballot(sg);
+        if (wSg) {  // wave-uniform
+          // ... summed in interval order: the other lanes hold +0.0f, which changes nothing
+          auc = RowSeqSum<15>::run(auc, term);
+          // summit of this chunk: maximum pq, earliest lane (956-961); among the lanes at the maximum the first
+          // one with the greatest length (962-968)
+          const float mx = row_max_f(pq);
+          const bool atMax = sg && pq == mx;
+          const u32 len = atMax ? e[a] - sPrev[a] : 0u;
+          const u32 ml = row_max_u(len);
+          const bool rowSg = ((u32)(wSg >> rowBase) & 0xFFFFu) != 0;
+          const bool better = rowSg && mx > summitVal, longer = rowSg && mx == summitVal && ml > summitLen;
+          if (__ballot(better || longer)) {  // wave-uniform: some row moves its summit (rare in a long candidate)
+            const u32 rowMax = (u32)(__ballot(atMax) >> rowBase) & 0xFFFFu;
+            const u32 rowLen = (u32)(__ballot(atMax && len == ml) >> rowBase) & 0xFFFFu;
+            const int firstMax = rowBase + (rowMax ? __builtin_ctz(rowMax) : 0);
+            const int firstLen = rowBase + (rowLen ? __builtin_ctz(rowLen) : 0);
+            const u32 myPos = (u32)(((u64)e[a] + sPrev[a]) / 2 - peakStart);
+            const u32 cPos = (u32)__shfl((int)myPos, firstLen, 64);
+            const float spN = __shfl(pv[a], firstMax, 64), sqN = __shfl(qv[a], firstMax, 64);
+            if (better) {
+              summitVal = mx;
+              sp = spN;
+              sq = sqN;
+              summitPos = cPos;
+              summitLen = ml;
+            } else if (longer) {
+              summitPos = cPos;
+              summitLen = ml;
+            }
+          }
+        }
       }
     }
-    peak_finish(c, h, a.auc, a.summitPos, a.sp, a.sq, minAUC, minLen, chromOff, nChrom, cand, valid);
+    if (mine && rl == 0) peak_finish(c, h, auc, summitPos, sp, sq, minAUC, minLen, chromOff, nChrom, cand, valid);
   }
 }
 
@@ -974,34 +1180,39 @@ __global__ __launch_bounds__(SW_NT) void k_peaks_count(const u32* __restrict__ v
                                                        u32* __restrict__ chunkCnt) {
   __shared__ u32 s_cnt[SW_NT / 64];
   const u32 H = *nHeads;
-  if (blockIdx.x * SW_CHUNK >= H) return;
-  const u32 h0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
-  u32 cnt = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++)
-    if (h0 + k < H) cnt += valid[h0 + k];
+  if (blockIdx.x * RC_CHUNK >= H) return;
+  const u32 h = blockIdx.x * RC_CHUNK + threadIdx.x;
+  u32 cnt = h < H ? valid[h] : 0u;
   cnt = wave_sum(cnt);
   if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// The workgroup's peaks are packed in LDS and leave as one contiguous run of dwords: the destination is pinned
+// host memory, where 64 consecutive dwords of a wavefront make a few full-size PCIe writes and a 28-byte
+// record per lane makes seven small ones.
 __global__ __launch_bounds__(SW_NT) void k_peaks_write(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
                                                        const u32* __restrict__ nHeads, const u32* __restrict__ chunkOff,
                                                        gx_peak* __restrict__ peaks /* pinned host memory */) {
+  constexpr int PW = sizeof(gx_peak) / 4;
+  static_assert(sizeof(gx_peak) % 4 == 0, "gx_peak is a whole number of dwords");
   __shared__ u32 scratch[8];
+  __shared__ u32 stage[RC_CHUNK * PW];
   const u32 H = *nHeads;
-  if (blockIdx.x * SW_CHUNK >= H) return;
-  const u32 h0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
-  u32 keep = 0, cnt = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++)
-    if (h0 + k < H && valid[h0 + k]) { keep |= 1u << k; cnt++; }
+  if (blockIdx.x * RC_CHUNK >= H) return;
+  const u32 h = blockIdx.x * RC_CHUNK + threadIdx.x;
+  const u32 keep = h < H ? valid[h] : 0u;
   u32 tot;
-  u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(cnt, scratch, &tot);
+  const u32 r = block_excl_scan<u32, SW_NT>(keep, scratch, &tot);
+  if (keep) {
+    const u32* src = reinterpret_cast<const u32*>(cand + h);
 #pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++)
-    if (keep & (1u << k)) peaks[o++] = cand[h0 + k];
+    for (int k = 0; k < PW; k++) stage[r * PW + k] = src[k];
+  }
+  __syncthreads();
+  u32* dst = reinterpret_cast<u32*>(peaks + chunkOff[blockIdx.x]);
+  for (u32 i = threadIdx.x; i < tot * PW; i += SW_NT) dst[i] = stage[i];
 }
 
 }  // namespace gx

@@ -72,6 +72,7 @@ _SIGS = {
     "gx_selftest": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_selftest2": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)],
     "gx_selftest_host": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_set_phase_timing": [C.c_void_p, C.c_int],
     "gx_phase_times": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float))],
 }
 
@@ -312,6 +313,10 @@ class Genrich:
         n = C.c_size_t(0)
         self._check(self.lib.gx_total_intervals(self.ctx, int(which), C.byref(n)))
         return n.value
+
+    def set_phase_timing(self, level):
+        """0 none (default), 1 the tile stage only, 2 every phase (each event record costs the stream ~5 us)."""
+        self._check(self.lib.gx_set_phase_timing(self.ctx, int(level)))
 
     def phase_times(self):
         names = C.c_char_p()

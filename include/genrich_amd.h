@@ -233,7 +233,11 @@ int gx_set_keep_pileups(gx_ctx* ctx, int keep);
 /* ---- introspection used by bench.py / tests ---- */
 
 /* Per-phase device times (ms, HIP events on the library's stream) of the last
- * gx_* call sequence; names are NUL-separated in *names. Returns count. */
+ * gx_* call sequence; names are NUL-separated in *names. Returns count.
+ * gx_set_phase_timing chooses what is timed: 0 nothing (default: an event record costs a
+ * ~5 us bubble on the stream), 1 the tile stage only ("t.tile" / "c.tile": what
+ * bench.py's roofline needs inside its timed region), 2 every phase. */
+int gx_set_phase_timing(gx_ctx* ctx, int level);
 int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
 
 /* Evaluate one scalar device function on n inputs (numerics tests):

@@ -21,5 +21,6 @@ for world in worlds:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    gx.set_phase_timing(2); step()
     ph = dict(gx.phase_times())
     print(world, f"{dt*1e3:.3f} ms", {k: round(v, 3) for k, v in ph.items()}, "sum", round(sum(ph.values()), 3), flush=True)
