@@ -184,7 +184,6 @@ struct gx_ctx {
   u32 bhCapLog = 22;            // log2 of its slots (grows by 3 after ST_HASH_FULL)
   // sweep
   DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
-  DevBuf peaksDev;
   PinnedBuf hPeaks;             // the peak list on the host (pinned: the read-back is asynchronous)
   size_t nHostPeaks = 0;
   u32* nIvTarget = nullptr;
@@ -923,9 +922,7 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
       HIPCHECK(ctx->headPos.ensure((size_t)cap * 4 + 16));
       HIPCHECK(ctx->cand.ensure((size_t)cap * sizeof(gx_peak)));
       HIPCHECK(ctx->valid.ensure((size_t)cap * 4 + 16));
-      // (at most one peak per run; never a small allocation -- GX_HPEAKS_MIN: experiment on the mapping granularity)
-      static const size_t hpMin = getenv("GX_HPEAKS_MIN") ? (size_t)atoll(getenv("GX_HPEAKS_MIN")) : 0;
-      HIPCHECK(ctx->hPeaks.ensure(std::max((size_t)cap * sizeof(gx_peak) + 16, hpMin)));
+      HIPCHECK(ctx->hPeaks.ensure((size_t)cap * sizeof(gx_peak) + 16));  // (at most one peak per run)
       HIPCHECK(ctx->candHdr.ensure((size_t)cap * sizeof(uint4)));
       HIPCHECK(ctx->longList.ensure((size_t)cap * 4 + 16));
       const u32 rChunks = (cap + RC_CHUNK - 1) / RC_CHUNK;
@@ -975,11 +972,8 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
         ScanJobs J{{{cnt3, misc + M_NHEADS, rChunks, (u32)RC_CHUNK, off3, misc + M_NPEAKS, &dm->nPeaks, nullptr, 0}, {}}};
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, J);
       }
-      static const bool peaksViaDevice = getenv("GX_PEAKS_DEVICE") != nullptr;  // (experiment)
-      if (peaksViaDevice) HIPCHECK(ctx->peaksDev.ensure((size_t)cap * sizeof(gx_peak) + 16));
       hipLaunchKernelGGL(k_peaks_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
-                         misc + M_NHEADS, off3,
-                         peaksViaDevice ? ctx->peaksDev.as<gx_peak>() : static_cast<gx_peak*>(ctx->hPeaks.dp));
+                         misc + M_NHEADS, off3, static_cast<gx_peak*>(ctx->hPeaks.dp));
       if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
       // the end: status, counts (and whatever else is pending) through the mail kernel, one synchronisation
       if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
@@ -997,10 +991,6 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
     if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
   }
   if (R) nPeaks = ctx->mail->nPeaks;
-  if (nPeaks && getenv("GX_PEAKS_DEVICE")) {
-    HIPCHECK(hipMemcpyAsync(ctx->hPeaks.p, ctx->peaksDev.p, (size_t)nPeaks * sizeof(gx_peak), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-  }
   ctx->nHostPeaks = nPeaks;
   const gx_peak* hp = static_cast<const gx_peak*>(ctx->hPeaks.p);
   uint64_t bp = 0;

@@ -54,50 +54,44 @@ struct Sort1Out {
 // one event -> its two endpoint records.  Returns the weight in 1/120 units (0: nothing to add).
 struct Endpoints { u32 t0, o0, t1, o1; int w; };
 
-// FX: with the side effects of the first conversion (status bits, covered bases, end-of-chromosome weights)
+// FX: with the side effects of the first conversion (status bits, covered bases, end-of-chromosome weights).
+// Straight-line code (selects, one rare branch): the kernel converts eight events per thread, and as a tree of
+// branches -- a switch over the count, one `return` per rejected case -- this function alone was ~180 instructions
+// per event, most of them scalar mask bookkeeping.
+// `c` = the chromosome's record, loaded by the caller for chromosome min(e.x, nChrom - 1) (so that a batch of
+// events has its loads in flight together); `have` = false for the slots past the end of the input.
 template <bool FX>
-__device__ __forceinline__ Endpoints convert_event(const uint4 e, const DChrom* __restrict__ chroms, u32 nChrom, const Sort1Out& out,
+__device__ __forceinline__ Endpoints convert_event(const uint4 e, const DChrom c, bool have, u32 nChrom, const Sort1Out& out,
                                                    u32& bad, u64& covered) {
-  Endpoints r{NULL_TILE, 0u, NULL_TILE, 0u, 0};
-  int w = 0;
-  switch (e.w) {
-    case 1: w = 120; break;
-    case 2: w = 60; break;
-    case 3: w = 40; break;
-    case 4: w = 30; break;
-    case 5: w = 24; break;
-    case 6: w = 20; break;
-    case 8: w = 15; break;
-    case 10: w = 12; break;
-    default: if (FX) bad |= ST_BAD_COUNT;  // ERRALNS, 2402
-  }
-  if (e.x >= nChrom) {
-    if (FX) bad |= ST_BAD_CHROM;
-    return r;
-  }
-  if (!w) return r;
-  const DChrom c = chroms[e.x];
-  if (!chrom_active(c)) return r;
-  if (e.y >= c.len) {  // ERRPOS, 2531
-    if (FX) bad |= ST_BAD_POS;
-    return r;
-  }
-  const u32 end = e.z > c.len ? c.len : e.z;  // 2536-2544
+  // weight 1/count in 1/120 units for count in {1,2,3,4,5,6,8,10} (bit mask 0x57E), else 0: ERRALNS, 2402
+  const u32 cnt = e.w;
+  const bool cntOk = cnt <= 10u && ((0x57Eu >> cnt) & 1u);
+  // (120 / count is an integer for every accepted count: the rounded float quotient is exact)
+  const int w0 = cntOk ? (int)(120.5f * __builtin_amdgcn_rcpf((float)cnt)) : 0;
+  const bool chromOk = e.x < nChrom;
+  const bool posOk = e.y < c.len;               // ERRPOS, 2531
+  const u32 end = e.z > c.len ? c.len : e.z;    // 2536-2544
   // (an empty interval adds and removes the same weight.  One that ends before it starts -- the reference's
   // BAM reader makes them from reverse reads without SEQ -- is counted like any other: +w at its start, -w
   // at its end, a negative length towards fragLen)
-  if (end == e.y) return r;
-  if (FX) covered += (u64)((long long)end - (long long)e.y);
-  r.w = w;
-  r.t0 = c.tileBase + (e.y >> TB);
+  const bool live = have && chromOk && w0 != 0 && chrom_active(c) && posOk && end != e.y;
+  if (FX) {
+    bad |= !have ? 0u
+                 : (cntOk ? 0u : ST_BAD_COUNT) | (chromOk ? 0u : ST_BAD_CHROM) |
+                       (chromOk && w0 != 0 && chrom_active(c) && !posOk ? ST_BAD_POS : 0u);
+    covered += live ? (u64)((long long)end - (long long)e.y) : 0ull;
+  }
+  Endpoints r;
+  r.w = live ? w0 : 0;
+  r.t0 = live ? c.tileBase + (e.y >> TB) : NULL_TILE;
   r.o0 = e.y & (TILE - 1);
-  if (end < c.len) {
-    r.t1 = c.tileBase + (end >> TB);
-    r.o1 = end & (TILE - 1);
-  } else if (FX && atomicAdd(&out.endAtLen[e.x], (u32)w) + (u32)w >= HOT16) {
+  const bool hasEnd = live && end < c.len;
+  r.t1 = hasEnd ? c.tileBase + (end >> TB) : NULL_TILE;
+  r.o1 = end & (TILE - 1);
+  if (FX && live && !hasEnd) {  // rare: the fragment reaches the chromosome's end
     // the reference's diff has an entry at `len` too, and its int16 saturates there like anywhere else
     // (2565-2573): these ends have no record, so they are counted here
-    atomicOr(out.hot, 1u);
+    if (atomicAdd(&out.endAtLen[e.x], (u32)w0) + (u32)w0 >= HOT16) atomicOr(out.hot, 1u);
   }
   return r;
 }
@@ -106,10 +100,14 @@ __device__ __forceinline__ Endpoints convert_event(const uint4 e, const DChrom* 
 #define GX_S1_NT 1024
 #endif
 constexpr int S1_NT = GX_S1_NT;             // threads per workgroup
-constexpr int S1_CHUNK = 8192;              // events per workgroup
+#ifndef GX_S1_CHUNK
+#define GX_S1_CHUNK 8192
+#endif
+constexpr int S1_CHUNK = GX_S1_CHUNK;       // events per workgroup
 constexpr int S1_ITEMS = S1_CHUNK / S1_NT;
 constexpr int S1_BPT = MAX_BINS / S1_NT;    // level-1 bins owned by a thread
-static_assert(S1_CHUNK == (1 << PgCfg<u32>::SHIFT), "a chunk's run for one bin never spans more than two pages");
+static_assert(S1_CHUNK <= (1 << PgCfg<u32>::SHIFT), "a chunk's run for one bin never spans more than two pages");
+constexpr u32 S1_STAGE_BYTES = S1_CHUNK * 4;  // a round's records: S1_CHUNK keys, or S1_CHUNK / 2 F records
 static_assert(S1_BPT == 2 || S1_BPT == 4, "two or four bins per thread");
 
 struct S1Lds {
@@ -119,7 +117,7 @@ struct S1Lds {
   u32 base1[MAX_BINS];       // ... of its first record in the second page
   __attribute__((aligned(8))) u32 scratch[40];
   u32 count;
-  __attribute__((aligned(16))) unsigned char stage[PG_BYTES];
+  __attribute__((aligned(16))) unsigned char stage[S1_STAGE_BYTES];
 };
 
 // the page whose first slot the caller's run holds: allocate and publish
@@ -160,7 +158,7 @@ __device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStr
                                               u32* __restrict__ st) {
   constexpr int SHIFT = PgCfg<R>::SHIFT;
   constexpr u32 PG = 1u << SHIFT;
-  static_assert((size_t)NR * S1_NT * sizeof(R) <= PG_BYTES && (u32)NR * S1_NT <= PG, "one page holds a workgroup's records");
+  static_assert((size_t)NR * S1_NT * sizeof(R) <= S1_STAGE_BYTES && (u32)NR * S1_NT <= PG, "one page holds a workgroup's records");
   const u32 x = blockIdx.x % NXCD;
   R* stage = reinterpret_cast<R*>(L.stage);
   for (int i = threadIdx.x; i < (int)nBins; i += S1_NT) L.hist[i] = 0;
@@ -249,12 +247,29 @@ __device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStr
   __syncthreads();
   const u32 cnt = L.count;
   R* pool = reinterpret_cast<R*>(P.pool);
-  for (u32 i = threadIdx.x; i < cnt; i += S1_NT) {
-    const R v = stage[i];
-    const u32 b = RecT<R>::tile(v) >> sbShift;
-    const u32 ss = L.startSplit[b];
-    const u32 r = i - (ss & 0xFFFFu), sp = ss >> 16;
-    pool[r < sp ? L.base0[b] + r : L.base1[b] + (r - sp)] = v;
+  // (a fixed, unrolled trip count: the LDS reads of all NR records are in flight together)
+  R v[NR];
+  u32 ss[NR], b0[NR], b1[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const u32 i = (u32)k * S1_NT + threadIdx.x;
+    v[k] = stage[i < cnt ? i : 0u];
+  }
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const u32 i = (u32)k * S1_NT + threadIdx.x;
+    const u32 b = i < cnt ? RecT<R>::tile(v[k]) >> sbShift : 0u;
+    ss[k] = L.startSplit[b];
+    b0[k] = L.base0[b];
+    b1[k] = L.base1[b];
+  }
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const u32 i = (u32)k * S1_NT + threadIdx.x;
+    if (i < cnt) {
+      const u32 r = i - (ss[k] & 0xFFFFu), sp = ss[k] >> 16;
+      pool[r < sp ? b0[k] + r : b1[k] + (r - sp)] = v[k];
+    }
   }
   __syncthreads();
 }
@@ -270,21 +285,29 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
   u32 bad = 0, frac = 0;
   u64 covered = 0;
   u32 ks[S1_ITEMS], ke[S1_ITEMS];
+  // batches of S1_BATCH events: their loads, then their chromosomes' records, are in flight together (one event
+  // after the other, each waiting for its two dependent loads, the conversion was a chain of 16 memory round trips)
+  constexpr int S1_BATCH = 4;
 #pragma unroll
-  for (int k = 0; k < S1_ITEMS; k++) {
-    const u32 i = begin + k * S1_NT + threadIdx.x;
-    ks[k] = NULL32;
-    ke[k] = NULL32;
-    if (i < n) {
-      const uint4 e = reinterpret_cast<const uint4*>(ev)[i];  // chrom, start, end, count
-      const Endpoints p = convert_event<true>(e, chroms, nChrom, out, bad, covered);
-      if (p.w) {
-        if (UNIT32 && p.w == GX_UNIT) {
-          ks[k] = (p.t0 << TB) | p.o0;
-          if (p.t1 != NULL_TILE) ke[k] = (p.t1 << TB) | p.o1;
-        } else
-          frac = 1;
-      }
+  for (int k0 = 0; k0 < S1_ITEMS; k0 += S1_BATCH) {
+    uint4 e[S1_BATCH];
+    DChrom c[S1_BATCH];
+    bool have[S1_BATCH];
+#pragma unroll
+    for (int q = 0; q < S1_BATCH; q++) {
+      const u32 i = begin + (k0 + q) * S1_NT + threadIdx.x;
+      have[q] = i < n;
+      e[q] = reinterpret_cast<const uint4*>(ev)[have[q] ? i : n - 1];  // chrom, start, end, count
+    }
+#pragma unroll
+    for (int q = 0; q < S1_BATCH; q++) c[q] = chroms[min(e[q].x, nChrom - 1)];
+#pragma unroll
+    for (int q = 0; q < S1_BATCH; q++) {
+      const Endpoints p = convert_event<true>(e[q], c[q], have[q], nChrom, out, bad, covered);
+      const bool unit = UNIT32 && p.w == GX_UNIT;
+      ks[k0 + q] = unit ? (p.t0 << TB) | p.o0 : NULL32;
+      ke[k0 + q] = unit && p.t1 != NULL_TILE ? (p.t1 << TB) | p.o1 : NULL32;
+      frac |= (u32)(p.w != 0 && !unit);
     }
   }
   if (UNIT32) {
@@ -306,7 +329,7 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
           const uint4 e = reinterpret_cast<const uint4*>(ev)[i];
           u32 bad2 = 0;
           u64 cov2 = 0;
-          const Endpoints p = convert_event<false>(e, chroms, nChrom, out, bad2, cov2);
+          const Endpoints p = convert_event<false>(e, chroms[min(e.x, nChrom - 1)], true, nChrom, out, bad2, cov2);
           if (p.w && !(UNIT32 && p.w == GX_UNIT)) {
             fr[2 * q] = make_rec64(p.t0, p.o0, p.w);
             if (p.t1 != NULL_TILE) fr[2 * q + 1] = make_rec64(p.t1, p.o1, -p.w);

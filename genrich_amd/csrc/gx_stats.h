@@ -1110,7 +1110,10 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
   }
 }
 
-// one wavefront per candidate: updatePeak (943-970) over its intervals, then checkPeak (916-927)
+// one wavefront per candidate: updatePeak (943-970) over its intervals, then checkPeak (916-927).  64 intervals
+// per step, PK_AHEAD steps of loads in flight; the ordered float sum runs row after row (16 dependent DPP adds
+// each, the running value carried from row to row by a readlane); maxima by DPP rotations inside the rows and
+// readlanes across them: no LDS shuffle anywhere.
 __global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr, const u32* __restrict__ end,
                                                    const float* __restrict__ p, const float* __restrict__ q,
                                                    const u32* __restrict__ chromOff, u32 nChrom,
@@ -1120,54 +1123,66 @@ __global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr
   const u32 L = *nLong;
   const u32 wavesPerGrid = gridDim.x * 4;
   const int lane = lane_id();
+  auto rdf = [](float v, int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
   for (u32 li = blockIdx.x * 4 + (threadIdx.x >> 6); li < L; li += wavesPerGrid) {
     const u32 c = longList[li];
     const uint4 h = hdr[c];
     const u32 i0 = h.x, i1 = h.y, peakStart = h.z;
     float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
     u32 summitPos = 0, summitLen = 0;
-    for (u32 base = i0; base <= i1; base += 64) {
-      const u32 i = base + lane;
-      const bool in = i <= i1;
-      float pv = 0.0f, qv = GX_SKIPF, pq = -2.0f, term = 0.0f;
-      u32 s = 0, e = 0;
-      if (in) {
-        e = end[i];
-        s = i == i0 ? peakStart : end[i - 1];
-        pv = p[i];
-        if (q) qv = q[i];
-        pq = q ? qv : pv;
+    for (u32 base = i0; base <= i1; base += 64 * PK_AHEAD) {
+      u32 e[PK_AHEAD], sPrev[PK_AHEAD];
+      float pv[PK_AHEAD], qv[PK_AHEAD];
+      bool in[PK_AHEAD];
+#pragma unroll
+      for (int a = 0; a < PK_AHEAD; a++) {
+        const u32 i = base + a * 64 + lane;
+        in[a] = i <= i1;
+        e[a] = 0; sPrev[a] = 0; pv[a] = 0.0f; qv[a] = GX_SKIPF;
+        if (in[a]) {
+          e[a] = end[i];
+          sPrev[a] = i == i0 ? peakStart : end[i - 1];
+          pv[a] = p[i];
+          if (q) qv[a] = q[i];
+        }
       }
-      const bool sg = in && pq > thr;       // non-significant intervals inside the span only fill gaps
-      if (!sg) pq = -2.0f; else term = (float)(e - s) * (pq - thr);  // 949-950: float product ...
-      u64 sgMask = __ballot(sg);
-      if (sgMask) {  // ... summed in lane order; the other lanes hold +0.0f, which changes nothing
 #pragma unroll
-        for (int k = 0; k < 64; k++) auc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(term), k));
-      }
-      if (sgMask) {
-        // summit of this chunk: maximum pq, earliest lane (956-961); among the lanes at the maximum
-        // the first one with the greatest length (962-968)
-        float mx = pq;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-        const u64 atMax = __ballot(sg && pq == mx);
-        const int firstMax = __builtin_ctzll(atMax);
-        const u32 len = (sg && pq == mx) ? e - s : 0;
-        u32 ml = len;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) ml = max(ml, (u32)__shfl_xor((int)ml, d, 64));
-        const int firstLen = __builtin_ctzll(__ballot(sg && pq == mx && len == ml));
-        const u32 cPos = (u32)(((u64)(u32)__shfl((int)e, firstLen, 64) + (u32)__shfl((int)s, firstLen, 64)) / 2 - peakStart);
-        if (mx > summitVal) {
-          summitVal = mx;
-          sp = __shfl(pv, firstMax, 64);
-          sq = __shfl(qv, firstMax, 64);
-          summitPos = cPos;
-          summitLen = ml;
-        } else if (mx == summitVal && ml > summitLen) {
-          summitPos = cPos;
-          summitLen = ml;
+      for (int a = 0; a < PK_AHEAD; a++) {
+        if (base + a * 64 > i1) break;  // wave-uniform
+        float pq = q ? qv[a] : pv[a];
+        const bool sg = in[a] && pq > thr;       // non-significant intervals inside the span only fill gaps
+        float term = 0.0f;
+        if (sg) term = (float)(e[a] - sPrev[a]) * (pq - thr);  // 949-950: float product ...
+        else pq = -2.0f;
+        if (__ballot(sg)) {  // wave-uniform
+          // ... summed in lane order, row after row; the other lanes hold +0.0f, which changes nothing
+          float acc = RowSeqSum<15>::run(auc, term);
+          acc = RowSeqSum<15>::run(rdf(acc, 0), term);
+          acc = RowSeqSum<15>::run(rdf(acc, 16), term);
+          acc = RowSeqSum<15>::run(rdf(acc, 32), term);
+          auc = rdf(acc, 48);
+          // summit of this chunk: maximum pq, earliest lane (956-961); among the lanes at the maximum
+          // the first one with the greatest length (962-968)
+          float mx = row_max_f(pq);
+          mx = fmaxf(fmaxf(rdf(mx, 0), rdf(mx, 16)), fmaxf(rdf(mx, 32), rdf(mx, 48)));
+          const bool atMax = sg && pq == mx;
+          const u32 len = atMax ? e[a] - sPrev[a] : 0u;
+          u32 ml = row_max_u(len);
+          ml = max(max((u32)__builtin_amdgcn_readlane((int)ml, 0), (u32)__builtin_amdgcn_readlane((int)ml, 16)),
+                   max((u32)__builtin_amdgcn_readlane((int)ml, 32), (u32)__builtin_amdgcn_readlane((int)ml, 48)));
+          if (mx > summitVal || (mx == summitVal && ml > summitLen)) {  // wave-uniform
+            const int firstMax = __builtin_ctzll(__ballot(atMax));
+            const int firstLen = __builtin_ctzll(__ballot(atMax && len == ml));
+            const u32 myPos = (u32)(((u64)e[a] + sPrev[a]) / 2 - peakStart);
+            const u32 cPos = (u32)__builtin_amdgcn_readlane((int)myPos, firstLen);
+            if (mx > summitVal) {
+              summitVal = mx;
+              sp = rdf(pv[a], firstMax);
+              sq = rdf(qv[a], firstMax);
+            }
+            summitPos = cPos;
+            summitLen = ml;
+          }
         }
       }
     }

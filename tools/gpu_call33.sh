@@ -1,0 +1,19 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -s KILL 900 python -m pytest tests -m gpu -q --timeout 600 -x > gpurun_out/c33_pytest.log 2>&1
+grep -E "passed|failed|^FAILED|Error" gpurun_out/c33_pytest.log | tail -12
+run() { tag=$1; shift; ( env "$@" timeout -s KILL 300 python bench.py --steps 20 --warmup 3 --no-cpu --no-e2e ) > gpurun_out/c33_bench_$tag.json 2> gpurun_out/c33_bench_$tag.err; }
+run dflt
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/c33_bench*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d["ms_per_step"],3), {k: round(v,3) for k,v in d["phases_ms"].items()}, d["config"]["peaks"], d.get("gate",{}).get("passed"))
+    except Exception as e: print(f, "ERR", e, open(f.replace(".json",".err")).read()[-600:])
+PY
+export TMPDIR=/tmp
+for m in 0 1; do
+if [ $m = 1 ]; then export GX_POKE=1; fi
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_emul8f_$m/trace -o emul -- python tools/emulate_ranks.py 8 > gpurun_out/c33_emul_$m.log 2>&1
+echo "== poke $m"; grep -v amdgpu gpurun_out/c33_emul_$m.log | grep " ms " | tail -1; python tools/trace_timeline.py gpurun_out/prof_emul8f_$m/trace k_sort1 -2 | grep -E "k_peaks_write|k_peak_short|k_peak_walk|k_poke|k_mail"
+done

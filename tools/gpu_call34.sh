@@ -1,0 +1,17 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -s KILL 900 python -m pytest tests -m gpu -q --timeout 600 -x > gpurun_out/c34_pytest.log 2>&1
+grep -E "passed|failed|^FAILED|Error" gpurun_out/c34_pytest.log | tail -12
+run() { tag=$1; shift; ( env "$@" timeout -s KILL 300 python bench.py --steps 20 --warmup 3 --no-cpu --no-e2e ) > gpurun_out/c34_bench_$tag.json 2> gpurun_out/c34_bench_$tag.err; }
+run dflt
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/c34_bench*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d["ms_per_step"],3), {k: round(v,3) for k,v in d["phases_ms"].items()}, d["config"]["peaks"], d.get("gate",{}).get("passed"))
+    except Exception as e: print(f, "ERR", e, open(f.replace(".json",".err")).read()[-600:])
+PY
+export TMPDIR=/tmp
+GX_PROF_PASSES=trace timeout -s KILL 400 tools/profile_round.sh r02e 2 > gpurun_out/c34_prof.log 2>&1
+python tools/trace_timeline.py gpurun_out/prof_r02e/trace k_sort1 -2 | tail -24
+timeout -s KILL 300 python tools/emulate_ranks.py 8 2>&1 | grep -v amdgpu.ids | tail -1
