@@ -199,6 +199,7 @@ struct gx_ctx {
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
   DevBuf dColl, dCounts, dGather;
   int phaseLevel = 0;       // gx_set_phase_timing
+  u32 statusSeen = 1;       // status bits read back since the device word was last cleared (1: not cleared yet)
   u64 runCap = 0, runSeen = 0;  // run_sweep: runs its arrays are sized for; runs of the last sweep
   bool phaseOpen = false;
   int numCU = 0, resTile = 0, resTileHalf = 0, resTileFast = 0, resSweep = 0;  // co-resident workgroups per kernel class
@@ -286,6 +287,7 @@ void phase_end(gx_ctx* ctx) {
 }
 
 int status_to_rc(gx_ctx* ctx, u32 st) {
+  ctx->statusSeen |= st;  // (gx_reset clears the device word only when something was ever raised)
   if (!st) return GX_OK;
   struct { u32 bit; int rc; const char* msg; } tab[] = {
       {ST_LOOKBACK, GX_ERR_DEVICE, "look-back / page-table spin limit reached"},
@@ -390,9 +392,15 @@ uint64_t genome_len_for(const gx_ctx* ctx, const std::vector<uint8_t>& present) 
   return g;
 }
 
-int upload_chroms(gx_ctx* ctx) {
-  for (u32 i = 0; i < ctx->nChrom; i++)
-    ctx->hChrom[i].flags = (ctx->skip[i] ? CH_SKIP : 0) | (ctx->save[i] ? CH_SAVE : 0) | (ctx->owned[i] ? CH_OWNED : 0);
+int upload_chroms(gx_ctx* ctx, bool force = true) {
+  bool changed = force;
+  for (u32 i = 0; i < ctx->nChrom; i++) {
+    const u32 f = (ctx->skip[i] ? CH_SKIP : 0) | (ctx->save[i] ? CH_SAVE : 0) | (ctx->owned[i] ? CH_OWNED : 0);
+    changed |= f != ctx->hChrom[i].flags;
+    ctx->hChrom[i].flags = f;
+  }
+  if (!changed) return GX_OK;  // (the table on the device is this one already: no copy launch per sample)
+  // (hChrom may be rewritten by the next call while this copy is in flight: pageable memory is staged by the runtime)
   HIPCHECK(hipMemcpyAsync(ctx->dChrom.p, ctx->hChrom.data(), ctx->nChrom * sizeof(DChrom), hipMemcpyHostToDevice,
                           ctx->stream));
   return GX_OK;
@@ -1288,7 +1296,10 @@ int gx_reset(gx_ctx* ctx) {
   ctx->segs.clear();
   ctx->evChunkIdx = ctx->evChunkFill = ctx->evPoolUsed = 0;
   ctx->nHostPeaks = 0;
-  HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
+  if (ctx->statusSeen) {  // (a clean run leaves the status words at zero: no fill launch)
+    HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
+    ctx->statusSeen = 0;
+  }
   return GX_OK;
 }
 
@@ -1302,7 +1313,7 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
       if (ctx->reps[r].loose || ctx->reps[r].pilesPending)
         if (int rc = ensure_piles(ctx, (int)r)) return rc;
     for (u32 i = 0; i < ctx->nChrom; i++) ctx->save[i] = save ? (save[i] != 0) : 1;
-    int rc = upload_chroms(ctx);
+    int rc = upload_chroms(ctx, false);
     if (rc) return rc;
     uint64_t g = ctx->par.genome_len ? ctx->par.genome_len : genome_len_for(ctx, ctx->save);
     if (!g) {
@@ -1312,7 +1323,7 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
     Scalars z{};
     z.genomeLen = g;
     ctx->hScal = z;
-    HIPCHECK(hipMemcpyAsync(ctx->dScal.p, &ctx->hScal, sizeof(Scalars), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_begin_sample, dim3(1), dim3(64), 0, ctx->stream, ctx->dScal.as<Scalars>(), (u64)g);  // (no copy launch)
     ctx->nPhases = 0;
     ctx->phase = 1;
   } else {

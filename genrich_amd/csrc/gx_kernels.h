@@ -1232,6 +1232,15 @@ __global__ void k_frag_select(const FragFix* __restrict__ ff, long long* acc, lo
     finish_frag(scal, isCtrl, st, nullptr);  // one rank: the sums are final (otherwise k_finish_frag, after the all-reduce)
 }
 
+// a replicate begins: its scalars at zero, the genome length in place
+__global__ void k_begin_sample(Scalars* __restrict__ s, u64 genomeLen) {
+  static_assert(sizeof(Scalars) % 8 == 0 && sizeof(Scalars) / 8 <= 64, "one wavefront clears the block");
+  u64* w = reinterpret_cast<u64*>(s);
+  if (threadIdx.x < sizeof(Scalars) / 8) w[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) s->genomeLen = genomeLen;
+}
+
 __global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st, const long long* __restrict__ coll) {
   if (threadIdx.x || blockIdx.x) return;
   finish_frag(s, isCtrl, st, coll);
