@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 #include <unistd.h>
@@ -69,6 +71,7 @@ struct HostMail {
   u32 nF, nIv, status, R, nPeaks, nMerged, D, n, hot;
   long long coll[4];   // this rank's / all ranks' {fragLen parts, saturation flag}
   u32 counts[64];      // BH records per rank (all-gather)
+  u32 seq;             // k_mail's last write (mail_sync polls it)
 };
 
 struct PinnedBuf {
@@ -199,6 +202,7 @@ struct gx_ctx {
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
   DevBuf dColl, dCounts, dGather;
   int phaseLevel = 0;       // gx_set_phase_timing
+  u32 mailSeq = 0;          // mail_sync: the sequence number the next k_mail writes
   u32 statusSeen = 1;       // status bits read back since the device word was last cleared (1: not cleared yet)
   u64 runCap = 0, runSeen = 0;  // run_sweep: runs its arrays are sized for; runs of the last sweep
   bool phaseOpen = false;
@@ -321,12 +325,27 @@ int read_status(gx_ctx* ctx) {
 // risk_apply: after it, evaluate the listed values with the host's libm and send them back (k_risk_apply).
 // One small kernel writes everything the host wants to know into pinned memory (scalars, status, flags, the
 // risky list's count and first records), then the stream is synchronised.  Null pointers: not wanted.
+// The host does not wait in hipStreamSynchronize (an interrupt and a wake-up: 20-30 us after the kernel): k_mail
+// writes a sequence number behind everything else and the host polls that word in pinned memory (a few us).  After
+// 20 ms of polling -- or with GX_NO_SPIN -- it blocks in the runtime after all, which also reports a device fault.
 int mail_sync(gx_ctx* ctx, const Scalars* ds, const u32* hot, const u32* nIv, const long long* coll, const u32* extra) {
   HostMail* dm = static_cast<HostMail*>(ctx->mailBuf.dp);
-  MailOut mo{&dm->scal, &dm->status, &dm->hot, &dm->nIv, &dm->coll[2], &dm->nMerged, static_cast<RiskBuf*>(ctx->riskHost.dp)};
+  MailOut mo{&dm->scal, &dm->status, &dm->hot, &dm->nIv, &dm->coll[2], &dm->nMerged, static_cast<RiskBuf*>(ctx->riskHost.dp),
+             &dm->seq};
+  const u32 seq = ++ctx->mailSeq;
   hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, ds, ctx->dStatus.as<u32>(), hot, nIv, coll, extra,
-                     ctx->dRisk.as<RiskBuf>(), mo);
-  HIPCHECK(hipStreamSynchronize(ctx->stream));
+                     ctx->dRisk.as<RiskBuf>(), mo, seq);
+  static const bool spin = getenv("GX_NO_SPIN") == nullptr;
+  volatile u32* word = &ctx->mail->seq;
+  if (spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (u32 it = 0; *word != seq; it++) {
+      __builtin_ia32_pause();
+      if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+  }
+  if (*word != seq) HIPCHECK(hipStreamSynchronize(ctx->stream));
+  std::atomic_thread_fence(std::memory_order_acquire);
   return GX_OK;
 }
 
@@ -924,7 +943,8 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
     hipLaunchKernelGGL(k_runs_count, dim3(wChunks), dim3(SW_NT), 0, s, SM, cntS, cntE);
     for (int attempt = 0;; attempt++) {
       // arrays for `cap` runs (never more runs than intervals)
-      const u32 cap = std::min<u64>(std::max<u64>(ctx->runCap, 1u << 16), (u64)nWords * 64);
+      static const u64 capMin = getenv("GX_RUN_CAP_MIN") ? (u64)atoll(getenv("GX_RUN_CAP_MIN")) : (u64)1 << 16;  // (tests: a tiny first guess)
+      const u32 cap = std::min<u64>(std::max<u64>(ctx->runCap, std::max<u64>(capMin, 1)), (u64)nWords * 64);
       HIPCHECK(ctx->swStart.ensure((size_t)cap * 4 + 16));
       HIPCHECK(ctx->swEnd.ensure((size_t)cap * 4 + 16));
       HIPCHECK(ctx->headPos.ensure((size_t)cap * 4 + 16));

@@ -1257,11 +1257,13 @@ struct MailOut {
   long long* again;   // the ranks' "build this sample again" flags (several ranks only)
   u32* extra;         // one more word (interval count of a merge)
   RiskBuf* risk;
+  u32* seq;           // written last: the host polls it (mail_sync)
 };
 
 __global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, const u32* __restrict__ st, const u32* __restrict__ hot,
                                              const u32* __restrict__ nIv, const long long* __restrict__ coll,
-                                             const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, MailOut m) {
+                                             const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, MailOut m,
+                                             u32 seq) {
   const u32 n = rb->count;
   if (threadIdx.x == 0) {
     if (ds) *m.scal = *ds;
@@ -1273,6 +1275,10 @@ __global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, con
     m.risk->count = n;
   }
   if (threadIdx.x < n && threadIdx.x < RISK_PREFIX) m.risk->rec[threadIdx.x] = rb->rec[threadIdx.x];
+  // the sequence number goes last, behind a system-scope fence: a host that sees it sees the mail
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(m.seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace gx

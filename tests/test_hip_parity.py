@@ -2,6 +2,10 @@
 Everything must be bit-exact: interval ends, pileups, peak coordinates, and -log10 p / q / AUC too
 (north_star asks for 1e-5; the library re-evaluates with the host's libm the few p-values whose
 double lies next to a float rounding boundary, gx_math.h, so the floats are the reference's)."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -627,3 +631,62 @@ def test_bh_table_grows_when_full(monkeypatch):
     o, h, so, sh = run_both(case, B.make_params(pq=0.2, qval=True, min_auc=20.0))
     assert_same_run(o, h, so, sh, case)
     assert h.n_peaks > 0
+
+
+def test_many_distinct_pvalues_take_the_chunked_bh_table(monkeypatch):
+    """Three replicates combined by Fisher's method give tens of thousands of distinct p-values: the BH table
+    is then built by the chunked kernels (k_qt_sums / k_qt_raw / k_qt_apply), forced here for any count --
+    same q-values and peaks as the oracle."""
+    monkeypatch.setenv("GX_QT_MULTI", "1")
+    lens = [300_000, 120_000]
+    reps = [dict(save=None, treat=synth.make_fragments(lens, 90_000, 50 + r, peak_every=15_000, tower_every=80_000,
+                                                       frac_tower=0.1), ctrl=None) for r in range(3)]
+    case = dict(lens=lens, replicates=reps)
+    o, h, so, sh = run_both(case, B.make_params(pq=0.1, qval=True, min_auc=20.0))
+    assert_same_run(o, h, so, sh, case)
+    assert h.n_peaks > 0
+
+
+def test_peak_sweep_repeats_when_its_guess_is_too_small():
+    """The sweep sizes its run / candidate arrays by a guess and checks the true run count at the end; when the
+    guess was too small the pass is thrown away and repeated with arrays that fit.  The first guess is 4 runs
+    here (GX_RUN_CAP_MIN; 65,536 normally): same peaks as the oracle, and again on a second run of the same
+    context (the guess is remembered)."""
+    code = (
+        "import os, sys\n"
+        "os.environ['GX_RUN_CAP_MIN'] = '4'\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, backends as B, synth, genrich_amd\n"
+        "lens = [400_000, 150_000]\n"
+        "tr = synth.make_fragments(lens, 120_000, 77, peak_every=20_000, tower_every=90_000, frac_tower=0.1)\n"
+        "case = dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=None)])\n"
+        "par = B.make_params(pq=0.05, qval=False, min_auc=20.0)\n"
+        "o = B.Oracle(par); B.run_case(o, case)\n"
+        "h = genrich_amd.Genrich(par); B.run_case(h, case)\n"
+        "assert o.n_peaks > 16, o.n_peaks\n"
+        "assert o.get_peaks().tobytes() == h.get_peaks().tobytes()\n"
+        "h.reset(); B.run_case(h, case)\n"
+        "assert o.get_peaks().tobytes() == h.get_peaks().tobytes()\n"
+        "print('OK', o.n_peaks)\n"
+    ) % (os.path.join(os.path.dirname(__file__), ".."), os.path.dirname(__file__))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_phase_timers_follow_their_level():
+    """gx_set_phase_timing: nothing by default, the tile stage at level 1, every phase at level 2."""
+    lens = [200_000]
+    tr = synth.make_fragments(lens, 30_000, 5)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=None)])
+    g = hip_backend(B.make_params(pq=0.01))
+    B.run_case(g, case)
+    assert g.phase_times() == []
+    g.set_phase_timing(1)
+    g.reset()
+    B.run_case(g, case)
+    assert [n for n, _ in g.phase_times()] == ["t.tile"]
+    g.set_phase_timing(2)
+    g.reset()
+    B.run_case(g, case)
+    names = [n for n, _ in g.phase_times()]
+    assert "t.sort1" in names and "t.tile" in names and "sweep" in names
