@@ -68,7 +68,7 @@ def main():
     cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     from bench import source_hash
-    steps = 3  # profile_round.sh: --warmup 1 --steps 2
+    steps = 5  # profile_round.sh: --warmup 1 --steps 2, and bench.py's two extra steps that time every phase
     out = {"_how": __doc__.strip().split("\n\n")[1].replace("\n", " "), "tag": tag, "config": cfg, "source_hash": source_hash(),
            "kernels": {}, "whole_step": {}}
     # kernel durations
