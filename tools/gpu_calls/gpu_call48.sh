@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -s KILL 900 python -m pytest tests -m gpu -q --timeout 600 -x > gpurun_out/c48_pytest.log 2>&1
+grep -E "passed|failed|^FAILED|Error" gpurun_out/c48_pytest.log | tail -12
+( timeout -s KILL 600 python bench.py --config 5 --steps 5 --warmup 2 --no-e2e ) > gpurun_out/c48_bench_config5.json 2> gpurun_out/c48_bench_config5.err
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/c48_bench*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d["ms_per_step"],3), {k: round(v,3) for k,v in d["phases_ms"].items()}, d["config"]["peaks"], d.get("gate",{}).get("passed"))
+    except Exception as e: print(f, "ERR", e, open(f.replace(".json",".err")).read()[-600:])
+PY
