@@ -179,6 +179,7 @@ struct gx_ctx {
   DevBuf pvLut, dRisk, dDeep;
   PinnedBuf riskHost;           // count + records of the risky p-values, as read back / as sent with the host's values
   bool pairTabsReady = false;   // the control's p-value tables were built when its sample was closed
+  DevBuf fisherCache;  // k_mergeN's device-wide table of (sum, df) -> p
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhDl, bhTmp, bhRecs;
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
@@ -1635,11 +1636,15 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     const size_t lds = mergeN_lds_bytes((int)nr);
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
+    // the device-wide table of Fisher results: empty at the start of every run (within a run the same pairs recur
+    // across tiles; across runs it would be a cache of outputs)
+    HIPCHECK(ctx->fisherCache.ensure(((size_t)16 << MN_GLOBAL_LOG)));
+    HIPCHECK(hipMemsetAsync(ctx->fisherCache.p, 0, (size_t)16 << MN_GLOBAL_LOG, s));
     int mnBlocks = 0;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN, MG_NT, lds));
     hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(std::max(1, mnBlocks) * ctx->numCU))), dim3(MG_NT), lds, s, S,
                        ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
-                       ctx->dRisk.as<RiskBuf>());
+                       ctx->dRisk.as<RiskBuf>(), ctx->fisherCache.as<uint4>());
     if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
     const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
     HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));

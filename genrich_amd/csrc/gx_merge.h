@@ -460,6 +460,11 @@ struct MergeNOut {   // loose slots: tile t writes at sum_r tileOff_r[t]
 //      workgroup has not met), written, and entered into the cache (one writer per entry, chosen by an
 //      LDS atomic, so an entry is never torn).  Risky roundings (gx_math.h) are not cached: they go on the
 //      host's list every time.
+// Behind the workgroup's 512 LDS entries sits a table of 2^20 in device memory, shared by all workgroups and
+// cleared for every run: a workgroup meets about every second pair for the first time, the GPU as a whole
+// hardly any.  An entry is one aligned 16-byte word {sum bits, p, df ^ mix}: written and read whole, checked
+// against the query (the mix also rejects a torn or foreign entry), and right whenever it checks out -- p is a
+// pure function of the pair -- so stale copies in another XCD's L2 cost a recomputation, never a wrong value.
 // Tiles with more than MN_CAP merged intervals take several rounds.
 #ifndef GX_MN_CAP
 #define GX_MN_CAP 512
@@ -470,6 +475,11 @@ struct MergeNOut {   // loose slots: tile t writes at sum_r tileOff_r[t]
 constexpr int MN_CAP = GX_MN_CAP;                 // merged intervals per round
 constexpr int MN_CACHE = 1 << GX_MN_CACHE_LOG;    // cache entries (16 B)
 struct MnEntry { u32 lo, hi; float p; u32 df; };
+constexpr u32 MN_GLOBAL_LOG = 20;  // entries of the device-wide table (16 B each)
+__device__ __forceinline__ u32 mn_mix(u32 lo, u32 hi, u32 pbits) {
+  u32 x = lo * 0x9E3779B1u ^ hi * 0x85EBCA6Bu ^ pbits * 0xC2B2AE35u;
+  return (x ^ (x >> 15)) & ~0xFFu;  // (the low byte stays free for df)
+}
 __host__ __device__ constexpr size_t mergeN_lds_bytes(int n) {
   return (size_t)n * MG_WORDS * 4 + (size_t)n * MG_WORDS * 2 + MN_CAP * 2 /*offL*/ + MN_CAP * 8 /*missSum*/ +
          MN_CAP * 2 /*missI*/ + MN_CAP /*missDf*/ + MN_CACHE * sizeof(MnEntry) + MN_CACHE * 4 /*owner*/ + 64;
@@ -477,7 +487,8 @@ __host__ __device__ constexpr size_t mergeN_lds_bytes(int n) {
 
 __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restrict__ tileChrom,
                                                   const DChrom* __restrict__ chroms, u32 nTiles,
-                                                  MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk) {
+                                                  MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk,
+                                                  uint4* gcache /* 2^MN_GLOBAL_LOG entries, zeroed per run */) {
   static_assert(MG_WPT == 1, "one bitmap word per thread");
   extern __shared__ __attribute__((aligned(16))) u32 dyn[];
   const int n = S.n;
@@ -563,6 +574,14 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
           out.p[o] = e.p;
           continue;
         }
+        {  // the device-wide table
+          const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ ((u32)df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
+          const uint4 g = gcache[hg];
+          if (g.x == lo && g.y == hi && g.w == (mn_mix(lo, hi, g.z) | (u32)df)) {
+            out.p[o] = __uint_as_float(g.z);
+            continue;
+          }
+        }
         const u32 j = atomicAdd(&nMiss, 1u);
         missI[j] = (uint16_t)i;
         missDf[j] = (uint8_t)df;
@@ -588,7 +607,11 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
           hi = (u32)(__double_as_longlong(sum) >> 32);
           h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ (df << 20)) * 0x9E3779B1u) >> (32 - GX_MN_CACHE_LOG);
           enter = !risky;
-          if (enter) atomicMax(&owner[h], j + 1);
+          if (enter) {
+            atomicMax(&owner[h], j + 1);
+            const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ (df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
+            gcache[hg] = make_uint4(lo, hi, __float_as_uint(pv), mn_mix(lo, hi, __float_as_uint(pv)) | df);
+          }
         }
         __syncthreads();
         if (enter && owner[h] == j + 1) {
