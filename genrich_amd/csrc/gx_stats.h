@@ -642,10 +642,17 @@ __global__ __launch_bounds__(QT_NT) void k_qt_apply(const u32* __restrict__ slot
 // per interval: q = table[p] (lookup 196-206), SKIP stays SKIP (237-238); the sweep's significance /
 // SKIP masks are written on the way (whole words: one wavefront per 64 intervals, four words per
 // iteration so that four loads per lane are in flight)
+// (a direct-mapped LDS cache of {p bits, q} sits in front of the table: the genome's common values -- the background
+// pileups -- are asked for millions of times, and a hit saves the two dependent gathers of the probe.  An entry is
+// one 8-byte LDS word, written and read whole; q is a function of p within a run.)
+constexpr int QL_CACHE_LOG = 11;
 __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, const u32* __restrict__ nPtr,
                                                  const u32* __restrict__ gKeys, const float* __restrict__ qOfSlot,
                                                  u32 capMask, float* __restrict__ q, float thr, u64* __restrict__ sigMask,
                                                  u64* __restrict__ skipMask) {
+  __shared__ u64 lc[1 << QL_CACHE_LOG];  // [31:0] key, [63:32] q bits; key EMPTY_KEY: free
+  for (int i = threadIdx.x; i < (1 << QL_CACHE_LOG); i += 256) lc[i] = (u64)EMPTY_KEY;
+  __syncthreads();
   const u32 n = *nPtr;
   const u32 nw = (n + 63) >> 6;
   for (u32 w0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; w0 < nw; w0 += gridDim.x * 16) {
@@ -664,9 +671,17 @@ __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, co
           qv = GX_SKIPF;
         else {
           const u32 key = pv[k] == 0.0f ? 0u : __float_as_uint(pv[k]);
-          u32 h = bh_hash(key) & capMask;
-          while (gKeys[h] != key) h = (h + 1) & capMask;  // every p was inserted
-          qv = qOfSlot[h];
+          const u32 hh = bh_hash(key);
+          const u32 hl = (hh >> 7) & ((1u << QL_CACHE_LOG) - 1);
+          const u64 c = lc[hl];
+          if ((u32)c == key)
+            qv = __uint_as_float((u32)(c >> 32));
+          else {
+            u32 h = hh & capMask;
+            while (gKeys[h] != key) h = (h + 1) & capMask;  // every p was inserted
+            qv = qOfSlot[h];
+            lc[hl] = (u64)key | ((u64)__float_as_uint(qv) << 32);
+          }
         }
         q[i] = qv;
       }
