@@ -945,7 +945,10 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
     for (int attempt = 0;; attempt++) {
       // arrays for `cap` runs (never more runs than intervals)
       static const u64 capMin = getenv("GX_RUN_CAP_MIN") ? (u64)atoll(getenv("GX_RUN_CAP_MIN")) : (u64)1 << 16;  // (tests: a tiny first guess)
-      const u32 cap = std::min<u64>(std::max<u64>(ctx->runCap, std::max<u64>(capMin, 1)), (u64)nWords * 64);
+      // (first guess: one run per 256 intervals -- several times what a default threshold leaves on a genome --
+      // so that a single call does not pay for a second pass)
+      const u64 guess = getenv("GX_RUN_CAP_MIN") ? capMin : std::max<u64>(capMin, (u64)nWords / 4);
+      const u32 cap = std::min<u64>(std::max<u64>(ctx->runCap, std::max<u64>(guess, 1)), (u64)nWords * 64);
       HIPCHECK(ctx->swStart.ensure((size_t)cap * 4 + 16));
       HIPCHECK(ctx->swEnd.ensure((size_t)cap * 4 + 16));
       HIPCHECK(ctx->headPos.ensure((size_t)cap * 4 + 16));
