@@ -627,10 +627,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     hipLaunchKernelGGL((k_tile<true, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
   } else if (!getenv("GX_TILE_OLD")) {
-    // the common case: one wavefront per narrow tile, work laid out by touched base (gx_tile_fast.h)
+    // the common case: one wavefront per tile, work laid out by touched base, unit-weight and fractional records
+    // alike (gx_tile_fast.h)
     hipLaunchKernelGGL(k_tile_fast, dim3(std::min<u32>(nTiles, (u32)ctx->resTileFast)), dim3(64), 0, s, tin, nTiles, nw, to,
-                       ctx->dStatus.as<u32>());
-    hipLaunchKernelGGL((k_tile<false, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
   } else {
     hipLaunchKernelGGL((k_tile<false, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,

@@ -1,7 +1,7 @@
-// gx_tile_fast.h -- the tile kernel for the common case: narrow tiles (unit-weight records only, fewer
-// than 32,767 per stream) of a run without -E regions.  Same contract as k_tile<false, true>
-// (gx_kernels.h): LDS difference slice -> prefix sum -> run-length pileup in the tile's loose slot,
-// replacing savePileupExpt's two per-base passes (Genrich.c:2197-2273).  Wide tiles and -E runs keep
+// gx_tile_fast.h -- the tile kernel of every run without -E regions: unit-weight starts / ends (2-byte
+// offsets) and fractional-weight records of multimapped reads (8 bytes, signed weight in 1/120 units) alike.
+// Same contract as k_tile (gx_kernels.h): LDS difference slice -> prefix sum -> run-length pileup in the
+// tile's loose slot, replacing savePileupExpt's two per-base passes (Genrich.c:2197-2273).  -E runs keep
 // the general kernel.
 //
 // Why another kernel.  k_tile is VALU-issue bound (SQ counters, profiles/r02a_*: 554 VALU instructions
@@ -13,7 +13,8 @@
 //   B  every lane owns two bitmap words: popcounts -> DPP scan -> the number of touched bases before
 //      each word (`pre`, 16 bits per word);
 //   A2 every record finds its base's rank, pre[word] + popc(word & bits below), adds its sign to
-//      cnt[rank] and writes its offset to list[rank] (records of one base write the same value): the
+//      cnt[rank] (32-bit sums in 1/120 units: +-120 for a start / an end, the record's weight for a
+//      fractional one) and writes its offset to list[rank] (records of one base write the same value): the
 //      position-ordered list of touched bases falls out without any per-lane bit loop;
 //   C  64 list entries per step, one per lane: the difference is cnt[j] (cleared on the way), DPP scan
 //      for the running pileup, ballot / mbcnt for the output rank, coalesced stores of (end, V120).
@@ -31,6 +32,7 @@
 namespace gx {
 
 constexpr int TF_KPL = 2;                                       // prefetched keys per lane and stream (128 per tile)
+constexpr int TF_FPL = 2;                                       // fractional records per lane kept in registers (128 per tile)
 constexpr int TF_WG_PER_CU = 24;                                // one-wavefront workgroups per CU (see above)
 constexpr int TR_CAP = 512;
 constexpr int TR_WORDS = TILE / 32 + TILE / 64 + TR_CAP + TR_CAP / 2;
@@ -46,7 +48,6 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
   const int lane = threadIdx.x;
   for (int i = lane * 4; i < TR_WORDS; i += 64 * 4) *reinterpret_cast<int4*>(lds + i) = make_int4(0, 0, 0, 0);
   __syncthreads();
-  if (*nWide > nTiles / 2) return;  // (most tiles are wide: the general kernel takes them all)
   const u32 G = gridDim.x;
   const u32 lb = xcd_local_block(blockIdx.x, G);
   u32 bad = 0;
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
   auto uni = [](u32 v) -> u32 { return (u32)__builtin_amdgcn_readfirstlane((int)v); };
   auto cook = [&](const Raw& r, u32 i) -> TileMeta {
     TileMeta m;
-    m.sb = uni(r.a.x); m.eb = uni(r.a.y); m.fb = 0; m.nS = uni(r.a.w);
-    m.nE = uni(r.b.x); m.nF = 0; m.carry = (int)uni(r.b.z); m.ci = 0;
+    m.sb = uni(r.a.x); m.eb = uni(r.a.y); m.fb = uni(r.a.z); m.nS = uni(r.a.w);
+    m.nE = uni(r.b.x); m.nF = uni(r.b.y); m.carry = (int)uni(r.b.z); m.ci = 0;
     m.pos0 = uni(r.c.x); m.len = uni(r.c.y); m.flags = uni(r.c.z); m.slot = uni(r.c.w);
     if (i >= nTiles) { m.nS = 0; m.nE = 0; m.nF = 0; m.flags = 0; }
     return m;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
 #pragma unroll
     for (int q = 0; q < TF_KPL; q++) {
       const u32 ix = (u32)lane + q * 64;
-      r.v[q] = ix < nk && !(flags & TM_WIDE) ? K[kb + ix] : 0u;
+      r.v[q] = ix < nk ? K[kb + ix] : 0u;
     }
     return r;
   };
@@ -93,12 +94,10 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
   for (u32 i = lb; i < nTiles; i += G) {
     const u32 t = tC;
     TileMeta m = mC;
-    const bool mine = !(m.flags & TM_WIDE);  // a wide tile belongs to the general kernel: here it passes as empty
-    if (!mine) { m.nS = 0; m.nE = 0; m.flags = 0; }
     const Keys ks0 = ksC, ke0 = keC;
     auto collect = [&]() {
       asm volatile("" : "+v"(ksL.v[0]), "+v"(ksL.v[1]), "+v"(keL.v[0]), "+v"(keL.v[1]), "+v"(rF.a.x), "+v"(rF.a.y),
-                        "+v"(rF.a.w), "+v"(rF.b.x), "+v"(rF.b.z), "+v"(rF.c.x),
+                        "+v"(rF.a.z), "+v"(rF.a.w), "+v"(rF.b.x), "+v"(rF.b.y), "+v"(rF.b.z), "+v"(rF.c.x),
                         "+v"(rF.c.y), "+v"(rF.c.z), "+v"(rF.c.w) :: "memory");
       ksN = ksL;
       keN = keL;
@@ -117,7 +116,16 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
     const bool active = m.flags & TM_ACTIVE;
     const bool lastTile = (m.flags & TM_LAST) != 0;
     const u32 pos0 = m.pos0, slot = m.slot;
-    const u32 nS = m.nS, nE = m.nE;
+    const u32 nS = m.nS, nE = m.nE, nF = m.nF;
+    // the tile's fractional records (multimapped reads; none in most runs): the first TF_FPL per lane stay in
+    // registers for both passes
+    u64 fr[TF_FPL];
+    if (nF) {  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < TF_FPL; q++) fr[q] = (u32)lane + q * 64 < nF ? in.F[m.fb + lane + q * 64] : 0ull;
+    }
+    auto fOff = [](u64 r) -> u32 { return (u32)(r >> 8) & (TILE - 1); };
+    auto fW = [](u64 r) -> int { return (int)(int8_t)(r & 0xFF); };
     // ---- A1: records -> occupancy bitmap -----------------------------------------------------------------------
     auto mark = [&](u32 off) { atomicOr(&occ[off >> 5], 1u << (off & 31)); };
 #pragma unroll
@@ -127,10 +135,16 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
     }
     for (u32 k = TF_KPL * 64 + lane; k < nS; k += 64) mark(in.S[m.sb + k]);
     for (u32 k = TF_KPL * 64 + lane; k < nE; k += 64) mark(in.E[m.eb + k]);
+    if (nF) {  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < TF_FPL; q++)
+        if ((u32)lane + q * 64 < nF) mark(fOff(fr[q]));
+      for (u32 k = TF_FPL * 64 + lane; k < nF; k += 64) mark(fOff(in.F[m.fb + k]));
+    }
     __syncthreads();
     // ---- B: bitmap -> touched bases before each word -----------------------------------------------------------
     u32 w0 = 0, w1 = 0;
-    if (nS + nE) {  // wave-uniform
+    if (nS + nE + nF) {  // wave-uniform
       const uint2 ww = *reinterpret_cast<const uint2*>(occ + 2 * lane);
       w0 = ww.x;
       w1 = ww.y;
@@ -163,20 +177,29 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
     }
     for (u32 r0 = 0; r0 < T; r0 += TR_CAP) {
       if (r0) __syncthreads();  // the previous round is through with cnt and list
-      auto put = [&](u32 r, u32 off, int sign) {
+      auto put = [&](u32 r, u32 off, int w) {  // w: the record's weight in 1/120 units
         r -= r0;
         if (r < (u32)TR_CAP) {
           list[r] = (uint16_t)off;
-          atomicAdd(&cnt[r], sign);
+          atomicAdd(&cnt[r], w);
         }
       };
 #pragma unroll
       for (int q = 0; q < TF_KPL; q++) {
-        if ((u32)lane + q * 64 < nS) put(rs[q], ks0.v[q], 1);
-        if ((u32)lane + q * 64 < nE) put(re[q], ke0.v[q], -1);
+        if ((u32)lane + q * 64 < nS) put(rs[q], ks0.v[q], GX_UNIT);
+        if ((u32)lane + q * 64 < nE) put(re[q], ke0.v[q], -GX_UNIT);
       }
-      for (u32 k = TF_KPL * 64 + lane; k < nS; k += 64) { const u32 off = in.S[m.sb + k]; put(rankOf(off), off, 1); }
-      for (u32 k = TF_KPL * 64 + lane; k < nE; k += 64) { const u32 off = in.E[m.eb + k]; put(rankOf(off), off, -1); }
+      for (u32 k = TF_KPL * 64 + lane; k < nS; k += 64) { const u32 off = in.S[m.sb + k]; put(rankOf(off), off, GX_UNIT); }
+      for (u32 k = TF_KPL * 64 + lane; k < nE; k += 64) { const u32 off = in.E[m.eb + k]; put(rankOf(off), off, -GX_UNIT); }
+      if (nF) {  // wave-uniform
+#pragma unroll
+        for (int q = 0; q < TF_FPL; q++)
+          if ((u32)lane + q * 64 < nF) put(rankOf(fOff(fr[q])), fOff(fr[q]), fW(fr[q]));
+        for (u32 k = TF_FPL * 64 + lane; k < nF; k += 64) {
+          const u64 r = in.F[m.fb + k];
+          put(rankOf(fOff(r)), fOff(r), fW(r));
+        }
+      }
       __syncthreads();
       // ---- C: 64 touched bases per step ------------------------------------------------------------------------
       const u32 nL = min((u32)TR_CAP, T - r0);
@@ -184,17 +207,16 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
         const u32 j = j0 + lane;
         const bool valid = j < nL;
         u32 p = 0;
-        int d = 0;
+        int d120 = 0;
         if (valid) {
           p = list[j];
-          d = cnt[j];          // this base's net count of records
+          d120 = cnt[j];       // this base's net weight (1/120 units)
           cnt[j] = 0;          // the next round / tile finds it clear
         }
-        const int d120 = __mul24(d, GX_UNIT);
         const int incS = dpp_scan_add(d120);
         const int after = runBase + incS;
         const int before = after - d120;            // the pileup of the interval that ends at this base (2244)
-        const bool nz = d != 0 && active && (pos0 + p != 0);  // 2241: base 0 closes nothing
+        const bool nz = d120 != 0 && active && (pos0 + p != 0);  // 2241: base 0 closes nothing
         const u64 mask = __ballot(nz);
         if (nz) {
           const u32 o = slot + outCount +
@@ -226,7 +248,7 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
       if (negM) bad |= ST_NEG_PILE;
       if (bigM && lane == 0) atomicOr(&out.tileDeep[t], 1u);  // rare
     }
-    if (lane == 0) out.tileCount[t] = total;  // (0 for a wide tile: overwritten by the kernel that owns it)
+    if (lane == 0) out.tileCount[t] = total;
     issue();
   }
   if (bad && lane == 0) atomicOr(st, bad);
