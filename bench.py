@@ -365,7 +365,7 @@ def main():
             prof = json.load(open(ppath))
             if prof.get("source_hash") != source_hash() or world != 1 or args.frags != 50_000_000 or args.qval or args.control:
                 prof = None  # counters of another build / another workload are not this run's
-        # (the tile stage = k_tile_fast for the narrow tiles + k_tile for the wide ones, one launch each per sample)
+        # (the tile stage = k_tile_fast, one launch per sample; k_tile only exists in -E runs)
         traffic = (sum(prof["kernels"].get(k, {}).get("hbm_bytes_per_step", 0.0) for k in ("k_tile_fast", "k_tile")) / launches
                    if prof else None)
         alg_tile = (2.0 * 2.0 * ev_n + 8.0 * (iv0 if launches == 1 else 2.0 * ev_n)) / launches + 56.0 * n_tiles
@@ -374,7 +374,7 @@ def main():
         # whole step: events in + final interval table (end, p[, pileup]) + sweep masks out
         alg_step = 16.0 * ev_n + (12.0 if not args.lean else 8.0) * iv0 + 3.0 * iv0 / 8.0
         roof = {
-            "bound": "hbm", "kernel": "k_tile_fast (+ k_tile for wide tiles)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_tile_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": tile_ms,
             "algorithmic_bytes": alg_tile,
             "traffic_over_algorithmic": (traffic / alg_tile) if traffic else None,
