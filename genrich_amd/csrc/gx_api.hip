@@ -20,6 +20,7 @@
 #include "gx_rccl.h"
 #include "gx_sort.h"
 #include "gx_tile_fast.h"
+#include "gx_sbtile.h"
 #include "gx_saturate.h"
 
 using namespace gx;
@@ -108,6 +109,10 @@ struct PArray {  // p-value intervals of one replicate (or the Fisher combinatio
   u32 n = 0;
   bool loose = false;     // no control: the intervals still sit in the tile kernel's loose slots (ctx->looseEnd / looseV);
                           // the tight table is made when somebody asks for it (materialize_rep)
+  bool looseSweep = false;    // ... and the tile stage left the sweep's significance bits for them (LooseCtl): gx_find_peaks on
+                              // this replicate alone, with -p, walks the loose slots as they are
+  DevBuf chromLooseOff;       // [nChrom + 1] first loose slot of each chromosome
+  size_t looseStride = 0;     // words between the sig / brk masks in swMask
   bool pilesPending = false;  // no control: the pileup floats are wanted but not made yet (ensure_piles)
   bool hasPiles = false;  // expt/ctrl filled (single-replicate logging)
   bool pilesDropped = false;  // ... deliberately not (gx_set_keep_pileups(0))
@@ -165,6 +170,16 @@ struct gx_ctx {
     DevBuf a, pool, pt, cursor, sbOff;  // level-2 output; level-1 pages, page table, list cursors; super-bucket offsets
   };
   size_t b2LdsSet = 0;          // dynamic LDS the level-2 kernel was last configured for
+  bool sbtLdsSet = false;       // ... and k_sbtile
+  bool sawFrac = false;         // a sample of this context held fractional weights: k_sbtile is not tried again
+  bool fusedOff = false;        // this sample: a super-bucket did not fit k_sbtile (the general chain runs instead)
+  bool fusedUsed = false;       // the last build went through k_sbtile
+  bool looseSwept = false;      // the last gx_find_peaks swept the loose slots
+  bool fellBack = false;        // some sample was sent back from k_sbtile to the general chain
+  bool looseOk = false;         // the treatment sample's tile stage left valid sweep bits on the loose slots
+  bool riskNearThr = false;     // a re-evaluated table entry lies next to the significance threshold
+  size_t looseStride = 0;       // words between the sig / brk masks the tile stage wrote into swMask
+  DevBuf tileSlot, chromW0, chromLooseOff, looseCtl;
   u32 ptJmax = 16;              // pages per (XCD class, super-bucket) list; grown after ST_PT_FULL
   DevBuf lbIv;
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
@@ -385,7 +400,14 @@ int risk_apply(gx_ctx* ctx, RiskTargets T, RiskHostIn in = RiskHostIn{nullptr, n
                             (size_t)(n - RISK_PREFIX) * sizeof(RiskRec), hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
   }
-  for (u32 i = 0; i < n; i++) hb->rec[i].pnew = risk_host_value(ctx, hb->rec[i], in);
+  for (u32 i = 0; i < n; i++) {
+    const float pn = risk_host_value(ctx, hb->rec[i], in);
+    hb->rec[i].pnew = pn;
+    // (the tile stage compared the device's table entry, one float away at most, with the threshold: LooseCtl)
+    const float thr = ctx->par.thr;
+    if (hb->rec[i].kind == RK_LUT && ((pn > thr) != (nextafterf(pn, -INFINITY) > thr) || (pn > thr) != (nextafterf(pn, INFINITY) > thr)))
+      ctx->riskNearThr = true;
+  }
   // (the pinned records stay untouched until the next mail_sync)
   // A short list is read by the kernel where it lies (mapped pinned memory): no copy launch.
   const RiskRec* src = static_cast<const RiskBuf*>(ctx->riskHost.dp)->rec;
@@ -484,12 +506,14 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     const size_t curBytes = up((size_t)NXCD * nL1 * 4 + 64);          // cursors + (last word) pages handed out
     const size_t ptBytes = up((size_t)NXCD * nL1 * jmax * 4);
     const size_t lbTBytes = up((size_t)3 * (tChunks + 2) * 8), lbIBytes = up((size_t)(2 * tChunks + 4) * 8);
-    const size_t total = ffBytes + 256 + endBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
+    const size_t total = ffBytes + 256 + 256 + endBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
     HIPCHECK(ctx->zeroArena.ensure(total));
     char* base = ctx->zeroArena.as<char>();
     ctx->fragSum.view(base, ffBytes);
     base += ffBytes;
     ctx->nWide.view(base, 256);
+    base += 256;
+    ctx->looseCtl.view(base, 256);
     base += 256;
     ctx->endAtLen.view(base, endBytes);
     base += endBytes;
@@ -551,10 +575,42 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   if (int rc__ = dbg_sync(ctx, "k_sort1")) return rc__;
   phase_end(ctx);
 
+  // ---- what the tile stage will be -------------------------------------------------------------------------
+  // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- unit weights, no -E regions, at most
+  // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
+  // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
+  const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
+  const bool fused = unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && !ctx->sawFrac && !ctx->fusedOff &&
+                     !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 26000;
+  ctx->fusedUsed = fused;
+  // lambda ahead of the tile stage (closed form of fragLen; LooseCtl): one rank, a treatment sample, -p
+  const bool multiRank = ctx->world > 1 || ctx->forceColl;
+  const bool wantEarly = !isCtrl && !multiRank && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag;
+  LooseCtl* ctl = ctx->looseCtl.as<LooseCtl>();
+  HIPCHECK(ctx->tileSlot.ensure((size_t)(nTiles + 2) * 4));
+  HIPCHECK(ctx->chromW0.ensure((size_t)(nChrom + 1) * 4));
+  HIPCHECK(ctx->chromLooseOff.ensure((size_t)(nChrom + 2) * 4));
+  const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
+  u64* sigMask = nullptr;
+  if (wantEarly) {
+    // the sweep's masks in loose-slot index space: [significant | first of its chromosome]
+    ctx->looseStride = (looseCap + 63) / 64 + 2;
+    HIPCHECK(ctx->swMask.ensure(ctx->looseStride * 8 * 3));
+    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, ctx->looseStride * 8 * 2, s));
+    sigMask = ctx->swMask.as<u64>();
+    ctx->maskIdx = -1;
+  }
   phase_begin(ctx, isCtrl ? "c.bucket" : "t.bucket");
   {
-    BinScan bs{{SS.cursor.as<u32>(), SE.cursor.as<u32>(), SF.cursor.as<u32>()}, {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()}};
-    hipLaunchKernelGGL(k_scan_bins, dim3(3), dim3(1024), 0, s, bs, nL1);
+    BinScan bs{{SS.cursor.as<u32>(), SE.cursor.as<u32>(), SF.cursor.as<u32>()}, {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()},
+               ctx->endAtLen.as<u32>(), ctx->chromW0.as<int>(), nChrom, ff, ctx->dScal.as<Scalars>(), ctl, wantEarly ? 1 : 0};
+    hipLaunchKernelGGL(k_scan_bins, dim3(4), dim3(1024), 0, s, bs, nL1);
+    if (wantEarly)  // the table p(V) for that lambda, and from which pileup on an interval is significant
+      hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>(),
+                         ctx->dRisk.as<RiskBuf>(), ctx->dDeep.as<DeepTab>(), PackIn{}, ff, ctx->fragList.as<u32>(), ctl, 1,
+                         ctx->par.thr);
+  }
+  if (!fused) {
     // level 2: one workgroup per super-bucket
     const size_t lds2 = std::max(b2_lds_bytes<u32>(1u << ctx->sbShift), b2_lds_bytes<u64>(1u << ctx->sbShift));
     if (ctx->b2LdsSet != lds2) {
@@ -591,11 +647,12 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   tt.wsumF = ctx->tileWsum.as<int>();
   tt.prefW = ctx->tileCarry.as<int>();
-  hipLaunchKernelGGL(k_scan_tiles, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s, tt, nTiles,
-                     ctx->lb.as<u64>(), ctx->lb.as<u64>() + tChunks + 2, ctx->lb.as<u64>() + 2 * (tChunks + 2),
-                     ctx->dStatus.as<u32>());
-  if (int rc__ = dbg_sync(ctx, "k_scan_tiles")) return rc__;
-  const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
+  if (!fused) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s, tt, nTiles,
+                       ctx->lb.as<u64>(), ctx->lb.as<u64>() + tChunks + 2, ctx->lb.as<u64>() + 2 * (tChunks + 2),
+                       ctx->dStatus.as<u32>());
+    if (int rc__ = dbg_sync(ctx, "k_scan_tiles")) return rc__;
+  }
   HIPCHECK(ctx->looseEnd.ensure(looseCap * 4));
   HIPCHECK(ctx->looseV.ensure(looseCap * 4));
   HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
@@ -604,14 +661,15 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   Scalars* ds = ctx->dScal.as<Scalars>();
   long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;  // zero since gx_sample_begin(treatment)
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(),
-             ctx->tileDeep.as<u32>()};
+             ctx->tileDeep.as<u32>(), sigMask, wantEarly ? ctl : (LooseCtl*)nullptr};
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
   HIPCHECK(ctx->tileMeta.ensure((size_t)(nTiles + 1) * sizeof(TileMeta)));
   HIPCHECK(ctx->wideList.ensure((size_t)(nTiles + 1) * 4));
-  hipLaunchKernelGGL(k_tile_meta, dim3((nTiles + 255) / 256), dim3(256), 0, s, ctx->tileOff[0].as<u32>(),
-                     ctx->tileOff[1].as<u32>(), ctx->tileOff[2].as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
-                     ctx->dChrom.as<DChrom>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, nTiles,
-                     ctx->tileMeta.as<TileMeta>(), ctx->wideList.as<u32>(), ctx->nWide.as<u32>());
+  if (!fused)
+    hipLaunchKernelGGL(k_tile_meta, dim3((nTiles + 255) / 256), dim3(256), 0, s, ctx->tileOff[0].as<u32>(),
+                       ctx->tileOff[1].as<u32>(), ctx->tileOff[2].as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
+                       ctx->dChrom.as<DChrom>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, nTiles,
+                       ctx->tileMeta.as<TileMeta>(), ctx->wideList.as<u32>(), ctx->nWide.as<u32>(), ctx->tileSlot.as<u32>());
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");  // k_tile alone: the dominant kernel (bench.py's roofline)
@@ -621,7 +679,18 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   const u32* wl = ctx->wideList.as<u32>();
   const u32* nw = ctx->nWide.as<u32>();
   const dim3 gHalf(std::min<u32>(nTiles, (u32)ctx->resTileHalf)), gWide(std::min<u32>(nTiles, (u32)ctx->resTile));
-  if (ctx->hasBed) {
+  if (fused) {
+    // level 2 of the sort and the tile passes in one kernel, one workgroup per super-bucket (gx_sbtile.h)
+    if (!ctx->sbtLdsSet) {
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(SbtLds)));
+      ctx->sbtLdsSet = true;
+    }
+    SbtIn si{PG3[0], PG3[1], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
+             ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, ctx->sbShift};
+    SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>()};
+    hipLaunchKernelGGL(k_sbtile, dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+  } else if (ctx->hasBed) {
     hipLaunchKernelGGL((k_tile<true, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
     hipLaunchKernelGGL((k_tile<true, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
@@ -640,12 +709,14 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   phase_end(ctx);
   // (word 1 of the nWide block: the "a base can reach the int16 limits" flag, also set by k_convert)
-  hipLaunchKernelGGL(k_hot_check, dim3(std::min<u32>(nTiles, 256u)), dim3(256), 0, s, tin, wl, nw, ctx->nWide.as<u32>() + 1);
+  // (a bin that fits k_sbtile holds fewer than 32,767 records of a stream: no base of it can reach the limits)
+  if (!fused) hipLaunchKernelGGL(k_hot_check, dim3(std::min<u32>(nTiles, 256u)), dim3(256), 0, s, tin, wl, nw, ctx->nWide.as<u32>() + 1);
   if (int rc__ = dbg_sync(ctx, "k_hot_check")) return rc__;
 
   phase_begin(ctx, isCtrl ? "c.pack" : "t.pack");
   const u32 ivChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
-  IvScanOut so{out.tileIvOff.as<u32>(), ctx->tilePrevEnd.as<u32>(), out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV};
+  IvScanOut so{out.tileIvOff.as<u32>(), ctx->tilePrevEnd.as<u32>(), out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV,
+               ctx->tileSlot.as<u32>(), ctx->chromLooseOff.as<u32>(), ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctl};
   hipLaunchKernelGGL(k_scan_iv, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
                      ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
                      ctx->dChrom.as<DChrom>(), nTiles, ctx->lbIv.as<u64>(), ctx->lbIv.as<u64>() + ivChunks + 1, so,
@@ -666,7 +737,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ff, acc,
                        ctx->world > 1 || ctx->forceColl ? ctx->dColl.as<long long>() : (long long*)nullptr,
                        ctx->nWide.as<u32>() + 1, ctx->dStatus.as<u32>(), ctx->dChrom.as<DChrom>(), nChrom,
-                       out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV, ds, isCtrl);
+                       out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV, ds, isCtrl, ctx->chromLooseOff.as<u32>(),
+                       ctx->tileSlot.as<u32>(), nTiles, ctl);
   }
   if (int rc__ = dbg_sync(ctx, "k_frag")) return rc__;
   out.packed = false;
@@ -680,6 +752,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   return GX_OK;
 }
 
+constexpr int RETRY_GENERAL = 3;    // (internal) k_sbtile could not take the sample: build it again on the general chain
 constexpr int RETRY_SATURATED = 1;  // (internal) finish_scalars: filter the events and build the sample again
 constexpr int RETRY_PT = 2;         // (internal) a level-1 page list overflowed: build again with a longer page table
 constexpr u32 PT_JMAX_CAP = 1u << 20;
@@ -725,9 +798,10 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
   // host has to re-evaluate (risky ones) travel with the synchronisation that returns the scalars
   if (!isCtrl) {
     PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>()};
+    // (when the tile stage had lambda already -- LooseCtl -- and it has not changed, only the deep tiles' part runs)
     hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256 + DEEP_BLOCKS), dim3(256), 0, s, ds, ctx->pvLut.as<float>(),
                        ctx->dRisk.as<RiskBuf>(), ctx->dDeep.as<DeepTab>(), pin, ctx->fragSum.as<FragFix>(),
-                       ctx->fragList.as<u32>());
+                       ctx->fragList.as<u32>(), ctx->looseCtl.as<LooseCtl>(), 0, ctx->par.thr);
   } else {
     hipLaunchKernelGGL(k_pair_tabs, dim3(PAIR_LUT / 256), dim3(256), 0, s, ds, ctx->pairLogE.as<double>(),
                        ctx->pairCtab.as<CtrlEntry>());
@@ -736,13 +810,29 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     ctx->pairTabsReady = true;
   }
   if (int rc__ = dbg_sync(ctx, "p-value tables")) return rc__;
-  if (int rc__ = mail_sync(ctx, ds, ctx->nWide.as<u32>() + 1, ctx->misc.as<u32>() + M_NIV, dcoll, nullptr)) return rc__;
+  ctx->mail->nMerged = 0;
+  if (int rc__ = mail_sync(ctx, ds, ctx->nWide.as<u32>() + 1, ctx->misc.as<u32>() + M_NIV, dcoll,
+                           isCtrl ? (const u32*)nullptr : &ctx->looseCtl.as<LooseCtl>()->ok))
+    return rc__;
   ctx->hScal = ctx->mail->scal;
+  ctx->riskNearThr = false;
   const int rcRisk = risk_apply(ctx, RiskTargets{});
+  if (!isCtrl) ctx->looseOk = ctx->mail->nMerged != 0 && !ctx->riskNearThr;
   // (with several ranks: if any of them has to rebuild its sample, all go round again with it)
   const long long again = multi ? ctx->mail->coll[2]
-                                : (long long)(ctx->mail->hot ? 1 : 0) + ((ctx->mail->status & ST_PT_FULL) ? 65536 : 0);
-  if (again >= 65536 && ctx->ptJmax < PT_JMAX_CAP) return RETRY_PT;
+                                : (long long)(ctx->mail->hot ? 1 : 0) + ((ctx->mail->status & ST_PT_FULL) ? 65536 : 0) +
+                                      ((ctx->mail->status & (ST_SB_FULL | ST_SB_FRAC)) ? (1ll << 32) : 0);
+  if (again >> 32) {
+    // k_sbtile could not take some rank's sample (a bin beyond its LDS, or fractional weights): once more, on the
+    // general chain
+    if (ctx->mail->status & ST_SB_FRAC) ctx->sawFrac = true;
+    ctx->fusedOff = true;
+    ctx->fellBack = true;
+    static_cast<RiskBuf*>(ctx->riskHost.p)->count = 0;
+    HIPCHECK(hipMemsetAsync(ctx->dRisk.p, 0, 4, s));
+    return RETRY_GENERAL;
+  }
+  if ((again & 0xFFFFFFFFll) >= 65536 && ctx->ptJmax < PT_JMAX_CAP) return RETRY_PT;
   int rc = status_to_rc(ctx, ctx->mail->status);
   if ((again & 0xFFFF) && !ctx->satDone) return RETRY_SATURATED;
   if (ctx->nIvTarget) *ctx->nIvTarget = ctx->mail->nIv;
@@ -791,29 +881,33 @@ int drop_saturated(gx_ctx* ctx, int isCtrl) {
 }
 
 int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
-  int rc = build_pileup(ctx, P, isCtrl);
-  if (rc) return rc;
-  rc = finish_scalars(ctx, isCtrl);
-  while (rc == RETRY_PT) {
-    // a (XCD class, super-bucket) list needed more pages than its table row holds -- reads piled up in one
-    // spot: what the first build left behind goes, the table grows, the sample is built again
-    ctx->ptJmax = std::min(ctx->ptJmax * 16, PT_JMAX_CAP);
+  ctx->fusedOff = false;
+  if (!isCtrl) ctx->looseOk = false;
+  auto wipe = [&]() -> int {  // what a build that is repeated left behind: status bits, its part of fragLen / ctrlFrag
     Scalars* ds = ctx->dScal.as<Scalars>();
     HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
     HIPCHECK(hipMemsetAsync(isCtrl ? ds->ctrlAcc : ds->fragAcc, 0, 16, ctx->stream));
-    if ((rc = build_pileup(ctx, P, isCtrl))) return rc;
+    return GX_OK;
+  };
+  for (int attempt = 0; attempt < 12; attempt++) {
+    int rc = build_pileup(ctx, P, isCtrl);
+    if (rc) return rc;
     rc = finish_scalars(ctx, isCtrl);
+    if (rc == RETRY_GENERAL) {
+      // k_sbtile could not take the sample (finish_scalars has switched it off for this one): the general chain
+      if (int w = wipe()) return w;
+    } else if (rc == RETRY_PT) {
+      // a (XCD class, super-bucket) list needed more pages than its table row holds -- reads piled up in one
+      // spot: what the first build left behind goes, the table grows, the sample is built again
+      ctx->ptJmax = std::min(ctx->ptJmax * 16, PT_JMAX_CAP);
+      if (int w = wipe()) return w;
+    } else if (rc == RETRY_SATURATED) {
+      if ((rc = drop_saturated(ctx, isCtrl))) return rc;  // (sets satDone: finish_scalars asks for this once)
+    } else
+      return rc;
   }
-  if (rc == RETRY_SATURATED) {
-    if ((rc = drop_saturated(ctx, isCtrl))) return rc;
-    if ((rc = build_pileup(ctx, P, isCtrl))) return rc;
-    rc = finish_scalars(ctx, isCtrl);
-    if (rc == RETRY_PT || rc == RETRY_SATURATED) {
-      ctx->err = "sample could not be rebuilt";
-      rc = GX_ERR_DEVICE;
-    }
-  }
-  return rc;
+  ctx->err = "sample could not be rebuilt";
+  return GX_ERR_DEVICE;
 }
 
 // tile space, super-buckets, -E edge lists and the chromosome table for the chromosomes this
@@ -858,7 +952,8 @@ int layout_tiles(gx_ctx* ctx) {
   // tiles per super-bucket: the level-1 scatter wants few bins (long runs per bin and chunk); level 2 wants
   // a super-bucket's keys to fit its one-pass LDS sort (45 K keys: ~2^9 tiles at hg38 / 50 M fragments) and
   // enough super-buckets for every CU; GX_SBSHIFT overrides for experiments
-  ctx->sbShift = std::min(11, std::max(0, (lg - 1) / 2));
+  // (k_sbtile, the fused level 2 + tile kernel, takes super-buckets of up to 2^8 tiles: hg38 = 2,946 bins)
+  ctx->sbShift = std::min(SBT_MAXSHIFT, std::max(0, (lg - 1) / 2));
   if (const char* e = getenv("GX_SBSHIFT")) ctx->sbShift = std::max(0, std::min(11, atoi(e)));
   while (((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1 > (u32)MAX_BINS) ctx->sbShift++;
   if ((1u << ctx->sbShift) > (u32)MAX_BINS) {
@@ -909,6 +1004,9 @@ struct SweepSrc {
   const u32* end = nullptr;
   const float* p = nullptr;
   const float* q = nullptr;
+  // the sweep on the loose slots (LooseCtl): `end` = the loose ends, p = the table p(V) looked up with the slots' exact
+  // pileups `V`; the masks are [significant | first of its chromosome], `mStride` apart, and there are no SKIP intervals
+  const int* V = nullptr;
   bool haveMasks = false, hasSkip = true;
   const u32* chromOff = nullptr;
   u32 nChrom = 0, nWords = 0;
@@ -927,6 +1025,7 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
   const u32 nWords = S.nWords, nChrom = S.nChrom;
   const u32 wChunks = (nWords + SW_CHUNK - 1) / SW_CHUNK;
   SweepMasks SM{ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + S.mStride, ctx->swMask.as<u64>() + 2 * S.mStride, nWords};
+  if (S.V) SM = SweepMasks{ctx->swMask.as<u64>(), nullptr, ctx->swMask.as<u64>() + S.mStride, nWords};
   u32 R = 0, nPeaks = 0;
   ctx->peakBP = 0;
   ctx->nHostPeaks = 0;
@@ -991,11 +1090,21 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
   hipLaunchKernelGGL((k_peak_short<Q>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,     \
                      misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),             \
                      ctx->valid.as<u32>())
+        if (S.V) {  // p from the table p(V) (`q` carries the exact pileups)
+          const float* vq = reinterpret_cast<const float*>(S.V);
+          hipLaunchKernelGGL((k_peak_short<false, true>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, vq, S.chromOff,
+                             nChrom, misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),
+                             ctx->valid.as<u32>());
+          hipLaunchKernelGGL(k_peak_walk<true>, gridW, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, vq, S.chromOff, nChrom,
+                             ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
+                             ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
+        } else {
         if (S.q) GX_LAUNCH_PEAK_SHORT(true); else GX_LAUNCH_PEAK_SHORT(false);
-#undef GX_LAUNCH_PEAK_SHORT
-        hipLaunchKernelGGL(k_peak_walk, gridW, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,
+        hipLaunchKernelGGL(k_peak_walk<false>, gridW, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,
                            ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
                            ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
+        }
+#undef GX_LAUNCH_PEAK_SHORT
       }
       // candidates C <= R: chunk arrays sized by the run capacity; kernels bound themselves by *nCands
       hipLaunchKernelGGL(k_peaks_count, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
@@ -1489,6 +1598,11 @@ int gx_pvalues(gx_ctx* ctx) {
     pa.ctrlIsConst = !ctx->hasBed;
     pa.ctrlConst = ctx->hScal.lambda;
     pa.loose = true;
+    // (the tile stage wrote the sweep's significance bits, in loose-slot index space: LooseCtl)
+    pa.looseSweep = ctx->looseOk && !ctx->par.qval_opt && !getenv("GX_NO_LOOSE");
+    pa.looseStride = ctx->looseStride;
+    if (pa.looseSweep) pa.chromLooseOff = std::move(ctx->chromLooseOff);
+    ctx->looseOk = false;
     ctx->reps.push_back(std::move(pa));
     ctx->sample++;
     ctx->phase = 0;
@@ -1597,8 +1711,12 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   HIPCHECK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   u32* misc = ctx->misc.as<u32>();
+  // One replicate without a control, -p, and the tile stage left the sweep's bits on the loose slots (LooseCtl): the
+  // sweep walks them where they are -- no tight interval table is made unless somebody asks for it later
+  const bool looseFast = ctx->sample == 1 && ctx->reps.size() == 1 && ctx->reps[0].loose && ctx->reps[0].looseSweep &&
+                         !ctx->par.qval_opt;
   for (size_t r = 0; r < ctx->reps.size(); r++) {
-    if (ctx->reps[r].loose)
+    if (ctx->reps[r].loose && !looseFast)
       if (int rc = materialize_rep(ctx, (int)r)) return rc;
     // (the Fisher combination of several replicates reuses the loose slots: the last replicate's pileup
     // floats, if wanted, have to be made before)
@@ -1687,7 +1805,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   ctx->mail->n = n;
   // genome length and interval count for the kernels that read them through pointers (BH, k_sig_mask): one tiny
   // kernel instead of two copy launches, and none at all when the masks came with the p-values
-  const bool masksReady = ctx->maskIdx == ctx->finalIdx && ctx->maskN == n;
+  const bool masksReady = looseFast || (ctx->maskIdx == ctx->finalIdx && ctx->maskN == n);
   if (ctx->par.qval_opt || !masksReady)
     hipLaunchKernelGGL(k_set_misc, dim3(1), dim3(1), 0, s, misc, (u32)M_NIV, (u32)M_GENOME, (u64)g, n);
 
@@ -1879,7 +1997,16 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   phase_begin(ctx, "sweep");
   SweepSrc src{};
   src.nChrom = nChrom;
-  {
+  if (looseFast) {
+    src.end = ctx->looseEnd.as<u32>();
+    src.V = ctx->looseV.as<int>();
+    src.p = ctx->pvLut.as<float>();
+    src.chromOff = fa.chromLooseOff.as<u32>();
+    src.mStride = fa.looseStride;
+    src.nWords = (u32)(fa.looseStride - 2);
+    src.haveMasks = true;
+    src.hasSkip = false;
+  } else {
     src.end = fa.end.as<u32>();
     src.p = fa.p.as<float>();
     src.q = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
@@ -1894,6 +2021,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     if (!src.haveMasks) HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, src.mStride * 8 * 3, s));
   }
   ctx->maskIdx = -1;
+  ctx->looseSwept = looseFast;
   u32 nPeaks = 0;
   if (int rc = run_sweep(ctx, src, &nPeaks)) return rc;
   phase_end(ctx);
@@ -2033,6 +2161,13 @@ int gx_total_intervals(gx_ctx* ctx, int which, size_t* n_iv) {
   int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
   if (w < 0 || w >= (int)ctx->reps.size()) return GX_ERR_ORDER;
   *n_iv = ctx->reps[w].n;
+  return GX_OK;
+}
+
+int gx_path_info(gx_ctx* ctx, unsigned* flags) {
+  if (!ctx || !flags) return GX_ERR_ORDER;
+  *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
+           (ctx->fellBack ? GX_PATH_FELL_BACK : 0u);
   return GX_OK;
 }
 

@@ -33,7 +33,7 @@ typedef uint32_t u32;
 constexpr int TB = GX_TB;              // tile bits
 constexpr int TILE = 1 << TB;          // bases per tile
 constexpr u32 NULL_TILE = 0xFFFFFFFFu; // dropped endpoint
-constexpr int MAX_BINS = 2048;         // bins of one bucket-sort level
+constexpr int MAX_BINS = 4096;         // bins of one bucket-sort level
 
 // device status bits (checked by the host at every sync point)
 enum : u32 {
@@ -446,12 +446,41 @@ struct BedIn {
   const uint8_t* tileSave0;
 };
 
+// ---- the peak sweep on the loose slots (gx_find_peaks, one replicate, no control, -p) ------------------------
+// Without a control p is a function of the exact pileup V (the table p(V), k_pval_lut), and with the closed
+// form of fragLen lambda -- hence the table -- is known BEFORE the tile stage.  The tile kernels then write the
+// sweep's significance bits themselves, in loose-slot index space, and fill a tile's unused slots with
+// zero-length intervals, so that the sweep walks the loose slots as they are (no k_pack_pval round trip).
+// One block of words per sample (zero arena) says whether that is valid.
+constexpr u32 PV_LUT = 1u << 18;  // entries of the table p(V)
+struct LooseCtl {
+  u32 sigInv;     // max of (PV_LUT - V) over the significant table entries V (0: none)
+  u32 nonP1;      // max of (V + 1) over the others
+  u32 bad;        // something forbids the loose sweep (a pileup beyond the table, a table that is not monotone)
+  u32 earlyBits;  // lambda as the tile stage knew it (float bits)
+  u32 enabled;    // lambda was known before the tile stage
+  u32 ok;         // the verdict for the host (k_frag_select): enabled, nothing bad, lambda unchanged
+  u32 pad[2];
+};
+// pileups (1/120 units) from which an interval is significant; INT_MAX: the tile kernels write no bits
+__device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporter) {
+  if (!c || !c->enabled) return 0x7FFFFFFF;
+  const u32 minSig = PV_LUT - c->sigInv;
+  if (minSig < c->nonP1) {  // p(V) > thr is not a threshold on V: leave it to the general path
+    if (reporter) atomicOr(&c->bad, 2u);
+    return 0x7FFFFFFF;
+  }
+  return (int)minSig;
+}
+
 struct TileOut {
   u32* looseEnd;    // interval end (chromosome coordinate), loose slots
   int* looseV;      // pileup in 1/120 units
   u32* tileCount;   // [nTiles] intervals written by each tile
   u32* tileLastEnd; // [nTiles] end of the tile's last interval (valid when tileCount > 0)
   u32* tileDeep;    // [nTiles] pre-zeroed; set when a pileup of the tile reaches FRAG_FAST_MAXV (see k_frag)
+  u64* sigMask;     // bit i: loose slot i holds a significant interval (pre-zeroed; see LooseCtl)
+  LooseCtl* ctl;
 };
 
 // savePileupExpt 2246/2271, calcFactor 2018/2038: `fragLen += (j - start) * val` is a float
@@ -492,7 +521,7 @@ __global__ __launch_bounds__(256) void k_tile_meta(const u32* __restrict__ offS,
                                                    const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
                                                    const u32* __restrict__ bedTileOff, u32 nTiles,
                                                    TileMeta* __restrict__ meta, u32* __restrict__ wideList,
-                                                   u32* __restrict__ nWide) {
+                                                   u32* __restrict__ nWide, u32* __restrict__ tileSlot) {
   // (the grid covers the tiles exactly once: every wavefront reaches the ballot below together)
   for (u32 t0 = blockIdx.x * 256; t0 < nTiles; t0 += gridDim.x * 256) {
     const u32 t = t0 + threadIdx.x;
@@ -513,6 +542,8 @@ __global__ __launch_bounds__(256) void k_tile_meta(const u32* __restrict__ offS,
     m.flags = (chrom_active(c) ? TM_ACTIVE : 0u) | (tl + 1 == c.nTiles ? TM_LAST : 0u) | (wide ? TM_WIDE : 0u);
     m.slot = m.sb + m.eb + m.fb + t + (bedTileOff ? bedTileOff[t] : 0u);  // <= records + edges + 1 intervals per tile
     meta[t] = m;
+    tileSlot[t] = m.slot;
+    if (t + 1 == nTiles) tileSlot[nTiles] = m.slot + m.nS + m.nE + m.nF + 1 + (bedTileOff ? bedTileOff[nTiles] - bedTileOff[t] : 0u);
     }
     // the wide tiles, as a list for k_tile<.., false> (one reservation per wavefront, ascending inside it)
     const u64 wm = __ballot(wide);
@@ -932,6 +963,13 @@ struct IvScanOut {
   u32* tilePrevEnd; // [nTiles] start of the tile's first interval
   u32* chromIvOff;  // [nChrom+1] (entries of chromosomes without tiles are filled by k_fix_chrom_off)
   u32* nIv;
+  // for the sweep on the loose slots (LooseCtl): the chromosomes' first loose slots, and the slots of the tiles
+  // without intervals filled with zero-length intervals that end where the previous interval ended
+  const u32* tileSlot;   // [nTiles+1]
+  u32* chromLooseOff;    // [nChrom+1]
+  u32* looseEnd;
+  int* looseV;
+  LooseCtl* ctl;
 };
 
 __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
@@ -998,8 +1036,24 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
       if (t < nTiles) {
         u32 ci = tileChrom[t];
         out.tileIvOff[t] = cex;
-        out.tilePrevEnd[t] = (u32)(kex >> 32) == ci + 1 ? (u32)kex : 0u;
-        if (t == chroms[ci].tileBase) out.chromIvOff[ci] = cex;
+        const u32 prevEnd = (u32)(kex >> 32) == ci + 1 ? (u32)kex : 0u;
+        out.tilePrevEnd[t] = prevEnd;
+        if (t == chroms[ci].tileBase) {
+          out.chromIvOff[ci] = cex;
+          out.chromLooseOff[ci] = out.tileSlot[t];
+        }
+        if (c[k] == 0 && (chroms[ci].flags & CH_SAVE)) {
+          // (a tile without intervals has few slots -- one more than it has records, all of which cancel; if it has
+          // many, the sweep on the loose slots is called off rather than filled in by one thread)
+          const u32 s0 = out.tileSlot[t], s1 = out.tileSlot[t + 1];
+          if (s1 - s0 > 64u)
+            atomicOr(&out.ctl->bad, 4u);
+          else
+            for (u32 j = s0; j < s1; j++) {
+              out.looseEnd[j] = prevEnd;
+              out.looseV[j] = 0;
+            }
+        }
       }
       cex += c[k];
       if (key[k] > kex) kex = key[k];
@@ -1206,16 +1260,21 @@ __device__ __forceinline__ void finish_frag(Scalars* s, int isCtrl, u32* st, con
 __global__ void k_frag_select(const FragFix* __restrict__ ff, long long* acc, long long* __restrict__ coll,
                               const u32* __restrict__ hot, u32* st, const DChrom* __restrict__ chroms,
                               u32 nChrom, u32* __restrict__ chromIvOff, const u32* __restrict__ nIv, Scalars* scal,
-                              int isCtrl) {
+                              int isCtrl, u32* __restrict__ chromLooseOff, const u32* __restrict__ tileSlot, u32 nTiles,
+                              LooseCtl* ctl) {
   if (threadIdx.x || blockIdx.x) return;
   {  // chromosome table epilogue (as k_fix_chrom_off): offsets of the chromosomes without tiles
-    u32 next = *nIv;
+    u32 next = *nIv, nextL = tileSlot[nTiles];
     chromIvOff[nChrom] = next;
+    chromLooseOff[nChrom] = nextL;
     for (int c = (int)nChrom - 1; c >= 0; c--) {
-      if (chroms[c].tileBase == NULL_TILE)
+      if (chroms[c].tileBase == NULL_TILE) {
         chromIvOff[c] = next;
-      else
+        chromLooseOff[c] = nextL;
+      } else {
         next = chromIvOff[c];
+        nextL = chromLooseOff[c];
+      }
     }
   }
   if (!ff->slow) {
@@ -1227,9 +1286,11 @@ __global__ void k_frag_select(const FragFix* __restrict__ ff, long long* acc, lo
   if (coll) {
     coll[0] = acc[0];
     coll[1] = acc[1];
-    coll[2] = (*hot ? 1 : 0) + ((*st & 512u) ? 65536 : 0);
+    coll[2] = (*hot ? 1 : 0) + ((*st & 512u) ? 65536 : 0) + ((*st & 3072u) ? (1ll << 32) : 0);  // (ST_SB_FULL | ST_SB_FRAC)
   } else
     finish_frag(scal, isCtrl, st, nullptr);  // one rank: the sums are final (otherwise k_finish_frag, after the all-reduce)
+  // the sweep may use the loose slots if the tile stage wrote its bits with the lambda that turned out final
+  ctl->ok = !coll && ctl->enabled && !ctl->bad && ctl->earlyBits == __float_as_uint(scal->lambda) ? 1u : 0u;
 }
 
 // a replicate begins: its scalars at zero, the genome length in place

@@ -1,0 +1,412 @@
+// gx_sbtile.h -- level 2 of the bucket sort FUSED with the tile stage, for samples of unit-weight records
+// without -E regions (the common case: every config but -s multimapping).
+//
+// Replaces k_scan_bins' consumer chain  k_bucket2p -> k_scan_tiles -> k_tile_meta -> k_tile_fast  (gx_sort.h,
+// gx_kernels.h, gx_tile_fast.h) and with it savePileupExpt's two per-base passes (Genrich.c:2197-2273):
+// round 2 wrote a super-bucket's keys back to HBM as 16-bit tile offsets (0.34 GB), scanned the per-tile counts
+// in two more launches, and then let one wavefront per tile fetch ~130 two-byte keys and a 48-byte descriptor --
+// a kernel bounded by the latency of those small loads (28 % of the HBM peak, 58 % of the wave cycles waiting).
+// Here ONE workgroup owns a super-bucket (2^sbShift <= 256 tiles) from its level-1 pages to its run-length
+// intervals:
+//   1  slot descriptors: the bin's sixteen page lists (8 XCD classes x start / end keys) cut into slots of 256
+//      keys = one 16-byte load per lane of one wavefront; a slot never crosses a page
+//   2  all slots of the bin in flight at once (up to 8 + 8 loads of 16 bytes per lane: the whole bin, ~136 KB,
+//      is requested before anything waits), the tiles' chromosome records next to them
+//   3  per-tile histogram (LDS atomics: starts in the low half of a word, ends in the high half), one block
+//      scan -> where a tile's keys lie, its loose output slot and its carry-in pileup:
+//        slot(t)  = start keys before t + end keys before t + t           (as k_tile_meta's)
+//        carry(t) = 120 (starts before t - ends before t) - weight of the ends that earlier chromosomes dropped
+//      (an end at the chromosome's length has no record: k_sort1 counts them per chromosome, endAtLen)
+//   4  the keys are scattered to their tiles' lists in LDS (13-bit values: offset + "is an end"; 112 KB hold 57 K
+//      keys, 1.7x what a bin of config 2 holds) and the sixteen wavefronts take tiles from an LDS counter:
+//      k_tile_fast's passes (occupancy bitmap -> rank of every touched base -> counters by rank -> 64 touched
+//      bases per step) with the keys coming from LDS -- no global load in the tile loop at all
+// A tile also leaves (a) its descriptor for the kernels downstream (k_pack_pval, k_frag_*), (b) when the
+// significance threshold is known already (gx_loose.h: lambda from the closed form of fragLen), the sweep's
+// significance bits for its intervals, in loose-slot index space, and (c) its unused slots filled with
+// zero-length intervals (end = the tile's last end), so that the peak sweep can walk the loose slots as they
+// are and k_pack_pval's 1.6 GB round trip disappears from the common run.
+// A bin that does not fit (more than SBT_SLOTS slots in a stream, more than SBT_KEYCAP keys: reads
+// piled up in one place) raises ST_SB_FULL and leaves empty tiles behind; the host then runs the general chain
+// on the same pages.
+#pragma once
+#include "gx_sort.h"
+#include "gx_tile_fast.h"
+
+namespace gx {
+
+constexpr u32 ST_SB_FULL = 1024u;  // (internal) a super-bucket does not fit k_sbtile: the host takes the general chain
+constexpr u32 ST_SB_FRAC = 2048u;  // (internal) the sample holds fractional-weight records: likewise, and for good
+
+constexpr int SBT_NT = 1024;
+constexpr int SBT_NW = SBT_NT / 64;
+constexpr int SBT_MAXSHIFT = 8;
+constexpr int SBT_TILES = 1 << SBT_MAXSHIFT;          // tiles per super-bucket the LDS tables are made for
+constexpr int SBT_K = 8;                               // 16-byte loads per lane and stream
+constexpr u32 SBT_SLOT = 256;                          // keys per slot
+constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K keys)
+constexpr u32 SBT_KEYCAP = 57344;                      // keys of a super-bucket (both streams) that fit the LDS
+constexpr int SBT_TR = 192;                            // touched bases per round of a tile's passes (k_tile_fast: TR_CAP)
+constexpr int SBT_TW = TILE / 32 + TILE / 64 + SBT_TR + SBT_TR / 2;  // a wavefront's scratch in words (1,920 bytes)
+static_assert((1u << PgCfg<u32>::SHIFT) % SBT_SLOT == 0, "a slot never crosses a page");
+static_assert(TILE == 4096, "13-bit LDS keys: 12 bits of offset and the stream");
+static_assert((SBT_NW * SBT_TW) % 4 == 0, "the scratch is cleared by 16-byte stores");
+
+struct SbtLds {
+  uint16_t keys[SBT_KEYCAP];               // the bin's keys, tile after tile: [11:0] offset, [15] end key
+  int tile[SBT_NW][SBT_TW];                // k_tile_fast's scratch, one per wavefront
+  u32 hist[SBT_TILES];                     // [15:0] start keys, [31:16] end keys of the tile
+  u32 startC[SBT_TILES + 1];               // keys (both streams) of the bin before the tile
+  int netPref[SBT_TILES];                  // start keys - end keys of the bin before the tile
+  u32 cur[2 * SBT_TILES];                  // scatter cursors: starts, ends
+  uint4 tinfo[SBT_TILES];                  // pos0, chromosome length, TM_ flags, weight dropped by earlier chromosomes
+  unsigned long long slotPtr[2 * SBT_SLOTS];
+  u32 slotCnt[2 * SBT_SLOTS];
+  u32 pre[2][NXCD + 1];
+  __attribute__((aligned(8))) u32 scratch[40];
+  u32 work;
+  u32 overflow;
+};
+
+struct SbtIn {
+  PagedStream PS, PE;
+  const u32* sbOffS;          // [nSeg + 1] start keys in the bins before (k_scan_bins)
+  const u32* sbOffE;
+  const u32* sbOffF;          // (only its total is looked at: any fractional record sends the sample to the general chain)
+  const u32* tileChrom;
+  const DChrom* chroms;
+  const int* chromW0;         // [nChrom] weight (1/120) of the ends dropped at the ends of the chromosomes before
+  u32 nSeg, nTiles;
+  int sbShift;
+};
+
+struct SbtOut {
+  TileOut to;
+  TileMeta* meta;
+  u32* tileSlot;              // [nTiles + 1] first loose slot of a tile (a compact copy of meta[].slot)
+};
+
+// LDS operations of ONE wavefront execute in order; what is needed between a wavefront's phases is only that
+// the compiler keeps them in order (no workgroup barrier: the wavefronts of k_sbtile walk different tiles)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One tile, one wavefront: the passes of k_tile_fast with the keys in LDS (kl[0 .. n): [11:0] offset, [15] end).
+__device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
+                                         int carry, u32 slot, int vsig, const SbtOut& out, u32& bad) {
+  u32* occ = reinterpret_cast<u32*>(lds);
+  u32* pre = reinterpret_cast<u32*>(lds + TILE / 32);
+  const uint16_t* pre16 = reinterpret_cast<const uint16_t*>(pre);
+  int* cnt = lds + TILE / 32 + TILE / 64;
+  uint16_t* list = reinterpret_cast<uint16_t*>(lds + TILE / 32 + TILE / 64 + SBT_TR);
+  constexpr int TR_CAP = SBT_TR;  // (shadows k_tile_fast's: the rounds below are its code)
+  const int lane = lane_id();
+  const bool active = flags & TM_ACTIVE;
+  const bool lastTile = (flags & TM_LAST) != 0;
+  constexpr int KR = 3;  // keys per lane kept in registers (192 per tile; a tile of config 2 holds ~135)
+  u32 kr[KR];
+#pragma unroll
+  for (int q = 0; q < KR; q++) kr[q] = (u32)lane + q * 64 < n ? kl[lane + q * 64] : 0u;
+  // ---- A1: keys -> occupancy bitmap
+  auto mark = [&](u32 key) { const u32 off = key & (TILE - 1); atomicOr(&occ[off >> 5], 1u << (off & 31)); };
+#pragma unroll
+  for (int q = 0; q < KR; q++)
+    if ((u32)lane + q * 64 < n) mark(kr[q]);
+  for (u32 k = KR * 64 + lane; k < n; k += 64) mark(kl[k]);
+  wave_lds_sync();
+  // ---- B: touched bases before each bitmap word
+  u32 w0 = 0, w1 = 0;
+  if (n) {  // wave-uniform
+    const uint2 ww = *reinterpret_cast<const uint2*>(occ + 2 * lane);
+    w0 = ww.x;
+    w1 = ww.y;
+  }
+  const int c0 = __popc(w0), c = c0 + __popc(w1);
+  const int incC = dpp_scan_add(c);
+  const u32 exc = (u32)(incC - c);
+  const u32 T = (u32)__builtin_amdgcn_readlane(incC, 63);
+  if (T) pre[lane] = exc | ((exc + (u32)c0) << 16);
+  wave_lds_sync();
+  int runBase = carry;
+  u32 outCount = 0, lastEnd = 0;
+  u64 negM = 0, bigM = carry >= FRAG_FAST_MAXV ? ~0ull : 0ull;
+  auto rankOf = [&](u32 off) -> u32 {
+    const u32 wi = off >> 5;
+    return (u32)pre16[wi] + (u32)__popc(occ[wi] & ((1u << (off & 31)) - 1u));
+  };
+  u32 rr[KR];
+  if (T) {
+#pragma unroll
+    for (int q = 0; q < KR; q++) rr[q] = rankOf(kr[q] & (TILE - 1));
+  }
+  for (u32 r0 = 0; r0 < T; r0 += TR_CAP) {
+    if (r0) wave_lds_sync();
+    // ---- A2: keys -> cnt[rank], list[rank]
+    auto put = [&](u32 r, u32 key) {
+      r -= r0;
+      if (r < (u32)TR_CAP) {
+        list[r] = (uint16_t)(key & (TILE - 1));
+        atomicAdd(&cnt[r], (key & 0x8000u) ? -GX_UNIT : GX_UNIT);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < KR; q++)
+      if ((u32)lane + q * 64 < n) put(rr[q], kr[q]);
+    for (u32 k = KR * 64 + lane; k < n; k += 64) {
+      const u32 key = kl[k];
+      put(rankOf(key & (TILE - 1)), key);
+    }
+    wave_lds_sync();
+    // ---- C: 64 touched bases per step
+    const u32 nL = min((u32)TR_CAP, T - r0);
+    for (u32 j0 = 0; j0 < nL; j0 += 64) {
+      const u32 j = j0 + lane;
+      const bool valid = j < nL;
+      u32 p = 0;
+      int d120 = 0;
+      if (valid) {
+        p = list[j];
+        d120 = cnt[j];
+        cnt[j] = 0;
+      }
+      const int incS = dpp_scan_add(d120);
+      const int after = runBase + incS;
+      const int before = after - d120;                          // the pileup of the interval that ends here (2244)
+      const bool nz = d120 != 0 && active && (pos0 + p != 0);   // 2241: base 0 closes nothing
+      const u64 mask = __ballot(nz);
+      if (nz) {
+        const u32 o = slot + outCount +
+                      __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+        out.to.looseEnd[o] = pos0 + p;
+        out.to.looseV[o] = before;
+        if (before >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[o >> 6], 1ull << (o & 63));  // rare
+      }
+      negM |= __ballot(after < 0);
+      bigM |= __ballot(after >= FRAG_FAST_MAXV);
+      runBase += __builtin_amdgcn_readlane(incS, 63);
+      if (mask) {  // wave-uniform
+        outCount += (u32)__popcll(mask);
+        lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(mask));
+      }
+    }
+  }
+  if (T) *reinterpret_cast<uint2*>(occ + 2 * lane) = make_uint2(0u, 0u);
+  u32 total = 0;
+  if (active) {  // wave-uniform
+    total = outCount + (lastTile ? 1u : 0u);
+    if (lane == 0) {
+      if (lastTile) {  // closing interval [.., len): 2268-2273
+        const u32 o = slot + outCount;
+        out.to.looseEnd[o] = len;
+        out.to.looseV[o] = runBase;
+        if (runBase >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[o >> 6], 1ull << (o & 63));
+        lastEnd = len;
+      }
+      if (total) out.to.tileLastEnd[t] = lastEnd;
+    }
+    lastEnd = (u32)__builtin_amdgcn_readfirstlane((int)lastEnd);
+    if (negM) bad |= ST_NEG_PILE;
+    if (bigM && lane == 0) {  // rare
+      atomicOr(&out.to.tileDeep[t], 1u);
+      if (out.to.ctl) atomicOr(&out.to.ctl->bad, 1u);  // a pileup beyond (or close to the end of) the table p(V)
+    }
+  }
+  if (lane == 0) out.to.tileCount[t] = total;
+  // the unused slots of the tile: zero-length intervals behind its last one (a tile without intervals does not
+  // know where the previous one ended: k_scan_iv fills its slots)
+  if (total && vsig != 0x7FFFFFFF) {  // wave-uniform
+    const u32 size = n + 1;
+    for (u32 j = total + lane; j < size; j += 64) {
+      out.to.looseEnd[slot + j] = lastEnd;
+      out.to.looseV[slot + j] = 0;
+    }
+  }
+  wave_lds_sync();
+}
+
+__global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
+  SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
+  const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+  const u32 seg = blockIdx.x, nSeg = in.nSeg;
+  const u32 nT = 1u << in.sbShift;           // tiles per super-bucket (<= SBT_TILES)
+  const u32 segTileBase = seg << in.sbShift;
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, blockIdx.x == 0 && tid == 0));
+  // scratch and tables start at zero
+  for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
+  if (tid < SBT_TILES) L.hist[tid] = 0;
+  if (tid == 0) L.overflow = 0;
+  if (tid < 2 * NXCD) {
+    const PagedStream& P = tid < NXCD ? in.PS : in.PE;
+    L.scratch[tid] = P.cursor[(u32)(tid & (NXCD - 1)) * nSeg + seg];
+  }
+  __syncthreads();
+  if (tid < 2) {
+    u32 a = 0;
+    for (int x = 0; x < NXCD; x++) {
+      L.pre[tid][x] = a;
+      a += L.scratch[tid * NXCD + x];
+    }
+    L.pre[tid][NXCD] = a;
+  }
+  __syncthreads();
+  // ---- 1: slot descriptors (thread k of the first 2 SBT_SLOTS: slot k & 127 of stream k >> 7)
+  if (tid < 2 * (int)SBT_SLOTS) {
+    const int q = tid / (int)SBT_SLOTS;
+    const u32 k = (u32)tid % SBT_SLOTS;
+    const PagedStream& P = q ? in.PE : in.PS;
+    const u32* pre = L.pre[q];
+    u32 x = NXCD, k0 = 0, acc = 0;
+    for (u32 y = 0; y < NXCD; y++) {
+      const u32 ns = (pre[y + 1] - pre[y] + SBT_SLOT - 1) / SBT_SLOT;
+      if (x == NXCD && k < acc + ns) {
+        x = y;
+        k0 = acc;
+      }
+      acc += ns;
+    }
+    if (k == 0 && acc > SBT_SLOTS) L.overflow = 1;  // more slots than descriptors: the bin does not fit
+    unsigned long long ptr = 0;
+    u32 cnt = 0;
+    if (x < NXCD) {
+      const u32 off = (k - k0) * SBT_SLOT;
+      const u32 jp = off >> PgCfg<u32>::SHIFT, li = x * nSeg + seg;
+      const u32 page = jp ? P.pt[(size_t)li * P.jmax + jp] - 1u : first_page(li);
+      ptr = (unsigned long long)(reinterpret_cast<const u32*>(P.pool) + ((size_t)page << PgCfg<u32>::SHIFT) +
+                                 (off & ((1u << PgCfg<u32>::SHIFT) - 1u)));
+      cnt = min(SBT_SLOT, pre[x + 1] - pre[x] - off);
+    }
+    L.slotPtr[tid] = ptr;
+    L.slotCnt[tid] = cnt;
+  }
+  // the tiles' chromosome records (thread b: tile b of the bin), in flight next to the keys
+  uint4 ti = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < (int)nT) {
+    const u32 t = segTileBase + tid;
+    if (t < in.nTiles) {
+      const u32 ci = in.tileChrom[t];
+      const DChrom c = in.chroms[ci];
+      const u32 tl = t - c.tileBase;
+      ti.x = tl << TB;
+      ti.y = c.len;
+      ti.z = (chrom_active(c) ? TM_ACTIVE : 0u) | (tl + 1 == c.nTiles ? TM_LAST : 0u);
+      ti.w = (u32)in.chromW0[ci];
+    }
+  }
+  __syncthreads();
+  const bool ovfSlots = L.overflow != 0;
+  // ---- 2: the bin's keys, all loads in flight together
+  uint4 kS[SBT_K], kE[SBT_K];
+  u32 cS[SBT_K], cE[SBT_K];
+#pragma unroll
+  for (int i = 0; i < SBT_K; i++) {  // (wave-uniform: scalar registers)
+    cS[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
+    cE[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[SBT_SLOTS + i * SBT_NW + wv]);
+  }
+#pragma unroll
+  for (int i = 0; i < SBT_K; i++) {
+    kS[i] = make_uint4(0u, 0u, 0u, 0u);
+    if ((u32)lane * 4 < cS[i]) kS[i] = reinterpret_cast<const uint4*>(L.slotPtr[i * SBT_NW + wv])[lane];
+  }
+#pragma unroll
+  for (int i = 0; i < SBT_K; i++) {
+    kE[i] = make_uint4(0u, 0u, 0u, 0u);
+    if ((u32)lane * 4 < cE[i]) kE[i] = reinterpret_cast<const uint4*>(L.slotPtr[SBT_SLOTS + i * SBT_NW + wv])[lane];
+  }
+  if (tid < (int)nT) L.tinfo[tid] = ti;
+  // ---- 3: per-tile histogram
+  auto keyAt = [](const uint4& v, int j) -> u32 { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
+#pragma unroll
+  for (int i = 0; i < SBT_K; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if ((u32)lane * 4 + j < cS[i]) atomicAdd(&L.hist[(keyAt(kS[i], j) >> TB) - segTileBase], 1u);
+      if ((u32)lane * 4 + j < cE[i]) atomicAdd(&L.hist[(keyAt(kE[i], j) >> TB) - segTileBase], 65536u);
+    }
+  }
+  __syncthreads();
+  {
+    u32 h = tid < (int)nT ? L.hist[tid] : 0u;
+    const u32 nS = h & 0xFFFFu, nE = h >> 16;
+    const u64 v = (u64)(nS + nE) | ((u64)(u32)((int)nS - (int)nE) << 32);
+    u64 tot;
+    const u64 ex = block_excl_scan<u64, SBT_NT>(v, reinterpret_cast<u64*>(L.scratch), &tot);
+    if (tid < (int)nT) {
+      L.startC[tid] = (u32)ex;
+      L.netPref[tid] = (int)(u32)(ex >> 32);
+    }
+    if (tid == 0) L.startC[nT] = (u32)tot;
+  }
+  __syncthreads();
+  const bool ovf = ovfSlots || L.startC[nT] > SBT_KEYCAP;
+  // (the slot capacity bounds a stream at 32 K keys, so a tile's 16-bit counts cannot have wrapped)
+  if (ovf && tid == 0) atomicOr(st, ST_SB_FULL);
+  if (seg == 0 && tid == 0 && in.sbOffF[nSeg] != 0) atomicOr(st, ST_SB_FRAC);
+  // descriptors for the kernels downstream, scatter cursors
+  const u32 segS = in.sbOffS[seg], segE = in.sbOffE[seg];
+  const u32 segSlot = segS + segE + segTileBase;
+  const int segNet = (int)segS - (int)segE;
+  if (tid < (int)nT) {
+    const u32 t = segTileBase + tid;
+    const u32 h = ovf ? 0u : L.hist[tid];
+    const u32 nS = h & 0xFFFFu, nE = h >> 16;
+    const u32 sc = ovf ? 0u : L.startC[tid];
+    L.cur[tid] = sc;
+    L.cur[SBT_TILES + tid] = sc + nS;
+    if (t < in.nTiles) {
+      TileMeta m;
+      m.sb = 0; m.eb = 0; m.fb = 0;
+      m.nS = nS; m.nE = nE; m.nF = 0;
+      m.carry = ovf ? 0 : GX_UNIT * (segNet + L.netPref[tid]) - (int)ti.w;
+      m.ci = 0;
+      m.pos0 = ti.x; m.len = ti.y; m.flags = ti.z;
+      m.slot = segSlot + sc + (u32)tid;
+      out.meta[t] = m;
+      out.tileSlot[t] = m.slot;
+      if (t + 1 == in.nTiles) out.tileSlot[in.nTiles] = m.slot + nS + nE + 1;
+    }
+  }
+  if (ovf) {
+    // leave empty tiles behind (the host repeats the sample on the general chain)
+    if (tid < (int)nT && segTileBase + tid < in.nTiles) out.to.tileCount[segTileBase + tid] = 0;
+    return;
+  }
+  u32 bad = 0;
+  // ---- 4: the keys to their tiles' lists in LDS; then the wavefronts take tiles from a counter
+  if (tid == 0) L.work = 0;
+  __syncthreads();  // the cursors are there
+#pragma unroll
+  for (int i = 0; i < SBT_K; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if ((u32)lane * 4 + j < cS[i]) {
+        const u32 key = keyAt(kS[i], j);
+        L.keys[atomicAdd(&L.cur[(key >> TB) - segTileBase], 1u)] = (uint16_t)(key & (TILE - 1));
+      }
+      if ((u32)lane * 4 + j < cE[i]) {
+        const u32 key = keyAt(kE[i], j);
+        L.keys[atomicAdd(&L.cur[SBT_TILES + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | 0x8000u);
+      }
+    }
+  }
+  __syncthreads();
+  for (;;) {
+    u32 b = 0;
+    if (lane == 0) b = atomicAdd(&L.work, 1u);
+    b = (u32)__builtin_amdgcn_readfirstlane((int)b);
+    if (b >= nT) break;
+    const u32 t = segTileBase + b;
+    if (t >= in.nTiles) continue;
+    const u32 h = L.hist[b], n = (h & 0xFFFFu) + (h >> 16);
+    const uint4 tf = L.tinfo[b];
+    const u32 sc = L.startC[b];
+    const int carry = GX_UNIT * (segNet + L.netPref[b]) - (int)tf.w;
+    sbt_tile(L.tile[wv], L.keys + sc, n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad);
+  }
+  if (bad && lane == 0) atomicOr(st, bad);
+}
+
+}  // namespace gx

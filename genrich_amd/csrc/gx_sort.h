@@ -345,11 +345,50 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
   if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 16 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
 }
 
-// bin totals (over the XCD classes) -> where each super-bucket's records start after level 2; one workgroup per stream
-struct BinScan { const u32* cursor[3]; u32* sbOff[3]; };
+// bin totals (over the XCD classes) -> where each super-bucket's records start after level 2; one workgroup per stream.
+// A fourth workgroup prepares what the tile stage needs besides:
+//   chromW0[c]  weight of the ends that the chromosomes before c dropped at their own end (no record: endAtLen) --
+//               the genome-wide prefix of the tiles' weights at chromosome c's first tile (k_sbtile's carry-in);
+//   lambda from the closed form of fragLen (`wantEarly`: one rank, a treatment sample, unit weights so far),
+//               so that the table p(V) exists before the tile stage (LooseCtl, gx_kernels.h)
+struct BinScan {
+  const u32* cursor[3];
+  u32* sbOff[3];
+  const u32* endAtLen;
+  int* chromW0;
+  u32 nChrom;
+  const FragFix* ff;
+  Scalars* scal;
+  LooseCtl* ctl;
+  int wantEarly;
+};
 
 __global__ __launch_bounds__(1024) void k_scan_bins(BinScan B, u32 nBins) {
   __shared__ u32 scratch[20];
+  if (blockIdx.x == 3) {
+    const u32 per = (B.nChrom + 1023) / 1024;
+    const u32 c0 = min(B.nChrom, threadIdx.x * per), c1 = min(B.nChrom, c0 + per);
+    u32 sum = 0;
+    for (u32 c = c0; c < c1; c++) sum += B.endAtLen[c];
+    u32 tot;
+    u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
+    for (u32 c = c0; c < c1; c++) {
+      B.chromW0[c] = (int)ex;
+      ex += B.endAtLen[c];
+    }
+    if (threadIdx.x == 0 && B.wantEarly && !B.ff->slow) {
+      u64 t = 0;
+      for (int i = 0; i < FRAG_SLOTS; i++) t += B.ff->fragSum[i];
+      if (t) {  // (as finish_frag will compute it when the correction of k_frag_fix1 / k_frag_walk is zero)
+        const double fragLen = (double)(long long)t + (double)0ll * (1.0 / 134217728.0);
+        const float lambda = (float)(fragLen / (double)B.scal->genomeLen);
+        B.scal->lambda = lambda;
+        B.ctl->earlyBits = __float_as_uint(lambda);
+        B.ctl->enabled = 1u;
+      }
+    }
+    return;
+  }
   const u32* cursor = B.cursor[blockIdx.x];
   u32* sbOff = B.sbOff[blockIdx.x];
   constexpr int PER = MAX_BINS / 1024;

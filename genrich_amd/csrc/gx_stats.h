@@ -12,7 +12,7 @@ namespace gx {
 // tabulated once per replicate for V < PV_LUT (pileups up to ~2184x; a 1 MiB table that stays in
 // L2) by the very same double-precision routine, and looked up per interval; larger V are
 // computed directly.  Same bits either way.
-constexpr u32 PV_LUT = 1u << 18;
+// (PV_LUT = 2^18 entries: gx_kernels.h)
 
 __device__ __forceinline__ float pval_of_v(int v, float lambda, double ml, double sl, float* valOut, bool* neg, bool* risky) {
   float val = getval(v, neg);
@@ -26,22 +26,39 @@ __device__ __forceinline__ void deep_risky_body(PackIn in, const FragFix* __rest
 
 // blocks [0, PV_LUT / 256): the table; DEEP_BLOCKS more: the deep tiles' risky values (k_deep_risky's work, same launch)
 constexpr u32 DEEP_BLOCKS = 32;
+// `early` (LooseCtl, gx_kernels.h): the launch ahead of the tile stage, with the lambda of the closed form of fragLen --
+// it also finds from which pileup on an interval is significant (p > thr; the tile kernels write the sweep's bits
+// with it).  The launch after the tile stage then only rebuilds the table when lambda turned out different.
 __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc, float* __restrict__ lutP,
                                                   RiskBuf* __restrict__ risk, DeepTab* __restrict__ deep, PackIn in,
-                                                  const FragFix* __restrict__ ff, const u32* __restrict__ list) {
+                                                  const FragFix* __restrict__ ff, const u32* __restrict__ list,
+                                                  LooseCtl* __restrict__ ctl, int early, float thr) {
   if (blockIdx.x == 0 && threadIdx.x == 0) deep->n = 0;  // this sample's host-evaluated deep values come later
   if (blockIdx.x >= PV_LUT / 256) {
     if (in.meta) deep_risky_body(in, ff, list, sc, risk, blockIdx.x - PV_LUT / 256, gridDim.x - PV_LUT / 256);
     return;
   }
   const float lambda = sc->lambda;
+  if (ctl) {
+    if (early && !ctl->enabled) return;                                                // lambda is not known yet
+    if (!early && ctl->enabled && ctl->earlyBits == __float_as_uint(lambda)) return;   // the table is this one already
+  }
   double ml = 0, sl = 1;
   if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
   for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += (PV_LUT / 256) * 256) {
     float val;
     bool ng, risky = false;
-    lutP[v] = pval_of_v((int)v, lambda, ml, sl, &val, &ng, &risky);
+    const float p = pval_of_v((int)v, lambda, ml, sl, &val, &ng, &risky);
+    lutP[v] = p;
     if (risky) risk_add(risk, RK_LUT, v, 0, 0, 0.0);
+    if (early && ctl) {  // (the grid covers the table once: v = this wavefront's first entry + lane)
+      const u64 sg = __ballot(p > thr);
+      if (lane_id() == 0) {
+        const u32 v0 = v;
+        if (sg) atomicMax(&ctl->sigInv, PV_LUT - (v0 + (u32)__builtin_ctzll(sg)));
+        if (~sg) atomicMax(&ctl->nonP1, v0 + (u32)(63 - __builtin_clzll(~sg)) + 1u);
+      }
+    }
   }
 }
 
@@ -1042,7 +1059,12 @@ __device__ __forceinline__ u32 row_max_u(u32 v) {
 // (round 1) paid n / 32 round trips AND ran every updatePeak serially (a 1,000-interval candidate held its
 // wavefront for ~100 us, which is what the kernel took).
 constexpr int PK_AHEAD = 4;
-template <bool USEQ>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
+// PV: `p` is the table p(V) and `q` (reinterpreted) the intervals' exact pileups V -- the sweep on the loose slots.
+__device__ __forceinline__ float p_from_v(const float* __restrict__ lut, const int* __restrict__ V, u32 i) {
+  const u32 v = (u32)V[i];
+  return lut[v < PV_LUT ? v : 0u];  // (pileups beyond the table forbid this sweep: LooseCtl::bad)
+}
+template <bool USEQ, bool PV = false>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
 __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hdr, const u32* __restrict__ end,
                                                     const float* __restrict__ p, const float* __restrict__ q,
                                                     const u32* __restrict__ chromOff, u32 nChrom,
@@ -1075,7 +1097,8 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
         if (in[a]) {
           e[a] = end[i];
           sPrev[a] = i == i0 ? peakStart : end[i - 1];
-          pv[a] = p[i];
+          if (PV) pv[a] = p_from_v(p, reinterpret_cast<const int*>(q), i);
+          else pv[a] = p[i];
           if (USEQ) qv[a] = q[i];
         }
       }
@@ -1129,12 +1152,14 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
 // per step, PK_AHEAD steps of loads in flight; the ordered float sum runs row after row (16 dependent DPP adds
 // each, the running value carried from row to row by a readlane); maxima by DPP rotations inside the rows and
 // readlanes across them: no LDS shuffle anywhere.
+template <bool PV = false>
 __global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr, const u32* __restrict__ end,
-                                                   const float* __restrict__ p, const float* __restrict__ q,
+                                                   const float* __restrict__ p, const float* __restrict__ qIn,
                                                    const u32* __restrict__ chromOff, u32 nChrom,
                                                    const u32* __restrict__ longList, const u32* __restrict__ nLong,
                                                    float thr, float minAUC, int minLen,
                                                    gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  const float* __restrict__ q = PV ? nullptr : qIn;
   const u32 L = *nLong;
   const u32 wavesPerGrid = gridDim.x * 4;
   const int lane = lane_id();
@@ -1157,7 +1182,8 @@ __global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr
         if (in[a]) {
           e[a] = end[i];
           sPrev[a] = i == i0 ? peakStart : end[i - 1];
-          pv[a] = p[i];
+          if (PV) pv[a] = p_from_v(p, reinterpret_cast<const int*>(qIn), i);
+          else pv[a] = p[i];
           if (q) qv[a] = q[i];
         }
       }

@@ -51,6 +51,8 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
   const u32 G = gridDim.x;
   const u32 lb = xcd_local_block(blockIdx.x, G);
   u32 bad = 0;
+  // pileups from which an interval is significant, when lambda was known before this kernel (LooseCtl)
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.ctl, blockIdx.x == 0 && lane == 0));
   // Software pipeline over this wavefront's tiles, with k_tile's discipline (loads and stores share the
   // in-order vmcnt): prefetches are issued right after a tile's stores and collected right before the
   // next tile's stores.
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
                         __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
           out.looseEnd[o] = pos0 + p;
           out.looseV[o] = before;
+          if (before >= vsig) atomicOr((unsigned long long*)&out.sigMask[o >> 6], 1ull << (o & 63));  // rare
         }
         negM |= __ballot(after < 0);
         bigM |= __ballot(after >= FRAG_FAST_MAXV);
@@ -239,16 +242,31 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
       total = outCount + (lastTile ? 1u : 0u);
       if (lane == 0) {
         if (lastTile) {  // closing interval [.., len): 2268-2273
-          out.looseEnd[slot + outCount] = m.len;
-          out.looseV[slot + outCount] = runBase;
+          const u32 o = slot + outCount;
+          out.looseEnd[o] = m.len;
+          out.looseV[o] = runBase;
+          if (runBase >= vsig) atomicOr((unsigned long long*)&out.sigMask[o >> 6], 1ull << (o & 63));
           lastEnd = m.len;
         }
         if (total) out.tileLastEnd[t] = lastEnd;
       }
+      lastEnd = (u32)__builtin_amdgcn_readfirstlane((int)lastEnd);
       if (negM) bad |= ST_NEG_PILE;
-      if (bigM && lane == 0) atomicOr(&out.tileDeep[t], 1u);  // rare
+      if (bigM && lane == 0) {  // rare
+        atomicOr(&out.tileDeep[t], 1u);
+        if (out.ctl) atomicOr(&out.ctl->bad, 1u);  // a pileup beyond (or close to the end of) the table p(V)
+      }
     }
     if (lane == 0) out.tileCount[t] = total;
+    // the tile's unused slots: zero-length intervals behind its last one, for the sweep on the loose slots (a
+    // tile without intervals does not know where the previous one ended: k_scan_iv fills its slots)
+    if (total && vsig != 0x7FFFFFFF) {  // wave-uniform
+      const u32 size = nS + nE + nF + 1;
+      for (u32 j = total + lane; j < size; j += 64) {
+        out.looseEnd[slot + j] = lastEnd;
+        out.looseV[slot + j] = 0;
+      }
+    }
     issue();
   }
   if (bad && lane == 0) atomicOr(st, bad);

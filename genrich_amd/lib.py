@@ -72,6 +72,7 @@ _SIGS = {
     "gx_selftest": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_selftest2": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)],
     "gx_selftest_host": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_path_info": [C.c_void_p, C.POINTER(C.c_uint)],
     "gx_set_phase_timing": [C.c_void_p, C.c_int],
     "gx_phase_times": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float))],
 }
@@ -313,6 +314,12 @@ class Genrich:
         n = C.c_size_t(0)
         self._check(self.lib.gx_total_intervals(self.ctx, int(which), C.byref(n)))
         return n.value
+
+    def path_info(self):
+        """Which device path the last calls took: GX_PATH_* bits (1 fused tile stage, 2 loose-slot sweep, 4 fell back)."""
+        f = C.c_uint(0)
+        self._check(self.lib.gx_path_info(self.ctx, C.byref(f)))
+        return f.value
 
     def set_phase_timing(self, level):
         """0 none (default), 1 the tile stage only, 2 every phase (each event record costs the stream ~5 us)."""

@@ -239,6 +239,15 @@ int gx_set_keep_pileups(gx_ctx* ctx, int keep);
  * bench.py's roofline needs inside its timed region), 2 every phase. */
 int gx_set_phase_timing(gx_ctx* ctx, int level);
 int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
+/* Which device path the last calls took (tests assert that the fast paths really run):
+ * bit 0: the last sample's tile stage was k_sbtile (level 2 of the sort fused with the tile passes, gx_sbtile.h);
+ * bit 1: the last gx_find_peaks swept the tile stage's loose slots (no k_pack_pval, gx_kernels.h LooseCtl);
+ * bit 2: a sample of this context was sent back to the general chain (a super-bucket beyond k_sbtile's LDS, or
+ *        fractional weights). */
+#define GX_PATH_FUSED 1u
+#define GX_PATH_LOOSE_SWEEP 2u
+#define GX_PATH_FELL_BACK 4u
+int gx_path_info(gx_ctx* ctx, unsigned* flags);
 
 /* Evaluate one scalar device function on n inputs (numerics tests):
  * what 0: log10f as the host libm computes it (saveQval 221/226)   out = f(a)

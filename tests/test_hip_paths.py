@@ -1,0 +1,140 @@
+"""GPU parity of the round-3 fast paths against the CPU oracle, and proof that they are the paths that ran:
+  * k_sbtile (gx_sbtile.h): level 2 of the bucket sort fused with the tile passes;
+  * the peak sweep on the tile stage's loose slots (gx_kernels.h LooseCtl): no k_pack_pval round trip;
+  * the way back to the general chain when a super-bucket does not fit k_sbtile's LDS or the sample holds
+    fractional weights (Genrich.c:2311-2488 addFrac / subFrac).
+Every combination must give the oracle's bits (the reference's: oracle pinned in tests/test_oracle.py)."""
+import numpy as np
+import pytest
+
+import backends as B
+import synth
+from test_hip_parity import assert_same_run, hip_backend
+
+pytestmark = pytest.mark.gpu
+
+FUSED, LOOSE, FELL_BACK = 1, 2, 4
+
+
+def _case(seed=11, n=90_000, lens=(400_000, 123_457, 16_384, 4_097, 5), **kw):
+    lens = list(lens)
+    ev = synth.make_fragments(lens[:4], n, seed, peak_every=20_000, tower_every=150_000, **kw)
+    return dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None)])
+
+
+def _run(case, params):
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    sh = B.run_case(h, case)
+    flags = h.path_info()
+    assert_same_run(o, h, so, sh, case)
+    return o, h, flags
+
+
+@pytest.mark.parametrize("no_fused,no_loose", [(False, False), (True, False), (False, True), (True, True)])
+def test_every_combination_of_the_fast_paths_is_the_oracles_bits(monkeypatch, no_fused, no_loose):
+    if no_fused:
+        monkeypatch.setenv("GX_NO_FUSED", "1")
+    if no_loose:
+        monkeypatch.setenv("GX_NO_LOOSE", "1")
+    o, h, flags = _run(_case(), B.make_params(pq=0.01, min_auc=50.0))
+    assert h.n_peaks > 0
+    assert bool(flags & FUSED) == (not no_fused)
+    assert bool(flags & LOOSE) == (not no_loose)
+    assert not flags & FELL_BACK
+
+
+def test_default_run_takes_both_fast_paths_and_a_second_sweep_agrees():
+    case = _case(seed=5, n=150_000)
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    B.run_case(o, case)
+    h = hip_backend(params)
+    B.run_case(h, case)
+    assert h.path_info() & (FUSED | LOOSE) == FUSED | LOOSE
+    first = h.get_peaks().copy()
+    h.find_peaks()  # once more, on the same loose slots
+    again = h.get_peaks()
+    assert first.tobytes() == again.tobytes() == o.get_peaks().tobytes()
+
+
+def test_q_mode_uses_the_fused_tile_stage_but_the_tight_table():
+    o, h, flags = _run(_case(seed=3), B.make_params(pq=0.05, qval=True, min_auc=20.0))
+    assert flags & FUSED and not flags & LOOSE
+
+
+def test_a_control_uses_the_fused_tile_stage_for_both_samples():
+    lens = [300_000, 70_001]
+    t = synth.make_fragments(lens, 70_000, 21, peak_every=20_000, tower_every=150_000)
+    c = synth.make_fragments(lens, 50_000, 22, uniform_only=True)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=t, ctrl=c)])
+    o, h, flags = _run(case, B.make_params(pq=0.01, min_auc=20.0))
+    assert flags & FUSED and not flags & LOOSE
+
+
+def test_a_super_bucket_beyond_the_lds_goes_back_to_the_general_chain():
+    # 49 tiles -> 4 tiles per super-bucket; 45,000 fragments inside one of them = 90,000 keys > SBT_KEYCAP
+    lens = [200_000]
+    rng = np.random.default_rng(9)
+    ev = synth.make_fragments(lens, 20_000, 2, peak_every=20_000, tower_every=150_000)
+    pile = np.zeros(45_000, dtype=B.EVENT_DTYPE)
+    pile["start"] = 66_000 + rng.integers(0, 12_000, size=len(pile))
+    pile["end"] = pile["start"] + 100 + rng.integers(0, 200, size=len(pile))
+    pile["count"] = 1
+    case = dict(lens=lens, replicates=[dict(save=None, treat=np.concatenate([ev, pile]), ctrl=None)])
+    o, h, flags = _run(case, B.make_params(pq=0.01, min_auc=20.0))
+    assert flags & FELL_BACK and not flags & FUSED
+    assert flags & LOOSE  # (the general chain's tile kernel writes the sweep's bits too)
+
+
+def test_fractional_weights_go_back_to_the_general_chain_for_good():
+    lens = [300_000, 70_001]
+    ev = synth.add_multimap(synth.make_fragments(lens, 60_000, 31, peak_every=20_000, tower_every=150_000), lens, 0.3, 32)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None), dict(save=None, treat=ev[::2].copy(), ctrl=None)])
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    sh = B.run_case(h, case)
+    flags = h.path_info()
+    assert_same_run(o, h, so, sh, case)
+    assert flags & FELL_BACK and not flags & FUSED and not flags & LOOSE
+
+
+def test_tiles_without_intervals_and_unsaved_chromosomes_under_the_loose_sweep():
+    # long empty stretches (tiles whose slots k_scan_iv has to fill), a chromosome without reads, one that is
+    # not saved (its tiles hold records but no intervals), peaks that run across tile borders
+    lens = [250_000, 40_000, 90_000, 30_000]
+    rng = np.random.default_rng(4)
+    parts = []
+    for ci, centre in [(0, 4_096), (0, 8_192), (0, 200_000), (2, 45_056), (3, 12_288)]:
+        e = np.zeros(900, dtype=B.EVENT_DTYPE)
+        e["chrom"] = ci
+        e["start"] = centre - 300 + rng.integers(0, 400, size=len(e))
+        e["end"] = e["start"] + 150 + rng.integers(0, 100, size=len(e))
+        e["count"] = 1
+        parts.append(e)
+    ev = np.concatenate(parts)
+    rng.shuffle(ev)
+    for save in (None, [1, 1, 0, 1]):
+        case = dict(lens=lens, replicates=[dict(save=save, treat=ev, ctrl=None)])
+        o, h, flags = _run(case, B.make_params(pq=0.01, min_auc=20.0, max_gap=300))
+        assert flags & FUSED and flags & LOOSE
+        assert h.n_peaks >= 3
+
+
+def test_a_flat_significant_plateau_across_a_tile_without_records():
+    # one significant interval that spans a whole tile with no breakpoint in it: the tile's slot must carry the
+    # previous interval's end (k_scan_iv) for the candidate walk to see the right lengths
+    lens = [60_000]
+    e = np.zeros(40, dtype=B.EVENT_DTYPE)
+    e["start"] = 3_000
+    e["end"] = 14_000
+    e["count"] = 1
+    bg = synth.make_fragments(lens, 300, 8, uniform_only=True)
+    bg = bg[(bg["end"] < 2_500) | (bg["start"] > 20_000)]
+    case = dict(lens=lens, replicates=[dict(save=None, treat=np.concatenate([e, bg]), ctrl=None)])
+    o, h, flags = _run(case, B.make_params(pq=0.01, min_auc=20.0))
+    assert flags & FUSED and flags & LOOSE
+    assert h.n_peaks >= 1
