@@ -473,6 +473,23 @@ __device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporte
   return (int)minSig;
 }
 
+// The significance bits of one step of a tile kernel (up to 64 intervals written to consecutive loose slots from
+// `pos` on; lane's interval is the rank-th of them and significant iff sg): gathered into one 64-bit word by a
+// wave-wide sum of disjoint bits and ORed into the mask by ONE lane.  (One atomic per significant interval was the
+// first version: peaks are dense in breakpoints, a third of all intervals of config 2 are significant, and 64 lanes
+// hammering one 8-byte word serialise in the L2.)  Call with all lanes active.
+__device__ __forceinline__ void sig_flush(u64* __restrict__ sigMask, u32 pos, bool sg, u32 rank) {
+  if (!__ballot(sg)) return;  // wave-uniform
+  const int lo = sg && rank < 32u ? (int)(1u << rank) : 0, hi = sg && rank >= 32u ? (int)(1u << (rank - 32u)) : 0;
+  const u32 mlo = (u32)__builtin_amdgcn_readlane(dpp_scan_add(lo), 63), mhi = (u32)__builtin_amdgcn_readlane(dpp_scan_add(hi), 63);
+  if (lane_id() == 0) {
+    const u64 m = (u64)mlo | ((u64)mhi << 32);
+    const u32 w = pos >> 6, sh = pos & 63;
+    atomicOr((unsigned long long*)&sigMask[w], (unsigned long long)(m << sh));
+    if (sh && (m >> (64 - sh))) atomicOr((unsigned long long*)&sigMask[w + 1], (unsigned long long)(m >> (64 - sh)));
+  }
+}
+
 struct TileOut {
   u32* looseEnd;    // interval end (chromosome coordinate), loose slots
   int* looseV;      // pileup in 1/120 units

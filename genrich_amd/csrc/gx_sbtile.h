@@ -60,7 +60,7 @@ struct SbtLds {
   int netPref[SBT_TILES];                  // start keys - end keys of the bin before the tile
   u32 cur[2 * SBT_TILES];                  // scatter cursors: starts, ends
   uint4 tinfo[SBT_TILES];                  // pos0, chromosome length, TM_ flags, weight dropped by earlier chromosomes
-  unsigned long long slotPtr[2 * SBT_SLOTS];
+  u32 slotOff[2 * SBT_SLOTS];              // first key of a slot, as an index into its stream's page pool
   u32 slotCnt[2 * SBT_SLOTS];
   u32 pre[2][NXCD + 1];
   __attribute__((aligned(8))) u32 scratch[40];
@@ -177,13 +177,13 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
       const int before = after - d120;                          // the pileup of the interval that ends here (2244)
       const bool nz = d120 != 0 && active && (pos0 + p != 0);   // 2241: base 0 closes nothing
       const u64 mask = __ballot(nz);
+      const u32 orank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
       if (nz) {
-        const u32 o = slot + outCount +
-                      __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+        const u32 o = slot + outCount + orank;
         out.to.looseEnd[o] = pos0 + p;
         out.to.looseV[o] = before;
-        if (before >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[o >> 6], 1ull << (o & 63));  // rare
       }
+      if (vsig != 0x7FFFFFFF) sig_flush(out.to.sigMask, slot + outCount, nz && before >= vsig, orank);  // wave-uniform
       negM |= __ballot(after < 0);
       bigM |= __ballot(after >= FRAG_FAST_MAXV);
       runBase += __builtin_amdgcn_readlane(incS, 63);
@@ -269,17 +269,16 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
       acc += ns;
     }
     if (k == 0 && acc > SBT_SLOTS) L.overflow = 1;  // more slots than descriptors: the bin does not fit
-    unsigned long long ptr = 0;
+    u32 ptr = 0;
     u32 cnt = 0;
     if (x < NXCD) {
       const u32 off = (k - k0) * SBT_SLOT;
       const u32 jp = off >> PgCfg<u32>::SHIFT, li = x * nSeg + seg;
       const u32 page = jp ? P.pt[(size_t)li * P.jmax + jp] - 1u : first_page(li);
-      ptr = (unsigned long long)(reinterpret_cast<const u32*>(P.pool) + ((size_t)page << PgCfg<u32>::SHIFT) +
-                                 (off & ((1u << PgCfg<u32>::SHIFT) - 1u)));
+      ptr = (page << PgCfg<u32>::SHIFT) + (off & ((1u << PgCfg<u32>::SHIFT) - 1u));
       cnt = min(SBT_SLOT, pre[x + 1] - pre[x] - off);
     }
-    L.slotPtr[tid] = ptr;
+    L.slotOff[tid] = ptr;
     L.slotCnt[tid] = cnt;
   }
   // the tiles' chromosome records (thread b: tile b of the bin), in flight next to the keys
@@ -299,6 +298,8 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   __syncthreads();
   const bool ovfSlots = L.overflow != 0;
   // ---- 2: the bin's keys, all loads in flight together
+  const uint4* __restrict__ poolS = reinterpret_cast<const uint4*>(in.PS.pool);
+  const uint4* __restrict__ poolE = reinterpret_cast<const uint4*>(in.PE.pool);
   uint4 kS[SBT_K], kE[SBT_K];
   u32 cS[SBT_K], cE[SBT_K];
 #pragma unroll
@@ -309,12 +310,12 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
     kS[i] = make_uint4(0u, 0u, 0u, 0u);
-    if ((u32)lane * 4 < cS[i]) kS[i] = reinterpret_cast<const uint4*>(L.slotPtr[i * SBT_NW + wv])[lane];
+    if ((u32)lane * 4 < cS[i]) kS[i] = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
   }
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
     kE[i] = make_uint4(0u, 0u, 0u, 0u);
-    if ((u32)lane * 4 < cE[i]) kE[i] = reinterpret_cast<const uint4*>(L.slotPtr[SBT_SLOTS + i * SBT_NW + wv])[lane];
+    if ((u32)lane * 4 < cE[i]) kE[i] = poolE[(L.slotOff[SBT_SLOTS + i * SBT_NW + wv] >> 2) + lane];
   }
   if (tid < (int)nT) L.tinfo[tid] = ti;
   // ---- 3: per-tile histogram

@@ -220,13 +220,13 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
         const int before = after - d120;            // the pileup of the interval that ends at this base (2244)
         const bool nz = d120 != 0 && active && (pos0 + p != 0);  // 2241: base 0 closes nothing
         const u64 mask = __ballot(nz);
+        const u32 orank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
         if (nz) {
-          const u32 o = slot + outCount +
-                        __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+          const u32 o = slot + outCount + orank;
           out.looseEnd[o] = pos0 + p;
           out.looseV[o] = before;
-          if (before >= vsig) atomicOr((unsigned long long*)&out.sigMask[o >> 6], 1ull << (o & 63));  // rare
         }
+        if (vsig != 0x7FFFFFFF) sig_flush(out.sigMask, slot + outCount, nz && before >= vsig, orank);  // wave-uniform
         negM |= __ballot(after < 0);
         bigM |= __ballot(after >= FRAG_FAST_MAXV);
         runBase += __builtin_amdgcn_readlane(incS, 63);

@@ -127,7 +127,7 @@ def test_tiles_without_intervals_and_unsaved_chromosomes_under_the_loose_sweep()
 def test_a_flat_significant_plateau_across_a_tile_without_records():
     # one significant interval that spans a whole tile with no breakpoint in it: the tile's slot must carry the
     # previous interval's end (k_scan_iv) for the candidate walk to see the right lengths
-    lens = [60_000]
+    lens = [600_000]
     e = np.zeros(40, dtype=B.EVENT_DTYPE)
     e["start"] = 3_000
     e["end"] = 14_000
