@@ -1090,9 +1090,10 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
   hipLaunchKernelGGL((k_peak_short<Q>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,     \
                      misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),             \
                      ctx->valid.as<u32>())
-        if (S.V) {  // p from the table p(V) (`q` carries the exact pileups)
+        if (S.V) {  // p from the table p(V) (`q` carries the exact pileups); every workgroup copies the table's compact form to LDS
           const float* vq = reinterpret_cast<const float*>(S.V);
-          hipLaunchKernelGGL((k_peak_short<false, true>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, vq, S.chromOff,
+          const dim3 gridV(std::min<u32>(grid.x, (u32)(8 * ctx->numCU)));
+          hipLaunchKernelGGL((k_peak_short<false, true>), gridV, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, vq, S.chromOff,
                              nChrom, misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),
                              ctx->valid.as<u32>());
           hipLaunchKernelGGL(k_peak_walk<true>, gridW, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, vq, S.chromOff, nChrom,
@@ -1262,7 +1263,7 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   HIPCHECK(ctx->dScal.ensure(sizeof(Scalars)));
   HIPCHECK(ctx->dStatus.ensure(64));
   // p-value tables and the list of risky values: fixed sizes, built while a sample is closed
-  HIPCHECK(ctx->pvLut.ensure((size_t)PV_LUT * 4));
+  HIPCHECK(ctx->pvLut.ensure((size_t)(PV_LUT + PV_WHOLE) * 4));  // p(V), and p of the whole pileups once more (compact)
   HIPCHECK(ctx->pairLogE.ensure((size_t)PAIR_LUT * 8));
   HIPCHECK(ctx->pairCtab.ensure((size_t)PAIR_LUT * sizeof(CtrlEntry)));
   HIPCHECK(ctx->pairP2d.ensure((size_t)PT_N * PT_N * 4));

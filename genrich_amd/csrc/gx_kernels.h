@@ -453,20 +453,29 @@ struct BedIn {
 // zero-length intervals, so that the sweep walks the loose slots as they are (no k_pack_pval round trip).
 // One block of words per sample (zero arena) says whether that is valid.
 constexpr u32 PV_LUT = 1u << 18;  // entries of the table p(V)
+constexpr u32 PV_WHOLE = (PV_LUT + GX_UNIT - 1) / GX_UNIT;  // whole pileups in the table (2,185): p(120 c), compact copy
 struct LooseCtl {
-  u32 sigInv;     // max of (PV_LUT - V) over the significant table entries V (0: none)
-  u32 nonP1;      // max of (V + 1) over the others
   u32 bad;        // something forbids the loose sweep (a pileup beyond the table, a table that is not monotone)
   u32 earlyBits;  // lambda as the tile stage knew it (float bits)
   u32 enabled;    // lambda was known before the tile stage
   u32 ok;         // the verdict for the host (k_frag_select): enabled, nothing bad, lambda unchanged
-  u32 pad[2];
+  u32 pad[4];
+  // 64 slots each (k_pval_lut's wavefronts spread over them: one word would take 8,192 same-address atomics)
+  u32 sigInv[64]; // max of (PV_LUT - V) over the significant table entries V (0: none)
+  u32 nonP1[64];  // max of (V + 1) over the others
 };
-// pileups (1/120 units) from which an interval is significant; INT_MAX: the tile kernels write no bits
+// pileups (1/120 units) from which an interval is significant; INT_MAX: the tile kernels write no bits.
+// Call with whole wavefronts (every lane reads one slot).
 __device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporter) {
   if (!c || !c->enabled) return 0x7FFFFFFF;
-  const u32 minSig = PV_LUT - c->sigInv;
-  if (minSig < c->nonP1) {  // p(V) > thr is not a threshold on V: leave it to the general path
+  u32 a = c->sigInv[lane_id()], b = c->nonP1[lane_id()];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    a = max(a, (u32)__shfl_xor((int)a, d, 64));
+    b = max(b, (u32)__shfl_xor((int)b, d, 64));
+  }
+  const u32 minSig = PV_LUT - a;
+  if (minSig < b) {  // p(V) > thr is not a threshold on V: leave it to the general path
     if (reporter) atomicOr(&c->bad, 2u);
     return 0x7FFFFFFF;
   }

@@ -705,7 +705,10 @@ __global__ __launch_bounds__(256) void k_risk_apply(RiskBuf* __restrict__ rb, co
   for (u32 i = threadIdx.x; i < n; i += 256) {
     const RiskRec r = recs[i];  // (device copy of a long list, or the host's mapped pinned records)
     switch (r.kind) {
-      case RK_LUT: T.lutP[r.a] = r.pnew; break;
+      case RK_LUT:
+        T.lutP[r.a] = r.pnew;
+        if (r.a % GX_UNIT == 0) T.lutP[PV_LUT + r.a / GX_UNIT] = r.pnew;  // (the compact copy of the whole pileups)
+        break;
       case RK_TAB2D: T.p2d[r.a] = r.pnew; break;
       case RK_DEEP: {
         const u32 j = atomicAdd(&T.deep->n, 1u);

@@ -35,6 +35,11 @@
 
 namespace gx {
 
+// measurement hook (tools/build_variant.sh -DGX_EXP_SBT=n): k_sbtile stops after its loads (1), its histogram and
+// scan (2), its scatter (3) and leaves empty tiles behind -- where the kernel's time goes.  0: the product.
+#ifndef GX_EXP_SBT
+#define GX_EXP_SBT 0
+#endif
 constexpr u32 ST_SB_FULL = 1024u;  // (internal) a super-bucket does not fit k_sbtile: the host takes the general chain
 constexpr u32 ST_SB_FRAC = 2048u;  // (internal) the sample holds fractional-weight records: likewise, and for good
 
@@ -318,14 +323,34 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
     if ((u32)lane * 4 < cE[i]) kE[i] = poolE[(L.slotOff[SBT_SLOTS + i * SBT_NW + wv] >> 2) + lane];
   }
   if (tid < (int)nT) L.tinfo[tid] = ti;
+  if (GX_EXP_SBT == 1) {
+    u32 x = 0;
+#pragma unroll
+    for (int i = 0; i < SBT_K; i++) x ^= kS[i].x ^ kS[i].y ^ kS[i].z ^ kS[i].w ^ kE[i].x ^ kE[i].y ^ kE[i].z ^ kE[i].w;
+    if (x == 0xDEADBEEFu) atomicOr(st, 1u << 30);
+  }
   // ---- 3: per-tile histogram
   auto keyAt = [](const uint4& v, int j) -> u32 { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
+  // (a slot is full -- 256 keys -- unless it is the last of its list: the full ones without per-key predicates;
+  // the counts are wave-uniform)
+  if (GX_EXP_SBT != 1)
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
+    if (cS[i] == SBT_SLOT) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if ((u32)lane * 4 + j < cS[i]) atomicAdd(&L.hist[(keyAt(kS[i], j) >> TB) - segTileBase], 1u);
-      if ((u32)lane * 4 + j < cE[i]) atomicAdd(&L.hist[(keyAt(kE[i], j) >> TB) - segTileBase], 65536u);
+      for (int j = 0; j < 4; j++) atomicAdd(&L.hist[(keyAt(kS[i], j) >> TB) - segTileBase], 1u);
+    } else if (cS[i]) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if ((u32)lane * 4 + j < cS[i]) atomicAdd(&L.hist[(keyAt(kS[i], j) >> TB) - segTileBase], 1u);
+    }
+    if (cE[i] == SBT_SLOT) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) atomicAdd(&L.hist[(keyAt(kE[i], j) >> TB) - segTileBase], 65536u);
+    } else if (cE[i]) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if ((u32)lane * 4 + j < cE[i]) atomicAdd(&L.hist[(keyAt(kE[i], j) >> TB) - segTileBase], 65536u);
     }
   }
   __syncthreads();
@@ -342,9 +367,10 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
     if (tid == 0) L.startC[nT] = (u32)tot;
   }
   __syncthreads();
-  const bool ovf = ovfSlots || L.startC[nT] > SBT_KEYCAP;
+  const bool ovfReal = ovfSlots || L.startC[nT] > SBT_KEYCAP;
+  const bool ovf = ovfReal || GX_EXP_SBT == 1 || GX_EXP_SBT == 2;
   // (the slot capacity bounds a stream at 32 K keys, so a tile's 16-bit counts cannot have wrapped)
-  if (ovf && tid == 0) atomicOr(st, ST_SB_FULL);
+  if (ovfReal && tid == 0) atomicOr(st, ST_SB_FULL);
   if (seg == 0 && tid == 0 && in.sbOffF[nSeg] != 0) atomicOr(st, ST_SB_FRAC);
   // descriptors for the kernels downstream, scatter cursors
   const u32 segS = in.sbOffS[seg], segE = in.sbOffE[seg];
@@ -379,21 +405,40 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   // ---- 4: the keys to their tiles' lists in LDS; then the wavefronts take tiles from a counter
   if (tid == 0) L.work = 0;
   __syncthreads();  // the cursors are there
+  auto place = [&](u32 key, u32 curBase, u32 flag) {
+    L.keys[atomicAdd(&L.cur[curBase + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | flag);
+  };
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
+    if (cS[i] == SBT_SLOT) {
+      // (the four cursor atomics in flight together, then the four stores)
+      u32 ps[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if ((u32)lane * 4 + j < cS[i]) {
-        const u32 key = keyAt(kS[i], j);
-        L.keys[atomicAdd(&L.cur[(key >> TB) - segTileBase], 1u)] = (uint16_t)(key & (TILE - 1));
-      }
-      if ((u32)lane * 4 + j < cE[i]) {
-        const u32 key = keyAt(kE[i], j);
-        L.keys[atomicAdd(&L.cur[SBT_TILES + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | 0x8000u);
-      }
+      for (int j = 0; j < 4; j++) ps[j] = atomicAdd(&L.cur[(keyAt(kS[i], j) >> TB) - segTileBase], 1u);
+#pragma unroll
+      for (int j = 0; j < 4; j++) L.keys[ps[j]] = (uint16_t)(keyAt(kS[i], j) & (TILE - 1));
+    } else if (cS[i]) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if ((u32)lane * 4 + j < cS[i]) place(keyAt(kS[i], j), 0u, 0u);
+    }
+    if (cE[i] == SBT_SLOT) {
+      u32 ps[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) ps[j] = atomicAdd(&L.cur[SBT_TILES + (keyAt(kE[i], j) >> TB) - segTileBase], 1u);
+#pragma unroll
+      for (int j = 0; j < 4; j++) L.keys[ps[j]] = (uint16_t)((keyAt(kE[i], j) & (TILE - 1)) | 0x8000u);
+    } else if (cE[i]) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if ((u32)lane * 4 + j < cE[i]) place(keyAt(kE[i], j), (u32)SBT_TILES, 0x8000u);
     }
   }
   __syncthreads();
+  if (GX_EXP_SBT == 3) {
+    if (tid < (int)nT && segTileBase + tid < in.nTiles) out.to.tileCount[segTileBase + tid] = L.keys[L.startC[tid]] == 0xFFFFu;
+    return;
+  }
   for (;;) {
     u32 b = 0;
     if (lane == 0) b = atomicAdd(&L.work, 1u);

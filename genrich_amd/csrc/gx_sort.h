@@ -105,6 +105,10 @@ constexpr int S1_NT = GX_S1_NT;             // threads per workgroup
 #endif
 constexpr int S1_CHUNK = GX_S1_CHUNK;       // events per workgroup
 constexpr int S1_ITEMS = S1_CHUNK / S1_NT;
+#ifndef GX_S1_BATCH
+#define GX_S1_BATCH 8
+#endif
+constexpr int S1_LCHROM = 256;              // chromosome records kept in LDS (larger tables stay in global memory)
 constexpr int S1_BPT = MAX_BINS / S1_NT;    // level-1 bins owned by a thread
 static_assert(S1_CHUNK <= (1 << PgCfg<u32>::SHIFT), "a chunk's run for one bin never spans more than two pages");
 constexpr u32 S1_STAGE_BYTES = S1_CHUNK * 4;  // a round's records: S1_CHUNK keys, or S1_CHUNK / 2 F records
@@ -281,13 +285,21 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
                                                  u32 nChrom, int sbShift, u32 nBins, PagedStream PS, PagedStream PE,
                                                  PagedStream PF, Sort1Out out, u32* __restrict__ st) {
   __shared__ S1Lds L;
+  // the chromosome table in LDS when it fits (hg38: 25 records): the conversion's second, dependent round trip
+  // becomes an LDS look-up
+  __shared__ DChrom lchrom[S1_LCHROM];
+  const bool chromLds = nChrom <= (u32)S1_LCHROM;
+  if (chromLds) {
+    for (u32 i = threadIdx.x; i < nChrom; i += S1_NT) lchrom[i] = chroms[i];
+    __syncthreads();
+  }
   const u32 begin = blockIdx.x * S1_CHUNK;
   u32 bad = 0, frac = 0;
   u64 covered = 0;
   u32 ks[S1_ITEMS], ke[S1_ITEMS];
   // batches of S1_BATCH events: their loads, then their chromosomes' records, are in flight together (one event
   // after the other, each waiting for its two dependent loads, the conversion was a chain of 16 memory round trips)
-  constexpr int S1_BATCH = 4;
+  constexpr int S1_BATCH = GX_S1_BATCH;
 #pragma unroll
   for (int k0 = 0; k0 < S1_ITEMS; k0 += S1_BATCH) {
     uint4 e[S1_BATCH];
@@ -299,8 +311,13 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
       have[q] = i < n;
       e[q] = reinterpret_cast<const uint4*>(ev)[have[q] ? i : n - 1];  // chrom, start, end, count
     }
+    if (chromLds) {  // block-uniform
 #pragma unroll
-    for (int q = 0; q < S1_BATCH; q++) c[q] = chroms[min(e[q].x, nChrom - 1)];
+      for (int q = 0; q < S1_BATCH; q++) c[q] = lchrom[min(e[q].x, nChrom - 1)];
+    } else {
+#pragma unroll
+      for (int q = 0; q < S1_BATCH; q++) c[q] = chroms[min(e[q].x, nChrom - 1)];
+    }
 #pragma unroll
     for (int q = 0; q < S1_BATCH; q++) {
       const Endpoints p = convert_event<true>(e[q], c[q], have[q], nChrom, out, bad, covered);
@@ -310,9 +327,17 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
       frac |= (u32)(p.w != 0 && !unit);
     }
   }
-  if (UNIT32) {
+#ifndef GX_EXP_S1   // measurement hook (tools/build_variant.sh -DGX_EXP_S1=n): 1 no scatter at all, 2 the start keys only
+#define GX_EXP_S1 0
+#endif
+  if (GX_EXP_S1 == 1) {
+    u32 x = 0;
+#pragma unroll
+    for (int k = 0; k < S1_ITEMS; k++) x ^= ks[k] ^ ke[k];
+    if (x == 0xDEADBEEFu) atomicOr(st, 1u << 30);
+  } else if (UNIT32) {
     scatter_paged<u32, S1_ITEMS>(ks, PS, sbShift, nBins, L, st);
-    scatter_paged<u32, S1_ITEMS>(ke, PE, sbShift, nBins, L, st);
+    if (GX_EXP_S1 != 2) scatter_paged<u32, S1_ITEMS>(ke, PE, sbShift, nBins, L, st);
   }
   // fractional (or wide) records: rare, so the events are converted again (they are in L2) instead of being
   // kept in registers; two events = up to four records per thread and round

@@ -50,13 +50,14 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
     bool ng, risky = false;
     const float p = pval_of_v((int)v, lambda, ml, sl, &val, &ng, &risky);
     lutP[v] = p;
+    if (v % GX_UNIT == 0) lutP[PV_LUT + v / GX_UNIT] = p;  // the whole pileups once more, compact (the sweep's LDS copy)
     if (risky) risk_add(risk, RK_LUT, v, 0, 0, 0.0);
     if (early && ctl) {  // (the grid covers the table once: v = this wavefront's first entry + lane)
       const u64 sg = __ballot(p > thr);
       if (lane_id() == 0) {
-        const u32 v0 = v;
-        if (sg) atomicMax(&ctl->sigInv, PV_LUT - (v0 + (u32)__builtin_ctzll(sg)));
-        if (~sg) atomicMax(&ctl->nonP1, v0 + (u32)(63 - __builtin_clzll(~sg)) + 1u);
+        const u32 v0 = v, slot = (v0 >> 6) & 63u;
+        if (sg) atomicMax(&ctl->sigInv[slot], PV_LUT - (v0 + (u32)__builtin_ctzll(sg)));
+        if (~sg) atomicMax(&ctl->nonP1[slot], v0 + (u32)(63 - __builtin_clzll(~sg)) + 1u);
       }
     }
   }
@@ -1060,9 +1061,15 @@ __device__ __forceinline__ u32 row_max_u(u32 v) {
 // wavefront for ~100 us, which is what the kernel took).
 constexpr int PK_AHEAD = 4;
 // PV: `p` is the table p(V) and `q` (reinterpreted) the intervals' exact pileups V -- the sweep on the loose slots.
-__device__ __forceinline__ float p_from_v(const float* __restrict__ lut, const int* __restrict__ V, u32 i) {
-  const u32 v = (u32)V[i];
-  return lut[v < PV_LUT ? v : 0u];  // (pileups beyond the table forbid this sweep: LooseCtl::bad)
+// (that sweep only runs on unit-weight samples whose pileups all lie within the table -- LooseCtl::bad otherwise --, so
+// every V is 120 x a whole pileup below PV_WHOLE: the table's compact copy, lut + PV_LUT, sits in LDS)
+__device__ __forceinline__ void load_whole_lut(float* __restrict__ hot, const float* __restrict__ lut) {
+  for (u32 i = threadIdx.x; i < PV_WHOLE; i += blockDim.x) hot[i] = lut[PV_LUT + i];
+  __syncthreads();
+}
+__device__ __forceinline__ float p_from_v(const float* __restrict__ hot, const int* __restrict__ V, u32 i) {
+  const u32 c = __umulhi((u32)V[i], 0x88888889u) >> 6;  // V / 120
+  return hot[c < PV_WHOLE ? c : 0u];
 }
 template <bool USEQ, bool PV = false>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
 __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hdr, const u32* __restrict__ end,
@@ -1070,6 +1077,8 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
                                                     const u32* __restrict__ chromOff, u32 nChrom,
                                                     const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
                                                     gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  __shared__ float hot[PV ? PV_WHOLE : 1];
+  if (PV) load_whole_lut(hot, p);
   const u32 C = *nCands;
   const int lane = lane_id(), rowBase = lane & 48, rl = lane & 15;
   const u32 rowId = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (u32)(lane >> 4);  // 16 rows per workgroup
@@ -1097,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
         if (in[a]) {
           e[a] = end[i];
           sPrev[a] = i == i0 ? peakStart : end[i - 1];
-          if (PV) pv[a] = p_from_v(p, reinterpret_cast<const int*>(q), i);
+          if (PV) pv[a] = p_from_v(hot, reinterpret_cast<const int*>(q), i);
           else pv[a] = p[i];
           if (USEQ) qv[a] = q[i];
         }
@@ -1160,6 +1169,8 @@ __global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr
                                                    float thr, float minAUC, int minLen,
                                                    gx_peak* __restrict__ cand, u32* __restrict__ valid) {
   const float* __restrict__ q = PV ? nullptr : qIn;
+  __shared__ float hot[PV ? PV_WHOLE : 1];
+  if (PV) load_whole_lut(hot, p);
   const u32 L = *nLong;
   const u32 wavesPerGrid = gridDim.x * 4;
   const int lane = lane_id();
@@ -1182,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr
         if (in[a]) {
           e[a] = end[i];
           sPrev[a] = i == i0 ? peakStart : end[i - 1];
-          if (PV) pv[a] = p_from_v(p, reinterpret_cast<const int*>(qIn), i);
+          if (PV) pv[a] = p_from_v(hot, reinterpret_cast<const int*>(qIn), i);
           else pv[a] = p[i];
           if (q) qv[a] = q[i];
         }
