@@ -506,15 +506,16 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     const size_t curBytes = up((size_t)NXCD * nL1 * 4 + 64);          // cursors + (last word) pages handed out
     const size_t ptBytes = up((size_t)NXCD * nL1 * jmax * 4);
     const size_t lbTBytes = up((size_t)3 * (tChunks + 2) * 8), lbIBytes = up((size_t)(2 * tChunks + 4) * 8);
-    const size_t total = ffBytes + 256 + 256 + endBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
+    const size_t ctlBytes = up(sizeof(LooseCtl));
+    const size_t total = ffBytes + 256 + ctlBytes + endBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
     HIPCHECK(ctx->zeroArena.ensure(total));
     char* base = ctx->zeroArena.as<char>();
     ctx->fragSum.view(base, ffBytes);
     base += ffBytes;
     ctx->nWide.view(base, 256);
     base += 256;
-    ctx->looseCtl.view(base, 256);
-    base += 256;
+    ctx->looseCtl.view(base, ctlBytes);
+    base += ctlBytes;
     ctx->endAtLen.view(base, endBytes);
     base += endBytes;
     for (int q = 0; q < 3; q++) {
