@@ -51,7 +51,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 CONFIGS = {
     2: dict(name="configs[1]", desc="treatment only, -p 0.01", qval=False, control=False, atac=False, multimap=False, reps=1,
             gate_chroms=25),
-    3: dict(name="configs[2]", desc="treatment + 50M-fragment uniform control, -q 0.05", qval=True, control=True, atac=False,
+    3: dict(name="configs[2]", desc="treatment (peaks every 200 kb) + 50M-fragment uniform control, -q 0.05", qval=True, control=True, atac=False,
             multimap=False, reps=1, gate_chroms=8),
     4: dict(name="configs[3]", desc="ATAC -j -d 100 cut-site intervals, 10 % of fragments multimapped (-s weights 1/k), -p 0.01",
             qval=False, control=False, atac=True, multimap=True, reps=1, gate_chroms=12),
@@ -76,7 +76,10 @@ def build_workload(cfg, frags, lens):
     seeds = [1, 3, 5, 7, 9][:cfg["reps"]]
     for sd in seeds:
         # with a control the treatment needs towers whose q survives the genome-wide correction
-        tv = synth.make_fragments(lens, frags, seed=sd, tower_every=50_000_000 if cfg["control"] else 5_000_000)
+        # (and peaks of ~1,000 fragments every 200 kb instead of ~250 every 50 kb, so that > 10^4 peaks stay significant
+        # at -q 0.05, not only the towers: round 2's stream left the q-mode sweep 33 peaks to work on)
+        tv = (synth.make_fragments(lens, frags, seed=sd, peak_every=200_000, tower_every=50_000_000) if cfg["control"]
+              else synth.make_fragments(lens, frags, seed=sd))
         if cfg["multimap"]:
             tv = synth.add_multimap(tv, lens, 0.10, seed=sd + 10)
         if cfg["atac"]:
@@ -175,6 +178,70 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device):
     return gate, cpu
 
 
+KERNEL_PHASE = {  # which library phase (gx_set_phase_filter) brackets a kernel
+    "k_sort1": "sort1", "k_sbtile": "tile", "k_tile_fast": "tile", "k_tile": "tile", "k_bucket2p": "bucket",
+    "k_pack_pval": "pval", "k_pack_pairs": "pval", "k_pack_pairs_full": "pval", "k_merge2": "merge", "k_mergeN": "fisher",
+    "k_pack_ep": "fisher", "k_bh_hist": "bh", "k_qlookup": "bh", "k_peak_both": "sweep",
+}
+
+
+def load_profile(config, frags, world, plain):
+    """The rocprofv3 counters of THIS build for this config (tools/profile_round.sh + tools/make_counters_json.py):
+    accepted only when the hash of the kernel sources matches and the workload is the profiled one."""
+    ppath = os.path.join(ROOT, "profiles", f"r03_counters_config{config}.json")
+    if not os.path.exists(ppath):
+        return None
+    prof = json.load(open(ppath))
+    if prof.get("source_hash") != source_hash() or world != 1 or frags != 50_000_000 or not plain:
+        return None
+    return prof
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
+def reference_e2e(lens, reps, max_frags=1_500_000):
+    """SAM text -> narrowPeak through the REFERENCE binary built by oracle/Makefile (oracle/_ref/Genrich; it travels
+    with the repo), one thread, on a bounded sample: BASELINE.md section 4's end-to-end CPU figure."""
+    import subprocess
+    ref = os.path.join(ROOT, "oracle", "_ref", "Genrich")
+    if not os.path.exists(ref):
+        return None
+    sel = [18, 19, 20, 21]  # chr19..chr22 (220 Mbp): a genome the reference's per-base arrays fill in seconds
+    tv = reps[0][0]
+    tv = tv[np.isin(tv["chrom"], sel)][:max_frags].copy()
+    remap = {c: i for i, c in enumerate(sel)}
+    tv["chrom"] = np.array([remap[c] for c in tv["chrom"]], dtype=np.uint32)
+    names = [synth.HG38_NAMES[c] for c in sel]
+    slens = [lens[c] for c in sel]
+    td = tempfile.mkdtemp()
+    sam, outp = os.path.join(td, "t.sam"), os.path.join(td, "o.narrowPeak")
+    synth.write_sam(sam, names, slens, tv)
+    nrec = 2 * len(tv)
+    t0 = time.perf_counter()
+    rc = subprocess.call([ref, "-t", sam, "-o", outp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dt = time.perf_counter() - t0
+    for f in (sam, outp):
+        if os.path.exists(f):
+            os.remove(f)
+    os.rmdir(td)
+    if rc != 0:
+        return None
+    return {"kind": "reference", "seconds": dt, "sam_records": nrec, "records_per_s": nrec / dt,
+            "gbases_per_s": sum(slens) / dt / 1e9,
+            "sample": f"oracle/_ref/Genrich -t (SAM text, {nrec} records = {len(tv)} fragments of the workload on chr19-chr22, "
+                      f"{sum(slens)/1e6:.0f} Mbp) -> narrowPeak, one thread, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,9 +253,10 @@ def main():
     ap.add_argument("--control", action="store_true", help="add a uniform control (on top of --config)")
     ap.add_argument("--lean", action="store_true",
                     help="do not materialise the pileup floats of the intervals (gx_set_keep_pileups(0))")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the gate + cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the gate + cpu_baseline leg (and the other configs)")
     ap.add_argument("--cpu-chroms", type=int, default=0, help="gate / cpu_baseline on the first K chromosomes (0: per config)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D / end-to-end-from-pinned figures")
+    ap.add_argument("--no-others", action="store_true", help="headline config only (default: configs 3, 4, 5 ride along, 3 steps each)")
     args = ap.parse_args()
     # The JSON line must be the only thing on stdout: libraries below Python (RCCL prints a version banner
     # through C stdio, flushed at exit) write to file descriptor 1, so the real stdout is put aside and
@@ -196,9 +264,6 @@ def main():
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    cfg = dict(CONFIGS[args.config])
-    cfg["qval"] = cfg["qval"] or args.qval
-    cfg["control"] = cfg["control"] or args.control
 
     import torch
     import torch.distributed as dist
@@ -226,7 +291,43 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+    env = dict(torch=torch, dist=dist, rank=rank, world=world, local_dev=local_dev, dev=dev, cdev=cdev, backend=backend, ndev=ndev)
 
+    cfg = dict(CONFIGS[args.config])
+    plain = not (args.qval or args.control)
+    if args.qval and not cfg["qval"]:
+        cfg["desc"] = cfg["desc"].replace("-p 0.01", "-q 0.05")
+    if args.control and not cfg["control"]:
+        cfg["desc"] = cfg["desc"].replace("treatment only", "treatment + 50M-fragment uniform control")
+    cfg["qval"] = cfg["qval"] or args.qval
+    cfg["control"] = cfg["control"] or args.control
+    out = bench_one(args.config, cfg, args, env, steps=args.steps, warmup=args.warmup, plain=plain,
+                    want_e2e=not args.no_e2e, want_cpu=not args.no_cpu, headline=True)
+    if rank == 0 and world == 1 and args.config == 2 and plain and not args.no_cpu and not args.no_others:
+        # BASELINE.json's other GPU configs in the same line (the driver runs bench.py once, with defaults)
+        others = {}
+        for c in (3, 4, 5):
+            try:
+                r = bench_one(c, dict(CONFIGS[c]), args, env, steps=3, warmup=1, plain=True, want_e2e=False, want_cpu=True,
+                              headline=False)
+                others[str(c)] = {k: r[k] for k in ("ms_per_step", "value", "unit", "steps", "gate", "phases_ms") if k in r}
+                others[str(c)]["workload"] = r["config"]["workload"]
+                others[str(c)]["whole_step"] = r["roofline"]["whole_step"]
+                others[str(c)]["dominant"] = {k: r["roofline"].get(k) for k in ("kernel", "frac", "achieved", "launch_ms", "traffic")}
+                others[str(c)]["cpu_baseline"] = r.get("cpu_baseline")
+            except Exception as e:  # noqa: BLE001  (the headline must still be printed)
+                others[str(c)] = {"error": repr(e)}
+        out["other_configs"] = others
+    if rank == 0:
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, headline):
+    torch, dist = env["torch"], env["dist"]
+    rank, world, local_dev, dev, cdev, backend, ndev = (env[k] for k in ("rank", "world", "local_dev", "dev", "cdev", "backend", "ndev"))
     lens = synth.HG38_LENS
     G = int(sum(lens))
     reps_all = build_workload(cfg, args.frags, lens)
@@ -288,6 +389,7 @@ def main():
             coll = Collectives(device=cdev)
             gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
             coll_kind = f"host callbacks over torch.distributed/{backend} (validation mode)"
+    rccl_nranks = gx.rccl_nranks()
 
     def step(dreps=d_reps):
         gx.reset()
@@ -316,25 +418,34 @@ def main():
         for name, ms in seen.items():
             acc.setdefault(name, []).append(ms)
 
-    # Inside the timed region only the tile stage is bracketed by HIP events (the roofline's live duration): an event
-    # record costs the stream a ~5 us bubble, so the other phases are timed in two extra, untimed steps afterwards.
-    gx.set_phase_timing(1)
-    for _ in range(args.warmup):
+    # The roofline's kernel = the longest kernel of this build's rocprofv3 profile of this config (k_sort1 at config 2);
+    # without a matching profile, the tile stage.  Inside the timed region only THAT kernel's phase is bracketed by HIP
+    # events on the library's stream (an event record costs the stream a ~5 us bubble); all phases are timed in two extra,
+    # untimed steps afterwards.
+    prof = load_profile(config, args.frags, world, plain)
+    dom = prof.get("dominant", {}).get("kernel") if prof else None
+    dom_phase = KERNEL_PHASE.get(dom, "tile")
+    if dom not in KERNEL_PHASE:
+        dom = None
+    gx.set_phase_filter(dom_phase)
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
     phase_acc = {}
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = step()
         collect(phase_acc)
     barrier()
     dt = time.perf_counter() - t0
+    path_flags = gx.path_info()
     gx.set_phase_timing(2)
     all_phases = {}
     for _ in range(2):
         step()
         collect(all_phases)
-    gx.set_phase_timing(1)
+    gx.set_phase_timing(0)
+    peaks_local = gx.get_peaks()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -342,63 +453,79 @@ def main():
         npk = torch.tensor([res[0]], dtype=torch.int64, device=cdev)
         dist.all_reduce(npk)
         n_peaks = int(npk.item())
+        nr = torch.tensor([rccl_nranks], dtype=torch.int64, device=cdev)
+        dist.all_reduce(nr, op=dist.ReduceOp.MIN)
+        rccl_nranks = int(nr.item())
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(peaks_local, gathered, dst=0)
     else:
         n_peaks = res[0]
+        gathered = [peaks_local]
 
+    out = None
     if rank == 0:
-        step_s = dt / args.steps
+        step_s = dt / steps
         phases = {k: float(np.mean(v)) for k, v in all_phases.items()}       # untimed steps, every phase
-        phases.update({k: float(np.mean(v)) for k, v in phase_acc.items()})  # the tile stage: live, timed region
+        phases.update({k: float(np.mean(v)) for k, v in phase_acc.items()})  # the roofline kernel's phase: live, timed region
         n_rep = len(reps_all)
         iv0 = float(gx.interval_total())
         ev_n = float(sum(d_tv.shape[0] + (0 if d_cv is None else d_cv.shape[0]) for d_tv, d_cv in d_reps))
-        # ---- roofline of the dominant kernel (k_tile: LDS difference slices -> run-length pileup) -------------
-        # compulsory HBM bytes of the sparse formulation, per launch: 2 B per endpoint record in (two per event),
-        # a 48 B descriptor per tile, 8 B per interval out + 8 B of per-tile counts
         n_tiles = sum((l + 4095) // 4096 for l, o in zip(lens, owner) if o == 0)
-        launches = n_rep * (2 if cfg["control"] else 1)   # k_tile runs once per sample (its narrow + wide launch pair)
+        launches = n_rep * (2 if cfg["control"] else 1)   # sort / tile kernels run once per sample
         # (the library's phase timers cover the last replicate of a step and gx_find_peaks)
-        tile_ms = (phases.get("t.tile", 0.0) + phases.get("c.tile", 0.0)) / (2 if cfg["control"] else 1)
-        prof = None
-        ppath = os.path.join(ROOT, "profiles", f"r02_counters_config{args.config}.json")
-        if os.path.exists(ppath):
-            prof = json.load(open(ppath))
-            if prof.get("source_hash") != source_hash() or world != 1 or args.frags != 50_000_000 or args.qval or args.control:
-                prof = None  # counters of another build / another workload are not this run's
-        # (the tile stage = k_tile_fast, one launch per sample; k_tile only exists in -E runs)
-        traffic = (sum(prof["kernels"].get(k, {}).get("hbm_bytes_per_step", 0.0) for k in ("k_tile_fast", "k_tile")) / launches
-                   if prof else None)
-        alg_tile = (2.0 * 2.0 * ev_n + 8.0 * (iv0 if launches == 1 else 2.0 * ev_n)) / launches + 56.0 * n_tiles
-        used = traffic if traffic else alg_tile
-        achieved = used / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
-        # whole step: events in + final interval table (end, p[, pileup]) + sweep masks out
-        alg_step = 16.0 * ev_n + (12.0 if not args.lean else 8.0) * iv0 + 3.0 * iv0 / 8.0
+        per_sample = dom_phase in ("sort1", "tile", "bucket")
+        live_ms = sum(phases.get(pfx + dom_phase, 0.0) for pfx in (("t.", "c.") if per_sample else ("",)))
+        if per_sample and cfg["control"]:
+            live_ms /= 2
+        kname = dom or ("k_sbtile" if path_flags & 1 else "k_tile_fast")
+        kprof = prof["kernels"].get(kname) if prof else None
+        klaunch = max(1.0, kprof.get("launches_per_step", 1.0)) if kprof else float(launches)
+        traffic = kprof["hbm_bytes_per_step"] / klaunch if kprof and kprof.get("hbm_bytes_per_step") else None
+        # compulsory HBM bytes of the sparse formulation, per launch:
+        #   k_sort1: 16 B per event in, 4 B per endpoint key out (two per event)
+        #   tile stage: 4 B per key in (k_sbtile reads level 1's pages; k_tile_fast 2 B offsets), 8 B per interval out,
+        #               56 B of descriptors / counts per tile
+        ev_launch = ev_n / launches
+        if dom_phase == "sort1":
+            alg_k = 16.0 * ev_launch + 8.0 * ev_launch
+        else:
+            alg_k = (4.0 if path_flags & 1 else 2.0) * 2.0 * ev_launch + 8.0 * (iv0 if launches == 1 else 2.0 * ev_launch) + 56.0 * n_tiles
+        used = traffic if traffic else alg_k
+        achieved = used / (live_ms * 1e-3) / 1e9 if live_ms > 0 else 0.0
+        # whole step: events in + final interval table (end, p[, pileup]) + sweep masks out; the loose-slot sweep of a
+        # single sample with -p leaves (end, V) in the tile stage's slots and makes no second table
+        loose = bool(path_flags & 2)
+        alg_step = 16.0 * ev_n + (8.0 if loose else (12.0 if not args.lean else 8.0)) * iv0 + (2.0 if loose else 3.0) * iv0 / 8.0
+        whole_traffic = prof["whole_step"]["hbm_bytes_per_step"] if prof else None
         roof = {
-            "bound": "hbm", "kernel": "k_tile_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": tile_ms,
-            "algorithmic_bytes": alg_tile,
-            "traffic_over_algorithmic": (traffic / alg_tile) if traffic else None,
+            "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": live_ms / (klaunch if dom_phase not in ("sort1", "tile", "bucket") else 1.0),
+            "algorithmic_bytes": alg_k,
+            "traffic_over_algorithmic": (traffic / alg_k) if traffic else None,
+            "profile": f"profiles/r03_counters_config{config}.json" if prof else None,
             "whole_step": {
                 "ms": step_s * 1e3,
                 "algorithmic_bytes": alg_step,
-                "traffic": prof["whole_step"]["hbm_bytes_per_step"] if prof else None,
-                "frac_of_peak": ((prof["whole_step"]["hbm_bytes_per_step"] if prof else alg_step) / step_s / 1e9) / HBM_PEAK_GBS,
-                "traffic_over_algorithmic": (prof["whole_step"]["hbm_bytes_per_step"] / alg_step) if prof else None,
+                "traffic": whole_traffic,
+                "frac_of_peak": ((whole_traffic if whole_traffic else alg_step) / step_s / 1e9) / HBM_PEAK_GBS,
+                "traffic_over_algorithmic": (whole_traffic / alg_step) if whole_traffic else None,
             },
             "issue": prof.get("issue") if prof else None,
             "dense_model": {"bytes": 8.0 * G + 16.0 * ev_n + 52.0 * iv0,
                             "note": "SURVEY 8(d)'s dense int32-array model; the array lives in LDS here, so this is not HBM traffic"},
-            "note": "achieved = HBM bytes the tile stage moves per sample (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of this build, "
-                    "profiles/r02_counters_config*.json; the sparse formulation's compulsory bytes when no counter file matches "
-                    "this build) / its mean duration (HIP events on the library's stream); frac <= 1 by construction",
+            "note": "kernel = the longest kernel of this build's rocprofv3 profile of this config (profiles/); achieved = the HBM bytes "
+                    "it moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of that profile; the sparse formulation's compulsory bytes when "
+                    "no profile matches this build) / its mean duration measured here (HIP events on the library's stream, inside the "
+                    "timed region); frac <= 1 by construction",
         }
+        qdesc = cfg["desc"]
         out = {
             "metric": "genome bases p-scored/sec, hg38 50M frags",
             "value": n_rep * G / step_s / 1e9,
             "unit": "Gbases/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
+            "warmup": warmup,
             "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
@@ -406,11 +533,14 @@ def main():
             "dtype": "int32 pileup (1/120 units) + f64 p-values",
             "data": "synthetic",
             "config": {
-                "workload": f"hg38 25 contigs ({G} bp), {args.frags} paired fragments x {n_rep} replicate(s), {cfg['desc']} "
-                            f"(BASELINE.json {cfg['name']})",
+                "workload": f"hg38 25 contigs ({G} bp), {args.frags} paired fragments x {n_rep} replicate(s), {qdesc} "
+                            f"(BASELINE.json {cfg['name']}{'' if plain else ', modified by --qval / --control'})",
                 "parallelism": f"chromosome-sharded x{world}"
                                + ("" if backend == "nccl" or world == 1 else f" ({backend} validation mode, {ndev} GPU(s))"),
                 "collectives": coll_kind,
+                "rccl_nranks": rccl_nranks,
+                "device_path": {"fused_sort_tile_kernel": bool(path_flags & 1), "sweep_on_loose_slots": loose,
+                                "fell_back_to_general_chain": bool(path_flags & 4)},
                 "peaks": n_peaks,
                 "intervals": int(iv0),
                 "events_per_step": int(ev_n),
@@ -419,10 +549,10 @@ def main():
             },
             "roofline": roof,
             "phases_ms": phases,
-            "phases_note": "t.tile / c.tile: HIP events inside the timed region; the other phases: two extra untimed steps "
-                           "(an event record costs the stream ~5 us, so the timed steps carry only the tile stage's pair)",
+            "phases_note": f"{dom_phase}: HIP events inside the timed region; the other phases: two extra untimed steps "
+                           "(an event record costs the stream ~5 us, so the timed steps carry only the roofline kernel's pair)",
         }
-        if world == 1 and not args.no_e2e:
+        if world == 1 and want_e2e:
             # PCIe upload of the events from pinned host memory, and a step that starts there (gx_push_events)
             pin = [(torch.from_numpy(tv.view(np.uint32).reshape(-1, 4)).pin_memory(),
                     None if cv is None else torch.from_numpy(cv.view(np.uint32).reshape(-1, 4)).pin_memory()) for tv, cv in reps_all]
@@ -467,15 +597,50 @@ def main():
             out["e2e_from_pinned"] = {"ms_per_step": e2e_ms, "value": n_rep * G / (e2e_ms * 1e-3) / 1e9, "unit": "Gbases/s",
                                       "note": "gx_push_events_pinned: 64 MiB pieces uploaded on a side stream, the first kernel "
                                               "(k_sort1) starts on the pieces that have arrived -> peak list on the host"}
-        if not args.no_cpu and world == 1:
+            del pin
+    # the timed context and its device arrays go before the gate's (and the next config's) are made
+    gx.close()
+    del d_reps
+    torch.cuda.empty_cache()
+    if rank == 0 and want_cpu:
+        if world == 1:
             k = args.cpu_chroms or cfg["gate_chroms"]
             gate, cpu = gate_and_cpu_baseline(cfg, lens, reps_all, min(k, len(lens)), cfg["qval"], local_dev)
-            out["gate"] = gate
-            out["cpu_baseline"] = cpu
-        real_stdout.write(json.dumps(out) + "\n")
-        real_stdout.flush()
-    if world > 1:
-        dist.destroy_process_group()
+        else:
+            # N ranks: the ranks' peak lists, merged in chromosome order, against the oracle's list for the whole workload
+            gate, cpu = gate_merged_peaks(cfg, lens, reps_all, gathered, cfg["qval"])
+        model, ncpu = cpu_info()
+        cpu["cpu_model"], cpu["nproc"] = model, ncpu
+        if headline:
+            cpu["end_to_end"] = reference_e2e(lens, reps_all)
+        out["gate"] = gate
+        out["cpu_baseline"] = cpu
+    return out
+
+
+def gate_merged_peaks(cfg, lens, reps, gathered, qval):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import backends as B
+
+    par = B.make_params(pq=0.05 if qval else 0.01, qval=qval)
+    o = B.Oracle(par)
+    dt = run_backend(o, lens, reps)
+    want = o.get_peaks()
+    got = np.concatenate([g for g in gathered if g is not None and len(g)]) if any(len(g) for g in gathered) else want[:0]
+    got = got[np.lexsort((got["start"], got["chrom"]))]
+    same = len(got) == len(want) and got.tobytes() == want.tobytes()
+    ndiff = 0 if same else max(1, abs(len(got) - len(want)) + int(sum(1 for a, b in zip(got, want) if a.tobytes() != b.tobytes())))
+    bases = float(sum(lens)) * len(reps)
+    n_ev = int(sum(len(t) + (0 if c is None else len(c)) for t, c in reps))
+    gate = dict(narrowpeak_diff=ndiff, peaks_oracle=int(len(want)), peaks_hip=int(len(got)), passed=bool(same),
+                note="the ranks' peak records gathered to rank 0 and merged in chromosome order, compared field by field "
+                     "(chrom, start, end, summit, AUC / p / q bits) with the oracle's list for the whole workload: the narrowPeak "
+                     "text is a function of exactly these records")
+    cpu = dict(value=bases / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
+               sample=f"the whole workload ({sum(lens)/1e6:.0f} Mbp x {len(reps)} replicate(s), {n_ev} events), events in memory -> "
+                      f"peaks, {dt:.1f} s")
+    o.close()
+    return gate, cpu
 
 
 if __name__ == "__main__":

@@ -218,6 +218,7 @@ struct gx_ctx {
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
   DevBuf dColl, dCounts, dGather;
   int phaseLevel = 0;       // gx_set_phase_timing
+  std::string phaseFilter = "tile";  // level 1: the one phase that is timed (gx_set_phase_filter)
   u32 mailSeq = 0;          // mail_sync: the sequence number the next k_mail writes
   u32 statusSeen = 1;       // status bits read back since the device word was last cleared (1: not cleared yet)
   u64 runCap = 0, runSeen = 0;  // run_sweep: runs its arrays are sized for; runs of the last sweep
@@ -286,7 +287,10 @@ int dbg_sync(gx_ctx* ctx, const char* what) {
 // phase timers: the event pairs are created once and reused run after run
 // (an event record costs a ~5 us bubble on the stream: gx_set_phase_timing chooses none / the tile stage / all)
 static bool phase_wanted(const gx_ctx* ctx, const char* name) {
-  return ctx->phaseLevel >= 2 || (ctx->phaseLevel == 1 && name[1] == '.' && strcmp(name + 2, "tile") == 0);
+  if (ctx->phaseLevel >= 2) return true;
+  if (ctx->phaseLevel != 1) return false;
+  const char* base = name[0] && name[1] == '.' ? name + 2 : name;  // "t.tile" / "c.tile" -> "tile"
+  return ctx->phaseFilter == base;
 }
 void phase_begin(gx_ctx* ctx, const char* name) {
   ctx->phaseOpen = phase_wanted(ctx, name);
@@ -717,7 +721,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   phase_begin(ctx, isCtrl ? "c.pack" : "t.pack");
   const u32 ivChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
   IvScanOut so{out.tileIvOff.as<u32>(), ctx->tilePrevEnd.as<u32>(), out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV,
-               ctx->tileSlot.as<u32>(), ctx->chromLooseOff.as<u32>(), ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctl};
+               ctx->tileSlot.as<u32>(), ctx->chromLooseOff.as<u32>(), ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctl,
+               ctx->tileDeep.as<u32>(), ff, ctx->fragList.as<u32>()};
   hipLaunchKernelGGL(k_scan_iv, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
                      ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
                      ctx->dChrom.as<DChrom>(), nTiles, ctx->lbIv.as<u64>(), ctx->lbIv.as<u64>() + ivChunks + 1, so,
@@ -729,8 +734,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     const TileMeta* tm = ctx->tileMeta.as<TileMeta>();
     const u32* tOff = out.tileIvOff.as<u32>();
     const u32* tPrev = ctx->tilePrevEnd.as<u32>();
-    hipLaunchKernelGGL(k_frag_fix1, dim3((nTiles + 255) / 256), dim3(256), 0, s, lE, lV, tm, tOff, tPrev,
-                       ctx->tileDeep.as<u32>(), nTiles, ff, ctx->fragList.as<u32>());
+    // (k_frag_fix1's pass over the tiles -- deep-tile list, long first intervals -- rides in k_scan_iv)
     hipLaunchKernelGGL(k_frag_walk, dim3(std::max(1u, std::min((nTiles + 3) / 4, 4096u))), dim3(256), 0, s, lE, lV, tm, tOff,
                        tPrev, nTiles, ff, ctx->fragList.as<u32>(), acc);
     // (single thread: chromosome offsets of the chromosomes without tiles, closed form -> accumulator pair,
@@ -1087,26 +1091,19 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
       {
         const dim3 grid(std::max(1u, std::min((cap + 15) / 16, 16384u)));  // 16 candidates per workgroup and round
         const dim3 gridW(std::max(1u, std::min((cap + 3) / 4, (u32)(8 * ctx->numCU))));
-#define GX_LAUNCH_PEAK_SHORT(Q)                                                                                          \
-  hipLaunchKernelGGL((k_peak_short<Q>), grid, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,     \
-                     misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),             \
-                     ctx->valid.as<u32>())
+// (k_peak_both: the short candidates' workgroups first, the long candidates' behind them, one launch)
+#define GX_LAUNCH_PEAKS(Q, V, NSHORT, QPTR)                                                                               \
+  hipLaunchKernelGGL((k_peak_both<Q, V>), dim3((NSHORT) + gridW.x), dim3(256), 0, s, (u32)(NSHORT), ctx->candHdr.as<uint4>(), \
+                     S.end, S.p, QPTR, S.chromOff, nChrom, misc + M_NHEADS, ctx->longList.as<u32>(), misc + M_TICKET3,       \
+                     ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>())
         if (S.V) {  // p from the table p(V) (`q` carries the exact pileups); every workgroup copies the table's compact form to LDS
-          const float* vq = reinterpret_cast<const float*>(S.V);
-          const dim3 gridV(std::min<u32>(grid.x, (u32)(8 * ctx->numCU)));
-          hipLaunchKernelGGL((k_peak_short<false, true>), gridV, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, vq, S.chromOff,
-                             nChrom, misc + M_NHEADS, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),
-                             ctx->valid.as<u32>());
-          hipLaunchKernelGGL(k_peak_walk<true>, gridW, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, vq, S.chromOff, nChrom,
-                             ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
-                             ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
-        } else {
-        if (S.q) GX_LAUNCH_PEAK_SHORT(true); else GX_LAUNCH_PEAK_SHORT(false);
-        hipLaunchKernelGGL(k_peak_walk<false>, gridW, dim3(256), 0, s, ctx->candHdr.as<uint4>(), S.end, S.p, S.q, S.chromOff, nChrom,
-                           ctx->longList.as<u32>(), misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len,
-                           ctx->cand.as<gx_peak>(), ctx->valid.as<u32>());
-        }
-#undef GX_LAUNCH_PEAK_SHORT
+          const u32 nShortV = std::min<u32>(grid.x, (u32)(8 * ctx->numCU));
+          GX_LAUNCH_PEAKS(false, true, nShortV, reinterpret_cast<const float*>(S.V));
+        } else if (S.q)
+          GX_LAUNCH_PEAKS(true, false, grid.x, S.q);
+        else
+          GX_LAUNCH_PEAKS(false, false, grid.x, S.q);
+#undef GX_LAUNCH_PEAKS
       }
       // candidates C <= R: chunk arrays sized by the run capacity; kernels bound themselves by *nCands
       hipLaunchKernelGGL(k_peaks_count, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
@@ -2163,6 +2160,23 @@ int gx_total_intervals(gx_ctx* ctx, int which, size_t* n_iv) {
   int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
   if (w < 0 || w >= (int)ctx->reps.size()) return GX_ERR_ORDER;
   *n_iv = ctx->reps[w].n;
+  return GX_OK;
+}
+
+int gx_set_phase_filter(gx_ctx* ctx, const char* name) {
+  if (!ctx || !name) return GX_ERR_ORDER;
+  ctx->phaseFilter = name;
+  ctx->phaseLevel = 1;
+  return GX_OK;
+}
+
+int gx_rccl_nranks(gx_ctx* ctx, int* n) {
+  if (!ctx || !n) return GX_ERR_ORDER;
+  *n = 0;
+  if (ctx->comm) {
+    const gxrccl::Api* api = gxrccl::load(nullptr);
+    if (api && api->commCount && api->commCount(ctx->comm, n) != ncclSuccess) *n = 0;
+  }
   return GX_OK;
 }
 

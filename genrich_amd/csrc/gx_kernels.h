@@ -934,6 +934,33 @@ __global__ __launch_bounds__(256) void k_hot_check(TileIn in, const u32* __restr
   }
 }
 
+// fragLen.  savePileupExpt adds (float)len * val per interval into a double.  With unit weights
+// only (no fractional records, no -E regions) val is an integer, and a product below 2^24 is
+// exact, so the sum over such intervals is the number of covered (base, fragment) pairs: the sum
+// of the clamped fragment lengths, which k_convert accumulates for free ("closed form").  Only
+// intervals with len * val >= 2^24 can round, and they are easy to find:
+//   * val >= 2^24 / (2 TILE): k_tile marks the tiles in which the pileup gets that deep;
+//   * otherwise len >= 2 TILE: the interval starts before its tile does, so it is the tile's first.
+// k_scan_iv looks at every other tile's first interval (and lists the deep tiles), k_frag_walk walks
+// the listed ones; both add (rounded product - exact product), an integer, to a correction.
+// Everything else (fractional weights, -E, wide records) takes k_frag_walk's general path, which
+// walks every interval and accumulates exactly in (integer, fraction * 2^27) form.
+struct FragFix {
+  u64 fragSum[FRAG_SLOTS];  // closed form partial sums
+  u32 slow;                 // general path wanted
+  u32 nList;
+  long long corr;
+  u32 nF;                   // fractional records appended by k_convert (not fragLen's, but zeroed with it)
+  u32 pad_;
+};
+
+__device__ __forceinline__ long long frag_corr(u32 len, int v) {
+  if (v <= 0) return 0;  // V_MARK never occurs on this path
+  const u32 cnt = (u32)v / GX_UNIT;
+  const float term = (float)len * (float)cnt;  // what getval returns for a whole pileup
+  return (long long)term - (long long)((u64)len * cnt);
+}
+
 // tile interval counts -> tight offsets (sum scan) and, per tile, the end of the last interval
 // that precedes it on the same chromosome (max scan over (chromosome, end) keys).  Persistent
 // multi-workgroup chained scan, 2048 tiles per item; also fills chromIvOff for tiled
@@ -996,6 +1023,12 @@ struct IvScanOut {
   u32* looseEnd;
   int* looseV;
   LooseCtl* ctl;
+  // fragLen's correction terms (what k_frag_fix1 did in a launch of its own): the deep tiles go on a list, and of
+  // every other tile the first interval is looked at when it can be 2 tiles long -- only when the tile before holds
+  // no interval at all
+  const u32* tileDeep;
+  FragFix* ff;
+  u32* fragList;
 };
 
 __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
@@ -1006,6 +1039,7 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
   __shared__ u64 s64[8];
   __shared__ u64 s_sum, s_max;
   const u32 nChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  const bool slowFrag = out.ff->slow != 0;
   for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
     const u32 tb = id * STL_CHUNK + threadIdx.x * STL_ITEMS;
     u32 c[STL_ITEMS];
@@ -1064,6 +1098,22 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
         out.tileIvOff[t] = cex;
         const u32 prevEnd = (u32)(kex >> 32) == ci + 1 ? (u32)kex : 0u;
         out.tilePrevEnd[t] = prevEnd;
+        if (c[k]) {
+          if (out.tileDeep[t])
+            out.fragList[atomicAdd(&out.ff->nList, 1u)] = t;
+          else if (!slowFrag) {
+            // the tile's first interval ends inside the tile: it is >= 2 TILE long only if it starts a whole tile earlier
+            const u32 pos0 = (t - chroms[ci].tileBase) << TB;
+            if (pos0 >= (u32)TILE && prevEnd <= pos0 - (u32)TILE) {
+              const u32 slot = out.tileSlot[t];
+              const u32 len = out.looseEnd[slot] - prevEnd;
+              if (len >= 2u * TILE) {
+                const long long cc = frag_corr(len, out.looseV[slot]);
+                if (cc) atomicAdd((u64*)&out.ff->corr, (u64)cc);
+              }
+            }
+          }
+        }
         if (t == chroms[ci].tileBase) {
           out.chromIvOff[ci] = cex;
           out.chromLooseOff[ci] = out.tileSlot[t];
@@ -1085,57 +1135,6 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
       if (key[k] > kex) kex = key[k];
     }
     __syncthreads();
-  }
-}
-
-// fragLen.  savePileupExpt adds (float)len * val per interval into a double.  With unit weights
-// only (no fractional records, no -E regions) val is an integer, and a product below 2^24 is
-// exact, so the sum over such intervals is the number of covered (base, fragment) pairs: the sum
-// of the clamped fragment lengths, which k_convert accumulates for free ("closed form").  Only
-// intervals with len * val >= 2^24 can round, and they are easy to find:
-//   * val >= 2^24 / (2 TILE): k_tile marks the tiles in which the pileup gets that deep;
-//   * otherwise len >= 2 TILE: the interval starts before its tile does, so it is the tile's first.
-// k_frag_fix1 looks at every other tile's first interval (and lists the deep tiles), k_frag_walk walks
-// the listed ones; both add (rounded product - exact product), an integer, to a correction.
-// Everything else (fractional weights, -E, wide records) takes k_frag_walk's general path, which
-// walks every interval and accumulates exactly in (integer, fraction * 2^27) form.
-struct FragFix {
-  u64 fragSum[FRAG_SLOTS];  // closed form partial sums
-  u32 slow;                 // general path wanted
-  u32 nList;
-  long long corr;
-  u32 nF;                   // fractional records appended by k_convert (not fragLen's, but zeroed with it)
-  u32 pad_;
-};
-
-__device__ __forceinline__ long long frag_corr(u32 len, int v) {
-  if (v <= 0) return 0;  // V_MARK never occurs on this path
-  const u32 cnt = (u32)v / GX_UNIT;
-  const float term = (float)len * (float)cnt;  // what getval returns for a whole pileup
-  return (long long)term - (long long)((u64)len * cnt);
-}
-
-// One pass over the tiles: a tile k_tile marked deep (and that holds intervals) goes on a list (walked by
-// k_frag_walk and k_pval_deep); of every other tile the first interval is looked at (it may start before
-// its tile: the only place where len >= 2 TILE can hide).
-__global__ __launch_bounds__(256) void k_frag_fix1(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
-                                                   const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
-                                                   const u32* __restrict__ tilePrevEnd, const u32* __restrict__ tileDeep,
-                                                   u32 nTiles, FragFix* __restrict__ ff, u32* __restrict__ list) {
-  long long c = 0;
-  const u32 t = blockIdx.x * 256 + threadIdx.x;
-  if (t < nTiles && tileIvOff[t + 1] != tileIvOff[t]) {
-    if (tileDeep[t])
-      list[atomicAdd(&ff->nList, 1u)] = t;
-    else if (!ff->slow) {
-      const u32 slot = meta[t].slot;
-      const u32 len = looseEnd[slot] - tilePrevEnd[t];
-      if (len >= 2 * TILE) c = frag_corr(len, looseV[slot]);
-    }
-  }
-  if (__ballot(c != 0)) {
-    c = wave_sum(c);
-    if (lane_id() == 0) atomicAdd((u64*)&ff->corr, (u64)c);
   }
 }
 

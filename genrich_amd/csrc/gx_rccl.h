@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <mutex>
 #include <string>
 
 namespace gxrccl {
@@ -25,14 +26,15 @@ struct Api {
   decltype(&ncclAllReduce) allReduce = nullptr;
   decltype(&ncclAllGather) allGather = nullptr;
   decltype(&ncclGetErrorString) getErrorString = nullptr;
+  decltype(&ncclCommCount) commCount = nullptr;   // (optional: introspection only)
 };
 
+// (one host thread per GPU may come here side by side: the tables are filled exactly once)
 inline const Api* load(std::string* err) {
   static Api api;
-  static bool tried = false;
   static std::string why;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;
+  std::call_once(once, [&]() {
     // The RCCL that belongs to the HIP runtime this process actually runs on: a Python host may have
     // loaded PyTorch's bundled ROCm (its own libamdhip64 + librccl) before or after this library, and an
     // RCCL build only works on the runtime it ships with.  So look next to the loaded libamdhip64 first.
@@ -58,13 +60,14 @@ inline const Api* load(std::string* err) {
       api.allReduce = reinterpret_cast<decltype(api.allReduce)>(dlsym(api.handle, "ncclAllReduce"));
       api.allGather = reinterpret_cast<decltype(api.allGather)>(dlsym(api.handle, "ncclAllGather"));
       api.getErrorString = reinterpret_cast<decltype(api.getErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+      api.commCount = reinterpret_cast<decltype(api.commCount)>(dlsym(api.handle, "ncclCommCount"));
       if (!api.getUniqueId || !api.commInitRank || !api.commDestroy || !api.allReduce || !api.allGather ||
           !api.getErrorString) {
         why = "librccl lacks an entry point";
         api.handle = nullptr;
       }
     }
-  }
+  });
   if (!api.handle) {
     if (err) *err = why;
     return nullptr;

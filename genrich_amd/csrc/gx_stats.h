@@ -1071,18 +1071,17 @@ __device__ __forceinline__ float p_from_v(const float* __restrict__ hot, const i
   const u32 c = __umulhi((u32)V[i], 0x88888889u) >> 6;  // V / 120
   return hot[c < PV_WHOLE ? c : 0u];
 }
-template <bool USEQ, bool PV = false>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
-__global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hdr, const u32* __restrict__ end,
-                                                    const float* __restrict__ p, const float* __restrict__ q,
-                                                    const u32* __restrict__ chromOff, u32 nChrom,
-                                                    const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
-                                                    gx_peak* __restrict__ cand, u32* __restrict__ valid) {
-  __shared__ float hot[PV ? PV_WHOLE : 1];
-  if (PV) load_whole_lut(hot, p);
+template <bool USEQ, bool PV>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
+__device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, const float* __restrict__ hot,
+                                                const uint4* __restrict__ hdr, const u32* __restrict__ end,
+                                                const float* __restrict__ p, const float* __restrict__ q,
+                                                const u32* __restrict__ chromOff, u32 nChrom,
+                                                const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
+                                                gx_peak* __restrict__ cand, u32* __restrict__ valid) {
   const u32 C = *nCands;
   const int lane = lane_id(), rowBase = lane & 48, rl = lane & 15;
-  const u32 rowId = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (u32)(lane >> 4);  // 16 rows per workgroup
-  for (u32 c0 = 0; c0 < C; c0 += gridDim.x * 16) {  // (wave-uniform bound: every lane takes part in the shuffles)
+  const u32 rowId = (blk * 4 + (threadIdx.x >> 6)) * 4 + (u32)(lane >> 4);  // 16 rows per workgroup
+  for (u32 c0 = 0; c0 < C; c0 += nBlk * 16) {  // (wave-uniform bound: every lane takes part in the shuffles)
     const u32 c = c0 + rowId;
     uint4 h = make_uint4(1u, 0u, 0u, 0u);
     if (c < C) h = hdr[c];
@@ -1161,21 +1160,20 @@ __global__ __launch_bounds__(256) void k_peak_short(const uint4* __restrict__ hd
 // per step, PK_AHEAD steps of loads in flight; the ordered float sum runs row after row (16 dependent DPP adds
 // each, the running value carried from row to row by a readlane); maxima by DPP rotations inside the rows and
 // readlanes across them: no LDS shuffle anywhere.
-template <bool PV = false>
-__global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr, const u32* __restrict__ end,
-                                                   const float* __restrict__ p, const float* __restrict__ qIn,
-                                                   const u32* __restrict__ chromOff, u32 nChrom,
-                                                   const u32* __restrict__ longList, const u32* __restrict__ nLong,
-                                                   float thr, float minAUC, int minLen,
-                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+template <bool PV>
+__device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, const float* __restrict__ hot,
+                                               const uint4* __restrict__ hdr, const u32* __restrict__ end,
+                                               const float* __restrict__ p, const float* __restrict__ qIn,
+                                               const u32* __restrict__ chromOff, u32 nChrom,
+                                               const u32* __restrict__ longList, const u32* __restrict__ nLong,
+                                               float thr, float minAUC, int minLen,
+                                               gx_peak* __restrict__ cand, u32* __restrict__ valid) {
   const float* __restrict__ q = PV ? nullptr : qIn;
-  __shared__ float hot[PV ? PV_WHOLE : 1];
-  if (PV) load_whole_lut(hot, p);
   const u32 L = *nLong;
-  const u32 wavesPerGrid = gridDim.x * 4;
+  const u32 wavesPerGrid = nBlk * 4;
   const int lane = lane_id();
   auto rdf = [](float v, int l) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-  for (u32 li = blockIdx.x * 4 + (threadIdx.x >> 6); li < L; li += wavesPerGrid) {
+  for (u32 li = blk * 4 + (threadIdx.x >> 6); li < L; li += wavesPerGrid) {
     const u32 c = longList[li];
     const uint4 h = hdr[c];
     const u32 i0 = h.x, i1 = h.y, peakStart = h.z;
@@ -1240,6 +1238,25 @@ __global__ __launch_bounds__(256) void k_peak_walk(const uint4* __restrict__ hdr
     }
     if (lane == 0) peak_finish(c, h, auc, summitPos, sp, sq, minAUC, minLen, chromOff, nChrom, cand, valid);
   }
+}
+
+// The two walks in ONE launch (they share nothing but the candidate headers): the first workgroups take the
+// long candidates, the other nShort the short ones -- the few long candidates (one wavefront each, a chain of dependent
+// round trips) run beside the short ones instead of behind them.
+template <bool USEQ, bool PV>
+__global__ __launch_bounds__(256) void k_peak_both(u32 nShort, const uint4* __restrict__ hdr, const u32* __restrict__ end,
+                                                   const float* __restrict__ p, const float* __restrict__ q,
+                                                   const u32* __restrict__ chromOff, u32 nChrom,
+                                                   const u32* __restrict__ nCands, const u32* __restrict__ longList,
+                                                   const u32* __restrict__ nLong, float thr, float minAUC, int minLen,
+                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  __shared__ float hot[PV ? PV_WHOLE : 1];
+  if (PV) load_whole_lut(hot, p);
+  const u32 nWalk = gridDim.x - nShort;  // (the long candidates' workgroups come first in the grid: they are the long pole)
+  if (blockIdx.x >= nWalk)
+    peak_short_body<USEQ, PV>(blockIdx.x - nWalk, nShort, hot, hdr, end, p, q, chromOff, nChrom, nCands, thr, minAUC, minLen, cand, valid);
+  else
+    peak_walk_body<PV>(blockIdx.x, nWalk, hot, hdr, end, p, q, chromOff, nChrom, longList, nLong, thr, minAUC, minLen, cand, valid);
 }
 
 // pass 4: ordered compaction of the candidates that passed checkPeak (chunks of 2048 heads)

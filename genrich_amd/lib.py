@@ -73,6 +73,8 @@ _SIGS = {
     "gx_selftest2": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)],
     "gx_selftest_host": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_path_info": [C.c_void_p, C.POINTER(C.c_uint)],
+    "gx_rccl_nranks": [C.c_void_p, C.POINTER(C.c_int)],
+    "gx_set_phase_filter": [C.c_void_p, C.c_char_p],
     "gx_set_phase_timing": [C.c_void_p, C.c_int],
     "gx_phase_times": [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float))],
 }
@@ -320,6 +322,16 @@ class Genrich:
         f = C.c_uint(0)
         self._check(self.lib.gx_path_info(self.ctx, C.byref(f)))
         return f.value
+
+    def rccl_nranks(self):
+        """Ranks of the library's own RCCL communicator as RCCL reports them (0: none)."""
+        n = C.c_int(0)
+        self._check(self.lib.gx_rccl_nranks(self.ctx, C.byref(n)))
+        return n.value
+
+    def set_phase_filter(self, name):
+        """Time only the phase `name` (HIP events on the library's stream)."""
+        self._check(self.lib.gx_set_phase_filter(self.ctx, name.encode()))
 
     def set_phase_timing(self, level):
         """0 none (default), 1 the tile stage only, 2 every phase (each event record costs the stream ~5 us)."""

@@ -218,6 +218,8 @@ int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn all
  * for host programs without RCCL (the tests' gloo mode).  librccl is opened at run time. */
 int gx_rccl_unique_id(void* out, size_t cap /* >= 128 */);
 int gx_set_rccl(gx_ctx* ctx, int rank, int world, const void* unique_id);
+/* Ranks of the library's communicator as RCCL itself reports them (ncclCommCount); 0 without one. */
+int gx_rccl_nranks(gx_ctx* ctx, int* n);
 /* owned[i] = 1: this rank computes chromosome i (default: all).  The full table still goes to
  * gx_set_chroms on every rank, so genome lengths and output order are global; device work and
  * memory are laid out for the owned chromosomes only.  Call after gx_set_chroms and before the
@@ -238,6 +240,10 @@ int gx_set_keep_pileups(gx_ctx* ctx, int keep);
  * ~5 us bubble on the stream), 1 the tile stage only ("t.tile" / "c.tile": what
  * bench.py's roofline needs inside its timed region), 2 every phase. */
 int gx_set_phase_timing(gx_ctx* ctx, int level);
+/* Like level 1, for another phase: only the phases called `name` ("sort1", "tile", "bucket" -- per sample, reported
+ * as "t.<name>" / "c.<name>" --, "pval", "merge", "fisher", "bh", "sweep") are bracketed by events.  bench.py times
+ * the phase of its roofline kernel this way inside the timed region. */
+int gx_set_phase_filter(gx_ctx* ctx, const char* name);
 int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
 /* Which device path the last calls took (tests assert that the fast paths really run):
  * bit 0: the last sample's tile stage was k_sbtile (level 2 of the sort fused with the tile passes, gx_sbtile.h);

@@ -145,3 +145,64 @@ def test_midsize_slice_against_oracle():
         assert np.array_equal(eo, eh)
         assert np.array_equal(co["expt"].view(np.uint32), ch["expt"].view(np.uint32))
         assert np.array_equal(co["p"].view(np.uint32), ch["p"].view(np.uint32))
+
+
+# ---- BASELINE.json's other GPU configs at full size: all 25 contigs against the oracle, byte for byte -------------
+# (configs[2] control + -q, configs[3] ATAC geometry + -s multimapping weights, configs[4] three replicates + Fisher + -q;
+#  savePileupCtrl Genrich.c:2052-2161, saveFragAtac 2728-2749 + addFrac / subFrac 2311-2488, combinePval 612-667)
+
+def _whole_genome_against_oracle(case, params, min_peaks):
+    import genrich_amd
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = genrich_amd.Genrich(params)
+    sh = B.run_case(h, case)
+    for (fo, lo, co), (fh, lh, ch) in zip(so, sh):
+        assert fo == fh or (fo >= 2.0 ** 26 and abs(fo - fh) <= 4 * np.spacing(fo)), ("fragLen", fo, fh)
+        assert np.float32(lo).tobytes() == np.float32(lh).tobytes()
+        if co is not None:
+            assert np.float32(co).tobytes() == np.float32(ch).tobytes()
+    po, ph = o.get_peaks(), h.get_peaks()
+    assert len(po) == len(ph) >= min_peaks, (len(po), len(ph))
+    assert po.tobytes() == ph.tobytes(), "peak lists differ"
+    assert o.peak_bp == h.peak_bp
+    nrep = len(case["replicates"])
+    total = 0
+    for which in [-1] + (list(range(nrep)) if nrep > 1 else []):
+        for c in range(len(LENS)):
+            eo, co = o.get_intervals(which, c)
+            eh, ch = h.get_intervals(which, c, piles=False)
+            assert np.array_equal(eo, eh), f"interval ends differ on contig {c} (array {which})"
+            for k in ("p", "q"):
+                assert np.array_equal(co[k].view(np.uint32), ch[k].view(np.uint32)), f"{k} differs on contig {c} (array {which})"
+            if which == -1:
+                total += len(eo)
+    assert total == h.interval_total()
+    flags = h.path_info()
+    o.close()
+    h.close()
+    return flags
+
+
+def test_fullsize_config3_control_and_q_is_the_oracles_bytes():
+    # (peaks of ~1,000 fragments every 200 kb: strong enough to stay significant after the genome-wide correction --
+    # SURVEY 8(d)'s generator caveat -- so the q-mode sweep sees > 10^4 peaks, not just the towers)
+    t = synth.make_fragments(LENS, 50_000_000, seed=1, peak_every=200_000, tower_every=50_000_000)
+    c = synth.make_fragments(LENS, 50_000_000, seed=2, uniform_only=True)
+    case = dict(lens=LENS, replicates=[dict(save=None, treat=t, ctrl=c)])
+    flags = _whole_genome_against_oracle(case, B.make_params(pq=0.05, qval=True), 1_000)
+    assert flags & 1, "the tile stage of a unit-weight sample is k_sbtile"
+
+
+def test_fullsize_config4_atac_multimap_is_the_oracles_bytes():
+    ev = synth.make_fragments(LENS, 50_000_000, seed=1)
+    ev = synth.atac_events(synth.add_multimap(ev, LENS, 0.10, seed=11), LENS, d=100)
+    case = dict(lens=LENS, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    flags = _whole_genome_against_oracle(case, B.make_params(pq=0.01), 10_000)
+    assert flags & 4 and not flags & 1, "fractional weights take the general chain"
+
+
+def test_fullsize_config5_three_replicates_fisher_q_is_the_oracles_bytes():
+    reps = [dict(save=None, treat=synth.make_fragments(LENS, 50_000_000, seed=s), ctrl=None) for s in (1, 3, 5)]
+    case = dict(lens=LENS, replicates=reps)
+    _whole_genome_against_oracle(case, B.make_params(pq=0.05, qval=True), 1_000)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 runs of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the tracked summaries
-under profiles/:  <tag>_kernel_stats.txt, <tag>_pmc.txt and r02_counters_config<C>.json (what bench.py's
+under profiles/:  <tag>_config<C>_kernel_stats.txt, <tag>_config<C>_pmc.txt and r03_counters_config<C>.json (what bench.py's
 `roofline` object reads; it carries the hash of the kernel sources it was measured on).
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB = 1024 B): on gfx950 FETCH_SIZE tallies the 128-byte
@@ -118,13 +118,21 @@ def main():
     out["whole_step"]["fetch_kb_raw"] = fetch_tot / steps
     out["whole_step"]["write_kb_raw"] = write_tot / steps
     out["whole_step"]["hbm_bytes_per_step"] = (2 * fetch_tot + write_tot) * 1024 / steps
-    # issue model of the dominant kernel from the SQ counters (quad-cycle units, MI355X_MICROARCH.md)
-    kt = out["kernels"].get("k_tile_fast", out["kernels"].get("k_tile", {}))
+    # the dominant kernel = the one with the most time per step; its issue model from the SQ counters (quad-cycle
+    # units, MI355X_MICROARCH.md)
+    timed = {k: v for k, v in out["kernels"].items() if v.get("us_per_step") and k.startswith("k_")}
+    domk = max(timed, key=lambda k: timed[k]["us_per_step"]) if timed else None
+    if domk:
+        d = timed[domk]
+        out["dominant"] = {"kernel": domk, "us_per_step": d["us_per_step"], "launches_per_step": d.get("launches_per_step"),
+                           "hbm_bytes_per_step": d.get("hbm_bytes_per_step"),
+                           "tbs": (d["hbm_bytes_per_step"] / d["us_per_step"] / 1e6) if d.get("hbm_bytes_per_step") else None}
+    kt = out["kernels"].get(domk, {}) if domk else {}
     sq = kt.get("sq", {})
     if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_BUSY_CYCLES"):
         wc = sq["SQ_WAVE_CYCLES"]
         out["issue"] = {
-            "kernel": "k_tile_fast" if "k_tile_fast" in out["kernels"] else "k_tile",
+            "kernel": domk,
             "valu_insts_per_wave": sq.get("SQ_INSTS_VALU", 0) / max(1.0, sq.get("SQ_WAVES", 1)),
             "lds_insts_per_wave": sq.get("SQ_INSTS_LDS", 0) / max(1.0, sq.get("SQ_WAVES", 1)),
             "active_valu_frac_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU", 0) / wc,
@@ -136,7 +144,7 @@ def main():
             if sq.get("SQ_LDS_IDX_ACTIVE") else None,
             "raw": sq,
         }
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"r02_counters_config{cfg}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"r03_counters_config{cfg}.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1)[:3000])
 
 
