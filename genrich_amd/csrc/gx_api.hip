@@ -586,7 +586,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
   const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
   const bool fused = unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && !ctx->sawFrac && !ctx->fusedOff &&
-                     !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 26000;
+                     !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 26000 &&
+                     (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
   ctx->fusedUsed = fused;
   // lambda ahead of the tile stage (closed form of fragLen; LooseCtl): one rank, a treatment sample, -p
   const bool multiRank = ctx->world > 1 || ctx->forceColl;
@@ -827,6 +828,10 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
   const long long again = multi ? ctx->mail->coll[2]
                                 : (long long)(ctx->mail->hot ? 1 : 0) + ((ctx->mail->status & ST_PT_FULL) ? 65536 : 0) +
                                       ((ctx->mail->status & (ST_SB_FULL | ST_SB_FRAC)) ? (1ll << 32) : 0);
+  if (again >> 48) {
+    ctx->err = "another rank could not build its sample";
+    return GX_ERR_DEVICE;
+  }
   if (again >> 32) {
     // k_sbtile could not take some rank's sample (a bin beyond its LDS, or fractional weights): once more, on the
     // general chain
@@ -885,6 +890,24 @@ int drop_saturated(gx_ctx* ctx, int isCtrl) {
   return GX_OK;
 }
 
+constexpr long long COLL_FAILED = 1ll << 48;  // third all-reduce word: some rank could not build its sample
+
+void poison_allreduce(gx_ctx* ctx) {
+  if (!(ctx->world > 1 || ctx->forceColl)) return;
+  hipStream_t s = ctx->stream;
+  long long w[3] = {0, 0, COLL_FAILED};
+  if (ctx->comm) {
+    const gxrccl::Api* api = gxrccl::load(nullptr);
+    if (!api || !ctx->dColl.p) return;
+    if (hipMemcpyAsync(ctx->dColl.p, w, sizeof w, hipMemcpyHostToDevice, s) != hipSuccess) return;
+    (void)api->allReduce(ctx->dColl.p, ctx->dColl.p, 3, ncclInt64, ncclSum, ctx->comm, s);
+    (void)hipStreamSynchronize(s);
+  } else if (ctx->allreduce) {
+    int64_t buf[3] = {w[0], w[1], w[2]};
+    (void)ctx->allreduce(buf, 3, ctx->user);
+  }
+}
+
 int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
   ctx->fusedOff = false;
   if (!isCtrl) ctx->looseOk = false;
@@ -896,7 +919,14 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
   };
   for (int attempt = 0; attempt < 12; attempt++) {
     int rc = build_pileup(ctx, P, isCtrl);
-    if (rc) return rc;
+    if (rc) {
+      // With several ranks the others are about to wait for this one in the fragLen all-reduce: take part in it with a
+      // "this rank has failed" word, so that every rank returns an error instead of one returning and the rest hanging.
+      const std::string why = ctx->err;
+      poison_allreduce(ctx);
+      ctx->err = why;
+      return rc;
+    }
     rc = finish_scalars(ctx, isCtrl);
     if (rc == RETRY_GENERAL) {
       // k_sbtile could not take the sample (finish_scalars has switched it off for this one): the general chain

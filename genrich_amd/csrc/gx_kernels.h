@@ -62,7 +62,9 @@ enum : u32 {
   RK_SELF = 6,   // a = index, b = function (gx_selftest)
 };
 struct RiskRec { u32 kind, a, b, c; double x; float pnew; u32 pad; };
-constexpr u32 RISK_CAP = 16384, RISK_PREFIX = 64;  // records kept / records the host reads with the count
+// (about 1.2e-4 of the directly evaluated p-values are risky: 2^20 records carry a run of ~10^10 evaluations -- 32 MB on
+// the device and as many pinned on the host; round 2's 2^14 made a control / Fisher run beyond ~10^8 evaluations fail)
+constexpr u32 RISK_CAP = 1u << 20, RISK_PREFIX = 64;  // records kept / records the host reads with the count
 struct RiskBuf { u32 count; u32 pad[7]; RiskRec rec[RISK_CAP]; };
 static_assert(sizeof(RiskRec) == 32 && sizeof(RiskBuf) == 32 + 32 * RISK_CAP, "layout shared with the host");
 

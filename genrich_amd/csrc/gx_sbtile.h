@@ -52,13 +52,19 @@ constexpr u32 SBT_SLOT = 256;                          // keys per slot
 constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K keys)
 constexpr u32 SBT_KEYCAP = 57344;                      // keys of a super-bucket (both streams) that fit the LDS
 constexpr int SBT_TR = 192;                            // touched bases per round of a tile's passes (k_tile_fast: TR_CAP)
-constexpr int SBT_TW = TILE / 32 + TILE / 64 + SBT_TR + SBT_TR / 2;  // a wavefront's scratch in words (1,920 bytes)
+// a wavefront's scratch, in words: occupancy bitmap (+ a dummy word that absorbs the lanes without a key), the words'
+// prefix counts (+ a dummy entry that ranks those lanes out of every round), counters and offsets by rank
+constexpr int SBT_OCCW = TILE / 32 + 4, SBT_PREW = TILE / 64 + 4;
+constexpr int SBT_TW = SBT_OCCW + SBT_PREW + SBT_TR + SBT_TR / 2;    // 1,952 bytes
+constexpr u32 SBT_NOKEY = 0x1000u;                     // "no key": offset 4096 = bit 0 of the dummy bitmap word
+static_assert(SBT_TR % 64 == 0, "the last step of a round reads whole wavefronts of counters");
 static_assert((1u << PgCfg<u32>::SHIFT) % SBT_SLOT == 0, "a slot never crosses a page");
 static_assert(TILE == 4096, "13-bit LDS keys: 12 bits of offset and the stream");
 static_assert((SBT_NW * SBT_TW) % 4 == 0, "the scratch is cleared by 16-byte stores");
 
 struct SbtLds {
-  uint16_t keys[SBT_KEYCAP];               // the bin's keys, tile after tile: [11:0] offset, [15] end key
+  uint16_t keys[SBT_KEYCAP + 192];         // the bin's keys, tile after tile: [11:0] offset, [15] end key (+ slack: a
+                                           // tile's first 192 keys are read without a bounds check)
   int tile[SBT_NW][SBT_TW];                // k_tile_fast's scratch, one per wavefront
   u32 hist[SBT_TILES];                     // [15:0] start keys, [31:16] end keys of the tile
   u32 startC[SBT_TILES + 1];               // keys (both streams) of the bin before the tile
@@ -99,14 +105,22 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// 32-bit byte offsets against a uniform base pointer: one shift instead of 64-bit address arithmetic per store
+__device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
+  *reinterpret_cast<u32*>(static_cast<char*>(base) + (size_t)(index << 2)) = v;
+}
+
 // One tile, one wavefront: the passes of k_tile_fast with the keys in LDS (kl[0 .. n): [11:0] offset, [15] end).
+// Lanes without a key carry SBT_NOKEY instead of sitting out: their bit goes to a dummy bitmap word and their rank
+// (the dummy prefix entry: 0xFFFF) lies outside every round, so the three passes over the register-held keys run
+// without per-lane predicates.
 __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad) {
   u32* occ = reinterpret_cast<u32*>(lds);
-  u32* pre = reinterpret_cast<u32*>(lds + TILE / 32);
+  u32* pre = reinterpret_cast<u32*>(lds + SBT_OCCW);
   const uint16_t* pre16 = reinterpret_cast<const uint16_t*>(pre);
-  int* cnt = lds + TILE / 32 + TILE / 64;
-  uint16_t* list = reinterpret_cast<uint16_t*>(lds + TILE / 32 + TILE / 64 + SBT_TR);
+  int* cnt = lds + SBT_OCCW + SBT_PREW;
+  uint16_t* list = reinterpret_cast<uint16_t*>(lds + SBT_OCCW + SBT_PREW + SBT_TR);
   constexpr int TR_CAP = SBT_TR;  // (shadows k_tile_fast's: the rounds below are its code)
   const int lane = lane_id();
   const bool active = flags & TM_ACTIVE;
@@ -114,39 +128,35 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   constexpr int KR = 3;  // keys per lane kept in registers (192 per tile; a tile of config 2 holds ~135)
   u32 kr[KR];
 #pragma unroll
-  for (int q = 0; q < KR; q++) kr[q] = (u32)lane + q * 64 < n ? kl[lane + q * 64] : 0u;
+  for (int q = 0; q < KR; q++) {
+    const u32 v = kl[lane + q * 64];  // (in bounds: the key array has 192 entries of slack)
+    kr[q] = (u32)lane + q * 64 < n ? v : SBT_NOKEY;
+  }
   // ---- A1: keys -> occupancy bitmap
-  auto mark = [&](u32 key) { const u32 off = key & (TILE - 1); atomicOr(&occ[off >> 5], 1u << (off & 31)); };
+  auto mark = [&](u32 key) { const u32 off = key & (2 * TILE - 1); atomicOr(&occ[off >> 5], 1u << (off & 31)); };
 #pragma unroll
-  for (int q = 0; q < KR; q++)
-    if ((u32)lane + q * 64 < n) mark(kr[q]);
+  for (int q = 0; q < KR; q++) mark(kr[q]);
   for (u32 k = KR * 64 + lane; k < n; k += 64) mark(kl[k]);
   wave_lds_sync();
   // ---- B: touched bases before each bitmap word
-  u32 w0 = 0, w1 = 0;
-  if (n) {  // wave-uniform
-    const uint2 ww = *reinterpret_cast<const uint2*>(occ + 2 * lane);
-    w0 = ww.x;
-    w1 = ww.y;
-  }
+  const uint2 ww = *reinterpret_cast<const uint2*>(occ + 2 * lane);
+  const u32 w0 = ww.x, w1 = ww.y;
   const int c0 = __popc(w0), c = c0 + __popc(w1);
   const int incC = dpp_scan_add(c);
   const u32 exc = (u32)(incC - c);
   const u32 T = (u32)__builtin_amdgcn_readlane(incC, 63);
-  if (T) pre[lane] = exc | ((exc + (u32)c0) << 16);
+  pre[lane] = exc | ((exc + (u32)c0) << 16);
   wave_lds_sync();
   int runBase = carry;
   u32 outCount = 0, lastEnd = 0;
   u64 negM = 0, bigM = carry >= FRAG_FAST_MAXV ? ~0ull : 0ull;
-  auto rankOf = [&](u32 off) -> u32 {
-    const u32 wi = off >> 5;
+  auto rankOf = [&](u32 key) -> u32 {
+    const u32 off = key & (2 * TILE - 1), wi = off >> 5;
     return (u32)pre16[wi] + (u32)__popc(occ[wi] & ((1u << (off & 31)) - 1u));
   };
   u32 rr[KR];
-  if (T) {
 #pragma unroll
-    for (int q = 0; q < KR; q++) rr[q] = rankOf(kr[q] & (TILE - 1));
-  }
+  for (int q = 0; q < KR; q++) rr[q] = rankOf(kr[q]);
   for (u32 r0 = 0; r0 < T; r0 += TR_CAP) {
     if (r0) wave_lds_sync();
     // ---- A2: keys -> cnt[rank], list[rank]
@@ -158,25 +168,18 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
       }
     };
 #pragma unroll
-    for (int q = 0; q < KR; q++)
-      if ((u32)lane + q * 64 < n) put(rr[q], kr[q]);
+    for (int q = 0; q < KR; q++) put(rr[q], kr[q]);
     for (u32 k = KR * 64 + lane; k < n; k += 64) {
       const u32 key = kl[k];
-      put(rankOf(key & (TILE - 1)), key);
+      put(rankOf(key), key);
     }
     wave_lds_sync();
-    // ---- C: 64 touched bases per step
+    // ---- C: 64 touched bases per step (whole wavefronts: the counters behind the last touched base are zero)
     const u32 nL = min((u32)TR_CAP, T - r0);
     for (u32 j0 = 0; j0 < nL; j0 += 64) {
       const u32 j = j0 + lane;
-      const bool valid = j < nL;
-      u32 p = 0;
-      int d120 = 0;
-      if (valid) {
-        p = list[j];
-        d120 = cnt[j];
-        cnt[j] = 0;
-      }
+      const u32 p = list[j];
+      const int d120 = __hip_atomic_exchange(&cnt[j], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // read and clear
       const int incS = dpp_scan_add(d120);
       const int after = runBase + incS;
       const int before = after - d120;                          // the pileup of the interval that ends here (2244)
@@ -185,8 +188,8 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
       const u32 orank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
       if (nz) {
         const u32 o = slot + outCount + orank;
-        out.to.looseEnd[o] = pos0 + p;
-        out.to.looseV[o] = before;
+        st_u32(out.to.looseEnd, o, pos0 + p);
+        st_u32(out.to.looseV, o, (u32)before);
       }
       if (vsig != 0x7FFFFFFF) sig_flush(out.to.sigMask, slot + outCount, nz && before >= vsig, orank);  // wave-uniform
       negM |= __ballot(after < 0);
@@ -198,7 +201,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
       }
     }
   }
-  if (T) *reinterpret_cast<uint2*>(occ + 2 * lane) = make_uint2(0u, 0u);
+  *reinterpret_cast<uint2*>(occ + 2 * lane) = make_uint2(0u, 0u);
   u32 total = 0;
   if (active) {  // wave-uniform
     total = outCount + (lastTile ? 1u : 0u);
@@ -225,8 +228,8 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   if (total && vsig != 0x7FFFFFFF) {  // wave-uniform
     const u32 size = n + 1;
     for (u32 j = total + lane; j < size; j += 64) {
-      out.to.looseEnd[slot + j] = lastEnd;
-      out.to.looseV[slot + j] = 0;
+      st_u32(out.to.looseEnd, slot + j, lastEnd);
+      st_u32(out.to.looseV, slot + j, 0u);
     }
   }
   wave_lds_sync();
@@ -244,6 +247,8 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
   if (tid < SBT_TILES) L.hist[tid] = 0;
   if (tid == 0) L.overflow = 0;
+  __syncthreads();
+  if (tid < SBT_NW) L.tile[tid][SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
   if (tid < 2 * NXCD) {
     const PagedStream& P = tid < NXCD ? in.PS : in.PE;
     L.scratch[tid] = P.cursor[(u32)(tid & (NXCD - 1)) * nSeg + seg];

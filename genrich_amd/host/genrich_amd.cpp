@@ -36,6 +36,7 @@
 #include <string>
 #include <tuple>
 #include <pthread.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -209,7 +210,7 @@ void check(State& S, int rc, gx_ctx* which = nullptr) {
 }
 
 // f(context index) on every device context: in place for one, one host thread each for several (the calls
-// that contain collectives must run side by side); the first failure ends the program like any other
+// that contain collectives must run side by side); the first failure ends the program like any other,
 template <typename F>
 void onEachDevice(State& S, F f) {
   Devs& D = S.devs;
@@ -217,11 +218,20 @@ void onEachDevice(State& S, F f) {
     check(S, f(0), D.ctx[0]);
     return;
   }
-  std::vector<int> rc(D.n(), GX_OK);
+  // A context that fails ends the program FROM ITS OWN THREAD: the others may already be waiting for it inside a
+  // collective (ncclAllReduce / ncclAllGather, or the barrier of the callback mode), where a join would wait forever.
   std::vector<std::thread> th;
-  for (size_t g = 0; g < D.n(); g++) th.emplace_back([&, g] { rc[g] = f((int)g); });
+  for (size_t g = 0; g < D.n(); g++)
+    th.emplace_back([&, g] {
+      const int rc = f((int)g);
+      if (rc != GX_OK) {
+        const std::string detail = gx_last_error(D.ctx[g]);
+        fprintf(stderr, "Error! %s\n", detail.empty() ? gx_strerror(rc) : detail.c_str());
+        fflush(nullptr);
+        _exit(EXIT_FAILURE);  // (no atexit handlers: the other threads' device work is still in flight)
+      }
+    });
   for (auto& t : th) t.join();
-  for (size_t g = 0; g < D.n(); g++) check(S, rc[g], D.ctx[g]);
 }
 
 // the events gathered so far go to the contexts that own their chromosomes
