@@ -106,8 +106,15 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // 32-bit byte offsets against a uniform base pointer: one shift instead of 64-bit address arithmetic per store
+#ifndef GX_SBT_KNOBS   // measurement knobs (tools/build_variant.sh): 1 exchange-and-clear, 2 32-bit store offsets, 4 unpredicated key loads
+#define GX_SBT_KNOBS 7
+#endif
 __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
+#if GX_SBT_KNOBS & 2
   *reinterpret_cast<u32*>(static_cast<char*>(base) + (size_t)(index << 2)) = v;
+#else
+  static_cast<u32*>(base)[index] = v;
+#endif
 }
 
 // One tile, one wavefront: the passes of k_tile_fast with the keys in LDS (kl[0 .. n): [11:0] offset, [15] end).
@@ -129,13 +136,21 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   u32 kr[KR];
 #pragma unroll
   for (int q = 0; q < KR; q++) {
+#if GX_SBT_KNOBS & 4
     const u32 v = kl[lane + q * 64];  // (in bounds: the key array has 192 entries of slack)
     kr[q] = (u32)lane + q * 64 < n ? v : SBT_NOKEY;
+#else
+    kr[q] = SBT_NOKEY;
+    if ((u32)lane + q * 64 < n) kr[q] = kl[lane + q * 64];
+#endif
   }
   // ---- A1: keys -> occupancy bitmap
   auto mark = [&](u32 key) { const u32 off = key & (2 * TILE - 1); atomicOr(&occ[off >> 5], 1u << (off & 31)); };
+  // (predicated after all: the lanes without a key would all hit the one dummy word, and same-address LDS atomics
+  // serialise -- measured 0.71 -> 0.81 ms for the kernel)
 #pragma unroll
-  for (int q = 0; q < KR; q++) mark(kr[q]);
+  for (int q = 0; q < KR; q++)
+    if (kr[q] != SBT_NOKEY) mark(kr[q]);
   for (u32 k = KR * 64 + lane; k < n; k += 64) mark(kl[k]);
   wave_lds_sync();
   // ---- B: touched bases before each bitmap word
@@ -179,7 +194,12 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
     for (u32 j0 = 0; j0 < nL; j0 += 64) {
       const u32 j = j0 + lane;
       const u32 p = list[j];
+#if GX_SBT_KNOBS & 1
       const int d120 = __hip_atomic_exchange(&cnt[j], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // read and clear
+#else
+      const int d120 = cnt[j];
+      cnt[j] = 0;
+#endif
       const int incS = dpp_scan_add(d120);
       const int after = runBase + incS;
       const int before = after - d120;                          // the pileup of the interval that ends here (2244)
