@@ -72,6 +72,7 @@ struct HostMail {
   u32 nF, nIv, status, R, nPeaks, nMerged, D, n, hot;
   long long coll[4];   // this rank's / all ranks' {fragLen parts, saturation flag}
   u32 counts[64];      // BH records per rank (all-gather)
+  u32 closeState;      // k_close: 1 the sample is closed, 2 the separate kernels have to run
   u32 seq;             // k_mail's last write (mail_sync polls it)
 };
 
@@ -175,6 +176,10 @@ struct gx_ctx {
   bool fusedOff = false;        // this sample: a super-bucket did not fit k_sbtile (the general chain runs instead)
   bool fusedUsed = false;       // the last build went through k_sbtile
   bool looseSwept = false;      // the last gx_find_peaks swept the loose slots
+  DevBuf lbSweep, lbSweep2;     // look-back granules of the sweep's one-pass compactions (generation-tagged)
+  u32 sweepGen = 0;
+  FragSelect closeSel{};        // the sample's k_frag_select arguments (k_close took them; finish_scalars may need them again)
+  u32 closeSeq = 0;             // sequence number of the mail k_close sends (0: the separate kernels were launched)
   bool fellBack = false;        // some sample was sent back from k_sbtile to the general chain
   bool looseOk = false;         // the treatment sample's tile stage left valid sweep bits on the loose slots
   bool riskNearThr = false;     // a re-evaluated table entry lies next to the significance threshold
@@ -202,7 +207,7 @@ struct gx_ctx {
   bool bhDirty = false;         // the BH table was left with entries (an error path): wipe it before use
   u32 bhCapLog = 22;            // log2 of its slots (grows by 3 after ST_HASH_FULL)
   // sweep
-  DevBuf swChrom, swStart, swEnd, swMask, cand, valid, peaks, lb2, headPos, candHdr, longList;
+  DevBuf swStart, swEnd, swMask, cand, valid, peaks, headPos, candHdr, longList;
   PinnedBuf hPeaks;             // the peak list on the host (pinned: the read-back is asynchronous)
   size_t nHostPeaks = 0;
   u32* nIvTarget = nullptr;
@@ -348,13 +353,23 @@ int read_status(gx_ctx* ctx) {
 // The host does not wait in hipStreamSynchronize (an interrupt and a wake-up: 20-30 us after the kernel): k_mail
 // writes a sequence number behind everything else and the host polls that word in pinned memory (a few us).  After
 // 20 ms of polling -- or with GX_NO_SPIN -- it blocks in the runtime after all, which also reports a device fault.
-int mail_sync(gx_ctx* ctx, const Scalars* ds, const u32* hot, const u32* nIv, const long long* coll, const u32* extra) {
+MailOut mail_out(gx_ctx* ctx) {
   HostMail* dm = static_cast<HostMail*>(ctx->mailBuf.dp);
-  MailOut mo{&dm->scal, &dm->status, &dm->hot, &dm->nIv, &dm->coll[2], &dm->nMerged, static_cast<RiskBuf*>(ctx->riskHost.dp),
-             &dm->seq};
+  return MailOut{&dm->scal, &dm->status, &dm->hot, &dm->nIv, &dm->coll[2], &dm->nMerged, static_cast<RiskBuf*>(ctx->riskHost.dp),
+                 &dm->seq};
+}
+
+int mail_wait(gx_ctx* ctx, u32 seq);
+
+int mail_sync(gx_ctx* ctx, const Scalars* ds, const u32* hot, const u32* nIv, const long long* coll, const u32* extra) {
   const u32 seq = ++ctx->mailSeq;
   hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, ds, ctx->dStatus.as<u32>(), hot, nIv, coll, extra,
-                     ctx->dRisk.as<RiskBuf>(), mo, seq);
+                     ctx->dRisk.as<RiskBuf>(), mail_out(ctx), seq);
+  return mail_wait(ctx, seq);
+}
+
+// (the mail kernel -- k_mail, or k_close -- has been launched with this sequence number)
+int mail_wait(gx_ctx* ctx, u32 seq) {
   static const bool spin = getenv("GX_NO_SPIN") == nullptr;
   volatile u32* word = &ctx->mail->seq;
   if (spin) {
@@ -736,15 +751,30 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     const u32* tOff = out.tileIvOff.as<u32>();
     const u32* tPrev = ctx->tilePrevEnd.as<u32>();
     // (k_frag_fix1's pass over the tiles -- deep-tile list, long first intervals -- rides in k_scan_iv)
+    FragSelect fsel{ff, acc, ctx->world > 1 || ctx->forceColl ? ctx->dColl.as<long long>() : (long long*)nullptr,
+                    ctx->nWide.as<u32>() + 1, ctx->dStatus.as<u32>(), ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
+                    ctx->misc.as<u32>() + M_NIV, ds, isCtrl, ctx->chromLooseOff.as<u32>(), ctx->tileSlot.as<u32>(), nTiles, ctl,
+                    wantEarly ? ctx->swMask.as<u64>() + ctx->looseStride : (u64*)nullptr};
+    ctx->closeSel = fsel;
+    ctx->closeSeq = 0;
+    static const bool noClose = getenv("GX_NO_CLOSE") != nullptr;
+    if (wantEarly && !noClose) {
+      // lambda was known before the tile stage: k_frag_select's work and the mail in one launch (k_close); if a deep tile,
+      // the general fragLen path or a changed lambda stands in the way, finish_scalars runs the separate kernels after all
+      ctx->closeSeq = ++ctx->mailSeq;
+      ctx->mail->nMerged = 0;
+      ctx->mail->closeState = 0;
+      HostMail* dm = static_cast<HostMail*>(ctx->mailBuf.dp);
+      hipLaunchKernelGGL(k_close, dim3(1), dim3(64), 0, s, fsel, ctx->misc.as<u32>() + M_NIV, (const u32*)&ctl->ok,
+                         ctx->dRisk.as<RiskBuf>(), mail_out(ctx), &dm->closeState, ctx->closeSeq);
+      if (int rc__ = dbg_sync(ctx, "k_close")) return rc__;
+    } else {
     hipLaunchKernelGGL(k_frag_walk, dim3(std::max(1u, std::min((nTiles + 3) / 4, 4096u))), dim3(256), 0, s, lE, lV, tm, tOff,
                        tPrev, nTiles, ff, ctx->fragList.as<u32>(), acc);
     // (single thread: chromosome offsets of the chromosomes without tiles, closed form -> accumulator pair,
     // this rank's words of the all-reduce)
-    hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ff, acc,
-                       ctx->world > 1 || ctx->forceColl ? ctx->dColl.as<long long>() : (long long*)nullptr,
-                       ctx->nWide.as<u32>() + 1, ctx->dStatus.as<u32>(), ctx->dChrom.as<DChrom>(), nChrom,
-                       out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV, ds, isCtrl, ctx->chromLooseOff.as<u32>(),
-                       ctx->tileSlot.as<u32>(), nTiles, ctl);
+    hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, fsel);
+    }
   }
   if (int rc__ = dbg_sync(ctx, "k_frag")) return rc__;
   out.packed = false;
@@ -800,6 +830,22 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>(), (const long long*)dcoll);
     if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
   }
+  bool closed = false;
+  if (ctx->closeSeq) {
+    // k_close has sent the mail (build_pileup); only if something stood in its way do the separate kernels run
+    if (int rc__ = mail_wait(ctx, ctx->closeSeq)) return rc__;
+    ctx->closeSeq = 0;
+    closed = ctx->mail->closeState == 1;
+    if (!closed) {
+      const u32 nTiles = ctx->nTiles;
+      hipLaunchKernelGGL(k_frag_walk, dim3(std::max(1u, std::min((nTiles + 3) / 4, 4096u))), dim3(256), 0, s, ctx->looseEnd.as<u32>(),
+                         ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>(),
+                         ctx->tilePrevEnd.as<u32>(), nTiles, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(), ctx->closeSel.acc);
+      hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ctx->closeSel);
+      if (int rc__ = dbg_sync(ctx, "k_frag (after k_close)")) return rc__;
+    }
+  }
+  if (!closed) {
   // lambda (and with a control the factor) is final: build the p-value tables now, so that the values the
   // host has to re-evaluate (risky ones) travel with the synchronisation that returns the scalars
   if (!isCtrl) {
@@ -820,6 +866,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
   if (int rc__ = mail_sync(ctx, ds, ctx->nWide.as<u32>() + 1, ctx->misc.as<u32>() + M_NIV, dcoll,
                            isCtrl ? (const u32*)nullptr : &ctx->looseCtl.as<LooseCtl>()->ok))
     return rc__;
+  }
   ctx->hScal = ctx->mail->scal;
   ctx->riskNearThr = false;
   const int rcRisk = risk_apply(ctx, RiskTargets{});
@@ -1065,16 +1112,19 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
   ctx->peakBP = 0;
   ctx->nHostPeaks = 0;
   if (nWords) {
-    HIPCHECK(ctx->lb2.ensure(((size_t)wChunks * 4 + 64) * 4));
-    u32* cntS = ctx->lb2.as<u32>();
-    u32* offS = cntS + wChunks + 8;
-    u32* cntE = offS + wChunks + 8;
-    u32* offE = cntE + wChunks + 8;
-    hipLaunchKernelGGL(k_brk_mask, dim3((nChrom + 255) / 256), dim3(256), 0, s, S.chromOff, nChrom, SM.brk);
+    // (in loose-slot index space the chromosome starts were marked when the sample was closed: k_close / k_frag_select)
+    if (!S.V) hipLaunchKernelGGL(k_brk_mask, dim3((nChrom + 255) / 256), dim3(256), 0, s, S.chromOff, nChrom, SM.brk);
     if (!S.haveMasks)
       hipLaunchKernelGGL(k_sig_mask, dim3(std::max(1u, std::min((nWords + 15) / 16, 4096u))), dim3(256), 0, s, S.p, S.q,
                          misc + M_NIV, ctx->par.thr, SM);
-    hipLaunchKernelGGL(k_runs_count, dim3(wChunks), dim3(SW_NT), 0, s, SM, cntS, cntE);
+    // look-back granules of the three one-pass compactions (generation-tagged: never cleared between calls)
+    {
+      const size_t need = (size_t)2 * (wChunks + 8) * 8;
+      if (ctx->lbSweep.cap < need) {
+        HIPCHECK(ctx->lbSweep.ensure(need));
+        HIPCHECK(hipMemsetAsync(ctx->lbSweep.p, 0, ctx->lbSweep.cap, s));
+      }
+    }
     for (int attempt = 0;; attempt++) {
       // arrays for `cap` runs (never more runs than intervals)
       static const u64 capMin = getenv("GX_RUN_CAP_MIN") ? (u64)atoll(getenv("GX_RUN_CAP_MIN")) : (u64)1 << 16;  // (tests: a tiny first guess)
@@ -1091,30 +1141,34 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
       HIPCHECK(ctx->candHdr.ensure((size_t)cap * sizeof(uint4)));
       HIPCHECK(ctx->longList.ensure((size_t)cap * 4 + 16));
       const u32 rChunks = (cap + RC_CHUNK - 1) / RC_CHUNK;
-      HIPCHECK(ctx->swChrom.ensure(((size_t)rChunks * 4 + 64) * 4));
-      u32* cnt2 = ctx->swChrom.as<u32>();
-      u32* off2 = cnt2 + rChunks + 8;
-      u32* cnt3 = off2 + rChunks + 8;
-      u32* off3 = cnt3 + rChunks + 8;
+      {
+        const size_t need = (size_t)2 * (rChunks + 8) * 8;
+        if (ctx->lbSweep2.cap < need) {
+          HIPCHECK(ctx->lbSweep2.ensure(need));
+          HIPCHECK(hipMemsetAsync(ctx->lbSweep2.p, 0, ctx->lbSweep2.cap, s));
+        }
+      }
+      if (++ctx->sweepGen >= (1u << 24)) {  // (the generation field wraps: start over with clean arrays)
+        ctx->sweepGen = 1;
+        HIPCHECK(hipMemsetAsync(ctx->lbSweep.p, 0, ctx->lbSweep.cap, s));
+        HIPCHECK(hipMemsetAsync(ctx->lbSweep2.p, 0, ctx->lbSweep2.cap, s));
+      }
+      const u32 gen = ctx->sweepGen;
+      u64* lbS = ctx->lbSweep.as<u64>();
+      u64* lbE = lbS + wChunks + 8;
+      u64* lbC = ctx->lbSweep2.as<u64>();
+      u64* lbP = lbC + rChunks + 8;
       u32* runStart = ctx->swStart.as<u32>();
       u32* runEnd = ctx->swEnd.as<u32>();
       const u64* skipM = S.hasSkip ? SM.skip : (const u64*)nullptr;
-      {  // run count: the true one to the host, at most `cap` for the kernels
-        ScanJobs J{{{cntS, nullptr, wChunks, (u32)SW_CHUNK, offS, misc + M_SWCOUNT, &dm->R, misc + M_TICKET3, cap},
-                    {cntE, nullptr, wChunks, (u32)SW_CHUNK, offE, misc + M_TICKET2, nullptr, nullptr, 0}}};
-        hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, s, J);
-      }
-      hipLaunchKernelGGL(k_runs_write, dim3(wChunks), dim3(SW_NT), 0, s, SM, offS, offE, runStart, runEnd, cap);
-      // (`valid` holds the runs' "opens a candidate" flags until the peak kernels reuse it per candidate;
-      // workgroups beyond the device-side counts leave at once)
-      hipLaunchKernelGGL(k_cands_count, dim3(rChunks), dim3(SW_NT), 0, s, SM, skipM, S.end, runStart, runEnd, misc + M_SWCOUNT,
-                         ctx->par.max_gap, S.chromOff, nChrom, ctx->valid.as<u32>(), cnt2);
-      {
-        ScanJobs J{{{cnt2, misc + M_SWCOUNT, rChunks, (u32)RC_CHUNK, off2, misc + M_NHEADS, nullptr, nullptr, 0}, {}}};
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, J);
-      }
-      hipLaunchKernelGGL(k_cands_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_SWCOUNT, off2,
-                         ctx->headPos.as<u32>());
+      const u32 gridP = (u32)std::max(1, ctx->resSweep);
+      // runs: count, place and write in one pass; the true count goes to the host, at most `cap` to the kernels
+      hipLaunchKernelGGL(k_runs, dim3(std::min<u32>(wChunks, gridP)), dim3(SW_NT), 0, s, SM, lbS, lbE, gen, runStart, runEnd, cap,
+                         misc + M_SWCOUNT, &dm->R, misc + M_TICKET3, ctx->dStatus.as<u32>());
+      // candidates (chunks beyond the device-side run count leave at once)
+      hipLaunchKernelGGL(k_cands, dim3(std::min<u32>(rChunks, gridP)), dim3(SW_NT), 0, s, SM, skipM, S.end, runStart, runEnd,
+                         misc + M_SWCOUNT, ctx->par.max_gap, S.chromOff, nChrom, lbC, gen, ctx->headPos.as<u32>(), misc + M_NHEADS,
+                         ctx->dStatus.as<u32>());
       hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((cap + 255) / 256, 4096u))), dim3(256), 0, s, SM, S.end, runStart,
                          runEnd, misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->candHdr.as<uint4>(),
                          ctx->longList.as<u32>(), misc + M_TICKET3);
@@ -1135,14 +1189,10 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
           GX_LAUNCH_PEAKS(false, false, grid.x, S.q);
 #undef GX_LAUNCH_PEAKS
       }
-      // candidates C <= R: chunk arrays sized by the run capacity; kernels bound themselves by *nCands
-      hipLaunchKernelGGL(k_peaks_count, dim3(rChunks), dim3(SW_NT), 0, s, ctx->valid.as<u32>(), misc + M_NHEADS, cnt3);
-      {
-        ScanJobs J{{{cnt3, misc + M_NHEADS, rChunks, (u32)RC_CHUNK, off3, misc + M_NPEAKS, &dm->nPeaks, nullptr, 0}, {}}};
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, J);
-      }
-      hipLaunchKernelGGL(k_peaks_write, dim3(rChunks), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
-                         misc + M_NHEADS, off3, static_cast<gx_peak*>(ctx->hPeaks.dp));
+      // the peaks, in order, into pinned host memory; their number with them
+      hipLaunchKernelGGL(k_peaks, dim3(std::min<u32>(rChunks, gridP)), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
+                         misc + M_NHEADS, lbP, gen, static_cast<gx_peak*>(ctx->hPeaks.dp), misc + M_NPEAKS, &dm->nPeaks,
+                         ctx->dStatus.as<u32>());
       if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
       // the end: status, counts (and whatever else is pending) through the mail kernel, one synchronisation
       if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;

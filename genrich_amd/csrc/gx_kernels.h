@@ -1284,26 +1284,49 @@ __device__ __forceinline__ void finish_frag(Scalars* s, int isCtrl, u32* st, con
 // (every rank must learn whether any rank has to, before the sums mean anything): +1 when a base can
 // reach the reference's int16 limits, +65536 when a level-1 page list overflowed (ST_PT_FULL = 512)
 // (acc points into *scal: no __restrict__ on either)
-__global__ void k_frag_select(const FragFix* __restrict__ ff, long long* acc, long long* __restrict__ coll,
-                              const u32* __restrict__ hot, u32* st, const DChrom* __restrict__ chroms,
-                              u32 nChrom, u32* __restrict__ chromIvOff, const u32* __restrict__ nIv, Scalars* scal,
-                              int isCtrl, u32* __restrict__ chromLooseOff, const u32* __restrict__ tileSlot, u32 nTiles,
-                              LooseCtl* ctl) {
-  if (threadIdx.x || blockIdx.x) return;
+struct FragSelect {
+  const FragFix* ff;
+  long long* acc;            // (points into *scal: no __restrict__ on either)
+  long long* coll;
+  const u32* hot;
+  u32* st;
+  const DChrom* chroms;
+  u32 nChrom;
+  u32* chromIvOff;
+  const u32* nIv;
+  Scalars* scal;
+  int isCtrl;
+  u32* chromLooseOff;
+  const u32* tileSlot;
+  u32 nTiles;
+  LooseCtl* ctl;
+  u64* brkLoose;             // the sweep's "first of its chromosome" mask in loose-slot index space (or null)
+};
+
+__device__ __forceinline__ void frag_select_body(const FragSelect& A) {
+  const FragFix* ff = A.ff;
+  long long* acc = A.acc;
+  long long* coll = A.coll;
+  u32* st = A.st;
+  Scalars* scal = A.scal;
+  LooseCtl* ctl = A.ctl;
   {  // chromosome table epilogue (as k_fix_chrom_off): offsets of the chromosomes without tiles
-    u32 next = *nIv, nextL = tileSlot[nTiles];
-    chromIvOff[nChrom] = next;
-    chromLooseOff[nChrom] = nextL;
-    for (int c = (int)nChrom - 1; c >= 0; c--) {
-      if (chroms[c].tileBase == NULL_TILE) {
-        chromIvOff[c] = next;
-        chromLooseOff[c] = nextL;
+    u32 next = *A.nIv, nextL = A.tileSlot[A.nTiles];
+    A.chromIvOff[A.nChrom] = next;
+    A.chromLooseOff[A.nChrom] = nextL;
+    for (int c = (int)A.nChrom - 1; c >= 0; c--) {
+      if (A.chroms[c].tileBase == NULL_TILE) {
+        A.chromIvOff[c] = next;
+        A.chromLooseOff[c] = nextL;
       } else {
-        next = chromIvOff[c];
-        nextL = chromLooseOff[c];
+        next = A.chromIvOff[c];
+        nextL = A.chromLooseOff[c];
+        if (A.brkLoose) A.brkLoose[nextL >> 6] |= 1ull << (nextL & 63);  // (this thread alone writes the mask)
       }
     }
   }
+  const u32* hot = A.hot;
+  const int isCtrl = A.isCtrl;
   if (!ff->slow) {
     u64 t = 0;
     for (int i = 0; i < FRAG_SLOTS; i++) t += ff->fragSum[i];
@@ -1318,6 +1341,11 @@ __global__ void k_frag_select(const FragFix* __restrict__ ff, long long* acc, lo
     finish_frag(scal, isCtrl, st, nullptr);  // one rank: the sums are final (otherwise k_finish_frag, after the all-reduce)
   // the sweep may use the loose slots if the tile stage wrote its bits with the lambda that turned out final
   ctl->ok = !coll && ctl->enabled && !ctl->bad && ctl->earlyBits == __float_as_uint(scal->lambda) ? 1u : 0u;
+}
+
+__global__ void k_frag_select(FragSelect A) {
+  if (threadIdx.x || blockIdx.x) return;
+  frag_select_body(A);
 }
 
 // a replicate begins: its scalars at zero, the genome length in place
@@ -1348,10 +1376,9 @@ struct MailOut {
   u32* seq;           // written last: the host polls it (mail_sync)
 };
 
-__global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, const u32* __restrict__ st, const u32* __restrict__ hot,
-                                             const u32* __restrict__ nIv, const long long* __restrict__ coll,
-                                             const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, MailOut m,
-                                             u32 seq) {
+__device__ __forceinline__ void mail_body(const Scalars* __restrict__ ds, const u32* __restrict__ st, const u32* __restrict__ hot,
+                                          const u32* __restrict__ nIv, const long long* __restrict__ coll,
+                                          const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, const MailOut& m, u32 seq) {
   const u32 n = rb->count;
   if (threadIdx.x == 0) {
     if (ds) *m.scal = *ds;
@@ -1367,6 +1394,31 @@ __global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, con
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(m.seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, const u32* __restrict__ st, const u32* __restrict__ hot,
+                                             const u32* __restrict__ nIv, const long long* __restrict__ coll,
+                                             const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, MailOut m,
+                                             u32 seq) {
+  mail_body(ds, st, hot, nIv, coll, extra, rb, m, seq);
+}
+
+// The end of a treatment sample whose lambda -- and with it the table p(V) -- was known before the tile stage (LooseCtl):
+// k_frag_select's work and the mail in ONE launch, when nothing else stands between them: no deep tile to walk
+// (k_frag_walk), no general fragLen path, and the table built for the lambda that turns out final.  Otherwise
+// `*closeState` = 2 (in the mail block) tells the host to run the separate kernels (k_frag_walk, k_frag_select, k_pval_lut, k_mail) after all.
+__global__ __launch_bounds__(64) void k_close(FragSelect A, const u32* __restrict__ nIv, const u32* __restrict__ extra,
+                                              const RiskBuf* __restrict__ rb, MailOut m, u32* __restrict__ closeState, u32 seq) {
+  if (threadIdx.x == 0) {
+    u32 ok = 0;
+    if (!A.ff->slow && A.ff->nList == 0 && !A.coll) {
+      frag_select_body(A);
+      ok = A.ctl->enabled && A.ctl->earlyBits == __float_as_uint(A.scal->lambda);
+    }
+    *closeState = ok ? 1u : 2u;  // (pinned host memory, ahead of the mail's fence and sequence number)
+  }
+  __syncthreads();
+  mail_body(A.scal, A.st, A.hot, nIv, nullptr, extra, rb, m, seq);
 }
 
 }  // namespace gx

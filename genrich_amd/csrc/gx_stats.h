@@ -720,12 +720,13 @@ __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, co
 // significant (peaks are dense in breakpoints), so nothing per-interval is materialised beyond
 // three bit masks (significant / SKIP / first-of-chromosome, 1 bit per interval each, L2-resident):
 //   k_sig_mask     pq[] -> bit masks                                   (the only full-length read)
-//   k_runs_*       maximal runs of adjacent significant intervals: count -> k_scan_small -> write
-//   k_cands_*      a run opens a new candidate unless it links to the previous run
-//   k_peak_walk    one wavefront per candidate over the ORIGINAL arrays; the float AUC is summed
-//                  strictly in interval order (950): lanes form the products in parallel, the
-//                  additions are replayed serially through shuffles
-//   k_peaks_*      ordered compaction of the candidates passing checkPeak (916-927)
+//   k_runs         maximal runs of adjacent significant intervals, counted, placed and written in one pass
+//   k_cands        a run opens a new candidate unless it links to the previous run (one pass as well)
+//   k_cand_hdr     candidate -> {first interval, last interval, start, end}
+//   k_peak_both    updatePeak over the ORIGINAL arrays: 16 lanes per candidate (a wavefront for a long one); the
+//                  float AUC is summed strictly in interval order (950): lanes form the products in parallel, the
+//                  additions are replayed serially through DPP
+//   k_peaks        ordered compaction of the candidates passing checkPeak (916-927), into pinned host memory
 // List lengths stay on the device (kernels read them through pointers).
 constexpr int SW_NT = 256;
 constexpr int SW_ITEMS = 8;
@@ -733,44 +734,6 @@ constexpr int SW_CHUNK = SW_NT * SW_ITEMS;  // mask words per workgroup in the c
 // Runs and candidates are few (tens of thousands) and every one costs a chain of dependent loads: one per
 // thread, so the chains of a workgroup run side by side instead of eight in a row.
 constexpr int RC_CHUNK = SW_NT;
-
-// exclusive scan of a short u32 array (chunk counts) by one workgroup; total -> *total (and, when the host
-// wants it at its next synchronisation, -> *totalHost in pinned memory: no copy launch).  One workgroup per
-// job: the two scans that follow the same kernel share a launch.
-struct ScanJob {
-  const u32* in;
-  const u32* nPtr;   // items = ceil(*nPtr / chunk) when given (a device-side count), else nMax
-  u32 nMax, chunk;
-  u32* out;
-  u32* total;
-  u32* totalHost;    // optional
-  u32* zeroMe;       // optional: a counter the kernels after this one expect at zero
-  u32 clamp;         // 0: none; else *total = min(total, clamp) while *totalHost gets the true total (arrays sized by guess)
-};
-struct ScanJobs { ScanJob j[2]; };
-
-__global__ __launch_bounds__(1024) void k_scan_small(ScanJobs J) {
-  __shared__ u32 scratch[20];
-  const ScanJob& jb = J.j[blockIdx.x];
-  u32 n = jb.nPtr ? (*jb.nPtr + jb.chunk - 1) / jb.chunk : jb.nMax;
-  if (n > jb.nMax) n = jb.nMax;
-  const u32 per = (n + 1023) / 1024;
-  const u32 i0 = min(n, threadIdx.x * per), i1 = min(n, i0 + per);
-  u32 sum = 0;
-  for (u32 i = i0; i < i1; i++) sum += jb.in[i];
-  u32 tot;
-  u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
-  for (u32 i = i0; i < i1; i++) {
-    u32 v = jb.in[i];
-    jb.out[i] = ex;
-    ex += v;
-  }
-  if (threadIdx.x == 0) {
-    *jb.total = jb.clamp && tot > jb.clamp ? jb.clamp : tot;
-    if (jb.totalHost) *jb.totalHost = tot;
-    if (jb.zeroMe) *jb.zeroMe = 0;
-  }
-}
 
 // gx_find_peaks' two scalars for the kernels that read them through pointers (M_NIV, M_GENOME of the misc block)
 __global__ void k_set_misc(u32* __restrict__ misc, u32 nivWord, u32 genomeWord, u64 genome, u32 n) {
@@ -829,66 +792,6 @@ __device__ __forceinline__ void run_bits(const SweepMasks& M, u32 w, u64* starts
   *ends = sg & (~((sg >> 1) | (nextBit << 63)) | ((bk >> 1) | (nextBrk << 63)));
 }
 
-// count run starts and ends per chunk of 2048 words (one word per thread x 8)
-__global__ __launch_bounds__(SW_NT) void k_runs_count(SweepMasks M, u32* __restrict__ cntS, u32* __restrict__ cntE) {
-  __shared__ u32 s_a[SW_NT / 64], s_b[SW_NT / 64];
-  const u32 w0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
-  u32 a = 0, b = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++)
-    if (w0 + k < M.nWords) {
-      u64 st, en;
-      run_bits(M, w0 + k, &st, &en);
-      a += __popcll(st);
-      b += __popcll(en);
-    }
-  a = wave_sum(a);
-  b = wave_sum(b);
-  if (lane_id() == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    cntS[blockIdx.x] = s_a[0] + s_a[1] + s_a[2] + s_a[3];
-    cntE[blockIdx.x] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
-  }
-}
-
-__global__ __launch_bounds__(SW_NT) void k_runs_write(SweepMasks M, const u32* __restrict__ offS, const u32* __restrict__ offE,
-                                                      u32* __restrict__ runStart, u32* __restrict__ runEnd,
-                                                      u32 cap /* runs the arrays hold (a guess: the host checks the true count) */) {
-  __shared__ u32 scratch[8];
-  const u32 w0 = blockIdx.x * SW_CHUNK + threadIdx.x * SW_ITEMS;
-  u64 st[SW_ITEMS], en[SW_ITEMS];
-  u32 a = 0, b = 0;
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++) {
-    st[k] = 0;
-    en[k] = 0;
-    if (w0 + k < M.nWords) run_bits(M, w0 + k, &st[k], &en[k]);
-    a += __popcll(st[k]);
-    b += __popcll(en[k]);
-  }
-  u32 tot;
-  u32 oa = offS[blockIdx.x] + block_excl_scan<u32, SW_NT>(a, scratch, &tot);
-  u32 ob = offE[blockIdx.x] + block_excl_scan<u32, SW_NT>(b, scratch, &tot);
-#pragma unroll
-  for (int k = 0; k < SW_ITEMS; k++) {
-    u64 x = st[k];
-    while (x) {
-      int bit = __builtin_ctzll(x);
-      x &= x - 1;
-      if (oa < cap) runStart[oa] = ((w0 + k) << 6) + bit;
-      oa++;
-    }
-    x = en[k];
-    while (x) {
-      int bit = __builtin_ctzll(x);
-      x &= x - 1;
-      if (ob < cap) runEnd[ob] = ((w0 + k) << 6) + bit;
-      ob++;
-    }
-  }
-}
-
 // any bit of mask set in the interval-index range [lo, hi) ?
 __device__ __forceinline__ bool any_bit(const u64* __restrict__ mask, u32 lo, u32 hi) {
   if (lo >= hi) return false;
@@ -920,39 +823,6 @@ __device__ __forceinline__ bool run_is_head(const SweepMasks& M, const u64* __re
   // at most `gap` intervals (each >= 1 bp) lie between linked runs: a short scan
   if (skipMask && any_bit(skipMask, a + 1, s)) return true;  // (no SKIP intervals without -E regions)
   return false;
-}
-
-__global__ __launch_bounds__(SW_NT) void k_cands_count(SweepMasks M, const u64* __restrict__ skipMask, const u32* __restrict__ end,
-                                                       const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
-                                                       const u32* __restrict__ nRuns, int maxGap,
-                                                       const u32* __restrict__ chromOff, u32 nChrom,
-                                                       u32* __restrict__ isHead /* [R], for k_cands_write */,
-                                                       u32* __restrict__ chunkCnt) {
-  __shared__ u32 s_cnt[SW_NT / 64];
-  const u32 R = *nRuns;
-  if (blockIdx.x * RC_CHUNK >= R) return;
-  const u32 r = blockIdx.x * RC_CHUNK + threadIdx.x;
-  u32 cnt = 0;
-  if (r < R) {
-    cnt = run_is_head(M, skipMask, end, runStart, runEnd, r, maxGap, chromOff, nChrom);
-    isHead[r] = cnt;
-  }
-  cnt = wave_sum(cnt);
-  if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-}
-
-__global__ __launch_bounds__(SW_NT) void k_cands_write(const u32* __restrict__ isHead, const u32* __restrict__ nRuns,
-                                                       const u32* __restrict__ chunkOff, u32* __restrict__ candRun) {
-  __shared__ u32 scratch[8];
-  const u32 R = *nRuns;
-  if (blockIdx.x * RC_CHUNK >= R) return;
-  const u32 r = blockIdx.x * RC_CHUNK + threadIdx.x;
-  const u32 keep = r < R ? isHead[r] : 0u;
-  u32 tot;
-  const u32 o = chunkOff[blockIdx.x] + block_excl_scan<u32, SW_NT>(keep, scratch, &tot);
-  if (keep) candRun[o] = r;
 }
 
 #ifndef GX_PK_SHORT
@@ -1259,44 +1129,185 @@ __global__ __launch_bounds__(256) void k_peak_both(u32 nShort, const uint4* __re
     peak_walk_body<PV>(blockIdx.x, nWalk, hot, hdr, end, p, q, chromOff, nChrom, longList, nLong, thr, minAUC, minLen, cand, valid);
 }
 
-// pass 4: ordered compaction of the candidates that passed checkPeak (chunks of 2048 heads)
-__global__ __launch_bounds__(SW_NT) void k_peaks_count(const u32* __restrict__ valid, const u32* __restrict__ nHeads,
-                                                       u32* __restrict__ chunkCnt) {
-  __shared__ u32 s_cnt[SW_NT / 64];
-  const u32 H = *nHeads;
-  if (blockIdx.x * RC_CHUNK >= H) return;
-  const u32 h = blockIdx.x * RC_CHUNK + threadIdx.x;
-  u32 cnt = h < H ? valid[h] : 0u;
-  cnt = wave_sum(cnt);
-  if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) chunkCnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+// ---- the sweep's three ordered compactions, each in ONE pass -------------------------------------------------
+// (round 2: count kernel -> k_scan_small -> write kernel, three launches each.)  A chunk counts its items, learns
+// how many the chunks before it hold through a decoupled look-back, and writes.  The look-back granules carry a
+// GENERATION number (one per gx_find_peaks call), so the arrays are never cleared: an entry of an earlier call
+// reads as "nothing yet".   granule = [63:62] flag (1 aggregate, 2 inclusive prefix)  [61:38] generation  [37:0] value
+// Forward progress as for lookback_excl: persistent workgroups (grid <= co-resident), chunks taken round-robin.
+constexpr int LBG_SHIFT = 38;
+__device__ __forceinline__ u64 lookback_gen(u64* lb, u32 id, u64 aggregate, u32 gen, u32* st) {
+  const u64 tag = (u64)(gen & 0xFFFFFFu) << LBG_SHIFT, vmask = (1ull << LBG_SHIFT) - 1;
+  u64 excl = 0;
+  if (id > 0) {
+    if (lane_id() == 0)
+      __hip_atomic_store(&lb[id], LB_AGG | tag | (aggregate & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int look = (int)id - 1;
+    u32 spins = 0;
+    bool done = false;
+    while (!done) {
+      const int idx = look - lane_id();  // lane 0 = nearest predecessor
+      u64 v = idx >= 0 ? __hip_atomic_load(&lb[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (LB_INC | tag);
+      if (((v >> LBG_SHIFT) & 0xFFFFFFu) != (gen & 0xFFFFFFu)) v = 0;  // another call's entry: nothing yet
+      const u64 flag = v >> 62;
+      const u64 invalidMask = __ballot(flag == 0), incMask = __ballot(flag == 2);
+      const int firstInvalid = invalidMask ? __builtin_ctzll(invalidMask) : 64;
+      const int firstInc = incMask ? __builtin_ctzll(incMask) : 64;
+      if (firstInc < firstInvalid) {
+        excl += wave_sum(lane_id() <= firstInc ? (v & vmask) : 0ull);
+        done = true;
+      } else if (firstInvalid > 0) {
+        excl += wave_sum(lane_id() < firstInvalid ? (v & vmask) : 0ull);
+        look -= firstInvalid;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+        bool abort_ = spins > LB_SPIN_LIMIT;
+        if (!abort_ && (spins & 1023u) == 0)
+          abort_ = (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_LOOKBACK) != 0;
+        if (abort_) {
+          if (lane_id() == 0) atomicOr(st, ST_LOOKBACK);
+          done = true;
+        }
+      }
+    }
+  }
+  excl &= vmask;
+  if (lane_id() == 0)
+    __hip_atomic_store(&lb[id], LB_INC | tag | ((excl + aggregate) & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
 }
 
-// The workgroup's peaks are packed in LDS and leave as one contiguous run of dwords: the destination is pinned
-// host memory, where 64 consecutive dwords of a wavefront make a few full-size PCIe writes and a 28-byte
-// record per lane makes seven small ones.
-__global__ __launch_bounds__(SW_NT) void k_peaks_write(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
-                                                       const u32* __restrict__ nHeads, const u32* __restrict__ chunkOff,
-                                                       gx_peak* __restrict__ peaks /* pinned host memory */) {
+// runs of adjacent significant intervals: starts and ends, counted, placed and written in one pass
+__global__ __launch_bounds__(SW_NT) void k_runs(SweepMasks M, u64* __restrict__ lbS, u64* __restrict__ lbE, u32 gen,
+                                                u32* __restrict__ runStart, u32* __restrict__ runEnd, u32 cap,
+                                                u32* __restrict__ nRuns /* min(total, cap) */, u32* __restrict__ nRunsHost /* total */,
+                                                u32* __restrict__ zeroMe, u32* __restrict__ st) {
+  __shared__ u32 scratch[8];
+  __shared__ u64 s_base[2];
+  const u32 nChunks = (M.nWords + SW_CHUNK - 1) / SW_CHUNK;
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
+    const u32 w0 = id * SW_CHUNK + threadIdx.x * SW_ITEMS;
+    u64 stb[SW_ITEMS], enb[SW_ITEMS];
+    u32 a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < SW_ITEMS; k++) {
+      stb[k] = 0;
+      enb[k] = 0;
+      if (w0 + k < M.nWords) run_bits(M, w0 + k, &stb[k], &enb[k]);
+      a += __popcll(stb[k]);
+      b += __popcll(enb[k]);
+    }
+    u32 totA, totB;
+    u32 oa = block_excl_scan<u32, SW_NT>(a, scratch, &totA);
+    u32 ob = block_excl_scan<u32, SW_NT>(b, scratch, &totB);
+    if (threadIdx.x < 64) {
+      const u64 ea = lookback_gen(lbS, id, totA, gen, st);
+      const u64 eb = lookback_gen(lbE, id, totB, gen, st);
+      if (threadIdx.x == 0) {
+        s_base[0] = ea;
+        s_base[1] = eb;
+        if (id == nChunks - 1) {
+          const u32 total = (u32)ea + totA;
+          *nRuns = total > cap ? cap : total;
+          *nRunsHost = total;
+          *zeroMe = 0;
+        }
+      }
+    }
+    __syncthreads();
+    oa += (u32)s_base[0];
+    ob += (u32)s_base[1];
+#pragma unroll
+    for (int k = 0; k < SW_ITEMS; k++) {
+      u64 x = stb[k];
+      while (x) {
+        const int bit = __builtin_ctzll(x);
+        x &= x - 1;
+        if (oa < cap) runStart[oa] = ((w0 + k) << 6) + bit;
+        oa++;
+      }
+      x = enb[k];
+      while (x) {
+        const int bit = __builtin_ctzll(x);
+        x &= x - 1;
+        if (ob < cap) runEnd[ob] = ((w0 + k) << 6) + bit;
+        ob++;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// candidates: the runs that open one (run_is_head), counted, placed and listed in one pass
+__global__ __launch_bounds__(SW_NT) void k_cands(SweepMasks M, const u64* __restrict__ skipMask, const u32* __restrict__ end,
+                                                 const u32* __restrict__ runStart, const u32* __restrict__ runEnd,
+                                                 const u32* __restrict__ nRuns, int maxGap, const u32* __restrict__ chromOff,
+                                                 u32 nChrom, u64* __restrict__ lb, u32 gen, u32* __restrict__ candRun,
+                                                 u32* __restrict__ nCands, u32* __restrict__ st) {
+  __shared__ u32 scratch[8];
+  __shared__ u64 s_base;
+  const u32 R = *nRuns;
+  const u32 nChunks = (R + RC_CHUNK - 1) / RC_CHUNK;
+  if (nChunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) *nCands = 0;
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
+    const u32 r = id * RC_CHUNK + threadIdx.x;
+    const u32 keep = r < R ? (u32)run_is_head(M, skipMask, end, runStart, runEnd, r, maxGap, chromOff, nChrom) : 0u;
+    u32 tot;
+    u32 o = block_excl_scan<u32, SW_NT>(keep, scratch, &tot);
+    if (threadIdx.x < 64) {
+      const u64 e = lookback_gen(lb, id, tot, gen, st);
+      if (threadIdx.x == 0) {
+        s_base = e;
+        if (id == nChunks - 1) *nCands = (u32)e + tot;
+      }
+    }
+    __syncthreads();
+    if (keep) candRun[o + (u32)s_base] = r;
+    __syncthreads();
+  }
+}
+
+// the candidates that passed checkPeak (916-927), in order, straight into pinned host memory (the workgroup's peaks are packed in LDS and leave as one contiguous run of dwords: 64 consecutive dwords of a wavefront make a few full-size PCIe writes, a 28-byte record per lane seven small ones)
+__global__ __launch_bounds__(SW_NT) void k_peaks(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
+                                                 const u32* __restrict__ nHeads, u64* __restrict__ lb, u32 gen,
+                                                 gx_peak* __restrict__ peaks /* pinned host memory */, u32* __restrict__ nPeaks,
+                                                 u32* __restrict__ nPeaksHost, u32* __restrict__ st) {
   constexpr int PW = sizeof(gx_peak) / 4;
-  static_assert(sizeof(gx_peak) % 4 == 0, "gx_peak is a whole number of dwords");
   __shared__ u32 scratch[8];
   __shared__ u32 stage[RC_CHUNK * PW];
+  __shared__ u64 s_base;
   const u32 H = *nHeads;
-  if (blockIdx.x * RC_CHUNK >= H) return;
-  const u32 h = blockIdx.x * RC_CHUNK + threadIdx.x;
-  const u32 keep = h < H ? valid[h] : 0u;
-  u32 tot;
-  const u32 r = block_excl_scan<u32, SW_NT>(keep, scratch, &tot);
-  if (keep) {
-    const u32* src = reinterpret_cast<const u32*>(cand + h);
-#pragma unroll
-    for (int k = 0; k < PW; k++) stage[r * PW + k] = src[k];
+  const u32 nChunks = (H + RC_CHUNK - 1) / RC_CHUNK;
+  if (nChunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    *nPeaks = 0;
+    *nPeaksHost = 0;
   }
-  __syncthreads();
-  u32* dst = reinterpret_cast<u32*>(peaks + chunkOff[blockIdx.x]);
-  for (u32 i = threadIdx.x; i < tot * PW; i += SW_NT) dst[i] = stage[i];
+  for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
+    const u32 h = id * RC_CHUNK + threadIdx.x;
+    const u32 keep = h < H ? valid[h] : 0u;
+    u32 tot;
+    const u32 r = block_excl_scan<u32, SW_NT>(keep, scratch, &tot);
+    if (keep) {
+      const u32* src = reinterpret_cast<const u32*>(cand + h);
+#pragma unroll
+      for (int k = 0; k < PW; k++) stage[r * PW + k] = src[k];
+    }
+    if (threadIdx.x < 64) {
+      const u64 e = lookback_gen(lb, id, tot, gen, st);
+      if (threadIdx.x == 0) {
+        s_base = e;
+        if (id == nChunks - 1) {
+          *nPeaks = (u32)e + tot;
+          *nPeaksHost = (u32)e + tot;
+        }
+      }
+    }
+    __syncthreads();
+    u32* dst = reinterpret_cast<u32*>(peaks + (u32)s_base);
+    for (u32 i = threadIdx.x; i < tot * PW; i += SW_NT) dst[i] = stage[i];
+    __syncthreads();
+  }
 }
 
 }  // namespace gx
