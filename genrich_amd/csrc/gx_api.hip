@@ -610,7 +610,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   LooseCtl* ctl = ctx->looseCtl.as<LooseCtl>();
   HIPCHECK(ctx->tileSlot.ensure((size_t)(nTiles + 2) * 4));
   HIPCHECK(ctx->chromW0.ensure((size_t)(nChrom + 1) * 4));
-  HIPCHECK(ctx->chromLooseOff.ensure((size_t)(nChrom + 2) * 4));
+  HIPCHECK(pooled(ctx, ctx->chromLooseOff, (size_t)(nChrom + 2) * 4));  // (moves into the replicate's record: gx_pvalues)
   const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
   u64* sigMask = nullptr;
   if (wantEarly) {
@@ -1499,6 +1499,7 @@ int gx_reset(gx_ctx* ctx) {
   for (auto& pa : ctx->reps) {
     recycle(ctx, pa.end); recycle(ctx, pa.p); recycle(ctx, pa.expt); recycle(ctx, pa.ctrl);
     recycle(ctx, pa.chromOff); recycle(ctx, pa.q); recycle(ctx, pa.tileOff); recycle(ctx, pa.dPresent);
+    recycle(ctx, pa.chromLooseOff);
   }
   ctx->reps.clear();
   ctx->sample = 0;

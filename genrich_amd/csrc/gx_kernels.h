@@ -462,19 +462,34 @@ struct LooseCtl {
   u32 enabled;    // lambda was known before the tile stage
   u32 ok;         // the verdict for the host (k_frag_select): enabled, nothing bad, lambda unchanged
   u32 pad[4];
-  // 64 slots each (k_pval_lut's wavefronts spread over them: one word would take 8,192 same-address atomics)
-  u32 sigInv[64]; // max of (PV_LUT - V) over the significant table entries V (0: none)
-  u32 nonP1[64];  // max of (V + 1) over the others
+  // one slot per workgroup of k_pval_lut (plain stores: two contended words took 8,192 same-address atomics, 45 us)
+  u32 sigInv[PV_LUT / 256]; // max of (PV_LUT - V) over the workgroup's significant table entries V (0: none)
+  u32 nonP1[PV_LUT / 256];  // max of (V + 1) over the others
 };
 // pileups (1/120 units) from which an interval is significant; INT_MAX: the tile kernels write no bits.
-// Call with whole wavefronts (every lane reads one slot).
-__device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporter) {
-  if (!c || !c->enabled) return 0x7FFFFFFF;
-  u32 a = c->sigInv[lane_id()], b = c->nonP1[lane_id()];
+// Call with the whole workgroup (`red`: two words of LDS; contains a barrier).
+__device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporter, u32* __restrict__ red) {
+  if (!c || !c->enabled) return 0x7FFFFFFF;  // (block-uniform)
+  u32 a = 0, b = 0;
+  for (u32 i = threadIdx.x; i < PV_LUT / 256; i += blockDim.x) {
+    a = max(a, c->sigInv[i]);
+    b = max(b, c->nonP1[i]);
+  }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     a = max(a, (u32)__shfl_xor((int)a, d, 64));
     b = max(b, (u32)__shfl_xor((int)b, d, 64));
+  }
+  if (blockDim.x > 64) {
+    if (threadIdx.x < 2) red[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane_id() == 0) {
+      atomicMax(&red[0], a);
+      atomicMax(&red[1], b);
+    }
+    __syncthreads();
+    a = red[0];
+    b = red[1];
   }
   const u32 minSig = PV_LUT - a;
   if (minSig < b) {  // p(V) > thr is not a threshold on V: leave it to the general path
@@ -1303,7 +1318,8 @@ struct FragSelect {
   u64* brkLoose;             // the sweep's "first of its chromosome" mask in loose-slot index space (or null)
 };
 
-__device__ __forceinline__ void frag_select_body(const FragSelect& A) {
+// (ivIn / looseIn: LDS copies of chromIvOff / chromLooseOff to read from, or null)
+__device__ __forceinline__ void frag_select_body(const FragSelect& A, const u32* ivIn = nullptr, const u32* looseIn = nullptr) {
   const FragFix* ff = A.ff;
   long long* acc = A.acc;
   long long* coll = A.coll;
@@ -1319,8 +1335,8 @@ __device__ __forceinline__ void frag_select_body(const FragSelect& A) {
         A.chromIvOff[c] = next;
         A.chromLooseOff[c] = nextL;
       } else {
-        next = A.chromIvOff[c];
-        nextL = A.chromLooseOff[c];
+        next = ivIn ? ivIn[c] : A.chromIvOff[c];
+        nextL = looseIn ? looseIn[c] : A.chromLooseOff[c];
         if (A.brkLoose) A.brkLoose[nextL >> 6] |= 1ull << (nextL & 63);  // (this thread alone writes the mask)
       }
     }
@@ -1409,10 +1425,34 @@ __global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, con
 // `*closeState` = 2 (in the mail block) tells the host to run the separate kernels (k_frag_walk, k_frag_select, k_pval_lut, k_mail) after all.
 __global__ __launch_bounds__(64) void k_close(FragSelect A, const u32* __restrict__ nIv, const u32* __restrict__ extra,
                                               const RiskBuf* __restrict__ rb, MailOut m, u32* __restrict__ closeState, u32 seq) {
+  // (the single thread of k_frag_select walks ~90 dependent loads -- the 64 partial sums, the chromosome table: the
+  // wavefront fetches them side by side into LDS first, where the walk costs nothing)
+  __shared__ FragFix sff;
+  __shared__ DChrom schrom[64];
+  __shared__ u32 sIv[64], sLoose[64];
+  const bool small = A.nChrom <= 64;
+  if (threadIdx.x < FRAG_SLOTS) sff.fragSum[threadIdx.x] = A.ff->fragSum[threadIdx.x];
+  if (threadIdx.x == 0) {
+    sff.slow = A.ff->slow;
+    sff.nList = A.ff->nList;
+    sff.corr = A.ff->corr;
+  }
+  if (small && threadIdx.x < A.nChrom) {
+    schrom[threadIdx.x] = A.chroms[threadIdx.x];
+    sIv[threadIdx.x] = A.chromIvOff[threadIdx.x];
+    sLoose[threadIdx.x] = A.chromLooseOff[threadIdx.x];
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     u32 ok = 0;
-    if (!A.ff->slow && A.ff->nList == 0 && !A.coll) {
-      frag_select_body(A);
+    if (!sff.slow && sff.nList == 0 && !A.coll) {
+      FragSelect B = A;
+      B.ff = &sff;
+      if (small) {  // (entries of chromosomes with tiles are only read, the others only written: the copies serve)
+        B.chroms = schrom;
+        frag_select_body(B, sIv, sLoose);
+      } else
+        frag_select_body(B, nullptr, nullptr);
       ok = A.ctl->enabled && A.ctl->earlyBits == __float_as_uint(A.scal->lambda);
     }
     *closeState = ok ? 1u : 2u;  // (pinned host memory, ahead of the mail's fence and sequence number)

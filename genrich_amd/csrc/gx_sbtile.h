@@ -262,7 +262,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   const u32 seg = blockIdx.x, nSeg = in.nSeg;
   const u32 nT = 1u << in.sbShift;           // tiles per super-bucket (<= SBT_TILES)
   const u32 segTileBase = seg << in.sbShift;
-  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, blockIdx.x == 0 && tid == 0));
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, blockIdx.x == 0 && tid == 0, &L.work));  // (&L.work: two words)
   // scratch and tables start at zero
   for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
   if (tid < SBT_TILES) L.hist[tid] = 0;

@@ -52,12 +52,20 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
     lutP[v] = p;
     if (v % GX_UNIT == 0) lutP[PV_LUT + v / GX_UNIT] = p;  // the whole pileups once more, compact (the sweep's LDS copy)
     if (risky) risk_add(risk, RK_LUT, v, 0, 0, 0.0);
-    if (early && ctl) {  // (the grid covers the table once: v = this wavefront's first entry + lane)
+    if (early && ctl) {  // (the grid covers the table once: v = this wavefront's first entry + lane, one slot per workgroup)
+      __shared__ u32 red[2];
+      if (threadIdx.x < 2) red[threadIdx.x] = 0;
+      __syncthreads();
       const u64 sg = __ballot(p > thr);
       if (lane_id() == 0) {
-        const u32 v0 = v, slot = (v0 >> 6) & 63u;
-        if (sg) atomicMax(&ctl->sigInv[slot], PV_LUT - (v0 + (u32)__builtin_ctzll(sg)));
-        if (~sg) atomicMax(&ctl->nonP1[slot], v0 + (u32)(63 - __builtin_clzll(~sg)) + 1u);
+        const u32 v0 = v;
+        if (sg) atomicMax(&red[0], PV_LUT - (v0 + (u32)__builtin_ctzll(sg)));
+        if (~sg) atomicMax(&red[1], v0 + (u32)(63 - __builtin_clzll(~sg)) + 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        ctl->sigInv[blockIdx.x] = red[0];
+        ctl->nonP1[blockIdx.x] = red[1];
       }
     }
   }

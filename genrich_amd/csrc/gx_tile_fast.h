@@ -52,7 +52,8 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
   const u32 lb = xcd_local_block(blockIdx.x, G);
   u32 bad = 0;
   // pileups from which an interval is significant, when lambda was known before this kernel (LooseCtl)
-  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.ctl, blockIdx.x == 0 && lane == 0));
+  __shared__ u32 vsRed[2];
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.ctl, blockIdx.x == 0 && lane == 0, vsRed));
   // Software pipeline over this wavefront's tiles, with k_tile's discipline (loads and stores share the
   // in-order vmcnt): prefetches are issued right after a tile's stores and collected right before the
   // next tile's stores.
