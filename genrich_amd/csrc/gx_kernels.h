@@ -1337,7 +1337,8 @@ __device__ __forceinline__ void frag_select_body(const FragSelect& A, const u32*
       } else {
         next = ivIn ? ivIn[c] : A.chromIvOff[c];
         nextL = looseIn ? looseIn[c] : A.chromLooseOff[c];
-        if (A.brkLoose) A.brkLoose[nextL >> 6] |= 1ull << (nextL & 63);  // (this thread alone writes the mask)
+        // (one thread: a chain of read-modify-writes; k_close marks the starts with all its lanes instead)
+        if (A.brkLoose) A.brkLoose[nextL >> 6] |= 1ull << (nextL & 63);
       }
     }
   }
@@ -1448,6 +1449,7 @@ __global__ __launch_bounds__(64) void k_close(FragSelect A, const u32* __restric
     if (!sff.slow && sff.nList == 0 && !A.coll) {
       FragSelect B = A;
       B.ff = &sff;
+      B.brkLoose = nullptr;  // (the lanes mark the chromosome starts below)
       if (small) {  // (entries of chromosomes with tiles are only read, the others only written: the copies serve)
         B.chroms = schrom;
         frag_select_body(B, sIv, sLoose);
@@ -1457,6 +1459,13 @@ __global__ __launch_bounds__(64) void k_close(FragSelect A, const u32* __restric
     }
     *closeState = ok ? 1u : 2u;  // (pinned host memory, ahead of the mail's fence and sequence number)
   }
+  // the chromosomes' first loose slots in the sweep's mask (chromLooseOff of a chromosome with tiles: k_scan_iv's)
+  if (A.brkLoose)
+    for (u32 c = threadIdx.x; c < A.nChrom; c += 64)
+      if ((small ? schrom[c].tileBase : A.chroms[c].tileBase) != NULL_TILE) {
+        const u32 a = small ? sLoose[c] : A.chromLooseOff[c];
+        atomicOr((unsigned long long*)&A.brkLoose[a >> 6], 1ull << (a & 63));
+      }
   __syncthreads();
   mail_body(A.scal, A.st, A.hot, nIv, nullptr, extra, rb, m, seq);
 }

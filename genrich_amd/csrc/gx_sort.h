@@ -114,14 +114,21 @@ static_assert(S1_CHUNK <= (1 << PgCfg<u32>::SHIFT), "a chunk's run for one bin n
 constexpr u32 S1_STAGE_BYTES = S1_CHUNK * 4;  // a round's records: S1_CHUNK keys, or S1_CHUNK / 2 F records
 static_assert(S1_BPT == 2 || S1_BPT == 4, "two or four bins per thread");
 
+// The start keys and the end keys of a chunk go through level 1 TOGETHER (scatter_paged2): one set of barriers, one
+// round of cursor reservations in flight for both -- each stream on its own was a chain of eight barrier-separated
+// phases with a global atomic's round trip in the middle, in a kernel that runs one workgroup per CU.
+//   tabA[s]  per bin: the number of records of stream s, then (same words: the counts are dead once their owners have
+//            read them) the record index in the pool of the run's first record
+//   tabB[s]  per bin: [15:0] start of the run in the staged chunk, [31:16] records of it in its first page
+// (a run that crosses into a second page -- rare: a run is a few records, a page 8192 -- is finished by its OWNER
+// thread, so no table of second pages is kept.)  The single-stream rounds of the fractional records use the same
+// memory as hist / base0 / startSplit / base1.
 struct S1Lds {
-  u32 hist[MAX_BINS];
-  u32 startSplit[MAX_BINS];  // [15:0] start of the bin's run in the staged chunk, [31:16] records of it in its first page
-  u32 base0[MAX_BINS];       // record index (in the pool) of the run's first record
-  u32 base1[MAX_BINS];       // ... of its first record in the second page
+  u32 tabA[2][MAX_BINS];
+  u32 tabB[2][MAX_BINS];
   __attribute__((aligned(8))) u32 scratch[40];
-  u32 count;
-  __attribute__((aligned(16))) unsigned char stage[S1_STAGE_BYTES];
+  u32 count[2];
+  __attribute__((aligned(16))) unsigned char stage[2][S1_STAGE_BYTES];
 };
 
 // the page whose first slot the caller's run holds: allocate and publish
@@ -164,14 +171,18 @@ __device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStr
   constexpr u32 PG = 1u << SHIFT;
   static_assert((size_t)NR * S1_NT * sizeof(R) <= S1_STAGE_BYTES && (u32)NR * S1_NT <= PG, "one page holds a workgroup's records");
   const u32 x = blockIdx.x % NXCD;
-  R* stage = reinterpret_cast<R*>(L.stage);
-  for (int i = threadIdx.x; i < (int)nBins; i += S1_NT) L.hist[i] = 0;
+  R* stage = reinterpret_cast<R*>(L.stage[0]);
+  u32* const Lhist = L.tabA[0];
+  u32* const LstartSplit = L.tabB[0];
+  u32* const Lbase0 = L.tabA[1];
+  u32* const Lbase1 = L.tabB[1];
+  for (int i = threadIdx.x; i < (int)nBins; i += S1_NT) Lhist[i] = 0;
   __syncthreads();
   u32 rk[NR];
 #pragma unroll
   for (int k = 0; k < NR; k++) {
     const u32 t = RecT<R>::tile(rec[k]);
-    rk[k] = t != NULL_TILE ? atomicAdd(&L.hist[t >> sbShift], 1u) : 0u;
+    rk[k] = t != NULL_TILE ? atomicAdd(&Lhist[t >> sbShift], 1u) : 0u;
   }
   __syncthreads();
   {
@@ -182,7 +193,7 @@ __device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStr
 #pragma unroll
     for (int q = 0; q < S1_BPT; q++) {
       const u32 b = threadIdx.x + q * S1_NT;
-      cq[q] = b < nBins ? L.hist[b] : 0u;
+      cq[q] = b < nBins ? Lhist[b] : 0u;
       liq[q] = x * nBins + b;
       oq[q] = 0; j0q[q] = 0; in0q[q] = 0; split[q] = 0; base[q][0] = 0; base[q][1] = 0; rowq[q] = nullptr; need[q] = false;
     }
@@ -234,22 +245,22 @@ __device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStr
     for (int q = 0; q < S1_BPT; q++) {
       const u32 b = threadIdx.x + q * S1_NT;
       if (b < nBins) {
-        L.startSplit[b] = (before + (u32)((ex >> (16 * q)) & 0xFFFFu)) | (split[q] << 16);
-        L.base0[b] = base[q][0];
-        L.base1[b] = base[q][1];
+        LstartSplit[b] = (before + (u32)((ex >> (16 * q)) & 0xFFFFu)) | (split[q] << 16);
+        Lbase0[b] = base[q][0];
+        Lbase1[b] = base[q][1];
       }
       before += (u32)((tot >> (16 * q)) & 0xFFFFu);
     }
-    if (threadIdx.x == 0) L.count = before;
+    if (threadIdx.x == 0) L.count[0] = before;
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < NR; k++) {
     const u32 t = RecT<R>::tile(rec[k]);
-    if (t != NULL_TILE) stage[(L.startSplit[t >> sbShift] & 0xFFFFu) + rk[k]] = rec[k];
+    if (t != NULL_TILE) stage[(LstartSplit[t >> sbShift] & 0xFFFFu) + rk[k]] = rec[k];
   }
   __syncthreads();
-  const u32 cnt = L.count;
+  const u32 cnt = L.count[0];
   R* pool = reinterpret_cast<R*>(P.pool);
   // (a fixed, unrolled trip count: the LDS reads of all NR records are in flight together)
   R v[NR];
@@ -263,9 +274,9 @@ __device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStr
   for (int k = 0; k < NR; k++) {
     const u32 i = (u32)k * S1_NT + threadIdx.x;
     const u32 b = i < cnt ? RecT<R>::tile(v[k]) >> sbShift : 0u;
-    ss[k] = L.startSplit[b];
-    b0[k] = L.base0[b];
-    b1[k] = L.base1[b];
+    ss[k] = LstartSplit[b];
+    b0[k] = Lbase0[b];
+    b1[k] = Lbase1[b];
   }
 #pragma unroll
   for (int k = 0; k < NR; k++) {
@@ -273,6 +284,162 @@ __device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStr
     if (i < cnt) {
       const u32 r = i - (ss[k] & 0xFFFFu), sp = ss[k] >> 16;
       pool[r < sp ? b0[k] + r : b1[k] + (r - sp)] = v[k];
+    }
+  }
+  __syncthreads();
+}
+
+// The unit-weight start keys and end keys of a chunk, both streams at once (see S1Lds).
+template <int NR>
+__device__ __forceinline__ void scatter_paged2(const u32 (&recS)[NR], const u32 (&recE)[NR], const PagedStream& PS, const PagedStream& PE,
+                                               int sbShift, u32 nBins, S1Lds& L, u32* __restrict__ st) {
+  constexpr int SHIFT = PgCfg<u32>::SHIFT;
+  constexpr u32 PG = 1u << SHIFT;
+  static_assert((size_t)NR * S1_NT * 4 <= S1_STAGE_BYTES && (u32)NR * S1_NT <= PG, "one page holds a workgroup's records");
+  const u32 x = blockIdx.x % NXCD;
+  for (int i = threadIdx.x; i < (int)nBins; i += S1_NT) {
+    L.tabA[0][i] = 0;
+    L.tabA[1][i] = 0;
+  }
+  __syncthreads();
+  u32 rkS[NR], rkE[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    rkS[k] = recS[k] != NULL32 ? atomicAdd(&L.tabA[0][(recS[k] >> TB) >> sbShift], 1u) : 0u;
+    rkE[k] = recE[k] != NULL32 ? atomicAdd(&L.tabA[1][(recE[k] >> TB) >> sbShift], 1u) : 0u;
+  }
+  __syncthreads();
+  // thread t owns bins t, t + NT, t + 2 NT ... of both streams
+  u32 cq[2][S1_BPT], oq[2][S1_BPT];
+#pragma unroll
+  for (int sI = 0; sI < 2; sI++)
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) {
+      const u32 b = threadIdx.x + q * S1_NT;
+      cq[sI][q] = b < nBins ? L.tabA[sI][b] : 0u;
+      oq[sI][q] = 0;
+    }
+  // (all reservations of both streams in flight together)
+#pragma unroll
+  for (int sI = 0; sI < 2; sI++) {
+    const PagedStream& P = sI ? PE : PS;
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++)
+      if (cq[sI][q]) oq[sI][q] = atomicAdd(&P.cursor[x * nBins + threadIdx.x + q * S1_NT], cq[sI][q]);
+  }
+  // block scans of a thread's counts (each total <= 8192 < 2^16): 16-bit fields of one word per stream.  (Every owner
+  // has read its counts; the scans' barriers lie between those reads and the writes of the runs' bases into the same
+  // words below.)
+  static_assert(S1_BPT <= 4, "four 16-bit fields");
+#pragma unroll
+  for (int sI = 0; sI < 2; sI++) {
+    u64 packed = 0;
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) packed |= (u64)cq[sI][q] << (16 * q);
+    u64 tot;
+    const u64 ex = block_excl_scan<u64, S1_NT>(packed, reinterpret_cast<u64*>(L.scratch), &tot);
+    u32 before = 0;  // records of the lower bin groups
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) {
+      const u32 b = threadIdx.x + q * S1_NT;
+      if (b < nBins) {
+        const u32 split = min(cq[sI][q], PG - (oq[sI][q] & (PG - 1)));
+        L.tabB[sI][b] = (before + (u32)((ex >> (16 * q)) & 0xFFFFu)) | (split << 16);
+      }
+      before += (u32)((tot >> (16 * q)) & 0xFFFFu);
+    }
+    if (threadIdx.x == 0) L.count[sI] = before;
+  }
+  // Where the runs go.  Two passes, in this order for every lane of the wavefront: first everything this thread has to
+  // PUBLISH (the pages whose first slot its reservations hold), then the waiting for pages that others publish.  As
+  // one if / else the compiler may run the waiting lanes of a wavefront before its allocating lanes, and two
+  // wavefronts then wait for each other's allocators (seen on MI355X: spin limit).
+  u32 waitMask = 0;
+#pragma unroll
+  for (int sI = 0; sI < 2; sI++) {
+    const PagedStream& P = sI ? PE : PS;
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) {
+      const u32 c = cq[sI][q];
+      if (c) {
+        const u32 b = threadIdx.x + q * S1_NT, li = x * nBins + b, o = oq[sI][q], in0 = o & (PG - 1);
+        if (o + c <= PG) {  // the list's fixed first page (the common case): nothing to look up
+          L.tabA[sI][b] = (first_page(li) << SHIFT) + in0;
+        } else {
+          const u32 j0 = o >> SHIFT, j1 = (o + c - 1) >> SHIFT;
+          u32* row = P.pt + (size_t)li * P.jmax;
+          if (j1 != j0) (void)page_alloc(P, row, j1, st);  // (published in the table: its owner finds it there, below)
+          if (j0 == 0)
+            L.tabA[sI][b] = (first_page(li) << SHIFT) + in0;
+          else if (in0 == 0)
+            L.tabA[sI][b] = page_alloc(P, row, j0, st) << SHIFT;
+          else
+            waitMask |= 1u << (sI * S1_BPT + q);
+        }
+      }
+    }
+  }
+  if (waitMask) {
+#pragma unroll
+    for (int sI = 0; sI < 2; sI++) {
+      const PagedStream& P = sI ? PE : PS;
+#pragma unroll
+      for (int q = 0; q < S1_BPT; q++)
+        if (waitMask & (1u << (sI * S1_BPT + q))) {
+          const u32 b = threadIdx.x + q * S1_NT, li = x * nBins + b, o = oq[sI][q];
+          L.tabA[sI][b] = (page_wait(P, P.pt + (size_t)li * P.jmax, o >> SHIFT, st) << SHIFT) + (o & (PG - 1));
+        }
+    }
+  }
+  __syncthreads();
+  u32* stageS = reinterpret_cast<u32*>(L.stage[0]);
+  u32* stageE = reinterpret_cast<u32*>(L.stage[1]);
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    if (recS[k] != NULL32) stageS[(L.tabB[0][(recS[k] >> TB) >> sbShift] & 0xFFFFu) + rkS[k]] = recS[k];
+    if (recE[k] != NULL32) stageE[(L.tabB[1][(recE[k] >> TB) >> sbShift] & 0xFFFFu) + rkE[k]] = recE[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int sI = 0; sI < 2; sI++) {
+    const PagedStream& P = sI ? PE : PS;
+    const u32* stage = sI ? stageE : stageS;
+    u32* pool = reinterpret_cast<u32*>(P.pool);
+    const u32 cnt = L.count[sI];
+    // (a fixed, unrolled trip count: the LDS reads of all NR records are in flight together)
+    u32 v[NR], ss[NR], b0[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const u32 i = (u32)k * S1_NT + threadIdx.x;
+      v[k] = stage[i < cnt ? i : 0u];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const u32 i = (u32)k * S1_NT + threadIdx.x;
+      const u32 b = i < cnt ? (v[k] >> TB) >> sbShift : 0u;
+      ss[k] = L.tabB[sI][b];
+      b0[k] = L.tabA[sI][b];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const u32 i = (u32)k * S1_NT + threadIdx.x;
+      if (i < cnt) {
+        const u32 r = i - (ss[k] & 0xFFFFu), sp = ss[k] >> 16;
+        if (r < sp) pool[b0[k] + r] = v[k];  // (the part of a run beyond its first page: its owner, below)
+      }
+    }
+    // the owners of the runs that cross into a second page copy that part
+#pragma unroll
+    for (int q = 0; q < S1_BPT; q++) {
+      const u32 c = cq[sI][q], o = oq[sI][q];
+      if (c && ((o + c - 1) >> SHIFT) != (o >> SHIFT)) {  // rare
+        const u32 b = threadIdx.x + q * S1_NT, li = x * nBins + b, j1 = (o + c - 1) >> SHIFT;
+        const u32 split = PG - (o & (PG - 1)), start = L.tabB[sI][b] & 0xFFFFu;
+        // (this thread allocated that page and published it itself; past the table's end, or with the pool exhausted,
+        // the records go to the sink page 0 and ST_PT_FULL is up)
+        const u32 page = j1 < P.jmax ? __hip_atomic_load(&P.pt[(size_t)li * P.jmax + j1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u : 0u;
+        for (u32 k = split; k < c; k++) pool[(page << SHIFT) + (k - split)] = stage[start + k];
+      }
     }
   }
   __syncthreads();
@@ -289,10 +456,6 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
   // becomes an LDS look-up
   __shared__ DChrom lchrom[S1_LCHROM];
   const bool chromLds = nChrom <= (u32)S1_LCHROM;
-  if (chromLds) {
-    for (u32 i = threadIdx.x; i < nChrom; i += S1_NT) lchrom[i] = chroms[i];
-    __syncthreads();
-  }
   const u32 begin = blockIdx.x * S1_CHUNK;
   u32 bad = 0, frac = 0;
   u64 covered = 0;
@@ -310,6 +473,10 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
       const u32 i = begin + (k0 + q) * S1_NT + threadIdx.x;
       have[q] = i < n;
       e[q] = reinterpret_cast<const uint4*>(ev)[have[q] ? i : n - 1];  // chrom, start, end, count
+    }
+    if (k0 == 0 && chromLds) {  // (behind the first batch of event loads: the table's round trip rides along with theirs)
+      for (u32 i = threadIdx.x; i < nChrom; i += S1_NT) lchrom[i] = chroms[i];
+      __syncthreads();
     }
     if (chromLds) {  // block-uniform
 #pragma unroll
@@ -336,8 +503,7 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
     for (int k = 0; k < S1_ITEMS; k++) x ^= ks[k] ^ ke[k];
     if (x == 0xDEADBEEFu) atomicOr(st, 1u << 30);
   } else if (UNIT32) {
-    scatter_paged<u32, S1_ITEMS>(ks, PS, sbShift, nBins, L, st);
-    if (GX_EXP_S1 != 2) scatter_paged<u32, S1_ITEMS>(ke, PE, sbShift, nBins, L, st);
+    scatter_paged2<S1_ITEMS>(ks, ke, PS, PE, sbShift, nBins, L, st);
   }
   // fractional (or wide) records: rare, so the events are converted again (they are in L2) instead of being
   // kept in registers; two events = up to four records per thread and round
