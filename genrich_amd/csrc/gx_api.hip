@@ -73,6 +73,7 @@ struct HostMail {
   long long coll[4];   // this rank's / all ranks' {fragLen parts, saturation flag}
   u32 counts[64];      // BH records per rank (all-gather)
   u32 closeState;      // k_close: 1 the sample is closed, 2 the separate kernels have to run
+  u32 statusKeep;      // (host -> device: the status bits a repeated tile stage must keep)
   u32 seq;             // k_mail's last write (mail_sync polls it)
 };
 
@@ -482,7 +483,10 @@ int pack_pileup(gx_ctx* ctx, Pileup& P) {
 }
 
 // events -> tile-bucketed endpoint records -> run-length pileup (loose slots + offsets) and fragLen
-int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
+// reuseSort: the sample was built a moment ago and only its tile stage has to be done again on the general chain
+// (k_sbtile sent it back): level 1 of the sort -- the pages, the cursors, the closed form of fragLen -- is still
+// there, so k_sort1 does not run again and only what the first tile stage and the scans wrote is cleared.
+int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // (host-pushed events sit in the library's device chunks, device-resident segments are used in place)
   const std::vector<gx_ctx::Seg>& segs = ctx->segs;
   size_t n = 0;
@@ -551,7 +555,18 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
     ctx->lb.view(base, lbTBytes);      // k_scan_tiles' three look-back arrays
     base += lbTBytes;
     ctx->lbIv.view(base, lbIBytes);    // k_scan_iv's two
-    HIPCHECK(hipMemsetAsync(ctx->zeroArena.p, 0, total, s));
+    if (!reuseSort)
+      HIPCHECK(hipMemsetAsync(ctx->zeroArena.p, 0, total, s));
+    else {
+      // what the tile stage and the scans of the first attempt left: the per-tile tables and look-back arrays (the
+      // arena's tail), the loose-sweep block, the correction words of fragLen and the wide-tile count
+      char* tail = ctx->tileCnt[0].as<char>();
+      HIPCHECK(hipMemsetAsync(tail, 0, (size_t)(ctx->zeroArena.as<char>() + total - tail), s));
+      HIPCHECK(hipMemsetAsync(ctx->looseCtl.p, 0, ctlBytes, s));
+      FragFix* f0 = ctx->fragSum.as<FragFix>();
+      HIPCHECK(hipMemsetAsync(&f0->nList, 0, 12, s));   // nList, corr (the partial sums and the slow flag stay)
+      HIPCHECK(hipMemsetAsync(ctx->nWide.p, 0, 4, s));  // (word 1, the int16 flag of k_sort1, stays)
+    }
   }
   for (int q = 0; q < 3; q++) {
     HIPCHECK(ctx->str[q].sbOff.ensure((MAX_BINS + 2) * 4));
@@ -580,7 +595,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl) {
   }
   Sort1Out so1{ff->fragSum, slowFrag, ctx->endAtLen.as<u32>(), ctx->nWide.as<u32>() + 1};
   for (auto& seg : segs) {
-    if (!seg.n) continue;
+    if (!seg.n || reuseSort) continue;
     // (a piece that is still on its way from the host: the main stream waits for that copy only, so the
     // scatter of the pieces that have arrived overlaps the upload of the rest)
     if (seg.ready) HIPCHECK(hipStreamWaitEvent(s, seg.ready, 0));
@@ -964,8 +979,10 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
     HIPCHECK(hipMemsetAsync(isCtrl ? ds->ctrlAcc : ds->fragAcc, 0, 16, ctx->stream));
     return GX_OK;
   };
+  bool reuseSort = false;
   for (int attempt = 0; attempt < 12; attempt++) {
-    int rc = build_pileup(ctx, P, isCtrl);
+    int rc = build_pileup(ctx, P, isCtrl, reuseSort);
+    reuseSort = false;
     if (rc) {
       // With several ranks the others are about to wait for this one in the fragLen all-reduce: take part in it with a
       // "this rank has failed" word, so that every rank returns an error instead of one returning and the rest hanging.
@@ -976,8 +993,15 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
     }
     rc = finish_scalars(ctx, isCtrl);
     if (rc == RETRY_GENERAL) {
-      // k_sbtile could not take the sample (finish_scalars has switched it off for this one): the general chain
+      // k_sbtile could not take the sample (finish_scalars has switched it off for this one): the general chain,
+      // on the pages level 1 of the sort has already filled
       if (int w = wipe()) return w;
+      reuseSort = getenv("GX_NO_REUSE_SORT") == nullptr;
+      if (reuseSort) {
+        // (k_sort1 does not run again: the status bits IT raised -- bad counts, positions, chromosomes -- must survive)
+        ctx->mail->statusKeep = ctx->mail->status & ~(ST_SB_FULL | ST_SB_FRAC);
+        HIPCHECK(hipMemcpyAsync(ctx->dStatus.p, &ctx->mail->statusKeep, 4, hipMemcpyHostToDevice, ctx->stream));
+      }
     } else if (rc == RETRY_PT) {
       // a (XCD class, super-bucket) list needed more pages than its table row holds -- reads piled up in one
       // spot: what the first build left behind goes, the table grows, the sample is built again
