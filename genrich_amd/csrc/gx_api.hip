@@ -176,6 +176,7 @@ struct gx_ctx {
   bool sawFrac = false;         // a sample of this context held fractional weights: k_sbtile is not tried again
   bool fusedOff = false;        // this sample: a super-bucket did not fit k_sbtile (the general chain runs instead)
   bool fusedUsed = false;       // the last build went through k_sbtile
+  int fusedBackoff[2] = {0, 0}; // treatment / control samples for which k_sbtile is not tried (after one that did not fit)
   bool looseSwept = false;      // the last gx_find_peaks swept the loose slots
   DevBuf lbSweep, lbSweep2;     // look-back granules of the sweep's one-pass compactions (generation-tagged)
   u32 sweepGen = 0;
@@ -190,7 +191,7 @@ struct gx_ctx {
   DevBuf lbIv;
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3];
-  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, nWide, wideList;
+  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, nWide, wideList, heavyList;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};  // host copy of the device scalars (refreshed from the mail block)
@@ -566,6 +567,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       FragFix* f0 = ctx->fragSum.as<FragFix>();
       HIPCHECK(hipMemsetAsync(&f0->nList, 0, 12, s));   // nList, corr (the partial sums and the slow flag stay)
       HIPCHECK(hipMemsetAsync(ctx->nWide.p, 0, 4, s));  // (word 1, the int16 flag of k_sort1, stays)
+      HIPCHECK(hipMemsetAsync(ctx->nWide.as<u32>() + 2, 0, 4, s));
     }
   }
   for (int q = 0; q < 3; q++) {
@@ -615,7 +617,11 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
   // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
   const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
-  const bool fused = unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && !ctx->sawFrac && !ctx->fusedOff &&
+  // (a sample whose predecessor of the same kind did not fit is not even tried for a while: the same experiment's
+  // next replicate, or the next run on the same data, has the same pile-ups)
+  const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
+  if (backoff) ctx->fusedBackoff[isCtrl ? 1 : 0]--;
+  const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && !ctx->sawFrac && !ctx->fusedOff &&
                      !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 26000 &&
                      (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
   ctx->fusedUsed = fused;
@@ -701,11 +707,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
   HIPCHECK(ctx->tileMeta.ensure((size_t)(nTiles + 1) * sizeof(TileMeta)));
   HIPCHECK(ctx->wideList.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(ctx->heavyList.ensure((size_t)(nTiles + 1) * 4));
   if (!fused)
     hipLaunchKernelGGL(k_tile_meta, dim3((nTiles + 255) / 256), dim3(256), 0, s, ctx->tileOff[0].as<u32>(),
                        ctx->tileOff[1].as<u32>(), ctx->tileOff[2].as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
                        ctx->dChrom.as<DChrom>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, nTiles,
-                       ctx->tileMeta.as<TileMeta>(), ctx->wideList.as<u32>(), ctx->nWide.as<u32>(), ctx->tileSlot.as<u32>());
+                       ctx->tileMeta.as<TileMeta>(), ctx->wideList.as<u32>(), ctx->nWide.as<u32>(), ctx->tileSlot.as<u32>(),
+                       ctx->hasBed || getenv("GX_TILE_OLD") ? (u32*)nullptr : ctx->heavyList.as<u32>());
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");  // k_tile alone: the dominant kernel (bench.py's roofline)
@@ -736,6 +744,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     // alike (gx_tile_fast.h)
     hipLaunchKernelGGL(k_tile_fast, dim3(std::min<u32>(nTiles, (u32)ctx->resTileFast)), dim3(64), 0, s, tin, nTiles, nw, to,
                        ctx->dStatus.as<u32>());
+    // the tiles with thousands of records (pile-ups): a workgroup each, a counter per base (usually none: an idle launch)
+    hipLaunchKernelGGL(k_tile_heavy, dim3(64), dim3(TH_NT), 0, s, tin, ctx->heavyList.as<u32>(), nw + 2, to, ctx->dStatus.as<u32>());
   } else {
     hipLaunchKernelGGL((k_tile<false, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
@@ -898,6 +908,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     // k_sbtile could not take some rank's sample (a bin beyond its LDS, or fractional weights): once more, on the
     // general chain
     if (ctx->mail->status & ST_SB_FRAC) ctx->sawFrac = true;
+    if (ctx->mail->status & ST_SB_FULL) ctx->fusedBackoff[isCtrl ? 1 : 0] = 8;
     ctx->fusedOff = true;
     ctx->fellBack = true;
     static_cast<RiskBuf*>(ctx->riskHost.p)->count = 0;

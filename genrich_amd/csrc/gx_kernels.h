@@ -434,7 +434,11 @@ constexpr int TL_LDS = TILE + 64 + 2 * (TILE / 32); // ints: slice, scan scratch
 // records in a stream) or that hold fractional records are "wide" and go through the 32-bit variant.
 constexpr int TL_LDS_HALF = TILE / 2 + 64 + 2 * (TILE / 32);
 constexpr u32 TL_HALF_MAX = 32767;                // records per stream at which a tile turns wide
-constexpr u32 TM_ACTIVE = 1u, TM_LAST = 2u, TM_WIDE = 4u;  // TileMeta::flags
+constexpr u32 TM_ACTIVE = 1u, TM_LAST = 2u, TM_WIDE = 4u, TM_HEAVY = 8u;  // TileMeta::flags
+// A tile with more records than this is not walked by one wavefront (k_tile_fast spends ~3 passes of n / 64 steps
+// on a tile: a pile-up of 16,000 fragments in one place held the whole kernel for a millisecond) but by a workgroup
+// with a counter per base (k_tile_heavy).
+constexpr u32 HEAVY_MIN = 4096;
 constexpr int FRAG_FAST_MAXV = ((1 << 24) / (2 * TILE)) * GX_UNIT;  // len < 2 TILE and V below this: len * val < 2^24
 constexpr int V_MARK = (int)0x80000000;           // "pileup" of an interval inside an excluded (-E) region
 
@@ -564,7 +568,8 @@ __global__ __launch_bounds__(256) void k_tile_meta(const u32* __restrict__ offS,
                                                    const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
                                                    const u32* __restrict__ bedTileOff, u32 nTiles,
                                                    TileMeta* __restrict__ meta, u32* __restrict__ wideList,
-                                                   u32* __restrict__ nWide, u32* __restrict__ tileSlot) {
+                                                   u32* __restrict__ nWide, u32* __restrict__ tileSlot,
+                                                   u32* __restrict__ heavyList /* or null; its length: nWide[2] */) {
   // (the grid covers the tiles exactly once: every wavefront reaches the ballot below together)
   for (u32 t0 = blockIdx.x * 256; t0 < nTiles; t0 += gridDim.x * 256) {
     const u32 t = t0 + threadIdx.x;
@@ -582,7 +587,10 @@ __global__ __launch_bounds__(256) void k_tile_meta(const u32* __restrict__ offS,
     m.pos0 = tl << TB;
     m.len = c.len;
     wide = m.nF != 0 || m.nS >= TL_HALF_MAX || m.nE >= TL_HALF_MAX;
-    m.flags = (chrom_active(c) ? TM_ACTIVE : 0u) | (tl + 1 == c.nTiles ? TM_LAST : 0u) | (wide ? TM_WIDE : 0u);
+    const bool heavy = heavyList && (u64)m.nS + m.nE + m.nF > HEAVY_MIN;
+    m.flags = (chrom_active(c) ? TM_ACTIVE : 0u) | (tl + 1 == c.nTiles ? TM_LAST : 0u) | (wide ? TM_WIDE : 0u) |
+              (heavy ? TM_HEAVY : 0u);
+    if (heavy) heavyList[atomicAdd(nWide + 2, 1u)] = t;  // rare
     m.slot = m.sb + m.eb + m.fb + t + (bedTileOff ? bedTileOff[t] : 0u);  // <= records + edges + 1 intervals per tile
     meta[t] = m;
     tileSlot[t] = m.slot;
@@ -948,6 +956,102 @@ __global__ __launch_bounds__(256) void k_hot_check(TileIn in, const u32* __restr
     for (int j = threadIdx.x; j < TILE; j += 256) h |= ws[j] >= HOT16 || we[j] >= HOT16;
     if (h) atomicOr(hot, 1u);
     __syncthreads();
+  }
+}
+
+// ---- heavy tiles: one WORKGROUP per tile, a counter per base (the general chain's tile stage, after k_tile_fast) ----
+// The reference's own formulation on one tile (savePileupExpt 2197-2273): difference array -> prefix sum ->
+// run-length intervals, with the array (16 KB) in LDS.  Each thread owns four consecutive bases.
+constexpr int TH_NT = 1024;
+__global__ __launch_bounds__(TH_NT) void k_tile_heavy(TileIn in, const u32* __restrict__ heavyList, const u32* __restrict__ nHeavy,
+                                                      TileOut out, u32* __restrict__ st) {
+  static_assert(TILE == 4 * TH_NT, "four bases per thread");
+  __shared__ int delta[TILE];
+  __shared__ u32 scratch[40];
+  __shared__ u32 vsRed[2];
+  __shared__ u32 sLast;
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.ctl, false, vsRed));
+  const u32 nH = *nHeavy;
+  for (u32 it = blockIdx.x; it < nH; it += gridDim.x) {
+    const u32 t = heavyList[it];
+    const TileMeta m = in.meta[t];
+    __syncthreads();
+    *reinterpret_cast<int4*>(delta + 4 * threadIdx.x) = make_int4(0, 0, 0, 0);
+    if (threadIdx.x == 0) sLast = 0;
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < m.nS; k += TH_NT) atomicAdd(&delta[in.S[m.sb + k]], GX_UNIT);
+    for (u32 k = threadIdx.x; k < m.nE; k += TH_NT) atomicAdd(&delta[in.E[m.eb + k]], -GX_UNIT);
+    for (u32 k = threadIdx.x; k < m.nF; k += TH_NT) {
+      const u64 r = in.F[m.fb + k];
+      atomicAdd(&delta[(u32)(r >> 8) & (TILE - 1)], (int)(int8_t)(r & 0xFF));
+    }
+    __syncthreads();
+    const bool active = m.flags & TM_ACTIVE, lastTile = (m.flags & TM_LAST) != 0;
+    const int4 d4 = *reinterpret_cast<const int4*>(delta + 4 * threadIdx.x);
+    const int d[4] = {d4.x, d4.y, d4.z, d4.w};
+    u32 nzc = 0;
+    int dsum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      dsum += d[k];
+      nzc += (u32)(d[k] != 0 && active && (m.pos0 + 4 * threadIdx.x + k != 0));
+    }
+    // the pileup before the thread's first base, and its output rank
+    int dtot;
+    const int dex = block_excl_scan<int, TH_NT>(dsum, reinterpret_cast<int*>(scratch), &dtot);
+    u32 total;
+    const u32 oex = block_excl_scan<u32, TH_NT>(nzc, scratch, &total);
+    int run = m.carry + dex;
+    u32 o = m.slot + oex;
+    u32 neg = 0, big = (u32)(m.carry >= FRAG_FAST_MAXV), last = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 pos = m.pos0 + 4 * threadIdx.x + k;
+      if (d[k] != 0 && active && pos != 0) {   // 2241: base 0 closes nothing
+        out.looseEnd[o] = pos;
+        out.looseV[o] = run;                   // the pileup of the interval that ends here (2244)
+        if (run >= vsig) atomicOr((unsigned long long*)&out.sigMask[o >> 6], 1ull << (o & 63));
+        o++;
+        last = pos;
+      }
+      run += d[k];
+      neg |= (u32)(run < 0);
+      big |= (u32)(run >= FRAG_FAST_MAXV);
+    }
+    if (last) atomicMax(&sLast, last);
+    const u32 flagsW = (u32)__syncthreads_or((int)(neg | (big << 1)));
+    u32 lastEnd = sLast, all = total;
+    if (active) {
+      if (lastTile) {  // closing interval [.., len): 2268-2273
+        const int runEnd = m.carry + dtot;
+        if (threadIdx.x == 0) {
+          const u32 oc = m.slot + total;
+          out.looseEnd[oc] = m.len;
+          out.looseV[oc] = runEnd;
+          if (runEnd >= vsig) atomicOr((unsigned long long*)&out.sigMask[oc >> 6], 1ull << (oc & 63));
+        }
+        lastEnd = m.len;
+        all = total + 1;
+      }
+      if (threadIdx.x == 0) {
+        if (all) out.tileLastEnd[t] = lastEnd;
+        if (flagsW & 1u) atomicOr(st, ST_NEG_PILE);
+        if (flagsW & 2u) {
+          atomicOr(&out.tileDeep[t], 1u);
+          if (out.ctl) atomicOr(&out.ctl->bad, 1u);
+        }
+      }
+    } else
+      all = 0;
+    if (threadIdx.x == 0) out.tileCount[t] = all;
+    // (unused slots: zero-length intervals behind the last one, for the sweep on the loose slots)
+    if (all && vsig != 0x7FFFFFFF) {
+      const u32 size = m.nS + m.nE + m.nF + 1;
+      for (u32 j = all + threadIdx.x; j < size; j += TH_NT) {
+        out.looseEnd[m.slot + j] = lastEnd;
+        out.looseV[m.slot + j] = 0;
+      }
+    }
   }
 }
 

@@ -76,6 +76,8 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
     m.nE = uni(r.b.x); m.nF = uni(r.b.y); m.carry = (int)uni(r.b.z); m.ci = 0;
     m.pos0 = uni(r.c.x); m.len = uni(r.c.y); m.flags = uni(r.c.z); m.slot = uni(r.c.w);
     if (i >= nTiles) { m.nS = 0; m.nE = 0; m.nF = 0; m.flags = 0; }
+    // (a heavy tile is k_tile_heavy's: here it looks empty and inactive -- its count, written as zero, is overwritten there)
+    if (m.flags & TM_HEAVY) { m.nS = 0; m.nE = 0; m.nF = 0; m.flags &= ~TM_ACTIVE; }
     return m;
   };
   auto keyOf = [&](const uint16_t* K, u32 kb, u32 nk, u32 flags) -> Keys {
