@@ -1010,7 +1010,9 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
       reuseSort = getenv("GX_NO_REUSE_SORT") == nullptr;
       if (reuseSort) {
         // (k_sort1 does not run again: the status bits IT raised -- bad counts, positions, chromosomes -- must survive)
-        ctx->mail->statusKeep = ctx->mail->status & ~(ST_SB_FULL | ST_SB_FRAC);
+        // (and only those: what the abandoned tile stage raised -- e.g. "negative pileup" from carries that count the
+        // dropped ends of fractional records it never saw -- means nothing)
+        ctx->mail->statusKeep = ctx->mail->status & (ST_BAD_CHROM | ST_BAD_POS | ST_BAD_COUNT | ST_PT_FULL | ST_LOOKBACK);
         HIPCHECK(hipMemcpyAsync(ctx->dStatus.p, &ctx->mail->statusKeep, 4, hipMemcpyHostToDevice, ctx->stream));
       }
     } else if (rc == RETRY_PT) {
