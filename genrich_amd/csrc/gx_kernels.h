@@ -1019,7 +1019,8 @@ __global__ __launch_bounds__(TH_NT) void k_tile_heavy(TileIn in, const u32* __re
       big |= (u32)(run >= FRAG_FAST_MAXV);
     }
     if (last) atomicMax(&sLast, last);
-    const u32 flagsW = (u32)__syncthreads_or((int)(neg | (big << 1)));
+    // (__syncthreads_or answers "any non-zero?", not a bitwise or: one call per flag)
+    const u32 flagsW = (__syncthreads_or((int)neg) ? 1u : 0u) | (__syncthreads_or((int)big) ? 2u : 0u);
     u32 lastEnd = sLast, all = total;
     if (active) {
       if (lastTile) {  // closing interval [.., len): 2268-2273
