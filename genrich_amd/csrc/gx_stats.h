@@ -938,6 +938,9 @@ __device__ __forceinline__ u32 row_max_u(u32 v) {
 // (round 1) paid n / 32 round trips AND ran every updatePeak serially (a 1,000-interval candidate held its
 // wavefront for ~100 us, which is what the kernel took).
 constexpr int PK_AHEAD = 4;
+#ifndef GX_PK_AHEAD_V
+#define GX_PK_AHEAD_V 8
+#endif
 // PV: `p` is the table p(V) and `q` (reinterpreted) the intervals' exact pileups V -- the sweep on the loose slots.
 // (that sweep only runs on unit-weight samples whose pileups all lie within the table -- LooseCtl::bad otherwise --, so
 // every V is 120 x a whole pileup below PV_WHOLE: the table's compact copy, lut + PV_LUT, sits in LDS)
@@ -956,6 +959,7 @@ __device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, c
                                                 const u32* __restrict__ chromOff, u32 nChrom,
                                                 const u32* __restrict__ nCands, float thr, float minAUC, int minLen,
                                                 gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  constexpr int AH = PV ? GX_PK_AHEAD_V : PK_AHEAD;  // steps of loads in flight (the loose-slot walk adds an LDS look-up per step)
   const u32 C = *nCands;
   const int lane = lane_id(), rowBase = lane & 48, rl = lane & 15;
   const u32 rowId = (blk * 4 + (threadIdx.x >> 6)) * 4 + (u32)(lane >> 4);  // 16 rows per workgroup
@@ -971,12 +975,12 @@ __device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, c
     steps = max(steps, (u32)__shfl_xor((int)steps, 32, 64));  // the wavefront's longest candidate
     float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
     u32 summitPos = 0, summitLen = 0;
-    for (u32 st0 = 0; st0 < steps; st0 += PK_AHEAD) {
-      u32 e[PK_AHEAD], sPrev[PK_AHEAD];
-      float pv[PK_AHEAD], qv[PK_AHEAD];
-      bool in[PK_AHEAD];
+    for (u32 st0 = 0; st0 < steps; st0 += AH) {
+      u32 e[AH], sPrev[AH];
+      float pv[AH], qv[AH];
+      bool in[AH];
 #pragma unroll
-      for (int a = 0; a < PK_AHEAD; a++) {
+      for (int a = 0; a < AH; a++) {
         const u32 i = i0 + (st0 + a) * 16 + rl;
         in[a] = mine && i <= i1;
         e[a] = 0; sPrev[a] = 0; pv[a] = 0.0f; qv[a] = GX_SKIPF;
@@ -989,7 +993,7 @@ __device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, c
         }
       }
 #pragma unroll
-      for (int a = 0; a < PK_AHEAD; a++) {
+      for (int a = 0; a < AH; a++) {
         if (st0 + a >= steps) break;  // wave-uniform
         float pq = USEQ ? qv[a] : pv[a];
         const bool sg = in[a] && pq > thr;  // non-significant intervals inside the span only fill gaps
@@ -1035,7 +1039,7 @@ __device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, c
 }
 
 // one wavefront per candidate: updatePeak (943-970) over its intervals, then checkPeak (916-927).  64 intervals
-// per step, PK_AHEAD steps of loads in flight; the ordered float sum runs row after row (16 dependent DPP adds
+// per step, AH steps of loads in flight; the ordered float sum runs row after row (16 dependent DPP adds
 // each, the running value carried from row to row by a readlane); maxima by DPP rotations inside the rows and
 // readlanes across them: no LDS shuffle anywhere.
 template <bool PV>
@@ -1046,6 +1050,7 @@ __device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, co
                                                const u32* __restrict__ longList, const u32* __restrict__ nLong,
                                                float thr, float minAUC, int minLen,
                                                gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+  constexpr int AH = PV ? GX_PK_AHEAD_V : PK_AHEAD;
   const float* __restrict__ q = PV ? nullptr : qIn;
   const u32 L = *nLong;
   const u32 wavesPerGrid = nBlk * 4;
@@ -1057,12 +1062,12 @@ __device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, co
     const u32 i0 = h.x, i1 = h.y, peakStart = h.z;
     float auc = 0.0f, summitVal = -1.0f, sp = -1.0f, sq = -1.0f;
     u32 summitPos = 0, summitLen = 0;
-    for (u32 base = i0; base <= i1; base += 64 * PK_AHEAD) {
-      u32 e[PK_AHEAD], sPrev[PK_AHEAD];
-      float pv[PK_AHEAD], qv[PK_AHEAD];
-      bool in[PK_AHEAD];
+    for (u32 base = i0; base <= i1; base += 64 * AH) {
+      u32 e[AH], sPrev[AH];
+      float pv[AH], qv[AH];
+      bool in[AH];
 #pragma unroll
-      for (int a = 0; a < PK_AHEAD; a++) {
+      for (int a = 0; a < AH; a++) {
         const u32 i = base + a * 64 + lane;
         in[a] = i <= i1;
         e[a] = 0; sPrev[a] = 0; pv[a] = 0.0f; qv[a] = GX_SKIPF;
@@ -1075,7 +1080,7 @@ __device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, co
         }
       }
 #pragma unroll
-      for (int a = 0; a < PK_AHEAD; a++) {
+      for (int a = 0; a < AH; a++) {
         if (base + a * 64 > i1) break;  // wave-uniform
         float pq = q ? qv[a] : pv[a];
         const bool sg = in[a] && pq > thr;       // non-significant intervals inside the span only fill gaps
