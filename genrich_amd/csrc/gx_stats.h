@@ -939,7 +939,7 @@ __device__ __forceinline__ u32 row_max_u(u32 v) {
 // wavefront for ~100 us, which is what the kernel took).
 constexpr int PK_AHEAD = 4;
 #ifndef GX_PK_AHEAD_V
-#define GX_PK_AHEAD_V 8
+#define GX_PK_AHEAD_V 4
 #endif
 // PV: `p` is the table p(V) and `q` (reinterpreted) the intervals' exact pileups V -- the sweep on the loose slots.
 // (that sweep only runs on unit-weight samples whose pileups all lie within the table -- LooseCtl::bad otherwise --, so
