@@ -756,7 +756,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   phase_end(ctx);
   // (word 1 of the nWide block: the "a base can reach the int16 limits" flag, also set by k_convert)
   // (a bin that fits k_sbtile holds fewer than 32,767 records of a stream: no base of it can reach the limits)
-  if (!fused) hipLaunchKernelGGL(k_hot_check, dim3(std::min<u32>(nTiles, 256u)), dim3(256), 0, s, tin, wl, nw, ctx->nWide.as<u32>() + 1);
+  // (a tile that can hold such a base has >= 32,766 records: it is on the list of the heavy tiles -- walking the list of
+  // the WIDE tiles instead cost config 4, where every tile holds fractional records and is "wide", 2.1 ms of header reads)
+  if (!fused) {
+    const bool haveHeavy = !(ctx->hasBed || getenv("GX_TILE_OLD"));
+    hipLaunchKernelGGL(k_hot_check, dim3(std::min<u32>(nTiles, 256u)), dim3(256), 0, s, tin, haveHeavy ? ctx->heavyList.as<u32>() : wl,
+                       haveHeavy ? nw + 2 : nw, ctx->nWide.as<u32>() + 1);
+  }
   if (int rc__ = dbg_sync(ctx, "k_hot_check")) return rc__;
 
   phase_begin(ctx, isCtrl ? "c.pack" : "t.pack");
