@@ -91,7 +91,7 @@ struct PinnedBuf {
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 4 + 4096;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocCoherent);  // (fine-grained: the kernels write mail and peaks into it while the host polls)
     if (e == hipSuccess) {
       cap = want;
       e = hipHostGetDevicePointer(&dp, p, 0);
@@ -182,6 +182,8 @@ struct gx_ctx {
   u32 sweepGen = 0;
   FragSelect closeSel{};        // the sample's k_frag_select arguments (k_close took them; finish_scalars may need them again)
   u32 closeSeq = 0;             // sequence number of the mail k_close sends (0: the separate kernels were launched)
+  bool beginPending = false;    // gx_sample_begin's clearing of the scalars is still to be done (k_build_init / flush_begin)
+  u64 beginGenome = 0;
   bool fellBack = false;        // some sample was sent back from k_sbtile to the general chain
   bool looseOk = false;         // the treatment sample's tile stage left valid sweep bits on the loose slots
   bool riskNearThr = false;     // a re-evaluated table entry lies next to the significance threshold
@@ -483,6 +485,14 @@ int pack_pileup(gx_ctx* ctx, Pileup& P) {
   return GX_OK;
 }
 
+// gx_sample_begin's clearing of the replicate's scalars, when no k_build_init is going to do it
+int flush_begin(gx_ctx* ctx) {
+  if (!ctx->beginPending) return GX_OK;
+  hipLaunchKernelGGL(k_begin_sample, dim3(1), dim3(64), 0, ctx->stream, ctx->dScal.as<Scalars>(), ctx->beginGenome);
+  ctx->beginPending = false;
+  return GX_OK;
+}
+
 // events -> tile-bucketed endpoint records -> run-length pileup (loose slots + offsets) and fragLen
 // reuseSort: the sample was built a moment ago and only its tile stage has to be done again on the general chain
 // (k_sbtile sent it back): level 1 of the sort -- the pages, the cursors, the closed form of fragLen -- is still
@@ -520,7 +530,22 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   poolPages[0] = poolPages[1] = (u32)(nEv >> PgCfg<u32>::SHIFT) + NXCD * nL1 + 4;
   poolPages[2] = (u32)(((size_t)2 * nEv) >> PgCfg<u64>::SHIFT) + NXCD * nL1 + 4;
   for (int q = 0; q < 3; q++) HIPCHECK(ctx->str[q].pool.ensure((size_t)poolPages[q] * PG_BYTES));
-  // everything that must start at zero lives in one arena: one memset per sample
+  // lambda ahead of the tile stage (closed form of fragLen; LooseCtl): one rank, a treatment sample, -p
+  static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
+  const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
+  const bool multiRank = ctx->world > 1 || ctx->forceColl;
+  const bool wantEarly = !isCtrl && !multiRank && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag;
+  const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
+  u64* sigMask = nullptr;
+  if (wantEarly) {
+    // the sweep's masks in loose-slot index space: [significant | first of its chromosome]
+    ctx->looseStride = (looseCap + 63) / 64 + 2;
+    HIPCHECK(ctx->swMask.ensure(ctx->looseStride * 8 * 3));
+    sigMask = ctx->swMask.as<u64>();
+    ctx->maskIdx = -1;
+  }
+  // everything that must start at zero lives in one arena: one launch per sample clears it (k_build_init: with the
+  // sweep's masks and the replicate's scalars)
   const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
   {
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -556,9 +581,16 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     ctx->lb.view(base, lbTBytes);      // k_scan_tiles' three look-back arrays
     base += lbTBytes;
     ctx->lbIv.view(base, lbIBytes);    // k_scan_iv's two
-    if (!reuseSort)
-      HIPCHECK(hipMemsetAsync(ctx->zeroArena.p, 0, total, s));
-    else {
+    if (!reuseSort) {
+      const size_t nA = total / 16, nB = wantEarly ? ctx->looseStride * 8 * 2 / 16 : 0;
+      static_assert(sizeof(Scalars) / 8 <= 256, "one workgroup clears the scalars");
+      hipLaunchKernelGGL(k_build_init, dim3((u32)std::min<size_t>((nA + nB + 1023) / 1024, 4096)), dim3(256), 0, s,
+                         ctx->dScal.as<Scalars>(), ctx->beginPending ? 1 : 0, ctx->beginGenome, ctx->zeroArena.as<uint4>(), nA,
+                         wantEarly ? ctx->swMask.as<uint4>() : (uint4*)nullptr, nB);
+      ctx->beginPending = false;
+    } else {
+      if (int rc__ = flush_begin(ctx)) return rc__;
+      if (wantEarly) HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, ctx->looseStride * 8 * 2, s));
       // what the tile stage and the scans of the first attempt left: the per-tile tables and look-back arrays (the
       // arena's tail), the loose-sweep block, the correction words of fragLen and the wide-tile count
       char* tail = ctx->tileCnt[0].as<char>();
@@ -584,7 +616,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
 
   phase_begin(ctx, isCtrl ? "c.sort1" : "t.sort1");
   // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
-  static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
   HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
   FragFix* ff = ctx->fragSum.as<FragFix>();
   u32* slowFrag = &ff->slow;
@@ -616,7 +647,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- unit weights, no -E regions, at most
   // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
   // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
-  const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
   // (a sample whose predecessor of the same kind did not fit is not even tried for a while: the same experiment's
   // next replicate, or the next run on the same data, has the same pile-ups)
   const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
@@ -625,32 +655,20 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                      !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 26000 &&
                      (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
   ctx->fusedUsed = fused;
-  // lambda ahead of the tile stage (closed form of fragLen; LooseCtl): one rank, a treatment sample, -p
-  const bool multiRank = ctx->world > 1 || ctx->forceColl;
-  const bool wantEarly = !isCtrl && !multiRank && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag;
   LooseCtl* ctl = ctx->looseCtl.as<LooseCtl>();
   HIPCHECK(ctx->tileSlot.ensure((size_t)(nTiles + 2) * 4));
   HIPCHECK(ctx->chromW0.ensure((size_t)(nChrom + 1) * 4));
   HIPCHECK(pooled(ctx, ctx->chromLooseOff, (size_t)(nChrom + 2) * 4));  // (moves into the replicate's record: gx_pvalues)
-  const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
-  u64* sigMask = nullptr;
-  if (wantEarly) {
-    // the sweep's masks in loose-slot index space: [significant | first of its chromosome]
-    ctx->looseStride = (looseCap + 63) / 64 + 2;
-    HIPCHECK(ctx->swMask.ensure(ctx->looseStride * 8 * 3));
-    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, ctx->looseStride * 8 * 2, s));
-    sigMask = ctx->swMask.as<u64>();
-    ctx->maskIdx = -1;
-  }
   phase_begin(ctx, isCtrl ? "c.bucket" : "t.bucket");
   {
     BinScan bs{{SS.cursor.as<u32>(), SE.cursor.as<u32>(), SF.cursor.as<u32>()}, {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()},
                ctx->endAtLen.as<u32>(), ctx->chromW0.as<int>(), nChrom, ff, ctx->dScal.as<Scalars>(), ctl, wantEarly ? 1 : 0};
-    hipLaunchKernelGGL(k_scan_bins, dim3(4), dim3(1024), 0, s, bs, nL1);
-    if (wantEarly)  // the table p(V) for that lambda, and from which pileup on an interval is significant
-      hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256), dim3(256), 0, s, ctx->dScal.as<Scalars>(), ctx->pvLut.as<float>(),
-                         ctx->dRisk.as<RiskBuf>(), ctx->dDeep.as<DeepTab>(), PackIn{}, ff, ctx->fragList.as<u32>(), ctl, 1,
-                         ctx->par.thr);
+    static_assert(PV_LUT % 1024 == 0, "k_bins_lut: four of k_pval_lut's workgroups per block");
+    if (wantEarly)  // with the table p(V) for that lambda, and from which pileup on an interval is significant
+      hipLaunchKernelGGL(k_bins_lut, dim3(4 + PV_LUT / 1024), dim3(1024), 0, s, bs, nL1, ctx->pvLut.as<float>(),
+                         ctx->dRisk.as<RiskBuf>(), ctx->dDeep.as<DeepTab>(), ctx->par.thr, ctx->dStatus.as<u32>());
+    else
+      hipLaunchKernelGGL(k_scan_bins, dim3(4), dim3(1024), 0, s, bs, nL1);
   }
   if (!fused) {
     // level 2: one workgroup per super-bucket
@@ -770,10 +788,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   IvScanOut so{out.tileIvOff.as<u32>(), ctx->tilePrevEnd.as<u32>(), out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV,
                ctx->tileSlot.as<u32>(), ctx->chromLooseOff.as<u32>(), ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctl,
                ctx->tileDeep.as<u32>(), ff, ctx->fragList.as<u32>()};
-  hipLaunchKernelGGL(k_scan_iv, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
-                     ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
-                     ctx->dChrom.as<DChrom>(), nTiles, ctx->lbIv.as<u64>(), ctx->lbIv.as<u64>() + ivChunks + 1, so,
-                     ctx->dStatus.as<u32>());
+  static const bool noClose = getenv("GX_NO_CLOSE") != nullptr, sepClose = getenv("GX_SEPARATE_CLOSE") != nullptr;
+  const bool closeInScan = wantEarly && !noClose && !sepClose;  // (k_scan_iv_close, below)
+  if (!closeInScan)
+    hipLaunchKernelGGL(k_scan_iv, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
+                       ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
+                       ctx->dChrom.as<DChrom>(), nTiles, ctx->lbIv.as<u64>(), ctx->lbIv.as<u64>() + ivChunks + 1, so,
+                       ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_scan_iv")) return rc__;
   {
     const u32* lE = ctx->looseEnd.as<u32>();
@@ -788,7 +809,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                     wantEarly ? ctx->swMask.as<u64>() + ctx->looseStride : (u64*)nullptr};
     ctx->closeSel = fsel;
     ctx->closeSeq = 0;
-    static const bool noClose = getenv("GX_NO_CLOSE") != nullptr;
     if (wantEarly && !noClose) {
       // lambda was known before the tile stage: k_frag_select's work and the mail in one launch (k_close); if a deep tile,
       // the general fragLen path or a changed lambda stands in the way, finish_scalars runs the separate kernels after all
@@ -796,8 +816,17 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       ctx->mail->nMerged = 0;
       ctx->mail->closeState = 0;
       HostMail* dm = static_cast<HostMail*>(ctx->mailBuf.dp);
-      hipLaunchKernelGGL(k_close, dim3(1), dim3(64), 0, s, fsel, ctx->misc.as<u32>() + M_NIV, (const u32*)&ctl->ok,
-                         ctx->dRisk.as<RiskBuf>(), mail_out(ctx), &dm->closeState, ctx->closeSeq);
+      if (closeInScan) {
+        // (the scan's last workgroup closes the sample: one launch)
+        CloseArgs ca{fsel, ctx->misc.as<u32>() + M_NIV, (const u32*)&ctl->ok, ctx->dRisk.as<RiskBuf>(), mail_out(ctx),
+                     &dm->closeState, ctx->closeSeq, ctx->nWide.as<u32>() + 8};
+        hipLaunchKernelGGL(k_scan_iv_close, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
+                           ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
+                           ctx->dChrom.as<DChrom>(), nTiles, ctx->lbIv.as<u64>(), ctx->lbIv.as<u64>() + ivChunks + 1, so,
+                           ctx->dStatus.as<u32>(), ca);
+      } else
+        hipLaunchKernelGGL(k_close, dim3(1), dim3(64), 0, s, fsel, ctx->misc.as<u32>() + M_NIV, (const u32*)&ctl->ok,
+                           ctx->dRisk.as<RiskBuf>(), mail_out(ctx), &dm->closeState, ctx->closeSeq);
       if (int rc__ = dbg_sync(ctx, "k_close")) return rc__;
     } else {
     hipLaunchKernelGGL(k_frag_walk, dim3(std::max(1u, std::min((nTiles + 3) / 4, 4096u))), dim3(256), 0, s, lE, lV, tm, tOff,
@@ -1233,12 +1262,14 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
 #undef GX_LAUNCH_PEAKS
       }
       // the peaks, in order, into pinned host memory; their number with them
+      const u32 seq = ++ctx->mailSeq;
       hipLaunchKernelGGL(k_peaks, dim3(std::min<u32>(rChunks, gridP)), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
                          misc + M_NHEADS, lbP, gen, static_cast<gx_peak*>(ctx->hPeaks.dp), misc + M_NPEAKS, &dm->nPeaks,
-                         ctx->dStatus.as<u32>());
+                         ctx->dStatus.as<u32>(), misc + M_TICKET4, reinterpret_cast<u64*>(misc + M_PEAKBP), reinterpret_cast<u64*>(&dm->peakBP),
+                         ctx->dRisk.as<RiskBuf>(), mail_out(ctx), seq);
       if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
-      // the end: status, counts (and whatever else is pending) through the mail kernel, one synchronisation
-      if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
+      // the end: status and counts came with k_peaks' last workgroup (the mail), one synchronisation
+      if (int rc__ = mail_wait(ctx, seq)) return rc__;
       R = ctx->mail->R;
       ctx->runSeen = R;
       if (R <= cap) break;
@@ -1254,10 +1285,7 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
   }
   if (R) nPeaks = ctx->mail->nPeaks;
   ctx->nHostPeaks = nPeaks;
-  const gx_peak* hp = static_cast<const gx_peak*>(ctx->hPeaks.p);
-  uint64_t bp = 0;
-  for (u32 i = 0; i < nPeaks; i++) bp += hp[i].end - hp[i].start;  // peakBP (callPeaks 925)
-  ctx->peakBP = bp;
+  ctx->peakBP = R ? ctx->mail->peakBP : 0;  // (callPeaks 925: summed by k_peaks)
   *nPeaksOut = nPeaks;
   return status_to_rc(ctx, ctx->mail->status);
 }
@@ -1578,7 +1606,9 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
     Scalars z{};
     z.genomeLen = g;
     ctx->hScal = z;
-    hipLaunchKernelGGL(k_begin_sample, dim3(1), dim3(64), 0, ctx->stream, ctx->dScal.as<Scalars>(), (u64)g);  // (no copy launch)
+    // (the device's copy is cleared by the first launch of the build: k_build_init)
+    ctx->beginPending = true;
+    ctx->beginGenome = (u64)g;
     ctx->nPhases = 0;
     ctx->phase = 1;
   } else {

@@ -465,7 +465,8 @@ struct LooseCtl {
   u32 earlyBits;  // lambda as the tile stage knew it (float bits)
   u32 enabled;    // lambda was known before the tile stage
   u32 ok;         // the verdict for the host (k_frag_select): enabled, nothing bad, lambda unchanged
-  u32 pad[4];
+  u32 ready;      // k_bins_lut: the three words above are written (its table blocks wait for this one)
+  u32 pad[3];
   // one slot per workgroup of k_pval_lut (plain stores: two contended words took 8,192 same-address atomics, 45 us)
   u32 sigInv[PV_LUT / 256]; // max of (PV_LUT - V) over the workgroup's significant table entries V (0: none)
   u32 nonP1[PV_LUT / 256];  // max of (V + 1) over the others
@@ -1133,6 +1134,20 @@ __device__ __forceinline__ u64 lookback_excl_max(u64* lb, u32 id, u64 aggregate,
   return excl;
 }
 
+// "My stores have completed": what a workgroup needs before it takes a ticket that tells another workgroup to read
+// them, WHEN those stores were agent-scope atomic stores or went to host memory.  A release fence (__threadfence)
+// would also write back the XCD's whole L2 -- tens of microseconds behind a kernel that left it full of dirty lines,
+// and that once per workgroup (measured: k_scan_iv 27 -> 80 us, k_peaks 37 -> 104 us).
+__device__ __forceinline__ void stores_done() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (the compiler keeps the stores above ...
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // ... vmcnt(0) ...
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);   // ... and what follows below)
+}
+__device__ __forceinline__ void st_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 ld_agent(const u32* p) {
+  return __hip_atomic_load(const_cast<u32*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct IvScanOut {
   u32* tileIvOff;   // [nTiles+1]
   u32* tilePrevEnd; // [nTiles] start of the tile's first interval
@@ -1153,10 +1168,10 @@ struct IvScanOut {
   u32* fragList;
 };
 
-__global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
-                                                    const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
-                                                    u32 nTiles, u64* __restrict__ lbSum, u64* __restrict__ lbMax,
-                                                    IvScanOut out, u32* __restrict__ st) {
+__device__ __forceinline__ void scan_iv_body(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
+                                             const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+                                             u32 nTiles, u64* __restrict__ lbSum, u64* __restrict__ lbMax,
+                                             const IvScanOut& out, u32* __restrict__ st) {
   __shared__ u32 scratch[8];
   __shared__ u64 s64[8];
   __shared__ u64 s_sum, s_max;
@@ -1205,7 +1220,7 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
         s_max = em;
         if (id == nChunks - 1) {
           out.tileIvOff[nTiles] = (u32)es + ctot;
-          *out.nIv = (u32)es + ctot;
+          st_agent(out.nIv, (u32)es + ctot);  // (agent-scope stores: k_scan_iv_close's last workgroup reads these three)
         }
       }
     }
@@ -1237,8 +1252,8 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
           }
         }
         if (t == chroms[ci].tileBase) {
-          out.chromIvOff[ci] = cex;
-          out.chromLooseOff[ci] = out.tileSlot[t];
+          st_agent(&out.chromIvOff[ci], cex);
+          st_agent(&out.chromLooseOff[ci], out.tileSlot[t]);
         }
         if (c[k] == 0 && (chroms[ci].flags & CH_SAVE)) {
           // (a tile without intervals has few slots -- one more than it has records, all of which cancel; if it has
@@ -1258,6 +1273,13 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
+                                                    const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+                                                    u32 nTiles, u64* __restrict__ lbSum, u64* __restrict__ lbMax,
+                                                    IvScanOut out, u32* __restrict__ st) {
+  scan_iv_body(tileCount, tileLastEnd, tileChrom, chroms, nTiles, lbSum, lbMax, out, st);
 }
 
 // One wavefront per tile walks the tile's loose slots (read only).  Closed form: the deep tiles of the list,
@@ -1479,6 +1501,23 @@ __global__ void k_begin_sample(Scalars* __restrict__ s, u64 genomeLen) {
   if (threadIdx.x == 0) s->genomeLen = genomeLen;
 }
 
+// What a build starts from, in ONE launch (round 3: k_begin_sample, then two fill launches): the replicate's scalars
+// (`begin`: gx_sample_begin leaves them to this kernel), the arena of everything that must start at zero, and the
+// sweep's masks in loose-slot index space.  Sizes in 16-byte units.
+__global__ __launch_bounds__(256) void k_build_init(Scalars* __restrict__ s, int begin, u64 genomeLen, uint4* __restrict__ a,
+                                                    size_t nA, uint4* __restrict__ b, size_t nB) {
+  if (begin && blockIdx.x == 0) {  // (block-uniform)
+    u64* w = reinterpret_cast<u64*>(s);
+    if (threadIdx.x < sizeof(Scalars) / 8) w[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) s->genomeLen = genomeLen;
+  }
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nA; i += stride) a[i] = z;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nB; i += stride) b[i] = z;
+}
+
 __global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st, const long long* __restrict__ coll) {
   if (threadIdx.x || blockIdx.x) return;
   finish_frag(s, isCtrl, st, coll);
@@ -1529,8 +1568,8 @@ __global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, con
 // k_frag_select's work and the mail in ONE launch, when nothing else stands between them: no deep tile to walk
 // (k_frag_walk), no general fragLen path, and the table built for the lambda that turns out final.  Otherwise
 // `*closeState` = 2 (in the mail block) tells the host to run the separate kernels (k_frag_walk, k_frag_select, k_pval_lut, k_mail) after all.
-__global__ __launch_bounds__(64) void k_close(FragSelect A, const u32* __restrict__ nIv, const u32* __restrict__ extra,
-                                              const RiskBuf* __restrict__ rb, MailOut m, u32* __restrict__ closeState, u32 seq) {
+__device__ __forceinline__ void close_body(const FragSelect& A, const u32* nIv, const u32* extra, const RiskBuf* rb,
+                                           const MailOut& m, u32* closeState, u32 seq) {
   // (the single thread of k_frag_select walks ~90 dependent loads -- the 64 partial sums, the chromosome table: the
   // wavefront fetches them side by side into LDS first, where the walk costs nothing)
   __shared__ FragFix sff;
@@ -1566,13 +1605,48 @@ __global__ __launch_bounds__(64) void k_close(FragSelect A, const u32* __restric
   }
   // the chromosomes' first loose slots in the sweep's mask (chromLooseOff of a chromosome with tiles: k_scan_iv's)
   if (A.brkLoose)
-    for (u32 c = threadIdx.x; c < A.nChrom; c += 64)
+    for (u32 c = threadIdx.x; c < A.nChrom; c += blockDim.x)
       if ((small ? schrom[c].tileBase : A.chroms[c].tileBase) != NULL_TILE) {
         const u32 a = small ? sLoose[c] : A.chromLooseOff[c];
         atomicOr((unsigned long long*)&A.brkLoose[a >> 6], 1ull << (a & 63));
       }
   __syncthreads();
   mail_body(A.scal, A.st, A.hot, nIv, nullptr, extra, rb, m, seq);
+}
+
+// k_scan_iv and k_close in one launch: the workgroup of the scan that finishes LAST closes the sample.
+struct CloseArgs {
+  FragSelect sel;
+  const u32* nIv;
+  const u32* extra;
+  const RiskBuf* rb;
+  MailOut m;
+  u32* closeState;
+  u32 seq;
+  u32* ticket;   // zero before the launch; left at zero
+};
+__global__ __launch_bounds__(STL_NT) void k_scan_iv_close(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
+                                                          const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+                                                          u32 nTiles, u64* __restrict__ lbSum, u64* __restrict__ lbMax,
+                                                          IvScanOut out, u32* __restrict__ st, CloseArgs C) {
+  __shared__ u32 s_last;
+  scan_iv_body(tileCount, tileLastEnd, tileChrom, chroms, nTiles, lbSum, lbMax, out, st);
+  // (what the closing workgroup reads of the others: the interval count and the chromosomes' offsets -- agent-scope
+  // stores -- and words only ever touched by atomics: fragLen's correction, the list count, LooseCtl::bad, the status)
+  stores_done();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(C.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (s_last) {  // block-uniform
+    if (threadIdx.x == 0) *C.ticket = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    close_body(C.sel, C.nIv, C.extra, C.rb, C.m, C.closeState, C.seq);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_close(FragSelect A, const u32* __restrict__ nIv, const u32* __restrict__ extra,
+                                              const RiskBuf* __restrict__ rb, MailOut m, u32* __restrict__ closeState, u32 seq) {
+  close_body(A, nIv, extra, rb, m, closeState, seq);
 }
 
 }  // namespace gx

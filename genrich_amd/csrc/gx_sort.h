@@ -24,6 +24,7 @@
 // Level 2 (k_bucket2p, one workgroup per super-bucket) walks the eight lists of its bin.
 #pragma once
 #include "gx_kernels.h"
+#include "gx_stats.h"   // (lut_entry: k_bins_lut)
 
 namespace gx {
 
@@ -554,9 +555,31 @@ struct BinScan {
   int wantEarly;
 };
 
-__global__ __launch_bounds__(1024) void k_scan_bins(BinScan B, u32 nBins) {
-  __shared__ u32 scratch[20];
-  if (blockIdx.x == 3) {
+// (block: 0..2 the streams' bin offsets, 3 the chromosome prefix and the early lambda.  `ready`: set -- behind a fence --
+// once lambda and LooseCtl's early words are written, for the table blocks of k_bins_lut that wait in the same launch)
+__device__ __forceinline__ void scan_bins_body(const BinScan& B, u32 nBins, u32 block, u32* __restrict__ scratch, u32* ready) {
+  if (block == 3) {
+    if (threadIdx.x < 64 && B.wantEarly) {  // (first: the table blocks wait for it)
+      // the wavefront fetches the partial sums side by side (one thread: a chain of FRAG_SLOTS round trips)
+      static_assert(FRAG_SLOTS <= 64, "one lane per partial sum");
+      u64 t = threadIdx.x < FRAG_SLOTS ? B.ff->fragSum[threadIdx.x] : 0ull;
+      t = wave_sum(t);
+      if (threadIdx.x == 0) {
+        if (!B.ff->slow && t) {  // (as finish_frag will compute it when the correction of k_scan_iv / k_frag_walk is zero)
+          const double fragLen = (double)(long long)t + (double)0ll * (1.0 / 134217728.0);
+          const float lambda = (float)(fragLen / (double)B.scal->genomeLen);
+          // (agent-scope stores, then "they have completed", then the flag: a release fence would write back an L2
+          // that k_sort1 left full of dirty lines)
+          st_agent(reinterpret_cast<u32*>(&B.scal->lambda), __float_as_uint(lambda));
+          st_agent(&B.ctl->earlyBits, __float_as_uint(lambda));
+          st_agent(&B.ctl->enabled, 1u);
+        }
+        if (ready) {
+          stores_done();
+          st_agent(ready, 1u);
+        }
+      }
+    }
     const u32 per = (B.nChrom + 1023) / 1024;
     const u32 c0 = min(B.nChrom, threadIdx.x * per), c1 = min(B.nChrom, c0 + per);
     u32 sum = 0;
@@ -567,21 +590,10 @@ __global__ __launch_bounds__(1024) void k_scan_bins(BinScan B, u32 nBins) {
       B.chromW0[c] = (int)ex;
       ex += B.endAtLen[c];
     }
-    if (threadIdx.x == 0 && B.wantEarly && !B.ff->slow) {
-      u64 t = 0;
-      for (int i = 0; i < FRAG_SLOTS; i++) t += B.ff->fragSum[i];
-      if (t) {  // (as finish_frag will compute it when the correction of k_frag_fix1 / k_frag_walk is zero)
-        const double fragLen = (double)(long long)t + (double)0ll * (1.0 / 134217728.0);
-        const float lambda = (float)(fragLen / (double)B.scal->genomeLen);
-        B.scal->lambda = lambda;
-        B.ctl->earlyBits = __float_as_uint(lambda);
-        B.ctl->enabled = 1u;
-      }
-    }
     return;
   }
-  const u32* cursor = B.cursor[blockIdx.x];
-  u32* sbOff = B.sbOff[blockIdx.x];
+  const u32* cursor = B.cursor[block];
+  u32* sbOff = B.sbOff[block];
   constexpr int PER = MAX_BINS / 1024;
   u32 v[PER], sum = 0;
 #pragma unroll
@@ -601,6 +613,46 @@ __global__ __launch_bounds__(1024) void k_scan_bins(BinScan B, u32 nBins) {
     ex += v[k];
   }
   if (threadIdx.x == 0) sbOff[nBins] = tot;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_bins(BinScan B, u32 nBins) {
+  __shared__ u32 scratch[20];
+  scan_bins_body(B, nBins, blockIdx.x, scratch, nullptr);
+}
+
+// The launch ahead of the tile stage, folded into the one that scans the level-1 bins (round 3: k_scan_bins, then
+// k_pval_lut with `early`, two launches): blocks 0-3 are k_scan_bins', the PV_LUT / 1024 behind them build the table
+// p(V) -- each quarter of a block is one of k_pval_lut's workgroups -- as soon as block 3 has published lambda.
+// (Block 3 never waits and is dispatched before the table blocks: they cannot starve it.)
+__global__ __launch_bounds__(1024) void k_bins_lut(BinScan B, u32 nBins, float* __restrict__ lutP, RiskBuf* __restrict__ risk,
+                                                   DeepTab* __restrict__ deep, float thr, u32* __restrict__ st) {
+  __shared__ u32 scratch[20];
+  __shared__ u32 red[4][2];
+  __shared__ u32 s_lambda, s_enabled;
+  if (blockIdx.x < 4) {
+    scan_bins_body(B, nBins, blockIdx.x, scratch, &B.ctl->ready);
+    return;
+  }
+  if (blockIdx.x == 4 && threadIdx.x == 0) deep->n = 0;  // this sample's host-evaluated deep values come later
+  if (threadIdx.x == 0) {
+    u32 spins = 0;
+    while (!ld_agent(&B.ctl->ready)) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > LB_SPIN_LIMIT) {
+        atomicOr(st, ST_LOOKBACK);
+        break;
+      }
+    }
+    s_enabled = ld_agent(&B.ctl->enabled);
+    s_lambda = ld_agent(reinterpret_cast<u32*>(&B.scal->lambda));
+  }
+  __syncthreads();
+  if (!s_enabled) return;  // lambda is not known yet: the launch after the tile stage builds the table
+  const float lambda = __uint_as_float(s_lambda);
+  double ml = 0, sl = 1;
+  if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
+  const u32 v = (blockIdx.x - 4) * 1024 + threadIdx.x;
+  lut_entry(v, lambda, ml, sl, lutP, risk, B.ctl, thr, red[threadIdx.x >> 8], threadIdx.x & 255u, v >> 8);
 }
 
 // ---- level 2 on paged input: one workgroup per super-bucket ---------------------------------------------------

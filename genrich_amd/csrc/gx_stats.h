@@ -24,6 +24,35 @@ __device__ __forceinline__ float pval_of_v(int v, float lambda, double ml, doubl
 __device__ __forceinline__ void deep_risky_body(PackIn in, const FragFix* __restrict__ ff, const u32* __restrict__ list,
                                                 const Scalars* __restrict__ sc, RiskBuf* __restrict__ risk, u32 block, u32 nBlocks);
 
+// one entry of the table p(V); with `ctl` also the workgroup's slot of LooseCtl (from which pileup on an interval is
+// significant).  Call with all 256 threads of the (possibly virtual: a quarter of k_bins_lut's) workgroup `wg`: the slot
+// reduction contains barriers.
+__device__ __forceinline__ void lut_entry(u32 v, float lambda, double ml, double sl, float* __restrict__ lutP,
+                                          RiskBuf* __restrict__ risk, LooseCtl* __restrict__ ctl, float thr, u32* red, u32 tid,
+                                          u32 wg) {
+  float val;
+  bool ng, risky = false;
+  const float p = pval_of_v((int)v, lambda, ml, sl, &val, &ng, &risky);
+  lutP[v] = p;
+  if (v % GX_UNIT == 0) lutP[PV_LUT + v / GX_UNIT] = p;  // the whole pileups once more, compact (the sweep's LDS copy)
+  if (risky) risk_add(risk, RK_LUT, v, 0, 0, 0.0);
+  if (ctl) {
+    if (tid < 2) red[tid] = 0;
+    __syncthreads();
+    const u64 sg = __ballot(p > thr);
+    if (lane_id() == 0) {
+      const u32 v0 = v;
+      if (sg) atomicMax(&red[0], PV_LUT - (v0 + (u32)__builtin_ctzll(sg)));
+      if (~sg) atomicMax(&red[1], v0 + (u32)(63 - __builtin_clzll(~sg)) + 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      ctl->sigInv[wg] = red[0];
+      ctl->nonP1[wg] = red[1];
+    }
+  }
+}
+
 // blocks [0, PV_LUT / 256): the table; DEEP_BLOCKS more: the deep tiles' risky values (k_deep_risky's work, same launch)
 constexpr u32 DEEP_BLOCKS = 32;
 // `early` (LooseCtl, gx_kernels.h): the launch ahead of the tile stage, with the lambda of the closed form of fragLen --
@@ -45,30 +74,10 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
   }
   double ml = 0, sl = 1;
   if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
-  for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += (PV_LUT / 256) * 256) {
-    float val;
-    bool ng, risky = false;
-    const float p = pval_of_v((int)v, lambda, ml, sl, &val, &ng, &risky);
-    lutP[v] = p;
-    if (v % GX_UNIT == 0) lutP[PV_LUT + v / GX_UNIT] = p;  // the whole pileups once more, compact (the sweep's LDS copy)
-    if (risky) risk_add(risk, RK_LUT, v, 0, 0, 0.0);
-    if (early && ctl) {  // (the grid covers the table once: v = this wavefront's first entry + lane, one slot per workgroup)
-      __shared__ u32 red[2];
-      if (threadIdx.x < 2) red[threadIdx.x] = 0;
-      __syncthreads();
-      const u64 sg = __ballot(p > thr);
-      if (lane_id() == 0) {
-        const u32 v0 = v;
-        if (sg) atomicMax(&red[0], PV_LUT - (v0 + (u32)__builtin_ctzll(sg)));
-        if (~sg) atomicMax(&red[1], v0 + (u32)(63 - __builtin_clzll(~sg)) + 1u);
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        ctl->sigInv[blockIdx.x] = red[0];
-        ctl->nonP1[blockIdx.x] = red[1];
-      }
-    }
-  }
+  __shared__ u32 red[2];
+  for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += (PV_LUT / 256) * 256)
+    // (the grid covers the table once: v = this wavefront's first entry + lane, one slot per workgroup)
+    lut_entry(v, lambda, ml, sl, lutP, risk, early && ctl ? ctl : nullptr, thr, red, threadIdx.x, blockIdx.x);
 }
 
 // p-values against a constant control (no control sample), straight from the tile kernel's
@@ -1285,13 +1294,18 @@ __global__ __launch_bounds__(SW_NT) void k_cands(SweepMasks M, const u64* __rest
 __global__ __launch_bounds__(SW_NT) void k_peaks(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
                                                  const u32* __restrict__ nHeads, u64* __restrict__ lb, u32 gen,
                                                  gx_peak* __restrict__ peaks /* pinned host memory */, u32* __restrict__ nPeaks,
-                                                 u32* __restrict__ nPeaksHost, u32* __restrict__ st) {
+                                                 u32* __restrict__ nPeaksHost, u32* __restrict__ st, u32* __restrict__ ticket,
+                                                 u64* __restrict__ bpAcc /* zero before, zero after */,
+                                                 u64* __restrict__ bpHost /* pinned: the peaks' total length (callPeaks 925) */,
+                                                 const RiskBuf* __restrict__ rb, MailOut m, u32 seq) {
   constexpr int PW = sizeof(gx_peak) / 4;
   __shared__ u32 scratch[8];
   __shared__ u32 stage[RC_CHUNK * PW];
   __shared__ u64 s_base;
+  __shared__ u32 s_last;
   const u32 H = *nHeads;
   const u32 nChunks = (H + RC_CHUNK - 1) / RC_CHUNK;
+  u64 bp = 0;  // (the host summed the lengths over the pinned records: 1.7 MB of reads behind the kernel)
   if (nChunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     *nPeaks = 0;
     *nPeaksHost = 0;
@@ -1305,6 +1319,7 @@ __global__ __launch_bounds__(SW_NT) void k_peaks(const gx_peak* __restrict__ can
       const u32* src = reinterpret_cast<const u32*>(cand + h);
 #pragma unroll
       for (int k = 0; k < PW; k++) stage[r * PW + k] = src[k];
+      bp += cand[h].end - cand[h].start;
     }
     if (threadIdx.x < 64) {
       const u64 e = lookback_gen(lb, id, tot, gen, st);
@@ -1320,6 +1335,24 @@ __global__ __launch_bounds__(SW_NT) void k_peaks(const gx_peak* __restrict__ can
     u32* dst = reinterpret_cast<u32*>(peaks + (u32)s_base);
     for (u32 i = threadIdx.x; i < tot * PW; i += SW_NT) dst[i] = stage[i];
     __syncthreads();
+  }
+  // The sweep's mail (round 3: a k_mail launch behind this kernel): the workgroup that finishes LAST sends it.  Every
+  // workgroup's writes that the host reads -- peaks and their count, in pinned memory -- have completed before its ticket
+  // (stores_done: no L2 to write back for host memory); the status word is only ever touched by atomics.  The last
+  // workgroup sees the full count, hence all of them.  (The ticket cleans up after itself.)
+  bp = wave_sum(bp);
+  if (lane_id() == 0 && bp) atomicAdd((unsigned long long*)bpAcc, (unsigned long long)bp);
+  stores_done();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (s_last) {  // block-uniform
+    if (threadIdx.x == 0) {
+      *ticket = 0;
+      *bpHost = atomicExch((unsigned long long*)bpAcc, 0ull);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    mail_body(nullptr, st, nullptr, nullptr, nullptr, nullptr, rb, m, seq);
   }
 }
 
