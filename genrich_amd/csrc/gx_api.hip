@@ -104,6 +104,10 @@ struct Pileup {  // run-length pileup of one sample (treatment or control)
   DevBuf ivEnd, ivV, tileIvOff, chromIvOff;
   u32 nIv = 0;
   bool packed = false;  // ivEnd / ivV filled (otherwise the intervals still sit in the loose slots)
+  // a sample that waits for its control merge where the tile stage left it (stash_loose): its loose slots and its tile
+  // descriptors (slot, carry) taken out of the context, which builds the next sample into other buffers
+  DevBuf looseEnd, looseV, meta;
+  bool inLoose = false;
 };
 
 struct PArray {  // p-value intervals of one replicate (or the Fisher combination)
@@ -185,6 +189,7 @@ struct gx_ctx {
   bool beginPending = false;    // gx_sample_begin's clearing of the scalars is still to be done (k_build_init / flush_begin)
   u64 beginGenome = 0;
   bool fellBack = false;        // some sample was sent back from k_sbtile to the general chain
+  bool ptGrew = false;          // some sample was built again with larger page tables (RETRY_PT)
   bool looseOk = false;         // the treatment sample's tile stage left valid sweep bits on the loose slots
   bool riskNearThr = false;     // a re-evaluated table entry lies next to the significance threshold
   size_t looseStride = 0;       // words between the sig / brk masks the tile stage wrote into swMask
@@ -369,6 +374,7 @@ int mail_sync(gx_ctx* ctx, const Scalars* ds, const u32* hot, const u32* nIv, co
   const u32 seq = ++ctx->mailSeq;
   hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, ds, ctx->dStatus.as<u32>(), hot, nIv, coll, extra,
                      ctx->dRisk.as<RiskBuf>(), mail_out(ctx), seq);
+  HIPCHECK(hipGetLastError());  // (a launch that failed is reported now, not after the polling gives up)
   return mail_wait(ctx, seq);
 }
 
@@ -490,6 +496,23 @@ int flush_begin(gx_ctx* ctx) {
   if (!ctx->beginPending) return GX_OK;
   hipLaunchKernelGGL(k_begin_sample, dim3(1), dim3(64), 0, ctx->stream, ctx->dScal.as<Scalars>(), ctx->beginGenome);
   ctx->beginPending = false;
+  return GX_OK;
+}
+
+// A sample about to be merged with its control stays in its loose slots (k_merge2<true> reads them there): the
+// buffers leave the context -- no copy -- and the context takes others for the next build (pooled).  With -E regions
+// the merge needs tight arrays after all (gx_merge.h): pack_pileup.
+int stash_or_pack(gx_ctx* ctx, Pileup& P) {
+  static const bool noStash = getenv("GX_PACK_FOR_MERGE") != nullptr;   // (tests / measurements: round 2's way)
+  if (ctx->hasBed || noStash) return pack_pileup(ctx, P);
+  if (P.inLoose) return GX_OK;
+  recycle(ctx, P.looseEnd);
+  recycle(ctx, P.looseV);
+  recycle(ctx, P.meta);
+  P.looseEnd = std::move(ctx->looseEnd);
+  P.looseV = std::move(ctx->looseV);
+  P.meta = std::move(ctx->tileMeta);
+  P.inLoose = true;
   return GX_OK;
 }
 
@@ -661,7 +684,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   HIPCHECK(pooled(ctx, ctx->chromLooseOff, (size_t)(nChrom + 2) * 4));  // (moves into the replicate's record: gx_pvalues)
   phase_begin(ctx, isCtrl ? "c.bucket" : "t.bucket");
   {
-    BinScan bs{{SS.cursor.as<u32>(), SE.cursor.as<u32>(), SF.cursor.as<u32>()}, {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()},
+    auto capOf = [&](int shift) -> u32 { return jmax >= (1u << (31 - shift)) ? 0x7FFFFFFFu : jmax << shift; };  // (list_cap)
+    BinScan bs{{SS.cursor.as<u32>(), SE.cursor.as<u32>(), SF.cursor.as<u32>()},
+               {capOf(PgCfg<u32>::SHIFT), capOf(PgCfg<u32>::SHIFT), capOf(PgCfg<u64>::SHIFT)},
+               {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()},
                ctx->endAtLen.as<u32>(), ctx->chromW0.as<int>(), nChrom, ff, ctx->dScal.as<Scalars>(), ctl, wantEarly ? 1 : 0};
     static_assert(PV_LUT % 1024 == 0, "k_bins_lut: four of k_pval_lut's workgroups per block");
     if (wantEarly)  // with the table p(V) for that lambda, and from which pileup on an interval is significant
@@ -713,8 +739,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                        ctx->dStatus.as<u32>());
     if (int rc__ = dbg_sync(ctx, "k_scan_tiles")) return rc__;
   }
-  HIPCHECK(ctx->looseEnd.ensure(looseCap * 4));
-  HIPCHECK(ctx->looseV.ensure(looseCap * 4));
+  HIPCHECK(pooled(ctx, ctx->looseEnd, looseCap * 4));  // (pooled: a sample stashed for its control merge took the last ones along)
+  HIPCHECK(pooled(ctx, ctx->looseV, looseCap * 4));
   HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tileLastEnd.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->tilePrevEnd.ensure((size_t)(nTiles + 1) * 4));
@@ -723,7 +749,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(),
              ctx->tileDeep.as<u32>(), sigMask, wantEarly ? ctl : (LooseCtl*)nullptr};
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
-  HIPCHECK(ctx->tileMeta.ensure((size_t)(nTiles + 1) * sizeof(TileMeta)));
+  HIPCHECK(pooled(ctx, ctx->tileMeta, (size_t)(nTiles + 1) * sizeof(TileMeta)));
   HIPCHECK(ctx->wideList.ensure((size_t)(nTiles + 1) * 4));
   HIPCHECK(ctx->heavyList.ensure((size_t)(nTiles + 1) * 4));
   if (!fused)
@@ -838,8 +864,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   }
   if (int rc__ = dbg_sync(ctx, "k_frag")) return rc__;
   out.packed = false;
-  if (isCtrl) {  // a control is always merged against the treatment: tight arrays needed
-    int rc = pack_pileup(ctx, out);
+  out.inLoose = false;
+  if (isCtrl) {  // a control is always merged against the treatment
+    int rc = stash_or_pack(ctx, out);
     if (rc) return rc;
   }
   phase_end(ctx);
@@ -851,7 +878,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
 constexpr int RETRY_GENERAL = 3;    // (internal) k_sbtile could not take the sample: build it again on the general chain
 constexpr int RETRY_SATURATED = 1;  // (internal) finish_scalars: filter the events and build the sample again
 constexpr int RETRY_PT = 2;         // (internal) a level-1 page list overflowed: build again with a longer page table
-constexpr u32 PT_JMAX_CAP = 1u << 20;
+// (the page tables -- NXCD x bins x jmax x 4 bytes, three streams -- at the cap and hg38's 2,946 bins: 18.5 GB, which a
+// 288 GB device holds; 2^20, round 2's cap, would have asked for 50 GB per stream.  A list beyond 2^16 pages holds
+// more than 5 x 10^8 keys of ONE super-bucket: such a sample fails with "could not be rebuilt")
+constexpr u32 PT_JMAX_CAP = 1u << 16;
 
 // fragLen / ctrlFrag partial sums -> (all ranks) -> lambda, factor
 int finish_scalars(gx_ctx* ctx, int isCtrl) {
@@ -1054,6 +1084,7 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
       // a (XCD class, super-bucket) list needed more pages than its table row holds -- reads piled up in one
       // spot: what the first build left behind goes, the table grows, the sample is built again
       ctx->ptJmax = std::min(ctx->ptJmax * 16, PT_JMAX_CAP);
+      ctx->ptGrew = true;
       if (int w = wipe()) return w;
     } else if (rc == RETRY_SATURATED) {
       if ((rc = drop_saturated(ctx, isCtrl))) return rc;  // (sets satDone: finish_scalars asks for this once)
@@ -1400,6 +1431,7 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   ctx->par = *par;
   ctx->device = par->device;
   if (const char* e = getenv("GX_BH_CAPLOG")) ctx->bhCapLog = (u32)std::max(4, std::min(28, atoi(e)));  // (tests: a tiny first table)
+  if (const char* e = getenv("GX_PT_JMAX")) ctx->ptJmax = (u32)std::max(1, std::min(1 << 16, atoi(e)));  // (tests: short page-table rows)
   *out = ctx;
   HIPCHECK(hipSetDevice(ctx->device));
   HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -1567,6 +1599,10 @@ int gx_reset(gx_ctx* ctx) {
   if (!ctx) return GX_ERR_ORDER;
   HIPCHECK(hipSetDevice(ctx->device));
   HIPCHECK(hipStreamSynchronize(ctx->stream));
+  for (Pileup* P : {&ctx->expt, &ctx->ctrl}) {  // (samples stashed for a control merge give their buffers back)
+    recycle(ctx, P->looseEnd); recycle(ctx, P->looseV); recycle(ctx, P->meta);
+    P->inLoose = false;
+  }
   for (auto& pa : ctx->reps) {
     recycle(ctx, pa.end); recycle(ctx, pa.p); recycle(ctx, pa.expt); recycle(ctx, pa.ctrl);
     recycle(ctx, pa.chromOff); recycle(ctx, pa.q); recycle(ctx, pa.tileOff); recycle(ctx, pa.dPresent);
@@ -1613,7 +1649,7 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
     ctx->phase = 1;
   } else {
     if (ctx->phase != 2) return GX_ERR_ORDER;
-    int rc = pack_pileup(ctx, ctx->expt);  // the control's tiles are about to reuse the loose slots
+    int rc = stash_or_pack(ctx, ctx->expt);  // the control's tiles are about to be built: the treatment steps aside
     if (rc) return rc;
     ctx->phase = 3;
   }
@@ -1773,19 +1809,32 @@ int gx_pvalues(gx_ctx* ctx) {
     HIPCHECK(pooled(ctx, pa.p, cap * 4));
     HIPCHECK(pooled(ctx, pa.tileOff, (size_t)(nTiles + 2) * 4));
     HIPCHECK(pooled(ctx, pa.chromOff, (size_t)(nChrom + 2) * 4));
-    // loose slots reuse the tile kernel's loose buffers (+ one more int array)
-    HIPCHECK(ctx->looseEnd.ensure(cap * 4));
-    HIPCHECK(ctx->looseV.ensure(cap * 4));
+    // loose slots: the tile kernel's loose buffers, or others like them (+ one more int array)
+    HIPCHECK(pooled(ctx, ctx->looseEnd, cap * 4));
+    HIPCHECK(pooled(ctx, ctx->looseV, cap * 4));
     HIPCHECK(ctx->looseC.ensure(cap * 4));
     HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
     u32* misc = ctx->misc.as<u32>();
     phase_begin(ctx, "merge");
-    RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>()};
-    RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>()};
+    const bool fromLoose = ctx->expt.inLoose && ctx->ctrl.inLoose;
+    if (!fromLoose && (ctx->expt.inLoose || ctx->ctrl.inLoose || !ctx->expt.packed || !ctx->ctrl.packed)) {
+      ctx->err = "control merge: the two samples are not in the same form";
+      return GX_ERR_ORDER;
+    }
     Merge2Out mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->tileIvCount.as<u32>()};
-    // (ctx->tileMeta still holds the control build's descriptors: pos0 / len / flags do not depend on the sample)
-    hipLaunchKernelGGL(k_merge2, dim3(std::min(nTiles, (u32)(8 * ctx->numCU))), dim3(MG_NT), 0, s, A, Bc,
-                       ctx->dScal.as<Scalars>(), ctx->tileMeta.as<TileMeta>(), nTiles, mo, ctx->dStatus.as<u32>());
+    // (pos0 / len / flags of a tile do not depend on the sample: the control build's descriptors serve)
+    const dim3 gridM(std::min(nTiles, (u32)(8 * ctx->numCU)));
+    if (fromLoose) {
+      RleIn A{ctx->expt.looseEnd.as<u32>(), ctx->expt.looseV.as<int>(), ctx->expt.tileIvOff.as<u32>(), ctx->expt.meta.as<TileMeta>()};
+      RleIn Bc{ctx->ctrl.looseEnd.as<u32>(), ctx->ctrl.looseV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), ctx->ctrl.meta.as<TileMeta>()};
+      hipLaunchKernelGGL(k_merge2<true>, gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->ctrl.meta.as<TileMeta>(),
+                         nTiles, mo, ctx->dStatus.as<u32>());
+    } else {
+      RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>(), nullptr};
+      RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), nullptr};
+      hipLaunchKernelGGL(k_merge2<false>, gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->tileMeta.as<TileMeta>(),
+                         nTiles, mo, ctx->dStatus.as<u32>());
+    }
     if (int rc__ = dbg_sync(ctx, "k_merge2")) return rc__;
     const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
     HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));
@@ -2337,7 +2386,7 @@ int gx_rccl_nranks(gx_ctx* ctx, int* n) {
 int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   if (!ctx || !flags) return GX_ERR_ORDER;
   *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
-           (ctx->fellBack ? GX_PATH_FELL_BACK : 0u);
+           (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u);
   return GX_OK;
 }
 

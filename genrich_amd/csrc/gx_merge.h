@@ -21,10 +21,13 @@ constexpr int MG_NT = MG_WORDS_ < 256 ? MG_WORDS_ : 256;
 constexpr int MG_WORDS = TILE / 32;        // 512 bitmap words per input
 constexpr int MG_WPT = MG_WORDS / MG_NT;   // 2 consecutive words per thread
 
-struct RleIn {   // run-length pileup from k_tile
+struct RleIn {   // run-length pileup of a sample
   const u32* end;
   const int* v;
-  const u32* tileOff;
+  const u32* tileOff;     // [nTiles + 1] tight offsets (k_scan_iv): a tile's interval count, its share of the output slot
+  const TileMeta* meta;   // LOOSE: the sample's own tile descriptors -- `end` / `v` are its loose slots, tile t's intervals
+                          // start at meta[t].slot, and the interval that covers the tile's tail has the pileup
+                          // meta[t + 1].carry (no breakpoint lies between: it is the next tile's first interval)
 };
 
 struct Merge2Out {   // loose slots: tile t writes at A.tileOff[t] + B.tileOff[t] (a union is never longer)
@@ -41,22 +44,42 @@ struct Merge2Out {   // loose slots: tile t writes at A.tileOff[t] + B.tileOff[t
 // dependent loads, so, as in k_tile, tile headers are fetched two tiles ahead and the first MG_NT
 // intervals of both inputs one tile ahead; the pileup values of the tile's intervals are staged
 // in LDS so that the emit loop does no dependent global gather.
+// LOOSE (round 3): the two samples are read where the tile stage left them -- their loose slots -- instead of from
+// tight copies (k_pack twice: 0.66 ms and 2.7 GB per step at config 3).  Not with -E regions: there the value of the
+// interval behind a tile's last breakpoint can be V_MARK, which no carry says.
 constexpr int MG_CAP = 1024;  // intervals per input and tile whose values are staged in LDS
 
 struct MergeHdr {
   u32 a0, a1c, a1, b0, b1c, b1, pos0, len, flags;  // flags: 1 active, 2 last tile of its chromosome
+  u32 slot;                                         // the tile's first output slot
+  int nvA, nvB;                                     // LOOSE: pileups of the intervals that cover the tile's tail
 };
 
-__device__ __forceinline__ MergeHdr merge_hdr(const RleIn& A, const RleIn& B, const TileMeta* __restrict__ meta, u32 t) {
+template <bool LOOSE>
+__device__ __forceinline__ MergeHdr merge_hdr(const RleIn& A, const RleIn& B, const TileMeta* __restrict__ meta, u32 t, u32 nTiles) {
   MergeHdr h;
   const TileMeta m = meta[t];
   h.pos0 = m.pos0;
   h.len = m.len;
   h.flags = m.flags & 3u;
-  h.a0 = A.tileOff[t];
-  h.a1 = A.tileOff[t + 1];
-  h.b0 = B.tileOff[t];
-  h.b1 = B.tileOff[t + 1];
+  const u32 ao = A.tileOff[t], bo = B.tileOff[t];
+  const u32 na = A.tileOff[t + 1] - ao, nb = B.tileOff[t + 1] - bo;
+  h.slot = ao + bo;
+  h.nvA = 0;
+  h.nvB = 0;
+  if (LOOSE) {
+    h.a0 = A.meta[t].slot;
+    h.b0 = B.meta[t].slot;
+    if (t + 1 < nTiles) {
+      h.nvA = A.meta[t + 1].carry;
+      h.nvB = B.meta[t + 1].carry;
+    }
+  } else {
+    h.a0 = ao;
+    h.b0 = bo;
+  }
+  h.a1 = h.a0 + na;
+  h.b1 = h.b0 + nb;
   if (!(h.flags & 1u)) { h.a1 = h.a0; h.b1 = h.b0; }
   const bool lastTile = h.flags & 2u;
   h.a1c = (lastTile && h.a1 > h.a0) ? h.a1 - 1 : h.a1;  // the chromosome-closing interval is handled apart
@@ -64,6 +87,7 @@ __device__ __forceinline__ MergeHdr merge_hdr(const RleIn& A, const RleIn& B, co
   return h;
 }
 
+template <bool LOOSE>
 __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalars* __restrict__ sc,
                                                   const TileMeta* __restrict__ meta, u32 nTiles, Merge2Out out,
                                                   u32* __restrict__ st) {
@@ -79,15 +103,21 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
   bmC[threadIdx.x] = 0;
   const u32 lb = xcd_local_block(blockIdx.x, G);  // neighbouring tiles (neighbouring loose slots) on one XCD
   MergeHdr h1{}, h2{};
-  if (lb < nTiles) h1 = merge_hdr(A, B, meta, lb);
-  if (lb + G < nTiles) h2 = merge_hdr(A, B, meta, lb + G);
+  if (lb < nTiles) h1 = merge_hdr<LOOSE>(A, B, meta, lb, nTiles);
+  if (lb + G < nTiles) h2 = merge_hdr<LOOSE>(A, B, meta, lb + G, nTiles);
+  // the pileup of the control interval BEHIND interval j of the tile: the next slot -- unless j is the tile's last
+  // interval and the tile not its chromosome's last (LOOSE: the next tile's slots are elsewhere; its carry says it)
+  auto nextB = [&](const MergeHdr& h, u32 j) -> int {
+    const int v = B.v[h.b0 + j + 1];  // (in bounds: the slot arrays carry slack)
+    return LOOSE && h.b0 + j + 1 == h.b1 && !(h.flags & 2u) ? h.nvB : v;
+  };
   u32 eA1 = 0, eB1 = 0;
   int vA1 = 0, vB1 = 0, vBn1 = 0;
   if (h1.a0 + threadIdx.x < h1.a1c) { eA1 = A.end[h1.a0 + threadIdx.x]; vA1 = A.v[h1.a0 + threadIdx.x]; }
   if (h1.b0 + threadIdx.x < h1.b1c) {
     eB1 = B.end[h1.b0 + threadIdx.x];
     vB1 = B.v[h1.b0 + threadIdx.x];
-    vBn1 = B.v[h1.b0 + threadIdx.x + 1];
+    vBn1 = nextB(h1, threadIdx.x);
   }
   __syncthreads();
   for (u32 t = lb; t < nTiles; t += G) {
@@ -100,14 +130,16 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
       if (h1.b0 + threadIdx.x < h1.b1c) {
         eB1 = B.end[h1.b0 + threadIdx.x];
         vB1 = B.v[h1.b0 + threadIdx.x];
-        vBn1 = B.v[h1.b0 + threadIdx.x + 1];  // exists: at least the closing interval follows
+        vBn1 = nextB(h1, threadIdx.x);  // exists: at least the closing interval follows
       }
     }
-    if (t + 2 * G < nTiles) h2 = merge_hdr(A, B, meta, t + 2 * G);
+    if (t + 2 * G < nTiles) h2 = merge_hdr<LOOSE>(A, B, meta, t + 2 * G, nTiles);
     const bool active = h.flags & 1u, lastTile = h.flags & 2u;
     const u32 a0 = h.a0, b0 = h.b0, pos0 = h.pos0;
     const u32 nA = h.a1c - a0, nB = h.b1c - b0;
     const bool staged = nA <= MG_CAP && nB <= MG_CAP;  // block-uniform
+    // the pileups of the intervals that cover what follows the tile's last breakpoint
+    const bool tailElsewhere = LOOSE && !lastTile;
     // (bitmap words are zero here: each thread clears its words as soon as it has read them)
     // (the prefetched first MG_NT intervals of each input come from registers, the rest -- dense
     // tiles only -- from memory: two pieces of straight code, not a select inside one loop)
@@ -129,10 +161,10 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
     if (threadIdx.x < nA) addA(threadIdx.x, eA0, vA0);
     for (u32 j = threadIdx.x + MG_NT; j < nA; j += MG_NT) addA(j, A.end[a0 + j], A.v[a0 + j]);
     if (threadIdx.x < nB) addB(threadIdx.x, eB0, vB0, vBn0);
-    for (u32 j = threadIdx.x + MG_NT; j < nB; j += MG_NT) addB(j, B.end[b0 + j], B.v[b0 + j], B.v[b0 + j + 1]);
+    for (u32 j = threadIdx.x + MG_NT; j < nB; j += MG_NT) addB(j, B.end[b0 + j], B.v[b0 + j], nextB(h, j));
     if (active && staged && threadIdx.x == 0) {  // the interval that covers what follows the tile's last breakpoint
-      sA[nA] = A.v[h.a1c];
-      sC[nB] = B.v[h.b1c];
+      sA[nA] = tailElsewhere ? h.nvA : A.v[h.a1c];
+      sC[nB] = tailElsewhere ? h.nvB : B.v[h.b1c];
     }
     __syncthreads();
     const u32 wA = bmA[threadIdx.x], wC = bmC[threadIdx.x], wU = wA | bmB[threadIdx.x];
@@ -145,7 +177,7 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
     const u64 ex3 = block_excl_scan<u64, MG_NT>((u64)cU | ((u64)cA << 16) | ((u64)cC << 32), scratch64, &tot3);
     const u32 tU = (u32)tot3 & 0xFFFFu;
     const u32 exU = (u32)ex3 & 0xFFFFu, exA = (u32)(ex3 >> 16) & 0xFFFFu, exC = (u32)(ex3 >> 32) & 0xFFFFu;
-    const u32 slot = a0 + b0;
+    const u32 slot = h.slot;
     if (threadIdx.x == 0) out.tileCount[t] = active ? tU + (lastTile ? 1u : 0u) : 0u;
     if (active) {  // block-uniform
       u32 o = slot + exU;
@@ -163,8 +195,10 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
           const int b = __ffs(bits) - 1;
           const u32 below = (1u << b) - 1;
           out.end[o] = pos0 + threadIdx.x * 32 + b;
-          out.exptV[o] = A.v[a0 + exA + __popc(wA & below)];
-          out.ctrlV[o] = B.v[b0 + exC + __popc(wC & below)];
+          const u32 ia = exA + __popc(wA & below), ic = exC + __popc(wC & below);
+          const int va = A.v[a0 + ia], vc = B.v[b0 + ic];  // (in bounds: slack)
+          out.exptV[o] = tailElsewhere && ia == nA ? h.nvA : va;
+          out.ctrlV[o] = tailElsewhere && ic == nB ? h.nvB : vc;
           o++;
         }
       }

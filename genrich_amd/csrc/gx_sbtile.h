@@ -271,7 +271,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   if (tid < SBT_NW) L.tile[tid][SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
   if (tid < 2 * NXCD) {
     const PagedStream& P = tid < NXCD ? in.PS : in.PE;
-    L.scratch[tid] = P.cursor[(u32)(tid & (NXCD - 1)) * nSeg + seg];
+    L.scratch[tid] = list_len<u32>(P, (u32)(tid & (NXCD - 1)) * nSeg + seg);
   }
   __syncthreads();
   if (tid < 2) {

@@ -164,6 +164,18 @@ __device__ __forceinline__ u32 page_wait(const PagedStream& P, u32* __restrict__
   }
 }
 
+// What the READERS of a list take as its length: the cursor, but no more than the table row's pages hold.  A list
+// that outgrew its row (ST_PT_FULL: the host builds the sample again with longer rows) put the rest in the sink page;
+// its readers -- which run before the host has seen the flag -- must neither index the table beyond the row nor take
+// keys from the sink (another bin's: their tile offsets would index LDS tables out of range).  Everybody who turns
+// cursors into counts clamps the same way, so offsets derived from them agree.
+template <typename R> __device__ __forceinline__ u32 list_cap(u32 jmax) {
+  return jmax >= (1u << (31 - PgCfg<R>::SHIFT)) ? 0x7FFFFFFFu : jmax << PgCfg<R>::SHIFT;
+}
+template <typename R> __device__ __forceinline__ u32 list_len(const PagedStream& P, u32 li) {
+  return min(P.cursor[li], list_cap<R>(P.jmax));
+}
+
 // Scatter NR records per thread (NULL tile = none) of the whole workgroup into their bins' page lists.
 template <typename R, int NR>
 __device__ __forceinline__ void scatter_paged(const R (&rec)[NR], const PagedStream& P, int sbShift, u32 nBins, S1Lds& L,
@@ -545,6 +557,7 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
 //               so that the table p(V) exists before the tile stage (LooseCtl, gx_kernels.h)
 struct BinScan {
   const u32* cursor[3];
+  u32 cap[3];          // list_cap of the three streams (what a page-table row holds)
   u32* sbOff[3];
   const u32* endAtLen;
   int* chromW0;
@@ -601,7 +614,7 @@ __device__ __forceinline__ void scan_bins_body(const BinScan& B, u32 nBins, u32 
     const u32 i = threadIdx.x * PER + k;
     v[k] = 0;
     if (i < nBins)
-      for (int x = 0; x < NXCD; x++) v[k] += cursor[x * nBins + i];
+      for (int x = 0; x < NXCD; x++) v[k] += min(cursor[x * nBins + i], B.cap[block]);  // (list_len)
     sum += v[k];
   }
   u32 tot;
@@ -708,7 +721,7 @@ __device__ __forceinline__ void bucket2p_body(const PagedStream& P, typename B2O
       u32 a = 0;
       for (int x = 0; x < NXCD; x++) {
         pre[x] = a;
-        a += P.cursor[x * nSeg + seg];
+        a += list_len<R>(P, x * nSeg + seg);
       }
       pre[NXCD] = a;
     }

@@ -37,6 +37,7 @@ constexpr int TF_WG_PER_CU = 24;                                // one-wavefront
 constexpr int TR_CAP = 512;
 constexpr int TR_WORDS = TILE / 32 + TILE / 64 + TR_CAP + TR_CAP / 2;
 
+static_assert(TILE == 64 * 2 * 32, "k_tile_fast / k_tile_heavy: two 32-bit bitmap words per lane, 64 prefix entries (GX_TB = 12)");
 __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u32* __restrict__ nWide, TileOut out,
                                                   u32* __restrict__ st) {
   __shared__ __attribute__((aligned(16))) int lds[TR_WORDS];

@@ -318,7 +318,7 @@ class Genrich:
         return n.value
 
     def path_info(self):
-        """Which device path the last calls took: GX_PATH_* bits (1 fused tile stage, 2 loose-slot sweep, 4 fell back)."""
+        """Which device path the last calls took: GX_PATH_* bits (1 fused tile stage, 2 loose-slot sweep, 4 fell back, 8 page tables grew)."""
         f = C.c_uint(0)
         self._check(self.lib.gx_path_info(self.ctx, C.byref(f)))
         return f.value

@@ -249,10 +249,13 @@ int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
  * bit 0: the last sample's tile stage was k_sbtile (level 2 of the sort fused with the tile passes, gx_sbtile.h);
  * bit 1: the last gx_find_peaks swept the tile stage's loose slots (no k_pack_pval, gx_kernels.h LooseCtl);
  * bit 2: a sample of this context was sent back to the general chain (a super-bucket beyond k_sbtile's LDS, or
- *        fractional weights). */
+ *        fractional weights);
+ * bit 3: a sample of this context was built again with larger page tables (reads piled up in one super-bucket
+ *        beyond what a row of the level-1 page table held). */
 #define GX_PATH_FUSED 1u
 #define GX_PATH_LOOSE_SWEEP 2u
 #define GX_PATH_FELL_BACK 4u
+#define GX_PATH_PT_GREW 8u
 int gx_path_info(gx_ctx* ctx, unsigned* flags);
 
 /* Evaluate one scalar device function on n inputs (numerics tests):

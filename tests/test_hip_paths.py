@@ -13,7 +13,7 @@ from test_hip_parity import assert_same_run, hip_backend
 
 pytestmark = pytest.mark.gpu
 
-FUSED, LOOSE, FELL_BACK = 1, 2, 4
+FUSED, LOOSE, FELL_BACK, PT_GREW = 1, 2, 4, 8
 
 
 def _case(seed=11, n=90_000, lens=(400_000, 123_457, 16_384, 4_097, 5), **kw):
@@ -138,3 +138,21 @@ def test_a_flat_significant_plateau_across_a_tile_without_records():
     o, h, flags = _run(case, B.make_params(pq=0.01, min_auc=20.0))
     assert flags & FUSED and flags & LOOSE
     assert h.n_peaks >= 1
+
+
+def test_page_tables_grow_when_a_list_outgrows_its_row(monkeypatch):
+    """RETRY_PT: with one page per (XCD class, super-bucket) list (GX_PT_JMAX=1; 16 normally) and everything in one
+    super-bucket (GX_SBSHIFT=8) a list of 90,000 fragments needs more pages than a row of the page table holds --
+    k_sort1 raises ST_PT_FULL, the host grows the tables and builds the sample again: same bits as the oracle, and the
+    flag says that this is what happened.  (The kernels behind k_sort1 run on the short lists before the host has
+    seen the flag: they must stay inside the table rows -- list_len, gx_sort.h; round 3 found them reading past.)"""
+    monkeypatch.setenv("GX_PT_JMAX", "1")
+    monkeypatch.setenv("GX_SBSHIFT", "8")
+    o, h, flags = _run(_case(seed=23, n=90_000), B.make_params(pq=0.01, min_auc=50.0))
+    assert h.n_peaks > 0
+    assert flags & PT_GREW
+
+
+def test_page_tables_do_not_grow_in_an_ordinary_run():
+    o, h, flags = _run(_case(seed=23, n=90_000), B.make_params(pq=0.01, min_auc=50.0))
+    assert not flags & PT_GREW
