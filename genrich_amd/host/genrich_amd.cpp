@@ -13,7 +13,8 @@
 // and so does -r / -R (PCR-duplicate removal, Genrich.c:2776-2977 and 3267-4042).
 //
 // Extra long options:
-//   --threads N     threads that inflate BGZF (BAM, bgzip-ped SAM) input; default min(8, cores)
+//   --threads N     threads that inflate BGZF (BAM, bgzip-ped SAM) input, and as many that decode records (SAM lines,
+//                   BAM blocks: everything that does not touch the run's state); default min(16, cores); 1: one thread does it all
 //   (environment: GENRICH_HOST_PROF=1 prints the CPU time of the parsing thread after the last input)
 //   --events-only   parse and write the -b file without touching a GPU (diagnostics)
 //   --device N      HIP device ordinal (default 0)
@@ -32,9 +33,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <pthread.h>
 #include <unistd.h>
 #include <thread>
@@ -49,7 +55,17 @@ static const float NOSCORE = -FLT_MAX;
 
 namespace {
 
+// A decoding thread (parallel record decoding, below) must not end the program: an earlier record, still on its way
+// through the run's state, may have a warning to print or an error of its own.  With t_capture set, die() keeps the
+// message and unwinds to the decoder; the thread that owns the state dies with it when that record's turn comes.
+struct DecodeAbort {};
+thread_local std::pair<std::string, std::string>* t_capture = nullptr;
+
 [[noreturn]] void die(const std::string& msg, const char* tail) {  // error(), Genrich.c:78-81
+  if (t_capture) {
+    *t_capture = {msg, tail};
+    throw DecodeAbort{};
+  }
   fprintf(stderr, "Error! %s%s\n", msg.c_str(), tail);
   exit(EXIT_FAILURE);
 }
@@ -839,12 +855,6 @@ void headerLine(State& S, char* line) {  // checkHeader 4307-4342, loadChrom 427
   }
 }
 
-int findChrom(State& S, const char* rname) {
-  for (size_t i = 0; i < S.chrom.size(); i++)
-    if (S.chrom[i].name == rname) return (int)i;
-  die(rname, ": cannot find reference sequence name in SAM header");
-}
-
 // the header of the current file is complete: open the sample on the device
 void openSample(State& S) {
   if (S.sampleOpen) return;
@@ -921,60 +931,303 @@ void finishFile(State& S, ReadSet& rs, Counts& C) {  // the tail of readSAM / pa
   }
 }
 
-uint64_t readSAM(State& S, In& in, char* first, Counts& C) {
-  std::vector<char> line(65520);
+// ---- record decoding, apart from the run's state ---------------------------------------------
+// What readSAM's / readBAM's loop knows about a record BEFORE it touches the run's state -- the fields cut up and
+// converted, the reference sequence looked up, the distance to the 3' end, the alignment score -- depends on nothing
+// but the record (and the header, which is complete by then).  That part, three quarters of the parsing thread's
+// time on bowtie2-style SAM text, runs on `--threads` decoder threads over batches of records; the rest -- counters,
+// read-name groups, pairing, weights, -b lines, events: everything whose order matters -- stays on the one thread
+// that owns the state and takes the decoded batches in file order.  An error found while decoding is kept with its
+// record and raised when its turn comes, so warnings and errors appear in the order of a sequential run.
+struct Decoded {
+  enum Kind : uint8_t { REC, UNMAPPED, SUPP, LOWQ, FAIL };
+  uint8_t kind = REC, mapq = 0;
+  uint16_t flag = 0;
+  int ci = 0, length = 0, qualLen = 0;
+  uint32_t pos = 0, pnext = 0;
+  float score = 0.0f;
+  uint32_t qname = 0, qual = 0;   // offsets into the batch's bytes
+  int fail = -1;                   // FAIL: index into the batch's messages
+};
+
+constexpr size_t REC_MAX = 65520;  // (a line is read in pieces of at most 65,520 bytes: readSAM's buffer)
+// bytes of records per batch (GENRICH_BATCH_BYTES: tests cut the input into batches of a line or two)
+const size_t BATCH_BYTES = getenv("GENRICH_BATCH_BYTES") ? (size_t)std::max(1L, atol(getenv("GENRICH_BATCH_BYTES"))) : (size_t)1 << 20;
+
+struct Batch {
+  std::unique_ptr<char[]> bytes;   // the records' text lines (NUL-terminated) or BAM blocks
+  size_t used = 0, cap = 0;
+  std::vector<uint32_t> off, len;  // one entry per record
+  std::vector<Decoded> rec;
+  std::vector<std::pair<std::string, std::string>> fails;
+  bool decoded = false;
+  void reset(size_t want) {
+    if (cap < want) {
+      bytes.reset(new char[want]);
+      cap = want;
+    }
+    used = 0;
+    off.clear(); len.clear(); rec.clear(); fails.clear();
+    decoded = false;
+  }
+  char* room(size_t n) {  // n more bytes behind the records so far (the batch grows when a record needs it)
+    if (used + n > cap) {
+      const size_t want = std::max(cap * 2, used + n);
+      std::unique_ptr<char[]> nb(new char[want]);
+      memcpy(nb.get(), bytes.get(), used);
+      bytes = std::move(nb);
+      cap = want;
+    }
+    return bytes.get() + used;
+  }
+  void add(size_t n) {
+    off.push_back((uint32_t)used);
+    len.push_back((uint32_t)n);
+    used += n;
+  }
+};
+
+struct ChromIndex {  // findChrom without the linear search (first of equal names, as the search finds it)
+  std::unordered_map<std::string, int> at;
+  explicit ChromIndex(const State& S) {
+    for (size_t i = 0; i < S.chrom.size(); i++) at.emplace(S.chrom[i].name, (int)i);
+  }
+  int find(const char* rname) const {
+    auto it = at.find(rname);
+    if (it == at.end()) die(rname, ": cannot find reference sequence name in SAM header");
+    return it->second;
+  }
+};
+
+// one SAM line (readSAM 4524-4560 up to the call of parseAlign)
+void decodeSamLine(const Opts& o, const ChromIndex& cx, char* base, char* l, Decoded& r) {
+  if (l[0] == '@') die(l, ": misplaced SAM header line");
+  // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [extra], cut up as the reference does
+  // (readSAM 4524-4530, loadFields 4350-4377): strtok on TAB -- so a run of tabs is one separator, and
+  // the last field of a line keeps its line end -- with the integer fields converted (getInt: the whole
+  // token must be a number) as they are met, QUAL included in that order of events.
+  char* save = nullptr;
+  char* qname = strtok_r(l, "\t", &save);
+  if (!qname) die(l, ": poorly formatted SAM/BAM record");
+  char* fld[12] = {nullptr};
+  fld[0] = qname;
+  char* extra = nullptr;
+  int nf = 1;
+  for (char* f = strtok_r(nullptr, "\t", &save); f; f = strtok_r(nullptr, "\t", &save)) {
+    fld[nf] = f;
+    switch (nf) {
+      case 1: r.flag = (uint16_t)getInt(f); break;
+      case 3: r.pos = (uint32_t)(getInt(f) - 1); break;
+      case 4: r.mapq = (uint8_t)getInt(f); break;
+      case 7: r.pnext = (uint32_t)(getInt(f) - 1); break;
+      case 8: (void)getInt(f); break;  // TLEN: converted, then ignored
+      default: break;
+    }
+    if (++nf == 11) {
+      extra = strtok_r(nullptr, "\n", &save);
+      break;
+    }
+  }
+  if (nf < 11) die(qname, ": poorly formatted SAM/BAM record");
+  r.qname = (uint32_t)(qname - base);
+  if (r.flag & 0x4) { r.kind = Decoded::UNMAPPED; return; }
+  if (!strcmp(qname, "*") || !strcmp(fld[2], "*")) die(qname, ": poorly formatted SAM/BAM record");
+  if (r.flag & 0xE00) { r.kind = Decoded::SUPP; return; }
+  r.ci = cx.find(fld[2]);
+  if (r.mapq < o.minMapQ) { r.kind = Decoded::LOWQ; return; }
+  r.length = calcDist(qname, fld[9], fld[5]);
+  r.score = samScore(extra);
+  r.qual = (uint32_t)(fld[10] - base);
+  r.qualLen = (int)strlen(fld[10]);
+  r.kind = Decoded::REC;
+}
+
+// the state's side of a decoded record (the counters of readSAM / parseBAM, then parseAlign)
+inline void applyDecoded(State& S, ReadSet& rs, Counts& C, const Batch& B, const Decoded& r, int qualOffset) {
+  switch (r.kind) {
+    case Decoded::FAIL: die(B.fails[(size_t)r.fail].first, B.fails[(size_t)r.fail].second.c_str());
+    case Decoded::UNMAPPED: C.count++; C.unmapped++; return;
+    case Decoded::SUPP: C.count++; C.supp++; return;
+    case Decoded::LOWQ: C.count++; C.lowMapQ++; return;
+    default: break;
+  }
+  C.count++;
+  const char* base = B.bytes.get();
+  record(S, rs, C, base + r.qname, r.flag, r.ci, r.pos, r.mapq, r.length, r.pnext, r.score, base + r.qual, r.qualLen, qualOffset);
+}
+
+// decode every record of a batch (any thread); a record that fails ends the batch: nothing behind it will be looked at
+template <class F>
+void decodeBatch(Batch& B, F one) {
+  B.rec.assign(B.off.size(), Decoded{});
+  std::pair<std::string, std::string> msg;
+  t_capture = &msg;
+  for (size_t i = 0; i < B.off.size(); i++) {
+    try {
+      one(B.bytes.get(), B.off[i], B.len[i], B.rec[i]);
+    } catch (const DecodeAbort&) {
+      B.rec[i].kind = Decoded::FAIL;
+      B.rec[i].fail = (int)B.fails.size();
+      B.fails.push_back(msg);
+      B.rec.resize(i + 1);
+      break;
+    }
+  }
+  t_capture = nullptr;
+}
+
+// The pipeline: a reader thread cuts the input into batches, `nDec` threads decode them, the caller's thread takes them
+// in file order.  At most `window` batches exist at a time.
+class DecodePipe {
+ public:
+  typedef std::shared_ptr<Batch> Ptr;
+  // fill(B): the reader's step -- append records to B, return false when the input is exhausted (B may hold records)
+  template <class Fill, class One>
+  DecodePipe(int nDec, Fill fill, One one) : window_((size_t)std::max(4, 3 * nDec)) {
+    reader_ = std::thread([this, fill]() {
+      for (;;) {
+        Ptr b;
+        {
+          std::lock_guard<std::mutex> lk(m_);
+          if (!free_.empty()) {
+            b = free_.back();
+            free_.pop_back();
+          }
+        }
+        if (!b) b = std::make_shared<Batch>();
+        const bool more = fill(*b);
+        {
+          std::unique_lock<std::mutex> lk(m_);
+          if (!b->off.empty()) {
+            space_.wait(lk, [&] { return order_.size() < window_ || stop_; });
+            if (stop_) break;
+            order_.push_back(b);
+            work_.push_back(b);
+          }
+          if (!more) {
+            eof_ = true;
+            avail_.notify_all();
+            done_.notify_all();
+            break;
+          }
+        }
+        avail_.notify_one();
+      }
+    });
+    for (int i = 0; i < nDec; i++)
+      dec_.emplace_back([this, one]() {
+        for (;;) {
+          Ptr b;
+          {
+            std::unique_lock<std::mutex> lk(m_);
+            avail_.wait(lk, [&] { return !work_.empty() || eof_ || stop_; });
+            if (stop_ || (work_.empty() && eof_)) return;
+            b = work_.front();
+            work_.pop_front();
+          }
+          decodeBatch(*b, one);
+          {
+            std::lock_guard<std::mutex> lk(m_);
+            b->decoded = true;
+          }
+          done_.notify_all();
+        }
+      });
+  }
+  // the next batch in file order, decoded; nullptr at the end of the input
+  Ptr next() {
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return (!order_.empty() && order_.front()->decoded) || (order_.empty() && eof_); });
+    if (order_.empty()) return nullptr;
+    Ptr b = order_.front();
+    order_.pop_front();
+    space_.notify_one();
+    return b;
+  }
+  void give(Ptr b) {  // a batch the caller is done with: its memory serves the next one
+    std::lock_guard<std::mutex> lk(m_);
+    free_.push_back(std::move(b));
+  }
+  ~DecodePipe() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    space_.notify_all();
+    avail_.notify_all();
+    if (reader_.joinable()) reader_.join();
+    for (auto& t : dec_) t.join();
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable avail_, done_, space_;
+  std::deque<Ptr> work_, order_;
+  std::vector<Ptr> free_;
+  size_t window_;
+  bool eof_ = false, stop_ = false;
+  std::thread reader_;
+  std::vector<std::thread> dec_;
+};
+
+int g_decoders = 0;  // --threads / GENRICH_THREADS (0 or 1: records are decoded on the parsing thread)
+
+// reader -> decoders -> the caller's thread, or all three in turn on the caller's thread (one decoder or none)
+template <class Fill, class One, class Apply>
+void runDecode(int nDec, Fill fill, One one, Apply apply) {
+  if (nDec > 1) {
+    DecodePipe pipe(nDec, fill, one);
+    while (DecodePipe::Ptr b = pipe.next()) {
+      for (const Decoded& r : b->rec) apply(*b, r);
+      pipe.give(std::move(b));
+    }
+  } else {
+    Batch B;
+    for (bool more = true; more;) {
+      more = fill(B);
+      decodeBatch(B, one);
+      for (const Decoded& r : B.rec) apply(B, r);
+    }
+  }
+}
+
+// a failure of the READER (a truncated BAM record ...) travels as a pseudo-record of length 0 whose bytes are the
+// message: the decoder "dies" with it, and it is raised in file order like any other
+void readerFailure(Batch& B, const char* tail) {
+  const size_t n = strlen(tail) + 1;
+  memcpy(B.room(n), tail, n);
+  B.off.push_back((uint32_t)B.used);
+  B.len.push_back(0u);
+  B.used += n;
+}
+
+uint64_t readSAM(State& S, In& in, Counts& C) {
+  std::vector<char> line(REC_MAX);
   ReadSet rs;
-  bool pastHeader = false;
-  bool useFirst = first != nullptr;
-  for (;;) {
-    char* l;
-    if (useFirst) { l = first; useFirst = false; }
-    else if (!(l = in.gets(line.data(), (int)line.size()))) break;
-    if (l[0] == '@') {
-      if (pastHeader) die(l, ": misplaced SAM header line");
-      headerLine(S, l);
-      continue;
-    }
-    pastHeader = true;
-    // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [extra], cut up as the reference does
-    // (readSAM 4524-4530, loadFields 4350-4377): strtok on TAB -- so a run of tabs is one separator, and
-    // the last field of a line keeps its line end -- with the integer fields converted (getInt: the whole
-    // token must be a number) as they are met, QUAL included in that order of events.
-    char* save = nullptr;
-    char* qname = strtok_r(l, "\t", &save);
-    if (!qname) die(l, ": poorly formatted SAM/BAM record");
-    char* fld[12] = {nullptr};
-    fld[0] = qname;
-    uint16_t flag = 0;
-    uint32_t pos = 0, pnext = 0;
-    uint8_t mapq = 0;
-    char* extra = nullptr;
-    int nf = 1;
-    for (char* f = strtok_r(nullptr, "\t", &save); f; f = strtok_r(nullptr, "\t", &save)) {
-      fld[nf] = f;
-      switch (nf) {
-        case 1: flag = (uint16_t)getInt(f); break;
-        case 3: pos = (uint32_t)(getInt(f) - 1); break;
-        case 4: mapq = (uint8_t)getInt(f); break;
-        case 7: pnext = (uint32_t)(getInt(f) - 1); break;
-        case 8: (void)getInt(f); break;  // TLEN: converted, then ignored
-        default: break;
+  // the header: on this thread, line by line (it builds the table the decoders look reference names up in)
+  char* l;
+  while ((l = in.gets(line.data(), (int)line.size())) && l[0] == '@') headerLine(S, l);
+  if (l) {
+    const ChromIndex cx(S);
+    const Opts& o = S.o;
+    bool firstPending = true;
+    auto fill = [&in, &line, &firstPending](Batch& B) -> bool {
+      B.reset(BATCH_BYTES + REC_MAX);
+      if (firstPending) {  // (the line that ended the header)
+        firstPending = false;
+        const size_t n = strlen(line.data()) + 1;
+        memcpy(B.room(n), line.data(), n);
+        B.add(n);
       }
-      if (++nf == 11) {
-        extra = strtok_r(nullptr, "\n", &save);
-        break;
+      while (B.used < BATCH_BYTES) {
+        char* at = B.room(REC_MAX);
+        if (!in.gets(at, (int)REC_MAX)) return false;
+        B.add(strlen(at) + 1);
       }
-    }
-    if (nf < 11) die(qname, ": poorly formatted SAM/BAM record");
-    C.count++;
-    if (flag & 0x4) { C.unmapped++; continue; }
-    if (!strcmp(qname, "*") || !strcmp(fld[2], "*")) die(qname, ": poorly formatted SAM/BAM record");
-    if (flag & 0xE00) { C.supp++; continue; }
-    int ci = findChrom(S, fld[2]);
-    if (mapq < S.o.minMapQ) { C.lowMapQ++; continue; }
-    int length = calcDist(qname, fld[9], fld[5]);
-    float score = samScore(extra);
-    record(S, rs, C, qname, flag, ci, pos, mapq, length, pnext, score, fld[10], (int)strlen(fld[10]), 33);
+      return true;
+    };
+    auto one = [&o, &cx](char* base, uint32_t off, uint32_t, Decoded& r) { decodeSamLine(o, cx, base, base + off, r); };
+    runDecode(g_decoders, fill, one, [&](const Batch& B, const Decoded& r) { applyDecoded(S, rs, C, B, r, 33); });
   }
   finishFile(S, rs, C);
   return C.count;
@@ -1075,76 +1328,76 @@ std::vector<int> bamRefTable(State& S, In& g) {
   return idx;
 }
 
+// one BAM alignment block (parseBAM 4826-4977 up to the call of parseAlign; loadBAMfields 4660-4688)
+void decodeBamBlock(const Opts& o, const std::vector<int>& idx, char* base, uint32_t off, uint32_t blkLen, Decoded& r) {
+  const uint8_t* blk = reinterpret_cast<const uint8_t*>(base) + off;
+  if (blkLen == 0) die("", reinterpret_cast<const char*>(blk));  // (readerFailure)
+  const int32_t n_ref = (int32_t)idx.size();
+  auto i32 = [&](size_t p) { return (int32_t)(blk[p] | (blk[p + 1] << 8) | (blk[p + 2] << 16) | ((uint32_t)blk[p + 3] << 24)); };
+  auto u16 = [&](size_t p) { return (uint16_t)(blk[p] | (blk[p + 1] << 8)); };
+  // the name length is a signed byte, and only the end of the last field is checked against the block (4885).
+  // (Offsets that leave the block on the way are an error here; the reference reads whatever its line buffer
+  // holds there.)
+  const int32_t refID = i32(0), pos = i32(4);
+  const int l_read_name = (int8_t)blk[8];
+  r.mapq = blk[9];
+  const uint16_t n_cigar = u16(12);
+  r.flag = u16(14);
+  const int32_t l_seq = i32(16), next_pos = i32(24);
+  const long long nameOff = 32, cigOff = nameOff + l_read_name, seqOff = cigOff + 4LL * n_cigar,
+                  qualOff = seqOff + (l_seq + 1) / 2, auxOff = qualOff + l_seq;
+  if (auxOff > (long long)blkLen) die("", "Cannot parse BAM file");
+  if (cigOff < 32 || seqOff > (long long)blkLen || qualOff < 32 || qualOff > (long long)blkLen || auxOff < 32 ||
+      !memchr(blk + nameOff, '\0', blkLen - (size_t)nameOff))
+    die("", "Cannot parse BAM file");
+  const char* qname = (const char*)&blk[nameOff];
+  r.qname = off + (uint32_t)nameOff;
+  if (r.flag & 0x4) { r.kind = Decoded::UNMAPPED; return; }
+  if (!strcmp(qname, "*") || refID < 0 || refID >= n_ref || pos < 0) die(qname, ": poorly formatted SAM/BAM record");
+  if (r.flag & 0xE00) { r.kind = Decoded::SUPP; return; }
+  if (r.mapq < o.minMapQ) { r.kind = Decoded::LOWQ; return; }
+  // calcDistBAM 4694-4706: the distance to the 3' end is l_seq - I - S + D, with no check of the CIGAR
+  // against the sequence (unlike calcDist for SAM) -- also when SEQ is absent (l_seq = 0)
+  int length = l_seq;
+  for (int k = 0; k < n_cigar; k++) {
+    const uint32_t c = (uint32_t)i32((size_t)cigOff + 4 * (size_t)k);
+    const int op = (int)(c & 15);
+    if (op == 1 || op == 4) length -= (int)(c >> 4);
+    else if (op == 2) length += (int)(c >> 4);
+  }
+  r.length = length;
+  r.score = bamScore(blk + (size_t)auxOff, blk + blkLen);
+  r.ci = idx[(size_t)refID];
+  r.pos = (uint32_t)pos;
+  r.pnext = (uint32_t)next_pos;
+  r.qual = off + (uint32_t)qualOff;
+  r.qualLen = l_seq;
+  r.kind = Decoded::REC;
+}
+
 uint64_t readBAM(State& S, In& in, Counts& C) {
   In& g = in;
   bamHeaderText(S, g);
-  std::vector<int> idx = bamRefTable(S, g);
-  const int32_t n_ref = (int32_t)idx.size();
+  const std::vector<int> idx = bamRefTable(S, g);
   ReadSet rs;
-  std::vector<uint8_t> copy;
-  for (;;) {
-    // a record that lies inside one inflated block is parsed where it is; one that straddles two
-    // blocks (or any record, with zlib's reader) is copied first
-    const uint8_t* blk;
-    size_t blkLen;
-    const uint8_t* p4 = g.peek(4);
-    const uint8_t* whole = nullptr;
-    if (p4) {
-      const int32_t bs = (int32_t)(p4[0] | (p4[1] << 8) | (p4[2] << 16) | ((uint32_t)p4[3] << 24));
-      if (bs == -1) break;  // (see rdI32)
-      if (bs < 32) die("", "Cannot parse BAM file");  // (a negative size passes the reference's unsigned test and fails its end-of-block test, 4870 / 4885)
-      whole = g.peek(4 + (size_t)bs);
-      if (whole) {
-        blk = whole + 4;
-        blkLen = (size_t)bs;
-        g.advance(4 + (size_t)bs);
+  const Opts& o = S.o;
+  // the reader: alignment blocks (block_size, then that many bytes), copied out of the inflated stream
+  auto fill = [&g](Batch& B) -> bool {
+    B.reset(BATCH_BYTES + REC_MAX);
+    while (B.used < BATCH_BYTES) {
+      const int32_t bs = rdI32(g, false);
+      if (bs == -1) return false;  // (see rdI32)
+      // (a negative size passes the reference's unsigned test and fails its end-of-block test, 4870 / 4885)
+      if (bs < 32 || !gzReadAll(g, B.room((size_t)bs), (size_t)bs)) {
+        readerFailure(B, "Cannot parse BAM file");
+        return false;
       }
+      B.add((size_t)bs);
     }
-    if (!whole) {
-      int32_t bs = rdI32(g, false);
-      if (bs == -1) break;
-      if (bs < 32) die("", "Cannot parse BAM file");
-      copy.resize((size_t)bs);
-      if (!gzReadAll(g, copy.data(), (size_t)bs)) die("", "Cannot parse BAM file");
-      blk = copy.data();
-      blkLen = (size_t)bs;
-    }
-    auto i32 = [&](size_t o) { return (int32_t)(blk[o] | (blk[o + 1] << 8) | (blk[o + 2] << 16) | ((uint32_t)blk[o + 3] << 24)); };
-    auto u16 = [&](size_t o) { return (uint16_t)(blk[o] | (blk[o + 1] << 8)); };
-    // loadBAMfields 4660-4688: the name length is a signed byte, and only the end of the last field is
-    // checked against the block (4885).  (Offsets that leave the block on the way are an error here; the
-    // reference reads whatever its line buffer holds there.)
-    const int32_t refID = i32(0), pos = i32(4);
-    const int l_read_name = (int8_t)blk[8];
-    const uint8_t mapq = blk[9];
-    const uint16_t n_cigar = u16(12), flag = u16(14);
-    const int32_t l_seq = i32(16), next_pos = i32(24);
-    const long long nameOff = 32, cigOff = nameOff + l_read_name, seqOff = cigOff + 4LL * n_cigar,
-                    qualOff = seqOff + (l_seq + 1) / 2, auxOff = qualOff + l_seq;
-    if (auxOff > (long long)blkLen) die("", "Cannot parse BAM file");
-    if (cigOff < 32 || seqOff > (long long)blkLen || qualOff < 32 || qualOff > (long long)blkLen || auxOff < 32 ||
-        !memchr(blk + nameOff, '\0', blkLen - (size_t)nameOff))
-      die("", "Cannot parse BAM file");
-    const char* qname = (const char*)&blk[nameOff];
-    const size_t off = (size_t)auxOff;
-    C.count++;
-    if (flag & 0x4) { C.unmapped++; continue; }
-    if (!strcmp(qname, "*") || refID < 0 || refID >= n_ref || pos < 0) die(qname, ": poorly formatted SAM/BAM record");
-    if (flag & 0xE00) { C.supp++; continue; }
-    if (mapq < S.o.minMapQ) { C.lowMapQ++; continue; }
-    // calcDistBAM 4694-4706: the distance to the 3' end is l_seq - I - S + D, with no check of the CIGAR
-    // against the sequence (unlike calcDist for SAM) -- also when SEQ is absent (l_seq = 0)
-    int length = l_seq;
-    for (int k = 0; k < n_cigar; k++) {
-      const uint32_t c = (uint32_t)i32((size_t)cigOff + 4 * (size_t)k);
-      const int op = (int)(c & 15);
-      if (op == 1 || op == 4) length -= (int)(c >> 4);
-      else if (op == 2) length += (int)(c >> 4);
-    }
-    float score = bamScore(blk + off, blk + blkLen);
-    record(S, rs, C, qname, flag, idx[refID], (uint32_t)pos, mapq, length, (uint32_t)next_pos, score,
-           (const char*)blk + qualOff, l_seq, 0);
-  }
+    return true;
+  };
+  auto one = [&o, &idx](char* base, uint32_t off, uint32_t len, Decoded& r) { decodeBamBlock(o, idx, base, off, len, r); };
+  runDecode(g_decoders, fill, one, [&](const Batch& B, const Decoded& r) { applyDecoded(S, rs, C, B, r, 0); });
   finishFile(S, rs, C);
   return C.count;
 }
@@ -1518,10 +1771,10 @@ int main(int argc, char** argv) {
                                      {"devices", required_argument, nullptr, 1003},
                                      {"threads", required_argument, nullptr, 1002},
                                      {nullptr, 0, nullptr, 0}};
-  {  // BGZF inflate threads: --threads N, else GENRICH_THREADS, else up to 8 of the machine's cores
+  {  // BGZF inflate threads and record decoders: --threads N, else GENRICH_THREADS, else up to 16 of the machine's cores
     const char* e = getenv("GENRICH_THREADS");
     unsigned hw = std::thread::hardware_concurrency();
-    g_threads = e ? atoi(e) : (int)std::min(8u, hw ? hw : 1u);
+    g_threads = e ? atoi(e) : (int)std::min(16u, hw ? hw : 1u);
   }
   int c;
   while ((c = getopt_long(argc, argv, "ht:c:o:f:k:b:zyw:xjd:De:E:m:s:p:q:a:l:g:rR:XPSL:vV", longOpts, nullptr)) != -1)
@@ -1597,6 +1850,7 @@ int main(int argc, char** argv) {
     std::string list(o.xchrom);
     for (char* t = strtok(list.data(), ", "); t; t = strtok(nullptr, ", ")) S.xchr.push_back(t);
   }
+  g_decoders = g_threads;
   if (o.pqvalue <= 0.0f || o.pqvalue > 1.0f) die("", "p-/q-value must be in (0,1]");
   const float thr = -log10f(o.pqvalue);
 
@@ -1699,7 +1953,7 @@ int main(int argc, char** argv) {
         readBAM(S, in, C);
       else {
         in.unread(magic, (size_t)std::max(0, got));  // the sniffed bytes are the beginning of the first line
-        readSAM(S, in, nullptr, C);
+        readSAM(S, in, C);
       }
       checkIn(in);
       if (!isStdin) in.close();

@@ -348,3 +348,59 @@ def test_cli_two_contexts_one_gpu_equal_one(name):
     assert open(out + ".log", "rb").read() == G.read_gz(name, "out.log")
     if "-X" not in case["args"]:
         assert open(out + ".narrowPeak", "rb").read() == G.read_gz(name, "out.narrowPeak")
+
+
+# ---- parallel record decoding: decoder threads over batches of records, the state on one thread ----
+@pytest.mark.parametrize("name", ["basic", "multimap", "dups_pairs", "dups_x_bam", "quirks_sam", "quirks_bam",
+                                  "unpaired_x", "unpaired_bam_atac", "ctrl_q", "reps3"])
+@pytest.mark.parametrize("threads,batch", [("1", None), ("4", None), ("4", "150"), ("3", "1")])
+def test_cli_parallel_decoding_is_the_sequential_stream(name, threads, batch, tmp_path):
+    """The -b event stream, the -R log and everything -v prints must not depend on how many threads decode the
+    records or where the batches are cut (GENRICH_BATCH_BYTES: batches of a line or two, so that read-name groups,
+    pairs and multimapping sets straddle them).  The golden event stream is the reference's."""
+    cases, mg = _cases()
+    args = _write_inputs(cases[name], mg, str(tmp_path / "in"))
+    a = [x for x in args if x != "-X"] + ["-v"]
+    bed, dups = str(tmp_path / "events.bed"), str(tmp_path / "dups.txt")
+    if "-r" in a:
+        a += ["-R", dups]
+    env = dict(os.environ)
+    if batch:
+        env["GENRICH_BATCH_BYTES"] = batch
+    res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-b", bed] + a, capture_output=True, text=True, env=env)
+    assert res.returncode == 0, res.stderr
+    assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
+    ref = subprocess.run([_binary(), "--events-only", "--threads", "1", "-b", bed + ".1"] + [x if x != dups else dups + ".1" for x in a],
+                         capture_output=True, text=True)
+    assert res.stderr == ref.stderr
+    if "-r" in a:
+        assert open(dups).read() == open(dups + ".1").read()
+
+
+def test_cli_parallel_decoding_keeps_warnings_and_errors_in_file_order(tmp_path):
+    """A record that cannot be decoded is found by a decoder thread, possibly long before the records ahead of it have
+    gone through the run's state: its error must still come after their warnings, and be the reference's."""
+    sq = "@HD\tVN:1.0\tSO:queryname\n@SQ\tSN:chr1\tLN:100000\n"
+    rec = lambda q, flag, pos, pn, tl, cigar="50M": f"{q}\t{flag}\tchr1\t{pos}\t30\t{cigar}\t=\t{pn}\t{tl}\t*\t*\tAS:i:0\n"
+    body = ""
+    for i in range(40):
+        body += rec(f"r{i}", 99, 100 + 10 * i, 300 + 10 * i, 250) + rec(f"r{i}", 147, 300 + 10 * i, 100 + 10 * i, -250)
+    # a read with more alignments than the reference's buffer holds: a -v warning (Genrich.c:4169-4171)
+    many = "".join(rec("crowd", 256 | 0x10 * (k % 2), 5000 + 7 * k, 0, 0) for k in range(140))
+    bad = rec("broken", 99, 9000, 9100, 150, cigar="50Q")  # unknown CIGAR op: an error
+    tail = "".join(rec(f"t{i}", 99, 20000 + i, 20100 + i, 150) for i in range(30))
+    sam = tmp_path / "t.sam"
+    sam.write_text(sq + body + many + body.replace("r", "s").replace("chs1", "chr1") + bad + tail)
+    outs = []
+    for threads, batch in (("1", None), ("4", "120"), ("3", "1"), ("8", None)):
+        env = dict(os.environ)
+        if batch:
+            env["GENRICH_BATCH_BYTES"] = batch
+        res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-v", "-y", "-t", str(sam), "-b", str(tmp_path / "e.bed")],
+                             capture_output=True, text=True, env=env)
+        assert res.returncode != 0
+        outs.append(res.stderr)
+    lines = outs[0].splitlines()
+    assert lines[-1] == "Error! 'Q': unknown Op in CIGAR"
+    assert any("more than 128 alignments" in l for l in lines[:-1])
+    assert all(o == outs[0] for o in outs[1:])
