@@ -1293,14 +1293,12 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
 #undef GX_LAUNCH_PEAKS
       }
       // the peaks, in order, into pinned host memory; their number with them
-      const u32 seq = ++ctx->mailSeq;
       hipLaunchKernelGGL(k_peaks, dim3(std::min<u32>(rChunks, gridP)), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
                          misc + M_NHEADS, lbP, gen, static_cast<gx_peak*>(ctx->hPeaks.dp), misc + M_NPEAKS, &dm->nPeaks,
-                         ctx->dStatus.as<u32>(), misc + M_TICKET4, reinterpret_cast<u64*>(misc + M_PEAKBP), reinterpret_cast<u64*>(&dm->peakBP),
-                         ctx->dRisk.as<RiskBuf>(), mail_out(ctx), seq);
+                         ctx->dStatus.as<u32>(), misc + M_TICKET4, reinterpret_cast<u64*>(misc + M_PEAKBP), reinterpret_cast<u64*>(&dm->peakBP));
       if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
-      // the end: status and counts came with k_peaks' last workgroup (the mail), one synchronisation
-      if (int rc__ = mail_wait(ctx, seq)) return rc__;
+      // the end: status, counts (and whatever else is pending) through the mail kernel, one synchronisation
+      if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
       R = ctx->mail->R;
       ctx->runSeen = R;
       if (R <= cap) break;

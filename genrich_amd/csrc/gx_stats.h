@@ -1143,8 +1143,11 @@ __global__ __launch_bounds__(256) void k_peak_both(u32 nShort, const uint4* __re
                                                    const u32* __restrict__ nLong, float thr, float minAUC, int minLen,
                                                    gx_peak* __restrict__ cand, u32* __restrict__ valid) {
   __shared__ float hot[PV ? PV_WHOLE : 1];
-  if (PV) load_whole_lut(hot, p);
   const u32 nWalk = gridDim.x - nShort;  // (the long candidates' workgroups come first in the grid: they are the long pole)
+#ifndef GX_PK_NO_EARLY_EXIT
+  if (blockIdx.x < nWalk && blockIdx.x * 4 >= *nLong) return;  // (no long candidate for this workgroup: not even the table)
+#endif
+  if (PV) load_whole_lut(hot, p);
   if (blockIdx.x >= nWalk)
     peak_short_body<USEQ, PV>(blockIdx.x - nWalk, nShort, hot, hdr, end, p, q, chromOff, nChrom, nCands, thr, minAUC, minLen, cand, valid);
   else
@@ -1220,15 +1223,15 @@ __global__ __launch_bounds__(SW_NT) void k_runs(SweepMasks M, u64* __restrict__ 
       a += __popcll(stb[k]);
       b += __popcll(enb[k]);
     }
-    u32 totA, totB;
+    // ONE scan and one look-back (round 3; two of each before): starts and ends alternate, so the ends before a word
+    // are the starts before it minus one if a run is open across its first bit -- that bit significant, but not a start
+    u32 totA;
     u32 oa = block_excl_scan<u32, SW_NT>(a, scratch, &totA);
-    u32 ob = block_excl_scan<u32, SW_NT>(b, scratch, &totB);
+    (void)b;
     if (threadIdx.x < 64) {
       const u64 ea = lookback_gen(lbS, id, totA, gen, st);
-      const u64 eb = lookback_gen(lbE, id, totB, gen, st);
       if (threadIdx.x == 0) {
         s_base[0] = ea;
-        s_base[1] = eb;
         if (id == nChunks - 1) {
           const u32 total = (u32)ea + totA;
           *nRuns = total > cap ? cap : total;
@@ -1239,7 +1242,24 @@ __global__ __launch_bounds__(SW_NT) void k_runs(SweepMasks M, u64* __restrict__ 
     }
     __syncthreads();
     oa += (u32)s_base[0];
-    ob += (u32)s_base[1];
+    u32 ob = oa;
+    if (w0 < M.nWords) {
+      const u64 sig0 = M.sig[w0];
+      ob -= (u32)(sig0 & ~stb[0] & 1ull);
+    }
+#ifdef GX_RUNS_TWO_SCANS
+    {
+      u32 totB;
+      ob = block_excl_scan<u32, SW_NT>(b, scratch, &totB);
+      __shared__ u64 s_b;
+      if (threadIdx.x < 64) {
+        const u64 eb = lookback_gen(lbE, id, totB, gen, st);
+        if (threadIdx.x == 0) s_b = eb;
+      }
+      __syncthreads();
+      ob += (u32)s_b;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < SW_ITEMS; k++) {
       u64 x = stb[k];
@@ -1296,13 +1316,11 @@ __global__ __launch_bounds__(SW_NT) void k_peaks(const gx_peak* __restrict__ can
                                                  gx_peak* __restrict__ peaks /* pinned host memory */, u32* __restrict__ nPeaks,
                                                  u32* __restrict__ nPeaksHost, u32* __restrict__ st, u32* __restrict__ ticket,
                                                  u64* __restrict__ bpAcc /* zero before, zero after */,
-                                                 u64* __restrict__ bpHost /* pinned: the peaks' total length (callPeaks 925) */,
-                                                 const RiskBuf* __restrict__ rb, MailOut m, u32 seq) {
+                                                 u64* __restrict__ bpHost /* pinned: the peaks' total length (callPeaks 925) */) {
   constexpr int PW = sizeof(gx_peak) / 4;
   __shared__ u32 scratch[8];
   __shared__ u32 stage[RC_CHUNK * PW];
   __shared__ u64 s_base;
-  __shared__ u32 s_last;
   const u32 H = *nHeads;
   const u32 nChunks = (H + RC_CHUNK - 1) / RC_CHUNK;
   u64 bp = 0;  // (the host summed the lengths over the pinned records: 1.7 MB of reads behind the kernel)
@@ -1336,23 +1354,19 @@ __global__ __launch_bounds__(SW_NT) void k_peaks(const gx_peak* __restrict__ can
     for (u32 i = threadIdx.x; i < tot * PW; i += SW_NT) dst[i] = stage[i];
     __syncthreads();
   }
-  // The sweep's mail (round 3: a k_mail launch behind this kernel): the workgroup that finishes LAST sends it.  Every
-  // workgroup's writes that the host reads -- peaks and their count, in pinned memory -- have completed before its ticket
-  // (stores_done: no L2 to write back for host memory); the status word is only ever touched by atomics.  The last
-  // workgroup sees the full count, hence all of them.  (The ticket cleans up after itself.)
+  // The peaks' total length (callPeaks 925; the host used to sum it over the pinned records): every workgroup adds its
+  // share with an atomic and takes a ticket; the one that finishes LAST hands the sum over and clears it.
+  // (The sweep's mail stays a launch of its own behind this kernel.  Sending it from the last workgroup was tried:
+  // the peaks are posted writes to HOST memory from many CUs, and "my stores have completed" on one CU does not order
+  // them ahead of another CU's write of the sequence number -- a two-process test saw a stale record once in ten runs.
+  // The end of a kernel does.)
   bp = wave_sum(bp);
   if (lane_id() == 0 && bp) atomicAdd((unsigned long long*)bpAcc, (unsigned long long)bp);
   stores_done();
   __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (s_last) {  // block-uniform
-    if (threadIdx.x == 0) {
-      *ticket = 0;
-      *bpHost = atomicExch((unsigned long long*)bpAcc, 0ull);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    mail_body(nullptr, st, nullptr, nullptr, nullptr, nullptr, rb, m, seq);
+  if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+    *ticket = 0;
+    *bpHost = atomicExch((unsigned long long*)bpAcc, 0ull);
   }
 }
 

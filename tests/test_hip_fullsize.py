@@ -205,7 +205,8 @@ def test_fullsize_config4_atac_multimap_is_the_oracles_bytes():
     ev = synth.atac_events(synth.add_multimap(ev, LENS, 0.10, seed=11), LENS, d=100)
     case = dict(lens=LENS, replicates=[dict(save=None, treat=ev, ctrl=None)])
     flags = _whole_genome_against_oracle(case, B.make_params(pq=0.01), 10_000)
-    assert flags & 4 and not flags & 1, "fractional weights take the general chain"
+    # (2 x 10^8 events are more than the fused tile stage is even tried on: straight to the general chain)
+    assert not flags & 1, "fractional weights take the general chain"
 
 
 def test_fullsize_config5_three_replicates_fisher_q_is_the_oracles_bytes():
