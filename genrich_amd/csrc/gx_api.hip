@@ -190,6 +190,7 @@ struct gx_ctx {
   u64 beginGenome = 0;
   bool fellBack = false;        // some sample was sent back from k_sbtile to the general chain
   bool ptGrew = false;          // some sample was built again with larger page tables (RETRY_PT)
+  bool fragFused = false;       // the last build's tile kernel adds the general fragLen path's terms itself (TileIn::fragAcc)
   bool looseOk = false;         // the treatment sample's tile stage left valid sweep bits on the loose slots
   bool riskNearThr = false;     // a re-evaluated table entry lies next to the significance threshold
   size_t looseStride = 0;       // words between the sig / brk masks the tile stage wrote into swMask
@@ -762,6 +763,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");  // k_tile alone: the dominant kernel (bench.py's roofline)
   TileIn tin{SS.a.as<uint16_t>(), SE.a.as<uint16_t>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
+  // the tile stage is k_tile_fast (+ k_tile_heavy): the general fragLen path's terms ride in it (TileIn::fragAcc)
+  static const bool noFragFuse = getenv("GX_FRAG_WALK_ALL") != nullptr;  // (tests / measurements: round 2's separate walk)
+  ctx->fragFused = !fused && !ctx->hasBed && !getenv("GX_TILE_OLD") && !noFragFuse;
+  if (ctx->fragFused) {
+    tin.ff = ff;
+    tin.fragAcc = acc;
+  }
   // narrow tiles with 16-bit LDS counters (twice the tiles in flight), then the wide ones from their list
   // (whose length stays on the device: an empty list costs one idle launch)
   const u32* wl = ctx->wideList.as<u32>();
@@ -813,7 +821,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   const u32 ivChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
   IvScanOut so{out.tileIvOff.as<u32>(), ctx->tilePrevEnd.as<u32>(), out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV,
                ctx->tileSlot.as<u32>(), ctx->chromLooseOff.as<u32>(), ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctl,
-               ctx->tileDeep.as<u32>(), ff, ctx->fragList.as<u32>()};
+               ctx->tileDeep.as<u32>(), ff, ctx->fragList.as<u32>(), ctx->fragFused ? acc : (long long*)nullptr};
   static const bool noClose = getenv("GX_NO_CLOSE") != nullptr, sepClose = getenv("GX_SEPARATE_CLOSE") != nullptr;
   const bool closeInScan = wantEarly && !noClose && !sepClose;  // (k_scan_iv_close, below)
   if (!closeInScan)
@@ -856,7 +864,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       if (int rc__ = dbg_sync(ctx, "k_close")) return rc__;
     } else {
     hipLaunchKernelGGL(k_frag_walk, dim3(std::max(1u, std::min((nTiles + 3) / 4, 4096u))), dim3(256), 0, s, lE, lV, tm, tOff,
-                       tPrev, nTiles, ff, ctx->fragList.as<u32>(), acc);
+                       tPrev, nTiles, ff, ctx->fragList.as<u32>(), acc,
+                       ctx->fragFused ? ctx->heavyList.as<u32>() : (const u32*)nullptr, ctx->nWide.as<u32>() + 2);
     // (single thread: chromosome offsets of the chromosomes without tiles, closed form -> accumulator pair,
     // this rank's words of the all-reduce)
     hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, fsel);
@@ -930,7 +939,8 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
       const u32 nTiles = ctx->nTiles;
       hipLaunchKernelGGL(k_frag_walk, dim3(std::max(1u, std::min((nTiles + 3) / 4, 4096u))), dim3(256), 0, s, ctx->looseEnd.as<u32>(),
                          ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), ctx->expt.tileIvOff.as<u32>(),
-                         ctx->tilePrevEnd.as<u32>(), nTiles, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(), ctx->closeSel.acc);
+                         ctx->tilePrevEnd.as<u32>(), nTiles, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(), ctx->closeSel.acc,
+                         ctx->fragFused ? ctx->heavyList.as<u32>() : (const u32*)nullptr, ctx->nWide.as<u32>() + 2);
       hipLaunchKernelGGL(k_frag_select, dim3(1), dim3(1), 0, s, ctx->closeSel);
       if (int rc__ = dbg_sync(ctx, "k_frag (after k_close)")) return rc__;
     }

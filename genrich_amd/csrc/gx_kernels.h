@@ -558,10 +558,17 @@ struct __attribute__((aligned(16))) TileMeta {
   u32 slot;               // first loose output slot
 };
 
+struct FragFix;
 struct TileIn {
   const uint16_t* S;  const uint16_t* E;  // start / end offsets inside the tile, bucketed by tile
   const u64* F;                           // fractional-weight records
   const TileMeta* meta;
+  // k_tile_fast only: with the general fragLen path on (FragFix::slow: fractional weights), the tile kernel adds the
+  // exact term of every interval but a tile's first -- it knows where each one starts -- to `fragAcc` itself
+  // (frag_term; k_scan_iv adds the tiles' first intervals, k_frag_walk what k_tile_heavy emitted): round 2 walked
+  // all loose slots once more for that (k_frag_walk over every tile: 0.87 ms at config 4)
+  const FragFix* ff = nullptr;
+  long long* fragAcc = nullptr;
 };
 
 __global__ __launch_bounds__(256) void k_tile_meta(const u32* __restrict__ offS, const u32* __restrict__ offE,
@@ -1166,6 +1173,8 @@ struct IvScanOut {
   const u32* tileDeep;
   FragFix* ff;
   u32* fragList;
+  // the general fragLen path shared with the tile kernel (TileIn::fragAcc): the tiles' first intervals are added here
+  long long* fragAcc = nullptr;
 };
 
 __device__ __forceinline__ void scan_iv_body(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
@@ -1177,6 +1186,8 @@ __device__ __forceinline__ void scan_iv_body(const u32* __restrict__ tileCount, 
   __shared__ u64 s_sum, s_max;
   const u32 nChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
   const bool slowFrag = out.ff->slow != 0;
+  const bool firstTerms = slowFrag && out.fragAcc != nullptr;
+  long long fhi = 0, flo = 0;
   for (u32 id = blockIdx.x; id < nChunks; id += gridDim.x) {
     const u32 tb = id * STL_CHUNK + threadIdx.x * STL_ITEMS;
     u32 c[STL_ITEMS];
@@ -1236,7 +1247,11 @@ __device__ __forceinline__ void scan_iv_body(const u32* __restrict__ tileCount, 
         const u32 prevEnd = (u32)(kex >> 32) == ci + 1 ? (u32)kex : 0u;
         out.tilePrevEnd[t] = prevEnd;
         if (c[k]) {
-          if (out.tileDeep[t])
+          if (firstTerms) {  // the tile's first interval: it starts where the last interval before the tile ended
+            const u32 slot = out.tileSlot[t];
+            frag_term(out.looseEnd[slot] - prevEnd, out.looseV[slot], fhi, flo);
+          }
+          if (out.tileDeep[t])  // (the list also serves the p-values of the deep tiles: k_pval_deep)
             out.fragList[atomicAdd(&out.ff->nList, 1u)] = t;
           else if (!slowFrag) {
             // the tile's first interval ends inside the tile: it is >= 2 TILE long only if it starts a whole tile earlier
@@ -1273,6 +1288,14 @@ __device__ __forceinline__ void scan_iv_body(const u32* __restrict__ tileCount, 
     }
     __syncthreads();
   }
+  if (firstTerms) {  // block-uniform
+    fhi = wave_sum(fhi);
+    flo = wave_sum(flo);
+    if (lane_id() == 0) {
+      if (fhi) atomicAdd((u64*)&out.fragAcc[0], (u64)fhi);
+      if (flo) atomicAdd((u64*)&out.fragAcc[1], (u64)flo);
+    }
+  }
 }
 
 __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
@@ -1288,13 +1311,16 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv(const u32* __restrict__ tile
 __global__ __launch_bounds__(256) void k_frag_walk(const u32* __restrict__ looseEnd, const int* __restrict__ looseV,
                                                    const TileMeta* __restrict__ meta, const u32* __restrict__ tileIvOff,
                                                    const u32* __restrict__ tilePrevEnd, u32 nTiles, FragFix* __restrict__ ff,
-                                                   const u32* __restrict__ list, long long* __restrict__ acc) {
-  const bool slow = ff->slow != 0;
-  const u32 nItems = slow ? nTiles : ff->nList;
+                                                   const u32* __restrict__ list, long long* __restrict__ acc,
+                                                   const u32* __restrict__ heavyList, const u32* __restrict__ nHeavy) {
+  // heavyList: the tile stage was k_tile_fast, which adds the general path's terms itself (TileIn::fragAcc) -- but for
+  // the heavy tiles (k_tile_heavy's): of those, everything behind the first interval (k_scan_iv's) is added here
+  const bool slow = ff->slow != 0, heavyOnly = slow && heavyList != nullptr;
+  const u32 nItems = heavyOnly ? *nHeavy : slow ? nTiles : ff->nList;
   long long c = 0, hi = 0, lo = 0;
   const int wv = threadIdx.x >> 6, lane = lane_id();
   for (u32 it = blockIdx.x * 4 + wv; it < nItems; it += gridDim.x * 4) {
-    const u32 t = slow ? it : list[it];
+    const u32 t = heavyOnly ? heavyList[it] : slow ? it : list[it];
     const u32 src = meta[t].slot, n = tileIvOff[t + 1] - tileIvOff[t];
     u32 prevEnd = tilePrevEnd[t];
     for (u32 b = 0; b < n; b += 64) {
@@ -1308,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_frag_walk(const u32* __restrict__ loose
       u32 s = __shfl_up(e, 1, 64);
       if (lane == 0) s = prevEnd;
       prevEnd = __shfl(e, 63, 64);
-      if (i < n) {
+      if (i < n && !(heavyOnly && i == 0)) {
         if (slow) frag_term(e - s, v, hi, lo); else c += frag_corr(e - s, v);
       }
     }

@@ -52,6 +52,9 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
   const u32 G = gridDim.x;
   const u32 lb = xcd_local_block(blockIdx.x, G);
   u32 bad = 0;
+  // the general fragLen path (fractional weights): this kernel adds the intervals' exact terms itself (TileIn::fragAcc)
+  const bool fragTerms = in.fragAcc != nullptr && (u32)__builtin_amdgcn_readfirstlane((int)in.ff->slow) != 0u;
+  long long fhi = 0, flo = 0;
   // pileups from which an interval is significant, when lambda was known before this kernel (LooseCtl)
   __shared__ u32 vsRed[2];
   const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.ctl, blockIdx.x == 0 && lane == 0, vsRed));
@@ -234,6 +237,14 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
         negM |= __ballot(after < 0);
         bigM |= __ballot(after >= FRAG_FAST_MAXV);
         runBase += __builtin_amdgcn_readlane(incS, 63);
+        if (fragTerms && mask) {  // wave-uniform
+          // the interval that ends here starts at the end before it: the lane's, the steps', or -- the tile's first
+          // interval -- somewhere before the tile (k_scan_iv adds that one: it knows where)
+          const u64 below = mask & ((1ull << lane) - 1ull);
+          const int prevLane = below ? 63 - __builtin_clzll(below) : 0;
+          const u32 pp = (u32)__shfl((int)p, prevLane, 64);
+          if (nz && (below || outCount)) frag_term(pos0 + p - (below ? pos0 + pp : lastEnd), before, fhi, flo);
+        }
         if (mask) {  // wave-uniform
           outCount += (u32)__popcll(mask);
           lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(mask));
@@ -250,6 +261,7 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
           out.looseEnd[o] = m.len;
           out.looseV[o] = runBase;
           if (runBase >= vsig) atomicOr((unsigned long long*)&out.sigMask[o >> 6], 1ull << (o & 63));
+          if (fragTerms && outCount) frag_term(m.len - lastEnd, runBase, fhi, flo);  // (the tile's first interval: k_scan_iv)
           lastEnd = m.len;
         }
         if (total) out.tileLastEnd[t] = lastEnd;
@@ -272,6 +284,14 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
       }
     }
     issue();
+  }
+  if (fragTerms) {  // wave-uniform
+    fhi = wave_sum(fhi);
+    flo = wave_sum(flo);
+    if (lane == 0) {
+      if (fhi) atomicAdd((u64*)&in.fragAcc[0], (u64)fhi);
+      if (flo) atomicAdd((u64*)&in.fragAcc[1], (u64)flo);
+    }
   }
   if (bad && lane == 0) atomicOr(st, bad);
 }
