@@ -230,13 +230,24 @@ def reference_e2e(lens, reps, max_frags=1_500_000):
     t0 = time.perf_counter()
     rc = subprocess.call([ref, "-t", sam, "-o", outp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     dt = time.perf_counter() - t0
+    # the same SAM text through THIS repo's host program up to the events (--events-only: no device work), with its
+    # default number of decoder threads: the ingest rate SURVEY 8 row f3 is about
+    host = None
+    hb = os.path.join(ROOT, "genrich_amd", "genrich-amd")
+    if os.path.exists(hb):
+        t1 = time.perf_counter()
+        hrc = subprocess.call([hb, "--events-only", "-t", sam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        hdt = time.perf_counter() - t1
+        if hrc == 0:
+            host = {"records_per_s": nrec / hdt, "seconds": hdt, "threads": min(16, os.cpu_count() or 1),
+                    "what": "genrich-amd --events-only on the same SAM text (parse, pair, weight -> events; no device work)"}
     for f in (sam, outp):
         if os.path.exists(f):
             os.remove(f)
     os.rmdir(td)
     if rc != 0:
         return None
-    return {"kind": "reference", "seconds": dt, "sam_records": nrec, "records_per_s": nrec / dt,
+    return {"kind": "reference", "host_ingest": host, "seconds": dt, "sam_records": nrec, "records_per_s": nrec / dt,
             "gbases_per_s": sum(slens) / dt / 1e9,
             "sample": f"oracle/_ref/Genrich -t (SAM text, {nrec} records = {len(tv)} fragments of the workload on chr19-chr22, "
                       f"{sum(slens)/1e6:.0f} Mbp) -> narrowPeak, one thread, {dt:.1f} s"}
@@ -308,7 +319,7 @@ def main():
         others = {}
         for c in (3, 4, 5):
             try:
-                r = bench_one(c, dict(CONFIGS[c]), args, env, steps=3, warmup=1, plain=True, want_e2e=False, want_cpu=True,
+                r = bench_one(c, dict(CONFIGS[c]), args, env, steps=5, warmup=3, plain=True, want_e2e=False, want_cpu=True,
                               headline=False)
                 others[str(c)] = {k: r[k] for k in ("ms_per_step", "value", "unit", "steps", "gate", "phases_ms") if k in r}
                 others[str(c)]["workload"] = r["config"]["workload"]

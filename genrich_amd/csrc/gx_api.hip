@@ -365,16 +365,17 @@ int read_status(gx_ctx* ctx) {
 // 20 ms of polling -- or with GX_NO_SPIN -- it blocks in the runtime after all, which also reports a device fault.
 MailOut mail_out(gx_ctx* ctx) {
   HostMail* dm = static_cast<HostMail*>(ctx->mailBuf.dp);
-  return MailOut{&dm->scal, &dm->status, &dm->hot, &dm->nIv, &dm->coll[2], &dm->nMerged, static_cast<RiskBuf*>(ctx->riskHost.dp),
-                 &dm->seq};
+  return MailOut{&dm->scal, &dm->status, &dm->hot, &dm->nIv, &dm->coll[2], &dm->nMerged, reinterpret_cast<u64*>(&dm->peakBP),
+                 static_cast<RiskBuf*>(ctx->riskHost.dp), &dm->seq};
 }
 
 int mail_wait(gx_ctx* ctx, u32 seq);
 
-int mail_sync(gx_ctx* ctx, const Scalars* ds, const u32* hot, const u32* nIv, const long long* coll, const u32* extra) {
+int mail_sync(gx_ctx* ctx, const Scalars* ds, const u32* hot, const u32* nIv, const long long* coll, const u32* extra,
+              const u64* extra64 = nullptr) {
   const u32 seq = ++ctx->mailSeq;
   hipLaunchKernelGGL(k_mail, dim3(1), dim3(64), 0, ctx->stream, ds, ctx->dStatus.as<u32>(), hot, nIv, coll, extra,
-                     ctx->dRisk.as<RiskBuf>(), mail_out(ctx), seq);
+                     ctx->dRisk.as<RiskBuf>(), mail_out(ctx), seq, extra64);
   HIPCHECK(hipGetLastError());  // (a launch that failed is reported now, not after the polling gives up)
   return mail_wait(ctx, seq);
 }
@@ -1277,7 +1278,7 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
       const u32 gridP = (u32)std::max(1, ctx->resSweep);
       // runs: count, place and write in one pass; the true count goes to the host, at most `cap` to the kernels
       hipLaunchKernelGGL(k_runs, dim3(std::min<u32>(wChunks, gridP)), dim3(SW_NT), 0, s, SM, lbS, lbE, gen, runStart, runEnd, cap,
-                         misc + M_SWCOUNT, &dm->R, misc + M_TICKET3, ctx->dStatus.as<u32>());
+                         misc + M_SWCOUNT, &dm->R, misc + M_TICKET3, reinterpret_cast<u64*>(misc + M_PEAKBP), ctx->dStatus.as<u32>());
       // candidates (chunks beyond the device-side run count leave at once)
       hipLaunchKernelGGL(k_cands, dim3(std::min<u32>(rChunks, gridP)), dim3(SW_NT), 0, s, SM, skipM, S.end, runStart, runEnd,
                          misc + M_SWCOUNT, ctx->par.max_gap, S.chromOff, nChrom, lbC, gen, ctx->headPos.as<u32>(), misc + M_NHEADS,
@@ -1305,10 +1306,12 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
       // the peaks, in order, into pinned host memory; their number with them
       hipLaunchKernelGGL(k_peaks, dim3(std::min<u32>(rChunks, gridP)), dim3(SW_NT), 0, s, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>(),
                          misc + M_NHEADS, lbP, gen, static_cast<gx_peak*>(ctx->hPeaks.dp), misc + M_NPEAKS, &dm->nPeaks,
-                         ctx->dStatus.as<u32>(), misc + M_TICKET4, reinterpret_cast<u64*>(misc + M_PEAKBP), reinterpret_cast<u64*>(&dm->peakBP));
+                         ctx->dStatus.as<u32>(), reinterpret_cast<u64*>(misc + M_PEAKBP));
       if (int rc__ = dbg_sync(ctx, "sweep kernels")) return rc__;
-      // the end: status, counts (and whatever else is pending) through the mail kernel, one synchronisation
-      if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr)) return rc__;
+      // the end: status, counts, the peaks' total length (and whatever else is pending) through the mail kernel, one
+      // synchronisation
+      if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const u64*>(misc + M_PEAKBP)))
+        return rc__;
       R = ctx->mail->R;
       ctx->runSeen = R;
       if (R <= cap) break;

@@ -1559,15 +1559,18 @@ struct MailOut {
   u32* nIv;
   long long* again;   // the ranks' "build this sample again" flags (several ranks only)
   u32* extra;         // one more word (interval count of a merge)
+  u64* extra64;       // ... and a 64-bit one (the peaks' total length)
   RiskBuf* risk;
   u32* seq;           // written last: the host polls it (mail_sync)
 };
 
 __device__ __forceinline__ void mail_body(const Scalars* __restrict__ ds, const u32* __restrict__ st, const u32* __restrict__ hot,
                                           const u32* __restrict__ nIv, const long long* __restrict__ coll,
-                                          const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, const MailOut& m, u32 seq) {
+                                          const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, const MailOut& m, u32 seq,
+                                          const u64* __restrict__ extra64 = nullptr) {
   const u32 n = rb->count;
   if (threadIdx.x == 0) {
+    if (extra64) *m.extra64 = *extra64;
     if (ds) *m.scal = *ds;
     *m.status = *st;
     if (hot) *m.hot = *hot;
@@ -1586,8 +1589,8 @@ __device__ __forceinline__ void mail_body(const Scalars* __restrict__ ds, const 
 __global__ __launch_bounds__(64) void k_mail(const Scalars* __restrict__ ds, const u32* __restrict__ st, const u32* __restrict__ hot,
                                              const u32* __restrict__ nIv, const long long* __restrict__ coll,
                                              const u32* __restrict__ extra, const RiskBuf* __restrict__ rb, MailOut m,
-                                             u32 seq) {
-  mail_body(ds, st, hot, nIv, coll, extra, rb, m, seq);
+                                             u32 seq, const u64* __restrict__ extra64) {
+  mail_body(ds, st, hot, nIv, coll, extra, rb, m, seq, extra64);
 }
 
 // The end of a treatment sample whose lambda -- and with it the table p(V) -- was known before the tile stage (LooseCtl):

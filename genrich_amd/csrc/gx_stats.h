@@ -1207,7 +1207,7 @@ __device__ __forceinline__ u64 lookback_gen(u64* lb, u32 id, u64 aggregate, u32 
 __global__ __launch_bounds__(SW_NT) void k_runs(SweepMasks M, u64* __restrict__ lbS, u64* __restrict__ lbE, u32 gen,
                                                 u32* __restrict__ runStart, u32* __restrict__ runEnd, u32 cap,
                                                 u32* __restrict__ nRuns /* min(total, cap) */, u32* __restrict__ nRunsHost /* total */,
-                                                u32* __restrict__ zeroMe, u32* __restrict__ st) {
+                                                u32* __restrict__ zeroMe, u64* __restrict__ zeroBp, u32* __restrict__ st) {
   __shared__ u32 scratch[8];
   __shared__ u64 s_base[2];
   const u32 nChunks = (M.nWords + SW_CHUNK - 1) / SW_CHUNK;
@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(SW_NT) void k_runs(SweepMasks M, u64* __restrict__ 
           *nRuns = total > cap ? cap : total;
           *nRunsHost = total;
           *zeroMe = 0;
+          *zeroBp = 0;   // (k_peaks' sum of the peaks' lengths)
         }
       }
     }
@@ -1314,9 +1315,8 @@ __global__ __launch_bounds__(SW_NT) void k_cands(SweepMasks M, const u64* __rest
 __global__ __launch_bounds__(SW_NT) void k_peaks(const gx_peak* __restrict__ cand, const u32* __restrict__ valid,
                                                  const u32* __restrict__ nHeads, u64* __restrict__ lb, u32 gen,
                                                  gx_peak* __restrict__ peaks /* pinned host memory */, u32* __restrict__ nPeaks,
-                                                 u32* __restrict__ nPeaksHost, u32* __restrict__ st, u32* __restrict__ ticket,
-                                                 u64* __restrict__ bpAcc /* zero before, zero after */,
-                                                 u64* __restrict__ bpHost /* pinned: the peaks' total length (callPeaks 925) */) {
+                                                 u32* __restrict__ nPeaksHost, u32* __restrict__ st,
+                                                 u64* __restrict__ bpAcc /* the peaks' total length (callPeaks 925); k_runs left it at zero */) {
   constexpr int PW = sizeof(gx_peak) / 4;
   __shared__ u32 scratch[8];
   __shared__ u32 stage[RC_CHUNK * PW];
@@ -1354,20 +1354,19 @@ __global__ __launch_bounds__(SW_NT) void k_peaks(const gx_peak* __restrict__ can
     for (u32 i = threadIdx.x; i < tot * PW; i += SW_NT) dst[i] = stage[i];
     __syncthreads();
   }
-  // The peaks' total length (callPeaks 925; the host used to sum it over the pinned records): every workgroup adds its
-  // share with an atomic and takes a ticket; the one that finishes LAST hands the sum over and clears it.
-  // (The sweep's mail stays a launch of its own behind this kernel.  Sending it from the last workgroup was tried:
-  // the peaks are posted writes to HOST memory from many CUs, and "my stores have completed" on one CU does not order
-  // them ahead of another CU's write of the sequence number -- a two-process test saw a stale record once in ten runs.
-  // The end of a kernel does.)
-  bp = wave_sum(bp);
-  if (lane_id() == 0 && bp) atomicAdd((unsigned long long*)bpAcc, (unsigned long long)bp);
-  stores_done();
+  // The peaks' total length (callPeaks 925; the host used to sum it over 1.7 MB of pinned records behind the kernel):
+  // one atomic per workgroup that wrote peaks; the mail behind this kernel takes the sum along.
+  // (Sending the mail itself from the workgroup that finishes last was tried: the peaks are posted writes to HOST
+  // memory from many CUs, and "my stores have completed" on one CU does not order them ahead of another CU's write of
+  // the sequence number -- a two-process test saw a stale record once in ten runs.  The end of a kernel does.  A
+  // ticket per workgroup, for the last one to hand the sum over, cost 16 us of same-address atomics.)
+  __shared__ unsigned long long s_bp;
+  if (threadIdx.x == 0) s_bp = 0;
   __syncthreads();
-  if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
-    *ticket = 0;
-    *bpHost = atomicExch((unsigned long long*)bpAcc, 0ull);
-  }
+  bp = wave_sum(bp);
+  if (lane_id() == 0 && bp) atomicAdd(&s_bp, (unsigned long long)bp);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_bp) atomicAdd((unsigned long long*)bpAcc, s_bp);
 }
 
 }  // namespace gx
