@@ -231,6 +231,13 @@ class Input {
   }
   void advance(size_t n) { pos_ += n; }
 
+  // A plain mapped file whose replay buffer is exhausted: the rest of the stream as one span of memory, for readers
+  // that cut it up themselves (parallel record decoding).  plainTake(n) moves the stream past n bytes of it.
+  bool plainDirect() const { return pmap_ && prePos_ >= pre_.size() && !recording_; }
+  const uint8_t* plainPtr() const { return pmap_ + ppos_; }
+  size_t plainLeft() const { return plen_ - ppos_; }
+  void plainTake(size_t n) { ppos_ += std::min(n, plen_ - ppos_); }
+
   void close() {
     if (gz_) {
       gzclose(gz_);

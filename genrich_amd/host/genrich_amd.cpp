@@ -961,6 +961,11 @@ struct Batch {
   std::vector<Decoded> rec;
   std::vector<std::pair<std::string, std::string>> fails;
   bool decoded = false;
+  // a batch of text that the READER only delimited (a span of a mapped file that ends behind a line feed): the
+  // decoder that takes the batch cuts it into lines itself (cutSpan) -- the reader's part is then a memchr per batch
+  const char* span = nullptr;
+  size_t spanLen = 0;
+  bool hasWork() const { return !off.empty() || spanLen; }
   void reset(size_t want) {
     if (cap < want) {
       bytes.reset(new char[want]);
@@ -969,6 +974,8 @@ struct Batch {
     used = 0;
     off.clear(); len.clear(); rec.clear(); fails.clear();
     decoded = false;
+    span = nullptr;
+    spanLen = 0;
   }
   char* room(size_t n) {  // n more bytes behind the records so far (the batch grows when a record needs it)
     if (used + n > cap) {
@@ -1056,9 +1063,28 @@ inline void applyDecoded(State& S, ReadSet& rs, Counts& C, const Batch& B, const
   record(S, rs, C, base + r.qname, r.flag, r.ci, r.pos, r.mapq, r.length, r.pnext, r.score, base + r.qual, r.qualLen, qualOffset);
 }
 
+// A span of text -> the lines gets() would have handed out, one after the other, NUL-terminated, in the batch's own
+// memory (the decoders write into them): through the line feed, or REC_MAX - 1 characters of a longer line at a time.
+void cutSpan(Batch& B) {
+  const char* p = B.span;
+  const char* const end = p + B.spanLen;
+  B.reset(B.spanLen + B.spanLen / 8 + REC_MAX);   // (clears span / spanLen: p and end are copies)
+  while (p < end) {
+    const size_t avail = std::min((size_t)(end - p), REC_MAX - 1);
+    const void* nl = memchr(p, '\n', avail);
+    const size_t k = nl ? (size_t)(static_cast<const char*>(nl) - p) + 1 : avail;
+    char* at = B.room(k + 1);
+    memcpy(at, p, k);
+    at[k] = '\0';
+    B.add(k + 1);
+    p += k;
+  }
+}
+
 // decode every record of a batch (any thread); a record that fails ends the batch: nothing behind it will be looked at
 template <class F>
 void decodeBatch(Batch& B, F one) {
+  if (B.spanLen) cutSpan(B);
   B.rec.assign(B.off.size(), Decoded{});
   std::pair<std::string, std::string> msg;
   t_capture = &msg;
@@ -1098,7 +1124,7 @@ class DecodePipe {
         const bool more = fill(*b);
         {
           std::unique_lock<std::mutex> lk(m_);
-          if (!b->off.empty()) {
+          if (b->hasWork()) {
             space_.wait(lk, [&] { return order_.size() < window_ || stop_; });
             if (stop_) break;
             order_.push_back(b);
@@ -1210,14 +1236,34 @@ uint64_t readSAM(State& S, In& in, Counts& C) {
   if (l) {
     const ChromIndex cx(S);
     const Opts& o = S.o;
-    bool firstPending = true;
-    auto fill = [&in, &line, &firstPending](Batch& B) -> bool {
+    bool firstPending = true, firstOnly = true;
+    auto fill = [&in, &line, &firstPending, &firstOnly](Batch& B) -> bool {
       B.reset(BATCH_BYTES + REC_MAX);
       if (firstPending) {  // (the line that ended the header)
         firstPending = false;
         const size_t n = strlen(line.data()) + 1;
         memcpy(B.room(n), line.data(), n);
         B.add(n);
+      }
+      if (firstOnly) {  // (the spans start with the next batch)
+        firstOnly = false;
+        if (!B.off.empty()) return true;
+      }
+      if (in.plainDirect()) {
+        // a plain mapped file: the batch is the next BATCH_BYTES of it, extended to the end of the line they end in;
+        // the decoder that gets it cuts it into lines (cutSpan)
+        const char* p = reinterpret_cast<const char*>(in.plainPtr());
+        const size_t left = in.plainLeft();
+        if (!left) return false;
+        size_t take = std::min(left, BATCH_BYTES);
+        if (take < left) {
+          const void* nl = memchr(p + take - 1, '\n', left - take + 1);
+          take = nl ? (size_t)(static_cast<const char*>(nl) - p) + 1 : left;
+        }
+        B.span = p;
+        B.spanLen = take;
+        in.plainTake(take);
+        return take < left;
       }
       while (B.used < BATCH_BYTES) {
         char* at = B.room(REC_MAX);

@@ -404,3 +404,31 @@ def test_cli_parallel_decoding_keeps_warnings_and_errors_in_file_order(tmp_path)
     assert lines[-1] == "Error! 'Q': unknown Op in CIGAR"
     assert any("more than 128 alignments" in l for l in lines[:-1])
     assert all(o == outs[0] for o in outs[1:])
+
+
+def test_cli_line_longer_than_the_reference_buffer_is_cut_the_same_way(tmp_path):
+    """readSAM reads a line in pieces of at most 65,519 characters (its 65,520-byte buffer): a longer record loses
+    its tail and the piece behind it is a record of its own -- here an error, `poorly formatted`, exactly as the
+    reference binary reports it for this input (checked against oracle/_ref/Genrich when this test was written).  The
+    decoders that cut a mapped file into lines themselves (cutSpan) must cut at the same places, whatever the batches."""
+    sq = "@HD\tVN:1.0\tSO:queryname\n@SQ\tSN:chr1\tLN:1000000\n"
+    rec = lambda q, flag, pos, pn, tl, seq="*", qual="*", cig="50M": f"{q}\t{flag}\tchr1\t{pos}\t30\t{cig}\t=\t{pn}\t{tl}\t{seq}\t{qual}\tAS:i:0\n"
+    body = "".join(rec(f"r{i}", 99, 100 + 10 * i, 300 + 10 * i, 250) + rec(f"r{i}", 147, 300 + 10 * i, 100 + 10 * i, -250) for i in range(50))
+    L = 70000
+    long1 = rec("long", 99, 5000, 5300, 300 + L, seq="A" * L, qual="I" * L, cig=f"{L}M") + rec("long", 147, 5300, 5000, -(300 + L))
+    tail = "".join(rec(f"t{i}", 99, 20000 + i, 20100 + i, 150) for i in range(20))
+    sam = tmp_path / "t.sam"
+    sam.write_text(sq + body + long1 + tail)
+    beds = []
+    for threads, batch in (("1", None), ("4", "100"), ("8", None), ("3", "1")):
+        env = dict(os.environ)
+        if batch:
+            env["GENRICH_BATCH_BYTES"] = batch
+        bed = tmp_path / f"e{threads}{batch}.bed"
+        res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-t", str(sam), "-b", str(bed)],
+                             capture_output=True, text=True, env=env)
+        assert res.returncode != 0
+        assert res.stderr.splitlines()[-1] == "Error! long: poorly formatted SAM/BAM record"
+        beds.append(bed.read_text())
+    # (49: the last pair before the bad record is still waiting for the next read name when the error ends the run)
+    assert beds[0].count("\n") == 49 and all(b == beds[0] for b in beds[1:])
