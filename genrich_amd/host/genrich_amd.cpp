@@ -319,38 +319,91 @@ int saveChrom(State& S, const char* name, uint32_t len) {
   return (int)S.chrom.size() - 1;
 }
 
-// ---- saveInterval (2516-2591): clamp, event, -b line ----------------------------------------
-uint32_t saveInterval(State& S, int ci, int64_t start, int64_t end, const char* qname, uint8_t count) {
-  Chrom& c = S.chrom[ci];
-  if (start < 0) {
-    if (S.o.verbose) {
-      if (S.errCount < MAX_ALNS)
-        fprintf(stderr, "Warning! Read %s prevented from extending below 0 on %s\n", qname, c.name.c_str());
-      S.errCount++;
-    }
-    start = 0;
+// ---- where a read-name group's results go -----------------------------------------------------
+// Read-name groups do not depend on each other, only their results have an order: the events (the int16 replay of
+// the library goes by it), the -b lines, the -v warnings (and the count that suppresses them after the first 128),
+// the additions into the float sum behind the -x average.  A worker thread that takes a chunk of whole groups
+// (parallel state, below) has `t_sink` set: everything that would touch the run's state is written there instead and
+// merged into the state by its owner, chunk after chunk in file order.  Without a sink (one thread; the tails of
+// finishFile) the state is written directly, as before.
+struct Sink {
+  std::vector<gx_event> ev;
+  std::string bed;                                      // -b lines
+  std::vector<std::pair<std::string, bool>> warn;       // stderr lines in order; true: counts towards errCount
+  std::vector<double> lenTerms;                         // C.totalLen += ... in order (a float sum: not associative)
+};
+thread_local Sink* t_sink = nullptr;
+
+std::string vformat(const char* fmt, va_list ap) {
+  va_list ap2;
+  va_copy(ap2, ap);
+  const int n = vsnprintf(nullptr, 0, fmt, ap2);
+  va_end(ap2);
+  std::string out((size_t)std::max(0, n), '\0');
+  if (n > 0) vsnprintf(&out[0], (size_t)n + 1, fmt, ap);
+  return out;
+}
+// a warning that takes part in the "(another N warning messages suppressed)" count (saveInterval's two)
+void warnCounted(State& S, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (t_sink)
+    t_sink->warn.emplace_back(vformat(fmt, ap), true);
+  else {
+    if (S.errCount < MAX_ALNS) vfprintf(stderr, fmt, ap);
+    S.errCount++;
   }
-  if (start >= c.len) {
-    char msg[512];
-    snprintf(msg, sizeof msg, "Read %s, ref. %s", qname, c.name.c_str());
-    die(msg, ": read aligned beyond reference end");
-  }
-  if (end > c.len) {
-    if (S.o.verbose) {
-      if (S.errCount < MAX_ALNS)
-        fprintf(stderr, "Warning! Read %s prevented from extending past %d on %s\n", qname, c.len, c.name.c_str());
-      S.errCount++;
-    }
-    end = c.len;
-  }
-  S.buf.push_back(gx_event{(uint32_t)ci, (uint32_t)start, (uint32_t)end, count});
+  va_end(ap);
+}
+// ... and one that does not
+void warnPlain(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (t_sink) t_sink->warn.emplace_back(vformat(fmt, ap), false);
+  else vfprintf(stderr, fmt, ap);
+  va_end(ap);
+}
+void pushEvent(State& S, const gx_event& e) {  // (state's side: the library takes the events in pieces of 2^20)
+  S.buf.push_back(e);
   if (S.buf.size() >= (1u << 20)) {
     if (S.gx && S.sampleOpen) flushEvents(S);
     if (!S.gx || S.sampleOpen) S.buf.clear();  // --events-only keeps nothing
   }
-  if (S.bedOpt)
-    fprintf(S.bed.f, "%s\t%ld\t%ld\t%s_%d_%c_%d\n", c.name.c_str(), (long)start, (long)end, qname, count,
-            S.ctrl ? 'C' : 'E', S.sample);
+}
+
+// ---- saveInterval (2516-2591): clamp, event, -b line ----------------------------------------
+uint32_t saveInterval(State& S, int ci, int64_t start, int64_t end, const char* qname, uint8_t count) {
+  Chrom& c = S.chrom[ci];
+  if (start < 0) {
+    if (S.o.verbose) warnCounted(S, "Warning! Read %s prevented from extending below 0 on %s\n", qname, c.name.c_str());
+    start = 0;
+  }
+  if (start >= c.len) {
+    std::string msg = std::string("Read ") + qname + ", ref. " + c.name;
+    if (msg.size() > 511) msg.resize(511);  // (snprintf into char msg[512])
+    die(msg, ": read aligned beyond reference end");
+  }
+  if (end > c.len) {
+    if (S.o.verbose) warnCounted(S, "Warning! Read %s prevented from extending past %d on %s\n", qname, c.len, c.name.c_str());
+    end = c.len;
+  }
+  const gx_event e{(uint32_t)ci, (uint32_t)start, (uint32_t)end, count};
+  if (t_sink) t_sink->ev.push_back(e);
+  else pushEvent(S, e);
+  if (S.bedOpt) {
+    if (t_sink) {
+      char num[96];
+      std::string& b = t_sink->bed;
+      b += c.name;
+      snprintf(num, sizeof num, "\t%ld\t%ld\t", (long)start, (long)end);
+      b += num;
+      b += qname;
+      snprintf(num, sizeof num, "_%d_%c_%d\n", count, S.ctrl ? 'C' : 'E', S.sample);
+      b += num;
+    } else
+      fprintf(S.bed.f, "%s\t%ld\t%ld\t%s_%d_%c_%d\n", c.name.c_str(), (long)start, (long)end, qname, count,
+              S.ctrl ? 'C' : 'E', S.sample);
+  }
   return (uint32_t)(end - start);
 }
 
@@ -432,7 +485,8 @@ int processPair(State& S, const char* qname, std::vector<Aln>& aln, Counts& C, f
       fragLen += saveFragment(S, qname, a, count);
       if (++saved == count) break;  // in case of AS ties
     }
-  C.totalLen += (double)fragLen / count;
+  if (t_sink) t_sink->lenTerms.push_back((double)fragLen / count);  // (added by the state's owner, in file order)
+  else C.totalLen += (double)fragLen / count;
   return 1;
 }
 
@@ -892,7 +946,7 @@ uint16_t sumQual(const char* qual, int len, int offset) {
 void record(State& S, ReadSet& rs, Counts& C, const char* qname, uint16_t flag, int ci, uint32_t pos, uint8_t mapq,
             int length, uint32_t pnext, float score, const char* qual, int qualLen, int qualOffset) {
   if (mapq < S.o.minMapQ) { C.lowMapQ++; return; }
-  openSample(S);  // the header is complete once the first record arrives
+  if (!t_sink) openSample(S);  // the header is complete once the first record arrives (workers: the state's owner does it)
   if (!rs.have || rs.name != qname) {
     flushSet(S, rs, C);
     rs.have = true;
@@ -904,7 +958,7 @@ void record(State& S, ReadSet& rs, Counts& C, const char* qname, uint16_t flag, 
     if (!q && !star) q = sumQual(qual, qualLen, qualOffset);
   }
   if (!parseAlign(S, rs.aln, flag, ci, pos, length, pnext, C, score) && S.o.verbose)
-    fprintf(stderr, "Warning! Read %s has more than %d alignments\n", qname, MAX_ALNS);
+    warnPlain("Warning! Read %s has more than %d alignments\n", qname, MAX_ALNS);
 }
 
 void finishFile(State& S, ReadSet& rs, Counts& C) {  // the tail of readSAM / parseBAM
@@ -1217,6 +1271,197 @@ void runDecode(int nDec, Fill fill, One one, Apply apply) {
   }
 }
 
+// ---- parallel state: whole read-name groups to worker threads ---------------------------------------------------
+// The decoded records still went through ONE thread's state machine (groups, pairing, weights, intervals): 15-18 M
+// records/s.  But a read-name group only depends on its own records; what has an order are its RESULTS (Sink, above).
+// So the thread that owns the state only (1) finds where groups begin -- a record starts a group when its name is
+// not the current group's, exactly record()'s test, and skipped records (unmapped, supplementary, low MAPQ) never do --,
+// (2) cuts the stream into chunks of whole groups right before such a record, and (3) merges the chunks' sinks, in
+// order, into the state.  A worker runs the unchanged state machine over its chunk with a ReadSet and Counts of its
+// own.  Order of events as in one thread: a chunk's last group is flushed at the chunk's end, i.e. exactly when the
+// next chunk's first record -- a group start by construction -- would have flushed it; a record that fails (or a
+// die() inside the state machine) ends its chunk there, with the group before it unflushed, as it ends a sequential
+// run.
+void addCounts(Counts& a, const Counts& b) {
+  a.count += b.count; a.unmapped += b.unmapped; a.paired += b.paired; a.single += b.single; a.orphan += b.orphan;
+  a.pairedPr += b.pairedPr; a.singlePr += b.singlePr; a.supp += b.supp; a.skipped += b.skipped; a.lowMapQ += b.lowMapQ;
+  a.secPair += b.secPair; a.secSingle += b.secSingle;
+  a.countPr += b.countPr; a.dupsPr += b.dupsPr; a.countDc += b.countDc; a.dupsDc += b.dupsDc; a.countSn += b.countSn;
+  a.dupsSn += b.dupsSn;
+}
+
+struct Chunk {
+  struct Seg { std::shared_ptr<Batch> b; uint32_t i0, i1; };
+  std::vector<Seg> segs;
+  size_t nrec = 0;
+  // results
+  Sink sink;
+  Counts C;
+  std::vector<Unpair> unpair;
+  DupReads dup;
+  bool failed = false;
+  std::pair<std::string, std::string> fail;
+  bool done = false;
+};
+
+void processChunk(State& S, Chunk& ch, int qualOffset) {
+  std::pair<std::string, std::string> msg;
+  t_capture = &msg;
+  t_sink = &ch.sink;
+  ReadSet rs;
+  try {
+    for (auto& sg : ch.segs)
+      for (uint32_t i = sg.i0; i < sg.i1; i++) applyDecoded(S, rs, ch.C, *sg.b, sg.b->rec[i], qualOffset);
+    flushSet(S, rs, ch.C);
+  } catch (const DecodeAbort&) {
+    ch.failed = true;
+    ch.fail = msg;
+  }
+  t_sink = nullptr;
+  t_capture = nullptr;
+  ch.unpair = std::move(rs.unpair);
+  ch.dup = std::move(rs.dup);
+  ch.segs.clear();  // (the batches go as soon as nobody needs their bytes)
+}
+
+// the state's owner takes a chunk's results (in file order)
+void mergeChunk(State& S, ReadSet& rs, Counts& C, Chunk& ch) {
+  openSample(S);  // (record() does it at the first record that gets that far; nothing goes to the device before)
+  for (auto& w : ch.sink.warn) {
+    if (w.second) {
+      if (S.errCount < MAX_ALNS) fputs(w.first.c_str(), stderr);
+      S.errCount++;
+    } else
+      fputs(w.first.c_str(), stderr);
+  }
+  if (S.bedOpt && !ch.sink.bed.empty()) fwrite(ch.sink.bed.data(), 1, ch.sink.bed.size(), S.bed.f);
+  for (const gx_event& e : ch.sink.ev) pushEvent(S, e);
+  addCounts(C, ch.C);
+  for (double x : ch.sink.lenTerms) C.totalLen += x;
+  for (auto& u : ch.unpair) rs.unpair.push_back(std::move(u));
+  for (auto& d : ch.dup.pr) rs.dup.pr.push_back(std::move(d));
+  for (auto& d : ch.dup.dc) rs.dup.dc.push_back(std::move(d));
+  for (auto& d : ch.dup.sn) rs.dup.sn.push_back(std::move(d));
+  if (ch.failed) die(ch.fail.first, ch.fail.second.c_str());
+}
+
+class ChunkPool {
+ public:
+  typedef std::shared_ptr<Chunk> Ptr;
+  ChunkPool(int n, State& S, int qualOffset) {
+    for (int i = 0; i < n; i++)
+      th_.emplace_back([this, &S, qualOffset]() {
+        for (;;) {
+          Ptr c;
+          {
+            std::unique_lock<std::mutex> lk(m_);
+            avail_.wait(lk, [&] { return !work_.empty() || stop_; });
+            if (work_.empty()) return;
+            c = work_.front();
+            work_.pop_front();
+          }
+          processChunk(S, *c, qualOffset);
+          {
+            std::lock_guard<std::mutex> lk(m_);
+            c->done = true;
+          }
+          done_.notify_all();
+        }
+      });
+  }
+  void submit(Ptr c) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      work_.push_back(c);
+      order_.push_back(c);
+    }
+    avail_.notify_one();
+  }
+  // the next finished chunk in file order; with `block` waits for it, otherwise nullptr when it is not ready
+  Ptr take(bool block) {
+    std::unique_lock<std::mutex> lk(m_);
+    if (order_.empty()) return nullptr;
+    if (block) done_.wait(lk, [&] { return order_.front()->done; });
+    else if (!order_.front()->done) return nullptr;
+    Ptr c = order_.front();
+    order_.pop_front();
+    return c;
+  }
+  size_t pending() {
+    std::lock_guard<std::mutex> lk(m_);
+    return order_.size();
+  }
+  ~ChunkPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+      work_.clear();
+    }
+    avail_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable avail_, done_;
+  std::deque<Ptr> work_, order_;
+  bool stop_ = false;
+  std::vector<std::thread> th_;
+};
+
+// records per chunk (GENRICH_CHUNK_RECS: tests cut a chunk at every group)
+const size_t CHUNK_RECS = getenv("GENRICH_CHUNK_RECS") ? (size_t)std::max(1L, atol(getenv("GENRICH_CHUNK_RECS"))) : (size_t)4096;
+const bool g_serialState = getenv("GENRICH_SERIAL_STATE") != nullptr;  // (the one-thread state machine of before)
+
+// reader -> decoders -> (this thread: group starts, chunks) -> workers -> (this thread: merge, in order)
+template <class Fill, class One>
+void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOffset, Fill fill, One one) {
+  DecodePipe pipe(nThreads, fill, one);
+  ChunkPool pool(nThreads, S, qualOffset);
+  const size_t window = (size_t)std::max(8, 4 * nThreads);
+  std::shared_ptr<Chunk> cur = std::make_shared<Chunk>();
+  bool have = false;
+  std::string name;  // the current group's name as record() keeps it (the first MAX_ALNS characters)
+  auto mergeReady = [&](bool block) {
+    while (ChunkPool::Ptr c = pool.take(block)) mergeChunk(S, rs, C, *c);
+  };
+  while (DecodePipe::Ptr b = pipe.next()) {
+    const char* base = b->bytes.get();
+    uint32_t i0 = 0;
+    const uint32_t n = (uint32_t)b->rec.size();
+    for (uint32_t i = 0; i < n; i++) {
+      const Decoded& r = b->rec[i];
+      if (r.kind != Decoded::REC) continue;
+      const char* qname = base + r.qname;
+      if (have && name == qname) continue;  // (std::string == const char*: the whole name, as record() compares)
+      // a group starts at record i
+      have = true;
+      name.assign(qname, strnlen(qname, MAX_ALNS));
+      if (cur->nrec + (i - i0) >= CHUNK_RECS) {
+        if (i > i0) cur->segs.push_back(Chunk::Seg{b, i0, i});
+        cur->nrec += i - i0;
+        pool.submit(cur);
+        cur = std::make_shared<Chunk>();
+        i0 = i;
+      }
+    }
+    if (n > i0) {
+      cur->segs.push_back(Chunk::Seg{b, i0, n});
+      cur->nrec += n - i0;
+    }
+    mergeReady(false);
+    while (pool.pending() > window) {  // (the workers are behind: wait for the oldest chunk rather than queue without bound)
+      ChunkPool::Ptr c = pool.take(true);
+      if (c) mergeChunk(S, rs, C, *c);
+    }
+  }
+  if (cur->nrec) pool.submit(cur);
+  while (pool.pending()) {
+    ChunkPool::Ptr c = pool.take(true);
+    if (c) mergeChunk(S, rs, C, *c);
+  }
+}
+
 // a failure of the READER (a truncated BAM record ...) travels as a pseudo-record of length 0 whose bytes are the
 // message: the decoder "dies" with it, and it is raised in file order like any other
 void readerFailure(Batch& B, const char* tail) {
@@ -1273,7 +1518,10 @@ uint64_t readSAM(State& S, In& in, Counts& C) {
       return true;
     };
     auto one = [&o, &cx](char* base, uint32_t off, uint32_t, Decoded& r) { decodeSamLine(o, cx, base, base + off, r); };
-    runDecode(g_decoders, fill, one, [&](const Batch& B, const Decoded& r) { applyDecoded(S, rs, C, B, r, 33); });
+    if (g_decoders > 1 && !g_serialState)
+      runParallelState(S, rs, C, g_decoders, 33, fill, one);
+    else
+      runDecode(g_decoders, fill, one, [&](const Batch& B, const Decoded& r) { applyDecoded(S, rs, C, B, r, 33); });
   }
   finishFile(S, rs, C);
   return C.count;
@@ -1431,6 +1679,19 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
   auto fill = [&g](Batch& B) -> bool {
     B.reset(BATCH_BYTES + REC_MAX);
     while (B.used < BATCH_BYTES) {
+      // (a block that lies inside one inflated BGZF member is copied from where it is: one peek for its size, one for
+      // its bytes; one that straddles two members -- or any block, with zlib's reader -- goes through read())
+      if (const uint8_t* p4 = g.peek(4)) {
+        const int32_t sz = (int32_t)(p4[0] | (p4[1] << 8) | (p4[2] << 16) | ((uint32_t)p4[3] << 24));
+        if (sz >= 32) {
+          if (const uint8_t* whole = g.peek(4 + (size_t)sz)) {
+            memcpy(B.room((size_t)sz), whole + 4, (size_t)sz);
+            g.advance(4 + (size_t)sz);
+            B.add((size_t)sz);
+            continue;
+          }
+        }
+      }
       const int32_t bs = rdI32(g, false);
       if (bs == -1) return false;  // (see rdI32)
       // (a negative size passes the reference's unsigned test and fails its end-of-block test, 4870 / 4885)
@@ -1443,7 +1704,10 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     return true;
   };
   auto one = [&o, &idx](char* base, uint32_t off, uint32_t len, Decoded& r) { decodeBamBlock(o, idx, base, off, len, r); };
-  runDecode(g_decoders, fill, one, [&](const Batch& B, const Decoded& r) { applyDecoded(S, rs, C, B, r, 0); });
+  if (g_decoders > 1 && !g_serialState)
+    runParallelState(S, rs, C, g_decoders, 0, fill, one);
+  else
+    runDecode(g_decoders, fill, one, [&](const Batch& B, const Decoded& r) { applyDecoded(S, rs, C, B, r, 0); });
   finishFile(S, rs, C);
   return C.count;
 }

@@ -353,11 +353,14 @@ def test_cli_two_contexts_one_gpu_equal_one(name):
 # ---- parallel record decoding: decoder threads over batches of records, the state on one thread ----
 @pytest.mark.parametrize("name", ["basic", "multimap", "dups_pairs", "dups_x_bam", "quirks_sam", "quirks_bam",
                                   "unpaired_x", "unpaired_bam_atac", "ctrl_q", "reps3"])
-@pytest.mark.parametrize("threads,batch", [("1", None), ("4", None), ("4", "150"), ("3", "1")])
-def test_cli_parallel_decoding_is_the_sequential_stream(name, threads, batch, tmp_path):
+@pytest.mark.parametrize("threads,batch,chunk", [("1", None, None), ("4", None, None), ("4", "150", "3"), ("3", "1", "1"),
+                                                 ("4", None, "serial")])
+def test_cli_parallel_decoding_is_the_sequential_stream(name, threads, batch, chunk, tmp_path):
     """The -b event stream, the -R log and everything -v prints must not depend on how many threads decode the
-    records or where the batches are cut (GENRICH_BATCH_BYTES: batches of a line or two, so that read-name groups,
-    pairs and multimapping sets straddle them).  The golden event stream is the reference's."""
+    records, where the batches are cut (GENRICH_BATCH_BYTES: batches of a line or two, so that read-name groups,
+    pairs and multimapping sets straddle them) or how the read-name groups are dealt to the threads that run the
+    state machine (GENRICH_CHUNK_RECS: a chunk per group; GENRICH_SERIAL_STATE: one thread for all of them).  The
+    golden event stream is the reference's."""
     cases, mg = _cases()
     args = _write_inputs(cases[name], mg, str(tmp_path / "in"))
     a = [x for x in args if x != "-X"] + ["-v"]
@@ -367,6 +370,10 @@ def test_cli_parallel_decoding_is_the_sequential_stream(name, threads, batch, tm
     env = dict(os.environ)
     if batch:
         env["GENRICH_BATCH_BYTES"] = batch
+    if chunk == "serial":
+        env["GENRICH_SERIAL_STATE"] = "1"
+    elif chunk:
+        env["GENRICH_CHUNK_RECS"] = chunk
     res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-b", bed] + a, capture_output=True, text=True, env=env)
     assert res.returncode == 0, res.stderr
     assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
@@ -392,10 +399,12 @@ def test_cli_parallel_decoding_keeps_warnings_and_errors_in_file_order(tmp_path)
     sam = tmp_path / "t.sam"
     sam.write_text(sq + body + many + body.replace("r", "s").replace("chs1", "chr1") + bad + tail)
     outs = []
-    for threads, batch in (("1", None), ("4", "120"), ("3", "1"), ("8", None)):
+    for threads, batch, chunk in (("1", None, None), ("4", "120", "1"), ("3", "1", "2"), ("8", None, None)):
         env = dict(os.environ)
         if batch:
             env["GENRICH_BATCH_BYTES"] = batch
+        if chunk:
+            env["GENRICH_CHUNK_RECS"] = chunk
         res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-v", "-y", "-t", str(sam), "-b", str(tmp_path / "e.bed")],
                              capture_output=True, text=True, env=env)
         assert res.returncode != 0
@@ -424,6 +433,7 @@ def test_cli_line_longer_than_the_reference_buffer_is_cut_the_same_way(tmp_path)
         env = dict(os.environ)
         if batch:
             env["GENRICH_BATCH_BYTES"] = batch
+            env["GENRICH_CHUNK_RECS"] = "1"
         bed = tmp_path / f"e{threads}{batch}.bed"
         res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-t", str(sam), "-b", str(bed)],
                              capture_output=True, text=True, env=env)
@@ -432,3 +442,42 @@ def test_cli_line_longer_than_the_reference_buffer_is_cut_the_same_way(tmp_path)
         beds.append(bed.read_text())
     # (49: the last pair before the bad record is still waiting for the next read name when the error ends the run)
     assert beds[0].count("\n") == 49 and all(b == beds[0] for b in beds[1:])
+
+
+def test_cli_parallel_state_keeps_the_warning_count_and_the_float_sum_in_file_order(tmp_path):
+    """Two things that are summed ACROSS read-name groups and are not just integers: the count that suppresses -v
+    warnings after the first 128 (saveInterval 2530-2543; the tail line `(another N warning messages suppressed)`), and
+    the double behind the -x average length, to which a multimapping pair adds length / count (processPair 3150) -- a
+    float sum, so the workers hand their terms to the state's owner, which adds them in file order."""
+    L = 30000
+    sq = f"@HD\tVN:1.0\tSO:queryname\n@SQ\tSN:chr1\tLN:{L}\n"
+    rec = lambda q, flag, pos, pn, tl, ln=50: f"{q}\t{flag}\tchr1\t{pos}\t30\t{ln}M\t=\t{pn}\t{tl}\t*\t*\tAS:i:0\n"
+    body = ""
+    for i in range(300):  # pairs whose second mate runs past the end of the reference: a counted warning each
+        body += rec(f"e{i}", 99, L - 300 - i, L - 40, 340 + i) + rec(f"e{i}", 147, L - 40, L - 300 - i, -(340 + i), ln=60 + i % 7)
+    for i in range(200):  # pairs with two or three equally good alignments: totalLen += length / count
+        k = 2 + i % 2
+        for j in range(k):
+            p = 1000 + 37 * i + 3000 * j
+            body += rec(f"m{i}", 99 if j == 0 else 355, p, p + 150 + i % 11, 200 + i % 11) + \
+                    rec(f"m{i}", 147 if j == 0 else 403, p + 150 + i % 11, p, -(200 + i % 11))
+    for i in range(150):  # unpaired alignments, extended to the average length by -x
+        body += rec(f"u{i}", 0 if i % 2 else 16, 5000 + 31 * i, 0, 0)
+    sam = tmp_path / "t.sam"
+    sam.write_text(sq + body)
+    outs = []
+    for threads, batch, chunk in (("1", None, None), ("4", None, None), ("4", "200", "1"), ("3", "1", "5")):
+        env = dict(os.environ)
+        if batch:
+            env["GENRICH_BATCH_BYTES"] = batch
+        if chunk:
+            env["GENRICH_CHUNK_RECS"] = chunk
+        bed = tmp_path / f"e{threads}{batch}.bed"
+        res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-v", "-x", "-s", "20", "-t", str(sam), "-b", str(bed)],
+                             capture_output=True, text=True, env=env)
+        assert res.returncode == 0, res.stderr
+        outs.append((res.stderr, bed.read_text()))
+    err = outs[0][0]
+    assert err.count("prevented from extending past") == 128 and "warning messages suppressed" in err
+    assert "extended to" in err
+    assert all(o == outs[0] for o in outs[1:])
