@@ -230,6 +230,9 @@ class Input {
     return cur_->outLen - pos_ >= n ? cur_->out.get() + pos_ : nullptr;
   }
   void advance(size_t n) { pos_ += n; }
+  // keeps the inflated member that the last peek()'s pointer lies in alive for as long as the handle lives (records
+  // decoded by other threads straight out of the inflated data, without a copy)
+  std::shared_ptr<const void> holdCurrent() const { return cur_; }
 
   // A plain mapped file whose replay buffer is exhausted: the rest of the stream as one span of memory, for readers
   // that cut it up themselves (parallel record decoding).  plainTake(n) moves the stream past n bytes of it.

@@ -1000,7 +1000,7 @@ struct Decoded {
   int ci = 0, length = 0, qualLen = 0;
   uint32_t pos = 0, pnext = 0;
   float score = 0.0f;
-  uint32_t qname = 0, qual = 0;   // offsets into the batch's bytes
+  uint32_t qname = 0, qual = 0;   // offsets from the record's first byte
   int fail = -1;                   // FAIL: index into the batch's messages
 };
 
@@ -1019,6 +1019,19 @@ struct Batch {
   // decoder that takes the batch cuts it into lines itself (cutSpan) -- the reader's part is then a memchr per batch
   const char* span = nullptr;
   size_t spanLen = 0;
+  // records that stay where they are -- BAM blocks inside an inflated BGZF member, which `holds` keeps alive: off[i] has
+  // its top bit set and indexes `ext`
+  std::vector<const char*> ext;
+  std::vector<std::shared_ptr<const void>> holds;
+  size_t extBytes = 0;
+  static constexpr uint32_t EXT = 0x80000000u;
+  const char* at(size_t i) const { return (off[i] & EXT) ? ext[off[i] & ~EXT] : bytes.get() + off[i]; }
+  void addExt(const void* p, size_t n) {
+    off.push_back(EXT | (uint32_t)ext.size());
+    len.push_back((uint32_t)n);
+    ext.push_back(static_cast<const char*>(p));
+    extBytes += n;
+  }
   bool hasWork() const { return !off.empty() || spanLen; }
   void reset(size_t want) {
     if (cap < want) {
@@ -1030,6 +1043,9 @@ struct Batch {
     decoded = false;
     span = nullptr;
     spanLen = 0;
+    ext.clear();
+    holds.clear();
+    extBytes = 0;
   }
   char* room(size_t n) {  // n more bytes behind the records so far (the batch grows when a record needs it)
     if (used + n > cap) {
@@ -1061,7 +1077,8 @@ struct ChromIndex {  // findChrom without the linear search (first of equal name
 };
 
 // one SAM line (readSAM 4524-4560 up to the call of parseAlign)
-void decodeSamLine(const Opts& o, const ChromIndex& cx, char* base, char* l, Decoded& r) {
+void decodeSamLine(const Opts& o, const ChromIndex& cx, char* l, Decoded& r) {
+  char* const base = l;
   if (l[0] == '@') die(l, ": misplaced SAM header line");
   // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL [extra], cut up as the reference does
   // (readSAM 4524-4530, loadFields 4350-4377): strtok on TAB -- so a run of tabs is one separator, and
@@ -1104,7 +1121,8 @@ void decodeSamLine(const Opts& o, const ChromIndex& cx, char* base, char* l, Dec
 }
 
 // the state's side of a decoded record (the counters of readSAM / parseBAM, then parseAlign)
-inline void applyDecoded(State& S, ReadSet& rs, Counts& C, const Batch& B, const Decoded& r, int qualOffset) {
+inline void applyDecoded(State& S, ReadSet& rs, Counts& C, const Batch& B, size_t i, int qualOffset) {
+  const Decoded& r = B.rec[i];
   switch (r.kind) {
     case Decoded::FAIL: die(B.fails[(size_t)r.fail].first, B.fails[(size_t)r.fail].second.c_str());
     case Decoded::UNMAPPED: C.count++; C.unmapped++; return;
@@ -1113,7 +1131,7 @@ inline void applyDecoded(State& S, ReadSet& rs, Counts& C, const Batch& B, const
     default: break;
   }
   C.count++;
-  const char* base = B.bytes.get();
+  const char* base = B.at(i);
   record(S, rs, C, base + r.qname, r.flag, r.ci, r.pos, r.mapq, r.length, r.pnext, r.score, base + r.qual, r.qualLen, qualOffset);
 }
 
@@ -1144,7 +1162,7 @@ void decodeBatch(Batch& B, F one) {
   t_capture = &msg;
   for (size_t i = 0; i < B.off.size(); i++) {
     try {
-      one(B.bytes.get(), B.off[i], B.len[i], B.rec[i]);
+      one(const_cast<char*>(B.at(i)), B.len[i], B.rec[i]);
     } catch (const DecodeAbort&) {
       B.rec[i].kind = Decoded::FAIL;
       B.rec[i].fail = (int)B.fails.size();
@@ -1258,7 +1276,7 @@ void runDecode(int nDec, Fill fill, One one, Apply apply) {
   if (nDec > 1) {
     DecodePipe pipe(nDec, fill, one);
     while (DecodePipe::Ptr b = pipe.next()) {
-      for (const Decoded& r : b->rec) apply(*b, r);
+      for (size_t i = 0; i < b->rec.size(); i++) apply(*b, i);
       pipe.give(std::move(b));
     }
   } else {
@@ -1266,7 +1284,7 @@ void runDecode(int nDec, Fill fill, One one, Apply apply) {
     for (bool more = true; more;) {
       more = fill(B);
       decodeBatch(B, one);
-      for (const Decoded& r : B.rec) apply(B, r);
+      for (size_t i = 0; i < B.rec.size(); i++) apply(B, i);
     }
   }
 }
@@ -1311,7 +1329,7 @@ void processChunk(State& S, Chunk& ch, int qualOffset) {
   ReadSet rs;
   try {
     for (auto& sg : ch.segs)
-      for (uint32_t i = sg.i0; i < sg.i1; i++) applyDecoded(S, rs, ch.C, *sg.b, sg.b->rec[i], qualOffset);
+      for (uint32_t i = sg.i0; i < sg.i1; i++) applyDecoded(S, rs, ch.C, *sg.b, i, qualOffset);
     flushSet(S, rs, ch.C);
   } catch (const DecodeAbort&) {
     ch.failed = true;
@@ -1426,13 +1444,12 @@ void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOf
     while (ChunkPool::Ptr c = pool.take(block)) mergeChunk(S, rs, C, *c);
   };
   while (DecodePipe::Ptr b = pipe.next()) {
-    const char* base = b->bytes.get();
     uint32_t i0 = 0;
     const uint32_t n = (uint32_t)b->rec.size();
     for (uint32_t i = 0; i < n; i++) {
       const Decoded& r = b->rec[i];
       if (r.kind != Decoded::REC) continue;
-      const char* qname = base + r.qname;
+      const char* qname = b->at(i) + r.qname;
       if (have && name == qname) continue;  // (std::string == const char*: the whole name, as record() compares)
       // a group starts at record i
       have = true;
@@ -1517,11 +1534,11 @@ uint64_t readSAM(State& S, In& in, Counts& C) {
       }
       return true;
     };
-    auto one = [&o, &cx](char* base, uint32_t off, uint32_t, Decoded& r) { decodeSamLine(o, cx, base, base + off, r); };
+    auto one = [&o, &cx](char* rec, uint32_t, Decoded& r) { decodeSamLine(o, cx, rec, r); };
     if (g_decoders > 1 && !g_serialState)
       runParallelState(S, rs, C, g_decoders, 33, fill, one);
     else
-      runDecode(g_decoders, fill, one, [&](const Batch& B, const Decoded& r) { applyDecoded(S, rs, C, B, r, 33); });
+      runDecode(g_decoders, fill, one, [&](const Batch& B, size_t i) { applyDecoded(S, rs, C, B, i, 33); });
   }
   finishFile(S, rs, C);
   return C.count;
@@ -1623,8 +1640,8 @@ std::vector<int> bamRefTable(State& S, In& g) {
 }
 
 // one BAM alignment block (parseBAM 4826-4977 up to the call of parseAlign; loadBAMfields 4660-4688)
-void decodeBamBlock(const Opts& o, const std::vector<int>& idx, char* base, uint32_t off, uint32_t blkLen, Decoded& r) {
-  const uint8_t* blk = reinterpret_cast<const uint8_t*>(base) + off;
+void decodeBamBlock(const Opts& o, const std::vector<int>& idx, const char* rec, uint32_t blkLen, Decoded& r) {
+  const uint8_t* blk = reinterpret_cast<const uint8_t*>(rec);
   if (blkLen == 0) die("", reinterpret_cast<const char*>(blk));  // (readerFailure)
   const int32_t n_ref = (int32_t)idx.size();
   auto i32 = [&](size_t p) { return (int32_t)(blk[p] | (blk[p + 1] << 8) | (blk[p + 2] << 16) | ((uint32_t)blk[p + 3] << 24)); };
@@ -1645,7 +1662,7 @@ void decodeBamBlock(const Opts& o, const std::vector<int>& idx, char* base, uint
       !memchr(blk + nameOff, '\0', blkLen - (size_t)nameOff))
     die("", "Cannot parse BAM file");
   const char* qname = (const char*)&blk[nameOff];
-  r.qname = off + (uint32_t)nameOff;
+  r.qname = (uint32_t)nameOff;
   if (r.flag & 0x4) { r.kind = Decoded::UNMAPPED; return; }
   if (!strcmp(qname, "*") || refID < 0 || refID >= n_ref || pos < 0) die(qname, ": poorly formatted SAM/BAM record");
   if (r.flag & 0xE00) { r.kind = Decoded::SUPP; return; }
@@ -1664,7 +1681,7 @@ void decodeBamBlock(const Opts& o, const std::vector<int>& idx, char* base, uint
   r.ci = idx[(size_t)refID];
   r.pos = (uint32_t)pos;
   r.pnext = (uint32_t)next_pos;
-  r.qual = off + (uint32_t)qualOff;
+  r.qual = (uint32_t)qualOff;
   r.qualLen = l_seq;
   r.kind = Decoded::REC;
 }
@@ -1678,16 +1695,22 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
   // the reader: alignment blocks (block_size, then that many bytes), copied out of the inflated stream
   auto fill = [&g](Batch& B) -> bool {
     B.reset(BATCH_BYTES + REC_MAX);
-    while (B.used < BATCH_BYTES) {
-      // (a block that lies inside one inflated BGZF member is copied from where it is: one peek for its size, one for
-      // its bytes; one that straddles two members -- or any block, with zlib's reader -- goes through read())
+    const void* held = nullptr;
+    while (B.used + B.extBytes < BATCH_BYTES) {
+      // (a block that lies inside one inflated BGZF member stays where it is -- the batch keeps the member alive and
+      // the decoders read it there: one peek for its size, one for its bytes; one that straddles two members -- or any
+      // block, with zlib's reader -- is copied through read())
       if (const uint8_t* p4 = g.peek(4)) {
         const int32_t sz = (int32_t)(p4[0] | (p4[1] << 8) | (p4[2] << 16) | ((uint32_t)p4[3] << 24));
         if (sz >= 32) {
           if (const uint8_t* whole = g.peek(4 + (size_t)sz)) {
-            memcpy(B.room((size_t)sz), whole + 4, (size_t)sz);
+            std::shared_ptr<const void> h = g.holdCurrent();
+            if (h.get() != held) {
+              held = h.get();
+              B.holds.push_back(std::move(h));
+            }
+            B.addExt(whole + 4, (size_t)sz);
             g.advance(4 + (size_t)sz);
-            B.add((size_t)sz);
             continue;
           }
         }
@@ -1703,11 +1726,11 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
     }
     return true;
   };
-  auto one = [&o, &idx](char* base, uint32_t off, uint32_t len, Decoded& r) { decodeBamBlock(o, idx, base, off, len, r); };
+  auto one = [&o, &idx](char* rec, uint32_t len, Decoded& r) { decodeBamBlock(o, idx, rec, len, r); };
   if (g_decoders > 1 && !g_serialState)
     runParallelState(S, rs, C, g_decoders, 0, fill, one);
   else
-    runDecode(g_decoders, fill, one, [&](const Batch& B, const Decoded& r) { applyDecoded(S, rs, C, B, r, 0); });
+    runDecode(g_decoders, fill, one, [&](const Batch& B, size_t i) { applyDecoded(S, rs, C, B, i, 0); });
   finishFile(S, rs, C);
   return C.count;
 }
