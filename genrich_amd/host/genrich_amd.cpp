@@ -13,8 +13,12 @@
 // and so does -r / -R (PCR-duplicate removal, Genrich.c:2776-2977 and 3267-4042).
 //
 // Extra long options:
-//   --threads N     threads that inflate BGZF (BAM, bgzip-ped SAM) input, and as many that decode records (SAM lines,
-//                   BAM blocks: everything that does not touch the run's state); default min(16, cores); 1: one thread does it all
+//   --threads N     threads that inflate BGZF (BAM, bgzip-ped SAM) input, as many that decode records (SAM lines,
+//                   BAM blocks: everything that does not touch the run's state) and as many that run the pairing /
+//                   weighting state machine over chunks of whole read-name groups (results merged in file order);
+//                   default min(16, cores); 1: one thread does it all, in the reference's order of operations
+//   (environment, for tests: GENRICH_BATCH_BYTES, GENRICH_CHUNK_RECS -- where the input is cut; GENRICH_SERIAL_STATE=1 --
+//   one thread for the state machine)
 //   (environment: GENRICH_HOST_PROF=1 prints the CPU time of the parsing thread after the last input)
 //   --events-only   parse and write the -b file without touching a GPU (diagnostics)
 //   --device N      HIP device ordinal (default 0)
