@@ -612,11 +612,24 @@ void processAlns(State& S, const char* qname, std::vector<Aln>& aln, std::vector
 // both 5' ends), discordant pairs by both ends with their strands in either order, singletons by
 // (chrom, 5' end, strand) -- against kept singletons and against both ends of every kept pair.
 // Only membership matters, so ordered maps stand in for the reference's chained hash tables.
-struct KeyPr { int chrom; uint32_t p0, p1; bool operator<(const KeyPr& o) const { return std::tie(chrom, p0, p1) < std::tie(o.chrom, o.p0, o.p1); } };
-struct KeySn { int chrom; uint32_t pos; bool strand; bool operator<(const KeySn& o) const { return std::tie(chrom, pos, strand) < std::tie(o.chrom, o.pos, o.strand); } };
+// (hash tables, as the reference's: only "is this key there, and who put it there first" is ever asked -- an ordered
+// map of 10^7 keys made findDups the slowest part of a -r run)
+struct KeyPr { int chrom; uint32_t p0, p1; bool operator==(const KeyPr& o) const { return chrom == o.chrom && p0 == o.p0 && p1 == o.p1; } };
+struct KeySn { int chrom; uint32_t pos; bool strand; bool operator==(const KeySn& o) const { return chrom == o.chrom && pos == o.pos && strand == o.strand; } };
 struct KeyDc {
   int c0, c1; uint32_t p0, p1; bool s0, s1;
-  bool operator<(const KeyDc& o) const { return std::tie(c0, c1, p0, p1, s0, s1) < std::tie(o.c0, o.c1, o.p0, o.p1, o.s0, o.s1); }
+  bool operator==(const KeyDc& o) const { return c0 == o.c0 && c1 == o.c1 && p0 == o.p0 && p1 == o.p1 && s0 == o.s0 && s1 == o.s1; }
+};
+inline uint64_t mix64(uint64_t x) {  // (splitmix64's finaliser)
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+  return x;
+}
+struct KeyHash {
+  size_t operator()(const KeyPr& k) const { return (size_t)mix64(((uint64_t)k.p0 << 32 | k.p1) ^ mix64((uint64_t)(uint32_t)k.chrom)); }
+  size_t operator()(const KeySn& k) const { return (size_t)mix64(((uint64_t)k.pos << 1 | (uint64_t)k.strand) ^ mix64((uint64_t)(uint32_t)k.chrom + 0x9e3779b97f4a7c15ull)); }
+  size_t operator()(const KeyDc& k) const {
+    return (size_t)mix64(((uint64_t)k.p0 << 32 | k.p1) ^ mix64(((uint64_t)(uint32_t)k.c0 << 32 | (uint32_t)k.c1) ^ ((uint64_t)k.s0 << 1 | (uint64_t)k.s1)));
+  }
 };
 
 void dupLine(State& S, const char* fmt, ...) {
@@ -630,7 +643,7 @@ void dupLine(State& S, const char* fmt, ...) {
 
 void findDups(State& S, DupReads& D, Counts& C) {
   const bool verb = S.dupsVerb;
-  std::map<KeySn, std::string> tabSn;
+  std::unordered_map<KeySn, std::string, KeyHash> tabSn;
   const bool useSn = S.o.singleOpt && !D.sn.empty();  // the singleton table exists only when there are singletons
   auto addSn = [&](int chrom, uint32_t pos, bool strand, const std::string& name) {  // checkAndAdd 3514
     tabSn.emplace(KeySn{chrom, pos, strand}, verb ? name : std::string());
@@ -643,7 +656,7 @@ void findDups(State& S, DupReads& D, Counts& C) {
   };
 
   {  // properly paired sets (findDupsPr 3616)
-    std::map<KeyPr, std::string> tab;
+    std::unordered_map<KeyPr, std::string, KeyHash> tab;
     for (uint32_t i : order(D.pr)) {
       DRead& r = D.pr[i];
       bool dup = false;
@@ -691,7 +704,7 @@ void findDups(State& S, DupReads& D, Counts& C) {
   std::vector<Unpair> none;
 
   {  // discordant sets (findDupsDc 3761): every R1 x R2 combination, either order
-    std::map<KeyDc, std::string> tab;
+    std::unordered_map<KeyDc, std::string, KeyHash> tab;
     auto end5 = [](const Aln& a) { return a.strand ? a.pos[0] : a.pos[1]; };
     for (uint32_t i : order(D.dc)) {
       DRead& r = D.dc[i];
