@@ -1463,9 +1463,36 @@ void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOf
   while (DecodePipe::Ptr b = pipe.next()) {
     uint32_t i0 = 0;
     const uint32_t n = (uint32_t)b->rec.size();
+    // A long run of records that never reach the state machine (unmapped, supplementary, low MAPQ: counters only) is
+    // counted here and left out of the chunk: a chunk cannot end inside an open group, and a file that goes on for
+    // millions of such records would otherwise keep all their batches in memory until the next group starts.
+    constexpr uint32_t NONE = 0xFFFFFFFFu, LONG_RUN = 64;
+    uint32_t runStart = NONE;
+    auto endRun = [&](uint32_t i) {
+      if (runStart != NONE && i - runStart >= LONG_RUN) {
+        if (runStart > i0) {
+          cur->segs.push_back(Chunk::Seg{b, i0, runStart});
+          cur->nrec += runStart - i0;
+        }
+        for (uint32_t k = runStart; k < i; k++) {
+          C.count++;
+          const uint8_t kind = b->rec[k].kind;
+          if (kind == Decoded::UNMAPPED) C.unmapped++;
+          else if (kind == Decoded::SUPP) C.supp++;
+          else C.lowMapQ++;
+        }
+        i0 = i;
+      }
+      runStart = NONE;
+    };
     for (uint32_t i = 0; i < n; i++) {
       const Decoded& r = b->rec[i];
-      if (r.kind != Decoded::REC) continue;
+      if (r.kind == Decoded::UNMAPPED || r.kind == Decoded::SUPP || r.kind == Decoded::LOWQ) {
+        if (runStart == NONE) runStart = i;
+        continue;
+      }
+      endRun(i);
+      if (r.kind != Decoded::REC) continue;  // (a record that failed keeps its place in the chunk: it ends the run there)
       const char* qname = b->at(i) + r.qname;
       if (have && name == qname) continue;  // (std::string == const char*: the whole name, as record() compares)
       // a group starts at record i
@@ -1479,6 +1506,7 @@ void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOf
         i0 = i;
       }
     }
+    endRun(n);
     if (n > i0) {
       cur->segs.push_back(Chunk::Seg{b, i0, n});
       cur->nrec += n - i0;

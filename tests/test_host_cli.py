@@ -481,3 +481,48 @@ def test_cli_parallel_state_keeps_the_warning_count_and_the_float_sum_in_file_or
     assert err.count("prevented from extending past") == 128 and "warning messages suppressed" in err
     assert "extended to" in err
     assert all(o == outs[0] for o in outs[1:])
+
+
+def test_cli_long_runs_of_skipped_records_neither_end_a_group_nor_change_the_counts(tmp_path):
+    """Records that never reach the state machine (unmapped, low MAPQ) do not end a read-name group: a pair whose mates
+    are 200 unmapped records apart is still a pair (record() keeps the name until a different one gets that far).  The
+    thread that cuts the stream into chunks of whole groups counts long runs of such records itself and leaves them out
+    of the chunks; the -v accounting and the events must be the sequential run's (the numbers below are the reference
+    binary's for this input)."""
+    import random
+    random.seed(3)
+    sq = "@HD\tVN:1.0\tSO:queryname\n@SQ\tSN:chr1\tLN:1000000\n"
+    rec = lambda q, flag, pos, pn, tl, mapq=30: f"{q}\t{flag}\tchr1\t{pos}\t{mapq}\t50M\t=\t{pn}\t{tl}\t*\t*\tAS:i:0\n"
+    unm = lambda q, flag: f"{q}\t{flag}\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII\n"
+    out = [unm(f"u{i}", 77) + unm(f"u{i}", 141) for i in range(500)]
+    for i in range(300):
+        out.append(rec(f"r{i}", 99, 1000 + 10 * i, 1200 + 10 * i, 250) + rec(f"r{i}", 147, 1200 + 10 * i, 1000 + 10 * i, -250))
+        if i % 50 == 10:
+            out += [unm(f"x{i}_{k}", 77) + unm(f"x{i}_{k}", 141) for k in range(random.choice([10, 40, 100, 300]))]
+        if i % 70 == 5:
+            out += [rec(f"q{i}_{k}", 99, 5000 + k, 5200 + k, 250, mapq=0) + rec(f"q{i}_{k}", 147, 5200 + k, 5000 + k, -250, mapq=0)
+                    for k in range(120)]
+    out.append(rec("split", 99, 70000, 70200, 250))
+    out += [unm(f"y{k}", 77) for k in range(200)]
+    out.append(rec("split", 147, 70200, 70000, -250))
+    out += [unm(f"z{i}", 77) for i in range(1000)]
+    sam = tmp_path / "t.sam"
+    sam.write_text(sq + "".join(out))
+    outs = []
+    for threads, batch, chunk in (("1", None, None), ("4", None, None), ("4", "300", "1"), ("3", "1", "2"), ("8", "5000", "50")):
+        env = dict(os.environ)
+        if batch:
+            env["GENRICH_BATCH_BYTES"] = batch
+        if chunk:
+            env["GENRICH_CHUNK_RECS"] = chunk
+        bed = tmp_path / f"e{threads}{batch}.bed"
+        res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-v", "-m", "10", "-t", str(sam), "-b", str(bed)],
+                             capture_output=True, text=True, env=env)
+        assert res.returncode == 0, res.stderr
+        outs.append((res.stderr, bed.read_text()))
+    err = outs[0][0]
+    nums = {l.split(":")[0].strip(): int(l.split(":")[1]) for l in err.splitlines() if ":" in l and l.split(":")[1].strip().isdigit()}
+    assert nums["SAM records analyzed"] == 5002 and nums["Unmapped"] == 3200 and nums["MAPQ < 10"] == 1200
+    assert nums["Paired alignments"] == 602 and nums["Full fragments"] == 301
+    assert outs[0][1].count("\n") == 301 and "split_1_E_0" in outs[0][1]
+    assert all(o == outs[0] for o in outs[1:])
