@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gx_api.hip")
 EMIT = os.path.join(HERE, "csrc", "gx_emit.cpp")
-DEPS = [SRC, EMIT] + [os.path.join(HERE, "csrc", f) for f in ("gx_kernels.h", "gx_stats.h", "gx_merge.h", "gx_math.h", "gx_saturate.h", "gx_tile_fast.h", "gx_sort.h", "gx_rccl.h")] + [
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".h", ".hip", ".cpp"))) + [
     os.path.join(os.path.dirname(HERE), "include", "genrich_amd.h")]
 LIB = os.path.join(HERE, "libgenrich_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -155,6 +155,7 @@ struct gx_ctx {
   u32 nSB = 0;
   DevBuf dChrom, dTileChrom, dBedTileOff, dBedEdge, dTileSave0;
   bool hasBed = false;
+  bool bedGiven = false;        // some chromosome (of any rank) has -E regions: what every rank knows alike
   size_t nBedEdges = 0;
   // per-sample state
   int phase = 0;  // 0 idle, 1 treatment open, 2 treatment done, 3 control open, 4 control done
@@ -180,6 +181,11 @@ struct gx_ctx {
   bool sawFrac = false;         // a sample of this context held fractional weights: k_sbtile is not tried again
   bool fusedOff = false;        // this sample: a super-bucket did not fit k_sbtile (the general chain runs instead)
   bool fusedUsed = false;       // the last build went through k_sbtile
+  bool pairsUsed = false;       // ... on level 1's pair records (k_sort1p)
+  bool earlyColl = false;       // this build: the ranks exchange the closed form of fragLen ahead of the tile stage
+  bool earlyOwed = false;       // ... and this rank has not taken part in that all-reduce yet (poison_allreduce)
+  bool earlyPending = false;
+  size_t s1pLdsSet = 0;
   int fusedBackoff[2] = {0, 0}; // treatment / control samples for which k_sbtile is not tried (after one that did not fit)
   bool looseSwept = false;      // the last gx_find_peaks swept the loose slots
   DevBuf lbSweep, lbSweep2;     // look-back granules of the sweep's one-pass compactions (generation-tagged)
@@ -199,7 +205,7 @@ struct gx_ctx {
   DevBuf lbIv;
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3];
-  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, nWide, wideList, heavyList;
+  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, binNet, nWide, wideList, heavyList;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};  // host copy of the device scalars (refreshed from the mail block)
@@ -559,7 +565,16 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
   const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
   const bool multiRank = ctx->world > 1 || ctx->forceColl;
-  const bool wantEarly = !isCtrl && !multiRank && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag;
+  // Several ranks: lambda needs every rank's fragLen.  Its closed form (the sum of the fragment lengths, k_sort1) is
+  // known BEFORE the tile stage, so the ranks exchange that (`earlyColl`: one all-reduce of three words behind
+  // k_sort1; decided by what every rank knows alike) and each of them has the table p(V) and the sweep's bits from the
+  // tile stage, as a single rank has.  The all-reduce behind the tile stage (finish_scalars) still carries the exact
+  // parts and the ranks' flags; a rank whose lambda came out different there falls back to k_pack_pval as before.
+  const bool earlyColl = multiRank && !isCtrl && !ctx->par.qval_opt && !ctx->bedGiven && !noLoose && !forceSlowFrag &&
+                         getenv("GX_NO_EARLY_COLL") == nullptr;
+  ctx->earlyColl = earlyColl;
+  ctx->earlyOwed = earlyColl;
+  const bool wantEarly = !isCtrl && (!multiRank || earlyColl) && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag;
   const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
   u64* sigMask = nullptr;
   if (wantEarly) {
@@ -581,7 +596,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     const size_t ptBytes = up((size_t)NXCD * nL1 * jmax * 4);
     const size_t lbTBytes = up((size_t)3 * (tChunks + 2) * 8), lbIBytes = up((size_t)(2 * tChunks + 4) * 8);
     const size_t ctlBytes = up(sizeof(LooseCtl));
-    const size_t total = ffBytes + 256 + ctlBytes + endBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
+    const size_t netBytes = up((size_t)(MAX_BINS + 2) * 4);  // pair mode: the singles' weight per level-1 bin
+    const size_t total = ffBytes + 256 + ctlBytes + endBytes + netBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
     HIPCHECK(ctx->zeroArena.ensure(total));
     char* base = ctx->zeroArena.as<char>();
     ctx->fragSum.view(base, ffBytes);
@@ -592,6 +608,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     base += ctlBytes;
     ctx->endAtLen.view(base, endBytes);
     base += endBytes;
+    ctx->binNet.view(base, netBytes);
+    base += netBytes;
     for (int q = 0; q < 3; q++) {
       ctx->str[q].cursor.view(base, curBytes);
       base += curBytes;
@@ -639,6 +657,22 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   HIPCHECK(pooled(ctx, out.tileIvOff, (size_t)(nTiles + 2) * 4));
   HIPCHECK(pooled(ctx, out.chromIvOff, (size_t)(nChrom + 2) * 4));
 
+  // ---- what the tile stage will be -------------------------------------------------------------------------
+  // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- unit weights, no -E regions, at most
+  // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
+  // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
+  // (a sample whose predecessor of the same kind did not fit is not even tried for a while: the same experiment's
+  // next replicate, or the next run on the same data, has the same pile-ups)
+  const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
+  if (backoff) ctx->fusedBackoff[isCtrl ? 1 : 0]--;
+  const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && !ctx->sawFrac && !ctx->fusedOff &&
+                     !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 26000 &&
+                     (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
+  ctx->fusedUsed = fused;
+  // ... and with it level 1: one record per fragment (k_sort1p) when k_sbtile will read it
+  const bool pairs = fused && !reuseSort && getenv("GX_NO_PAIRS") == nullptr;
+  ctx->pairsUsed = pairs;
+
   phase_begin(ctx, isCtrl ? "c.sort1" : "t.sort1");
   // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
   HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
@@ -658,7 +692,16 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     // scatter of the pieces that have arrived overlaps the upload of the rest)
     if (seg.ready) HIPCHECK(hipStreamWaitEvent(s, seg.ready, 0));
     const u32 blocks = (u32)((seg.n + S1_CHUNK - 1) / S1_CHUNK);
-    if (unit32)
+    static_assert(S1P_CHUNK == S1_CHUNK, "one grid size for both level-1 kernels");
+    if (pairs) {
+      const size_t lds1 = s1p_lds_bytes(nL1, nChrom);
+      if (ctx->s1pLdsSet < lds1) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort1p), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        ctx->s1pLdsSet = lds1;
+      }
+      hipLaunchKernelGGL(k_sort1p, dim3(blocks), dim3(S1P_NT), lds1, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
+                         ctx->sbShift, nL1, PG3[0], PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
+    } else if (unit32)
       hipLaunchKernelGGL(k_sort1<true>, dim3(blocks), dim3(S1_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
                          ctx->sbShift, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
     else
@@ -667,19 +710,15 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   }
   if (int rc__ = dbg_sync(ctx, "k_sort1")) return rc__;
   phase_end(ctx);
+  long long* earlyWords = nullptr;
+  if (earlyColl) {
+    // this rank's closed form, whether it is valid here (unit weights so far, no -E regions, 4-byte keys), [2] unused
+    earlyWords = ctx->dColl.as<long long>() + 4;
+    hipLaunchKernelGGL(k_early_words, dim3(1), dim3(64), 0, s, (const FragFix*)ff, wantEarly ? 0 : 1, earlyWords);
+    if (int rc__ = allreduce_words(ctx, earlyWords, 3)) return rc__;
+    ctx->earlyOwed = false;
+  }
 
-  // ---- what the tile stage will be -------------------------------------------------------------------------
-  // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- unit weights, no -E regions, at most
-  // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
-  // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
-  // (a sample whose predecessor of the same kind did not fit is not even tried for a while: the same experiment's
-  // next replicate, or the next run on the same data, has the same pile-ups)
-  const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
-  if (backoff) ctx->fusedBackoff[isCtrl ? 1 : 0]--;
-  const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && !ctx->sawFrac && !ctx->fusedOff &&
-                     !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 26000 &&
-                     (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
-  ctx->fusedUsed = fused;
   LooseCtl* ctl = ctx->looseCtl.as<LooseCtl>();
   HIPCHECK(ctx->tileSlot.ensure((size_t)(nTiles + 2) * 4));
   HIPCHECK(ctx->chromW0.ensure((size_t)(nChrom + 1) * 4));
@@ -690,7 +729,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     BinScan bs{{SS.cursor.as<u32>(), SE.cursor.as<u32>(), SF.cursor.as<u32>()},
                {capOf(PgCfg<u32>::SHIFT), capOf(PgCfg<u32>::SHIFT), capOf(PgCfg<u64>::SHIFT)},
                {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()},
-               ctx->endAtLen.as<u32>(), ctx->chromW0.as<int>(), nChrom, ff, ctx->dScal.as<Scalars>(), ctl, wantEarly ? 1 : 0};
+               ctx->endAtLen.as<u32>(), ctx->chromW0.as<int>(), nChrom, ff, ctx->dScal.as<Scalars>(), ctl, wantEarly ? 1 : 0,
+               pairs ? 1 : 0, ctx->binNet.as<int>(), earlyWords};
     static_assert(PV_LUT % 1024 == 0, "k_bins_lut: four of k_pval_lut's workgroups per block");
     if (wantEarly)  // with the table p(V) for that lambda, and from which pileup on an interval is significant
       hipLaunchKernelGGL(k_bins_lut, dim3(4 + PV_LUT / 1024), dim3(1024), 0, s, bs, nL1, ctx->pvLut.as<float>(),
@@ -779,14 +819,19 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   if (fused) {
     // level 2 of the sort and the tile passes in one kernel, one workgroup per super-bucket (gx_sbtile.h)
     if (!ctx->sbtLdsSet) {
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile), hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(SbtLds)));
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(SbtLds)));
       ctx->sbtLdsSet = true;
     }
-    SbtIn si{PG3[0], PG3[1], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
+    SbtIn si{PG3[0], PG3[1], PG3[2], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
              ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, ctx->sbShift};
     SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>()};
-    hipLaunchKernelGGL(k_sbtile, dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+    if (ctx->pairsUsed)
+      hipLaunchKernelGGL(k_sbtile<true>, dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+    else
+      hipLaunchKernelGGL(k_sbtile<false>, dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
   } else if (ctx->hasBed) {
     hipLaunchKernelGGL((k_tile<true, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
@@ -824,7 +869,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                ctx->tileSlot.as<u32>(), ctx->chromLooseOff.as<u32>(), ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctl,
                ctx->tileDeep.as<u32>(), ff, ctx->fragList.as<u32>(), ctx->fragFused ? acc : (long long*)nullptr};
   static const bool noClose = getenv("GX_NO_CLOSE") != nullptr, sepClose = getenv("GX_SEPARATE_CLOSE") != nullptr;
-  const bool closeInScan = wantEarly && !noClose && !sepClose;  // (k_scan_iv_close, below)
+  const bool closeInScan = wantEarly && !noClose && !sepClose && !multiRank;  // (k_scan_iv_close, below)
   if (!closeInScan)
     hipLaunchKernelGGL(k_scan_iv, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
                        ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
@@ -844,7 +889,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                     wantEarly ? ctx->swMask.as<u64>() + ctx->looseStride : (u64*)nullptr};
     ctx->closeSel = fsel;
     ctx->closeSeq = 0;
-    if (wantEarly && !noClose) {
+    if (wantEarly && !noClose && !multiRank) {
       // lambda was known before the tile stage: k_frag_select's work and the mail in one launch (k_close); if a deep tile,
       // the general fragLen path or a changed lambda stands in the way, finish_scalars runs the separate kernels after all
       ctx->closeSeq = ++ctx->mailSeq;
@@ -893,41 +938,54 @@ constexpr int RETRY_PT = 2;         // (internal) a level-1 page list overflowed
 // more than 5 x 10^8 keys of ONE super-bucket: such a sample fails with "could not be rebuilt")
 constexpr u32 PT_JMAX_CAP = 1u << 16;
 
+// n (<= 4) 64-bit words on the device, summed over all ranks in place: RCCL in stream order (no host hop), or the host
+// program's callback (a copy down, a synchronisation, a copy up)
+int allreduce_words(gx_ctx* ctx, long long* d, int n) {
+  hipStream_t s = ctx->stream;
+  if (ctx->comm) {
+    const gxrccl::Api* api = gxrccl::load(&ctx->err);
+    if (!api) return GX_ERR_DEVICE;
+    ncclResult_t r = api->allReduce(d, d, (size_t)n, ncclInt64, ncclSum, ctx->comm, s);
+    if (r != ncclSuccess) {
+      ctx->err = std::string("ncclAllReduce: ") + api->getErrorString(r);
+      return GX_ERR_DEVICE;
+    }
+  } else if (ctx->allreduce) {
+    long long* acc = ctx->mail->coll;
+    HIPCHECK(hipMemcpyAsync(acc, d, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    int64_t buf[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++) buf[i] = acc[i];
+    if (ctx->allreduce(buf, n, ctx->user)) {
+      ctx->err = "allreduce callback failed";
+      return GX_ERR_DEVICE;
+    }
+    for (int i = 0; i < n; i++) acc[i] = buf[i];
+    HIPCHECK(hipMemcpyAsync(d, acc, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipStreamSynchronize(s));  // (the pinned words are reused by the next exchange)
+  } else {
+    ctx->err = "several ranks but no collectives (gx_set_rccl / gx_set_collectives)";
+    return GX_ERR_ORDER;
+  }
+  return GX_OK;
+}
+
 // fragLen / ctrlFrag partial sums -> (all ranks) -> lambda, factor
 int finish_scalars(gx_ctx* ctx, int isCtrl) {
   hipStream_t s = ctx->stream;
   Scalars* ds = ctx->dScal.as<Scalars>();
   const bool multi = ctx->world > 1 || ctx->forceColl;
   long long* dcoll = multi ? ctx->dColl.as<long long>() : nullptr;
-  if (multi && ctx->comm) {
-    // RCCL on the device words, in stream order: no host hop.  The third word sums the ranks' saturation
-    // flags, so that every rank learns from the one synchronisation below whether the sums are final.
-    const gxrccl::Api* api = gxrccl::load(&ctx->err);
-    if (!api) return GX_ERR_DEVICE;
-    ncclResult_t r = api->allReduce(dcoll, dcoll, 3, ncclInt64, ncclSum, ctx->comm, s);
-    if (r != ncclSuccess) {
-      ctx->err = std::string("ncclAllReduce: ") + api->getErrorString(r);
-      return GX_ERR_DEVICE;
-    }
-  } else if (multi && ctx->allreduce) {
-    long long* acc = ctx->mail->coll;
-    HIPCHECK(hipMemcpyAsync(acc, dcoll, 24, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    int64_t buf[3] = {acc[0], acc[1], acc[2]};
-    if (ctx->allreduce(buf, 3, ctx->user)) {
-      ctx->err = "allreduce callback failed";
-      return GX_ERR_DEVICE;
-    }
-    acc[0] = buf[0];
-    acc[1] = buf[1];
-    acc[2] = buf[2];
-    HIPCHECK(hipMemcpyAsync(dcoll, acc, 24, hipMemcpyHostToDevice, s));
-  } else if (multi) {
-    ctx->err = "several ranks but no collectives (gx_set_rccl / gx_set_collectives)";
-    return GX_ERR_ORDER;
-  }
-  if (multi) {  // (one rank: k_frag_select has done it)
-    hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>(), (const long long*)dcoll);
+  if (multi) {
+    // The third word sums the ranks' "build this sample again" flags, so that every rank learns from the one
+    // synchronisation below whether the sums are final.
+    if (int rc__ = allreduce_words(ctx, dcoll, 3)) return rc__;
+    ctx->earlyPending = false;
+    // (one rank: k_frag_select has done it).  With lambda known to every rank before the tile stage (the early
+    // all-reduce of build_pileup), this is also where a rank learns whether its sweep bits were written with the
+    // lambda that turned out final.
+    hipLaunchKernelGGL(k_finish_frag, dim3(1), dim3(1), 0, s, ds, isCtrl, ctx->dStatus.as<u32>(), (const long long*)dcoll,
+                       !isCtrl && ctx->earlyColl ? ctx->looseCtl.as<LooseCtl>() : (LooseCtl*)nullptr);
     if (int rc__ = dbg_sync(ctx, "k_finish_frag")) return rc__;
   }
   bool closed = false;
@@ -1045,15 +1103,21 @@ void poison_allreduce(gx_ctx* ctx) {
   if (!(ctx->world > 1 || ctx->forceColl)) return;
   hipStream_t s = ctx->stream;
   long long w[3] = {0, 0, COLL_FAILED};
-  if (ctx->comm) {
-    const gxrccl::Api* api = gxrccl::load(nullptr);
-    if (!api || !ctx->dColl.p) return;
-    if (hipMemcpyAsync(ctx->dColl.p, w, sizeof w, hipMemcpyHostToDevice, s) != hipSuccess) return;
-    (void)api->allReduce(ctx->dColl.p, ctx->dColl.p, 3, ncclInt64, ncclSum, ctx->comm, s);
-    (void)hipStreamSynchronize(s);
-  } else if (ctx->allreduce) {
-    int64_t buf[3] = {w[0], w[1], w[2]};
-    (void)ctx->allreduce(buf, 3, ctx->user);
+  // (a build that fails ahead of its early all-reduce -- the closed form of fragLen, build_pileup -- owes the other
+  // ranks that one too: they are in it, or about to be)
+  const int rounds = ctx->earlyOwed ? 2 : 1;
+  ctx->earlyOwed = false;
+  for (int r = 0; r < rounds; r++) {
+    if (ctx->comm) {
+      const gxrccl::Api* api = gxrccl::load(nullptr);
+      if (!api || !ctx->dColl.p) return;
+      if (hipMemcpyAsync(ctx->dColl.p, w, sizeof w, hipMemcpyHostToDevice, s) != hipSuccess) return;
+      (void)api->allReduce(ctx->dColl.p, ctx->dColl.p, 3, ncclInt64, ncclSum, ctx->comm, s);
+      (void)hipStreamSynchronize(s);
+    } else if (ctx->allreduce) {
+      int64_t buf[3] = {w[0], w[1], w[2]};
+      (void)ctx->allreduce(buf, 3, ctx->user);
+    }
   }
 }
 
@@ -1083,7 +1147,8 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
       // k_sbtile could not take the sample (finish_scalars has switched it off for this one): the general chain,
       // on the pages level 1 of the sort has already filled
       if (int w = wipe()) return w;
-      reuseSort = getenv("GX_NO_REUSE_SORT") == nullptr;
+      // (pair records are of no use to the general chain: level 1 runs again as start / end keys)
+      reuseSort = getenv("GX_NO_REUSE_SORT") == nullptr && !ctx->pairsUsed;
       if (reuseSort) {
         // (k_sort1 does not run again: the status bits IT raised -- bad counts, positions, chromosomes -- must survive)
         // (and only those: what the abandoned tile stage raised -- e.g. "negative pileup" from carries that count the
@@ -1527,9 +1592,13 @@ int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip, 
   ctx->save.assign(n, 1);
   ctx->owned.assign(n, 1);
   ctx->bed.assign(n, {});
+  ctx->bedGiven = false;
   for (int i = 0; i < n; i++) {
     ctx->skip[i] = skip && skip[i];
-    if (bed && bed_len && bed_len[i] > 0 && !ctx->skip[i]) ctx->bed[i].assign(bed[i], bed[i] + bed_len[i]);
+    if (bed && bed_len && bed_len[i] > 0 && !ctx->skip[i]) {
+      ctx->bed[i].assign(bed[i], bed[i] + bed_len[i]);
+      ctx->bedGiven = true;
+    }
   }
   int rc = layout_tiles(ctx);
   if (rc) return rc;
@@ -2396,7 +2465,7 @@ int gx_rccl_nranks(gx_ctx* ctx, int* n) {
 
 int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   if (!ctx || !flags) return GX_ERR_ORDER;
-  *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
+  *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u);
   return GX_OK;
 }

@@ -1544,9 +1544,12 @@ __global__ __launch_bounds__(256) void k_build_init(Scalars* __restrict__ s, int
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nB; i += stride) b[i] = z;
 }
 
-__global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st, const long long* __restrict__ coll) {
+// (ctl: several ranks that knew lambda ahead of the tile stage -- was it the final one?  frag_select_body's verdict for
+// one rank)
+__global__ void k_finish_frag(Scalars* s, int isCtrl, u32* st, const long long* __restrict__ coll, LooseCtl* ctl) {
   if (threadIdx.x || blockIdx.x) return;
   finish_frag(s, isCtrl, st, coll);
+  if (ctl) ctl->ok = ctl->enabled && !ctl->bad && ctl->earlyBits == __float_as_uint(s->lambda) ? 1u : 0u;
 }
 
 // Everything the host wants to know at a synchronisation point, written by ONE small kernel straight into

@@ -45,12 +45,12 @@ constexpr u32 ST_SB_FRAC = 2048u;  // (internal) the sample holds fractional-wei
 
 constexpr int SBT_NT = 1024;
 constexpr int SBT_NW = SBT_NT / 64;
-constexpr int SBT_MAXSHIFT = 8;
 constexpr int SBT_TILES = 1 << SBT_MAXSHIFT;          // tiles per super-bucket the LDS tables are made for
 constexpr int SBT_K = 8;                               // 16-byte loads per lane and stream
 constexpr u32 SBT_SLOT = 256;                          // keys per slot
 constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K keys)
 constexpr u32 SBT_KEYCAP = 57344;                      // keys of a super-bucket (both streams) that fit the LDS
+constexpr u32 SBT_FCAP = 16384;                        // pair mode: singles of a super-bucket (read where they lie, twice)
 constexpr int SBT_TR = 192;                            // touched bases per round of a tile's passes (k_tile_fast: TR_CAP)
 // a wavefront's scratch, in words: occupancy bitmap (+ a dummy word that absorbs the lanes without a key), the words'
 // prefix counts (+ a dummy entry that ranks those lanes out of every round), counters and offsets by rank
@@ -77,12 +77,14 @@ struct SbtLds {
   __attribute__((aligned(8))) u32 scratch[40];
   u32 work;
   u32 overflow;
+  u32 vsRed[2];                            // loose_vsig's reduction words (its own: tid 0 initialises the others right after)
 };
 
 struct SbtIn {
-  PagedStream PS, PE;
-  const u32* sbOffS;          // [nSeg + 1] start keys in the bins before (k_scan_bins)
-  const u32* sbOffE;
+  PagedStream PS, PE;         // (pair mode: PS = the pair records' lists, PE unused)
+  PagedStream PF;             // pair mode: the singles' lists (8-byte signed-weight records)
+  const u32* sbOffS;          // [nSeg + 1] start keys in the bins before (k_scan_bins); pair mode: endpoint keys before
+  const u32* sbOffE;          //            end keys in the bins before; pair mode: weight (1/120) handed on by the bins before
   const u32* sbOffF;          // (only its total is looked at: any fractional record sends the sample to the general chain)
   const u32* tileChrom;
   const DChrom* chroms;
@@ -255,6 +257,10 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   wave_lds_sync();
 }
 
+// PAIRS: level 1 was k_sort1p (gx_sort.h): one 4-byte record per fragment (start within the bin, length) in PS, the few
+// other records ("singles") as 8-byte signed-weight records in PF -- half the bytes to load, one LDS atomic per fragment
+// in the histogram and in the scatter where both ends share a tile (19 of 20).
+template <bool PAIRS>
 __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
   SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   const u32 seg = blockIdx.x, nSeg = in.nSeg;
   const u32 nT = 1u << in.sbShift;           // tiles per super-bucket (<= SBT_TILES)
   const u32 segTileBase = seg << in.sbShift;
-  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, blockIdx.x == 0 && tid == 0, &L.work));  // (&L.work: two words)
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, blockIdx.x == 0 && tid == 0, L.vsRed));
   // scratch and tables start at zero
   for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
   if (tid < SBT_TILES) L.hist[tid] = 0;
@@ -270,8 +276,11 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   __syncthreads();
   if (tid < SBT_NW) L.tile[tid][SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
   if (tid < 2 * NXCD) {
-    const PagedStream& P = tid < NXCD ? in.PS : in.PE;
-    L.scratch[tid] = list_len<u32>(P, (u32)(tid & (NXCD - 1)) * nSeg + seg);
+    const u32 li = (u32)(tid & (NXCD - 1)) * nSeg + seg;
+    if (PAIRS)
+      L.scratch[tid] = tid < NXCD ? list_len<u32>(in.PS, li) : list_len<u64>(in.PF, li);
+    else
+      L.scratch[tid] = list_len<u32>(tid < NXCD ? in.PS : in.PE, li);
   }
   __syncthreads();
   if (tid < 2) {
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   }
   __syncthreads();
   // ---- 1: slot descriptors (thread k of the first 2 SBT_SLOTS: slot k & 127 of stream k >> 7)
-  if (tid < 2 * (int)SBT_SLOTS) {
+  if (tid < (PAIRS ? 1 : 2) * (int)SBT_SLOTS) {
     const int q = tid / (int)SBT_SLOTS;
     const u32 k = (u32)tid % SBT_SLOTS;
     const PagedStream& P = q ? in.PE : in.PS;
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {  // (wave-uniform: scalar registers)
     cS[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
-    cE[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[SBT_SLOTS + i * SBT_NW + wv]);
+    cE[i] = ovfSlots || PAIRS ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[SBT_SLOTS + i * SBT_NW + wv]);
   }
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
@@ -345,8 +354,13 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
     kE[i] = make_uint4(0u, 0u, 0u, 0u);
-    if ((u32)lane * 4 < cE[i]) kE[i] = poolE[(L.slotOff[SBT_SLOTS + i * SBT_NW + wv] >> 2) + lane];
+    if (!PAIRS && (u32)lane * 4 < cE[i]) kE[i] = poolE[(L.slotOff[SBT_SLOTS + i * SBT_NW + wv] >> 2) + lane];
   }
+  // pair mode: the bin's singles (a handful; 8-byte records of weight +-120 = a start / an end key; anything else is a
+  // fractional weight: the sample goes to the general chain) are read where they lie, once per pass
+  const BinSrc<u64> srcF{reinterpret_cast<const u64*>(in.PF.pool), in.PF.pt, nSeg, in.PF.jmax, seg, L.pre[1]};
+  const u32 nF = PAIRS && !ovfSlots ? L.pre[1][NXCD] : 0u;
+  if (PAIRS && tid == 0 && nF > SBT_FCAP) L.overflow = 1;  // (read behind the histogram's barrier)
   if (tid < (int)nT) L.tinfo[tid] = ti;
   if (GX_EXP_SBT == 1) {
     u32 x = 0;
@@ -358,7 +372,36 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   auto keyAt = [](const uint4& v, int j) -> u32 { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
   // (a slot is full -- 256 keys -- unless it is the last of its list: the full ones without per-key predicates;
   // the counts are wave-uniform)
-  if (GX_EXP_SBT != 1)
+  // (pair record: [31:12] start within the bin, [11:0] length; both ends lie in this bin)
+  auto pairTs = [](u32 r) -> u32 { return r >> (PAIR_LEN_BITS + TB); };
+  auto pairEnd = [](u32 r) -> u32 { return (r >> PAIR_LEN_BITS) + (r & ((1u << PAIR_LEN_BITS) - 1u)); };
+  auto histPair = [&](u32 r) {
+    const u32 ts = pairTs(r), te = pairEnd(r) >> TB;
+    atomicAdd(&L.hist[ts], ts == te ? 65537u : 1u);
+    if (ts != te) atomicAdd(&L.hist[te], 65536u);
+  };
+  if (PAIRS) {
+#pragma unroll
+    for (int i = 0; i < SBT_K; i++) {
+      if (cS[i] == SBT_SLOT) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) histPair(keyAt(kS[i], j));
+      } else if (cS[i]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if ((u32)lane * 4 + j < cS[i]) histPair(keyAt(kS[i], j));
+      }
+    }
+    if (nF <= SBT_FCAP)
+      for (u32 i = tid; i < nF; i += SBT_NT) {
+        const u64 r = srcF.at(i);
+        const int w = (int)(int8_t)(r & 0xFF);
+        if (w == GX_UNIT || w == -GX_UNIT)
+          atomicAdd(&L.hist[(u32)(r >> 32) - segTileBase], w > 0 ? 1u : 65536u);
+        else
+          L.overflow = 2;
+      }
+  } else if (GX_EXP_SBT != 1)
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
     if (cS[i] == SBT_SLOT) {
@@ -392,15 +435,18 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
     if (tid == 0) L.startC[nT] = (u32)tot;
   }
   __syncthreads();
-  const bool ovfReal = ovfSlots || L.startC[nT] > SBT_KEYCAP;
+  const u32 ovfWord = PAIRS ? L.overflow : 0u;  // (pair mode: 1 too many singles, 2 a fractional weight among them)
+  const bool ovfReal = ovfSlots || L.startC[nT] > SBT_KEYCAP || ovfWord != 0;
   const bool ovf = ovfReal || GX_EXP_SBT == 1 || GX_EXP_SBT == 2;
-  // (the slot capacity bounds a stream at 32 K keys, so a tile's 16-bit counts cannot have wrapped)
-  if (ovfReal && tid == 0) atomicOr(st, ST_SB_FULL);
-  if (seg == 0 && tid == 0 && in.sbOffF[nSeg] != 0) atomicOr(st, ST_SB_FRAC);
+  // (the slot capacity bounds a stream at 32 K keys -- pair mode: 32 K pairs and SBT_FCAP singles --, so a tile's 16-bit
+  // counts cannot have wrapped)
+  if (ovfReal && tid == 0) atomicOr(st, ovfWord == 2 ? ST_SB_FRAC : ST_SB_FULL);
+  if (!PAIRS && seg == 0 && tid == 0 && in.sbOffF[nSeg] != 0) atomicOr(st, ST_SB_FRAC);
   // descriptors for the kernels downstream, scatter cursors
   const u32 segS = in.sbOffS[seg], segE = in.sbOffE[seg];
-  const u32 segSlot = segS + segE + segTileBase;
-  const int segNet = (int)segS - (int)segE;
+  const u32 segSlot = PAIRS ? segS + segTileBase : segS + segE + segTileBase;
+  // weight (1/120) that the bins before hand on
+  const int segNet = PAIRS ? (int)segE : GX_UNIT * ((int)segS - (int)segE);
   if (tid < (int)nT) {
     const u32 t = segTileBase + tid;
     const u32 h = ovf ? 0u : L.hist[tid];
@@ -412,7 +458,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
       TileMeta m;
       m.sb = 0; m.eb = 0; m.fb = 0;
       m.nS = nS; m.nE = nE; m.nF = 0;
-      m.carry = ovf ? 0 : GX_UNIT * (segNet + L.netPref[tid]) - (int)ti.w;
+      m.carry = ovf ? 0 : segNet + GX_UNIT * L.netPref[tid] - (int)ti.w;
       m.ci = 0;
       m.pos0 = ti.x; m.len = ti.y; m.flags = ti.z;
       m.slot = segSlot + sc + (u32)tid;
@@ -433,6 +479,34 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   auto place = [&](u32 key, u32 curBase, u32 flag) {
     L.keys[atomicAdd(&L.cur[curBase + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | flag);
   };
+  if (PAIRS) {
+    // one cursor per tile (starts and ends of a tile share its list: a key says which it is); a pair whose ends share a
+    // tile takes its two places with one atomic
+    auto placePair = [&](u32 r) {
+      const u32 e = pairEnd(r), ts = pairTs(r), te = e >> TB;
+      const u32 so = (r >> PAIR_LEN_BITS) & (TILE - 1), eo = (e & (TILE - 1)) | 0x8000u;
+      const u32 ps = atomicAdd(&L.cur[ts], ts == te ? 2u : 1u);
+      const u32 pe = ts == te ? ps + 1u : atomicAdd(&L.cur[te], 1u);
+      L.keys[ps] = (uint16_t)so;
+      L.keys[pe] = (uint16_t)eo;
+    };
+#pragma unroll
+    for (int i = 0; i < SBT_K; i++) {
+      if (cS[i] == SBT_SLOT) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) placePair(keyAt(kS[i], j));
+      } else if (cS[i]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if ((u32)lane * 4 + j < cS[i]) placePair(keyAt(kS[i], j));
+      }
+    }
+    for (u32 i = tid; i < nF; i += SBT_NT) {
+      const u64 r = srcF.at(i);
+      const u32 off = (u32)(r >> 8) & (TILE - 1);
+      L.keys[atomicAdd(&L.cur[(u32)(r >> 32) - segTileBase], 1u)] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u));
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
     if (cS[i] == SBT_SLOT) {
@@ -474,7 +548,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
     const u32 h = L.hist[b], n = (h & 0xFFFFu) + (h >> 16);
     const uint4 tf = L.tinfo[b];
     const u32 sc = L.startC[b];
-    const int carry = GX_UNIT * (segNet + L.netPref[b]) - (int)tf.w;
+    const int carry = segNet + GX_UNIT * L.netPref[b] - (int)tf.w;
     sbt_tile(L.tile[wv], L.keys + sc, n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad);
   }
   if (bad && lane == 0) atomicOr(st, bad);
