@@ -179,7 +179,7 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device):
 
 
 KERNEL_PHASE = {  # which library phase (gx_set_phase_filter) brackets a kernel
-    "k_sort1": "sort1", "k_sbtile": "tile", "k_tile_fast": "tile", "k_tile": "tile", "k_bucket2p": "bucket",
+    "k_sort1": "sort1", "k_sort1p": "sort1", "k_sbtile": "tile", "k_tile_fast": "tile", "k_tile": "tile", "k_bucket2p": "bucket",
     "k_pack_pval": "pval", "k_pack_pairs": "pval", "k_pack_pairs_full": "pval", "k_merge2": "merge", "k_mergeN": "fisher",
     "k_pack_ep": "fisher", "k_bh_hist": "bh", "k_qlookup": "bh", "k_peak_both": "sweep",
 }
@@ -188,7 +188,7 @@ KERNEL_PHASE = {  # which library phase (gx_set_phase_filter) brackets a kernel
 def load_profile(config, frags, world, plain):
     """The rocprofv3 counters of THIS build for this config (tools/profile_round.sh + tools/make_counters_json.py):
     accepted only when the hash of the kernel sources matches and the workload is the profiled one."""
-    ppath = os.path.join(ROOT, "profiles", f"r03_counters_config{config}.json")
+    ppath = os.path.join(ROOT, "profiles", f"r04_counters_config{config}.json")
     if not os.path.exists(ppath):
         return None
     prof = json.load(open(ppath))
@@ -450,6 +450,26 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     barrier()
     dt = time.perf_counter() - t0
     path_flags = gx.path_info()
+    # The same step with the tight interval table MATERIALISED (GX_NO_LOOSE: lambda only after the tile stage, then
+    # k_pack_pval writes (end, p) and the sweep's masks, as every run with -q / a control / a further replicate / -f / -k
+    # does): what the default step of a single -p sample leaves out because the sweep reads (end, V) where the tile
+    # stage put them.  Only for the headline, one rank.
+    mat_ms = None
+    if headline and world == 1 and not cfg["qval"] and not cfg["control"] and cfg["reps"] == 1:
+        os.environ["GX_NO_LOOSE"] = "1"
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            mat_ms = (time.perf_counter() - t1) / steps * 1e3
+            mat_flags = gx.path_info()
+        finally:
+            del os.environ["GX_NO_LOOSE"]
+        step()
     gx.set_phase_timing(2)
     all_phases = {}
     for _ in range(2):
@@ -500,7 +520,9 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
         if dom_phase == "sort1":
             alg_k = 16.0 * ev_launch + 8.0 * ev_launch
         else:
-            alg_k = (4.0 if path_flags & 1 else 2.0) * 2.0 * ev_launch + 8.0 * (iv0 if launches == 1 else 2.0 * ev_launch) + 56.0 * n_tiles
+            # (pair mode: one 4-byte record per fragment; else two 4-byte keys (k_sbtile) or two 2-byte offsets (k_tile_fast))
+            key_bytes = 4.0 if path_flags & 16 else (8.0 if path_flags & 1 else 4.0)
+            alg_k = key_bytes * ev_launch + 8.0 * (iv0 if launches == 1 else 2.0 * ev_launch) + 56.0 * n_tiles
         used = traffic if traffic else alg_k
         achieved = used / (live_ms * 1e-3) / 1e9 if live_ms > 0 else 0.0
         # whole step: events in + final interval table (end, p[, pileup]) + sweep masks out; the loose-slot sweep of a
@@ -513,7 +535,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": live_ms / (klaunch if dom_phase not in ("sort1", "tile", "bucket") else 1.0),
             "algorithmic_bytes": alg_k,
             "traffic_over_algorithmic": (traffic / alg_k) if traffic else None,
-            "profile": f"profiles/r03_counters_config{config}.json" if prof else None,
+            "profile": f"profiles/r04_counters_config{config}.json" if prof else None,
             "whole_step": {
                 "ms": step_s * 1e3,
                 "algorithmic_bytes": alg_step,
@@ -527,7 +549,9 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             "note": "kernel = the longest kernel of this build's rocprofv3 profile of this config (profiles/); achieved = the HBM bytes "
                     "it moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of that profile; the sparse formulation's compulsory bytes when "
                     "no profile matches this build) / its mean duration measured here (HIP events on the library's stream, inside the "
-                    "timed region); frac <= 1 by construction",
+                    "timed region); frac <= 1 by construction.  `traffic` (here and in whole_step) is NOT measured in this run: it is "
+                    "the PMC figure of the committed profile of this very build (source hash checked), collected by "
+                    "tools/profile_round.sh in separate rocprofv3 --pmc passes",
         }
         qdesc = cfg["desc"]
         out = {
@@ -550,15 +574,27 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                                + ("" if backend == "nccl" or world == 1 else f" ({backend} validation mode, {ndev} GPU(s))"),
                 "collectives": coll_kind,
                 "rccl_nranks": rccl_nranks,
-                "device_path": {"fused_sort_tile_kernel": bool(path_flags & 1), "sweep_on_loose_slots": loose,
+                "device_path": {"fused_sort_tile_kernel": bool(path_flags & 1), "pair_records": bool(path_flags & 16), "sweep_on_loose_slots": loose,
                                 "fell_back_to_general_chain": bool(path_flags & 4)},
                 "peaks": n_peaks,
                 "intervals": int(iv0),
                 "events_per_step": int(ev_n),
-                "pileup_floats_kept": not args.lean,
+                # what the timed step wrote to HBM besides the loose (end, V) slots of the tile stage
+                "tables_written_in_step": {
+                    "tight_interval_table_end_p": not loose,
+                    "p_values_per_interval": not loose,
+                    "pileup_floats": False,   # made on request only (gx_get_intervals / -f / -k: ensure_piles)
+                    "note": ("single -p sample: the sweep walks the tile stage's (end, V) slots, p comes from the table p(V); "
+                             "the tight table is made when somebody asks (gx_get_intervals) -- see `materialised`") if loose else
+                            "the tight (end, p[, q]) table of the final p-array",
+                },
                 "source_hash": source_hash(),
             },
             "roofline": roof,
+            "materialised": ({"ms_per_step": mat_ms, "value": n_rep * G / (mat_ms * 1e-3) / 1e9, "unit": "Gbases/s",
+                              "sweep_on_loose_slots": bool(mat_flags & 2),
+                              "note": "the same step with the tight (end, p) interval table written (k_pack_pval) and the sweep on it"}
+                             if mat_ms else None),
             "phases_ms": phases,
             "phases_note": f"{dom_phase}: HIP events inside the timed region; the other phases: two extra untimed steps "
                            "(an event record costs the stream ~5 us, so the timed steps carry only the roofline kernel's pair)",

@@ -205,7 +205,7 @@ struct gx_ctx {
   DevBuf lbIv;
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3];
-  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, binNet, nWide, wideList, heavyList;
+  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, binNet, curC, ptC, poolC, auxC, nWide, wideList, heavyList;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};  // host copy of the device scalars (refreshed from the mail block)
@@ -525,6 +525,22 @@ int stash_or_pack(gx_ctx* ctx, Pileup& P) {
 }
 
 // events -> tile-bucketed endpoint records -> run-length pileup (loose slots + offsets) and fragLen
+int allreduce_words(gx_ctx* ctx, long long* d, int n);
+
+// the most level-1 chunks (workgroups of k_sort_a) any XCD class gets: class = blockIdx % NXCD of each piece's launch
+template <typename Segs> static u32 class_chunks(const Segs& segs) {
+  u32 best = 0;
+  for (u32 x = 0; x < (u32)NXCD; x++) {
+    u32 c = 0;
+    for (auto& sg : segs) {
+      const u32 b = (u32)((sg.n + S2_CHUNK - 1) / S2_CHUNK);
+      c += b / NXCD + (b % NXCD > x ? 1u : 0u);
+    }
+    best = std::max(best, c);
+  }
+  return best;
+}
+
 // reuseSort: the sample was built a moment ago and only its tile stage has to be done again on the general chain
 // (k_sbtile sent it back): level 1 of the sort -- the pages, the cursors, the closed form of fragLen -- is still
 // there, so k_sort1 does not run again and only what the first tile stage and the scans wrote is cleared.
@@ -597,7 +613,11 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     const size_t lbTBytes = up((size_t)3 * (tChunks + 2) * 8), lbIBytes = up((size_t)(2 * tChunks + 4) * 8);
     const size_t ctlBytes = up(sizeof(LooseCtl));
     const size_t netBytes = up((size_t)(MAX_BINS + 2) * 4);  // pair mode: the singles' weight per level-1 bin
-    const size_t total = ffBytes + 256 + ctlBytes + endBytes + netBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
+    // pair mode in two passes (k_sort_a / k_sort_b): the coarse lists' cursors and page tables
+    const u32 nCoarse = (std::max(1u, nL1) + (1u << S2_FINE_SHIFT) - 1) >> S2_FINE_SHIFT;
+    const u32 jmaxC = class_chunks(segs) + 3;   // (a class's workgroups cannot fill more pages than that in one list)
+    const size_t curCBytes = up((size_t)NXCD * nCoarse * 4 + 64), ptCBytes = up((size_t)NXCD * nCoarse * jmaxC * 4);
+    const size_t total = ffBytes + 256 + ctlBytes + endBytes + netBytes + curCBytes + ptCBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
     HIPCHECK(ctx->zeroArena.ensure(total));
     char* base = ctx->zeroArena.as<char>();
     ctx->fragSum.view(base, ffBytes);
@@ -610,6 +630,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     base += endBytes;
     ctx->binNet.view(base, netBytes);
     base += netBytes;
+    ctx->curC.view(base, curCBytes);
+    base += curCBytes;
+    ctx->ptC.view(base, ptCBytes);
+    base += ptCBytes;
     for (int q = 0; q < 3; q++) {
       ctx->str[q].cursor.view(base, curBytes);
       base += curBytes;
@@ -686,6 +710,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                          NXCD * nL1};
   }
   Sort1Out so1{ff->fragSum, slowFrag, ctx->endAtLen.as<u32>(), ctx->nWide.as<u32>() + 1};
+  static const bool onePass = getenv("GX_SORT_ONE_PASS") != nullptr;  // (measurements: k_sort1p instead of k_sort_a + k_sort_b)
+  PagedStream pcLast{};
+  u32 ncLast = 0, gridB = 0;
   for (auto& seg : segs) {
     if (!seg.n || reuseSort) continue;
     // (a piece that is still on its way from the host: the main stream waits for that copy only, so the
@@ -693,7 +720,22 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     if (seg.ready) HIPCHECK(hipStreamWaitEvent(s, seg.ready, 0));
     const u32 blocks = (u32)((seg.n + S1_CHUNK - 1) / S1_CHUNK);
     static_assert(S1P_CHUNK == S1_CHUNK, "one grid size for both level-1 kernels");
-    if (pairs) {
+    if (pairs && !onePass) {
+      // two passes: coarse bins, then the fine ones (gx_sort.h)
+      u32 nWG1 = 0;
+      for (auto& sg : segs) nWG1 += (u32)((sg.n + S2_CHUNK - 1) / S2_CHUNK);
+      const u32 nCoarse = (std::max(1u, nL1) + (1u << S2_FINE_SHIFT) - 1) >> S2_FINE_SHIFT;
+      const u32 perClass = class_chunks(segs), jmaxC = perClass + 3, nListsC = NXCD * nCoarse;
+      const u32 pagesC = nWG1 + 2 * nListsC + 8;
+      HIPCHECK(ctx->poolC.ensure((size_t)pagesC * PG_BYTES));
+      HIPCHECK(ctx->auxC.ensure((size_t)pagesC << PgCfg<u32>::SHIFT));
+      PagedStream PC{ctx->poolC.p, ctx->ptC.as<u32>(), ctx->curC.as<u32>(), ctx->curC.as<u32>() + nListsC, jmaxC, pagesC, nListsC};
+      hipLaunchKernelGGL(k_sort_a, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, ctx->sbShift,
+                         nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
+      pcLast = PC;
+      ncLast = nCoarse;
+      gridB = NXCD * (perClass + nCoarse);   // (a class's lists hold at most its chunks' + one partly filled page each)
+    } else if (pairs) {
       const size_t lds1 = s1p_lds_bytes(nL1, nChrom);
       if (ctx->s1pLdsSet < lds1) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort1p), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
@@ -708,6 +750,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       hipLaunchKernelGGL(k_sort1<false>, dim3(blocks), dim3(S1_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
                          ctx->sbShift, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
   }
+  if (gridB)  // the coarse lists (all pieces' events) -> the fine bins' lists
+    hipLaunchKernelGGL(k_sort_b, dim3(gridB), dim3(S2_NT), 0, s, pcLast, (const uint8_t*)ctx->auxC.as<uint8_t>(), ncLast, nL1, PG3[0],
+                       ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_sort1")) return rc__;
   phase_end(ctx);
   long long* earlyWords = nullptr;

@@ -810,6 +810,276 @@ __global__ __launch_bounds__(S1P_NT, 4) void k_sort1p(const gx_event* __restrict
   if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 8 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
 }
 
+// ---- pair mode in two passes: 64 coarse bins, then 64 fine bins each --------------------------------------------
+// Measured on k_sort1p (hg38, 50 M fragments; tools/build_variant.sh -DGX_EXP_S1P): loads + conversion 0.14 ms, with the
+// reservations 0.46 ms, everything 0.59 ms -- what costs is one atomic add per (workgroup, bin) on the bins' cursors,
+// 6,104 x 2,946 = 18 M of them onto 12 KB of cursors per XCD class, and what they buy are runs of 2.8 records (11 bytes).
+// Two passes with at most 64 bins each instead:
+//   k_sort_a  events -> pair records, grouped by COARSE bin (64 level-1 bins = 2^26 bases): 46 reservations per
+//             workgroup for hg38, runs of ~180 records.  A record leaves as the 4-byte pair record it will be (start within
+//             its fine bin, length) plus one byte, the fine bin's index within the coarse one -- two arrays over one
+//             index space (a coarse list's pages hold 8192 x (4 + 1) bytes).
+//   k_sort_b  one workgroup per page of a coarse list: the page's records to the 64 fine bins' lists (the ones
+//             k_sbtile<true> reads: unchanged), 64 reservations per workgroup, runs of ~128 records.
+// 0.7 M atomics instead of 18 M, every run a few full cache lines; the price is 0.25 GB written and read once more.
+// Both kernels are the same scatter over <= 64 keys (scatter64): LDS histogram with ranks, the first wavefront reserves
+// the runs and finds their pages (the page protocol of scatter_paged: allocations before waits), records staged by
+// key, written in staged order so that neighbouring lanes write neighbouring words.
+#ifndef GX_S2A_WAVES
+#define GX_S2A_WAVES 4   // waves per SIMD k_sort_a is compiled for (two workgroups per CU; at six it spills 24 dwords)
+#endif
+#ifndef GX_S2B_WAVES
+#define GX_S2B_WAVES 6   // ... and k_sort_b (three workgroups per CU)
+#endif
+constexpr int S2_NT = 512;
+#ifndef GX_S2_BATCH
+#define GX_S2_BATCH 4
+#endif
+constexpr int S2_BATCH = GX_S2_BATCH;   // event loads in flight per thread (k_sort_a)
+constexpr int S2_LCHROM = 96;     // chromosome records k_sort_a keeps in LDS (larger tables stay in global memory)
+constexpr int S2_ITEMS = 16;
+constexpr int S2_CHUNK = S2_NT * S2_ITEMS;
+constexpr int S2_KEYS = 64;
+constexpr int S2_FINE_SHIFT = 6;   // fine bins per coarse bin (log2)
+static_assert(S2_CHUNK == (1 << PgCfg<u32>::SHIFT), "k_sort_b: one workgroup per page of a coarse list");
+static_assert(S2_CHUNK == S1_CHUNK, "one grid size for the level-1 kernels");
+
+struct S2Lds {
+  u32 cnt[S2_KEYS];       // records of this chunk per key
+  u32 start[S2_KEYS];     // where a key's run starts in the staged chunk
+  u32 split[S2_KEYS];     // records of the run that fit its first page
+  u32 base0[S2_KEYS];     // pool index of the run's first record
+  u32 base1[S2_KEYS];     // pool index of the first record in the run's second page
+  u32 total;
+  u32 scratch[24];
+  u32 stage[S2_CHUNK];
+  uint8_t aux[S2_CHUNK];  // (k_sort_a: the fine bin within the coarse one)
+  uint8_t key[S2_CHUNK];  // the key of a staged record
+};
+
+// The coarse lists' pages hold the 4-byte records at page * 8192 * 4 of `pool` and the bytes at page * 8192 of `aux`.
+// AUX: whether the byte array is written (k_sort_a).  `listBase + key` = the list a key's run goes to.
+template <bool AUX>
+__device__ __forceinline__ void scatter64(const u32 (&rec)[S2_ITEMS], u32 (&ka)[S2_ITEMS], const PagedStream& P,
+                                          uint8_t* __restrict__ auxPool, u32 listBase, u32 nKeys, S2Lds& L, u32* __restrict__ st) {
+  // ka[k]: [5:0] key, [15:8] the byte that travels along, [31:16] the record's rank among its key's (filled here);
+  // NULL32 in rec = no record
+  constexpr int SHIFT = PgCfg<u32>::SHIFT;
+  constexpr u32 PG = 1u << SHIFT;
+#pragma unroll
+  for (int k = 0; k < S2_ITEMS; k++) ka[k] = (ka[k] & 0xFFFFu) | ((rec[k] != NULL32 ? atomicAdd(&L.cnt[ka[k] & 63u], 1u) : 0u) << 16);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const u32 key = threadIdx.x;
+    const u32 c = key < nKeys ? L.cnt[key] : 0u;
+    const u32 li = listBase + key;
+    u32 o = 0;
+    if (c) o = atomicAdd(&P.cursor[li], c);
+    const u32 inc = (u32)dpp_scan_add((int)c);
+    L.start[key] = inc - c;
+    if (key == 63) L.total = inc;
+    const u32 in0 = o & (PG - 1), j0 = o >> SHIFT, j1 = (o + c - 1) >> SHIFT;
+    L.split[key] = min(c, PG - in0);
+    u32* row = P.pt + (size_t)li * P.jmax;
+    u32 p0 = 0, p1 = 0;
+    bool wait0 = false;
+    if (c) {
+      if (j1 != j0) p1 = page_alloc(P, row, j1, st);  // (the run holds that page's first slot)
+      if (j0 == 0)
+        p0 = first_page(li);
+      else if (in0 == 0)
+        p0 = page_alloc(P, row, j0, st);
+      else
+        wait0 = true;
+    }
+    __builtin_amdgcn_wave_barrier();  // (every allocation of the wavefront is published before any of its lanes waits)
+    if (wait0) p0 = page_wait(P, row, j0, st);
+    L.base0[key] = (p0 << SHIFT) + in0;
+    L.base1[key] = p1 << SHIFT;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < S2_ITEMS; k++)
+    if (rec[k] != NULL32) {
+      const u32 key = ka[k] & 63u, pos = L.start[key] + (ka[k] >> 16);
+      L.stage[pos] = rec[k];
+      L.key[pos] = (uint8_t)key;
+      if (AUX) L.aux[pos] = (uint8_t)((ka[k] >> 8) & 0xFFu);
+    }
+  __syncthreads();
+  u32* pool = reinterpret_cast<u32*>(P.pool);
+  const u32 cnt = L.total;
+#pragma unroll
+  for (int h = 0; h < S2_ITEMS; h += 8) {
+    u32 v[8], kk[8], ax[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {  // (a fixed trip count: the LDS reads of eight records in flight together)
+      const u32 i = (u32)(h + k) * S2_NT + threadIdx.x, ii = i < cnt ? i : 0u;
+      v[k] = L.stage[ii];
+      kk[k] = L.key[ii];
+      ax[k] = AUX ? L.aux[ii] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u32 i = (u32)(h + k) * S2_NT + threadIdx.x;
+      const u32 r = i - L.start[kk[k]], sp = L.split[kk[k]];
+      const u32 dst = r < sp ? L.base0[kk[k]] + r : L.base1[kk[k]] + (r - sp);
+      if (i < cnt) {
+        pool[dst] = v[k];
+        if (AUX) auxPool[dst] = (uint8_t)ax[k];
+      }
+    }
+  }
+}
+
+// events -> pair records in the coarse bins' lists (+ the slow events' records straight to the fine F lists, as
+// k_sort1p does).  PC: the coarse lists, [NXCD][nCoarse]; its page-table rows hold every page a class can fill.
+__global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* __restrict__ ev, u32 n, const DChrom* __restrict__ chroms,
+                                                     u32 nChrom, int sbShift, u32 nBins, u32 nCoarse, PagedStream PC,
+                                                     uint8_t* __restrict__ auxPool, PagedStream PF, int* __restrict__ binNet,
+                                                     Sort1Out out, u32* __restrict__ st) {
+  __shared__ S2Lds L;
+  __shared__ DChrom lchrom[S2_LCHROM];
+  const bool chromLds = nChrom <= (u32)S2_LCHROM;
+  const u32 x = blockIdx.x % NXCD;
+  const u32 begin = blockIdx.x * S2_CHUNK;
+  const u32 binMask = (1u << sbShift) - 1u;
+  u32 bad = 0, slow = 0;
+  u32 covered32 = 0;  // (sixteen lengths below 2^12)
+  u32 rec[S2_ITEMS], ka[S2_ITEMS];
+  if (threadIdx.x < S2_KEYS) L.cnt[threadIdx.x] = 0;
+  const uint4* __restrict__ evb = reinterpret_cast<const uint4*>(ev) + begin;
+  const u32 lastIn = n - 1u - begin;  // (the grid covers the input: begin < n)
+  // (the conversion: see k_sort1p)
+#pragma unroll
+  for (int k0 = 0; k0 < S2_ITEMS; k0 += S2_BATCH) {
+    uint4 e[S2_BATCH];
+    bool have[S2_BATCH];
+#pragma unroll
+    for (int q = 0; q < S2_BATCH; q++) {
+      // (a uniform base and a 32-bit offset within the chunk: no 64-bit address per load)
+      const u32 li = (k0 + q) * S2_NT + threadIdx.x;
+      have[q] = li <= lastIn;
+      e[q] = evb[min(li, lastIn)];  // chrom, start, end, count
+    }
+    if (k0 == 0) {
+      if (chromLds)
+        for (u32 i = threadIdx.x; i < nChrom; i += S2_NT) lchrom[i] = chroms[i];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < S2_BATCH; q++) {
+      const u32 ci = min(e[q].x, nChrom - 1);
+      const DChrom c = chromLds ? lchrom[ci] : chroms[ci];
+      const bool ok1 = have[q] && e[q].w == 1u && e[q].x < nChrom;
+      const bool act = chrom_active(c);
+      const u32 len = e[q].z - e[q].y;
+      const u32 t0 = c.tileBase + (e[q].y >> TB), t1 = c.tileBase + (e[q].z >> TB);
+      const u32 bin = t0 >> sbShift;
+      const bool fast = ok1 && act && e[q].z < c.len && len - 1u < (1u << PAIR_LEN_BITS) - 1u && e[q].y < e[q].z && (t1 >> sbShift) == bin;
+      const bool nothing = !have[q] || (ok1 && !act);
+      rec[k0 + q] = fast ? ((((t0 & binMask) << TB) | (e[q].y & (TILE - 1))) << PAIR_LEN_BITS) | len : NULL32;
+      ka[k0 + q] = (bin >> S2_FINE_SHIFT) | ((bin & ((1u << S2_FINE_SHIFT) - 1u)) << 8);
+      covered32 += fast ? len : 0u;
+      slow |= (u32)(!fast && !nothing) << (k0 + q);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the next batch's loads stay behind this one's conversion: registers)
+  }
+  u64 covered = covered32;
+  scatter64<true>(rec, ka, PC, auxPool, x * nCoarse, nCoarse, L, st);
+  // the slow events: loaded again (they are in L2), converted as k_sort1 converts every event, their records appended
+  // one by one
+  if (__ballot(slow != 0)) {
+#pragma unroll 1
+    for (int k = 0; k < S2_ITEMS; k++) {
+      bool mine = (slow >> k) & 1u;
+      if (!__ballot(mine)) continue;
+      u64 r0 = 0, r1 = 0;
+      u32 l0 = 0, l1 = 0;
+      bool h1 = false;
+      if (mine) {
+        const uint4 e = reinterpret_cast<const uint4*>(ev)[begin + k * S2_NT + threadIdx.x];
+        const Endpoints p = convert_event<true>(e, chroms[min(e.x, nChrom - 1)], true, nChrom, out, bad, covered);
+        mine = p.w != 0;  // (else: an event that only raised a status bit, or one without effect)
+        if (mine) {
+          if (p.w != GX_UNIT) atomicOr(out.slowFrag, 1u);  // (a fractional weight: k_sbtile will turn the sample away)
+          r0 = make_rec64(p.t0, p.o0, p.w);
+          l0 = x * nBins + (p.t0 >> sbShift);
+          atomicAdd(&binNet[p.t0 >> sbShift], p.w);
+          h1 = p.t1 != NULL_TILE;
+        }
+        if (h1) {
+          r1 = make_rec64(p.t1, p.o1, -p.w);
+          l1 = x * nBins + (p.t1 >> sbShift);
+          atomicAdd(&binNet[p.t1 >> sbShift], -p.w);
+        }
+      }
+      append_single(PF, l0, r0, mine, st);
+      append_single(PF, l1, r1, h1, st);
+    }
+  }
+  if (bad) atomicOr(st, bad);
+  covered = wave_sum(covered);
+  if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 8 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
+}
+
+// one workgroup per page of a coarse list -> the fine bins' lists (PP: what k_sbtile<true> reads).  The grid is an
+// upper bound (NXCD x the most pages a class can hold); a workgroup finds its page from its class's cursors: list
+// l = x * nCoarse + cb has ceil(cursor / 8192) pages.
+__global__ __launch_bounds__(S2_NT, GX_S2B_WAVES) void k_sort_b(PagedStream PC, const uint8_t* __restrict__ auxPool, u32 nCoarse, u32 nBins,
+                                                     PagedStream PP, u32* __restrict__ st) {
+  constexpr int SHIFT = PgCfg<u32>::SHIFT;
+  __shared__ S2Lds L;
+  __shared__ u32 sList, sPage, sCount;
+  // workgroup b takes page b / NXCD of XCD class b % NXCD (the class of the workgroups that filled the list: the fine
+  // lists' cache lines are completed inside one L2, as in the single-pass kernels)
+  if (threadIdx.x < 64) {
+    const u32 xc = blockIdx.x % NXCD, q = blockIdx.x / NXCD;
+    const u32 len = threadIdx.x < nCoarse ? PC.cursor[xc * nCoarse + threadIdx.x] : 0u;
+    const u32 np = (len + S2_CHUNK - 1) >> SHIFT;
+    const u32 inc = (u32)dpp_scan_add((int)np), ex = inc - np;
+    if (threadIdx.x == 0) sCount = 0;
+    L.cnt[threadIdx.x] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (q >= ex && q < inc) {
+      const u32 j = q - ex;
+      sList = xc * nCoarse + threadIdx.x;
+      sPage = j;
+      sCount = min((u32)S2_CHUNK, len - (j << SHIFT));
+    }
+  }
+  __syncthreads();
+  const u32 count = sCount;
+  if (count == 0) return;  // (beyond the last page)
+  const u32 li = sList, j = sPage;
+  const u32 x = li / nCoarse, cb = li - x * nCoarse;
+  const u32 page = j ? __hip_atomic_load(&PC.pt[(size_t)li * PC.jmax + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u : first_page(li);
+  const u32* src = reinterpret_cast<const u32*>(PC.pool) + ((size_t)page << SHIFT);
+  const uint8_t* srcA = auxPool + ((size_t)page << SHIFT);
+  // (thread t: records 16 t .. 16 t + 15 of the page -- four 16-byte loads of records, one of their bytes)
+  u32 rec[S2_ITEMS], ka[S2_ITEMS];
+  {
+    static_assert(S2_ITEMS == 16, "one 16-byte load of bytes per thread");
+    uint4 r4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) r4[q] = reinterpret_cast<const uint4*>(src)[threadIdx.x * 4 + q];
+    const uint4 a4 = reinterpret_cast<const uint4*>(srcA)[threadIdx.x];
+    const u32 aw[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const u32 rw[4] = {r4[q].x, r4[q].y, r4[q].z, r4[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const u32 i = threadIdx.x * S2_ITEMS + q * 4 + j;
+        rec[q * 4 + j] = i < count ? rw[j] : NULL32;
+        ka[q * 4 + j] = (aw[q] >> (8 * j)) & 0xFFu;
+      }
+    }
+  }
+  // (a pair record is never NULL32: its length is below 2^12 - 1 ... and a page holds only records)
+  scatter64<false>(rec, ka, PP, nullptr, x * nBins + (cb << S2_FINE_SHIFT), min((u32)S2_KEYS, nBins - (cb << S2_FINE_SHIFT)), L, st);
+}
+
 // bin totals (over the XCD classes) -> where each super-bucket's records start after level 2; one workgroup per stream.
 // A fourth workgroup prepares what the tile stage needs besides:
 //   chromW0[c]  weight of the ends that the chromosomes before c dropped at their own end (no record: endAtLen) --
