@@ -509,12 +509,21 @@ __device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporte
 // wave-wide sum of disjoint bits and ORed into the mask by ONE lane.  (One atomic per significant interval was the
 // first version: peaks are dense in breakpoints, a third of all intervals of config 2 are significant, and 64 lanes
 // hammering one 8-byte word serialise in the L2.)  Call with all lanes active.
-__device__ __forceinline__ void sig_flush(u64* __restrict__ sigMask, u32 pos, bool sg, u32 rank) {
-  if (!__ballot(sg)) return;  // wave-uniform
-  const int lo = sg && rank < 32u ? (int)(1u << rank) : 0, hi = sg && rank >= 32u ? (int)(1u << (rank - 32u)) : 0;
-  const u32 mlo = (u32)__builtin_amdgcn_readlane(dpp_scan_add(lo), 63), mhi = (u32)__builtin_amdgcn_readlane(dpp_scan_add(hi), 63);
+// `written`: the lanes that wrote an interval (rank = a lane's number among them).  When they are the lanes 0 .. k-1 --
+// nearly always: a touched base whose starts and ends cancel is rare -- a lane's rank is its number and the word is
+// the ballot itself (two scalar instructions instead of two DPP scans).
+__device__ __forceinline__ void sig_flush(u64* __restrict__ sigMask, u32 pos, bool sg, u32 rank, u64 written) {
+  const u64 sgm = __ballot(sg);
+  if (!sgm) return;  // wave-uniform
+  u64 m;
+  if (((written + 1ull) & written) == 0ull) {  // wave-uniform
+    m = sgm;
+  } else {
+    const int lo = sg && rank < 32u ? (int)(1u << rank) : 0, hi = sg && rank >= 32u ? (int)(1u << (rank - 32u)) : 0;
+    const u32 mlo = (u32)__builtin_amdgcn_readlane(dpp_scan_add(lo), 63), mhi = (u32)__builtin_amdgcn_readlane(dpp_scan_add(hi), 63);
+    m = (u64)mlo | ((u64)mhi << 32);
+  }
   if (lane_id() == 0) {
-    const u64 m = (u64)mlo | ((u64)mhi << 32);
     const u32 w = pos >> 6, sh = pos & 63;
     atomicOr((unsigned long long*)&sigMask[w], (unsigned long long)(m << sh));
     if (sh && (m >> (64 - sh))) atomicOr((unsigned long long*)&sigMask[w + 1], (unsigned long long)(m >> (64 - sh)));

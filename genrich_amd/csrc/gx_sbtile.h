@@ -213,7 +213,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
         st_u32(out.to.looseEnd, o, pos0 + p);
         st_u32(out.to.looseV, o, (u32)before);
       }
-      if (vsig != 0x7FFFFFFF) sig_flush(out.to.sigMask, slot + outCount, nz && before >= vsig, orank);  // wave-uniform
+      if (vsig != 0x7FFFFFFF) sig_flush(out.to.sigMask, slot + outCount, nz && before >= vsig, orank, mask);  // wave-uniform
       negM |= __ballot(after < 0);
       bigM |= __ballot(after >= FRAG_FAST_MAXV);
       runBase += __builtin_amdgcn_readlane(incS, 63);

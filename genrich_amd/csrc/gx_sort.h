@@ -846,15 +846,13 @@ static_assert(S2_CHUNK == S1_CHUNK, "one grid size for the level-1 kernels");
 
 struct S2Lds {
   u32 cnt[S2_KEYS];       // records of this chunk per key
-  u32 start[S2_KEYS];     // where a key's run starts in the staged chunk
-  u32 split[S2_KEYS];     // records of the run that fit its first page
-  u32 base0[S2_KEYS];     // pool index of the run's first record
-  u32 base1[S2_KEYS];     // pool index of the first record in the run's second page
+  // per key: x where its run starts in the staged chunk, y records of the run that fit its first page, z pool index of
+  // the run's first record, w pool index of the first record in the run's second page (one 16-byte read per record)
+  __attribute__((aligned(16))) uint4 run[S2_KEYS];
   u32 total;
   u32 scratch[24];
   u32 stage[S2_CHUNK];
-  uint8_t aux[S2_CHUNK];  // (k_sort_a: the fine bin within the coarse one)
-  uint8_t key[S2_CHUNK];  // the key of a staged record
+  uint16_t ka[S2_CHUNK];  // of a staged record: [5:0] its key, [15:8] the byte that travels along (k_sort_a: the fine bin)
 };
 
 // The coarse lists' pages hold the 4-byte records at page * 8192 * 4 of `pool` and the bytes at page * 8192 of `aux`.
@@ -876,10 +874,8 @@ __device__ __forceinline__ void scatter64(const u32 (&rec)[S2_ITEMS], u32 (&ka)[
     u32 o = 0;
     if (c) o = atomicAdd(&P.cursor[li], c);
     const u32 inc = (u32)dpp_scan_add((int)c);
-    L.start[key] = inc - c;
     if (key == 63) L.total = inc;
     const u32 in0 = o & (PG - 1), j0 = o >> SHIFT, j1 = (o + c - 1) >> SHIFT;
-    L.split[key] = min(c, PG - in0);
     u32* row = P.pt + (size_t)li * P.jmax;
     u32 p0 = 0, p1 = 0;
     bool wait0 = false;
@@ -894,39 +890,37 @@ __device__ __forceinline__ void scatter64(const u32 (&rec)[S2_ITEMS], u32 (&ka)[
     }
     __builtin_amdgcn_wave_barrier();  // (every allocation of the wavefront is published before any of its lanes waits)
     if (wait0) p0 = page_wait(P, row, j0, st);
-    L.base0[key] = (p0 << SHIFT) + in0;
-    L.base1[key] = p1 << SHIFT;
+    L.run[key] = make_uint4(inc - c, min(c, PG - in0), (p0 << SHIFT) + in0, p1 << SHIFT);
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < S2_ITEMS; k++)
     if (rec[k] != NULL32) {
-      const u32 key = ka[k] & 63u, pos = L.start[key] + (ka[k] >> 16);
+      const u32 pos = L.run[ka[k] & 63u].x + (ka[k] >> 16);
       L.stage[pos] = rec[k];
-      L.key[pos] = (uint8_t)key;
-      if (AUX) L.aux[pos] = (uint8_t)((ka[k] >> 8) & 0xFFu);
+      L.ka[pos] = (uint16_t)ka[k];
     }
   __syncthreads();
   u32* pool = reinterpret_cast<u32*>(P.pool);
   const u32 cnt = L.total;
 #pragma unroll
   for (int h = 0; h < S2_ITEMS; h += 8) {
-    u32 v[8], kk[8], ax[8];
+    u32 v[8], kk[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {  // (a fixed trip count: the LDS reads of eight records in flight together)
       const u32 i = (u32)(h + k) * S2_NT + threadIdx.x, ii = i < cnt ? i : 0u;
       v[k] = L.stage[ii];
-      kk[k] = L.key[ii];
-      ax[k] = AUX ? L.aux[ii] : 0u;
+      kk[k] = L.ka[ii];
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const u32 i = (u32)(h + k) * S2_NT + threadIdx.x;
-      const u32 r = i - L.start[kk[k]], sp = L.split[kk[k]];
-      const u32 dst = r < sp ? L.base0[kk[k]] + r : L.base1[kk[k]] + (r - sp);
+      const uint4 rn = L.run[kk[k] & 63u];
+      const u32 r = i - rn.x;
+      const u32 dst = r < rn.y ? rn.z + r : rn.w + (r - rn.y);
       if (i < cnt) {
         pool[dst] = v[k];
-        if (AUX) auxPool[dst] = (uint8_t)ax[k];
+        if (AUX) auxPool[dst] = (uint8_t)(kk[k] >> 8);
       }
     }
   }

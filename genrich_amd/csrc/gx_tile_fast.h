@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64) void k_tile_fast(TileIn in, u32 nTiles, const u
           out.looseEnd[o] = pos0 + p;
           out.looseV[o] = before;
         }
-        if (vsig != 0x7FFFFFFF) sig_flush(out.sigMask, slot + outCount, nz && before >= vsig, orank);  // wave-uniform
+        if (vsig != 0x7FFFFFFF) sig_flush(out.sigMask, slot + outCount, nz && before >= vsig, orank, mask);  // wave-uniform
         negM |= __ballot(after < 0);
         bigM |= __ballot(after >= FRAG_FAST_MAXV);
         runBase += __builtin_amdgcn_readlane(incS, 63);

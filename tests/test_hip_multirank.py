@@ -32,6 +32,12 @@ def _scenario(name):
         reps = [(synth.make_fragments(LENS, 40_000, sd, peak_every=20_000, tower_every=70_000, frac_tower=0.1), None)
                 for sd in (11, 13, 15)]
         return B.make_params(pq=0.3, qval=True, min_auc=20.0), reps
+    if name == "plain_p":  # one sample, -p, unit weights: every rank must keep the single-rank fast path
+        tr = synth.make_fragments(LENS, 80_000, 21, peak_every=20_000, tower_every=70_000, frac_tower=0.1)
+        return B.make_params(pq=0.01, min_auc=20.0), [(tr, None)]
+    if name == "noctrl_q":  # one sample without a control, -q: the dense BH exchange
+        tr = synth.make_fragments(LENS, 80_000, 23, peak_every=20_000, tower_every=70_000, frac_tower=0.1)
+        return B.make_params(pq=0.3, qval=True, min_auc=20.0), [(tr, None)]
     raise KeyError(name)
 
 
@@ -71,11 +77,11 @@ def _worker(rank, world, port, q, name):
     coll = Collectives(device="cpu")
     gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
     scal, peaks = _run(gx, reps, owned)
-    q.put((rank, scal, peaks.tobytes()))
+    q.put((rank, scal, peaks.tobytes(), gx.path_info()))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["ctrl_q", "atac_multimap", "reps3_q"])
+@pytest.mark.parametrize("name", ["ctrl_q", "atac_multimap", "reps3_q", "plain_p", "noctrl_q"])
 def test_two_ranks_equal_one_rank(name):
     import torch.multiprocessing as mp
 
@@ -108,7 +114,11 @@ def test_two_ranks_equal_one_rank(name):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for _, scal, _ in res:
+    for _, scal, _, flags in res:
+        if name == "plain_p":
+            # lambda reached every rank ahead of the tile stage (the early all-reduce of the closed form of fragLen): the
+            # fused kernel wrote the sweep's bits, and the sweep walked the loose slots, as on one rank
+            assert flags & 1 and flags & 2, flags
         for (f, lam, fac), (f1, lam1, fac1) in zip(scal, scal1):
             assert f == f1, "fragLen must be the exact fixed-point sum whatever the number of ranks"
             assert np.float32(lam).tobytes() == np.float32(lam1).tobytes()
@@ -117,7 +127,7 @@ def test_two_ranks_equal_one_rank(name):
     assert merged.tobytes() == peaks1.tobytes(), "sharded peaks (coordinates, AUC, p, q) differ from the single-rank run"
 
 
-@pytest.mark.parametrize("name", ["ctrl_q", "reps3_q"])
+@pytest.mark.parametrize("name", ["ctrl_q", "reps3_q", "plain_p", "noctrl_q"])
 def test_rccl_path_with_one_rank(name, monkeypatch):
     """gx_set_rccl + GX_FORCE_COLL=1: the all-reduce of the fragLen words and the all-gather of the BH
     records run through RCCL on the library's stream (a communicator of one rank) and must change nothing."""
@@ -136,3 +146,6 @@ def test_rccl_path_with_one_rank(name, monkeypatch):
     scal2, peaks2 = _run(g2, reps)
     assert scal2 == scal1
     assert peaks2.tobytes() == peaks1.tobytes()
+    if name == "plain_p":
+        assert g2.path_info() & 2, "the loose-slot sweep must survive the collectives"
+
