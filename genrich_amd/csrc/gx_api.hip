@@ -69,7 +69,7 @@ struct HostMail {
   Scalars scal;
   long long acc[2];
   uint64_t peakBP, genome;
-  u32 nF, nIv, status, R, nPeaks, nMerged, D, n, hot;
+  u32 nF, nIv, status, R, nPeaks, nMerged, D, n, hot, bhOvf;
   long long coll[4];   // this rank's / all ranks' {fragLen parts, saturation flag}
   u32 counts[64];      // BH records per rank (all-gather)
   u32 closeState;      // k_close: 1 the sample is closed, 2 the separate kernels have to run
@@ -237,7 +237,8 @@ struct gx_ctx {
   void* user = nullptr;
   ncclComm_t comm = nullptr;    // the library's own collectives (gx_set_rccl): RCCL on device buffers, on `stream`
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
-  DevBuf dColl, dCounts, dGather;
+  DevBuf dColl, dCounts, dGather, bhDense;
+  bool denseBhUsed = false;     // the last gx_find_peaks exchanged the p-value histogram as one dense all-reduce
   int phaseLevel = 0;       // gx_set_phase_timing
   std::string phaseFilter = "tile";  // level 1: the one phase that is timed (gx_set_phase_filter)
   u32 mailSeq = 0;          // mail_sync: the sequence number the next k_mail writes
@@ -284,7 +285,7 @@ void recycle(gx_ctx* ctx, DevBuf& b) {
 }
 
 // misc device words (u32 indices into ctx->misc)
-enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_GENOME = 10 /* u64 */, M_NMERGED = 15,
+enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_BHOVF = 7, M_GENOME = 10 /* u64 */, M_NMERGED = 15,
        // the sweep's counters are contiguous: one memset clears them
        M_TICKET2 = 16, M_SWCOUNT = 17, M_NPEAKS = 18, M_TICKET3 = 19, M_TICKET4 = 20, M_NHEADS = 21, M_PEAKBP = 22 /* u64 */,
        M_SWEEP_FIRST = 16, M_SWEEP_WORDS = 8, M_WORDS = 32 };
@@ -525,7 +526,7 @@ int stash_or_pack(gx_ctx* ctx, Pileup& P) {
 }
 
 // events -> tile-bucketed endpoint records -> run-length pileup (loose slots + offsets) and fragLen
-int allreduce_words(gx_ctx* ctx, long long* d, int n);
+int allreduce_words(gx_ctx* ctx, long long* d, size_t n);
 
 // the most level-1 chunks (workgroups of k_sort_a) any XCD class gets: class = blockIdx % NXCD of each piece's launch
 template <typename Segs> static u32 class_chunks(const Segs& segs) {
@@ -985,28 +986,29 @@ constexpr u32 PT_JMAX_CAP = 1u << 16;
 
 // n (<= 4) 64-bit words on the device, summed over all ranks in place: RCCL in stream order (no host hop), or the host
 // program's callback (a copy down, a synchronisation, a copy up)
-int allreduce_words(gx_ctx* ctx, long long* d, int n) {
+int allreduce_words(gx_ctx* ctx, long long* d, size_t n) {
   hipStream_t s = ctx->stream;
   if (ctx->comm) {
     const gxrccl::Api* api = gxrccl::load(&ctx->err);
     if (!api) return GX_ERR_DEVICE;
-    ncclResult_t r = api->allReduce(d, d, (size_t)n, ncclInt64, ncclSum, ctx->comm, s);
+    ncclResult_t r = api->allReduce(d, d, n, ncclInt64, ncclSum, ctx->comm, s);
     if (r != ncclSuccess) {
       ctx->err = std::string("ncclAllReduce: ") + api->getErrorString(r);
       return GX_ERR_DEVICE;
     }
   } else if (ctx->allreduce) {
     long long* acc = ctx->mail->coll;
-    HIPCHECK(hipMemcpyAsync(acc, d, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (n > 4) {  // (the dense p-value histogram)
+      HIPCHECK(ctx->hostRecs.ensure(n * 8));
+      acc = static_cast<long long*>(ctx->hostRecs.p);
+    }
+    HIPCHECK(hipMemcpyAsync(acc, d, n * 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    int64_t buf[4] = {0, 0, 0, 0};
-    for (int i = 0; i < n; i++) buf[i] = acc[i];
-    if (ctx->allreduce(buf, n, ctx->user)) {
+    if (ctx->allreduce(reinterpret_cast<int64_t*>(acc), n, ctx->user)) {
       ctx->err = "allreduce callback failed";
       return GX_ERR_DEVICE;
     }
-    for (int i = 0; i < n; i++) acc[i] = buf[i];
-    HIPCHECK(hipMemcpyAsync(d, acc, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d, acc, n * 8, hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));  // (the pinned words are reused by the next exchange)
   } else {
     ctx->err = "several ranks but no collectives (gx_set_rccl / gx_set_collectives)";
@@ -2187,7 +2189,47 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     }
     const bool multi = ctx->world > 1 || ctx->forceColl;
     u32 D = 0;
-    if (multi && ctx->comm) {
+    bool denseDone = false;
+    ctx->denseBhUsed = false;
+    // One sample without a control: p is a function of the pileup, every rank holds the same table p(V), and the
+    // genome-wide histogram is ONE all-reduce of a dense "bp at V" array (gx_stats.h: k_bh_dense_fill) -- decided by what
+    // every rank knows alike
+    if (multi && ctx->sample == 1 && ctx->reps.size() == 1 && fa.ctrlIsConst && !ctx->bedGiven && (u32)std::max(1, ctx->world) <= 64 &&
+        getenv("GX_NO_DENSE_BH") == nullptr) {
+      const u32 W = (u32)std::max(1, ctx->world);
+      const size_t words = bhd_words(W);
+      HIPCHECK(ctx->bhDense.ensure(words * 8));
+      HIPCHECK(hipMemsetAsync(ctx->bhDense.p, 0, words * 8, s));
+      HIPCHECK(hipMemsetAsync(misc + M_BHOVF, 0, 4, s));  // (the "a rank's region overflowed" word)
+      hipLaunchKernelGGL(k_bh_dense_fill, dim3(std::max(1u, std::min((Dlocal + 255) / 256, 1024u))), dim3(256), 0, s,
+                         ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), ctx->bhLens.as<u64>(), misc + M_BHCOUNT,
+                         ctx->pvLut.as<float>(), ctx->bhDense.as<u64>(), (u32)ctx->rank);
+      if (int rc__ = allreduce_words(ctx, ctx->bhDense.as<long long>(), words)) return rc__;
+      hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+      HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
+      hipLaunchKernelGGL(k_bh_from_dense, dim3(256), dim3(256), 0, s, (const u64*)ctx->bhDense.as<u64>(), ctx->pvLut.as<float>(), W, T,
+                         misc + M_BHOVF, ctx->dStatus.as<u32>());
+      HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipMemcpyAsync(&ctx->mail->bhOvf, misc + M_BHOVF, 4, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      if (ctx->mail->bhOvf == 0) {
+        D = ctx->mail->D;
+        denseDone = true;
+        ctx->denseBhUsed = true;
+      } else {
+        // some rank holds more values outside the table than its region takes: every rank saw it, all go back to their own
+        // tables and take the general exchange
+        hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+        HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
+        hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
+                           fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
+                           ctx->dStatus.as<u32>());
+        if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;
+        Dlocal = ctx->mail->nMerged;
+      }
+    }
+    if (denseDone) {
+    } else if (multi && ctx->comm) {
       // every rank contributes its {p bits, bp} pairs; all ranks rebuild the same genome-wide table
       // (hashPval 300-327 runs over all chromosomes).  RCCL on device buffers: the counts first (the
       // host needs their maximum to size the exchange), then the records, padded to that maximum.
@@ -2510,7 +2552,7 @@ int gx_rccl_nranks(gx_ctx* ctx, int* n) {
 
 int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   if (!ctx || !flags) return GX_ERR_ORDER;
-  *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
+  *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u);
   return GX_OK;
 }

@@ -432,6 +432,69 @@ __global__ __launch_bounds__(256) void k_bh_insert_gathered(const BhRec* __restr
   }
 }
 
+// ---- the genome-wide p-value histogram of several ranks, dense (no control: p is a function of the pileup V) ---------
+// hashPval (300-327) over ALL chromosomes.  Every rank has the same table p(V) (same lambda), so "bp at p" travels as
+// "bp at V": one u64 per table entry, summed over the ranks by ONE all-reduce -- no counts to exchange first, no host
+// synchronisation inside the exchange (north_star's "single RCCL allreduce for the global p-value histogram").  The few
+// values that are not in the table (pileups beyond 2^18 / 120 = 2,184: k_pval_deep's) ride in the same buffer: behind
+// the dense part every rank owns a region {count, (key, bp) x BHD_SIDE} that only it writes -- the sum over the ranks is
+// the concatenation.  A rank with more such values than fit says so in its count; every rank sees that after the
+// all-reduce and all take the general exchange together.
+constexpr u32 BHD_SIDE = 4096;                       // values outside the table per rank
+constexpr u32 BHD_REGION = 2 + 2 * BHD_SIDE;         // u64 words of a rank's region
+__host__ __device__ inline size_t bhd_words(u32 world) { return (size_t)PV_LUT + (size_t)world * BHD_REGION; }
+
+// this rank's distinct values (the claimed slots of its table) -> the dense buffer
+__global__ __launch_bounds__(256) void k_bh_dense_fill(const u32* __restrict__ keys, const u32* __restrict__ slots,
+                                                       const u64* __restrict__ gLens, const u32* __restrict__ nPtr,
+                                                       const float* __restrict__ lutP, u64* __restrict__ dense, u32 rank) {
+  const u32 n = *nPtr;
+  u64* region = dense + PV_LUT + (size_t)rank * BHD_REGION;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const u32 key = keys[i];
+    const u64 bp = gLens[slots[i]];
+    // first V with p(V) >= key (p is non-decreasing in V; a table that is not misses, and the value travels in the region)
+    u32 lo = 0, hi = PV_LUT;
+    while (lo < hi) {
+      const u32 mid = (lo + hi) >> 1;
+      const float pm = lutP[mid];
+      if ((pm == 0.0f ? 0u : __float_as_uint(pm)) < key) lo = mid + 1; else hi = mid;
+    }
+    const float pl = lo < PV_LUT ? lutP[lo] : -1.0f;
+    if (lo < PV_LUT && (pl == 0.0f ? 0u : __float_as_uint(pl)) == key)
+      atomicAdd(&dense[lo], bp);
+    else {
+      const u64 j = atomicAdd(&region[0], 1ull);
+      if (j < BHD_SIDE) {
+        region[2 + 2 * j] = key;
+        region[3 + 2 * j] = bp;
+      }
+    }
+  }
+}
+
+// the summed buffer -> a fresh table (equal p of different V fall into one entry, as in the reference's hash)
+__global__ __launch_bounds__(256) void k_bh_from_dense(const u64* __restrict__ dense, const float* __restrict__ lutP, u32 world,
+                                                       BhTable T, u32* __restrict__ overflow, u32* __restrict__ st) {
+  for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += gridDim.x * 256) {
+    const u64 bp = dense[v];
+    if (bp) {
+      const float p = lutP[v];
+      bh_global_add(T, p == 0.0f ? 0u : __float_as_uint(p), bp, st);
+    }
+  }
+  for (u32 r = 0; r < world; r++) {
+    const u64* region = dense + PV_LUT + (size_t)r * BHD_REGION;
+    u64 n = region[0];
+    if (n > BHD_SIDE) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 1u;
+      n = BHD_SIDE;
+    }
+    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < (u32)n; j += gridDim.x * 256)
+      bh_global_add(T, (u32)region[2 + 2 * j], region[3 + 2 * j], st);
+  }
+}
+
 // float log10 exactly as the host's libm evaluates it (saveQval 221, 226 call log10f).
 // glibc 2.35's log10f is the fdlibm formula  z = y*log10_2lo + ivln10*logf(m);  z + y*log10_2hi
 // (float ops) around its table-driven logf (16-entry table, cubic in double).  Restated here and

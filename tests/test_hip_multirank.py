@@ -115,6 +115,8 @@ def test_two_ranks_equal_one_rank(name):
         p.join(60)
         assert p.exitcode == 0
     for _, scal, _, flags in res:
+        if name == "noctrl_q":
+            assert flags & 32, "the p-value histogram must have travelled as the dense all-reduce"
         if name == "plain_p":
             # lambda reached every rank ahead of the tile stage (the early all-reduce of the closed form of fragLen): the
             # fused kernel wrote the sweep's bits, and the sweep walked the loose slots, as on one rank
@@ -148,4 +150,6 @@ def test_rccl_path_with_one_rank(name, monkeypatch):
     assert peaks2.tobytes() == peaks1.tobytes()
     if name == "plain_p":
         assert g2.path_info() & 2, "the loose-slot sweep must survive the collectives"
+    if name == "noctrl_q":
+        assert g2.path_info() & 32, "the dense all-reduce of the p-value histogram (RCCL, one rank)"
 
