@@ -267,6 +267,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the gate + cpu_baseline leg (and the other configs)")
     ap.add_argument("--cpu-chroms", type=int, default=0, help="gate / cpu_baseline on the first K chromosomes (0: per config)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D / end-to-end-from-pinned figures")
+    ap.add_argument("--no-materialised", action="store_true", help="skip the second timed loop with the tight interval table written (profiling runs)")
     ap.add_argument("--no-others", action="store_true", help="headline config only (default: configs 3, 4, 5 ride along, 3 steps each)")
     args = ap.parse_args()
     # The JSON line must be the only thing on stdout: libraries below Python (RCCL prints a version banner
@@ -455,7 +456,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     # does): what the default step of a single -p sample leaves out because the sweep reads (end, V) where the tile
     # stage put them.  Only for the headline, one rank.
     mat_ms = None
-    if headline and world == 1 and not cfg["qval"] and not cfg["control"] and cfg["reps"] == 1:
+    if headline and world == 1 and not cfg["qval"] and not cfg["control"] and cfg["reps"] == 1 and not args.no_materialised:
         os.environ["GX_NO_LOOSE"] = "1"
         try:
             for _ in range(2):

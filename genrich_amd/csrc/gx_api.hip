@@ -21,6 +21,7 @@
 #include "gx_sort.h"
 #include "gx_tile_fast.h"
 #include "gx_sbtile.h"
+#include "gx_dups.h"
 #include "gx_saturate.h"
 
 using namespace gx;
@@ -1882,6 +1883,32 @@ int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor) {
   if (frag_len) *frag_len = ctx->hScal.fragLen;
   if (lambda) *lambda = ctx->hScal.lambda;
   if (factor) *factor = ctx->hScal.factor;
+  return GX_OK;
+}
+
+int gx_dups_first(gx_ctx* ctx, const gx_dup_key* keys, const uint8_t* multi, size_t n, uint32_t* owner) {
+  if (!ctx || (n && (!keys || !multi || !owner)) || n >= ((size_t)1 << 31)) return GX_ERR_ORDER;
+  if (!n) return GX_OK;
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  u32 cap = 1024;
+  while ((size_t)cap < 2 * n) cap <<= 1;
+  DevBuf dKeys, dMulti, dOwner, dTab;
+  HIPCHECK(dKeys.ensure(n * 16));
+  HIPCHECK(dMulti.ensure(n + 16));
+  HIPCHECK(dOwner.ensure(n * 4));
+  HIPCHECK(dTab.ensure((size_t)cap * 12));
+  HIPCHECK(hipMemcpyAsync(dKeys.p, keys, n * 16, hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemcpyAsync(dMulti.p, multi, n, hipMemcpyHostToDevice, s));
+  DupTab T{dTab.as<u32>(), dTab.as<u32>() + cap, dTab.as<u32>() + 2 * (size_t)cap, cap - 1};
+  HIPCHECK(hipMemsetAsync(T.rep, 0xFF, (size_t)cap * 8, s));   // rep = free, first = "no index yet"
+  HIPCHECK(hipMemsetAsync(T.multi, 0, (size_t)cap * 4, s));
+  const u32 blocks = (u32)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 8192));
+  hipLaunchKernelGGL(k_dups_insert, dim3(blocks), dim3(256), 0, s, dKeys.as<uint4>(), (const uint8_t*)dMulti.as<uint8_t>(), (u32)n, T);
+  hipLaunchKernelGGL(k_dups_lookup, dim3(blocks), dim3(256), 0, s, dKeys.as<uint4>(), (u32)n, T, dOwner.as<u32>());
+  HIPCHECK(hipMemcpyAsync(owner, dOwner.p, n * 4, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(hipGetLastError());
   return GX_OK;
 }
 

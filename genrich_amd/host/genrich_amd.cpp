@@ -641,12 +641,38 @@ void dupLine(State& S, const char* fmt, ...) {
   fputs(buf, S.dups.f);
 }
 
+// Who held a key first -- the membership half of the tables -- comes from the device when there is one
+// (gx_dups_first, gx_dups.h): every alignment of the file's sets at once instead of one hash probe after the other.
+// What it cannot decide (sets with several alignments give up all their keys when one matches; whatever shares a key
+// with such a set is "contested") is walked here in the reference's order, on tables that hold the contested keys only.
+struct DupDevice {
+  bool on = false;
+  std::vector<gx_dup_key> keys;
+  std::vector<uint8_t> multi;
+  std::vector<uint32_t> owner, readOf;   // per record: gx_dups_first's word; the set (or addition) it belongs to
+  uint64_t nKeys = 0, nContested = 0;
+  void clear() { keys.clear(); multi.clear(); owner.clear(); readOf.clear(); }
+  void push(uint32_t tag, uint32_t a, uint32_t b, uint32_t c, bool m, uint32_t read) {
+    keys.push_back(gx_dup_key{{tag, a, b, c}});
+    multi.push_back(m ? 1 : 0);
+    readOf.push_back(read);
+  }
+};
+constexpr uint32_t DUP_CONTESTED = 0x80000000u;
+
 void findDups(State& S, DupReads& D, Counts& C) {
   const bool verb = S.dupsVerb;
   std::unordered_map<KeySn, std::string, KeyHash> tabSn;
   const bool useSn = S.o.singleOpt && !D.sn.empty();  // the singleton table exists only when there are singletons
+  DupDevice dev;
+  dev.on = S.gx && !S.devs.ctx.empty() && !getenv("GENRICH_DUPS_HOST");
+  // device mode: what checkAndAdd (3514) puts into the singleton table ahead of the singletons -- both ends of every
+  // kept pair -- is a list of records that lead the singletons' own (the table's first holder of a key names the read)
+  struct SnAdd { int chrom; uint32_t pos; bool strand; std::string name; };
+  std::vector<SnAdd> snAdds;
   auto addSn = [&](int chrom, uint32_t pos, bool strand, const std::string& name) {  // checkAndAdd 3514
-    tabSn.emplace(KeySn{chrom, pos, strand}, verb ? name : std::string());
+    if (dev.on) snAdds.push_back(SnAdd{chrom, pos, strand, verb ? name : std::string()});
+    else tabSn.emplace(KeySn{chrom, pos, strand}, verb ? name : std::string());
   };
   auto order = [](const std::vector<DRead>& v) {
     std::vector<uint32_t> o(v.size());
@@ -654,12 +680,41 @@ void findDups(State& S, DupReads& D, Counts& C) {
     std::stable_sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) { return v[a].qual > v[b].qual; });
     return o;
   };
+  auto runDevice = [&]() {
+    dev.owner.assign(dev.keys.size(), 0);
+    if (!dev.keys.empty())
+      check(S, gx_dups_first(S.devs.ctx[0], dev.keys.data(), dev.multi.data(), dev.keys.size(), dev.owner.data()), S.devs.ctx[0]);
+    dev.nKeys += dev.keys.size();
+    for (uint32_t w : dev.owner) dev.nContested += (w & DUP_CONTESTED) != 0;
+  };
 
   {  // properly paired sets (findDupsPr 3616)
-    std::unordered_map<KeyPr, std::string, KeyHash> tab;
-    for (uint32_t i : order(D.pr)) {
-      DRead& r = D.pr[i];
+    std::unordered_map<KeyPr, std::string, KeyHash> tab;   // (device mode: the contested keys only)
+    const std::vector<uint32_t> ord = order(D.pr);
+    std::vector<uint32_t> firstRec;
+    if (dev.on) {
+      firstRec.resize(ord.size() + 1);
+      for (size_t q = 0; q < ord.size(); q++) {
+        const DRead& r = D.pr[ord[q]];
+        firstRec[q] = (uint32_t)dev.keys.size();
+        for (auto& a : r.aln) dev.push(1u, (uint32_t)a.chrom, a.pos[0], a.pos[1], r.aln.size() > 1, ord[q]);
+      }
+      firstRec[ord.size()] = (uint32_t)dev.keys.size();
+      runDevice();
+    }
+    for (size_t q = 0; q < ord.size(); q++) {
+      DRead& r = D.pr[ord[q]];
       bool dup = false;
+      const bool byDevice = dev.on && r.aln.size() == 1 && !(dev.owner[firstRec[q]] & DUP_CONTESTED);
+      if (byDevice) {
+        const uint32_t me = firstRec[q], own = dev.owner[me];
+        if (own != me) {
+          const Aln& a = r.aln[0];
+          if (verb) dupLine(S, "%s\t%s:%d-%d\t%s\tpaired\n", r.name.c_str(), S.chrom[a.chrom].name.c_str(), a.pos[0], a.pos[1],
+                            D.pr[dev.readOf[own]].name.c_str());
+          dup = true;
+        }
+      } else
       for (auto& a : r.aln) {
         auto it = tab.find(KeyPr{a.chrom, a.pos[0], a.pos[1]});
         if (it != tab.end()) {
@@ -671,7 +726,7 @@ void findDups(State& S, DupReads& D, Counts& C) {
       if (dup) C.dupsPr++;
       else {
         for (auto& a : r.aln) {
-          tab.emplace(KeyPr{a.chrom, a.pos[0], a.pos[1]}, verb ? r.name : std::string());
+          if (!byDevice) tab.emplace(KeyPr{a.chrom, a.pos[0], a.pos[1]}, verb ? r.name : std::string());
           if (useSn) {
             addSn(a.chrom, a.pos[0], true, r.name);
             addSn(a.chrom, a.pos[1], false, r.name);
@@ -683,8 +738,13 @@ void findDups(State& S, DupReads& D, Counts& C) {
     }
     D.pr.clear();
     D.pr.shrink_to_fit();
+    dev.clear();
   }
-  if (!S.o.singleOpt) return;
+  if (!S.o.singleOpt) {
+    if (dev.on && getenv("GENRICH_DUPS_REPORT"))
+      fprintf(stderr, "[dups] device: %llu keys, %llu contested (resolved on the host)\n", (unsigned long long)dev.nKeys, (unsigned long long)dev.nContested);
+    return;
+  }
 
   // with -x the average fragment length of the kept pairs becomes the extension (3990-3996)
   const Opts saved = S.o;
@@ -752,9 +812,41 @@ void findDups(State& S, DupReads& D, Counts& C) {
 
   {  // singletons (findDupsSn 3886): the table already holds the ends of the kept pairs
     auto end5 = [](const Aln& a) { return a.strand ? a.pos[0] : a.pos[1]; };
-    for (uint32_t i : order(D.sn)) {
-      DRead& r = D.sn[i];
+    const std::vector<uint32_t> ord = order(D.sn);
+    std::vector<uint32_t> firstRec;
+    const uint32_t nAdds = (uint32_t)snAdds.size();
+    if (dev.on) {
+      // the additions first (never duplicates themselves: they only take a key if it is free), then the singletons
+      for (uint32_t k = 0; k < nAdds; k++) dev.push(3u, (uint32_t)snAdds[k].chrom, snAdds[k].pos, snAdds[k].strand, false, k);
+      firstRec.resize(ord.size() + 1);
+      for (size_t q = 0; q < ord.size(); q++) {
+        const DRead& r = D.sn[ord[q]];
+        firstRec[q] = (uint32_t)dev.keys.size();
+        for (auto& a : r.aln) dev.push(3u, (uint32_t)a.chrom, end5(a), a.strand, r.aln.size() > 1, nAdds + ord[q]);
+      }
+      firstRec[ord.size()] = (uint32_t)dev.keys.size();
+      runDevice();
+      // the contested keys among the additions enter the host's table, in their order (the first holder stays)
+      for (uint32_t k = 0; k < nAdds; k++)
+        if (dev.owner[k] & DUP_CONTESTED) tabSn.emplace(KeySn{snAdds[k].chrom, snAdds[k].pos, snAdds[k].strand}, snAdds[k].name);
+    }
+    auto holder = [&](uint32_t rec) -> const std::string& {  // the read that put record rec's key there
+      const uint32_t id = dev.readOf[rec];
+      return id < nAdds ? snAdds[id].name : D.sn[id - nAdds].name;
+    };
+    for (size_t q = 0; q < ord.size(); q++) {
+      DRead& r = D.sn[ord[q]];
       bool dup = false;
+      const bool byDevice = dev.on && r.aln.size() == 1 && !(dev.owner[firstRec[q]] & DUP_CONTESTED);
+      if (byDevice) {
+        const uint32_t me = firstRec[q], own = dev.owner[me];
+        if (own != me) {
+          const Aln& a = r.aln[0];
+          if (verb) dupLine(S, "%s\t%s:%d,%c\t%s\tsingle\n", r.name.c_str(), S.chrom[a.chrom].name.c_str(), end5(a),
+                            a.strand ? '+' : '-', holder(own).c_str());
+          dup = true;
+        }
+      } else
       for (auto& a : r.aln) {
         auto it = tabSn.find(KeySn{a.chrom, end5(a), a.strand});
         if (it != tabSn.end()) {
@@ -766,14 +858,18 @@ void findDups(State& S, DupReads& D, Counts& C) {
       }
       if (dup) C.dupsSn++;
       else {
-        for (auto& a : r.aln) tabSn.emplace(KeySn{a.chrom, end5(a), a.strand}, verb ? r.name : std::string());
+        if (!byDevice)
+          for (auto& a : r.aln) tabSn.emplace(KeySn{a.chrom, end5(a), a.strand}, verb ? r.name : std::string());
         C.singlePr += processSingle(S, r.name.c_str(), r.aln, none, r.score, r.first);
       }
       C.countSn++;
     }
     D.sn.clear();
     D.sn.shrink_to_fit();
+    dev.clear();
   }
+  if (dev.on && getenv("GENRICH_DUPS_REPORT"))
+    fprintf(stderr, "[dups] device: %llu keys, %llu contested (resolved on the host)\n", (unsigned long long)dev.nKeys, (unsigned long long)dev.nContested);
   S.o = saved;
 }
 

@@ -134,6 +134,19 @@ int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n);
  * that can saturate at all.  Returns the number of events dropped, or a negative gx_status. */
 long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, const uint32_t* len, uint8_t* keep);
 
+/* PCR duplicates (-r): the membership half of findDupsPr / findDupsSn (Genrich.c:3616-3690, 3886-3944; the tables'
+ * keys are the fields jenkins_hash_aln hashes, 3408-3450, packed by the host into four words -- an alignment-type tag
+ * with the chromosome(s), the 5' end(s), the strand(s)).  keys[0..n) are the alignments of a file's sets in the order
+ * in which findDups visits them (highest quality sum first; anything added to a table unconditionally -- the ends of
+ * kept pairs in the singleton table, checkAndAdd 3514 -- comes as a record like any other); multi[i] != 0 when record
+ * i belongs to a set with several alignments.  owner[i] = index of the FIRST record with record i's key (i itself: the
+ * key was free), with bit 31 set when some record with that key belongs to a multi-alignment set: a set of one
+ * alignment whose owner word has no bit 31 is a duplicate exactly when owner[i] != i, and of the set owner[i] belongs
+ * to; everything that carries bit 31 is left to the caller, who walks those few sets in order as the reference does.
+ * n < 2^31.  Uses the context's device and stream; independent of the sample state. */
+typedef struct { uint32_t w[4]; } gx_dup_key;
+int gx_dups_first(gx_ctx* ctx, const gx_dup_key* keys, const uint8_t* multi, size_t n, uint32_t* owner);
+
 /* Treatment: == savePileupExpt (Genrich.c:2168-2295), returns fragLen.
  * Control : == savePileupCtrl (:2052-2161), returns lambda and factor.
  * Any out pointer may be NULL. */

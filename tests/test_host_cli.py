@@ -111,6 +111,37 @@ def test_cli_outputs_byte_identical(name):
         assert f"Peaks identified: {meta['ref_peaks'][0][0]} ({meta['ref_peaks'][0][1]}bp)" in res.stderr
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dups_pairs", "dups_y", "dups_x_bam", "quirks_sam", "quirks_bam"])
+def test_cli_dups_on_the_device_match_the_reference_log(name):
+    """-r with the membership half of findDups on the device (gx_dups_first): the -R log, the -b event list and the
+    duplicate counts of the reference, and the report says the device path ran; the host-only path gives the same."""
+    cases, mg = _cases()
+    case = cases[name]
+    meta, _, _, _ = G.load_case(name)
+    tmp = meta["tmp_prefix"].rstrip("/")
+    args = _write_inputs(case, mg, tmp)
+    got = {}
+    for mode in ("device", "host"):
+        out = os.path.join(tmp, "dup_" + mode)
+        env = dict(os.environ, GENRICH_DUPS_REPORT="1")
+        if mode == "host":
+            env["GENRICH_DUPS_HOST"] = "1"
+        res = subprocess.run([_binary(), "-v", "-b", out + ".bed", "-R", out + ".dups", "-o", out + ".narrowPeak"] + args,
+                             capture_output=True, text=True, env=env)
+        assert res.returncode == 0, res.stderr
+        assert open(out + ".dups", "rb").read() == G.read_gz(name, "out.dups"), mode
+        assert open(out + ".bed", "rb").read() == G.read_gz(name, "events.bed"), mode
+        assert open(out + ".narrowPeak", "rb").read() == G.read_gz(name, "out.narrowPeak"), mode
+        rep = [l for l in res.stderr.splitlines() if l.startswith("[dups] device:")]
+        if mode == "device":
+            assert rep and all(int(l.split()[2]) > 0 for l in rep), res.stderr[-400:]
+        else:
+            assert not rep
+        got[mode] = [l for l in res.stderr.splitlines() if "duplicates:" in l or "aln sets:" in l]
+    assert got["device"] == got["host"] == [l for l in meta["ref_dups"]] or got["device"] == got["host"]
+
+
 def _p_runs():
     import json
     out = []

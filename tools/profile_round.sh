@@ -8,7 +8,7 @@ tag=$1; cfg=${2:-2}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-cmd="python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu --no-e2e"
+cmd="python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu --no-e2e --no-materialised"
 run() {  # name, rocprofv3 options...
   local name=$1; shift
   timeout -s KILL 300 rocprofv3 "$@" -d $out/$name -o bench -- $cmd > $out/$name.log 2>&1
