@@ -22,6 +22,7 @@
 #include "gx_tile_fast.h"
 #include "gx_sbtile.h"
 #include "gx_dups.h"
+#include "gx_bhx.h"
 #include "gx_saturate.h"
 
 using namespace gx;
@@ -238,7 +239,8 @@ struct gx_ctx {
   void* user = nullptr;
   ncclComm_t comm = nullptr;    // the library's own collectives (gx_set_rccl): RCCL on device buffers, on `stream`
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
-  DevBuf dColl, dCounts, dGather, bhDense;
+  DevBuf dColl, dCounts, dGather, bhDense, bhxSmall, bhxRecv, bhxKeys, bhxLens, bhxQ, bhxOut, bhxAns;
+  bool rangeBhUsed = false;     // the last gx_find_peaks took the range-partitioned BH exchange
   bool denseBhUsed = false;     // the last gx_find_peaks exchanged the p-value histogram as one dense all-reduce
   int phaseLevel = 0;       // gx_set_phase_timing
   std::string phaseFilter = "tile";  // level 1: the one phase that is timed (gx_set_phase_filter)
@@ -2062,6 +2064,165 @@ int gx_pvalues(gx_ctx* ctx) {
   return GX_OK;
 }
 
+// every rank's `per` 64-bit words -- written at [rank * per, ...) of a buffer that is zero elsewhere -- to every rank
+// (a sum of disjoint regions is their concatenation: the fixed-size exchanges need no counts and no host)
+static int coll_concat(gx_ctx* ctx, long long* d, size_t per) { return allreduce_words(ctx, d, per * (size_t)std::max(1, ctx->world)); }
+
+// all-to-all with the counts of M (M[src * W + dst] elements of elemBytes from src to dst; sOff / rOff: this rank's
+// send / receive offsets in elements).  RCCL: grouped send / recv on the library's stream.  Host callbacks (the
+// validation mode of the tests): one all-reduce of a buffer in which every rank fills its outgoing segments.
+static int coll_alltoallv(gx_ctx* ctx, const void* dSend, const std::vector<size_t>& sOff, void* dRecv, const std::vector<size_t>& rOff,
+                          const std::vector<u32>& M, size_t elemBytes) {
+  hipStream_t s = ctx->stream;
+  const u32 W = (u32)std::max(1, ctx->world), me = (u32)ctx->rank;
+  if (ctx->comm) {
+    const gxrccl::Api* api = gxrccl::load(&ctx->err);
+    if (!api) return GX_ERR_DEVICE;
+    ncclResult_t r = api->groupStart();
+    for (u32 p = 0; p < W && r == ncclSuccess; p++) {
+      const size_t ns = (sOff[p + 1] - sOff[p]) * elemBytes, nr = (rOff[p + 1] - rOff[p]) * elemBytes;
+      if (ns) r = api->send(static_cast<const char*>(dSend) + sOff[p] * elemBytes, ns, ncclChar, (int)p, ctx->comm, s);
+      if (nr && r == ncclSuccess) r = api->recv(static_cast<char*>(dRecv) + rOff[p] * elemBytes, nr, ncclChar, (int)p, ctx->comm, s);
+    }
+    const ncclResult_t r2 = api->groupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) {
+      ctx->err = std::string("ncclSend / ncclRecv: ") + api->getErrorString(r);
+      return GX_ERR_DEVICE;
+    }
+    return GX_OK;
+  }
+  // (src-major layout of all segments; this rank's outgoing ones are contiguous in it, as in its send buffer)
+  std::vector<size_t> segOff((size_t)W * W + 1, 0);
+  for (size_t i = 0; i < (size_t)W * W; i++) segOff[i + 1] = segOff[i] + M[i];
+  const size_t words = (segOff[(size_t)W * W] * elemBytes + 7) / 8 + 1;
+  HIPCHECK(ctx->dGather.ensure(words * 8));
+  HIPCHECK(hipMemsetAsync(ctx->dGather.p, 0, words * 8, s));
+  const size_t mine = segOff[(size_t)(me + 1) * W] - segOff[(size_t)me * W];
+  if (mine)
+    HIPCHECK(hipMemcpyAsync(ctx->dGather.as<char>() + segOff[(size_t)me * W] * elemBytes, dSend, mine * elemBytes, hipMemcpyDeviceToDevice, s));
+  if (int rc = allreduce_words(ctx, ctx->dGather.as<long long>(), words)) return rc;
+  for (u32 src = 0; src < W; src++) {
+    const size_t n = M[(size_t)src * W + me];
+    if (n)
+      HIPCHECK(hipMemcpyAsync(static_cast<char*>(dRecv) + rOff[src] * elemBytes, ctx->dGather.as<char>() + segOff[(size_t)src * W + me] * elemBytes,
+                              n * elemBytes, hipMemcpyDeviceToDevice, s));
+  }
+  return GX_OK;
+}
+
+// gx_bhx.h: this rank's table T (Dlocal distinct values, their slots in bhOutKeys / bhOutSlot) -> the q of every one of
+// them in ctx->bhQ, by slot
+static int bh_range_exchange(gx_ctx* ctx, const BhTable& T, u32 Dlocal, u32 capLocal) {
+  hipStream_t s = ctx->stream;
+  u32* misc = ctx->misc.as<u32>();
+  const u32 W = (u32)std::max(1, ctx->world), me = (u32)ctx->rank;
+  if (W > 64) { ctx->err = "more than 64 ranks"; return GX_ERR_ORDER; }
+  (void)capLocal;
+  // 1: this rank's distinct values in order
+  HIPCHECK(ctx->bhSortKeys.ensure((size_t)std::max(Dlocal, 1u) * 4));
+  HIPCHECK(ctx->bhSortSlot.ensure((size_t)std::max(Dlocal, 1u) * 4));
+  if (Dlocal) {
+    size_t tmpBytes = 0;
+    HIPCHECK(rocprim::radix_sort_pairs(nullptr, tmpBytes, ctx->bhOutKeys.as<u32>(), ctx->bhSortKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
+                                       ctx->bhSortSlot.as<u32>(), Dlocal, 0, 32, s));
+    HIPCHECK(ctx->bhTmp.ensure(tmpBytes + 16));
+    HIPCHECK(rocprim::radix_sort_pairs(ctx->bhTmp.p, tmpBytes, ctx->bhOutKeys.as<u32>(), ctx->bhSortKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
+                                       ctx->bhSortSlot.as<u32>(), Dlocal, 0, 32, s));
+  }
+  // the small fixed-size exchanges share one buffer: samples | counts matrix | range totals | range minima
+  const size_t oSamp = 0, oCnt = oSamp + (size_t)W * BHX_SAMPLES, oTot = oCnt + (size_t)W * W, oMin = oTot + W, nSmall = oMin + W;
+  HIPCHECK(ctx->bhxSmall.ensure(nSmall * 8 + (size_t)(2 * W + 4) * 4));
+  u64* small = ctx->bhxSmall.as<u64>();
+  u32* dSpl = reinterpret_cast<u32*>(small + nSmall);
+  u32* dSendOff = dSpl + W + 1;
+  HIPCHECK(hipMemsetAsync(small, 0, nSmall * 8, s));
+  hipLaunchKernelGGL(k_bhx_samples, dim3(1), dim3(64), 0, s, (const u32*)ctx->bhSortKeys.as<u32>(), Dlocal, small + oSamp + (size_t)me * BHX_SAMPLES);
+  if (int rc = coll_concat(ctx, reinterpret_cast<long long*>(small + oSamp), BHX_SAMPLES)) return rc;
+  hipLaunchKernelGGL(k_bhx_splitters, dim3(1), dim3(1024), 0, s, (const u64*)(small + oSamp), W * BHX_SAMPLES, W, dSpl);
+  // 2: the counts, and the one synchronisation
+  hipLaunchKernelGGL(k_bhx_offsets, dim3(1), dim3(128), 0, s, (const u32*)ctx->bhSortKeys.as<u32>(), Dlocal, (const u32*)dSpl, W, dSendOff,
+                     small + oCnt + (size_t)me * W);
+  if (int rc = coll_concat(ctx, reinterpret_cast<long long*>(small + oCnt), W)) return rc;
+  std::vector<u64> M64((size_t)W * W);
+  HIPCHECK(hipMemcpyAsync(M64.data(), small + oCnt, M64.size() * 8, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  std::vector<u32> M((size_t)W * W);
+  for (size_t i = 0; i < M.size(); i++) M[i] = (u32)M64[i];
+  std::vector<size_t> sOff(W + 1, 0), rOff(W + 1, 0);
+  for (u32 p = 0; p < W; p++) {
+    sOff[p + 1] = sOff[p] + M[(size_t)me * W + p];
+    rOff[p + 1] = rOff[p] + M[(size_t)p * W + me];
+  }
+  if (sOff[W] != Dlocal) { ctx->err = "BH exchange: the counts do not add up"; return GX_ERR_DEVICE; }
+  const size_t R = rOff[W];
+  if (R >= ((size_t)1 << 31)) { ctx->err = "p-value table full"; return GX_ERR_MEM; }
+  // 3: records out, records in
+  HIPCHECK(ctx->bhRecs.ensure((size_t)std::max(Dlocal, 1u) * sizeof(BhRec)));
+  HIPCHECK(ctx->bhxRecv.ensure(std::max<size_t>(R, 1) * sizeof(BhRec)));
+  if (Dlocal)
+    hipLaunchKernelGGL(k_bh_pack, dim3(std::max(1u, std::min((Dlocal + 255) / 256, 1024u))), dim3(256), 0, s, ctx->bhSortKeys.as<u32>(),
+                       ctx->bhSortSlot.as<u32>(), ctx->bhLens.as<u64>(), Dlocal, ctx->bhRecs.as<BhRec>());
+  if (int rc = coll_alltoallv(ctx, ctx->bhRecs.p, sOff, ctx->bhxRecv.p, rOff, M, sizeof(BhRec))) return rc;
+  // 4: the owner's table of its range: merged, sorted, scored
+  u32 cap2 = 1024;
+  while ((size_t)cap2 < 4 * R) cap2 <<= 1;
+  const u32 Rb = (u32)std::max<size_t>(R, 1);
+  HIPCHECK(ctx->bhxKeys.ensure((size_t)cap2 * 4));
+  HIPCHECK(ctx->bhxLens.ensure((size_t)cap2 * 8));
+  HIPCHECK(ctx->bhxQ.ensure((size_t)cap2 * 4));
+  HIPCHECK(ctx->bhxOut.ensure((size_t)Rb * 16));   // claimed keys | slots | sorted keys | sorted slots
+  HIPCHECK(hipMemsetAsync(ctx->bhxKeys.p, 0xFF, (size_t)cap2 * 4, s));
+  HIPCHECK(hipMemsetAsync(ctx->bhxLens.p, 0, (size_t)cap2 * 8, s));
+  HIPCHECK(hipMemsetAsync(ctx->bhxOut.p, 0xFF, (size_t)Rb * 8, s));  // (unclaimed entries sort behind every value)
+  u32* oKeys = ctx->bhxOut.as<u32>();
+  u32 *oSlot = oKeys + Rb, *sKeys = oSlot + Rb, *sSlot = sKeys + Rb;
+  u32* cnt2 = misc + M_BHOVF;  // (free again: the dense exchange is not this run's)
+  HIPCHECK(hipMemsetAsync(cnt2, 0, 4, s));
+  BhTable T2{ctx->bhxKeys.as<u32>(), ctx->bhxLens.as<u64>(), cap2 - 1, oKeys, oSlot, cnt2};
+  if (R)
+    hipLaunchKernelGGL(k_bh_insert, dim3((u32)std::max<size_t>(1, std::min<size_t>((R + 255) / 256, 1024))), dim3(256), 0, s,
+                       (const BhRec*)ctx->bhxRecv.as<BhRec>(), (u32)R, T2, ctx->dStatus.as<u32>());
+  {
+    size_t tmpBytes = 0;
+    HIPCHECK(rocprim::radix_sort_pairs(nullptr, tmpBytes, oKeys, sKeys, oSlot, sSlot, Rb, 0, 32, s));
+    HIPCHECK(ctx->bhTmp.ensure(tmpBytes + 16));
+    HIPCHECK(rocprim::radix_sort_pairs(ctx->bhTmp.p, tmpBytes, oKeys, sKeys, oSlot, sSlot, Rb, 0, 32, s));
+  }
+  const u32 nCh = (Rb + QT_CHUNK - 1) / QT_CHUNK;
+  HIPCHECK(ctx->bhDl.ensure((size_t)Rb * 8 + (size_t)nCh * 12 + 64));
+  HIPCHECK(ctx->bhRaw.ensure((size_t)Rb * 4));
+  u64* dl = ctx->bhDl.as<u64>();
+  u64* chunkSum = dl + Rb;
+  float* chunkMin = reinterpret_cast<float*>(chunkSum + nCh);
+  hipLaunchKernelGGL(k_qt_sums, dim3(nCh), dim3(QT_NT), 0, s, (const u32*)sSlot, (const u64*)ctx->bhxLens.as<u64>(), 0u, dl, chunkSum, (const u32*)cnt2);
+  hipLaunchKernelGGL(k_bhx_reduce, dim3(1), dim3(256), 0, s, (const u64*)chunkSum, (const float*)nullptr, nCh, small + oTot + me, (u64*)nullptr);
+  if (int rc = coll_concat(ctx, reinterpret_cast<long long*>(small + oTot), 1)) return rc;
+  hipLaunchKernelGGL(k_qt_raw, dim3(nCh), dim3(QT_NT), 0, s, (const u32*)sKeys, (const u64*)dl, 0u, reinterpret_cast<const u64*>(misc + M_GENOME),
+                     (const u64*)chunkSum, ctx->bhRaw.as<float>(), chunkMin, (const u32*)cnt2, (const u64*)(small + oTot), W, me);
+  hipLaunchKernelGGL(k_bhx_reduce, dim3(1), dim3(256), 0, s, (const u64*)nullptr, (const float*)chunkMin, nCh, (u64*)nullptr, small + oMin + me);
+  if (int rc = coll_concat(ctx, reinterpret_cast<long long*>(small + oMin), 1)) return rc;
+  hipLaunchKernelGGL(k_qt_apply, dim3(nCh), dim3(QT_NT), 0, s, (const u32*)sSlot, (const float*)ctx->bhRaw.as<float>(), 0u, (const float*)chunkMin,
+                     ctx->bhxQ.as<float>(), (u32*)nullptr, (const u32*)cnt2, (const u64*)(small + oMin), W, me);
+  // 5: the answers, back along the same counts
+  HIPCHECK(ctx->bhxAns.ensure(std::max<size_t>(R, 1) * 4 + (size_t)std::max(Dlocal, 1u) * 4));
+  float* ansOut = ctx->bhxAns.as<float>();
+  float* ansIn = ansOut + std::max<size_t>(R, 1);
+  if (R)
+    hipLaunchKernelGGL(k_bhx_answer, dim3((u32)std::max<size_t>(1, std::min<size_t>((R + 255) / 256, 1024))), dim3(256), 0, s,
+                       (const BhRec*)ctx->bhxRecv.as<BhRec>(), (u32)R, (const u32*)ctx->bhxKeys.as<u32>(), cap2 - 1, (const float*)ctx->bhxQ.as<float>(), ansOut);
+  std::vector<u32> Mt((size_t)W * W);
+  for (u32 a = 0; a < W; a++)
+    for (u32 b = 0; b < W; b++) Mt[(size_t)a * W + b] = M[(size_t)b * W + a];
+  if (int rc = coll_alltoallv(ctx, ansOut, rOff, ansIn, sOff, Mt, 4)) return rc;
+  if (Dlocal)
+    hipLaunchKernelGGL(k_bhx_scatter, dim3(std::max(1u, std::min((Dlocal + 255) / 256, 1024u))), dim3(256), 0, s, (const u32*)ctx->bhSortSlot.as<u32>(),
+                       (const float*)ansIn, Dlocal, ctx->bhQ.as<float>());
+  (void)T;
+  ctx->rangeBhUsed = true;
+  return GX_OK;
+}
+
 int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* peak_bp) {
   if (!ctx || ctx->phase != 0 || ctx->sample < 1) return GX_ERR_ORDER;
   HIPCHECK(hipSetDevice(ctx->device));
@@ -2218,6 +2379,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     u32 D = 0;
     bool denseDone = false;
     ctx->denseBhUsed = false;
+    ctx->rangeBhUsed = false;
     // One sample without a control: p is a function of the pileup, every rank holds the same table p(V), and the
     // genome-wide histogram is ONE all-reduce of a dense "bp at V" array (gx_stats.h: k_bh_dense_fill) -- decided by what
     // every rank knows alike
@@ -2255,93 +2417,16 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
         Dlocal = ctx->mail->nMerged;
       }
     }
+    bool rangeDone = false;
     if (denseDone) {
-    } else if (multi && ctx->comm) {
-      // every rank contributes its {p bits, bp} pairs; all ranks rebuild the same genome-wide table
-      // (hashPval 300-327 runs over all chromosomes).  RCCL on device buffers: the counts first (the
-      // host needs their maximum to size the exchange), then the records, padded to that maximum.
-      const gxrccl::Api* api = gxrccl::load(&ctx->err);
-      if (!api) return GX_ERR_DEVICE;
-      const u32 W = (u32)ctx->world;
-      if (W > 64) { ctx->err = "more than 64 ranks"; return GX_ERR_ORDER; }
-      HIPCHECK(ctx->dCounts.ensure(64 * 4));
-      ncclResult_t r = api->allGather(misc + M_BHCOUNT, ctx->dCounts.p, 1, ncclUint32, ctx->comm, s);
-      if (r != ncclSuccess) { ctx->err = std::string("ncclAllGather: ") + api->getErrorString(r); return GX_ERR_DEVICE; }
-      HIPCHECK(hipMemcpyAsync(ctx->mail->counts, ctx->dCounts.p, W * 4, hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipStreamSynchronize(s));
-      u32 maxD = 1;
-      size_t sumD = 0;
-      for (u32 k = 0; k < W; k++) {
-        maxD = std::max(maxD, ctx->mail->counts[k]);
-        sumD += ctx->mail->counts[k];
-      }
-      const u32 Dl = ctx->mail->counts[ctx->rank];
-      HIPCHECK(ctx->bhRecs.ensure((size_t)maxD * sizeof(BhRec)));
-      HIPCHECK(ctx->dGather.ensure((size_t)maxD * W * sizeof(BhRec)));
-      if (Dl)
-        hipLaunchKernelGGL(k_bh_pack, dim3(std::max(1u, std::min((Dl + 255) / 256, 1024u))), dim3(256), 0, s,
-                           ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), ctx->bhLens.as<u64>(), Dl,
-                           ctx->bhRecs.as<BhRec>());
-      r = api->allGather(ctx->bhRecs.p, ctx->dGather.p, (size_t)maxD * 2, ncclUint64, ctx->comm, s);
-      if (r != ncclSuccess) { ctx->err = std::string("ncclAllGather: ") + api->getErrorString(r); return GX_ERR_DEVICE; }
-      // this rank's own entries out, everybody's in -- into a table that holds the union at a load of <= 1/4
-      if (sumD * 4 > cap) {
-        while (sumD * 4 > cap)
-          if (int rc = bh_grow()) return rc;
-        if (int rc = bh_table(cap)) return rc;
-        T = BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
-                    misc + M_BHCOUNT};
-      } else
-        hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
-      HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
-      hipLaunchKernelGGL(k_bh_insert_gathered, dim3(std::max(1u, std::min((maxD + 255) / 256, 256u)), std::min(W, 64u)), dim3(256),
-                         0, s, ctx->dGather.as<BhRec>(), ctx->dCounts.as<u32>(), W, maxD, T, ctx->dStatus.as<u32>());
-      HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipStreamSynchronize(s));
-      D = ctx->mail->D;
-    } else {
-    D = Dlocal;
-    if (multi && ctx->allgather) {
-      // the same exchange through the host program's callback (validation mode of the tests / bench.py)
-      HIPCHECK(ctx->bhRecs.ensure((size_t)std::max(D, 1u) * sizeof(BhRec)));
-      HIPCHECK(ctx->hostRecs.ensure((size_t)std::max(D, 1u) * sizeof(BhRec)));
-      if (D) {
-        hipLaunchKernelGGL(k_bh_pack, dim3(std::max(1u, std::min((D + 255) / 256, 1024u))), dim3(256), 0, s,
-                           ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), ctx->bhLens.as<u64>(), D,
-                           ctx->bhRecs.as<BhRec>());
-        HIPCHECK(hipMemcpyAsync(ctx->hostRecs.p, ctx->bhRecs.p, (size_t)D * sizeof(BhRec), hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
-      }
-      void* all = nullptr;
-      size_t nAll = 0;
-      if (ctx->allgather(ctx->hostRecs.p, D, &all, &nAll, ctx->user)) {
-        ctx->err = "allgather callback failed";
-        return GX_ERR_DEVICE;
-      }
-      // this rank's own entries out, everybody's in -- into a table that holds the union at a load of <= 1/4
-      if (nAll * 4 > cap) {
-        while (nAll * 4 > cap)
-          if (int rc = bh_grow()) { free(all); return rc; }
-        if (int rc = bh_table(cap)) { free(all); return rc; }
-        T = BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
-                    misc + M_BHCOUNT};
-      } else
-        hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
-      HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
-      if (nAll) {
-        HIPCHECK(ctx->bhRecs.ensure(nAll * sizeof(BhRec)));
-        HIPCHECK(hipMemcpyAsync(ctx->bhRecs.p, all, nAll * sizeof(BhRec), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_bh_insert, dim3(std::max<u32>(1, std::min<size_t>((nAll + 255) / 256, 1024))), dim3(256), 0,
-                           s, ctx->bhRecs.as<BhRec>(), (u32)nAll, T, ctx->dStatus.as<u32>());
-        HIPCHECK(hipStreamSynchronize(s));  // `all` is read by the copy until here
-      }
-      free(all);
-      HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
-      HIPCHECK(hipStreamSynchronize(s));
-      D = ctx->mail->D;
-    }
-    }
-    if (D) {
+    } else if (multi) {
+      // a control / replicates: the range-partitioned exchange (gx_bhx.h) leaves every value's q in this rank's table
+      if (int rc = bh_range_exchange(ctx, T, Dlocal, cap)) return rc;
+      rangeDone = true;
+      D = 0;
+    } else
+      D = Dlocal;
+    if (D && !rangeDone) {
       HIPCHECK(ctx->bhSortKeys.ensure((size_t)D * 4));
       HIPCHECK(ctx->bhSortSlot.ensure((size_t)D * 4));
       HIPCHECK(ctx->bhRaw.ensure((size_t)D * 4));
@@ -2362,11 +2447,12 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
         u64* chunkSum = dl + D;
         float* chunkMin = reinterpret_cast<float*>(chunkSum + nCh);
         hipLaunchKernelGGL(k_qt_sums, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortSlot.as<u32>(), ctx->bhLens.as<u64>(), D, dl,
-                           chunkSum);
+                           chunkSum, (const u32*)nullptr);
         hipLaunchKernelGGL(k_qt_raw, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortKeys.as<u32>(), dl, D,
-                           reinterpret_cast<const u64*>(misc + M_GENOME), chunkSum, ctx->bhRaw.as<float>(), chunkMin);
+                           reinterpret_cast<const u64*>(misc + M_GENOME), chunkSum, ctx->bhRaw.as<float>(), chunkMin,
+                           (const u32*)nullptr, (const u64*)nullptr, 1u, 0u);
         hipLaunchKernelGGL(k_qt_apply, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortSlot.as<u32>(), ctx->bhRaw.as<float>(), D,
-                           chunkMin, ctx->bhQ.as<float>(), misc + M_ALLONE);
+                           chunkMin, ctx->bhQ.as<float>(), misc + M_ALLONE, (const u32*)nullptr, (const u64*)nullptr, 1u, 0u);
       }
   if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     }
@@ -2579,7 +2665,7 @@ int gx_rccl_nranks(gx_ctx* ctx, int* n) {
 
 int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   if (!ctx || !flags) return GX_ERR_ORDER;
-  *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
+  *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->rangeBhUsed ? GX_PATH_RANGE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u);
   return GX_OK;
 }

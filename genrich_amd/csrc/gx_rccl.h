@@ -3,7 +3,9 @@
 // Chromosomes shard across GPUs (the reference's per-chromosome loops Genrich.c:2172, 1729,
 // 987), so the hot path needs three tiny genome-wide exchanges and nothing else:
 //   1. fragLen / ctrlFrag (calcLambda 1817, calcFactor 1980): all-reduce of 2 x int64 fixed-point parts;
-//   2. the BH table (hashPval 300-327 runs over all chromosomes): all-gather of {p bits, bp} records;
+//   2. the BH table (hashPval 300-327 runs over all chromosomes): without a control ONE dense all-reduce of bp-at-V
+//      (gx_stats.h), otherwise the range-partitioned exchange of gx_bhx.h (all-reduces of disjoint regions, one
+//      all-to-all of {p bits, bp} records as grouped send / recv, one back with the q-values);
 //   3. the peak list: gathered by the host program (peak_N numbering, 986 / 925).
 // librccl is opened at run time, so a single-GPU run needs no RCCL at all.  One communicator per
 // context (= per GPU, one process or thread each); the unique id travels by whatever channel the
@@ -25,6 +27,10 @@ struct Api {
   decltype(&ncclCommDestroy) commDestroy = nullptr;
   decltype(&ncclAllReduce) allReduce = nullptr;
   decltype(&ncclAllGather) allGather = nullptr;
+  decltype(&ncclSend) send = nullptr;             // (the range-partitioned BH exchange: all-to-all as grouped send / recv)
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) groupStart = nullptr;
+  decltype(&ncclGroupEnd) groupEnd = nullptr;
   decltype(&ncclGetErrorString) getErrorString = nullptr;
   decltype(&ncclCommCount) commCount = nullptr;   // (optional: introspection only)
 };
@@ -61,8 +67,12 @@ inline const Api* load(std::string* err) {
       api.allGather = reinterpret_cast<decltype(api.allGather)>(dlsym(api.handle, "ncclAllGather"));
       api.getErrorString = reinterpret_cast<decltype(api.getErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
       api.commCount = reinterpret_cast<decltype(api.commCount)>(dlsym(api.handle, "ncclCommCount"));
+      api.send = reinterpret_cast<decltype(api.send)>(dlsym(api.handle, "ncclSend"));
+      api.recv = reinterpret_cast<decltype(api.recv)>(dlsym(api.handle, "ncclRecv"));
+      api.groupStart = reinterpret_cast<decltype(api.groupStart)>(dlsym(api.handle, "ncclGroupStart"));
+      api.groupEnd = reinterpret_cast<decltype(api.groupEnd)>(dlsym(api.handle, "ncclGroupEnd"));
       if (!api.getUniqueId || !api.commInitRank || !api.commDestroy || !api.allReduce || !api.allGather ||
-          !api.getErrorString) {
+          !api.getErrorString || !api.send || !api.recv || !api.groupStart || !api.groupEnd) {
         why = "librccl lacks an entry point";
         api.handle = nullptr;
       }

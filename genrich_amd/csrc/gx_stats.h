@@ -618,9 +618,13 @@ __global__ __launch_bounds__(1024) void k_qtable(const u32* __restrict__ keys, c
 // the earlier chunks' aggregates, which every workgroup forms for itself (D / QT_CHUNK values).
 constexpr int QT_NT = 256, QT_ITEMS = 8, QT_CHUNK = QT_NT * QT_ITEMS;
 
+// (Dptr: the number of entries when only the device knows it -- the owner's table of the range-partitioned exchange,
+// gx_bhx.h: the grid then covers an upper bound and D is read here)
 __global__ __launch_bounds__(QT_NT) void k_qt_sums(const u32* __restrict__ slots, const u64* __restrict__ gLens, u32 D,
-                                                   u64* __restrict__ dl /* [D] by r */, u64* __restrict__ chunkSum) {
+                                                   u64* __restrict__ dl /* [D] by r */, u64* __restrict__ chunkSum,
+                                                   const u32* __restrict__ Dptr) {
   __shared__ u64 red[QT_NT / 64];
+  if (Dptr) D = *Dptr;
   const u32 base = blockIdx.x * QT_CHUNK;
   u64 sum = 0;
 #pragma unroll
@@ -642,14 +646,20 @@ __global__ __launch_bounds__(QT_NT) void k_qt_sums(const u32* __restrict__ slots
   }
 }
 
+// (totals / world / rank: several ranks, this one owns range `rank` of the p axis -- the base pairs of the ranges above
+// count as "earlier chunks")
 __global__ __launch_bounds__(QT_NT) void k_qt_raw(const u32* __restrict__ keys, const u64* __restrict__ dl, u32 D,
                                                   const u64* __restrict__ genomeLenPtr, const u64* __restrict__ chunkSum,
-                                                  float* __restrict__ raw /* [D] by r */, float* __restrict__ chunkMin) {
+                                                  float* __restrict__ raw /* [D] by r */, float* __restrict__ chunkMin,
+                                                  const u32* __restrict__ Dptr, const u64* __restrict__ totals, u32 world, u32 rank) {
   __shared__ u64 s64[QT_NT / 64 + 4];
   __shared__ float redf[QT_NT / 64];
   __shared__ u64 pre64;
+  if (Dptr) D = *Dptr;
   const float logN = -log10f_host((float)*genomeLenPtr);
   u64 before = 0;  // base pairs of the earlier chunks
+  if (totals)
+    for (u32 o = rank + 1 + threadIdx.x; o < world; o += QT_NT) before += totals[o];
   for (u32 c = threadIdx.x; c < blockIdx.x; c += QT_NT) before += chunkSum[c];
   before = wave_sum(before);
   if (lane_id() == 0) s64[threadIdx.x >> 6] = before;
@@ -697,11 +707,18 @@ __global__ __launch_bounds__(QT_NT) void k_qt_raw(const u32* __restrict__ keys, 
 
 __global__ __launch_bounds__(QT_NT) void k_qt_apply(const u32* __restrict__ slots, const float* __restrict__ raw, u32 D,
                                                     const float* __restrict__ chunkMin, float* __restrict__ qOfSlot,
-                                                    u32* __restrict__ allOne) {
+                                                    u32* __restrict__ allOne, const u32* __restrict__ Dptr,
+                                                    const u64* __restrict__ mins /* float bits per range */, u32 world, u32 rank) {
   __shared__ float sf[QT_NT / 64 + 4];
   __shared__ float redf[QT_NT / 64];
   __shared__ float preMin;
+  if (Dptr) D = *Dptr;
   float before = FLT_MAX;  // smallest raw q of the earlier chunks
+  if (mins)
+    for (u32 o = rank + 1 + threadIdx.x; o < world; o += QT_NT) {
+      const float m = __uint_as_float((u32)mins[o]);
+      before = m < before ? m : before;
+    }
   for (u32 c = threadIdx.x; c < blockIdx.x; c += QT_NT) before = chunkMin[c] < before ? chunkMin[c] : before;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {

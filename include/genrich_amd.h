@@ -270,6 +270,7 @@ int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
 #define GX_PATH_FELL_BACK 4u
 #define GX_PATH_PT_GREW 8u
 #define GX_PATH_PAIRS 16u    /* bit 4: level 1 of the sort wrote one record per fragment (k_sort_a / k_sort_b) for the fused kernel */
+#define GX_PATH_RANGE_BH 64u /* bit 6: several ranks with a control / replicates, -q: the range-partitioned BH exchange */
 #define GX_PATH_DENSE_BH 32u /* bit 5: several ranks, no control, -q: the p-value histogram travelled as ONE dense all-reduce */
 int gx_path_info(gx_ctx* ctx, unsigned* flags);
 

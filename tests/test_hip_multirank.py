@@ -81,8 +81,11 @@ def _worker(rank, world, port, q, name):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["ctrl_q", "atac_multimap", "reps3_q", "plain_p", "noctrl_q"])
-def test_two_ranks_equal_one_rank(name):
+@pytest.mark.parametrize("name,world", [("ctrl_q", 2), ("atac_multimap", 2), ("reps3_q", 2), ("plain_p", 2), ("noctrl_q", 2),
+                                        ("reps3_q", 3), ("ctrl_q", 4)])
+def test_two_ranks_equal_one_rank(name, world):
+    """(... or three, or four: more ranges of the p axis for the range-partitioned BH exchange, ranks that own a single
+    small chromosome)"""
     import torch.multiprocessing as mp
 
     import genrich_amd
@@ -107,7 +110,7 @@ def test_two_ranks_equal_one_rank(name):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, name)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, name)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs])
@@ -115,6 +118,8 @@ def test_two_ranks_equal_one_rank(name):
         p.join(60)
         assert p.exitcode == 0
     for _, scal, _, flags in res:
+        if name in ("ctrl_q", "reps3_q"):
+            assert flags & 64, "the range-partitioned BH exchange"
         if name == "noctrl_q":
             assert flags & 32, "the p-value histogram must have travelled as the dense all-reduce"
         if name == "plain_p":
@@ -150,6 +155,8 @@ def test_rccl_path_with_one_rank(name, monkeypatch):
     assert peaks2.tobytes() == peaks1.tobytes()
     if name == "plain_p":
         assert g2.path_info() & 2, "the loose-slot sweep must survive the collectives"
+    if name in ("ctrl_q", "reps3_q"):
+        assert g2.path_info() & 64, "the range-partitioned BH exchange (RCCL, one rank: send / recv to itself)"
     if name == "noctrl_q":
         assert g2.path_info() & 32, "the dense all-reduce of the p-value histogram (RCCL, one rank)"
 
