@@ -239,6 +239,7 @@ struct gx_ctx {
   void* user = nullptr;
   ncclComm_t comm = nullptr;    // the library's own collectives (gx_set_rccl): RCCL on device buffers, on `stream`
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
+  DevBuf bigBins;               // pair mode: the super-buckets k_sbtile's first launch leaves to its second
   DevBuf dColl, dCounts, dGather, bhDense, bhxSmall, bhxRecv, bhxKeys, bhxLens, bhxQ, bhxOut, bhxAns;
   bool rangeBhUsed = false;     // the last gx_find_peaks took the range-partitioned BH exchange
   bool denseBhUsed = false;     // the last gx_find_peaks exchanged the p-value histogram as one dense all-reduce
@@ -779,7 +780,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                {capOf(PgCfg<u32>::SHIFT), capOf(PgCfg<u32>::SHIFT), capOf(PgCfg<u64>::SHIFT)},
                {SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>()},
                ctx->endAtLen.as<u32>(), ctx->chromW0.as<int>(), nChrom, ff, ctx->dScal.as<Scalars>(), ctl, wantEarly ? 1 : 0,
-               pairs ? 1 : 0, ctx->binNet.as<int>(), earlyWords};
+               pairs ? 1 : 0, ctx->binNet.as<int>(), ctx->nWide.as<u32>() + 12, earlyWords};
     static_assert(PV_LUT % 1024 == 0, "k_bins_lut: four of k_pval_lut's workgroups per block");
     if (wantEarly)  // with the table p(V) for that lambda, and from which pileup on an interval is significant
       hipLaunchKernelGGL(k_bins_lut, dim3(4 + PV_LUT / 1024), dim3(1024), 0, s, bs, nL1, ctx->pvLut.as<float>(),
@@ -868,19 +869,27 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   if (fused) {
     // level 2 of the sort and the tile passes in one kernel, one workgroup per super-bucket (gx_sbtile.h)
     if (!ctx->sbtLdsSet) {
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(SbtLds)));
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(SbtLds)));
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(SbtLds)));
       ctx->sbtLdsSet = true;
     }
+    HIPCHECK(ctx->bigBins.ensure((size_t)(MAX_BINS + 4) * 4));
     SbtIn si{PG3[0], PG3[1], PG3[2], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
              ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, ctx->sbShift};
-    SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>()};
-    if (ctx->pairsUsed)
-      hipLaunchKernelGGL(k_sbtile<true>, dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
-    else
-      hipLaunchKernelGGL(k_sbtile<false>, dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+    SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>(), ctx->nWide.as<u32>() + 1, ctx->nWide.as<u32>() + 13,
+               ctx->bigBins.as<u32>()};
+    if (ctx->pairsUsed) {
+      hipLaunchKernelGGL((k_sbtile<true, false>), dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+      // the bins it left on its list (reads piled up: more keys than the key array holds, a tile with thousands of keys):
+      // usually none -- an idle launch
+      hipLaunchKernelGGL((k_sbtile<true, true>), dim3(std::max(1u, std::min(nL1, (u32)ctx->numCU))), dim3(SBT_NT), sizeof(SbtLds), s, si, so2,
+                         ctx->dStatus.as<u32>());
+    } else
+      hipLaunchKernelGGL((k_sbtile<false, false>), dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
   } else if (ctx->hasBed) {
     hipLaunchKernelGGL((k_tile<true, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
@@ -1001,10 +1010,20 @@ int allreduce_words(gx_ctx* ctx, long long* d, size_t n) {
     }
   } else if (ctx->allreduce) {
     long long* acc = ctx->mail->coll;
-    if (n > 4) {  // (the dense p-value histogram)
+    // (a big payload -- the dense p-value histogram, the all-to-all buffer of the range exchange -- is timed as a phase of
+    // its own, "xfer": the trips to the host are this mode's stand-in for RCCL, not part of the phase they interrupt)
+    const bool big = n > 4, wasOpen = ctx->phaseOpen;
+    const std::string resume = wasOpen && ctx->nPhases ? ctx->phases[ctx->nPhases - 1].name : std::string();
+    if (big) {
       HIPCHECK(ctx->hostRecs.ensure(n * 8));
       acc = static_cast<long long*>(ctx->hostRecs.p);
+      phase_end(ctx);
+      phase_begin(ctx, "xfer");
     }
+    struct Resume {
+      gx_ctx* c; std::string nm; bool on;
+      ~Resume() { if (on) { phase_end(c); if (!nm.empty()) phase_begin(c, nm.c_str()); } }
+    } resumeGuard{ctx, resume, big};
     HIPCHECK(hipMemcpyAsync(acc, d, n * 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     if (ctx->allreduce(reinterpret_cast<int64_t*>(acc), n, ctx->user)) {
@@ -1209,7 +1228,12 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
     } else if (rc == RETRY_PT) {
       // a (XCD class, super-bucket) list needed more pages than its table row holds -- reads piled up in one
       // spot: what the first build left behind goes, the table grows, the sample is built again
-      ctx->ptJmax = std::min(ctx->ptJmax * 16, PT_JMAX_CAP);
+      // ... to what the longest list asked for (k_scan_bins: the cursors count every reservation), with a quarter to
+      // spare -- not by a blind factor: the table is NXCD x bins x jmax words per stream, cleared for every sample
+      u32 need = 0;
+      HIPCHECK(hipMemcpy(&need, ctx->nWide.as<u32>() + 12, 4, hipMemcpyDeviceToHost));
+      u32 want = std::max(ctx->ptJmax * 2, need + need / 4 + 2);
+      ctx->ptJmax = std::min(want, PT_JMAX_CAP);
       ctx->ptGrew = true;
       if (int w = wipe()) return w;
     } else if (rc == RETRY_SATURATED) {

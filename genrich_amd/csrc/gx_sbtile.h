@@ -46,10 +46,19 @@ constexpr u32 ST_SB_FRAC = 2048u;  // (internal) the sample holds fractional-wei
 constexpr int SBT_NT = 1024;
 constexpr int SBT_NW = SBT_NT / 64;
 constexpr int SBT_TILES = 1 << SBT_MAXSHIFT;          // tiles per super-bucket the LDS tables are made for
-constexpr int SBT_K = 8;                               // 16-byte loads per lane and stream
+constexpr int SBT_K = 8;                               // 16-byte loads per lane and stream (start / end keys)
+#ifndef GX_SBT_KP
+#define GX_SBT_KP 8
+#endif
+constexpr int SBT_KP = GX_SBT_KP;                      // ... of pair records kept in registers (pair mode: one stream)
+constexpr int SBT_KX = 16;                             // ... and slots per wavefront in all: those beyond SBT_KP (a bin of more than 32 K pairs:
+                                                       // reads piled up) are read from global memory by every pass that wants them
+static_assert(SBT_KX <= 2 * SBT_K && SBT_KP <= SBT_KX, "the slot tables hold 2 x SBT_K x SBT_NW descriptors");
 constexpr u32 SBT_SLOT = 256;                          // keys per slot
 constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K keys)
 constexpr u32 SBT_KEYCAP = 57344;                      // keys of a super-bucket (both streams) that fit the LDS
+constexpr u32 SBT_HEAVY = 4096;                        // keys from which a tile is the whole workgroup's (a counter per base), not one wavefront's
+constexpr int SBT_MAXR = 8;                            // pair mode: rounds of a super-bucket whose keys do not fit the LDS at once
 constexpr u32 SBT_FCAP = 16384;                        // pair mode: singles of a super-bucket (read where they lie, twice)
 constexpr int SBT_TR = 192;                            // touched bases per round of a tile's passes (k_tile_fast: TR_CAP)
 // a wavefront's scratch, in words: occupancy bitmap (+ a dummy word that absorbs the lanes without a key), the words'
@@ -77,6 +86,10 @@ struct SbtLds {
   __attribute__((aligned(8))) u32 scratch[40];
   u32 work;
   u32 overflow;
+  u32 rnd[SBT_MAXR + 1];                   // pair mode: the tiles of round r are rnd[r] .. rnd[r + 1] - 1 (a bin beyond the key array)
+  u32 nRounds;
+  u32 nHeavy;                              // tiles of the round that the whole workgroup takes (sbt_heavy)
+  uint16_t heavy[SBT_TILES];
   u32 vsRed[2];                            // loose_vsig's reduction words (its own: tid 0 initialises the others right after)
 };
 
@@ -97,6 +110,9 @@ struct SbtOut {
   TileOut to;
   TileMeta* meta;
   u32* tileSlot;              // [nTiles + 1] first loose slot of a tile (a compact copy of meta[].slot)
+  u32* hot;                   // set when a tile holds enough starts (or ends) for a base to reach the reference's int16 limits
+  u32* nBig;                  // pair mode: the bins left to the second launch (k_sbtile<true, true>), and how many
+  u32* bigList;
 };
 
 // LDS operations of ONE wavefront execute in order; what is needed between a wavefront's phases is only that
@@ -257,22 +273,120 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   wave_lds_sync();
 }
 
+// A tile with thousands of keys (reads piled up on a few bases: a tower, chrM) by the WHOLE workgroup with a counter per
+// base, as k_tile_heavy does on the general chain -- one wavefront walking 30,000 keys in rounds of 192 touched bases held
+// its workgroup, and the kernel, for a millisecond.  The counters take the place of the wavefronts' scratch (all of
+// them are through with their tiles); every thread owns four consecutive bases.  Same outputs as sbt_tile.
+__device__ __forceinline__ void sbt_heavy(SbtLds& L, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
+                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad) {
+  static_assert(SBT_NW * SBT_TW >= TILE, "the counters fit the wavefronts' scratch");
+  static_assert(TILE == SBT_NT * 4, "four bases per thread");
+  int* cnt = &L.tile[0][0];
+  const int tid = threadIdx.x;
+  const bool active = flags & TM_ACTIVE, lastTile = (flags & TM_LAST) != 0;
+  for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(cnt + i) = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  for (u32 k = tid; k < n; k += SBT_NT) {
+    const u32 key = kl[k];
+    atomicAdd(&cnt[key & (TILE - 1)], (key & 0x8000u) ? -GX_UNIT : GX_UNIT);
+  }
+  __syncthreads();
+  const int4 d4 = *reinterpret_cast<const int4*>(cnt + tid * 4);
+  const int d[4] = {d4.x, d4.y, d4.z, d4.w};
+  int tot;
+  const int ex = block_excl_scan<int, SBT_NT>(d[0] + d[1] + d[2] + d[3], reinterpret_cast<int*>(L.scratch), &tot);
+  int run = carry + ex;  // the pileup before this thread's first base
+  bool nz[4];
+  int before[4];
+  u32 mine = 0, neg = 0, big = (u32)(tid == 0 && carry >= FRAG_FAST_MAXV);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    before[j] = run;
+    run += d[j];
+    nz[j] = d[j] != 0 && active && (pos0 + (u32)tid * 4 + j != 0);  // 2241: base 0 closes nothing
+    mine += nz[j];
+    neg |= (u32)(run < 0);
+    big |= (u32)(run >= FRAG_FAST_MAXV);
+  }
+  u32 outCount;
+  u32 o = slot + block_excl_scan<u32, SBT_NT>(mine, L.scratch, &outCount);
+  u32 lastPos = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (nz[j]) {
+      const u32 p = pos0 + (u32)tid * 4 + j;
+      out.to.looseEnd[o] = p;
+      out.to.looseV[o] = before[j];
+      if (before[j] >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[o >> 6], 1ull << (o & 63));  // (vsig: INT_MAX when no bits are wanted)
+      lastPos = p;
+      o++;
+    }
+  // the last interval's end: the largest position written (positions grow with the thread index)
+  u32 lastEnd;
+  {
+    u32 m = lastPos;
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) m = max(m, (u32)__shfl_xor((int)m, dd, 64));
+    __syncthreads();
+    if (lane_id() == 0) L.scratch[tid >> 6] = m;
+    __syncthreads();
+    m = 0;
+    for (int w = 0; w < SBT_NW; w++) m = max(m, L.scratch[w]);
+    lastEnd = m;
+    __syncthreads();
+  }
+  const int endRun = carry + tot;  // the pileup behind the tile's last base
+  u32 total = 0;
+  if (active) {
+    total = outCount + (lastTile ? 1u : 0u);
+    if (tid == 0) {
+      if (lastTile) {  // closing interval [.., len): 2268-2273
+        const u32 oc = slot + outCount;
+        out.to.looseEnd[oc] = len;
+        out.to.looseV[oc] = endRun;
+        if (endRun >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[oc >> 6], 1ull << (oc & 63));
+      }
+      if (total) out.to.tileLastEnd[t] = lastTile ? len : lastEnd;
+    }
+    if (lastTile) lastEnd = len;
+    if (neg) bad |= ST_NEG_PILE;
+    if (__syncthreads_or((int)big) && tid == 0) {
+      atomicOr(&out.to.tileDeep[t], 1u);
+      if (out.to.ctl) atomicOr(&out.to.ctl->bad, 1u);  // a pileup beyond (or close to the end of) the table p(V)
+    }
+  }
+  if (tid == 0) out.to.tileCount[t] = total;
+  if (total && vsig != 0x7FFFFFFF)  // the unused slots: zero-length intervals behind the last one (the sweep walks the loose slots)
+    for (u32 j = total + tid; j < n + 1; j += SBT_NT) {
+      out.to.looseEnd[slot + j] = lastEnd;
+      out.to.looseV[slot + j] = 0;
+    }
+  __syncthreads();
+}
+
 // PAIRS: level 1 was k_sort1p (gx_sort.h): one 4-byte record per fragment (start within the bin, length) in PS, the few
 // other records ("singles") as 8-byte signed-weight records in PF -- half the bytes to load, one LDS atomic per fragment
 // in the histogram and in the scatter where both ends share a tile (19 of 20).
-template <bool PAIRS>
-__global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
-  SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
+// BIG (pair mode only): the second launch, for the few bins the first one put on its list -- more keys than the key
+// array holds (worked off in rounds of tiles), a tile with thousands of keys (sbt_heavy: the whole workgroup), more than
+// 32 K pair records.  It keeps no record in registers (every pass reads the bin's slots from global memory: they are
+// in L2), so that none of this costs the first launch -- the one every bin of an ordinary sample takes -- a register.
+template <bool PAIRS, bool BIG>
+__device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32* __restrict__ st, const u32 seg, SbtLds& L) {
+  static_assert(PAIRS || !BIG, "the second launch exists in pair mode only");
+  constexpr int K = BIG ? 0 : (PAIRS ? SBT_KP : SBT_K);   // slots per wavefront of the (first) stream held in registers
+  constexpr int KX = BIG ? SBT_KX : K;                    // ... and in all
+  constexpr int KR = K ? K : 1;                           // (array sizes)
+  constexpr u32 NSLOTS = (u32)KX * SBT_NW;
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-  const u32 seg = blockIdx.x, nSeg = in.nSeg;
+  const u32 nSeg = in.nSeg;
   const u32 nT = 1u << in.sbShift;           // tiles per super-bucket (<= SBT_TILES)
   const u32 segTileBase = seg << in.sbShift;
-  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, blockIdx.x == 0 && tid == 0, L.vsRed));
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, !BIG && seg == 0 && tid == 0, L.vsRed));
   // scratch and tables start at zero
   for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
   if (tid < SBT_TILES) L.hist[tid] = 0;
-  if (tid == 0) L.overflow = 0;
+  if (tid == 0) { L.overflow = 0; L.nHeavy = 0; }
   __syncthreads();
   if (tid < SBT_NW) L.tile[tid][SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
   if (tid < 2 * NXCD) {
@@ -293,9 +407,9 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   }
   __syncthreads();
   // ---- 1: slot descriptors (thread k of the first 2 SBT_SLOTS: slot k & 127 of stream k >> 7)
-  if (tid < (PAIRS ? 1 : 2) * (int)SBT_SLOTS) {
-    const int q = tid / (int)SBT_SLOTS;
-    const u32 k = (u32)tid % SBT_SLOTS;
+  if (tid < (PAIRS ? 1 : 2) * (int)NSLOTS) {
+    const int q = tid / (int)NSLOTS;
+    const u32 k = (u32)tid % NSLOTS;
     const PagedStream& P = q ? in.PE : in.PS;
     const u32* pre = L.pre[q];
     u32 x = NXCD, k0 = 0, acc = 0;
@@ -307,7 +421,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
       }
       acc += ns;
     }
-    if (k == 0 && acc > SBT_SLOTS) L.overflow = 1;  // more slots than descriptors: the bin does not fit
+    if (k == 0 && acc > NSLOTS) L.overflow = 1;  // more slots than descriptors: the bin does not fit
     u32 ptr = 0;
     u32 cnt = 0;
     if (x < NXCD) {
@@ -339,33 +453,35 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   // ---- 2: the bin's keys, all loads in flight together
   const uint4* __restrict__ poolS = reinterpret_cast<const uint4*>(in.PS.pool);
   const uint4* __restrict__ poolE = reinterpret_cast<const uint4*>(in.PE.pool);
-  uint4 kS[SBT_K], kE[SBT_K];
-  u32 cS[SBT_K], cE[SBT_K];
+  uint4 kS[KR], kE[PAIRS ? 1 : KR];
+  u32 cS[KR], cE[PAIRS ? 1 : KR];
 #pragma unroll
-  for (int i = 0; i < SBT_K; i++) {  // (wave-uniform: scalar registers)
+  for (int i = 0; i < K; i++)  // (wave-uniform: scalar registers)
     cS[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
-    cE[i] = ovfSlots || PAIRS ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[SBT_SLOTS + i * SBT_NW + wv]);
-  }
 #pragma unroll
-  for (int i = 0; i < SBT_K; i++) {
+  for (int i = 0; i < (PAIRS ? 1 : K); i++)
+    cE[i] = ovfSlots || PAIRS ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[NSLOTS + i * SBT_NW + wv]);
+#pragma unroll
+  for (int i = 0; i < K; i++) {
     kS[i] = make_uint4(0u, 0u, 0u, 0u);
     if ((u32)lane * 4 < cS[i]) kS[i] = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
   }
 #pragma unroll
-  for (int i = 0; i < SBT_K; i++) {
+  for (int i = 0; i < (PAIRS ? 1 : K); i++) {
     kE[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (!PAIRS && (u32)lane * 4 < cE[i]) kE[i] = poolE[(L.slotOff[SBT_SLOTS + i * SBT_NW + wv] >> 2) + lane];
+    if (!PAIRS && (u32)lane * 4 < cE[i]) kE[i] = poolE[(L.slotOff[NSLOTS + i * SBT_NW + wv] >> 2) + lane];
   }
   // pair mode: the bin's singles (a handful; 8-byte records of weight +-120 = a start / an end key; anything else is a
   // fractional weight: the sample goes to the general chain) are read where they lie, once per pass
   const BinSrc<u64> srcF{reinterpret_cast<const u64*>(in.PF.pool), in.PF.pt, nSeg, in.PF.jmax, seg, L.pre[1]};
   const u32 nF = PAIRS && !ovfSlots ? L.pre[1][NXCD] : 0u;
-  if (PAIRS && tid == 0 && nF > SBT_FCAP) L.overflow = 1;  // (read behind the histogram's barrier)
+  // (16-bit counts per tile: the bin's pairs and singles together stay below 2^16)
+  if (PAIRS && tid == 0 && (nF > SBT_FCAP || L.pre[0][NXCD] + nF > 65535u)) L.overflow = 1;  // (read behind the histogram's barrier)
   if (tid < (int)nT) L.tinfo[tid] = ti;
   if (GX_EXP_SBT == 1) {
     u32 x = 0;
 #pragma unroll
-    for (int i = 0; i < SBT_K; i++) x ^= kS[i].x ^ kS[i].y ^ kS[i].z ^ kS[i].w ^ kE[i].x ^ kE[i].y ^ kE[i].z ^ kE[i].w;
+    for (int i = 0; i < K; i++) x ^= kS[i].x ^ kS[i].y ^ kS[i].z ^ kS[i].w ^ kE[PAIRS ? 0 : i].x;
     if (x == 0xDEADBEEFu) atomicOr(st, 1u << 30);
   }
   // ---- 3: per-tile histogram
@@ -382,7 +498,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   };
   if (PAIRS) {
 #pragma unroll
-    for (int i = 0; i < SBT_K; i++) {
+    for (int i = 0; i < K; i++) {
       if (cS[i] == SBT_SLOT) {
 #pragma unroll
         for (int j = 0; j < 4; j++) histPair(keyAt(kS[i], j));
@@ -391,6 +507,15 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
         for (int j = 0; j < 4; j++)
           if ((u32)lane * 4 + j < cS[i]) histPair(keyAt(kS[i], j));
       }
+    }
+    for (int i = K; i < KX; i++) {  // (slots beyond the registers: only a bin of more than 32 K pairs has any)
+      const u32 c = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
+      if (!c) continue;  // wave-uniform
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if ((u32)lane * 4 < c) v = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if ((u32)lane * 4 + j < c) histPair(keyAt(v, j));
     }
     if (nF <= SBT_FCAP)
       for (u32 i = tid; i < nF; i += SBT_NT) {
@@ -401,7 +526,8 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
         else
           L.overflow = 2;
       }
-  } else if (GX_EXP_SBT != 1)
+  } else if constexpr (!PAIRS) {
+  if (GX_EXP_SBT != 1)
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
     if (cS[i] == SBT_SLOT) {
@@ -421,6 +547,7 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
         if ((u32)lane * 4 + j < cE[i]) atomicAdd(&L.hist[(keyAt(kE[i], j) >> TB) - segTileBase], 65536u);
     }
   }
+  }
   __syncthreads();
   {
     u32 h = tid < (int)nT ? L.hist[tid] : 0u;
@@ -435,8 +562,45 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
     if (tid == 0) L.startC[nT] = (u32)tot;
   }
   __syncthreads();
+  if constexpr (PAIRS && !BIG) {
+    // what this launch does not take: it goes on the list of the second one, untouched
+    const u32 hh = tid < (int)nT ? L.hist[tid] : 0u;
+    const bool heavyTile = (hh & 0xFFFFu) + (hh >> 16) > SBT_HEAVY;
+    const bool big = __syncthreads_or((int)heavyTile) || ovfSlots || L.startC[nT] > SBT_KEYCAP || L.overflow == 1;
+    if (big) {  // block-uniform
+      if (tid == 0) out.bigList[atomicAdd(out.nBig, 1u)] = seg;
+      return;
+    }
+  }
+  // Pair mode: a bin with more keys than the key array holds (reads piled up: a tower, chrM) is worked off in ROUNDS of
+  // consecutive tiles whose keys fit -- the records stay in their registers, every round scatters the keys of its tiles
+  // only.  What still does not fit: more records than the slots take, a single tile beyond the array, too many rounds.
+  if (BIG && tid == 0) {
+    u32 nr = 0;
+    bool fits = true;
+    if (L.startC[nT] <= SBT_KEYCAP) {
+      L.rnd[0] = 0;
+      L.rnd[1] = nT;
+      nr = 1;
+    } else if (!ovfSlots) {
+      u32 tb = 0;
+      L.rnd[0] = 0;
+      while (tb < nT && fits) {
+        u32 te = tb;
+        while (te < nT && L.startC[te + 1] - L.startC[tb] <= SBT_KEYCAP) te++;
+        if (te == tb || nr == (u32)SBT_MAXR) fits = false;
+        else {
+          L.rnd[++nr] = te;
+          tb = te;
+        }
+      }
+    }
+    L.nRounds = fits ? nr : 0u;
+  }
+  if (BIG) __syncthreads();
+  const u32 nRounds = BIG ? L.nRounds : 1u;
   const u32 ovfWord = PAIRS ? L.overflow : 0u;  // (pair mode: 1 too many singles, 2 a fractional weight among them)
-  const bool ovfReal = ovfSlots || L.startC[nT] > SBT_KEYCAP || ovfWord != 0;
+  const bool ovfReal = ovfSlots || (BIG ? nRounds == 0 : L.startC[nT] > SBT_KEYCAP) || ovfWord != 0;
   const bool ovf = ovfReal || GX_EXP_SBT == 1 || GX_EXP_SBT == 2;
   // (the slot capacity bounds a stream at 32 K keys -- pair mode: 32 K pairs and SBT_FCAP singles --, so a tile's 16-bit
   // counts cannot have wrapped)
@@ -454,6 +618,9 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
     const u32 sc = ovf ? 0u : L.startC[tid];
     L.cur[tid] = sc;
     L.cur[SBT_TILES + tid] = sc + nS;
+    // (a base can only reach the reference's int16 limits where 32,766 starts, or ends, share a tile: the host then
+    // replays the events -- gx_saturate.h; a bin worked off in rounds can hold that many)
+    if (nS >= HOT16 / GX_UNIT || nE >= HOT16 / GX_UNIT) atomicOr(out.hot, 1u);
     if (t < in.nTiles) {
       TileMeta m;
       m.sb = 0; m.eb = 0; m.fb = 0;
@@ -479,34 +646,125 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
   auto place = [&](u32 key, u32 curBase, u32 flag) {
     L.keys[atomicAdd(&L.cur[curBase + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | flag);
   };
-  if (PAIRS) {
-    // one cursor per tile (starts and ends of a tile share its list: a key says which it is); a pair whose ends share a
-    // tile takes its two places with one atomic
-    auto placePair = [&](u32 r) {
-      const u32 e = pairEnd(r), ts = pairTs(r), te = e >> TB;
-      const u32 so = (r >> PAIR_LEN_BITS) & (TILE - 1), eo = (e & (TILE - 1)) | 0x8000u;
-      const u32 ps = atomicAdd(&L.cur[ts], ts == te ? 2u : 1u);
-      const u32 pe = ts == te ? ps + 1u : atomicAdd(&L.cur[te], 1u);
-      L.keys[ps] = (uint16_t)so;
-      L.keys[pe] = (uint16_t)eo;
-    };
+  // the wavefronts take the tiles [L.work .. tileEnd) from a counter; keyBase: where the first key in LDS lies in the bin's order
+  auto tiles = [&](u32 tileEnd, u32 keyBase) {
+    for (;;) {
+      u32 b = 0;
+      if (lane == 0) b = atomicAdd(&L.work, 1u);
+      b = (u32)__builtin_amdgcn_readfirstlane((int)b);
+      if (b >= tileEnd) break;
+      const u32 t = segTileBase + b;
+      if (t >= in.nTiles) continue;
+      const u32 h = L.hist[b], n = (h & 0xFFFFu) + (h >> 16);
+      if (BIG && n > SBT_HEAVY) {  // wave-uniform: left to the whole workgroup
+        if (lane == 0) L.heavy[atomicAdd(&L.nHeavy, 1u)] = (uint16_t)b;
+        continue;
+      }
+      const uint4 tf = L.tinfo[b];
+      const u32 sc = L.startC[b];
+      const int carry = segNet + GX_UNIT * L.netPref[b] - (int)tf.w;
+      sbt_tile(L.tile[wv], L.keys + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad);
+    }
+    if constexpr (BIG) {
+    __syncthreads();  // (every wavefront is through with its tiles; the list of the heavy ones is complete)
+    const u32 nH = L.nHeavy;
+    if (nH) {  // block-uniform
+      for (u32 i = 0; i < nH; i++) {
+        const u32 b = L.heavy[i], t = segTileBase + b;
+        const u32 h = L.hist[b], n = (h & 0xFFFFu) + (h >> 16);
+        const uint4 tf = L.tinfo[b];
+        const u32 sc = L.startC[b];
+        const int carry = segNet + GX_UNIT * L.netPref[b] - (int)tf.w;
+        sbt_heavy(L, L.keys + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad);
+      }
+      // the wavefronts' scratch as the next round's tiles expect it
+      for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
+      __syncthreads();
+      if (tid < SBT_NW) L.tile[tid][SBT_OCCW + TILE / 64] = -1;
+      if (tid == 0) L.nHeavy = 0;
+      __syncthreads();
+    }
+    }
+  };
+  if constexpr (PAIRS && !BIG) {
+    {
+      // one cursor per tile (starts and ends of a tile share its list: a key says which it is); a pair whose ends share a
+      // tile takes its two places with one atomic
+      auto placePair = [&](u32 r) {
+        const u32 e = pairEnd(r), ts = pairTs(r), te = e >> TB;
+        const u32 so = (r >> PAIR_LEN_BITS) & (TILE - 1), eo = (e & (TILE - 1)) | 0x8000u;
+        const u32 ps = atomicAdd(&L.cur[ts], ts == te ? 2u : 1u);
+        const u32 pe = ts == te ? ps + 1u : atomicAdd(&L.cur[te], 1u);
+        L.keys[ps] = (uint16_t)so;
+        L.keys[pe] = (uint16_t)eo;
+      };
 #pragma unroll
-    for (int i = 0; i < SBT_K; i++) {
-      if (cS[i] == SBT_SLOT) {
+      for (int i = 0; i < K; i++) {
+        if (cS[i] == SBT_SLOT) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) placePair(keyAt(kS[i], j));
-      } else if (cS[i]) {
+          for (int j = 0; j < 4; j++) placePair(keyAt(kS[i], j));
+        } else if (cS[i]) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if ((u32)lane * 4 + j < cS[i]) placePair(keyAt(kS[i], j));
+        }
+      }
+      for (int i = K; i < KX; i++) {
+        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
+        if (!c) continue;  // wave-uniform
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((u32)lane * 4 < c) v = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if ((u32)lane * 4 + j < cS[i]) placePair(keyAt(kS[i], j));
+          if ((u32)lane * 4 + j < c) placePair(keyAt(v, j));
+      }
+      for (u32 i = tid; i < nF; i += SBT_NT) {
+        const u64 r = srcF.at(i);
+        const u32 off = (u32)(r >> 8) & (TILE - 1);
+        L.keys[atomicAdd(&L.cur[(u32)(r >> 32) - segTileBase], 1u)] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u));
+      }
+      __syncthreads();
+      if (GX_EXP_SBT == 3) {
+        if (tid < (int)nT && segTileBase + tid < in.nTiles) out.to.tileCount[segTileBase + tid] = L.keys[L.startC[tid]] == 0xFFFFu;
+        return;
+      }
+      tiles(nT, 0u);
+    }
+  } else if constexpr (BIG) {
+    {
+      // Rounds (one, when only a heavy tile brought the bin here).  Every round loads the bin's records -- they are in L2 -- and
+      // scatters the ends that lie in its tiles; the cursors count in the bin's order, the key array from the round's first
+      // key.  (Keeping the records in their registers across the tile loop cost the common path its registers.)
+      for (u32 round = 0; round < nRounds; round++) {
+        const u32 tileBeg = L.rnd[round], tileEnd = L.rnd[round + 1], keyBase = L.startC[tileBeg];
+        if (round) {
+          __syncthreads();  // (the previous round's tiles are through with the keys)
+          if (tid == 0) L.work = tileBeg;
+          __syncthreads();
+        }
+        for (int i = 0; i < KX; i++) {
+          const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
+          if (!c) continue;  // wave-uniform
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if ((u32)lane * 4 < c) v = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if ((u32)lane * 4 + j < c) {
+              const u32 r = keyAt(v, j), e = pairEnd(r), ts = pairTs(r), te = e >> TB;
+              if (ts - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[ts], 1u) - keyBase] = (uint16_t)((r >> PAIR_LEN_BITS) & (TILE - 1));
+              if (te - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)((e & (TILE - 1)) | 0x8000u);
+            }
+        }
+        for (u32 i = tid; i < nF; i += SBT_NT) {
+          const u64 r = srcF.at(i);
+          const u32 tl = (u32)(r >> 32) - segTileBase, off = (u32)(r >> 8) & (TILE - 1);
+          if (tl - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[tl], 1u) - keyBase] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u));
+        }
+        __syncthreads();
+        tiles(tileEnd, keyBase);
       }
     }
-    for (u32 i = tid; i < nF; i += SBT_NT) {
-      const u64 r = srcF.at(i);
-      const u32 off = (u32)(r >> 8) & (TILE - 1);
-      L.keys[atomicAdd(&L.cur[(u32)(r >> 32) - segTileBase], 1u)] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u));
-    }
-  } else
+  } else {
 #pragma unroll
   for (int i = 0; i < SBT_K; i++) {
     if (cS[i] == SBT_SLOT) {
@@ -538,20 +796,24 @@ __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __
     if (tid < (int)nT && segTileBase + tid < in.nTiles) out.to.tileCount[segTileBase + tid] = L.keys[L.startC[tid]] == 0xFFFFu;
     return;
   }
-  for (;;) {
-    u32 b = 0;
-    if (lane == 0) b = atomicAdd(&L.work, 1u);
-    b = (u32)__builtin_amdgcn_readfirstlane((int)b);
-    if (b >= nT) break;
-    const u32 t = segTileBase + b;
-    if (t >= in.nTiles) continue;
-    const u32 h = L.hist[b], n = (h & 0xFFFFu) + (h >> 16);
-    const uint4 tf = L.tinfo[b];
-    const u32 sc = L.startC[b];
-    const int carry = segNet + GX_UNIT * L.netPref[b] - (int)tf.w;
-    sbt_tile(L.tile[wv], L.keys + sc, n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad);
+  tiles(nT, 0u);
   }
   if (bad && lane == 0) atomicOr(st, bad);
+}
+
+template <bool PAIRS, bool BIG>
+__global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
+  SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
+  if constexpr (!BIG)
+    sbt_bin<PAIRS, false>(in, out, st, blockIdx.x, L);
+  else {
+    const u32 nBig = *out.nBig;
+    for (u32 item = blockIdx.x; item < nBig; item += gridDim.x) {  // (usually none)
+      sbt_bin<PAIRS, true>(in, out, st, out.bigList[item], L);
+      __syncthreads();
+    }
+  }
 }
 
 }  // namespace gx

@@ -1096,6 +1096,7 @@ struct BinScan {
   //   sbOff[1][b] = weight (1/120) the bins before b hand on: the sum of their singles' weights (a pair hands on nothing)
   int pairMode;
   const int* binNet;
+  u32* needPages;      // max over the lists of the pages a list would need (what the host sizes a longer page table by)
   // several ranks: {sum over the ranks of the closed form of fragLen, ranks for which it is not valid} (build_pileup's
   // early all-reduce) instead of this rank's partial sums
   const long long* early;
@@ -1147,6 +1148,14 @@ __device__ __forceinline__ void scan_bins_body(const BinScan& B, u32 nBins, u32 
   u32* sbOff = B.sbOff[block];
   constexpr int PER = MAX_BINS / 1024;
   u32 v[PER], sum = 0;
+  {  // the longest list of this stream, in pages (cursors count every reservation, also those beyond the table row)
+    const int shift = block == 2 ? PgCfg<u64>::SHIFT : PgCfg<u32>::SHIFT;
+    u32 mx = 0;
+    for (u32 i = threadIdx.x; i < nBins * NXCD; i += 1024) mx = max(mx, cursor[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, d, 64));
+    if (lane_id() == 0 && mx) atomicMax(B.needPages, (mx >> shift) + 1u);
+  }
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const u32 i = threadIdx.x * PER + k;

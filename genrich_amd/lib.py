@@ -203,7 +203,8 @@ class Genrich:
         self._check(self.lib.gx_set_owned(self.ctx, a.ctypes.data))
 
     def set_collectives(self, rank, world, allreduce, allgather):
-        self._cb = (ALLREDUCE_FN(allreduce), ALLGATHER_FN(allgather))
+        # (allgather: kept in the ABI for older host programs; the library's exchanges are all-reduces now -- None is fine)
+        self._cb = (ALLREDUCE_FN(allreduce), ALLGATHER_FN(allgather) if allgather is not None else C.cast(None, ALLGATHER_FN))
         self._check(self.lib.gx_set_collectives(self.ctx, rank, world, self._cb[0], self._cb[1], None))
 
     def set_rccl(self, rank, world, unique_id: bytes):

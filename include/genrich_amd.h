@@ -213,10 +213,14 @@ int gx_write_log_path(gx_ctx* ctx, int n_rep, const char* const* names, int n_ch
  *      three genome-wide quantities are exchanged through host-supplied callbacks
  *      (RCCL via torch.distributed in bench.py; a no-op on one GPU). ---- */
 
-/* Sum `n` int64 values over all ranks in place (fragLen / ctrlFrag fixed-point parts and the
- * ranks' "a base can saturate" flags: n = 3).  buf is host memory. */
+/* Sum `n` int64 values over all ranks in place.  EVERY exchange of the library goes through this one callback in the
+ * callback mode: the fragLen / ctrlFrag fixed-point parts and the ranks' flags (n = 3, twice per sample when lambda is
+ * exchanged ahead of the tile stage), the dense p-value histogram of a run without a control (n = 2^18 + 8,194 per
+ * rank), and -- as sums of disjoint regions of a zeroed buffer, i.e. concatenations -- the samples, counts, totals,
+ * minima and the all-to-all segments of the range-partitioned BH exchange (gx_bhx.h).  buf is host memory. */
 typedef int (*gx_allreduce_i64_fn)(int64_t* buf, size_t n, void* user);
-/* Gather variable-length tables: every rank contributes n_local 16-byte records
+/* (Not called any more: the BH table is exchanged by all-reduces since round 4; the parameter stays for source
+ * compatibility and may be NULL.)  Gather variable-length tables: every rank contributes n_local 16-byte records
  * {uint32 key, uint32 pad, uint64 bp}; the callback returns a malloc'd concatenation of
  * all ranks' records in *out / *n_out (freed by the library with free()).  `local` is host
  * memory owned by the library. */

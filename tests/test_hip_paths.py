@@ -73,12 +73,29 @@ def test_a_control_uses_the_fused_tile_stage_for_both_samples():
     assert flags & FUSED and not flags & LOOSE
 
 
+@pytest.mark.parametrize("n_pile", [30_000, 44_000, 58_000])
+def test_a_super_bucket_beyond_the_key_array_is_worked_off_in_rounds(n_pile):
+    # 49 tiles -> 4 tiles per super-bucket; 30,000 / 44,000 fragments inside one of them = more keys than SBT_KEYCAP (57,344)
+    # but no more pair records than the slots take (64 K): rounds of tiles, no fall-back
+    lens = [200_000]
+    rng = np.random.default_rng(9)
+    ev = synth.make_fragments(lens, 4_000, 2, peak_every=20_000, tower_every=150_000)
+    pile = np.zeros(n_pile, dtype=B.EVENT_DTYPE)
+    pile["start"] = 66_000 + rng.integers(0, 12_000, size=len(pile))
+    pile["end"] = pile["start"] + 100 + rng.integers(0, 200, size=len(pile))
+    pile["count"] = 1
+    case = dict(lens=lens, replicates=[dict(save=None, treat=np.concatenate([ev, pile]), ctrl=None)])
+    o, h, flags = _run(case, B.make_params(pq=0.01, min_auc=20.0))
+    assert flags & FUSED and not flags & FELL_BACK
+    assert flags & LOOSE
+
+
 def test_a_super_bucket_beyond_the_lds_goes_back_to_the_general_chain():
-    # 49 tiles -> 4 tiles per super-bucket; 45,000 fragments inside one of them = 90,000 keys > SBT_KEYCAP
+    # 49 tiles -> 4 tiles per super-bucket; 70,000 fragments inside one of them: more pair records than k_sbtile's slots take
     lens = [200_000]
     rng = np.random.default_rng(9)
     ev = synth.make_fragments(lens, 20_000, 2, peak_every=20_000, tower_every=150_000)
-    pile = np.zeros(45_000, dtype=B.EVENT_DTYPE)
+    pile = np.zeros(70_000, dtype=B.EVENT_DTYPE)
     pile["start"] = 66_000 + rng.integers(0, 12_000, size=len(pile))
     pile["end"] = pile["start"] + 100 + rng.integers(0, 200, size=len(pile))
     pile["count"] = 1

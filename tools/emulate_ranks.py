@@ -2,14 +2,15 @@
 
    python tools/emulate_ranks.py [--config 2|3|4|5] [N | N:rank] ...        (default config 2; 1 2 4 8, rank 0)
 
-The collectives are host callbacks that add / append what the OTHER ranks would contribute, so lambda, the factor and
-the q-values -- and with them the sweep's work -- are the real run's; the callbacks' host round trips stand in for
-RCCL.  What the other ranks contribute is measured first, in two passes over every rank's share:
-  pass 1  the all-reduces (fragLen / ctrlFrag: exact fixed-point parts + flags) only depend on a rank's own events:
-          every rank's words are recorded, call by call;
-  pass 2  with the true sums replayed, every rank's part of the BH table (-q: the all-gather of {p bits, bp}) is
-          recorded -- it depends on lambda, hence on pass 1.
-Then the chosen rank is timed with both kinds of callback replaying the others' parts."""
+Every exchange of the library is an all-reduce in the callback mode (sums of words, or of disjoint regions of a zeroed
+buffer = concatenation, gx_api.hip: coll_concat / coll_alltoallv), so ONE callback stands for all of them: it adds what
+the OTHER ranks would contribute, call by call, and lambda, the factor, the splitters and the q-values -- and with them
+every kernel's work -- are the real run's.  What the other ranks contribute to call k can depend on the results of the
+calls before it (the closed form of fragLen -> lambda -> the BH tables -> the splitters -> the records sent), so the
+contributions are found by iteration: every rank's share is run with the others' words of the previous round until a
+round changes nothing (a handful of rounds).  Then the chosen rank is timed.  The callbacks' host round trips (a copy
+down, a synchronisation, a copy up per exchange; the whole exchange buffer for the all-to-all) stand in for RCCL in
+the wall time; the phases' device times are printed next to it, `bh.xfer` = the exchange buffers' trips to the host."""
 import ctypes as C
 import sys
 import time
@@ -68,33 +69,22 @@ def step(gx, dreps):
 
 
 class Replay:
-    """Collective callbacks of one rank: record its own contributions, add / append the others' (by call index)."""
+    """The all-reduce callback of one rank: record its own contribution, add the others' (by call index)."""
 
-    def __init__(self, red_others=None, gat_others=None):
-        self.red_others, self.gat_others = red_others, gat_others
-        self.red, self.gat = [], []
-        self.ri = self.gi = 0
+    def __init__(self, others=None):
+        self.others = others
+        self.red = []
+        self.ri = 0
 
     def begin(self):
-        self.red, self.gat, self.ri, self.gi = [], [], 0, 0
+        self.red, self.ri = [], 0
 
     def allreduce(self, buf, n, _user):
-        self.red.append([int(buf[i]) for i in range(n)])
-        if self.red_others is not None:
-            for i in range(n):
-                buf[i] += self.red_others[self.ri][i]
+        a = np.ctypeslib.as_array(buf, shape=(n,))
+        self.red.append(a.copy())
+        if self.others is not None and self.ri < len(self.others) and len(self.others[self.ri]) == n:
+            a += self.others[self.ri]
         self.ri += 1
-        return 0
-
-    def allgather(self, local, n_local, out, n_out, _user):
-        mine = C.string_at(local, n_local * 16) if n_local else b""
-        self.gat.append(mine)
-        cat = mine + (self.gat_others[self.gi] if self.gat_others is not None else b"")
-        self.gi += 1
-        mem = libc.malloc(max(16, len(cat)))
-        C.memmove(mem, cat, len(cat))
-        out[0] = mem
-        n_out[0] = len(cat) // 16
         return 0
 
 
@@ -103,47 +93,54 @@ def context(owned, rp, rank, world):
     gx.set_chroms(lens)
     gx.set_owned(owned)
     if world > 1:
-        gx.set_collectives(rank, world, rp.allreduce, rp.allgather)
+        gx.set_collectives(rank, world, rp.allreduce, None)
     return gx
 
 
 def others_sum(recs, rank):
-    """per call: the sum over the other ranks of the words they handed to the all-reduce"""
-    calls = len(recs[0])
-    return [[sum(recs[r][k][i] for r in range(len(recs)) if r != rank) for i in range(len(recs[0][k]))] for k in range(calls)]
+    """per call: the sum over the other ranks of the words they handed to the all-reduce (None before the first round)"""
+    if any(r is None for r in recs):
+        return None
+    calls = min(len(r) for r in recs)
+    out = []
+    for k in range(calls):
+        n = len(recs[rank][k]) if k < len(recs[rank]) else -1
+        if any(len(recs[r][k]) != n for r in range(len(recs))):
+            break  # (the ranks are not yet in step at this call: a later round)
+        out.append(sum(recs[r][k] for r in range(len(recs)) if r != rank))
+    return out
 
 
-def others_cat(recs, rank):
-    calls = len(recs[0])
-    return [b"".join(recs[r][k] for r in range(len(recs)) if r != rank) for k in range(calls)]
+def same(a, b):
+    return a is not None and b is not None and len(a) == len(b) and all(len(x) == len(y) and np.array_equal(x, y) for x, y in zip(a, b))
 
 
 for spec in worlds:
     world, rank = (int(x) for x in (spec.split(":") + ["0"])[:2])
     owner = lpt_partition(lens, world)
     owneds = [np.array([o == r for o in owner], dtype=np.uint8) for r in range(world)]
-    red, gat = [None] * world, [None] * world
+    red = [None] * world
     if world > 1:
-        for r in range(world):  # pass 1: the all-reduce words
-            rp = Replay()
-            gx = context(owneds[r], rp, r, world)
-            d = share(owneds[r])
-            rp.begin()
-            step(gx, d)
-            red[r] = rp.red
-            gx.close()
-            del d
-        if cfg["qval"]:
-            for r in range(world):  # pass 2: the BH tables, under the true lambda
+        for rnd in range(12):
+            new = [None] * world
+            for r in range(world):
                 rp = Replay(others_sum(red, r))
                 gx = context(owneds[r], rp, r, world)
                 d = share(owneds[r])
                 rp.begin()
-                step(gx, d)
-                gat[r] = rp.gat
+                try:
+                    step(gx, d)
+                except RuntimeError:  # (a round with stale words of the others may fail an internal check: the next one has better ones)
+                    pass
+                new[r] = rp.red
                 gx.close()
                 del d
-    rp = Replay(others_sum(red, rank) if world > 1 else None, others_cat(gat, rank) if world > 1 and cfg["qval"] else None)
+            done = all(same(a, b) for a, b in zip(red, new))
+            red = new
+            if done:
+                break
+        print(f"  ({world} ranks: the others' words settled after {rnd + 1} rounds, {len(red[0])} exchanges per step)", flush=True)
+    rp = Replay(others_sum(red, rank) if world > 1 else None)
     d_reps = share(owneds[rank])
     gx = context(owneds[rank], rp, rank, world)
 
