@@ -183,7 +183,8 @@ struct gx_ctx {
   bool sawFrac = false;         // a sample of this context held fractional weights: k_sbtile is not tried again
   bool fusedOff = false;        // this sample: a super-bucket did not fit k_sbtile (the general chain runs instead)
   bool fusedUsed = false;       // the last build went through k_sbtile
-  bool pairsUsed = false;       // ... on level 1's pair records (k_sort1p)
+  bool pairsUsed = false;       // ... on level 1's pair records (k_sort_a / k_sort_b)
+  bool fracPairsUsed = false;   // ... with a weight class per record (fractional weights)
   bool earlyColl = false;       // this build: the ranks exchange the closed form of fragLen ahead of the tile stage
   bool earlyOwed = false;       // ... and this rank has not taken part in that all-reduce yet (poison_allreduce)
   bool earlyPending = false;
@@ -595,7 +596,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                          getenv("GX_NO_EARLY_COLL") == nullptr;
   ctx->earlyColl = earlyColl;
   ctx->earlyOwed = earlyColl;
-  const bool wantEarly = !isCtrl && (!multiRank || earlyColl) && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag;
+  const bool wantEarly = !isCtrl && (!multiRank || earlyColl) && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag &&
+                         !ctx->sawFrac;  // (fractional weights: the closed form of fragLen is off, lambda only comes with the sample's end)
   const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
   u64* sigMask = nullptr;
   if (wantEarly) {
@@ -694,13 +696,20 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // next replicate, or the next run on the same data, has the same pile-ups)
   const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
   if (backoff) ctx->fusedBackoff[isCtrl ? 1 : 0]--;
-  const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && !ctx->sawFrac && !ctx->fusedOff &&
-                     !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 26000 &&
+  const bool pairsAllowed = getenv("GX_NO_PAIRS") == nullptr;
+  static const bool onePass = getenv("GX_SORT_ONE_PASS") != nullptr;  // (measurements: k_sort1p instead of k_sort_a + k_sort_b)
+  // (fractional weights ride the pair records -- k_sort_a<true>, k_sbtile<.., true> -- once a sample of this context has
+  // shown one; the start / end keys of the other fused variant cannot carry a weight)
+  const bool fracOk = pairsAllowed && !onePass && getenv("GX_NO_FRAC_PAIRS") == nullptr;
+  const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && (!ctx->sawFrac || fracOk) &&
+                     !ctx->fusedOff && !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 64000 &&
                      (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
   ctx->fusedUsed = fused;
-  // ... and with it level 1: one record per fragment (k_sort1p) when k_sbtile will read it
-  const bool pairs = fused && !reuseSort && getenv("GX_NO_PAIRS") == nullptr;
+  // ... and with it level 1: one record per fragment (k_sort_a / k_sort_b) when k_sbtile will read it
+  const bool pairs = fused && !reuseSort && pairsAllowed;
+  const bool fracPairs = pairs && ctx->sawFrac;
   ctx->pairsUsed = pairs;
+  ctx->fracPairsUsed = fracPairs;
 
   phase_begin(ctx, isCtrl ? "c.sort1" : "t.sort1");
   // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
@@ -715,7 +724,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                          NXCD * nL1};
   }
   Sort1Out so1{ff->fragSum, slowFrag, ctx->endAtLen.as<u32>(), ctx->nWide.as<u32>() + 1};
-  static const bool onePass = getenv("GX_SORT_ONE_PASS") != nullptr;  // (measurements: k_sort1p instead of k_sort_a + k_sort_b)
   PagedStream pcLast{};
   u32 ncLast = 0, gridB = 0;
   for (auto& seg : segs) {
@@ -735,8 +743,12 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       HIPCHECK(ctx->poolC.ensure((size_t)pagesC * PG_BYTES));
       HIPCHECK(ctx->auxC.ensure((size_t)pagesC << PgCfg<u32>::SHIFT));
       PagedStream PC{ctx->poolC.p, ctx->ptC.as<u32>(), ctx->curC.as<u32>(), ctx->curC.as<u32>() + nListsC, jmaxC, pagesC, nListsC};
-      hipLaunchKernelGGL(k_sort_a, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, ctx->sbShift,
-                         nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
+      if (fracPairs)
+        hipLaunchKernelGGL(k_sort_a<true>, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, ctx->sbShift,
+                           nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
+      else
+        hipLaunchKernelGGL(k_sort_a<false>, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, ctx->sbShift,
+                           nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
       pcLast = PC;
       ncLast = nCoarse;
       gridB = NXCD * (perClass + nCoarse);   // (a class's lists hold at most its chunks' + one partly filled page each)
@@ -856,7 +868,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   TileIn tin{SS.a.as<uint16_t>(), SE.a.as<uint16_t>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
   // the tile stage is k_tile_fast (+ k_tile_heavy): the general fragLen path's terms ride in it (TileIn::fragAcc)
   static const bool noFragFuse = getenv("GX_FRAG_WALK_ALL") != nullptr;  // (tests / measurements: round 2's separate walk)
-  ctx->fragFused = !fused && !ctx->hasBed && !getenv("GX_TILE_OLD") && !noFragFuse;
+  ctx->fragFused = (!fused && !ctx->hasBed && !getenv("GX_TILE_OLD") && !noFragFuse) || ctx->fracPairsUsed;
   if (ctx->fragFused) {
     tin.ff = ff;
     tin.fragAcc = acc;
@@ -869,27 +881,38 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   if (fused) {
     // level 2 of the sort and the tile passes in one kernel, one workgroup per super-bucket (gx_sbtile.h)
     if (!ctx->sbtLdsSet) {
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sizeof(SbtLds)));
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sizeof(SbtLds)));
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sizeof(SbtLds)));
+      for (const void* f : {reinterpret_cast<const void*>(k_sbtile<false, false, false>), reinterpret_cast<const void*>(k_sbtile<true, false, false>),
+                            reinterpret_cast<const void*>(k_sbtile<true, true, false>), reinterpret_cast<const void*>(k_sbtile<true, false, true>),
+                            reinterpret_cast<const void*>(k_sbtile<true, true, true>)})
+        HIPCHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbtLds)));
       ctx->sbtLdsSet = true;
     }
     HIPCHECK(ctx->bigBins.ensure((size_t)(MAX_BINS + 4) * 4));
     SbtIn si{PG3[0], PG3[1], PG3[2], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
-             ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, ctx->sbShift};
+             ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, ctx->sbShift,
+             ctx->fracPairsUsed ? (const FragFix*)ff : (const FragFix*)nullptr, ctx->fracPairsUsed ? acc : (long long*)nullptr};
     SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>(), ctx->nWide.as<u32>() + 1, ctx->nWide.as<u32>() + 13,
-               ctx->bigBins.as<u32>()};
-    if (ctx->pairsUsed) {
-      hipLaunchKernelGGL((k_sbtile<true, false>), dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+               ctx->bigBins.as<u32>(), ctx->heavyList.as<u32>(), ctx->nWide.as<u32>() + 2};
+    const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
+    // a sample so dense that the average bin already holds more keys than the key array (ATAC cut sites of a deep
+    // library): every bin takes the rounds of the second launch, the first one would only find that out bin by bin
+    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 4);
+    if (dense) {
+      so2.bigList = nullptr;
+      if (ctx->fracPairsUsed)
+        hipLaunchKernelGGL((k_sbtile<true, true, true>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+      else
+        hipLaunchKernelGGL((k_sbtile<true, true, false>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+    } else if (ctx->fracPairsUsed) {
+      hipLaunchKernelGGL((k_sbtile<true, false, true>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<true, true, true>), gBig, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+    } else if (ctx->pairsUsed) {
+      hipLaunchKernelGGL((k_sbtile<true, false, false>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
       // the bins it left on its list (reads piled up: more keys than the key array holds, a tile with thousands of keys):
       // usually none -- an idle launch
-      hipLaunchKernelGGL((k_sbtile<true, true>), dim3(std::max(1u, std::min(nL1, (u32)ctx->numCU))), dim3(SBT_NT), sizeof(SbtLds), s, si, so2,
-                         ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<true, true, false>), gBig, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
     } else
-      hipLaunchKernelGGL((k_sbtile<false, false>), dim3(std::max(1u, nL1)), dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<false, false, false>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
   } else if (ctx->hasBed) {
     hipLaunchKernelGGL((k_tile<true, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
@@ -1110,8 +1133,12 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
   if (again >> 32) {
     // k_sbtile could not take some rank's sample (a bin beyond its LDS, or fractional weights): once more, on the
     // general chain
+    // (fractional weights in a unit-weight build: its singles may also have overfilled a bin -- that says nothing about
+    // the next sample, which writes pair records with a weight class)
+    if (getenv("GX_DEBUG_RETRY")) fprintf(stderr, "[gx] sample sent back to the general chain: status %u (fused %d pairs %d frac %d)\n",
+                                          ctx->mail->status, (int)ctx->fusedUsed, (int)ctx->pairsUsed, (int)ctx->fracPairsUsed);
     if (ctx->mail->status & ST_SB_FRAC) ctx->sawFrac = true;
-    if (ctx->mail->status & ST_SB_FULL) ctx->fusedBackoff[isCtrl ? 1 : 0] = 8;
+    else if (ctx->mail->status & ST_SB_FULL) ctx->fusedBackoff[isCtrl ? 1 : 0] = 8;
     ctx->fusedOff = true;
     ctx->fellBack = true;
     static_cast<RiskBuf*>(ctx->riskHost.p)->count = 0;

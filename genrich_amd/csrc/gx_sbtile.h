@@ -40,8 +40,6 @@ namespace gx {
 #ifndef GX_EXP_SBT
 #define GX_EXP_SBT 0
 #endif
-constexpr u32 ST_SB_FULL = 1024u;  // (internal) a super-bucket does not fit k_sbtile: the host takes the general chain
-constexpr u32 ST_SB_FRAC = 2048u;  // (internal) the sample holds fractional-weight records: likewise, and for good
 
 constexpr int SBT_NT = 1024;
 constexpr int SBT_NW = SBT_NT / 64;
@@ -90,6 +88,7 @@ struct SbtLds {
   u32 nRounds;
   u32 nHeavy;                              // tiles of the round that the whole workgroup takes (sbt_heavy)
   uint16_t heavy[SBT_TILES];
+  int netW[SBT_TILES];                     // fractional pairs: weight (1/120) a tile hands on (ends it receives count negative)
   u32 vsRed[2];                            // loose_vsig's reduction words (its own: tid 0 initialises the others right after)
 };
 
@@ -104,6 +103,8 @@ struct SbtIn {
   const int* chromW0;         // [nChrom] weight (1/120) of the ends dropped at the ends of the chromosomes before
   u32 nSeg, nTiles;
   int sbShift;
+  const FragFix* ff;          // fractional pairs: the general fragLen path's switch and accumulator pair (k_tile_fast's TileIn::ff / fragAcc)
+  long long* fragAcc;
 };
 
 struct SbtOut {
@@ -113,6 +114,8 @@ struct SbtOut {
   u32* hot;                   // set when a tile holds enough starts (or ends) for a base to reach the reference's int16 limits
   u32* nBig;                  // pair mode: the bins left to the second launch (k_sbtile<true, true>), and how many
   u32* bigList;
+  u32* heavyList;             // fractional pairs: the tiles sbt_heavy took (k_frag_walk adds their fragLen terms), and how many
+  u32* nHeavyG;
 };
 
 // LDS operations of ONE wavefront execute in order; what is needed between a wavefront's phases is only that
@@ -139,8 +142,28 @@ __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
 // Lanes without a key carry SBT_NOKEY instead of sitting out: their bit goes to a dummy bitmap word and their rank
 // (the dummy prefix entry: 0xFFFF) lies outside every round, so the three passes over the register-held keys run
 // without per-lane predicates.
+// FRAC (fractional pair records, k_sort_a<true>): a key carries its weight class in [14:12] -- weight 120 / count for
+// count 1, 2, 3, 4, 5, 6, 8, 10 -- so "no key" moves to bit 16 of the register; with the general fragLen path on
+// (FragFix::slow) the tile also adds the exact term of every interval but its first to fhi / flo, as k_tile_fast does.
+constexpr u32 SBT_NOKEY_F = 0x10000u;
+__device__ __forceinline__ int sbt_weight(u32 key) {  // 1/120 units, signed: [14:12] class, [15] end
+  const int w = (int)((0x0C0F14181E283C78ull >> (8 * ((key >> 12) & 7u))) & 0xFFu);
+  return (key & 0x8000u) ? -w : w;
+}
+__device__ __forceinline__ u32 sbt_class_of(int w) {  // weight (> 0) -> class; 8: not one of the eight
+  u32 c = 8;
+#pragma unroll
+  for (u32 k = 0; k < 8; k++) c = (int)((0x0C0F14181E283C78ull >> (8 * k)) & 0xFFu) == w ? k : c;
+  return c;
+}
+
+template <bool FRAC>
 __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
-                                         int carry, u32 slot, int vsig, const SbtOut& out, u32& bad) {
+                                         int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms, long long& fhi,
+                                         long long& flo) {
+  constexpr u32 NOKEY = FRAC ? SBT_NOKEY_F : SBT_NOKEY;
+  // a key's offset with "no key" at 4096 (the dummy bitmap word)
+  auto offOf = [](u32 key) -> u32 { return FRAC ? (key & (TILE - 1)) | ((key >> 4) & (u32)TILE) : key & (2 * TILE - 1); };
   u32* occ = reinterpret_cast<u32*>(lds);
   u32* pre = reinterpret_cast<u32*>(lds + SBT_OCCW);
   const uint16_t* pre16 = reinterpret_cast<const uint16_t*>(pre);
@@ -156,19 +179,19 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   for (int q = 0; q < KR; q++) {
 #if GX_SBT_KNOBS & 4
     const u32 v = kl[lane + q * 64];  // (in bounds: the key array has 192 entries of slack)
-    kr[q] = (u32)lane + q * 64 < n ? v : SBT_NOKEY;
+    kr[q] = (u32)lane + q * 64 < n ? v : NOKEY;
 #else
-    kr[q] = SBT_NOKEY;
+    kr[q] = NOKEY;
     if ((u32)lane + q * 64 < n) kr[q] = kl[lane + q * 64];
 #endif
   }
   // ---- A1: keys -> occupancy bitmap
-  auto mark = [&](u32 key) { const u32 off = key & (2 * TILE - 1); atomicOr(&occ[off >> 5], 1u << (off & 31)); };
+  auto mark = [&](u32 key) { const u32 off = offOf(key); atomicOr(&occ[off >> 5], 1u << (off & 31)); };
   // (predicated after all: the lanes without a key would all hit the one dummy word, and same-address LDS atomics
   // serialise -- measured 0.71 -> 0.81 ms for the kernel)
 #pragma unroll
   for (int q = 0; q < KR; q++)
-    if (kr[q] != SBT_NOKEY) mark(kr[q]);
+    if (kr[q] != NOKEY) mark(kr[q]);
   for (u32 k = KR * 64 + lane; k < n; k += 64) mark(kl[k]);
   wave_lds_sync();
   // ---- B: touched bases before each bitmap word
@@ -184,7 +207,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   u32 outCount = 0, lastEnd = 0;
   u64 negM = 0, bigM = carry >= FRAG_FAST_MAXV ? ~0ull : 0ull;
   auto rankOf = [&](u32 key) -> u32 {
-    const u32 off = key & (2 * TILE - 1), wi = off >> 5;
+    const u32 off = offOf(key), wi = off >> 5;
     return (u32)pre16[wi] + (u32)__popc(occ[wi] & ((1u << (off & 31)) - 1u));
   };
   u32 rr[KR];
@@ -197,7 +220,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
       r -= r0;
       if (r < (u32)TR_CAP) {
         list[r] = (uint16_t)(key & (TILE - 1));
-        atomicAdd(&cnt[r], (key & 0x8000u) ? -GX_UNIT : GX_UNIT);
+        atomicAdd(&cnt[r], FRAC ? sbt_weight(key) : ((key & 0x8000u) ? -GX_UNIT : GX_UNIT));
       }
     };
 #pragma unroll
@@ -233,6 +256,14 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
       negM |= __ballot(after < 0);
       bigM |= __ballot(after >= FRAG_FAST_MAXV);
       runBase += __builtin_amdgcn_readlane(incS, 63);
+      if (FRAC && fragTerms && mask) {  // wave-uniform
+        // the interval that ends here starts at the end before it: the lane's, the steps', or -- the tile's first
+        // interval -- somewhere before the tile (k_scan_iv adds that one: it knows where)
+        const u64 below = mask & ((1ull << lane) - 1ull);
+        const int prevLane = below ? 63 - __builtin_clzll(below) : 0;
+        const u32 pp = (u32)__shfl((int)p, prevLane, 64);
+        if (nz && (below || outCount)) frag_term(pos0 + p - (below ? pos0 + pp : lastEnd), before, fhi, flo);
+      }
       if (mask) {  // wave-uniform
         outCount += (u32)__popcll(mask);
         lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(mask));
@@ -249,6 +280,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
         out.to.looseEnd[o] = len;
         out.to.looseV[o] = runBase;
         if (runBase >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[o >> 6], 1ull << (o & 63));
+        if (FRAC && fragTerms && outCount) frag_term(len - lastEnd, runBase, fhi, flo);  // (the tile's first interval: k_scan_iv)
         lastEnd = len;
       }
       if (total) out.to.tileLastEnd[t] = lastEnd;
@@ -277,8 +309,10 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
 // base, as k_tile_heavy does on the general chain -- one wavefront walking 30,000 keys in rounds of 192 touched bases held
 // its workgroup, and the kernel, for a millisecond.  The counters take the place of the wavefronts' scratch (all of
 // them are through with their tiles); every thread owns four consecutive bases.  Same outputs as sbt_tile.
+// (FRAC with the general fragLen path on: the tile goes on the list of the heavy tiles, whose terms k_frag_walk adds)
+template <bool FRAC>
 __device__ __forceinline__ void sbt_heavy(SbtLds& L, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
-                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad) {
+                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms) {
   static_assert(SBT_NW * SBT_TW >= TILE, "the counters fit the wavefronts' scratch");
   static_assert(TILE == SBT_NT * 4, "four bases per thread");
   int* cnt = &L.tile[0][0];
@@ -288,7 +322,7 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const uint16_t* __restrict_
   __syncthreads();
   for (u32 k = tid; k < n; k += SBT_NT) {
     const u32 key = kl[k];
-    atomicAdd(&cnt[key & (TILE - 1)], (key & 0x8000u) ? -GX_UNIT : GX_UNIT);
+    atomicAdd(&cnt[key & (TILE - 1)], FRAC ? sbt_weight(key) : ((key & 0x8000u) ? -GX_UNIT : GX_UNIT));
   }
   __syncthreads();
   const int4 d4 = *reinterpret_cast<const int4*>(cnt + tid * 4);
@@ -356,6 +390,7 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const uint16_t* __restrict_
     }
   }
   if (tid == 0) out.to.tileCount[t] = total;
+  if (FRAC && fragTerms && tid == 0) out.heavyList[atomicAdd(out.nHeavyG, 1u)] = t;
   if (total && vsig != 0x7FFFFFFF)  // the unused slots: zero-length intervals behind the last one (the sweep walks the loose slots)
     for (u32 j = total + tid; j < n + 1; j += SBT_NT) {
       out.to.looseEnd[slot + j] = lastEnd;
@@ -371,9 +406,13 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const uint16_t* __restrict_
 // array holds (worked off in rounds of tiles), a tile with thousands of keys (sbt_heavy: the whole workgroup), more than
 // 32 K pair records.  It keeps no record in registers (every pass reads the bin's slots from global memory: they are
 // in L2), so that none of this costs the first launch -- the one every bin of an ordinary sample takes -- a register.
-template <bool PAIRS, bool BIG>
+template <bool PAIRS, bool BIG, bool FRAC>
 __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32* __restrict__ st, const u32 seg, SbtLds& L) {
   static_assert(PAIRS || !BIG, "the second launch exists in pair mode only");
+  static_assert(PAIRS || !FRAC, "fractional weights ride pair records only");
+  constexpr u32 LENB = FRAC ? 9u : PAIR_LEN_BITS;      // a pair record's length bits (fractional: [11:9] the weight class)
+  const bool fragTerms = FRAC && in.fragAcc != nullptr && (u32)__builtin_amdgcn_readfirstlane((int)in.ff->slow) != 0u;
+  long long fhi = 0, flo = 0;
   constexpr int K = BIG ? 0 : (PAIRS ? SBT_KP : SBT_K);   // slots per wavefront of the (first) stream held in registers
   constexpr int KX = BIG ? SBT_KX : K;                    // ... and in all
   constexpr int KR = K ? K : 1;                           // (array sizes)
@@ -385,7 +424,10 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, !BIG && seg == 0 && tid == 0, L.vsRed));
   // scratch and tables start at zero
   for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
-  if (tid < SBT_TILES) L.hist[tid] = 0;
+  if (tid < SBT_TILES) {
+    L.hist[tid] = 0;
+    if (FRAC) L.netW[tid] = 0;
+  }
   if (tid == 0) { L.overflow = 0; L.nHeavy = 0; }
   __syncthreads();
   if (tid < SBT_NW) L.tile[tid][SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
@@ -490,11 +532,23 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   // the counts are wave-uniform)
   // (pair record: [31:12] start within the bin, [11:0] length; both ends lie in this bin)
   auto pairTs = [](u32 r) -> u32 { return r >> (PAIR_LEN_BITS + TB); };
-  auto pairEnd = [](u32 r) -> u32 { return (r >> PAIR_LEN_BITS) + (r & ((1u << PAIR_LEN_BITS) - 1u)); };
+  auto pairEnd = [](u32 r) -> u32 { return (r >> PAIR_LEN_BITS) + (r & ((1u << LENB) - 1u)); };
+  auto pairCls = [](u32 r) -> u32 { return FRAC ? ((r >> 9) & 7u) << 12 : 0u; };  // (where a key carries it)
+  auto fCls = [](u64 r) -> u32 {  // a single's weight class, where a key carries it
+    const int w = (int)(int8_t)(r & 0xFF);
+    return FRAC ? (sbt_class_of(w < 0 ? -w : w) & 7u) << 12 : 0u;
+  };
   auto histPair = [&](u32 r) {
     const u32 ts = pairTs(r), te = pairEnd(r) >> TB;
     atomicAdd(&L.hist[ts], ts == te ? 65537u : 1u);
-    if (ts != te) atomicAdd(&L.hist[te], 65536u);
+    if (ts != te) {
+      atomicAdd(&L.hist[te], 65536u);
+      if (FRAC) {  // (the pileup a tile hands on: only what starts in one tile and ends in another changes it)
+        const int w = sbt_weight(pairCls(r));
+        atomicAdd(&L.netW[ts], w);
+        atomicAdd(&L.netW[te], -w);
+      }
+    }
   };
   if (PAIRS) {
 #pragma unroll
@@ -521,9 +575,11 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       for (u32 i = tid; i < nF; i += SBT_NT) {
         const u64 r = srcF.at(i);
         const int w = (int)(int8_t)(r & 0xFF);
-        if (w == GX_UNIT || w == -GX_UNIT)
+        const bool ok = FRAC ? sbt_class_of(w < 0 ? -w : w) < 8u : (w == GX_UNIT || w == -GX_UNIT);
+        if (ok) {
           atomicAdd(&L.hist[(u32)(r >> 32) - segTileBase], w > 0 ? 1u : 65536u);
-        else
+          if (FRAC) atomicAdd(&L.netW[(u32)(r >> 32) - segTileBase], w);
+        } else
           L.overflow = 2;
       }
   } else if constexpr (!PAIRS) {
@@ -552,7 +608,8 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   {
     u32 h = tid < (int)nT ? L.hist[tid] : 0u;
     const u32 nS = h & 0xFFFFu, nE = h >> 16;
-    const u64 v = (u64)(nS + nE) | ((u64)(u32)((int)nS - (int)nE) << 32);
+    // (what the tiles before hand on: starts - ends in records; fractional pairs: the net weight itself)
+    const u64 v = (u64)(nS + nE) | ((u64)(u32)(FRAC ? (tid < (int)nT ? L.netW[tid] : 0) : (int)nS - (int)nE) << 32);
     u64 tot;
     const u64 ex = block_excl_scan<u64, SBT_NT>(v, reinterpret_cast<u64*>(L.scratch), &tot);
     if (tid < (int)nT) {
@@ -625,7 +682,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       TileMeta m;
       m.sb = 0; m.eb = 0; m.fb = 0;
       m.nS = nS; m.nE = nE; m.nF = 0;
-      m.carry = ovf ? 0 : segNet + GX_UNIT * L.netPref[tid] - (int)ti.w;
+      m.carry = ovf ? 0 : segNet + (FRAC ? 1 : GX_UNIT) * L.netPref[tid] - (int)ti.w;
       m.ci = 0;
       m.pos0 = ti.x; m.len = ti.y; m.flags = ti.z;
       m.slot = segSlot + sc + (u32)tid;
@@ -662,8 +719,8 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       }
       const uint4 tf = L.tinfo[b];
       const u32 sc = L.startC[b];
-      const int carry = segNet + GX_UNIT * L.netPref[b] - (int)tf.w;
-      sbt_tile(L.tile[wv], L.keys + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad);
+      const int carry = segNet + (FRAC ? 1 : GX_UNIT) * L.netPref[b] - (int)tf.w;
+      sbt_tile<FRAC>(L.tile[wv], L.keys + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad, fragTerms, fhi, flo);
     }
     if constexpr (BIG) {
     __syncthreads();  // (every wavefront is through with its tiles; the list of the heavy ones is complete)
@@ -674,8 +731,8 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         const u32 h = L.hist[b], n = (h & 0xFFFFu) + (h >> 16);
         const uint4 tf = L.tinfo[b];
         const u32 sc = L.startC[b];
-        const int carry = segNet + GX_UNIT * L.netPref[b] - (int)tf.w;
-        sbt_heavy(L, L.keys + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad);
+        const int carry = segNet + (FRAC ? 1 : GX_UNIT) * L.netPref[b] - (int)tf.w;
+        sbt_heavy<FRAC>(L, L.keys + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad, fragTerms);
       }
       // the wavefronts' scratch as the next round's tiles expect it
       for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
@@ -692,7 +749,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       // tile takes its two places with one atomic
       auto placePair = [&](u32 r) {
         const u32 e = pairEnd(r), ts = pairTs(r), te = e >> TB;
-        const u32 so = (r >> PAIR_LEN_BITS) & (TILE - 1), eo = (e & (TILE - 1)) | 0x8000u;
+        const u32 so = ((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r), eo = (e & (TILE - 1)) | 0x8000u | pairCls(r);
         const u32 ps = atomicAdd(&L.cur[ts], ts == te ? 2u : 1u);
         const u32 pe = ts == te ? ps + 1u : atomicAdd(&L.cur[te], 1u);
         L.keys[ps] = (uint16_t)so;
@@ -721,7 +778,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       for (u32 i = tid; i < nF; i += SBT_NT) {
         const u64 r = srcF.at(i);
         const u32 off = (u32)(r >> 8) & (TILE - 1);
-        L.keys[atomicAdd(&L.cur[(u32)(r >> 32) - segTileBase], 1u)] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u));
+        L.keys[atomicAdd(&L.cur[(u32)(r >> 32) - segTileBase], 1u)] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
       }
       __syncthreads();
       if (GX_EXP_SBT == 3) {
@@ -751,14 +808,14 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
           for (int j = 0; j < 4; j++)
             if ((u32)lane * 4 + j < c) {
               const u32 r = keyAt(v, j), e = pairEnd(r), ts = pairTs(r), te = e >> TB;
-              if (ts - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[ts], 1u) - keyBase] = (uint16_t)((r >> PAIR_LEN_BITS) & (TILE - 1));
-              if (te - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)((e & (TILE - 1)) | 0x8000u);
+              if (ts - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[ts], 1u) - keyBase] = (uint16_t)(((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r));
+              if (te - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)((e & (TILE - 1)) | 0x8000u | pairCls(r));
             }
         }
         for (u32 i = tid; i < nF; i += SBT_NT) {
           const u64 r = srcF.at(i);
           const u32 tl = (u32)(r >> 32) - segTileBase, off = (u32)(r >> 8) & (TILE - 1);
-          if (tl - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[tl], 1u) - keyBase] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u));
+          if (tl - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[tl], 1u) - keyBase] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
         }
         __syncthreads();
         tiles(tileEnd, keyBase);
@@ -798,19 +855,28 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   }
   tiles(nT, 0u);
   }
+  if (FRAC && fragTerms) {  // wave-uniform
+    fhi = wave_sum(fhi);
+    flo = wave_sum(flo);
+    if (lane == 0) {
+      if (fhi) atomicAdd((u64*)&in.fragAcc[0], (u64)fhi);
+      if (flo) atomicAdd((u64*)&in.fragAcc[1], (u64)flo);
+    }
+  }
   if (bad && lane == 0) atomicOr(st, bad);
 }
 
-template <bool PAIRS, bool BIG>
+template <bool PAIRS, bool BIG, bool FRAC>
 __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
   SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
   if constexpr (!BIG)
-    sbt_bin<PAIRS, false>(in, out, st, blockIdx.x, L);
+    sbt_bin<PAIRS, false, FRAC>(in, out, st, blockIdx.x, L);
   else {
-    const u32 nBig = *out.nBig;
+    // (no list: a sample so dense that most bins need rounds -- the host sends every bin here and skips the first launch)
+    const u32 nBig = out.bigList ? *out.nBig : in.nSeg;
     for (u32 item = blockIdx.x; item < nBig; item += gridDim.x) {  // (usually none)
-      sbt_bin<PAIRS, true>(in, out, st, out.bigList[item], L);
+      sbt_bin<PAIRS, true, FRAC>(in, out, st, out.bigList ? out.bigList[item] : item, L);
       __syncthreads();
     }
   }

@@ -29,6 +29,9 @@
 namespace gx {
 
 constexpr u32 ST_PT_FULL = 512u;  // page table row / page pool exhausted (internal: the host retries)
+constexpr u32 ST_SB_FULL = 1024u;  // (internal) a super-bucket does not fit k_sbtile: the host takes the general chain
+constexpr u32 ST_SB_FRAC = 2048u;  // (internal) the sample holds fractional-weight records: likewise -- and the context's next
+                                   // samples write pair records with a weight class (k_sort_a<true>)
 
 template <typename R> struct PgCfg { static constexpr int SHIFT = 12; };   // 4096 x 8 B
 template <> struct PgCfg<u32> { static constexpr int SHIFT = 13; };       // 8192 x 4 B
@@ -928,6 +931,10 @@ __device__ __forceinline__ void scatter64(const u32 (&rec)[S2_ITEMS], u32 (&ka)[
 
 // events -> pair records in the coarse bins' lists (+ the slow events' records straight to the fine F lists, as
 // k_sort1p does).  PC: the coarse lists, [NXCD][nCoarse]; its page-table rows hold every page a class can fill.
+// FRAC: fractional weights ride along -- [11:9] of a record is the weight class (count 1, 2, 3, 4, 5, 6, 8, 10 -> 0 .. 7),
+// the length keeps 9 bits (cut-site intervals and most fragments are shorter than 512 bases; the others are singles).
+// A context switches to it once a sample has shown a fractional weight (gx_api.hip: sawFrac).
+template <bool FRAC>
 __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* __restrict__ ev, u32 n, const DChrom* __restrict__ chroms,
                                                      u32 nChrom, int sbShift, u32 nBins, u32 nCoarse, PagedStream PC,
                                                      uint8_t* __restrict__ auxPool, PagedStream PF, int* __restrict__ binNet,
@@ -938,7 +945,7 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
   const u32 x = blockIdx.x % NXCD;
   const u32 begin = blockIdx.x * S2_CHUNK;
   const u32 binMask = (1u << sbShift) - 1u;
-  u32 bad = 0, slow = 0;
+  u32 bad = 0, slow = 0, fracSeen = 0;
   u32 covered32 = 0;  // (sixteen lengths below 2^12)
   u32 rec[S2_ITEMS], ka[S2_ITEMS];
   if (threadIdx.x < S2_KEYS) L.cnt[threadIdx.x] = 0;
@@ -965,16 +972,22 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
     for (int q = 0; q < S2_BATCH; q++) {
       const u32 ci = min(e[q].x, nChrom - 1);
       const DChrom c = chromLds ? lchrom[ci] : chroms[ci];
-      const bool ok1 = have[q] && e[q].w == 1u && e[q].x < nChrom;
+      const u32 cnt = e[q].w;
+      const bool cntOk = FRAC ? (cnt <= 10u && ((0x57Eu >> cnt) & 1u)) : cnt == 1u;
+      const bool ok1 = have[q] && cntOk && e[q].x < nChrom;
       const bool act = chrom_active(c);
       const u32 len = e[q].z - e[q].y;
       const u32 t0 = c.tileBase + (e[q].y >> TB), t1 = c.tileBase + (e[q].z >> TB);
       const u32 bin = t0 >> sbShift;
-      const bool fast = ok1 && act && e[q].z < c.len && len - 1u < (1u << PAIR_LEN_BITS) - 1u && e[q].y < e[q].z && (t1 >> sbShift) == bin;
+      constexpr u32 LENB = FRAC ? 9u : PAIR_LEN_BITS;
+      const bool fast = ok1 && act && e[q].z < c.len && len - 1u < (1u << LENB) - 1u && e[q].y < e[q].z && (t1 >> sbShift) == bin;
       const bool nothing = !have[q] || (ok1 && !act);
-      rec[k0 + q] = fast ? ((((t0 & binMask) << TB) | (e[q].y & (TILE - 1))) << PAIR_LEN_BITS) | len : NULL32;
+      // (the weight class of a count: a nibble per count)
+      const u32 cls = FRAC ? (u32)((0x70605432100ull >> (4u * (cnt & 15u))) & 7ull) << 9 : 0u;
+      fracSeen |= (u32)(FRAC && fast && cnt != 1u);
+      rec[k0 + q] = fast ? ((((t0 & binMask) << TB) | (e[q].y & (TILE - 1))) << PAIR_LEN_BITS) | cls | len : NULL32;
       ka[k0 + q] = (bin >> S2_FINE_SHIFT) | ((bin & ((1u << S2_FINE_SHIFT) - 1u)) << 8);
-      covered32 += fast ? len : 0u;
+      covered32 += fast && cnt == 1u ? len : 0u;
       slow |= (u32)(!fast && !nothing) << (k0 + q);
     }
     __builtin_amdgcn_sched_barrier(0);  // (the next batch's loads stay behind this one's conversion: registers)
@@ -996,7 +1009,10 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
         const Endpoints p = convert_event<true>(e, chroms[min(e.x, nChrom - 1)], true, nChrom, out, bad, covered);
         mine = p.w != 0;  // (else: an event that only raised a status bit, or one without effect)
         if (mine) {
-          if (p.w != GX_UNIT) atomicOr(out.slowFrag, 1u);  // (a fractional weight: k_sbtile will turn the sample away)
+          if (p.w != GX_UNIT) {
+            atomicOr(out.slowFrag, 1u);
+            if (!FRAC) atomicOr(st, ST_SB_FRAC);  // (unit-weight pair records: this sample goes to the general chain)
+          }
           r0 = make_rec64(p.t0, p.o0, p.w);
           l0 = x * nBins + (p.t0 >> sbShift);
           atomicAdd(&binNet[p.t0 >> sbShift], p.w);
@@ -1013,6 +1029,7 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
     }
   }
   if (bad) atomicOr(st, bad);
+  if (FRAC && __ballot(fracSeen != 0) && lane_id() == 0) atomicOr(out.slowFrag, 1u);  // (the closed form of fragLen is off)
   covered = wave_sum(covered);
   if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 8 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
 }

@@ -105,7 +105,25 @@ def test_a_super_bucket_beyond_the_lds_goes_back_to_the_general_chain():
     assert flags & LOOSE  # (the general chain's tile kernel writes the sweep's bits too)
 
 
-def test_fractional_weights_go_back_to_the_general_chain_for_good():
+def test_fractional_weights_ride_the_pair_records_from_the_second_sample_on():
+    """The first sample with a fractional weight is turned away by the fused kernel (unit-weight records) and built on the
+    general chain; the context then writes pair records with a weight class and the next samples stay fused."""
+    lens = [300_000, 70_001]
+    ev = synth.add_multimap(synth.make_fragments(lens, 60_000, 31, peak_every=20_000, tower_every=150_000), lens, 0.3, 32)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None), dict(save=None, treat=ev[::2].copy(), ctrl=None),
+                                       dict(save=None, treat=ev[1::2].copy(), ctrl=None)])
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    sh = B.run_case(h, case)
+    flags = h.path_info()
+    assert_same_run(o, h, so, sh, case)
+    assert flags & FELL_BACK and flags & FUSED and flags & 16 and not flags & LOOSE
+
+
+def test_fractional_weights_without_pair_records_stay_on_the_general_chain(monkeypatch):
+    monkeypatch.setenv("GX_NO_FRAC_PAIRS", "1")
     lens = [300_000, 70_001]
     ev = synth.add_multimap(synth.make_fragments(lens, 60_000, 31, peak_every=20_000, tower_every=150_000), lens, 0.3, 32)
     case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None), dict(save=None, treat=ev[::2].copy(), ctrl=None)])
@@ -117,6 +135,24 @@ def test_fractional_weights_go_back_to_the_general_chain_for_good():
     flags = h.path_info()
     assert_same_run(o, h, so, sh, case)
     assert flags & FELL_BACK and not flags & FUSED and not flags & LOOSE
+
+
+def test_fractional_pairs_atac_geometry_towers_and_a_dense_sample():
+    """ATAC cut sites with -s weights on the fractional pair records: heavy tiles (a tower: the whole workgroup), bins
+    beyond the key array (rounds), and a sample dense enough for the all-bins launch -- bits of the oracle everywhere."""
+    lens = [200_000, 90_000]
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    warm = synth.add_multimap(synth.make_fragments(lens, 2_000, 5), lens, 0.5, 6)
+    tr = synth.make_fragments(lens, 70_000, 41, peak_every=20_000, tower_every=70_000, frac_tower=0.25)
+    tr = synth.atac_events(synth.add_multimap(tr, lens, 0.25, seed=42), lens, d=100)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=warm, ctrl=None), dict(save=None, treat=tr, ctrl=None)])
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    sh = B.run_case(h, case)
+    flags = h.path_info()
+    assert_same_run(o, h, so, sh, case)
+    assert flags & FUSED and flags & 16
 
 
 def test_tiles_without_intervals_and_unsaved_chromosomes_under_the_loose_sweep():
