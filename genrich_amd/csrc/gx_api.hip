@@ -2329,10 +2329,21 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     HIPCHECK(ctx->fisherCache.ensure(((size_t)16 << MN_GLOBAL_LOG)));
     HIPCHECK(hipMemsetAsync(ctx->fisherCache.p, 0, (size_t)16 << MN_GLOBAL_LOG, s));
     int mnBlocks = 0;
+    if (nr <= MNW_MAXREP && !getenv("GX_MERGEN_OLD")) {
+      // one wavefront per tile (no workgroup barrier in the tile loop, twenty tiles in flight per CU)
+      const size_t ldsw = mergeNw_lds_bytes((int)nr);
+      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+      HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN_w, MNW_NW * 64, ldsw));
+      const u32 want = (nTiles + MNW_NW - 1) / MNW_NW;
+      hipLaunchKernelGGL(k_mergeN_w, dim3(std::max(1u, std::min(want, (u32)(std::max(1, mnBlocks) * ctx->numCU)))), dim3(MNW_NW * 64), ldsw, s, S,
+                         ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
+                         ctx->dRisk.as<RiskBuf>(), ctx->fisherCache.as<uint4>());
+    } else {
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN, MG_NT, lds));
     hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(std::max(1, mnBlocks) * ctx->numCU))), dim3(MG_NT), lds, s, S,
                        ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
                        ctx->dRisk.as<RiskBuf>(), ctx->fisherCache.as<uint4>());
+    }
     if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
     const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
     HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));

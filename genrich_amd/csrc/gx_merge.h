@@ -608,7 +608,10 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
           out.p[o] = e.p;
           continue;
         }
-        {  // the device-wide table
+#ifndef GX_EXP_MN   // measurement hook (tools/build_variant.sh -DGX_EXP_MN=n): 1 no device-wide table, 2 no Fisher evaluation, 3 both
+#define GX_EXP_MN 0
+#endif
+        if (!(GX_EXP_MN & 1)) {  // the device-wide table
           const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ ((u32)df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
           const uint4 g = gcache[hg];
           if (g.x == lo && g.y == hi && g.w == (mn_mix(lo, hi, g.z) | (u32)df)) {
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
           const double sum = missSum[j];
           df = missDf[j];
           bool risky = false;
-          pv = pval_round(fisher_double(sum, (int)df), &risky);
+          pv = (GX_EXP_MN & 2) ? (float)sum : pval_round(fisher_double(sum, (int)df), &risky);
           const u32 i = missI[j];
           out.p[slot + r0 + i] = pv;
           if (risky) risk_add(risk, RK_FISHER, t, r0 + i, df, sum);
@@ -643,8 +646,10 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
           enter = !risky;
           if (enter) {
             atomicMax(&owner[h], j + 1);
+            if (!(GX_EXP_MN & 1)) {
             const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ (df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
             gcache[hg] = make_uint4(lo, hi, __float_as_uint(pv), mn_mix(lo, hi, __float_as_uint(pv)) | df);
+            }
           }
         }
         __syncthreads();
@@ -658,6 +663,205 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
       __syncthreads();
     }
     if (lastTile && threadIdx.x == 0) {  // closing interval [.., len)
+      double sum = 0.0;
+      int df = 0;
+      for (int r = 0; r < n; r++) {
+        if (!S.r[r].present[ci]) continue;
+        const float pv = S.r[r].p[S.r[r].tileOff[t + 1] - 1];
+        if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
+      }
+      const u32 oc = slot + tU;
+      out.end[oc] = c.len;
+      bool risky = false;
+      out.p[oc] = fisher_combine(sum, df, &risky);
+      if (risky) risk_add(risk, RK_FISHER, t, tU, (u32)df, sum);
+    }
+  }
+  if (bad) atomicOr(st, bad);
+}
+
+// ---- the same merge, ONE WAVEFRONT per tile -----------------------------------------------------------------------------
+// k_mergeN spends its time waiting (SQ counters, config 5: the waves wait 82 % of their cycles, VALU active 6 %; with the
+// Fisher evaluation compiled out it still takes 7.5 of its 7.8 ms): a tile is ~20 workgroup barriers and three dependent
+// memory round trips, for two wavefronts, four of them per SIMD.  Here a wavefront owns a tile -- every lane two
+// bitmap words per replicate, the prefix sums are DPP scans, the phases are ordered by the wavefront's own program
+// order (wave_lds_sync: no barrier) -- and a CU holds five workgroups of four such wavefronts, so one tile's round
+// trips run under the others' arithmetic.  Work layout per merged interval as in k_mergeN (listed by rank, gathered,
+// summed in replicate order, looked up in the caches, the misses evaluated densely); the LDS cache is the wavefront's
+// own (128 entries, a 16-byte write per lane: whole entries, no arbitration), behind it the same device-wide table.
+constexpr int MNW_NW = 4;          // wavefronts (tiles in flight) per workgroup
+#ifndef GX_MNW_CAP
+#define GX_MNW_CAP 256
+#endif
+constexpr int MNW_CAP = GX_MNW_CAP;   // merged intervals per round
+#ifndef GX_MNW_CACHE_LOG
+#define GX_MNW_CACHE_LOG 8
+#endif
+constexpr int MNW_CACHE = 1 << GX_MNW_CACHE_LOG;   // LDS cache entries per WORKGROUP (shared by its wavefronts: entries are validated like the device-wide table's)
+#ifndef GX_MNW_GTHR
+#define GX_MNW_GTHR 1e30
+#endif
+constexpr double MNW_GTHR = GX_MNW_GTHR;  // sums from which the device-wide table is not consulted (such values hardly repeat)
+constexpr int MNW_MAXREP = 8;      // replicates this kernel takes (beyond: k_mergeN)
+__host__ __device__ constexpr size_t mergeNw_wave_words(int n) {  // LDS words of one wavefront
+  return (size_t)n * MG_WORDS + (size_t)n * MG_WORDS / 2 /*preR u16*/ + MNW_CAP / 2 /*offL u16*/ + MNW_CAP * 2 /*missSum*/ +
+         MNW_CAP / 2 /*missI u16*/ + MNW_CAP / 4 /*missDf u8*/;
+}
+__host__ __device__ constexpr size_t mergeNw_lds_bytes(int n) {
+  return (size_t)MNW_CACHE * 16 + MNW_NW * ((mergeNw_wave_words(n) * 4 + 15) / 16 * 16);
+}
+
+__device__ __forceinline__ void mnw_sync() {  // (LDS operations of one wavefront execute in order: keep the compiler from reordering them)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef GX_MNW_WAVES
+#define GX_MNW_WAVES 4
+#endif
+__global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S, const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+                                                          u32 nTiles, MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk,
+                                                          uint4* gcache /* 2^MN_GLOBAL_LOG entries, zeroed per run */) {
+  static_assert(MG_WORDS == 128, "two bitmap words per lane");
+  extern __shared__ __attribute__((aligned(16))) u32 dynw[];
+  const int n = S.n, lane = lane_id(), wv = threadIdx.x >> 6;
+  MnEntry* cache = reinterpret_cast<MnEntry*>(dynw);  // the workgroup's
+  u32* base = dynw + MNW_CACHE * 4 + (size_t)wv * ((mergeNw_wave_words(n) * 4 + 15) / 16 * 4);
+  // (8-byte items first)
+  double* missSum = reinterpret_cast<double*>(base);
+  u32* bm = reinterpret_cast<u32*>(missSum + MNW_CAP);                  // n bitmaps of MG_WORDS words
+  uint16_t* preR = reinterpret_cast<uint16_t*>(bm + n * MG_WORDS);       // [r][w]: intervals of r before word w
+  uint16_t* offL = preR + n * MG_WORDS;                                  // offset of merged interval i of the round
+  uint16_t* missI = offL + MNW_CAP;
+  uint8_t* missDf = reinterpret_cast<uint8_t*>(missI + MNW_CAP);
+  for (int i = threadIdx.x; i < MNW_CACHE * 4; i += MNW_NW * 64) reinterpret_cast<u32*>(cache)[i] = 0;
+  __syncthreads();
+  u32 bad = 0;
+  const u32 stride = gridDim.x * MNW_NW;
+  for (u32 t = blockIdx.x * MNW_NW + wv; t < nTiles; t += stride) {
+    mnw_sync();
+    const u32 ci = tileChrom[t];
+    const DChrom c = chroms[ci];
+    const u32 tl = t - c.tileBase, pos0 = tl << TB;
+    const bool lastTile = tl + 1 == c.nTiles;
+    // this lane's two words of every bitmap start empty
+    for (int r = 0; r < n; r++) *reinterpret_cast<uint2*>(bm + r * MG_WORDS + 2 * lane) = make_uint2(0u, 0u);
+    mnw_sync();
+    bool any = false;
+    u32 slot = 0;
+    for (int r = 0; r < n; r++) {
+      const u32 a0 = S.r[r].tileOff[t];
+      slot += a0;
+      if (!S.r[r].present[ci]) continue;
+      any = true;
+      const u32 a1 = S.r[r].tileOff[t + 1];
+      const u32 a1c = (lastTile && a1 > a0) ? a1 - 1 : a1;
+      for (u32 i = a0 + lane; i < a1c; i += 64) {
+        const u32 off = S.r[r].end[i] - pos0;
+        atomicOr(&bm[r * MG_WORDS + (off >> 5)], 1u << (off & 31));
+      }
+    }
+    mnw_sync();
+    u32 wU0 = 0, wU1 = 0;
+    for (int r = 0; r < n; r++) {  // per replicate: intervals ending before each word; the union on the way
+      const uint2 w = *reinterpret_cast<const uint2*>(bm + r * MG_WORDS + 2 * lane);
+      wU0 |= w.x;
+      wU1 |= w.y;
+      const int c0 = __popc(w.x), cc = c0 + __popc(w.y);
+      const int inc = dpp_scan_add(cc);
+      const u32 ex = (u32)(inc - cc);
+      *reinterpret_cast<u32*>(preR + r * MG_WORDS + 2 * lane) = ex | ((ex + (u32)c0) << 16);
+    }
+    const int cU = __popc(wU0) + __popc(wU1);
+    const int incU = dpp_scan_add(cU);
+    const u32 exU = (u32)(incU - cU), tU = (u32)__builtin_amdgcn_readlane(incU, 63);
+    if (lane == 0) out.tileCount[t] = any ? tU + (lastTile ? 1u : 0u) : 0u;
+    if (!any) continue;  // wave-uniform
+    for (u32 r0 = 0; r0 < tU; r0 += MNW_CAP) {
+      mnw_sync();
+      // ---- 1: the merged intervals of this round, by rank (a lane lists the set bits of its own two words)
+      {
+        u32 rank = exU - r0;  // (unsigned: earlier rounds' ranks wrap far beyond the cap)
+        for (u32 bits = wU0; bits; bits &= bits - 1, rank++)
+          if (rank < (u32)MNW_CAP) offL[rank] = (uint16_t)(lane * 64 + __builtin_ctz(bits));
+        for (u32 bits = wU1; bits; bits &= bits - 1, rank++)
+          if (rank < (u32)MNW_CAP) offL[rank] = (uint16_t)(lane * 64 + 32 + __builtin_ctz(bits));
+      }
+      mnw_sync();
+      // ---- 2: gather, sum, classify; the misses compacted by ballot
+      const u32 nC = min((u32)MNW_CAP, tU - r0);
+      u32 nM = 0;
+      for (u32 i0 = 0; i0 < nC; i0 += 64) {
+        const u32 i = i0 + lane;
+        bool miss = false;
+        double sum = 0.0;
+        int df = 0;
+        if (i < nC) {
+          const u32 off = offL[i], ww = off >> 5, below = (1u << (off & 31)) - 1u;
+          for (int r = 0; r < n; r++) {  // multPval 570-574, replicate order
+            if (!S.r[r].present[ci]) continue;
+            const u32 idx = S.r[r].tileOff[t] + preR[r * MG_WORDS + ww] + __popc(bm[r * MG_WORDS + ww] & below);
+            const float pv = S.r[r].p[idx];
+            if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
+          }
+          if (df > 400) bad |= ST_BAD_DF;
+          const u32 o = slot + r0 + i;
+          out.end[o] = pos0 + off;
+          if (df <= 2 || sum == 0.0) {
+            out.p[o] = df == 0 ? GX_SKIPF : (float)sum;   // fisher_combine's cases without maths
+          } else {
+            const u32 lo = (u32)__double_as_longlong(sum), hi = (u32)(__double_as_longlong(sum) >> 32);
+            const u32 h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ ((u32)df << 20)) * 0x9E3779B1u) >> (32 - GX_MNW_CACHE_LOG);
+            const uint4 e = *reinterpret_cast<const uint4*>(cache + h);
+            if (e.x == lo && e.y == hi && e.w == (mn_mix(lo, hi, e.z) | (u32)df)) {
+              out.p[o] = __uint_as_float(e.z);
+            } else if (sum < MNW_GTHR) {
+              const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ ((u32)df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
+              const uint4 g = gcache[hg];
+              if (g.x == lo && g.y == hi && g.w == (mn_mix(lo, hi, g.z) | (u32)df))
+                out.p[o] = __uint_as_float(g.z);
+              else
+                miss = true;
+            } else
+              miss = true;
+          }
+        }
+        const u64 mm = __ballot(miss);
+        if (mm) {  // wave-uniform
+          const u32 j = nM + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
+          if (miss) {
+            missI[j] = (uint16_t)i;
+            missDf[j] = (uint8_t)df;
+            missSum[j] = sum;
+          }
+          nM += (u32)__popcll(mm);
+        }
+      }
+      mnw_sync();
+      // ---- 3: the pairs not met before
+      for (u32 j = lane; j < nM; j += 64) {
+        const double sum = missSum[j];
+        const u32 df = missDf[j];
+        bool risky = false;
+        const float pv = pval_round(fisher_double(sum, (int)df), &risky);
+        const u32 i = missI[j];
+        out.p[slot + r0 + i] = pv;
+        if (risky)
+          risk_add(risk, RK_FISHER, t, r0 + i, df, sum);
+        else {
+          const u32 lo = (u32)__double_as_longlong(sum), hi = (u32)(__double_as_longlong(sum) >> 32);
+          const u32 h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ (df << 20)) * 0x9E3779B1u) >> (32 - GX_MNW_CACHE_LOG);
+          const uint4 ent = make_uint4(lo, hi, __float_as_uint(pv), mn_mix(lo, hi, __float_as_uint(pv)) | df);
+          *reinterpret_cast<uint4*>(cache + h) = ent;  // (readers check the mix: a torn or foreign entry is a miss)
+          if (sum < MNW_GTHR) {
+            const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ (df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
+            gcache[hg] = ent;
+          }
+        }
+      }
+    }
+    if (lastTile && lane == 0) {  // closing interval [.., len)
       double sum = 0.0;
       int df = 0;
       for (int r = 0; r < n; r++) {
