@@ -239,7 +239,11 @@ def reference_e2e(lens, reps, max_frags=1_500_000):
         hrc = subprocess.call([hb, "--events-only", "-t", sam], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         hdt = time.perf_counter() - t1
         if hrc == 0:
-            host = {"records_per_s": nrec / hdt, "seconds": hdt, "threads": min(16, os.cpu_count() or 1),
+            ncpu = os.cpu_count() or 1
+            n = min(16, ncpu)
+            pools = {"inflate": n, "decode": n, "state": n} if 3 * n + 2 <= ncpu or n <= 2 else \
+                    {"inflate": max(2, n // 4), "decode": max(2, n // 2), "state": max(1, n // 2)}
+            host = {"records_per_s": nrec / hdt, "seconds": hdt, "threads": pools,
                     "what": "genrich-amd --events-only on the same SAM text (parse, pair, weight -> events; no device work)"}
     for f in (sam, outp):
         if os.path.exists(f):

@@ -1939,6 +1939,12 @@ int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor) {
   return GX_OK;
 }
 
+int gx_expect_fractional(gx_ctx* ctx, int on) {
+  if (!ctx) return GX_ERR_ORDER;
+  ctx->sawFrac = on != 0;
+  return GX_OK;
+}
+
 int gx_dups_first(gx_ctx* ctx, const gx_dup_key* keys, const uint8_t* multi, size_t n, uint32_t* owner) {
   if (!ctx || (n && (!keys || !multi || !owner)) || n >= ((size_t)1 << 31)) return GX_ERR_ORDER;
   if (!n) return GX_OK;

@@ -941,6 +941,9 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
                                                      Sort1Out out, u32* __restrict__ st) {
   __shared__ S2Lds L;
   __shared__ DChrom lchrom[S2_LCHROM];
+  // (unit-weight records and a fractional weight somewhere in the input: the sample is going to be built again on the
+  // general chain whatever this launch still does -- the workgroups that start after the flag went up leave at once)
+  if (!FRAC && (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_SB_FRAC)) return;
   const bool chromLds = nChrom <= (u32)S2_LCHROM;
   const u32 x = blockIdx.x % NXCD;
   const u32 begin = blockIdx.x * S2_CHUNK;
@@ -1011,12 +1014,17 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
         if (mine) {
           if (p.w != GX_UNIT) {
             atomicOr(out.slowFrag, 1u);
-            if (!FRAC) atomicOr(st, ST_SB_FRAC);  // (unit-weight pair records: this sample goes to the general chain)
+            if (!FRAC) {  // (unit-weight pair records: this sample goes to the general chain -- nothing more to append)
+              atomicOr(st, ST_SB_FRAC);
+              mine = false;
+            }
           }
+          if (mine) {
           r0 = make_rec64(p.t0, p.o0, p.w);
           l0 = x * nBins + (p.t0 >> sbShift);
           atomicAdd(&binNet[p.t0 >> sbShift], p.w);
           h1 = p.t1 != NULL_TILE;
+          }
         }
         if (h1) {
           r1 = make_rec64(p.t1, p.o1, -p.w);
@@ -1232,14 +1240,18 @@ __global__ __launch_bounds__(1024) void k_bins_lut(BinScan B, u32 nBins, float* 
   if (blockIdx.x == 4 && threadIdx.x == 0) deep->n = 0;  // this sample's host-evaluated deep values come later
   if (threadIdx.x == 0) {
     u32 spins = 0;
+    bool timedOut = false;
     while (!ld_agent(&B.ctl->ready)) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > LB_SPIN_LIMIT) {
-        atomicOr(st, ST_LOOKBACK);
+        // (block 3 of this launch has not published: no table from here -- the launch behind the tile stage builds it, and
+        // the sweep takes the tight table; nothing is raised: the run is only slower)
+        timedOut = true;
         break;
       }
     }
-    s_enabled = ld_agent(&B.ctl->enabled);
+    s_enabled = timedOut ? 0u : ld_agent(&B.ctl->enabled);
+    if (timedOut) atomicOr(&B.ctl->bad, 4u);
     s_lambda = ld_agent(reinterpret_cast<u32*>(&B.scal->lambda));
   }
   __syncthreads();

@@ -285,6 +285,7 @@ class Input {
   void mapFile() {
     struct stat st;
     if (fstat(fileno(f_), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return;
+    if (getenv("GENRICH_NO_MMAP")) return;  // (a file that may be truncated or rewritten while it is read: the read path reports a short read, a mapping dies of SIGBUS)
     void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f_), 0);
     if (m == MAP_FAILED) return;
     madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);

@@ -1382,6 +1382,7 @@ class DecodePipe {
 };
 
 int g_decoders = 0;  // --threads / GENRICH_THREADS (0 or 1: records are decoded on the parsing thread)
+int g_stateWorkers = 0;  // (0: as many as decoders)
 
 // reader -> decoders -> the caller's thread, or all three in turn on the caller's thread (one decoder or none)
 template <class Fill, class One, class Apply>
@@ -1548,7 +1549,7 @@ const bool g_serialState = getenv("GENRICH_SERIAL_STATE") != nullptr;  // (the o
 template <class Fill, class One>
 void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOffset, Fill fill, One one) {
   DecodePipe pipe(nThreads, fill, one);
-  ChunkPool pool(nThreads, S, qualOffset);
+  ChunkPool pool(g_stateWorkers ? g_stateWorkers : nThreads, S, qualOffset);
   const size_t window = (size_t)std::max(8, 4 * nThreads);
   std::shared_ptr<Chunk> cur = std::make_shared<Chunk>();
   bool have = false;
@@ -2325,6 +2326,19 @@ int main(int argc, char** argv) {
     for (char* t = strtok(list.data(), ", "); t; t = strtok(nullptr, ", ")) S.xchr.push_back(t);
   }
   g_decoders = g_threads;
+  {
+    // --threads N sizes three pools (BGZF inflaters, record decoders, state workers) next to the reader and the owner:
+    // on a host with fewer than 3 N + 2 cores the pools share the budget instead of each taking N
+    // (inflate N / 4, decode N / 2, state workers N / 2: the stages' measured shares of the work)
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && (unsigned)(3 * g_threads + 2) > hw && g_threads > 2) {
+      g_stateWorkers = std::max(1, g_threads / 2);
+      g_decoders = std::max(2, g_threads / 2);
+      g_threads = std::max(2, g_threads / 4);   // (from here on: the inflaters; two keep the BGZF reader with its block checks)
+    }
+    if (getenv("GENRICH_THREADS_REPORT"))
+      fprintf(stderr, "[threads] inflate %d, decode %d, state %d\n", g_threads, g_decoders, g_stateWorkers ? g_stateWorkers : g_decoders);
+  }
   if (o.pqvalue <= 0.0f || o.pqvalue > 1.0f) die("", "p-/q-value must be in (0,1]");
   const float thr = -log10f(o.pqvalue);
 
@@ -2353,6 +2367,7 @@ int main(int argc, char** argv) {
       int rc = gx_create(&g, &par);
       if (rc) die(g ? gx_last_error(g) : gx_strerror(rc), "");
       check(S, gx_set_keep_pileups(g, o.logFile || o.pileFile), g);  // only -f / -k print pileup values
+      if (o.asDiff > 0.0f) check(S, gx_expect_fractional(g, 1), g);  // (-s: multimapping reads get weights 1/k)
       D.ctx.push_back(g);
     }
     S.gx = D.ctx[0];

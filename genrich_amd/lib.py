@@ -49,6 +49,7 @@ _SIGS = {
     "gx_set_chroms": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "gx_set_owned": [C.c_void_p, C.c_void_p],
     "gx_set_keep_pileups": [C.c_void_p, C.c_int],
+    "gx_expect_fractional": [C.c_void_p, C.c_int],
     "gx_set_collectives": [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p],
     "gx_rccl_unique_id": [C.c_void_p, C.c_size_t],
     "gx_set_rccl": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -192,6 +193,10 @@ class Genrich:
 
     def reset(self):
         self._check(self.lib.gx_reset(self.ctx))
+
+    def expect_fractional(self, on=True):
+        """Hint: the run may hold fractional weights (Genrich's -s): pair records with a weight class from the first sample on."""
+        self._check(self.lib.gx_expect_fractional(self.ctx, int(bool(on))))
 
     def set_keep_pileups(self, keep):
         """keep=False: the pileup floats of the p-value intervals (only the -f / -k emitters read them)

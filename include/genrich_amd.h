@@ -262,6 +262,10 @@ int gx_set_phase_timing(gx_ctx* ctx, int level);
  * the phase of its roofline kernel this way inside the timed region. */
 int gx_set_phase_filter(gx_ctx* ctx, const char* name);
 int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
+/* A hint, before the first sample: the run may hold fractional weights (count > 1: Genrich's -s).  The device path then
+ * writes its pair records with a weight class from the start; without the hint the first sample that shows a fractional
+ * weight is built a second time, on the general chain (same results either way). */
+int gx_expect_fractional(gx_ctx* ctx, int on);
 /* Which device path the last calls took (tests assert that the fast paths really run):
  * bit 0: the last sample's tile stage was k_sbtile (level 2 of the sort fused with the tile passes, gx_sbtile.h);
  * bit 1: the last gx_find_peaks swept the tile stage's loose slots (no k_pack_pval, gx_kernels.h LooseCtl);

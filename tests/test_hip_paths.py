@@ -122,6 +122,21 @@ def test_fractional_weights_ride_the_pair_records_from_the_second_sample_on():
     assert flags & FELL_BACK and flags & FUSED and flags & 16 and not flags & LOOSE
 
 
+def test_fractional_hint_keeps_the_first_sample_fused():
+    lens = [300_000, 70_001]
+    ev = synth.add_multimap(synth.make_fragments(lens, 60_000, 31, peak_every=20_000, tower_every=150_000), lens, 0.3, 32)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    h.expect_fractional(True)
+    sh = B.run_case(h, case)
+    flags = h.path_info()
+    assert_same_run(o, h, so, sh, case)
+    assert flags & FUSED and flags & 16 and not flags & FELL_BACK
+
+
 def test_fractional_weights_without_pair_records_stay_on_the_general_chain(monkeypatch):
     monkeypatch.setenv("GX_NO_FRAC_PAIRS", "1")
     lens = [300_000, 70_001]

@@ -14,6 +14,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.environ.get("GX_PROFILE_OUT", os.path.join(ROOT, "profiles"))  # (on the GPU box: a directory under gpurun_out/, the only one that travels back)
 sys.path.insert(0, ROOT)
 
 
@@ -66,7 +67,7 @@ def pmc_means(db):
 def main():
     tag = sys.argv[1]
     cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    src = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     from bench import source_hash
     steps = 5  # profile_round.sh: --warmup 1 --steps 2, and bench.py's two extra steps that time every phase
     out = {"_how": __doc__.strip().split("\n\n")[1].replace("\n", " "), "tag": tag, "config": cfg, "source_hash": source_hash(),
@@ -85,7 +86,7 @@ def main():
             k["us_per_step"] = k.get("us_per_step", 0.0) + sum(v) / 1e3 / steps
             k["launches_per_step"] = k.get("launches_per_step", 0.0) + len(v) / steps
         out["whole_step"]["kernel_ms_per_step"] = tot / 1e6 / steps
-        open(os.path.join(ROOT, "profiles", f"{tag}_config{cfg}_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
+        open(os.path.join(OUT, f"{tag}_config{cfg}_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
     # counters
     pm = {}
     for p in ("fetch", "write", "sq1", "sq2"):
@@ -95,7 +96,7 @@ def main():
     lines = [f"{'kernel':58s} {'counter':22s} {'calls':>6s} {'mean':>18s}"]
     for (name, ctr), v in sorted(pm.items(), key=lambda kv: (kv[0][1], -sum(kv[1]) / len(kv[1]))):
         lines.append(f"{name[:58]:58s} {ctr:22s} {len(v):6d} {sum(v)/len(v):18.1f}")
-    open(os.path.join(ROOT, "profiles", f"{tag}_config{cfg}_pmc.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(OUT, f"{tag}_config{cfg}_pmc.txt"), "w").write("\n".join(lines) + "\n")
     fetch_tot = write_tot = 0.0
     per = {}
     for (name, ctr), v in pm.items():
@@ -144,7 +145,7 @@ def main():
             if sq.get("SQ_LDS_IDX_ACTIVE") else None,
             "raw": sq,
         }
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"r04_counters_config{cfg}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(OUT, f"r04_counters_config{cfg}.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1)[:3000])
 
 
