@@ -528,6 +528,26 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   }
   // ---- 3: per-tile histogram
   auto keyAt = [](const uint4& v, int j) -> u32 { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; };
+  // every record of this wavefront's slots i0 .. KX - 1, read from global memory four slots at a time
+  auto slotsFrom = [&](int i0, auto&& f) {
+    for (int i = i0; i < KX; i += 4) {
+      u32 c[4];
+      uint4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        c[q] = i + q < KX ? (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[(i + q) * SBT_NW + wv]) : 0u;
+        v[q] = make_uint4(0u, 0u, 0u, 0u);
+        if ((u32)lane * 4 < c[q]) v[q] = poolS[(L.slotOff[(i + q) * SBT_NW + wv] >> 2) + lane];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (!c[q]) continue;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if ((u32)lane * 4 + j < c[q]) f(keyAt(v[q], j));
+      }
+    }
+  };
   // (a slot is full -- 256 keys -- unless it is the last of its list: the full ones without per-key predicates;
   // the counts are wave-uniform)
   // (pair record: [31:12] start within the bin, [11:0] length; both ends lie in this bin)
@@ -562,15 +582,8 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
           if ((u32)lane * 4 + j < cS[i]) histPair(keyAt(kS[i], j));
       }
     }
-    for (int i = K; i < KX; i++) {  // (slots beyond the registers: only a bin of more than 32 K pairs has any)
-      const u32 c = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
-      if (!c) continue;  // wave-uniform
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if ((u32)lane * 4 < c) v = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if ((u32)lane * 4 + j < c) histPair(keyAt(v, j));
-    }
+    // (the second launch: no record in registers -- the slots are read four at a time, their loads in flight together)
+    if (!ovfSlots) slotsFrom(K, [&](u32 r) { histPair(r); });
     if (nF <= SBT_FCAP)
       for (u32 i = tid; i < nF; i += SBT_NT) {
         const u64 r = srcF.at(i);
@@ -643,8 +656,14 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       u32 tb = 0;
       L.rnd[0] = 0;
       while (tb < nT && fits) {
-        u32 te = tb;
-        while (te < nT && L.startC[te + 1] - L.startC[tb] <= SBT_KEYCAP) te++;
+        // the last tile whose keys still fit behind tb's (startC grows: a bisection)
+        u32 lo = tb, hi = nT;
+        const u32 lim = L.startC[tb] + SBT_KEYCAP;
+        while (lo < hi) {
+          const u32 mid = (lo + hi + 1) >> 1;
+          if (L.startC[mid] <= lim) lo = mid; else hi = mid - 1;
+        }
+        const u32 te = lo;
         if (te == tb || nr == (u32)SBT_MAXR) fits = false;
         else {
           L.rnd[++nr] = te;
@@ -766,15 +785,6 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
             if ((u32)lane * 4 + j < cS[i]) placePair(keyAt(kS[i], j));
         }
       }
-      for (int i = K; i < KX; i++) {
-        const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
-        if (!c) continue;  // wave-uniform
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if ((u32)lane * 4 < c) v = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if ((u32)lane * 4 + j < c) placePair(keyAt(v, j));
-      }
       for (u32 i = tid; i < nF; i += SBT_NT) {
         const u64 r = srcF.at(i);
         const u32 off = (u32)(r >> 8) & (TILE - 1);
@@ -799,19 +809,11 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
           if (tid == 0) L.work = tileBeg;
           __syncthreads();
         }
-        for (int i = 0; i < KX; i++) {
-          const u32 c = (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
-          if (!c) continue;  // wave-uniform
-          uint4 v = make_uint4(0u, 0u, 0u, 0u);
-          if ((u32)lane * 4 < c) v = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if ((u32)lane * 4 + j < c) {
-              const u32 r = keyAt(v, j), e = pairEnd(r), ts = pairTs(r), te = e >> TB;
-              if (ts - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[ts], 1u) - keyBase] = (uint16_t)(((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r));
-              if (te - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)((e & (TILE - 1)) | 0x8000u | pairCls(r));
-            }
-        }
+        slotsFrom(0, [&](u32 r) {
+          const u32 e = pairEnd(r), ts = pairTs(r), te = e >> TB;
+          if (ts - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[ts], 1u) - keyBase] = (uint16_t)(((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r));
+          if (te - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)((e & (TILE - 1)) | 0x8000u | pairCls(r));
+        });
         for (u32 i = tid; i < nF; i += SBT_NT) {
           const u64 r = srcF.at(i);
           const u32 tl = (u32)(r >> 32) - segTileBase, off = (u32)(r >> 8) & (TILE - 1);

@@ -834,13 +834,17 @@ __global__ __launch_bounds__(S1P_NT, 4) void k_sort1p(const gx_event* __restrict
 #ifndef GX_S2B_WAVES
 #define GX_S2B_WAVES 6   // ... and k_sort_b (three workgroups per CU)
 #endif
-constexpr int S2_NT = 512;
+#ifndef GX_S2_NT
+#define GX_S2_NT 512
+#endif
+constexpr int S2_NT = GX_S2_NT;
 #ifndef GX_S2_BATCH
 #define GX_S2_BATCH 4
 #endif
 constexpr int S2_BATCH = GX_S2_BATCH;   // event loads in flight per thread (k_sort_a)
 constexpr int S2_LCHROM = 96;     // chromosome records k_sort_a keeps in LDS (larger tables stay in global memory)
-constexpr int S2_ITEMS = 16;
+constexpr int S2_ITEMS = 8192 / S2_NT;
+static_assert(S2_ITEMS == 16 || S2_ITEMS == 8, "512 or 1024 threads");
 constexpr int S2_CHUNK = S2_NT * S2_ITEMS;
 constexpr int S2_KEYS = 64;
 constexpr int S2_FINE_SHIFT = 6;   // fine bins per coarse bin (log2)
@@ -1078,14 +1082,20 @@ __global__ __launch_bounds__(S2_NT, GX_S2B_WAVES) void k_sort_b(PagedStream PC, 
   // (thread t: records 16 t .. 16 t + 15 of the page -- four 16-byte loads of records, one of their bytes)
   u32 rec[S2_ITEMS], ka[S2_ITEMS];
   {
-    static_assert(S2_ITEMS == 16, "one 16-byte load of bytes per thread");
-    uint4 r4[4];
+    constexpr int NQ = S2_ITEMS / 4;  // 16-byte loads of records per thread
+    uint4 r4[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; q++) r4[q] = reinterpret_cast<const uint4*>(src)[threadIdx.x * 4 + q];
-    const uint4 a4 = reinterpret_cast<const uint4*>(srcA)[threadIdx.x];
-    const u32 aw[4] = {a4.x, a4.y, a4.z, a4.w};
+    for (int q = 0; q < NQ; q++) r4[q] = reinterpret_cast<const uint4*>(src)[threadIdx.x * NQ + q];
+    u32 aw[4] = {0u, 0u, 0u, 0u};
+    if (NQ == 4) {
+      const uint4 a4 = reinterpret_cast<const uint4*>(srcA)[threadIdx.x];
+      aw[0] = a4.x; aw[1] = a4.y; aw[2] = a4.z; aw[3] = a4.w;
+    } else {
+      const uint2 a2 = reinterpret_cast<const uint2*>(srcA)[threadIdx.x];
+      aw[0] = a2.x; aw[1] = a2.y;
+    }
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NQ; q++) {
       const u32 rw[4] = {r4[q].x, r4[q].y, r4[q].z, r4[q].w};
 #pragma unroll
       for (int j = 0; j < 4; j++) {
