@@ -569,7 +569,45 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   gx_ctx::Stream& SS = ctx->str[0];
   gx_ctx::Stream& SE = ctx->str[1];
   gx_ctx::Stream& SF = ctx->str[2];
-  const u32 nL1 = nSB - 1;  // level-1 bins = super-buckets (records without a tile are not scattered at all)
+  const u32 nL1base = nSB - 1;  // level-1 bins = super-buckets (records without a tile are not scattered at all)
+  static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
+  const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
+  // ---- what the tile stage will be -------------------------------------------------------------------------
+  // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- unit weights, no -E regions, at most
+  // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
+  // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
+  // (a sample whose predecessor of the same kind did not fit is not even tried for a while: the same experiment's
+  // next replicate, or the next run on the same data, has the same pile-ups)
+  const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
+  if (backoff) ctx->fusedBackoff[isCtrl ? 1 : 0]--;
+  const bool pairsAllowed = getenv("GX_NO_PAIRS") == nullptr;
+  static const bool onePass = getenv("GX_SORT_ONE_PASS") != nullptr;  // (measurements: k_sort1p instead of k_sort_a + k_sort_b)
+  // (fractional weights ride the pair records -- k_sort_a<true>, k_sbtile<.., true> -- once a sample of this context has
+  // shown one; the start / end keys of the other fused variant cannot carry a weight)
+  const bool fracOk = pairsAllowed && !onePass && getenv("GX_NO_FRAC_PAIRS") == nullptr;
+  const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && (!ctx->sawFrac || fracOk) &&
+                     !ctx->fusedOff && !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1base) * 64000 &&
+                     (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
+  ctx->fusedUsed = fused;
+  // ... and with it level 1: one record per fragment (k_sort_a / k_sort_b) when k_sbtile will read it
+  const bool pairs = fused && !reuseSort && pairsAllowed;
+  const bool fracPairs = pairs && ctx->sawFrac;
+  ctx->pairsUsed = pairs;
+  ctx->fracPairsUsed = fracPairs;
+
+  // A sample so dense that the average bin holds more keys than k_sbtile's key array (ATAC cut sites of a deep library)
+  // takes bins of half the size -- level 1 of the pair mode reaches 64 x 128 of them -- so that a bin is one round of
+  // the tile kernel again; the general chain (a later fall-back) keeps the context's own bin size.
+  int sbS = ctx->sbShift;
+  u32 nL1 = nL1base;
+  // (not with fractional weights: measured at config 4, the tile passes with weights and the fragLen terms cost more per
+  // key than the rounds of full-size bins -- 2.98 against 2.67 ms)
+  if (pairs && !fracPairs && !onePass && sbS > 0 && (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * (SBT_KEYCAP - SBT_KEYCAP / 4) &&
+      ((nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1)) <= (u32)MAX_BINS_P && getenv("GX_NO_HALF_BINS") == nullptr) {
+    sbS--;
+    nL1 = (nTiles + (1u << sbS) - 1) >> sbS;
+  }
+
   // level-2 output: 16-bit tile offsets (S, E) / whole records (F), tile-contiguous
   if (unit32) {
     HIPCHECK(SS.a.ensure((size_t)nEv * 2 + 16));
@@ -584,8 +622,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   poolPages[2] = (u32)(((size_t)2 * nEv) >> PgCfg<u64>::SHIFT) + NXCD * nL1 + 4;
   for (int q = 0; q < 3; q++) HIPCHECK(ctx->str[q].pool.ensure((size_t)poolPages[q] * PG_BYTES));
   // lambda ahead of the tile stage (closed form of fragLen; LooseCtl): one rank, a treatment sample, -p
-  static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
-  const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
   const bool multiRank = ctx->world > 1 || ctx->forceColl;
   // Several ranks: lambda needs every rank's fragLen.  Its closed form (the sum of the fragment lengths, k_sort1) is
   // known BEFORE the tile stage, so the ranks exchange that (`earlyColl`: one all-reduce of three words behind
@@ -619,9 +655,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     const size_t ptBytes = up((size_t)NXCD * nL1 * jmax * 4);
     const size_t lbTBytes = up((size_t)3 * (tChunks + 2) * 8), lbIBytes = up((size_t)(2 * tChunks + 4) * 8);
     const size_t ctlBytes = up(sizeof(LooseCtl));
-    const size_t netBytes = up((size_t)(MAX_BINS + 2) * 4);  // pair mode: the singles' weight per level-1 bin
+    const size_t netBytes = up((size_t)(MAX_BINS_P + 2) * 4);  // pair mode: the singles' weight per level-1 bin
     // pair mode in two passes (k_sort_a / k_sort_b): the coarse lists' cursors and page tables
-    const u32 nCoarse = (std::max(1u, nL1) + (1u << S2_FINE_SHIFT) - 1) >> S2_FINE_SHIFT;
+    const u32 nCoarse = (std::max(1u, nL1) + (1u << s2_fine_shift(nL1)) - 1) >> s2_fine_shift(nL1);
     const u32 jmaxC = class_chunks(segs) + 3;   // (a class's workgroups cannot fill more pages than that in one list)
     const size_t curCBytes = up((size_t)NXCD * nCoarse * 4 + 64), ptCBytes = up((size_t)NXCD * nCoarse * jmaxC * 4);
     const size_t total = ffBytes + 256 + ctlBytes + endBytes + netBytes + curCBytes + ptCBytes + 3 * (curBytes + ptBytes) + 5 * tileBytes + lbTBytes + lbIBytes;
@@ -677,7 +713,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     }
   }
   for (int q = 0; q < 3; q++) {
-    HIPCHECK(ctx->str[q].sbOff.ensure((MAX_BINS + 2) * 4));
+    HIPCHECK(ctx->str[q].sbOff.ensure((MAX_BINS_P + 2) * 4));
     HIPCHECK(ctx->tileOff[q].ensure((size_t)(nTiles + 2) * 4));
   }
   HIPCHECK(ctx->tileCarry.ensure((size_t)(nTiles + 1) * 4));
@@ -687,29 +723,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   HIPCHECK(pooled(ctx, out.ivEnd, ivCap * 4));
   HIPCHECK(pooled(ctx, out.tileIvOff, (size_t)(nTiles + 2) * 4));
   HIPCHECK(pooled(ctx, out.chromIvOff, (size_t)(nChrom + 2) * 4));
-
-  // ---- what the tile stage will be -------------------------------------------------------------------------
-  // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- unit weights, no -E regions, at most
-  // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
-  // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
-  // (a sample whose predecessor of the same kind did not fit is not even tried for a while: the same experiment's
-  // next replicate, or the next run on the same data, has the same pile-ups)
-  const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
-  if (backoff) ctx->fusedBackoff[isCtrl ? 1 : 0]--;
-  const bool pairsAllowed = getenv("GX_NO_PAIRS") == nullptr;
-  static const bool onePass = getenv("GX_SORT_ONE_PASS") != nullptr;  // (measurements: k_sort1p instead of k_sort_a + k_sort_b)
-  // (fractional weights ride the pair records -- k_sort_a<true>, k_sbtile<.., true> -- once a sample of this context has
-  // shown one; the start / end keys of the other fused variant cannot carry a weight)
-  const bool fracOk = pairsAllowed && !onePass && getenv("GX_NO_FRAC_PAIRS") == nullptr;
-  const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && (!ctx->sawFrac || fracOk) &&
-                     !ctx->fusedOff && !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1) * 64000 &&
-                     (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
-  ctx->fusedUsed = fused;
-  // ... and with it level 1: one record per fragment (k_sort_a / k_sort_b) when k_sbtile will read it
-  const bool pairs = fused && !reuseSort && pairsAllowed;
-  const bool fracPairs = pairs && ctx->sawFrac;
-  ctx->pairsUsed = pairs;
-  ctx->fracPairsUsed = fracPairs;
 
   phase_begin(ctx, isCtrl ? "c.sort1" : "t.sort1");
   // fragLen: closed form (sum of fragment lengths) unless something sets the slow flag
@@ -737,17 +750,17 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       // two passes: coarse bins, then the fine ones (gx_sort.h)
       u32 nWG1 = 0;
       for (auto& sg : segs) nWG1 += (u32)((sg.n + S2_CHUNK - 1) / S2_CHUNK);
-      const u32 nCoarse = (std::max(1u, nL1) + (1u << S2_FINE_SHIFT) - 1) >> S2_FINE_SHIFT;
+      const u32 nCoarse = (std::max(1u, nL1) + (1u << s2_fine_shift(nL1)) - 1) >> s2_fine_shift(nL1);
       const u32 perClass = class_chunks(segs), jmaxC = perClass + 3, nListsC = NXCD * nCoarse;
       const u32 pagesC = nWG1 + 2 * nListsC + 8;
       HIPCHECK(ctx->poolC.ensure((size_t)pagesC * PG_BYTES));
       HIPCHECK(ctx->auxC.ensure((size_t)pagesC << PgCfg<u32>::SHIFT));
       PagedStream PC{ctx->poolC.p, ctx->ptC.as<u32>(), ctx->curC.as<u32>(), ctx->curC.as<u32>() + nListsC, jmaxC, pagesC, nListsC};
       if (fracPairs)
-        hipLaunchKernelGGL(k_sort_a<true>, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, ctx->sbShift,
+        hipLaunchKernelGGL(k_sort_a<true>, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, sbS,
                            nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
       else
-        hipLaunchKernelGGL(k_sort_a<false>, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, ctx->sbShift,
+        hipLaunchKernelGGL(k_sort_a<false>, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, sbS,
                            nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
       pcLast = PC;
       ncLast = nCoarse;
@@ -759,13 +772,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
         ctx->s1pLdsSet = lds1;
       }
       hipLaunchKernelGGL(k_sort1p, dim3(blocks), dim3(S1P_NT), lds1, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
-                         ctx->sbShift, nL1, PG3[0], PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
+                         sbS, nL1, PG3[0], PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
     } else if (unit32)
       hipLaunchKernelGGL(k_sort1<true>, dim3(blocks), dim3(S1_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
-                         ctx->sbShift, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
+                         sbS, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
     else
       hipLaunchKernelGGL(k_sort1<false>, dim3(blocks), dim3(S1_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
-                         ctx->sbShift, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
+                         sbS, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
   }
   if (gridB)  // the coarse lists (all pieces' events) -> the fine bins' lists
     hipLaunchKernelGGL(k_sort_b, dim3(gridB), dim3(S2_NT), 0, s, pcLast, (const uint8_t*)ctx->auxC.as<uint8_t>(), ncLast, nL1, PG3[0],
@@ -802,7 +815,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   }
   if (!fused) {
     // level 2: one workgroup per super-bucket
-    const size_t lds2 = std::max(b2_lds_bytes<u32>(1u << ctx->sbShift), b2_lds_bytes<u64>(1u << ctx->sbShift));
+    const size_t lds2 = std::max(b2_lds_bytes<u32>(1u << sbS), b2_lds_bytes<u64>(1u << sbS));
     if (ctx->b2LdsSet != lds2) {
       HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket2p), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
       ctx->b2LdsSet = lds2;
@@ -811,7 +824,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     Bucket2Jobs BJ{{{PG3[0], SS.a.p, SS.sbOff.as<u32>(), ctx->tileCnt[0].as<u32>()},
                     {PG3[1], SE.a.p, SE.sbOff.as<u32>(), ctx->tileCnt[1].as<u32>()},
                     {PG3[2], SF.a.p, SF.sbOff.as<u32>(), ctx->tileCnt[2].as<u32>()}}};
-    hipLaunchKernelGGL(k_bucket2p, dim3(std::max(1u, nL1), 3), dim3(B2_NT), lds2, s, BJ, nL1, ctx->sbShift, nTiles,
+    hipLaunchKernelGGL(k_bucket2p, dim3(std::max(1u, nL1), 3), dim3(B2_NT), lds2, s, BJ, nL1, sbS, nTiles,
                        ctx->tileWsum.as<int>());
     if (int rc__ = dbg_sync(ctx, "k_bucket2p")) return rc__;
     if (getenv("GX_DEBUG_SORT")) {
@@ -887,16 +900,16 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
         HIPCHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbtLds)));
       ctx->sbtLdsSet = true;
     }
-    HIPCHECK(ctx->bigBins.ensure((size_t)(MAX_BINS + 4) * 4));
+    HIPCHECK(ctx->bigBins.ensure((size_t)(MAX_BINS_P + 4) * 4));
     SbtIn si{PG3[0], PG3[1], PG3[2], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
-             ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, ctx->sbShift,
+             ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, sbS,
              ctx->fracPairsUsed ? (const FragFix*)ff : (const FragFix*)nullptr, ctx->fracPairsUsed ? acc : (long long*)nullptr};
     SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>(), ctx->nWide.as<u32>() + 1, ctx->nWide.as<u32>() + 13,
                ctx->bigBins.as<u32>(), ctx->heavyList.as<u32>(), ctx->nWide.as<u32>() + 2};
     const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
     // a sample so dense that the average bin already holds more keys than the key array (ATAC cut sites of a deep
     // library): every bin takes the rounds of the second launch, the first one would only find that out bin by bin
-    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 4);
+    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 16);
     if (dense) {
       so2.bigList = nullptr;
       if (ctx->fracPairsUsed)

@@ -846,8 +846,9 @@ constexpr int S2_LCHROM = 96;     // chromosome records k_sort_a keeps in LDS (l
 constexpr int S2_ITEMS = 8192 / S2_NT;
 static_assert(S2_ITEMS == 16 || S2_ITEMS == 8, "512 or 1024 threads");
 constexpr int S2_CHUNK = S2_NT * S2_ITEMS;
-constexpr int S2_KEYS = 64;
-constexpr int S2_FINE_SHIFT = 6;   // fine bins per coarse bin (log2)
+constexpr int S2_KEYS = 128;       // keys of one scatter at most (k_sort_a: <= 64 coarse bins; k_sort_b: 64 or 128 fine bins)
+constexpr int MAX_BINS_P = 8192;   // level-1 bins in pair mode: 64 coarse x 128 fine (a dense sample takes half-size bins)
+__host__ __device__ inline int s2_fine_shift(u32 nBins) { return nBins > 4096u ? 7 : 6; }  // fine bins per coarse bin (log2)
 static_assert(S2_CHUNK == (1 << PgCfg<u32>::SHIFT), "k_sort_b: one workgroup per page of a coarse list");
 static_assert(S2_CHUNK == S1_CHUNK, "one grid size for the level-1 kernels");
 
@@ -857,35 +858,48 @@ struct S2Lds {
   // the run's first record, w pool index of the first record in the run's second page (one 16-byte read per record)
   __attribute__((aligned(16))) uint4 run[S2_KEYS];
   u32 total;
+  u32 wtot[2];            // records of the keys 0 .. 63 / 64 .. 127 (the two owner wavefronts' totals)
   u32 scratch[24];
   u32 stage[S2_CHUNK];
-  uint16_t ka[S2_CHUNK];  // of a staged record: [5:0] its key, [15:8] the byte that travels along (k_sort_a: the fine bin)
+  uint16_t ka[S2_CHUNK];  // of a staged record: [6:0] its key, [15:8] the byte that travels along (k_sort_a: the fine bin)
 };
 
 // The coarse lists' pages hold the 4-byte records at page * 8192 * 4 of `pool` and the bytes at page * 8192 of `aux`.
 // AUX: whether the byte array is written (k_sort_a).  `listBase + key` = the list a key's run goes to.
-template <bool AUX>
+// KEYS: 64, or 128 (k_sort_b on a genome of more than 4096 bins): one owner thread per key -- the first wavefront, or two.
+template <bool AUX, int KEYS>
 __device__ __forceinline__ void scatter64(const u32 (&rec)[S2_ITEMS], u32 (&ka)[S2_ITEMS], const PagedStream& P,
                                           uint8_t* __restrict__ auxPool, u32 listBase, u32 nKeys, S2Lds& L, u32* __restrict__ st) {
-  // ka[k]: [5:0] key, [15:8] the byte that travels along, [31:16] the record's rank among its key's (filled here);
+  // ka[k]: [6:0] key, [15:8] the byte that travels along, [31:16] the record's rank among its key's (filled here);
   // NULL32 in rec = no record
+  static_assert(KEYS == 64 || KEYS == 128, "one or two owner wavefronts");
   constexpr int SHIFT = PgCfg<u32>::SHIFT;
   constexpr u32 PG = 1u << SHIFT;
+  constexpr u32 KM = (u32)KEYS - 1u;
 #pragma unroll
-  for (int k = 0; k < S2_ITEMS; k++) ka[k] = (ka[k] & 0xFFFFu) | ((rec[k] != NULL32 ? atomicAdd(&L.cnt[ka[k] & 63u], 1u) : 0u) << 16);
+  for (int k = 0; k < S2_ITEMS; k++) ka[k] = (ka[k] & 0xFFFFu) | ((rec[k] != NULL32 ? atomicAdd(&L.cnt[ka[k] & KM], 1u) : 0u) << 16);
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const u32 key = threadIdx.x;
-    const u32 c = key < nKeys ? L.cnt[key] : 0u;
-    const u32 li = listBase + key;
-    u32 o = 0;
+  // the owners: counts -> reservations on the lists' cursors -> where the runs start in the staged chunk and in the pool.
+  // Three steps with workgroup barriers between them (two owner wavefronts: the second needs the first one's total, and
+  // every page either of them allocates is published before any of their lanes waits for one)
+  const bool owner = threadIdx.x < (u32)KEYS;
+  const u32 key = threadIdx.x;
+  u32 c = 0, o = 0, inc = 0, li = 0;
+  if (owner) {
+    c = key < nKeys ? L.cnt[key] : 0u;
+    li = listBase + key;
     if (c) o = atomicAdd(&P.cursor[li], c);
-    const u32 inc = (u32)dpp_scan_add((int)c);
-    if (key == 63) L.total = inc;
-    const u32 in0 = o & (PG - 1), j0 = o >> SHIFT, j1 = (o + c - 1) >> SHIFT;
-    u32* row = P.pt + (size_t)li * P.jmax;
-    u32 p0 = 0, p1 = 0;
-    bool wait0 = false;
+    inc = (u32)dpp_scan_add((int)c);
+    if ((key & 63u) == 63u) L.wtot[key >> 6] = inc;
+  }
+  if (KEYS == 64 && threadIdx.x == 0) L.wtot[1] = 0;
+  __syncthreads();
+  const u32 in0 = o & (PG - 1), j0 = o >> SHIFT, j1 = (o + c - 1) >> SHIFT;
+  u32* row = P.pt + (size_t)li * P.jmax;
+  u32 p0 = 0, p1 = 0;
+  bool wait0 = false;
+  if (owner) {
+    if (key == 0) L.total = L.wtot[0] + L.wtot[1];
     if (c) {
       if (j1 != j0) p1 = page_alloc(P, row, j1, st);  // (the run holds that page's first slot)
       if (j0 == 0)
@@ -895,15 +909,17 @@ __device__ __forceinline__ void scatter64(const u32 (&rec)[S2_ITEMS], u32 (&ka)[
       else
         wait0 = true;
     }
-    __builtin_amdgcn_wave_barrier();  // (every allocation of the wavefront is published before any of its lanes waits)
+  }
+  __syncthreads();
+  if (owner) {
     if (wait0) p0 = page_wait(P, row, j0, st);
-    L.run[key] = make_uint4(inc - c, min(c, PG - in0), (p0 << SHIFT) + in0, p1 << SHIFT);
+    L.run[key] = make_uint4(inc - c + (key >= 64u ? L.wtot[0] : 0u), min(c, PG - in0), (p0 << SHIFT) + in0, p1 << SHIFT);
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < S2_ITEMS; k++)
     if (rec[k] != NULL32) {
-      const u32 pos = L.run[ka[k] & 63u].x + (ka[k] >> 16);
+      const u32 pos = L.run[ka[k] & KM].x + (ka[k] >> 16);
       L.stage[pos] = rec[k];
       L.ka[pos] = (uint16_t)ka[k];
     }
@@ -922,7 +938,7 @@ __device__ __forceinline__ void scatter64(const u32 (&rec)[S2_ITEMS], u32 (&ka)[
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const u32 i = (u32)(h + k) * S2_NT + threadIdx.x;
-      const uint4 rn = L.run[kk[k] & 63u];
+      const uint4 rn = L.run[kk[k] & KM];
       const u32 r = i - rn.x;
       const u32 dst = r < rn.y ? rn.z + r : rn.w + (r - rn.y);
       if (i < cnt) {
@@ -945,6 +961,7 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
                                                      Sort1Out out, u32* __restrict__ st) {
   __shared__ S2Lds L;
   __shared__ DChrom lchrom[S2_LCHROM];
+  const int fineShift = s2_fine_shift(nBins);
   // (unit-weight records and a fractional weight somewhere in the input: the sample is going to be built again on the
   // general chain whatever this launch still does -- the workgroups that start after the flag went up leave at once)
   if (!FRAC && (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_SB_FRAC)) return;
@@ -993,14 +1010,14 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
       const u32 cls = FRAC ? (u32)((0x70605432100ull >> (4u * (cnt & 15u))) & 7ull) << 9 : 0u;
       fracSeen |= (u32)(FRAC && fast && cnt != 1u);
       rec[k0 + q] = fast ? ((((t0 & binMask) << TB) | (e[q].y & (TILE - 1))) << PAIR_LEN_BITS) | cls | len : NULL32;
-      ka[k0 + q] = (bin >> S2_FINE_SHIFT) | ((bin & ((1u << S2_FINE_SHIFT) - 1u)) << 8);
+      ka[k0 + q] = (bin >> fineShift) | ((bin & ((1u << fineShift) - 1u)) << 8);
       covered32 += fast && cnt == 1u ? len : 0u;
       slow |= (u32)(!fast && !nothing) << (k0 + q);
     }
     __builtin_amdgcn_sched_barrier(0);  // (the next batch's loads stay behind this one's conversion: registers)
   }
   u64 covered = covered32;
-  scatter64<true>(rec, ka, PC, auxPool, x * nCoarse, nCoarse, L, st);
+  scatter64<true, 64>(rec, ka, PC, auxPool, x * nCoarse, nCoarse, L, st);
   // the slow events: loaded again (they are in L2), converted as k_sort1 converts every event, their records appended
   // one by one
   if (__ballot(slow != 0)) {
@@ -1063,6 +1080,7 @@ __global__ __launch_bounds__(S2_NT, GX_S2B_WAVES) void k_sort_b(PagedStream PC, 
     const u32 inc = (u32)dpp_scan_add((int)np), ex = inc - np;
     if (threadIdx.x == 0) sCount = 0;
     L.cnt[threadIdx.x] = 0;
+    L.cnt[threadIdx.x + 64] = 0;
     __builtin_amdgcn_wave_barrier();
     if (q >= ex && q < inc) {
       const u32 j = q - ex;
@@ -1106,7 +1124,12 @@ __global__ __launch_bounds__(S2_NT, GX_S2B_WAVES) void k_sort_b(PagedStream PC, 
     }
   }
   // (a pair record is never NULL32: its length is below 2^12 - 1 ... and a page holds only records)
-  scatter64<false>(rec, ka, PP, nullptr, x * nBins + (cb << S2_FINE_SHIFT), min((u32)S2_KEYS, nBins - (cb << S2_FINE_SHIFT)), L, st);
+  const int fineShift = s2_fine_shift(nBins);
+  const u32 firstBin = cb << fineShift, nk = min(1u << fineShift, nBins - firstBin);
+  if (fineShift == 7)  // block-uniform
+    scatter64<false, 128>(rec, ka, PP, nullptr, x * nBins + firstBin, nk, L, st);
+  else
+    scatter64<false, 64>(rec, ka, PP, nullptr, x * nBins + firstBin, nk, L, st);
 }
 
 // bin totals (over the XCD classes) -> where each super-bucket's records start after level 2; one workgroup per stream.
@@ -1181,7 +1204,7 @@ __device__ __forceinline__ void scan_bins_body(const BinScan& B, u32 nBins, u32 
   }
   const u32* cursor = B.cursor[block];
   u32* sbOff = B.sbOff[block];
-  constexpr int PER = MAX_BINS / 1024;
+  constexpr int PER = MAX_BINS_P / 1024;
   u32 v[PER], sum = 0;
   {  // the longest list of this stream, in pages (cursors count every reservation, also those beyond the table row)
     const int shift = block == 2 ? PgCfg<u64>::SHIFT : PgCfg<u32>::SHIFT;
@@ -1191,11 +1214,13 @@ __device__ __forceinline__ void scan_bins_body(const BinScan& B, u32 nBins, u32 
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, d, 64));
     if (lane_id() == 0 && mx) atomicMax(B.needPages, (mx >> shift) + 1u);
   }
+  // (a thread takes `per` consecutive bins, as few as the bin count asks for: 3 for hg38's 2,946)
+  const u32 per = (nBins + 1023u) / 1024u;
 #pragma unroll
   for (int k = 0; k < PER; k++) {
-    const u32 i = threadIdx.x * PER + k;
+    const u32 i = threadIdx.x * per + k;
     v[k] = 0;
-    if (i < nBins) {
+    if ((u32)k < per && i < nBins) {
       if (B.pairMode && block == 0) {
         for (int x = 0; x < NXCD; x++)
           v[k] += 2u * min(cursor[x * nBins + i], B.cap[0]) + min(B.cursor[2][x * nBins + i], B.cap[2]);
@@ -1211,8 +1236,8 @@ __device__ __forceinline__ void scan_bins_body(const BinScan& B, u32 nBins, u32 
   u32 ex = block_excl_scan<u32, 1024>(sum, scratch, &tot);
 #pragma unroll
   for (int k = 0; k < PER; k++) {
-    const u32 i = threadIdx.x * PER + k;
-    if (i < nBins) sbOff[i] = ex;
+    const u32 i = threadIdx.x * per + k;
+    if ((u32)k < per && i < nBins) sbOff[i] = ex;
     ex += v[k];
   }
   if (threadIdx.x == 0) sbOff[nBins] = tot;
