@@ -602,7 +602,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   u32 nL1 = nL1base;
   // (not with fractional weights: measured at config 4, the tile passes with weights and the fragLen terms cost more per
   // key than the rounds of full-size bins -- 2.98 against 2.67 ms)
-  if (pairs && !fracPairs && !onePass && sbS > 0 && (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * (SBT_KEYCAP - SBT_KEYCAP / 4) &&
+  const bool forceHalf = getenv("GX_FORCE_HALF_BINS") != nullptr;  // (tests: the 128-key level 1 on a small input)
+  if (pairs && (!fracPairs || forceHalf) && !onePass && sbS > 0 &&
+      (forceHalf || (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * (SBT_KEYCAP - SBT_KEYCAP / 4)) &&
       ((nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1)) <= (u32)MAX_BINS_P && getenv("GX_NO_HALF_BINS") == nullptr) {
     sbS--;
     nL1 = (nTiles + (1u << sbS) - 1) >> sbS;

@@ -224,3 +224,27 @@ def test_page_tables_grow_when_a_list_outgrows_its_row(monkeypatch):
 def test_page_tables_do_not_grow_in_an_ordinary_run():
     o, h, flags = _run(_case(seed=23, n=90_000), B.make_params(pq=0.01, min_auc=50.0))
     assert not flags & PT_GREW
+
+
+@pytest.mark.parametrize("frac", [False, True])
+def test_half_size_bins_and_the_128_key_level_1(monkeypatch, frac):
+    """A dense sample takes bins of half the size; beyond 4096 of them level 1's second pass scatters to 128 fine bins per
+    coarse one (two owner wavefronts).  Forced here on a 36 Mbp genome with 2-tile bins (4,395 half-size bins)."""
+    monkeypatch.setenv("GX_SBSHIFT", "1")
+    monkeypatch.setenv("GX_FORCE_HALF_BINS", "1")
+    lens = [20_000_000, 16_000_000]
+    # (fractional weights: fragLen stays below 2^26, where the reference's own accumulation is still exact)
+    ev = synth.make_fragments(lens, 250_000 if frac else 400_000, 77, peak_every=200_000, tower_every=5_000_000)
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    reps = [dict(save=None, treat=ev, ctrl=None)]
+    if frac:
+        warm = synth.add_multimap(synth.make_fragments(lens, 2_000, 5), lens, 0.5, 6)
+        reps = [dict(save=None, treat=warm, ctrl=None), dict(save=None, treat=synth.add_multimap(ev, lens, 0.2, 78), ctrl=None)]
+    case = dict(lens=lens, replicates=reps)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    sh = B.run_case(h, case)
+    flags = h.path_info()
+    assert_same_run(o, h, so, sh, case)
+    assert flags & FUSED and flags & 16
