@@ -1992,6 +1992,26 @@ int gx_saturation_dropped(gx_ctx* ctx, long long* n) {
   return GX_OK;
 }
 
+int gx_window_net(gx_ctx* ctx, uint32_t chrom, uint32_t pos0, uint32_t n, long long* net) {
+  if (!ctx || (ctx->phase != 1 && ctx->phase != 3) || !net || !n || n > (1u << 16) || chrom >= ctx->nChrom) return GX_ERR_ORDER;
+  HIPCHECK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  DevBuf dNet;
+  HIPCHECK(dNet.ensure((size_t)n * 8));
+  HIPCHECK(hipMemsetAsync(dNet.p, 0, (size_t)n * 8, s));
+  for (auto& sg : ctx->segs) {
+    if (!sg.n) continue;
+    if (sg.ready) HIPCHECK(hipStreamWaitEvent(s, sg.ready, 0));  // (its upload, on the side stream)
+    const u32 blocks = (u32)std::min<size_t>((sg.n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_window_net, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(sg.p), sg.n, chrom, ctx->len[chrom],
+                       pos0, n, dNet.as<unsigned long long>());
+  }
+  HIPCHECK(hipMemcpyAsync(net, dNet.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  HIPCHECK(hipGetLastError());
+  return GX_OK;
+}
+
 int gx_sample_no_control(gx_ctx* ctx, float* lambda) {
   if (!ctx || ctx->phase != 2) return GX_ERR_ORDER;
   if (lambda) *lambda = ctx->hScal.lambda;  // computed with fragLen (calcLambda 1831)

@@ -976,6 +976,23 @@ __global__ __launch_bounds__(256) void k_hot_check(TileIn in, const u32* __restr
   }
 }
 
+// The difference array of ONE window of a chromosome from the events pushed so far (gx_window_net): net[i] = weight of
+// the events that start at pos0 + i minus the weight of those that end there, as saveInterval's `diff` holds them
+// (Genrich.c:2576-2583; ends clamped to the chromosome's length as 2536-2544 does, the entry at `len` included).  For a
+// caller that reproduces the int16 checks read by read: it asks once per window that comes near the limits.
+__global__ __launch_bounds__(256) void k_window_net(const uint4* __restrict__ ev, size_t n, u32 chrom, u32 clen, u32 pos0, u32 nPos,
+                                                    unsigned long long* __restrict__ net) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint4 e = ev[i];
+    const u32 cnt = e.w;
+    if (e.x != chrom || e.y >= clen || cnt > 10u || !((0x57Eu >> cnt) & 1u)) continue;
+    const long long w = (long long)(GX_UNIT / (int)cnt);
+    const u32 end = e.z > clen ? clen : e.z;
+    if (e.y - pos0 < nPos) atomicAdd(&net[e.y - pos0], (unsigned long long)w);
+    if (end - pos0 < nPos) atomicAdd(&net[end - pos0], (unsigned long long)(-w));
+  }
+}
+
 // ---- heavy tiles: one WORKGROUP per tile, a counter per base (the general chain's tile stage, after k_tile_fast) ----
 // The reference's own formulation on one tile (savePileupExpt 2197-2273): difference array -> prefix sum ->
 // run-length intervals, with the array (16 KB) in LDS.  Each thread owns four consecutive bases.

@@ -52,6 +52,7 @@
 
 #include "../../include/genrich_amd.h"
 #include "bgzf_reader.h"
+#include "../csrc/gx_saturate.h"  // (host-only: the canonical int16 part of a difference, the weights)
 
 #define VERSION "0.6.2-amd"
 #define MAX_ALNS 128  // Genrich.h:17 (also the length of stored read names)
@@ -71,7 +72,11 @@ thread_local std::pair<std::string, std::string>* t_capture = nullptr;
     throw DecodeAbort{};
   }
   fprintf(stderr, "Error! %s%s\n", msg.c_str(), tail);
-  exit(EXIT_FAILURE);
+  // What the reference's exit() does that can be seen from outside is flushing its open streams; the reader, decoder,
+  // inflate and state threads of the ingest may still be running here, so nothing else is torn down under them (no
+  // static destructors, no atexit handlers -- the HIP runtime's among them -- next to live threads).
+  fflush(nullptr);
+  _exit(EXIT_FAILURE);
 }
 
 int getInt(const char* s) {  // 102-108
@@ -202,6 +207,46 @@ int devsAllgather(const void* local, size_t nLocal, void** out, size_t* nOut, vo
   return 0;
 }
 
+// ---- saveInterval's int16 checks, read by read (Genrich.c:2558-2573) ----------------------------------------------
+// The reference drops an alignment whose start lies on a base where its int16 difference already holds 32,767, or whose
+// end lies on one that holds -32,768: a warning with -v, no -b line, length 0 towards the -x average.  The library
+// reproduces the effect on the pileup by itself (gx_sample_end); what the reference PRINTS needs the decision when the
+// read is saved, in input order.  A base can only get there when its 4096-base window holds 32,766 starts (or ends), so:
+// the thread that owns the state counts the weight of starts and of ends per window (two increments per event); a window
+// that comes that far is "loaded" -- its exact difference per base so far comes from the device, which has every event
+// pushed up to now (gx_window_net) -- and kept on the host from then on.  Reads that touch a loaded window, or bring one
+// to the threshold, are decided on exact state; everything else cannot be dropped.  Real data never loads a window.
+struct HotWindows {
+  static constexpr int WB = 12;
+  static constexpr uint32_t WMASK = (1u << WB) - 1u;
+  bool on = false;
+  std::vector<size_t> base;                                   // first window of a chromosome (position `len` has an entry)
+  std::vector<uint32_t> ws, we;                               // weight (1/120) of the sample's starts / ends per window
+  std::unordered_map<size_t, std::vector<long long>> win;     // loaded windows: the exact difference per base
+  std::vector<gx_event> all;                                  // --events-only (no device to ask): the sample's events so far
+  void init(const std::vector<Chrom>& chrom) {
+    base.assign(chrom.size() + 1, 0);
+    for (size_t c = 0; c < chrom.size(); c++) base[c + 1] = base[c] + ((size_t)chrom[c].len >> WB) + 1;
+    ws.assign(base.back(), 0);
+    we.assign(base.back(), 0);
+    win.clear();
+    all.clear();
+  }
+  // an event of a chunk that the workers prepared: counted; true when it has to be decided on exact state instead
+  bool add(const gx_event& e) {
+    const uint32_t w = (uint32_t)gxsat::weight_of(e.count);
+    const size_t a = base[e.chrom] + (e.start >> WB), b = base[e.chrom] + (e.end >> WB);
+    ws[a] += w;
+    we[b] += w;
+    return ws[a] >= (uint32_t)gxsat::HOT || we[b] >= (uint32_t)gxsat::HOT || (!win.empty() && (win.count(a) || win.count(b)));
+  }
+  void sub(const gx_event& e) {
+    const uint32_t w = (uint32_t)gxsat::weight_of(e.count);
+    ws[base[e.chrom] + (e.start >> WB)] -= w;
+    we[base[e.chrom] + (e.end >> WB)] -= w;
+  }
+};
+
 struct State {
   Opts o;
   std::vector<Chrom> chrom;
@@ -220,6 +265,7 @@ struct State {
   bool ctrl = false;
   int sample = 0;
   uint64_t errCount = 0;
+  HotWindows hot;            // (with a device: saveInterval's int16 checks)
 };
 
 void check(State& S, int rc, gx_ctx* which = nullptr) {
@@ -368,11 +414,69 @@ void warnPlain(const char* fmt, ...) {
   va_end(ap);
 }
 void pushEvent(State& S, const gx_event& e) {  // (state's side: the library takes the events in pieces of 2^20)
+  if (!S.gx && S.hot.on) S.hot.all.push_back(e);
   S.buf.push_back(e);
   if (S.buf.size() >= (1u << 20)) {
     if (S.gx && S.sampleOpen) flushEvents(S);
     if (!S.gx || S.sampleOpen) S.buf.clear();  // --events-only keeps nothing
   }
+}
+
+// A loaded window's exact difference (1/120 units per base): from the device, which is sent what the host still holds first.
+std::vector<long long>& hotLoad(State& S, uint32_t ci, size_t gw) {
+  auto it = S.hot.win.find(gw);
+  if (it != S.hot.win.end()) return it->second;
+  if (S.gx && S.sampleOpen && !S.buf.empty()) {
+    flushEvents(S);
+    S.buf.clear();
+  }
+  std::vector<long long> net((size_t)1 << HotWindows::WB, 0);
+  const uint32_t pos0 = (uint32_t)((gw - S.hot.base[ci]) << HotWindows::WB);
+  const uint32_t n = std::min<uint32_t>(1u << HotWindows::WB, S.chrom[ci].len + 1 - pos0);
+  if (!S.gx) {  // --events-only: no device to ask; the sample's events were kept for this
+    for (const gx_event& e : S.hot.all) {
+      if (e.chrom != ci) continue;
+      const long long w = gxsat::weight_of(e.count);
+      if (e.start - pos0 < n) net[e.start - pos0] += w;
+      if (e.end - pos0 < n) net[e.end - pos0] -= w;
+    }
+  } else if (S.sampleOpen) {
+    gx_ctx* g = S.devs.n() == 1 ? S.gx : S.devs.ctx[S.devs.owner[ci]];
+    check(S, gx_window_net(g, ci, pos0, n, net.data()), g);
+  }
+  return S.hot.win.emplace(gw, std::move(net)).first->second;
+}
+// the state's owner, one event at a time: false when the reference would have dropped it (its warning printed)
+bool hotKeeps(State& S, const gx_event& e, const char* qname) {
+  HotWindows& H = S.hot;
+  const long long w = gxsat::weight_of(e.count);
+  if (!w) return true;  // (the library reports the count: ERRALNS)
+  const size_t a = H.base[e.chrom] + (e.start >> HotWindows::WB), b = H.base[e.chrom] + (e.end >> HotWindows::WB);
+  const bool nearA = H.ws[a] + (uint32_t)w >= (uint32_t)gxsat::HOT, nearB = H.we[b] + (uint32_t)w >= (uint32_t)gxsat::HOT;
+  if (nearA || nearB || !H.win.empty()) {
+    std::vector<long long>* wa = nearA || H.win.count(a) ? &hotLoad(S, e.chrom, a) : nullptr;
+    std::vector<long long>* wb = nearB || H.win.count(b) ? &hotLoad(S, e.chrom, b) : nullptr;
+    const Chrom& c = S.chrom[e.chrom];
+    if (wa && gxsat::canon_cov((*wa)[e.start & HotWindows::WMASK]) == 32767) {
+      if (S.o.verbose) {
+        fprintf(stderr, "Warning! Read %s, alignment at (%s, %ld-%ld)", qname, c.name.c_str(), (long)e.start, (long)e.end);
+        fprintf(stderr, " skipped due to overflow\n");
+      }
+      return false;
+    }
+    if (wb && gxsat::canon_cov((*wb)[e.end & HotWindows::WMASK]) == -32768) {
+      if (S.o.verbose) {
+        fprintf(stderr, "Warning! Read %s, alignment at (%s, %ld-%ld)", qname, c.name.c_str(), (long)e.start, (long)e.end);
+        fprintf(stderr, " skipped due to underflow\n");
+      }
+      return false;
+    }
+    if (wa) (*wa)[e.start & HotWindows::WMASK] += w;
+    if (wb) (*wb)[e.end & HotWindows::WMASK] -= w;
+  }
+  H.ws[a] += (uint32_t)w;
+  H.we[b] += (uint32_t)w;
+  return true;
 }
 
 // ---- saveInterval (2516-2591): clamp, event, -b line ----------------------------------------
@@ -393,7 +497,10 @@ uint32_t saveInterval(State& S, int ci, int64_t start, int64_t end, const char* 
   }
   const gx_event e{(uint32_t)ci, (uint32_t)start, (uint32_t)end, count};
   if (t_sink) t_sink->ev.push_back(e);
-  else pushEvent(S, e);
+  else {
+    if (S.hot.on && !hotKeeps(S, e, qname)) return 0;  // 2558-2573
+    pushEvent(S, e);
+  }
   if (S.bedOpt) {
     if (t_sink) {
       char num[96];
@@ -1026,10 +1133,14 @@ void headerLine(State& S, char* line) {  // checkHeader 4307-4342, loadChrom 427
 void openSample(State& S) {
   if (S.sampleOpen) return;
   S.sampleOpen = true;
-  if (!S.gx) return;
+  if (!S.gx) {
+    if (S.hot.on) S.hot.init(S.chrom);
+    return;
+  }
   std::vector<uint8_t> save(S.chrom.size());
   for (size_t k = 0; k < S.chrom.size(); k++) save[k] = S.chrom[k].save;
   for (gx_ctx* g : S.devs.ctx) check(S, gx_sample_begin(g, S.ctrl ? 1 : 0, S.ctrl ? nullptr : save.data()), g);
+  if (S.hot.on) S.hot.init(S.chrom);  // (the reference's difference arrays start at zero with every file)
 }
 
 struct ReadSet {
@@ -1453,12 +1564,33 @@ void processChunk(State& S, Chunk& ch, int qualOffset) {
   t_capture = nullptr;
   ch.unpair = std::move(rs.unpair);
   ch.dup = std::move(rs.dup);
-  ch.segs.clear();  // (the batches go as soon as nobody needs their bytes)
+  if (!S.hot.on) ch.segs.clear();  // (the batches go as soon as nobody needs their bytes; with the int16 checks on, the owner may want them again)
 }
 
 // the state's owner takes a chunk's results (in file order)
-void mergeChunk(State& S, ReadSet& rs, Counts& C, Chunk& ch) {
+void mergeChunk(State& S, ReadSet& rs, Counts& C, Chunk& ch, int qualOffset) {
   openSample(S);  // (record() does it at the first record that gets that far; nothing goes to the device before)
+  if (S.hot.on) {
+    // saveInterval's int16 checks: the chunk's events are counted; one that could be dropped, or that touches a window
+    // kept exactly, sends the whole chunk through the state machine again, on this thread and in order, where every
+    // read is decided as the reference decides it (the workers' results are not used)
+    bool exact = false;
+    for (const gx_event& e : ch.sink.ev) exact |= S.hot.add(e);
+    if (exact) {
+      for (const gx_event& e : ch.sink.ev) S.hot.sub(e);
+      ReadSet local;  // (a chunk begins and ends between two read-name groups)
+      for (auto& sg : ch.segs)
+        for (uint32_t i = sg.i0; i < sg.i1; i++) applyDecoded(S, local, C, *sg.b, i, qualOffset);
+      flushSet(S, local, C);
+      for (auto& u : local.unpair) rs.unpair.push_back(std::move(u));
+      for (auto& d : local.dup.pr) rs.dup.pr.push_back(std::move(d));
+      for (auto& d : local.dup.dc) rs.dup.dc.push_back(std::move(d));
+      for (auto& d : local.dup.sn) rs.dup.sn.push_back(std::move(d));
+      ch.segs.clear();
+      return;
+    }
+    ch.segs.clear();
+  }
   for (auto& w : ch.sink.warn) {
     if (w.second) {
       if (S.errCount < MAX_ALNS) fputs(w.first.c_str(), stderr);
@@ -1555,7 +1687,7 @@ void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOf
   bool have = false;
   std::string name;  // the current group's name as record() keeps it (the first MAX_ALNS characters)
   auto mergeReady = [&](bool block) {
-    while (ChunkPool::Ptr c = pool.take(block)) mergeChunk(S, rs, C, *c);
+    while (ChunkPool::Ptr c = pool.take(block)) mergeChunk(S, rs, C, *c, qualOffset);
   };
   while (DecodePipe::Ptr b = pipe.next()) {
     uint32_t i0 = 0;
@@ -1611,13 +1743,13 @@ void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOf
     mergeReady(false);
     while (pool.pending() > window) {  // (the workers are behind: wait for the oldest chunk rather than queue without bound)
       ChunkPool::Ptr c = pool.take(true);
-      if (c) mergeChunk(S, rs, C, *c);
+      if (c) mergeChunk(S, rs, C, *c, qualOffset);
     }
   }
   if (cur->nrec) pool.submit(cur);
   while (pool.pending()) {
     ChunkPool::Ptr c = pool.take(true);
-    if (c) mergeChunk(S, rs, C, *c);
+    if (c) mergeChunk(S, rs, C, *c, qualOffset);
   }
 }
 
@@ -2349,6 +2481,8 @@ int main(int argc, char** argv) {
   }
   if (o.bedFile) { S.bed = openWrite(o.bedFile, o.gzOut); S.bedOpt = true; }
   if (o.dupsOpt && o.dupsFile) { S.dups = openWrite(o.dupsFile, o.gzOut); S.dupsVerb = true; }  // 5411-5415
+  // (--events-only writes nothing but the -b file: without one there is nothing the checks could change)
+  if (o.eventsOnly) S.hot.on = o.bedFile != nullptr && getenv("GENRICH_NO_INT16") == nullptr;
   if (!o.eventsOnly) {
     gx_params par{};
     par.thr = thr;
@@ -2371,6 +2505,7 @@ int main(int argc, char** argv) {
       D.ctx.push_back(g);
     }
     S.gx = D.ctx[0];
+    S.hot.on = getenv("GENRICH_NO_INT16") == nullptr;  // (saveInterval's int16 checks, read by read: HotWindows)
     D.buf.resize(D.n());
     if (D.n() > 1) {
       const int W = (int)D.n();

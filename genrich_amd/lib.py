@@ -60,6 +60,7 @@ _SIGS = {
     "gx_sample_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "gx_sample_no_control": [C.c_void_p, C.POINTER(C.c_float)],
     "gx_saturation_dropped": [C.c_void_p, C.POINTER(C.c_longlong)],
+    "gx_window_net": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p],
     "gx_pvalues": [C.c_void_p],
     "gx_find_peaks": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "gx_get_peaks": [C.c_void_p, C.c_void_p, C.c_size_t],
@@ -197,6 +198,12 @@ class Genrich:
     def expect_fractional(self, on=True):
         """Hint: the run may hold fractional weights (Genrich's -s): pair records with a weight class from the first sample on."""
         self._check(self.lib.gx_expect_fractional(self.ctx, int(bool(on))))
+
+    def window_net(self, chrom, pos0, n):
+        """The open sample's difference array on [pos0, pos0 + n) of a chromosome (1/120 units), from the events pushed so far."""
+        out = np.zeros(n, dtype=np.int64)
+        self._check(self.lib.gx_window_net(self.ctx, chrom, pos0, n, out.ctypes.data))
+        return out
 
     def set_keep_pileups(self, keep):
         """keep=False: the pileup floats of the p-value intervals (only the -f / -k emitters read them)

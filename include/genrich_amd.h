@@ -134,6 +134,18 @@ int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n);
  * that can saturate at all.  Returns the number of events dropped, or a negative gx_status. */
 long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, const uint32_t* len, uint8_t* keep);
 
+/* The OPEN sample's difference array on [pos0, pos0 + n) of one chromosome, from the events pushed so far (between
+ * gx_sample_begin and gx_sample_end): net[i] = weight, in 1/120 units, of the events that start at pos0 + i minus the
+ * weight of those that end there -- the exact value of saveInterval's diff[pos0 + i] (Genrich.c:2576-2583; an end beyond
+ * the chromosome counts at its length, 2536-2544, so pos0 + i may be the length itself; events that gx_sample_end would
+ * reject are left out).  For a caller that needs saveInterval's int16 decisions READ BY READ -- the -v warnings
+ * "skipped due to overflow / underflow", the missing -b line, the length 0 towards the -x average (2558-2573) --
+ * and not only their effect on the pileup (which gx_sample_end reproduces by itself): it counts starts and ends per
+ * window as it pushes, asks for a window's exact state when one comes near 32,767, and keeps that window itself from
+ * then on (genrich_amd/host/genrich_amd.cpp: HotWindows).  One pass over the pushed events; waits for their uploads.
+ * n <= 65536. */
+int gx_window_net(gx_ctx* ctx, uint32_t chrom, uint32_t pos0, uint32_t n, long long* net);
+
 /* PCR duplicates (-r): the membership half of findDupsPr / findDupsSn (Genrich.c:3616-3690, 3886-3944; the tables'
  * keys are the fields jenkins_hash_aln hashes, 3408-3450, packed by the host into four words -- an alignment-type tag
  * with the chromosome(s), the 5' end(s), the strand(s)).  keys[0..n) are the alignments of a file's sets in the order

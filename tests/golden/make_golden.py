@@ -70,6 +70,20 @@ def mf(lens, n, seed, peak_every=8000, tower_every=30000, **kw):
                                 frac_tower=0.3, **kw)
 
 
+def int16_towers(lens, n_start, n_end, seed):
+    """n_start fragments [1000, 1200), n_end fragments that all end at 5400 (starts spread over 50 bases) and some
+    background, in random order."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bg = mf(lens, 1500, seed + 1000)
+    a = np.zeros(n_start, dtype=synth.EVENT_DTYPE)
+    a["start"], a["end"], a["count"] = 1000, 1200, 1
+    b = np.zeros(n_end, dtype=synth.EVENT_DTYPE)
+    b["start"] = 5000 + 2 * rng.integers(0, 50, n_end)
+    b["end"], b["count"] = 5400, 1
+    ev = np.concatenate([bg, a, b])
+    return ev[rng.permutation(len(ev))]
+
+
 def cases():
     L1 = [60_000]
     yield dict(
@@ -162,6 +176,15 @@ def cases():
             name=nm, names=N2, args=extra + ["-a", "20"], mixed=dict(seed=33, bam=isbam, writer="dups", quirks=0.3),
             reps=[dict(t=(N2, L2, mf(L2, 2000, 101)), c=(N2, L2, mf(L2, 1500, 102, uniform_only=True)))])
 
+    # saveInterval's int16 limits (Genrich.c:2558-2573): > 32,767 alignments that start on one base ("skipped due to
+    # overflow"), > 32,768 that end on one ("underflow"), in shuffled order among ordinary reads; 30 % of them unpaired
+    # and extended to the average fragment length at the end of the file (-x: the dropped pairs count as length 0).
+    # The control piles 20,000 reads on the same bases: nothing of the treatment's state may be left.
+    yield dict(
+        name="saturate16", names=["chrA"], args=["-x", "-a", "20"], mixed=dict(seed=5, bam=False), int16=True,
+        reps=[dict(t=(["chrA"], L1, int16_towers(L1, 47_600, 47_400, 61)),
+                   c=(["chrA"], L1, int16_towers(L1, 20_000, 20_000, 62)))])
+
     # -X: no peak calling, just the -f log (logIntervals, Genrich.c:837)
     yield dict(
         name="nopeaks_log", names=N2, args=["-X", "-q", "0.05"],
@@ -198,6 +221,8 @@ def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/Genrich missing: run `make -C oracle` in the build container")
     for case in cases():
+        if sys.argv[1:] and case["name"] not in sys.argv[1:]:
+            continue  # (python make_golden.py <case> ...: only those)
         out_dir = os.path.join(HERE, case["name"])
         os.makedirs(out_dir, exist_ok=True)
         tmp = os.path.join("/tmp/genrich_golden", case["name"])
@@ -276,6 +301,9 @@ def main():
         )
         with open(os.path.join(out_dir, "case.json"), "w") as f:
             json.dump(meta, f, indent=1)
+        if case.get("int16"):  # the reference's read-by-read warnings, in order
+            with gzip.GzipFile(os.path.join(out_dir, "out.int16.gz"), "wb", mtime=0) as g:
+                g.write("".join(l + "\n" for l in err.splitlines() if "skipped due to" in l).encode())
         for fn in ("events.bed", "out.narrowPeak", "out.log", "out.pile", "out.dups"):
             src = os.path.join(tmp, fn)
             if os.path.exists(src):

@@ -561,6 +561,38 @@ def test_int16_saturation_skips_as_in_the_reference(seed):
     assert_same_run(o, h, so, sh, case)
 
 
+def test_window_net_is_the_open_samples_difference_array():
+    """gx_window_net: the exact diff[] of saveInterval on a window, from the events pushed so far (several pushes, fractional
+    weights, ends clamped to the chromosome's length, rejected events left out) -- what genrich-amd's read-by-read int16
+    checks start from."""
+    lens = [20_000, 8_000]
+    _, ev = _saturating_case(1, frac=True)
+    extra = np.zeros(3, dtype=B.EVENT_DTYPE)
+    extra["chrom"], extra["start"], extra["end"], extra["count"] = [1, 1, 0], [7_900, 100, 19_000], [9_000, 200, 30_000], [1, 2, 4]
+    ev = np.concatenate([ev, extra])
+    h = hip_backend(B.make_params(pq=0.01))
+    h.set_chroms(lens)
+    h.sample_begin(0, None)
+    w = np.array([0, 120, 60, 40, 30, 24, 20, 0, 15, 0, 12], dtype=np.int64)
+    third = len(ev) // 3
+    for part, upto in ((ev[:third], third), (ev[third:], len(ev))):
+        h.push_events(part)
+        seen = ev[:upto]
+        for c, pos0, n in ((0, 4096, 4096), (0, 8192, 4096), (1, 4096, 8_001 - 4096), (0, 16384, 20_001 - 16384)):
+            want = np.zeros(n, dtype=np.int64)
+            m = seen[seen["chrom"] == c]
+            end = np.minimum(m["end"], lens[c])
+            ws = w[m["count"]]
+            a = (m["start"] >= pos0) & (m["start"] < pos0 + n)
+            np.add.at(want, m["start"][a] - pos0, ws[a])
+            b = (end >= pos0) & (end < pos0 + n)
+            np.add.at(want, end[b] - pos0, -ws[b])
+            assert np.array_equal(h.window_net(c, pos0, n), want), (c, pos0)
+    h.sample_end()
+    with pytest.raises(Exception):
+        h.window_net(0, 0, 16)  # (only while a sample is open)
+
+
 def test_saturation_only_at_the_chromosome_end():
     """The reference's difference array has an entry at `len` as well (every fragment clamped to the end
     of its chromosome lands there); those events have no end record on the device and are counted per

@@ -70,9 +70,14 @@ def test_cli_event_stream_matches_reference(name, tmp_path):
     dups = str(tmp_path / "dups.txt")
     if "-r" in a:  # -R: the log of removed PCR duplicates (file names in its '#' lines differ by directory)
         a += ["-R", dups, "-v"]
+    int16 = G.read_gz(name, "out.int16")  # saveInterval's "skipped due to overflow / underflow" lines (Genrich.c:2558-2573)
+    if int16 is not None:
+        a += ["-v"]
     res = subprocess.run([_binary(), "--events-only", "-b", bed] + a, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     assert open(bed, "rb").read() == G.read_gz(name, "events.bed")
+    if int16 is not None:
+        assert [l for l in res.stderr.splitlines() if "skipped due to" in l] == int16.decode().splitlines()
     if "-r" in a:
         strip = lambda txt: [l if not l.startswith("#") else l.rsplit("/", 1)[0].rsplit(" ", 1)[0] for l in txt.splitlines()]
         assert strip(open(dups).read()) == strip(G.read_gz(name, "out.dups").decode())
@@ -107,6 +112,10 @@ def test_cli_outputs_byte_identical(name):
         assert open(out + ".dups", "rb").read() == G.read_gz(name, "out.dups")
     lam = [f"{v:f}" for v in meta["ref_lambda"]]
     assert [l.split(": ")[1] for l in res.stderr.splitlines() if "Background pileup value" in l] == lam
+    int16 = G.read_gz(name, "out.int16")  # the reads saveInterval dropped at its int16 limits, read by read (2558-2573)
+    if int16 is not None:
+        assert [l for l in res.stderr.splitlines() if "skipped due to" in l] == int16.decode().splitlines()
+        assert "16-bit counters" not in res.stderr  # (nothing was left for the library's own replay to drop)
     if meta["ref_peaks"]:
         assert f"Peaks identified: {meta['ref_peaks'][0][0]} ({meta['ref_peaks'][0][1]}bp)" in res.stderr
 
@@ -383,7 +392,7 @@ def test_cli_two_contexts_one_gpu_equal_one(name):
 
 # ---- parallel record decoding: decoder threads over batches of records, the state on one thread ----
 @pytest.mark.parametrize("name", ["basic", "multimap", "dups_pairs", "dups_x_bam", "quirks_sam", "quirks_bam",
-                                  "unpaired_x", "unpaired_bam_atac", "ctrl_q", "reps3"])
+                                  "unpaired_x", "unpaired_bam_atac", "ctrl_q", "reps3", "saturate16"])
 @pytest.mark.parametrize("threads,batch,chunk", [("1", None, None), ("4", None, None), ("4", "150", "3"), ("3", "1", "1"),
                                                  ("4", None, "serial")])
 def test_cli_parallel_decoding_is_the_sequential_stream(name, threads, batch, chunk, tmp_path):
