@@ -62,6 +62,12 @@ typedef struct gxo_ctx {
   int sample;      /* replicates finished (runProgram's `sample`) */
   int phase;       /* 0 idle, 1 treatment open, 2 treatment done, 3 control open, 4 ctrl done */
   double fragLen;  /* of the current replicate */
+  /* The same sum WITHOUT the reference's rounding, for the tests (not part of the restatement): every product of
+   * 2246 is a float, hence a multiple of 2^-27 here (val >= 1/10), so integer part and fraction * 2^27 add up exactly
+   * in two int64; fragInexact counts the additions of 2246 / 2271 that rounded (each by at most half a unit in the
+   * last place of the sum at that time).  A sum that never rounded IS the exact one. */
+  long long fragHi, fragLo;
+  uint64_t fragInexact;
   gx_peak* peaks;
   size_t nPeaks, memPeaks;
   uint64_t genomeLenUsed, peakBP;
@@ -454,9 +460,22 @@ static int fail(gxo_ctx* x, int code, const char* msg) {
   return code;
 }
 
+/* fragLen += term (2246, 2271), and beside it the exact parts / the count of roundings (see gxo_ctx) */
+static void addTerm(gxo_ctx* x, double* sum, float term) {
+  const double a = *sum, b = (double)term, s = a + b;
+  const double bb = s - a, err = (a - (s - bb)) + (b - bb); /* TwoSum: err != 0 <=> the addition rounded */
+  if (err != 0.0) x->fragInexact++;
+  *sum = s;
+  const float fl = floorf(term);
+  x->fragHi += (long long)fl;
+  x->fragLo += (long long)((term - fl) * 134217728.0f);
+}
+
 /* savePileupExpt (2168-2295) */
 static int pileupExpt(gxo_ctx* x, double* fragOut) {
   double fragLen = 0.0;
+  x->fragHi = x->fragLo = 0;
+  x->fragInexact = 0;
   for (int i = 0; i < x->chromLen; i++) {
     OChrom* c = x->chrom + i;
     if (c->skip || !c->save) continue;
@@ -476,7 +495,7 @@ static int pileupExpt(gxo_ctx* x, double* fragOut) {
       if (j == b.pos || (b.save && d[j])) { /* 2241 */
         if (b.save) {
           rlePush(&c->expt, j, val);
-          fragLen += (float)(j - start) * val; /* 2246: uint32*float in float, summed in double */
+          addTerm(x, &fragLen, (float)(j - start) * val); /* 2246: uint32*float in float, summed in double */
         } else
           rlePush(&c->expt, j, 0.0f);
         start = j;
@@ -490,7 +509,7 @@ static int pileupExpt(gxo_ctx* x, double* fragOut) {
     }
     if (b.save) { /* 2268-2273 */
       rlePush(&c->expt, j, val);
-      fragLen += (float)(j - start) * val;
+      addTerm(x, &fragLen, (float)(j - start) * val);
     } else
       rlePush(&c->expt, j, 0.0f);
     if (v + d[j] != 0) /* 2283-2289 */
@@ -1149,4 +1168,7 @@ int gxo_find_peaks_path(gxo_ctx* x, const char* outPath, const char* logPath,
 }
 
 double gxo_frag_len(const gxo_ctx* x) { return x->fragLen; }
+/* the treatment's fragLen as the exact sum of the same products, rounded once; how many of the reference's additions rounded */
+double gxo_frag_len_exact(const gxo_ctx* x) { return (double)x->fragHi + (double)x->fragLo * (1.0 / 134217728.0); }
+uint64_t gxo_frag_inexact(const gxo_ctx* x) { return x->fragInexact; }
 uint64_t gxo_skipped_overflow(const gxo_ctx* x) { return x->skippedOverflow; }

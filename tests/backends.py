@@ -168,8 +168,16 @@ class Oracle(_Backend):
                        "sample_no_control", "pvalues", "find_peaks", "get_peaks",
                        "interval_count", "get_intervals"):
                 getattr(lib, "gxo_" + fn).argtypes = None
+            lib.gxo_frag_len_exact.restype = C.c_double
+            lib.gxo_frag_len_exact.argtypes = [C.c_void_p]
+            lib.gxo_frag_inexact.restype = C.c_uint64
+            lib.gxo_frag_inexact.argtypes = [C.c_void_p]
             Oracle._lib = lib
         super().__init__(Oracle._lib, params)
+        self.exact = []  # per replicate (run_case): the treatment's fragLen as an exact sum, and how many of the reference's additions rounded
+
+    def frag_exact(self):
+        return float(self.lib.gxo_frag_len_exact(self.ctx)), int(self.lib.gxo_frag_inexact(self.ctx))
 
     @staticmethod
     def lib():
@@ -200,6 +208,18 @@ class Oracle(_Backend):
         return n.value, g.value, bp.value
 
 
+def assert_fraglen(o, k, fo, fh):
+    """fragLen of replicate k: the device adds the reference's float products (Genrich.c:2246) EXACTLY -- two int64 parts,
+    rounded once -- so it must equal the oracle's exact sum of the same products bit for bit; the reference's own double
+    accumulation may have rounded `inexact` of its additions, each by at most half a unit in the last place (never, for
+    unit weights or below 2^26: then all three are the same number)."""
+    exact, inexact = o.exact[k]
+    assert fh == exact, ("fragLen (device vs the exact sum)", fh, exact)
+    assert abs(fo - exact) <= 0.5 * (inexact + 1) * np.spacing(max(fo, exact)), ("fragLen (reference's rounding)", fo, exact, inexact)
+    if inexact == 0:
+        assert fo == fh
+
+
 def run_case(be, case, names=None):
     """Drive one backend through a whole run.  `case` = dict(lens, skip, beds, replicates=[
     dict(save, treat=events, ctrl=events|None)]).  Returns per-replicate scalars."""
@@ -209,6 +229,8 @@ def run_case(be, case, names=None):
         be.sample_begin(0, rep.get("save"))
         be.push_events(rep["treat"])
         frag, _, _ = be.sample_end()
+        if hasattr(be, "frag_exact"):
+            be.exact.append(be.frag_exact())
         if rep.get("ctrl") is not None:
             be.sample_begin(1, None)
             be.push_events(rep["ctrl"])

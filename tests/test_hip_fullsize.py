@@ -157,14 +157,12 @@ def _whole_genome_against_oracle(case, params, min_peaks):
     so = B.run_case(o, case)
     h = genrich_amd.Genrich(params)
     sh = B.run_case(h, case)
-    n_ev = sum(len(r["treat"]) + (0 if r.get("ctrl") is None else len(r["ctrl"])) for r in case["replicates"])
-    for (fo, lo, co), (fh, lh, ch) in zip(so, sh):
-        # fragLen: the reference adds one float product per interval into a double, rounding at every addition once the
-        # sum has passed 2^26 and a product has bits below 2^-26 (fractional weights only); the device's sum is exact
-        # and rounded once.  Over the <= 2 * events intervals of a sample the reference's own
-        # rounding can move its sum by half a unit in the last place per addition -- that, and no more, is allowed
-        # here; lambda, the float that everything downstream uses, must be the same bits.
-        assert fo == fh or (fo >= 2.0 ** 26 and abs(fo - fh) <= n_ev * np.spacing(fo)), ("fragLen", fo, fh)
+    for k, ((fo, lo, co), (fh, lh, ch)) in enumerate(zip(so, sh)):
+        # fragLen: the device's sum is the exact sum of the reference's float products, rounded once, and is compared bit
+        # for bit with the oracle's exact sum; the reference's own double accumulation rounds at some of its additions once
+        # the sum has passed 2^26 (fractional weights only) -- counted by the oracle, half a unit in the last place each
+        # (DESIGN.md section 2).  lambda, the float that everything downstream uses, must be the same bits.
+        B.assert_fraglen(o, k, fo, fh)
         assert np.float32(lo).tobytes() == np.float32(lh).tobytes()
         if co is not None:
             assert np.float32(co).tobytes() == np.float32(ch).tobytes()

@@ -233,8 +233,7 @@ def test_half_size_bins_and_the_128_key_level_1(monkeypatch, frac):
     monkeypatch.setenv("GX_SBSHIFT", "1")
     monkeypatch.setenv("GX_FORCE_HALF_BINS", "1")
     lens = [20_000_000, 16_000_000]
-    # (fractional weights: fragLen stays below 2^26, where the reference's own accumulation is still exact)
-    ev = synth.make_fragments(lens, 250_000 if frac else 400_000, 77, peak_every=200_000, tower_every=5_000_000)
+    ev = synth.make_fragments(lens, 400_000, 77, peak_every=200_000, tower_every=5_000_000)
     params = B.make_params(pq=0.01, min_auc=20.0)
     reps = [dict(save=None, treat=ev, ctrl=None)]
     if frac:
