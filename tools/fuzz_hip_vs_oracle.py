@@ -8,6 +8,10 @@ default: the generator of tests/test_hip_parity.py::test_random_runs_against_ora
 --x50:   the default generator (skipped chromosomes, -E regions, replicates, -p / -q, -a / -l / -g) with
          chromosomes and samples 50 times larger
 
+--paths: mid-size runs with the device paths of round 4 forced at random -- few-tile bins (GX_SBSHIFT 1..3: rounds, heavy
+         tiles, the second launch), half-size bins with the 128-key level 1, pair records off, fractional pairs off or
+         announced (gx_expect_fractional), every sample pushed in 1-5 pieces; --seconds N stops after N seconds
+
 Inputs that saturate the reference's int16 difference array are compared like any other: the oracle
 drops alignments as the reference does, and so does the library (gx_saturate.h)."""
 import os
@@ -39,9 +43,60 @@ def mid_case(seed):
     return dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=ct)]), params
 
 
+def run_paths(seed):
+    """one mid-size run with random path knobs; returns what assert_same_run needs"""
+    rng = np.random.default_rng(seed + 12345)
+    case, params = mid_case(seed)
+    if rng.random() < 0.5:  # fractional weights more often than mid_case has them
+        for rep in case["replicates"]:
+            rep["treat"] = synth.add_multimap(rep["treat"][rep["treat"]["count"] == 1], case["lens"], float(rng.choice([0.1, 0.5])), seed=seed + 5)
+    knobs = {}
+    if rng.random() < 0.6:
+        knobs["GX_SBSHIFT"] = str(int(rng.integers(1, 4)))
+    if rng.random() < 0.3:
+        knobs["GX_FORCE_HALF_BINS"] = "1"
+    if rng.random() < 0.15:
+        knobs["GX_NO_PAIRS"] = "1"
+    if rng.random() < 0.15:
+        knobs["GX_NO_FRAC_PAIRS"] = "1"
+    for k in ("GX_SBSHIFT", "GX_FORCE_HALF_BINS", "GX_NO_PAIRS", "GX_NO_FRAC_PAIRS"):
+        os.environ.pop(k, None)
+    os.environ.update(knobs)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = T.hip_backend(params)
+    if rng.random() < 0.5:
+        h.expect_fractional(True)
+    pieces = int(rng.integers(1, 6))
+    whole = h.push_events
+
+    def in_pieces(ev):
+        cuts = sorted(int(x) for x in rng.integers(0, len(ev) + 1, pieces - 1))
+        for a, b in zip([0] + cuts, cuts + [len(ev)]):
+            whole(ev[a:b])
+    h.push_events = in_pieces
+    sh = B.run_case(h, case)
+    T.assert_same_run(o, h, so, sh, case)
+    return knobs, pieces, h.path_info()
+
+
 mid = "--mid" in sys.argv
+paths = "--paths" in sys.argv
+import time  # noqa: E402
+t_end = time.time() + float(sys.argv[sys.argv.index("--seconds") + 1]) if "--seconds" in sys.argv else None
 bad = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    if t_end and time.time() > t_end:
+        print("time is up at seed", seed)
+        break
+    if paths:
+        try:
+            knobs, pieces, flags = run_paths(seed)
+            print("seed", seed, knobs, "pieces", pieces, "path flags", flags, flush=True)
+        except Exception as ex:  # noqa: BLE001
+            bad += 1
+            print("seed", seed, type(ex).__name__, str(ex)[:300], {k: os.environ.get(k) for k in ("GX_SBSHIFT", "GX_FORCE_HALF_BINS", "GX_NO_PAIRS", "GX_NO_FRAC_PAIRS")}, flush=True)
+        continue
     case, params = mid_case(seed) if mid else T._random_case(seed, 50 if "--x50" in sys.argv else 1)
     if "--extreme" in sys.argv:
         r = np.random.default_rng(seed + 77)
