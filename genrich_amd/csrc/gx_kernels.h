@@ -512,13 +512,18 @@ __device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporte
 // `written`: the lanes that wrote an interval (rank = a lane's number among them).  When they are the lanes 0 .. k-1 --
 // nearly always: a touched base whose starts and ends cancel is rare -- a lane's rank is its number and the word is
 // the ballot itself (two scalar instructions instead of two DPP scans).
+__device__ __forceinline__ void sig_flush_m(u64* __restrict__ sigMask, u32 pos, u64 sgm, u32 rank, u64 written);
 __device__ __forceinline__ void sig_flush(u64* __restrict__ sigMask, u32 pos, bool sg, u32 rank, u64 written) {
-  const u64 sgm = __ballot(sg);
+  sig_flush_m(sigMask, pos, __ballot(sg), rank, written);
+}
+// (sgm: the lanes whose interval is significant, as a mask)
+__device__ __forceinline__ void sig_flush_m(u64* __restrict__ sigMask, u32 pos, u64 sgm, u32 rank, u64 written) {
   if (!sgm) return;  // wave-uniform
   u64 m;
   if (((written + 1ull) & written) == 0ull) {  // wave-uniform
     m = sgm;
   } else {
+    const bool sg = __builtin_amdgcn_inverse_ballot_w64(sgm);
     const int lo = sg && rank < 32u ? (int)(1u << rank) : 0, hi = sg && rank >= 32u ? (int)(1u << (rank - 32u)) : 0;
     const u32 mlo = (u32)__builtin_amdgcn_readlane(dpp_scan_add(lo), 63), mhi = (u32)__builtin_amdgcn_readlane(dpp_scan_add(hi), 63);
     m = (u64)mlo | ((u64)mhi << 32);

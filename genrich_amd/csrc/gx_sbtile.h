@@ -172,6 +172,8 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   constexpr int TR_CAP = SBT_TR;  // (shadows k_tile_fast's: the rounds below are its code)
   const int lane = lane_id();
   const bool active = flags & TM_ACTIVE;
+  const u64 activeM = active ? ~0ull : 0ull;
+  const u32 negPos0 = 0u - pos0;   // (pos0 + p != 0  <=>  p != -pos0)
   const bool lastTile = (flags & TM_LAST) != 0;
   constexpr int KR = 3;  // keys per lane kept in registers (192 per tile; a tile of config 2 holds ~135)
   u32 kr[KR];
@@ -244,17 +246,24 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
       const int incS = dpp_scan_add(d120);
       const int after = runBase + incS;
       const int before = after - d120;                          // the pileup of the interval that ends here (2244)
-      const bool nz = d120 != 0 && active && (pos0 + p != 0);   // 2241: base 0 closes nothing
-      const u64 mask = __ballot(nz);
+      // nz = d120 != 0 && active && pos0 + p != 0 (2241: base 0 closes nothing), as a lane mask made of the compares'
+      // own scalar results: __ballot() of a composite condition sends it through a VGPR and back (two more VALU
+      // instructions per ballot, four ballots per step)
+      const u64 mask = activeM & __builtin_amdgcn_uicmp((u32)d120, 0u, 33 /* ne */) & __builtin_amdgcn_uicmp(p, negPos0, 33);
+      const bool nz = __builtin_amdgcn_inverse_ballot_w64(mask);
       const u32 orank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
       if (nz) {
         const u32 o = slot + outCount + orank;
         st_u32(out.to.looseEnd, o, pos0 + p);
         st_u32(out.to.looseV, o, (u32)before);
       }
-      if (vsig != 0x7FFFFFFF) sig_flush(out.to.sigMask, slot + outCount, nz && before >= vsig, orank, mask);  // wave-uniform
-      negM |= __ballot(after < 0);
-      bigM |= __ballot(after >= FRAG_FAST_MAXV);
+      if (vsig != 0x7FFFFFFF)  // wave-uniform
+        sig_flush_m(out.to.sigMask, slot + outCount, mask & __builtin_amdgcn_sicmp(before, vsig, 39 /* sge */), orank, mask);
+      // (a pileup below zero or at the table's end: one unsigned compare finds either, the rare step that has one says which)
+      if (__builtin_amdgcn_uicmp((u32)after, (u32)FRAG_FAST_MAXV, 35 /* uge */)) {  // wave-uniform
+        negM |= __ballot(after < 0);
+        bigM |= __ballot(after >= FRAG_FAST_MAXV);
+      }
       runBase += __builtin_amdgcn_readlane(incS, 63);
       if (FRAC && fragTerms && mask) {  // wave-uniform
         // the interval that ends here starts at the end before it: the lane's, the steps', or -- the tile's first
