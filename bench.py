@@ -179,8 +179,8 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device):
 
 
 KERNEL_PHASE = {  # which library phase (gx_set_phase_filter) brackets a kernel
-    "k_sort1": "sort1", "k_sort1p": "sort1", "k_sbtile": "tile", "k_tile_fast": "tile", "k_tile": "tile", "k_bucket2p": "bucket",
-    "k_pack_pval": "pval", "k_pack_pairs": "pval", "k_pack_pairs_full": "pval", "k_merge2": "merge", "k_mergeN": "fisher",
+    "k_sort1": "sort1", "k_sort1p": "sort1", "k_sort_a": "sort1", "k_sort_b": "sort1", "k_sbtile": "tile", "k_tile_fast": "tile", "k_tile": "tile", "k_bucket2p": "bucket",
+    "k_pack_pval": "pval", "k_pack_pairs": "pval", "k_pack_pairs_full": "pval", "k_merge2": "merge", "k_mergeN": "fisher", "k_mergeN_w": "fisher",
     "k_pack_ep": "fisher", "k_bh_hist": "bh", "k_qlookup": "bh", "k_peak_both": "sweep",
 }
 
@@ -515,20 +515,24 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             live_ms /= 2
         kname = dom or ("k_sbtile" if path_flags & 1 else "k_tile_fast")
         kprof = prof["kernels"].get(kname) if prof else None
-        klaunch = max(1.0, kprof.get("launches_per_step", 1.0)) if kprof else float(launches)
+        # (a sample's tile stage = k_sbtile's first launch + its second, usually idle one over the listed bins: ONE launch
+        # here, as the phase timer brackets both -- the profile counts the instances of the template apart)
+        klaunch = float(launches) if per_sample or not kprof else max(1.0, kprof.get("launches_per_step", 1.0))
         traffic = kprof["hbm_bytes_per_step"] / klaunch if kprof and kprof.get("hbm_bytes_per_step") else None
         # compulsory HBM bytes of the sparse formulation, per launch:
         #   k_sort1: 16 B per event in, 4 B per endpoint key out (two per event)
         #   tile stage: 4 B per key in (k_sbtile reads level 1's pages; k_tile_fast 2 B offsets), 8 B per interval out,
         #               56 B of descriptors / counts per tile
         ev_launch = ev_n / launches
-        if dom_phase == "sort1":
+        if not per_sample:
+            alg_k = None  # (a merge / Fisher / BH kernel: only the counter figure is quoted)
+        elif dom_phase == "sort1":
             alg_k = 16.0 * ev_launch + 8.0 * ev_launch
         else:
             # (pair mode: one 4-byte record per fragment; else two 4-byte keys (k_sbtile) or two 2-byte offsets (k_tile_fast))
             key_bytes = 4.0 if path_flags & 16 else (8.0 if path_flags & 1 else 4.0)
             alg_k = key_bytes * ev_launch + 8.0 * (iv0 if launches == 1 else 2.0 * ev_launch) + 56.0 * n_tiles
-        used = traffic if traffic else alg_k
+        used = traffic if traffic else (alg_k or 0.0)
         achieved = used / (live_ms * 1e-3) / 1e9 if live_ms > 0 else 0.0
         # whole step: events in + final interval table (end, p[, pileup]) + sweep masks out; the loose-slot sweep of a
         # single sample with -p leaves (end, V) in the tile stage's slots and makes no second table
@@ -537,9 +541,9 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
         whole_traffic = prof["whole_step"]["hbm_bytes_per_step"] if prof else None
         roof = {
             "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": live_ms / (klaunch if dom_phase not in ("sort1", "tile", "bucket") else 1.0),
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": live_ms / (1.0 if per_sample else klaunch),
             "algorithmic_bytes": alg_k,
-            "traffic_over_algorithmic": (traffic / alg_k) if traffic else None,
+            "traffic_over_algorithmic": (traffic / alg_k) if traffic and alg_k else None,
             "profile": f"profiles/r04_counters_config{config}.json" if prof else None,
             "whole_step": {
                 "ms": step_s * 1e3,
@@ -552,7 +556,8 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             "dense_model": {"bytes": 8.0 * G + 16.0 * ev_n + 52.0 * iv0,
                             "note": "SURVEY 8(d)'s dense int32-array model; the array lives in LDS here, so this is not HBM traffic"},
             "note": "kernel = the longest kernel of this build's rocprofv3 profile of this config (profiles/); achieved = the HBM bytes "
-                    "it moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of that profile; the sparse formulation's compulsory bytes when "
+                    "it moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of that profile; a sample's tile stage -- k_sbtile's first launch "
+                    "and its usually idle second one -- counts as one launch; the sparse formulation's compulsory bytes when "
                     "no profile matches this build) / its mean duration measured here (HIP events on the library's stream, inside the "
                     "timed region); frac <= 1 by construction.  `traffic` (here and in whole_step) is NOT measured in this run: it is "
                     "the PMC figure of the committed profile of this very build (source hash checked), collected by "
