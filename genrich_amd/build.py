@@ -32,11 +32,24 @@ HOST_BIN = os.path.join(HERE, "genrich-amd")
 
 def build_host(force: bool = False) -> str:
     """The command-line host program (C++, g++): SAM/BAM ingest + options over the C ABI."""
-    deps = [HOST_SRC, os.path.join(os.path.dirname(HOST_SRC), "bgzf_reader.h"), LIB]
+    hd = os.path.dirname(HOST_SRC)
+    deps = [HOST_SRC, LIB] + [os.path.join(hd, f) for f in ("bgzf_reader.h", "gx_inflate.h", "gx_crc32.h")]
     if force or not os.path.exists(HOST_BIN) or os.path.getmtime(HOST_BIN) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", HOST_SRC, "-o", HOST_BIN, "-L" + HERE,
                                "-lgenrich_amd", "-lz", "-Wl,-rpath,$ORIGIN"])
     return HOST_BIN
+
+
+INFLATE_TEST_LIB = os.path.join(HERE, "libgx_inflate_test.so")
+
+
+def build_inflate_test() -> str:
+    """gx_inflate.h / gx_crc32.h behind a C entry point each, for tests/test_inflate.py (host code only: g++)."""
+    hd = os.path.dirname(HOST_SRC)
+    srcs = [os.path.join(hd, f) for f in ("inflate_test.cpp", "gx_inflate.h", "gx_crc32.h")]
+    if not os.path.exists(INFLATE_TEST_LIB) or os.path.getmtime(INFLATE_TEST_LIB) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-fPIC", "-shared", srcs[0], "-o", INFLATE_TEST_LIB, "-lz"])
+    return INFLATE_TEST_LIB
 
 
 def build(force: bool = False) -> str:

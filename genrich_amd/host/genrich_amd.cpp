@@ -1496,6 +1496,9 @@ class DecodePipe {
 };
 
 int g_decoders = 0;  // --threads / GENRICH_THREADS (0 or 1: records are decoded on the parsing thread)
+// BAM: inflating the blocks is ~90 % of the ingest's CPU time (binary records decode in no time), so a BAM stream gets
+// its own split of the thread budget once it has been recognised (0: as for SAM)
+int g_bamInflaters = 0, g_bamDecoders = 0, g_bamState = 0;
 int g_stateWorkers = 0;  // (0: as many as decoders)
 
 // reader -> decoders -> the caller's thread, or all three in turn on the caller's thread (one decoder or none)
@@ -2467,12 +2470,21 @@ int main(int argc, char** argv) {
     // (inflate N / 4, decode N / 2, state workers N / 2: the stages' measured shares of the work)
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw && (unsigned)(3 * g_threads + 2) > hw && g_threads > 2) {
-      g_stateWorkers = std::max(1, g_threads / 2);
-      g_decoders = std::max(2, g_threads / 2);
-      g_threads = std::max(2, g_threads / 4);   // (from here on: the inflaters; two keep the BGZF reader with its block checks)
+      const int n = g_threads;
+      g_stateWorkers = std::max(1, n / 2);
+      g_decoders = std::max(2, n / 2);
+      g_threads = std::max(2, n / 4);   // (from here on: the inflaters; two keep the BGZF reader with its block checks)
+      g_bamInflaters = std::max(2, n / 2);
+      g_bamDecoders = std::max(2, n / 4);
+      g_bamState = std::max(1, n / 4);
+    } else if (hw && g_threads > 1) {
+      // cores to spare: a BAM stream gets twice the inflaters (the other pools keep up with 40 M records/s of SAM text)
+      g_bamInflaters = std::min(2 * g_threads, std::max(g_threads, (int)hw - 2 * g_threads - 2));
     }
     if (getenv("GENRICH_THREADS_REPORT"))
-      fprintf(stderr, "[threads] inflate %d, decode %d, state %d\n", g_threads, g_decoders, g_stateWorkers ? g_stateWorkers : g_decoders);
+      fprintf(stderr, "[threads] inflate %d, decode %d, state %d; BAM: inflate %d, decode %d, state %d\n", g_threads, g_decoders,
+              g_stateWorkers ? g_stateWorkers : g_decoders, g_bamInflaters ? g_bamInflaters : g_threads,
+              g_bamDecoders ? g_bamDecoders : g_decoders, g_bamState ? g_bamState : (g_stateWorkers ? g_stateWorkers : g_decoders));
   }
   if (o.pqvalue <= 0.0f || o.pqvalue > 1.0f) die("", "p-/q-value must be in (0,1]");
   const float thr = -log10f(o.pqvalue);
@@ -2576,9 +2588,15 @@ int main(int argc, char** argv) {
       if (o.verbose) fprintf(stderr, "Processing %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
       if (S.dupsVerb) fprintf(S.dups.f, "# %s file #%d: %s\n", i ? "control" : "experimental", S.sample, filename);
       Counts C;
-      if (bam)
+      if (bam) {
+        const int dec = g_decoders, st = g_stateWorkers;
+        if (g_bamInflaters) in.growWorkers(g_bamInflaters);
+        if (g_bamDecoders) g_decoders = g_bamDecoders;
+        if (g_bamState) g_stateWorkers = g_bamState;
         readBAM(S, in, C);
-      else {
+        g_decoders = dec;
+        g_stateWorkers = st;
+      } else {
         in.unread(magic, (size_t)std::max(0, got));  // the sniffed bytes are the beginning of the first line
         readSAM(S, in, C);
       }
