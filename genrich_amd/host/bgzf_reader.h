@@ -237,6 +237,9 @@ class Input {
   // keeps the inflated member that the last peek()'s pointer lies in alive for as long as the handle lives (records
   // decoded by other threads straight out of the inflated data, without a copy)
   std::shared_ptr<const void> holdCurrent() const { return cur_; }
+  // (which member that is, without the reference count's atomic: a caller that takes many records out of one member asks
+  // for the handle once per member)
+  const void* currentId() const { return cur_.get(); }
 
   // A plain mapped file whose replay buffer is exhausted: the rest of the stream as one span of memory, for readers
   // that cut it up themselves (parallel record decoding).  plainTake(n) moves the stream past n bytes of it.

@@ -1241,6 +1241,15 @@ struct Batch {
   std::vector<uint32_t> off, len;  // one entry per record
   std::vector<Decoded> rec;
   std::vector<std::pair<std::string, std::string>> fails;
+  // What the thread that cuts the stream into chunks needs to know about a record, one byte each (made by the decoder
+  // that has the records in its cache: the cutting thread reads 64 records per cache line instead of two lines per
+  // record): [2:0] the record's kind, MARK_SAME when it has the name of the group the REC record before it IN THIS
+  // BATCH belongs to (record()'s comparison with its 128-character quirk); the first REC record of a batch is compared
+  // by the cutting thread itself, with the name it carries over (lastName: this batch's contribution to that)
+  static constexpr uint8_t MARK_SAME = 0x80;
+  std::vector<uint8_t> mark;
+  uint32_t firstRec = 0xFFFFFFFFu;  // index of the batch's first REC record
+  std::string lastName;             // the name of the group the batch's last REC record belongs to, as record() keeps it
   bool decoded = false;
   // a batch of text that the READER only delimited (a span of a mapped file that ends behind a line feed): the
   // decoder that takes the batch cuts it into lines itself (cutSpan) -- the reader's part is then a memchr per batch
@@ -1267,6 +1276,9 @@ struct Batch {
     }
     used = 0;
     off.clear(); len.clear(); rec.clear(); fails.clear();
+    mark.clear();
+    firstRec = 0xFFFFFFFFu;
+    lastName.clear();
     decoded = false;
     span = nullptr;
     spanLen = 0;
@@ -1399,6 +1411,26 @@ void decodeBatch(Batch& B, F one) {
     }
   }
   t_capture = nullptr;
+  // the marks (see Batch::mark)
+  const size_t n = B.rec.size();
+  B.mark.resize(n);
+  bool have = false;
+  for (size_t i = 0; i < n; i++) {
+    const Decoded& r = B.rec[i];
+    uint8_t m = r.kind;
+    if (r.kind == Decoded::REC) {
+      const char* qname = B.at(i) + r.qname;
+      if (!have) {
+        have = true;
+        B.firstRec = (uint32_t)i;
+        B.lastName.assign(qname, strnlen(qname, MAX_ALNS));
+      } else if (B.lastName == qname)  // (std::string == const char*: the whole name, as record() compares)
+        m |= Batch::MARK_SAME;
+      else
+        B.lastName.assign(qname, strnlen(qname, MAX_ALNS));
+    }
+    B.mark[i] = m;
+  }
 }
 
 // The pipeline: a reader thread cuts the input into batches, `nDec` threads decode them, the caller's thread takes them
@@ -1711,7 +1743,7 @@ void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOf
         }
         for (uint32_t k = runStart; k < i; k++) {
           C.count++;
-          const uint8_t kind = b->rec[k].kind;
+          const uint8_t kind = b->mark[k] & 7u;
           if (kind == Decoded::UNMAPPED) C.unmapped++;
           else if (kind == Decoded::SUPP) C.supp++;
           else C.lowMapQ++;
@@ -1720,19 +1752,23 @@ void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOf
       }
       runStart = NONE;
     };
+    const uint8_t* mark = b->mark.data();
     for (uint32_t i = 0; i < n; i++) {
-      const Decoded& r = b->rec[i];
-      if (r.kind == Decoded::UNMAPPED || r.kind == Decoded::SUPP || r.kind == Decoded::LOWQ) {
+      const uint8_t kind = mark[i] & 7u;
+      if (kind == Decoded::UNMAPPED || kind == Decoded::SUPP || kind == Decoded::LOWQ) {
         if (runStart == NONE) runStart = i;
         continue;
       }
       endRun(i);
-      if (r.kind != Decoded::REC) continue;  // (a record that failed keeps its place in the chunk: it ends the run there)
-      const char* qname = b->at(i) + r.qname;
-      if (have && name == qname) continue;  // (std::string == const char*: the whole name, as record() compares)
-      // a group starts at record i
+      if (kind != Decoded::REC) continue;  // (a record that failed keeps its place in the chunk: it ends the run there)
+      if (i == b->firstRec) {
+        // (the batch's first record that reaches the state machine: against the name carried over from the batches before)
+        const char* qname = b->at(i) + b->rec[i].qname;
+        if (have && name == qname) continue;  // (std::string == const char*: the whole name, as record() compares)
+      } else if (mark[i] & Batch::MARK_SAME)
+        continue;
+      // a group starts at record i (its name, as record() keeps it, is needed again at the next batch's first record only)
       have = true;
-      name.assign(qname, strnlen(qname, MAX_ALNS));
       if (cur->nrec + (i - i0) >= CHUNK_RECS) {
         if (i > i0) cur->segs.push_back(Chunk::Seg{b, i0, i});
         cur->nrec += i - i0;
@@ -1742,6 +1778,7 @@ void runParallelState(State& S, ReadSet& rs, Counts& C, int nThreads, int qualOf
       }
     }
     endRun(n);
+    if (b->firstRec != 0xFFFFFFFFu) name = b->lastName;  // (have is set: the first REC record either continued a group or began one)
     if (n > i0) {
       cur->segs.push_back(Chunk::Seg{b, i0, n});
       cur->nrec += n - i0;
@@ -1984,10 +2021,9 @@ uint64_t readBAM(State& S, In& in, Counts& C) {
         const int32_t sz = (int32_t)(p4[0] | (p4[1] << 8) | (p4[2] << 16) | ((uint32_t)p4[3] << 24));
         if (sz >= 32) {
           if (const uint8_t* whole = g.peek(4 + (size_t)sz)) {
-            std::shared_ptr<const void> h = g.holdCurrent();
-            if (h.get() != held) {
-              held = h.get();
-              B.holds.push_back(std::move(h));
+            if (g.currentId() != held) {
+              held = g.currentId();
+              B.holds.push_back(g.holdCurrent());
             }
             B.addExt(whole + 4, (size_t)sz);
             g.advance(4 + (size_t)sz);
