@@ -240,6 +240,8 @@ class Input {
   // (which member that is, without the reference count's atomic: a caller that takes many records out of one member asks
   // for the handle once per member)
   const void* currentId() const { return cur_.get(); }
+  // bytes of the current member behind the read position (after a successful peek())
+  size_t leftInCurrent() const { return cur_ ? cur_->outLen - pos_ : 0; }
 
   // A plain mapped file whose replay buffer is exhausted: the rest of the stream as one span of memory, for readers
   // that cut it up themselves (parallel record decoding).  plainTake(n) moves the stream past n bytes of it.
