@@ -1642,7 +1642,15 @@ void mergeChunk(State& S, ReadSet& rs, Counts& C, Chunk& ch, int qualOffset) {
       fputs(w.first.c_str(), stderr);
   }
   if (S.bedOpt && !ch.sink.bed.empty()) fwrite(ch.sink.bed.data(), 1, ch.sink.bed.size(), S.bed.f);
-  for (const gx_event& e : ch.sink.ev) pushEvent(S, e);
+  // (the chunk's events in one piece: pushEvent's bookkeeping once per chunk, not per event)
+  if (!ch.sink.ev.empty()) {
+    if (!S.gx && S.hot.on) S.hot.all.insert(S.hot.all.end(), ch.sink.ev.begin(), ch.sink.ev.end());
+    S.buf.insert(S.buf.end(), ch.sink.ev.begin(), ch.sink.ev.end());
+    if (S.buf.size() >= (1u << 20)) {
+      if (S.gx && S.sampleOpen) flushEvents(S);
+      if (!S.gx || S.sampleOpen) S.buf.clear();  // --events-only keeps nothing
+    }
+  }
   addCounts(C, ch.C);
   for (double x : ch.sink.lenTerms) C.totalLen += x;
   for (auto& u : ch.unpair) rs.unpair.push_back(std::move(u));
