@@ -22,7 +22,8 @@
 //   (environment: GENRICH_HOST_PROF=1 prints the CPU time of the parsing thread after the last input; GENRICH_DUPS_HOST=1
 //   keeps -r's tables on the host; GENRICH_NO_INT16=1 leaves saveInterval's int16 checks to the library -- the pileup is the
 //   reference's either way, the -v warnings / -b lines / -x average of dropped reads only with the checks on; GENRICH_NO_MMAP=1
-//   reads plain files through read() instead of mapping them)
+//   reads plain files through read() instead of mapping them; GENRICH_ZLIB_INFLATE=1 inflates BGZF blocks with zlib instead of
+//   gx_inflate.h; GENRICH_THREADS_REPORT=1 prints how the thread budget was split)
 //   --events-only   parse and write the -b file without touching a GPU (diagnostics)
 //   --device N      HIP device ordinal (default 0)
 //   --devices LIST  several GPUs of one node, e.g. 0-7 or 0,2,5: chromosomes are sharded over them by length, one
