@@ -84,6 +84,61 @@ def int16_towers(lens, n_start, n_end, seed):
     return ev[rng.permutation(len(ev))]
 
 
+def int16_towers_frac(lens, n_start, n_end, seed):
+    """As int16_towers, with a third of the tower reads multimapped (k = 2 .. 10 equally scored alignments, weight 1 / k):
+    one alignment on the tower, the others elsewhere -- the int16 part of the reference's (cov, eighths, sixths, tenths)
+    counters reaches its limits in between whole numbers.  Consecutive events with count = k are one read (write_sam)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    reads = [[(0, int(s), int(e), 1)] for _, s, e, _ in mf(lens, 1500, seed + 1000)]
+    L = lens[0]
+
+    def multi(first, k):
+        out = [first + (k,)]
+        for _ in range(k - 1):
+            s = 10_000 + 1_000 * int(rng.integers(0, 40))
+            out.append((0, s, s + 150 + 10 * int(rng.integers(0, 8)), k))
+        perm = rng.permutation(k)
+        return [out[j] for j in perm]
+
+    for _ in range(n_start):
+        k = int(rng.choice([1, 1, 1, 1, 2, 3, 4, 5, 6, 8, 10]))
+        reads.append(multi((0, 1000, 1200), k) if k > 1 else [(0, 1000, 1200, 1)])
+    for _ in range(n_end):
+        k = int(rng.choice([1, 1, 1, 1, 2, 3, 4, 5, 6, 8, 10]))
+        st = 5000 + 2 * int(rng.integers(0, 50))
+        reads.append(multi((0, st, 5400), k) if k > 1 else [(0, st, 5400, 1)])
+    order = rng.permutation(len(reads))
+    rows = [a for i in order for a in reads[i]]
+    return np.array(rows, dtype=synth.EVENT_DTYPE)
+
+
+def make_int16_frac():
+    """The CPU-only fixture of tests/test_host_cli.py::test_cli_int16_decisions_with_fractional_weights: the reference's
+    -b list and its read-by-read warnings on int16_towers_frac (not a `case`: no case.json, so the suites that walk every
+    case leave it alone)."""
+    L1 = [60_000]
+    out_dir = os.path.join(HERE, "saturate16_frac")
+    os.makedirs(out_dir, exist_ok=True)
+    tmp = "/tmp/genrich_golden/saturate16_frac"
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp)
+    sam = os.path.join(tmp, "t0.sam")
+    synth.write_sam(sam, ["chrA"], L1, int16_towers_frac(L1, 100_000, 100_000, 71), name_prefix="t0_")
+    res = subprocess.run([REF, "-t", sam, "-v", "-b", os.path.join(tmp, "events.bed"), "-o", os.path.join(tmp, "o.np"), "-a", "20"],
+                         capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.exit("saturate16_frac: reference failed:\n" + res.stderr)
+    import hashlib
+    bed = open(os.path.join(tmp, "events.bed"), "rb").read()
+    with open(os.path.join(out_dir, "events.bed.sha256"), "w") as f:  # (12 MB of lines: their hash and count are kept)
+        f.write(f"{hashlib.sha256(bed).hexdigest()} {bed.count(10)}\n")
+    with gzip.GzipFile(os.path.join(out_dir, "out.int16.gz"), "wb", mtime=0) as g:
+        g.write("".join(l + "\n" for l in res.stderr.splitlines() if "skipped due to" in l).encode())
+    n = sum(1 for l in res.stderr.splitlines() if "skipped due to" in l)
+    print(f"saturate16_frac    {n} alignments skipped by the reference")
+    shutil.rmtree(tmp)
+
+
 def cases():
     L1 = [60_000]
     yield dict(
@@ -220,6 +275,8 @@ def gz_copy(src, dst):
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/Genrich missing: run `make -C oracle` in the build container")
+    if not sys.argv[1:] or "saturate16_frac" in sys.argv[1:]:
+        make_int16_frac()
     for case in cases():
         if sys.argv[1:] and case["name"] not in sys.argv[1:]:
             continue  # (python make_golden.py <case> ...: only those)
