@@ -112,30 +112,42 @@ def int16_towers_frac(lens, n_start, n_end, seed):
     return np.array(rows, dtype=synth.EVENT_DTYPE)
 
 
-def make_int16_frac():
-    """The CPU-only fixture of tests/test_host_cli.py::test_cli_int16_decisions_with_fractional_weights: the reference's
-    -b list and its read-by-read warnings on int16_towers_frac (not a `case`: no case.json, so the suites that walk every
-    case leave it alone)."""
+# CPU-only fixtures of tests/test_host_cli.py::test_cli_int16_decisions_more: the reference's -b list (hash + line count) and
+# its read-by-read warnings.  Not `cases` (no case.json): the suites that walk every case leave them alone.
+def int16_extra():
     L1 = [60_000]
-    out_dir = os.path.join(HERE, "saturate16_frac")
+    return {
+        # a third of the piled-up reads multimapped
+        "saturate16_frac": dict(ev=lambda: int16_towers_frac(L1, 100_000, 100_000, 71), mixed=None, args=["-a", "20"]),
+        # ATAC cut sites (-j -d 40): two intervals per fragment, either of which can be the one that is dropped -- the
+        # fragment's length towards the -x average is then the other one's; unpaired reads kept (-y)
+        "saturate16_atac": dict(ev=lambda: int16_towers(L1, 47_600, 47_400, 81), mixed=dict(seed=6, bam=False),
+                                args=["-j", "-d", "40", "-y", "-a", "20"]),
+    }
+
+
+def make_int16_extra(name):
+    import hashlib
+    spec = int16_extra()[name]
+    L1 = [60_000]
+    out_dir = os.path.join(HERE, name)
     os.makedirs(out_dir, exist_ok=True)
-    tmp = "/tmp/genrich_golden/saturate16_frac"
+    tmp = os.path.join("/tmp/genrich_golden", name)
     shutil.rmtree(tmp, ignore_errors=True)
     os.makedirs(tmp)
     sam = os.path.join(tmp, "t0.sam")
-    synth.write_sam(sam, ["chrA"], L1, int16_towers_frac(L1, 100_000, 100_000, 71), name_prefix="t0_")
-    res = subprocess.run([REF, "-t", sam, "-v", "-b", os.path.join(tmp, "events.bed"), "-o", os.path.join(tmp, "o.np"), "-a", "20"],
+    write_input(sam, ["chrA"], L1, spec["ev"](), spec["mixed"], 0, "t0_")
+    res = subprocess.run([REF, "-t", sam, "-v", "-b", os.path.join(tmp, "events.bed"), "-o", os.path.join(tmp, "o.np")] + spec["args"],
                          capture_output=True, text=True)
     if res.returncode != 0:
-        sys.exit("saturate16_frac: reference failed:\n" + res.stderr)
-    import hashlib
+        sys.exit(name + ": reference failed:\n" + res.stderr)
     bed = open(os.path.join(tmp, "events.bed"), "rb").read()
-    with open(os.path.join(out_dir, "events.bed.sha256"), "w") as f:  # (12 MB of lines: their hash and count are kept)
+    with open(os.path.join(out_dir, "events.bed.sha256"), "w") as f:  # (megabytes of lines: their hash and count are kept)
         f.write(f"{hashlib.sha256(bed).hexdigest()} {bed.count(10)}\n")
     with gzip.GzipFile(os.path.join(out_dir, "out.int16.gz"), "wb", mtime=0) as g:
         g.write("".join(l + "\n" for l in res.stderr.splitlines() if "skipped due to" in l).encode())
     n = sum(1 for l in res.stderr.splitlines() if "skipped due to" in l)
-    print(f"saturate16_frac    {n} alignments skipped by the reference")
+    print(f"{name:18s} {n} alignments skipped by the reference")
     shutil.rmtree(tmp)
 
 
@@ -275,8 +287,9 @@ def gz_copy(src, dst):
 def main():
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/Genrich missing: run `make -C oracle` in the build container")
-    if not sys.argv[1:] or "saturate16_frac" in sys.argv[1:]:
-        make_int16_frac()
+    for extra in int16_extra():
+        if not sys.argv[1:] or extra in sys.argv[1:]:
+            make_int16_extra(extra)
     for case in cases():
         if sys.argv[1:] and case["name"] not in sys.argv[1:]:
             continue  # (python make_golden.py <case> ...: only those)

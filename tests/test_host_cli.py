@@ -425,26 +425,30 @@ def test_cli_parallel_decoding_is_the_sequential_stream(name, threads, batch, ch
 
 
 @pytest.mark.parametrize("threads", ["1", "4"])
-def test_cli_int16_decisions_with_fractional_weights(threads, tmp_path):
-    """saveInterval's int16 checks (Genrich.c:2558-2573) where a third of the piled-up reads are multimapped: the int16 part
-    of the reference's (cov, eighths, sixths, tenths) counters reaches 32,767 / -32,768 in between whole numbers, and which
-    alignments are dropped depends on the exact fractional state when each one arrives.  The reference's -b list (its hash)
-    and its 73,054 warnings, in order (tests/golden/saturate16_frac/, made by make_golden.py's make_int16_frac)."""
+@pytest.mark.parametrize("name", ["saturate16_frac", "saturate16_atac"])
+def test_cli_int16_decisions_more(name, threads, tmp_path):
+    """saveInterval's int16 checks (Genrich.c:2558-2573), read by read, beyond the `saturate16` case:
+    saturate16_frac -- a third of the piled-up reads multimapped: the int16 part of the reference's (cov, eighths, sixths,
+    tenths) counters reaches 32,767 / -32,768 in between whole numbers, and which alignments are dropped depends on the
+    exact fractional state when each one arrives (73,054 are);
+    saturate16_atac -- ATAC cut sites (-j -d 40 -y): two intervals per fragment, of which one may be dropped alone.
+    The reference's -b list (hash and line count) and its warnings, in order (tests/golden/<name>/, made by
+    make_golden.py's make_int16_extra)."""
     import hashlib
     _, mg = _cases()
-    import synth
-    L1 = [60_000]
+    spec = mg.int16_extra()[name]
     sam = str(tmp_path / "t0.sam")
-    synth.write_sam(sam, ["chrA"], L1, mg.int16_towers_frac(L1, 100_000, 100_000, 71), name_prefix="t0_")
+    mg.write_input(sam, ["chrA"], [60_000], spec["ev"](), spec["mixed"], 0, "t0_")
     bed = str(tmp_path / "events.bed")
-    res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-v", "-b", bed, "-t", sam, "-a", "20"],
+    res = subprocess.run([_binary(), "--events-only", "--threads", threads, "-v", "-b", bed, "-t", sam] + spec["args"],
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
-    want_hash, want_lines = open(os.path.join(G.GOLDEN, "saturate16_frac", "events.bed.sha256")).read().split()
+    want_hash, want_lines = open(os.path.join(G.GOLDEN, name, "events.bed.sha256")).read().split()
     got = open(bed, "rb").read()
     assert got.count(b"\n") == int(want_lines)
     assert hashlib.sha256(got).hexdigest() == want_hash
-    want = gzip.open(os.path.join(G.GOLDEN, "saturate16_frac", "out.int16.gz"), "rt").read().splitlines()
+    want = gzip.open(os.path.join(G.GOLDEN, name, "out.int16.gz"), "rt").read().splitlines()
+    assert len(want) > 1000
     assert [l for l in res.stderr.splitlines() if "skipped due to" in l] == want
 
 
