@@ -70,6 +70,13 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def decode_path(flags):
+    """gx_path_info's bits by name (include/genrich_amd.h GX_PATH_*): which device path a context took."""
+    return {"fused_sort_tile_kernel": bool(flags & 1), "pair_records": bool(flags & 16), "fractional_pair_records": bool(flags & 128),
+            "sweep_on_loose_slots": bool(flags & 2), "fell_back_to_general_chain": bool(flags & 4), "page_tables_grew": bool(flags & 8),
+            "dense_bh_allreduce": bool(flags & 32), "range_bh_exchange": bool(flags & 64)}
+
+
 def build_workload(cfg, frags, lens):
     """[(treatment events, control events or None)] per replicate, SURVEY.md 8(d)."""
     reps = []
@@ -117,9 +124,11 @@ def run_backend(be, lens, reps, peaks_to=None):
     return time.perf_counter() - t0
 
 
-def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device):
+def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device, timed_path=None):
     """The oracle (CPU restatement, one core) and the HIP path on the same events: narrowPeak text diff,
-    max |dp| / |dq| over all intervals, and the oracle's rate as the CPU baseline."""
+    max |dp| / |dq| over all intervals, and the oracle's rate as the CPU baseline.  The gate's context is given what the
+    timed context was given (the -s hint of a multimapped workload), its device path is reported next to the timed one,
+    and the gate fails when the two differ: what is compared with the oracle is the path that was timed."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import backends as B
 
@@ -133,7 +142,10 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device):
     dt = run_backend(o, sub_lens, sub, peaks_to=(po, names))
     par.device = device
     h = Genrich(par)
+    if cfg["multimap"]:
+        h.expect_fractional(True)   # (what genrich-amd -s tells the library, and what the timed context was told)
     run_backend(h, sub_lens, sub)
+    gate_flags = h.path_info()
     h.write_narrowpeak(names, ph)
     want, got = open(po, "rb").read(), open(ph, "rb").read()
     os.remove(po)
@@ -167,9 +179,15 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device):
             nbits += int((co[k].view(np.uint32) != ch[k].view(np.uint32)).sum())
     bases = float(sum(sub_lens)) * len(sub)
     n_ev = int(sum(len(t) + (0 if c is None else len(c)) for t, c in sub))
+    gate_path = decode_path(gate_flags)
+    # (the BH exchanges and "the page tables grew" belong to N ranks / to a pile-up, not to the choice of kernels)
+    same = timed_path is None or all(gate_path[k] == timed_path[k] for k in
+                                     ("fused_sort_tile_kernel", "pair_records", "fractional_pair_records", "sweep_on_loose_slots",
+                                      "fell_back_to_general_chain"))
     gate = dict(narrowpeak_diff=ndiff, peaks_oracle=int(o.n_peaks), peaks_hip=int(h.n_peaks), interval_ends_equal=ends_equal,
                 intervals_compared=n_iv, max_abs_dp=dp, max_abs_dq=dq if qval else None, pq_values_differing_in_bits=nbits,
-                passed=bool(ndiff == 0 and ends_equal and dp <= 1e-5 and dq <= 1e-5))
+                device_path=gate_path, same_path_as_timed=bool(same),
+                passed=bool(ndiff == 0 and ends_equal and dp <= 1e-5 and dq <= 1e-5 and same))
     what = "the whole workload" if n_chrom == len(lens) else f"hg38 chr1-chr{n_chrom} of the workload"
     cpu = dict(value=bases / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
                sample=f"{what} ({sum(sub_lens)/1e6:.0f} Mbp x {len(sub)} replicate(s), {n_ev} events), events in memory -> "
@@ -188,13 +206,36 @@ KERNEL_PHASE = {  # which library phase (gx_set_phase_filter) brackets a kernel
 def load_profile(config, frags, world, plain):
     """The rocprofv3 counters of THIS build for this config (tools/profile_round.sh + tools/make_counters_json.py):
     accepted only when the hash of the kernel sources matches and the workload is the profiled one."""
-    ppath = os.path.join(ROOT, "profiles", f"r04_counters_config{config}.json")
-    if not os.path.exists(ppath):
+    if world != 1 or frags != 50_000_000 or not plain:
         return None
-    prof = json.load(open(ppath))
-    if prof.get("source_hash") != source_hash() or world != 1 or frags != 50_000_000 or not plain:
-        return None
-    return prof
+    import glob
+    for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_counters_config{config}.json")), reverse=True):
+        prof = json.load(open(ppath))
+        if prof.get("source_hash") == source_hash():
+            prof["_path"] = os.path.relpath(ppath, ROOT)
+            return prof
+    return None
+
+
+def issue_roof(prof, kname, launches_per_step, launch_ms):
+    """The second bound of a kernel that is not waiting for HBM: instruction issue.  A wavefront's VALU instruction
+    occupies its SIMD for 4 cycles (64 lanes on 16), so the kernel cannot finish before
+        VALU wave-instructions x 4 / (256 CUs x 4 SIMDs x 2.4 GHz)
+    -- instruction counts from the SQ counters of this build's rocprofv3 profile (per launch), the duration measured
+    live; valu_frac = that floor / the measured duration.  SALU instructions issue from the same wavefronts' streams
+    (one instruction per wavefront and cycle) and are listed beside it."""
+    if not prof or not prof.get("issue") or prof["issue"].get("kernel") != kname or launch_ms <= 0:
+        return prof.get("issue") if prof else None
+    out = dict(prof["issue"])
+    raw = out.get("raw", {})
+    valu = raw.get("SQ_INSTS_VALU", 0.0) / max(1.0, launches_per_step)
+    salu = raw.get("SQ_INSTS_SALU", 0.0) / max(1.0, launches_per_step)
+    n_simd, clock = 256 * 4, 2.4e9
+    floor_ms = valu * 4.0 / (n_simd * clock) * 1e3
+    out.update({"bound": "valu-issue", "valu_wave_insts_per_launch": valu, "salu_wave_insts_per_launch": salu,
+                "salu_per_valu": (salu / valu) if valu else None, "simds": n_simd, "clock_ghz": clock / 1e9,
+                "valu_floor_ms": floor_ms, "launch_ms": launch_ms, "valu_frac": floor_ms / launch_ms})
+    return out
 
 
 def cpu_info():
@@ -255,6 +296,69 @@ def reference_e2e(lens, reps, max_frags=1_500_000):
             "gbases_per_s": sum(slens) / dt / 1e9,
             "sample": f"oracle/_ref/Genrich -t (SAM text, {nrec} records = {len(tv)} fragments of the workload on chr19-chr22, "
                       f"{sum(slens)/1e6:.0f} Mbp) -> narrowPeak, one thread, {dt:.1f} s"}
+
+
+def e2e_cli(lens, frags, n_frags=10_000_000):
+    """North_star's drop-in surface at size: SAM text of the headline stream's first `n_frags` fragments (2 x n_frags
+    records, the whole hg38 table) -> narrowPeak through `genrich-amd` (this repo's host program: threaded ingest ->
+    events -> the device path -> text), wall clock with process start and HIP initialisation; the REFERENCE binary
+    (oracle/_ref/Genrich, one thread) on the very same file beside it, and whether the two narrowPeak files are the
+    same bytes.  Outside the timed region of `value`."""
+    import shutil
+    import subprocess
+    hb = os.path.join(ROOT, "genrich_amd", "genrich-amd")
+    tool = os.path.join(ROOT, "tools", "events_to_sam")
+    ref = os.path.join(ROOT, "oracle", "_ref", "Genrich")
+    if not os.path.exists(tool) and os.path.exists(tool + ".c"):
+        subprocess.call(["gcc", "-O2", "-o", tool, tool + ".c"])
+    if not (os.path.exists(hb) and os.path.exists(tool)):
+        return {"error": "genrich-amd / tools/events_to_sam not built"}
+    td = tempfile.mkdtemp()
+    try:
+        if shutil.disk_usage(td).free < 4 << 30:
+            return {"error": "less than 4 GB free for the SAM text"}
+        ev = synth.make_fragments(lens, frags, seed=1)[:n_frags]
+        evp, chp, sam = os.path.join(td, "ev.bin"), os.path.join(td, "chroms.txt"), os.path.join(td, "t.sam")
+        ev.tofile(evp)
+        open(chp, "w").write("".join(f"{n} {l}\n" for n, l in zip(synth.HG38_NAMES, lens)))
+        subprocess.check_call([tool, evp, chp, sam])
+        os.remove(evp)
+        nrec, nbytes = 2 * len(ev), os.path.getsize(sam)
+        ncpu = os.cpu_count() or 1
+        out = {"sam_records": nrec, "sam_bytes": nbytes, "host_cores": ncpu,
+               "sample": f"SAM text, {nrec} records = the first {len(ev)} fragments of the headline stream on all 25 hg38 contigs, "
+                         "-p 0.01 defaults -> narrowPeak"}
+        runs = []
+        oh = os.path.join(td, "h.narrowPeak")
+        for _ in range(2):   # (the first run also pages the file and the HIP runtime in)
+            t0 = time.perf_counter()
+            rc = subprocess.call([hb, "-t", sam, "-o", oh], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            runs.append(time.perf_counter() - t0)
+            if rc != 0:
+                return dict(out, error=f"genrich-amd exited with {rc}")
+        dt = min(runs)
+        out["genrich_amd"] = {"seconds": dt, "seconds_first_run": runs[0], "records_per_s": nrec / dt, "gbases_per_s": sum(lens) / dt / 1e9,
+                              "threads": "default (min(16, cores) per pool: inflate / decode / state)",
+                              "what": "process start + HIP initialisation + threaded SAM ingest + the device path + narrowPeak text"}
+        if os.path.exists(ref):
+            orf = os.path.join(td, "r.narrowPeak")
+            t0 = time.perf_counter()
+            try:
+                rc = subprocess.call([ref, "-t", sam, "-o", orf], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            except subprocess.TimeoutExpired:
+                rc = -1
+            rdt = time.perf_counter() - t0
+            if rc == 0:
+                same = open(orf, "rb").read() == open(oh, "rb").read()
+                out["reference"] = {"seconds": rdt, "records_per_s": nrec / rdt, "gbases_per_s": sum(lens) / rdt / 1e9, "threads": 1,
+                                    "kind": "reference", "what": "oracle/_ref/Genrich -t on the same file"}
+                out["narrowpeak_identical_to_reference"] = bool(same)
+                out["speedup_vs_reference"] = rdt / dt
+            else:
+                out["reference"] = {"error": f"exit {rc} after {rdt:.0f} s"}
+        return out
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def main():
@@ -322,18 +426,28 @@ def main():
     if rank == 0 and world == 1 and args.config == 2 and plain and not args.no_cpu and not args.no_others:
         # BASELINE.json's other GPU configs in the same line (the driver runs bench.py once, with defaults)
         others = {}
-        for c in (3, 4, 5):
+        # "2q": the headline workload with -q 0.05 -- north_star's "p + q scan" of one 50 M-fragment sample
+        cfg2q = dict(CONFIGS[2], qval=True, gate_chroms=8, name="configs[1] with -q 0.05",
+                     desc=CONFIGS[2]["desc"].replace("-p 0.01", "-q 0.05"))
+        for c, ccfg, cplain in (("2q", cfg2q, False), (3, dict(CONFIGS[3]), True), (4, dict(CONFIGS[4]), True), (5, dict(CONFIGS[5]), True)):
             try:
-                r = bench_one(c, dict(CONFIGS[c]), args, env, steps=5, warmup=3, plain=True, want_e2e=False, want_cpu=True,
+                r = bench_one(2 if c == "2q" else c, ccfg, args, env, steps=5, warmup=3, plain=cplain, want_e2e=False, want_cpu=True,
                               headline=False)
                 others[str(c)] = {k: r[k] for k in ("ms_per_step", "value", "unit", "steps", "gate", "phases_ms") if k in r}
                 others[str(c)]["workload"] = r["config"]["workload"]
+                others[str(c)]["device_path"] = r["config"]["device_path"]
+                others[str(c)]["tables_written_in_step"] = r["config"]["tables_written_in_step"]
                 others[str(c)]["whole_step"] = r["roofline"]["whole_step"]
                 others[str(c)]["dominant"] = {k: r["roofline"].get(k) for k in ("kernel", "frac", "achieved", "launch_ms", "traffic")}
                 others[str(c)]["cpu_baseline"] = r.get("cpu_baseline")
             except Exception as e:  # noqa: BLE001  (the headline must still be printed)
                 others[str(c)] = {"error": repr(e)}
         out["other_configs"] = others
+    if rank == 0 and world == 1 and args.config == 2 and plain and not args.no_cpu and not args.no_e2e:
+        try:
+            out["e2e_cli"] = e2e_cli(synth.HG38_LENS, args.frags)
+        except Exception as e:  # noqa: BLE001
+            out["e2e_cli"] = {"error": repr(e)}
     if rank == 0:
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
@@ -367,6 +481,8 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     # By default the whole interval table (end, treatment pileup, p) is materialised, as the reference holds it.
     # --lean drops the pileup floats, which only the -f / -k emitters read: reported as such in `config`.
     gx.set_keep_pileups(not args.lean)
+    if cfg["multimap"]:
+        gx.expect_fractional(True)   # (genrich-amd -s does: pair records with a weight class from the first sample on)
     coll_kind = "none"
     force_rccl = world == 1 and os.environ.get("GX_BENCH_FORCE_RCCL") == "1"   # exercise the RCCL path with one rank
     if force_rccl:
@@ -454,14 +570,14 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
         collect(phase_acc)
     barrier()
     dt = time.perf_counter() - t0
-    path_flags = gx.path_info()
+    path_flags = gx.path_info()   # (after the timed steps: which path THEY took, and whether they wrote pileup floats)
     # The same step with the tight interval table MATERIALISED (GX_NO_LOOSE: lambda only after the tile stage, then
     # k_pack_pval writes (end, p) and the sweep's masks, as every run with -q / a control / a further replicate / -f / -k
     # does): what the default step of a single -p sample leaves out because the sweep reads (end, V) where the tile
     # stage put them.  Only for the headline, one rank.
     mat_ms = None
     if headline and world == 1 and not cfg["qval"] and not cfg["control"] and cfg["reps"] == 1 and not args.no_materialised:
-        os.environ["GX_NO_LOOSE"] = "1"
+        gx.set_knob("GX_NO_LOOSE", 1)
         try:
             for _ in range(2):
                 step()
@@ -473,7 +589,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             mat_ms = (time.perf_counter() - t1) / steps * 1e3
             mat_flags = gx.path_info()
         finally:
-            del os.environ["GX_NO_LOOSE"]
+            gx.set_knob("GX_NO_LOOSE", 0)
         step()
     gx.set_phase_timing(2)
     all_phases = {}
@@ -544,7 +660,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": live_ms / (1.0 if per_sample else klaunch),
             "algorithmic_bytes": alg_k,
             "traffic_over_algorithmic": (traffic / alg_k) if traffic and alg_k else None,
-            "profile": f"profiles/r04_counters_config{config}.json" if prof else None,
+            "profile": prof["_path"] if prof else None,
             "whole_step": {
                 "ms": step_s * 1e3,
                 "algorithmic_bytes": alg_step,
@@ -552,7 +668,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                 "frac_of_peak": ((whole_traffic if whole_traffic else alg_step) / step_s / 1e9) / HBM_PEAK_GBS,
                 "traffic_over_algorithmic": (whole_traffic / alg_step) if whole_traffic else None,
             },
-            "issue": prof.get("issue") if prof else None,
+            "issue": issue_roof(prof, kname, launches if per_sample else klaunch, live_ms / (1.0 if per_sample else klaunch)),
             "dense_model": {"bytes": 8.0 * G + 16.0 * ev_n + 52.0 * iv0,
                             "note": "SURVEY 8(d)'s dense int32-array model; the array lives in LDS here, so this is not HBM traffic"},
             "note": "kernel = the longest kernel of this build's rocprofv3 profile of this config (profiles/); achieved = the HBM bytes "
@@ -584,8 +700,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                                + ("" if backend == "nccl" or world == 1 else f" ({backend} validation mode, {ndev} GPU(s))"),
                 "collectives": coll_kind,
                 "rccl_nranks": rccl_nranks,
-                "device_path": {"fused_sort_tile_kernel": bool(path_flags & 1), "pair_records": bool(path_flags & 16), "sweep_on_loose_slots": loose,
-                                "fell_back_to_general_chain": bool(path_flags & 4)},
+                "device_path": decode_path(path_flags),
                 "peaks": n_peaks,
                 "intervals": int(iv0),
                 "events_per_step": int(ev_n),
@@ -593,7 +708,9 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                 "tables_written_in_step": {
                     "tight_interval_table_end_p": not loose,
                     "p_values_per_interval": not loose,
-                    "pileup_floats": False,   # made on request only (gx_get_intervals / -f / -k: ensure_piles)
+                    # (gx_path_info bit 8: k_piles_from_loose ran in a timed step; they are made on request only -- gx_get_intervals,
+                    # -f / -k -- and a replicate keeps its exact pileups for that; with a control k_pack_pairs writes them)
+                    "pileup_floats": bool(path_flags & 256) or (bool(cfg["control"]) and not args.lean),
                     "note": ("single -p sample: the sweep walks the tile stage's (end, V) slots, p comes from the table p(V); "
                              "the tight table is made when somebody asks (gx_get_intervals) -- see `materialised`") if loose else
                             "the tight (end, p[, q]) table of the final p-array",
@@ -662,7 +779,8 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     if rank == 0 and want_cpu:
         if world == 1:
             k = args.cpu_chroms or cfg["gate_chroms"]
-            gate, cpu = gate_and_cpu_baseline(cfg, lens, reps_all, min(k, len(lens)), cfg["qval"], local_dev)
+            gate, cpu = gate_and_cpu_baseline(cfg, lens, reps_all, min(k, len(lens)), cfg["qval"], local_dev,
+                                              timed_path=out["config"]["device_path"])
         else:
             # N ranks: the ranks' peak lists, merged in chromosome order, against the oracle's list for the whole workload
             gate, cpu = gate_merged_peaks(cfg, lens, reps_all, gathered, cfg["qval"])

@@ -122,6 +122,10 @@ struct PArray {  // p-value intervals of one replicate (or the Fisher combinatio
   DevBuf chromLooseOff;       // [nChrom + 1] first loose slot of each chromosome
   size_t looseStride = 0;     // words between the sig / brk masks in swMask
   bool pilesPending = false;  // no control: the pileup floats are wanted but not made yet (ensure_piles)
+  // ... and what they will be made from once the context has built another sample into its loose slots: this replicate's
+  // exact pileups and tile descriptors, taken out of the context (no copy; the context takes other buffers: pooled)
+  DevBuf keptV, keptMeta;
+  bool keptLoose = false;
   bool hasPiles = false;  // expt/ctrl filled (single-replicate logging)
   bool pilesDropped = false;  // ... deliberately not (gx_set_keep_pileups(0))
   float ctrlConst = 0.0f; // control value when ctrl is not materialised (no -E, no control file)
@@ -134,10 +138,59 @@ struct Phase {
   hipEvent_t a, b;
 };
 
+// Test and measurement switches.  They are read from the environment ONCE, when the context is made (gx_create), or
+// set on a live context by gx_set_knob; nothing in a build or a sweep calls getenv.  Every one of them is exercised
+// by tests/ (a forced path must give the oracle's bits like the default one) or by tools/.
+struct Knobs {
+  int debug = 0;          // GX_DEBUG: synchronise after every launch and say which kernel it was
+  int debugRetry = 0;     // GX_DEBUG_RETRY: say why a sample was built again
+  int noSpin = 0;         // GX_NO_SPIN: block in the runtime instead of polling for the mail
+  int forceRec64 = 0;     // GX_FORCE_REC64: 8-byte records although the genome fits 4-byte keys (only > 4.29 Gbp takes them naturally)
+  int forceSlowFrag = 0;  // GX_FORCE_SLOWFRAG: the general fragLen path
+  int noFused = 0;        // GX_NO_FUSED: the general chain instead of k_sbtile
+  int noLoose = 0;        // GX_NO_LOOSE: lambda after the tile stage, tight table, the sweep on it
+  int noPairs = 0;        // GX_NO_PAIRS: k_sort1's start / end keys for k_sbtile
+  int noFracPairs = 0;    // GX_NO_FRAC_PAIRS: fractional weights take the general chain
+  int forceHalfBins = 0;  // GX_FORCE_HALF_BINS: the 128-key level 1 on a small input
+  int noHalfBins = 0;     // GX_NO_HALF_BINS
+  int noEarlyColl = 0;    // GX_NO_EARLY_COLL: no all-reduce of the closed form of fragLen ahead of the tile stage
+  int noDenseBh = 0;      // GX_NO_DENSE_BH: the range-partitioned exchange also without a control
+  int qtMulti = 0;        // GX_QT_MULTI: the chunked BH table kernels for a small table
+  int forceColl = 0;      // GX_FORCE_COLL: run the collectives with a single rank too
+  int sbShift = -1;       // GX_SBSHIFT: tiles per super-bucket (log2)
+  long long runCapMin = 0;  // GX_RUN_CAP_MIN: the sweep's first guess of the run count (a tiny one forces the second pass)
+  int bhCapLog = 0;       // GX_BH_CAPLOG: log2 of the BH table's first size
+  int ptJmax = 0;         // GX_PT_JMAX: pages per level-1 list at first
+  int fault = 0;          // GX_FAULT: fault injection for the tests of the device-side invariants.  1: the weight of the ends at
+                          // chromosome 0's length is damaged behind level 1 of the sort (as if an end record had been lost)
+};
+struct KnobDef { const char* name; int Knobs::*i; long long Knobs::*ll; };
+const KnobDef KNOBS[] = {
+    {"GX_DEBUG", &Knobs::debug, nullptr}, {"GX_DEBUG_RETRY", &Knobs::debugRetry, nullptr}, {"GX_NO_SPIN", &Knobs::noSpin, nullptr},
+    {"GX_FORCE_REC64", &Knobs::forceRec64, nullptr}, {"GX_FORCE_SLOWFRAG", &Knobs::forceSlowFrag, nullptr},
+    {"GX_NO_FUSED", &Knobs::noFused, nullptr}, {"GX_NO_LOOSE", &Knobs::noLoose, nullptr}, {"GX_NO_PAIRS", &Knobs::noPairs, nullptr},
+    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
+    {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
+    {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
+    {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
+    {"GX_PT_JMAX", &Knobs::ptJmax, nullptr}, {"GX_FAULT", &Knobs::fault, nullptr},
+};
+// a switch that is merely present counts as 1 (GX_NO_LOOSE= is "on", as it was with getenv() != nullptr)
+bool set_knob(Knobs& k, const char* name, const char* value) {
+  for (const KnobDef& d : KNOBS)
+    if (!strcmp(d.name, name)) {
+      const long long v = value && *value ? atoll(value) : 1;
+      if (d.i) k.*(d.i) = (int)v; else k.*(d.ll) = v;
+      return true;
+    }
+  return false;
+}
+
 }  // namespace
 
 struct gx_ctx {
   gx_params par{};
+  Knobs knob;
   int device = 0;
   hipStream_t stream = nullptr;
   bool keepPiles = true;        // materialise the pileup floats of the p-value intervals
@@ -188,9 +241,9 @@ struct gx_ctx {
   bool earlyColl = false;       // this build: the ranks exchange the closed form of fragLen ahead of the tile stage
   bool earlyOwed = false;       // ... and this rank has not taken part in that all-reduce yet (poison_allreduce)
   bool earlyPending = false;
-  size_t s1pLdsSet = 0;
   int fusedBackoff[2] = {0, 0}; // treatment / control samples for which k_sbtile is not tried (after one that did not fit)
   bool looseSwept = false;      // the last gx_find_peaks swept the loose slots
+  bool pilesMade = false;       // pileup floats were written since the last gx_reset (ensure_piles)
   DevBuf lbSweep, lbSweep2;     // look-back granules of the sweep's one-pass compactions (generation-tagged)
   u32 sweepGen = 0;
   FragSelect closeSel{};        // the sample's k_frag_select arguments (k_close took them; finish_scalars may need them again)
@@ -297,8 +350,7 @@ enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_BHOVF = 7, M_GENO
 
 // GX_DEBUG=1: synchronise after every launch and say which kernel it was (hang / fault triage)
 int dbg_sync(gx_ctx* ctx, const char* what) {
-  static const bool on = getenv("GX_DEBUG") != nullptr;
-  if (!on) return GX_OK;
+  if (!ctx->knob.debug) return GX_OK;
   fprintf(stderr, "[gx] %s ...", what);
   fflush(stderr);
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -351,6 +403,8 @@ int status_to_rc(gx_ctx* ctx, u32 st) {
       {ST_HASH_FULL, GX_ERR_DEVICE, "p-value table full"},
       {ST_BAD_DF, GX_ERR_DF, "Invalid df in pchisq()"},
       {ST_PT_FULL, GX_ERR_MEM, "level-1 page table full"},
+      {ST_END_PILE, GX_ERR_ARR, "pileup of a chromosome does not return to 0 behind its last base"},
+      {ST_BH_LEN, GX_ERR_PVAL, "Genome length does not match p-value length"},
   };
   for (auto& t : tab)
     if (st & t.bit) {
@@ -394,7 +448,7 @@ int mail_sync(gx_ctx* ctx, const Scalars* ds, const u32* hot, const u32* nIv, co
 
 // (the mail kernel -- k_mail, or k_close -- has been launched with this sequence number)
 int mail_wait(gx_ctx* ctx, u32 seq) {
-  static const bool spin = getenv("GX_NO_SPIN") == nullptr;
+  const bool spin = !ctx->knob.noSpin;
   volatile u32* word = &ctx->mail->seq;
   if (spin) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -517,8 +571,7 @@ int flush_begin(gx_ctx* ctx) {
 // buffers leave the context -- no copy -- and the context takes others for the next build (pooled).  With -E regions
 // the merge needs tight arrays after all (gx_merge.h): pack_pileup.
 int stash_or_pack(gx_ctx* ctx, Pileup& P) {
-  static const bool noStash = getenv("GX_PACK_FOR_MERGE") != nullptr;   // (tests / measurements: round 2's way)
-  if (ctx->hasBed || noStash) return pack_pileup(ctx, P);
+  if (ctx->hasBed) return pack_pileup(ctx, P);
   if (P.inLoose) return GX_OK;
   recycle(ctx, P.looseEnd);
   recycle(ctx, P.looseV);
@@ -551,6 +604,19 @@ template <typename Segs> static u32 class_chunks(const Segs& segs) {
 // (k_sbtile sent it back): level 1 of the sort -- the pages, the cursors, the closed form of fragLen -- is still
 // there, so k_sort1 does not run again and only what the first tile stage and the scans wrote is cleared.
 int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
+  const Knobs& K = ctx->knob;
+  // Several ranks: lambda needs every rank's fragLen.  Its closed form (the sum of the fragment lengths, k_sort1) is
+  // known BEFORE the tile stage, so the ranks exchange that (`earlyColl`: one all-reduce of three words behind
+  // k_sort1; decided by what every rank knows alike) and each of them has the table p(V) and the sweep's bits from the
+  // tile stage, as a single rank has.  The all-reduce behind the tile stage (finish_scalars) still carries the exact
+  // parts and the ranks' flags; a rank whose lambda came out different there falls back to k_pack_pval as before.
+  // (decided ahead of everything that can fail -- the size check, the allocations: a rank that leaves this function
+  // early owes the others BOTH all-reduces, and poison_allreduce reads earlyOwed to know)
+  const bool multiRank = ctx->world > 1 || ctx->forceColl;
+  const bool forceSlowFrag = K.forceSlowFrag != 0, noFused = K.noFused != 0, noLoose = K.noLoose != 0;
+  const bool earlyColl = multiRank && !isCtrl && !ctx->par.qval_opt && !ctx->bedGiven && !noLoose && !forceSlowFrag && !K.noEarlyColl;
+  ctx->earlyColl = earlyColl;
+  ctx->earlyOwed = earlyColl;
   // (host-pushed events sit in the library's device chunks, device-resident segments are used in place)
   const std::vector<gx_ctx::Seg>& segs = ctx->segs;
   size_t n = 0;
@@ -563,15 +629,12 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   const u32 nTiles = ctx->nTiles, nSB = ctx->nSB, nChrom = ctx->nChrom;
   // tile id + offset fit a 4-byte key (GX_FORCE_REC64=1 forces the wide-record path: used by the tests,
   // since only a genome beyond 4.29 Gbp takes it naturally)
-  static const bool forceWide = getenv("GX_FORCE_REC64") != nullptr;
-  const bool unit32 = nTiles < MAX_TILES32 && !forceWide;
+  const bool unit32 = nTiles < MAX_TILES32 && !K.forceRec64;
   hipStream_t s = ctx->stream;
   gx_ctx::Stream& SS = ctx->str[0];
   gx_ctx::Stream& SE = ctx->str[1];
   gx_ctx::Stream& SF = ctx->str[2];
   const u32 nL1base = nSB - 1;  // level-1 bins = super-buckets (records without a tile are not scattered at all)
-  static const bool forceSlowFrag = getenv("GX_FORCE_SLOWFRAG") != nullptr;
-  const bool noFused = getenv("GX_NO_FUSED") != nullptr, noLoose = getenv("GX_NO_LOOSE") != nullptr;  // (tests: per call)
   // ---- what the tile stage will be -------------------------------------------------------------------------
   // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- unit weights, no -E regions, at most
   // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
@@ -580,11 +643,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // next replicate, or the next run on the same data, has the same pile-ups)
   const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
   if (backoff) ctx->fusedBackoff[isCtrl ? 1 : 0]--;
-  const bool pairsAllowed = getenv("GX_NO_PAIRS") == nullptr;
-  static const bool onePass = getenv("GX_SORT_ONE_PASS") != nullptr;  // (measurements: k_sort1p instead of k_sort_a + k_sort_b)
+  const bool pairsAllowed = !K.noPairs;
   // (fractional weights ride the pair records -- k_sort_a<true>, k_sbtile<.., true> -- once a sample of this context has
   // shown one; the start / end keys of the other fused variant cannot carry a weight)
-  const bool fracOk = pairsAllowed && !onePass && getenv("GX_NO_FRAC_PAIRS") == nullptr;
+  const bool fracOk = pairsAllowed && !K.noFracPairs;
   const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && (!ctx->sawFrac || fracOk) &&
                      !ctx->fusedOff && !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1base) * 64000 &&
                      (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
@@ -602,10 +664,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   u32 nL1 = nL1base;
   // (not with fractional weights: measured at config 4, the tile passes with weights and the fragLen terms cost more per
   // key than the rounds of full-size bins -- 2.98 against 2.67 ms)
-  const bool forceHalf = getenv("GX_FORCE_HALF_BINS") != nullptr;  // (tests: the 128-key level 1 on a small input)
-  if (pairs && (!fracPairs || forceHalf) && !onePass && sbS > 0 &&
+  const bool forceHalf = K.forceHalfBins != 0;  // (tests: the 128-key level 1 on a small input)
+  if (pairs && (!fracPairs || forceHalf) && sbS > 0 &&
       (forceHalf || (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * (SBT_KEYCAP - SBT_KEYCAP / 4)) &&
-      ((nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1)) <= (u32)MAX_BINS_P && getenv("GX_NO_HALF_BINS") == nullptr) {
+      ((nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1)) <= (u32)MAX_BINS_P && !K.noHalfBins) {
     sbS--;
     nL1 = (nTiles + (1u << sbS) - 1) >> sbS;
   }
@@ -624,16 +686,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   poolPages[2] = (u32)(((size_t)2 * nEv) >> PgCfg<u64>::SHIFT) + NXCD * nL1 + 4;
   for (int q = 0; q < 3; q++) HIPCHECK(ctx->str[q].pool.ensure((size_t)poolPages[q] * PG_BYTES));
   // lambda ahead of the tile stage (closed form of fragLen; LooseCtl): one rank, a treatment sample, -p
-  const bool multiRank = ctx->world > 1 || ctx->forceColl;
-  // Several ranks: lambda needs every rank's fragLen.  Its closed form (the sum of the fragment lengths, k_sort1) is
-  // known BEFORE the tile stage, so the ranks exchange that (`earlyColl`: one all-reduce of three words behind
-  // k_sort1; decided by what every rank knows alike) and each of them has the table p(V) and the sweep's bits from the
-  // tile stage, as a single rank has.  The all-reduce behind the tile stage (finish_scalars) still carries the exact
-  // parts and the ranks' flags; a rank whose lambda came out different there falls back to k_pack_pval as before.
-  const bool earlyColl = multiRank && !isCtrl && !ctx->par.qval_opt && !ctx->bedGiven && !noLoose && !forceSlowFrag &&
-                         getenv("GX_NO_EARLY_COLL") == nullptr;
-  ctx->earlyColl = earlyColl;
-  ctx->earlyOwed = earlyColl;
   const bool wantEarly = !isCtrl && (!multiRank || earlyColl) && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag &&
                          !ctx->sawFrac;  // (fractional weights: the closed form of fragLen is off, lambda only comes with the sample's end)
   const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
@@ -747,8 +799,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     // scatter of the pieces that have arrived overlaps the upload of the rest)
     if (seg.ready) HIPCHECK(hipStreamWaitEvent(s, seg.ready, 0));
     const u32 blocks = (u32)((seg.n + S1_CHUNK - 1) / S1_CHUNK);
-    static_assert(S1P_CHUNK == S1_CHUNK, "one grid size for both level-1 kernels");
-    if (pairs && !onePass) {
+    if (pairs) {
       // two passes: coarse bins, then the fine ones (gx_sort.h)
       u32 nWG1 = 0;
       for (auto& sg : segs) nWG1 += (u32)((sg.n + S2_CHUNK - 1) / S2_CHUNK);
@@ -767,14 +818,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       pcLast = PC;
       ncLast = nCoarse;
       gridB = NXCD * (perClass + nCoarse);   // (a class's lists hold at most its chunks' + one partly filled page each)
-    } else if (pairs) {
-      const size_t lds1 = s1p_lds_bytes(nL1, nChrom);
-      if (ctx->s1pLdsSet < lds1) {
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort1p), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        ctx->s1pLdsSet = lds1;
-      }
-      hipLaunchKernelGGL(k_sort1p, dim3(blocks), dim3(S1P_NT), lds1, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
-                         sbS, nL1, PG3[0], PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
     } else if (unit32)
       hipLaunchKernelGGL(k_sort1<true>, dim3(blocks), dim3(S1_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom,
                          sbS, nL1, PG3[0], PG3[1], PG3[2], so1, ctx->dStatus.as<u32>());
@@ -787,6 +830,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                        ctx->dStatus.as<u32>());
   if (int rc__ = dbg_sync(ctx, "k_sort1")) return rc__;
   phase_end(ctx);
+  if (K.fault == 1 && !reuseSort) HIPCHECK(hipMemsetAsync(ctx->endAtLen.p, 0x01, 4, s));  // (tests: ST_END_PILE must catch it)
   long long* earlyWords = nullptr;
   if (earlyColl) {
     // this rank's closed form, whether it is valid here (unit weights so far, no -E regions, 4-byte keys), [2] unused
@@ -829,21 +873,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     hipLaunchKernelGGL(k_bucket2p, dim3(std::max(1u, nL1), 3), dim3(B2_NT), lds2, s, BJ, nL1, sbS, nTiles,
                        ctx->tileWsum.as<int>());
     if (int rc__ = dbg_sync(ctx, "k_bucket2p")) return rc__;
-    if (getenv("GX_DEBUG_SORT")) {
-      HIPCHECK(hipStreamSynchronize(s));
-      for (int q = 0; q < 3; q++) {
-        std::vector<u32> cur((size_t)NXCD * nL1 + 1), off(nL1 + 1);
-        HIPCHECK(hipMemcpy(cur.data(), ctx->str[q].cursor.p, cur.size() * 4, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(off.data(), ctx->str[q].sbOff.p, off.size() * 4, hipMemcpyDeviceToHost));
-        unsigned long long tot = 0;
-        u32 mx = 0;
-        for (size_t i = 0; i < (size_t)NXCD * nL1; i++) { tot += cur[i]; mx = std::max(mx, cur[i]); }
-        u32 stw = 0;
-        HIPCHECK(hipMemcpy(&stw, ctx->dStatus.p, 4, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[gx sort] stream %d: records %llu (sbOff total %u), longest list %u, pages used %u of %u, status %u\n", q, tot,
-                off[nL1], mx, cur[(size_t)NXCD * nL1], poolPages[q], stw);
-      }
-    }
   }
   TileTabs tt{};
   for (int q = 0; q < 3; q++) {
@@ -876,14 +905,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                        ctx->tileOff[1].as<u32>(), ctx->tileOff[2].as<u32>(), ctx->tileCarry.as<int>(), ctx->dTileChrom.as<u32>(),
                        ctx->dChrom.as<DChrom>(), ctx->hasBed ? ctx->dBedTileOff.as<u32>() : (const u32*)nullptr, nTiles,
                        ctx->tileMeta.as<TileMeta>(), ctx->wideList.as<u32>(), ctx->nWide.as<u32>(), ctx->tileSlot.as<u32>(),
-                       ctx->hasBed || getenv("GX_TILE_OLD") ? (u32*)nullptr : ctx->heavyList.as<u32>());
+                       ctx->hasBed ? (u32*)nullptr : ctx->heavyList.as<u32>());
   phase_end(ctx);
 
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");  // k_tile alone: the dominant kernel (bench.py's roofline)
   TileIn tin{SS.a.as<uint16_t>(), SE.a.as<uint16_t>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
   // the tile stage is k_tile_fast (+ k_tile_heavy): the general fragLen path's terms ride in it (TileIn::fragAcc)
-  static const bool noFragFuse = getenv("GX_FRAG_WALK_ALL") != nullptr;  // (tests / measurements: round 2's separate walk)
-  ctx->fragFused = (!fused && !ctx->hasBed && !getenv("GX_TILE_OLD") && !noFragFuse) || ctx->fracPairsUsed;
+  ctx->fragFused = (!fused && !ctx->hasBed) || ctx->fracPairsUsed;
   if (ctx->fragFused) {
     tin.ff = ff;
     tin.fragAcc = acc;
@@ -933,18 +961,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                        ctx->dStatus.as<u32>());
     hipLaunchKernelGGL((k_tile<true, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());
-  } else if (!getenv("GX_TILE_OLD")) {
+  } else {
     // the common case: one wavefront per tile, work laid out by touched base, unit-weight and fractional records
     // alike (gx_tile_fast.h)
     hipLaunchKernelGGL(k_tile_fast, dim3(std::min<u32>(nTiles, (u32)ctx->resTileFast)), dim3(64), 0, s, tin, nTiles, nw, to,
                        ctx->dStatus.as<u32>());
     // the tiles with thousands of records (pile-ups): a workgroup each, a counter per base (usually none: an idle launch)
     hipLaunchKernelGGL(k_tile_heavy, dim3(64), dim3(TH_NT), 0, s, tin, ctx->heavyList.as<u32>(), nw + 2, to, ctx->dStatus.as<u32>());
-  } else {
-    hipLaunchKernelGGL((k_tile<false, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
-                       ctx->dStatus.as<u32>());
-    hipLaunchKernelGGL((k_tile<false, false>), gWide, dim3(TL_NT), TL_LDS * 4, s, tin, nTiles, wl, nw, bin, to,
-                       ctx->dStatus.as<u32>());
   }
   if (int rc__ = dbg_sync(ctx, "k_tile")) return rc__;
   phase_end(ctx);
@@ -953,7 +976,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // (a tile that can hold such a base has >= 32,766 records: it is on the list of the heavy tiles -- walking the list of
   // the WIDE tiles instead cost config 4, where every tile holds fractional records and is "wide", 2.1 ms of header reads)
   if (!fused) {
-    const bool haveHeavy = !(ctx->hasBed || getenv("GX_TILE_OLD"));
+    const bool haveHeavy = !ctx->hasBed;
     hipLaunchKernelGGL(k_hot_check, dim3(std::min<u32>(nTiles, 256u)), dim3(256), 0, s, tin, haveHeavy ? ctx->heavyList.as<u32>() : wl,
                        haveHeavy ? nw + 2 : nw, ctx->nWide.as<u32>() + 1);
   }
@@ -963,9 +986,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   const u32 ivChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
   IvScanOut so{out.tileIvOff.as<u32>(), ctx->tilePrevEnd.as<u32>(), out.chromIvOff.as<u32>(), ctx->misc.as<u32>() + M_NIV,
                ctx->tileSlot.as<u32>(), ctx->chromLooseOff.as<u32>(), ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctl,
-               ctx->tileDeep.as<u32>(), ff, ctx->fragList.as<u32>(), ctx->fragFused ? acc : (long long*)nullptr};
-  static const bool noClose = getenv("GX_NO_CLOSE") != nullptr, sepClose = getenv("GX_SEPARATE_CLOSE") != nullptr;
-  const bool closeInScan = wantEarly && !noClose && !sepClose && !multiRank;  // (k_scan_iv_close, below)
+               ctx->tileDeep.as<u32>(), ff, ctx->fragList.as<u32>(), ctx->fragFused ? acc : (long long*)nullptr,
+               ctx->endAtLen.as<u32>()};
+  const bool closeInScan = wantEarly && !multiRank;  // (k_scan_iv_close, below)
   if (!closeInScan)
     hipLaunchKernelGGL(k_scan_iv, dim3(std::min<u32>(ivChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
                        ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
@@ -985,14 +1008,14 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                     wantEarly ? ctx->swMask.as<u64>() + ctx->looseStride : (u64*)nullptr};
     ctx->closeSel = fsel;
     ctx->closeSeq = 0;
-    if (wantEarly && !noClose && !multiRank) {
-      // lambda was known before the tile stage: k_frag_select's work and the mail in one launch (k_close); if a deep tile,
+    if (closeInScan) {
+      // lambda was known before the tile stage: k_frag_select's work and the mail ride in the scan's launch; if a deep tile,
       // the general fragLen path or a changed lambda stands in the way, finish_scalars runs the separate kernels after all
       ctx->closeSeq = ++ctx->mailSeq;
       ctx->mail->nMerged = 0;
       ctx->mail->closeState = 0;
       HostMail* dm = static_cast<HostMail*>(ctx->mailBuf.dp);
-      if (closeInScan) {
+      {
         // (the scan's last workgroup closes the sample: one launch)
         CloseArgs ca{fsel, ctx->misc.as<u32>() + M_NIV, (const u32*)&ctl->ok, ctx->dRisk.as<RiskBuf>(), mail_out(ctx),
                      &dm->closeState, ctx->closeSeq, ctx->nWide.as<u32>() + 8};
@@ -1000,9 +1023,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                            ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->dTileChrom.as<u32>(),
                            ctx->dChrom.as<DChrom>(), nTiles, ctx->lbIv.as<u64>(), ctx->lbIv.as<u64>() + ivChunks + 1, so,
                            ctx->dStatus.as<u32>(), ca);
-      } else
-        hipLaunchKernelGGL(k_close, dim3(1), dim3(64), 0, s, fsel, ctx->misc.as<u32>() + M_NIV, (const u32*)&ctl->ok,
-                           ctx->dRisk.as<RiskBuf>(), mail_out(ctx), &dm->closeState, ctx->closeSeq);
+      }
       if (int rc__ = dbg_sync(ctx, "k_close")) return rc__;
     } else {
     hipLaunchKernelGGL(k_frag_walk, dim3(std::max(1u, std::min((nTiles + 3) / 4, 4096u))), dim3(256), 0, s, lE, lV, tm, tOff,
@@ -1150,7 +1171,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     // general chain
     // (fractional weights in a unit-weight build: its singles may also have overfilled a bin -- that says nothing about
     // the next sample, which writes pair records with a weight class)
-    if (getenv("GX_DEBUG_RETRY")) fprintf(stderr, "[gx] sample sent back to the general chain: status %u (fused %d pairs %d frac %d)\n",
+    if (ctx->knob.debugRetry) fprintf(stderr, "[gx] sample sent back to the general chain: status %u (fused %d pairs %d frac %d)\n",
                                           ctx->mail->status, (int)ctx->fusedUsed, (int)ctx->pairsUsed, (int)ctx->fracPairsUsed);
     if (ctx->mail->status & ST_SB_FRAC) ctx->sawFrac = true;
     else if (ctx->mail->status & ST_SB_FULL) ctx->fusedBackoff[isCtrl ? 1 : 0] = 8;
@@ -1259,7 +1280,7 @@ int close_sample(gx_ctx* ctx, Pileup& P, int isCtrl) {
       // on the pages level 1 of the sort has already filled
       if (int w = wipe()) return w;
       // (pair records are of no use to the general chain: level 1 runs again as start / end keys)
-      reuseSort = getenv("GX_NO_REUSE_SORT") == nullptr && !ctx->pairsUsed;
+      reuseSort = !ctx->pairsUsed;
       if (reuseSort) {
         // (k_sort1 does not run again: the status bits IT raised -- bad counts, positions, chromosomes -- must survive)
         // (and only those: what the abandoned tile stage raised -- e.g. "negative pileup" from carries that count the
@@ -1331,7 +1352,7 @@ int layout_tiles(gx_ctx* ctx) {
   // enough super-buckets for every CU; GX_SBSHIFT overrides for experiments
   // (k_sbtile, the fused level 2 + tile kernel, takes super-buckets of up to 2^8 tiles: hg38 = 2,946 bins)
   ctx->sbShift = std::min(SBT_MAXSHIFT, std::max(0, (lg - 1) / 2));
-  if (const char* e = getenv("GX_SBSHIFT")) ctx->sbShift = std::max(0, std::min(11, atoi(e)));
+  if (ctx->knob.sbShift >= 0) ctx->sbShift = std::max(0, std::min(11, ctx->knob.sbShift));
   while (((t + (1u << ctx->sbShift) - 1) >> ctx->sbShift) + 1 > (u32)MAX_BINS) ctx->sbShift++;
   if ((1u << ctx->sbShift) > (u32)MAX_BINS) {
     ctx->err = "genome too large for the two-level tile sort";
@@ -1422,10 +1443,10 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
     }
     for (int attempt = 0;; attempt++) {
       // arrays for `cap` runs (never more runs than intervals)
-      static const u64 capMin = getenv("GX_RUN_CAP_MIN") ? (u64)atoll(getenv("GX_RUN_CAP_MIN")) : (u64)1 << 16;  // (tests: a tiny first guess)
+      const u64 capMin = ctx->knob.runCapMin > 0 ? (u64)ctx->knob.runCapMin : (u64)1 << 16;  // (tests: a tiny first guess)
       // (first guess: one run per 256 intervals -- several times what a default threshold leaves on a genome --
       // so that a single call does not pay for a second pass)
-      const u64 guess = getenv("GX_RUN_CAP_MIN") ? capMin : std::max<u64>(capMin, (u64)nWords / 4);
+      const u64 guess = ctx->knob.runCapMin > 0 ? capMin : std::max<u64>(capMin, (u64)nWords / 4);
       const u32 cap = std::min<u64>(std::max<u64>(ctx->runCap, std::max<u64>(guess, 1)), (u64)nWords * 64);
       HIPCHECK(ctx->swStart.ensure((size_t)cap * 4 + 16));
       HIPCHECK(ctx->swEnd.ensure((size_t)cap * 4 + 16));
@@ -1573,17 +1594,40 @@ int ensure_piles(gx_ctx* ctx, int idx) {
   hipStream_t s = ctx->stream;
   HIPCHECK(pooled(ctx, pa.expt, (size_t)pa.n * 4 + 16));
   if (ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)pa.n * 4 + 16));
-  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), pa.tileOff.as<u32>()};
+  PackIn pin{ctx->looseEnd.as<u32>(), pa.keptLoose ? pa.keptV.as<int>() : ctx->looseV.as<int>(),
+             pa.keptLoose ? pa.keptMeta.as<TileMeta>() : ctx->tileMeta.as<TileMeta>(), pa.tileOff.as<u32>()};
   const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+  // (the control value of a replicate without control is its lambda: saveLambda 1847-1876)
   if (ctx->hasBed)
-    hipLaunchKernelGGL(k_piles_from_loose<true>, grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
-                       pa.expt.as<float>(), pa.ctrl.as<float>());
+    hipLaunchKernelGGL(k_piles_from_loose<true>, grid, dim3(256), 0, s, pin, ctx->nTiles, pa.ctrlConst, pa.expt.as<float>(),
+                       pa.ctrl.as<float>());
   else
-    hipLaunchKernelGGL(k_piles_from_loose<false>, grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
-                       pa.expt.as<float>(), (float*)nullptr);
+    hipLaunchKernelGGL(k_piles_from_loose<false>, grid, dim3(256), 0, s, pin, ctx->nTiles, pa.ctrlConst, pa.expt.as<float>(),
+                       (float*)nullptr);
   if (int rc__ = dbg_sync(ctx, "k_piles_from_loose")) return rc__;
   pa.hasPiles = true;
   pa.pilesPending = false;
+  ctx->pilesMade = true;
+  if (pa.keptLoose) {
+    recycle(ctx, pa.keptV);
+    recycle(ctx, pa.keptMeta);
+    pa.keptLoose = false;
+  }
+  return GX_OK;
+}
+
+// The context's loose slots are about to be reused (a further replicate is built, or the Fisher combination writes its
+// merged intervals there): a replicate whose pileup floats are still pending keeps what they are made of -- the exact
+// pileups (looseV) and the tile descriptors -- instead of having the floats written now for nobody (k_piles_from_loose:
+// 0.36 ms and 0.8 GB per replicate at hg38 / 50 M fragments; 0.4 GB of a 288 GB device kept instead).
+int keep_loose_for_piles(gx_ctx* ctx, int idx) {
+  PArray& pa = ctx->reps[idx];
+  if (pa.loose)
+    if (int rc = materialize_rep(ctx, idx)) return rc;
+  if (!pa.pilesPending || pa.keptLoose) return GX_OK;
+  pa.keptV = std::move(ctx->looseV);
+  pa.keptMeta = std::move(ctx->tileMeta);
+  pa.keptLoose = true;
   return GX_OK;
 }
 
@@ -1622,8 +1666,10 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   gx_ctx* ctx = new gx_ctx();
   ctx->par = *par;
   ctx->device = par->device;
-  if (const char* e = getenv("GX_BH_CAPLOG")) ctx->bhCapLog = (u32)std::max(4, std::min(28, atoi(e)));  // (tests: a tiny first table)
-  if (const char* e = getenv("GX_PT_JMAX")) ctx->ptJmax = (u32)std::max(1, std::min(1 << 16, atoi(e)));  // (tests: short page-table rows)
+  for (const KnobDef& d : KNOBS)
+    if (const char* e = getenv(d.name)) set_knob(ctx->knob, d.name, e);
+  if (ctx->knob.bhCapLog) ctx->bhCapLog = (u32)std::max(4, std::min(28, ctx->knob.bhCapLog));  // (tests: a tiny first table)
+  if (ctx->knob.ptJmax) ctx->ptJmax = (u32)std::max(1, std::min(1 << 16, ctx->knob.ptJmax));   // (tests: short page-table rows)
   *out = ctx;
   HIPCHECK(hipSetDevice(ctx->device));
   HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -1652,8 +1698,6 @@ int gx_create(gx_ctx** out, const gx_params* par) {
   HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 64, ctx->stream));
   HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<true, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS * 4));
-  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<false, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS * 4));
   {
     // persistent kernels: the grid must not exceed what is co-resident (look-back forward progress)
     hipDeviceProp_t prop;
@@ -1666,8 +1710,7 @@ int gx_create(gx_ctx** out, const gx_params* par) {
     ctx->resTileHalf = std::max(1, nb) * ctx->numCU;
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile_fast, 64, 0));
     ctx->resTileFast = std::max(1, std::min(nb, TF_WG_PER_CU)) * ctx->numCU;
-    if (const char* e = getenv("GX_TILE_FAST_WG")) ctx->resTileFast = std::max(1, atoi(e)) * ctx->numCU;
-    if (getenv("GX_DEBUG"))
+    if (ctx->knob.debug)
       fprintf(stderr, "k_tile workgroups: half %d, wide %d, fast %d\n", ctx->resTileHalf, ctx->resTile, ctx->resTileFast);
     HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scan_iv, STL_NT, 0));
     ctx->resSweep = std::max(1, std::min(nb, 4)) * ctx->numCU;
@@ -1734,7 +1777,7 @@ int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn all
   ctx->allreduce = allreduce;
   ctx->allgather = allgather;
   ctx->user = user;
-  ctx->forceColl = getenv("GX_FORCE_COLL") != nullptr;
+  ctx->forceColl = ctx->knob.forceColl != 0;
   return GX_OK;
 }
 
@@ -1771,7 +1814,7 @@ int gx_set_rccl(gx_ctx* ctx, int rank, int world, const void* unique_id) {
   }
   ctx->rank = rank;
   ctx->world = world;
-  ctx->forceColl = getenv("GX_FORCE_COLL") != nullptr;
+  ctx->forceColl = ctx->knob.forceColl != 0;
   return GX_OK;
 }
 
@@ -1802,9 +1845,10 @@ int gx_reset(gx_ctx* ctx) {
   for (auto& pa : ctx->reps) {
     recycle(ctx, pa.end); recycle(ctx, pa.p); recycle(ctx, pa.expt); recycle(ctx, pa.ctrl);
     recycle(ctx, pa.chromOff); recycle(ctx, pa.q); recycle(ctx, pa.tileOff); recycle(ctx, pa.dPresent);
-    recycle(ctx, pa.chromLooseOff);
+    recycle(ctx, pa.chromLooseOff); recycle(ctx, pa.keptV); recycle(ctx, pa.keptMeta);
   }
   ctx->reps.clear();
+  ctx->pilesMade = false;
   ctx->sample = 0;
   ctx->phase = 0;
   ctx->finalIdx = -1;
@@ -1826,7 +1870,7 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
     // (a further replicate: the previous one's loose slots, tile tables and p(V) table are about to be reused)
     for (size_t r = 0; r < ctx->reps.size(); r++)
       if (ctx->reps[r].loose || ctx->reps[r].pilesPending)
-        if (int rc = ensure_piles(ctx, (int)r)) return rc;
+        if (int rc = keep_loose_for_piles(ctx, (int)r)) return rc;
     for (u32 i = 0; i < ctx->nChrom; i++) ctx->save[i] = save ? (save[i] != 0) : 1;
     int rc = upload_chroms(ctx, false);
     if (rc) return rc;
@@ -1956,17 +2000,29 @@ int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor) {
 
 int gx_expect_fractional(gx_ctx* ctx, int on) {
   if (!ctx) return GX_ERR_ORDER;
-  ctx->sawFrac = on != 0;
+  // (a hint can only add knowledge: what the library has learned from a sample by itself stays)
+  if (on) ctx->sawFrac = true;
+  return GX_OK;
+}
+
+int gx_set_knob(gx_ctx* ctx, const char* name, const char* value) {
+  if (!ctx || !name) return GX_ERR_ORDER;
+  if (!set_knob(ctx->knob, name, value)) {
+    ctx->err = std::string("unknown switch ") + name;
+    return GX_ERR_ORDER;
+  }
+  ctx->forceColl = ctx->knob.forceColl != 0;
   return GX_OK;
 }
 
 int gx_dups_first(gx_ctx* ctx, const gx_dup_key* keys, const uint8_t* multi, size_t n, uint32_t* owner) {
-  if (!ctx || (n && (!keys || !multi || !owner)) || n >= ((size_t)1 << 31)) return GX_ERR_ORDER;
+  // (the table has 2^k >= 2 n slots addressed by 32-bit indices: n <= 2^30)
+  if (!ctx || (n && (!keys || !multi || !owner)) || n > ((size_t)1 << 30)) return GX_ERR_ORDER;
   if (!n) return GX_OK;
   HIPCHECK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   u32 cap = 1024;
-  while ((size_t)cap < 2 * n) cap <<= 1;
+  while ((size_t)cap < 2 * n) cap <<= 1;   // (<= 2^31: no wrap)
   DevBuf dKeys, dMulti, dOwner, dTab;
   HIPCHECK(dKeys.ensure(n * 16));
   HIPCHECK(dMulti.ensure(n + 16));
@@ -2036,7 +2092,7 @@ int gx_pvalues(gx_ctx* ctx) {
     pa.ctrlConst = ctx->hScal.lambda;
     pa.loose = true;
     // (the tile stage wrote the sweep's significance bits, in loose-slot index space: LooseCtl)
-    pa.looseSweep = ctx->looseOk && !ctx->par.qval_opt && !getenv("GX_NO_LOOSE");
+    pa.looseSweep = ctx->looseOk && !ctx->par.qval_opt && !ctx->knob.noLoose;
     pa.looseStride = ctx->looseStride;
     if (pa.looseSweep) pa.chromLooseOff = std::move(ctx->chromLooseOff);
     ctx->looseOk = false;
@@ -2291,7 +2347,8 @@ static int bh_range_exchange(gx_ctx* ctx, const BhTable& T, u32 Dlocal, u32 capL
   hipLaunchKernelGGL(k_bhx_reduce, dim3(1), dim3(256), 0, s, (const u64*)chunkSum, (const float*)nullptr, nCh, small + oTot + me, (u64*)nullptr);
   if (int rc = coll_concat(ctx, reinterpret_cast<long long*>(small + oTot), 1)) return rc;
   hipLaunchKernelGGL(k_qt_raw, dim3(nCh), dim3(QT_NT), 0, s, (const u32*)sKeys, (const u64*)dl, 0u, reinterpret_cast<const u64*>(misc + M_GENOME),
-                     (const u64*)chunkSum, ctx->bhRaw.as<float>(), chunkMin, (const u32*)cnt2, (const u64*)(small + oTot), W, me);
+                     (const u64*)chunkSum, ctx->bhRaw.as<float>(), chunkMin, (const u32*)cnt2, (const u64*)(small + oTot), W, me,
+                     ctx->par.genome_len == 0 ? ctx->dStatus.as<u32>() : (u32*)nullptr);
   hipLaunchKernelGGL(k_bhx_reduce, dim3(1), dim3(256), 0, s, (const u64*)nullptr, (const float*)chunkMin, nCh, (u64*)nullptr, small + oMin + me);
   if (int rc = coll_concat(ctx, reinterpret_cast<long long*>(small + oMin), 1)) return rc;
   hipLaunchKernelGGL(k_qt_apply, dim3(nCh), dim3(QT_NT), 0, s, (const u32*)sSlot, (const float*)ctx->bhRaw.as<float>(), 0u, (const float*)chunkMin,
@@ -2327,10 +2384,10 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   for (size_t r = 0; r < ctx->reps.size(); r++) {
     if (ctx->reps[r].loose && !looseFast)
       if (int rc = materialize_rep(ctx, (int)r)) return rc;
-    // (the Fisher combination of several replicates reuses the loose slots: the last replicate's pileup
-    // floats, if wanted, have to be made before)
+    // (the Fisher combination of several replicates reuses the loose slots: the last replicate keeps what its pileup
+    // floats, if somebody asks for them, are made of)
     if (ctx->sample > 1 && ctx->reps[r].pilesPending)
-      if (int rc = ensure_piles(ctx, (int)r)) return rc;
+      if (int rc = keep_loose_for_piles(ctx, (int)r)) return rc;
   }
   if (ctx->sample > 1 && (int)ctx->reps.size() == ctx->sample) {
     // combinePval (612-667): union of all replicates' breakpoints, Fisher's method per interval
@@ -2358,8 +2415,8 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     HIPCHECK(pooled(ctx, comb.tileOff, (size_t)(nTiles + 2) * 4));
     HIPCHECK(pooled(ctx, comb.chromOff, (size_t)(nChrom + 2) * 4));
     phase_begin(ctx, "fisher");
-    HIPCHECK(ctx->looseEnd.ensure(cap * 4));
-    HIPCHECK(ctx->looseV.ensure(cap * 4));
+    HIPCHECK(pooled(ctx, ctx->looseEnd, cap * 4));
+    HIPCHECK(pooled(ctx, ctx->looseV, cap * 4));   // (the last replicate may have kept the previous one: keep_loose_for_piles)
     HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
     MergeNOut mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<float>(), ctx->tileIvCount.as<u32>()};
     const size_t lds = mergeN_lds_bytes((int)nr);
@@ -2370,7 +2427,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     HIPCHECK(ctx->fisherCache.ensure(((size_t)16 << MN_GLOBAL_LOG)));
     HIPCHECK(hipMemsetAsync(ctx->fisherCache.p, 0, (size_t)16 << MN_GLOBAL_LOG, s));
     int mnBlocks = 0;
-    if (nr <= MNW_MAXREP && !getenv("GX_MERGEN_OLD")) {
+    if (nr <= MNW_MAXREP) {
       // one wavefront per tile (no workgroup barrier in the tile loop, twenty tiles in flight per CU)
       const size_t ldsw = mergeNw_lds_bytes((int)nr);
       HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
@@ -2479,6 +2536,8 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       if (int rc = bh_grow()) return rc;
     }
     const bool multi = ctx->world > 1 || ctx->forceColl;
+    // (computeQval 377-382: checked when the genome length was computed -- not with -L)
+    u32* lenCheck = genomeOpt ? ctx->dStatus.as<u32>() : (u32*)nullptr;
     u32 D = 0;
     bool denseDone = false;
     ctx->denseBhUsed = false;
@@ -2487,7 +2546,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     // genome-wide histogram is ONE all-reduce of a dense "bp at V" array (gx_stats.h: k_bh_dense_fill) -- decided by what
     // every rank knows alike
     if (multi && ctx->sample == 1 && ctx->reps.size() == 1 && fa.ctrlIsConst && !ctx->bedGiven && (u32)std::max(1, ctx->world) <= 64 &&
-        getenv("GX_NO_DENSE_BH") == nullptr) {
+        !ctx->knob.noDenseBh) {
       const u32 W = (u32)std::max(1, ctx->world);
       const size_t words = bhd_words(W);
       HIPCHECK(ctx->bhDense.ensure(words * 8));
@@ -2539,10 +2598,10 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
       HIPCHECK(ctx->bhTmp.ensure(tmpBytes + 16));
       HIPCHECK(rocprim::radix_sort_pairs(ctx->bhTmp.p, tmpBytes, ctx->bhOutKeys.as<u32>(), ctx->bhSortKeys.as<u32>(),
                                          ctx->bhOutSlot.as<u32>(), ctx->bhSortSlot.as<u32>(), D, 0, 32, s));
-      if (D <= 16384 && !getenv("GX_QT_MULTI")) {
+      if (D <= 16384 && !ctx->knob.qtMulti) {
         hipLaunchKernelGGL(k_qtable, dim3(1), dim3(1024), 0, s, ctx->bhSortKeys.as<u32>(), ctx->bhSortSlot.as<u32>(),
                            ctx->bhLens.as<u64>(), D, reinterpret_cast<const u64*>(misc + M_GENOME), ctx->bhQ.as<float>(),
-                           ctx->bhRaw.as<float>(), misc + M_ALLONE);
+                           ctx->bhRaw.as<float>(), misc + M_ALLONE, lenCheck);
       } else {  // many distinct values (Fisher-combined replicates): the chunked kernels
         const u32 nCh = (D + QT_CHUNK - 1) / QT_CHUNK;
         HIPCHECK(ctx->bhDl.ensure((size_t)D * 8 + (size_t)nCh * 12 + 64));
@@ -2553,7 +2612,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
                            chunkSum, (const u32*)nullptr);
         hipLaunchKernelGGL(k_qt_raw, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortKeys.as<u32>(), dl, D,
                            reinterpret_cast<const u64*>(misc + M_GENOME), chunkSum, ctx->bhRaw.as<float>(), chunkMin,
-                           (const u32*)nullptr, (const u64*)nullptr, 1u, 0u);
+                           (const u32*)nullptr, (const u64*)nullptr, 1u, 0u, lenCheck);
         hipLaunchKernelGGL(k_qt_apply, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortSlot.as<u32>(), ctx->bhRaw.as<float>(), D,
                            chunkMin, ctx->bhQ.as<float>(), misc + M_ALLONE, (const u32*)nullptr, (const u64*)nullptr, 1u, 0u);
       }
@@ -2769,7 +2828,8 @@ int gx_rccl_nranks(gx_ctx* ctx, int* n) {
 int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   if (!ctx || !flags) return GX_ERR_ORDER;
   *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->rangeBhUsed ? GX_PATH_RANGE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
-           (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u);
+           (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u) | (ctx->fusedUsed && ctx->fracPairsUsed ? GX_PATH_FRAC_PAIRS : 0u) |
+           (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u);
   return GX_OK;
 }
 

@@ -46,6 +46,9 @@ enum : u32 {
   ST_HASH_FULL = 64u,    // p-value table overflow (internal)
   ST_NO_FRAGS = 128u,    // fragLen == 0                     (ERREXPT, :2292)
   ST_BAD_DF = 256u,      // more than 200 replicates         (ERRDF, :556)
+  // (512 / 1024 / 2048: ST_PT_FULL / ST_SB_FULL / ST_SB_FRAC, gx_sort.h -- internal, the host retries)
+  ST_END_PILE = 4096u,   // a chromosome's pileup does not return to 0 behind its last base ("finishes at %f (not 0.0)", :2283-2289)
+  ST_BH_LEN = 8192u,     // the lengths behind the p-value table do not add up to the genome length (ERRISSUE, :377-382)
 };
 
 // ---- "risky" p-values (gx_math.h: round_checked) ------------------------------------------------
@@ -1206,6 +1209,10 @@ struct IvScanOut {
   u32* fragList;
   // the general fragLen path shared with the tile kernel (TileIn::fragAcc): the tiles' first intervals are added here
   long long* fragAcc = nullptr;
+  // the reference's check that a chromosome's pileup returns to zero (savePileupExpt 2283-2289, savePileupCtrl 2152-2158):
+  // [nChrom] weight (1/120) of the events that end at the chromosome's length -- all that may still be open in the
+  // closing interval [.., len) of its last tile
+  const u32* endAtLen = nullptr;
 };
 
 __device__ __forceinline__ void scan_iv_body(const u32* __restrict__ tileCount, const u32* __restrict__ tileLastEnd,
@@ -1296,6 +1303,15 @@ __device__ __forceinline__ void scan_iv_body(const u32* __restrict__ tileCount, 
               }
             }
           }
+        }
+        if (out.endAtLen && c[k] && t + 1 == chroms[ci].tileBase + chroms[ci].nTiles) {
+          // the chromosome's last tile: its last interval is the closing one, [.., len) (2268-2273).  Behind it the
+          // reference's difference array must be back at zero (updateVal(diff[len]), 2283-2289); diff[len] holds the ends
+          // of the fragments that reach the chromosome's end, which have no record here (k_sort1 / k_sort_a count their
+          // weight per chromosome): the closing pileup must be exactly that weight.  (-E: a closing interval inside an
+          // excluded region carries no pileup)
+          const int vEnd = out.looseV[out.tileSlot[t] + c[k] - 1];
+          if (vEnd != V_MARK && vEnd != (int)out.endAtLen[ci]) atomicOr(st, ST_END_PILE);
         }
         if (t == chroms[ci].tileBase) {
           st_agent(&out.chromIvOff[ci], cex);
@@ -1705,11 +1721,6 @@ __global__ __launch_bounds__(STL_NT) void k_scan_iv_close(const u32* __restrict_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     close_body(C.sel, C.nIv, C.extra, C.rb, C.m, C.closeState, C.seq);
   }
-}
-
-__global__ __launch_bounds__(64) void k_close(FragSelect A, const u32* __restrict__ nIv, const u32* __restrict__ extra,
-                                              const RiskBuf* __restrict__ rb, MailOut m, u32* __restrict__ closeState, u32 seq) {
-  close_body(A, nIv, extra, rb, m, closeState, seq);
 }
 
 }  // namespace gx

@@ -565,22 +565,9 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
 // fractional weight, which sends the sample to the general chain afterwards) is appended record by record to the
 // F stream as 8-byte signed-weight records, straight to global memory: a handful per workgroup.  A pair adds nothing
 // to the pileup that a super-bucket hands to the next one; the singles' weights are summed per bin (binNet).
-constexpr int S1P_NT = 512;
-constexpr int S1P_ITEMS = 16;
-constexpr int S1P_CHUNK = S1P_NT * S1P_ITEMS;
-constexpr int S1P_BATCH = 8;
-constexpr int S1P_BPT = MAX_BINS / S1P_NT;   // consecutive level-1 bins owned by a thread
 constexpr u32 PAIR_LEN_BITS = 12;
-static_assert(S1P_CHUNK <= (1 << PgCfg<u32>::SHIFT), "a chunk's run for one bin never spans more than two pages");
-static_assert(S1P_BPT == 8, "an owner reads its counts as two 16-byte words");
 constexpr int SBT_MAXSHIFT = 8;            // tiles per super-bucket (log2) that k_sbtile takes
 static_assert(TB + SBT_MAXSHIFT + PAIR_LEN_BITS <= 32, "start within the super-bucket and length share 32 bits");
-
-__host__ __device__ inline u32 s1p_bins_pad(u32 nBins) { return (nBins + S1P_BPT - 1) / S1P_BPT * S1P_BPT; }
-__host__ __device__ inline size_t s1p_lds_bytes(u32 nBins, u32 nChrom) {
-  return (size_t)2 * s1p_bins_pad(nBins) * 4 + (size_t)S1P_CHUNK * 6 + 64 * 4 +
-         (size_t)(nChrom <= (u32)S1_LCHROM ? nChrom : 0) * sizeof(DChrom);
-}
 
 // one record to the end of its (XCD class, bin) list, by the thread that holds it (lanes without one: have = false).
 // The page protocol of scatter_paged with runs of one record; the wavefront's allocations come before any of its waits.
@@ -605,217 +592,9 @@ __device__ __forceinline__ void append_single(const PagedStream& P, u32 li, u64 
   if (have) reinterpret_cast<u64*>(P.pool)[((size_t)page << SHIFT) + (o & (PG - 1))] = rec;
 }
 
-__global__ __launch_bounds__(S1P_NT, 4) void k_sort1p(const gx_event* __restrict__ ev, u32 n, const DChrom* __restrict__ chroms,
-                                                   u32 nChrom, int sbShift, u32 nBins, PagedStream PP, PagedStream PF,
-                                                   int* __restrict__ binNet, Sort1Out out, u32* __restrict__ st) {
-  constexpr int SHIFT = PgCfg<u32>::SHIFT;
-  constexpr u32 PG = 1u << SHIFT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char s1p_raw[];
-  const u32 nPad = s1p_bins_pad(nBins);
-  u32* const tabA = reinterpret_cast<u32*>(s1p_raw);   // per bin: records of this chunk, then the pool index of the run's first record
-  u32* const tabB = tabA + nPad;                        // per bin: [15:0] start of the run in the staged chunk, [31:16] records in its first page
-  u32* const stage = tabB + nPad;
-  uint16_t* const binOf = reinterpret_cast<uint16_t*>(stage + S1P_CHUNK);  // the bin of a staged record (a record does not say)
-  u32* const scratch = reinterpret_cast<u32*>(binOf + S1P_CHUNK);
-  u32* const count = scratch + 48;
-  DChrom* const lchrom = reinterpret_cast<DChrom*>(scratch + 64);
-  const bool chromLds = nChrom <= (u32)S1_LCHROM;
-  const u32 x = blockIdx.x % NXCD;
-  const u32 begin = blockIdx.x * S1P_CHUNK;
-  const u32 binMask = (1u << sbShift) - 1u;
-  u32 bad = 0, singles = 0;
-  u32 covered32 = 0;  // (sixteen lengths below 2^12)
-  u32 rec[S1P_ITEMS], br[S1P_ITEMS];  // the record; its bin << 16 | rank within the chunk's run
-  for (u32 i = threadIdx.x; i < nPad; i += S1P_NT) tabA[i] = 0;
-  // The common event -- count 1, on a chromosome this context works on, 0 < end - start < 2^12, both ends inside the
-  // chromosome and in one super-bucket -- is recognised and converted by straight-line code (a dozen compares and
-  // shifts); so is one with nothing to do (beyond the input; count 1 on a chromosome that is skipped, not saved or
-  // another rank's).  Everything else ("slow": the singles, fractional weights, whatever raises a status bit) waits
-  // for the loop behind the scatter, where convert_event does what k_sort1 does for every event.
-#pragma unroll
-  for (int k0 = 0; k0 < S1P_ITEMS; k0 += S1P_BATCH) {
-    uint4 e[S1P_BATCH];
-    bool have[S1P_BATCH];
-#pragma unroll
-    for (int q = 0; q < S1P_BATCH; q++) {
-      const u32 i = begin + (k0 + q) * S1P_NT + threadIdx.x;
-      have[q] = i < n;
-      e[q] = reinterpret_cast<const uint4*>(ev)[have[q] ? i : n - 1];  // chrom, start, end, count
-    }
-    if (k0 == 0) {  // (behind the first batch of event loads; the barrier also ends the clearing of the counts)
-      if (chromLds)
-        for (u32 i = threadIdx.x; i < nChrom; i += S1P_NT) lchrom[i] = chroms[i];
-      __syncthreads();
-    }
-    u32 binq[S1P_BATCH];
-#pragma unroll
-    for (int q = 0; q < S1P_BATCH; q++) {
-      const u32 ci = min(e[q].x, nChrom - 1);
-      const DChrom c = chromLds ? lchrom[ci] : chroms[ci];
-      const bool ok1 = have[q] && e[q].w == 1u && e[q].x < nChrom;
-      const bool act = chrom_active(c);
-      const u32 len = e[q].z - e[q].y;
-      const u32 t0 = c.tileBase + (e[q].y >> TB), t1 = c.tileBase + (e[q].z >> TB);
-      const u32 bin = t0 >> sbShift;
-      const bool fast = ok1 && act && e[q].z < c.len && len - 1u < (1u << PAIR_LEN_BITS) - 1u && e[q].y < e[q].z && (t1 >> sbShift) == bin;
-      const bool nothing = !have[q] || (ok1 && !act);
-      rec[k0 + q] = fast ? ((((t0 & binMask) << TB) | (e[q].y & (TILE - 1))) << PAIR_LEN_BITS) | len : NULL32;
-      binq[q] = bin;
-      covered32 += fast ? len : 0u;
-      singles |= (u32)(!fast && !nothing) << (k0 + q);
-    }
-    // (the batch's LDS atomics in flight together)
-#pragma unroll
-    for (int q = 0; q < S1P_BATCH; q++) br[k0 + q] = rec[k0 + q] != NULL32 ? atomicAdd(&tabA[binq[q]], 1u) : 0u;
-#pragma unroll
-    for (int q = 0; q < S1P_BATCH; q++) br[k0 + q] |= binq[q] << 16;
-  }
-  u64 covered = covered32;
-#ifndef GX_EXP_S1P   // measurement hook (tools/build_variant.sh -DGX_EXP_S1P=n): 1 loads + conversion only, 2 no staging / writing, 3 no slow loop
-#define GX_EXP_S1P 0
-#endif
-  if (GX_EXP_S1P == 1) {
-    u32 xx = 0;
-#pragma unroll
-    for (int k = 0; k < S1P_ITEMS; k++) xx ^= rec[k] ^ br[k];
-    if (xx == 0xDEADBEEFu) atomicOr(st, 1u << 30);
-    return;
-  }
-  __syncthreads();
-  {
-    // thread t owns bins 8 t .. 8 t + 7: counts -> reservations on the lists' cursors (all in flight together) -> where the
-    // runs start in the staged chunk (one block scan of the threads' totals) and in the pool
-    const u32 b0 = threadIdx.x * S1P_BPT;
-    u32 cq[S1P_BPT], oq[S1P_BPT];
-    if (b0 < nPad) {
-      const uint4 lo = *reinterpret_cast<const uint4*>(tabA + b0), hi = *reinterpret_cast<const uint4*>(tabA + b0 + 4);
-      cq[0] = lo.x; cq[1] = lo.y; cq[2] = lo.z; cq[3] = lo.w; cq[4] = hi.x; cq[5] = hi.y; cq[6] = hi.z; cq[7] = hi.w;
-    } else {
-#pragma unroll
-      for (int q = 0; q < S1P_BPT; q++) cq[q] = 0;
-    }
-    u32 sum = 0;
-#pragma unroll
-    for (int q = 0; q < S1P_BPT; q++) {
-      oq[q] = 0;
-      if (cq[q]) oq[q] = atomicAdd(&PP.cursor[x * nBins + b0 + q], cq[q]);
-      sum += cq[q];
-    }
-    u32 tot;
-    u32 run = block_excl_scan<u32, S1P_NT>(sum, scratch, &tot);
-    if (threadIdx.x == 0) count[0] = tot;
-    u32 waitMask = 0;
-#pragma unroll
-    for (int q = 0; q < S1P_BPT; q++) {
-      const u32 c = cq[q];
-      if (c) {
-        const u32 b = b0 + q, li = x * nBins + b, o = oq[q], in0 = o & (PG - 1);
-        tabB[b] = run | (min(c, PG - in0) << 16);
-        run += c;
-        if (o + c <= PG) {  // the list's fixed first page (the common case): nothing to look up
-          tabA[b] = (first_page(li) << SHIFT) + in0;
-        } else {
-          const u32 j0 = o >> SHIFT, j1 = (o + c - 1) >> SHIFT;
-          u32* row = PP.pt + (size_t)li * PP.jmax;
-          if (j1 != j0) (void)page_alloc(PP, row, j1, st);  // (published in the table: this thread finds it there, below)
-          if (j0 == 0)
-            tabA[b] = (first_page(li) << SHIFT) + in0;
-          else if (in0 == 0)
-            tabA[b] = page_alloc(PP, row, j0, st) << SHIFT;
-          else
-            waitMask |= 1u << q;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // (every allocation of the wavefront is published before any of its lanes waits)
-    if (waitMask) {
-#pragma unroll
-      for (int q = 0; q < S1P_BPT; q++)
-        if (waitMask & (1u << q)) {
-          const u32 b = b0 + q, li = x * nBins + b, o = oq[q];
-          tabA[b] = (page_wait(PP, PP.pt + (size_t)li * PP.jmax, o >> SHIFT, st) << SHIFT) + (o & (PG - 1));
-        }
-    }
-    __syncthreads();
-    if (GX_EXP_S1P == 2) return;
-#pragma unroll
-    for (int k = 0; k < S1P_ITEMS; k++)
-      if (rec[k] != NULL32) {
-        const u32 bin = br[k] >> 16, pos = (tabB[bin] & 0xFFFFu) + (br[k] & 0xFFFFu);
-        stage[pos] = rec[k];
-        binOf[pos] = (uint16_t)bin;
-      }
-    __syncthreads();
-    u32* pool = reinterpret_cast<u32*>(PP.pool);
-    const u32 cnt = count[0];
-#pragma unroll
-    for (int h = 0; h < S1P_ITEMS; h += 8) {
-      u32 v[8], bb[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {  // (a fixed trip count: the LDS reads of eight records in flight together)
-        const u32 i = (u32)(h + k) * S1P_NT + threadIdx.x, ii = i < cnt ? i : 0u;
-        v[k] = stage[ii];
-        bb[k] = binOf[ii];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const u32 i = (u32)(h + k) * S1P_NT + threadIdx.x;
-        const u32 ss = tabB[bb[k]], a0 = tabA[bb[k]];
-        const u32 r = i - (ss & 0xFFFFu);
-        if (i < cnt && r < (ss >> 16)) pool[a0 + r] = v[k];  // (the part of a run beyond its first page: its owner, below)
-      }
-    }
-    // the owners of the runs that cross into a second page copy that part
-#pragma unroll
-    for (int q = 0; q < S1P_BPT; q++) {
-      const u32 c = cq[q], o = oq[q];
-      if (c && ((o + c - 1) >> SHIFT) != (o >> SHIFT)) {  // rare
-        const u32 b = b0 + q, li = x * nBins + b, j1 = (o + c - 1) >> SHIFT;
-        const u32 split = PG - (o & (PG - 1)), start = tabB[b] & 0xFFFFu;
-        const u32 page = j1 < PP.jmax ? __hip_atomic_load(&PP.pt[(size_t)li * PP.jmax + j1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u : 0u;
-        for (u32 k = split; k < c; k++) pool[(page << SHIFT) + (k - split)] = stage[start + k];
-      }
-    }
-  }
-  // the slow events: loaded again (they are in L2), converted as k_sort1 converts every event, their records appended
-  // one by one
-  if (GX_EXP_S1P != 3 && __ballot(singles != 0)) {
-#pragma unroll 1
-    for (int k = 0; k < S1P_ITEMS; k++) {
-      bool mine = (singles >> k) & 1u;
-      if (!__ballot(mine)) continue;
-      u64 r0 = 0, r1 = 0;
-      u32 l0 = 0, l1 = 0;
-      bool h1 = false;
-      if (mine) {
-        const uint4 e = reinterpret_cast<const uint4*>(ev)[begin + k * S1P_NT + threadIdx.x];
-        const Endpoints p = convert_event<true>(e, chroms[min(e.x, nChrom - 1)], true, nChrom, out, bad, covered);
-        mine = p.w != 0;  // (else: an event that only raised a status bit, or one without effect)
-        if (mine) {
-        if (p.w != GX_UNIT) atomicOr(out.slowFrag, 1u);  // (a fractional weight: k_sbtile will turn the sample away)
-        r0 = make_rec64(p.t0, p.o0, p.w);
-        l0 = x * nBins + (p.t0 >> sbShift);
-        atomicAdd(&binNet[p.t0 >> sbShift], p.w);
-        h1 = p.t1 != NULL_TILE;
-        }
-        if (h1) {
-          r1 = make_rec64(p.t1, p.o1, -p.w);
-          l1 = x * nBins + (p.t1 >> sbShift);
-          atomicAdd(&binNet[p.t1 >> sbShift], -p.w);
-        }
-      }
-      append_single(PF, l0, r0, mine, st);
-      append_single(PF, l1, r1, h1, st);
-    }
-  }
-  if (bad) atomicOr(st, bad);
-  covered = wave_sum(covered);
-  if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 8 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
-}
-
 // ---- pair mode in two passes: 64 coarse bins, then 64 fine bins each --------------------------------------------
-// Measured on k_sort1p (hg38, 50 M fragments; tools/build_variant.sh -DGX_EXP_S1P): loads + conversion 0.14 ms, with the
-// reservations 0.46 ms, everything 0.59 ms -- what costs is one atomic add per (workgroup, bin) on the bins' cursors,
+// Measured in round 4 on a one-pass pair kernel (k_sort1p, since removed; hg38, 50 M fragments): loads + conversion 0.14 ms,
+// with the reservations 0.46 ms, everything 0.59 ms -- what costs is one atomic add per (workgroup, bin) on the bins' cursors,
 // 6,104 x 2,946 = 18 M of them onto 12 KB of cursors per XCD class, and what they buy are runs of 2.8 records (11 bytes).
 // Two passes with at most 64 bins each instead:
 //   k_sort_a  events -> pair records, grouped by COARSE bin (64 level-1 bins = 2^26 bases): 46 reservations per

@@ -283,9 +283,8 @@ __global__ __launch_bounds__(256) void k_pval_deep(PackIn in, const FragFix* __r
 // pileup (1902-1907; 0.0f inside an excluded region, 2248), control = lambda (SKIP inside one, 1871).  One
 // wavefront per tile, from the loose slots to the tight position.
 template <bool CTRL>
-__global__ __launch_bounds__(256) void k_piles_from_loose(PackIn in, u32 nTiles, const Scalars* __restrict__ sc,
+__global__ __launch_bounds__(256) void k_piles_from_loose(PackIn in, u32 nTiles, const float lambda,
                                                           float* __restrict__ exptOut, float* __restrict__ ctrlOut) {
-  const float lambda = sc->lambda;
   const int wv = threadIdx.x >> 6, lane = lane_id();
   for (u32 t = blockIdx.x * 4 + wv; t < nTiles; t += gridDim.x * 4) {
     const u32 src = in.meta[t].slot, dst = in.tileIvOff[t], n = in.tileIvOff[t + 1] - dst;
@@ -583,7 +582,7 @@ struct OpMinF { __device__ float operator()(float a, float b) const { return a <
 __global__ __launch_bounds__(1024) void k_qtable(const u32* __restrict__ keys, const u32* __restrict__ slots,
                                                  const u64* __restrict__ gLens, u32 D, const u64* __restrict__ genomeLenPtr,
                                                  float* __restrict__ qOfSlot, float* __restrict__ raw /* scratch [D] */,
-                                                 u32* __restrict__ allOne) {
+                                                 u32* __restrict__ allOne, u32* __restrict__ lenCheck) {
   __shared__ u64 s64[20];
   __shared__ float sf[20];
   const float logN = -log10f_host((float)*genomeLenPtr);
@@ -592,6 +591,10 @@ __global__ __launch_bounds__(1024) void k_qtable(const u32* __restrict__ keys, c
   u64 sum = 0;
   for (u32 r = r0; r < r1; r++) sum += gLens[slots[D - 1 - r]];
   u64 k = 1 + block_excl_scan_op<u64, 1024>(sum, 0ull, s64, OpAddU64());
+  // computeQval 377-382: the lengths collected with the p-values must add up to the genome length (lenCheck: the status
+  // word, when the genome length was computed and not given with -L).  With several ranks this is the table AFTER the
+  // exchange: a rank whose histogram never arrived shows up here, on every rank.
+  if (lenCheck && threadIdx.x == 1023 && k - 1 + sum != *genomeLenPtr) atomicOr(lenCheck, ST_BH_LEN);
   float mn = FLT_MAX;
   for (u32 r = r0; r < r1; r++) {
     u32 i = D - 1 - r;
@@ -651,11 +654,30 @@ __global__ __launch_bounds__(QT_NT) void k_qt_sums(const u32* __restrict__ slots
 __global__ __launch_bounds__(QT_NT) void k_qt_raw(const u32* __restrict__ keys, const u64* __restrict__ dl, u32 D,
                                                   const u64* __restrict__ genomeLenPtr, const u64* __restrict__ chunkSum,
                                                   float* __restrict__ raw /* [D] by r */, float* __restrict__ chunkMin,
-                                                  const u32* __restrict__ Dptr, const u64* __restrict__ totals, u32 world, u32 rank) {
+                                                  const u32* __restrict__ Dptr, const u64* __restrict__ totals, u32 world, u32 rank,
+                                                  u32* __restrict__ lenCheck) {
   __shared__ u64 s64[QT_NT / 64 + 4];
   __shared__ float redf[QT_NT / 64];
   __shared__ u64 pre64;
   if (Dptr) D = *Dptr;
+  // computeQval 377-382 (see k_qtable): several ranks -- the ranges' totals, which every rank holds after their exchange;
+  // one rank -- the chunks' totals (<= D / QT_CHUNK words, by the first workgroup)
+  if (lenCheck && blockIdx.x == 0) {
+    u64 all = 0;
+    if (totals)
+      for (u32 o = threadIdx.x; o < world; o += QT_NT) all += totals[o];
+    else
+      for (u32 c = threadIdx.x; c < gridDim.x; c += QT_NT) all += chunkSum[c];
+    all = wave_sum(all);
+    if (lane_id() == 0) s64[threadIdx.x >> 6] = all;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      u64 t = 0;
+      for (int w = 0; w < QT_NT / 64; w++) t += s64[w];
+      if (t != *genomeLenPtr) atomicOr(lenCheck, ST_BH_LEN);
+    }
+    __syncthreads();
+  }
   const float logN = -log10f_host((float)*genomeLenPtr);
   u64 before = 0;  // base pairs of the earlier chunks
   if (totals)

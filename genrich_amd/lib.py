@@ -50,6 +50,7 @@ _SIGS = {
     "gx_set_owned": [C.c_void_p, C.c_void_p],
     "gx_set_keep_pileups": [C.c_void_p, C.c_int],
     "gx_expect_fractional": [C.c_void_p, C.c_int],
+    "gx_set_knob": [C.c_void_p, C.c_char_p, C.c_char_p],
     "gx_set_collectives": [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p],
     "gx_rccl_unique_id": [C.c_void_p, C.c_size_t],
     "gx_set_rccl": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -199,6 +200,10 @@ class Genrich:
         """Hint: the run may hold fractional weights (Genrich's -s): pair records with a weight class from the first sample on."""
         self._check(self.lib.gx_expect_fractional(self.ctx, int(bool(on))))
 
+    def set_knob(self, name, value=1):
+        """A test / measurement switch (GX_NO_LOOSE, ...) on the live context; the environment is read once, in gx_create."""
+        self._check(self.lib.gx_set_knob(self.ctx, name.encode(), str(int(value)).encode()))
+
     def window_net(self, chrom, pos0, n):
         """The open sample's difference array on [pos0, pos0 + n) of a chromosome (1/120 units), from the events pushed so far."""
         out = np.zeros(n, dtype=np.int64)
@@ -331,7 +336,8 @@ class Genrich:
         return n.value
 
     def path_info(self):
-        """Which device path the last calls took: GX_PATH_* bits (1 fused tile stage, 2 loose-slot sweep, 4 fell back, 8 page tables grew)."""
+        """Which device path the last calls took: GX_PATH_* bits (1 fused tile stage, 2 loose-slot sweep, 4 fell back, 8 page tables grew,
+        16 pair records, 32 dense BH all-reduce, 64 range BH exchange, 128 fractional pair records, 256 pileup floats written)."""
         f = C.c_uint(0)
         self._check(self.lib.gx_path_info(self.ctx, C.byref(f)))
         return f.value

@@ -278,6 +278,11 @@ int gx_phase_times(gx_ctx* ctx, const char** names, const float** ms);
  * writes its pair records with a weight class from the start; without the hint the first sample that shows a fractional
  * weight is built a second time, on the general chain (same results either way). */
 int gx_expect_fractional(gx_ctx* ctx, int on);
+/* Test and measurement switches (the GX_* names of DESIGN.md's knob table: GX_NO_FUSED, GX_NO_LOOSE, GX_SBSHIFT, ...).  The
+ * library reads them from the environment once, in gx_create; this sets one on a live context (bench.py times the
+ * "materialised" step that way).  value: a number as text; NULL or "" = 1.  An unknown name is GX_ERR_ORDER.  Not part of
+ * what a host program needs: every switch only forces a path that the default run chooses by itself. */
+int gx_set_knob(gx_ctx* ctx, const char* name, const char* value);
 /* Which device path the last calls took (tests assert that the fast paths really run):
  * bit 0: the last sample's tile stage was k_sbtile (level 2 of the sort fused with the tile passes, gx_sbtile.h);
  * bit 1: the last gx_find_peaks swept the tile stage's loose slots (no k_pack_pval, gx_kernels.h LooseCtl);
@@ -292,6 +297,8 @@ int gx_expect_fractional(gx_ctx* ctx, int on);
 #define GX_PATH_PAIRS 16u    /* bit 4: level 1 of the sort wrote one record per fragment (k_sort_a / k_sort_b) for the fused kernel */
 #define GX_PATH_RANGE_BH 64u /* bit 6: several ranks with a control / replicates, -q: the range-partitioned BH exchange */
 #define GX_PATH_DENSE_BH 32u /* bit 5: several ranks, no control, -q: the p-value histogram travelled as ONE dense all-reduce */
+#define GX_PATH_PILES_MADE 256u /* bit 8: pileup floats (Pileup.cov, printed by -f / -k only) were written since the last gx_reset */
+#define GX_PATH_FRAC_PAIRS 128u /* bit 7: ... and the pair records carried a weight class (k_sort_a<FRAC> / k_sbtile<.., FRAC>: -s multimapping) */
 int gx_path_info(gx_ctx* ctx, unsigned* flags);
 
 /* Evaluate one scalar device function on n inputs (numerics tests):

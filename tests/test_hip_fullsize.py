@@ -151,41 +151,54 @@ def test_midsize_slice_against_oracle():
 # (configs[2] control + -q, configs[3] ATAC geometry + -s multimapping weights, configs[4] three replicates + Fisher + -q;
 #  savePileupCtrl Genrich.c:2052-2161, saveFragAtac 2728-2749 + addFrac / subFrac 2311-2488, combinePval 612-667)
 
-def _whole_genome_against_oracle(case, params, min_peaks):
+def _whole_genome_against_oracle(case, params, min_peaks, setups=(None,)):
+    """One oracle run, and one run of the HIP library per entry of `setups` (a function that prepares the fresh context --
+    a hint, a switch -- or None): everything of every run against the oracle.  Returns the runs' gx_path_info flags."""
     import genrich_amd
     o = B.Oracle(params)
     so = B.run_case(o, case)
-    h = genrich_amd.Genrich(params)
-    sh = B.run_case(h, case)
-    for k, ((fo, lo, co), (fh, lh, ch)) in enumerate(zip(so, sh)):
-        # fragLen: the device's sum is the exact sum of the reference's float products, rounded once, and is compared bit
-        # for bit with the oracle's exact sum; the reference's own double accumulation rounds at some of its additions once
-        # the sum has passed 2^26 (fractional weights only) -- counted by the oracle, half a unit in the last place each
-        # (DESIGN.md section 2).  lambda, the float that everything downstream uses, must be the same bits.
-        B.assert_fraglen(o, k, fo, fh)
-        assert np.float32(lo).tobytes() == np.float32(lh).tobytes()
-        if co is not None:
-            assert np.float32(co).tobytes() == np.float32(ch).tobytes()
-    po, ph = o.get_peaks(), h.get_peaks()
-    assert len(po) == len(ph) >= min_peaks, (len(po), len(ph))
-    assert po.tobytes() == ph.tobytes(), "peak lists differ"
-    assert o.peak_bp == h.peak_bp
+    po = o.get_peaks()
     nrep = len(case["replicates"])
+    whiches = [-1] + (list(range(nrep)) if nrep > 1 else [])
+    runs = []
+    for setup in setups:
+        h = genrich_amd.Genrich(params)
+        if setup is not None:
+            setup(h)
+        sh = B.run_case(h, case)
+        flags = h.path_info()
+        for k, ((fo, lo, co), (fh, lh, ch)) in enumerate(zip(so, sh)):
+            # fragLen: the device's sum is the exact sum of the reference's float products, rounded once, and is compared bit
+            # for bit with the oracle's exact sum; the reference's own double accumulation rounds at some of its additions once
+            # the sum has passed 2^26 (fractional weights only) -- counted by the oracle, half a unit in the last place each
+            # (DESIGN.md section 2).  lambda, the float that everything downstream uses, must be the same bits.
+            B.assert_fraglen(o, k, fo, fh)
+            assert np.float32(lo).tobytes() == np.float32(lh).tobytes()
+            if co is not None:
+                assert np.float32(co).tobytes() == np.float32(ch).tobytes()
+        ph = h.get_peaks()
+        assert len(po) == len(ph) >= min_peaks, (len(po), len(ph))
+        assert po.tobytes() == ph.tobytes(), "peak lists differ"
+        assert o.peak_bp == h.peak_bp
+        runs.append((h, flags))
     total = 0
-    for which in [-1] + (list(range(nrep)) if nrep > 1 else []):
+    for which in whiches:
         for c in range(len(LENS)):
-            eo, co = o.get_intervals(which, c)
-            eh, ch = h.get_intervals(which, c, piles=False)
-            assert np.array_equal(eo, eh), f"interval ends differ on contig {c} (array {which})"
-            for k in ("p", "q"):
-                assert np.array_equal(co[k].view(np.uint32), ch[k].view(np.uint32)), f"{k} differs on contig {c} (array {which})"
+            eo, co = o.get_intervals(which, c)   # (one contig of the oracle's table at a time, against every run)
+            for h, _ in runs:
+                eh, ch = h.get_intervals(which, c, piles=False)
+                assert np.array_equal(eo, eh), f"interval ends differ on contig {c} (array {which})"
+                for k in ("p", "q"):
+                    assert np.array_equal(co[k].view(np.uint32), ch[k].view(np.uint32)), f"{k} differs on contig {c} (array {which})"
             if which == -1:
                 total += len(eo)
-    assert total == h.interval_total()
-    flags = h.path_info()
+    out = []
+    for h, flags in runs:
+        assert total == h.interval_total()
+        h.close()
+        out.append(flags)
     o.close()
-    h.close()
-    return flags
+    return out[0] if len(out) == 1 else out
 
 
 def test_fullsize_config3_control_and_q_is_the_oracles_bytes():
@@ -199,12 +212,18 @@ def test_fullsize_config3_control_and_q_is_the_oracles_bytes():
 
 
 def test_fullsize_config4_atac_multimap_is_the_oracles_bytes():
+    """BASELINE.json configs[3] on BOTH of its device paths, against one oracle run: (1) as `genrich-amd -s` and bench.py run
+    it -- the library is told that fractional weights may come (gx_expect_fractional), the first sample already leaves level 1
+    as pair records with a weight class and goes through k_sbtile<.., FRAC>: THE PATH bench.py TIMES; (2) without the hint:
+    the unit-weight level 1 meets a fractional weight, gives the sample up (ST_SB_FRAC) and the general chain builds it."""
     ev = synth.make_fragments(LENS, 50_000_000, seed=1)
     ev = synth.atac_events(synth.add_multimap(ev, LENS, 0.10, seed=11), LENS, d=100)
     case = dict(lens=LENS, replicates=[dict(save=None, treat=ev, ctrl=None)])
-    flags = _whole_genome_against_oracle(case, B.make_params(pq=0.01), 10_000)
-    # (2 x 10^8 events are more than the fused tile stage is even tried on: straight to the general chain)
-    assert not flags & 1, "fractional weights take the general chain"
+    hinted, plain = _whole_genome_against_oracle(case, B.make_params(pq=0.01), 10_000,
+                                                 setups=(lambda h: h.expect_fractional(True), None))
+    assert hinted & 1 and hinted & 16 and hinted & 128, "the hinted run is the fused tile stage on fractional pair records"
+    assert not hinted & 4, "... from the first sample on: nothing was sent back"
+    assert not plain & 1 and plain & 4, "without the hint the first fractional weight sends the sample to the general chain"
 
 
 def test_fullsize_config5_three_replicates_fisher_q_is_the_oracles_bytes():

@@ -134,6 +134,60 @@ def test_two_ranks_equal_one_rank(name, world):
     assert merged.tobytes() == peaks1.tobytes(), "sharded peaks (coordinates, AUC, p, q) differ from the single-rank run"
 
 
+def _withholding_worker(rank, world, port, q):
+    """Rank 1 takes part in every exchange but contributes nothing to the big one (the dense p-value histogram)."""
+    import torch.distributed as dist
+
+    import genrich_amd
+    from genrich_amd.dist import Collectives, lpt_partition
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    params, reps = _scenario("noctrl_q")
+    owner = lpt_partition(LENS, world)
+    owned = np.array([o == rank for o in owner], dtype=np.uint8)
+    gx = genrich_amd.Genrich(params)
+    gx.set_chroms(LENS)
+    gx.set_owned(owned)
+    coll = Collectives(device="cpu")
+
+    def allreduce(buf, n, user):
+        if rank == 1 and n > 4096:
+            np.ctypeslib.as_array(buf, shape=(n,))[:] = 0   # "lost": this rank's histogram never arrives
+        return coll.allreduce_i64(buf, n, user)
+
+    gx.set_collectives(rank, world, allreduce, None)
+    try:
+        _run(gx, reps, owned)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.destroy_process_group()
+
+
+def test_a_rank_whose_histogram_is_lost_fails_every_rank():
+    """computeQval 377-382: the lengths collected with the p-values must add up to the genome length.  On N ranks that is
+    checked on the table AFTER the exchange: a rank whose contribution never arrived would otherwise leave plausible, wrong
+    q-values behind.  Every rank must return GX_ERR_PVAL."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_withholding_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, msg in res:
+        assert "error -8" in msg and "does not match p-value length" in msg, (rank, msg)
+
+
 @pytest.mark.parametrize("name", ["ctrl_q", "reps3_q", "plain_p", "noctrl_q"])
 def test_rccl_path_with_one_rank(name, monkeypatch):
     """gx_set_rccl + GX_FORCE_COLL=1: the all-reduce of the fragLen words and the all-gather of the BH

@@ -13,7 +13,7 @@ from test_hip_parity import assert_same_run, hip_backend
 
 pytestmark = pytest.mark.gpu
 
-FUSED, LOOSE, FELL_BACK, PT_GREW = 1, 2, 4, 8
+FUSED, LOOSE, FELL_BACK, PT_GREW, PAIRS, FRAC_PAIRS, PILES_MADE = 1, 2, 4, 8, 16, 128, 256
 
 
 def _case(seed=11, n=90_000, lens=(400_000, 123_457, 16_384, 4_097, 5), **kw):
@@ -247,3 +247,92 @@ def test_half_size_bins_and_the_128_key_level_1(monkeypatch, frac):
     flags = h.path_info()
     assert_same_run(o, h, so, sh, case)
     assert flags & FUSED and flags & 16
+
+
+def test_replicates_keep_their_exact_pileups_until_somebody_asks():
+    """Three replicates without control, Fisher, -q (combinePval Genrich.c:612-667): a replicate's pileup floats -- the
+    reference's Pileup.cov, which only -f / -k print -- are not written when the next replicate reuses the loose slots;
+    the replicate keeps its exact pileups instead and the floats are made when somebody asks, here after the peaks
+    are out.  They must be the bits a single-sample run of that replicate gives (there the oracle has them)."""
+    lens = [300_000, 120_000, 4_097]
+    reps = [dict(save=None, treat=synth.make_fragments(lens, 60_000, 100 + r, peak_every=25_000, tower_every=110_000), ctrl=None)
+            for r in range(3)]
+    case = dict(lens=lens, replicates=reps)
+    params = B.make_params(pq=0.05, qval=True, min_auc=20.0)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    sh = B.run_case(h, case)
+    assert not h.path_info() & PILES_MADE, "no pileup float was written on the way to the peaks"
+    assert_same_run(o, h, so, sh, case)      # (ends / p / q of every array, the peaks: asks for no pileups of a replicate)
+    for r, rep in enumerate(reps):
+        o1 = B.Oracle(params)
+        B.run_case(o1, dict(lens=lens, replicates=[rep]))
+        for c in range(len(lens)):
+            e1, c1 = o1.get_intervals(-1, c)
+            eh, ch = h.get_intervals(r, c)   # the late request: from what the replicate kept
+            assert np.array_equal(e1, eh)
+            assert np.array_equal(c1["expt"].view(np.uint32), ch["expt"].view(np.uint32)), (r, c)
+            assert np.array_equal(c1["ctrl"].view(np.uint32), ch["ctrl"].view(np.uint32)), (r, c)
+        o1.close()
+    assert h.path_info() & PILES_MADE
+    h.reset()                                 # the kept buffers go back to the pool: a second run of the same context
+    sh = B.run_case(h, case)
+    assert_same_run(o, h, so, sh, case)
+    assert not h.path_info() & PILES_MADE
+
+
+def test_switches_are_read_when_the_context_is_made_and_can_be_set_on_it(monkeypatch):
+    """The GX_* test switches are parsed once, in gx_create; gx_set_knob changes one on a live context (bench.py's
+    `materialised` loop).  Both routes must give the oracle's bits and say which path ran."""
+    case = _case(seed=21, n=60_000)
+    params = B.make_params(pq=0.01, min_auc=50.0)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    sh = B.run_case(h, case)
+    assert h.path_info() & LOOSE
+    monkeypatch.setenv("GX_NO_LOOSE", "1")     # (too late for this context: it was read when the context was made)
+    h.reset()
+    sh = B.run_case(h, case)
+    assert h.path_info() & LOOSE
+    h.set_knob("GX_NO_LOOSE", 1)
+    h.reset()
+    sh = B.run_case(h, case)
+    assert not h.path_info() & LOOSE
+    assert_same_run(o, h, so, sh, case)
+    h.set_knob("GX_NO_LOOSE", 0)
+    h.reset()
+    sh = B.run_case(h, case)
+    assert h.path_info() & LOOSE
+    assert_same_run(o, h, so, sh, case)
+    with pytest.raises(RuntimeError):
+        h.set_knob("GX_NO_SUCH_SWITCH", 1)
+    h2 = hip_backend(params)                   # a new context sees the environment
+    sh = B.run_case(h2, case)
+    assert not h2.path_info() & LOOSE
+    assert_same_run(o, h2, so, sh, case)
+
+
+def test_a_pileup_that_does_not_return_to_zero_is_an_error(monkeypatch):
+    """savePileupExpt 2283-2289: behind a chromosome's last base the difference array must be back at zero ("finishes at
+    %f (not 0.0)").  On the device: the closing interval of a chromosome's last tile may only hold the fragments that end
+    at the chromosome's length (they have no end record) -- checked by the scan over the tiles, GX_ERR_ARR otherwise.
+    A healthy sample with fragments that reach the end passes; with the weight of those ends damaged behind level 1 of the
+    sort (GX_FAULT=1: as if a record had been lost) every tile-stage variant must refuse the sample."""
+    lens = [150_000]
+    ev = synth.make_fragments(lens, 30_000, 3, peak_every=20_000)
+    tail = np.array([(0, lens[0] - 180 - 3 * k, lens[0], 1) for k in range(40)], dtype=B.EVENT_DTYPE)  # 40 fragments end at len
+    case = dict(lens=lens, replicates=[dict(save=None, treat=np.concatenate([ev, tail]), ctrl=None)])
+    params = B.make_params(pq=0.01, min_auc=50.0)
+    _run(case, params)                                    # healthy: the oracle's bits, no error
+    monkeypatch.setenv("GX_FAULT", "1")
+    for knobs in ({}, {"GX_NO_PAIRS": "1"}, {"GX_NO_FUSED": "1"}):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        h = hip_backend(params)
+        with pytest.raises(RuntimeError, match="return to 0"):
+            B.run_case(h, case)
+        h.close()
+        for k in knobs:
+            monkeypatch.delenv(k)

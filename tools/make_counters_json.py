@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 runs of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the tracked summaries
-under profiles/:  <tag>_config<C>_kernel_stats.txt, <tag>_config<C>_pmc.txt and r04_counters_config<C>.json (what bench.py's
+under profiles/:  <tag>_config<C>_kernel_stats.txt, <tag>_config<C>_pmc.txt and <tag>_counters_config<C>.json (what bench.py's
 `roofline` object reads; it carries the hash of the kernel sources it was measured on).
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB = 1024 B): on gfx950 FETCH_SIZE tallies the 128-byte
@@ -145,7 +145,7 @@ def main():
             if sq.get("SQ_LDS_IDX_ACTIVE") else None,
             "raw": sq,
         }
-    json.dump(out, open(os.path.join(OUT, f"r04_counters_config{cfg}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(OUT, f"{tag}_counters_config{cfg}.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1)[:3000])
 
 
