@@ -54,11 +54,24 @@ constexpr int SBT_KX = 16;                             // ... and slots per wave
 static_assert(SBT_KX <= 2 * SBT_K && SBT_KP <= SBT_KX, "the slot tables hold 2 x SBT_K x SBT_NW descriptors");
 constexpr u32 SBT_SLOT = 256;                          // keys per slot
 constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K keys)
-constexpr u32 SBT_KEYCAP = 57344;                      // keys of a super-bucket (both streams) that fit the LDS
+#ifndef GX_SBT_TR
+#define GX_SBT_TR 448
+#endif
+// keys of a super-bucket (both streams) that fit the LDS: what the 160 KiB leave once the wavefronts' scratch is taken
+// (SBT_TR touched bases per round: 6 bytes each and wavefront)
+// = (160 KiB - 13,120 bytes of tables - 16 wavefronts x (800 + 6 SBT_TR) bytes of scratch) / 2 - 192 keys of slack, in whole K
+constexpr u32 SBT_KEYCAP = ((163840u - 13120u - 16u * (800u + 6u * GX_SBT_TR)) / 2u - 192u) / 1024u * 1024u;
 constexpr u32 SBT_HEAVY = 4096;                        // keys from which a tile is the whole workgroup's (a counter per base), not one wavefront's
 constexpr int SBT_MAXR = 8;                            // pair mode: rounds of a super-bucket whose keys do not fit the LDS at once
 constexpr u32 SBT_FCAP = 16384;                        // pair mode: singles of a super-bucket (read where they lie, twice)
-constexpr int SBT_TR = 192;                            // touched bases per round of a tile's passes (k_tile_fast: TR_CAP)
+// Touched bases per round of a tile's passes.  A round walks ALL keys of the tile (rank, range check, counter) and then
+// the round's touched bases in steps of 64; a tile with more touched bases than SBT_TR takes several rounds.  192 (round
+// 3, k_tile_fast's TR_CAP) fits the ordinary tile -- but a tile with a peak on it (hg38 / 50 M fragments: one tile in
+// twelve, ~575 keys on ~400 bases, at most 459; an ATAC sample: every tile) then pays three rounds -- 4.06 passes over a
+// tile's keys on average instead of 2.65 (counted on the bench's stream).  448 covers them in one; the price is LDS
+// (6 bytes per base and wavefront), taken from the key array: 47 K keys instead of 57 K (a bin of that sample holds 34 K,
+// the fullest 37 K; fuller bins are the second launch's, as before).
+constexpr int SBT_TR = GX_SBT_TR;
 // a wavefront's scratch, in words: occupancy bitmap (+ a dummy word that absorbs the lanes without a key), the words'
 // prefix counts (+ a dummy entry that ranks those lanes out of every round), counters and offsets by rank
 constexpr int SBT_OCCW = TILE / 32 + 4, SBT_PREW = TILE / 64 + 4;
@@ -91,6 +104,8 @@ struct SbtLds {
   int netW[SBT_TILES];                     // fractional pairs: weight (1/120) a tile hands on (ends it receives count negative)
   u32 vsRed[2];                            // loose_vsig's reduction words (its own: tid 0 initialises the others right after)
 };
+
+static_assert(sizeof(SbtLds) <= 160 * 1024, "k_sbtile's LDS: one workgroup per CU");
 
 struct SbtIn {
   PagedStream PS, PE;         // (pair mode: PS = the pair records' lists, PE unused)
@@ -127,8 +142,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // 32-bit byte offsets against a uniform base pointer: one shift instead of 64-bit address arithmetic per store
-#ifndef GX_SBT_KNOBS   // measurement knobs (tools/build_variant.sh): 1 exchange-and-clear, 2 32-bit store offsets, 4 unpredicated key loads
-#define GX_SBT_KNOBS 7
+#ifndef GX_SBT_KNOBS   // measurement knobs (tools/build_variant.sh): 1 exchange-and-clear, 2 32-bit store offsets, 4 unpredicated key loads,
+#define GX_SBT_KNOBS 15   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off)
 #endif
 __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
 #if GX_SBT_KNOBS & 2
@@ -175,10 +190,18 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   const u64 activeM = active ? ~0ull : 0ull;
   const u32 negPos0 = 0u - pos0;   // (pos0 + p != 0  <=>  p != -pos0)
   const bool lastTile = (flags & TM_LAST) != 0;
-  constexpr int KR = 3;  // keys per lane kept in registers (192 per tile; a tile of config 2 holds ~135)
+  constexpr int KR = 3;  // keys per lane kept in registers (192 per tile)
+  // (n is wave-uniform -- the caller hands it over in a scalar register: an ordinary tile of hg38 / 50 M fragments holds ~90
+  // keys, so the third register-held key is all "no key" there and its three passes are skipped by scalar branches)
+#if GX_SBT_KNOBS & 8
+  const bool third = n > 128u;
+#else
+  constexpr bool third = true;
+#endif
   u32 kr[KR];
 #pragma unroll
   for (int q = 0; q < KR; q++) {
+    if (q == 2 && !third) { kr[q] = NOKEY; continue; }
 #if GX_SBT_KNOBS & 4
     const u32 v = kl[lane + q * 64];  // (in bounds: the key array has 192 entries of slack)
     kr[q] = (u32)lane + q * 64 < n ? v : NOKEY;
@@ -193,8 +216,9 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   // serialise -- measured 0.71 -> 0.81 ms for the kernel)
 #pragma unroll
   for (int q = 0; q < KR; q++)
-    if (kr[q] != NOKEY) mark(kr[q]);
-  for (u32 k = KR * 64 + lane; k < n; k += 64) mark(kl[k]);
+    if ((q < 2 || third) && kr[q] != NOKEY) mark(kr[q]);
+  if (third)
+    for (u32 k = KR * 64 + lane; k < n; k += 64) mark(kl[k]);
   wave_lds_sync();
   // ---- B: touched bases before each bitmap word
   const uint2 ww = *reinterpret_cast<const uint2*>(occ + 2 * lane);
@@ -214,7 +238,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   };
   u32 rr[KR];
 #pragma unroll
-  for (int q = 0; q < KR; q++) rr[q] = rankOf(kr[q]);
+  for (int q = 0; q < KR; q++) rr[q] = (q < 2 || third) ? rankOf(kr[q]) : 0xFFFFu;
   for (u32 r0 = 0; r0 < T; r0 += TR_CAP) {
     if (r0) wave_lds_sync();
     // ---- A2: keys -> cnt[rank], list[rank]
@@ -226,11 +250,13 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
       }
     };
 #pragma unroll
-    for (int q = 0; q < KR; q++) put(rr[q], kr[q]);
-    for (u32 k = KR * 64 + lane; k < n; k += 64) {
-      const u32 key = kl[k];
-      put(rankOf(key), key);
-    }
+    for (int q = 0; q < KR; q++)
+      if (q < 2 || third) put(rr[q], kr[q]);
+    if (third)
+      for (u32 k = KR * 64 + lane; k < n; k += 64) {
+        const u32 key = kl[k];
+        put(rankOf(key), key);
+      }
     wave_lds_sync();
     // ---- C: 64 touched bases per step (whole wavefronts: the counters behind the last touched base are zero)
     const u32 nL = min((u32)TR_CAP, T - r0);
@@ -733,14 +759,21 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   };
   // the wavefronts take the tiles [L.work .. tileEnd) from a counter; keyBase: where the first key in LDS lies in the bin's order
   auto tiles = [&](u32 tileEnd, u32 keyBase) {
-    for (;;) {
+    // (BIG: the rounds' tiles come from the counter, which a round sets to its first tile; the ordinary launch deals them
+    // to the sixteen wavefronts in turn: no atomic, no wait, no readfirstlane per tile)
+    constexpr bool STATIC_DEAL = !BIG && (GX_SBT_KNOBS & 16) != 0;
+    for (u32 it = 0;; it++) {
       u32 b = 0;
-      if (lane == 0) b = atomicAdd(&L.work, 1u);
-      b = (u32)__builtin_amdgcn_readfirstlane((int)b);
+      if constexpr (STATIC_DEAL)
+        b = (u32)__builtin_amdgcn_readfirstlane(wv) + it * (u32)SBT_NW;
+      else {
+        if (lane == 0) b = atomicAdd(&L.work, 1u);
+        b = (u32)__builtin_amdgcn_readfirstlane((int)b);
+      }
       if (b >= tileEnd) break;
       const u32 t = segTileBase + b;
       if (t >= in.nTiles) continue;
-      const u32 h = L.hist[b], n = (h & 0xFFFFu) + (h >> 16);
+      const u32 h = (u32)__builtin_amdgcn_readfirstlane((int)L.hist[b]), n = (h & 0xFFFFu) + (h >> 16);
       if (BIG && n > SBT_HEAVY) {  // wave-uniform: left to the whole workgroup
         if (lane == 0) L.heavy[atomicAdd(&L.nHeavy, 1u)] = (uint16_t)b;
         continue;

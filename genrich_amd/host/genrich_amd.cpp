@@ -761,7 +761,7 @@ struct DupDevice {
   std::vector<gx_dup_key> keys;
   std::vector<uint8_t> multi;
   std::vector<uint32_t> owner, readOf;   // per record: gx_dups_first's word; the set (or addition) it belongs to
-  uint64_t nKeys = 0, nContested = 0;
+  uint64_t nKeys = 0, nContested = 0, nByTable[4] = {0, 0, 0, 0};   // (by the key's tag: 1 proper pairs, 2 discordant, 3 singletons)
   void clear() { keys.clear(); multi.clear(); owner.clear(); readOf.clear(); }
   void push(uint32_t tag, uint32_t a, uint32_t b, uint32_t c, bool m, uint32_t read) {
     keys.push_back(gx_dup_key{{tag, a, b, c}});
@@ -796,6 +796,7 @@ void findDups(State& S, DupReads& D, Counts& C) {
     if (!dev.keys.empty())
       check(S, gx_dups_first(S.devs.ctx[0], dev.keys.data(), dev.multi.data(), dev.keys.size(), dev.owner.data()), S.devs.ctx[0]);
     dev.nKeys += dev.keys.size();
+    if (!dev.keys.empty()) dev.nByTable[dev.keys[0].w[0] & 3u] += dev.keys.size();
     for (uint32_t w : dev.owner) dev.nContested += (w & DUP_CONTESTED) != 0;
   };
 
@@ -853,7 +854,9 @@ void findDups(State& S, DupReads& D, Counts& C) {
   }
   if (!S.o.singleOpt) {
     if (dev.on && getenv("GENRICH_DUPS_REPORT"))
-      fprintf(stderr, "[dups] device: %llu keys, %llu contested (resolved on the host)\n", (unsigned long long)dev.nKeys, (unsigned long long)dev.nContested);
+      fprintf(stderr, "[dups] device: %llu keys, %llu contested (resolved on the host); by table: %llu paired, %llu discordant, %llu single\n",
+            (unsigned long long)dev.nKeys, (unsigned long long)dev.nContested, (unsigned long long)dev.nByTable[1],
+            (unsigned long long)dev.nByTable[2], (unsigned long long)dev.nByTable[3]);
     return;
   }
 
@@ -875,11 +878,66 @@ void findDups(State& S, DupReads& D, Counts& C) {
   std::vector<Unpair> none;
 
   {  // discordant sets (findDupsDc 3761): every R1 x R2 combination, either order
-    std::unordered_map<KeyDc, std::string, KeyHash> tab;
+    std::unordered_map<KeyDc, std::string, KeyHash> tab;   // (device mode: the contested keys only)
     auto end5 = [](const Aln& a) { return a.strand ? a.pos[0] : a.pos[1]; };
-    for (uint32_t i : order(D.dc)) {
-      DRead& r = D.dc[i];
+    const std::vector<uint32_t> ord = order(D.dc);
+    // Device mode: the reference looks a combination up in both orders and stores it in one (3786-3837), i.e. the table is
+    // keyed on the UNORDERED pair of ends -- one record per combination with the two ends in a canonical order.  The
+    // chromosomes share a word: genomes of more than 65,536 sequences keep the host's tables.
+    const bool dcDev = dev.on && S.chrom.size() <= 65536;
+    std::vector<uint32_t> firstRec;
+    auto canon = [&](const Aln& a, const Aln& b, uint32_t w[4]) {
+      const uint32_t pa = end5(a), pb = end5(b);
+      const bool swap = std::make_tuple(b.chrom, pb, (int)b.strand) < std::make_tuple(a.chrom, pa, (int)a.strand);
+      const Aln &x = swap ? b : a, &y = swap ? a : b;
+      w[0] = 2u | ((uint32_t)x.strand << 8) | ((uint32_t)y.strand << 9);
+      w[1] = (uint32_t)x.chrom | ((uint32_t)y.chrom << 16);
+      w[2] = swap ? pb : pa;
+      w[3] = swap ? pa : pb;
+    };
+    if (dcDev) {
+      firstRec.resize(ord.size() + 1);
+      for (size_t q = 0; q < ord.size(); q++) {
+        const DRead& r = D.dc[ord[q]];
+        firstRec[q] = (uint32_t)dev.keys.size();
+        const bool multi = r.aln.size() * r.alnR2.size() > 1;
+        for (auto& a : r.aln)
+          for (auto& b : r.alnR2) {
+            uint32_t w[4];
+            canon(a, b, w);
+            dev.keys.push_back(gx_dup_key{{w[0], w[1], w[2], w[3]}});
+            dev.multi.push_back(multi ? 1 : 0);
+            dev.readOf.push_back(ord[q]);
+          }
+      }
+      firstRec[ord.size()] = (uint32_t)dev.keys.size();
+      runDevice();
+    }
+    for (size_t q = 0; q < ord.size(); q++) {
+      DRead& r = D.dc[ord[q]];
       bool dup = false;
+      const bool byDevice = dcDev && r.aln.size() == 1 && r.alnR2.size() == 1 && !(dev.owner[firstRec[q]] & DUP_CONTESTED);
+      if (byDevice) {
+        const uint32_t me = firstRec[q], own = dev.owner[me];
+        if (own != me) {
+          // (an uncontested key: its first holder is a set of one combination too, stored as (its R1, its R2); the
+          // reference finds it in the order of this set's ends first, in the swapped order otherwise -- 3786 / 3812)
+          const DRead& hr = D.dc[dev.readOf[own]];
+          const Aln &a = r.aln[0], &b = r.alnR2[0], &ha = hr.aln[0], &hb = hr.alnR2[0];
+          const uint32_t pos = end5(a), pos1 = end5(b);
+          const bool sameOrder = ha.chrom == a.chrom && hb.chrom == b.chrom && end5(ha) == pos && end5(hb) == pos1 &&
+                                 ha.strand == a.strand && hb.strand == b.strand;
+          if (verb) {
+            if (sameOrder)
+              dupLine(S, "%s\t%s:%d,%c;%s:%d,%c\t%s\tdiscordant\n", r.name.c_str(), S.chrom[a.chrom].name.c_str(), pos,
+                      a.strand ? '+' : '-', S.chrom[b.chrom].name.c_str(), pos1, b.strand ? '+' : '-', hr.name.c_str());
+            else
+              dupLine(S, "%s\t%s:%d,%c;%s:%d,%c\t%s\tdiscordant\n", r.name.c_str(), S.chrom[b.chrom].name.c_str(), pos1,
+                      b.strand ? '+' : '-', S.chrom[a.chrom].name.c_str(), pos, a.strand ? '+' : '-', hr.name.c_str());
+          }
+          dup = true;
+        }
+      } else
       for (size_t k = 0; k < r.aln.size() && !dup; k++) {
         const Aln& a = r.aln[k];
         const uint32_t pos = end5(a);
@@ -906,7 +964,7 @@ void findDups(State& S, DupReads& D, Counts& C) {
         for (size_t k = 0; k < r.aln.size(); k++)
           for (size_t j = 0; j < r.alnR2.size(); j++) {
             const Aln &a = r.aln[k], &b = r.alnR2[j];
-            tab.emplace(KeyDc{a.chrom, b.chrom, end5(a), end5(b), a.strand, b.strand}, verb ? r.name : std::string());
+            if (!byDevice) tab.emplace(KeyDc{a.chrom, b.chrom, end5(a), end5(b), a.strand, b.strand}, verb ? r.name : std::string());
             if (useSn) {
               if (!j) addSn(a.chrom, end5(a), a.strand, r.name);
               if (!k) addSn(b.chrom, end5(b), b.strand, r.name);
@@ -919,6 +977,7 @@ void findDups(State& S, DupReads& D, Counts& C) {
     }
     D.dc.clear();
     D.dc.shrink_to_fit();
+    dev.clear();
   }
 
   {  // singletons (findDupsSn 3886): the table already holds the ends of the kept pairs
@@ -980,7 +1039,9 @@ void findDups(State& S, DupReads& D, Counts& C) {
     dev.clear();
   }
   if (dev.on && getenv("GENRICH_DUPS_REPORT"))
-    fprintf(stderr, "[dups] device: %llu keys, %llu contested (resolved on the host)\n", (unsigned long long)dev.nKeys, (unsigned long long)dev.nContested);
+    fprintf(stderr, "[dups] device: %llu keys, %llu contested (resolved on the host); by table: %llu paired, %llu discordant, %llu single\n",
+            (unsigned long long)dev.nKeys, (unsigned long long)dev.nContested, (unsigned long long)dev.nByTable[1],
+            (unsigned long long)dev.nByTable[2], (unsigned long long)dev.nByTable[3]);
   S.o = saved;
 }
 

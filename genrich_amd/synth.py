@@ -321,3 +321,95 @@ def write_sam_dups(path, names, lens, ev, seed, read_len=50, name_prefix="d", ba
         raw += struct.pack("<i", len(body)) + body
     with gzip.GzipFile(path, "wb", mtime=0) as g:
         g.write(bytes(raw))
+
+
+# ---- -r at size: 10^6 .. 10^7 alignments, vectorised (write_sam_dups above walks a Python loop per record) ----------
+# 28-byte records, the input of tools/records_to_sam (which renders them as SAM text)
+REC_DTYPE = np.dtype([("tmpl", "<u4"), ("flag", "<u2"), ("chrom", "<i2"), ("pos", "<i4"), ("rnext", "<i2"), ("rl", "u1"),
+                      ("qual", "u1"), ("pnext", "<i4"), ("tlen", "<i4"), ("AS", "i1"), ("mapq", "u1"), ("pad", "<u2")])
+
+
+def make_dups_records(lens, n_templates, seed, dup_frac=0.2, read_len=50):
+    """Queryname-grouped alignment records for -r (PCR duplicates, Genrich.c:3267-4042) at size: proper pairs (55 %), proper
+    pairs with a secondary pair elsewhere (10 %: multi-alignment sets), singletons with the mate unmapped (15 %), discordant
+    pairs (20 %, possibly on two chromosomes).  `dup_frac` of the templates take the coordinates of an earlier template --
+    pairs and singletons from one pool (a singleton can duplicate an end of a kept pair: checkAndAdd 3514), discordant
+    pairs from their own, with the mates swapped half of the time (findDupsDc looks both orders up).  Every read has its own
+    base quality (one Phred value on all bases; 5 % have none): the quality sums decide which copy of a set is kept."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(n_templates)
+    lens = np.asarray(lens, dtype=np.int64)
+    kind = rng.choice(4, n, p=[0.55, 0.10, 0.15, 0.20])          # 0 pair, 1 pair + secondary pair, 2 singleton, 3 discordant
+    chrom = rng.choice(len(lens), n, p=lens / lens.sum())
+    flen = 100 + rng.integers(0, 100, n) + rng.integers(0, 100, n)
+    start = (rng.random(n) * np.maximum(1, lens[chrom] - flen - 2100)).astype(np.int64)
+    # a quarter of the templates within ~+-150 bp of a centre every 100 kb (peaks for the caller to find once the copies are gone)
+    near = rng.random(n) < 0.25
+    centre = (rng.integers(0, 1 << 30, n) % np.maximum(1, (lens[chrom] - 4000) // 100_000)) * 100_000 + 50_000
+    start = np.where(near, np.clip(centre + rng.normal(0, 70, n).astype(np.int64) - flen // 2, 0, lens[chrom] - flen - 2100), start)
+    end = start + flen
+    dup = rng.random(n) < dup_frac
+    pick = rng.random(n)
+
+    def sources(members):
+        """For the templates `members` (indices, ascending): the member whose coordinates each one ends up with."""
+        k = np.arange(len(members))
+        src = np.where(dup[members] & (k > 0), (pick[members] * k).astype(np.int64), k)
+        for _ in range(40):   # (pointer jumping: a copy of a copy of ...)
+            nxt = src[src]
+            if np.array_equal(nxt, src):
+                break
+            src = nxt
+        return members[src]
+
+    pool = np.flatnonzero(kind != 3)
+    src = np.arange(n)
+    src[pool] = sources(pool)
+    chrom, start, end = chrom[src], start[src], end[src]      # (discordant templates: src is the identity so far)
+    # discordant pairs: R1 at one end of the template's fragment, R2 anywhere
+    dc = np.flatnonzero(kind == 3)
+    r1rev, r2rev = rng.random(n) < 0.5, rng.random(n) < 0.5
+    c2 = rng.choice(len(lens), n, p=lens / lens.sum())
+    p2 = (rng.random(n) * np.maximum(1, lens[c2] - read_len - 1)).astype(np.int64)
+    c1 = chrom.copy()
+    p1 = np.where(r1rev, end - read_len, start)
+    sdc = sources(dc)
+    swap = np.zeros(n, dtype=bool)
+    swap[dc] = (sdc != dc) & (rng.random(len(dc)) < 0.5)
+    for a in (c1, p1, r1rev, c2, p2, r2rev):
+        a[dc] = a[sdc]
+    c1s, p1s, r1s = np.where(swap, c2, c1), np.where(swap, p2, p1), np.where(swap, r2rev, r1rev)
+    c2s, p2s, r2s = np.where(swap, c1, c2), np.where(swap, p1, p2), np.where(swap, r1rev, r2rev)
+    # singletons
+    srev, sfirst = rng.random(n) < 0.5, rng.random(n) < 0.5
+    # secondary pairs of kind 1
+    d = rng.integers(300, 2000, n)
+    s2 = start + d
+    e2 = s2 + (end - start)
+    qual = rng.integers(2, 41, (n, 2)).astype(np.uint8)
+    qual[rng.random((n, 2)) < 0.05] = 0xFF
+    per = np.array([2, 4, 1, 2])[kind]
+    first = np.concatenate([[0], np.cumsum(per)])
+    recs = np.zeros(int(first[-1]), dtype=REC_DTYPE)
+    recs["rl"] = read_len
+    recs["mapq"] = 30
+    recs["tmpl"] = np.repeat(np.arange(n, dtype=np.uint32), per)
+
+    def put(sel, slot, flag, c, pos, rn, pn, tlen, AS, q):
+        at = first[:-1][sel] + slot
+        for k, v in (("flag", flag), ("chrom", c), ("pos", pos), ("rnext", rn), ("pnext", pn), ("tlen", tlen), ("AS", AS), ("qual", q)):
+            recs[k][at] = v[sel] if isinstance(v, np.ndarray) else v
+
+    pr = kind <= 1
+    tl = end - start
+    put(pr, 0, 99, chrom, start, chrom, end - read_len, tl, -2, qual[:, 0])
+    put(pr, 1, 147, chrom, end - read_len, chrom, start, -tl, -3, qual[:, 1])
+    mu = kind == 1
+    put(mu, 2, 99 | 256, chrom, s2, chrom, e2 - read_len, tl, -4, 0xFF)
+    put(mu, 3, 147 | 256, chrom, e2 - read_len, chrom, s2, -tl, -4, 0xFF)
+    sn = kind == 2
+    put(sn, 0, 1 | 8 | np.where(sfirst, 64, 128) | np.where(srev, 16, 0), chrom, np.where(srev, end - read_len, start), -1, -1, 0, -1, qual[:, 0])
+    dd = kind == 3
+    put(dd, 0, 1 | 64 | np.where(r1s, 16, 0) | np.where(r2s, 32, 0), c1s, p1s, c2s, p2s, 0, -1, qual[:, 0])
+    put(dd, 1, 1 | 128 | np.where(r2s, 16, 0) | np.where(r1s, 32, 0), c2s, p2s, c1s, p1s, 0, -2, qual[:, 1])
+    return recs

@@ -146,7 +146,9 @@ long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, co
  * n <= 65536. */
 int gx_window_net(gx_ctx* ctx, uint32_t chrom, uint32_t pos0, uint32_t n, long long* net);
 
-/* PCR duplicates (-r): the membership half of findDupsPr / findDupsSn (Genrich.c:3616-3690, 3886-3944; the tables'
+/* PCR duplicates (-r): the membership half of findDupsPr / findDupsDc / findDupsSn (Genrich.c:3616-3690, 3761-3880, 3886-3944;
+ * a discordant combination is looked up in both orders of its ends and stored in one -- the table is keyed on the unordered
+ * pair, so the host hands the two ends over in a canonical order; the tables'
  * keys are the fields jenkins_hash_aln hashes, 3408-3450, packed by the host into four words -- an alignment-type tag
  * with the chromosome(s), the 5' end(s), the strand(s)).  keys[0..n) are the alignments of a file's sets in the order
  * in which findDups visits them (highest quality sum first; anything added to a table unconditionally -- the ends of
