@@ -101,8 +101,9 @@ __global__ __launch_bounds__(256) void k_bhx_answer(const BhRec* __restrict__ re
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const u32 key = recs[i].key;
     u32 h = bh_hash(key) & capMask;
-    while (keys[h] != key) h = (h + 1) & capMask;  // (inserted a moment ago: the probe ends)
-    out[i] = qOfSlot[h];
+    u32 gk;
+    while ((gk = keys[h]) != key && gk != EMPTY_KEY) h = (h + 1) & capMask;  // (inserted a moment ago: the probe ends at the key)
+    out[i] = gk == key ? qOfSlot[h] : 0.0f;
   }
 }
 

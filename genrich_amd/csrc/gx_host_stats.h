@@ -1,0 +1,461 @@
+// gx_host_stats.h -- the p-value side: the tight interval table of a replicate without control, its pileup floats on request,
+// the merge with a control, the Fisher combination of replicates, Benjamini-Hochberg.
+// (a part of gx_api.hip's translation unit: the kernels are templates and inline functions of the headers it includes;
+// split by phase -- context / build / stats / sweep / collectives -- in round 5)
+#pragma once
+namespace {
+
+// Loose slots -> the tight interval table (end, p[, pileups]) of a replicate without control: savePval
+// (Genrich.c:1720-1794) against the constant control lambda.  Needs the sample's loose slots, tile tables and
+// p(V) table, i.e. must run before the next sample is built (gx_sample_begin sees to that).
+int materialize_rep(gx_ctx* ctx, int idx) {
+  PArray& pa = ctx->reps[idx];
+  if (!pa.loose) return GX_OK;
+  hipStream_t s = ctx->stream;
+  const u32 n = pa.n;
+  HIPCHECK(pooled(ctx, pa.p, (size_t)n * 4 + 16));
+  phase_begin(ctx, "pval");
+  // (the table p(V) was built when the treatment sample was closed: finish_scalars)
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), pa.tileOff.as<u32>()};
+  // p-mode: the sweep's significance / skip masks are filled on the way (gx_find_peaks reuses them
+  // when this replicate turns out to be the only one)
+  u64 *sigM = nullptr, *skipM = nullptr;
+  ctx->maskIdx = -1;
+  if (!ctx->par.qval_opt) {
+    const u32 nWords = (n + 63) / 64;
+    HIPCHECK(ctx->swMask.ensure((size_t)(nWords + 2) * 8 * 3));
+    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, (size_t)(nWords + 2) * 8 * 3, s));
+    sigM = ctx->swMask.as<u64>();
+    skipM = sigM + (nWords + 2);
+    ctx->maskIdx = idx;
+    ctx->maskN = n;
+    ctx->maskStride = nWords + 2;
+  }
+  {
+    const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+    if (sigM)
+      hipLaunchKernelGGL((k_pack_pval<true>), grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
+                         ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(), pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                         ctx->dStatus.as<u32>());
+    else
+      hipLaunchKernelGGL((k_pack_pval<false>), grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
+                         ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(), pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                         ctx->dStatus.as<u32>());
+  }
+  hipLaunchKernelGGL(k_pval_deep, dim3(256), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(),
+                     ctx->dScal.as<Scalars>(), ctx->dDeep.as<DeepTab>(), pa.p.as<float>(), ctx->par.thr, sigM);
+  if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
+  phase_end(ctx);
+  HIPCHECK(hipGetLastError());
+  pa.end = std::move(ctx->expt.ivEnd);
+  pa.hasPiles = false;
+  pa.pilesPending = ctx->keepPiles;  // made when somebody asks (ensure_piles), from the exact pileups in the loose slots
+  pa.pilesDropped = !ctx->keepPiles;
+  pa.loose = false;
+  return GX_OK;
+}
+
+// The pileup floats of a no-control replicate (Pileup.cov of the reference: only -f / -k print them): made on
+// request from the exact pileups, while the sample's loose slots are still there.
+int ensure_piles(gx_ctx* ctx, int idx) {
+  PArray& pa = ctx->reps[idx];
+  if (pa.loose)
+    if (int rc = materialize_rep(ctx, idx)) return rc;
+  if (!pa.pilesPending) return GX_OK;
+  hipStream_t s = ctx->stream;
+  HIPCHECK(pooled(ctx, pa.expt, (size_t)pa.n * 4 + 16));
+  if (ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)pa.n * 4 + 16));
+  PackIn pin{ctx->looseEnd.as<u32>(), pa.keptLoose ? pa.keptV.as<int>() : ctx->looseV.as<int>(),
+             pa.keptLoose ? pa.keptMeta.as<TileMeta>() : ctx->tileMeta.as<TileMeta>(), pa.tileOff.as<u32>()};
+  const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+  // (the control value of a replicate without control is its lambda: saveLambda 1847-1876)
+  if (ctx->hasBed)
+    hipLaunchKernelGGL(k_piles_from_loose<true>, grid, dim3(256), 0, s, pin, ctx->nTiles, pa.ctrlConst, pa.expt.as<float>(),
+                       pa.ctrl.as<float>());
+  else
+    hipLaunchKernelGGL(k_piles_from_loose<false>, grid, dim3(256), 0, s, pin, ctx->nTiles, pa.ctrlConst, pa.expt.as<float>(),
+                       (float*)nullptr);
+  if (int rc__ = dbg_sync(ctx, "k_piles_from_loose")) return rc__;
+  pa.hasPiles = true;
+  pa.pilesPending = false;
+  ctx->pilesMade = true;
+  if (pa.keptLoose) {
+    recycle(ctx, pa.keptV);
+    recycle(ctx, pa.keptMeta);
+    pa.keptLoose = false;
+  }
+  return GX_OK;
+}
+
+// The context's loose slots are about to be reused (a further replicate is built, or the Fisher combination writes its
+// merged intervals there): a replicate whose pileup floats are still pending keeps what they are made of -- the exact
+// pileups (looseV) and the tile descriptors -- instead of having the floats written now for nobody (k_piles_from_loose:
+// 0.36 ms and 0.8 GB per replicate at hg38 / 50 M fragments; 0.4 GB of a 288 GB device kept instead).
+int keep_loose_for_piles(gx_ctx* ctx, int idx) {
+  PArray& pa = ctx->reps[idx];
+  if (pa.loose)
+    if (int rc = materialize_rep(ctx, idx)) return rc;
+  if (!pa.pilesPending || pa.keptLoose) return GX_OK;
+  pa.keptV = std::move(ctx->looseV);
+  pa.keptMeta = std::move(ctx->tileMeta);
+  pa.keptLoose = true;
+  return GX_OK;
+}
+
+// treatment + control -> the p-value intervals of the replicate (savePval Genrich.c:1720-1794): tile-local union of the
+// two samples' breakpoints, p per interval from the control's tables, the sweep's masks on the way (p mode)
+int merge_with_control(gx_ctx* ctx, PArray& pa) {
+  hipStream_t s = ctx->stream;
+  // treatment + control: tile-local union of breakpoints (savePval 1768-1791)
+  const u32 nTiles = ctx->nTiles, nChrom = ctx->nChrom;
+  const size_t cap = (size_t)ctx->expt.nIv + ctx->ctrl.nIv + 16;
+  HIPCHECK(pooled(ctx, pa.end, cap * 4));
+  const bool keep = ctx->keepPiles;
+  if (keep) {
+    HIPCHECK(pooled(ctx, pa.expt, cap * 4));
+    HIPCHECK(pooled(ctx, pa.ctrl, cap * 4));
+  }
+  HIPCHECK(pooled(ctx, pa.p, cap * 4));
+  HIPCHECK(pooled(ctx, pa.tileOff, (size_t)(nTiles + 2) * 4));
+  HIPCHECK(pooled(ctx, pa.chromOff, (size_t)(nChrom + 2) * 4));
+  // loose slots: the tile kernel's loose buffers, or others like them (+ one more int array)
+  HIPCHECK(pooled(ctx, ctx->looseEnd, cap * 4));
+  HIPCHECK(pooled(ctx, ctx->looseV, cap * 4));
+  HIPCHECK(ctx->looseC.ensure(cap * 4));
+  HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
+  u32* misc = ctx->misc.as<u32>();
+  phase_begin(ctx, "merge");
+  const bool fromLoose = ctx->expt.inLoose && ctx->ctrl.inLoose;
+  if (!fromLoose && (ctx->expt.inLoose || ctx->ctrl.inLoose || !ctx->expt.packed || !ctx->ctrl.packed)) {
+    ctx->err = "control merge: the two samples are not in the same form";
+    return GX_ERR_ORDER;
+  }
+  Merge2Out mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->tileIvCount.as<u32>()};
+  // (pos0 / len / flags of a tile do not depend on the sample: the control build's descriptors serve)
+  const dim3 gridM(std::min(nTiles, (u32)(8 * ctx->numCU)));
+  if (fromLoose) {
+    RleIn A{ctx->expt.looseEnd.as<u32>(), ctx->expt.looseV.as<int>(), ctx->expt.tileIvOff.as<u32>(), ctx->expt.meta.as<TileMeta>()};
+    RleIn Bc{ctx->ctrl.looseEnd.as<u32>(), ctx->ctrl.looseV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), ctx->ctrl.meta.as<TileMeta>()};
+    hipLaunchKernelGGL(k_merge2<true>, gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->ctrl.meta.as<TileMeta>(),
+                       nTiles, mo, ctx->dStatus.as<u32>());
+  } else {
+    RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>(), nullptr};
+    RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), nullptr};
+    hipLaunchKernelGGL(k_merge2<false>, gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->tileMeta.as<TileMeta>(),
+                       nTiles, mo, ctx->dStatus.as<u32>());
+  }
+  if (int rc__ = dbg_sync(ctx, "k_merge2")) return rc__;
+  const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));
+  hipLaunchKernelGGL(k_scan_counts, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
+                     ctx->tileIvCount.as<u32>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles,
+                     ctx->lb.as<u64>(), pa.tileOff.as<u32>(), pa.chromOff.as<u32>(), misc + M_NMERGED,
+                     ctx->dStatus.as<u32>());
+  hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, pa.chromOff.as<u32>(),
+                     misc + M_NMERGED);
+  if (int rc__ = dbg_sync(ctx, "k_scan_counts")) return rc__;
+  phase_end(ctx);
+  phase_begin(ctx, "pval");
+  // (the control's tables -- log(treatment), control parameters, p of whole pileup pairs -- were built when
+  // its sample was closed: finish_scalars)
+  PackPairsIn ppi{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->expt.tileIvOff.as<u32>(),
+                  ctx->ctrl.tileIvOff.as<u32>(), pa.tileOff.as<u32>()};
+  HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
+  // p-mode: the sweep's masks are filled on the way (the interval count is only bounded here, so the
+  // masks are laid out for the bound and gx_find_peaks is told the stride)
+  u64 *sigM = nullptr, *skipM = nullptr;
+  ctx->maskIdx = -1;
+  if (!ctx->par.qval_opt) {
+    const size_t stride = (cap + 63) / 64 + 2;
+    HIPCHECK(ctx->swMask.ensure(stride * 8 * 3));
+    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, stride * 8 * 3, s));
+    sigM = ctx->swMask.as<u64>();
+    skipM = sigM + stride;
+    ctx->maskIdx = (int)ctx->reps.size();
+    ctx->maskStride = stride;
+  }
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
+  {
+    const dim3 grid(std::max(1u, std::min((nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+    const bool msk = sigM != nullptr;
+#define GX_LAUNCH_PACK_PAIRS(K, M)                                                                                     \
+hipLaunchKernelGGL((k_pack_pairs<K, M>), grid, dim3(256), 0, s, ppi, nTiles, ctx->pairCtab.as<CtrlEntry>(),           \
+                   ctx->pairP2d.as<float>(), pa.end.as<u32>(), pa.expt.as<float>(), pa.ctrl.as<float>(),              \
+                   pa.p.as<float>(), ctx->par.thr, sigM, skipM, ctx->fragList.as<u32>(), misc + M_TICKET)
+    if (keep) { if (msk) GX_LAUNCH_PACK_PAIRS(true, true); else GX_LAUNCH_PACK_PAIRS(true, false); }
+    else { if (msk) GX_LAUNCH_PACK_PAIRS(false, true); else GX_LAUNCH_PACK_PAIRS(false, false); }
+#undef GX_LAUNCH_PACK_PAIRS
+  }
+  hipLaunchKernelGGL(k_pack_pairs_full, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(4 * ctx->numCU)))), dim3(256), 0, s,
+                     ppi, ctx->fragList.as<u32>(), misc + M_TICKET, ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(),
+                     ctx->pairCtab.as<CtrlEntry>(), keep ? pa.expt.as<float>() : (float*)nullptr,
+                     keep ? pa.ctrl.as<float>() : (float*)nullptr, pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                     ctx->dStatus.as<u32>(), ctx->dRisk.as<RiskBuf>());
+  if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
+  phase_end(ctx);
+  HIPCHECK(hipGetLastError());
+  if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_NMERGED)) return rc__;
+  int rc = status_to_rc(ctx, ctx->mail->status);
+  {
+    RiskTargets T{};
+    T.pairP = pa.p.as<float>();
+    T.sigMask = sigM;
+    T.thr = ctx->par.thr;
+    const int rcRisk = risk_apply(ctx, T);
+    if (!rc) rc = rcRisk;
+  }
+  if (rc) return rc;
+  pa.n = ctx->mail->nMerged;
+  ctx->maskN = pa.n;
+  pa.hasPiles = keep;
+  pa.pilesDropped = !keep;
+  pa.ctrlIsConst = false;
+  return GX_OK;
+}
+
+// combinePval (Genrich.c:612-667): union of all replicates' breakpoints, Fisher's method per interval; appends the
+// combined array to ctx->reps
+int combine_replicates(gx_ctx* ctx) {
+  hipStream_t s = ctx->stream;
+  u32* misc = ctx->misc.as<u32>();
+  // combinePval (612-667): union of all replicates' breakpoints, Fisher's method per interval
+  const int nr = ctx->sample;
+  if (nr > MAX_REPS) {
+    ctx->err = "more than 32 replicates are not supported";
+    return GX_ERR_DF;
+  }
+  const u32 nTiles = ctx->nTiles, nChrom = ctx->nChrom;
+  PArray comb;
+  comb.present.assign(nChrom, 0);
+  size_t cap = nChrom + 16;
+  RepSet S{};
+  S.n = nr;
+  for (int r = 0; r < nr; r++) {
+    PArray& pa = ctx->reps[r];
+    HIPCHECK(pooled(ctx, pa.dPresent, nChrom + 16));
+    HIPCHECK(hipMemcpyAsync(pa.dPresent.p, pa.present.data(), nChrom, hipMemcpyHostToDevice, s));
+    for (u32 i = 0; i < nChrom; i++) comb.present[i] |= pa.present[i];
+    cap += pa.n;
+    S.r[r] = RepIn{pa.end.as<u32>(), pa.p.as<float>(), pa.tileOff.as<u32>(), pa.dPresent.as<uint8_t>()};
+  }
+  HIPCHECK(pooled(ctx, comb.end, cap * 4));
+  HIPCHECK(pooled(ctx, comb.p, cap * 4));
+  HIPCHECK(pooled(ctx, comb.tileOff, (size_t)(nTiles + 2) * 4));
+  HIPCHECK(pooled(ctx, comb.chromOff, (size_t)(nChrom + 2) * 4));
+  phase_begin(ctx, "fisher");
+  HIPCHECK(pooled(ctx, ctx->looseEnd, cap * 4));
+  HIPCHECK(pooled(ctx, ctx->looseV, cap * 4));   // (the last replicate may have kept the previous one: keep_loose_for_piles)
+  HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
+  MergeNOut mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<float>(), ctx->tileIvCount.as<u32>()};
+  const size_t lds = mergeN_lds_bytes((int)nr);
+  HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  // the device-wide table of Fisher results: empty at the start of every run (within a run the same pairs recur
+  // across tiles; across runs it would be a cache of outputs)
+  HIPCHECK(ctx->fisherCache.ensure(((size_t)16 << MN_GLOBAL_LOG)));
+  HIPCHECK(hipMemsetAsync(ctx->fisherCache.p, 0, (size_t)16 << MN_GLOBAL_LOG, s));
+  int mnBlocks = 0;
+  if (nr <= MNW_MAXREP) {
+    // one wavefront per tile (no workgroup barrier in the tile loop, twenty tiles in flight per CU)
+    const size_t ldsw = mergeNw_lds_bytes((int)nr);
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN_w, MNW_NW * 64, ldsw));
+    const u32 want = (nTiles + MNW_NW - 1) / MNW_NW;
+    hipLaunchKernelGGL(k_mergeN_w, dim3(std::max(1u, std::min(want, (u32)(std::max(1, mnBlocks) * ctx->numCU)))), dim3(MNW_NW * 64), ldsw, s, S,
+                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
+                       ctx->dRisk.as<RiskBuf>(), ctx->fisherCache.as<uint4>());
+  } else {
+  HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN, MG_NT, lds));
+  hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(std::max(1, mnBlocks) * ctx->numCU))), dim3(MG_NT), lds, s, S,
+                     ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
+                     ctx->dRisk.as<RiskBuf>(), ctx->fisherCache.as<uint4>());
+  }
+  if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
+  const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
+  HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));
+  hipLaunchKernelGGL(k_scan_counts, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
+                     ctx->tileIvCount.as<u32>(), ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles,
+                     ctx->lb.as<u64>(), comb.tileOff.as<u32>(), comb.chromOff.as<u32>(), misc + M_NMERGED,
+                     ctx->dStatus.as<u32>());
+  hipLaunchKernelGGL(k_fix_chrom_off, dim3(1), dim3(1), 0, s, ctx->dChrom.as<DChrom>(), nChrom, comb.chromOff.as<u32>(),
+                     misc + M_NMERGED);
+  hipLaunchKernelGGL(k_pack_ep, dim3(std::max(1u, std::min((nTiles + 3) / 4, 8192u))), dim3(256), 0, s, S,
+                     ctx->looseEnd.as<u32>(), ctx->looseV.as<float>(), comb.tileOff.as<u32>(), nTiles, comb.end.as<u32>(),
+                     comb.p.as<float>());
+  if (int rc__ = dbg_sync(ctx, "k_pack_ep")) return rc__;
+  phase_end(ctx);
+  HIPCHECK(hipGetLastError());
+  if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_NMERGED)) return rc__;
+  int rc = status_to_rc(ctx, ctx->mail->status);
+  {
+    RiskTargets T{};
+    T.fisherP = comb.p.as<float>();
+    T.fisherTileOff = comb.tileOff.as<u32>();
+    const int rcRisk = risk_apply(ctx, T);
+    if (!rc) rc = rcRisk;
+  }
+  if (rc) return rc;
+  comb.n = ctx->mail->nMerged;
+  ctx->reps.push_back(std::move(comb));
+  return GX_OK;
+}
+
+// computeQval / saveQval (Genrich.c:352-401, 212-250) for the final p-array `fa` of n intervals: the genome-wide table
+// {p -> bp} (with several ranks: after the exchange, gx_host_coll.h), its sort and suffix scan, q per interval and the
+// sweep's masks on the way.  genomeOpt: the genome length was computed (not -L): the lengths must add up to it
+int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
+  hipStream_t s = ctx->stream;
+  u32* misc = ctx->misc.as<u32>();
+  const u32 nChrom = ctx->nChrom;
+  phase_begin(ctx, "bh");
+  // The table of distinct p-values: open addressing, 2^bhCapLog slots.  It starts at 2^22 (16 MiB of keys: L2 /
+  // Infinity-Cache resident for the per-interval look-ups) and grows by 8x, for good, whenever an insertion
+  // gives up (ST_HASH_FULL: bh_global_add stops after BH_MAX_PROBE steps instead of crawling through a full
+  // table) -- the reference's chained hash (recordPval 277-295) has no limit either.
+  u32 cap = 1u << ctx->bhCapLog;
+  auto bh_table = [&](u32 c) -> int {
+    const bool fresh = ctx->bhKeys.cap < (size_t)c * 4;
+    HIPCHECK(ctx->bhKeys.ensure((size_t)c * 4));
+    HIPCHECK(ctx->bhLens.ensure((size_t)c * 8));
+    HIPCHECK(ctx->bhQ.ensure((size_t)c * 4));
+    HIPCHECK(ctx->bhOutKeys.ensure((size_t)c * 4));
+    HIPCHECK(ctx->bhOutSlot.ensure((size_t)c * 4));
+    if (fresh || ctx->bhDirty) {  // normally the table comes back clean from the previous call (k_bh_clear)
+      HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)c * 4, s));
+      HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)c * 8, s));
+    }
+    ctx->bhDirty = true;
+    return GX_OK;
+  };
+  auto bh_grow = [&]() -> int {
+    if (ctx->bhCapLog >= 28) {
+      ctx->err = "p-value table full";
+      return GX_ERR_MEM;
+    }
+    ctx->bhCapLog += 3;
+    cap = 1u << ctx->bhCapLog;
+    ctx->bhDirty = true;  // (whatever the failed attempt left behind is wiped)
+    return GX_OK;
+  };
+  BhTable T{};
+  u32 Dlocal = 0;
+  for (;;) {
+    if (int rc = bh_table(cap)) return rc;
+    HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
+    T = BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
+                misc + M_BHCOUNT};
+    hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
+                       fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
+                       ctx->dStatus.as<u32>());
+    if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
+    if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;
+    Dlocal = ctx->mail->nMerged;
+    if (!(ctx->mail->status & ST_HASH_FULL)) break;
+    if (ctx->mail->status != ST_HASH_FULL) return status_to_rc(ctx, ctx->mail->status & ~ST_HASH_FULL);
+    HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 4, s));
+    if (int rc = bh_grow()) return rc;
+  }
+  const bool multi = ctx->world > 1 || ctx->forceColl;
+  // (computeQval 377-382: checked when the genome length was computed -- not with -L)
+  u32* lenCheck = genomeOpt ? ctx->dStatus.as<u32>() : (u32*)nullptr;
+  u32 D = 0;
+  bool denseDone = false;
+  ctx->denseBhUsed = false;
+  ctx->rangeBhUsed = false;
+  // One sample without a control: p is a function of the pileup, every rank holds the same table p(V), and the
+  // genome-wide histogram is ONE all-reduce of a dense "bp at V" array (gx_stats.h: k_bh_dense_fill) -- decided by what
+  // every rank knows alike
+  if (multi && ctx->sample == 1 && ctx->reps.size() == 1 && fa.ctrlIsConst && !ctx->bedGiven && (u32)std::max(1, ctx->world) <= 64 &&
+      !ctx->knob.noDenseBh) {
+    const u32 W = (u32)std::max(1, ctx->world);
+    const size_t words = bhd_words(W);
+    HIPCHECK(ctx->bhDense.ensure(words * 8));
+    HIPCHECK(hipMemsetAsync(ctx->bhDense.p, 0, words * 8, s));
+    HIPCHECK(hipMemsetAsync(misc + M_BHOVF, 0, 4, s));  // (the "a rank's region overflowed" word)
+    hipLaunchKernelGGL(k_bh_dense_fill, dim3(std::max(1u, std::min((Dlocal + 255) / 256, 1024u))), dim3(256), 0, s,
+                       ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), ctx->bhLens.as<u64>(), misc + M_BHCOUNT,
+                       ctx->pvLut.as<float>(), ctx->bhDense.as<u64>(), (u32)ctx->rank);
+    if (int rc__ = allreduce_words(ctx, ctx->bhDense.as<long long>(), words)) return rc__;
+    hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+    HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
+    hipLaunchKernelGGL(k_bh_from_dense, dim3(256), dim3(256), 0, s, (const u64*)ctx->bhDense.as<u64>(), ctx->pvLut.as<float>(), W, T,
+                       misc + M_BHOVF, ctx->dStatus.as<u32>());
+    HIPCHECK(hipMemcpyAsync(&ctx->mail->D, misc + M_BHCOUNT, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&ctx->mail->bhOvf, misc + M_BHOVF, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (ctx->mail->bhOvf == 0) {
+      D = ctx->mail->D;
+      denseDone = true;
+      ctx->denseBhUsed = true;
+    } else {
+      // some rank holds more values outside the table than its region takes: every rank saw it, all go back to their own
+      // tables and take the general exchange
+      hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+      HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
+      hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
+                         fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
+                         ctx->dStatus.as<u32>());
+      if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;
+      Dlocal = ctx->mail->nMerged;
+    }
+  }
+  bool rangeDone = false;
+  if (denseDone) {
+  } else if (multi) {
+    // a control / replicates: the range-partitioned exchange (gx_bhx.h) leaves every value's q in this rank's table
+    if (int rc = bh_range_exchange(ctx, T, Dlocal, cap)) return rc;
+    rangeDone = true;
+    D = 0;
+  } else
+    D = Dlocal;
+  if (D && !rangeDone) {
+    HIPCHECK(ctx->bhSortKeys.ensure((size_t)D * 4));
+    HIPCHECK(ctx->bhSortSlot.ensure((size_t)D * 4));
+    HIPCHECK(ctx->bhRaw.ensure((size_t)D * 4));
+    size_t tmpBytes = 0;
+    HIPCHECK(rocprim::radix_sort_pairs(nullptr, tmpBytes, ctx->bhOutKeys.as<u32>(), ctx->bhSortKeys.as<u32>(),
+                                       ctx->bhOutSlot.as<u32>(), ctx->bhSortSlot.as<u32>(), D, 0, 32, s));
+    HIPCHECK(ctx->bhTmp.ensure(tmpBytes + 16));
+    HIPCHECK(rocprim::radix_sort_pairs(ctx->bhTmp.p, tmpBytes, ctx->bhOutKeys.as<u32>(), ctx->bhSortKeys.as<u32>(),
+                                       ctx->bhOutSlot.as<u32>(), ctx->bhSortSlot.as<u32>(), D, 0, 32, s));
+    if (D <= 16384 && !ctx->knob.qtMulti) {
+      hipLaunchKernelGGL(k_qtable, dim3(1), dim3(1024), 0, s, ctx->bhSortKeys.as<u32>(), ctx->bhSortSlot.as<u32>(),
+                         ctx->bhLens.as<u64>(), D, reinterpret_cast<const u64*>(misc + M_GENOME), ctx->bhQ.as<float>(),
+                         ctx->bhRaw.as<float>(), misc + M_ALLONE, lenCheck);
+    } else {  // many distinct values (Fisher-combined replicates): the chunked kernels
+      const u32 nCh = (D + QT_CHUNK - 1) / QT_CHUNK;
+      HIPCHECK(ctx->bhDl.ensure((size_t)D * 8 + (size_t)nCh * 12 + 64));
+      u64* dl = ctx->bhDl.as<u64>();
+      u64* chunkSum = dl + D;
+      float* chunkMin = reinterpret_cast<float*>(chunkSum + nCh);
+      hipLaunchKernelGGL(k_qt_sums, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortSlot.as<u32>(), ctx->bhLens.as<u64>(), D, dl,
+                         chunkSum, (const u32*)nullptr);
+      hipLaunchKernelGGL(k_qt_raw, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortKeys.as<u32>(), dl, D,
+                         reinterpret_cast<const u64*>(misc + M_GENOME), chunkSum, ctx->bhRaw.as<float>(), chunkMin,
+                         (const u32*)nullptr, (const u64*)nullptr, 1u, 0u, lenCheck);
+      hipLaunchKernelGGL(k_qt_apply, dim3(nCh), dim3(QT_NT), 0, s, ctx->bhSortSlot.as<u32>(), ctx->bhRaw.as<float>(), D,
+                         chunkMin, ctx->bhQ.as<float>(), misc + M_ALLONE, (const u32*)nullptr, (const u64*)nullptr, 1u, 0u);
+    }
+if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
+  }
+  HIPCHECK(pooled(ctx, fa.q, (size_t)n * 4 + 16));
+  {  // q-values and, on the way, the sweep's significance / SKIP masks
+    const size_t stride = (size_t)((n + 63) / 64) + 2;
+    HIPCHECK(ctx->swMask.ensure(stride * 8 * 3));
+    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, stride * 8 * 3, s));
+    ctx->maskIdx = ctx->finalIdx;
+    ctx->maskN = n;
+    ctx->maskStride = stride;
+    hipLaunchKernelGGL(k_qlookup, dim3(std::max(1u, std::min((n + 4095) / 4096, 4096u))), dim3(256), 0, s, fa.p.as<float>(),
+                       misc + M_NIV, ctx->bhKeys.as<u32>(), ctx->bhQ.as<float>(), cap - 1, fa.q.as<float>(), ctx->par.thr,
+                       ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride, ctx->dStatus.as<u32>());
+  }
+  hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+  ctx->bhDirty = false;
+if (int rc__ = dbg_sync(ctx, "k_qlookup")) return rc__;
+  phase_end(ctx);
+  HIPCHECK(hipGetLastError());
+  return GX_OK;
+}
+
+}  // namespace

@@ -786,7 +786,7 @@ constexpr int QL_CACHE_LOG = 11;
 __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, const u32* __restrict__ nPtr,
                                                  const u32* __restrict__ gKeys, const float* __restrict__ qOfSlot,
                                                  u32 capMask, float* __restrict__ q, float thr, u64* __restrict__ sigMask,
-                                                 u64* __restrict__ skipMask) {
+                                                 u64* __restrict__ skipMask, u32* __restrict__ st) {
   __shared__ u64 lc[1 << QL_CACHE_LOG];  // [31:0] key, [63:32] q bits; key EMPTY_KEY: free
   for (int i = threadIdx.x; i < (1 << QL_CACHE_LOG); i += 256) lc[i] = (u64)EMPTY_KEY;
   __syncthreads();
@@ -815,9 +815,15 @@ __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, co
             qv = __uint_as_float((u32)(c >> 32));
           else {
             u32 h = hh & capMask;
-            while (gKeys[h] != key) h = (h + 1) & capMask;  // every p was inserted
-            qv = qOfSlot[h];
-            lc[hl] = (u64)key | ((u64)__float_as_uint(qv) << 32);
+            // (every p of this rank was inserted -- and if an exchange lost the table, the probe ends at a free slot
+            // instead of circling: the run fails with the reference's "does not match p-value length", 377-382)
+            u32 gk;
+            while ((gk = gKeys[h]) != key && gk != EMPTY_KEY) h = (h + 1) & capMask;
+            if (gk == key) {
+              qv = qOfSlot[h];
+              lc[hl] = (u64)key | ((u64)__float_as_uint(qv) << 32);
+            } else
+              atomicOr(st, ST_BH_LEN);
           }
         }
         q[i] = qv;

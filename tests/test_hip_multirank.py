@@ -177,13 +177,18 @@ def test_a_rank_whose_histogram_is_lost_fails_every_rank():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_withholding_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_withholding_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in procs])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=120) for _ in procs])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:   # (a rank that never came back must not outlive the test)
+            if p.is_alive():
+                p.kill()
     for rank, msg in res:
         assert "error -8" in msg and "does not match p-value length" in msg, (rank, msg)
 
