@@ -150,7 +150,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // key than the rounds of full-size bins -- 2.98 against 2.67 ms)
   const bool forceHalf = K.forceHalfBins != 0;  // (tests: the 128-key level 1 on a small input)
   if (pairs && (!fracPairs || forceHalf || K.fracHalfBins) && sbS > 0 &&
-      (forceHalf || (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * (SBT_KEYCAP - SBT_KEYCAP / 4)) &&
+      (forceHalf || (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * (SBT_KEYCAP - SBT_KEYCAP / 10)) &&
       ((nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1)) <= (u32)MAX_BINS_P && !K.noHalfBins) {
     sbS--;
     nL1 = (nTiles + (1u << sbS) - 1) >> sbS;
@@ -411,13 +411,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       for (const void* f : {reinterpret_cast<const void*>(k_sbtile<false, false, false>), reinterpret_cast<const void*>(k_sbtile<true, false, false>),
                             reinterpret_cast<const void*>(k_sbtile<true, true, false>), reinterpret_cast<const void*>(k_sbtile<true, false, true>),
                             reinterpret_cast<const void*>(k_sbtile<true, true, true>)})
-        HIPCHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbtLds)));
+        HIPCHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SBT_LDS_BYTES));
       ctx->sbtLdsSet = true;
     }
     HIPCHECK(ctx->bigBins.ensure((size_t)(MAX_BINS_P + 4) * 4));
     SbtIn si{PG3[0], PG3[1], PG3[2], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
              ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, sbS,
-             ctx->fracPairsUsed ? (const FragFix*)ff : (const FragFix*)nullptr, ctx->fracPairsUsed ? acc : (long long*)nullptr};
+             ctx->fracPairsUsed ? (const FragFix*)ff : (const FragFix*)nullptr, ctx->fracPairsUsed ? acc : (long long*)nullptr, (u32)SBT_TR};
     SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>(), ctx->nWide.as<u32>() + 1, ctx->nWide.as<u32>() + 13,
                ctx->bigBins.as<u32>(), ctx->heavyList.as<u32>(), ctx->nWide.as<u32>() + 2};
     const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
@@ -426,20 +426,30 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 16);
     if (dense) {
       so2.bigList = nullptr;
+      // touched bases per round of the tile passes against keys per round of a bin (they share the LDS, gx_sbtile.h): what
+      // costs a dense sample is the number of rounds a bin takes -- each reads the bin's records again --, so: the
+      // largest TR among those that give the fewest rounds for the average bin (with a margin for the fuller ones)
+      const size_t avgKeys = (size_t)2 * nEv / std::max(1u, nL1), want = avgKeys + avgKeys / 32;
+      u32 best = (u32)SBT_TR, bestRounds = ~0u;
+      for (u32 tr = 448; tr >= 192; tr -= 64) {
+        const u32 rounds = (u32)((want + sbt_keycap(tr) - 1) / sbt_keycap(tr));
+        if (rounds < bestRounds) { bestRounds = rounds; best = tr; }
+      }
+      si.tr = K.sbtTr >= 192 && K.sbtTr <= 448 && K.sbtTr % 64 == 0 ? (u32)K.sbtTr : best;
       if (ctx->fracPairsUsed)
-        hipLaunchKernelGGL((k_sbtile<true, true, true>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+        hipLaunchKernelGGL((k_sbtile<true, true, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       else
-        hipLaunchKernelGGL((k_sbtile<true, true, false>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+        hipLaunchKernelGGL((k_sbtile<true, true, false>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
     } else if (ctx->fracPairsUsed) {
-      hipLaunchKernelGGL((k_sbtile<true, false, true>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
-      hipLaunchKernelGGL((k_sbtile<true, true, true>), gBig, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<true, false, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<true, true, true>), gBig, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
     } else if (ctx->pairsUsed) {
-      hipLaunchKernelGGL((k_sbtile<true, false, false>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<true, false, false>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       // the bins it left on its list (reads piled up: more keys than the key array holds, a tile with thousands of keys):
       // usually none -- an idle launch
-      hipLaunchKernelGGL((k_sbtile<true, true, false>), gBig, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<true, true, false>), gBig, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
     } else
-      hipLaunchKernelGGL((k_sbtile<false, false, false>), gAll, dim3(SBT_NT), sizeof(SbtLds), s, si, so2, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<false, false, false>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
   } else if (ctx->hasBed) {
     hipLaunchKernelGGL((k_tile<true, true>), gHalf, dim3(TL_NT), TL_LDS_HALF * 4, s, tin, nTiles, wl, nw, bin, to,
                        ctx->dStatus.as<u32>());

@@ -163,6 +163,7 @@ struct Knobs {
   long long runCapMin = 0;  // GX_RUN_CAP_MIN: the sweep's first guess of the run count (a tiny one forces the second pass)
   int bhCapLog = 0;       // GX_BH_CAPLOG: log2 of the BH table's first size
   int ptJmax = 0;         // GX_PT_JMAX: pages per level-1 list at first
+  int sbtTr = 0;          // GX_SBT_TR: touched bases per round of the tile passes in k_sbtile's second launch of a dense sample (measurements)
   int fault = 0;          // GX_FAULT: fault injection for the tests of the device-side invariants.  1: the weight of the ends at
                           // chromosome 0's length is damaged behind level 1 of the sort (as if an end record had been lost)
 };
@@ -175,7 +176,7 @@ const KnobDef KNOBS[] = {
     {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
     {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
     {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
-    {"GX_PT_JMAX", &Knobs::ptJmax, nullptr}, {"GX_FAULT", &Knobs::fault, nullptr},
+    {"GX_PT_JMAX", &Knobs::ptJmax, nullptr}, {"GX_FAULT", &Knobs::fault, nullptr}, {"GX_SBT_TR", &Knobs::sbtTr, nullptr},
 };
 // a switch that is merely present counts as 1 (GX_NO_LOOSE= is "on", as it was with getenv() != nullptr)
 bool set_knob(Knobs& k, const char* name, const char* value) {

@@ -60,15 +60,19 @@ GX_HD __forceinline__ bool getval_neg(int32_t v) {
 
 // ---- the one rounding of a p-value: double -> float, with the "risky" test ----------------------
 // Device and host evaluate the same IEEE operations around different libm calls (<= ~1.5 ulp of the
-// double apart per call); through calcPval / pchisq that propagates to a relative difference of at
-// most a few 1e-14 in the double result.  A result whose distance to the
-// nearest float rounding boundary (the midpoint of two neighbouring floats) is below RISK_B of its
-// value is not rounded here but flagged.  Measured on MI355X against glibc 2.35 (400,000 random pairs,
-// tools/diag_pval.py): the doubles agree to 1e-15 in 99.9 % of the cases and to 7e-14 in 99.99 %; the
-// worst case is the lower tail, where a relative difference dz in z = (log expt - meanlog) / sdlog
-// becomes z^2 dz in the result: <= ~1e-13 for any p that is not zero as a float (z^2 / 2 <= 103).
-// RISK_B = 2^-38 = 3.6e-12 leaves a factor of >= 30; the numerics tests measure the double-level
-// difference against it.  About 2 * RISK_B / 2^-24 = 1.2e-4 of all values are flagged.
+// double apart per call); through calcPval / pchisq that propagates to a relative difference in the double
+// result that grows towards the lower tail, where a relative difference dz in z = (log expt - meanlog) / sdlog
+// becomes z^2 dz in the result (z^2 / 2 <= 103 for any p that is not zero as a float).  A result whose distance
+// to the nearest float rounding boundary (the midpoint of two neighbouring floats) is below RISK_B of its
+// value is not rounded here but flagged, and the host evaluates it.  That is sound as long as the two doubles
+// never differ by RISK_B or more -- SWEPT over the reachable domain in round 5 (tools/sweep_risk_margin.py on
+// MI355X against glibc 2.35, profiles/r05_risk_margin.txt): every exact pileup V in [0, 2^18) x 307 values of
+// lambda in [1e-4, 2000] (80 M pairs) and the 256 x 256 table of whole pileups x 26 factors x 7 lambda (12 M):
+// max |device - host| / |host| = 7.4e-13 = 0.20 x RISK_B, reached for lambda > 1500 (pileups far below a control in the
+// thousands: p ~ 1e-31); 0.03 x RISK_B for every lambda <= 240, 0.055 x RISK_B over the pair tables; 0 floats differ
+// after the re-evaluation.  (Round 2's sample of 400,000 random pairs had seen 7e-14 at the 99.99th percentile and
+// claimed a factor of 30: true below lambda ~ 240, a factor of 5 over everything.)
+// RISK_B = 2^-38 = 3.6e-12.  About 2 * RISK_B / 2^-24 = 1.2e-4 of all values are flagged.
 #define GX_RISK_B 0x1p-38
 
 GX_HD __forceinline__ float bits_float(uint32_t u) { union { uint32_t u; float f; } x; x.u = u; return x.f; }

@@ -57,35 +57,33 @@ constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K
 #ifndef GX_SBT_TR
 #define GX_SBT_TR 448
 #endif
-// keys of a super-bucket (both streams) that fit the LDS: what the 160 KiB leave once the wavefronts' scratch is taken
-// (SBT_TR touched bases per round: 6 bytes each and wavefront)
-// = (160 KiB - 13,120 bytes of tables - 16 wavefronts x (800 + 6 SBT_TR) bytes of scratch) / 2 - 192 keys of slack, in whole K
-constexpr u32 SBT_KEYCAP = ((163840u - 13120u - 16u * (800u + 6u * GX_SBT_TR)) / 2u - 192u) / 1024u * 1024u;
 constexpr u32 SBT_HEAVY = 4096;                        // keys from which a tile is the whole workgroup's (a counter per base), not one wavefront's
 constexpr int SBT_MAXR = 8;                            // pair mode: rounds of a super-bucket whose keys do not fit the LDS at once
 constexpr u32 SBT_FCAP = 16384;                        // pair mode: singles of a super-bucket (read where they lie, twice)
-// Touched bases per round of a tile's passes.  A round walks ALL keys of the tile (rank, range check, counter) and then
-// the round's touched bases in steps of 64; a tile with more touched bases than SBT_TR takes several rounds.  192 (round
-// 3, k_tile_fast's TR_CAP) fits the ordinary tile -- but a tile with a peak on it (hg38 / 50 M fragments: one tile in
-// twelve, ~575 keys on ~400 bases, at most 459; an ATAC sample: every tile) then pays three rounds -- 4.06 passes over a
-// tile's keys on average instead of 2.65 (counted on the bench's stream).  448 covers them in one; the price is LDS
-// (6 bytes per base and wavefront), taken from the key array: 47 K keys instead of 57 K (a bin of that sample holds 34 K,
-// the fullest 37 K; fuller bins are the second launch's, as before).
+// Touched bases per round of a tile's passes (TR).  A round walks ALL keys of the tile (rank, range check, counter) and then
+// the round's touched bases in steps of 64; a tile with more touched bases than TR takes several rounds.  192 (round 3,
+// k_tile_fast's TR_CAP) fits the ordinary tile -- but a tile with a peak on it (hg38 / 50 M fragments: one tile in twelve,
+// ~575 keys on ~400 bases, at most 459; an ATAC sample: every tile) then pays three rounds -- 4.06 passes over a tile's keys
+// on average instead of 2.65 (counted on the bench's stream).  448 covers them in one.  The price is LDS (6 bytes per base
+// and wavefront), which comes out of the key array: the two share what the tables leave of the 160 KiB (sbt_keycap).
+//   The ordinary launch is compiled for SBT_TR = 448 (47 K keys: a bin of that sample holds 34 K, the fullest 37 K).  The
+// second launch -- the bins beyond the key array, worked off in rounds of tiles -- takes TR at run time (SbtIn::tr): what
+// costs there is the number of rounds, every one of which reads the bin's records again, so the host picks the largest
+// TR that still gives the fewest rounds (an ATAC sample with 95 K keys per bin: 384 -> 50 K keys, two rounds; 448 would
+// need three: measured 2.21 against 2.51 ms).
 constexpr int SBT_TR = GX_SBT_TR;
 // a wavefront's scratch, in words: occupancy bitmap (+ a dummy word that absorbs the lanes without a key), the words'
 // prefix counts (+ a dummy entry that ranks those lanes out of every round), counters and offsets by rank
 constexpr int SBT_OCCW = TILE / 32 + 4, SBT_PREW = TILE / 64 + 4;
-constexpr int SBT_TW = SBT_OCCW + SBT_PREW + SBT_TR + SBT_TR / 2;    // 1,952 bytes
+__host__ __device__ constexpr u32 sbt_tw(u32 tr) { return (u32)(SBT_OCCW + SBT_PREW) + tr + tr / 2; }   // words; 3,488 bytes at 448
 constexpr u32 SBT_NOKEY = 0x1000u;                     // "no key": offset 4096 = bit 0 of the dummy bitmap word
 static_assert(SBT_TR % 64 == 0, "the last step of a round reads whole wavefronts of counters");
 static_assert((1u << PgCfg<u32>::SHIFT) % SBT_SLOT == 0, "a slot never crosses a page");
 static_assert(TILE == 4096, "13-bit LDS keys: 12 bits of offset and the stream");
-static_assert((SBT_NW * SBT_TW) % 4 == 0, "the scratch is cleared by 16-byte stores");
+static_assert((SBT_NW * sbt_tw(64)) % 4 == 0 && (SBT_NW * 96) % 4 == 0, "the scratch is cleared by 16-byte stores (TR: a multiple of 64)");
+constexpr u32 SBT_LDS_BYTES = 160u * 1024u;           // what a launch asks for: one workgroup per CU
 
 struct SbtLds {
-  uint16_t keys[SBT_KEYCAP + 192];         // the bin's keys, tile after tile: [11:0] offset, [15] end key (+ slack: a
-                                           // tile's first 192 keys are read without a bounds check)
-  int tile[SBT_NW][SBT_TW];                // k_tile_fast's scratch, one per wavefront
   u32 hist[SBT_TILES];                     // [15:0] start keys, [31:16] end keys of the tile
   u32 startC[SBT_TILES + 1];               // keys (both streams) of the bin before the tile
   int netPref[SBT_TILES];                  // start keys - end keys of the bin before the tile
@@ -103,9 +101,16 @@ struct SbtLds {
   uint16_t heavy[SBT_TILES];
   int netW[SBT_TILES];                     // fractional pairs: weight (1/120) a tile hands on (ends it receives count negative)
   u32 vsRed[2];                            // loose_vsig's reduction words (its own: tid 0 initialises the others right after)
+  // what is left of the 160 KiB, split by TR: k_tile_fast's scratch, one per wavefront -- int [SBT_NW][sbt_tw(TR)] --, then
+  // the bin's keys, tile after tile -- uint16_t [sbt_keycap(TR) + 192]: [11:0] offset, [15] end key (+ slack: a tile's
+  // first 192 keys are read without a bounds check)
+  __attribute__((aligned(16))) int dyn[4];
 };
-
-static_assert(sizeof(SbtLds) <= 160 * 1024, "k_sbtile's LDS: one workgroup per CU");
+constexpr u32 SBT_DYN_OFF = (u32)offsetof(SbtLds, dyn);
+// keys of a super-bucket (both streams) that fit the LDS next to the scratch for TR touched bases per round, in whole K
+__host__ __device__ constexpr u32 sbt_keycap(u32 tr) { return ((SBT_LDS_BYTES - SBT_DYN_OFF - SBT_NW * sbt_tw(tr) * 4u) / 2u - 192u) / 1024u * 1024u; }
+constexpr u32 SBT_KEYCAP = sbt_keycap(SBT_TR);        // ... of the ordinary launch
+static_assert(sbt_keycap(192) > sbt_keycap(448) && sbt_keycap(448) >= 40960, "the split of the LDS");
 
 struct SbtIn {
   PagedStream PS, PE;         // (pair mode: PS = the pair records' lists, PE unused)
@@ -120,6 +125,7 @@ struct SbtIn {
   int sbShift;
   const FragFix* ff;          // fractional pairs: the general fragLen path's switch and accumulator pair (k_tile_fast's TileIn::ff / fragAcc)
   long long* fragAcc;
+  u32 tr;                     // the second launch's touched bases per round (a multiple of 64 in [192, 448]; the first launch: SBT_TR)
 };
 
 struct SbtOut {
@@ -143,7 +149,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // 32-bit byte offsets against a uniform base pointer: one shift instead of 64-bit address arithmetic per store
 #ifndef GX_SBT_KNOBS   // measurement knobs (tools/build_variant.sh): 1 exchange-and-clear, 2 32-bit store offsets, 4 unpredicated key loads,
-#define GX_SBT_KNOBS 15   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off)
+#define GX_SBT_KNOBS 39   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off),
+                          // 32 the prologue's global loads ahead of the clearing of the scratch, 64 two steps per turn of a round's loop (off)
 #endif
 __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
 #if GX_SBT_KNOBS & 2
@@ -173,7 +180,7 @@ __device__ __forceinline__ u32 sbt_class_of(int w) {  // weight (> 0) -> class; 
 }
 
 template <bool FRAC>
-__device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
+__device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms, long long& fhi,
                                          long long& flo) {
   constexpr u32 NOKEY = FRAC ? SBT_NOKEY_F : SBT_NOKEY;
@@ -183,17 +190,19 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
   u32* pre = reinterpret_cast<u32*>(lds + SBT_OCCW);
   const uint16_t* pre16 = reinterpret_cast<const uint16_t*>(pre);
   int* cnt = lds + SBT_OCCW + SBT_PREW;
-  uint16_t* list = reinterpret_cast<uint16_t*>(lds + SBT_OCCW + SBT_PREW + SBT_TR);
-  constexpr int TR_CAP = SBT_TR;  // (shadows k_tile_fast's: the rounds below are its code)
+  uint16_t* list = reinterpret_cast<uint16_t*>(lds + SBT_OCCW + SBT_PREW + TR_CAP);   // (TR_CAP: a constant in the ordinary launch)
   const int lane = lane_id();
   const bool active = flags & TM_ACTIVE;
   const u64 activeM = active ? ~0ull : 0ull;
   const u32 negPos0 = 0u - pos0;   // (pos0 + p != 0  <=>  p != -pos0)
   const bool lastTile = (flags & TM_LAST) != 0;
-  constexpr int KR = 3;  // keys per lane kept in registers (192 per tile)
+#ifndef GX_SBT_KR
+#define GX_SBT_KR 3
+#endif
+  constexpr int KR = GX_SBT_KR;  // keys per lane kept in registers (192 per tile)
   // (n is wave-uniform -- the caller hands it over in a scalar register: an ordinary tile of hg38 / 50 M fragments holds ~90
   // keys, so the third register-held key is all "no key" there and its three passes are skipped by scalar branches)
-#if GX_SBT_KNOBS & 8
+#if (GX_SBT_KNOBS & 8) && GX_SBT_KR == 3
   const bool third = n > 128u;
 #else
   constexpr bool third = true;
@@ -260,16 +269,17 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
     wave_lds_sync();
     // ---- C: 64 touched bases per step (whole wavefronts: the counters behind the last touched base are zero)
     const u32 nL = min((u32)TR_CAP, T - r0);
-    for (u32 j0 = 0; j0 < nL; j0 += 64) {
-      const u32 j = j0 + lane;
-      const u32 p = list[j];
+    auto loadEl = [&](u32 j, u32& p, int& d120) {
+      p = list[j];
 #if GX_SBT_KNOBS & 1
-      const int d120 = __hip_atomic_exchange(&cnt[j], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // read and clear
+      d120 = __hip_atomic_exchange(&cnt[j], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // read and clear
 #else
-      const int d120 = cnt[j];
+      d120 = cnt[j];
       cnt[j] = 0;
 #endif
-      const int incS = dpp_scan_add(d120);
+    };
+    // one step's 64 touched bases: p their offsets, d120 their differences, incS the inclusive scan of the differences
+    auto emit = [&](const u32 p, const int d120, const int incS) {
       const int after = runBase + incS;
       const int before = after - d120;                          // the pileup of the interval that ends here (2244)
       // nz = d120 != 0 && active && pos0 + p != 0 (2241: base 0 closes nothing), as a lane mask made of the compares'
@@ -303,7 +313,30 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
         outCount += (u32)__popcll(mask);
         lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(mask));
       }
+    };
+#if GX_SBT_KNOBS & 64
+    // two steps per turn of the loop: the second step's counters are fetched and scanned before the first step's intervals
+    // leave (two independent chains; an ordinary tile -- ~90 touched bases -- is ONE turn, no loop)
+    for (u32 j0 = 0; j0 < nL; j0 += 128) {
+      const bool two = j0 + 64 < nL;  // wave-uniform
+      u32 pA, pB = 0;
+      int dA, dB = 0;
+      loadEl(j0 + lane, pA, dA);
+      if (two) loadEl(j0 + 64 + lane, pB, dB);
+      const int incA = dpp_scan_add(dA);
+      int incB = 0;
+      if (two) incB = dpp_scan_add(dB);
+      emit(pA, dA, incA);
+      if (two) emit(pB, dB, incB);
     }
+#else
+    for (u32 j0 = 0; j0 < nL; j0 += 64) {
+      u32 p;
+      int d120;
+      loadEl(j0 + lane, p, d120);
+      emit(p, d120, dpp_scan_add(d120));
+    }
+#endif
   }
   *reinterpret_cast<uint2*>(occ + 2 * lane) = make_uint2(0u, 0u);
   u32 total = 0;
@@ -346,14 +379,14 @@ __device__ __forceinline__ void sbt_tile(int* lds, const uint16_t* __restrict__ 
 // them are through with their tiles); every thread owns four consecutive bases.  Same outputs as sbt_tile.
 // (FRAC with the general fragLen path on: the tile goes on the list of the heavy tiles, whose terms k_frag_walk adds)
 template <bool FRAC>
-__device__ __forceinline__ void sbt_heavy(SbtLds& L, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
+__device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
                                           int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms) {
-  static_assert(SBT_NW * SBT_TW >= TILE, "the counters fit the wavefronts' scratch");
+  static_assert(SBT_NW * sbt_tw(192) >= TILE, "the counters fit the wavefronts' scratch");
   static_assert(TILE == SBT_NT * 4, "four bases per thread");
-  int* cnt = &L.tile[0][0];
+  int* cnt = L.dyn;
   const int tid = threadIdx.x;
   const bool active = flags & TM_ACTIVE, lastTile = (flags & TM_LAST) != 0;
-  for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(cnt + i) = make_int4(0, 0, 0, 0);
+  for (u32 i = (u32)tid * 4; i < scrWords; i += SBT_NT * 4) *reinterpret_cast<int4*>(cnt + i) = make_int4(0, 0, 0, 0);
   __syncthreads();
   for (u32 k = tid; k < n; k += SBT_NT) {
     const u32 key = kl[k];
@@ -453,27 +486,64 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   constexpr int KR = K ? K : 1;                           // (array sizes)
   constexpr u32 NSLOTS = (u32)KX * SBT_NW;
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+  // how the LDS behind the tables is split (the ordinary launch: constants)
+  const u32 trCap = BIG ? (u32)__builtin_amdgcn_readfirstlane((int)in.tr) : (u32)SBT_TR;
+  const u32 tw = sbt_tw(trCap), scrWords = SBT_NW * tw, keyCap = BIG ? sbt_keycap(trCap) : SBT_KEYCAP;
+  int* const scr = L.dyn;
+  uint16_t* const keysL = reinterpret_cast<uint16_t*>(L.dyn + scrWords);
   const u32 nSeg = in.nSeg;
   const u32 nT = 1u << in.sbShift;           // tiles per super-bucket (<= SBT_TILES)
   const u32 segTileBase = seg << in.sbShift;
   const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, !BIG && seg == 0 && tid == 0, L.vsRed));
+  // (one workgroup per CU: a global round trip in this prologue is a round trip of the whole CU.  The lists' lengths and the
+  // tiles' chromosome records -- two dependent loads -- are asked for first and arrive while the scratch is cleared)
+  u32 myLen = 0;
+  auto loadTi = [&]() {   // the tiles' chromosome records (thread b: tile b of the bin)
+    uint4 ti = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < (int)nT) {
+      const u32 t = segTileBase + tid;
+      if (t < in.nTiles) {
+        const u32 ci = in.tileChrom[t];
+        const DChrom c = in.chroms[ci];
+        const u32 tl = t - c.tileBase;
+        ti.x = tl << TB;
+        ti.y = c.len;
+        ti.z = (chrom_active(c) ? TM_ACTIVE : 0u) | (tl + 1 == c.nTiles ? TM_LAST : 0u);
+        ti.w = (u32)in.chromW0[ci];
+      }
+    }
+    return ti;
+  };
+  constexpr bool HOIST = (GX_SBT_KNOBS & 32) != 0;
+  if (HOIST && tid < 2 * NXCD) {
+    const u32 li = (u32)(tid & (NXCD - 1)) * nSeg + seg;
+    if (PAIRS)
+      myLen = tid < NXCD ? list_len<u32>(in.PS, li) : list_len<u64>(in.PF, li);
+    else
+      myLen = list_len<u32>(tid < NXCD ? in.PS : in.PE, li);
+  }
+  uint4 ti = make_uint4(0u, 0u, 0u, 0u);
+  if (HOIST) ti = loadTi();
   // scratch and tables start at zero
-  for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
+  for (u32 i = (u32)tid * 4; i < scrWords; i += SBT_NT * 4) *reinterpret_cast<int4*>(scr + i) = make_int4(0, 0, 0, 0);
   if (tid < SBT_TILES) {
     L.hist[tid] = 0;
     if (FRAC) L.netW[tid] = 0;
   }
   if (tid == 0) { L.overflow = 0; L.nHeavy = 0; }
+  if (HOIST && tid < 2 * NXCD) L.scratch[tid] = myLen;
   __syncthreads();
-  if (tid < SBT_NW) L.tile[tid][SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
-  if (tid < 2 * NXCD) {
-    const u32 li = (u32)(tid & (NXCD - 1)) * nSeg + seg;
-    if (PAIRS)
-      L.scratch[tid] = tid < NXCD ? list_len<u32>(in.PS, li) : list_len<u64>(in.PF, li);
-    else
-      L.scratch[tid] = list_len<u32>(tid < NXCD ? in.PS : in.PE, li);
+  if (tid < SBT_NW) scr[(u32)tid * tw + SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
+  if (!HOIST) {   // (round 4's order: the loads behind the clearing, a barrier of their own)
+    if (tid < 2 * NXCD) {
+      const u32 li = (u32)(tid & (NXCD - 1)) * nSeg + seg;
+      if (PAIRS)
+        L.scratch[tid] = tid < NXCD ? list_len<u32>(in.PS, li) : list_len<u64>(in.PF, li);
+      else
+        L.scratch[tid] = list_len<u32>(tid < NXCD ? in.PS : in.PE, li);
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (tid < 2) {
     u32 a = 0;
     for (int x = 0; x < NXCD; x++) {
@@ -511,20 +581,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     L.slotOff[tid] = ptr;
     L.slotCnt[tid] = cnt;
   }
-  // the tiles' chromosome records (thread b: tile b of the bin), in flight next to the keys
-  uint4 ti = make_uint4(0u, 0u, 0u, 0u);
-  if (tid < (int)nT) {
-    const u32 t = segTileBase + tid;
-    if (t < in.nTiles) {
-      const u32 ci = in.tileChrom[t];
-      const DChrom c = in.chroms[ci];
-      const u32 tl = t - c.tileBase;
-      ti.x = tl << TB;
-      ti.y = c.len;
-      ti.z = (chrom_active(c) ? TM_ACTIVE : 0u) | (tl + 1 == c.nTiles ? TM_LAST : 0u);
-      ti.w = (u32)in.chromW0[ci];
-    }
-  }
+  if (!HOIST) ti = loadTi();
   __syncthreads();
   const bool ovfSlots = L.overflow != 0;
   // ---- 2: the bin's keys, all loads in flight together
@@ -671,7 +728,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     // what this launch does not take: it goes on the list of the second one, untouched
     const u32 hh = tid < (int)nT ? L.hist[tid] : 0u;
     const bool heavyTile = (hh & 0xFFFFu) + (hh >> 16) > SBT_HEAVY;
-    const bool big = __syncthreads_or((int)heavyTile) || ovfSlots || L.startC[nT] > SBT_KEYCAP || L.overflow == 1;
+    const bool big = __syncthreads_or((int)heavyTile) || ovfSlots || L.startC[nT] > keyCap || L.overflow == 1;
     if (big) {  // block-uniform
       if (tid == 0) out.bigList[atomicAdd(out.nBig, 1u)] = seg;
       return;
@@ -683,7 +740,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   if (BIG && tid == 0) {
     u32 nr = 0;
     bool fits = true;
-    if (L.startC[nT] <= SBT_KEYCAP) {
+    if (L.startC[nT] <= keyCap) {
       L.rnd[0] = 0;
       L.rnd[1] = nT;
       nr = 1;
@@ -693,7 +750,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       while (tb < nT && fits) {
         // the last tile whose keys still fit behind tb's (startC grows: a bisection)
         u32 lo = tb, hi = nT;
-        const u32 lim = L.startC[tb] + SBT_KEYCAP;
+        const u32 lim = L.startC[tb] + keyCap;
         while (lo < hi) {
           const u32 mid = (lo + hi + 1) >> 1;
           if (L.startC[mid] <= lim) lo = mid; else hi = mid - 1;
@@ -711,7 +768,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   if (BIG) __syncthreads();
   const u32 nRounds = BIG ? L.nRounds : 1u;
   const u32 ovfWord = PAIRS ? L.overflow : 0u;  // (pair mode: 1 too many singles, 2 a fractional weight among them)
-  const bool ovfReal = ovfSlots || (BIG ? nRounds == 0 : L.startC[nT] > SBT_KEYCAP) || ovfWord != 0;
+  const bool ovfReal = ovfSlots || (BIG ? nRounds == 0 : L.startC[nT] > keyCap) || ovfWord != 0;
   const bool ovf = ovfReal || GX_EXP_SBT == 1 || GX_EXP_SBT == 2;
   // (the slot capacity bounds a stream at 32 K keys -- pair mode: 32 K pairs and SBT_FCAP singles --, so a tile's 16-bit
   // counts cannot have wrapped)
@@ -755,7 +812,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   if (tid == 0) L.work = 0;
   __syncthreads();  // the cursors are there
   auto place = [&](u32 key, u32 curBase, u32 flag) {
-    L.keys[atomicAdd(&L.cur[curBase + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | flag);
+    keysL[atomicAdd(&L.cur[curBase + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | flag);
   };
   // the wavefronts take the tiles [L.work .. tileEnd) from a counter; keyBase: where the first key in LDS lies in the bin's order
   auto tiles = [&](u32 tileEnd, u32 keyBase) {
@@ -781,7 +838,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       const uint4 tf = L.tinfo[b];
       const u32 sc = L.startC[b];
       const int carry = segNet + (FRAC ? 1 : GX_UNIT) * L.netPref[b] - (int)tf.w;
-      sbt_tile<FRAC>(L.tile[wv], L.keys + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad, fragTerms, fhi, flo);
+      sbt_tile<FRAC>(scr + (u32)__builtin_amdgcn_readfirstlane(wv) * tw, trCap, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad, fragTerms, fhi, flo);
     }
     if constexpr (BIG) {
     __syncthreads();  // (every wavefront is through with its tiles; the list of the heavy ones is complete)
@@ -793,12 +850,12 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         const uint4 tf = L.tinfo[b];
         const u32 sc = L.startC[b];
         const int carry = segNet + (FRAC ? 1 : GX_UNIT) * L.netPref[b] - (int)tf.w;
-        sbt_heavy<FRAC>(L, L.keys + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad, fragTerms);
+        sbt_heavy<FRAC>(L, scrWords, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad, fragTerms);
       }
       // the wavefronts' scratch as the next round's tiles expect it
-      for (int i = tid * 4; i < SBT_NW * SBT_TW; i += SBT_NT * 4) *reinterpret_cast<int4*>(&L.tile[0][0] + i) = make_int4(0, 0, 0, 0);
+      for (u32 i = (u32)tid * 4; i < scrWords; i += SBT_NT * 4) *reinterpret_cast<int4*>(scr + i) = make_int4(0, 0, 0, 0);
       __syncthreads();
-      if (tid < SBT_NW) L.tile[tid][SBT_OCCW + TILE / 64] = -1;
+      if (tid < SBT_NW) scr[(u32)tid * tw + SBT_OCCW + TILE / 64] = -1;
       if (tid == 0) L.nHeavy = 0;
       __syncthreads();
     }
@@ -813,8 +870,8 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         const u32 so = ((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r), eo = (e & (TILE - 1)) | 0x8000u | pairCls(r);
         const u32 ps = atomicAdd(&L.cur[ts], ts == te ? 2u : 1u);
         const u32 pe = ts == te ? ps + 1u : atomicAdd(&L.cur[te], 1u);
-        L.keys[ps] = (uint16_t)so;
-        L.keys[pe] = (uint16_t)eo;
+        keysL[ps] = (uint16_t)so;
+        keysL[pe] = (uint16_t)eo;
       };
 #pragma unroll
       for (int i = 0; i < K; i++) {
@@ -830,11 +887,11 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       for (u32 i = tid; i < nF; i += SBT_NT) {
         const u64 r = srcF.at(i);
         const u32 off = (u32)(r >> 8) & (TILE - 1);
-        L.keys[atomicAdd(&L.cur[(u32)(r >> 32) - segTileBase], 1u)] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
+        keysL[atomicAdd(&L.cur[(u32)(r >> 32) - segTileBase], 1u)] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
       }
       __syncthreads();
       if (GX_EXP_SBT == 3) {
-        if (tid < (int)nT && segTileBase + tid < in.nTiles) out.to.tileCount[segTileBase + tid] = L.keys[L.startC[tid]] == 0xFFFFu;
+        if (tid < (int)nT && segTileBase + tid < in.nTiles) out.to.tileCount[segTileBase + tid] = keysL[L.startC[tid]] == 0xFFFFu;
         return;
       }
       tiles(nT, 0u);
@@ -853,13 +910,13 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         }
         slotsFrom(0, [&](u32 r) {
           const u32 e = pairEnd(r), ts = pairTs(r), te = e >> TB;
-          if (ts - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[ts], 1u) - keyBase] = (uint16_t)(((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r));
-          if (te - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)((e & (TILE - 1)) | 0x8000u | pairCls(r));
+          if (ts - tileBeg < tileEnd - tileBeg) keysL[atomicAdd(&L.cur[ts], 1u) - keyBase] = (uint16_t)(((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r));
+          if (te - tileBeg < tileEnd - tileBeg) keysL[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)((e & (TILE - 1)) | 0x8000u | pairCls(r));
         });
         for (u32 i = tid; i < nF; i += SBT_NT) {
           const u64 r = srcF.at(i);
           const u32 tl = (u32)(r >> 32) - segTileBase, off = (u32)(r >> 8) & (TILE - 1);
-          if (tl - tileBeg < tileEnd - tileBeg) L.keys[atomicAdd(&L.cur[tl], 1u) - keyBase] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
+          if (tl - tileBeg < tileEnd - tileBeg) keysL[atomicAdd(&L.cur[tl], 1u) - keyBase] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
         }
         __syncthreads();
         tiles(tileEnd, keyBase);
@@ -874,7 +931,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
 #pragma unroll
       for (int j = 0; j < 4; j++) ps[j] = atomicAdd(&L.cur[(keyAt(kS[i], j) >> TB) - segTileBase], 1u);
 #pragma unroll
-      for (int j = 0; j < 4; j++) L.keys[ps[j]] = (uint16_t)(keyAt(kS[i], j) & (TILE - 1));
+      for (int j = 0; j < 4; j++) keysL[ps[j]] = (uint16_t)(keyAt(kS[i], j) & (TILE - 1));
     } else if (cS[i]) {
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -885,7 +942,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
 #pragma unroll
       for (int j = 0; j < 4; j++) ps[j] = atomicAdd(&L.cur[SBT_TILES + (keyAt(kE[i], j) >> TB) - segTileBase], 1u);
 #pragma unroll
-      for (int j = 0; j < 4; j++) L.keys[ps[j]] = (uint16_t)((keyAt(kE[i], j) & (TILE - 1)) | 0x8000u);
+      for (int j = 0; j < 4; j++) keysL[ps[j]] = (uint16_t)((keyAt(kE[i], j) & (TILE - 1)) | 0x8000u);
     } else if (cE[i]) {
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -894,7 +951,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   }
   __syncthreads();
   if (GX_EXP_SBT == 3) {
-    if (tid < (int)nT && segTileBase + tid < in.nTiles) out.to.tileCount[segTileBase + tid] = L.keys[L.startC[tid]] == 0xFFFFu;
+    if (tid < (int)nT && segTileBase + tid < in.nTiles) out.to.tileCount[segTileBase + tid] = keysL[L.startC[tid]] == 0xFFFFu;
     return;
   }
   tiles(nT, 0u);

@@ -80,5 +80,10 @@ def test_dups_mid_on_the_device_is_the_references(sam):
             else:
                 assert not rep
         times[mode] = best
-    print(f"\n[dups_mid] {META['alignments']} alignments, SAM text -> narrowPeak with -r: device tables {times['device']:.2f} s, "
-          f"host tables {times['host']:.2f} s (wall, process start and HIP initialisation included)")
+    line = (f"[dups_mid] {META['alignments']} alignments, SAM text -> narrowPeak with -r: device tables {times['device']:.2f} s, "
+            f"host tables {times['host']:.2f} s (best of 2; wall, process start and HIP initialisation included; "
+            f"{os.cpu_count()} host cores)")
+    print("\n" + line)
+    rep = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(rep):   # (on the GPU box: the only directory that travels back)
+        open(os.path.join(rep, "dups_mid_times.txt"), "a").write(line + "\n")

@@ -278,8 +278,8 @@ def test_replicates_keep_their_exact_pileups_until_somebody_asks():
     assert h.path_info() & PILES_MADE
     h.reset()                                 # the kept buffers go back to the pool: a second run of the same context
     sh = B.run_case(h, case)
-    assert_same_run(o, h, so, sh, case)
     assert not h.path_info() & PILES_MADE
+    assert_same_run(o, h, so, sh, case)
 
 
 def test_switches_are_read_when_the_context_is_made_and_can_be_set_on_it(monkeypatch):
