@@ -454,7 +454,6 @@ int gx_sample_no_control(gx_ctx* ctx, float* lambda) {
 int gx_pvalues(gx_ctx* ctx) {
   if (!ctx || (ctx->phase != 4 && ctx->phase != 5)) return GX_ERR_ORDER;
   HIPCHECK(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
   PArray pa;
   pa.present.assign(ctx->nChrom, 0);
   for (u32 i = 0; i < ctx->nChrom; i++) pa.present[i] = !ctx->skip[i] && ctx->save[i];

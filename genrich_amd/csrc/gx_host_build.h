@@ -410,14 +410,15 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     if (!ctx->sbtLdsSet) {
       for (const void* f : {reinterpret_cast<const void*>(k_sbtile<false, false, false>), reinterpret_cast<const void*>(k_sbtile<true, false, false>),
                             reinterpret_cast<const void*>(k_sbtile<true, true, false>), reinterpret_cast<const void*>(k_sbtile<true, false, true>),
-                            reinterpret_cast<const void*>(k_sbtile<true, true, true>)})
+                            reinterpret_cast<const void*>(k_sbtile<true, true, true>), reinterpret_cast<const void*>(k_sbtile<true, true, false, SBT_TR_DENSE>),
+                            reinterpret_cast<const void*>(k_sbtile<true, true, true, SBT_TR_DENSE>)})
         HIPCHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SBT_LDS_BYTES));
       ctx->sbtLdsSet = true;
     }
     HIPCHECK(ctx->bigBins.ensure((size_t)(MAX_BINS_P + 4) * 4));
     SbtIn si{PG3[0], PG3[1], PG3[2], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
              ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, sbS,
-             ctx->fracPairsUsed ? (const FragFix*)ff : (const FragFix*)nullptr, ctx->fracPairsUsed ? acc : (long long*)nullptr, (u32)SBT_TR};
+             ctx->fracPairsUsed ? (const FragFix*)ff : (const FragFix*)nullptr, ctx->fracPairsUsed ? acc : (long long*)nullptr};
     SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>(), ctx->nWide.as<u32>() + 1, ctx->nWide.as<u32>() + 13,
                ctx->bigBins.as<u32>(), ctx->heavyList.as<u32>(), ctx->nWide.as<u32>() + 2};
     const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
@@ -428,18 +429,18 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       so2.bigList = nullptr;
       // touched bases per round of the tile passes against keys per round of a bin (they share the LDS, gx_sbtile.h): what
       // costs a dense sample is the number of rounds a bin takes -- each reads the bin's records again --, so: the
-      // largest TR among those that give the fewest rounds for the average bin (with a margin for the fuller ones)
+      // instance with the smaller scratch when that saves the average bin (with a margin for the fuller ones) a round
       const size_t avgKeys = (size_t)2 * nEv / std::max(1u, nL1), want = avgKeys + avgKeys / 32;
-      u32 best = (u32)SBT_TR, bestRounds = ~0u;
-      for (u32 tr = 448; tr >= 192; tr -= 64) {
-        const u32 rounds = (u32)((want + sbt_keycap(tr) - 1) / sbt_keycap(tr));
-        if (rounds < bestRounds) { bestRounds = rounds; best = tr; }
+      auto rounds = [&](u32 tr) { return (want + sbt_keycap(tr) - 1) / sbt_keycap(tr); };
+      bool small = rounds((u32)SBT_TR_DENSE) < rounds((u32)SBT_TR);
+      if (K.sbtTr) small = K.sbtTr == SBT_TR_DENSE;   // (measurements)
+      if (ctx->fracPairsUsed) {
+        if (small) hipLaunchKernelGGL((k_sbtile<true, true, true, SBT_TR_DENSE>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
+        else hipLaunchKernelGGL((k_sbtile<true, true, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
+      } else {
+        if (small) hipLaunchKernelGGL((k_sbtile<true, true, false, SBT_TR_DENSE>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
+        else hipLaunchKernelGGL((k_sbtile<true, true, false>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       }
-      si.tr = K.sbtTr >= 192 && K.sbtTr <= 448 && K.sbtTr % 64 == 0 ? (u32)K.sbtTr : best;
-      if (ctx->fracPairsUsed)
-        hipLaunchKernelGGL((k_sbtile<true, true, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
-      else
-        hipLaunchKernelGGL((k_sbtile<true, true, false>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
     } else if (ctx->fracPairsUsed) {
       hipLaunchKernelGGL((k_sbtile<true, false, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       hipLaunchKernelGGL((k_sbtile<true, true, true>), gBig, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());

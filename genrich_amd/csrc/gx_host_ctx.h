@@ -163,7 +163,7 @@ struct Knobs {
   long long runCapMin = 0;  // GX_RUN_CAP_MIN: the sweep's first guess of the run count (a tiny one forces the second pass)
   int bhCapLog = 0;       // GX_BH_CAPLOG: log2 of the BH table's first size
   int ptJmax = 0;         // GX_PT_JMAX: pages per level-1 list at first
-  int sbtTr = 0;          // GX_SBT_TR: touched bases per round of the tile passes in k_sbtile's second launch of a dense sample (measurements)
+  int sbtTr = 0;          // GX_SBT_TR: 384 / 448: which instance of k_sbtile's dense launch runs (measurements; default: by the sample's density)
   int fault = 0;          // GX_FAULT: fault injection for the tests of the device-side invariants.  1: the weight of the ends at
                           // chromosome 0's length is damaged behind level 1 of the sort (as if an end record had been lost)
 };

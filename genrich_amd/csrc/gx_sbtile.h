@@ -67,11 +67,13 @@ constexpr u32 SBT_FCAP = 16384;                        // pair mode: singles of 
 // on average instead of 2.65 (counted on the bench's stream).  448 covers them in one.  The price is LDS (6 bytes per base
 // and wavefront), which comes out of the key array: the two share what the tables leave of the 160 KiB (sbt_keycap).
 //   The ordinary launch is compiled for SBT_TR = 448 (47 K keys: a bin of that sample holds 34 K, the fullest 37 K).  The
-// second launch -- the bins beyond the key array, worked off in rounds of tiles -- takes TR at run time (SbtIn::tr): what
-// costs there is the number of rounds, every one of which reads the bin's records again, so the host picks the largest
-// TR that still gives the fewest rounds (an ATAC sample with 95 K keys per bin: 384 -> 50 K keys, two rounds; 448 would
-// need three: measured 2.21 against 2.51 ms).
+// launch of a DENSE sample -- every bin beyond the key array, worked off in rounds of tiles -- exists for 448 and for
+// SBT_TR_DENSE = 384 (50 K keys): what costs there is the number of rounds, every one of which reads the bin's records
+// again, so the host picks the instance that gives fewer rounds (an ATAC sample with 95 K keys per bin: two rounds with
+// 384, three with 448: measured 2.21 against 2.51 ms).  (TR as a run-time value of one instance: 2.48 ms -- the rounds
+// kernel sits at 126 VGPRs and spills scalars; constants matter there.)
 constexpr int SBT_TR = GX_SBT_TR;
+constexpr int SBT_TR_DENSE = 384;
 // a wavefront's scratch, in words: occupancy bitmap (+ a dummy word that absorbs the lanes without a key), the words'
 // prefix counts (+ a dummy entry that ranks those lanes out of every round), counters and offsets by rank
 constexpr int SBT_OCCW = TILE / 32 + 4, SBT_PREW = TILE / 64 + 4;
@@ -81,14 +83,15 @@ static_assert(SBT_TR % 64 == 0, "the last step of a round reads whole wavefronts
 static_assert((1u << PgCfg<u32>::SHIFT) % SBT_SLOT == 0, "a slot never crosses a page");
 static_assert(TILE == 4096, "13-bit LDS keys: 12 bits of offset and the stream");
 static_assert((SBT_NW * sbt_tw(64)) % 4 == 0 && (SBT_NW * 96) % 4 == 0, "the scratch is cleared by 16-byte stores (TR: a multiple of 64)");
-constexpr u32 SBT_LDS_BYTES = 160u * 1024u;           // what a launch asks for: one workgroup per CU
+constexpr u32 SBT_LDS_BYTES = 160u * 1024u - 512u;    // what a launch asks for (dynamic; the kernel's few static words come on top): one workgroup per CU
 
 struct SbtLds {
   u32 hist[SBT_TILES];                     // [15:0] start keys, [31:16] end keys of the tile
   u32 startC[SBT_TILES + 1];               // keys (both streams) of the bin before the tile
   int netPref[SBT_TILES];                  // start keys - end keys of the bin before the tile
   u32 cur[2 * SBT_TILES];                  // scatter cursors: starts, ends
-  uint4 tinfo[SBT_TILES];                  // pos0, chromosome length, TM_ flags, weight dropped by earlier chromosomes
+  uint4 tinfo[SBT_TILES];                  // what a wavefront needs to start a tile, one 16-byte read: pos0, chromosome length,
+                                           // TM_ flags | keys of the tile << 8, carry-in pileup (1/120)
   u32 slotOff[2 * SBT_SLOTS];              // first key of a slot, as an index into its stream's page pool
   u32 slotCnt[2 * SBT_SLOTS];
   u32 pre[2][NXCD + 1];
@@ -107,8 +110,8 @@ struct SbtLds {
   __attribute__((aligned(16))) int dyn[4];
 };
 constexpr u32 SBT_DYN_OFF = (u32)offsetof(SbtLds, dyn);
-// keys of a super-bucket (both streams) that fit the LDS next to the scratch for TR touched bases per round, in whole K
-__host__ __device__ constexpr u32 sbt_keycap(u32 tr) { return ((SBT_LDS_BYTES - SBT_DYN_OFF - SBT_NW * sbt_tw(tr) * 4u) / 2u - 192u) / 1024u * 1024u; }
+// keys of a super-bucket (both streams) that fit the LDS next to the scratch for TR touched bases per round
+__host__ __device__ constexpr u32 sbt_keycap(u32 tr) { return ((SBT_LDS_BYTES - SBT_DYN_OFF - SBT_NW * sbt_tw(tr) * 4u) / 2u - 192u) / 64u * 64u; }
 constexpr u32 SBT_KEYCAP = sbt_keycap(SBT_TR);        // ... of the ordinary launch
 static_assert(sbt_keycap(192) > sbt_keycap(448) && sbt_keycap(448) >= 40960, "the split of the LDS");
 
@@ -125,7 +128,6 @@ struct SbtIn {
   int sbShift;
   const FragFix* ff;          // fractional pairs: the general fragLen path's switch and accumulator pair (k_tile_fast's TileIn::ff / fragAcc)
   long long* fragAcc;
-  u32 tr;                     // the second launch's touched bases per round (a multiple of 64 in [192, 448]; the first launch: SBT_TR)
 };
 
 struct SbtOut {
@@ -149,8 +151,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // 32-bit byte offsets against a uniform base pointer: one shift instead of 64-bit address arithmetic per store
 #ifndef GX_SBT_KNOBS   // measurement knobs (tools/build_variant.sh): 1 exchange-and-clear, 2 32-bit store offsets, 4 unpredicated key loads,
-#define GX_SBT_KNOBS 39   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off),
-                          // 32 the prologue's global loads ahead of the clearing of the scratch, 64 two steps per turn of a round's loop (off)
+#define GX_SBT_KNOBS 167   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off),
+                          // 32 the prologue's global loads ahead of the clearing of the scratch, 64 two steps per turn of a round's loop (off),
+                          // 128 the tile counter and the significance words without the compiler's atomic optimizer on top
 #endif
 __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
 #if GX_SBT_KNOBS & 2
@@ -158,6 +161,48 @@ __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
 #else
   static_cast<u32*>(base)[index] = v;
 #endif
+}
+
+// Two atomics of the tile loop whose address and value are wave-uniform, issued WITHOUT the compiler's atomic optimizer on
+// top (LLVM's pass picks "the first active lane" itself -- two v_mbcnt, a compare, an exec save -- although the source
+// has already sent one lane, or needs none).  Switching the pass off for the whole library costs k_bh_hist's slot counter
+// 7 ms at config 5, so only these two sites go around it (knob 128; measured 0.558 -> 0.540 ms together with KR = 2):
+//   * the wavefronts' tile counter: DS_APPEND adds the number of active lanes -- all 64 take part, the tile is old / 64;
+//   * the sweep's significance words: one lane's global_atomic_or_x2 as inline assembly.
+__device__ __forceinline__ u32 sbt_next_tile(u32* counter) {
+#if GX_SBT_KNOBS & 128
+  return (u32)__builtin_amdgcn_ds_append((__attribute__((address_space(3))) int*)counter) >> 6;
+#else
+  u32 b = 0;
+  if (lane_id() == 0) b = atomicAdd(counter, 1u);
+  return (u32)__builtin_amdgcn_readfirstlane((int)b);
+#endif
+}
+__device__ __forceinline__ void sbt_or64(u64* __restrict__ base, u32 word, u64 bits) {  // (called by one lane)
+#if GX_SBT_KNOBS & 128
+  const u32 off = word << 3;
+  asm volatile("global_atomic_or_x2 %0, %1, %2" : : "v"(off), "v"(bits), "s"(base) : "memory");
+#else
+  atomicOr((unsigned long long*)&base[word], (unsigned long long)bits);
+#endif
+}
+// sig_flush_m (gx_kernels.h) with these atomics
+__device__ __forceinline__ void sbt_sig_flush(u64* __restrict__ sigMask, u32 pos, u64 sgm, u32 rank, u64 written) {
+  if (!sgm) return;  // wave-uniform
+  u64 m;
+  if (((written + 1ull) & written) == 0ull) {  // wave-uniform: the lanes that wrote are the lanes 0 .. k - 1
+    m = sgm;
+  } else {
+    const bool sg = __builtin_amdgcn_inverse_ballot_w64(sgm);
+    const int lo = sg && rank < 32u ? (int)(1u << rank) : 0, hi = sg && rank >= 32u ? (int)(1u << (rank - 32u)) : 0;
+    const u32 mlo = (u32)__builtin_amdgcn_readlane(dpp_scan_add(lo), 63), mhi = (u32)__builtin_amdgcn_readlane(dpp_scan_add(hi), 63);
+    m = (u64)mlo | ((u64)mhi << 32);
+  }
+  if (lane_id() == 0) {
+    const u32 w = pos >> 6, sh = pos & 63;
+    sbt_or64(sigMask, w, m << sh);
+    if (sh && (m >> (64 - sh))) sbt_or64(sigMask, w + 1, m >> (64 - sh));
+  }
 }
 
 // One tile, one wavefront: the passes of k_tile_fast with the keys in LDS (kl[0 .. n): [11:0] offset, [15] end).
@@ -197,9 +242,12 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
   const u32 negPos0 = 0u - pos0;   // (pos0 + p != 0  <=>  p != -pos0)
   const bool lastTile = (flags & TM_LAST) != 0;
 #ifndef GX_SBT_KR
-#define GX_SBT_KR 3
+#define GX_SBT_KR 2
 #endif
-  constexpr int KR = GX_SBT_KR;  // keys per lane kept in registers (192 per tile)
+  // keys per lane kept in registers: 128 per tile (an ordinary tile of hg38 / 50 M fragments holds ~90, nine in ten at most
+  // 128; the third register of round 4 was all "no key" there and cost its three passes: 0.577 -> 0.567 ms.  Skipping it by
+  // a scalar branch where the tile is small -- knob 8 -- cost more than it saved: 0.572 -> 0.585)
+  constexpr int KR = GX_SBT_KR;
   // (n is wave-uniform -- the caller hands it over in a scalar register: an ordinary tile of hg38 / 50 M fragments holds ~90
   // keys, so the third register-held key is all "no key" there and its three passes are skipped by scalar branches)
 #if (GX_SBT_KNOBS & 8) && GX_SBT_KR == 3
@@ -294,7 +342,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
         st_u32(out.to.looseV, o, (u32)before);
       }
       if (vsig != 0x7FFFFFFF)  // wave-uniform
-        sig_flush_m(out.to.sigMask, slot + outCount, mask & __builtin_amdgcn_sicmp(before, vsig, 39 /* sge */), orank, mask);
+        sbt_sig_flush(out.to.sigMask, slot + outCount, mask & __builtin_amdgcn_sicmp(before, vsig, 39 /* sge */), orank, mask);
       // (a pileup below zero or at the table's end: one unsigned compare finds either, the rare step that has one says which)
       if (__builtin_amdgcn_uicmp((u32)after, (u32)FRAG_FAST_MAXV, 35 /* uge */)) {  // wave-uniform
         negM |= __ballot(after < 0);
@@ -474,7 +522,7 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
 // array holds (worked off in rounds of tiles), a tile with thousands of keys (sbt_heavy: the whole workgroup), more than
 // 32 K pair records.  It keeps no record in registers (every pass reads the bin's slots from global memory: they are
 // in L2), so that none of this costs the first launch -- the one every bin of an ordinary sample takes -- a register.
-template <bool PAIRS, bool BIG, bool FRAC>
+template <bool PAIRS, bool BIG, bool FRAC, int TRC>
 __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32* __restrict__ st, const u32 seg, SbtLds& L) {
   static_assert(PAIRS || !BIG, "the second launch exists in pair mode only");
   static_assert(PAIRS || !FRAC, "fractional weights ride pair records only");
@@ -486,9 +534,10 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   constexpr int KR = K ? K : 1;                           // (array sizes)
   constexpr u32 NSLOTS = (u32)KX * SBT_NW;
   const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-  // how the LDS behind the tables is split (the ordinary launch: constants)
-  const u32 trCap = BIG ? (u32)__builtin_amdgcn_readfirstlane((int)in.tr) : (u32)SBT_TR;
-  const u32 tw = sbt_tw(trCap), scrWords = SBT_NW * tw, keyCap = BIG ? sbt_keycap(trCap) : SBT_KEYCAP;
+  // how the LDS behind the tables is split: constants of the instance (runtime values cost the rounds launch 12 %: measured)
+  static_assert(TRC % 64 == 0 && TRC >= 192 && TRC <= 448, "touched bases per round");
+  constexpr u32 trCap = (u32)TRC;
+  constexpr u32 tw = sbt_tw(trCap), scrWords = SBT_NW * tw, keyCap = sbt_keycap(trCap);
   int* const scr = L.dyn;
   uint16_t* const keysL = reinterpret_cast<uint16_t*>(L.dyn + scrWords);
   const u32 nSeg = in.nSeg;
@@ -611,7 +660,6 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   const u32 nF = PAIRS && !ovfSlots ? L.pre[1][NXCD] : 0u;
   // (16-bit counts per tile: the bin's pairs and singles together stay below 2^16)
   if (PAIRS && tid == 0 && (nF > SBT_FCAP || L.pre[0][NXCD] + nF > 65535u)) L.overflow = 1;  // (read behind the histogram's barrier)
-  if (tid < (int)nT) L.tinfo[tid] = ti;
   if (GX_EXP_SBT == 1) {
     u32 x = 0;
 #pragma unroll
@@ -798,6 +846,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       m.pos0 = ti.x; m.len = ti.y; m.flags = ti.z;
       m.slot = segSlot + sc + (u32)tid;
       out.meta[t] = m;
+      L.tinfo[tid] = make_uint4(ti.x, ti.y, ti.z | ((nS + nE) << 8), (u32)m.carry);
       out.tileSlot[t] = m.slot;
       if (t + 1 == in.nTiles) out.tileSlot[in.nTiles] = m.slot + nS + nE + 1;
     }
@@ -809,7 +858,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   }
   u32 bad = 0;
   // ---- 4: the keys to their tiles' lists in LDS; then the wavefronts take tiles from a counter
-  if (tid == 0) L.work = 0;
+  if (tid == 0) L.work = 0;   // (knob 128: the counter runs in units of 64 -- DS_APPEND adds the wavefront's 64 lanes)
   __syncthreads();  // the cursors are there
   auto place = [&](u32 key, u32 curBase, u32 flag) {
     keysL[atomicAdd(&L.cur[curBase + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | flag);
@@ -823,22 +872,20 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       u32 b = 0;
       if constexpr (STATIC_DEAL)
         b = (u32)__builtin_amdgcn_readfirstlane(wv) + it * (u32)SBT_NW;
-      else {
-        if (lane == 0) b = atomicAdd(&L.work, 1u);
-        b = (u32)__builtin_amdgcn_readfirstlane((int)b);
-      }
+      else
+        b = sbt_next_tile(&L.work);
       if (b >= tileEnd) break;
       const u32 t = segTileBase + b;
       if (t >= in.nTiles) continue;
-      const u32 h = (u32)__builtin_amdgcn_readfirstlane((int)L.hist[b]), n = (h & 0xFFFFu) + (h >> 16);
+      const uint4 tf = L.tinfo[b];
+      const u32 sc = L.startC[b];
+      const u32 fz = (u32)__builtin_amdgcn_readfirstlane((int)tf.z), n = fz >> 8;
       if (BIG && n > SBT_HEAVY) {  // wave-uniform: left to the whole workgroup
         if (lane == 0) L.heavy[atomicAdd(&L.nHeavy, 1u)] = (uint16_t)b;
         continue;
       }
-      const uint4 tf = L.tinfo[b];
-      const u32 sc = L.startC[b];
-      const int carry = segNet + (FRAC ? 1 : GX_UNIT) * L.netPref[b] - (int)tf.w;
-      sbt_tile<FRAC>(scr + (u32)__builtin_amdgcn_readfirstlane(wv) * tw, trCap, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad, fragTerms, fhi, flo);
+      sbt_tile<FRAC>(scr + (u32)__builtin_amdgcn_readfirstlane(wv) * tw, trCap, keysL + (sc - keyBase), n, t, tf.x, tf.y, fz & 0xFFu, (int)tf.w,
+                     segSlot + sc + b, vsig, out, bad, fragTerms, fhi, flo);
     }
     if constexpr (BIG) {
     __syncthreads();  // (every wavefront is through with its tiles; the list of the heavy ones is complete)
@@ -846,11 +893,9 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     if (nH) {  // block-uniform
       for (u32 i = 0; i < nH; i++) {
         const u32 b = L.heavy[i], t = segTileBase + b;
-        const u32 h = L.hist[b], n = (h & 0xFFFFu) + (h >> 16);
         const uint4 tf = L.tinfo[b];
-        const u32 sc = L.startC[b];
-        const int carry = segNet + (FRAC ? 1 : GX_UNIT) * L.netPref[b] - (int)tf.w;
-        sbt_heavy<FRAC>(L, scrWords, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z, carry, segSlot + sc + b, vsig, out, bad, fragTerms);
+        const u32 sc = L.startC[b], n = tf.z >> 8;
+        sbt_heavy<FRAC>(L, scrWords, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z & 0xFFu, (int)tf.w, segSlot + sc + b, vsig, out, bad, fragTerms);
       }
       // the wavefronts' scratch as the next round's tiles expect it
       for (u32 i = (u32)tid * 4; i < scrWords; i += SBT_NT * 4) *reinterpret_cast<int4*>(scr + i) = make_int4(0, 0, 0, 0);
@@ -905,7 +950,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         const u32 tileBeg = L.rnd[round], tileEnd = L.rnd[round + 1], keyBase = L.startC[tileBeg];
         if (round) {
           __syncthreads();  // (the previous round's tiles are through with the keys)
-          if (tid == 0) L.work = tileBeg;
+          if (tid == 0) L.work = (GX_SBT_KNOBS & 128) ? tileBeg << 6 : tileBeg;
           __syncthreads();
         }
         slotsFrom(0, [&](u32 r) {
@@ -967,17 +1012,17 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   if (bad && lane == 0) atomicOr(st, bad);
 }
 
-template <bool PAIRS, bool BIG, bool FRAC>
+template <bool PAIRS, bool BIG, bool FRAC, int TRC = SBT_TR>
 __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
   SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
   if constexpr (!BIG)
-    sbt_bin<PAIRS, false, FRAC>(in, out, st, blockIdx.x, L);
+    sbt_bin<PAIRS, false, FRAC, TRC>(in, out, st, blockIdx.x, L);
   else {
     // (no list: a sample so dense that most bins need rounds -- the host sends every bin here and skips the first launch)
     const u32 nBig = out.bigList ? *out.nBig : in.nSeg;
     for (u32 item = blockIdx.x; item < nBig; item += gridDim.x) {  // (usually none)
-      sbt_bin<PAIRS, true, FRAC>(in, out, st, out.bigList ? out.bigList[item] : item, L);
+      sbt_bin<PAIRS, true, FRAC, TRC>(in, out, st, out.bigList ? out.bigList[item] : item, L);
       __syncthreads();
     }
   }

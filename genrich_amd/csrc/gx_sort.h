@@ -1107,7 +1107,6 @@ __device__ __forceinline__ void bucket2p_body(const PagedStream& P, typename B2O
   constexpr int ITEMS = ScCfg<R>::ITEMS;
   constexpr int CHUNK = B2_NT * ITEMS;
   constexpr int FITEMS = B2Cfg<R>::FITEMS;
-  constexpr u32 FCAP = (u32)FITEMS * B2_NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char b2_lds[];
   __shared__ u32 pre[NXCD + 1];
   __shared__ u64 slotPtr[B2Cfg<R>::FITEMS];
