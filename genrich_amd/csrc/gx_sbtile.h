@@ -151,9 +151,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // 32-bit byte offsets against a uniform base pointer: one shift instead of 64-bit address arithmetic per store
 #ifndef GX_SBT_KNOBS   // measurement knobs (tools/build_variant.sh): 1 exchange-and-clear, 2 32-bit store offsets, 4 unpredicated key loads,
-#define GX_SBT_KNOBS 167   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off),
+#define GX_SBT_KNOBS 39   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off),
                           // 32 the prologue's global loads ahead of the clearing of the scratch, 64 two steps per turn of a round's loop (off),
-                          // 128 the tile counter and the significance words without the compiler's atomic optimizer on top
+                          // 128 the tile counter, 256 the significance words without the compiler's atomic optimizer on top
 #endif
 __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
 #if GX_SBT_KNOBS & 2
@@ -165,10 +165,13 @@ __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
 
 // Two atomics of the tile loop whose address and value are wave-uniform, issued WITHOUT the compiler's atomic optimizer on
 // top (LLVM's pass picks "the first active lane" itself -- two v_mbcnt, a compare, an exec save -- although the source
-// has already sent one lane, or needs none).  Switching the pass off for the whole library costs k_bh_hist's slot counter
-// 7 ms at config 5, so only these two sites go around it (knob 128; measured 0.558 -> 0.540 ms together with KR = 2):
-//   * the wavefronts' tile counter: DS_APPEND adds the number of active lanes -- all 64 take part, the tile is old / 64;
-//   * the sweep's significance words: one lane's global_atomic_or_x2 as inline assembly.
+// has already sent one lane, or needs none).  Measured in round 5: the whole library built without the pass gives the tile
+// stage 0.558 -> 0.548 ms and costs k_bh_hist's slot counter 7 ms at config 5, so only these two sites would go around it:
+//   * knob 128: the wavefronts' tile counter by DS_APPEND (adds the number of active lanes: all 64 take part, tile = old / 64);
+//   * knob 256: the sweep's significance words by one lane's global_atomic_or_x2 as inline assembly.
+// NOT ADOPTED: each alone gave the oracle's bits in every run, the two together gave wrong intervals in the FIRST sample of a
+// process twice out of twice (a tower's bin on the second launch; not explained) -- for 0.01 ms the default keeps the
+// compiler's atomics.  The code stays for the measurement.
 __device__ __forceinline__ u32 sbt_next_tile(u32* counter) {
 #if GX_SBT_KNOBS & 128
   return (u32)__builtin_amdgcn_ds_append((__attribute__((address_space(3))) int*)counter) >> 6;
@@ -179,7 +182,7 @@ __device__ __forceinline__ u32 sbt_next_tile(u32* counter) {
 #endif
 }
 __device__ __forceinline__ void sbt_or64(u64* __restrict__ base, u32 word, u64 bits) {  // (called by one lane)
-#if GX_SBT_KNOBS & 128
+#if GX_SBT_KNOBS & 256
   const u32 off = word << 3;
   asm volatile("global_atomic_or_x2 %0, %1, %2" : : "v"(off), "v"(bits), "s"(base) : "memory");
 #else
