@@ -36,7 +36,8 @@
 namespace gx {
 
 // measurement hook (tools/build_variant.sh -DGX_EXP_SBT=n): k_sbtile stops after its loads (1), its histogram and
-// scan (2), its scatter (3) and leaves empty tiles behind -- where the kernel's time goes.  0: the product.
+// scan (2), its scatter (3) and leaves empty tiles behind -- where the kernel's time goes; 4: at once, 5: after the
+// lists' lengths (both leave garbage behind: timing only).  0: the product.
 #ifndef GX_EXP_SBT
 #define GX_EXP_SBT 0
 #endif
@@ -153,7 +154,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef GX_SBT_KNOBS   // measurement knobs (tools/build_variant.sh): 1 exchange-and-clear, 2 32-bit store offsets, 4 unpredicated key loads,
 #define GX_SBT_KNOBS 39   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off),
                           // 32 the prologue's global loads ahead of the clearing of the scratch, 64 two steps per turn of a round's loop (off),
-                          // 128 the tile counter, 256 the significance words without the compiler's atomic optimizer on top
+                          // 128 the tile counter, 256 the significance words without the compiler's atomic optimizer on top (off: see below),
+                          // 512 the ordinary launch reads its pair records by a static deal of classes and chunks: no length, no barrier ahead of the loads
 #endif
 __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
 #if GX_SBT_KNOBS & 2
@@ -567,6 +569,40 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     return ti;
   };
   constexpr bool HOIST = (GX_SBT_KNOBS & 32) != 0;
+  auto expLeave = [&]() {   // (measurement exits: empty tiles with valid slots behind them)
+    if (tid < (int)nT && segTileBase + tid < in.nTiles) {
+      const u32 t = segTileBase + tid;
+      TileMeta m{};
+      m.slot = t;
+      out.meta[t] = m;
+      out.tileSlot[t] = t;
+      if (t + 1 == in.nTiles) out.tileSlot[in.nTiles] = in.nTiles;
+      out.to.tileCount[t] = 0;
+    }
+  };
+  if (GX_EXP_SBT == 4) { expLeave(); return; }   // (measurement: what launching the workgroups costs)
+  // The ordinary launch on pair records: which records a wavefront reads does not wait for the lists' lengths.  Wavefront w
+  // takes class w & 7 (a bin's eight page lists, one per XCD class of level 1's workgroups) and of it the chunks of 256
+  // records number 2 i + (w >> 3), i = 0 .. 7 -- all inside the list's fixed first page, whose address is a function of
+  // the list's number.  The loads leave with the kernel's first instructions, next to the one length the wavefront needs;
+  // what lies behind the list's end is read (the page is there) and masked by the counts.  Round 4's mapping cut the
+  // lists into slots by a prefix over the lengths: lengths -> barrier -> slot table -> barrier -> loads, two round trips
+  // of a CU that has nothing else to run (GX_EXP_SBT: 0.13 of the kernel's 0.55 ms pass before the first key arrives).
+  // A class with more than 4096 records (a bin of > 32 K pairs: reads piled up) sends the bin to the second launch.
+  constexpr bool EARLY = PAIRS && !BIG && HOIST && (GX_SBT_KNOBS & 512) != 0;
+  constexpr int KE = EARLY ? SBT_KP : 1;
+  uint4 kEarly[KE];
+  u32 lenMine = 0;
+  if constexpr (EARLY) {
+    static_assert(SBT_KP == 8 && SBT_NW == 16 && NXCD == 8 && SBT_SLOT == 256, "wavefront w: class w & 7, chunks 2 i + (w >> 3)");
+    static_assert((1u << PgCfg<u32>::SHIFT) >= 16u * SBT_SLOT, "sixteen chunks inside a list's first page");
+    const u32 wU = (u32)__builtin_amdgcn_readfirstlane(wv);
+    const u32 li = (wU & 7u) * nSeg + seg;
+    lenMine = list_len<u32>(in.PS, li);
+    const uint4* __restrict__ pg = reinterpret_cast<const uint4*>(in.PS.pool) + ((size_t)first_page(li) << (PgCfg<u32>::SHIFT - 2));
+#pragma unroll
+    for (int i = 0; i < KE; i++) kEarly[i] = pg[(2u * (u32)i + (wU >> 3)) * (SBT_SLOT / 4) + (u32)lane];
+  }
   if (HOIST && tid < 2 * NXCD) {
     const u32 li = (u32)(tid & (NXCD - 1)) * nSeg + seg;
     if (PAIRS)
@@ -585,6 +621,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   if (tid == 0) { L.overflow = 0; L.nHeavy = 0; }
   if (HOIST && tid < 2 * NXCD) L.scratch[tid] = myLen;
   __syncthreads();
+  if (EARLY && tid < NXCD && L.scratch[tid] > 16u * SBT_SLOT) L.overflow = 1;   // (read behind the next barrier)
   if (tid < SBT_NW) scr[(u32)tid * tw + SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
   if (!HOIST) {   // (round 4's order: the loads behind the clearing, a barrier of their own)
     if (tid < 2 * NXCD) {
@@ -605,8 +642,9 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     L.pre[tid][NXCD] = a;
   }
   __syncthreads();
+  if (GX_EXP_SBT == 5) { expLeave(); return; }   // (measurement: ... and clearing the scratch, the lists' lengths)
   // ---- 1: slot descriptors (thread k of the first 2 SBT_SLOTS: slot k & 127 of stream k >> 7)
-  if (tid < (PAIRS ? 1 : 2) * (int)NSLOTS) {
+  if (!EARLY && tid < (PAIRS ? 1 : 2) * (int)NSLOTS) {
     const int q = tid / (int)NSLOTS;
     const u32 k = (u32)tid % NSLOTS;
     const PagedStream& P = q ? in.PE : in.PS;
@@ -641,16 +679,26 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   const uint4* __restrict__ poolE = reinterpret_cast<const uint4*>(in.PE.pool);
   uint4 kS[KR], kE[PAIRS ? 1 : KR];
   u32 cS[KR], cE[PAIRS ? 1 : KR];
+  const u32 lenW = EARLY ? (u32)__builtin_amdgcn_readfirstlane((int)lenMine) : 0u;
 #pragma unroll
-  for (int i = 0; i < K; i++)  // (wave-uniform: scalar registers)
-    cS[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
+  for (int i = 0; i < K; i++) {  // (wave-uniform: scalar registers)
+    if constexpr (EARLY) {
+      const u32 first = (2u * (u32)i + ((u32)__builtin_amdgcn_readfirstlane(wv) >> 3)) * SBT_SLOT;
+      cS[i] = ovfSlots || lenW <= first ? 0u : min(SBT_SLOT, lenW - first);
+    } else
+      cS[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
+  }
 #pragma unroll
   for (int i = 0; i < (PAIRS ? 1 : K); i++)
     cE[i] = ovfSlots || PAIRS ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[NSLOTS + i * SBT_NW + wv]);
 #pragma unroll
   for (int i = 0; i < K; i++) {
-    kS[i] = make_uint4(0u, 0u, 0u, 0u);
-    if ((u32)lane * 4 < cS[i]) kS[i] = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
+    if constexpr (EARLY)
+      kS[i] = kEarly[i < KE ? i : 0];   // (what lies behind the list's end is masked by cS)
+    else {
+      kS[i] = make_uint4(0u, 0u, 0u, 0u);
+      if ((u32)lane * 4 < cS[i]) kS[i] = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
+    }
   }
 #pragma unroll
   for (int i = 0; i < (PAIRS ? 1 : K); i++) {

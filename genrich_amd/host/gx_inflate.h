@@ -246,7 +246,11 @@ inline bool inflate(const uint8_t* in, size_t inLen, uint8_t* out, size_t outLen
       }
     } else if (type == 1 || type == 2) {
       if (type == 1) {
-        if (!fixed_tables(T)) return false;
+        // (the fixed code's tables are the same for every block: built once per process, copied -- 43 KB -- instead of
+        // rebuilt entry by entry; thread-safe: a function-local static is initialised once)
+        static const struct Fixed { Tables T; bool ok; Fixed() { ok = fixed_tables(T); } } fixed;
+        if (!fixed.ok) return false;
+        T = fixed.T;
       } else if (!read_dynamic(B, T))
         return false;
       // ---- the block's data
