@@ -429,8 +429,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       so2.bigList = nullptr;
       // touched bases per round of the tile passes against keys per round of a bin (they share the LDS, gx_sbtile.h): what
       // costs a dense sample is the number of rounds a bin takes -- each reads the bin's records again --, so: the
-      // instance with the smaller scratch when that saves the average bin (with a margin for the fuller ones) a round
-      const size_t avgKeys = (size_t)2 * nEv / std::max(1u, nL1), want = avgKeys + avgKeys / 32;
+      // instance with the smaller scratch when that saves the AVERAGE bin a round.  (No margin for the fuller bins: they
+      // take the extra round in either instance.  Config 4, 97.8 K keys per bin against 2 x 50,048: tile stage 2.17 ms
+      // with the small scratch, 2.49 with the large one, three runs each.)
+      const size_t want = (size_t)2 * nEv / std::max(1u, nL1);
       auto rounds = [&](u32 tr) { return (want + sbt_keycap(tr) - 1) / sbt_keycap(tr); };
       bool small = rounds((u32)SBT_TR_DENSE) < rounds((u32)SBT_TR);
       if (K.sbtTr) small = K.sbtTr == SBT_TR_DENSE;   // (measurements)
