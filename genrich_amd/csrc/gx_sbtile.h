@@ -1,5 +1,5 @@
-// gx_sbtile.h -- level 2 of the bucket sort FUSED with the tile stage, for samples of unit-weight records
-// without -E regions (the common case: every config but -s multimapping).
+// gx_sbtile.h -- level 2 of the bucket sort FUSED with the tile stage, for samples without -E regions (unit weights;
+// since round 4 also fractional weights, on pair records with a weight class).
 //
 // Replaces k_scan_bins' consumer chain  k_bucket2p -> k_scan_tiles -> k_tile_meta -> k_tile_fast  (gx_sort.h,
 // gx_kernels.h, gx_tile_fast.h) and with it savePileupExpt's two per-base passes (Genrich.c:2197-2273):
@@ -17,10 +17,13 @@
 //        slot(t)  = start keys before t + end keys before t + t           (as k_tile_meta's)
 //        carry(t) = 120 (starts before t - ends before t) - weight of the ends that earlier chromosomes dropped
 //      (an end at the chromosome's length has no record: k_sort1 counts them per chromosome, endAtLen)
-//   4  the keys are scattered to their tiles' lists in LDS (13-bit values: offset + "is an end"; 112 KB hold 57 K
-//      keys, 1.7x what a bin of config 2 holds) and the sixteen wavefronts take tiles from an LDS counter:
+//   4  the keys are scattered to their tiles' lists in LDS (13-bit values: offset + "is an end"; 92 KB hold 47 K
+//      keys, 1.4x what a bin of config 2 holds -- round 5 moved 24 KB from the keys to the wavefronts' scratch, 448
+//      touched bases per round instead of 192) and the sixteen wavefronts take tiles from an LDS counter:
 //      k_tile_fast's passes (occupancy bitmap -> rank of every touched base -> counters by rank -> 64 touched
 //      bases per step) with the keys coming from LDS -- no global load in the tile loop at all
+// Pair mode (round 4; the default): level 1 leaves ONE 4-byte record per fragment (gx_sort.h: k_sort_a / k_sort_b), step 1
+// reads eight lists instead of sixteen, a pair whose ends share a tile is one atomic in steps 3 and 4.
 // A tile also leaves (a) its descriptor for the kernels downstream (k_pack_pval, k_frag_*), (b) when the
 // significance threshold is known already (gx_loose.h: lambda from the closed form of fragLen), the sweep's
 // significance bits for its intervals, in loose-slot index space, and (c) its unused slots filled with
@@ -151,63 +154,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // 32-bit byte offsets against a uniform base pointer: one shift instead of 64-bit address arithmetic per store
-#ifndef GX_SBT_KNOBS   // measurement knobs (tools/build_variant.sh): 1 exchange-and-clear, 2 32-bit store offsets, 4 unpredicated key loads,
-#define GX_SBT_KNOBS 39   // 8 the third register-held key only for a tile of more than 128 keys, 16 tiles dealt to the wavefronts statically (off),
-                          // 32 the prologue's global loads ahead of the clearing of the scratch, 64 two steps per turn of a round's loop (off),
-                          // 128 the tile counter, 256 the significance words without the compiler's atomic optimizer on top (off: see below),
-                          // 512 the ordinary launch reads its pair records by a static deal of classes and chunks: no length, no barrier ahead of the loads
-#endif
 __device__ __forceinline__ void st_u32(void* base, u32 index, u32 v) {
-#if GX_SBT_KNOBS & 2
   *reinterpret_cast<u32*>(static_cast<char*>(base) + (size_t)(index << 2)) = v;
-#else
-  static_cast<u32*>(base)[index] = v;
-#endif
-}
-
-// Two atomics of the tile loop whose address and value are wave-uniform, issued WITHOUT the compiler's atomic optimizer on
-// top (LLVM's pass picks "the first active lane" itself -- two v_mbcnt, a compare, an exec save -- although the source
-// has already sent one lane, or needs none).  Measured in round 5: the whole library built without the pass gives the tile
-// stage 0.558 -> 0.548 ms and costs k_bh_hist's slot counter 7 ms at config 5, so only these two sites would go around it:
-//   * knob 128: the wavefronts' tile counter by DS_APPEND (adds the number of active lanes: all 64 take part, tile = old / 64);
-//   * knob 256: the sweep's significance words by one lane's global_atomic_or_x2 as inline assembly.
-// NOT ADOPTED: each alone gave the oracle's bits in every run, the two together gave wrong intervals in the FIRST sample of a
-// process twice out of twice (a tower's bin on the second launch; not explained) -- for 0.01 ms the default keeps the
-// compiler's atomics.  The code stays for the measurement.
-__device__ __forceinline__ u32 sbt_next_tile(u32* counter) {
-#if GX_SBT_KNOBS & 128
-  return (u32)__builtin_amdgcn_ds_append((__attribute__((address_space(3))) int*)counter) >> 6;
-#else
-  u32 b = 0;
-  if (lane_id() == 0) b = atomicAdd(counter, 1u);
-  return (u32)__builtin_amdgcn_readfirstlane((int)b);
-#endif
-}
-__device__ __forceinline__ void sbt_or64(u64* __restrict__ base, u32 word, u64 bits) {  // (called by one lane)
-#if GX_SBT_KNOBS & 256
-  const u32 off = word << 3;
-  asm volatile("global_atomic_or_x2 %0, %1, %2" : : "v"(off), "v"(bits), "s"(base) : "memory");
-#else
-  atomicOr((unsigned long long*)&base[word], (unsigned long long)bits);
-#endif
-}
-// sig_flush_m (gx_kernels.h) with these atomics
-__device__ __forceinline__ void sbt_sig_flush(u64* __restrict__ sigMask, u32 pos, u64 sgm, u32 rank, u64 written) {
-  if (!sgm) return;  // wave-uniform
-  u64 m;
-  if (((written + 1ull) & written) == 0ull) {  // wave-uniform: the lanes that wrote are the lanes 0 .. k - 1
-    m = sgm;
-  } else {
-    const bool sg = __builtin_amdgcn_inverse_ballot_w64(sgm);
-    const int lo = sg && rank < 32u ? (int)(1u << rank) : 0, hi = sg && rank >= 32u ? (int)(1u << (rank - 32u)) : 0;
-    const u32 mlo = (u32)__builtin_amdgcn_readlane(dpp_scan_add(lo), 63), mhi = (u32)__builtin_amdgcn_readlane(dpp_scan_add(hi), 63);
-    m = (u64)mlo | ((u64)mhi << 32);
-  }
-  if (lane_id() == 0) {
-    const u32 w = pos >> 6, sh = pos & 63;
-    sbt_or64(sigMask, w, m << sh);
-    if (sh && (m >> (64 - sh))) sbt_or64(sigMask, w + 1, m >> (64 - sh));
-  }
 }
 
 // One tile, one wavefront: the passes of k_tile_fast with the keys in LDS (kl[0 .. n): [11:0] offset, [15] end).
@@ -253,24 +201,11 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
   // 128; the third register of round 4 was all "no key" there and cost its three passes: 0.577 -> 0.567 ms.  Skipping it by
   // a scalar branch where the tile is small -- knob 8 -- cost more than it saved: 0.572 -> 0.585)
   constexpr int KR = GX_SBT_KR;
-  // (n is wave-uniform -- the caller hands it over in a scalar register: an ordinary tile of hg38 / 50 M fragments holds ~90
-  // keys, so the third register-held key is all "no key" there and its three passes are skipped by scalar branches)
-#if (GX_SBT_KNOBS & 8) && GX_SBT_KR == 3
-  const bool third = n > 128u;
-#else
-  constexpr bool third = true;
-#endif
   u32 kr[KR];
 #pragma unroll
   for (int q = 0; q < KR; q++) {
-    if (q == 2 && !third) { kr[q] = NOKEY; continue; }
-#if GX_SBT_KNOBS & 4
     const u32 v = kl[lane + q * 64];  // (in bounds: the key array has 192 entries of slack)
     kr[q] = (u32)lane + q * 64 < n ? v : NOKEY;
-#else
-    kr[q] = NOKEY;
-    if ((u32)lane + q * 64 < n) kr[q] = kl[lane + q * 64];
-#endif
   }
   // ---- A1: keys -> occupancy bitmap
   auto mark = [&](u32 key) { const u32 off = offOf(key); atomicOr(&occ[off >> 5], 1u << (off & 31)); };
@@ -278,9 +213,8 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
   // serialise -- measured 0.71 -> 0.81 ms for the kernel)
 #pragma unroll
   for (int q = 0; q < KR; q++)
-    if ((q < 2 || third) && kr[q] != NOKEY) mark(kr[q]);
-  if (third)
-    for (u32 k = KR * 64 + lane; k < n; k += 64) mark(kl[k]);
+    if (kr[q] != NOKEY) mark(kr[q]);
+  for (u32 k = KR * 64 + lane; k < n; k += 64) mark(kl[k]);
   wave_lds_sync();
   // ---- B: touched bases before each bitmap word
   const uint2 ww = *reinterpret_cast<const uint2*>(occ + 2 * lane);
@@ -300,7 +234,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
   };
   u32 rr[KR];
 #pragma unroll
-  for (int q = 0; q < KR; q++) rr[q] = (q < 2 || third) ? rankOf(kr[q]) : 0xFFFFu;
+  for (int q = 0; q < KR; q++) rr[q] = rankOf(kr[q]);
   for (u32 r0 = 0; r0 < T; r0 += TR_CAP) {
     if (r0) wave_lds_sync();
     // ---- A2: keys -> cnt[rank], list[rank]
@@ -312,24 +246,17 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
       }
     };
 #pragma unroll
-    for (int q = 0; q < KR; q++)
-      if (q < 2 || third) put(rr[q], kr[q]);
-    if (third)
-      for (u32 k = KR * 64 + lane; k < n; k += 64) {
-        const u32 key = kl[k];
-        put(rankOf(key), key);
-      }
+    for (int q = 0; q < KR; q++) put(rr[q], kr[q]);
+    for (u32 k = KR * 64 + lane; k < n; k += 64) {
+      const u32 key = kl[k];
+      put(rankOf(key), key);
+    }
     wave_lds_sync();
     // ---- C: 64 touched bases per step (whole wavefronts: the counters behind the last touched base are zero)
     const u32 nL = min((u32)TR_CAP, T - r0);
     auto loadEl = [&](u32 j, u32& p, int& d120) {
       p = list[j];
-#if GX_SBT_KNOBS & 1
       d120 = __hip_atomic_exchange(&cnt[j], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // read and clear
-#else
-      d120 = cnt[j];
-      cnt[j] = 0;
-#endif
     };
     // one step's 64 touched bases: p their offsets, d120 their differences, incS the inclusive scan of the differences
     auto emit = [&](const u32 p, const int d120, const int incS) {
@@ -347,7 +274,7 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
         st_u32(out.to.looseV, o, (u32)before);
       }
       if (vsig != 0x7FFFFFFF)  // wave-uniform
-        sbt_sig_flush(out.to.sigMask, slot + outCount, mask & __builtin_amdgcn_sicmp(before, vsig, 39 /* sge */), orank, mask);
+        sig_flush_m(out.to.sigMask, slot + outCount, mask & __builtin_amdgcn_sicmp(before, vsig, 39 /* sge */), orank, mask);
       // (a pileup below zero or at the table's end: one unsigned compare finds either, the rare step that has one says which)
       if (__builtin_amdgcn_uicmp((u32)after, (u32)FRAG_FAST_MAXV, 35 /* uge */)) {  // wave-uniform
         negM |= __ballot(after < 0);
@@ -367,29 +294,12 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
         lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(mask));
       }
     };
-#if GX_SBT_KNOBS & 64
-    // two steps per turn of the loop: the second step's counters are fetched and scanned before the first step's intervals
-    // leave (two independent chains; an ordinary tile -- ~90 touched bases -- is ONE turn, no loop)
-    for (u32 j0 = 0; j0 < nL; j0 += 128) {
-      const bool two = j0 + 64 < nL;  // wave-uniform
-      u32 pA, pB = 0;
-      int dA, dB = 0;
-      loadEl(j0 + lane, pA, dA);
-      if (two) loadEl(j0 + 64 + lane, pB, dB);
-      const int incA = dpp_scan_add(dA);
-      int incB = 0;
-      if (two) incB = dpp_scan_add(dB);
-      emit(pA, dA, incA);
-      if (two) emit(pB, dB, incB);
-    }
-#else
     for (u32 j0 = 0; j0 < nL; j0 += 64) {
       u32 p;
       int d120;
       loadEl(j0 + lane, p, d120);
       emit(p, d120, dpp_scan_add(d120));
     }
-#endif
   }
   *reinterpret_cast<uint2*>(occ + 2 * lane) = make_uint2(0u, 0u);
   u32 total = 0;
@@ -568,7 +478,6 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     }
     return ti;
   };
-  constexpr bool HOIST = (GX_SBT_KNOBS & 32) != 0;
   auto expLeave = [&]() {   // (measurement exits: empty tiles with valid slots behind them)
     if (tid < (int)nT && segTileBase + tid < in.nTiles) {
       const u32 t = segTileBase + tid;
@@ -581,37 +490,14 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     }
   };
   if (GX_EXP_SBT == 4) { expLeave(); return; }   // (measurement: what launching the workgroups costs)
-  // The ordinary launch on pair records: which records a wavefront reads does not wait for the lists' lengths.  Wavefront w
-  // takes class w & 7 (a bin's eight page lists, one per XCD class of level 1's workgroups) and of it the chunks of 256
-  // records number 2 i + (w >> 3), i = 0 .. 7 -- all inside the list's fixed first page, whose address is a function of
-  // the list's number.  The loads leave with the kernel's first instructions, next to the one length the wavefront needs;
-  // what lies behind the list's end is read (the page is there) and masked by the counts.  Round 4's mapping cut the
-  // lists into slots by a prefix over the lengths: lengths -> barrier -> slot table -> barrier -> loads, two round trips
-  // of a CU that has nothing else to run (GX_EXP_SBT: 0.13 of the kernel's 0.55 ms pass before the first key arrives).
-  // A class with more than 4096 records (a bin of > 32 K pairs: reads piled up) sends the bin to the second launch.
-  constexpr bool EARLY = PAIRS && !BIG && HOIST && (GX_SBT_KNOBS & 512) != 0;
-  constexpr int KE = EARLY ? SBT_KP : 1;
-  uint4 kEarly[KE];
-  u32 lenMine = 0;
-  if constexpr (EARLY) {
-    static_assert(SBT_KP == 8 && SBT_NW == 16 && NXCD == 8 && SBT_SLOT == 256, "wavefront w: class w & 7, chunks 2 i + (w >> 3)");
-    static_assert((1u << PgCfg<u32>::SHIFT) >= 16u * SBT_SLOT, "sixteen chunks inside a list's first page");
-    const u32 wU = (u32)__builtin_amdgcn_readfirstlane(wv);
-    const u32 li = (wU & 7u) * nSeg + seg;
-    lenMine = list_len<u32>(in.PS, li);
-    const uint4* __restrict__ pg = reinterpret_cast<const uint4*>(in.PS.pool) + ((size_t)first_page(li) << (PgCfg<u32>::SHIFT - 2));
-#pragma unroll
-    for (int i = 0; i < KE; i++) kEarly[i] = pg[(2u * (u32)i + (wU >> 3)) * (SBT_SLOT / 4) + (u32)lane];
-  }
-  if (HOIST && tid < 2 * NXCD) {
+  if (tid < 2 * NXCD) {
     const u32 li = (u32)(tid & (NXCD - 1)) * nSeg + seg;
     if (PAIRS)
       myLen = tid < NXCD ? list_len<u32>(in.PS, li) : list_len<u64>(in.PF, li);
     else
       myLen = list_len<u32>(tid < NXCD ? in.PS : in.PE, li);
   }
-  uint4 ti = make_uint4(0u, 0u, 0u, 0u);
-  if (HOIST) ti = loadTi();
+  const uint4 ti = loadTi();
   // scratch and tables start at zero
   for (u32 i = (u32)tid * 4; i < scrWords; i += SBT_NT * 4) *reinterpret_cast<int4*>(scr + i) = make_int4(0, 0, 0, 0);
   if (tid < SBT_TILES) {
@@ -619,20 +505,9 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     if (FRAC) L.netW[tid] = 0;
   }
   if (tid == 0) { L.overflow = 0; L.nHeavy = 0; }
-  if (HOIST && tid < 2 * NXCD) L.scratch[tid] = myLen;
+  if (tid < 2 * NXCD) L.scratch[tid] = myLen;
   __syncthreads();
-  if (EARLY && tid < NXCD && L.scratch[tid] > 16u * SBT_SLOT) L.overflow = 1;   // (read behind the next barrier)
   if (tid < SBT_NW) scr[(u32)tid * tw + SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
-  if (!HOIST) {   // (round 4's order: the loads behind the clearing, a barrier of their own)
-    if (tid < 2 * NXCD) {
-      const u32 li = (u32)(tid & (NXCD - 1)) * nSeg + seg;
-      if (PAIRS)
-        L.scratch[tid] = tid < NXCD ? list_len<u32>(in.PS, li) : list_len<u64>(in.PF, li);
-      else
-        L.scratch[tid] = list_len<u32>(tid < NXCD ? in.PS : in.PE, li);
-    }
-    __syncthreads();
-  }
   if (tid < 2) {
     u32 a = 0;
     for (int x = 0; x < NXCD; x++) {
@@ -644,7 +519,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   __syncthreads();
   if (GX_EXP_SBT == 5) { expLeave(); return; }   // (measurement: ... and clearing the scratch, the lists' lengths)
   // ---- 1: slot descriptors (thread k of the first 2 SBT_SLOTS: slot k & 127 of stream k >> 7)
-  if (!EARLY && tid < (PAIRS ? 1 : 2) * (int)NSLOTS) {
+  if (tid < (PAIRS ? 1 : 2) * (int)NSLOTS) {
     const int q = tid / (int)NSLOTS;
     const u32 k = (u32)tid % NSLOTS;
     const PagedStream& P = q ? in.PE : in.PS;
@@ -671,7 +546,6 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     L.slotOff[tid] = ptr;
     L.slotCnt[tid] = cnt;
   }
-  if (!HOIST) ti = loadTi();
   __syncthreads();
   const bool ovfSlots = L.overflow != 0;
   // ---- 2: the bin's keys, all loads in flight together
@@ -679,26 +553,16 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   const uint4* __restrict__ poolE = reinterpret_cast<const uint4*>(in.PE.pool);
   uint4 kS[KR], kE[PAIRS ? 1 : KR];
   u32 cS[KR], cE[PAIRS ? 1 : KR];
-  const u32 lenW = EARLY ? (u32)__builtin_amdgcn_readfirstlane((int)lenMine) : 0u;
 #pragma unroll
-  for (int i = 0; i < K; i++) {  // (wave-uniform: scalar registers)
-    if constexpr (EARLY) {
-      const u32 first = (2u * (u32)i + ((u32)__builtin_amdgcn_readfirstlane(wv) >> 3)) * SBT_SLOT;
-      cS[i] = ovfSlots || lenW <= first ? 0u : min(SBT_SLOT, lenW - first);
-    } else
-      cS[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
-  }
+  for (int i = 0; i < K; i++)  // (wave-uniform: scalar registers)
+    cS[i] = ovfSlots ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
 #pragma unroll
   for (int i = 0; i < (PAIRS ? 1 : K); i++)
     cE[i] = ovfSlots || PAIRS ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[NSLOTS + i * SBT_NW + wv]);
 #pragma unroll
   for (int i = 0; i < K; i++) {
-    if constexpr (EARLY)
-      kS[i] = kEarly[i < KE ? i : 0];   // (what lies behind the list's end is masked by cS)
-    else {
-      kS[i] = make_uint4(0u, 0u, 0u, 0u);
-      if ((u32)lane * 4 < cS[i]) kS[i] = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
-    }
+    kS[i] = make_uint4(0u, 0u, 0u, 0u);
+    if ((u32)lane * 4 < cS[i]) kS[i] = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
   }
 #pragma unroll
   for (int i = 0; i < (PAIRS ? 1 : K); i++) {
@@ -909,22 +773,19 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   }
   u32 bad = 0;
   // ---- 4: the keys to their tiles' lists in LDS; then the wavefronts take tiles from a counter
-  if (tid == 0) L.work = 0;   // (knob 128: the counter runs in units of 64 -- DS_APPEND adds the wavefront's 64 lanes)
+  if (tid == 0) L.work = 0;
   __syncthreads();  // the cursors are there
   auto place = [&](u32 key, u32 curBase, u32 flag) {
     keysL[atomicAdd(&L.cur[curBase + (key >> TB) - segTileBase], 1u)] = (uint16_t)((key & (TILE - 1)) | flag);
   };
   // the wavefronts take the tiles [L.work .. tileEnd) from a counter; keyBase: where the first key in LDS lies in the bin's order
   auto tiles = [&](u32 tileEnd, u32 keyBase) {
-    // (BIG: the rounds' tiles come from the counter, which a round sets to its first tile; the ordinary launch deals them
-    // to the sixteen wavefronts in turn: no atomic, no wait, no readfirstlane per tile)
-    constexpr bool STATIC_DEAL = !BIG && (GX_SBT_KNOBS & 16) != 0;
-    for (u32 it = 0;; it++) {
+    // (from a counter, not dealt in turn: one tile in twelve carries a peak and costs several ordinary ones -- a static deal
+    // measured 0.628 against 0.590 ms, the workgroup waits for the wavefront that drew three of them)
+    for (;;) {
       u32 b = 0;
-      if constexpr (STATIC_DEAL)
-        b = (u32)__builtin_amdgcn_readfirstlane(wv) + it * (u32)SBT_NW;
-      else
-        b = sbt_next_tile(&L.work);
+      if (lane == 0) b = atomicAdd(&L.work, 1u);
+      b = (u32)__builtin_amdgcn_readfirstlane((int)b);
       if (b >= tileEnd) break;
       const u32 t = segTileBase + b;
       if (t >= in.nTiles) continue;
@@ -1001,7 +862,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         const u32 tileBeg = L.rnd[round], tileEnd = L.rnd[round + 1], keyBase = L.startC[tileBeg];
         if (round) {
           __syncthreads();  // (the previous round's tiles are through with the keys)
-          if (tid == 0) L.work = (GX_SBT_KNOBS & 128) ? tileBeg << 6 : tileBeg;
+          if (tid == 0) L.work = tileBeg;
           __syncthreads();
         }
         slotsFrom(0, [&](u32 r) {
