@@ -227,7 +227,10 @@ struct HotWindows {
   std::vector<size_t> base;                                   // first window of a chromosome (position `len` has an entry)
   std::vector<uint32_t> ws, we;                               // weight (1/120) of the sample's starts / ends per window
   std::unordered_map<size_t, std::vector<long long>> win;     // loaded windows: the exact difference per base
-  std::vector<gx_event> all;                                  // --events-only (no device to ask): the sample's events so far
+  // --events-only -b (no device to ask for a window's state): the sample's events so far, 16 bytes each -- 1.6 GB per 10^8
+  // fragments, scanned once per window that comes near the limits (real data: none).  GENRICH_NO_INT16=1 drops the copy
+  // (and the read-by-read decisions) for event dumps of that size.
+  std::vector<gx_event> all;
   void init(const std::vector<Chrom>& chrom) {
     base.assign(chrom.size() + 1, 0);
     for (size_t c = 0; c < chrom.size(); c++) base[c + 1] = base[c] + ((size_t)chrom[c].len >> WB) + 1;
@@ -422,7 +425,7 @@ void pushEvent(State& S, const gx_event& e) {  // (state's side: the library tak
   S.buf.push_back(e);
   if (S.buf.size() >= (1u << 20)) {
     if (S.gx && S.sampleOpen) flushEvents(S);
-    if (!S.gx || S.sampleOpen) S.buf.clear();  // --events-only keeps nothing
+    if (!S.gx || S.sampleOpen) S.buf.clear();  // (--events-only: nothing to send them to; with -b the int16 decisions keep their own copy, hot.all)
   }
 }
 
@@ -1710,7 +1713,7 @@ void mergeChunk(State& S, ReadSet& rs, Counts& C, Chunk& ch, int qualOffset) {
     S.buf.insert(S.buf.end(), ch.sink.ev.begin(), ch.sink.ev.end());
     if (S.buf.size() >= (1u << 20)) {
       if (S.gx && S.sampleOpen) flushEvents(S);
-      if (!S.gx || S.sampleOpen) S.buf.clear();  // --events-only keeps nothing
+      if (!S.gx || S.sampleOpen) S.buf.clear();  // (--events-only: nothing to send them to; with -b the int16 decisions keep their own copy, hot.all)
     }
   }
   addCounts(C, ch.C);
