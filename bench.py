@@ -20,10 +20,10 @@ Prints ONE JSON line (rank 0).  Besides the contract's fields:
   gate          the same workload (or its first chromosomes, see cpu_baseline.sample) through the CPU oracle
                 and through the HIP path: narrowpeak_diff (differing narrowPeak lines; must be 0), max_abs_dp /
                 max_abs_dq over every interval
-  roofline      bound "hbm" for the dominant kernel: achieved = HBM bytes it moves (PMC counters of a separate
-                rocprofv3 run of this very build, profiles/) / its mean duration measured here (HIP events);
-                frac = achieved / 8 TB/s <= 1 by construction; `algorithmic_bytes` = what the sparse formulation
-                must move; `whole_step` the same for the whole path; `issue` = the SQ-counter issue model
+  roofline      bound "hbm" for the dominant kernel: achieved = its ALGORITHMIC bytes per launch / its mean duration
+                measured here (HIP events); frac = achieved / 8 TB/s; `traffic` = the HBM bytes it moves (PMC counters of
+                a separate rocprofv3 run of this very build, profiles/), `traffic_frac` the same fraction on those;
+                `whole_step` both for the whole path; `issue` = the second bound (VALU issue) from the SQ counters
   h2d / e2e     PCIe upload of the events from pinned memory, and a step that starts from pinned host memory
   cpu_baseline  the oracle (kind "port"), one core, events in memory -> peaks, on the sample named
 """
@@ -448,7 +448,7 @@ def main():
                 others[str(c)]["device_path"] = r["config"]["device_path"]
                 others[str(c)]["tables_written_in_step"] = r["config"]["tables_written_in_step"]
                 others[str(c)]["whole_step"] = r["roofline"]["whole_step"]
-                others[str(c)]["dominant"] = {k: r["roofline"].get(k) for k in ("kernel", "frac", "achieved", "launch_ms", "traffic")}
+                others[str(c)]["dominant"] = {k: r["roofline"].get(k) for k in ("kernel", "frac", "frac_is", "achieved", "launch_ms", "traffic", "traffic_frac", "algorithmic_bytes")}
                 others[str(c)]["cpu_baseline"] = r.get("cpu_baseline")
             except Exception as e:  # noqa: BLE001  (the headline must still be printed)
                 others[str(c)] = {"error": repr(e)}
@@ -658,8 +658,12 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             # (pair mode: one 4-byte record per fragment; else two 4-byte keys (k_sbtile) or two 2-byte offsets (k_tile_fast))
             key_bytes = 4.0 if path_flags & 16 else (8.0 if path_flags & 1 else 4.0)
             alg_k = key_bytes * ev_launch + 8.0 * (iv0 if launches == 1 else 2.0 * ev_launch) + 56.0 * n_tiles
-        used = traffic if traffic else (alg_k or 0.0)
+        # `achieved` / `frac`: ALGORITHMIC bytes of the launch over its live duration (the contract's definition).  The same with
+        # the PMC traffic of the profile: `traffic_gbs` / `traffic_frac` (round 4's line quoted that one as `frac`).  A merge /
+        # Fisher / BH kernel has no closed form of its compulsory bytes here: the counter figure stands in, and says so.
+        used = alg_k if alg_k else (traffic or 0.0)
         achieved = used / (live_ms * 1e-3) / 1e9 if live_ms > 0 else 0.0
+        traffic_gbs = (traffic / (live_ms * 1e-3) / 1e9) if traffic and live_ms > 0 else None
         # whole step: events in + final interval table (end, p[, pileup]) + sweep masks out; the loose-slot sweep of a
         # single sample with -p leaves (end, V) in the tile stage's slots and makes no second table
         loose = bool(path_flags & 2)
@@ -667,7 +671,9 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
         whole_traffic = prof["whole_step"]["hbm_bytes_per_step"] if prof else None
         roof = {
             "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": live_ms / (1.0 if per_sample else klaunch),
+            "frac": achieved / HBM_PEAK_GBS, "frac_is": "algorithmic bytes" if alg_k else "PMC traffic (no closed form of this kernel's compulsory bytes)",
+            "traffic": traffic, "traffic_gbs": traffic_gbs, "traffic_frac": (traffic_gbs / HBM_PEAK_GBS) if traffic_gbs else None,
+            "launch_ms": live_ms / (1.0 if per_sample else klaunch),
             "algorithmic_bytes": alg_k,
             "traffic_over_algorithmic": (traffic / alg_k) if traffic and alg_k else None,
             "profile": prof["_path"] if prof else None,
@@ -675,17 +681,18 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                 "ms": step_s * 1e3,
                 "algorithmic_bytes": alg_step,
                 "traffic": whole_traffic,
-                "frac_of_peak": ((whole_traffic if whole_traffic else alg_step) / step_s / 1e9) / HBM_PEAK_GBS,
+                "frac_of_peak": (alg_step / step_s / 1e9) / HBM_PEAK_GBS,
+                "traffic_frac_of_peak": ((whole_traffic / step_s / 1e9) / HBM_PEAK_GBS) if whole_traffic else None,
                 "traffic_over_algorithmic": (whole_traffic / alg_step) if whole_traffic else None,
             },
             "issue": issue_roof(prof, kname, launches if per_sample else klaunch, live_ms / (1.0 if per_sample else klaunch)),
             "dense_model": {"bytes": 8.0 * G + 16.0 * ev_n + 52.0 * iv0,
                             "note": "SURVEY 8(d)'s dense int32-array model; the array lives in LDS here, so this is not HBM traffic"},
-            "note": "kernel = the longest kernel of this build's rocprofv3 profile of this config (profiles/); achieved = the HBM bytes "
-                    "it moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of that profile; a sample's tile stage -- k_sbtile's first launch "
-                    "and its usually idle second one -- counts as one launch; the sparse formulation's compulsory bytes when "
-                    "no profile matches this build) / its mean duration measured here (HIP events on the library's stream, inside the "
-                    "timed region); frac <= 1 by construction.  `traffic` (here and in whole_step) is NOT measured in this run: it is "
+            "note": "kernel = the longest kernel of this build's rocprofv3 profile of this config (profiles/); achieved = the ALGORITHMIC "
+                    "bytes of a launch (DESIGN.md section 4: pair records in, 8 B per interval + 56 B per tile out; a sample's tile stage "
+                    "-- k_sbtile's first launch and its usually idle second one -- counts as one launch) / its mean duration measured here "
+                    "(HIP events on the library's stream, inside the timed region); traffic_gbs / traffic_frac = the same with the HBM "
+                    "bytes the kernel moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of that profile); both <= 1 by construction.  `traffic` (here and in whole_step) is NOT measured in this run: it is "
                     "the PMC figure of the committed profile of this very build (source hash checked), collected by "
                     "tools/profile_round.sh in separate rocprofv3 --pmc passes",
         }
