@@ -75,7 +75,7 @@ def test_a_control_uses_the_fused_tile_stage_for_both_samples():
 
 @pytest.mark.parametrize("n_pile", [30_000, 44_000, 58_000])
 def test_a_super_bucket_beyond_the_key_array_is_worked_off_in_rounds(n_pile):
-    # 49 tiles -> 4 tiles per super-bucket; 30,000 / 44,000 fragments inside one of them = more keys than SBT_KEYCAP (57,344)
+    # 49 tiles -> 4 tiles per super-bucket; 30,000 / 44,000 fragments inside one of them = more keys than SBT_KEYCAP (46,976)
     # but no more pair records than the slots take (64 K): rounds of tiles, no fall-back
     lens = [200_000]
     rng = np.random.default_rng(9)
