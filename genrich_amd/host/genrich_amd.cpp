@@ -1334,7 +1334,12 @@ struct Batch {
     extBytes += n;
   }
   bool hasWork() const { return !off.empty() || spanLen; }
-  void reset(size_t want) {
+  void reset(size_t want) {  // (the reader's thread, before the batch is queued)
+    decoded = false;
+    clearRecords(want);
+  }
+  // ... and what a decoder may do to a queued batch: `decoded` belongs to the pipe's mutex (the taker polls it)
+  void clearRecords(size_t want) {
     if (cap < want) {
       bytes.reset(new char[want]);
       cap = want;
@@ -1344,7 +1349,6 @@ struct Batch {
     mark.clear();
     firstRec = 0xFFFFFFFFu;
     lastName.clear();
-    decoded = false;
     span = nullptr;
     spanLen = 0;
     ext.clear();
@@ -1444,7 +1448,7 @@ inline void applyDecoded(State& S, ReadSet& rs, Counts& C, const Batch& B, size_
 void cutSpan(Batch& B) {
   const char* p = B.span;
   const char* const end = p + B.spanLen;
-  B.reset(B.spanLen + B.spanLen / 8 + REC_MAX);   // (clears span / spanLen: p and end are copies)
+  B.clearRecords(B.spanLen + B.spanLen / 8 + REC_MAX);   // (clears span / spanLen: p and end are copies)
   while (p < end) {
     const size_t avail = std::min((size_t)(end - p), REC_MAX - 1);
     const void* nl = memchr(p, '\n', avail);
