@@ -150,7 +150,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // key than the rounds of full-size bins -- 2.98 against 2.67 ms)
   const bool forceHalf = K.forceHalfBins != 0;  // (tests: the 128-key level 1 on a small input)
   if (pairs && (!fracPairs || forceHalf || K.fracHalfBins) && sbS > 0 &&
-      (forceHalf || (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * (SBT_KEYCAP - SBT_KEYCAP / 10)) &&
+      (forceHalf || (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * SBT_R1 * (SBT_KEYCAP - SBT_KEYCAP / 10)) &&
       ((nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1)) <= (u32)MAX_BINS_P && !K.noHalfBins) {
     sbS--;
     nL1 = (nTiles + (1u << sbS) - 1) >> sbS;
@@ -424,7 +424,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
     // a sample so dense that the average bin already holds more keys than the key array (ATAC cut sites of a deep
     // library): every bin takes the rounds of the second launch, the first one would only find that out bin by bin
-    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 16);
+#ifndef GX_SBT_ALLBIG
+#define GX_SBT_ALLBIG 0
+#endif
+    const bool dense = ctx->pairsUsed && (GX_SBT_ALLBIG || (size_t)2 * nEv > (size_t)std::max(1u, nL1) * SBT_R1 * (SBT_KEYCAP - SBT_KEYCAP / 16));
     if (dense) {
       so2.bigList = nullptr;
       // touched bases per round of the tile passes against keys per round of a bin (they share the LDS, gx_sbtile.h): what

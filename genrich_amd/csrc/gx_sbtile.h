@@ -45,7 +45,10 @@ namespace gx {
 #define GX_EXP_SBT 0
 #endif
 
-constexpr int SBT_NT = 1024;
+#ifndef GX_SBT_NT
+#define GX_SBT_NT 1024
+#endif
+constexpr int SBT_NT = GX_SBT_NT;                      // threads of a workgroup: 1024 = one workgroup per CU; 512 = two (half the LDS each)
 constexpr int SBT_NW = SBT_NT / 64;
 constexpr int SBT_TILES = 1 << SBT_MAXSHIFT;          // tiles per super-bucket the LDS tables are made for
 constexpr int SBT_K = 8;                               // 16-byte loads per lane and stream (start / end keys)
@@ -53,9 +56,12 @@ constexpr int SBT_K = 8;                               // 16-byte loads per lane
 #define GX_SBT_KP 8
 #endif
 constexpr int SBT_KP = GX_SBT_KP;                      // ... of pair records kept in registers (pair mode: one stream)
-constexpr int SBT_KX = 16;                             // ... and slots per wavefront in all: those beyond SBT_KP (a bin of more than 32 K pairs:
-                                                       // reads piled up) are read from global memory by every pass that wants them
-static_assert(SBT_KX <= 2 * SBT_K && SBT_KP <= SBT_KX, "the slot tables hold 2 x SBT_K x SBT_NW descriptors");
+constexpr int SBT_KX = 16 * (1024 / SBT_NT);           // ... and slots per wavefront in all (64 K pair records per bin): those beyond SBT_KP (a bin of
+                                                       // more than 32 K pairs: reads piled up) are read from global memory by every pass that wants them
+static_assert(SBT_KP <= SBT_KX, "the slot tables hold SBT_KX x SBT_NW descriptors");
+// rounds of a bin that the FIRST launch works off with its records in registers (two workgroups per CU share the LDS: the key
+// array holds about half an ordinary bin); beyond that a bin goes on the second launch's list
+constexpr u32 SBT_R1 = SBT_NT < 1024 ? 3u : 1u;
 constexpr u32 SBT_SLOT = 256;                          // keys per slot
 constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K keys)
 #ifndef GX_SBT_TR
@@ -84,10 +90,11 @@ constexpr int SBT_OCCW = TILE / 32 + 4, SBT_PREW = TILE / 64 + 4;
 __host__ __device__ constexpr u32 sbt_tw(u32 tr) { return (u32)(SBT_OCCW + SBT_PREW) + tr + tr / 2; }   // words; 3,488 bytes at 448
 constexpr u32 SBT_NOKEY = 0x1000u;                     // "no key": offset 4096 = bit 0 of the dummy bitmap word
 static_assert(SBT_TR % 64 == 0, "the last step of a round reads whole wavefronts of counters");
+static_assert(2 * SBT_K <= SBT_KX, "start / end key mode: two streams of SBT_SLOTS descriptors");
 static_assert((1u << PgCfg<u32>::SHIFT) % SBT_SLOT == 0, "a slot never crosses a page");
 static_assert(TILE == 4096, "13-bit LDS keys: 12 bits of offset and the stream");
 static_assert((SBT_NW * sbt_tw(64)) % 4 == 0 && (SBT_NW * 96) % 4 == 0, "the scratch is cleared by 16-byte stores (TR: a multiple of 64)");
-constexpr u32 SBT_LDS_BYTES = 160u * 1024u - 512u;    // what a launch asks for (dynamic; the kernel's few static words come on top): one workgroup per CU
+constexpr u32 SBT_LDS_BYTES = 160u * 1024u / (1024u / SBT_NT) - 512u;    // what a launch asks for (dynamic; the kernel's few static words come on top): one workgroup per CU
 
 struct SbtLds {
   u32 hist[SBT_TILES];                     // [15:0] start keys, [31:16] end keys of the tile
@@ -96,8 +103,8 @@ struct SbtLds {
   u32 cur[2 * SBT_TILES];                  // scatter cursors: starts, ends
   uint4 tinfo[SBT_TILES];                  // what a wavefront needs to start a tile, one 16-byte read: pos0, chromosome length,
                                            // TM_ flags | keys of the tile << 8, carry-in pileup (1/120)
-  u32 slotOff[2 * SBT_SLOTS];              // first key of a slot, as an index into its stream's page pool
-  u32 slotCnt[2 * SBT_SLOTS];
+  u32 slotOff[SBT_KX * SBT_NW];            // first key of a slot, as an index into its stream's page pool (2 x SBT_SLOTS <= SBT_KX x SBT_NW)
+  u32 slotCnt[SBT_KX * SBT_NW];
   u32 pre[2][NXCD + 1];
   __attribute__((aligned(8))) u32 scratch[40];
   u32 work;
@@ -117,7 +124,7 @@ constexpr u32 SBT_DYN_OFF = (u32)offsetof(SbtLds, dyn);
 // keys of a super-bucket (both streams) that fit the LDS next to the scratch for TR touched bases per round
 __host__ __device__ constexpr u32 sbt_keycap(u32 tr) { return ((SBT_LDS_BYTES - SBT_DYN_OFF - SBT_NW * sbt_tw(tr) * 4u) / 2u - 192u) / 64u * 64u; }
 constexpr u32 SBT_KEYCAP = sbt_keycap(SBT_TR);        // ... of the ordinary launch
-static_assert(sbt_keycap(192) > sbt_keycap(448) && sbt_keycap(448) >= 40960, "the split of the LDS");
+static_assert(sbt_keycap(192) > sbt_keycap(448) && (SBT_NT != 1024 || sbt_keycap(448) >= 40960), "the split of the LDS");
 
 struct SbtIn {
   PagedStream PS, PE;         // (pair mode: PS = the pair records' lists, PE unused)
@@ -344,8 +351,8 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
 template <bool FRAC>
 __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
                                           int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms) {
-  static_assert(SBT_NW * sbt_tw(192) >= TILE, "the counters fit the wavefronts' scratch");
-  static_assert(TILE == SBT_NT * 4, "four bases per thread");
+  constexpr int BPT = TILE / SBT_NT;   // consecutive bases per thread
+  static_assert(BPT % 4 == 0 && TILE == SBT_NT * BPT, "whole int4 per thread");
   int* cnt = L.dyn;
   const int tid = threadIdx.x;
   const bool active = flags & TM_ACTIVE, lastTile = (flags & TM_LAST) != 0;
@@ -356,19 +363,24 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
     atomicAdd(&cnt[key & (TILE - 1)], FRAC ? sbt_weight(key) : ((key & 0x8000u) ? -GX_UNIT : GX_UNIT));
   }
   __syncthreads();
-  const int4 d4 = *reinterpret_cast<const int4*>(cnt + tid * 4);
-  const int d[4] = {d4.x, d4.y, d4.z, d4.w};
+  int d[BPT], dsum = 0;
+#pragma unroll
+  for (int q = 0; q < BPT / 4; q++) {
+    const int4 d4 = *reinterpret_cast<const int4*>(cnt + tid * BPT + 4 * q);
+    d[4 * q] = d4.x; d[4 * q + 1] = d4.y; d[4 * q + 2] = d4.z; d[4 * q + 3] = d4.w;
+    dsum += d4.x + d4.y + d4.z + d4.w;
+  }
   int tot;
-  const int ex = block_excl_scan<int, SBT_NT>(d[0] + d[1] + d[2] + d[3], reinterpret_cast<int*>(L.scratch), &tot);
+  const int ex = block_excl_scan<int, SBT_NT>(dsum, reinterpret_cast<int*>(L.scratch), &tot);
   int run = carry + ex;  // the pileup before this thread's first base
-  bool nz[4];
-  int before[4];
+  bool nz[BPT];
+  int before[BPT];
   u32 mine = 0, neg = 0, big = (u32)(tid == 0 && carry >= FRAG_FAST_MAXV);
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < BPT; j++) {
     before[j] = run;
     run += d[j];
-    nz[j] = d[j] != 0 && active && (pos0 + (u32)tid * 4 + j != 0);  // 2241: base 0 closes nothing
+    nz[j] = d[j] != 0 && active && (pos0 + (u32)tid * BPT + j != 0);  // 2241: base 0 closes nothing
     mine += nz[j];
     neg |= (u32)(run < 0);
     big |= (u32)(run >= FRAG_FAST_MAXV);
@@ -377,9 +389,9 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
   u32 o = slot + block_excl_scan<u32, SBT_NT>(mine, L.scratch, &outCount);
   u32 lastPos = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++)
+  for (int j = 0; j < BPT; j++)
     if (nz[j]) {
-      const u32 p = pos0 + (u32)tid * 4 + j;
+      const u32 p = pos0 + (u32)tid * BPT + j;
       out.to.looseEnd[o] = p;
       out.to.looseV[o] = before[j];
       if (before[j] >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[o >> 6], 1ull << (o & 63));  // (vsig: INT_MAX when no bits are wanted)
@@ -453,12 +465,13 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   static_assert(TRC % 64 == 0 && TRC >= 192 && TRC <= 448, "touched bases per round");
   constexpr u32 trCap = (u32)TRC;
   constexpr u32 tw = sbt_tw(trCap), scrWords = SBT_NW * tw, keyCap = sbt_keycap(trCap);
+  static_assert(scrWords >= (u32)TILE, "sbt_heavy's counters (one per base) fit the wavefronts' scratch");
   int* const scr = L.dyn;
   uint16_t* const keysL = reinterpret_cast<uint16_t*>(L.dyn + scrWords);
   const u32 nSeg = in.nSeg;
   const u32 nT = 1u << in.sbShift;           // tiles per super-bucket (<= SBT_TILES)
   const u32 segTileBase = seg << in.sbShift;
-  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, !BIG && seg == 0 && tid == 0, L.vsRed));
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, (!BIG || out.bigList == nullptr) && seg == 0 && tid == 0, L.vsRed));
   // (one workgroup per CU: a global round trip in this prologue is a round trip of the whole CU.  The lists' lengths and the
   // tiles' chromosome records -- two dependent loads -- are asked for first and arrive while the scratch is cleared)
   u32 myLen = 0;
@@ -687,20 +700,11 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     if (tid == 0) L.startC[nT] = (u32)tot;
   }
   __syncthreads();
-  if constexpr (PAIRS && !BIG) {
-    // what this launch does not take: it goes on the list of the second one, untouched
-    const u32 hh = tid < (int)nT ? L.hist[tid] : 0u;
-    const bool heavyTile = (hh & 0xFFFFu) + (hh >> 16) > SBT_HEAVY;
-    const bool big = __syncthreads_or((int)heavyTile) || ovfSlots || L.startC[nT] > keyCap || L.overflow == 1;
-    if (big) {  // block-uniform
-      if (tid == 0) out.bigList[atomicAdd(out.nBig, 1u)] = seg;
-      return;
-    }
-  }
-  // Pair mode: a bin with more keys than the key array holds (reads piled up: a tower, chrM) is worked off in ROUNDS of
-  // consecutive tiles whose keys fit -- the records stay in their registers, every round scatters the keys of its tiles
+  // Pair mode: a bin with more keys than the key array holds (reads piled up: a tower, chrM; with two workgroups per CU: the
+  // ordinary bin) is worked off in ROUNDS of consecutive tiles whose keys fit, every round scatters the keys of its tiles
   // only.  What still does not fit: more records than the slots take, a single tile beyond the array, too many rounds.
-  if (BIG && tid == 0) {
+  constexpr bool RNDS = BIG || (PAIRS && SBT_R1 > 1);
+  if (RNDS && tid == 0) {
     u32 nr = 0;
     bool fits = true;
     if (L.startC[nT] <= keyCap) {
@@ -728,10 +732,21 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     }
     L.nRounds = fits ? nr : 0u;
   }
-  if (BIG) __syncthreads();
-  const u32 nRounds = BIG ? L.nRounds : 1u;
+  if (RNDS) __syncthreads();
+  if constexpr (PAIRS && !BIG) {
+    // what this launch does not take: it goes on the list of the second one, untouched
+    const u32 hh = tid < (int)nT ? L.hist[tid] : 0u;
+    const bool heavyTile = (hh & 0xFFFFu) + (hh >> 16) > SBT_HEAVY;
+    const bool tooMany = RNDS ? L.nRounds == 0 || L.nRounds > SBT_R1 : L.startC[nT] > keyCap;
+    const bool big = __syncthreads_or((int)heavyTile) || ovfSlots || tooMany || L.overflow == 1;
+    if (big) {  // block-uniform
+      if (tid == 0) out.bigList[atomicAdd(out.nBig, 1u)] = seg;
+      return;
+    }
+  }
+  const u32 nRounds = RNDS ? L.nRounds : 1u;
   const u32 ovfWord = PAIRS ? L.overflow : 0u;  // (pair mode: 1 too many singles, 2 a fractional weight among them)
-  const bool ovfReal = ovfSlots || (BIG ? nRounds == 0 : L.startC[nT] > keyCap) || ovfWord != 0;
+  const bool ovfReal = ovfSlots || (RNDS ? nRounds == 0 : L.startC[nT] > keyCap) || ovfWord != 0;
   const bool ovf = ovfReal || GX_EXP_SBT == 1 || GX_EXP_SBT == 2;
   // (the slot capacity bounds a stream at 32 K keys -- pair mode: 32 K pairs and SBT_FCAP singles --, so a tile's 16-bit
   // counts cannot have wrapped)
@@ -818,7 +833,56 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     }
     }
   };
-  if constexpr (PAIRS && !BIG) {
+  if constexpr (PAIRS && !BIG && RNDS) {
+    // Two workgroups per CU: the records stay in their registers across the rounds, every round scatters the ends that lie in
+    // its tiles (the cursors count in the bin's order, the key array from the round's first key); while this workgroup loads,
+    // counts and scatters, the CU's other one walks its tiles.
+    for (u32 round = 0; round < nRounds; round++) {
+      const u32 tileBeg = L.rnd[round], nTr = L.rnd[round + 1] - tileBeg, tileEnd = tileBeg + nTr, keyBase = L.startC[tileBeg];
+      if (round) {
+        // (the records are not kept in their registers across the tile loop -- 175 spilled dwords --: a further round loads them
+        // again; they are in L2, and the CU's other workgroup has work meanwhile)
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          cS[i] = (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
+          kS[i] = make_uint4(0u, 0u, 0u, 0u);
+          if ((u32)lane * 4 < cS[i]) kS[i] = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
+        }
+        __syncthreads();  // (the previous round's tiles are through with the keys)
+        if (tid == 0) L.work = tileBeg;
+        __syncthreads();
+      }
+      auto placePairR = [&](u32 r) {
+        const u32 e = pairEnd(r), ts = pairTs(r), te = e >> TB;
+        const u32 so = ((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r), eo = (e & (TILE - 1)) | 0x8000u | pairCls(r);
+        const bool sIn = ts - tileBeg < nTr, eIn = te - tileBeg < nTr;
+        if (sIn) {
+          const u32 ps = atomicAdd(&L.cur[ts], ts == te ? 2u : 1u) - keyBase;
+          keysL[ps] = (uint16_t)so;
+          if (ts == te) keysL[ps + 1] = (uint16_t)eo;
+        }
+        if (eIn && ts != te) keysL[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)eo;
+      };
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        if (cS[i] == SBT_SLOT) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) placePairR(keyAt(kS[i], j));
+        } else if (cS[i]) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if ((u32)lane * 4 + j < cS[i]) placePairR(keyAt(kS[i], j));
+        }
+      }
+      for (u32 i = tid; i < nF; i += SBT_NT) {
+        const u64 r = srcF.at(i);
+        const u32 tl = (u32)(r >> 32) - segTileBase, off = (u32)(r >> 8) & (TILE - 1);
+        if (tl - tileBeg < nTr) keysL[atomicAdd(&L.cur[tl], 1u) - keyBase] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
+      }
+      __syncthreads();
+      tiles(tileEnd, keyBase);
+    }
+  } else if constexpr (PAIRS && !BIG) {
     {
       // one cursor per tile (starts and ends of a tile share its list: a key says which it is); a pair whose ends share a
       // tile takes its two places with one atomic
@@ -925,7 +989,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
 }
 
 template <bool PAIRS, bool BIG, bool FRAC, int TRC = SBT_TR>
-__global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
+__global__ __launch_bounds__(SBT_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
   SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
   if constexpr (!BIG)
