@@ -57,7 +57,22 @@ CONFIGS = {
             qval=False, control=False, atac=True, multimap=True, reps=1, gate_chroms=12),
     5: dict(name="configs[4]", desc="3 replicates, Fisher-combined p, global -q 0.05", qval=True, control=False, atac=False,
             multimap=False, reps=3, gate_chroms=6),
+    # the headline stream the way the reference's README runs its flagship command (README.md:463-465): -e chrM,chrY -E <N-gap
+    # regions> (synth.excluded_regions: 777 merged regions, 92 Mbp, one touching position 0, one reaching a chromosome's end)
+    "2E": dict(name="configs[1] with -e chrY,chrM -E <777 regions>", desc="treatment only, -p 0.01, -e chrY,chrM, -E 777 excluded regions (92 Mbp)",
+               qval=False, control=False, atac=False, multimap=False, reps=1, gate_chroms=8, excl=True),
 }
+for _c in CONFIGS.values():
+    _c.setdefault("excl", False)
+
+
+def exclusions(cfg, lens):
+    """(skip, beds) of a config: what gx_set_chroms takes besides the lengths."""
+    if not cfg["excl"]:
+        return None, None
+    skip = [False] * len(lens)
+    skip[23] = skip[24] = True   # chrY, chrM
+    return skip, synth.excluded_regions(lens, n=800, seed=7, skip=(23, 24))
 
 
 def source_hash():
@@ -70,11 +85,20 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+PATH_BITS = ((1, "fused"), (16, "pairs"), (128, "frac_pairs"), (2, "loose_sweep"), (4, "fell_back"), (8, "pt_grew"), (32, "dense_bh"),
+             (64, "range_bh"))
+
+
 def decode_path(flags):
-    """gx_path_info's bits by name (include/genrich_amd.h GX_PATH_*): which device path a context took."""
-    return {"fused_sort_tile_kernel": bool(flags & 1), "pair_records": bool(flags & 16), "fractional_pair_records": bool(flags & 128),
-            "sweep_on_loose_slots": bool(flags & 2), "fell_back_to_general_chain": bool(flags & 4), "page_tables_grew": bool(flags & 8),
-            "dense_bh_allreduce": bool(flags & 32), "range_bh_exchange": bool(flags & 64)}
+    """gx_path_info's bits by name (include/genrich_amd.h GX_PATH_*: k_sbtile, one record per fragment, ... with a weight class,
+    the sweep on the tile stage's loose slots, a sample sent back to the general chain, page tables grown, the dense /
+    range-partitioned BH exchange), joined with '+': which device path a context took."""
+    return "+".join(n for b, n in PATH_BITS if flags & b) or "general"
+
+
+def sig(x, n=4):
+    """n significant digits (the short per-config summary at the end of the line)"""
+    return None if x is None else float(f"{float(x):.{n}g}")
 
 
 _PLAIN = {}   # (fragments, seed) -> the plain config-2 stream of that seed: four of the default run's workloads start from seed 1
@@ -113,8 +137,8 @@ def subset(reps, n_chrom):
     return out
 
 
-def run_backend(be, lens, reps, peaks_to=None):
-    be.set_chroms(lens)
+def run_backend(be, lens, reps, peaks_to=None, skip=None, beds=None):
+    be.set_chroms(lens, skip, beds)
     t0 = time.perf_counter()
     for tv, cv in reps:
         be.sample_begin(0, None)
@@ -148,13 +172,16 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device, timed_path=Non
     par = B.make_params(pq=0.05 if qval else 0.01, qval=qval)
     td = tempfile.mkdtemp()
     po, ph = os.path.join(td, "o.narrowPeak"), os.path.join(td, "h.narrowPeak")
+    skip, beds = exclusions(cfg, lens)
+    if skip is not None:
+        skip, beds = skip[:n_chrom], beds[:n_chrom]
     o = B.Oracle(par)
-    dt = run_backend(o, sub_lens, sub, peaks_to=(po, names))
+    dt = run_backend(o, sub_lens, sub, peaks_to=(po, names), skip=skip, beds=beds)
     par.device = device
     h = Genrich(par)
     if cfg["multimap"]:
         h.expect_fractional(True)   # (what genrich-amd -s tells the library, and what the timed context was told)
-    run_backend(h, sub_lens, sub)
+    run_backend(h, sub_lens, sub, skip=skip, beds=beds)
     gate_flags = h.path_info()
     h.write_narrowpeak(names, ph)
     want, got = open(po, "rb").read(), open(ph, "rb").read()
@@ -171,6 +198,8 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device, timed_path=Non
     n_iv = 0
     ends_equal = True
     for c in range(n_chrom):
+        if skip is not None and skip[c]:
+            continue
         eo, co = o.get_intervals(-1, c)
         eh, ch = h.get_intervals(-1, c, piles=False)
         if len(eo) != len(eh) or not np.array_equal(eo, eh):
@@ -191,9 +220,8 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device, timed_path=Non
     n_ev = int(sum(len(t) + (0 if c is None else len(c)) for t, c in sub))
     gate_path = decode_path(gate_flags)
     # (the BH exchanges and "the page tables grew" belong to N ranks / to a pile-up, not to the choice of kernels)
-    same = timed_path is None or all(gate_path[k] == timed_path[k] for k in
-                                     ("fused_sort_tile_kernel", "pair_records", "fractional_pair_records", "sweep_on_loose_slots",
-                                      "fell_back_to_general_chain"))
+    kernels = lambda p: {x for x in p.split("+") if x in ("fused", "pairs", "frac_pairs", "loose_sweep", "fell_back")}  # noqa: E731
+    same = timed_path is None or kernels(gate_path) == kernels(timed_path)
     gate = dict(narrowpeak_diff=ndiff, peaks_oracle=int(o.n_peaks), peaks_hip=int(h.n_peaks), interval_ends_equal=ends_equal,
                 intervals_compared=n_iv, max_abs_dp=dp, max_abs_dq=dq if qval else None, pq_values_differing_in_bits=nbits,
                 device_path=gate_path, same_path_as_timed=bool(same),
@@ -235,9 +263,9 @@ def issue_roof(prof, kname, launches_per_step, launch_ms):
     live; valu_frac = that floor / the measured duration.  SALU instructions issue from the same wavefronts' streams
     (one instruction per wavefront and cycle) and are listed beside it."""
     if not prof or not prof.get("issue") or prof["issue"].get("kernel") != kname or launch_ms <= 0:
-        return prof.get("issue") if prof else None
-    out = dict(prof["issue"])
-    raw = out.get("raw", {})
+        return None
+    out = {k: v for k, v in prof["issue"].items() if k != "raw"}   # (no counter dumps in the line: profiles/ has them)
+    raw = prof["issue"].get("raw", {})
     valu = raw.get("SQ_INSTS_VALU", 0.0) / max(1.0, launches_per_step)
     salu = raw.get("SQ_INSTS_SALU", 0.0) / max(1.0, launches_per_step)
     n_simd, clock = 256 * 4, 2.4e9
@@ -294,8 +322,8 @@ def reference_e2e(lens, reps, max_frags=1_500_000):
             n = min(16, ncpu)
             pools = {"inflate": n, "decode": n, "state": n} if 3 * n + 2 <= ncpu or n <= 2 else \
                     {"inflate": max(2, n // 4), "decode": max(2, n // 2), "state": max(1, n // 2)}
-            host = {"records_per_s": nrec / hdt, "seconds": hdt, "threads": pools,
-                    "what": "genrich-amd --events-only on the same SAM text (parse, pair, weight -> events; no device work)"}
+            # (genrich-amd --events-only on the same SAM text: parse, pair, weight -> events; no device work)
+            host = {"records_per_s": nrec / hdt, "seconds": hdt, "threads": pools}
     for f in (sam, outp):
         if os.path.exists(f):
             os.remove(f)
@@ -348,8 +376,7 @@ def e2e_cli(lens, frags, n_frags=10_000_000):
                 return dict(out, error=f"genrich-amd exited with {rc}")
         dt = min(runs)
         out["genrich_amd"] = {"seconds": dt, "seconds_first_run": runs[0], "records_per_s": nrec / dt, "gbases_per_s": sum(lens) / dt / 1e9,
-                              "threads": "default (min(16, cores) per pool: inflate / decode / state)",
-                              "what": "process start + HIP initialisation + threaded SAM ingest + the device path + narrowPeak text"}
+                              "threads": "default"}   # (process start + HIP initialisation + threaded ingest + device path + text)
         if os.path.exists(ref):
             orf = os.path.join(td, "r.narrowPeak")
             t0 = time.perf_counter()
@@ -361,7 +388,7 @@ def e2e_cli(lens, frags, n_frags=10_000_000):
             if rc == 0:
                 same = open(orf, "rb").read() == open(oh, "rb").read()
                 out["reference"] = {"seconds": rdt, "records_per_s": nrec / rdt, "gbases_per_s": sum(lens) / rdt / 1e9, "threads": 1,
-                                    "kind": "reference", "what": "oracle/_ref/Genrich -t on the same file"}
+                                    "kind": "reference"}   # (oracle/_ref/Genrich -t on the same file)
                 out["narrowpeak_identical_to_reference"] = bool(same)
                 out["speedup_vs_reference"] = rdt / dt
             else:
@@ -377,7 +404,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frags", type=int, default=50_000_000)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=lambda v: v if v in CONFIGS else int(v), default=2, choices=list(CONFIGS))
     ap.add_argument("--qval", action="store_true", help="-q 0.05 instead of -p 0.01 (on top of --config)")
     ap.add_argument("--control", action="store_true", help="add a uniform control (on top of --config)")
     ap.add_argument("--lean", action="store_true",
@@ -435,30 +462,48 @@ def main():
                     want_e2e=not args.no_e2e, want_cpu=not args.no_cpu, headline=True)
     if rank == 0 and world == 1 and args.config == 2 and plain and not args.no_cpu and not args.no_others:
         # BASELINE.json's other GPU configs in the same line (the driver runs bench.py once, with defaults)
-        others = {}
+        detail, brief = {}, {}
         # "2q": the headline workload with -q 0.05 -- north_star's "p + q scan" of one 50 M-fragment sample
         cfg2q = dict(CONFIGS[2], qval=True, gate_chroms=8, name="configs[1] with -q 0.05",
                      desc=CONFIGS[2]["desc"].replace("-p 0.01", "-q 0.05"))
-        for c, ccfg, cplain in (("2q", cfg2q, False), (3, dict(CONFIGS[3]), True), (4, dict(CONFIGS[4]), True), (5, dict(CONFIGS[5]), True)):
+        for c, ccfg, cplain in (("2q", cfg2q, False), ("2E", dict(CONFIGS["2E"]), True), (3, dict(CONFIGS[3]), True), (4, dict(CONFIGS[4]), True),
+                                (5, dict(CONFIGS[5]), True)):
             try:
                 r = bench_one(2 if c == "2q" else c, ccfg, args, env, steps=5, warmup=3, plain=cplain, want_e2e=False, want_cpu=True,
                               headline=False)
-                others[str(c)] = {k: r[k] for k in ("ms_per_step", "value", "unit", "steps", "gate", "phases_ms") if k in r}
-                others[str(c)]["workload"] = r["config"]["workload"]
-                others[str(c)]["device_path"] = r["config"]["device_path"]
-                others[str(c)]["tables_written_in_step"] = r["config"]["tables_written_in_step"]
-                others[str(c)]["whole_step"] = r["roofline"]["whole_step"]
-                others[str(c)]["dominant"] = {k: r["roofline"].get(k) for k in ("kernel", "frac", "frac_is", "achieved", "launch_ms", "traffic", "traffic_frac", "algorithmic_bytes")}
-                others[str(c)]["cpu_baseline"] = r.get("cpu_baseline")
+                d = {k: r[k] for k in ("ms_per_step", "value", "gate", "phases_ms") if k in r}
+                d["workload"] = r["config"]["workload"]
+                d["whole_step"] = r["roofline"]["whole_step"]
+                d["dominant"] = {k: r["roofline"].get(k) for k in ("kernel", "frac", "frac_is", "achieved", "launch_ms", "traffic", "traffic_frac", "algorithmic_bytes")}
+                d["cpu_baseline"] = r.get("cpu_baseline")
+                detail[str(c)] = d
+                g, w = r.get("gate", {}), r["roofline"]["whole_step"]
+                brief[str(c)] = {"ms_per_step": sig(r["ms_per_step"]), "value": sig(r["value"]), "gate_passed": g.get("passed"),
+                                 "narrowpeak_diff": g.get("narrowpeak_diff"), "pq_bits_differing": g.get("pq_values_differing_in_bits"),
+                                 "path": r["config"]["device_path"], "dominant": r["roofline"]["kernel"],
+                                 "dominant_ms": sig(r["roofline"]["launch_ms"]), "dominant_frac": sig(r["roofline"]["frac"]),
+                                 "traffic_over_alg": sig(w.get("traffic_over_algorithmic"))}
             except Exception as e:  # noqa: BLE001  (the headline must still be printed)
-                others[str(c)] = {"error": repr(e)}
-        out["other_configs"] = others
+                brief[str(c)] = {"error": repr(e)[:120]}
+        out["other_configs_detail"] = detail
+        # north_star's sentence -- the p + q scan of one 50 M-fragment sample -- and the materialised step as flat keys, here and
+        # (the driver's record keeps the scalars of `config`) there
+        q2 = brief.get("2q", {})
+        flat = {"p_plus_q_ms_per_step": q2.get("ms_per_step"), "p_plus_q_value": q2.get("value"), "p_plus_q_gate_passed": q2.get("gate_passed"),
+                "excluded_regions_ms_per_step": brief.get("2E", {}).get("ms_per_step")}
+        out.update(flat)
+        out["config"].update(flat)
+        others_brief = brief
+    else:
+        others_brief = None
     if rank == 0 and world == 1 and args.config == 2 and plain and not args.no_cpu and not args.no_e2e:
         try:
             out["e2e_cli"] = e2e_cli(synth.HG38_LENS, args.frags)
         except Exception as e:  # noqa: BLE001
             out["e2e_cli"] = {"error": repr(e)}
     if rank == 0:
+        if others_brief is not None:
+            out["other_configs"] = others_brief   # LAST in the line, short: the tail of a truncated record still holds every config
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if world > 1:
@@ -487,7 +532,8 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
 
     params = GxParams(minus_log10f(0.05 if cfg["qval"] else 0.01), int(cfg["qval"]), 200.0, 0, 100, local_dev, 0)
     gx = Genrich(params)
-    gx.set_chroms(lens)
+    skip, beds = exclusions(cfg, lens)
+    gx.set_chroms(lens, skip, beds)
     # By default the whole interval table (end, treatment pileup, p) is materialised, as the reference holds it.
     # --lean drops the pileup floats, which only the -f / -k emitters read: reported as such in `config`.
     gx.set_keep_pileups(not args.lean)
@@ -496,7 +542,8 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     coll_kind = "none"
     force_rccl = world == 1 and os.environ.get("GX_BENCH_FORCE_RCCL") == "1"   # exercise the RCCL path with one rank
     if force_rccl:
-        os.environ["GX_FORCE_COLL"] = "1"
+        # (the library reads its switches once, in gx_create: the environment is too late here -- ADVICE r5)
+        gx.set_knob("GX_FORCE_COLL", 1)
         gx.set_rccl(0, 1, rccl_unique_id())
         coll_kind = "RCCL inside the library, one-rank communicator (exercise mode)"
     if world > 1:
@@ -525,11 +572,11 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             else:
                 # some rank could not open the library's communicator: all ranks take the callback route together
                 coll = Collectives(device=cdev)
-                gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
+                gx.set_collectives(rank, world, coll.allreduce_i64)
                 coll_kind = "host callbacks over torch.distributed/nccl (the library's own communicator failed)"
         else:
             coll = Collectives(device=cdev)
-            gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
+            gx.set_collectives(rank, world, coll.allreduce_i64)
             coll_kind = f"host callbacks over torch.distributed/{backend} (validation mode)"
     rccl_nranks = gx.rccl_nranks()
 
@@ -566,8 +613,9 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     # untimed steps afterwards.
     prof = load_profile(config, args.frags, world, plain)
     dom = prof.get("dominant", {}).get("kernel") if prof else None
-    dom_phase = KERNEL_PHASE.get(dom, "tile")
-    if dom not in KERNEL_PHASE:
+    # (its phase: from the profile's own marker trace -- roctx ranges, GX_ROCTX -- when it has one; the table otherwise)
+    dom_phase = (prof["kernels"].get(dom, {}).get("phase") if prof and dom else None) or KERNEL_PHASE.get(dom, "tile")
+    if dom not in KERNEL_PHASE and not (prof and prof["kernels"].get(dom, {}).get("phase")):
         dom = None
     gx.set_phase_filter(dom_phase)
     for _ in range(warmup):
@@ -581,6 +629,8 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     barrier()
     dt = time.perf_counter() - t0
     path_flags = gx.path_info()   # (after the timed steps: which path THEY took, and whether they wrote pileup floats)
+    if force_rccl and cfg["qval"] and not path_flags & (32 | 64):
+        raise RuntimeError("GX_BENCH_FORCE_RCCL: the BH exchange did not go through the collectives (path flags %#x)" % path_flags)
     # The same step with the tight interval table MATERIALISED (GX_NO_LOOSE: lambda only after the tile stage, then
     # k_pack_pval writes (end, p) and the sweep's masks, as every run with -q / a control / a further replicate / -f / -k
     # does): what the default step of a single -p sample leaves out because the sweep reads (end, V) where the tile
@@ -639,7 +689,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
         live_ms = sum(phases.get(pfx + dom_phase, 0.0) for pfx in (("t.", "c.") if per_sample else ("",)))
         if per_sample and cfg["control"]:
             live_ms /= 2
-        kname = dom or ("k_sbtile" if path_flags & 1 else "k_tile_fast")
+        kname = dom or ("k_sbtile" if path_flags & 1 else "k_tile" if cfg["excl"] else "k_tile_fast")
         kprof = prof["kernels"].get(kname) if prof else None
         # (a sample's tile stage = k_sbtile's first launch + its second, usually idle one over the listed bins: ONE launch
         # here, as the phase timer brackets both -- the profile counts the instances of the template apart)
@@ -671,7 +721,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
         whole_traffic = prof["whole_step"]["hbm_bytes_per_step"] if prof else None
         roof = {
             "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "frac_is": "algorithmic bytes" if alg_k else "PMC traffic (no closed form of this kernel's compulsory bytes)",
+            "frac": achieved / HBM_PEAK_GBS, "frac_is": "algorithmic bytes" if alg_k else "PMC traffic (no closed form)",
             "traffic": traffic, "traffic_gbs": traffic_gbs, "traffic_frac": (traffic_gbs / HBM_PEAK_GBS) if traffic_gbs else None,
             "launch_ms": live_ms / (1.0 if per_sample else klaunch),
             "algorithmic_bytes": alg_k,
@@ -686,15 +736,7 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                 "traffic_over_algorithmic": (whole_traffic / alg_step) if whole_traffic else None,
             },
             "issue": issue_roof(prof, kname, launches if per_sample else klaunch, live_ms / (1.0 if per_sample else klaunch)),
-            "dense_model": {"bytes": 8.0 * G + 16.0 * ev_n + 52.0 * iv0,
-                            "note": "SURVEY 8(d)'s dense int32-array model; the array lives in LDS here, so this is not HBM traffic"},
-            "note": "kernel = the longest kernel of this build's rocprofv3 profile of this config (profiles/); achieved = the ALGORITHMIC "
-                    "bytes of a launch (DESIGN.md section 4: pair records in, 8 B per interval + 56 B per tile out; a sample's tile stage "
-                    "-- k_sbtile's first launch and its usually idle second one -- counts as one launch) / its mean duration measured here "
-                    "(HIP events on the library's stream, inside the timed region); traffic_gbs / traffic_frac = the same with the HBM "
-                    "bytes the kernel moves per launch (PMC FETCH_SIZE x2 + WRITE_SIZE of that profile); both <= 1 by construction.  `traffic` (here and in whole_step) is NOT measured in this run: it is "
-                    "the PMC figure of the committed profile of this very build (source hash checked), collected by "
-                    "tools/profile_round.sh in separate rocprofv3 --pmc passes",
+            "dense_model_bytes": 8.0 * G + 16.0 * ev_n + 52.0 * iv0,   # SURVEY 8(d)'s dense int32-array model (the array lives in LDS here)
         }
         qdesc = cfg["desc"]
         out = {
@@ -721,28 +763,22 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                 "peaks": n_peaks,
                 "intervals": int(iv0),
                 "events_per_step": int(ev_n),
-                # what the timed step wrote to HBM besides the loose (end, V) slots of the tile stage
-                "tables_written_in_step": {
-                    "tight_interval_table_end_p": not loose,
-                    "p_values_per_interval": not loose,
-                    # (gx_path_info bit 8: k_piles_from_loose ran in a timed step; they are made on request only -- gx_get_intervals,
-                    # -f / -k -- and a replicate keeps its exact pileups for that; with a control k_pack_pairs writes them)
-                    "pileup_floats": bool(path_flags & 256) or (bool(cfg["control"]) and not args.lean),
-                    "note": ("single -p sample: the sweep walks the tile stage's (end, V) slots, p comes from the table p(V); "
-                             "the tight table is made when somebody asks (gx_get_intervals) -- see `materialised`") if loose else
-                            "the tight (end, p[, q]) table of the final p-array",
-                },
+                # what the timed step wrote to HBM besides the loose (end, V) slots of the tile stage and the sweep's masks
+                # (pileup floats: gx_path_info bit 8, or k_pack_pairs with a control)
+                "tables_written_in_step": ("none: the sweep walks the loose (end, V) slots, p = table p(V)" if loose else
+                                           "tight (end, p[, q]) interval table"
+                                           + (" + pileup floats" if bool(path_flags & 256) or (bool(cfg["control"]) and not args.lean) else "")),
                 "source_hash": source_hash(),
             },
             "roofline": roof,
+            # the same step with the tight (end, p) table written (k_pack_pval) and the sweep on it
             "materialised": ({"ms_per_step": mat_ms, "value": n_rep * G / (mat_ms * 1e-3) / 1e9, "unit": "Gbases/s",
-                              "sweep_on_loose_slots": bool(mat_flags & 2),
-                              "note": "the same step with the tight (end, p) interval table written (k_pack_pval) and the sweep on it"}
-                             if mat_ms else None),
+                              "sweep_on_loose_slots": bool(mat_flags & 2)} if mat_ms else None),
+            "materialised_ms_per_step": mat_ms,
+            # (the roofline kernel's phase: HIP events inside the timed region; the others: two extra untimed steps)
             "phases_ms": phases,
-            "phases_note": f"{dom_phase}: HIP events inside the timed region; the other phases: two extra untimed steps "
-                           "(an event record costs the stream ~5 us, so the timed steps carry only the roofline kernel's pair)",
         }
+        out["config"]["materialised_ms_per_step"] = mat_ms
         if world == 1 and want_e2e:
             # PCIe upload of the events from pinned host memory, and a step that starts there (gx_push_events)
             pin = [(torch.from_numpy(tv.view(np.uint32).reshape(-1, 4)).pin_memory(),
@@ -783,11 +819,9 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                 step_from_host()
             torch.cuda.synchronize()
             e2e_ms = (time.perf_counter() - t1) / 3 * 1e3
-            out["h2d"] = {"ms": h2d_ms, "bytes": nbytes, "gbs": nbytes / h2d_ms / 1e6,
-                          "note": "events from pinned host memory to HBM (outside the timed region of `value`)"}
-            out["e2e_from_pinned"] = {"ms_per_step": e2e_ms, "value": n_rep * G / (e2e_ms * 1e-3) / 1e9, "unit": "Gbases/s",
-                                      "note": "gx_push_events_pinned: 64 MiB pieces uploaded on a side stream, the first kernel "
-                                              "(k_sort1) starts on the pieces that have arrived -> peak list on the host"}
+            # (events from pinned host memory to HBM, outside the timed region of `value`; and gx_push_events_pinned -> peaks)
+            out["h2d"] = {"ms": h2d_ms, "bytes": nbytes, "gbs": nbytes / h2d_ms / 1e6}
+            out["e2e_from_pinned"] = {"ms_per_step": e2e_ms, "value": n_rep * G / (e2e_ms * 1e-3) / 1e9, "unit": "Gbases/s"}
             del pin
     # the timed context and its device arrays go before the gate's (and the next config's) are made
     gx.close()
@@ -824,10 +858,9 @@ def gate_merged_peaks(cfg, lens, reps, gathered, qval):
     ndiff = 0 if same else max(1, abs(len(got) - len(want)) + int(sum(1 for a, b in zip(got, want) if a.tobytes() != b.tobytes())))
     bases = float(sum(lens)) * len(reps)
     n_ev = int(sum(len(t) + (0 if c is None else len(c)) for t, c in reps))
-    gate = dict(narrowpeak_diff=ndiff, peaks_oracle=int(len(want)), peaks_hip=int(len(got)), passed=bool(same),
-                note="the ranks' peak records gathered to rank 0 and merged in chromosome order, compared field by field "
-                     "(chrom, start, end, summit, AUC / p / q bits) with the oracle's list for the whole workload: the narrowPeak "
-                     "text is a function of exactly these records")
+    # (the ranks' peak records gathered to rank 0, merged in chromosome order and compared field by field -- chrom, start, end,
+    # summit, AUC / p / q bits -- with the oracle's list for the whole workload: the narrowPeak text is a function of these)
+    gate = dict(narrowpeak_diff=ndiff, peaks_oracle=int(len(want)), peaks_hip=int(len(got)), passed=bool(same))
     cpu = dict(value=bases / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
                sample=f"the whole workload ({sum(lens)/1e6:.0f} Mbp x {len(reps)} replicate(s), {n_ev} events), events in memory -> "
                       f"peaks, {dt:.1f} s")

@@ -27,7 +27,6 @@ const char* gx_strerror(int status) {
     case GX_ERR_DF: return "Invalid df in pchisq()";
     case GX_ERR_ORDER: return "API called out of order";
     case GX_ERR_DEVICE: return "HIP device failure";
-    case GX_ERR_OVERFLOW: return "per-base difference beyond the reference's int16 range";
     default: return "Unknown error";
   }
 }
@@ -141,17 +140,15 @@ int gx_set_chroms(gx_ctx* ctx, int n, const uint32_t* len, const uint8_t* skip, 
   return GX_OK;
 }
 
-int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce, gx_allgather_tab_fn allgather,
-                       void* user) {
+int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce, void* user) {
   if (!ctx || world < 1 || rank < 0 || rank >= world) return GX_ERR_ORDER;
-  if (ctx->comm && (allreduce || allgather)) {  // callbacks replace a communicator of gx_set_rccl
+  if (ctx->comm && allreduce) {  // callbacks replace a communicator of gx_set_rccl
     if (const gxrccl::Api* api = gxrccl::load(nullptr)) (void)api->commDestroy(ctx->comm);
     ctx->comm = nullptr;
   }
   ctx->rank = rank;
   ctx->world = world;
   ctx->allreduce = allreduce;
-  ctx->allgather = allgather;
   ctx->user = user;
   ctx->forceColl = ctx->knob.forceColl != 0;
   return GX_OK;
@@ -376,13 +373,20 @@ int gx_sample_end(gx_ctx* ctx, double* frag_len, float* lambda, float* factor) {
 
 int gx_expect_fractional(gx_ctx* ctx, int on) {
   if (!ctx) return GX_ERR_ORDER;
-  // (a hint can only add knowledge: what the library has learned from a sample by itself stays)
-  if (on) ctx->sawFrac = true;
+  // (a hint selects kernels; what the library has learned from a sample by itself -- sawFrac -- is not the hint's to clear)
+  ctx->fracHint = on != 0;
   return GX_OK;
 }
 
 int gx_set_knob(gx_ctx* ctx, const char* name, const char* value) {
   if (!ctx || !name) return GX_ERR_ORDER;
+  // (GX_BH_CAPLOG, GX_PT_JMAX and GX_SBSHIFT size tables when the context and its tile layout are made: on a live context
+  // they would change nothing, so they are refused instead of accepted without effect)
+  for (const char* fixed : {"GX_BH_CAPLOG", "GX_PT_JMAX", "GX_SBSHIFT"})
+    if (!strcmp(name, fixed)) {
+      ctx->err = std::string(name) + " is read when the context is made (environment); it cannot change afterwards";
+      return GX_ERR_ORDER;
+    }
   if (!set_knob(ctx->knob, name, value)) {
     ctx->err = std::string("unknown switch ") + name;
     return GX_ERR_ORDER;

@@ -97,12 +97,15 @@ __global__ __launch_bounds__(256) void k_bhx_reduce(const u64* __restrict__ chun
 
 // the owner's answers: q of every record it received, in the order it received them
 __global__ __launch_bounds__(256) void k_bhx_answer(const BhRec* __restrict__ recs, u32 n, const u32* __restrict__ keys, u32 capMask,
-                                                    const float* __restrict__ qOfSlot, float* __restrict__ out) {
+                                                    const float* __restrict__ qOfSlot, float* __restrict__ out, u32* __restrict__ st) {
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const u32 key = recs[i].key;
     u32 h = bh_hash(key) & capMask;
     u32 gk;
     while ((gk = keys[h]) != key && gk != EMPTY_KEY) h = (h + 1) & capMask;  // (inserted a moment ago: the probe ends at the key)
+    // (a key that is not there -- a record lost on its way: with -L nothing else would notice -- fails the run as k_qlookup's
+    // probe does, computeQval 377-382, instead of leaving a q of 0 behind)
+    if (gk != key) atomicOr(st, ST_BH_LEN);
     out[i] = gk == key ? qOfSlot[h] : 0.0f;
   }
 }

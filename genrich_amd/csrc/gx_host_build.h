@@ -120,9 +120,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   gx_ctx::Stream& SF = ctx->str[2];
   const u32 nL1base = nSB - 1;  // level-1 bins = super-buckets (records without a tile are not scattered at all)
   // ---- what the tile stage will be -------------------------------------------------------------------------
-  // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- unit weights, no -E regions, at most
-  // 2^8 tiles per super-bucket, and bins that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional
-  // record ST_SB_FRAC: finish_scalars then has the sample built again on the general chain).
+  // k_sbtile (gx_sbtile.h): level 2 of the sort fused with the tile passes -- at most 2^8 tiles per super-bucket, and bins
+  // that fit its LDS (a bin that does not raises ST_SB_FULL, a fractional record among unit-weight ones ST_SB_FRAC:
+  // finish_scalars then has the sample built again on the general chain).  -E regions ride it since round 6 (pair mode: the
+  // tiles with an edge are the second launch's, gx_sbtile.h TM_BEDX).
   // (a sample whose predecessor of the same kind did not fit is not even tried for a while: the same experiment's
   // next replicate, or the next run on the same data, has the same pile-ups)
   const bool backoff = !ctx->fusedOff && ctx->fusedBackoff[isCtrl ? 1 : 0] > 0;
@@ -131,13 +132,14 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // (fractional weights ride the pair records -- k_sort_a<true>, k_sbtile<.., true> -- once a sample of this context has
   // shown one; the start / end keys of the other fused variant cannot carry a weight)
   const bool fracOk = pairsAllowed && !K.noFracPairs;
-  const bool fused = !backoff && unit32 && !ctx->hasBed && ctx->sbShift <= SBT_MAXSHIFT && !noFused && (!ctx->sawFrac || fracOk) &&
-                     !ctx->fusedOff && !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1base) * 64000 &&
-                     (size_t)2 * nEv + nTiles + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
+  const bool fracLikely = ctx->sawFrac || ctx->fracHint;
+  const bool fused = !backoff && unit32 && (!ctx->hasBed || (pairsAllowed && !K.noBedFused)) && ctx->sbShift <= SBT_MAXSHIFT && !noFused &&
+                     (!fracLikely || fracOk) && !ctx->fusedOff && !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1base) * 64000 &&
+                     (size_t)2 * nEv + nTiles + ctx->nBedEdges + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
   ctx->fusedUsed = fused;
   // ... and with it level 1: one record per fragment (k_sort_a / k_sort_b) when k_sbtile will read it
   const bool pairs = fused && !reuseSort && pairsAllowed;
-  const bool fracPairs = pairs && ctx->sawFrac;
+  const bool fracPairs = pairs && fracLikely;
   ctx->pairsUsed = pairs;
   ctx->fracPairsUsed = fracPairs;
 
@@ -150,7 +152,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // key than the rounds of full-size bins -- 2.98 against 2.67 ms)
   const bool forceHalf = K.forceHalfBins != 0;  // (tests: the 128-key level 1 on a small input)
   if (pairs && (!fracPairs || forceHalf || K.fracHalfBins) && sbS > 0 &&
-      (forceHalf || (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * SBT_R1 * (SBT_KEYCAP - SBT_KEYCAP / 10)) &&
+      (forceHalf || (size_t)2 * nEv > (size_t)std::max(1u, nL1base) * (SBT_KEYCAP - SBT_KEYCAP / 10)) &&
       ((nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1)) <= (u32)MAX_BINS_P && !K.noHalfBins) {
     sbS--;
     nL1 = (nTiles + (1u << sbS) - 1) >> sbS;
@@ -267,7 +269,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
   FragFix* ff = ctx->fragSum.as<FragFix>();
   u32* slowFrag = &ff->slow;
-  if (ctx->hasBed || !unit32 || forceSlowFrag) HIPCHECK(hipMemsetAsync(slowFrag, 1, 4, s));
+  // (-E regions: the fused tile stage takes the excluded bases' pileup off the closed form, FragFix::bedExcl; k_tile<BED> does not)
+  if ((ctx->hasBed && !fused) || !unit32 || forceSlowFrag) HIPCHECK(hipMemsetAsync(slowFrag, 1, 4, s));
   PagedStream PG3[3];
   for (int q = 0; q < 3; q++) {
     gx_ctx::Stream& st = ctx->str[q];
@@ -395,7 +398,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   phase_begin(ctx, isCtrl ? "c.tile" : "t.tile");  // k_tile alone: the dominant kernel (bench.py's roofline)
   TileIn tin{SS.a.as<uint16_t>(), SE.a.as<uint16_t>(), SF.a.as<u64>(), ctx->tileMeta.as<TileMeta>()};
   // the tile stage is k_tile_fast (+ k_tile_heavy): the general fragLen path's terms ride in it (TileIn::fragAcc)
-  ctx->fragFused = (!fused && !ctx->hasBed) || ctx->fracPairsUsed;
+  // (-E regions: k_frag_walk's general path walks every interval, on either chain)
+  ctx->fragFused = !ctx->hasBed && (!fused || ctx->fracPairsUsed);
   if (ctx->fragFused) {
     tin.ff = ff;
     tin.fragAcc = acc;
@@ -418,16 +422,15 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     HIPCHECK(ctx->bigBins.ensure((size_t)(MAX_BINS_P + 4) * 4));
     SbtIn si{PG3[0], PG3[1], PG3[2], SS.sbOff.as<u32>(), SE.sbOff.as<u32>(), SF.sbOff.as<u32>(), ctx->dTileChrom.as<u32>(),
              ctx->dChrom.as<DChrom>(), ctx->chromW0.as<int>(), nL1, nTiles, sbS,
-             ctx->fracPairsUsed ? (const FragFix*)ff : (const FragFix*)nullptr, ctx->fracPairsUsed ? acc : (long long*)nullptr};
+             ctx->fragFused && ctx->fracPairsUsed ? (const FragFix*)ff : (const FragFix*)nullptr,
+             ctx->fragFused && ctx->fracPairsUsed ? acc : (long long*)nullptr, ctx->hasBed ? bin : BedIn{nullptr, nullptr, nullptr},
+             ctx->hasBed ? ff->fragSum : (u64*)nullptr};
     SbtOut so2{to, ctx->tileMeta.as<TileMeta>(), ctx->tileSlot.as<u32>(), ctx->nWide.as<u32>() + 1, ctx->nWide.as<u32>() + 13,
                ctx->bigBins.as<u32>(), ctx->heavyList.as<u32>(), ctx->nWide.as<u32>() + 2};
     const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
     // a sample so dense that the average bin already holds more keys than the key array (ATAC cut sites of a deep
     // library): every bin takes the rounds of the second launch, the first one would only find that out bin by bin
-#ifndef GX_SBT_ALLBIG
-#define GX_SBT_ALLBIG 0
-#endif
-    const bool dense = ctx->pairsUsed && (GX_SBT_ALLBIG || (size_t)2 * nEv > (size_t)std::max(1u, nL1) * SBT_R1 * (SBT_KEYCAP - SBT_KEYCAP / 16));
+    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 16);
     if (dense) {
       so2.bigList = nullptr;
       // touched bases per round of the tile passes against keys per round of a bin (they share the LDS, gx_sbtile.h): what
@@ -612,6 +615,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     return rc__;
   }
   ctx->hScal = ctx->mail->scal;
+  if (ctx->hScal.fracSeen) ctx->sawFrac = true;  // (learned, not hinted: the next sample does without the early lambda)
   ctx->riskNearThr = false;
   const int rcRisk = risk_apply(ctx, RiskTargets{});
   if (!isCtrl) ctx->looseOk = ctx->mail->nMerged != 0 && !ctx->riskNearThr;

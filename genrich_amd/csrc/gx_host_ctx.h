@@ -152,6 +152,7 @@ struct Knobs {
   int noLoose = 0;        // GX_NO_LOOSE: lambda after the tile stage, tight table, the sweep on it
   int noPairs = 0;        // GX_NO_PAIRS: k_sort1's start / end keys for k_sbtile
   int noFracPairs = 0;    // GX_NO_FRAC_PAIRS: fractional weights take the general chain
+  int noBedFused = 0;     // GX_NO_BED_FUSED: a run with -E regions takes the general chain (k_tile<BED>), as until round 5
   int forceHalfBins = 0;  // GX_FORCE_HALF_BINS: the 128-key level 1 on a small input
   int noHalfBins = 0;     // GX_NO_HALF_BINS
   int fracHalfBins = 0;   // GX_FRAC_HALF_BINS: half-size bins also for a dense sample with fractional weights (measurements)
@@ -164,6 +165,7 @@ struct Knobs {
   int bhCapLog = 0;       // GX_BH_CAPLOG: log2 of the BH table's first size
   int ptJmax = 0;         // GX_PT_JMAX: pages per level-1 list at first
   int sbtTr = 0;          // GX_SBT_TR: 384 / 448: which instance of k_sbtile's dense launch runs (measurements; default: by the sample's density)
+  int roctx = 0;          // GX_ROCTX: a roctx range around every phase (rocprofv3 --marker-trace: kernel -> phase attribution)
   int fault = 0;          // GX_FAULT: fault injection for the tests of the device-side invariants.  1: the weight of the ends at
                           // chromosome 0's length is damaged behind level 1 of the sort (as if an end record had been lost)
 };
@@ -172,17 +174,24 @@ const KnobDef KNOBS[] = {
     {"GX_DEBUG", &Knobs::debug, nullptr}, {"GX_DEBUG_RETRY", &Knobs::debugRetry, nullptr}, {"GX_NO_SPIN", &Knobs::noSpin, nullptr},
     {"GX_FORCE_REC64", &Knobs::forceRec64, nullptr}, {"GX_FORCE_SLOWFRAG", &Knobs::forceSlowFrag, nullptr},
     {"GX_NO_FUSED", &Knobs::noFused, nullptr}, {"GX_NO_LOOSE", &Knobs::noLoose, nullptr}, {"GX_NO_PAIRS", &Knobs::noPairs, nullptr},
-    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
+    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
     {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
     {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
     {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
     {"GX_PT_JMAX", &Knobs::ptJmax, nullptr}, {"GX_FAULT", &Knobs::fault, nullptr}, {"GX_SBT_TR", &Knobs::sbtTr, nullptr},
+    {"GX_ROCTX", &Knobs::roctx, nullptr},
 };
-// a switch that is merely present counts as 1 (GX_NO_LOOSE= is "on", as it was with getenv() != nullptr)
+// a switch that is merely present counts as 1 (GX_NO_LOOSE= is "on", as it was with getenv() != nullptr), and so does a
+// value that is not a number (GX_NO_LOOSE=yes)
 bool set_knob(Knobs& k, const char* name, const char* value) {
   for (const KnobDef& d : KNOBS)
     if (!strcmp(d.name, name)) {
-      const long long v = value && *value ? atoll(value) : 1;
+      long long v = 1;
+      if (value && *value) {
+        char* end = nullptr;
+        v = strtoll(value, &end, 10);
+        if (end == value) v = 1;
+      }
       if (d.i) k.*(d.i) = (int)v; else k.*(d.ll) = v;
       return true;
     }
@@ -236,7 +245,10 @@ struct gx_ctx {
   };
   size_t b2LdsSet = 0;          // dynamic LDS the level-2 kernel was last configured for
   bool sbtLdsSet = false;       // ... and k_sbtile
-  bool sawFrac = false;         // a sample of this context held fractional weights: k_sbtile is not tried again
+  bool sawFrac = false;         // a sample of this context HELD fractional weights (learned: ST_SB_FRAC, Scalars::fracSeen): no closed
+                                // form of fragLen, no early lambda, no loose-slot sweep from then on
+  bool fracHint = false;        // gx_expect_fractional: only selects the kernels that can carry a weight class (k_sort_a<true>,
+                                // k_sbtile<.., true>); on unit-weight data they give what the unit-weight instances give
   bool fusedOff = false;        // this sample: a super-bucket did not fit k_sbtile (the general chain runs instead)
   bool fusedUsed = false;       // the last build went through k_sbtile
   bool pairsUsed = false;       // ... on level 1's pair records (k_sort_a / k_sort_b)
@@ -292,7 +304,6 @@ struct gx_ctx {
   // collectives
   int rank = 0, world = 1;
   gx_allreduce_i64_fn allreduce = nullptr;
-  gx_allgather_tab_fn allgather = nullptr;
   void* user = nullptr;
   ncclComm_t comm = nullptr;    // the library's own collectives (gx_set_rccl): RCCL on device buffers, on `stream`
   bool forceColl = false;       // GX_FORCE_COLL=1: run the collectives with a single rank too (tests)
@@ -306,6 +317,7 @@ struct gx_ctx {
   u32 statusSeen = 1;       // status bits read back since the device word was last cleared (1: not cleared yet)
   u64 runCap = 0, runSeen = 0;  // run_sweep: runs its arrays are sized for; runs of the last sweep
   bool phaseOpen = false;
+  bool roctxOpen = false;       // (GX_ROCTX: the range of the open phase)
   int numCU = 0, resTile = 0, resTileHalf = 0, resTileFast = 0, resSweep = 0;  // co-resident workgroups per kernel class
   // recycled device buffers (gx_reset keeps allocations alive across runs)
   std::vector<DevBuf> pool;
@@ -374,7 +386,36 @@ static bool phase_wanted(const gx_ctx* ctx, const char* name) {
   const char* base = name[0] && name[1] == '.' ? name + 2 : name;  // "t.tile" / "c.tile" -> "tile"
   return ctx->phaseFilter == base;
 }
+// roctx ranges ("roctx ranges per phase"): host-side markers of the profiler, opened at run time like RCCL --
+// librocprofiler-sdk-roctx is what rocprofv3 --marker-trace listens to, libroctx64 its predecessor.  Absent: no ranges.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+static const RoctxApi* roctx_api() {
+  static RoctxApi api;
+  static std::once_flag once;
+  std::call_once(once, [&]() {
+    for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (!h) continue;
+      api.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      api.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (api.push && api.pop) break;
+      api.push = nullptr;
+      api.pop = nullptr;
+    }
+  });
+  return api.push ? &api : nullptr;
+}
 void phase_begin(gx_ctx* ctx, const char* name) {
+  if (ctx->knob.roctx)
+    if (const RoctxApi* r = roctx_api()) {
+      char buf[48];
+      snprintf(buf, sizeof buf, "gx:%s", name);
+      (void)r->push(buf);
+      ctx->roctxOpen = true;
+    }
   ctx->phaseOpen = phase_wanted(ctx, name);
   if (!ctx->phaseOpen) return;
   if (ctx->nPhases == ctx->phases.size()) {
@@ -390,6 +431,10 @@ void phase_begin(gx_ctx* ctx, const char* name) {
 void phase_end(gx_ctx* ctx) {
   if (ctx->phaseOpen) (void)hipEventRecord(ctx->phases[ctx->nPhases - 1].b, ctx->stream);
   ctx->phaseOpen = false;
+  if (ctx->roctxOpen) {
+    (void)roctx_api()->pop();
+    ctx->roctxOpen = false;
+  }
 }
 
 int status_to_rc(gx_ctx* ctx, u32 st) {
@@ -402,7 +447,6 @@ int status_to_rc(gx_ctx* ctx, u32 st) {
       {ST_BAD_COUNT, GX_ERR_ALNS, "Disallowed number of alignments"},
       {ST_NEG_PILE, GX_ERR_PILE, "Invalid pileup value (< 0)"},
       {ST_NO_FRAGS, GX_ERR_EXPT, "Experimental sample has no analyzable fragments"},
-      {ST_SAT16, GX_ERR_OVERFLOW, "per-base difference beyond the reference's int16 range"},
       {ST_HASH_FULL, GX_ERR_DEVICE, "p-value table full"},
       {ST_BAD_DF, GX_ERR_DF, "Invalid df in pchisq()"},
       {ST_PT_FULL, GX_ERR_MEM, "level-1 page table full"},

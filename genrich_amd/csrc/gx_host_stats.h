@@ -65,7 +65,9 @@ int ensure_piles(gx_ctx* ctx, int idx) {
   hipStream_t s = ctx->stream;
   HIPCHECK(pooled(ctx, pa.expt, (size_t)pa.n * 4 + 16));
   if (ctx->hasBed) HIPCHECK(pooled(ctx, pa.ctrl, (size_t)pa.n * 4 + 16));
-  PackIn pin{ctx->looseEnd.as<u32>(), pa.keptLoose ? pa.keptV.as<int>() : ctx->looseV.as<int>(),
+  // (PackIn::end of a kept replicate would be a LATER sample's ends -- the replicate kept its pileups and descriptors only, and
+  // k_piles_from_loose reads nothing else: a null pointer says so)
+  PackIn pin{pa.keptLoose ? (const u32*)nullptr : ctx->looseEnd.as<u32>(), pa.keptLoose ? pa.keptV.as<int>() : ctx->looseV.as<int>(),
              pa.keptLoose ? pa.keptMeta.as<TileMeta>() : ctx->tileMeta.as<TileMeta>(), pa.tileOff.as<u32>()};
   const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
   // (the control value of a replicate without control is its lambda: saveLambda 1847-1876)

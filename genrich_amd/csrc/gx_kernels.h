@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(TH_NT) void k_tile_heavy(TileIn in, const u32* __re
 // walks every interval and accumulates exactly in (integer, fraction * 2^27) form.
 struct FragFix {
   u64 fragSum[FRAG_SLOTS];  // closed form partial sums
-  u32 slow;                 // general path wanted
+  u32 slow;                 // general path wanted (bit 1: a fractional weight was seen, FRAG_SLOW_FRAC)
   u32 nList;
   long long corr;
   u32 nF;                   // fractional records appended by k_convert (not fragLen's, but zeroed with it)
@@ -1475,6 +1475,7 @@ struct Scalars {
   float lambda;
   float factor;
   u64 genomeLen;
+  u64 fracSeen;          // the sample just closed held a fractional weight (count > 1: Genrich's -s)
 };
 
 // fragLen / ctrlFrag (exact fixed-point parts, summed over all ranks when `coll` is given) -> lambda, factor
@@ -1544,6 +1545,7 @@ __device__ __forceinline__ void frag_select_body(const FragSelect& A, const u32*
   }
   const u32* hot = A.hot;
   const int isCtrl = A.isCtrl;
+  scal->fracSeen = (ff->slow >> 1) & 1u;
   if (!ff->slow) {
     u64 t = 0;
     for (int i = 0; i < FRAG_SLOTS; i++) t += ff->fragSum[i];

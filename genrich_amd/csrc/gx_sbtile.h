@@ -45,10 +45,7 @@ namespace gx {
 #define GX_EXP_SBT 0
 #endif
 
-#ifndef GX_SBT_NT
-#define GX_SBT_NT 1024
-#endif
-constexpr int SBT_NT = GX_SBT_NT;                      // threads of a workgroup: 1024 = one workgroup per CU; 512 = two (half the LDS each)
+constexpr int SBT_NT = 1024;
 constexpr int SBT_NW = SBT_NT / 64;
 constexpr int SBT_TILES = 1 << SBT_MAXSHIFT;          // tiles per super-bucket the LDS tables are made for
 constexpr int SBT_K = 8;                               // 16-byte loads per lane and stream (start / end keys)
@@ -56,12 +53,9 @@ constexpr int SBT_K = 8;                               // 16-byte loads per lane
 #define GX_SBT_KP 8
 #endif
 constexpr int SBT_KP = GX_SBT_KP;                      // ... of pair records kept in registers (pair mode: one stream)
-constexpr int SBT_KX = 16 * (1024 / SBT_NT);           // ... and slots per wavefront in all (64 K pair records per bin): those beyond SBT_KP (a bin of
-                                                       // more than 32 K pairs: reads piled up) are read from global memory by every pass that wants them
-static_assert(SBT_KP <= SBT_KX, "the slot tables hold SBT_KX x SBT_NW descriptors");
-// rounds of a bin that the FIRST launch works off with its records in registers (two workgroups per CU share the LDS: the key
-// array holds about half an ordinary bin); beyond that a bin goes on the second launch's list
-constexpr u32 SBT_R1 = SBT_NT < 1024 ? 3u : 1u;
+constexpr int SBT_KX = 16;                             // ... and slots per wavefront in all: those beyond SBT_KP (a bin of more than 32 K pairs:
+                                                       // reads piled up) are read from global memory by every pass that wants them
+static_assert(SBT_KX <= 2 * SBT_K && SBT_KP <= SBT_KX, "the slot tables hold 2 x SBT_K x SBT_NW descriptors");
 constexpr u32 SBT_SLOT = 256;                          // keys per slot
 constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K keys)
 #ifndef GX_SBT_TR
@@ -90,11 +84,10 @@ constexpr int SBT_OCCW = TILE / 32 + 4, SBT_PREW = TILE / 64 + 4;
 __host__ __device__ constexpr u32 sbt_tw(u32 tr) { return (u32)(SBT_OCCW + SBT_PREW) + tr + tr / 2; }   // words; 3,488 bytes at 448
 constexpr u32 SBT_NOKEY = 0x1000u;                     // "no key": offset 4096 = bit 0 of the dummy bitmap word
 static_assert(SBT_TR % 64 == 0, "the last step of a round reads whole wavefronts of counters");
-static_assert(2 * SBT_K <= SBT_KX, "start / end key mode: two streams of SBT_SLOTS descriptors");
 static_assert((1u << PgCfg<u32>::SHIFT) % SBT_SLOT == 0, "a slot never crosses a page");
 static_assert(TILE == 4096, "13-bit LDS keys: 12 bits of offset and the stream");
 static_assert((SBT_NW * sbt_tw(64)) % 4 == 0 && (SBT_NW * 96) % 4 == 0, "the scratch is cleared by 16-byte stores (TR: a multiple of 64)");
-constexpr u32 SBT_LDS_BYTES = 160u * 1024u / (1024u / SBT_NT) - 512u;    // what a launch asks for (dynamic; the kernel's few static words come on top): one workgroup per CU
+constexpr u32 SBT_LDS_BYTES = 160u * 1024u - 512u;    // what a launch asks for (dynamic; the kernel's few static words come on top): one workgroup per CU
 
 struct SbtLds {
   u32 hist[SBT_TILES];                     // [15:0] start keys, [31:16] end keys of the tile
@@ -103,8 +96,8 @@ struct SbtLds {
   u32 cur[2 * SBT_TILES];                  // scatter cursors: starts, ends
   uint4 tinfo[SBT_TILES];                  // what a wavefront needs to start a tile, one 16-byte read: pos0, chromosome length,
                                            // TM_ flags | keys of the tile << 8, carry-in pileup (1/120)
-  u32 slotOff[SBT_KX * SBT_NW];            // first key of a slot, as an index into its stream's page pool (2 x SBT_SLOTS <= SBT_KX x SBT_NW)
-  u32 slotCnt[SBT_KX * SBT_NW];
+  u32 slotOff[2 * SBT_SLOTS];              // first key of a slot, as an index into its stream's page pool
+  u32 slotCnt[2 * SBT_SLOTS];
   u32 pre[2][NXCD + 1];
   __attribute__((aligned(8))) u32 scratch[40];
   u32 work;
@@ -124,8 +117,20 @@ constexpr u32 SBT_DYN_OFF = (u32)offsetof(SbtLds, dyn);
 // keys of a super-bucket (both streams) that fit the LDS next to the scratch for TR touched bases per round
 __host__ __device__ constexpr u32 sbt_keycap(u32 tr) { return ((SBT_LDS_BYTES - SBT_DYN_OFF - SBT_NW * sbt_tw(tr) * 4u) / 2u - 192u) / 64u * 64u; }
 constexpr u32 SBT_KEYCAP = sbt_keycap(SBT_TR);        // ... of the ordinary launch
-static_assert(sbt_keycap(192) > sbt_keycap(448) && (SBT_NT != 1024 || sbt_keycap(448) >= 40960), "the split of the LDS");
+static_assert(sbt_keycap(192) > sbt_keycap(448) && sbt_keycap(448) >= 40960, "the split of the LDS");
 
+// -E regions on the fused path (round 6; Genrich.c:2185-2263).  Three kinds of tile: (A) `save` on at its first base and no edge
+// inside -- the ordinary tile, untouched; (B) inside a region (`save` off, no edge, not its chromosome's last): nothing to emit,
+// the tile runs as an inactive one; (C) a tile with an edge, or a chromosome's last tile that ends inside a region (its closing
+// interval carries V_MARK): TM_BEDX -- its bin goes to the second launch and the tile to the whole workgroup with a counter per
+// base (sbt_heavy), where a base is a breakpoint when it is an edge or (save and its difference != 0), as in k_tile<BED>.
+// fragLen keeps its closed form: the sum of the fragments' lengths counts every covered base, the reference only the saved ones
+// (2246 adds nothing while `save` is off), so the tile stage sums the pileup over the excluded bases -- a tile of kind (B) from its
+// keys alone (a key at offset o with weight w lifts the TILE - o bases from o on), a tile of kind (C) base by base --, exact integers
+// in 1/120 units, and takes a wavefront's total off one of the closed form's partial sums (FragFix::fragSum: one atomic per
+// wavefront and bin -- 22,000 tiles adding to one word cost the tile stage 0.2 ms).
+constexpr u32 TM_BEDX = 16u;   // (in SbtLds::tinfo only; TileMeta::flags keeps the chromosome's state)
+constexpr u32 TM_BEDIN = 32u;  // (likewise) kind (B) on a saved chromosome
 struct SbtIn {
   PagedStream PS, PE;         // (pair mode: PS = the pair records' lists, PE unused)
   PagedStream PF;             // pair mode: the singles' lists (8-byte signed-weight records)
@@ -139,6 +144,8 @@ struct SbtIn {
   int sbShift;
   const FragFix* ff;          // fractional pairs: the general fragLen path's switch and accumulator pair (k_tile_fast's TileIn::ff / fragAcc)
   long long* fragAcc;
+  BedIn bed;                  // -E regions (bedTileOff == nullptr: none): a tile's slot also counts the edges before it
+  u64* fragSum;               // ... and FragFix::fragSum, the closed form of fragLen: the pileup over the excluded bases comes off it
 };
 
 struct SbtOut {
@@ -187,8 +194,19 @@ __device__ __forceinline__ u32 sbt_class_of(int w) {  // weight (> 0) -> class; 
 template <bool FRAC>
 __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms, long long& fhi,
-                                         long long& flo) {
+                                         long long& flo, long long& bedExcl) {
   constexpr u32 NOKEY = FRAC ? SBT_NOKEY_F : SBT_NOKEY;
+  if (flags & TM_BEDIN) {  // wave-uniform, -E runs only: a tile inside an excluded region -- no interval, its pileup off the closed form
+    long long s = 0;
+    for (u32 k = lane_id(); k < n; k += 64) {
+      const u32 key = kl[k];
+      const int w = FRAC ? sbt_weight(key) : ((key & 0x8000u) ? -GX_UNIT : GX_UNIT);
+      s += (long long)w * (long long)(TILE - (key & (TILE - 1)));
+    }
+    bedExcl += wave_sum(s) + (long long)carry * TILE;
+    if (lane_id() == 0) out.to.tileCount[t] = 0;
+    return;
+  }
   // a key's offset with "no key" at 4096 (the dummy bitmap word)
   auto offOf = [](u32 key) -> u32 { return FRAC ? (key & (TILE - 1)) | ((key >> 4) & (u32)TILE) : key & (2 * TILE - 1); };
   u32* occ = reinterpret_cast<u32*>(lds);
@@ -350,9 +368,10 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
 // (FRAC with the general fragLen path on: the tile goes on the list of the heavy tiles, whose terms k_frag_walk adds)
 template <bool FRAC>
 __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
-                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms) {
-  constexpr int BPT = TILE / SBT_NT;   // consecutive bases per thread
-  static_assert(BPT % 4 == 0 && TILE == SBT_NT * BPT, "whole int4 per thread");
+                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms, const BedIn& bed,
+                                          long long& bedExcl) {
+  static_assert(SBT_NW * sbt_tw(192) >= TILE, "the counters fit the wavefronts' scratch");
+  static_assert(TILE == SBT_NT * 4, "four bases per thread");
   int* cnt = L.dyn;
   const int tid = threadIdx.x;
   const bool active = flags & TM_ACTIVE, lastTile = (flags & TM_LAST) != 0;
@@ -363,35 +382,53 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
     atomicAdd(&cnt[key & (TILE - 1)], FRAC ? sbt_weight(key) : ((key & 0x8000u) ? -GX_UNIT : GX_UNIT));
   }
   __syncthreads();
-  int d[BPT], dsum = 0;
-#pragma unroll
-  for (int q = 0; q < BPT / 4; q++) {
-    const int4 d4 = *reinterpret_cast<const int4*>(cnt + tid * BPT + 4 * q);
-    d[4 * q] = d4.x; d[4 * q + 1] = d4.y; d[4 * q + 2] = d4.z; d[4 * q + 3] = d4.w;
-    dsum += d4.x + d4.y + d4.z + d4.w;
-  }
+  const int4 d4 = *reinterpret_cast<const int4*>(cnt + tid * 4);
+  const int d[4] = {d4.x, d4.y, d4.z, d4.w};
   int tot;
-  const int ex = block_excl_scan<int, SBT_NT>(dsum, reinterpret_cast<int*>(L.scratch), &tot);
+  const int ex = block_excl_scan<int, SBT_NT>(d[0] + d[1] + d[2] + d[3], reinterpret_cast<int*>(L.scratch), &tot);
   int run = carry + ex;  // the pileup before this thread's first base
-  bool nz[BPT];
-  int before[BPT];
+  bool nz[4];
+  int before[4];
   u32 mine = 0, neg = 0, big = (u32)(tid == 0 && carry >= FRAG_FAST_MAXV);
+  // -E (TM_BEDX): the tile's edges -- a handful, tile-local offsets in ascending order -- are breakpoints whatever the difference
+  // holds, a difference inside a region is none, and an interval that ends inside one carries V_MARK (2241-2263, as k_tile<BED>).
+  // `save` at this thread's first base = the tile's state ^ the parity of the edges before it.
+  const bool bedx = (flags & TM_BEDX) != 0;
+  bool save = true, saveEnd = true;
+  u32 edgeM = 0;
+  if (bedx) {  // block-uniform
+    const u32 e0 = bed.bedTileOff[t], e1 = bed.bedTileOff[t + 1];
+    u32 pre = 0;
+    for (u32 i = e0; i < e1; i++) {
+      const u32 off = bed.bedEdge[i];
+      pre += (u32)(off < (u32)tid * 4);
+      if (off - (u32)tid * 4 < 4u) edgeM |= 1u << (off - (u32)tid * 4);
+    }
+    const bool s0 = bed.tileSave0[t] != 0;
+    save = s0 ^ ((pre & 1u) != 0);
+    saveEnd = s0 ^ (((e1 - e0) & 1u) != 0);
+  }
+  long long excl = 0;   // the pileup over this thread's excluded bases (a base belongs to the region from its start edge on, 2258-2263)
 #pragma unroll
-  for (int j = 0; j < BPT; j++) {
-    before[j] = run;
+  for (int j = 0; j < 4; j++) {
+    const bool edge = (edgeM >> j) & 1u;
+    before[j] = save ? run : V_MARK;
     run += d[j];
-    nz[j] = d[j] != 0 && active && (pos0 + (u32)tid * BPT + j != 0);  // 2241: base 0 closes nothing
+    nz[j] = (edge || (save && d[j] != 0)) && active && (pos0 + (u32)tid * 4 + j != 0);  // 2241: base 0 closes nothing
+    if (edge) save = !save;
+    if (bedx && active && !save && pos0 + (u32)tid * 4 + j < len) excl += run;
     mine += nz[j];
     neg |= (u32)(run < 0);
     big |= (u32)(run >= FRAG_FAST_MAXV);
   }
+  if (bedx) bedExcl += wave_sum(excl);  // block-uniform (every wavefront keeps its own total)
   u32 outCount;
   u32 o = slot + block_excl_scan<u32, SBT_NT>(mine, L.scratch, &outCount);
   u32 lastPos = 0;
 #pragma unroll
-  for (int j = 0; j < BPT; j++)
+  for (int j = 0; j < 4; j++)
     if (nz[j]) {
-      const u32 p = pos0 + (u32)tid * BPT + j;
+      const u32 p = pos0 + (u32)tid * 4 + j;
       out.to.looseEnd[o] = p;
       out.to.looseV[o] = before[j];
       if (before[j] >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[o >> 6], 1ull << (o & 63));  // (vsig: INT_MAX when no bits are wanted)
@@ -420,8 +457,8 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
       if (lastTile) {  // closing interval [.., len): 2268-2273
         const u32 oc = slot + outCount;
         out.to.looseEnd[oc] = len;
-        out.to.looseV[oc] = endRun;
-        if (endRun >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[oc >> 6], 1ull << (oc & 63));
+        out.to.looseV[oc] = saveEnd ? endRun : V_MARK;   // (a chromosome that ends inside a -E region: 2268-2273 with save off)
+        if (saveEnd && endRun >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[oc >> 6], 1ull << (oc & 63));
       }
       if (total) out.to.tileLastEnd[t] = lastTile ? len : lastEnd;
     }
@@ -455,7 +492,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   static_assert(PAIRS || !FRAC, "fractional weights ride pair records only");
   constexpr u32 LENB = FRAC ? 9u : PAIR_LEN_BITS;      // a pair record's length bits (fractional: [11:9] the weight class)
   const bool fragTerms = FRAC && in.fragAcc != nullptr && (u32)__builtin_amdgcn_readfirstlane((int)in.ff->slow) != 0u;
-  long long fhi = 0, flo = 0;
+  long long fhi = 0, flo = 0, bedExcl = 0;
   constexpr int K = BIG ? 0 : (PAIRS ? SBT_KP : SBT_K);   // slots per wavefront of the (first) stream held in registers
   constexpr int KX = BIG ? SBT_KX : K;                    // ... and in all
   constexpr int KR = K ? K : 1;                           // (array sizes)
@@ -465,13 +502,12 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   static_assert(TRC % 64 == 0 && TRC >= 192 && TRC <= 448, "touched bases per round");
   constexpr u32 trCap = (u32)TRC;
   constexpr u32 tw = sbt_tw(trCap), scrWords = SBT_NW * tw, keyCap = sbt_keycap(trCap);
-  static_assert(scrWords >= (u32)TILE, "sbt_heavy's counters (one per base) fit the wavefronts' scratch");
   int* const scr = L.dyn;
   uint16_t* const keysL = reinterpret_cast<uint16_t*>(L.dyn + scrWords);
   const u32 nSeg = in.nSeg;
   const u32 nT = 1u << in.sbShift;           // tiles per super-bucket (<= SBT_TILES)
   const u32 segTileBase = seg << in.sbShift;
-  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, (!BIG || out.bigList == nullptr) && seg == 0 && tid == 0, L.vsRed));
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(out.to.ctl, !BIG && seg == 0 && tid == 0, L.vsRed));
   // (one workgroup per CU: a global round trip in this prologue is a round trip of the whole CU.  The lists' lengths and the
   // tiles' chromosome records -- two dependent loads -- are asked for first and arrive while the scratch is cleared)
   u32 myLen = 0;
@@ -490,6 +526,23 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       }
     }
     return ti;
+  };
+  // -E regions: the edges before this thread's tile (they take loose slots of their own) and the tile's kind (TM_BEDX: an edge
+  // inside, or a chromosome's last tile that ends inside a region; `inside`: nothing of the tile is saved)
+  const bool hasBed = in.bed.bedTileOff != nullptr;   // (uniform)
+  u32 bedBefore = 0, bedMine = 0;
+  bool bedInside = false;
+  auto loadBed = [&](const uint4& ti) {
+    if (hasBed && tid < (int)nT && segTileBase + tid < in.nTiles) {
+      const u32 t = segTileBase + tid;
+      bedBefore = in.bed.bedTileOff[t];
+      bedMine = in.bed.bedTileOff[t + 1] - bedBefore;
+      const bool s0 = in.bed.tileSave0[t] != 0;
+      bedInside = !bedMine && !s0 && !(ti.z & TM_LAST);
+      if (bedInside && (ti.z & TM_ACTIVE)) return TM_BEDIN;
+      if (bedMine || (!s0 && (ti.z & TM_LAST))) return TM_BEDX;
+    }
+    return 0u;
   };
   auto expLeave = [&]() {   // (measurement exits: empty tiles with valid slots behind them)
     if (tid < (int)nT && segTileBase + tid < in.nTiles) {
@@ -510,7 +563,8 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     else
       myLen = list_len<u32>(tid < NXCD ? in.PS : in.PE, li);
   }
-  const uint4 ti = loadTi();
+  uint4 ti = loadTi();
+  const u32 bedx = loadBed(ti);
   // scratch and tables start at zero
   for (u32 i = (u32)tid * 4; i < scrWords; i += SBT_NT * 4) *reinterpret_cast<int4*>(scr + i) = make_int4(0, 0, 0, 0);
   if (tid < SBT_TILES) {
@@ -700,11 +754,20 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     if (tid == 0) L.startC[nT] = (u32)tot;
   }
   __syncthreads();
-  // Pair mode: a bin with more keys than the key array holds (reads piled up: a tower, chrM; with two workgroups per CU: the
-  // ordinary bin) is worked off in ROUNDS of consecutive tiles whose keys fit, every round scatters the keys of its tiles
+  if constexpr (PAIRS && !BIG) {
+    // what this launch does not take: it goes on the list of the second one, untouched
+    const u32 hh = tid < (int)nT ? L.hist[tid] : 0u;
+    const bool heavyTile = (hh & 0xFFFFu) + (hh >> 16) > SBT_HEAVY || (bedx & TM_BEDX);   // (a tile with a -E edge: the whole workgroup's too)
+    const bool big = __syncthreads_or((int)heavyTile) || ovfSlots || L.startC[nT] > keyCap || L.overflow == 1;
+    if (big) {  // block-uniform
+      if (tid == 0) out.bigList[atomicAdd(out.nBig, 1u)] = seg;
+      return;
+    }
+  }
+  // Pair mode: a bin with more keys than the key array holds (reads piled up: a tower, chrM) is worked off in ROUNDS of
+  // consecutive tiles whose keys fit -- the records stay in their registers, every round scatters the keys of its tiles
   // only.  What still does not fit: more records than the slots take, a single tile beyond the array, too many rounds.
-  constexpr bool RNDS = BIG || (PAIRS && SBT_R1 > 1);
-  if (RNDS && tid == 0) {
+  if (BIG && tid == 0) {
     u32 nr = 0;
     bool fits = true;
     if (L.startC[nT] <= keyCap) {
@@ -732,21 +795,10 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     }
     L.nRounds = fits ? nr : 0u;
   }
-  if (RNDS) __syncthreads();
-  if constexpr (PAIRS && !BIG) {
-    // what this launch does not take: it goes on the list of the second one, untouched
-    const u32 hh = tid < (int)nT ? L.hist[tid] : 0u;
-    const bool heavyTile = (hh & 0xFFFFu) + (hh >> 16) > SBT_HEAVY;
-    const bool tooMany = RNDS ? L.nRounds == 0 || L.nRounds > SBT_R1 : L.startC[nT] > keyCap;
-    const bool big = __syncthreads_or((int)heavyTile) || ovfSlots || tooMany || L.overflow == 1;
-    if (big) {  // block-uniform
-      if (tid == 0) out.bigList[atomicAdd(out.nBig, 1u)] = seg;
-      return;
-    }
-  }
-  const u32 nRounds = RNDS ? L.nRounds : 1u;
+  if (BIG) __syncthreads();
+  const u32 nRounds = BIG ? L.nRounds : 1u;
   const u32 ovfWord = PAIRS ? L.overflow : 0u;  // (pair mode: 1 too many singles, 2 a fractional weight among them)
-  const bool ovfReal = ovfSlots || (RNDS ? nRounds == 0 : L.startC[nT] > keyCap) || ovfWord != 0;
+  const bool ovfReal = ovfSlots || (BIG ? nRounds == 0 : L.startC[nT] > keyCap) || ovfWord != 0;
   const bool ovf = ovfReal || GX_EXP_SBT == 1 || GX_EXP_SBT == 2;
   // (the slot capacity bounds a stream at 32 K keys -- pair mode: 32 K pairs and SBT_FCAP singles --, so a tile's 16-bit
   // counts cannot have wrapped)
@@ -774,11 +826,14 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       m.carry = ovf ? 0 : segNet + (FRAC ? 1 : GX_UNIT) * L.netPref[tid] - (int)ti.w;
       m.ci = 0;
       m.pos0 = ti.x; m.len = ti.y; m.flags = ti.z;
-      m.slot = segSlot + sc + (u32)tid;
+      m.slot = segSlot + sc + (u32)tid + bedBefore;   // (a tile holds <= records + edges + 1 intervals)
       out.meta[t] = m;
-      L.tinfo[tid] = make_uint4(ti.x, ti.y, ti.z | ((nS + nE) << 8), (u32)m.carry);
+      // (what the tile passes see: a tile inside a -E region runs as an inactive one, a tile with an edge is the workgroup's)
+      L.tinfo[tid] = make_uint4(ti.x, ti.y, ((bedInside ? ti.z & ~TM_ACTIVE : ti.z) | bedx) | ((nS + nE) << 8), (u32)m.carry);
+      static_assert((TM_BEDX | TM_BEDIN) < 256u, "the tile's flags take the low byte, its key count the rest");
+      if (hasBed) L.netPref[tid] = (int)bedBefore;   // (its prefix has gone into the carry: the word now holds the slot's extra)
       out.tileSlot[t] = m.slot;
-      if (t + 1 == in.nTiles) out.tileSlot[in.nTiles] = m.slot + nS + nE + 1;
+      if (t + 1 == in.nTiles) out.tileSlot[in.nTiles] = m.slot + nS + nE + 1 + bedMine;
     }
   }
   if (ovf) {
@@ -807,12 +862,13 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       const uint4 tf = L.tinfo[b];
       const u32 sc = L.startC[b];
       const u32 fz = (u32)__builtin_amdgcn_readfirstlane((int)tf.z), n = fz >> 8;
-      if (BIG && n > SBT_HEAVY) {  // wave-uniform: left to the whole workgroup
+      if (BIG && (n > SBT_HEAVY || (fz & TM_BEDX))) {  // wave-uniform: left to the whole workgroup
         if (lane == 0) L.heavy[atomicAdd(&L.nHeavy, 1u)] = (uint16_t)b;
         continue;
       }
+      const u32 bedSlots = hasBed ? (u32)__builtin_amdgcn_readfirstlane(L.netPref[b]) : 0u;
       sbt_tile<FRAC>(scr + (u32)__builtin_amdgcn_readfirstlane(wv) * tw, trCap, keysL + (sc - keyBase), n, t, tf.x, tf.y, fz & 0xFFu, (int)tf.w,
-                     segSlot + sc + b, vsig, out, bad, fragTerms, fhi, flo);
+                     segSlot + sc + b + bedSlots, vsig, out, bad, fragTerms, fhi, flo, bedExcl);
     }
     if constexpr (BIG) {
     __syncthreads();  // (every wavefront is through with its tiles; the list of the heavy ones is complete)
@@ -822,7 +878,8 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         const u32 b = L.heavy[i], t = segTileBase + b;
         const uint4 tf = L.tinfo[b];
         const u32 sc = L.startC[b], n = tf.z >> 8;
-        sbt_heavy<FRAC>(L, scrWords, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z & 0xFFu, (int)tf.w, segSlot + sc + b, vsig, out, bad, fragTerms);
+        sbt_heavy<FRAC>(L, scrWords, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z & 0xFFu, (int)tf.w,
+                        segSlot + sc + b + (hasBed ? (u32)L.netPref[b] : 0u), vsig, out, bad, fragTerms, in.bed, bedExcl);
       }
       // the wavefronts' scratch as the next round's tiles expect it
       for (u32 i = (u32)tid * 4; i < scrWords; i += SBT_NT * 4) *reinterpret_cast<int4*>(scr + i) = make_int4(0, 0, 0, 0);
@@ -833,56 +890,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     }
     }
   };
-  if constexpr (PAIRS && !BIG && RNDS) {
-    // Two workgroups per CU: the records stay in their registers across the rounds, every round scatters the ends that lie in
-    // its tiles (the cursors count in the bin's order, the key array from the round's first key); while this workgroup loads,
-    // counts and scatters, the CU's other one walks its tiles.
-    for (u32 round = 0; round < nRounds; round++) {
-      const u32 tileBeg = L.rnd[round], nTr = L.rnd[round + 1] - tileBeg, tileEnd = tileBeg + nTr, keyBase = L.startC[tileBeg];
-      if (round) {
-        // (the records are not kept in their registers across the tile loop -- 175 spilled dwords --: a further round loads them
-        // again; they are in L2, and the CU's other workgroup has work meanwhile)
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-          cS[i] = (u32)__builtin_amdgcn_readfirstlane((int)L.slotCnt[i * SBT_NW + wv]);
-          kS[i] = make_uint4(0u, 0u, 0u, 0u);
-          if ((u32)lane * 4 < cS[i]) kS[i] = poolS[(L.slotOff[i * SBT_NW + wv] >> 2) + lane];
-        }
-        __syncthreads();  // (the previous round's tiles are through with the keys)
-        if (tid == 0) L.work = tileBeg;
-        __syncthreads();
-      }
-      auto placePairR = [&](u32 r) {
-        const u32 e = pairEnd(r), ts = pairTs(r), te = e >> TB;
-        const u32 so = ((r >> PAIR_LEN_BITS) & (TILE - 1)) | pairCls(r), eo = (e & (TILE - 1)) | 0x8000u | pairCls(r);
-        const bool sIn = ts - tileBeg < nTr, eIn = te - tileBeg < nTr;
-        if (sIn) {
-          const u32 ps = atomicAdd(&L.cur[ts], ts == te ? 2u : 1u) - keyBase;
-          keysL[ps] = (uint16_t)so;
-          if (ts == te) keysL[ps + 1] = (uint16_t)eo;
-        }
-        if (eIn && ts != te) keysL[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)eo;
-      };
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        if (cS[i] == SBT_SLOT) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) placePairR(keyAt(kS[i], j));
-        } else if (cS[i]) {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if ((u32)lane * 4 + j < cS[i]) placePairR(keyAt(kS[i], j));
-        }
-      }
-      for (u32 i = tid; i < nF; i += SBT_NT) {
-        const u64 r = srcF.at(i);
-        const u32 tl = (u32)(r >> 32) - segTileBase, off = (u32)(r >> 8) & (TILE - 1);
-        if (tl - tileBeg < nTr) keysL[atomicAdd(&L.cur[tl], 1u) - keyBase] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
-      }
-      __syncthreads();
-      tiles(tileEnd, keyBase);
-    }
-  } else if constexpr (PAIRS && !BIG) {
+  if constexpr (PAIRS && !BIG) {
     {
       // one cursor per tile (starts and ends of a tile share its list: a key says which it is); a pair whose ends share a
       // tile takes its two places with one atomic
@@ -985,11 +993,14 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       if (flo) atomicAdd((u64*)&in.fragAcc[1], (u64)flo);
     }
   }
+  // (-E: this wavefront's share of the pileup over excluded bases, off the closed form of fragLen -- whole bases with unit weights;
+  // with fractional ones the closed form is not used, FRAG_SLOW_FRAC)
+  if (bedExcl && lane == 0) atomicAdd(&in.fragSum[(seg * SBT_NW + (u32)wv) % FRAG_SLOTS], (u64)(-(bedExcl / GX_UNIT)));
   if (bad && lane == 0) atomicOr(st, bad);
 }
 
 template <bool PAIRS, bool BIG, bool FRAC, int TRC = SBT_TR>
-__global__ __launch_bounds__(SBT_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
+__global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
   SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
   if constexpr (!BIG)

@@ -48,9 +48,12 @@ struct PagedStream {
 
 __device__ __forceinline__ u32 first_page(u32 list) { return 1u + list; }
 
+// FragFix::slow (gx_kernels.h): bit 0 -- the general fragLen path is wanted; bit 1 -- because a fractional weight was SEEN (the host
+// learns it with the sample's scalars: a context that was only told to expect fractions keeps the closed form until then)
+constexpr u32 FRAG_SLOW_FRAC = 3u;
 struct Sort1Out {
   u64* fragSum;   // [FRAG_SLOTS] sum of the clamped lengths of the fragments kept (closed form of fragLen)
-  u32* slowFrag;  // set when a fractional weight was seen (general fragLen path)
+  u32* slowFrag;  // FragFix::slow: FRAG_SLOW_FRAC goes up when a fractional weight is seen (general fragLen path)
   u32* endAtLen;  // [nChrom] weight of the events that end at (or beyond) the chromosome's end
   u32* hot;       // set when a base can reach the reference's int16 limits (see k_hot_check)
 };
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(S1_NT) void k_sort1(const gx_event* __restrict__ ev
     }
   }
   if (bad) atomicOr(st, bad);
-  if (frac) atomicOr(out.slowFrag, 1u);
+  if (frac) atomicOr(out.slowFrag, FRAG_SLOW_FRAC);
   covered = wave_sum(covered);
   if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 16 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
 }
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
         mine = p.w != 0;  // (else: an event that only raised a status bit, or one without effect)
         if (mine) {
           if (p.w != GX_UNIT) {
-            atomicOr(out.slowFrag, 1u);
+            atomicOr(out.slowFrag, FRAG_SLOW_FRAC);
             if (!FRAC) {  // (unit-weight pair records: this sample goes to the general chain -- nothing more to append)
               atomicOr(st, ST_SB_FRAC);
               mine = false;
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
     }
   }
   if (bad) atomicOr(st, bad);
-  if (FRAC && __ballot(fracSeen != 0) && lane_id() == 0) atomicOr(out.slowFrag, 1u);  // (the closed form of fragLen is off)
+  if (FRAC && __ballot(fracSeen != 0) && lane_id() == 0) atomicOr(out.slowFrag, FRAG_SLOW_FRAC);  // (the closed form of fragLen is off)
   covered = wave_sum(covered);
   if (lane_id() == 0 && covered) atomicAdd(&out.fragSum[(blockIdx.x * 8 + (threadIdx.x >> 6)) % FRAG_SLOTS], covered);
 }

@@ -45,38 +45,6 @@ class Collectives:
             print("allreduce callback failed:", e)
             return 1
 
-    # int (*)(const void* local, size_t n_local, void** out, size_t* n_out, void* user)
-    # records are 16 bytes {u32 key, u32 pad, u64 bp}; *out is malloc'd (freed by the library)
-    def allgather_tab(self, local, n_local, out, n_out, _user):
-        try:
-            torch, dist = self.torch, self.dist
-            world = dist.get_world_size()
-            cnt = torch.tensor([n_local], dtype=torch.int64, device=self.device)
-            cnts = [torch.zeros_like(cnt) for _ in range(world)]
-            dist.all_gather(cnts, cnt)
-            cnts = [int(c.item()) for c in cnts]
-            mx = max(cnts + [1])
-            mine = np.zeros((mx, 2), dtype=np.int64)
-            if n_local:
-                src = np.frombuffer(C.string_at(local, n_local * 16), dtype=np.int64).reshape(-1, 2)
-                mine[:n_local] = src
-            t = torch.from_numpy(mine).to(self.device)
-            parts = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(parts, t)
-            cat = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, cnts)], axis=0)
-            total = cat.shape[0]
-            libc = C.CDLL(None)
-            libc.malloc.restype = C.c_void_p
-            libc.malloc.argtypes = [C.c_size_t]
-            mem = libc.malloc(max(16, total * 16))
-            C.memmove(mem, cat.ctypes.data, total * 16)
-            out[0] = mem
-            n_out[0] = total
-            return 0
-        except Exception as e:
-            print("allgather callback failed:", e)
-            return 1
-
 
 def merge_peaks(per_rank_peaks):
     """Peaks of all ranks -> chromosome-table order then position (the order in which the

@@ -170,8 +170,6 @@ struct Devs {
   pthread_barrier_t bar;
   bool barInit = false;
   std::vector<std::vector<int64_t>> red;
-  std::vector<const void*> gatherPtr;
-  std::vector<size_t> gatherN;
   struct User { Devs* d; int rank; };
   std::vector<User> users;
   size_t n() const { return ctx.size(); }
@@ -187,26 +185,6 @@ int devsAllreduce(int64_t* buf, size_t n, void* user) {
     for (size_t r = 0; r < D.n(); r++) sum += D.red[r][k];
     buf[k] = sum;
   }
-  pthread_barrier_wait(&D.bar);
-  return 0;
-}
-
-int devsAllgather(const void* local, size_t nLocal, void** out, size_t* nOut, void* user) {
-  Devs::User* u = static_cast<Devs::User*>(user);
-  Devs& D = *u->d;
-  D.gatherPtr[u->rank] = local;
-  D.gatherN[u->rank] = nLocal;
-  pthread_barrier_wait(&D.bar);
-  size_t total = 0;
-  for (size_t r = 0; r < D.n(); r++) total += D.gatherN[r];
-  char* all = static_cast<char*>(malloc(std::max<size_t>(16, total * 16)));
-  size_t at = 0;
-  for (size_t r = 0; r < D.n(); r++) {
-    if (D.gatherN[r]) memcpy(all + at * 16, D.gatherPtr[r], D.gatherN[r] * 16);
-    at += D.gatherN[r];
-  }
-  *out = all;
-  *nOut = total;
   pthread_barrier_wait(&D.bar);
   return 0;
 }
@@ -2667,12 +2645,10 @@ int main(int argc, char** argv) {
         pthread_barrier_init(&D.bar, nullptr, (unsigned)W);
         D.barInit = true;
         D.red.resize(W);
-        D.gatherPtr.assign(W, nullptr);
-        D.gatherN.assign(W, 0);
         D.users.resize(W);
         for (int g = 0; g < W; g++) {
           D.users[g] = Devs::User{&D, g};
-          check(S, gx_set_collectives(D.ctx[g], g, W, devsAllreduce, devsAllgather, &D.users[g]), D.ctx[g]);
+          check(S, gx_set_collectives(D.ctx[g], g, W, devsAllreduce, &D.users[g]), D.ctx[g]);
         }
       }
     }

@@ -17,8 +17,6 @@ PEAK_DTYPE = np.dtype(
 GX_IV_FINAL = -1
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.c_size_t, C.c_void_p)
-ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p),
-                           C.POINTER(C.c_size_t), C.c_void_p)
 
 
 class GxParams(C.Structure):
@@ -51,7 +49,7 @@ _SIGS = {
     "gx_set_keep_pileups": [C.c_void_p, C.c_int],
     "gx_expect_fractional": [C.c_void_p, C.c_int],
     "gx_set_knob": [C.c_void_p, C.c_char_p, C.c_char_p],
-    "gx_set_collectives": [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, C.c_void_p],
+    "gx_set_collectives": [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p],
     "gx_rccl_unique_id": [C.c_void_p, C.c_size_t],
     "gx_set_rccl": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "gx_sample_begin": [C.c_void_p, C.c_int, C.c_void_p],
@@ -219,10 +217,10 @@ class Genrich:
         a = np.ascontiguousarray(owned, dtype=np.uint8)
         self._check(self.lib.gx_set_owned(self.ctx, a.ctypes.data))
 
-    def set_collectives(self, rank, world, allreduce, allgather):
-        # (allgather: kept in the ABI for older host programs; the library's exchanges are all-reduces now -- None is fine)
-        self._cb = (ALLREDUCE_FN(allreduce), ALLGATHER_FN(allgather) if allgather is not None else C.cast(None, ALLGATHER_FN))
-        self._check(self.lib.gx_set_collectives(self.ctx, rank, world, self._cb[0], self._cb[1], None))
+    def set_collectives(self, rank, world, allreduce):
+        """Every exchange of the library through ONE host callback: an all-reduce (sum) of int64 words."""
+        self._cb = ALLREDUCE_FN(allreduce)   # (kept alive with the object: the library calls it later)
+        self._check(self.lib.gx_set_collectives(self.ctx, rank, world, self._cb, None))
 
     def set_rccl(self, rank, world, unique_id: bytes):
         """The library's own RCCL communicator (collective over all ranks); unique_id = rccl_unique_id()

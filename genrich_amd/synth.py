@@ -98,6 +98,42 @@ def add_multimap(ev, lens, frac, seed):
     return np.concatenate([keep, out])
 
 
+def excluded_regions(lens, n=800, seed=7, skip=()):
+    """A deterministic -E file for a genome: `n` N-gap-like regions (most a few kilobases, some hundreds of kilobases, a few
+    centromere-sized), one that touches position 0 of the first chromosome and one that reaches the end of the second --
+    the two edge cases of saveXBed / savePileupExpt's bedPos walk (Genrich.c:1144-1206, 2185-2263) -- none on the chromosomes
+    listed in `skip` (-e).  Returns, per chromosome, the merged and sorted coordinates [s0, e0, s1, e1, ...] as saveXBed
+    leaves them (what gx_set_chroms takes)."""
+    rng = np.random.default_rng(seed)
+    lens = [int(x) for x in lens]
+    regs = [[] for _ in lens]
+    ok = [i for i, L in enumerate(lens) if i not in set(skip) and L > 200_000]
+    w = np.array([lens[i] for i in ok], dtype=np.float64)
+    where = rng.choice(len(ok), size=n, p=w / w.sum())
+    kind = rng.random(n)
+    for c, k in zip(where, kind):
+        c = ok[int(c)]
+        size = int(rng.integers(1_000, 50_000)) if k < 0.85 else int(rng.integers(50_000, 500_000)) if k < 0.98 else int(rng.integers(1_000_000, 3_000_000))
+        size = min(size, lens[c] // 4)
+        s = int(rng.integers(0, lens[c] - size))
+        regs[c].append((s, s + size))
+    if ok:
+        regs[ok[0]].append((0, 10_000))                                   # touches position 0
+        last = ok[1] if len(ok) > 1 else ok[0]
+        regs[last].append((lens[last] - 60_000, lens[last]))              # reaches the chromosome's end
+    out = []
+    for r in regs:
+        r.sort()
+        merged = []
+        for a, b in r:
+            if merged and a <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], b)
+            else:
+                merged.append([a, b])
+        out.append([v for m in merged for v in m])
+    return out
+
+
 def atac_events(ev, lens, d=100, adj=True):
     """ATAC-seq mode geometry (saveFragAtac, Genrich.c:2728-2749; -d halves 5796-5797):
     each fragment becomes one or two cut-site intervals, clamped like saveInterval."""

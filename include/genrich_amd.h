@@ -46,9 +46,9 @@ enum gx_status {
   GX_ERR_PVAL = -8,     /* ERRPVAL / genome-length mismatch                      :344,377 */
   GX_ERR_DF = -9,       /* ERRDF     "Invalid df in pchisq()"                    :556 */
   GX_ERR_ORDER = -10,   /* API called out of order / bad argument */
-  GX_ERR_DEVICE = -11,  /* HIP runtime failure (message via gx_last_error) */
-  GX_ERR_OVERFLOW = -12 /* (not returned any more: the reference's int16 saturation skips,
-                           Genrich.c:2558-2573, are reproduced -- see gx_filter_saturation) */
+  GX_ERR_DEVICE = -11   /* HIP runtime failure (message via gx_last_error) */
+  /* (-12 was GX_ERR_OVERFLOW until round 5; the reference's int16 saturation skips, Genrich.c:2558-2573, are
+   * reproduced -- gx_filter_saturation -- so nothing reports it: retired, the number is not reused) */
 };
 
 /* One alignment-derived interval AFTER saveInterval's clamping
@@ -233,15 +233,9 @@ int gx_write_log_path(gx_ctx* ctx, int n_rep, const char* const* names, int n_ch
  * rank), and -- as sums of disjoint regions of a zeroed buffer, i.e. concatenations -- the samples, counts, totals,
  * minima and the all-to-all segments of the range-partitioned BH exchange (gx_bhx.h).  buf is host memory. */
 typedef int (*gx_allreduce_i64_fn)(int64_t* buf, size_t n, void* user);
-/* (Not called any more: the BH table is exchanged by all-reduces since round 4; the parameter stays for source
- * compatibility and may be NULL.)  Gather variable-length tables: every rank contributes n_local 16-byte records
- * {uint32 key, uint32 pad, uint64 bp}; the callback returns a malloc'd concatenation of
- * all ranks' records in *out / *n_out (freed by the library with free()).  `local` is host
- * memory owned by the library. */
-typedef int (*gx_allgather_tab_fn)(const void* local, size_t n_local, void** out,
-                                   size_t* n_out, void* user);
-int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce,
-                       gx_allgather_tab_fn allgather, void* user);
+/* (Rounds 1-5 also took a table all-gather callback here; the BH table travels by all-reduces since round 4, and round 6
+ * dropped the parameter.) */
+int gx_set_collectives(gx_ctx* ctx, int rank, int world, gx_allreduce_i64_fn allreduce, void* user);
 /* The library's own collectives: RCCL over xGMI on device buffers, on the library's stream (no host
  * hop in the data path).  One rank calls gx_rccl_unique_id and hands the 128 bytes to every rank
  * by whatever channel the host program has; then every rank calls gx_set_rccl (collective: it
@@ -269,7 +263,11 @@ int gx_set_keep_pileups(gx_ctx* ctx, int keep);
  * gx_* call sequence; names are NUL-separated in *names. Returns count.
  * gx_set_phase_timing chooses what is timed: 0 nothing (default: an event record costs a
  * ~5 us bubble on the stream), 1 the tile stage only ("t.tile" / "c.tile": what
- * bench.py's roofline needs inside its timed region), 2 every phase. */
+ * bench.py's roofline needs inside its timed region), 2 every phase.
+ * Independently of the level, a context made with GX_ROCTX=1 in the environment (or gx_set_knob) brackets every phase
+ * with a roctx range of the phase's name ("gx:t.tile", ...) on the calling thread, so that a rocprofv3 --marker-trace
+ * --kernel-trace run attributes every kernel to its phase (tools/make_counters_json.py; host-side markers, no stream
+ * bubble; the roctx library is opened at run time and its absence is not an error). */
 int gx_set_phase_timing(gx_ctx* ctx, int level);
 /* Like level 1, for another phase: only the phases called `name` ("sort1", "tile", "bucket" -- per sample, reported
  * as "t.<name>" / "c.<name>" --, "pval", "merge", "fisher", "bh", "sweep") are bracketed by events.  bench.py times

@@ -42,16 +42,16 @@ def _worker(rank, world, port, q):
     # allreduce of the fixed-point fragLen parts
     buf = (C.c_int64 * 2)(10 + rank, 1 << (40 + rank))
     assert coll.allreduce_i64(buf, 2, None) == 0
-    # allgather of {key, bp} tables of different lengths
-    n_local = 2 + rank
-    tab = np.zeros((n_local, 2), dtype=np.int64)
-    tab[:, 0] = np.arange(n_local) + 100 * rank
-    tab[:, 1] = 7 + rank
-    out = C.c_void_p()
-    n_out = C.c_size_t()
-    assert coll.allgather_tab(tab.ctypes.data, n_local, C.pointer(out), C.pointer(n_out), None) == 0
-    got = np.frombuffer(C.string_at(out.value, n_out.value * 16), dtype=np.int64).reshape(-1, 2).copy()
-    C.CDLL(None).free(C.c_void_p(out.value))
+    # a concatenation of tables of different lengths, the way the library makes one out of the same callback (gx_host_coll.h):
+    # every rank writes its records into its own region of a zeroed buffer, the sum over ranks is the concatenation
+    counts = [2, 3]
+    tab = np.zeros((sum(counts), 2), dtype=np.int64)
+    at = sum(counts[:rank])
+    tab[at:at + counts[rank], 0] = np.arange(counts[rank]) + 100 * rank
+    tab[at:at + counts[rank], 1] = 7 + rank
+    cat = (C.c_int64 * tab.size)(*tab.reshape(-1).tolist())
+    assert coll.allreduce_i64(cat, tab.size, None) == 0
+    got = np.array(list(cat), dtype=np.int64).reshape(-1, 2)
     q.put((rank, [buf[0], buf[1]], got.tolist()))
     dist.destroy_process_group()
 

@@ -230,3 +230,46 @@ def test_fullsize_config5_three_replicates_fisher_q_is_the_oracles_bytes():
     reps = [dict(save=None, treat=synth.make_fragments(LENS, 50_000_000, seed=s), ctrl=None) for s in (1, 3, 5)]
     case = dict(lens=LENS, replicates=reps)
     _whole_genome_against_oracle(case, B.make_params(pq=0.05, qval=True), 1_000)
+
+
+def test_fullsize_config2_with_excluded_regions_is_the_oracles_bytes():
+    """The reference's own flagship command line is `-e chrM,chrY -E <N-gap BED files>` (README.md:463-465): BASELINE's config 2
+    stream with ~800 excluded regions (one touching position 0, one reaching a chromosome's end: synth.excluded_regions) and
+    two skipped contigs -- the whole genome against the oracle: peaks, interval ends, p (SKIP inside the regions), lambda with
+    the regions' bases taken out of the genome length (calcLambda 1819-1827; the bedPos / save toggling of savePileupExpt
+    2185-2263 and saveLambda 1847-1876)."""
+    skip = [False] * len(LENS)
+    skip[23] = skip[24] = True   # chrY, chrM
+    beds = synth.excluded_regions(LENS, n=800, seed=7, skip=(23, 24))
+    assert beds[0][0] == 0 and beds[1][-1] == LENS[1] and sum(len(b) for b in beds) // 2 > 700
+    ev = synth.make_fragments(LENS, 50_000_000, seed=1)
+    case = dict(lens=LENS, skip=skip, beds=beds, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    import genrich_amd
+    params = B.make_params(pq=0.01)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = genrich_amd.Genrich(params)
+    sh = B.run_case(h, case)
+    B.assert_fraglen(o, 0, so[0][0], sh[0][0])
+    assert np.float32(so[0][1]).tobytes() == np.float32(sh[0][1]).tobytes()
+    excl = sum(b[i + 1] - b[i] for b in beds for i in range(0, len(b), 2))
+    assert o.genome_len == h.genome_len == sum(L for L, s in zip(LENS, skip) if not s) - excl
+    po, ph = o.get_peaks(), h.get_peaks()
+    assert len(po) == len(ph) > 40_000
+    assert po.tobytes() == ph.tobytes(), "peak lists differ"
+    assert o.peak_bp == h.peak_bp
+    total = 0
+    for c in range(len(LENS)):
+        if skip[c]:
+            continue
+        eo, co = o.get_intervals(-1, c)
+        eh, ch = h.get_intervals(-1, c)
+        assert np.array_equal(eo, eh), f"interval ends differ on contig {c}"
+        for k in ("expt", "ctrl", "p"):
+            assert np.array_equal(co[k].view(np.uint32), ch[k].view(np.uint32)), f"{k} differs on contig {c}"
+        if beds[c]:
+            assert (co["p"] == -1.0).any(), "an excluded region carries SKIP"
+        total += len(eo)
+    assert total == h.interval_total()
+    o.close()
+    h.close()

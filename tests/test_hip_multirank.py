@@ -75,7 +75,7 @@ def _worker(rank, world, port, q, name):
     gx.set_chroms(LENS)
     gx.set_owned(owned)
     coll = Collectives(device="cpu")
-    gx.set_collectives(rank, world, coll.allreduce_i64, coll.allgather_tab)
+    gx.set_collectives(rank, world, coll.allreduce_i64)
     scal, peaks = _run(gx, reps, owned)
     q.put((rank, scal, peaks.tobytes(), gx.path_info()))
     dist.destroy_process_group()
@@ -156,7 +156,7 @@ def _withholding_worker(rank, world, port, q):
             np.ctypeslib.as_array(buf, shape=(n,))[:] = 0   # "lost": this rank's histogram never arrives
         return coll.allreduce_i64(buf, n, user)
 
-    gx.set_collectives(rank, world, allreduce, None)
+    gx.set_collectives(rank, world, allreduce)
     try:
         _run(gx, reps, owned)
         q.put((rank, "no error"))

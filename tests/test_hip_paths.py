@@ -137,6 +137,53 @@ def test_fractional_hint_keeps_the_first_sample_fused():
     assert flags & FUSED and flags & 16 and not flags & FELL_BACK
 
 
+def test_fractional_hint_on_unit_weight_data_keeps_the_early_lambda_and_the_loose_sweep():
+    """`genrich-amd -s` on a file without multimappers: the hint (gx_expect_fractional) only selects the kernels that can
+    carry a weight class; the closed form of fragLen, lambda ahead of the tile stage and the sweep on the loose slots
+    stay until a count > 1 really arrives (processPair, Genrich.c:3122-3176, gives every alignment of a unique read count 1)."""
+    case = _case(seed=13, n=120_000)
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    h.expect_fractional(True)
+    sh = B.run_case(h, case)
+    flags = h.path_info()
+    assert_same_run(o, h, so, sh, case)
+    assert flags & FUSED and flags & PAIRS and flags & FRAC_PAIRS and flags & LOOSE and not flags & FELL_BACK
+    # a second run of the same context, the hint withdrawn: unit-weight records again, same bits
+    h.reset()
+    h.expect_fractional(False)
+    sh = B.run_case(h, case)
+    flags = h.path_info()
+    assert_same_run(o, h, so, sh, case)
+    assert flags & FUSED and flags & LOOSE and not flags & FRAC_PAIRS
+
+
+def test_what_a_context_has_learned_about_fractions_is_not_the_hints_to_clear():
+    """A hinted context that then SEES a fractional weight (Scalars::fracSeen) does without the early lambda from the next
+    sample on, and withdrawing the hint does not bring it back: the next run still writes records with a weight class."""
+    lens = [300_000, 70_001]
+    unit = synth.make_fragments(lens, 60_000, 31, peak_every=20_000, tower_every=150_000)
+    ev = synth.add_multimap(unit, lens, 0.3, 32)
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    h = hip_backend(params)
+    h.expect_fractional(True)
+    for i, (treat, want_loose) in enumerate(((unit, True), (ev, False), (unit, False))):
+        case = dict(lens=lens, replicates=[dict(save=None, treat=treat, ctrl=None)])
+        o = B.Oracle(params)
+        so = B.run_case(o, case)
+        h.reset()
+        sh = B.run_case(h, case)
+        flags = h.path_info()
+        assert_same_run(o, h, so, sh, case)
+        assert flags & FUSED and flags & FRAC_PAIRS and not flags & FELL_BACK
+        assert bool(flags & LOOSE) == want_loose, (flags, want_loose)
+        if i == 1:
+            h.expect_fractional(False)   # (the third run: no hint any more -- what was learned stays)
+        o.close()
+
+
 def test_fractional_weights_without_pair_records_stay_on_the_general_chain(monkeypatch):
     monkeypatch.setenv("GX_NO_FRAC_PAIRS", "1")
     lens = [300_000, 70_001]

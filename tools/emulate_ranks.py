@@ -93,7 +93,7 @@ def context(owned, rp, rank, world):
     gx.set_chroms(lens)
     gx.set_owned(owned)
     if world > 1:
-        gx.set_collectives(rank, world, rp.allreduce, None)
+        gx.set_collectives(rank, world, rp.allreduce)
     return gx
 
 
