@@ -430,7 +430,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
     // a sample so dense that the average bin already holds more keys than the key array (ATAC cut sites of a deep
     // library): every bin takes the rounds of the second launch, the first one would only find that out bin by bin
-    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 16);
+    const u32 kcap = ctx->fracPairsUsed ? SBT_KEYCAP_FRAC : SBT_KEYCAP;   // (what the ordinary launch's key array holds)
+    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (kcap - kcap / 16);
     if (dense) {
       so2.bigList = nullptr;
       // touched bases per round of the tile passes against keys per round of a bin (they share the LDS, gx_sbtile.h): what
