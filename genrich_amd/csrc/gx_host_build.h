@@ -133,7 +133,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // shown one; the start / end keys of the other fused variant cannot carry a weight)
   const bool fracOk = pairsAllowed && !K.noFracPairs;
   const bool fracLikely = ctx->sawFrac || ctx->fracHint;
-  const bool fused = !backoff && unit32 && (!ctx->hasBed || (pairsAllowed && !K.noBedFused)) && ctx->sbShift <= SBT_MAXSHIFT && !noFused &&
+  // (-E regions: unit-weight pair records only -- with a weight class as well the instances would be twelve)
+  const bool fused = !backoff && unit32 && (!ctx->hasBed || (pairsAllowed && !K.noBedFused && !fracLikely)) && ctx->sbShift <= SBT_MAXSHIFT && !noFused &&
                      (!fracLikely || fracOk) && !ctx->fusedOff && !forceSlowFrag && (size_t)nEv <= (size_t)std::max(1u, nL1base) * 64000 &&
                      (size_t)2 * nEv + nTiles + ctx->nBedEdges + 64 < ((size_t)1 << 30);  // (k_sbtile's stores use 32-bit byte offsets)
   ctx->fusedUsed = fused;
@@ -415,7 +416,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       for (const void* f : {reinterpret_cast<const void*>(k_sbtile<false, false, false>), reinterpret_cast<const void*>(k_sbtile<true, false, false>),
                             reinterpret_cast<const void*>(k_sbtile<true, true, false>), reinterpret_cast<const void*>(k_sbtile<true, false, true>),
                             reinterpret_cast<const void*>(k_sbtile<true, true, true>), reinterpret_cast<const void*>(k_sbtile<true, true, false, SBT_TR_DENSE>),
-                            reinterpret_cast<const void*>(k_sbtile<true, true, true, SBT_TR_DENSE>)})
+                            reinterpret_cast<const void*>(k_sbtile<true, true, true, SBT_TR_DENSE>),
+                            reinterpret_cast<const void*>(k_sbtile<true, false, false, SBT_TR, true>), reinterpret_cast<const void*>(k_sbtile<true, true, false, SBT_TR, true>),
+                            reinterpret_cast<const void*>(k_sbtile<true, true, false, SBT_TR_DENSE, true>)})
         HIPCHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SBT_LDS_BYTES));
       ctx->sbtLdsSet = true;
     }
@@ -430,8 +433,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
     // a sample so dense that the average bin already holds more keys than the key array (ATAC cut sites of a deep
     // library): every bin takes the rounds of the second launch, the first one would only find that out bin by bin
-    const u32 kcap = ctx->fracPairsUsed ? SBT_KEYCAP_FRAC : SBT_KEYCAP;   // (what the ordinary launch's key array holds)
-    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (kcap - kcap / 16);
+    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 16);
     if (dense) {
       so2.bigList = nullptr;
       // touched bases per round of the tile passes against keys per round of a bin (they share the LDS, gx_sbtile.h): what
@@ -446,6 +448,9 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       if (ctx->fracPairsUsed) {
         if (small) hipLaunchKernelGGL((k_sbtile<true, true, true, SBT_TR_DENSE>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
         else hipLaunchKernelGGL((k_sbtile<true, true, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
+      } else if (ctx->hasBed) {
+        if (small) hipLaunchKernelGGL((k_sbtile<true, true, false, SBT_TR_DENSE, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
+        else hipLaunchKernelGGL((k_sbtile<true, true, false, SBT_TR, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       } else {
         if (small) hipLaunchKernelGGL((k_sbtile<true, true, false, SBT_TR_DENSE>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
         else hipLaunchKernelGGL((k_sbtile<true, true, false>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
@@ -453,6 +458,11 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     } else if (ctx->fracPairsUsed) {
       hipLaunchKernelGGL((k_sbtile<true, false, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       hipLaunchKernelGGL((k_sbtile<true, true, true>), gBig, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
+    } else if (ctx->pairsUsed && ctx->hasBed) {
+      // (-E regions: the bins with an edge tile are the second launch's as well -- every second bin of hg38 with ~800 regions, so
+      // a workgroup per bin of the grid, dealt by the dispatcher; the ones beyond the list leave at once)
+      hipLaunchKernelGGL((k_sbtile<true, false, false, SBT_TR, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
+      hipLaunchKernelGGL((k_sbtile<true, true, false, SBT_TR, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
     } else if (ctx->pairsUsed) {
       hipLaunchKernelGGL((k_sbtile<true, false, false>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       // the bins it left on its list (reads piled up: more keys than the key array holds, a tile with thousands of keys):

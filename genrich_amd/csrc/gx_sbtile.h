@@ -61,6 +61,7 @@ constexpr u32 SBT_SLOTS = SBT_K * SBT_NW;              // slots per stream (32 K
 #ifndef GX_SBT_TR
 #define GX_SBT_TR 448
 #endif
+constexpr u32 SBT_PEAK_KEYS = 200;                    // keys from which a tile is drawn ahead of the ordinary ones (a peak: ~575; ordinary: ~90)
 constexpr u32 SBT_HEAVY = 4096;                        // keys from which a tile is the whole workgroup's (a counter per base), not one wavefront's
 constexpr int SBT_MAXR = 8;                            // pair mode: rounds of a super-bucket whose keys do not fit the LDS at once
 constexpr u32 SBT_FCAP = 16384;                        // pair mode: singles of a super-bucket (read where they lie, twice)
@@ -80,16 +81,13 @@ constexpr int SBT_TR = GX_SBT_TR;
 constexpr int SBT_TR_DENSE = 384;
 // a wavefront's scratch, in words: occupancy bitmap (+ a dummy word that absorbs the lanes without a key), the words'
 // prefix counts (+ a dummy entry that ranks those lanes out of every round), counters and offsets by rank
-// (`dbl`: the layout of the instance that walks two neighbouring tiles as one unit of 8192 bases, sbt_tile2 -- twice the bitmap)
-__host__ __device__ constexpr int sbt_occw(bool dbl) { return (dbl ? 2 : 1) * TILE / 32 + 4; }
-__host__ __device__ constexpr int sbt_prew(bool dbl) { return (dbl ? 2 : 1) * TILE / 64 + 4; }
-__host__ __device__ constexpr u32 sbt_tw(u32 tr, bool dbl = false) { return (u32)(sbt_occw(dbl) + sbt_prew(dbl)) + tr + tr / 2; }   // words; 3,488 bytes at 448
+constexpr int SBT_OCCW = TILE / 32 + 4, SBT_PREW = TILE / 64 + 4;
+__host__ __device__ constexpr u32 sbt_tw(u32 tr) { return (u32)(SBT_OCCW + SBT_PREW) + tr + tr / 2; }   // words; 3,488 bytes at 448
 constexpr u32 SBT_NOKEY = 0x1000u;                     // "no key": offset 4096 = bit 0 of the dummy bitmap word
 static_assert(SBT_TR % 64 == 0, "the last step of a round reads whole wavefronts of counters");
 static_assert((1u << PgCfg<u32>::SHIFT) % SBT_SLOT == 0, "a slot never crosses a page");
 static_assert(TILE == 4096, "13-bit LDS keys: 12 bits of offset and the stream");
-static_assert((SBT_NW * sbt_tw(64)) % 4 == 0 && (SBT_NW * sbt_tw(64, true)) % 4 == 0 && (SBT_NW * 96) % 4 == 0,
-              "the scratch is cleared by 16-byte stores (TR: a multiple of 64)");
+static_assert((SBT_NW * sbt_tw(64)) % 4 == 0 && (SBT_NW * 96) % 4 == 0, "the scratch is cleared by 16-byte stores (TR: a multiple of 64)");
 constexpr u32 SBT_LDS_BYTES = 160u * 1024u - 512u;    // what a launch asks for (dynamic; the kernel's few static words come on top): one workgroup per CU
 
 struct SbtLds {
@@ -118,12 +116,9 @@ struct SbtLds {
 };
 constexpr u32 SBT_DYN_OFF = (u32)offsetof(SbtLds, dyn);
 // keys of a super-bucket (both streams) that fit the LDS next to the scratch for TR touched bases per round
-__host__ __device__ constexpr u32 sbt_keycap(u32 tr, bool dbl = false) {
-  return ((SBT_LDS_BYTES - SBT_DYN_OFF - SBT_NW * sbt_tw(tr, dbl) * 4u) / 2u - 192u) / 64u * 64u;
-}
-constexpr u32 SBT_KEYCAP = sbt_keycap(SBT_TR, true);  // ... of the ordinary launch of a unit-weight sample (tile pairs: 41 K keys)
-constexpr u32 SBT_KEYCAP_FRAC = sbt_keycap(SBT_TR);   // ... of a sample with a weight class in its records (single tiles: 47 K)
-static_assert(sbt_keycap(192) > sbt_keycap(448) && sbt_keycap(448, true) >= 40000, "the split of the LDS");
+__host__ __device__ constexpr u32 sbt_keycap(u32 tr) { return ((SBT_LDS_BYTES - SBT_DYN_OFF - SBT_NW * sbt_tw(tr) * 4u) / 2u - 192u) / 64u * 64u; }
+constexpr u32 SBT_KEYCAP = sbt_keycap(SBT_TR);        // ... of the ordinary launch
+static_assert(sbt_keycap(192) > sbt_keycap(448) && sbt_keycap(448) >= 40960, "the split of the LDS");
 
 // -E regions on the fused path (round 6; Genrich.c:2185-2263).  Three kinds of tile: (A) `save` on at its first base and no edge
 // inside -- the ordinary tile, untouched; (B) inside a region (`save` off, no edge, not its chromosome's last): nothing to emit,
@@ -197,12 +192,12 @@ __device__ __forceinline__ u32 sbt_class_of(int w) {  // weight (> 0) -> class; 
   return c;
 }
 
-template <bool FRAC, bool DBL = false>
+template <bool FRAC, bool BED>
 __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
                                          int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms, long long& fhi,
                                          long long& flo, long long& bedExcl) {
   constexpr u32 NOKEY = FRAC ? SBT_NOKEY_F : SBT_NOKEY;
-  if (flags & TM_BEDIN) {  // wave-uniform, -E runs only: a tile inside an excluded region -- no interval, its pileup off the closed form
+  if (BED && (flags & TM_BEDIN)) {  // wave-uniform, -E runs only: a tile inside an excluded region -- no interval, its pileup off the closed form
     long long s = 0;
     for (u32 k = lane_id(); k < n; k += 64) {
       const u32 key = kl[k];
@@ -215,18 +210,17 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
   }
   // a key's offset with "no key" at 4096 (the dummy bitmap word)
   auto offOf = [](u32 key) -> u32 { return FRAC ? (key & (TILE - 1)) | ((key >> 4) & (u32)TILE) : key & (2 * TILE - 1); };
-  constexpr int SBT_OCCW = sbt_occw(DBL), SBT_PREW = sbt_prew(DBL);
   u32* occ = reinterpret_cast<u32*>(lds);
   u32* pre = reinterpret_cast<u32*>(lds + SBT_OCCW);
   const uint16_t* pre16 = reinterpret_cast<const uint16_t*>(pre);
   int* cnt = lds + SBT_OCCW + SBT_PREW;
   uint16_t* list = reinterpret_cast<uint16_t*>(lds + SBT_OCCW + SBT_PREW + TR_CAP);   // (TR_CAP: a constant in the ordinary launch)
   const int lane = lane_id();
-  // (in the tile-pair layout the prefix entry of THIS function's dummy bitmap word -- word 128 -- is a real entry of sbt_tile2's:
-  // put back before the passes read it; LDS operations of one wavefront execute in order)
-  if (DBL && lane == 0) pre[TILE / 64] = 0xFFFFFFFFu;
-  const bool active = flags & TM_ACTIVE;
-  const u64 activeM = active ? ~0ull : 0ull;
+  if (!(flags & TM_ACTIVE)) {  // wave-uniform: a tile of a chromosome that is not saved -- nothing to emit, nothing touched
+    if (lane == 0) out.to.tileCount[t] = 0;
+    return;
+  }
+  constexpr bool active = true;
   const u32 negPos0 = 0u - pos0;   // (pos0 + p != 0  <=>  p != -pos0)
   const bool lastTile = (flags & TM_LAST) != 0;
 #ifndef GX_SBT_KR
@@ -297,10 +291,10 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
     auto emit = [&](const u32 p, const int d120, const int incS) {
       const int after = runBase + incS;
       const int before = after - d120;                          // the pileup of the interval that ends here (2244)
-      // nz = d120 != 0 && active && pos0 + p != 0 (2241: base 0 closes nothing), as a lane mask made of the compares'
+      // nz = d120 != 0 && pos0 + p != 0 (2241: base 0 closes nothing), as a lane mask made of the compares'
       // own scalar results: __ballot() of a composite condition sends it through a VGPR and back (two more VALU
       // instructions per ballot, four ballots per step)
-      const u64 mask = activeM & __builtin_amdgcn_uicmp((u32)d120, 0u, 33 /* ne */) & __builtin_amdgcn_uicmp(p, negPos0, 33);
+      const u64 mask = __builtin_amdgcn_uicmp((u32)d120, 0u, 33 /* ne */) & __builtin_amdgcn_uicmp(p, negPos0, 33);
       const bool nz = __builtin_amdgcn_inverse_ballot_w64(mask);
       const u32 orank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
       if (nz) {
@@ -371,216 +365,12 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
   wave_lds_sync();
 }
 
-// TWO neighbouring tiles of one chromosome as ONE unit of 8192 bases (round 6; unit weights, the ordinary launch).  The ordinary
-// tile of hg38 / 50 M fragments holds ~90 keys on ~89 touched bases: its two key registers and its two steps of 64 touched bases
-// run at 70 % of their lanes, and what a tile costs whatever it holds -- the draw from the counter, the descriptor, the scan over
-// the bitmap words, the epilogue -- is paid per 4096 bases.  A pair holds ~180 keys on ~178 bases: three registers and three
-// steps (94 %), one draw, one scan over a bitmap twice as long (four words per lane).  The two tiles' keys lie side by side in
-// the key array (the scatter goes by tile), so a key's 13-bit offset is its 12-bit one plus "second tile" from its index; the
-// touched bases of the first tile are the ranks below T0 (the prefix count at bitmap word 128).  What stays per tile is what
-// the kernels downstream read per tile: the loose slots (the second tile's intervals start at ITS slot, not behind the first
-// one's), count, last end, deep flag, fillers -- `finish0` closes the first tile where the ranks cross T0, in the middle of a
-// step if need be.  A pair with more touched bases than a round holds (a peak: one pair in six) is walked in rounds that end at
-// the tile border, so that no key is visited more often than in two single tiles.
-// Preconditions (sbt_bin's dispatcher): both tiles active, of one chromosome (the first is not its last), neither heavy nor
-// touched by a -E region.
-template <u32 TR_CAP>
-__device__ __forceinline__ void sbt_tile2(int* lds, const uint16_t* __restrict__ kl, const u32 n0, const u32 n1, const u32 t0, const u32 pos0,
-                                          const u32 len, const bool lastTile, const int carry, const u32 slot0, const int vsig,
-                                          const SbtOut& out, u32& bad) {
-  constexpr u32 NOKEY = 2u * TILE;                    // "no key": offset 8192 = bit 0 of the dummy bitmap word (256)
-  constexpr int OCCW = sbt_occw(true), PREW = sbt_prew(true);
-  u32* occ = reinterpret_cast<u32*>(lds);
-  u32* pre = reinterpret_cast<u32*>(lds + OCCW);
-  const uint16_t* pre16 = reinterpret_cast<const uint16_t*>(pre);
-  int* cnt = lds + OCCW + PREW;
-  uint16_t* list = reinterpret_cast<uint16_t*>(lds + OCCW + PREW + TR_CAP);
-  const int lane = lane_id();
-  const u32 n = n0 + n1, t1 = t0 + 1, slot1 = slot0 + n0 + 1;
-  const u32 negPos0 = 0u - pos0;
-  // a key in a register: [12:0] offset within the pair, [15] end
-  auto keyAt = [&](u32 k) -> u32 { return ((u32)kl[k] & 0x8FFFu) | (k >= n0 ? (u32)TILE : 0u); };
-  auto offOf = [](u32 key) -> u32 { return key & (4u * TILE - 1u); };
-  constexpr int KR = 3;
-  u32 kr[KR];
-#pragma unroll
-  for (int q = 0; q < KR; q++) {
-    const u32 k = (u32)lane + q * 64;  // (in bounds: the key array has 192 entries of slack)
-    const u32 v = keyAt(k);
-    kr[q] = k < n ? v : NOKEY;
-  }
-  // ---- A1
-  auto mark = [&](u32 key) { const u32 off = offOf(key); atomicOr(&occ[off >> 5], 1u << (off & 31)); };
-#pragma unroll
-  for (int q = 0; q < KR; q++)
-    if (kr[q] != NOKEY) mark(kr[q]);
-  for (u32 k = KR * 64 + lane; k < n; k += 64) mark(keyAt(k));
-  wave_lds_sync();
-  // ---- B: every lane owns four bitmap words
-  const uint4 ww = *reinterpret_cast<const uint4*>(occ + 4 * lane);
-  const int c0 = __popc(ww.x), c1 = __popc(ww.y), c2 = __popc(ww.z), c = c0 + c1 + c2 + __popc(ww.w);
-  const int incC = dpp_scan_add(c);
-  const u32 exc = (u32)(incC - c);
-  const u32 T = (u32)__builtin_amdgcn_readlane(incC, 63);
-  const u32 T0 = (u32)__builtin_amdgcn_readlane((int)exc, 32);   // touched bases of the first tile (words 0 .. 127)
-  {
-    const u32 e1 = exc + (u32)c0, e2 = e1 + (u32)c1, e3 = e2 + (u32)c2;
-    *reinterpret_cast<uint2*>(pre + 2 * lane) = make_uint2(exc | (e1 << 16), e2 | (e3 << 16));
-  }
-  wave_lds_sync();
-  auto rankOf = [&](u32 key) -> u32 {
-    const u32 off = offOf(key), wi = off >> 5;
-    return (u32)pre16[wi] + (u32)__popc(occ[wi] & ((1u << (off & 31)) - 1u));
-  };
-  u32 rr[KR];
-#pragma unroll
-  for (int q = 0; q < KR; q++) rr[q] = rankOf(kr[q]);
-  int runBase = carry;
-  u32 outCount = 0, lastEnd = 0, slot = slot0;
-  u64 negM = 0, bigM = carry >= FRAG_FAST_MAXV ? ~0ull : 0ull;
-  bool second = false;   // the emitter has moved on to the second tile (wave-uniform)
-  // the first tile is through: its count, its last end, its deep flag, its unused slots; `carry1`: the pileup it hands on
-  auto finish0 = [&](int carry1) {
-    if (lane == 0) {
-      out.to.tileCount[t0] = outCount;
-      if (outCount) out.to.tileLastEnd[t0] = lastEnd;
-      if (bigM) {  // rare
-        atomicOr(&out.to.tileDeep[t0], 1u);
-        if (out.to.ctl) atomicOr(&out.to.ctl->bad, 1u);
-      }
-    }
-    if (outCount && vsig != 0x7FFFFFFF)  // wave-uniform
-      for (u32 j = outCount + lane; j < n0 + 1; j += 64) {
-        st_u32(out.to.looseEnd, slot0 + j, lastEnd);
-        st_u32(out.to.looseV, slot0 + j, 0u);
-      }
-    bigM = carry1 >= FRAG_FAST_MAXV ? ~0ull : 0ull;
-    outCount = 0;
-    slot = slot1;
-    second = true;
-  };
-  const bool oneRound = T <= TR_CAP;
-  for (u32 r0 = 0; r0 < T;) {
-    // (several rounds: they end at the tile border -- a round only takes the keys whose base it holds, and the keys of a tile
-    // are then visited as often as if the tile were walked alone)
-    const u32 nL = oneRound ? T : min(TR_CAP, (r0 < T0 ? T0 : T) - r0);
-    if (r0) wave_lds_sync();
-    // ---- A2
-    auto put = [&](u32 r, u32 key) {
-      r -= r0;
-      if (r < nL) {
-        list[r] = (uint16_t)(key & (2u * TILE - 1u));
-        atomicAdd(&cnt[r], (key & 0x8000u) ? -GX_UNIT : GX_UNIT);
-      }
-    };
-#pragma unroll
-    for (int q = 0; q < KR; q++) put(rr[q], kr[q]);
-    // (the keys beyond the registers: in a round that ends at the tile border only those of the round's tile -- they lie apart)
-    const u32 kLo = oneRound || r0 < T0 ? 0u : n0, kHi = oneRound || r0 >= T0 ? n : n0;
-    for (u32 k = max((u32)KR * 64u, kLo) + lane; k < kHi; k += 64) {
-      const u32 key = keyAt(k);
-      put(rankOf(key), key);
-    }
-    wave_lds_sync();
-    // ---- C
-    for (u32 j0 = 0; j0 < nL; j0 += 64) {
-      const u32 jb = r0 + j0;   // rank of lane 0's touched base
-      if (!second && jb >= T0) finish0(runBase);   // wave-uniform
-      const u32 p = list[j0 + lane];
-      const int d120 = __hip_atomic_exchange(&cnt[j0 + lane], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);  // read and clear
-      const int incS = dpp_scan_add(d120);
-      const int after = runBase + incS;
-      const int before = after - d120;
-      const u64 mask = __builtin_amdgcn_uicmp((u32)d120, 0u, 33 /* ne */) & __builtin_amdgcn_uicmp(p, negPos0, 33);
-      if (second || jb + 64 <= T0) {  // wave-uniform: all of this step's touched bases lie in one tile (nearly always)
-        const bool nz = __builtin_amdgcn_inverse_ballot_w64(mask);
-        const u32 orank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
-        if (nz) {
-          const u32 o = slot + outCount + orank;
-          st_u32(out.to.looseEnd, o, pos0 + p);
-          st_u32(out.to.looseV, o, (u32)before);
-        }
-        if (vsig != 0x7FFFFFFF)  // wave-uniform
-          sig_flush_m(out.to.sigMask, slot + outCount, mask & __builtin_amdgcn_sicmp(before, vsig, 39 /* sge */), orank, mask);
-        if (__builtin_amdgcn_uicmp((u32)after, (u32)FRAG_FAST_MAXV, 35 /* uge */)) {  // wave-uniform
-          negM |= __ballot(after < 0);
-          bigM |= __ballot(after >= FRAG_FAST_MAXV);
-        }
-        runBase += __builtin_amdgcn_readlane(incS, 63);
-        if (mask) {  // wave-uniform
-          outCount += (u32)__popcll(mask);
-          lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(mask));
-        }
-      } else {
-        // the step that holds the first tile's last touched bases and the second tile's first ones: lanes below `split` write
-        // behind the first tile's intervals, the others from the second tile's slot on
-        const u32 split = T0 - jb;   // 1 .. 63
-        const u64 low = (1ull << split) - 1ull;
-        const u64 m0 = mask & low, m1 = mask & ~low;
-        const bool nz = __builtin_amdgcn_inverse_ballot_w64(mask), first = (u32)lane < split;
-        const u32 r0k = __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0u));
-        const u32 r1k = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0u));
-        if (nz) {
-          const u32 o = first ? slot0 + outCount + r0k : slot1 + r1k;
-          st_u32(out.to.looseEnd, o, pos0 + p);
-          st_u32(out.to.looseV, o, (u32)before);
-        }
-        const u64 sg = mask & __builtin_amdgcn_sicmp(before, vsig, 39 /* sge */);
-        const u64 big = __ballot(after >= FRAG_FAST_MAXV);
-        negM |= __ballot(after < 0);
-        if (vsig != 0x7FFFFFFF) sig_flush_m(out.to.sigMask, slot0 + outCount, sg & low, r0k, m0);
-        bigM |= big & low;
-        if (m0) {
-          outCount += (u32)__popcll(m0);
-          lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(m0));
-        }
-        finish0(runBase + __builtin_amdgcn_readlane(incS, (int)split - 1));
-        if (vsig != 0x7FFFFFFF) sig_flush_m(out.to.sigMask, slot1, sg & ~low, r1k, m1);
-        bigM |= big & ~low;
-        runBase += __builtin_amdgcn_readlane(incS, 63);
-        if (m1) {
-          outCount = (u32)__popcll(m1);
-          lastEnd = pos0 + (u32)__builtin_amdgcn_readlane((int)p, 63 - __builtin_clzll(m1));
-        }
-      }
-    }
-    r0 += nL;
-  }
-  if (!second) finish0(runBase);   // (the second tile holds no touched base)
-  *reinterpret_cast<uint4*>(occ + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
-  // ---- the second tile's epilogue (as sbt_tile's)
-  const u32 total = outCount + (lastTile ? 1u : 0u);
-  if (lane == 0) {
-    if (lastTile) {  // closing interval [.., len): 2268-2273
-      const u32 o = slot1 + outCount;
-      out.to.looseEnd[o] = len;
-      out.to.looseV[o] = runBase;
-      if (runBase >= vsig) atomicOr((unsigned long long*)&out.to.sigMask[o >> 6], 1ull << (o & 63));
-      lastEnd = len;
-    }
-    if (total) out.to.tileLastEnd[t1] = lastEnd;
-    out.to.tileCount[t1] = total;
-    if (bigM) {  // rare
-      atomicOr(&out.to.tileDeep[t1], 1u);
-      if (out.to.ctl) atomicOr(&out.to.ctl->bad, 1u);
-    }
-  }
-  lastEnd = (u32)__builtin_amdgcn_readfirstlane((int)lastEnd);
-  if (negM) bad |= ST_NEG_PILE;
-  if (total && vsig != 0x7FFFFFFF)  // wave-uniform
-    for (u32 j = total + lane; j < n1 + 1; j += 64) {
-      st_u32(out.to.looseEnd, slot1 + j, lastEnd);
-      st_u32(out.to.looseV, slot1 + j, 0u);
-    }
-  wave_lds_sync();
-}
-
 // A tile with thousands of keys (reads piled up on a few bases: a tower, chrM) by the WHOLE workgroup with a counter per
 // base, as k_tile_heavy does on the general chain -- one wavefront walking 30,000 keys in rounds of 192 touched bases held
 // its workgroup, and the kernel, for a millisecond.  The counters take the place of the wavefronts' scratch (all of
 // them are through with their tiles); every thread owns four consecutive bases.  Same outputs as sbt_tile.
 // (FRAC with the general fragLen path on: the tile goes on the list of the heavy tiles, whose terms k_frag_walk adds)
-template <bool FRAC>
+template <bool FRAC, bool BED>
 __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const uint16_t* __restrict__ kl, u32 n, u32 t, u32 pos0, u32 len, u32 flags,
                                           int carry, u32 slot, int vsig, const SbtOut& out, u32& bad, bool fragTerms, const BedIn& bed,
                                           long long& bedExcl) {
@@ -607,7 +397,7 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
   // -E (TM_BEDX): the tile's edges -- a handful, tile-local offsets in ascending order -- are breakpoints whatever the difference
   // holds, a difference inside a region is none, and an interval that ends inside one carries V_MARK (2241-2263, as k_tile<BED>).
   // `save` at this thread's first base = the tile's state ^ the parity of the edges before it.
-  const bool bedx = (flags & TM_BEDX) != 0;
+  const bool bedx = BED && (flags & TM_BEDX) != 0;
   bool save = true, saveEnd = true;
   u32 edgeM = 0;
   if (bedx) {  // block-uniform
@@ -700,10 +490,11 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
 // array holds (worked off in rounds of tiles), a tile with thousands of keys (sbt_heavy: the whole workgroup), more than
 // 32 K pair records.  It keeps no record in registers (every pass reads the bin's slots from global memory: they are
 // in L2), so that none of this costs the first launch -- the one every bin of an ordinary sample takes -- a register.
-template <bool PAIRS, bool BIG, bool FRAC, int TRC>
+template <bool PAIRS, bool BIG, bool FRAC, int TRC, bool BED>
 __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32* __restrict__ st, const u32 seg, SbtLds& L) {
   static_assert(PAIRS || !BIG, "the second launch exists in pair mode only");
   static_assert(PAIRS || !FRAC, "fractional weights ride pair records only");
+  static_assert(!BED || (PAIRS && !FRAC), "-E regions: unit-weight pair records (the tiles with an edge are the second launch's)");
   constexpr u32 LENB = FRAC ? 9u : PAIR_LEN_BITS;      // a pair record's length bits (fractional: [11:9] the weight class)
   const bool fragTerms = FRAC && in.fragAcc != nullptr && (u32)__builtin_amdgcn_readfirstlane((int)in.ff->slow) != 0u;
   long long fhi = 0, flo = 0, bedExcl = 0;
@@ -715,10 +506,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   // how the LDS behind the tables is split: constants of the instance (runtime values cost the rounds launch 12 %: measured)
   static_assert(TRC % 64 == 0 && TRC >= 192 && TRC <= 448, "touched bases per round");
   constexpr u32 trCap = (u32)TRC;
-  // the ordinary launch of a unit-weight sample walks its tiles in pairs (sbt_tile2): a bitmap twice as long per wavefront
-  constexpr bool DBL = PAIRS && !BIG && !FRAC;
-  constexpr int SBT_OCCW = sbt_occw(DBL);
-  constexpr u32 tw = sbt_tw(trCap, DBL), scrWords = SBT_NW * tw, keyCap = sbt_keycap(trCap, DBL);
+  constexpr u32 tw = sbt_tw(trCap), scrWords = SBT_NW * tw, keyCap = sbt_keycap(trCap);
   int* const scr = L.dyn;
   uint16_t* const keysL = reinterpret_cast<uint16_t*>(L.dyn + scrWords);
   const u32 nSeg = in.nSeg;
@@ -746,7 +534,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   };
   // -E regions: the edges before this thread's tile (they take loose slots of their own) and the tile's kind (TM_BEDX: an edge
   // inside, or a chromosome's last tile that ends inside a region; `inside`: nothing of the tile is saved)
-  const bool hasBed = in.bed.bedTileOff != nullptr;   // (uniform)
+  constexpr bool hasBed = BED;   // (instances of their own: the plumbing cost the run without regions 0.012 ms as a run-time switch)
   u32 bedBefore = 0, bedMine = 0;
   bool bedInside = false;
   auto loadBed = [&](const uint4& ti) {
@@ -791,10 +579,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   if (tid == 0) { L.overflow = 0; L.nHeavy = 0; L.nRounds = 0; }
   if (tid < 2 * NXCD) L.scratch[tid] = myLen;
   __syncthreads();
-  if (tid < SBT_NW) {
-    scr[(u32)tid * tw + SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
-    if (DBL) scr[(u32)tid * tw + SBT_OCCW + 2 * TILE / 64] = -1;   // ... and of the tile pair's
-  }
+  if (tid < SBT_NW) scr[(u32)tid * tw + SBT_OCCW + TILE / 64] = -1;  // the prefix entry of the dummy bitmap word: no rank at all
   if (tid < 2) {
     u32 a = 0;
     for (int x = 0; x < NXCD; x++) {
@@ -1056,15 +841,15 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       if (t + 1 == in.nTiles) out.tileSlot[in.nTiles] = m.slot + nS + nE + 1 + bedMine;
     }
   }
-  if constexpr (DBL) {
-    // the order in which the wavefronts draw the tile pairs: the ones with a peak (several times an ordinary pair's keys) first,
-    // so that none of them is the last thing a wavefront starts while the others have run out of work (L.heavy / L.nHeavy /
-    // L.nRounds are the second launch's: free here)
-    if (tid < (int)nT && !(tid & 1) && !ovf) {
-      const u32 hA = L.hist[tid], hB = tid + 1 < (int)nT ? L.hist[tid + 1] : 0u;
-      const u32 nk = (hA & 0xFFFFu) + (hA >> 16) + (hB & 0xFFFFu) + (hB >> 16);
-      const u32 pos = nk > 320u ? atomicAdd(&L.nHeavy, 1u) : ((nT + 1u) >> 1) - 1u - atomicAdd(&L.nRounds, 1u);
-      L.heavy[pos] = (uint16_t)(tid >> 1);
+  if constexpr (PAIRS && !BIG) {
+    // the order in which the wavefronts draw the tiles (round 6): the ones with a peak -- one in twelve, several times an ordinary
+    // tile's keys -- first, so that none of them is the last thing a wavefront starts while the others have run out of work
+    // (tile stage 0.572 -> 0.556 ms at config 2).  L.heavy / L.nHeavy / L.nRounds are the second launch's: free here.
+    if (tid < (int)nT && !ovf) {
+      const u32 hA = L.hist[tid];
+      const u32 nk = (hA & 0xFFFFu) + (hA >> 16);
+      const u32 pos = nk > SBT_PEAK_KEYS ? atomicAdd(&L.nHeavy, 1u) : nT - 1u - atomicAdd(&L.nRounds, 1u);
+      L.heavy[pos] = (uint16_t)tid;
     }
   }
   if (ovf) {
@@ -1083,56 +868,23 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   auto tiles = [&](u32 tileEnd, u32 keyBase) {
     // (from a counter, not dealt in turn: one tile in twelve carries a peak and costs several ordinary ones -- a static deal
     // measured 0.628 against 0.590 ms, the workgroup waits for the wavefront that drew three of them)
-    if constexpr (DBL) {
-      // pairs of tiles (2 b, 2 b + 1) from the counter; a pair that is not one -- the bin's or the genome's last tile alone, a
-      // chromosome border between the two, a tile that is not saved or lies in a -E region -- goes tile by tile
-      int* const myScr = scr + (u32)__builtin_amdgcn_readfirstlane(wv) * tw;
-      const u32 nPairs = (tileEnd + 1u) >> 1;
-      for (;;) {
-        u32 b2 = 0;
-        if (lane == 0) b2 = atomicAdd(&L.work, 1u);
-        b2 = (u32)__builtin_amdgcn_readfirstlane((int)b2);
-        if (b2 >= nPairs) break;
-        b2 = (u32)__builtin_amdgcn_readfirstlane((int)L.heavy[b2]);
-        const u32 b0 = 2u * b2, b1 = b0 + 1u, t = segTileBase + b0;
-        if (t >= in.nTiles) continue;
-        const bool has1 = b1 < tileEnd && t + 1u < in.nTiles;
-        const uint4 tf0 = L.tinfo[b0], tf1 = L.tinfo[has1 ? b1 : b0];
-        const u32 sc = L.startC[b0];
-        const u32 fz0 = (u32)__builtin_amdgcn_readfirstlane((int)tf0.z), fz1 = (u32)__builtin_amdgcn_readfirstlane((int)tf1.z);
-        const u32 n0 = fz0 >> 8, n1 = fz1 >> 8;
-        const u32 slot0 = segSlot + sc + b0 + (hasBed ? (u32)__builtin_amdgcn_readfirstlane(L.netPref[b0]) : 0u);
-        if (has1 && (fz0 & 0xFFu) == TM_ACTIVE && (fz1 & 0xFFu & ~TM_LAST) == TM_ACTIVE) {  // wave-uniform
-          sbt_tile2<trCap>(myScr, keysL + (sc - keyBase), n0, n1, t, tf0.x, tf0.y, (fz1 & TM_LAST) != 0, (int)tf0.w, slot0, vsig, out, bad);
-        } else {
-          sbt_tile<FRAC, true>(myScr, trCap, keysL + (sc - keyBase), n0, t, tf0.x, tf0.y, fz0 & 0xFFu, (int)tf0.w, slot0, vsig, out, bad, fragTerms,
-                               fhi, flo, bedExcl);
-          if (has1) {
-            const u32 sc1 = sc + n0;
-            const u32 slot1 = segSlot + sc1 + b1 + (hasBed ? (u32)__builtin_amdgcn_readfirstlane(L.netPref[b1]) : 0u);
-            sbt_tile<FRAC, true>(myScr, trCap, keysL + (sc1 - keyBase), n1, t + 1u, tf1.x, tf1.y, fz1 & 0xFFu, (int)tf1.w, slot1, vsig, out, bad,
-                                 fragTerms, fhi, flo, bedExcl);
-          }
-        }
-      }
-      return;
-    }
     for (;;) {
       u32 b = 0;
       if (lane == 0) b = atomicAdd(&L.work, 1u);
       b = (u32)__builtin_amdgcn_readfirstlane((int)b);
       if (b >= tileEnd) break;
+      if constexpr (PAIRS && !BIG) b = (u32)__builtin_amdgcn_readfirstlane((int)L.heavy[b]);   // (peaks first)
       const u32 t = segTileBase + b;
       if (t >= in.nTiles) continue;
       const uint4 tf = L.tinfo[b];
       const u32 sc = L.startC[b];
       const u32 fz = (u32)__builtin_amdgcn_readfirstlane((int)tf.z), n = fz >> 8;
-      if (BIG && (n > SBT_HEAVY || (fz & TM_BEDX))) {  // wave-uniform: left to the whole workgroup
+      if (BIG && (n > SBT_HEAVY || (BED && (fz & TM_BEDX)))) {  // wave-uniform: left to the whole workgroup
         if (lane == 0) L.heavy[atomicAdd(&L.nHeavy, 1u)] = (uint16_t)b;
         continue;
       }
       const u32 bedSlots = hasBed ? (u32)__builtin_amdgcn_readfirstlane(L.netPref[b]) : 0u;
-      sbt_tile<FRAC>(scr + (u32)__builtin_amdgcn_readfirstlane(wv) * tw, trCap, keysL + (sc - keyBase), n, t, tf.x, tf.y, fz & 0xFFu, (int)tf.w,
+      sbt_tile<FRAC, BED>(scr + (u32)__builtin_amdgcn_readfirstlane(wv) * tw, trCap, keysL + (sc - keyBase), n, t, tf.x, tf.y, fz & 0xFFu, (int)tf.w,
                      segSlot + sc + b + bedSlots, vsig, out, bad, fragTerms, fhi, flo, bedExcl);
     }
     if constexpr (BIG) {
@@ -1143,7 +895,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         const u32 b = L.heavy[i], t = segTileBase + b;
         const uint4 tf = L.tinfo[b];
         const u32 sc = L.startC[b], n = tf.z >> 8;
-        sbt_heavy<FRAC>(L, scrWords, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z & 0xFFu, (int)tf.w,
+        sbt_heavy<FRAC, BED>(L, scrWords, keysL + (sc - keyBase), n, t, tf.x, tf.y, tf.z & 0xFFu, (int)tf.w,
                         segSlot + sc + b + (hasBed ? (u32)L.netPref[b] : 0u), vsig, out, bad, fragTerms, in.bed, bedExcl);
       }
       // the wavefronts' scratch as the next round's tiles expect it
@@ -1264,17 +1016,17 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   if (bad && lane == 0) atomicOr(st, bad);
 }
 
-template <bool PAIRS, bool BIG, bool FRAC, int TRC = SBT_TR>
+template <bool PAIRS, bool BIG, bool FRAC, int TRC = SBT_TR, bool BED = false>
 __global__ __launch_bounds__(SBT_NT) void k_sbtile(SbtIn in, SbtOut out, u32* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
   SbtLds& L = *reinterpret_cast<SbtLds*>(sbt_raw);
   if constexpr (!BIG)
-    sbt_bin<PAIRS, false, FRAC, TRC>(in, out, st, blockIdx.x, L);
+    sbt_bin<PAIRS, false, FRAC, TRC, BED>(in, out, st, blockIdx.x, L);
   else {
     // (no list: a sample so dense that most bins need rounds -- the host sends every bin here and skips the first launch)
     const u32 nBig = out.bigList ? *out.nBig : in.nSeg;
     for (u32 item = blockIdx.x; item < nBig; item += gridDim.x) {  // (usually none)
-      sbt_bin<PAIRS, true, FRAC, TRC>(in, out, st, out.bigList ? out.bigList[item] : item, L);
+      sbt_bin<PAIRS, true, FRAC, TRC, BED>(in, out, st, out.bigList ? out.bigList[item] : item, L);
       __syncthreads();
     }
   }
