@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 from genrich_amd import synth  # noqa: E402
 from genrich_amd.dist import Collectives, lpt_partition  # noqa: E402
-from genrich_amd.lib import GxParams, Genrich, minus_log10f, rccl_unique_id  # noqa: E402
+from genrich_amd.lib import GxParams, Genrich, minus_log10f, pack_events, rccl_unique_id  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -651,6 +651,42 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
         finally:
             gx.set_knob("GX_NO_LOOSE", 0)
         step()
+    # The same step with the events in their 8-byte form (gx_event8, gx_push_events_packed: half of the step's largest stream),
+    # resident in HBM like the 16-byte ones of `value`.  Only for the headline, one rank.
+    packed_ms = packed_same = None
+    if headline and world == 1 and not args.no_materialised:
+        peaks16 = gx.get_peaks().tobytes()
+        p8 = [(pack_events(tv), None if cv is None else pack_events(cv)) for tv, cv in reps_all]
+        if all(len(t[1]) == 0 and (c is None or len(c[1]) == 0) for t, c in p8):
+            d8 = [(torch.from_numpy(t[0].view(np.uint32).reshape(-1, 2).copy()).to(dev),
+                   None if c is None else torch.from_numpy(c[0].view(np.uint32).reshape(-1, 2).copy()).to(dev)) for t, c in p8]
+
+            def step8():
+                gx.reset()
+                for d_tv, d_cv in d8:
+                    gx.sample_begin(0, None)
+                    gx.push_events_packed(d_tv.data_ptr(), where=2, n=d_tv.shape[0])
+                    gx.sample_end()
+                    if d_cv is not None:
+                        gx.sample_begin(1, None)
+                        gx.push_events_packed(d_cv.data_ptr(), where=2, n=d_cv.shape[0])
+                        gx.sample_end()
+                    else:
+                        gx.sample_no_control()
+                    gx.pvalues()
+                return gx.find_peaks()
+
+            for _ in range(2):
+                step8()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step8()
+            torch.cuda.synchronize()
+            packed_ms = (time.perf_counter() - t1) / steps * 1e3
+            packed_same = bool(gx.path_info() & 512) and gx.get_peaks().tobytes() == peaks16
+            del d8
+            step()
     gx.set_phase_timing(2)
     all_phases = {}
     for _ in range(2):
@@ -775,10 +811,14 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             "materialised": ({"ms_per_step": mat_ms, "value": n_rep * G / (mat_ms * 1e-3) / 1e9, "unit": "Gbases/s",
                               "sweep_on_loose_slots": bool(mat_flags & 2)} if mat_ms else None),
             "materialised_ms_per_step": mat_ms,
+            # the same step on 8-byte events (gx_event8) resident in HBM; same_peaks: read in place and the 16-byte step's peak bytes
+            "packed_events": ({"ms_per_step": packed_ms, "value": n_rep * G / (packed_ms * 1e-3) / 1e9, "unit": "Gbases/s",
+                               "same_peaks": packed_same} if packed_ms else None),
             # (the roofline kernel's phase: HIP events inside the timed region; the others: two extra untimed steps)
             "phases_ms": phases,
         }
         out["config"]["materialised_ms_per_step"] = mat_ms
+        out["config"]["packed_events_ms_per_step"] = packed_ms
         if world == 1 and want_e2e:
             # PCIe upload of the events from pinned host memory, and a step that starts there (gx_push_events)
             pin = [(torch.from_numpy(tv.view(np.uint32).reshape(-1, 4)).pin_memory(),
@@ -822,6 +862,36 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
             # (events from pinned host memory to HBM, outside the timed region of `value`; and gx_push_events_pinned -> peaks)
             out["h2d"] = {"ms": h2d_ms, "bytes": nbytes, "gbs": nbytes / h2d_ms / 1e6}
             out["e2e_from_pinned"] = {"ms_per_step": e2e_ms, "value": n_rep * G / (e2e_ms * 1e-3) / 1e9, "unit": "Gbases/s"}
+            # ... and from pinned 8-byte events (half the bytes over PCIe)
+            p8 = [(pack_events(tv), None if cv is None else pack_events(cv)) for tv, cv in reps_all]
+            if all(len(t[1]) == 0 and (c is None or len(c[1]) == 0) for t, c in p8):
+                pin8 = [(torch.from_numpy(t[0].view(np.uint32).reshape(-1, 2)).pin_memory(),
+                         None if c is None else torch.from_numpy(c[0].view(np.uint32).reshape(-1, 2)).pin_memory()) for t, c in p8]
+
+                def step_from_host8():
+                    gx.reset()
+                    for t, c in pin8:
+                        gx.sample_begin(0, None)
+                        gx.push_events_packed(t.data_ptr(), where=1, n=t.shape[0])
+                        gx.sample_end()
+                        if c is not None:
+                            gx.sample_begin(1, None)
+                            gx.push_events_packed(c.data_ptr(), where=1, n=c.shape[0])
+                            gx.sample_end()
+                        else:
+                            gx.sample_no_control()
+                        gx.pvalues()
+                    return gx.find_peaks()
+
+                step_from_host8()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step_from_host8()
+                torch.cuda.synchronize()
+                e8 = (time.perf_counter() - t1) / 3 * 1e3
+                out["e2e_from_pinned_packed"] = {"ms_per_step": e8, "value": n_rep * G / (e8 * 1e-3) / 1e9, "unit": "Gbases/s"}
+                del pin8
             del pin
     # the timed context and its device arrays go before the gate's (and the next config's) are made
     gx.close()

@@ -226,6 +226,7 @@ int gx_reset(gx_ctx* ctx) {
   ctx->phase = 0;
   ctx->finalIdx = -1;
   ctx->segs.clear();
+  ctx->unpackUsed = 0;
   ctx->evChunkIdx = ctx->evChunkFill = ctx->evPoolUsed = 0;
   ctx->nHostPeaks = 0;
   if (ctx->statusSeen) {  // (a clean run leaves the status words at zero: no fill launch)
@@ -267,6 +268,7 @@ int gx_sample_begin(gx_ctx* ctx, int is_ctrl, const uint8_t* save) {
     ctx->phase = 3;
   }
   ctx->segs.clear();
+  ctx->unpackUsed = 0;
   ctx->evChunkIdx = ctx->evChunkFill = ctx->evPoolUsed = 0;  // (the previous sample's uploads were consumed: gx_sample_end synchronised)
   ctx->satDone = false;
   ctx->satDropped = 0;
@@ -292,34 +294,38 @@ hipEvent_t ready_event(gx_ctx* ctx) {
 // otherwise the events go through two pinned staging buffers (the caller's buffer is free on return, and the
 // host keeps parsing while a buffer is in flight).  Nothing here waits for a copy to arrive: every piece
 // carries an event that the main stream waits for before the kernel that reads it (build_pileup).
-int push_host(gx_ctx* ctx, const gx_event* events, size_t n, bool pinned) {
+// (`esz`: 16, gx_event, or 8, gx_event8: the chunks are filled in 16-byte units either way, so every piece starts on a 16-byte
+// boundary -- k_sort_a<.., PACKED> reads two packed events per load -- and a piece with an odd count leaves 8 bytes unused)
+int push_host(gx_ctx* ctx, const void* events_, size_t n, bool pinned, size_t esz) {
+  const char* events = static_cast<const char*>(events_);
+  const size_t per16 = sizeof(gx_event) / esz;   // events per 16-byte unit
   while (n) {
     if (ctx->evChunkIdx == ctx->evChunks.size()) ctx->evChunks.emplace_back();
     DevBuf& chunk = ctx->evChunks[ctx->evChunkIdx];
     HIPCHECK(chunk.ensure(EV_CHUNK * sizeof(gx_event)));
-    size_t take = std::min(n, EV_CHUNK - ctx->evChunkFill);
-    if (!pinned) take = std::min(take, EV_STAGE);
-    gx_event* dst = chunk.as<gx_event>() + ctx->evChunkFill;
-    const gx_event* src = events;
+    size_t take = std::min(n, (EV_CHUNK - ctx->evChunkFill) * per16);
+    if (!pinned) take = std::min(take, EV_STAGE * per16);
+    char* dst = chunk.as<char>() + ctx->evChunkFill * sizeof(gx_event);
+    const char* src = events;
     if (!pinned) {
       const int k = ctx->stageNext;
       ctx->stageNext ^= 1;
       HIPCHECK(ctx->stage[k].ensure(EV_STAGE * sizeof(gx_event)));
       if (!ctx->stageFree[k]) HIPCHECK(hipEventCreateWithFlags(&ctx->stageFree[k], hipEventDisableTiming));
       else HIPCHECK(hipEventSynchronize(ctx->stageFree[k]));  // its previous upload has left the buffer
-      memcpy(ctx->stage[k].p, events, take * sizeof(gx_event));
-      src = static_cast<const gx_event*>(ctx->stage[k].p);
-      HIPCHECK(hipMemcpyAsync(dst, src, take * sizeof(gx_event), hipMemcpyHostToDevice, ctx->side));
+      memcpy(ctx->stage[k].p, events, take * esz);
+      src = static_cast<const char*>(ctx->stage[k].p);
+      HIPCHECK(hipMemcpyAsync(dst, src, take * esz, hipMemcpyHostToDevice, ctx->side));
       HIPCHECK(hipEventRecord(ctx->stageFree[k], ctx->side));
     } else
-      HIPCHECK(hipMemcpyAsync(dst, src, take * sizeof(gx_event), hipMemcpyHostToDevice, ctx->side));
+      HIPCHECK(hipMemcpyAsync(dst, src, take * esz, hipMemcpyHostToDevice, ctx->side));
     hipEvent_t ev = ready_event(ctx);
     if (!ev) { ctx->err = "hipEventCreate failed"; return GX_ERR_DEVICE; }
     HIPCHECK(hipEventRecord(ev, ctx->side));
-    ctx->segs.push_back({dst, take, ev});
-    ctx->evChunkFill += take;
+    ctx->segs.push_back({reinterpret_cast<const gx_event*>(dst), take, ev, esz != sizeof(gx_event)});
+    ctx->evChunkFill += (take + per16 - 1) / per16;
     if (ctx->evChunkFill == EV_CHUNK) { ctx->evChunkIdx++; ctx->evChunkFill = 0; }
-    events += take;
+    events += take * esz;
     n -= take;
   }
   return GX_OK;
@@ -331,14 +337,39 @@ int gx_push_events(gx_ctx* ctx, const gx_event* events, size_t n) {
   if (!ctx || (ctx->phase != 1 && ctx->phase != 3)) return GX_ERR_ORDER;
   if (!n) return GX_OK;
   HIPCHECK(hipSetDevice(ctx->device));
-  return push_host(ctx, events, n, false);
+  return push_host(ctx, events, n, false, sizeof(gx_event));
 }
 
 int gx_push_events_pinned(gx_ctx* ctx, const gx_event* events, size_t n) {
   if (!ctx || (ctx->phase != 1 && ctx->phase != 3)) return GX_ERR_ORDER;
   if (!n) return GX_OK;
   HIPCHECK(hipSetDevice(ctx->device));
-  return push_host(ctx, events, n, true);
+  return push_host(ctx, events, n, true, sizeof(gx_event));
+}
+
+int gx_push_events_packed(gx_ctx* ctx, const gx_event8* events, size_t n, int where) {
+  if (!ctx || (ctx->phase != 1 && ctx->phase != 3) || where < 0 || where > 2) return GX_ERR_ORDER;
+  if (!n) return GX_OK;
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (where == GX_EVENTS_DEVICE) {
+    // (used in place; k_sort_a reads two records per 16-byte load: a buffer that does not start on a 16-byte boundary, or an odd
+    // count at its end, goes through the 16-byte form instead -- unpack_segs)
+    ctx->segs.push_back({reinterpret_cast<const gx_event*>(events), n, nullptr, true});
+    return GX_OK;
+  }
+  return push_host(ctx, events, n, where == GX_EVENTS_PINNED, sizeof(gx_event8));
+}
+
+int gx_event8_pack(const gx_event* in, gx_event8* out) {
+  if (!in || !out) return 0;
+  const uint32_t len = in->end - in->start;
+  uint32_t cls = 8;
+  for (uint32_t k = 0; k < 8; k++)
+    if ((uint32_t)((0xA8654321u >> (4u * k)) & 15u) == in->count) cls = k;
+  if (in->end < in->start || len >= 0xFFFFu || cls == 8 || in->chrom >= (1u << 13)) return 0;
+  out->start = in->start;
+  out->lcc = len | (cls << 16) | (in->chrom << 19);
+  return 1;
 }
 
 long long gx_filter_saturation(const gx_event* events, size_t n, int n_chrom, const uint32_t* len, uint8_t* keep) {
@@ -432,6 +463,7 @@ int gx_window_net(gx_ctx* ctx, uint32_t chrom, uint32_t pos0, uint32_t n, long l
   if (!ctx || (ctx->phase != 1 && ctx->phase != 3) || !net || !n || n > (1u << 16) || chrom >= ctx->nChrom) return GX_ERR_ORDER;
   HIPCHECK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  if (int rc__ = unpack_segs(ctx, true)) return rc__;
   DevBuf dNet;
   HIPCHECK(dNet.ensure((size_t)n * 8));
   HIPCHECK(hipMemsetAsync(dNet.p, 0, (size_t)n * 8, s));
@@ -720,7 +752,7 @@ int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   if (!ctx || !flags) return GX_ERR_ORDER;
   *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->rangeBhUsed ? GX_PATH_RANGE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u) | (ctx->fusedUsed && ctx->fracPairsUsed ? GX_PATH_FRAC_PAIRS : 0u) |
-           (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u);
+           (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u) | (ctx->packedUsed ? GX_PATH_PACKED : 0u);
   return GX_OK;
 }
 

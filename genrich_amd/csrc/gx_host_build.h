@@ -84,6 +84,36 @@ template <typename Segs> static u32 class_chunks(const Segs& segs) {
   return best;
 }
 
+// Packed pieces (gx_event8) -> 16-byte events, in buffers of the library: for everything that reads gx_event records -- the general
+// chain's k_sort1, gx_window_net, the host's replay of the reference's int16 decisions -- and (`all` = false) for the pieces that
+// k_sort_a<.., PACKED> cannot read in place: a caller's device buffer that is not 16-byte aligned or ends on an odd count.
+int unpack_segs(gx_ctx* ctx, bool all) {
+  size_t total = 0;
+  auto wanted = [&](const gx_ctx::Seg& sg) {
+    return sg.packed && sg.n && (all || (reinterpret_cast<uintptr_t>(sg.p) & 15u) || (!sg.ready && (sg.n & 1u)));
+  };
+  for (auto& sg : ctx->segs)
+    if (wanted(sg)) total += sg.n;
+  if (!total) return GX_OK;
+  if (ctx->unpackUsed == ctx->unpackBufs.size()) ctx->unpackBufs.emplace_back();
+  DevBuf& buf = ctx->unpackBufs[ctx->unpackUsed++];
+  HIPCHECK(buf.ensure(total * sizeof(gx_event)));
+  hipStream_t s = ctx->stream;
+  gx_event* at = buf.as<gx_event>();
+  for (auto& sg : ctx->segs) {
+    if (!wanted(sg)) continue;
+    if (sg.ready) HIPCHECK(hipStreamWaitEvent(s, sg.ready, 0));  // (its upload, on the side stream)
+    hipLaunchKernelGGL(k_unpack_events, dim3((u32)std::min<size_t>((sg.n + 255) / 256, 8192)), dim3(256), 0, s,
+                       reinterpret_cast<const uint2*>(sg.p), sg.n, reinterpret_cast<uint4*>(at));
+    sg.p = at;
+    sg.ready = nullptr;   // (stream-ordered from here on)
+    sg.packed = false;
+    at += sg.n;
+  }
+  HIPCHECK(hipGetLastError());
+  return GX_OK;
+}
+
 // reuseSort: the sample was built a moment ago and only its tile stage has to be done again on the general chain
 // (k_sbtile sent it back): level 1 of the sort -- the pages, the cursors, the closed form of fragLen -- is still
 // there, so k_sort1 does not run again and only what the first tile stage and the scans wrote is cleared.
@@ -143,6 +173,10 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   const bool fracPairs = pairs && fracLikely;
   ctx->pairsUsed = pairs;
   ctx->fracPairsUsed = fracPairs;
+  ctx->packedUsed = false;
+  // (8-byte events: k_sort_a reads them in place; everything else -- and a piece it cannot read in place -- gets 16-byte copies)
+  if (!reuseSort)
+    if (int rc__ = unpack_segs(ctx, !pairs)) return rc__;
 
   // A sample so dense that the average bin holds more keys than k_sbtile's key array (ATAC cut sites of a deep library)
   // takes bins of half the size -- level 1 of the pair mode reaches 64 x 128 of them -- so that a bin is one round of
@@ -288,7 +322,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     if (seg.ready) HIPCHECK(hipStreamWaitEvent(s, seg.ready, 0));
     const u32 blocks = (u32)((seg.n + S1_CHUNK - 1) / S1_CHUNK);
     if (pairs) {
-      // two passes: coarse bins, then the fine ones (gx_sort.h)
+      // two passes: coarse bins, then the fine ones (gx_sort.h); a piece of 8-byte events by the instance that reads those
       u32 nWG1 = 0;
       for (auto& sg : segs) nWG1 += (u32)((sg.n + S2_CHUNK - 1) / S2_CHUNK);
       const u32 nCoarse = (std::max(1u, nL1) + (1u << s2_fine_shift(nL1)) - 1) >> s2_fine_shift(nL1);
@@ -297,12 +331,13 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       HIPCHECK(ctx->poolC.ensure((size_t)pagesC * PG_BYTES));
       HIPCHECK(ctx->auxC.ensure((size_t)pagesC << PgCfg<u32>::SHIFT));
       PagedStream PC{ctx->poolC.p, ctx->ptC.as<u32>(), ctx->curC.as<u32>(), ctx->curC.as<u32>() + nListsC, jmaxC, pagesC, nListsC};
-      if (fracPairs)
-        hipLaunchKernelGGL(k_sort_a<true>, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, sbS,
-                           nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
-      else
-        hipLaunchKernelGGL(k_sort_a<false>, dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, sbS,
-                           nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>());
+#define GX_LAUNCH_SORT_A(F, P)                                                                                                 \
+  hipLaunchKernelGGL((k_sort_a<F, P>), dim3(blocks), dim3(S2_NT), 0, s, seg.p, (u32)seg.n, ctx->dChrom.as<DChrom>(), nChrom, sbS, \
+                     nL1, nCoarse, PC, ctx->auxC.as<uint8_t>(), PG3[2], ctx->binNet.as<int>(), so1, ctx->dStatus.as<u32>())
+      if (fracPairs) { if (seg.packed) GX_LAUNCH_SORT_A(true, true); else GX_LAUNCH_SORT_A(true, false); }
+      else { if (seg.packed) GX_LAUNCH_SORT_A(false, true); else GX_LAUNCH_SORT_A(false, false); }
+#undef GX_LAUNCH_SORT_A
+      ctx->packedUsed |= seg.packed;
       pcLast = PC;
       ncLast = nCoarse;
       gridB = NXCD * (perClass + nCoarse);   // (a class's lists hold at most its chunks' + one partly filled page each)
@@ -665,6 +700,7 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
 // drop the ones saveInterval would drop (gx_saturate.h) and stage what is left for a second build.
 int drop_saturated(gx_ctx* ctx, int isCtrl) {
   hipStream_t s = ctx->stream;
+  if (int rc__ = unpack_segs(ctx, true)) return rc__;   // (the replay reads gx_event records)
   size_t total = 0;
   for (auto& sg : ctx->segs) total += sg.n;
   std::vector<gx_event> all(total);

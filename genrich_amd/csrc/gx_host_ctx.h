@@ -230,7 +230,9 @@ struct gx_ctx {
   // The sample's events, in push order: device-resident segments of the caller (gx_push_events_device) and
   // pieces of the library's own device chunks, filled from host memory by asynchronous copies on `side`
   // (`ready` = the copy has arrived: the main stream waits for it before the kernel that reads the piece).
-  struct Seg { const gx_event* p; size_t n; hipEvent_t ready; };
+  struct Seg { const gx_event* p; size_t n; hipEvent_t ready; bool packed = false; };   // (packed: 8-byte gx_event8 records behind p)
+  std::vector<DevBuf> unpackBufs; // packed pieces as 16-byte events, for the paths that read those (unpack_segs); reused sample after sample
+  size_t unpackUsed = 0;
   std::vector<Seg> segs;
   std::vector<DevBuf> evChunks;   // device chunks of EV_CHUNK events, reused sample after sample
   size_t evChunkIdx = 0, evChunkFill = 0;
@@ -267,6 +269,7 @@ struct gx_ctx {
   u64 beginGenome = 0;
   bool fellBack = false;        // some sample was sent back from k_sbtile to the general chain
   bool ptGrew = false;          // some sample was built again with larger page tables (RETRY_PT)
+  bool packedUsed = false;      // the last build read a piece of 8-byte events in place (k_sort_a<.., PACKED>: gx_path_info)
   bool fragFused = false;       // the last build's tile kernel adds the general fragLen path's terms itself (TileIn::fragAcc)
   bool looseOk = false;         // the treatment sample's tile stage left valid sweep bits on the loose slots
   bool riskNearThr = false;     // a re-evaluated table entry lies next to the significance threshold

@@ -736,7 +736,23 @@ __device__ __forceinline__ void scatter64(const u32 (&rec)[S2_ITEMS], u32 (&ka)[
 // FRAC: fractional weights ride along -- [11:9] of a record is the weight class (count 1, 2, 3, 4, 5, 6, 8, 10 -> 0 .. 7),
 // the length keeps 9 bits (cut-site intervals and most fragments are shorter than 512 bases; the others are singles).
 // A context switches to it once a sample has shown a fractional weight (gx_api.hip: sawFrac).
-template <bool FRAC>
+// PACKED: the events come as 8-byte gx_event8 records (include/genrich_amd.h: start; length, count class, chromosome) -- half the
+// bytes of the step's largest stream.  A thread takes them two to a 16-byte load; everything behind the load sees the four
+// words of a gx_event.
+__device__ __forceinline__ uint4 unpack_event8(u32 start, u32 lcc) {
+  // (count of a class: 1, 2, 3, 4, 5, 6, 8, 10 -- a nibble per class)
+  return make_uint4(lcc >> 19, start, start + (lcc & 0xFFFFu), (0xA8654321u >> (4u * ((lcc >> 16) & 7u))) & 15u);
+}
+// gx_event8 -> gx_event (the paths that read events as 16-byte records: the general chain's k_sort1, gx_window_net, the replay of
+// the reference's int16 decisions on the host)
+__global__ __launch_bounds__(256) void k_unpack_events(const uint2* __restrict__ in, size_t n, uint4* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint2 e = in[i];
+    out[i] = unpack_event8(e.x, e.y);
+  }
+}
+
+template <bool FRAC, bool PACKED = false>
 __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* __restrict__ ev, u32 n, const DChrom* __restrict__ chroms,
                                                      u32 nChrom, int sbShift, u32 nBins, u32 nCoarse, PagedStream PC,
                                                      uint8_t* __restrict__ auxPool, PagedStream PF, int* __restrict__ binNet,
@@ -762,12 +778,27 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
   for (int k0 = 0; k0 < S2_ITEMS; k0 += S2_BATCH) {
     uint4 e[S2_BATCH];
     bool have[S2_BATCH];
+    if constexpr (PACKED) {
+      static_assert(S2_BATCH % 2 == 0, "two packed events per 16-byte load");
+      // (item k of a thread is event 2 ((k / 2) S2_NT + thread) + (k & 1) of the chunk; the array is padded to an even count)
+      const uint4* __restrict__ evp = reinterpret_cast<const uint4*>(reinterpret_cast<const uint2*>(ev) + begin);
+#pragma unroll
+      for (int q = 0; q < S2_BATCH; q += 2) {
+        const u32 lp = ((k0 + q) >> 1) * S2_NT + threadIdx.x;
+        have[q] = 2u * lp <= lastIn;
+        have[q + 1] = 2u * lp + 1u <= lastIn;
+        const uint4 two = evp[min(lp, lastIn >> 1)];
+        e[q] = unpack_event8(two.x, two.y);
+        e[q + 1] = unpack_event8(two.z, two.w);
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < S2_BATCH; q++) {
       // (a uniform base and a 32-bit offset within the chunk: no 64-bit address per load)
       const u32 li = (k0 + q) * S2_NT + threadIdx.x;
       have[q] = li <= lastIn;
       e[q] = evb[min(li, lastIn)];  // chrom, start, end, count
+    }
     }
     if (k0 == 0) {
       if (chromLds)
@@ -811,7 +842,12 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
       u32 l0 = 0, l1 = 0;
       bool h1 = false;
       if (mine) {
-        const uint4 e = reinterpret_cast<const uint4*>(ev)[begin + k * S2_NT + threadIdx.x];
+        uint4 e;
+        if constexpr (PACKED) {
+          const uint2 e8 = reinterpret_cast<const uint2*>(ev)[begin + 2u * ((u32)(k >> 1) * S2_NT + threadIdx.x) + (u32)(k & 1)];
+          e = unpack_event8(e8.x, e8.y);
+        } else
+          e = reinterpret_cast<const uint4*>(ev)[begin + k * S2_NT + threadIdx.x];
         const Endpoints p = convert_event<true>(e, chroms[min(e.x, nChrom - 1)], true, nChrom, out, bad, covered);
         mine = p.w != 0;  // (else: an event that only raised a status bit, or one without effect)
         if (mine) {

@@ -15,6 +15,24 @@ PEAK_DTYPE = np.dtype(
      ("auc", "<f4"), ("p", "<f4"), ("q", "<f4")]
 )
 GX_IV_FINAL = -1
+EVENT8_DTYPE = np.dtype([("start", "<u4"), ("lcc", "<u4")])   # gx_event8: lcc = [15:0] end - start, [18:16] count class, [31:19] chromosome
+_COUNT_CLASS = np.full(11, 8, dtype=np.uint32)
+_COUNT_CLASS[[1, 2, 3, 4, 5, 6, 8, 10]] = np.arange(8, dtype=np.uint32)
+
+
+def pack_events(ev):
+    """gx_event records -> (gx_event8 records of the ones that fit, the others as they are): include/genrich_amd.h, gx_event8_pack
+    (the same rule, vectorised)."""
+    ev = np.ascontiguousarray(ev)
+    ln = ev["end"].astype(np.int64) - ev["start"].astype(np.int64)
+    cnt = ev["count"]
+    cls = np.where(cnt <= 10, _COUNT_CLASS[np.minimum(cnt, 10)], 8)
+    fits = (ln >= 0) & (ln < 0xFFFF) & (cls < 8) & (ev["chrom"] < (1 << 13))
+    out = np.empty(int(fits.sum()), dtype=EVENT8_DTYPE)
+    sel = ev[fits]
+    out["start"] = sel["start"]
+    out["lcc"] = ln[fits].astype(np.uint32) | (cls[fits].astype(np.uint32) << 16) | (sel["chrom"].astype(np.uint32) << 19)
+    return out, ev[~fits]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.c_size_t, C.c_void_p)
 
@@ -56,6 +74,8 @@ _SIGS = {
     "gx_push_events": [C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_push_events_device": [C.c_void_p, C.c_void_p, C.c_size_t],
     "gx_push_events_pinned": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "gx_push_events_packed": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int],
+    "gx_event8_pack": [C.c_void_p, C.c_void_p],
     "gx_sample_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "gx_sample_no_control": [C.c_void_p, C.POINTER(C.c_float)],
     "gx_saturation_dropped": [C.c_void_p, C.POINTER(C.c_longlong)],
@@ -249,6 +269,15 @@ class Genrich:
     def push_events_device(self, dev_ptr: int, n: int):
         """Events already resident in HBM (e.g. a torch tensor's data_ptr())."""
         self._check(self.lib.gx_push_events_device(self.ctx, C.c_void_p(dev_ptr), n))
+
+    def push_events_packed(self, ev8, where=0, n=None):
+        """8-byte events (gx_event8: pack_events): a numpy array of EVENT8_DTYPE in host memory (where=0), or a raw pointer
+        with n -- pinned host memory (where=1) or device memory (where=2)."""
+        if isinstance(ev8, np.ndarray):
+            ev8 = np.ascontiguousarray(ev8, dtype=EVENT8_DTYPE)
+            self._check(self.lib.gx_push_events_packed(self.ctx, ev8.ctypes.data, len(ev8), 0))
+        else:
+            self._check(self.lib.gx_push_events_packed(self.ctx, C.c_void_p(int(ev8)), int(n), int(where)))
 
     def sample_end(self):
         frag, lam, fac = C.c_double(0), C.c_float(0), C.c_float(0)

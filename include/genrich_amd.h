@@ -126,6 +126,27 @@ int gx_push_events_pinned(gx_ctx* ctx, const gx_event* events, size_t n);
  * valid until gx_sample_end). */
 int gx_push_events_device(gx_ctx* ctx, const gx_event* d_events, size_t n);
 
+/* The same event in 8 bytes (round 6): what saveInterval receives (Genrich.c:2516-2519) is a start, a length that a read pair
+ * bounds, one of eight weights and a chromosome -- 16 bytes of gx_event are the step's largest stream (0.8 GB for 50 M
+ * fragments) and twice what PCIe has to carry.
+ *   start : as gx_event's
+ *   lcc   : [15:0] end - start (< 65535);  [18:16] count class 0..7 = count 1, 2, 3, 4, 5, 6, 8, 10;  [31:19] chromosome (< 8192)
+ * An event that does not fit (65,535 bases or more, an end before its start, a chromosome index of 8192 or more) travels as a
+ * gx_event through gx_push_events; the two calls may be mixed within a sample in any order (the pileup is a sum; only the
+ * replay of the reference's int16 decisions, gx_filter_saturation, looks at the order, and takes the pushes as they came).
+ * gx_event8_pack: 1 and *out when `in` fits, 0 otherwise (host helper, no context).
+ * where: GX_EVENTS_HOST (pageable memory, consumed before return), GX_EVENTS_PINNED (page-locked, untouched until
+ * gx_sample_end), GX_EVENTS_DEVICE (device memory, valid until gx_sample_end; a 16-byte aligned buffer is read in place). */
+typedef struct gx_event8 {
+  uint32_t start;
+  uint32_t lcc;
+} gx_event8;
+#define GX_EVENTS_HOST 0
+#define GX_EVENTS_PINNED 1
+#define GX_EVENTS_DEVICE 2
+int gx_event8_pack(const gx_event* in, gx_event8* out);
+int gx_push_events_packed(gx_ctx* ctx, const gx_event8* events, size_t n, int where);
+
 /* The reference's int16 saturation rule (Genrich.c:2558-2573): saveInterval drops an alignment
  * when the int16 part of diff[start] already holds INT16_MAX or that of diff[end] INT16_MIN, which
  * depends on the order of the alignments.  keep[i] = 0 for the events (in input order, as for
@@ -298,6 +319,7 @@ int gx_set_knob(gx_ctx* ctx, const char* name, const char* value);
 #define GX_PATH_RANGE_BH 64u /* bit 6: several ranks with a control / replicates, -q: the range-partitioned BH exchange */
 #define GX_PATH_DENSE_BH 32u /* bit 5: several ranks, no control, -q: the p-value histogram travelled as ONE dense all-reduce */
 #define GX_PATH_PILES_MADE 256u /* bit 8: pileup floats (Pileup.cov, printed by -f / -k only) were written since the last gx_reset */
+#define GX_PATH_PACKED 512u  /* bit 9: the last sample's level 1 read 8-byte events in place (k_sort_a<.., PACKED>: gx_push_events_packed) */
 #define GX_PATH_FRAC_PAIRS 128u /* bit 7: ... and the pair records carried a weight class (k_sort_a<FRAC> / k_sbtile<.., FRAC>: -s multimapping) */
 int gx_path_info(gx_ctx* ctx, unsigned* flags);
 

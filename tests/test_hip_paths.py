@@ -383,3 +383,118 @@ def test_a_pileup_that_does_not_return_to_zero_is_an_error(monkeypatch):
         h.close()
         for k in knobs:
             monkeypatch.delenv(k)
+
+
+# ---- 8-byte events (gx_event8, gx_push_events_packed): the same sample, half the bytes (saveInterval's arguments, Genrich.c:2516-2519) ----
+
+def _push_mixed(h, ev, lens, where_packed=0):
+    """The sample through gx_push_events_packed for every event that fits the 8-byte form and gx_push_events for the rest,
+    in pieces (odd counts among them)."""
+    from genrich_amd.lib import pack_events
+    h.set_chroms(lens)
+    h.sample_begin(0, None)
+    p8, rest = pack_events(ev)
+    cuts = [0, 1, 1 + 4097, len(p8) // 2 | 1, len(p8)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            h.push_events_packed(p8[a:b])
+    if len(rest):
+        h.push_events(rest)
+    out = h.sample_end()
+    h.sample_no_control()
+    h.pvalues()
+    h.find_peaks()
+    return out, len(p8), len(rest)
+
+
+def test_packed_events_give_the_sixteen_byte_paths_bits():
+    """Unit-weight fragments plus what does NOT fit eight bytes (a fragment of 70,000 bases, an interval that ends before it
+    starts): the packed pieces are read in place by k_sort_a<.., PACKED>, the others travel as gx_event -- oracle's bits."""
+    lens = [400_000, 123_457, 16_384]
+    ev = synth.make_fragments(lens, 90_000, 21, peak_every=20_000, tower_every=150_000)
+    extra = np.zeros(3, dtype=B.EVENT_DTYPE)
+    extra["chrom"], extra["start"], extra["end"], extra["count"] = [0, 0, 1], [1000, 250_000, 5000], [71_000, 249_990, 5100], [1, 1, 1]
+    ev = np.concatenate([ev, extra])
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    h = hip_backend(params)
+    (frag, _, _), n8, nrest = _push_mixed(h, ev, lens)
+    assert n8 > 80_000 and nrest == 2
+    flags = h.path_info()
+    assert flags & FUSED and flags & PAIRS and flags & 512 and flags & LOOSE, flags
+    assert frag == so[0][0]
+    assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
+    for c in range(len(lens)):
+        eo, co = o.get_intervals(-1, c)
+        eh, ch = h.get_intervals(-1, c)
+        assert np.array_equal(eo, eh)
+        for k in ("expt", "p"):
+            assert np.array_equal(co[k].view(np.uint32), ch[k].view(np.uint32)), (k, c)
+
+
+def test_packed_events_with_weight_classes_and_on_the_general_chain(monkeypatch):
+    """All eight counts in the 8-byte form (hinted: fractional pair records), and the same pieces through the general chain
+    (GX_NO_FUSED: k_sort1 reads 16-byte events, so the library unpacks them first)."""
+    lens = [300_000, 70_001]
+    ev = synth.add_multimap(synth.make_fragments(lens, 60_000, 31, peak_every=20_000, tower_every=150_000), lens, 0.3, 32)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    B.run_case(o, case)
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("GX_NO_FUSED", "1")
+        h = hip_backend(params)
+        h.expect_fractional(True)
+        _, n8, nrest = _push_mixed(h, ev, lens)
+        flags = h.path_info()
+        assert bool(flags & 512) == (not general) and bool(flags & FUSED) == (not general), flags
+        assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
+        for c in range(len(lens)):
+            eo, co = o.get_intervals(-1, c)
+            eh, ch = h.get_intervals(-1, c)
+            assert np.array_equal(eo, eh)
+            assert np.array_equal(co["p"].view(np.uint32), ch["p"].view(np.uint32))
+        h.close()
+
+
+def test_packed_events_in_device_memory_aligned_or_not():
+    """A caller's device buffer of 8-byte events: read in place when it starts on a 16-byte boundary and has an even count,
+    unpacked by the library first otherwise -- the same peaks either way."""
+    import ctypes as C
+    from genrich_amd.lib import pack_events
+    # (device memory from the HIP runtime the library itself runs on: a second runtime in the process -- torch's -- sees no GPU)
+    hip = C.CDLL("libamdhip64.so.7")   # (already mapped: the library links against it)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    lens = [400_000, 123_457]
+    ev = synth.make_fragments(lens, 80_001, 5, peak_every=20_000, tower_every=150_000)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    o = B.Oracle(params)
+    B.run_case(o, case)
+    p8, rest = pack_events(ev)
+    assert len(rest) == 0
+    for shift, drop in ((0, len(p8) & 1), (1, 0), (0, 1 - (len(p8) & 1))):   # aligned + even, misaligned, odd count
+        h = hip_backend(params)   # (first: the context brings the device up)
+        n = len(p8) - drop
+        buf = C.c_void_p()
+        assert hip.hipMalloc(C.byref(buf), 8 * (len(p8) + 2)) == 0
+        assert hip.hipMemcpy(buf.value + 8 * shift, p8.ctypes.data, 8 * n, 1) == 0   # hipMemcpyHostToDevice
+        h.set_chroms(lens)
+        h.sample_begin(0, None)
+        h.push_events_packed(buf.value + 8 * shift, where=2, n=n)
+        if drop:
+            h.push_events(ev[n:])
+        h.sample_end()
+        h.sample_no_control()
+        h.pvalues()
+        h.find_peaks()
+        in_place = shift == 0 and n % 2 == 0
+        assert bool(h.path_info() & 512) == in_place, (shift, n, h.path_info())
+        assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
+        h.close()
+        assert hip.hipFree(buf) == 0
