@@ -234,13 +234,6 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device, timed_path=Non
     return gate, cpu
 
 
-KERNEL_PHASE = {  # which library phase (gx_set_phase_filter) brackets a kernel
-    "k_sort1": "sort1", "k_sort1p": "sort1", "k_sort_a": "sort1", "k_sort_b": "sort1", "k_sbtile": "tile", "k_tile_fast": "tile", "k_tile": "tile", "k_bucket2p": "bucket",
-    "k_pack_pval": "pval", "k_pack_pairs": "pval", "k_pack_pairs_full": "pval", "k_merge2": "merge", "k_mergeN": "fisher", "k_mergeN_w": "fisher",
-    "k_pack_ep": "fisher", "k_bh_hist": "bh", "k_qlookup": "bh", "k_peak_both": "sweep",
-}
-
-
 def load_profile(config, frags, world, plain):
     """The rocprofv3 counters of THIS build for this config (tools/profile_round.sh + tools/make_counters_json.py):
     accepted only when the hash of the kernel sources matches and the workload is the profiled one."""
@@ -613,10 +606,11 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     # untimed steps afterwards.
     prof = load_profile(config, args.frags, world, plain)
     dom = prof.get("dominant", {}).get("kernel") if prof else None
-    # (its phase: from the profile's own marker trace -- roctx ranges, GX_ROCTX -- when it has one; the table otherwise)
-    dom_phase = (prof["kernels"].get(dom, {}).get("phase") if prof and dom else None) or KERNEL_PHASE.get(dom, "tile")
-    if dom not in KERNEL_PHASE and not (prof and prof["kernels"].get(dom, {}).get("phase")):
-        dom = None
+    # (the library phase that brackets it -- gx_set_phase_filter -- comes from the profile's own marker trace: the library's roctx
+    # ranges, GX_ROCTX; without a profile of this build the tile stage is what is timed)
+    dom_phase = prof["kernels"].get(dom, {}).get("phase") if prof and dom else None
+    if not dom_phase:
+        dom, dom_phase = None, "tile"
     gx.set_phase_filter(dom_phase)
     for _ in range(warmup):
         step()

@@ -703,7 +703,7 @@ int gx_selftest(gx_ctx* ctx, int what, const float* a, const float* b, float* ou
 // the same scalar routines compiled for the host (what 1: calcPval, 3: multPval's tail): what the library
 // evaluates risky values with, i.e. with this machine's libm; no context, no device
 int gx_selftest_host(int what, const float* a, const float* b, float* out, double* out_double, size_t n) {
-  if (!a || !b || !out || (what != 1 && what != 3)) return GX_ERR_ORDER;
+  if (!a || !b || !out || (what != 1 && what != 3 && what != 4)) return GX_ERR_ORDER;
   for (size_t i = 0; i < n; i++) {
     bool rk = false;
     double d = 0.0;
@@ -714,9 +714,12 @@ int gx_selftest_host(int what, const float* a, const float* b, float* out, doubl
         lnorm_params(b[i], &ml, &sl);
         d = pval_double(a[i], log((double)a[i]), ml, sl);
       }
-    } else {
+    } else if (what == 3) {
       out[i] = fisher_combine((double)a[i], (int)b[i], &rk);
       if ((int)b[i] > 2 && a[i] != 0.0f) d = fisher_double((double)a[i], (int)b[i]);
+    } else {   // (4: the closed form, host build -- NOT what the library's host side ever rounds: a check of the formula itself)
+      out[i] = fisher_fast((double)a[i], (int)b[i], &rk);
+      if ((int)b[i] > 2 && a[i] != 0.0f) d = fisher_fast_double((double)a[i], (int)b[i]);
     }
     if (out_double) out_double[i] = d;
   }

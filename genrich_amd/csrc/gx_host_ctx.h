@@ -289,7 +289,6 @@ struct gx_ctx {
   DevBuf pvLut, dRisk, dDeep;
   PinnedBuf riskHost;           // count + records of the risky p-values, as read back / as sent with the host's values
   bool pairTabsReady = false;   // the control's p-value tables were built when its sample was closed
-  DevBuf fisherCache;  // k_mergeN's device-wide table of (sum, df) -> p
   DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhDl, bhTmp, bhRecs;
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
@@ -526,7 +525,7 @@ float risk_host_value(const gx_ctx* ctx, const RiskRec& r, const RiskHostIn& in)
     case RK_FISHER: return fisher_combine(r.x, (int)r.c, &rk);
     case RK_SELF:
       if (r.b == 1) return calc_pval(in.a[r.a], in.b[r.a], &rk);
-      if (r.b == 3) return fisher_combine((double)in.a[r.a], (int)in.b[r.a], &rk);
+      if (r.b == 3 || r.b == 4) return fisher_combine((double)in.a[r.a], (int)in.b[r.a], &rk);
       return 0.0f;
     default: return 0.0f;
   }

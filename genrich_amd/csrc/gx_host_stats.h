@@ -252,10 +252,6 @@ int combine_replicates(gx_ctx* ctx) {
   const size_t lds = mergeN_lds_bytes((int)nr);
   HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
-  // the device-wide table of Fisher results: empty at the start of every run (within a run the same pairs recur
-  // across tiles; across runs it would be a cache of outputs)
-  HIPCHECK(ctx->fisherCache.ensure(((size_t)16 << MN_GLOBAL_LOG)));
-  HIPCHECK(hipMemsetAsync(ctx->fisherCache.p, 0, (size_t)16 << MN_GLOBAL_LOG, s));
   int mnBlocks = 0;
   if (nr <= MNW_MAXREP) {
     // one wavefront per tile (no workgroup barrier in the tile loop, twenty tiles in flight per CU)
@@ -265,12 +261,12 @@ int combine_replicates(gx_ctx* ctx) {
     const u32 want = (nTiles + MNW_NW - 1) / MNW_NW;
     hipLaunchKernelGGL(k_mergeN_w, dim3(std::max(1u, std::min(want, (u32)(std::max(1, mnBlocks) * ctx->numCU)))), dim3(MNW_NW * 64), ldsw, s, S,
                        ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
-                       ctx->dRisk.as<RiskBuf>(), ctx->fisherCache.as<uint4>());
+                       ctx->dRisk.as<RiskBuf>());
   } else {
   HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN, MG_NT, lds));
   hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(std::max(1, mnBlocks) * ctx->numCU))), dim3(MG_NT), lds, s, S,
                      ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
-                     ctx->dRisk.as<RiskBuf>(), ctx->fisherCache.as<uint4>());
+                     ctx->dRisk.as<RiskBuf>());
   }
   if (int rc__ = dbg_sync(ctx, "k_mergeN")) return rc__;
   const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;

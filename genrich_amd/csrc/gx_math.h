@@ -298,6 +298,59 @@ GX_HD inline double fisher_double(double sum, int df) {
   return -pgamma_upper_log((2.0 * sum / 0.434294481903251827651) / 2.0, df / 2.0) / 2.30258509299404568402;
 }
 
+// The same tail in closed form (round 6).  df = 2 k is even -- two per replicate -- and the chi-squared upper tail of an even df is a
+// finite sum: with y = x / 2 = sum * ln 10,
+//     Q(x; 2k) = e^-y  S_k(y),  S_k(y) = sum_{j<k} y^j / j!        so   -log10 Q = sum - log10 S_k(y).
+// Up to eight replicates (k <= 8: k_mergeN_w) S_k - 1 = y (1 + y/2 (1 + y/3 (...))) by Horner and ONE log1p; beyond, from the
+// largest term down, y^(k-1) / (k-1)! (1 + (k-1)/y + ...), the reference's own pd_lower_series (496-504) with the Poisson density
+// written out (no overflow).  Where sum and log10 S_k nearly cancel -- y far below k, Q next to 1 -- the lower tail
+// P = e^-y y^k / k! (1 + y/(k+1) + ...) is small and -log10 (1 - P) = -log1p(-P) / ln 10 keeps its digits: below FISHER_Y0[k]
+// (the y from which the cancellation costs less than a factor of 200; k - 1 beyond eight replicates).
+// No data-dependent series of pgamma, no branch per regime of bd0 / stirlerr -- which is what lets the merge kernels evaluate every
+// merged interval on the spot instead of probing a device-wide table of results (4 GB of 128-byte lines for 16-byte probes at
+// hg38 x 3 replicates).  It is NOT the reference's sequence of operations, so it is only ever rounded through round_checked:
+// against the reference's algorithm with the host's libm (fisher_double) the two doubles differ by at most 6.3e-14 = 0.017 x
+// RISK_B over 11 M sums in [1e-6, 1e38] x df 4 .. 64 (tests/test_abi.py repeats a sweep on the CPU, the GPU suite on the device),
+// and a value next to a float rounding boundary goes to the host, which evaluates fisher_double.
+GX_HD inline double fisher_fast_double(double sum, int df) {
+  const double FISHER_Y0[9] = {0, 0, 0.0102, 0.1857, 0.5772, 1.1132, 1.7419, 2.4190, 3.1646};
+  const double LN10 = 2.30258509299404568402;
+  const int k = df >> 1;
+  const double y = sum * LN10;
+  if (y >= (k <= 8 ? FISHER_Y0[k] : (double)(k - 1))) {
+    if (k <= 8) {
+      double S = 1.0;
+      for (int j = k - 1; j >= 2; j--) S = 1.0 + S * (y * (1.0 / (double)j));
+      return sum - log1p(y * S) / LN10;
+    }
+    const double iy = 1.0 / y;
+    double term = 1.0, T = 1.0, fact = 1.0;
+    for (int j = k - 1; j >= 1; j--) {
+      term *= (double)j * iy;
+      T += term;
+    }
+    for (int j = 2; j <= k - 1; j++) fact *= (double)j;
+    return sum - (double)(k - 1) * log10(y) + log10(fact) - log10(T);
+  }
+  double term = 1.0, s = 1.0, fact = 1.0, yk = 1.0;
+  for (int j = 1; j < 400; j++) {
+    term *= y / (double)(k + j);
+    s += term;
+    if (term < s * 1e-18) break;
+  }
+  for (int j = 2; j <= k; j++) fact *= (double)j;
+  for (int j = 0; j < k; j++) yk *= y;
+  const double P = exp(-y) * yk / fact * s;
+  return -log1p(-P) / LN10;
+}
+
+// multPval (567-583) through the closed form; df <= 64 (32 replicates)
+GX_HD inline float fisher_fast(double sum, int df, bool* risky) {
+  if (df == 0) return GX_SKIPF;
+  if (df == 2 || sum == 0.0) return (float)sum;
+  return pval_round(fisher_fast_double(sum, df), risky);
+}
+
 GX_HD inline float fisher_combine(double sum, int df, bool* risky) {
   if (df == 0) return GX_SKIPF;
   if (df == 2 || sum == 0.0) return (float)sum;

@@ -487,58 +487,28 @@ struct MergeNOut {   // loose slots: tile t writes at sum_r tileOff_r[t]
 //   1  the owner of a bitmap word lists its set bits (offL[rank]): no memory access in the bit loop;
 //   2  thread i takes merged interval i: its position in each replicate = intervals before its word
 //      (preR) + set bits below it; gathers the replicates' p, sums them in replicate order (multPval
-//      570-574); no-maths cases (df <= 2, sum 0) are written at once; the others look (sum, df) up in an
-//      LDS cache of earlier results -- p is a deterministic function of the pair -- and the misses are
-//      compacted into a list;
-//   3  the misses are evaluated densely (double-precision series: the expensive part, now only for pairs the
-//      workgroup has not met), written, and entered into the cache (one writer per entry, chosen by an
-//      LDS atomic, so an entry is never torn).  Risky roundings (gx_math.h) are not cached: they go on the
-//      host's list every time.
-// Behind the workgroup's 512 LDS entries sits a table of 2^20 in device memory, shared by all workgroups and
-// cleared for every run: a workgroup meets about every second pair for the first time, the GPU as a whole
-// hardly any.  An entry is one aligned 16-byte word {sum bits, p, df ^ mix}: written and read whole, checked
-// against the query (the mix also rejects a torn or foreign entry), and right whenever it checks out -- p is a
-// pure function of the pair -- so stale copies in another XCD's L2 cost a recomputation, never a wrong value.
+//      570-574) and combines them on the spot: the closed form of the even-df chi-squared tail (gx_math.h
+//      fisher_fast; round 6 -- rounds 2-5 kept an LDS cache of results, a device-wide table behind it and a list
+//      of misses for pgamma's series).  Risky roundings (gx_math.h) go on the host's list.
 // Tiles with more than MN_CAP merged intervals take several rounds.
 #ifndef GX_MN_CAP
 #define GX_MN_CAP 512
 #endif
-#ifndef GX_MN_CACHE_LOG
-#define GX_MN_CACHE_LOG 9
-#endif
 constexpr int MN_CAP = GX_MN_CAP;                 // merged intervals per round
-constexpr int MN_CACHE = 1 << GX_MN_CACHE_LOG;    // cache entries (16 B)
-struct MnEntry { u32 lo, hi; float p; u32 df; };
-constexpr u32 MN_GLOBAL_LOG = 20;  // entries of the device-wide table (16 B each)
-__device__ __forceinline__ u32 mn_mix(u32 lo, u32 hi, u32 pbits) {
-  u32 x = lo * 0x9E3779B1u ^ hi * 0x85EBCA6Bu ^ pbits * 0xC2B2AE35u;
-  return (x ^ (x >> 15)) & ~0xFFu;  // (the low byte stays free for df)
-}
 __host__ __device__ constexpr size_t mergeN_lds_bytes(int n) {
-  return (size_t)n * MG_WORDS * 4 + (size_t)n * MG_WORDS * 2 + MN_CAP * 2 /*offL*/ + MN_CAP * 8 /*missSum*/ +
-         MN_CAP * 2 /*missI*/ + MN_CAP /*missDf*/ + MN_CACHE * sizeof(MnEntry) + MN_CACHE * 4 /*owner*/ + 64;
+  return (size_t)n * MG_WORDS * 4 + (size_t)n * MG_WORDS * 2 + MN_CAP * 2 /*offL*/ + 64;
 }
 
 __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restrict__ tileChrom,
                                                   const DChrom* __restrict__ chroms, u32 nTiles,
-                                                  MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk,
-                                                  uint4* gcache /* 2^MN_GLOBAL_LOG entries, zeroed per run */) {
+                                                  MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk) {
   static_assert(MG_WPT == 1, "one bitmap word per thread");
   extern __shared__ __attribute__((aligned(16))) u32 dyn[];
   const int n = S.n;
-  // (8-byte items first)
-  double* missSum = reinterpret_cast<double*>(dyn);
-  MnEntry* cache = reinterpret_cast<MnEntry*>(missSum + MN_CAP);
-  u32* owner = reinterpret_cast<u32*>(cache + MN_CACHE);
-  u32* bm = owner + MN_CACHE;                                           // n bitmaps of MG_WORDS words
+  u32* bm = dyn;                                                        // n bitmaps of MG_WORDS words
   uint16_t* preR = reinterpret_cast<uint16_t*>(bm + n * MG_WORDS);      // [r][w]: intervals of r before word w
   uint16_t* offL = preR + n * MG_WORDS;                                 // offset of merged interval i of the round
-  uint16_t* missI = offL + MN_CAP;
-  uint8_t* missDf = reinterpret_cast<uint8_t*>(missI + MN_CAP);
   __shared__ u32 scratch[8];
-  __shared__ u32 nMiss;
-  for (int i = threadIdx.x; i < MN_CACHE * 5; i += MG_NT) reinterpret_cast<u32*>(cache)[i] = 0;  // cache + owner
-  if (threadIdx.x == 0) nMiss = 0;
   u32 bad = 0;
   for (u32 t = blockIdx.x; t < nTiles; t += gridDim.x) {  // persistent, round-robin
     __syncthreads();
@@ -597,69 +567,10 @@ __global__ __launch_bounds__(MG_NT) void k_mergeN(RepSet S, const u32* __restric
         if (df > 400) bad |= ST_BAD_DF;
         const u32 o = slot + r0 + i;
         out.end[o] = pos0 + off;
-        if (df <= 2 || sum == 0.0) {
-          out.p[o] = df == 0 ? GX_SKIPF : (float)sum;   // fisher_combine's cases without maths
-          continue;
-        }
-        const u32 lo = (u32)__double_as_longlong(sum), hi = (u32)(__double_as_longlong(sum) >> 32);
-        const u32 h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ ((u32)df << 20)) * 0x9E3779B1u) >> (32 - GX_MN_CACHE_LOG);
-        const MnEntry e = cache[h];
-        if (e.df == (u32)df && e.lo == lo && e.hi == hi) {
-          out.p[o] = e.p;
-          continue;
-        }
-#ifndef GX_EXP_MN   // measurement hook (tools/build_variant.sh -DGX_EXP_MN=n): 1 no device-wide table, 2 no Fisher evaluation, 3 both
-#define GX_EXP_MN 0
-#endif
-        if (!(GX_EXP_MN & 1)) {  // the device-wide table
-          const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ ((u32)df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
-          const uint4 g = gcache[hg];
-          if (g.x == lo && g.y == hi && g.w == (mn_mix(lo, hi, g.z) | (u32)df)) {
-            out.p[o] = __uint_as_float(g.z);
-            continue;
-          }
-        }
-        const u32 j = atomicAdd(&nMiss, 1u);
-        missI[j] = (uint16_t)i;
-        missDf[j] = (uint8_t)df;
-        missSum[j] = sum;
+        bool risky = false;
+        out.p[o] = fisher_fast(sum, df, &risky);
+        if (risky) risk_add(risk, RK_FISHER, t, r0 + i, (u32)df, sum);
       }
-      __syncthreads();
-      // ---- 3: the pairs not met before --------------------------------------------------------------------------
-      const u32 nM = nMiss;
-      for (u32 j0 = 0; j0 < nM; j0 += MG_NT) {  // (block-uniform trip count: barriers inside)
-        const u32 j = j0 + threadIdx.x;
-        bool enter = false;
-        u32 h = 0, lo = 0, hi = 0, df = 0;
-        float pv = 0.0f;
-        if (j < nM) {
-          const double sum = missSum[j];
-          df = missDf[j];
-          bool risky = false;
-          pv = (GX_EXP_MN & 2) ? (float)sum : pval_round(fisher_double(sum, (int)df), &risky);
-          const u32 i = missI[j];
-          out.p[slot + r0 + i] = pv;
-          if (risky) risk_add(risk, RK_FISHER, t, r0 + i, df, sum);
-          lo = (u32)__double_as_longlong(sum);
-          hi = (u32)(__double_as_longlong(sum) >> 32);
-          h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ (df << 20)) * 0x9E3779B1u) >> (32 - GX_MN_CACHE_LOG);
-          enter = !risky;
-          if (enter) {
-            atomicMax(&owner[h], j + 1);
-            if (!(GX_EXP_MN & 1)) {
-            const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ (df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
-            gcache[hg] = make_uint4(lo, hi, __float_as_uint(pv), mn_mix(lo, hi, __float_as_uint(pv)) | df);
-            }
-          }
-        }
-        __syncthreads();
-        if (enter && owner[h] == j + 1) {
-          cache[h] = MnEntry{lo, hi, pv, df};
-          owner[h] = 0;
-        }
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) nMiss = 0;
       __syncthreads();
     }
     if (lastTile && threadIdx.x == 0) {  // closing interval [.., len)
@@ -694,22 +605,11 @@ constexpr int MNW_NW = 4;          // wavefronts (tiles in flight) per workgroup
 #define GX_MNW_CAP 256
 #endif
 constexpr int MNW_CAP = GX_MNW_CAP;   // merged intervals per round
-#ifndef GX_MNW_CACHE_LOG
-#define GX_MNW_CACHE_LOG 8
-#endif
-constexpr int MNW_CACHE = 1 << GX_MNW_CACHE_LOG;   // LDS cache entries per WORKGROUP (shared by its wavefronts: entries are validated like the device-wide table's)
-#ifndef GX_MNW_GTHR
-#define GX_MNW_GTHR 1e30
-#endif
-constexpr double MNW_GTHR = GX_MNW_GTHR;  // sums from which the device-wide table is not consulted (such values hardly repeat)
 constexpr int MNW_MAXREP = 8;      // replicates this kernel takes (beyond: k_mergeN)
 __host__ __device__ constexpr size_t mergeNw_wave_words(int n) {  // LDS words of one wavefront
-  return (size_t)n * MG_WORDS + (size_t)n * MG_WORDS / 2 /*preR u16*/ + MNW_CAP / 2 /*offL u16*/ + MNW_CAP * 2 /*missSum*/ +
-         MNW_CAP / 2 /*missI u16*/ + MNW_CAP / 4 /*missDf u8*/;
+  return (size_t)n * MG_WORDS + (size_t)n * MG_WORDS / 2 /*preR u16*/ + MNW_CAP / 2 /*offL u16*/;
 }
-__host__ __device__ constexpr size_t mergeNw_lds_bytes(int n) {
-  return (size_t)MNW_CACHE * 16 + MNW_NW * ((mergeNw_wave_words(n) * 4 + 15) / 16 * 16);
-}
+__host__ __device__ constexpr size_t mergeNw_lds_bytes(int n) { return MNW_NW * ((mergeNw_wave_words(n) * 4 + 15) / 16 * 16); }
 
 __device__ __forceinline__ void mnw_sync() {  // (LDS operations of one wavefront execute in order: keep the compiler from reordering them)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -721,22 +621,13 @@ __device__ __forceinline__ void mnw_sync() {  // (LDS operations of one wavefron
 #define GX_MNW_WAVES 4
 #endif
 __global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S, const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
-                                                          u32 nTiles, MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk,
-                                                          uint4* gcache /* 2^MN_GLOBAL_LOG entries, zeroed per run */) {
+                                                          u32 nTiles, MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk) {
   static_assert(MG_WORDS == 128, "two bitmap words per lane");
   extern __shared__ __attribute__((aligned(16))) u32 dynw[];
   const int n = S.n, lane = lane_id(), wv = threadIdx.x >> 6;
-  MnEntry* cache = reinterpret_cast<MnEntry*>(dynw);  // the workgroup's
-  u32* base = dynw + MNW_CACHE * 4 + (size_t)wv * ((mergeNw_wave_words(n) * 4 + 15) / 16 * 4);
-  // (8-byte items first)
-  double* missSum = reinterpret_cast<double*>(base);
-  u32* bm = reinterpret_cast<u32*>(missSum + MNW_CAP);                  // n bitmaps of MG_WORDS words
+  u32* bm = dynw + (size_t)wv * ((mergeNw_wave_words(n) * 4 + 15) / 16 * 4);   // n bitmaps of MG_WORDS words
   uint16_t* preR = reinterpret_cast<uint16_t*>(bm + n * MG_WORDS);       // [r][w]: intervals of r before word w
   uint16_t* offL = preR + n * MG_WORDS;                                  // offset of merged interval i of the round
-  uint16_t* missI = offL + MNW_CAP;
-  uint8_t* missDf = reinterpret_cast<uint8_t*>(missI + MNW_CAP);
-  for (int i = threadIdx.x; i < MNW_CACHE * 4; i += MNW_NW * 64) reinterpret_cast<u32*>(cache)[i] = 0;
-  __syncthreads();
   u32 bad = 0;
   const u32 stride = gridDim.x * MNW_NW;
   for (u32 t = blockIdx.x * MNW_NW + wv; t < nTiles; t += stride) {
@@ -789,12 +680,10 @@ __global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S
           if (rank < (u32)MNW_CAP) offL[rank] = (uint16_t)(lane * 64 + 32 + __builtin_ctz(bits));
       }
       mnw_sync();
-      // ---- 2: gather, sum, classify; the misses compacted by ballot
+      // ---- 2: gather, sum, combine
       const u32 nC = min((u32)MNW_CAP, tU - r0);
-      u32 nM = 0;
       for (u32 i0 = 0; i0 < nC; i0 += 64) {
         const u32 i = i0 + lane;
-        bool miss = false;
         double sum = 0.0;
         int df = 0;
         if (i < nC) {
@@ -808,56 +697,11 @@ __global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S
           if (df > 400) bad |= ST_BAD_DF;
           const u32 o = slot + r0 + i;
           out.end[o] = pos0 + off;
-          if (df <= 2 || sum == 0.0) {
-            out.p[o] = df == 0 ? GX_SKIPF : (float)sum;   // fisher_combine's cases without maths
-          } else {
-            const u32 lo = (u32)__double_as_longlong(sum), hi = (u32)(__double_as_longlong(sum) >> 32);
-            const u32 h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ ((u32)df << 20)) * 0x9E3779B1u) >> (32 - GX_MNW_CACHE_LOG);
-            const uint4 e = *reinterpret_cast<const uint4*>(cache + h);
-            if (e.x == lo && e.y == hi && e.w == (mn_mix(lo, hi, e.z) | (u32)df)) {
-              out.p[o] = __uint_as_float(e.z);
-            } else if (sum < MNW_GTHR) {
-              const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ ((u32)df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
-              const uint4 g = gcache[hg];
-              if (g.x == lo && g.y == hi && g.w == (mn_mix(lo, hi, g.z) | (u32)df))
-                out.p[o] = __uint_as_float(g.z);
-              else
-                miss = true;
-            } else
-              miss = true;
-          }
-        }
-        const u64 mm = __ballot(miss);
-        if (mm) {  // wave-uniform
-          const u32 j = nM + __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32)mm, 0u));
-          if (miss) {
-            missI[j] = (uint16_t)i;
-            missDf[j] = (uint8_t)df;
-            missSum[j] = sum;
-          }
-          nM += (u32)__popcll(mm);
-        }
-      }
-      mnw_sync();
-      // ---- 3: the pairs not met before
-      for (u32 j = lane; j < nM; j += 64) {
-        const double sum = missSum[j];
-        const u32 df = missDf[j];
-        bool risky = false;
-        const float pv = pval_round(fisher_double(sum, (int)df), &risky);
-        const u32 i = missI[j];
-        out.p[slot + r0 + i] = pv;
-        if (risky)
-          risk_add(risk, RK_FISHER, t, r0 + i, df, sum);
-        else {
-          const u32 lo = (u32)__double_as_longlong(sum), hi = (u32)(__double_as_longlong(sum) >> 32);
-          const u32 h = ((hi ^ (lo >> 9) ^ (lo << 5) ^ (df << 20)) * 0x9E3779B1u) >> (32 - GX_MNW_CACHE_LOG);
-          const uint4 ent = make_uint4(lo, hi, __float_as_uint(pv), mn_mix(lo, hi, __float_as_uint(pv)) | df);
-          *reinterpret_cast<uint4*>(cache + h) = ent;  // (readers check the mix: a torn or foreign entry is a miss)
-          if (sum < MNW_GTHR) {
-            const u32 hg = ((hi ^ (lo >> 7) ^ (lo << 9) ^ (df << 24)) * 0x9E3779B1u) >> (32 - MN_GLOBAL_LOG);
-            gcache[hg] = ent;
-          }
+          // (round 6: every interval evaluated on the spot -- the closed form of the even-df tail, gx_math.h fisher_fast -- where
+          // rounds 3-5 probed an LDS cache and a device-wide table of results and evaluated the misses by pgamma's series)
+          bool risky = false;
+          out.p[o] = fisher_fast(sum, df, &risky);
+          if (risky) risk_add(risk, RK_FISHER, t, r0 + i, (u32)df, sum);
         }
       }
     }
@@ -917,6 +761,10 @@ __global__ __launch_bounds__(256) void k_selftest(int what, const float* __restr
       case 3:
         out[i] = fisher_combine((double)a[i], (int)b[i], &risky);
         if (dbl && (int)b[i] > 2 && a[i] != 0.0f) d = fisher_double((double)a[i], (int)b[i]);
+        break;
+      case 4:  // the closed form the merge kernels use; a risky rounding is the host's, by the reference's algorithm
+        out[i] = fisher_fast((double)a[i], (int)b[i], &risky);
+        if (dbl && (int)b[i] > 2 && a[i] != 0.0f) d = fisher_fast_double((double)a[i], (int)b[i]);
         break;
       default: out[i] = 0.0f;
     }

@@ -327,14 +327,16 @@ int gx_path_info(gx_ctx* ctx, unsigned* flags);
  * what 0: log10f as the host libm computes it (saveQval 221/226)   out = f(a)
  *      1: calcPval(expt = a, ctrl = b)          (Genrich.c:1628)
  *      2: getVal of the exact pileup whose int32 bits are in a (1/120 units, :1902)
- *      3: multPval's combination of sum = a over df = b (567-583) */
+ *      3: multPval's combination of sum = a over df = b (567-583), by the reference's own algorithm (pgamma's series)
+ *      4: the same by the closed form of the even-df tail that the merge kernels evaluate (gx_math.h fisher_fast); a value next
+ *         to a float rounding boundary is re-evaluated by 3's algorithm on the host, like everywhere */
 int gx_selftest(gx_ctx* ctx, int what, const float* a, const float* b, float* out, size_t n);
 /* The same, plus (what 1 and 3) the double each result was rounded from in out_double (may be NULL)
  * and the number of results that lay next to a float rounding boundary and were therefore
  * re-evaluated with the host's libm ("risky", gx_math.h) in *n_risky (may be NULL). */
 int gx_selftest2(gx_ctx* ctx, int what, const float* a, const float* b, float* out, double* out_double,
                  size_t n, size_t* n_risky);
-/* what 1 and 3 evaluated by the host build of the same routines (this machine's libm, as the
+/* what 1, 3 and 4 evaluated by the host build of the same routines (this machine's libm, as the
  * reference would call it); no context and no device needed. */
 int gx_selftest_host(int what, const float* a, const float* b, float* out, double* out_double, size_t n);
 

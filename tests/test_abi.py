@@ -81,3 +81,20 @@ def test_host_build_of_the_p_value_routines_equals_the_oracle():
     want = np.array([min(lib.gxo_pchisq(2.0 * float(s) / 0.434294481903251827651, int(d)), 3.4028234663852886e38) if s else 0.0
                      for s, d in zip(sums, dfs)], dtype=np.float32)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_closed_form_of_the_fisher_tail_agrees_with_the_reference_algorithm_on_the_host():
+    """gx_math.h fisher_fast_double (what the merge kernels evaluate) against fisher_double (multPval's pchisq through pgamma's
+    series, Genrich.c:528-583), both compiled for the host: the doubles within 2^-41 of each other over sums in [1e-6, 1e38] and
+    every even df up to 64 -- an eighth of the margin (RISK_B = 2^-38) inside which a value is not rounded on the device at all."""
+    import numpy as np
+    from genrich_amd.lib import selftest_host
+    rng = np.random.default_rng(5)
+    n = 300_000
+    sums = np.concatenate([(rng.random(n // 3) * 60), 10.0 ** (-6 + 8 * rng.random(n // 3)), 10.0 ** (rng.random(n // 3) * 38.0)]).astype(np.float32)
+    dfs = (2 * rng.integers(2, 33, n)).astype(np.float32)
+    _, fast = selftest_host(4, sums, dfs)
+    _, ref = selftest_host(3, sums, dfs)
+    ok = (ref > 1e-40) & (ref < 1e30)
+    rel = np.abs(fast[ok] - ref[ok]) / ref[ok]
+    assert ok.sum() > n // 2 and rel.max() < 2.0 ** -41, rel.max()

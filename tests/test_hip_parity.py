@@ -223,6 +223,28 @@ def test_device_fisher_vs_host():
     assert rel.max() < 2.0 ** -41
 
 
+def test_device_fisher_closed_form_rounds_to_the_reference_algorithms_floats():
+    """The merge kernels combine replicates through the closed form of the even-df chi-squared tail (gx_math.h fisher_fast),
+    not through the reference's pgamma series: every float must still be the one the reference's algorithm gives with the
+    host's libm (the values next to a rounding boundary are the host's), and the two doubles must stay far inside the margin
+    behind that rule (RISK_B = 2^-38; measured on the CPU: 0.012 x)."""
+    from genrich_amd.lib import selftest_host
+    h = hip_backend(B.make_params())
+    rng = np.random.default_rng(22)
+    n = 400_000
+    sums = np.concatenate([(rng.random(n // 4) * 60), 10.0 ** (-6 + 8 * rng.random(n // 4)), rng.random(n // 4) * 3.0,
+                           10.0 ** (rng.random(n // 4) * 38.0)]).astype(np.float32)
+    dfs = (2 * rng.integers(2, 33, n)).astype(np.float32)
+    got, dd, nrisky = h.selftest2(4, sums, dfs)
+    want, hd = selftest_host(3, sums, dfs)          # the reference's algorithm, this machine's libm
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ok = (hd > 1e-40) & (hd < 1e30)
+    rel = np.abs(dd[ok] - hd[ok]) / hd[ok]
+    print(f"risky: {nrisky} of {n}; max relative difference closed form (device) / pgamma series (host): {rel.max():.3g}")
+    assert 0 < nrisky < n // 1000
+    assert rel.max() < 2.0 ** -41
+
+
 def test_device_getval_all_residues():
     h = hip_backend(B.make_params())
     lib = B.Oracle.lib()

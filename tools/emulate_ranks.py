@@ -92,6 +92,8 @@ def context(owned, rp, rank, world):
     gx = Genrich(params())
     gx.set_chroms(lens)
     gx.set_owned(owned)
+    if cfg["multimap"]:
+        gx.expect_fractional(True)   # (as genrich-amd -s and bench.py: fractional pair records from the first sample on)
     if world > 1:
         gx.set_collectives(rank, world, rp.allreduce)
     return gx

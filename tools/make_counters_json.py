@@ -3,9 +3,16 @@
 under profiles/:  <tag>_config<C>_kernel_stats.txt, <tag>_config<C>_pmc.txt and <tag>_counters_config<C>.json (what bench.py's
 `roofline` object reads; it carries the hash of the kernel sources it was measured on).
 
-HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB = 1024 B): on gfx950 FETCH_SIZE tallies the 128-byte
-requests of coalesced streams at 64 B (MI355X_MICROARCH.md, HBM section; calibrated on k_convert's event
-read in round 1), WRITE_SIZE is 1:1.
+HBM bytes per launch, since round 6 from the L2's memory-side requests BY SIZE (passes rdsz / wrsz of profile_round.sh):
+read = 32 x TCC_EA0_RDREQ_32B + 64 x TCC_EA0_RDREQ_64B + 128 x TCC_EA0_RDREQ_128B (+ 64 x whatever TCC_EA0_RDREQ counts beyond
+the three), written = 64 x TCC_EA0_WRREQ_64B + 32 x (TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B).  Checked on a known stream: k_sort_a's
+0.800 GB of events come out as 6.27 M requests of 128 bytes = 0.803 GB.  The figure of rounds 1-5 -- 2 x FETCH_SIZE + WRITE_SIZE
+(KB = 1024 B; FETCH_SIZE tallies a 128-byte request at 64, MI355X_MICROARCH.md HBM section) -- is right for kernels that read
+128-byte requests only and doubles everything else (a kernel of random 32- / 64-byte probes); it is kept beside the new one as
+`hbm_bytes_fetch_x2_per_step`.  Either way requests that the Infinity Cache serves are counted (the counters sit on the L2's
+side of it): a kernel whose figure exceeds the ~6.3 TB/s the HBM delivers says so (`above_hbm_achievable`).
+Kernel -> phase: the library's roctx ranges (GX_ROCTX=1) in the trace pass; a kernel dispatch carries the stack id of the range
+it was launched in.
 """
 import glob
 import json
@@ -52,6 +59,28 @@ def kernel_times(db):
     return agg
 
 
+def kernel_phases(db):
+    """kernel (short name) -> the library phase it is launched in ("tile" of "gx:t.tile"), from the marker regions of the trace."""
+    c = sqlite3.connect(db)
+    t = tables(c)
+    try:
+        kd, ks, ev, rg = t("rocpd_kernel_dispatch"), t("rocpd_info_kernel_symbol"), t("rocpd_event"), t("rocpd_region")
+    except StopIteration:
+        return {}
+    stack = {}
+    for sid, ext in c.execute(f"select e.stack_id, e.extdata from {rg} r join {ev} e on r.event_id = e.id"):
+        msg = json.loads(ext or "{}").get("message", "")
+        if msg.startswith("gx:"):
+            name = msg[3:]
+            stack[sid] = name[2:] if len(name) > 2 and name[1] == "." else name
+    votes = {}
+    for name, sid in c.execute(f"select s.kernel_name, e.stack_id from {kd} d join {ks} s on d.kernel_id = s.id join {ev} e on d.event_id = e.id"):
+        if sid in stack:
+            v = votes.setdefault(short(name), {})
+            v[stack[sid]] = v.get(stack[sid], 0) + 1
+    return {k: max(v, key=v.get) for k, v in votes.items()}
+
+
 def pmc_means(db):
     c = sqlite3.connect(db)
     t = tables(c)
@@ -66,11 +95,12 @@ def pmc_means(db):
 
 def main():
     tag = sys.argv[1]
-    cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "2"   # (2, 3, 4, 5 or a name: 2E)
     src = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     from bench import source_hash
     steps = 5  # profile_round.sh: --warmup 1 --steps 2, and bench.py's two extra steps that time every phase
-    out = {"_how": __doc__.strip().split("\n\n")[1].replace("\n", " "), "tag": tag, "config": cfg, "source_hash": source_hash(),
+    out = {"_how": __doc__.strip().split("\n\n")[1].replace("\n", " "), "tag": tag, "config": int(cfg) if cfg.isdigit() else cfg,
+           "source_hash": source_hash(),
            "kernels": {}, "whole_step": {}}
     # kernel durations
     db = db_of(os.path.join(src, "trace"))
@@ -86,10 +116,20 @@ def main():
             k["us_per_step"] = k.get("us_per_step", 0.0) + sum(v) / 1e3 / steps
             k["launches_per_step"] = k.get("launches_per_step", 0.0) + len(v) / steps
         out["whole_step"]["kernel_ms_per_step"] = tot / 1e6 / steps
+        ph = kernel_phases(db)
+        for k, p in ph.items():
+            out["kernels"].setdefault(k, {})["phase"] = p
+        by_phase = {}
+        for k, v in out["kernels"].items():
+            by_phase.setdefault(v.get("phase", "(none)"), []).append((v.get("us_per_step", 0.0), k))
+        lines.append("")
+        lines.append("phase (roctx range of the library) : kernels launched in it, us per step")
+        for p, ks_ in sorted(by_phase.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
+            lines.append(f"  {p:10s} {sum(x[0] for x in ks_):9.1f}  " + ", ".join(f"{k} {u:.1f}" for u, k in sorted(ks_, reverse=True) if u >= 0.05))
         open(os.path.join(OUT, f"{tag}_config{cfg}_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
     # counters
     pm = {}
-    for p in ("fetch", "write", "sq1", "sq2"):
+    for p in ("fetch", "write", "rdsz", "wrsz", "sq1", "sq2"):
         db = db_of(os.path.join(src, p))
         if db:
             pm.update(pmc_means(db))
@@ -110,15 +150,40 @@ def main():
         if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
             k["fetch_kb_raw_per_step"] = k.get("fetch_kb_raw_per_step", 0) + f[0] * f[1] / steps
             k["write_kb_raw_per_step"] = k.get("write_kb_raw_per_step", 0) + w[0] * w[1] / steps
-            k["hbm_bytes_per_step"] = k.get("hbm_bytes_per_step", 0) + (2 * f[0] * f[1] + w[0] * w[1]) * 1024 / steps
+            k["hbm_bytes_fetch_x2_per_step"] = k.get("hbm_bytes_fetch_x2_per_step", 0) + (2 * f[0] * f[1] + w[0] * w[1]) * 1024 / steps
+        tot_of = lambda c: cs[c][0] * cs[c][1] / steps if c in cs else None  # noqa: E731
+        if tot_of("TCC_EA0_RDREQ_sum") is not None:
+            r, r32, r64, r128 = (tot_of(c) or 0.0 for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"))
+            k["read_requests_per_step"] = {"all": k.get("read_requests_per_step", {}).get("all", 0) + r,
+                                           "32B": k.get("read_requests_per_step", {}).get("32B", 0) + r32,
+                                           "64B": k.get("read_requests_per_step", {}).get("64B", 0) + r64,
+                                           "128B": k.get("read_requests_per_step", {}).get("128B", 0) + r128}
+            k["read_bytes_per_step"] = k.get("read_bytes_per_step", 0) + 32 * r32 + 64 * r64 + 128 * r128 + 64 * max(0.0, r - r32 - r64 - r128)
+        if tot_of("TCC_EA0_WRREQ_sum") is not None:
+            wq, w64 = tot_of("TCC_EA0_WRREQ_sum") or 0.0, tot_of("TCC_EA0_WRREQ_64B_sum") or 0.0
+            k["written_bytes_per_step"] = k.get("written_bytes_per_step", 0) + 64 * w64 + 32 * max(0.0, wq - w64)
         # SQ counters: totals per step over the template instances of one kernel
         for c in cs:
             if c.startswith("SQ_"):
                 k.setdefault("sq", {})
                 k["sq"][c] = k["sq"].get(c, 0.0) + cs[c][0] * cs[c][1] / steps
+    # a kernel's HBM bytes: by request size when those passes ran, the FETCH_SIZE x 2 figure otherwise
+    by_size = any("read_bytes_per_step" in v for v in out["kernels"].values())
+    for kn, v in out["kernels"].items():
+        if "read_bytes_per_step" in v or "written_bytes_per_step" in v:
+            v["hbm_bytes_per_step"] = v.get("read_bytes_per_step", 0.0) + v.get("written_bytes_per_step", 0.0)
+        elif "hbm_bytes_fetch_x2_per_step" in v:
+            v["hbm_bytes_per_step"] = v["hbm_bytes_fetch_x2_per_step"]
+        if v.get("hbm_bytes_per_step") and v.get("us_per_step"):
+            v["tbs"] = v["hbm_bytes_per_step"] / v["us_per_step"] / 1e6
+            if v["tbs"] > 6.3:
+                v["above_hbm_achievable"] = "more than the ~6.3 TB/s HBM delivers: part of these requests were served by the Infinity Cache"
     out["whole_step"]["fetch_kb_raw"] = fetch_tot / steps
     out["whole_step"]["write_kb_raw"] = write_tot / steps
-    out["whole_step"]["hbm_bytes_per_step"] = (2 * fetch_tot + write_tot) * 1024 / steps
+    out["whole_step"]["hbm_bytes_fetch_x2_per_step"] = (2 * fetch_tot + write_tot) * 1024 / steps
+    out["whole_step"]["hbm_bytes_per_step"] = (sum(v.get("hbm_bytes_per_step", 0.0) for v in out["kernels"].values()) if by_size
+                                               else (2 * fetch_tot + write_tot) * 1024 / steps)
+    out["whole_step"]["bytes_from"] = "requests by size (TCC_EA0_RDREQ_32B/64B/128B, TCC_EA0_WRREQ[_64B])" if by_size else "2 x FETCH_SIZE + WRITE_SIZE"
     # the dominant kernel = the one with the most time per step; its issue model from the SQ counters (quad-cycle
     # units, MI355X_MICROARCH.md)
     timed = {k: v for k, v in out["kernels"].items() if v.get("us_per_step") and k.startswith("k_")}
