@@ -794,10 +794,10 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
                 "intervals": int(iv0),
                 "events_per_step": int(ev_n),
                 # what the timed step wrote to HBM besides the loose (end, V) slots of the tile stage and the sweep's masks
-                # (pileup floats: gx_path_info bit 8, or k_pack_pairs with a control)
+                # (pileup floats: gx_path_info bit 8 -- made on request only)
                 "tables_written_in_step": ("none: the sweep walks the loose (end, V) slots, p = table p(V)" if loose else
                                            "tight (end, p[, q]) interval table"
-                                           + (" + pileup floats" if bool(path_flags & 256) or (bool(cfg["control"]) and not args.lean) else "")),
+                                           + (" + pileup floats" if path_flags & 256 else "")),
                 "source_hash": source_hash(),
             },
             "roofline": roof,

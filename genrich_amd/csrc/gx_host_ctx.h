@@ -122,7 +122,9 @@ struct PArray {  // p-value intervals of one replicate (or the Fisher combinatio
                               // this replicate alone, with -p, walks the loose slots as they are
   DevBuf chromLooseOff;       // [nChrom + 1] first loose slot of each chromosome
   size_t looseStride = 0;     // words between the sig / brk masks in swMask
-  bool pilesPending = false;  // no control: the pileup floats are wanted but not made yet (ensure_piles)
+  bool pilesPending = false;  // the pileup floats are wanted but not made yet (ensure_piles)
+  bool pairPending = false;   // ... with a control: to be made from the merge's loose arrays, the two samples' tile offsets and the
+                              // control's tables, which all last until the next sample begins (make_pair_piles)
   // ... and what they will be made from once the context has built another sample into its loose slots: this replicate's
   // exact pileups and tile descriptors, taken out of the context (no copy; the context takes other buffers: pooled)
   DevBuf keptV, keptMeta;

@@ -57,8 +57,10 @@ int materialize_rep(gx_ctx* ctx, int idx) {
 
 // The pileup floats of a no-control replicate (Pileup.cov of the reference: only -f / -k print them): made on
 // request from the exact pileups, while the sample's loose slots are still there.
+int make_pair_piles(gx_ctx* ctx, int idx);
 int ensure_piles(gx_ctx* ctx, int idx) {
   PArray& pa = ctx->reps[idx];
+  if (pa.pairPending) return make_pair_piles(ctx, idx);
   if (pa.loose)
     if (int rc = materialize_rep(ctx, idx)) return rc;
   if (!pa.pilesPending) return GX_OK;
@@ -95,6 +97,7 @@ int ensure_piles(gx_ctx* ctx, int idx) {
 // 0.36 ms and 0.8 GB per replicate at hg38 / 50 M fragments; 0.4 GB of a 288 GB device kept instead).
 int keep_loose_for_piles(gx_ctx* ctx, int idx) {
   PArray& pa = ctx->reps[idx];
+  if (pa.pairPending) return make_pair_piles(ctx, idx);   // (with a control: what the floats are made of does not outlive the sample)
   if (pa.loose)
     if (int rc = materialize_rep(ctx, idx)) return rc;
   if (!pa.pilesPending || pa.keptLoose) return GX_OK;
@@ -112,11 +115,8 @@ int merge_with_control(gx_ctx* ctx, PArray& pa) {
   const u32 nTiles = ctx->nTiles, nChrom = ctx->nChrom;
   const size_t cap = (size_t)ctx->expt.nIv + ctx->ctrl.nIv + 16;
   HIPCHECK(pooled(ctx, pa.end, cap * 4));
-  const bool keep = ctx->keepPiles;
-  if (keep) {
-    HIPCHECK(pooled(ctx, pa.expt, cap * 4));
-    HIPCHECK(pooled(ctx, pa.ctrl, cap * 4));
-  }
+  // (the pileup floats -- Pileup.cov of the reference, printed by -f / -k only -- are made when somebody asks: make_pair_piles;
+  // round 5 wrote them in every step, 0.9 GB at hg38 / 50 M + 50 M fragments)
   HIPCHECK(pooled(ctx, pa.p, cap * 4));
   HIPCHECK(pooled(ctx, pa.tileOff, (size_t)(nTiles + 2) * 4));
   HIPCHECK(pooled(ctx, pa.chromOff, (size_t)(nChrom + 2) * 4));
@@ -184,14 +184,12 @@ int merge_with_control(gx_ctx* ctx, PArray& pa) {
 hipLaunchKernelGGL((k_pack_pairs<K, M>), grid, dim3(256), 0, s, ppi, nTiles, ctx->pairCtab.as<CtrlEntry>(),           \
                    ctx->pairP2d.as<float>(), pa.end.as<u32>(), pa.expt.as<float>(), pa.ctrl.as<float>(),              \
                    pa.p.as<float>(), ctx->par.thr, sigM, skipM, ctx->fragList.as<u32>(), misc + M_TICKET)
-    if (keep) { if (msk) GX_LAUNCH_PACK_PAIRS(true, true); else GX_LAUNCH_PACK_PAIRS(true, false); }
-    else { if (msk) GX_LAUNCH_PACK_PAIRS(false, true); else GX_LAUNCH_PACK_PAIRS(false, false); }
+    if (msk) GX_LAUNCH_PACK_PAIRS(false, true); else GX_LAUNCH_PACK_PAIRS(false, false);
 #undef GX_LAUNCH_PACK_PAIRS
   }
   hipLaunchKernelGGL(k_pack_pairs_full, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(4 * ctx->numCU)))), dim3(256), 0, s,
                      ppi, ctx->fragList.as<u32>(), misc + M_TICKET, ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(),
-                     ctx->pairCtab.as<CtrlEntry>(), keep ? pa.expt.as<float>() : (float*)nullptr,
-                     keep ? pa.ctrl.as<float>() : (float*)nullptr, pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                     ctx->pairCtab.as<CtrlEntry>(), (float*)nullptr, (float*)nullptr, pa.p.as<float>(), ctx->par.thr, sigM, skipM,
                      ctx->dStatus.as<u32>(), ctx->dRisk.as<RiskBuf>());
   if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
   phase_end(ctx);
@@ -209,9 +207,40 @@ hipLaunchKernelGGL((k_pack_pairs<K, M>), grid, dim3(256), 0, s, ppi, nTiles, ctx
   if (rc) return rc;
   pa.n = ctx->mail->nMerged;
   ctx->maskN = pa.n;
-  pa.hasPiles = keep;
-  pa.pilesDropped = !keep;
+  pa.hasPiles = false;
+  pa.pilesPending = pa.pairPending = ctx->keepPiles;
+  pa.pilesDropped = !ctx->keepPiles;
   pa.ctrlIsConst = false;
+  return GX_OK;
+}
+
+// The pileup floats of a replicate WITH a control, on request: k_pack_pairs' look-ups once more, writing the two float arrays only
+// (and the listed tiles -- fractional or very deep pileups -- in full).  Everything it reads is the merge's: valid until the next
+// sample begins or the Fisher combination takes the loose slots (keep_loose_for_piles sees to it that this has run by then).
+int make_pair_piles(gx_ctx* ctx, int idx) {
+  PArray& pa = ctx->reps[idx];
+  hipStream_t s = ctx->stream;
+  const u32 nTiles = ctx->nTiles;
+  HIPCHECK(pooled(ctx, pa.expt, (size_t)pa.n * 4 + 64));
+  HIPCHECK(pooled(ctx, pa.ctrl, (size_t)pa.n * 4 + 64));
+  u32* misc = ctx->misc.as<u32>();
+  PackPairsIn ppi{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->expt.tileIvOff.as<u32>(),
+                  ctx->ctrl.tileIvOff.as<u32>(), pa.tileOff.as<u32>()};
+  HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
+  const dim3 grid(std::max(1u, std::min((nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+  hipLaunchKernelGGL((k_pack_pairs<true, false, true>), grid, dim3(256), 0, s, ppi, nTiles, ctx->pairCtab.as<CtrlEntry>(),
+                     ctx->pairP2d.as<float>(), (u32*)nullptr, pa.expt.as<float>(), pa.ctrl.as<float>(), (float*)nullptr, ctx->par.thr,
+                     (u64*)nullptr, (u64*)nullptr, ctx->fragList.as<u32>(), misc + M_TICKET);
+  hipLaunchKernelGGL(k_pack_pairs_full, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(4 * ctx->numCU)))), dim3(256), 0, s,
+                     ppi, ctx->fragList.as<u32>(), misc + M_TICKET, ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(),
+                     ctx->pairCtab.as<CtrlEntry>(), pa.expt.as<float>(), pa.ctrl.as<float>(), (float*)nullptr, ctx->par.thr,
+                     (u64*)nullptr, (u64*)nullptr, ctx->dStatus.as<u32>(), ctx->dRisk.as<RiskBuf>());
+  if (int rc__ = dbg_sync(ctx, "k_pack_pairs (pileup floats)")) return rc__;
+  HIPCHECK(hipGetLastError());
+  pa.hasPiles = true;
+  pa.pilesPending = pa.pairPending = false;
+  ctx->pilesMade = true;
   return GX_OK;
 }
 

@@ -339,7 +339,9 @@ __global__ __launch_bounds__(256) void k_pair_tab2d(const Scalars* __restrict__ 
 // holding any other pair of values is put on a list and redone by k_pack_pairs_full (whose
 // double-precision path would cost this kernel most of its occupancy).
 // (KEEP / MASKS are compile-time for the same reason as in k_pack_pval)
-template <bool KEEP, bool MASKS>
+// PONLY (round 6): the pileup floats alone, later, for somebody who asks (gx_get_intervals: -f / -k) -- the step itself writes
+// (end, p) and the masks; the merge's loose arrays, the tile offsets and the control's tables are still there then.
+template <bool KEEP, bool MASKS, bool PONLY = false>
 __global__ __launch_bounds__(256) void k_pack_pairs(PackPairsIn in, u32 nTiles, const CtrlEntry* __restrict__ ctab,
                                                     const float* __restrict__ p2d, u32* __restrict__ end,
                                                     float* __restrict__ expt, float* __restrict__ ctrl,
@@ -400,12 +402,12 @@ __global__ __launch_bounds__(256) void k_pack_pairs(PackPairsIn in, u32 nTiles, 
             } else
               miss = true;
           }
-          end[dst + i] = e[k];
+          if (!PONLY) end[dst + i] = e[k];
           if (KEEP) {  // (otherwise the pileup floats are not kept, gx_set_keep_pileups)
             expt[dst + i] = ef;
             ctrl[dst + i] = cf;
           }
-          p[dst + i] = pv;
+          if (!PONLY) p[dst + i] = pv;
         }
         if (MASKS) {  // the sweep's masks while p is at hand (pre-zeroed words; a redone tile ORs its own bits in)
           const u64 sg = __ballot(pv > thr), sk = __ballot(pv == GX_SKIPF);
@@ -447,12 +449,13 @@ __global__ __launch_bounds__(256) void k_pack_pairs_full(PackPairsIn in, const u
       float e, c;
       const int ev = in.looseE[src + i], cv = in.looseC[src + i];
       const float pv = pval_pair(ev, cv, &e, &c, factor, lambda, logE, ctab, &ng, &risky);
-      if (risky) risk_add(risk, RK_PAIR, dst + i, (u32)ev, (u32)cv, 0.0);
+      if (risky && p) risk_add(risk, RK_PAIR, dst + i, (u32)ev, (u32)cv, 0.0);
       neg |= ng;
       if (expt) {
         expt[dst + i] = e;
         ctrl[dst + i] = c;
       }
+      if (!p) continue;   // (the pileup floats alone: p, its risky roundings and the masks were the step's)
       p[dst + i] = pv;
       if (sigMask) {  // the light pass saw p = 0 for the pairs it skipped: only bits to add
         if (pv > thr) atomicOr((unsigned long long*)&sigMask[(dst + i) >> 6], 1ull << ((dst + i) & 63));

@@ -777,7 +777,7 @@ void findDups(State& S, DupReads& D, Counts& C) {
     if (!dev.keys.empty())
       check(S, gx_dups_first(S.devs.ctx[0], dev.keys.data(), dev.multi.data(), dev.keys.size(), dev.owner.data()), S.devs.ctx[0]);
     dev.nKeys += dev.keys.size();
-    if (!dev.keys.empty()) dev.nByTable[dev.keys[0].w[0] & 3u] += dev.keys.size();
+    for (const gx_dup_key& k : dev.keys) dev.nByTable[k.w[0] & 3u]++;   // (per key: a batch need not hold one table's keys)
     for (uint32_t w : dev.owner) dev.nContested += (w & DUP_CONTESTED) != 0;
   };
 
@@ -866,6 +866,8 @@ void findDups(State& S, DupReads& D, Counts& C) {
     // keyed on the UNORDERED pair of ends -- one record per combination with the two ends in a canonical order.  The
     // chromosomes share a word: genomes of more than 65,536 sequences keep the host's tables.
     const bool dcDev = dev.on && S.chrom.size() <= 65536;
+    if (dev.on && !dcDev && !D.dc.empty() && getenv("GENRICH_DUPS_REPORT"))
+      fprintf(stderr, "[dups] discordant sets: the host's tables (more than 65,536 sequences: two chromosome indices do not fit a key word)\n");
     std::vector<uint32_t> firstRec;
     auto canon = [&](const Aln& a, const Aln& b, uint32_t w[4]) {
       const uint32_t pa = end5(a), pb = end5(b);
