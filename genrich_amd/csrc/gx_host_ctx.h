@@ -125,6 +125,8 @@ struct PArray {  // p-value intervals of one replicate (or the Fisher combinatio
   bool pilesPending = false;  // the pileup floats are wanted but not made yet (ensure_piles)
   bool pairPending = false;   // ... with a control: to be made from the merge's loose arrays, the two samples' tile offsets and the
                               // control's tables, which all last until the next sample begins (make_pair_piles)
+  bool mergedP = false;       // ... by a merge that wrote p-values, not pileups, into its loose slots (k_merge2<.., true>): the
+                              // pileups' merge runs when the floats are asked for
   // ... and what they will be made from once the context has built another sample into its loose slots: this replicate's
   // exact pileups and tile descriptors, taken out of the context (no copy; the context takes other buffers: pooled)
   DevBuf keptV, keptMeta;
@@ -155,6 +157,10 @@ struct Knobs {
   int noPairs = 0;        // GX_NO_PAIRS: k_sort1's start / end keys for k_sbtile
   int noFracPairs = 0;    // GX_NO_FRAC_PAIRS: fractional weights take the general chain
   int noBedFused = 0;     // GX_NO_BED_FUSED: a run with -E regions takes the general chain (k_tile<BED>), as until round 5
+  int bhVariant = -1;     // GX_BH_VARIANT: the instance of k_bh_hist / k_qlookup (0: 256 threads, 2048-entry LDS tables -- rounds 2-5; 1: 1024 threads,
+                          // one workgroup per CU, 8192 / 16384 entries; 2: 512 threads, 4096 / 8192 entries); default: chosen by the run
+  int mergeWg = 0;        // GX_MERGE_WG: the control merge by k_merge2 (a workgroup per tile, rounds 2-5) instead of k_merge2w (a wavefront per tile)
+  int noMergeP = 0;       // GX_NO_MERGE_P: the control merge leaves both pileups in its loose slots and k_pack_pairs scores them, as until round 5
   int forceHalfBins = 0;  // GX_FORCE_HALF_BINS: the 128-key level 1 on a small input
   int noHalfBins = 0;     // GX_NO_HALF_BINS
   int fracHalfBins = 0;   // GX_FRAC_HALF_BINS: half-size bins also for a dense sample with fractional weights (measurements)
@@ -176,7 +182,7 @@ const KnobDef KNOBS[] = {
     {"GX_DEBUG", &Knobs::debug, nullptr}, {"GX_DEBUG_RETRY", &Knobs::debugRetry, nullptr}, {"GX_NO_SPIN", &Knobs::noSpin, nullptr},
     {"GX_FORCE_REC64", &Knobs::forceRec64, nullptr}, {"GX_FORCE_SLOWFRAG", &Knobs::forceSlowFrag, nullptr},
     {"GX_NO_FUSED", &Knobs::noFused, nullptr}, {"GX_NO_LOOSE", &Knobs::noLoose, nullptr}, {"GX_NO_PAIRS", &Knobs::noPairs, nullptr},
-    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
+    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
     {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
     {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
     {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
@@ -263,6 +269,7 @@ struct gx_ctx {
   int fusedBackoff[2] = {0, 0}; // treatment / control samples for which k_sbtile is not tried (after one that did not fit)
   bool looseSwept = false;      // the last gx_find_peaks swept the loose slots
   bool pilesMade = false;       // pileup floats were written since the last gx_reset (ensure_piles)
+  bool mergePUsed = false;      // the last control merge wrote p-values into its loose slots (k_merge2<.., true>)
   DevBuf lbSweep, lbSweep2;     // look-back granules of the sweep's one-pass compactions (generation-tagged)
   u32 sweepGen = 0;
   FragSelect closeSel{};        // the sample's k_frag_select arguments (k_close took them; finish_scalars may need them again)
@@ -281,7 +288,7 @@ struct gx_ctx {
   DevBuf lbIv;
   Stream str[3];  // S (start keys), E (end keys), F (fractional records)
   DevBuf tileCnt[3], tileOff[3];
-  DevBuf looseC, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, binNet, curC, ptC, poolC, auxC, nWide, wideList, heavyList;
+  DevBuf looseC, looseC2, pairLogE, pairCtab, pairP2d, fragSum, tileDeep, fragList, zeroArena, endAtLen, binNet, curC, ptC, poolC, auxC, nWide, wideList, heavyList;
   DevBuf tileMeta, tileWsum, tileCarry, lb, misc, dScal, dStatus, looseEnd, looseV, tileIvCount, tileLastEnd, tilePrevEnd;
   Pileup expt, ctrl;
   Scalars hScal{};  // host copy of the device scalars (refreshed from the mail block)
@@ -291,7 +298,7 @@ struct gx_ctx {
   DevBuf pvLut, dRisk, dDeep;
   PinnedBuf riskHost;           // count + records of the risky p-values, as read back / as sent with the host's values
   bool pairTabsReady = false;   // the control's p-value tables were built when its sample was closed
-  DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhRaw, bhDl, bhTmp, bhRecs;
+  DevBuf bhKeys, bhLens, bhOutKeys, bhOutSlot, bhSortKeys, bhSortSlot, bhQ, bhKQ, bhRaw, bhDl, bhTmp, bhRecs;
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
   long long satDropped = 0;     // ... which dropped this many of them (gx_saturation_dropped)

@@ -3,6 +3,9 @@
 // (a part of gx_api.hip's translation unit: the kernels are templates and inline functions of the headers it includes;
 // split by phase -- context / build / stats / sweep / collectives -- in round 5)
 #pragma once
+#ifndef GX_BH_DEFAULT_VARIANT
+#define GX_BH_DEFAULT_VARIANT 1
+#endif
 namespace {
 
 // Loose slots -> the tight interval table (end, p[, pileups]) of a replicate without control: savePval
@@ -107,6 +110,63 @@ int keep_loose_for_piles(gx_ctx* ctx, int idx) {
   return GX_OK;
 }
 
+// k_merge2 on the two samples where they lie (their loose slots, or -- with -E regions -- their tight arrays).  pv: the p-value of
+// every merged interval on the way (Merge2Out::pBits; the pileups only of the intervals the tables do not hold)
+int launch_merge2(gx_ctx* ctx, const Merge2Out& mo, bool pv) {
+  hipStream_t s = ctx->stream;
+  const u32 nTiles = ctx->nTiles;
+  const bool fromLoose = ctx->expt.inLoose && ctx->ctrl.inLoose;
+  if (!fromLoose && (ctx->expt.inLoose || ctx->ctrl.inLoose || !ctx->expt.packed || !ctx->ctrl.packed)) {
+    ctx->err = "control merge: the two samples are not in the same form";
+    return GX_ERR_ORDER;
+  }
+  // (pos0 / len / flags of a tile do not depend on the sample: the control build's descriptors serve)
+  const dim3 gridM(std::min(nTiles, (u32)(8 * ctx->numCU)));
+  const float* p2d = ctx->pairP2d.as<float>();
+  if (!ctx->knob.mergeWg) {
+    // one wavefront per tile (round 6): as many workgroups as the CUs hold, each wavefront striding over the tiles
+#define GX_MERGE2W(LOOSE_, PV_, A_, B_, META_)                                                                                        \
+  do {                                                                                                                                \
+    int nb = 0;                                                                                                                       \
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_merge2w<LOOSE_, PV_>, M2W_NW * 64, 0));                              \
+    const u32 want = (nTiles + M2W_NW - 1) / M2W_NW;                                                                                 \
+    hipLaunchKernelGGL((k_merge2w<LOOSE_, PV_>), dim3(std::max(1u, std::min(want, (u32)(std::max(1, std::min(nb, M2W_WGS)) * ctx->numCU)))), \
+                       dim3(M2W_NW * 64), 0, s, A_, B_, ctx->dScal.as<Scalars>(), META_, nTiles, mo, ctx->dStatus.as<u32>(), p2d);   \
+  } while (0)
+    if (fromLoose) {
+      RleIn A{ctx->expt.looseEnd.as<u32>(), ctx->expt.looseV.as<int>(), ctx->expt.tileIvOff.as<u32>(), ctx->expt.meta.as<TileMeta>()};
+      RleIn Bc{ctx->ctrl.looseEnd.as<u32>(), ctx->ctrl.looseV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), ctx->ctrl.meta.as<TileMeta>()};
+      if (pv) GX_MERGE2W(true, true, A, Bc, ctx->ctrl.meta.as<TileMeta>()); else GX_MERGE2W(true, false, A, Bc, ctx->ctrl.meta.as<TileMeta>());
+    } else {
+      RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>(), nullptr};
+      RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), nullptr};
+      if (pv) GX_MERGE2W(false, true, A, Bc, ctx->tileMeta.as<TileMeta>()); else GX_MERGE2W(false, false, A, Bc, ctx->tileMeta.as<TileMeta>());
+    }
+#undef GX_MERGE2W
+    return dbg_sync(ctx, "k_merge2w");
+  }
+  if (fromLoose) {
+    RleIn A{ctx->expt.looseEnd.as<u32>(), ctx->expt.looseV.as<int>(), ctx->expt.tileIvOff.as<u32>(), ctx->expt.meta.as<TileMeta>()};
+    RleIn Bc{ctx->ctrl.looseEnd.as<u32>(), ctx->ctrl.looseV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), ctx->ctrl.meta.as<TileMeta>()};
+    if (pv)
+      hipLaunchKernelGGL((k_merge2<true, true>), gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->ctrl.meta.as<TileMeta>(),
+                         nTiles, mo, ctx->dStatus.as<u32>(), p2d);
+    else
+      hipLaunchKernelGGL((k_merge2<true, false>), gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->ctrl.meta.as<TileMeta>(),
+                         nTiles, mo, ctx->dStatus.as<u32>(), p2d);
+  } else {
+    RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>(), nullptr};
+    RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), nullptr};
+    if (pv)
+      hipLaunchKernelGGL((k_merge2<false, true>), gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->tileMeta.as<TileMeta>(),
+                         nTiles, mo, ctx->dStatus.as<u32>(), p2d);
+    else
+      hipLaunchKernelGGL((k_merge2<false, false>), gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->tileMeta.as<TileMeta>(),
+                         nTiles, mo, ctx->dStatus.as<u32>(), p2d);
+  }
+  return dbg_sync(ctx, "k_merge2");
+}
+
 // treatment + control -> the p-value intervals of the replicate (savePval Genrich.c:1720-1794): tile-local union of the
 // two samples' breakpoints, p per interval from the control's tables, the sweep's masks on the way (p mode)
 int merge_with_control(gx_ctx* ctx, PArray& pa) {
@@ -127,26 +187,20 @@ int merge_with_control(gx_ctx* ctx, PArray& pa) {
   HIPCHECK(ctx->tileIvCount.ensure((size_t)(nTiles + 1) * 4));
   u32* misc = ctx->misc.as<u32>();
   phase_begin(ctx, "merge");
-  const bool fromLoose = ctx->expt.inLoose && ctx->ctrl.inLoose;
-  if (!fromLoose && (ctx->expt.inLoose || ctx->ctrl.inLoose || !ctx->expt.packed || !ctx->ctrl.packed)) {
-    ctx->err = "control merge: the two samples are not in the same form";
-    return GX_ERR_ORDER;
-  }
-  Merge2Out mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->tileIvCount.as<u32>()};
-  // (pos0 / len / flags of a tile do not depend on the sample: the control build's descriptors serve)
-  const dim3 gridM(std::min(nTiles, (u32)(8 * ctx->numCU)));
-  if (fromLoose) {
-    RleIn A{ctx->expt.looseEnd.as<u32>(), ctx->expt.looseV.as<int>(), ctx->expt.tileIvOff.as<u32>(), ctx->expt.meta.as<TileMeta>()};
-    RleIn Bc{ctx->ctrl.looseEnd.as<u32>(), ctx->ctrl.looseV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), ctx->ctrl.meta.as<TileMeta>()};
-    hipLaunchKernelGGL(k_merge2<true>, gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->ctrl.meta.as<TileMeta>(),
-                       nTiles, mo, ctx->dStatus.as<u32>());
-  } else {
-    RleIn A{ctx->expt.ivEnd.as<u32>(), ctx->expt.ivV.as<int>(), ctx->expt.tileIvOff.as<u32>(), nullptr};
-    RleIn Bc{ctx->ctrl.ivEnd.as<u32>(), ctx->ctrl.ivV.as<int>(), ctx->ctrl.tileIvOff.as<u32>(), nullptr};
-    hipLaunchKernelGGL(k_merge2<false>, gridM, dim3(MG_NT), 0, s, A, Bc, ctx->dScal.as<Scalars>(), ctx->tileMeta.as<TileMeta>(),
-                       nTiles, mo, ctx->dStatus.as<u32>());
-  }
-  if (int rc__ = dbg_sync(ctx, "k_merge2")) return rc__;
+  // Round 6: the merge looks every interval's p-value up while both pileups are in registers and leaves (end, p) in its loose
+  // slots -- 8 bytes instead of 12 --, the pileups only for the intervals the tables do not hold (their tiles on a list:
+  // k_pairs_missed), and what makes the result tight is a copy (k_pack_ep2).  Loose p = the bits in looseV; the listed
+  // intervals' pileups in looseC / looseC2.
+  const bool mergeP = !ctx->knob.noMergeP;
+  ctx->mergePUsed = mergeP;
+  HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
+  HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
+  if (mergeP) HIPCHECK(ctx->looseC2.ensure(cap * 4));
+  Merge2Out mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->tileIvCount.as<u32>(), nullptr, nullptr, nullptr};
+  if (mergeP)
+    mo = Merge2Out{ctx->looseEnd.as<u32>(), ctx->looseC.as<int>(), ctx->looseC2.as<int>(), ctx->tileIvCount.as<u32>(),
+                   ctx->looseV.as<u32>(), ctx->fragList.as<u32>(), misc + M_TICKET};
+  if (int rc__ = launch_merge2(ctx, mo, mergeP)) return rc__;
   const u32 tChunks = (nTiles + STL_CHUNK - 1) / STL_CHUNK;
   HIPCHECK(hipMemsetAsync(ctx->lb.p, 0, (size_t)(tChunks + 2) * 8, s));
   hipLaunchKernelGGL(k_scan_counts, dim3(std::min<u32>(tChunks, (u32)ctx->resSweep)), dim3(STL_NT), 0, s,
@@ -162,7 +216,7 @@ int merge_with_control(gx_ctx* ctx, PArray& pa) {
   // its sample was closed: finish_scalars)
   PackPairsIn ppi{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->expt.tileIvOff.as<u32>(),
                   ctx->ctrl.tileIvOff.as<u32>(), pa.tileOff.as<u32>()};
-  HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
+  if (mergeP) { ppi.looseE = ctx->looseC.as<int>(); ppi.looseC = ctx->looseC2.as<int>(); }   // (the listed intervals' pileups)
   // p-mode: the sweep's masks are filled on the way (the interval count is only bounded here, so the
   // masks are laid out for the bound and gx_find_peaks is told the stride)
   u64 *sigM = nullptr, *skipM = nullptr;
@@ -176,7 +230,19 @@ int merge_with_control(gx_ctx* ctx, PArray& pa) {
     ctx->maskIdx = (int)ctx->reps.size();
     ctx->maskStride = stride;
   }
-  HIPCHECK(hipMemsetAsync(misc + M_TICKET, 0, 4, s));
+  if (mergeP) {
+    hipLaunchKernelGGL(k_pairs_missed, dim3(std::max(1u, std::min((nTiles + 3) / 4, (u32)(4 * ctx->numCU)))), dim3(256), 0, s, ppi,
+                       ctx->tileIvCount.as<u32>(), ctx->fragList.as<u32>(), misc + M_TICKET, ctx->dScal.as<Scalars>(),
+                       ctx->pairLogE.as<double>(), ctx->pairCtab.as<CtrlEntry>(), ctx->looseV.as<u32>(), ctx->dStatus.as<u32>(),
+                       ctx->dRisk.as<RiskBuf>());
+    const dim3 grid(std::max(1u, std::min((nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
+    if (sigM)
+      hipLaunchKernelGGL((k_pack_ep2<true>), grid, dim3(256), 0, s, ppi, ctx->looseV.as<float>(), nTiles, pa.end.as<u32>(), pa.p.as<float>(),
+                         ctx->par.thr, sigM, skipM);
+    else
+      hipLaunchKernelGGL((k_pack_ep2<false>), grid, dim3(256), 0, s, ppi, ctx->looseV.as<float>(), nTiles, pa.end.as<u32>(), pa.p.as<float>(),
+                         ctx->par.thr, sigM, skipM);
+  } else {
   {
     const dim3 grid(std::max(1u, std::min((nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
     const bool msk = sigM != nullptr;
@@ -191,6 +257,7 @@ hipLaunchKernelGGL((k_pack_pairs<K, M>), grid, dim3(256), 0, s, ppi, nTiles, ctx
                      ppi, ctx->fragList.as<u32>(), misc + M_TICKET, ctx->dScal.as<Scalars>(), ctx->pairLogE.as<double>(),
                      ctx->pairCtab.as<CtrlEntry>(), (float*)nullptr, (float*)nullptr, pa.p.as<float>(), ctx->par.thr, sigM, skipM,
                      ctx->dStatus.as<u32>(), ctx->dRisk.as<RiskBuf>());
+  }
   if (int rc__ = dbg_sync(ctx, "k_pack_pairs")) return rc__;
   phase_end(ctx);
   HIPCHECK(hipGetLastError());
@@ -211,6 +278,7 @@ hipLaunchKernelGGL((k_pack_pairs<K, M>), grid, dim3(256), 0, s, ppi, nTiles, ctx
   pa.pilesPending = pa.pairPending = ctx->keepPiles;
   pa.pilesDropped = !ctx->keepPiles;
   pa.ctrlIsConst = false;
+  pa.mergedP = mergeP;
   return GX_OK;
 }
 
@@ -224,6 +292,13 @@ int make_pair_piles(gx_ctx* ctx, int idx) {
   HIPCHECK(pooled(ctx, pa.expt, (size_t)pa.n * 4 + 64));
   HIPCHECK(pooled(ctx, pa.ctrl, (size_t)pa.n * 4 + 64));
   u32* misc = ctx->misc.as<u32>();
+  if (pa.mergedP) {
+    // the step's merge left p-values in its loose slots: the pileups' merge now, for the floats (the two samples, the tile tables
+    // and the scalars are where the step left them until the next sample begins)
+    Merge2Out mo{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->tileIvCount.as<u32>(), nullptr, nullptr, nullptr};
+    if (int rc__ = launch_merge2(ctx, mo, false)) return rc__;
+    pa.mergedP = false;
+  }
   PackPairsIn ppi{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseC.as<int>(), ctx->expt.tileIvOff.as<u32>(),
                   ctx->ctrl.tileIvOff.as<u32>(), pa.tileOff.as<u32>()};
   HIPCHECK(ctx->fragList.ensure((size_t)(nTiles + 1) * 4));
@@ -345,6 +420,9 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
     HIPCHECK(ctx->bhKeys.ensure((size_t)c * 4));
     HIPCHECK(ctx->bhLens.ensure((size_t)c * 8));
     HIPCHECK(ctx->bhQ.ensure((size_t)c * 4));
+    const bool freshKQ = ctx->bhKQ.cap < (size_t)c * 8;   // ({key, q} side by side for k_qlookup: free slots hold ~0)
+    HIPCHECK(ctx->bhKQ.ensure((size_t)c * 8));
+    if (freshKQ || ctx->bhDirty) HIPCHECK(hipMemsetAsync(ctx->bhKQ.p, 0xFF, (size_t)c * 8, s));
     HIPCHECK(ctx->bhOutKeys.ensure((size_t)c * 4));
     HIPCHECK(ctx->bhOutSlot.ensure((size_t)c * 4));
     if (fresh || ctx->bhDirty) {  // normally the table comes back clean from the previous call (k_bh_clear)
@@ -366,14 +444,29 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
   };
   BhTable T{};
   u32 Dlocal = 0;
+  // the instance of k_bh_hist / k_qlookup (gx_stats.h): LDS tables that hold a stretch of the genome's distinct values
+  const int bhv = ctx->knob.bhVariant >= 0 ? ctx->knob.bhVariant : GX_BH_DEFAULT_VARIANT;
+  auto launch_hist = [&]() -> int {
+    const u32 want = std::max(1u, (n + 4095) / 4096);
+#define GX_BH_HIST(NT, LT, PR, GRID)                                                                                                  \
+  do {                                                                                                                                \
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bh_hist<NT, LT, PR>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                 (int)bh_hist_lds(LT)));                                                                              \
+    hipLaunchKernelGGL((k_bh_hist<NT, LT, PR>), dim3(std::min(want, (u32)(GRID))), dim3(NT), bh_hist_lds(LT), s, fa.end.as<u32>(),     \
+                       fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T, ctx->dStatus.as<u32>());                   \
+  } while (0)
+    if (bhv == 1) GX_BH_HIST(1024, 8192, 16, ctx->numCU);
+    else if (bhv == 2) GX_BH_HIST(512, 4096, 16, 3 * ctx->numCU);
+    else GX_BH_HIST(256, 2048, 8, 2048);
+#undef GX_BH_HIST
+    return GX_OK;
+  };
   for (;;) {
     if (int rc = bh_table(cap)) return rc;
     HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
     T = BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
                 misc + M_BHCOUNT};
-    hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
-                       fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
-                       ctx->dStatus.as<u32>());
+    if (int rc__ = launch_hist()) return rc__;
     if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
     if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;
     Dlocal = ctx->mail->nMerged;
@@ -419,9 +512,7 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
       // tables and take the general exchange
       hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
       HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
-      hipLaunchKernelGGL(k_bh_hist, dim3(std::max(1u, std::min((n + 4095) / 4096, 2048u))), dim3(256), 0, s,
-                         fa.end.as<u32>(), fa.p.as<float>(), fa.chromOff.as<u32>(), nChrom, misc + M_NIV, T,
-                         ctx->dStatus.as<u32>());
+      if (int rc__ = launch_hist()) return rc__;
       if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;
       Dlocal = ctx->mail->nMerged;
     }
@@ -473,11 +564,22 @@ if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     ctx->maskIdx = ctx->finalIdx;
     ctx->maskN = n;
     ctx->maskStride = stride;
-    hipLaunchKernelGGL(k_qlookup, dim3(std::max(1u, std::min((n + 4095) / 4096, 4096u))), dim3(256), 0, s, fa.p.as<float>(),
-                       misc + M_NIV, ctx->bhKeys.as<u32>(), ctx->bhQ.as<float>(), cap - 1, fa.q.as<float>(), ctx->par.thr,
-                       ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride, ctx->dStatus.as<u32>());
+    hipLaunchKernelGGL(k_kq_build, dim3(64), dim3(256), 0, s, T, ctx->bhQ.as<float>(), ctx->bhKQ.as<u64>());
+    const u32 want = std::max(1u, (n + 4095) / 4096);
+#define GX_QLOOKUP(NT, CL, GRID)                                                                                                      \
+  do {                                                                                                                                \
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qlookup<NT, CL>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                 (int)(8u << CL)));                                                                                   \
+    hipLaunchKernelGGL((k_qlookup<NT, CL>), dim3(std::min(want, (u32)(GRID))), dim3(NT), (size_t)(8u << CL), s, fa.p.as<float>(),     \
+                       misc + M_NIV, ctx->bhKQ.as<u64>(), cap - 1, fa.q.as<float>(), ctx->par.thr,                                  \
+                       ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride, ctx->dStatus.as<u32>());                              \
+  } while (0)
+    if (bhv == 1) GX_QLOOKUP(1024, 14, ctx->numCU);
+    else if (bhv == 2) GX_QLOOKUP(512, 13, 2 * ctx->numCU);
+    else GX_QLOOKUP(256, 11, 4096);
+#undef GX_QLOOKUP
   }
-  hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+  hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T, ctx->bhKQ.as<u64>());
   ctx->bhDirty = false;
 if (int rc__ = dbg_sync(ctx, "k_qlookup")) return rc__;
   phase_end(ctx);

@@ -35,7 +35,13 @@ struct Merge2Out {   // loose slots: tile t writes at A.tileOff[t] + B.tileOff[t
   int* exptV;        // treatment pileup (1/120 units, V_MARK inside -E regions)
   int* ctrlV;        // control pileup of the covering control interval
   u32* tileCount;    // [nTiles]
+  // PV (round 6): p of the interval, looked up while both pileups are in registers -- the two int arrays are then only written
+  // for the intervals the tables do not hold (p = MG_P_MISS: a fractional or very deep pileup), whose tiles go on a list
+  u32* pBits;
+  u32* missList;
+  u32* nMiss;
 };
+constexpr u32 MG_P_MISS = 0x7FC0DEADu;   // (a NaN no evaluation produces: "p still to be computed", k_pairs_missed)
 
 // (expt_val / ctrl_net: the two pileup floats of a p-interval, gx_math.h)
 
@@ -48,6 +54,7 @@ struct Merge2Out {   // loose slots: tile t writes at A.tileOff[t] + B.tileOff[t
 // tight copies (k_pack twice: 0.66 ms and 2.7 GB per step at config 3).  Not with -E regions: there the value of the
 // interval behind a tile's last breakpoint can be V_MARK, which no carry says.
 constexpr int MG_CAP = 1024;  // intervals per input and tile whose values are staged in LDS
+constexpr u32 PT_N = 256, PT_HOT = 64;   // the table of p-values of whole pileup pairs (k_pair_tab2d below) and its corner kept in LDS
 
 struct MergeHdr {
   u32 a0, a1c, a1, b0, b1c, b1, pos0, len, flags;  // flags: 1 active, 2 last tile of its chromosome
@@ -87,17 +94,56 @@ __device__ __forceinline__ MergeHdr merge_hdr(const RleIn& A, const RleIn& B, co
   return h;
 }
 
-template <bool LOOSE>
+// PV: the p-value of every merged interval on the way (k_pack_pairs' table look-ups, the corner of the table in LDS): the loose
+// intermediate is (end, p) -- 8 bytes per interval instead of 12 -- and what follows is a copy (k_pack_ep2) instead of k_pack_pairs.
+constexpr u32 MG_HOT = 32;   // the corner of the pair table kept in LDS by k_merge2<.., true> (4 KiB: eight workgroups per CU stay)
+template <bool LOOSE, bool PV = false>
 __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalars* __restrict__ sc,
                                                   const TileMeta* __restrict__ meta, u32 nTiles, Merge2Out out,
-                                                  u32* __restrict__ st) {
+                                                  u32* __restrict__ st, const float* __restrict__ p2d) {
   __shared__ u32 bmA[MG_WORDS], bmB[MG_WORDS], bmC[MG_WORDS];
   __shared__ u64 scratch64[8];
   __shared__ int sA[MG_CAP + 1], sC[MG_CAP + 1];
+  __shared__ float hotP[PV ? MG_HOT * MG_HOT : 1];
+  __shared__ u32 sMiss;
   static_assert(MG_WPT == 1, "one bitmap word per thread");
   const float factor = sc->factor, lambda = sc->lambda;
   u32 neg = 0;
   const u32 G = gridDim.x;
+  if (PV) {
+    for (u32 i = threadIdx.x; i < MG_HOT * MG_HOT; i += MG_NT) hotP[i] = p2d[(i / MG_HOT) * PT_N + (i % MG_HOT)];
+    if (threadIdx.x == 0) sMiss = 0;
+  }
+  // one merged interval: its two pileups, or (PV) its p-value -- whole pileups below PT_N on both sides come from the table (as in
+  // k_pack_pairs), a pair of V_MARKs is SKIP (inside a -E region), anything else is left to k_pairs_missed with its pileups
+  auto emitV = [&](u32 o, int va, int vc) {
+    if constexpr (PV) {
+      u32 bits = MG_P_MISS;
+      if (va == V_MARK || vc == V_MARK) {
+        if (va == V_MARK && vc == V_MARK) bits = __float_as_uint(GX_SKIPF);
+      } else {
+        const u32 ec = __umulhi((u32)va, 0x88888889u) >> 6, cc = __umulhi((u32)vc, 0x88888889u) >> 6;
+        if (va >= 0 && vc >= 0 && ec < PT_N && cc < PT_N && ec * GX_UNIT == (u32)va && cc * GX_UNIT == (u32)vc)
+        {
+          // (never `in LDS ? hotP[..] : p2d[..]`: one FLAT load of a selected pointer -- the corner is read in any case, at a
+          // clamped index, and the table behind a branch of its own)
+          // (... and the corner through an atomic load, which no pass folds into the other one)
+          bits = __hip_atomic_load(reinterpret_cast<const u32*>(&hotP[(ec & (MG_HOT - 1)) * MG_HOT + (cc & (MG_HOT - 1))]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (ec >= MG_HOT || cc >= MG_HOT) bits = __float_as_uint(p2d[ec * PT_N + cc]);
+        }
+      }
+      out.pBits[o] = bits;
+      if (bits == MG_P_MISS) {
+        out.exptV[o] = va;
+        out.ctrlV[o] = vc;
+        sMiss = 1;
+      }
+    } else {
+      out.exptV[o] = va;
+      out.ctrlV[o] = vc;
+    }
+  };
   bmA[threadIdx.x] = 0;
   bmB[threadIdx.x] = 0;
   bmC[threadIdx.x] = 0;
@@ -186,8 +232,7 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
           const int b = __ffs(bits) - 1;
           const u32 below = (1u << b) - 1;
           out.end[o] = pos0 + threadIdx.x * 32 + b;
-          out.exptV[o] = sA[exA + __popc(wA & below)];
-          out.ctrlV[o] = sC[exC + __popc(wC & below)];
+          emitV(o, sA[exA + __popc(wA & below)], sC[exC + __popc(wC & below)]);
           o++;
         }
       } else {
@@ -197,20 +242,216 @@ __global__ __launch_bounds__(MG_NT) void k_merge2(RleIn A, RleIn B, const Scalar
           out.end[o] = pos0 + threadIdx.x * 32 + b;
           const u32 ia = exA + __popc(wA & below), ic = exC + __popc(wC & below);
           const int va = A.v[a0 + ia], vc = B.v[b0 + ic];  // (in bounds: slack)
-          out.exptV[o] = tailElsewhere && ia == nA ? h.nvA : va;
-          out.ctrlV[o] = tailElsewhere && ic == nB ? h.nvB : vc;
+          emitV(o, tailElsewhere && ia == nA ? h.nvA : va, tailElsewhere && ic == nB ? h.nvB : vc);
           o++;
         }
       }
       if (lastTile && threadIdx.x == 0) {  // 1779-1788 at the chromosome end: both pileups close at len
         const u32 oc = slot + tU;
         out.end[oc] = h.len;
-        out.exptV[oc] = A.v[h.a1 - 1];
-        out.ctrlV[oc] = B.v[h.b1 - 1];
+        emitV(oc, A.v[h.a1 - 1], B.v[h.b1 - 1]);
       }
     }
     // (block_excl_scan ends with a barrier after the scratch reads; the staged values are read above)
     __syncthreads();
+    // (PV: a tile with an interval the tables do not hold goes on k_pairs_missed's list; the flag is cleared before this thread
+    // reaches the next tile's barrier, the others set it behind that barrier)
+    if (PV && threadIdx.x == 0 && sMiss) {
+      out.missList[atomicAdd(out.nMiss, 1u)] = t;
+      sMiss = 0;
+    }
+  }
+  if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// ---- the same merge, ONE WAVEFRONT per tile (round 6) ------------------------------------------------------------------------
+// k_merge2 is bound by the chain of its round trips (1.7 ms for 3.3 GB at hg38 / 50 M + 50 M fragments): a tile is a handful of
+// dependent loads, two LDS passes and two workgroup barriers for two wavefronts, eight tiles in flight per CU.  Here a wavefront
+// owns a tile -- every lane two words of each bitmap, the prefix counts by DPP scans, the phases ordered by the wavefront's own
+// program order (no barrier) --, five workgroups of four such wavefronts per CU, and the emission is DENSE: the set bits are
+// listed by rank in LDS (a lane lists the bits of its own words: LDS stores only), then lane i takes merged interval i -- its
+// position in each input = intervals before its word + set bits below it --, so that the stores are coalesced and (PV) the
+// p-value look-ups of 64 intervals run side by side instead of one behind the other in a word's bit loop.
+__device__ __forceinline__ void m2w_sync() {  // (LDS operations of one wavefront execute in order: keep the compiler from reordering them)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#ifndef GX_M2W_CAP
+#define GX_M2W_CAP 384
+#endif
+#ifndef GX_M2W_HOT
+#define GX_M2W_HOT 32
+#endif
+#ifndef GX_M2W_WGS
+#define GX_M2W_WGS 6
+#endif
+constexpr u32 M2W_HOT = GX_M2W_HOT;  // the corner of the pair table kept in LDS (a power of two)
+constexpr int M2W_WGS = GX_M2W_WGS;  // workgroups per CU at most (measured: 24 wavefronts per CU beat 20 and 28)
+constexpr int M2W_NW = 4;            // wavefronts (tiles in flight) per workgroup
+constexpr int M2W_CAP = GX_M2W_CAP;         // intervals per input and tile whose pileups are staged in LDS
+constexpr int M2W_ROUND = 256;       // merged intervals listed per round
+struct M2wLds {
+  u32 bmA[MG_WORDS], bmB[MG_WORDS], bmC[MG_WORDS];
+  u32 preA[MG_WORDS / 2], preC[MG_WORDS / 2];   // (u16 pairs: intervals of the input before each word)
+  uint16_t offL[M2W_ROUND];
+  int sA[M2W_CAP + 1], sC[M2W_CAP + 1];
+};
+
+template <bool LOOSE, bool PV>
+__global__ __launch_bounds__(M2W_NW * 64) void k_merge2w(RleIn A, RleIn B, const Scalars* __restrict__ sc,
+                                                         const TileMeta* __restrict__ meta, u32 nTiles, Merge2Out out,
+                                                         u32* __restrict__ st, const float* __restrict__ p2d) {
+  static_assert(MG_WORDS == 128, "two bitmap words per lane");
+  __shared__ M2wLds LW[M2W_NW];
+  __shared__ float hotP[PV ? M2W_HOT * M2W_HOT : 1];
+  const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: the tile's header by scalar loads)
+  M2wLds& L = LW[wv];
+  const float factor = sc->factor, lambda = sc->lambda;
+  u32 neg = 0;
+  if (PV) {
+    for (u32 i = threadIdx.x; i < M2W_HOT * M2W_HOT; i += M2W_NW * 64) hotP[i] = p2d[(i / M2W_HOT) * PT_N + (i % M2W_HOT)];
+    __syncthreads();
+  }
+  const uint16_t* preA16 = reinterpret_cast<const uint16_t*>(L.preA);
+  const uint16_t* preC16 = reinterpret_cast<const uint16_t*>(L.preC);
+  // this lane's two words of every bitmap start empty (and are cleared again by whoever read them)
+  *reinterpret_cast<uint2*>(L.bmA + 2 * lane) = make_uint2(0u, 0u);
+  *reinterpret_cast<uint2*>(L.bmB + 2 * lane) = make_uint2(0u, 0u);
+  *reinterpret_cast<uint2*>(L.bmC + 2 * lane) = make_uint2(0u, 0u);
+  const u32 stride = gridDim.x * M2W_NW;
+  // neighbouring tiles (neighbouring loose slots) on one XCD, as in k_merge2
+  u32 t = xcd_local_block(blockIdx.x, gridDim.x) * M2W_NW + wv;
+  MergeHdr h1{};
+  if (t < nTiles) h1 = merge_hdr<LOOSE>(A, B, meta, t, nTiles);
+  for (; t < nTiles; t += stride) {
+    const MergeHdr h = h1;
+    if (t + stride < nTiles) h1 = merge_hdr<LOOSE>(A, B, meta, t + stride, nTiles);   // (the next tile's header rides under this tile)
+    const bool active = h.flags & 1u, lastTile = h.flags & 2u;
+    const u32 a0 = h.a0, b0 = h.b0, pos0 = h.pos0;
+    const u32 nA = h.a1c - a0, nB = h.b1c - b0;
+    const bool staged = nA <= (u32)M2W_CAP && nB <= (u32)M2W_CAP;  // wave-uniform
+    const bool tailElsewhere = LOOSE && !lastTile;
+    auto nextB = [&](u32 j, int v) -> int {   // the control pileup BEHIND interval j (v: what lies in the next slot)
+      return LOOSE && b0 + j + 1 == h.b1 && !lastTile ? h.nvB : v;
+    };
+    // ---- 1: breakpoints -> bitmaps; the pileups staged by interval
+    for (u32 j0 = 0; j0 < max(nA, nB); j0 += 64) {
+      const u32 j = j0 + lane;
+      u32 eA = 0, eB = 0;
+      int vA = 0, vB = 0, vBn = 0;
+      const bool inA = j < nA, inB = j < nB;
+      if (inA) { eA = A.end[a0 + j]; vA = A.v[a0 + j]; }
+      if (inB) { eB = B.end[b0 + j]; vB = B.v[b0 + j]; vBn = B.v[b0 + j + 1]; }  // (in bounds: the slot arrays carry slack)
+      if (inA) {
+        const u32 off = eA - pos0;
+        atomicOr(&L.bmA[off >> 5], 1u << (off & 31));
+        if (staged) L.sA[j] = vA;
+      }
+      if (inB) {
+        const u32 off = eB - pos0;
+        bool ng1, ng2;
+        const float here = ctrl_net(vB, factor, lambda, &ng1);
+        const float next = ctrl_net(nextB(j, vBn), factor, lambda, &ng2);
+        neg |= ng1 | ng2;
+        atomicOr(&L.bmC[off >> 5], 1u << (off & 31));
+        if (here != next) atomicOr(&L.bmB[off >> 5], 1u << (off & 31));  // 2122: net != MAX(val, lambda)
+        if (staged) L.sC[j] = vB;
+      }
+    }
+    if (active && staged && lane == 0) {  // the intervals that cover what follows the tile's last breakpoint
+      L.sA[nA] = tailElsewhere ? h.nvA : A.v[h.a1c];
+      L.sC[nB] = tailElsewhere ? h.nvB : B.v[h.b1c];
+    }
+    m2w_sync();
+    // ---- 2: this lane's words, the inputs' intervals before them, the union's rank
+    const uint2 wA2 = *reinterpret_cast<const uint2*>(L.bmA + 2 * lane);
+    const uint2 wB2 = *reinterpret_cast<const uint2*>(L.bmB + 2 * lane);
+    const uint2 wC2 = *reinterpret_cast<const uint2*>(L.bmC + 2 * lane);
+    const u32 wU0 = wA2.x | wB2.x, wU1 = wA2.y | wB2.y;
+    {
+      const int cA0 = __popc(wA2.x), cA = cA0 + __popc(wA2.y), cC0 = __popc(wC2.x), cC = cC0 + __popc(wC2.y);
+      const int inc = dpp_scan_add(cA | (cC << 16));   // (both totals <= TILE: 13 bits each)
+      const u32 exA = (u32)(inc & 0xFFFF) - (u32)cA, exC = (u32)(inc >> 16) - (u32)cC;
+      L.preA[lane] = exA | ((exA + (u32)cA0) << 16);
+      L.preC[lane] = exC | ((exC + (u32)cC0) << 16);
+    }
+    const int cU = __popc(wU0) + __popc(wU1);
+    const int incU = dpp_scan_add(cU);
+    const u32 exU = (u32)(incU - cU), tU = (u32)__builtin_amdgcn_readlane(incU, 63);
+    if (lane == 0) out.tileCount[t] = active ? tU + (lastTile ? 1u : 0u) : 0u;
+    bool missAny = false;
+    // one merged interval: its two pileups, or (PV) its p-value (as k_merge2's emitV)
+    auto emitV = [&](u32 o, int va, int vc) {
+      if constexpr (PV) {
+        u32 bits = MG_P_MISS;
+        if (va == V_MARK || vc == V_MARK) {
+          if (va == V_MARK && vc == V_MARK) bits = __float_as_uint(GX_SKIPF);
+        } else {
+          const u32 ec = __umulhi((u32)va, 0x88888889u) >> 6, cc = __umulhi((u32)vc, 0x88888889u) >> 6;
+          if (va >= 0 && vc >= 0 && ec < PT_N && cc < PT_N && ec * GX_UNIT == (u32)va && cc * GX_UNIT == (u32)vc) {
+            bits = __hip_atomic_load(reinterpret_cast<const u32*>(&hotP[(ec & (M2W_HOT - 1)) * M2W_HOT + (cc & (M2W_HOT - 1))]), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ec >= M2W_HOT || cc >= M2W_HOT) bits = __float_as_uint(p2d[ec * PT_N + cc]);
+          }
+        }
+        out.pBits[o] = bits;
+        if (bits == MG_P_MISS) {
+          out.exptV[o] = va;
+          out.ctrlV[o] = vc;
+          missAny = true;
+        }
+      } else {
+        out.exptV[o] = va;
+        out.ctrlV[o] = vc;
+      }
+    };
+    if (active) {  // wave-uniform
+      for (u32 r0 = 0; r0 < tU; r0 += M2W_ROUND) {
+        if (r0) m2w_sync();   // (the previous round's list has been read)
+        // ---- 3: the merged intervals of this round, by rank (a lane lists the set bits of its own two words)
+        {
+          u32 rank = exU - r0;  // (unsigned: earlier rounds' ranks wrap far beyond the round)
+          for (u32 bits = wU0; bits; bits &= bits - 1, rank++)
+            if (rank < (u32)M2W_ROUND) L.offL[rank] = (uint16_t)(lane * 64 + __builtin_ctz(bits));
+          for (u32 bits = wU1; bits; bits &= bits - 1, rank++)
+            if (rank < (u32)M2W_ROUND) L.offL[rank] = (uint16_t)(lane * 64 + 32 + __builtin_ctz(bits));
+        }
+        m2w_sync();
+        // ---- 4: lane i takes merged interval i
+        const u32 nC = min((u32)M2W_ROUND, tU - r0);
+        for (u32 i0 = 0; i0 < nC; i0 += 64) {
+          const u32 i = i0 + lane;
+          if (i < nC) {
+            const u32 off = L.offL[i], ww = off >> 5, below = (1u << (off & 31)) - 1u;
+            const u32 ia = (u32)preA16[ww] + (u32)__popc(L.bmA[ww] & below), ic = (u32)preC16[ww] + (u32)__popc(L.bmC[ww] & below);
+            int va, vc;
+            if (staged) {
+              va = L.sA[ia];
+              vc = L.sC[ic];
+            } else {
+              const int ga = A.v[a0 + ia], gc = B.v[b0 + ic];  // (in bounds: slack)
+              va = tailElsewhere && ia == nA ? h.nvA : ga;
+              vc = tailElsewhere && ic == nB ? h.nvB : gc;
+            }
+            const u32 o = h.slot + r0 + i;
+            out.end[o] = pos0 + off;
+            emitV(o, va, vc);
+          }
+        }
+      }
+      if (lastTile && lane == 0) {  // 1779-1788 at the chromosome end: both pileups close at len
+        const u32 oc = h.slot + tU;
+        out.end[oc] = h.len;
+        emitV(oc, A.v[h.a1 - 1], B.v[h.b1 - 1]);
+      }
+    }
+    m2w_sync();   // (every lane is through with the bitmaps and the staged pileups)
+    *reinterpret_cast<uint2*>(L.bmA + 2 * lane) = make_uint2(0u, 0u);
+    *reinterpret_cast<uint2*>(L.bmB + 2 * lane) = make_uint2(0u, 0u);
+    *reinterpret_cast<uint2*>(L.bmC + 2 * lane) = make_uint2(0u, 0u);
+    m2w_sync();
+    if (PV && __ballot(missAny) && lane == 0) out.missList[atomicAdd(out.nMiss, 1u)] = t;
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
 }
@@ -320,7 +561,6 @@ struct PackPairsIn {
 // Whole pileups (no fractional part) below PT_N on both sides -- nearly every interval of an
 // ordinary run -- have their p-value in a PT_N x PT_N table built once per replicate by the same
 // routine; the corner PT_HOT x PT_HOT of it and the control's net values sit in LDS.
-constexpr u32 PT_N = 256, PT_HOT = 64;
 
 __global__ __launch_bounds__(256) void k_pair_tab2d(const Scalars* __restrict__ sc, const double* __restrict__ logE,
                                                     const CtrlEntry* __restrict__ ctab, float* __restrict__ p2d,
@@ -398,7 +638,9 @@ __global__ __launch_bounds__(256) void k_pack_pairs(PackPairsIn in, u32 nTiles, 
             if (ev[k] >= 0 && cv[k] >= 0 && ec < PT_N && cc < PT_N && ec * GX_UNIT == (u32)ev[k] && cc * GX_UNIT == (u32)cv[k]) {
               ef = (float)ec;
               cf = net[cc];
-              pv = (ec < PT_HOT && cc < PT_HOT) ? hot[ec * PT_HOT + cc] : p2d[ec * PT_N + cc];
+              // (the corner in any case, the table behind a branch of its own: `? hot[..] : p2d[..]` is ONE flat load of a selected pointer)
+              pv = hot[(ec & (PT_HOT - 1)) * PT_HOT + (cc & (PT_HOT - 1))];
+              if (ec >= PT_HOT || cc >= PT_HOT) pv = p2d[ec * PT_N + cc];
             } else
               miss = true;
           }
@@ -464,6 +706,92 @@ __global__ __launch_bounds__(256) void k_pack_pairs_full(PackPairsIn in, const u
     }
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// k_merge2<.., true>'s listed tiles: the intervals it marked (MG_P_MISS) evaluated in full from the pileups it left beside them
+// (fractional pileups, very deep ones) -- in the loose slots, before k_pack_ep2 moves them; one wavefront per tile.  A risky
+// rounding goes on the host's list under the interval's TIGHT index (tileOff is there: k_scan_counts has run).
+__global__ __launch_bounds__(256) void k_pairs_missed(PackPairsIn in, const u32* __restrict__ tileCount, const u32* __restrict__ missList,
+                                                      const u32* __restrict__ nMiss, const Scalars* __restrict__ sc,
+                                                      const double* __restrict__ logE, const CtrlEntry* __restrict__ ctab,
+                                                      u32* __restrict__ pBits, u32* __restrict__ st, RiskBuf* __restrict__ risk) {
+  const float factor = sc->factor, lambda = sc->lambda;
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const u32 nH = *nMiss;
+  u32 neg = 0;
+  for (u32 li = blockIdx.x * 4 + wv; li < nH; li += gridDim.x * 4) {
+    const u32 t = missList[li];
+    const u32 src = in.slotA[t] + in.slotB[t], dst = in.tileOff[t], n = tileCount[t];
+    for (u32 i = lane; i < n; i += 64) {
+      if (pBits[src + i] != MG_P_MISS) continue;
+      bool ng, risky = false;
+      float e, c;
+      const int ev = in.looseE[src + i], cv = in.looseC[src + i];
+      const float pv = pval_pair(ev, cv, &e, &c, factor, lambda, logE, ctab, &ng, &risky);
+      if (risky) risk_add(risk, RK_PAIR, dst + i, (u32)ev, (u32)cv, 0.0);
+      neg |= ng;
+      pBits[src + i] = __float_as_uint(pv);
+    }
+  }
+  if (neg) atomicOr(st, ST_NEG_PILE);
+}
+
+// loose (end, p) slots of k_merge2<.., true> -> the tight arrays, the sweep's masks on the way (p mode); one wavefront per tile
+template <bool MASKS>
+__global__ __launch_bounds__(256) void k_pack_ep2(PackPairsIn in, const float* __restrict__ looseP, u32 nTiles, u32* __restrict__ end,
+                                                  float* __restrict__ p, float thr, u64* __restrict__ sigMask, u64* __restrict__ skipMask) {
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const u32 stride = gridDim.x * 4;
+  u32 t = blockIdx.x * 4 + wv;
+  u32 src1 = 0, dst1 = 0, n1 = 0;
+  if (t < nTiles) {
+    src1 = in.slotA[t] + in.slotB[t];
+    dst1 = in.tileOff[t];
+    n1 = in.tileOff[t + 1] - dst1;
+  }
+  for (; t < nTiles; t += stride) {
+    const u32 src = src1, dst = dst1, n = n1;
+    if (t + stride < nTiles) {
+      src1 = in.slotA[t + stride] + in.slotB[t + stride];
+      dst1 = in.tileOff[t + stride];
+      n1 = in.tileOff[t + stride + 1] - dst1;
+    }
+    for (u32 b = 0; b < n; b += 256) {
+      u32 e[4];
+      float pv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 i = b + k * 64 + lane;
+        e[k] = 0; pv[k] = 0.0f;
+        if (i < n) {
+          e[k] = in.looseEnd[src + i];
+          pv[k] = looseP[src + i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 i = b + k * 64 + lane;
+        if (i < n) {
+          end[dst + i] = e[k];
+          p[dst + i] = pv[k];
+        }
+        if (MASKS) {  // (pre-zeroed words)
+          const u64 sg = __ballot(i < n && pv[k] > thr), sk = __ballot(i < n && pv[k] == GX_SKIPF);
+          if ((sg | sk) && lane == 0) {
+            const u32 pos = dst + b + k * 64, w = pos >> 6, sh = pos & 63;
+            if (sg) {
+              atomicOr((unsigned long long*)&sigMask[w], (unsigned long long)(sg << sh));
+              if (sh && (sg >> (64 - sh))) atomicOr((unsigned long long*)&sigMask[w + 1], (unsigned long long)(sg >> (64 - sh)));
+            }
+            if (sk) {
+              atomicOr((unsigned long long*)&skipMask[w], (unsigned long long)(sk << sh));
+              if (sh && (sk >> (64 - sh))) atomicOr((unsigned long long*)&skipMask[w + 1], (unsigned long long)(sk >> (64 - sh)));
+            }
+          }
+        }
+      }
+    }
+  }
 }
 
 // ---- Fisher combination over replicates ---------------------------------------------------------

@@ -645,6 +645,14 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   // fractional weight: the sample goes to the general chain) are read where they lie, once per pass
   const BinSrc<u64> srcF{reinterpret_cast<const u64*>(in.PF.pool), in.PF.pt, nSeg, in.PF.jmax, seg, L.pre[1]};
   const u32 nF = PAIRS && !ovfSlots ? L.pre[1][NXCD] : 0u;
+  // (round 6: a thread's first single is asked for HERE, with the records, and kept for both passes -- read in the histogram's
+  // and in the scatter's loop each was a global round trip of its own, with the whole CU waiting: one workgroup per CU)
+#ifndef GX_SBT_FREG
+#define GX_SBT_FREG 1
+#endif
+  u64 fReg = 0;
+  if (GX_SBT_FREG && PAIRS && (u32)tid < nF) fReg = srcF.at((u32)tid);
+  auto singleAt = [&](u32 i) -> u64 { return GX_SBT_FREG && i == (u32)tid ? fReg : srcF.at(i); };
   // (16-bit counts per tile: the bin's pairs and singles together stay below 2^16)
   if (PAIRS && tid == 0 && (nF > SBT_FCAP || L.pre[0][NXCD] + nF > 65535u)) L.overflow = 1;  // (read behind the histogram's barrier)
   if (GX_EXP_SBT == 1) {
@@ -713,7 +721,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     if (!ovfSlots) slotsFrom(K, [&](u32 r) { histPair(r); });
     if (nF <= SBT_FCAP)
       for (u32 i = tid; i < nF; i += SBT_NT) {
-        const u64 r = srcF.at(i);
+        const u64 r = singleAt(i);
         const int w = (int)(int8_t)(r & 0xFF);
         const bool ok = FRAC ? sbt_class_of(w < 0 ? -w : w) < 8u : (w == GX_UNIT || w == -GX_UNIT);
         if (ok) {
@@ -879,7 +887,9 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
       const uint4 tf = L.tinfo[b];
       const u32 sc = L.startC[b];
       const u32 fz = (u32)__builtin_amdgcn_readfirstlane((int)tf.z), n = fz >> 8;
-      if (BIG && (n > SBT_HEAVY || (BED && (fz & TM_BEDX)))) {  // wave-uniform: left to the whole workgroup
+      // (a tile inside a -E region stays with its wavefront however many keys it holds: sbt_tile sums them, nothing is emitted --
+      // sbt_heavy would see an inactive tile and leave its pileup in the closed form of fragLen)
+      if (BIG && !(BED && (fz & TM_BEDIN)) && (n > SBT_HEAVY || (BED && (fz & TM_BEDX)))) {  // wave-uniform: left to the whole workgroup
         if (lane == 0) L.heavy[atomicAdd(&L.nHeavy, 1u)] = (uint16_t)b;
         continue;
       }
@@ -931,7 +941,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
         }
       }
       for (u32 i = tid; i < nF; i += SBT_NT) {
-        const u64 r = srcF.at(i);
+        const u64 r = singleAt(i);
         const u32 off = (u32)(r >> 8) & (TILE - 1);
         keysL[atomicAdd(&L.cur[(u32)(r >> 32) - segTileBase], 1u)] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
       }
@@ -960,7 +970,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
           if (te - tileBeg < tileEnd - tileBeg) keysL[atomicAdd(&L.cur[te], 1u) - keyBase] = (uint16_t)((e & (TILE - 1)) | 0x8000u | pairCls(r));
         });
         for (u32 i = tid; i < nF; i += SBT_NT) {
-          const u64 r = srcF.at(i);
+          const u64 r = singleAt(i);
           const u32 tl = (u32)(r >> 32) - segTileBase, off = (u32)(r >> 8) & (TILE - 1);
           if (tl - tileBeg < tileEnd - tileBeg) keysL[atomicAdd(&L.cur[tl], 1u) - keyBase] = (uint16_t)(off | ((r & 0x80) ? 0x8000u : 0u) | fCls(r));
         }

@@ -805,10 +805,19 @@ __global__ __launch_bounds__(S2_NT, GX_S2A_WAVES) void k_sort_a(const gx_event* 
         for (u32 i = threadIdx.x; i < nChrom; i += S2_NT) lchrom[i] = chroms[i];
       __syncthreads();
     }
+    // (two loops, not `chromLds ? lchrom[ci] : chroms[ci]`: the compiler makes ONE load of a selected pointer out of that -- a
+    // FLAT load, through the texture path and waiting on both counters, for a record that lies in LDS: round 6, found in the ISA)
+    DChrom cq[S2_BATCH];
+    if (chromLds) {  // block-uniform
+#pragma unroll
+      for (int q = 0; q < S2_BATCH; q++) cq[q] = lchrom[min(e[q].x, nChrom - 1)];
+    } else {
+#pragma unroll
+      for (int q = 0; q < S2_BATCH; q++) cq[q] = chroms[min(e[q].x, nChrom - 1)];
+    }
 #pragma unroll
     for (int q = 0; q < S2_BATCH; q++) {
-      const u32 ci = min(e[q].x, nChrom - 1);
-      const DChrom c = chromLds ? lchrom[ci] : chroms[ci];
+      const DChrom c = cq[q];
       const u32 cnt = e[q].w;
       const bool cntOk = FRAC ? (cnt <= 10u && ((0x57Eu >> cnt) & 1u)) : cnt == 1u;
       const bool ok1 = have[q] && cntOk && e[q].x < nChrom;

@@ -303,8 +303,9 @@ __global__ __launch_bounds__(256) void k_piles_from_loose(PackIn in, u32 nTiles,
 // == does, 282).  Each workgroup first aggregates into an LDS table so the global table sees
 // one atomic per (workgroup, distinct value).
 constexpr u32 EMPTY_KEY = 0xFFFFFFFFu;  // a NaN pattern: never a p-value
-constexpr int BH_LT = 2048;             // LDS table entries
-constexpr int BH_LPROBE = 8;
+// (round 6: the table's size, its probes and the workgroup's size are the instance's -- a run whose p-values are Fisher
+// combinations holds several thousand distinct values in any stretch of the genome, and a 2048-entry table with 8 probes
+// sent most of them to the device-wide table: 4 GB of atomics' lines at hg38 x 3 replicates)
 
 __device__ __forceinline__ u32 bh_hash(u32 k) {
   k *= 2654435761u;
@@ -344,32 +345,47 @@ __device__ __forceinline__ void bh_global_add(const BhTable& T, u32 key, u64 len
 }
 
 // frees the claimed slots again (the table is handed back clean instead of being wiped per call)
-__global__ __launch_bounds__(256) void k_bh_clear(BhTable T) {
+__global__ __launch_bounds__(256) void k_bh_clear(BhTable T, u64* __restrict__ kq = nullptr) {
   const u32 n = *T.counter;
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const u32 h = T.outSlot[i];
     T.keys[h] = EMPTY_KEY;
     T.lens[h] = 0;
+    if (kq) kq[h] = ~0ull;
   }
 }
 
-__global__ __launch_bounds__(256) void k_bh_hist(const u32* __restrict__ end, const float* __restrict__ p,
-                                                 const u32* __restrict__ chromOff, u32 nChrom,
-                                                 const u32* __restrict__ nPtr, BhTable T, u32* __restrict__ st) {
-  __shared__ u32 lk[BH_LT];
-  __shared__ u64 ll[BH_LT];
-  for (int i = threadIdx.x; i < BH_LT; i += 256) { lk[i] = EMPTY_KEY; ll[i] = 0; }
+// {key, q} of every claimed slot side by side (round 6): k_qlookup's probe of a value that its LDS cache does not hold -- a tenth of
+// the intervals of Fisher-combined replicates, whose p-values are nearly all different around the peaks -- was two dependent 128-byte
+// fetches (the key, then q of the slot); one now.  Free slots hold ~0 (EMPTY_KEY in the low word).
+__global__ __launch_bounds__(256) void k_kq_build(BhTable T, const float* __restrict__ qOfSlot, u64* __restrict__ kq) {
+  const u32 n = *T.counter;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const u32 h = T.outSlot[i];
+    kq[h] = (u64)T.keys[h] | ((u64)__float_as_uint(qOfSlot[h]) << 32);
+  }
+}
+
+__host__ __device__ constexpr size_t bh_hist_lds(int lt) { return (size_t)lt * 12; }
+template <int NT, int BH_LT, int BH_LPROBE>
+__global__ __launch_bounds__(NT) void k_bh_hist(const u32* __restrict__ end, const float* __restrict__ p,
+                                                const u32* __restrict__ chromOff, u32 nChrom,
+                                                const u32* __restrict__ nPtr, BhTable T, u32* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bh_raw[];
+  u64* ll = reinterpret_cast<u64*>(bh_raw);
+  u32* lk = reinterpret_cast<u32*>(bh_raw + (size_t)BH_LT * 8);
+  for (int i = threadIdx.x; i < BH_LT; i += NT) { lk[i] = EMPTY_KEY; ll[i] = 0; }
   __syncthreads();
   const u32 n = *nPtr;
   const u32 per = (n + gridDim.x - 1) / gridDim.x;
   const u32 b0 = blockIdx.x * per, b1 = min(n, b0 + per);
   ChromCursor cur;
-  for (u32 i0 = b0 + threadIdx.x; i0 < b1; i0 += 4 * 256) {  // four intervals per thread in flight
+  for (u32 i0 = b0 + threadIdx.x; i0 < b1; i0 += 4 * NT) {  // four intervals per thread in flight
     float pv4[4];
     u32 e4[4], s4[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const u32 i = i0 + k * 256;
+      const u32 i = i0 + k * NT;
       pv4[k] = GX_SKIPF;
       e4[k] = 0;
       s4[k] = 0;
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(256) void k_bh_hist(const u32* __restrict__ end, co
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const u32 i = i0 + k * 256;
+      const u32 i = i0 + k * NT;
       const float pv = pv4[k];
       if (i < b1 && pv != GX_SKIPF) {  // 319
         cur.seek(chromOff, nChrom, i);
@@ -404,7 +420,7 @@ __global__ __launch_bounds__(256) void k_bh_hist(const u32* __restrict__ end, co
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < BH_LT; i += 256)
+  for (int i = threadIdx.x; i < BH_LT; i += NT)
     if (lk[i] != EMPTY_KEY) bh_global_add(T, lk[i], ll[i], st);
 }
 
@@ -782,17 +798,20 @@ __global__ __launch_bounds__(QT_NT) void k_qt_apply(const u32* __restrict__ slot
 // (a direct-mapped LDS cache of {p bits, q} sits in front of the table: the genome's common values -- the background
 // pileups -- are asked for millions of times, and a hit saves the two dependent gathers of the probe.  An entry is
 // one 8-byte LDS word, written and read whole; q is a function of p within a run.)
-constexpr int QL_CACHE_LOG = 11;
-__global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, const u32* __restrict__ nPtr,
-                                                 const u32* __restrict__ gKeys, const float* __restrict__ qOfSlot,
-                                                 u32 capMask, float* __restrict__ q, float thr, u64* __restrict__ sigMask,
-                                                 u64* __restrict__ skipMask, u32* __restrict__ st) {
-  __shared__ u64 lc[1 << QL_CACHE_LOG];  // [31:0] key, [63:32] q bits; key EMPTY_KEY: free
-  for (int i = threadIdx.x; i < (1 << QL_CACHE_LOG); i += 256) lc[i] = (u64)EMPTY_KEY;
+// (round 6: the cache's size and the workgroup's are the instance's, as for k_bh_hist -- 2048 entries thrash on Fisher-combined
+// p-values, and every miss is two dependent 128-byte fetches from the table)
+template <int NT, int QL_CACHE_LOG>
+__global__ __launch_bounds__(NT) void k_qlookup(const float* __restrict__ p, const u32* __restrict__ nPtr,
+                                                const u64* __restrict__ kq, u32 capMask, float* __restrict__ q, float thr, u64* __restrict__ sigMask,
+                                                u64* __restrict__ skipMask, u32* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ql_raw[];
+  u64* lc = reinterpret_cast<u64*>(ql_raw);  // [31:0] key, [63:32] q bits; key EMPTY_KEY: free
+  for (int i = threadIdx.x; i < (1 << QL_CACHE_LOG); i += NT) lc[i] = (u64)EMPTY_KEY;
   __syncthreads();
   const u32 n = *nPtr;
   const u32 nw = (n + 63) >> 6;
-  for (u32 w0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; w0 < nw; w0 += gridDim.x * 16) {
+  constexpr u32 NW = NT / 64;
+  for (u32 w0 = (blockIdx.x * NW + (threadIdx.x >> 6)) * 4; w0 < nw; w0 += gridDim.x * NW * 4) {
     float pv[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -817,11 +836,11 @@ __global__ __launch_bounds__(256) void k_qlookup(const float* __restrict__ p, co
             u32 h = hh & capMask;
             // (every p of this rank was inserted -- and if an exchange lost the table, the probe ends at a free slot
             // instead of circling: the run fails with the reference's "does not match p-value length", 377-382)
-            u32 gk;
-            while ((gk = gKeys[h]) != key && gk != EMPTY_KEY) h = (h + 1) & capMask;
-            if (gk == key) {
-              qv = qOfSlot[h];
-              lc[hl] = (u64)key | ((u64)__float_as_uint(qv) << 32);
+            u64 ge;
+            while ((u32)(ge = kq[h]) != key && (u32)ge != EMPTY_KEY) h = (h + 1) & capMask;
+            if ((u32)ge == key) {
+              qv = __uint_as_float((u32)(ge >> 32));
+              lc[hl] = ge;
             } else
               atomicOr(st, ST_BH_LEN);
           }

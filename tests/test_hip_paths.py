@@ -14,6 +14,7 @@ from test_hip_parity import assert_same_run, hip_backend
 pytestmark = pytest.mark.gpu
 
 FUSED, LOOSE, FELL_BACK, PT_GREW, PAIRS, FRAC_PAIRS, PILES_MADE = 1, 2, 4, 8, 16, 128, 256
+MERGE_P = 1024
 
 
 def _case(seed=11, n=90_000, lens=(400_000, 123_457, 16_384, 4_097, 5), **kw):
@@ -498,3 +499,72 @@ def test_packed_events_in_device_memory_aligned_or_not():
         assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
         h.close()
         assert hip.hipFree(buf) == 0
+
+
+# ---- -E regions on the fused tile stage (round 6; savePileupExpt's bedPos / save walk, Genrich.c:2185-2263) ----
+
+def _bed_case(seed=41):
+    """Three chromosomes over several bins, regions of every kind: touching position 0, reaching a chromosome's end (so the
+    closing interval lies inside one), spanning whole tiles and whole bins, two edges in one tile, a region of one base."""
+    lens = [2_600_000, 1_100_000, 300_000]
+    ev = synth.make_fragments(lens, 260_000, seed, peak_every=20_000, tower_every=300_000)
+    beds = [[0, 9_000, 50_000, 50_001, 123_000, 123_900, 400_000, 1_500_000, 2_000_000, 2_000_700],
+            [5_000, 6_000, 600_000, 640_123, 1_090_000, 1_100_000],
+            []]
+    return dict(lens=lens, beds=beds, replicates=[dict(save=None, treat=ev, ctrl=None)])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_excluded_regions_on_the_fused_tile_stage_and_on_the_general_chain(monkeypatch, fused):
+    if not fused:
+        monkeypatch.setenv("GX_NO_BED_FUSED", "1")
+    o, h, flags = _run(_bed_case(), B.make_params(pq=0.01, min_auc=20.0))
+    assert h.n_peaks > 0
+    assert bool(flags & FUSED) == fused and bool(flags & PAIRS) == fused and not flags & FELL_BACK, flags
+    assert not flags & LOOSE   # (lambda only comes with the sample's end: the bases inside the regions leave the closed form there)
+
+
+def test_excluded_regions_with_a_control_and_q_on_the_fused_tile_stage():
+    case = _bed_case(43)
+    case["replicates"][0]["ctrl"] = synth.make_fragments(case["lens"], 200_000, 44, uniform_only=True)
+    o, h, flags = _run(case, B.make_params(pq=0.05, qval=True, min_auc=20.0))
+    assert flags & FUSED and flags & PAIRS and not flags & FELL_BACK, flags
+
+
+def test_a_tower_inside_an_excluded_region_comes_off_fraglen():
+    """Thousands of keys in one tile (the whole workgroup's tile outside a region) that lies INSIDE a -E region: nothing is
+    emitted, and the pileup over its bases leaves the closed form of fragLen like any other excluded base (round 6: sbt_heavy saw
+    an inactive tile and left it in; found by reading, not by a run)."""
+    lens = [1_000_000, 300_000]
+    ev = synth.make_fragments(lens, 60_000, 47, frac_tower=0.3, tower_every=500_000, peak_every=50_000)
+    beds = [[200_000, 300_000, 700_000, 750_010], []]   # the first tower inside a region, the second one on a region's edge
+    case = dict(lens=lens, beds=beds, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    o, h, flags = _run(case, B.make_params(pq=0.01, min_auc=20.0))
+    assert flags & FUSED and flags & PAIRS and not flags & FELL_BACK, flags
+
+
+# ---- the control merge that scores its own intervals (round 6: k_merge2<.., true> -> k_pairs_missed -> k_pack_ep2) ----
+
+@pytest.mark.parametrize("merge_p", [True, False])
+@pytest.mark.parametrize("kind", ["plain", "multimap", "bed", "deep"])
+def test_control_merge_with_and_without_its_own_p_values(monkeypatch, merge_p, kind):
+    """savePval (Genrich.c:1720-1794) both ways: the merge looks p up itself and leaves (end, p) -- whole pileups below 256 from the
+    table, fractional pileups (multimapping on either side) and very deep ones (a tower of > 256 reads) by k_pairs_missed, -E
+    regions as SKIP -- or leaves both pileups for k_pack_pairs (GX_NO_MERGE_P, the path until round 5).  assert_same_run asks for
+    the pileup floats too: with the merge's own p-values they come from a second merge, run on request."""
+    if not merge_p:
+        monkeypatch.setenv("GX_NO_MERGE_P", "1")
+    lens = [900_000, 250_000, 4_097]
+    tr = synth.make_fragments(lens, 120_000, 61, peak_every=20_000, tower_every=150_000,
+                              frac_tower=0.25 if kind == "deep" else 0.02)
+    ct = synth.make_fragments(lens, 100_000, 62, uniform_only=True)
+    if kind == "multimap":
+        tr = synth.add_multimap(tr, lens, 0.2, seed=63)
+        ct = synth.add_multimap(ct, lens, 0.1, seed=64)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=ct)])
+    if kind == "bed":
+        case["beds"] = [[0, 5_000, 100_000, 180_500, 890_000, 900_000], [10, 11], []]
+    for params in (B.make_params(pq=0.01, min_auc=20.0), B.make_params(pq=0.05, qval=True, min_auc=20.0)):
+        o, h, flags = _run(case, params)
+        assert bool(flags & MERGE_P) == merge_p, flags
+        assert h.path_info() & PILES_MADE   # (assert_same_run asked for the intervals' pileup floats)

@@ -50,6 +50,26 @@ def run_paths(seed):
     if rng.random() < 0.5:  # fractional weights more often than mid_case has them
         for rep in case["replicates"]:
             rep["treat"] = synth.add_multimap(rep["treat"][rep["treat"]["count"] == 1], case["lens"], float(rng.choice([0.1, 0.5])), seed=seed + 5)
+    if rng.random() < 0.35:  # -E regions (round 6: on the fused tile stage), some touching position 0 / the chromosome's end
+        beds = []
+        for L in case["lens"]:
+            regs = []
+            for _ in range(int(rng.integers(0, 6))):
+                s = int(rng.integers(0, max(1, L - 5)))
+                regs.append((s, min(L, s + int(rng.choice([1, 50, 3000, 40_000, 400_000])))))
+            if rng.random() < 0.3:
+                regs.append((0, int(rng.integers(1, 9000))))
+            if rng.random() < 0.3:
+                regs.append((L - int(rng.integers(1, 9000)), L))
+            regs.sort()
+            merged = []
+            for s, e in regs:
+                if merged and s <= merged[-1][1]:
+                    merged[-1][1] = max(merged[-1][1], e)
+                else:
+                    merged.append([s, e])
+            beds.append([v for r in merged for v in r])
+        case["beds"] = beds
     knobs = {}
     if rng.random() < 0.6:
         knobs["GX_SBSHIFT"] = str(int(rng.integers(1, 4)))
@@ -69,15 +89,32 @@ def run_paths(seed):
         h.expect_fractional(True)
     pieces = int(rng.integers(1, 6))
     whole = h.push_events
+    packed = rng.random() < 0.5   # the pieces as 8-byte events where they fit (gx_push_events_packed)
+    from genrich_amd.lib import pack_events
 
     def in_pieces(ev):
         cuts = sorted(int(x) for x in rng.integers(0, len(ev) + 1, pieces - 1))
         for a, b in zip([0] + cuts, cuts + [len(ev)]):
-            whole(ev[a:b])
+            if packed:
+                p8, rest = pack_events(ev[a:b])
+                if len(p8):
+                    h.push_events_packed(p8)
+                if len(rest):
+                    whole(rest)
+            else:
+                whole(ev[a:b])
     h.push_events = in_pieces
     sh = B.run_case(h, case)
     T.assert_same_run(o, h, so, sh, case)
+    knobs = dict(knobs, beds=bool(case.get("beds")), packed=packed)
     return knobs, pieces, h.path_info()
+
+
+def describe(case):
+    """what a failing run looked like (chromosome lengths, skipped ones, -E regions, samples)"""
+    reps = [dict(n=len(r["treat"]), frac=int((r["treat"]["count"] > 1).sum()), ctrl=None if r["ctrl"] is None else len(r["ctrl"]))
+            for r in case["replicates"]]
+    return dict(lens=case["lens"], skip=case.get("skip"), beds=case.get("beds"), reps=reps)
 
 
 mid = "--mid" in sys.argv
@@ -96,6 +133,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         except Exception as ex:  # noqa: BLE001
             bad += 1
             print("seed", seed, type(ex).__name__, str(ex)[:300], {k: os.environ.get(k) for k in ("GX_SBSHIFT", "GX_FORCE_HALF_BINS", "GX_NO_PAIRS", "GX_NO_FRAC_PAIRS")}, flush=True)
+            print("   ", describe(mid_case(seed)[0]), flush=True)
         continue
     case, params = mid_case(seed) if mid else T._random_case(seed, 50 if "--x50" in sys.argv else 1)
     if "--extreme" in sys.argv:
@@ -110,4 +148,5 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     except Exception as ex:  # noqa: BLE001
         bad += 1
         print("seed", seed, type(ex).__name__, str(ex)[:200], flush=True)
+        print("   ", describe(case), flush=True)
 print("done, failures:", bad)
