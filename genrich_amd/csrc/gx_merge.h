@@ -937,8 +937,12 @@ constexpr int MNW_NW = 4;          // wavefronts (tiles in flight) per workgroup
 #endif
 constexpr int MNW_CAP = GX_MNW_CAP;   // merged intervals per round
 constexpr int MNW_MAXREP = 8;      // replicates this kernel takes (beyond: k_mergeN)
+#ifndef GX_MNW_SCAP
+#define GX_MNW_SCAP 320
+#endif
+constexpr int MNW_SCAP = GX_MNW_SCAP;  // intervals per replicate and tile whose p-values are staged in LDS (round 6; + the one behind them)
 __host__ __device__ constexpr size_t mergeNw_wave_words(int n) {  // LDS words of one wavefront
-  return (size_t)n * MG_WORDS + (size_t)n * MG_WORDS / 2 /*preR u16*/ + MNW_CAP / 2 /*offL u16*/;
+  return (size_t)n * MG_WORDS + (size_t)n * MG_WORDS / 2 /*preR u16*/ + (size_t)n * (MNW_SCAP + 1) /*staged p*/ + MNW_CAP / 2 /*offL u16*/;
 }
 __host__ __device__ constexpr size_t mergeNw_lds_bytes(int n) { return MNW_NW * ((mergeNw_wave_words(n) * 4 + 15) / 16 * 16); }
 
@@ -948,41 +952,87 @@ __device__ __forceinline__ void mnw_sync() {  // (LDS operations of one wavefron
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#ifndef GX_MNW_WAVES
-#define GX_MNW_WAVES 4
-#endif
-__global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S, const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+// Round 6: what a tile needs from global memory is asked for ONCE and early -- the next tile's chromosome record rides under
+// this tile, a replicate's offsets and its "present" flag are read per tile (they were read per merged interval), and the
+// replicates' p-values are staged in LDS with their ends (the gather of the dense phase was three dependent global loads per
+// merged interval).
+__global__ __launch_bounds__(MNW_NW * 64) void k_mergeN_w(RepSet S, const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
                                                           u32 nTiles, MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk) {
   static_assert(MG_WORDS == 128, "two bitmap words per lane");
   extern __shared__ __attribute__((aligned(16))) u32 dynw[];
-  const int n = S.n, lane = lane_id(), wv = threadIdx.x >> 6;
+  const int n = S.n, lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   u32* bm = dynw + (size_t)wv * ((mergeNw_wave_words(n) * 4 + 15) / 16 * 4);   // n bitmaps of MG_WORDS words
   uint16_t* preR = reinterpret_cast<uint16_t*>(bm + n * MG_WORDS);       // [r][w]: intervals of r before word w
-  uint16_t* offL = preR + n * MG_WORDS;                                  // offset of merged interval i of the round
+  float* sP = reinterpret_cast<float*>(bm + n * MG_WORDS + n * MG_WORDS / 2);   // [r][MNW_SCAP + 1]: the tile's p-values of r
+  uint16_t* offL = reinterpret_cast<uint16_t*>(sP + n * (MNW_SCAP + 1)); // offset of merged interval i of the round
   u32 bad = 0;
   const u32 stride = gridDim.x * MNW_NW;
-  for (u32 t = blockIdx.x * MNW_NW + wv; t < nTiles; t += stride) {
+  u32 t = blockIdx.x * MNW_NW + wv;
+  u32 ciN = 0;
+  DChrom cN{};
+  if (t < nTiles) {
+    ciN = tileChrom[t];
+    cN = chroms[ciN];
+  }
+  for (int r = 0; r < n; r++) *reinterpret_cast<uint2*>(bm + r * MG_WORDS + 2 * lane) = make_uint2(0u, 0u);
+  for (; t < nTiles; t += stride) {
     mnw_sync();
-    const u32 ci = tileChrom[t];
-    const DChrom c = chroms[ci];
+    const u32 ci = ciN;
+    const DChrom c = cN;
+    if (t + stride < nTiles) {  // (consumed a tile later)
+      ciN = tileChrom[t + stride];
+      cN = chroms[ciN];
+    }
     const u32 tl = t - c.tileBase, pos0 = tl << TB;
     const bool lastTile = tl + 1 == c.nTiles;
-    // this lane's two words of every bitmap start empty
-    for (int r = 0; r < n; r++) *reinterpret_cast<uint2*>(bm + r * MG_WORDS + 2 * lane) = make_uint2(0u, 0u);
-    mnw_sync();
-    bool any = false;
-    u32 slot = 0;
-    for (int r = 0; r < n; r++) {
-      const u32 a0 = S.r[r].tileOff[t];
-      slot += a0;
-      if (!S.r[r].present[ci]) continue;
-      any = true;
-      const u32 a1 = S.r[r].tileOff[t + 1];
-      const u32 a1c = (lastTile && a1 > a0) ? a1 - 1 : a1;
-      for (u32 i = a0 + lane; i < a1c; i += 64) {
-        const u32 off = S.r[r].end[i] - pos0;
-        atomicOr(&bm[r * MG_WORDS + (off >> 5)], 1u << (off & 31));
+    // the replicates' slices of this tile (wave-uniform: scalar registers)
+    u32 a0[MNW_MAXREP], nR[MNW_MAXREP], aEnd[MNW_MAXREP];
+    u32 pres = 0, slot = 0, maxN = 0;
+#pragma unroll
+    for (int r = 0; r < MNW_MAXREP; r++) {
+      a0[r] = 0; nR[r] = 0; aEnd[r] = 0;
+      if (r < n) {
+        a0[r] = S.r[r].tileOff[t];
+        aEnd[r] = S.r[r].tileOff[t + 1];
+        slot += a0[r];
+        if (S.r[r].present[ci]) {
+          pres |= 1u << r;
+          const u32 a1c = (lastTile && aEnd[r] > a0[r]) ? aEnd[r] - 1 : aEnd[r];
+          nR[r] = a1c - a0[r];
+          maxN = max(maxN, nR[r]);
+        }
       }
+    }
+    const bool any = pres != 0;
+    const bool staged = maxN <= (u32)MNW_SCAP;   // wave-uniform
+    // ---- breakpoints -> bitmaps, p-values -> LDS: every replicate's loads of a step in flight together
+    for (u32 j0 = 0; j0 < maxN; j0 += 64) {
+      const u32 j = j0 + lane;
+      u32 e[MNW_MAXREP];
+      float pv[MNW_MAXREP];
+#pragma unroll
+      for (int r = 0; r < MNW_MAXREP; r++) {
+        e[r] = 0; pv[r] = 0.0f;
+        if (r < n && j < nR[r]) {
+          e[r] = S.r[r].end[a0[r] + j];
+          pv[r] = S.r[r].p[a0[r] + j];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < MNW_MAXREP; r++)
+        if (r < n && j < nR[r]) {
+          const u32 off = e[r] - pos0;
+          atomicOr(&bm[r * MG_WORDS + (off >> 5)], 1u << (off & 31));
+          if (staged) sP[r * (MNW_SCAP + 1) + j] = pv[r];
+        }
+    }
+    // (the interval that covers what follows a replicate's last breakpoint in the tile: the next one in its tight array)
+    if (staged && lane < n && ((pres >> lane) & 1u)) {
+      u32 a0l = 0, nRl = 0;
+#pragma unroll
+      for (int r = 0; r < MNW_MAXREP; r++)
+        if (r == lane) { a0l = a0[r]; nRl = nR[r]; }
+      sP[lane * (MNW_SCAP + 1) + nRl] = S.r[lane].p[a0l + nRl];
     }
     mnw_sync();
     u32 wU0 = 0, wU1 = 0;
@@ -999,7 +1049,7 @@ __global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S
     const int incU = dpp_scan_add(cU);
     const u32 exU = (u32)(incU - cU), tU = (u32)__builtin_amdgcn_readlane(incU, 63);
     if (lane == 0) out.tileCount[t] = any ? tU + (lastTile ? 1u : 0u) : 0u;
-    if (!any) continue;  // wave-uniform
+    if (any) {  // wave-uniform
     for (u32 r0 = 0; r0 < tU; r0 += MNW_CAP) {
       mnw_sync();
       // ---- 1: the merged intervals of this round, by rank (a lane lists the set bits of its own two words)
@@ -1019,10 +1069,11 @@ __global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S
         int df = 0;
         if (i < nC) {
           const u32 off = offL[i], ww = off >> 5, below = (1u << (off & 31)) - 1u;
-          for (int r = 0; r < n; r++) {  // multPval 570-574, replicate order
-            if (!S.r[r].present[ci]) continue;
-            const u32 idx = S.r[r].tileOff[t] + preR[r * MG_WORDS + ww] + __popc(bm[r * MG_WORDS + ww] & below);
-            const float pv = S.r[r].p[idx];
+#pragma unroll
+          for (int r = 0; r < MNW_MAXREP; r++) {  // multPval 570-574, replicate order
+            if (r >= n || !((pres >> r) & 1u)) continue;   // wave-uniform
+            const u32 idx = (u32)preR[r * MG_WORDS + ww] + (u32)__popc(bm[r * MG_WORDS + ww] & below);
+            const float pv = staged ? sP[r * (MNW_SCAP + 1) + idx] : S.r[r].p[a0[r] + idx];
             if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
           }
           if (df > 400) bad |= ST_BAD_DF;
@@ -1031,7 +1082,11 @@ __global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S
           // (round 6: every interval evaluated on the spot -- the closed form of the even-df tail, gx_math.h fisher_fast -- where
           // rounds 3-5 probed an LDS cache and a device-wide table of results and evaluated the misses by pgamma's series)
           bool risky = false;
+#ifdef GX_EXP_NOFISHER   // (measurement: the kernel without the combination's arithmetic)
+          out.p[o] = (float)sum;
+#else
           out.p[o] = fisher_fast(sum, df, &risky);
+#endif
           if (risky) risk_add(risk, RK_FISHER, t, r0 + i, (u32)df, sum);
         }
       }
@@ -1039,9 +1094,10 @@ __global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S
     if (lastTile && lane == 0) {  // closing interval [.., len)
       double sum = 0.0;
       int df = 0;
-      for (int r = 0; r < n; r++) {
-        if (!S.r[r].present[ci]) continue;
-        const float pv = S.r[r].p[S.r[r].tileOff[t + 1] - 1];
+#pragma unroll
+      for (int r = 0; r < MNW_MAXREP; r++) {
+        if (r >= n || !((pres >> r) & 1u)) continue;
+        const float pv = S.r[r].p[aEnd[r] - 1];
         if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
       }
       const u32 oc = slot + tU;
@@ -1050,6 +1106,9 @@ __global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S
       out.p[oc] = fisher_combine(sum, df, &risky);
       if (risky) risk_add(risk, RK_FISHER, t, tU, (u32)df, sum);
     }
+    }
+    mnw_sync();   // (every lane is through with the bitmaps: this lane's two words of each start the next tile empty)
+    for (int r = 0; r < n; r++) *reinterpret_cast<uint2*>(bm + r * MG_WORDS + 2 * lane) = make_uint2(0u, 0u);
   }
   if (bad) atomicOr(st, bad);
 }
