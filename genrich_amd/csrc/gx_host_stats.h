@@ -360,12 +360,18 @@ int combine_replicates(gx_ctx* ctx) {
   if (nr <= MNW_MAXREP) {
     // one wavefront per tile (no workgroup barrier in the tile loop, twenty tiles in flight per CU)
     const size_t ldsw = mergeNw_lds_bytes((int)nr);
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN_w, MNW_NW * 64, ldsw));
     const u32 want = (nTiles + MNW_NW - 1) / MNW_NW;
-    hipLaunchKernelGGL(k_mergeN_w, dim3(std::max(1u, std::min(want, (u32)(std::max(1, mnBlocks) * ctx->numCU)))), dim3(MNW_NW * 64), ldsw, s, S,
-                       ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo, ctx->dStatus.as<u32>(),
-                       ctx->dRisk.as<RiskBuf>());
+    // (two instances: the per-replicate registers of a tile are unrolled to the instance's bound)
+#define GX_MERGEN_W(MAXR)                                                                                                             \
+  do {                                                                                                                                \
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mergeN_w<MAXR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw)); \
+    HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN_w<MAXR>, MNW_NW * 64, ldsw));                           \
+    hipLaunchKernelGGL(k_mergeN_w<MAXR>, dim3(std::max(1u, std::min(want, (u32)(std::max(1, mnBlocks) * ctx->numCU)))),               \
+                       dim3(MNW_NW * 64), ldsw, s, S, ctx->dTileChrom.as<u32>(), ctx->dChrom.as<DChrom>(), nTiles, mo,                \
+                       ctx->dStatus.as<u32>(), ctx->dRisk.as<RiskBuf>());                                                             \
+  } while (0)
+    if (nr <= 4) GX_MERGEN_W(4); else GX_MERGEN_W(MNW_MAXREP);
+#undef GX_MERGEN_W
   } else {
   HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&mnBlocks, k_mergeN, MG_NT, lds));
   hipLaunchKernelGGL(k_mergeN, dim3(std::min(nTiles, (u32)(std::max(1, mnBlocks) * ctx->numCU))), dim3(MG_NT), lds, s, S,

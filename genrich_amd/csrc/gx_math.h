@@ -312,16 +312,72 @@ GX_HD inline double fisher_double(double sum, int df) {
 // against the reference's algorithm with the host's libm (fisher_double) the two doubles differ by at most 6.3e-14 = 0.017 x
 // RISK_B over 11 M sums in [1e-6, 1e38] x df 4 .. 64 (tests/test_abi.py repeats a sweep on the CPU, the GPU suite on the device),
 // and a value next to a float rounding boundary goes to the host, which evaluates fisher_double.
+// log1p for the closed form below: the algorithm of fdlibm's s_log1p.c (argument reduction to [sqrt(2)/2, sqrt(2)), the correction
+// term of 1 + x, a degree-14 polynomial in s = f / (2 + f); error below 1 ulp -- checked against glibc's over [-0.5, 1e300]) spelled
+// out here because the device library's log1p costs the merge kernel more than everything else in it (hg38 x 3 replicates: 2.0 of
+// k_mergeN_w's 3.9 ms were the combination's arithmetic).  The same operations on the host and on the device (IEEE divisions, no
+// contraction), so the host-side sweep of the closed form against the reference's algorithm holds for both.
+GX_HD inline double fast_log1p(double x) {  // x > -1, finite
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+               Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+               Lp7 = 1.479819860511658591e-01;
+  double f, c = 0.0;
+  int k = 0;
+  if (x > -0.2928932188134524 && x < 0.41421356237309503) {  // sqrt(2)/2 <= 1 + x < sqrt(2): no rescaling, f = x exactly
+    const double ax = fabs(x);
+    if (ax < 0x1p-29) return ax < 0x1p-54 ? x : x - x * x * 0.5;
+    f = x;
+  } else {
+    union { double d; uint64_t u; } v;
+    if (x < 0x1p53) {
+      v.d = 1.0 + x;
+      k = (int)((v.u >> 52) & 0x7FFu) - 1023;
+      c = (k > 0 ? 1.0 - (v.d - x) : x - (v.d - 1.0)) / v.d;  // what the rounding of 1 + x lost
+    } else {
+      v.d = x;
+      k = (int)((v.u >> 52) & 0x7FFu) - 1023;
+    }
+    const uint64_t hu = (v.u >> 32) & 0x000FFFFFu;
+    if (hu < 0x6A09Eu) {
+      v.u = (v.u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;   // u in [1, sqrt 2)
+    } else {
+      k += 1;
+      v.u = (v.u & 0x000FFFFFFFFFFFFFull) | 0x3FE0000000000000ull;   // u / 2 in [sqrt(2)/2, 1)
+    }
+    f = v.d - 1.0;
+  }
+  const double hfsq = 0.5 * f * f;
+  const double s = f / (2.0 + f), z = s * s;
+  const double R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+  if (k == 0) return f - (hfsq - s * (hfsq + R));
+  const double dk = (double)k;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + (dk * ln2_lo + c))) - f);
+}
+
+// 1 / m for m < 64, as the division gives them (literals folded by the compiler: the same doubles on the host and on the device):
+// the divisions of the closed form's Horner scheme and of its lower-tail series were a dozen instructions each on the device
+GX_HD inline double fisher_rcp(int m) {
+  static const double RK[64] = {
+      0.0,        1.0 / 1.0,  1.0 / 2.0,  1.0 / 3.0,  1.0 / 4.0,  1.0 / 5.0,  1.0 / 6.0,  1.0 / 7.0,  1.0 / 8.0,  1.0 / 9.0,  1.0 / 10.0,
+      1.0 / 11.0, 1.0 / 12.0, 1.0 / 13.0, 1.0 / 14.0, 1.0 / 15.0, 1.0 / 16.0, 1.0 / 17.0, 1.0 / 18.0, 1.0 / 19.0, 1.0 / 20.0, 1.0 / 21.0,
+      1.0 / 22.0, 1.0 / 23.0, 1.0 / 24.0, 1.0 / 25.0, 1.0 / 26.0, 1.0 / 27.0, 1.0 / 28.0, 1.0 / 29.0, 1.0 / 30.0, 1.0 / 31.0, 1.0 / 32.0,
+      1.0 / 33.0, 1.0 / 34.0, 1.0 / 35.0, 1.0 / 36.0, 1.0 / 37.0, 1.0 / 38.0, 1.0 / 39.0, 1.0 / 40.0, 1.0 / 41.0, 1.0 / 42.0, 1.0 / 43.0,
+      1.0 / 44.0, 1.0 / 45.0, 1.0 / 46.0, 1.0 / 47.0, 1.0 / 48.0, 1.0 / 49.0, 1.0 / 50.0, 1.0 / 51.0, 1.0 / 52.0, 1.0 / 53.0, 1.0 / 54.0,
+      1.0 / 55.0, 1.0 / 56.0, 1.0 / 57.0, 1.0 / 58.0, 1.0 / 59.0, 1.0 / 60.0, 1.0 / 61.0, 1.0 / 62.0, 1.0 / 63.0};
+  return m < 64 ? RK[m] : 1.0 / (double)m;
+}
+
 GX_HD inline double fisher_fast_double(double sum, int df) {
   const double FISHER_Y0[9] = {0, 0, 0.0102, 0.1857, 0.5772, 1.1132, 1.7419, 2.4190, 3.1646};
-  const double LN10 = 2.30258509299404568402;
+  const double LN10 = 2.30258509299404568402, INV_LN10 = 0.43429448190325182765;
   const int k = df >> 1;
   const double y = sum * LN10;
   if (y >= (k <= 8 ? FISHER_Y0[k] : (double)(k - 1))) {
     if (k <= 8) {
       double S = 1.0;
-      for (int j = k - 1; j >= 2; j--) S = 1.0 + S * (y * (1.0 / (double)j));
-      return sum - log1p(y * S) / LN10;
+      for (int j = k - 1; j >= 2; j--) S = 1.0 + S * (y * fisher_rcp(j));
+      return sum - fast_log1p(y * S) * INV_LN10;
     }
     const double iy = 1.0 / y;
     double term = 1.0, T = 1.0, fact = 1.0;
@@ -333,15 +389,22 @@ GX_HD inline double fisher_fast_double(double sum, int df) {
     return sum - (double)(k - 1) * log10(y) + log10(fact) - log10(T);
   }
   double term = 1.0, s = 1.0, fact = 1.0, yk = 1.0;
-  for (int j = 1; j < 400; j++) {
-    term *= y / (double)(k + j);
+  for (int j = 1; j < 400; j += 4) {  // (four terms a turn: their reciprocals are asked for together; a term too many changes nothing)
+    const double r0 = fisher_rcp(k + j), r1 = fisher_rcp(k + j + 1), r2 = fisher_rcp(k + j + 2), r3 = fisher_rcp(k + j + 3);
+    term *= y * r0;
+    s += term;
+    term *= y * r1;
+    s += term;
+    term *= y * r2;
+    s += term;
+    term *= y * r3;
     s += term;
     if (term < s * 1e-18) break;
   }
   for (int j = 2; j <= k; j++) fact *= (double)j;
   for (int j = 0; j < k; j++) yk *= y;
   const double P = exp(-y) * yk / fact * s;
-  return -log1p(-P) / LN10;
+  return -fast_log1p(-P) * INV_LN10;
 }
 
 // multPval (567-583) through the closed form; df <= 64 (32 replicates)

@@ -956,7 +956,11 @@ __device__ __forceinline__ void mnw_sync() {  // (LDS operations of one wavefron
 // this tile, a replicate's offsets and its "present" flag are read per tile (they were read per merged interval), and the
 // replicates' p-values are staged in LDS with their ends (the gather of the dense phase was three dependent global loads per
 // merged interval).
-__global__ __launch_bounds__(MNW_NW * 64) void k_mergeN_w(RepSet S, const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
+#ifndef GX_MNW_WAVES
+#define GX_MNW_WAVES 6
+#endif
+template <int MAXR>
+__global__ __launch_bounds__(MNW_NW * 64, GX_MNW_WAVES) void k_mergeN_w(RepSet S, const u32* __restrict__ tileChrom, const DChrom* __restrict__ chroms,
                                                           u32 nTiles, MergeNOut out, u32* __restrict__ st, RiskBuf* __restrict__ risk) {
   static_assert(MG_WORDS == 128, "two bitmap words per lane");
   extern __shared__ __attribute__((aligned(16))) u32 dynw[];
@@ -986,10 +990,10 @@ __global__ __launch_bounds__(MNW_NW * 64) void k_mergeN_w(RepSet S, const u32* _
     const u32 tl = t - c.tileBase, pos0 = tl << TB;
     const bool lastTile = tl + 1 == c.nTiles;
     // the replicates' slices of this tile (wave-uniform: scalar registers)
-    u32 a0[MNW_MAXREP], nR[MNW_MAXREP], aEnd[MNW_MAXREP];
+    u32 a0[MAXR], nR[MAXR], aEnd[MAXR];
     u32 pres = 0, slot = 0, maxN = 0;
 #pragma unroll
-    for (int r = 0; r < MNW_MAXREP; r++) {
+    for (int r = 0; r < MAXR; r++) {
       a0[r] = 0; nR[r] = 0; aEnd[r] = 0;
       if (r < n) {
         a0[r] = S.r[r].tileOff[t];
@@ -1008,10 +1012,10 @@ __global__ __launch_bounds__(MNW_NW * 64) void k_mergeN_w(RepSet S, const u32* _
     // ---- breakpoints -> bitmaps, p-values -> LDS: every replicate's loads of a step in flight together
     for (u32 j0 = 0; j0 < maxN; j0 += 64) {
       const u32 j = j0 + lane;
-      u32 e[MNW_MAXREP];
-      float pv[MNW_MAXREP];
+      u32 e[MAXR];
+      float pv[MAXR];
 #pragma unroll
-      for (int r = 0; r < MNW_MAXREP; r++) {
+      for (int r = 0; r < MAXR; r++) {
         e[r] = 0; pv[r] = 0.0f;
         if (r < n && j < nR[r]) {
           e[r] = S.r[r].end[a0[r] + j];
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(MNW_NW * 64) void k_mergeN_w(RepSet S, const u32* _
         }
       }
 #pragma unroll
-      for (int r = 0; r < MNW_MAXREP; r++)
+      for (int r = 0; r < MAXR; r++)
         if (r < n && j < nR[r]) {
           const u32 off = e[r] - pos0;
           atomicOr(&bm[r * MG_WORDS + (off >> 5)], 1u << (off & 31));
@@ -1030,7 +1034,7 @@ __global__ __launch_bounds__(MNW_NW * 64) void k_mergeN_w(RepSet S, const u32* _
     if (staged && lane < n && ((pres >> lane) & 1u)) {
       u32 a0l = 0, nRl = 0;
 #pragma unroll
-      for (int r = 0; r < MNW_MAXREP; r++)
+      for (int r = 0; r < MAXR; r++)
         if (r == lane) { a0l = a0[r]; nRl = nR[r]; }
       sP[lane * (MNW_SCAP + 1) + nRl] = S.r[lane].p[a0l + nRl];
     }
@@ -1070,7 +1074,7 @@ __global__ __launch_bounds__(MNW_NW * 64) void k_mergeN_w(RepSet S, const u32* _
         if (i < nC) {
           const u32 off = offL[i], ww = off >> 5, below = (1u << (off & 31)) - 1u;
 #pragma unroll
-          for (int r = 0; r < MNW_MAXREP; r++) {  // multPval 570-574, replicate order
+          for (int r = 0; r < MAXR; r++) {  // multPval 570-574, replicate order
             if (r >= n || !((pres >> r) & 1u)) continue;   // wave-uniform
             const u32 idx = (u32)preR[r * MG_WORDS + ww] + (u32)__popc(bm[r * MG_WORDS + ww] & below);
             const float pv = staged ? sP[r * (MNW_SCAP + 1) + idx] : S.r[r].p[a0[r] + idx];
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(MNW_NW * 64) void k_mergeN_w(RepSet S, const u32* _
       double sum = 0.0;
       int df = 0;
 #pragma unroll
-      for (int r = 0; r < MNW_MAXREP; r++) {
+      for (int r = 0; r < MAXR; r++) {
         if (r >= n || !((pres >> r) & 1u)) continue;
         const float pv = S.r[r].p[aEnd[r] - 1];
         if (pv != GX_SKIPF) { sum += (double)pv; df += 2; }
