@@ -86,7 +86,7 @@ def source_hash():
 
 
 PATH_BITS = ((1, "fused"), (16, "pairs"), (128, "frac_pairs"), (2, "loose_sweep"), (4, "fell_back"), (8, "pt_grew"), (32, "dense_bh"),
-             (64, "range_bh"), (1024, "merge_p"))
+             (64, "range_bh"), (1024, "merge_p"), (2048, "pack_hist"))
 
 
 def decode_path(flags):
@@ -220,7 +220,7 @@ def gate_and_cpu_baseline(cfg, lens, reps, n_chrom, qval, device, timed_path=Non
     n_ev = int(sum(len(t) + (0 if c is None else len(c)) for t, c in sub))
     gate_path = decode_path(gate_flags)
     # (the BH exchanges and "the page tables grew" belong to N ranks / to a pile-up, not to the choice of kernels)
-    kernels = lambda p: {x for x in p.split("+") if x in ("fused", "pairs", "frac_pairs", "loose_sweep", "fell_back", "merge_p")}  # noqa: E731
+    kernels = lambda p: {x for x in p.split("+") if x in ("fused", "pairs", "frac_pairs", "loose_sweep", "fell_back", "merge_p", "pack_hist")}  # noqa: E731
     same = timed_path is None or kernels(gate_path) == kernels(timed_path)
     gate = dict(narrowpeak_diff=ndiff, peaks_oracle=int(o.n_peaks), peaks_hip=int(h.n_peaks), interval_ends_equal=ends_equal,
                 intervals_compared=n_iv, max_abs_dp=dp, max_abs_dq=dq if qval else None, pq_values_differing_in_bits=nbits,

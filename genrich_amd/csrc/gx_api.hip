@@ -221,6 +221,7 @@ int gx_reset(gx_ctx* ctx) {
     recycle(ctx, pa.chromLooseOff); recycle(ctx, pa.keptV); recycle(ctx, pa.keptMeta);
   }
   ctx->reps.clear();
+  ctx->denseHistIdx = -1;
   ctx->pilesMade = false;
   ctx->sample = 0;
   ctx->phase = 0;
@@ -529,9 +530,13 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   // sweep walks them where they are -- no tight interval table is made unless somebody asks for it later
   const bool looseFast = ctx->sample == 1 && ctx->reps.size() == 1 && ctx->reps[0].loose && ctx->reps[0].looseSweep &&
                          !ctx->par.qval_opt;
+  // (one replicate, no control, unit weights, -q, one rank: the tight table's kernel sums "bp at pileup V" on its way -- BH's table
+  // of distinct p-values is made of those sums, not of a hash insertion per interval)
+  const bool packHist = ctx->par.qval_opt && ctx->sample == 1 && ctx->reps.size() == 1 && ctx->reps[0].ctrlIsConst && !ctx->sawFrac &&
+                        ctx->world <= 1 && !ctx->forceColl && !ctx->knob.noPackHist;
   for (size_t r = 0; r < ctx->reps.size(); r++) {
     if (ctx->reps[r].loose && !looseFast)
-      if (int rc = materialize_rep(ctx, (int)r)) return rc;
+      if (int rc = materialize_rep(ctx, (int)r, packHist)) return rc;
     // (the Fisher combination of several replicates reuses the loose slots: the last replicate keeps what its pileup
     // floats, if somebody asks for them, are made of)
     if (ctx->sample > 1 && ctx->reps[r].pilesPending)
@@ -755,7 +760,8 @@ int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   if (!ctx || !flags) return GX_ERR_ORDER;
   *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->rangeBhUsed ? GX_PATH_RANGE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u) | (ctx->fusedUsed && ctx->fracPairsUsed ? GX_PATH_FRAC_PAIRS : 0u) |
-           (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u) | (ctx->packedUsed ? GX_PATH_PACKED : 0u) | (ctx->mergePUsed ? GX_PATH_MERGE_P : 0u);
+           (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u) | (ctx->packedUsed ? GX_PATH_PACKED : 0u) | (ctx->mergePUsed ? GX_PATH_MERGE_P : 0u) |
+           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u);
   return GX_OK;
 }
 

@@ -160,6 +160,7 @@ struct Knobs {
   int bhVariant = -1;     // GX_BH_VARIANT: the instance of k_bh_hist / k_qlookup (0: 256 threads, 2048-entry LDS tables -- rounds 2-5; 1: 1024 threads,
                           // one workgroup per CU, 8192 / 16384 entries; 2: 512 threads, 4096 / 8192 entries); default: chosen by the run
   int mergeWg = 0;        // GX_MERGE_WG: the control merge by k_merge2 (a workgroup per tile, rounds 2-5) instead of k_merge2w (a wavefront per tile)
+  int noPackHist = 0;     // GX_NO_PACK_HIST: BH's histogram by k_bh_hist from the tight table also for a single replicate without control
   int noMergeP = 0;       // GX_NO_MERGE_P: the control merge leaves both pileups in its loose slots and k_pack_pairs scores them, as until round 5
   int forceHalfBins = 0;  // GX_FORCE_HALF_BINS: the 128-key level 1 on a small input
   int noHalfBins = 0;     // GX_NO_HALF_BINS
@@ -182,7 +183,7 @@ const KnobDef KNOBS[] = {
     {"GX_DEBUG", &Knobs::debug, nullptr}, {"GX_DEBUG_RETRY", &Knobs::debugRetry, nullptr}, {"GX_NO_SPIN", &Knobs::noSpin, nullptr},
     {"GX_FORCE_REC64", &Knobs::forceRec64, nullptr}, {"GX_FORCE_SLOWFRAG", &Knobs::forceSlowFrag, nullptr},
     {"GX_NO_FUSED", &Knobs::noFused, nullptr}, {"GX_NO_LOOSE", &Knobs::noLoose, nullptr}, {"GX_NO_PAIRS", &Knobs::noPairs, nullptr},
-    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
+    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_NO_PACK_HIST", &Knobs::noPackHist, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
     {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
     {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
     {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
@@ -269,6 +270,8 @@ struct gx_ctx {
   int fusedBackoff[2] = {0, 0}; // treatment / control samples for which k_sbtile is not tried (after one that did not fit)
   bool looseSwept = false;      // the last gx_find_peaks swept the loose slots
   bool pilesMade = false;       // pileup floats were written since the last gx_reset (ensure_piles)
+  int denseHistIdx = -1;        // the replicate whose "bp at V" histogram k_pack_pval<.., HIST> left in bhDense (and its deep values in the table)
+  bool denseHistUsed = false;   // ... and the last BH table was made from it
   bool mergePUsed = false;      // the last control merge wrote p-values into its loose slots (k_merge2<.., true>)
   DevBuf lbSweep, lbSweep2;     // look-back granules of the sweep's one-pass compactions (generation-tagged)
   u32 sweepGen = 0;

@@ -11,7 +11,36 @@ namespace {
 // Loose slots -> the tight interval table (end, p[, pileups]) of a replicate without control: savePval
 // (Genrich.c:1720-1794) against the constant control lambda.  Needs the sample's loose slots, tile tables and
 // p(V) table, i.e. must run before the next sample is built (gx_sample_begin sees to that).
-int materialize_rep(gx_ctx* ctx, int idx) {
+// The table of distinct p-values: open addressing, 2^bhCapLog slots.  It starts at 2^22 (16 MiB of keys: L2 /
+// Infinity-Cache resident for the per-interval look-ups) and grows by 8x, for good, whenever an insertion
+// gives up (ST_HASH_FULL: bh_global_add stops after BH_MAX_PROBE steps instead of crawling through a full
+// table) -- the reference's chained hash (recordPval 277-295) has no limit either.
+int bh_table_prepare(gx_ctx* ctx, u32 c) {
+  hipStream_t s = ctx->stream;
+  const bool fresh = ctx->bhKeys.cap < (size_t)c * 4;
+  HIPCHECK(ctx->bhKeys.ensure((size_t)c * 4));
+  HIPCHECK(ctx->bhLens.ensure((size_t)c * 8));
+  HIPCHECK(ctx->bhQ.ensure((size_t)c * 4));
+  const bool freshKQ = ctx->bhKQ.cap < (size_t)c * 8;   // ({key, q} side by side for k_qlookup: free slots hold ~0)
+  HIPCHECK(ctx->bhKQ.ensure((size_t)c * 8));
+  if (freshKQ || ctx->bhDirty) HIPCHECK(hipMemsetAsync(ctx->bhKQ.p, 0xFF, (size_t)c * 8, s));
+  HIPCHECK(ctx->bhOutKeys.ensure((size_t)c * 4));
+  HIPCHECK(ctx->bhOutSlot.ensure((size_t)c * 4));
+  if (fresh || ctx->bhDirty) {  // normally the table comes back clean from the previous call (k_bh_clear)
+    HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)c * 4, s));
+    HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)c * 8, s));
+  }
+  ctx->bhDirty = true;
+  return GX_OK;
+}
+BhTable bh_table_of(gx_ctx* ctx, u32 cap) {
+  return BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
+                 ctx->misc.as<u32>() + M_BHCOUNT};
+}
+
+// hist: the replicate is the run's only one, without a control, and -q follows (gx_find_peaks knows): its "bp at V" histogram is
+// made on the way (k_pack_pval<.., HIST>), for bh_qvalues
+int materialize_rep(gx_ctx* ctx, int idx, bool hist = false) {
   PArray& pa = ctx->reps[idx];
   if (!pa.loose) return GX_OK;
   hipStream_t s = ctx->stream;
@@ -36,7 +65,20 @@ int materialize_rep(gx_ctx* ctx, int idx) {
   }
   {
     const dim3 grid(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU))));
-    if (sigM)
+    if (hist) {
+      const u32 cap = 1u << ctx->bhCapLog;
+      if (int rc = bh_table_prepare(ctx, cap)) return rc;
+      HIPCHECK(hipMemsetAsync(ctx->misc.as<u32>() + M_BHCOUNT, 0, 8, s));
+      HIPCHECK(ctx->bhDense.ensure(bhd_words(1) * 8));
+      HIPCHECK(hipMemsetAsync(ctx->bhDense.p, 0, bhd_words(1) * 8, s));
+      // (as many workgroups as the CUs hold at once -- seven, with the histogram's LDS and registers: an eighth would run behind the others)
+      int nbH = 0;
+      HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbH, k_pack_pval<false, true>, 256, 0));
+      const dim3 gridH(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(std::max(1, std::min(nbH, 8)) * ctx->numCU))));
+      hipLaunchKernelGGL((k_pack_pval<false, true>), gridH, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
+                         ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(), pa.p.as<float>(), ctx->par.thr, sigM, skipM,
+                         ctx->dStatus.as<u32>(), (const u32*)ctx->tilePrevEnd.as<u32>(), ctx->bhDense.as<u64>());
+    } else if (sigM)
       hipLaunchKernelGGL((k_pack_pval<true>), grid, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
                          ctx->pvLut.as<float>(), ctx->expt.ivEnd.as<u32>(), pa.p.as<float>(), ctx->par.thr, sigM, skipM,
                          ctx->dStatus.as<u32>());
@@ -47,6 +89,12 @@ int materialize_rep(gx_ctx* ctx, int idx) {
   }
   hipLaunchKernelGGL(k_pval_deep, dim3(256), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(),
                      ctx->dScal.as<Scalars>(), ctx->dDeep.as<DeepTab>(), pa.p.as<float>(), ctx->par.thr, sigM);
+  if (hist) {
+    hipLaunchKernelGGL(k_deep_hist, dim3(64), dim3(256), 0, s, pin, ctx->fragSum.as<FragFix>(), ctx->fragList.as<u32>(),
+                       (const u32*)ctx->tilePrevEnd.as<u32>(), (const float*)pa.p.as<float>(), bh_table_of(ctx, 1u << ctx->bhCapLog),
+                       ctx->dStatus.as<u32>());
+    ctx->denseHistIdx = idx;
+  }
   if (int rc__ = dbg_sync(ctx, "k_pack_pval")) return rc__;
   phase_end(ctx);
   HIPCHECK(hipGetLastError());
@@ -416,28 +464,8 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
   u32* misc = ctx->misc.as<u32>();
   const u32 nChrom = ctx->nChrom;
   phase_begin(ctx, "bh");
-  // The table of distinct p-values: open addressing, 2^bhCapLog slots.  It starts at 2^22 (16 MiB of keys: L2 /
-  // Infinity-Cache resident for the per-interval look-ups) and grows by 8x, for good, whenever an insertion
-  // gives up (ST_HASH_FULL: bh_global_add stops after BH_MAX_PROBE steps instead of crawling through a full
-  // table) -- the reference's chained hash (recordPval 277-295) has no limit either.
   u32 cap = 1u << ctx->bhCapLog;
-  auto bh_table = [&](u32 c) -> int {
-    const bool fresh = ctx->bhKeys.cap < (size_t)c * 4;
-    HIPCHECK(ctx->bhKeys.ensure((size_t)c * 4));
-    HIPCHECK(ctx->bhLens.ensure((size_t)c * 8));
-    HIPCHECK(ctx->bhQ.ensure((size_t)c * 4));
-    const bool freshKQ = ctx->bhKQ.cap < (size_t)c * 8;   // ({key, q} side by side for k_qlookup: free slots hold ~0)
-    HIPCHECK(ctx->bhKQ.ensure((size_t)c * 8));
-    if (freshKQ || ctx->bhDirty) HIPCHECK(hipMemsetAsync(ctx->bhKQ.p, 0xFF, (size_t)c * 8, s));
-    HIPCHECK(ctx->bhOutKeys.ensure((size_t)c * 4));
-    HIPCHECK(ctx->bhOutSlot.ensure((size_t)c * 4));
-    if (fresh || ctx->bhDirty) {  // normally the table comes back clean from the previous call (k_bh_clear)
-      HIPCHECK(hipMemsetAsync(ctx->bhKeys.p, 0xFF, (size_t)c * 4, s));
-      HIPCHECK(hipMemsetAsync(ctx->bhLens.p, 0, (size_t)c * 8, s));
-    }
-    ctx->bhDirty = true;
-    return GX_OK;
-  };
+  auto bh_table = [&](u32 c) -> int { return bh_table_prepare(ctx, c); };
   auto bh_grow = [&]() -> int {
     if (ctx->bhCapLog >= 28) {
       ctx->err = "p-value table full";
@@ -467,11 +495,29 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
 #undef GX_BH_HIST
     return GX_OK;
   };
+  // (one replicate without a control: k_pack_pval<.., HIST> left "bp at V" in bhDense and the deep values in the table)
+  bool fromDense = ctx->denseHistIdx >= 0 && ctx->denseHistIdx == ctx->finalIdx && ctx->world <= 1 && !ctx->forceColl;
+  ctx->denseHistIdx = -1;
+  ctx->denseHistUsed = fromDense;
   for (;;) {
+    if (fromDense) {
+      T = bh_table_of(ctx, cap);
+      HIPCHECK(hipMemsetAsync(misc + M_BHOVF, 0, 4, s));
+      hipLaunchKernelGGL(k_bh_from_dense, dim3(256), dim3(256), 0, s, (const u64*)ctx->bhDense.as<u64>(), ctx->pvLut.as<float>(), 1u, T,
+                         misc + M_BHOVF, ctx->dStatus.as<u32>());
+      if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;
+      Dlocal = ctx->mail->nMerged;
+      if (!(ctx->mail->status & ST_HASH_FULL)) break;
+      if (ctx->mail->status != ST_HASH_FULL) return status_to_rc(ctx, ctx->mail->status & ~ST_HASH_FULL);
+      HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 4, s));   // (a table too small: once more from the tight intervals, into a larger one)
+      if (int rc = bh_grow()) return rc;
+      fromDense = false;
+      ctx->denseHistUsed = false;
+      continue;
+    }
     if (int rc = bh_table(cap)) return rc;
     HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
-    T = BhTable{ctx->bhKeys.as<u32>(), ctx->bhLens.as<u64>(), cap - 1, ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(),
-                misc + M_BHCOUNT};
+    T = bh_table_of(ctx, cap);
     if (int rc__ = launch_hist()) return rc__;
     if (int rc__ = dbg_sync(ctx, "k_bh_hist")) return rc__;
     if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;

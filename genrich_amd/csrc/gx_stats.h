@@ -95,13 +95,22 @@ constexpr int PP_HOT = 1024;   // whole pileups below this have their p-value in
 // when somebody asks (gx_get_intervals, a further sample about to reuse the slots).
 // MASKS: whether the sweep masks are written.  Compile-time on purpose: with the same choice as a run-time
 // null check on the output pointers the compiler schedules the stores of the hot loop 35 % slower (measured).
-template <bool MASKS>
+// HIST (round 6): the genome-wide "bp at pileup V" histogram on the way -- hashPval (Genrich.c:300-327) for a replicate that turns
+// out to be the run's only one, without a control, with -q: p is a function of V, so Benjamini-Hochberg's {p -> bp} table is made
+// of ~100 sums (k_bh_from_dense) instead of a hash insertion per interval read back from the tight table (k_bh_hist: 0.25 ms at
+// hg38 / 50 M fragments).  Whole pileups inside the table go to an LDS histogram (two copies, by lane parity; 32-bit: a workgroup's
+// share of a genome is far below 2^32 bases), fractional ones to `dense` directly; the pileups beyond the table are k_deep_hist's.
+template <bool MASKS, bool HIST = false>
 __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const Scalars* __restrict__ sc,
                                                    const float* __restrict__ lutP, u32* __restrict__ ivEnd,
                                                    float* __restrict__ pOut, float thr, u64* __restrict__ sigMask,
-                                                   u64* __restrict__ skipMask, u32* __restrict__ st) {
+                                                   u64* __restrict__ skipMask, u32* __restrict__ st,
+                                                   const u32* __restrict__ tilePrevEnd = nullptr, u64* __restrict__ dense = nullptr) {
   __shared__ float hot[PP_HOT];  // indexed by the whole pileup c = V / 120 (consecutive banks, unlike V itself)
+  __shared__ u32 vh[HIST ? 2 * PV_WHOLE : 1];
   for (int i = threadIdx.x; i < PP_HOT; i += 256) hot[i] = lutP[i * GX_UNIT];
+  if (HIST)
+    for (u32 i = threadIdx.x; i < 2 * PV_WHOLE; i += 256) vh[i] = 0;
   __syncthreads();
   u32 neg = 0;
   const int wv = threadIdx.x >> 6, lane = lane_id();
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
   // the tight arrays; a 4,096-base tile alone holds ~110 intervals, too few for 64 x PP_UNROLL
   // lanes).  Two-deep software pipeline: headers of pair k+2 and the first 64 * PP_UNROLL (end, V)
   // values of pair k+1 are in flight while pair k is scored.
-  struct Hdr { u32 s0, s1, n0, n, dst; };
+  struct Hdr { u32 s0, s1, n0, n, dst, pe0, pe1; };   // (pe0 / pe1, HIST: where the two tiles' first intervals start)
   const u32 nUnits = (nTiles + 1) / 2;
   auto loadHdr = [&](u32 u) {
     Hdr h;
@@ -121,15 +130,18 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
     h.n0 = mid - h.dst;
     h.s1 = 0;
     h.n = h.n0;
+    h.pe0 = h.pe1 = 0;
+    if (HIST) h.pe0 = tilePrevEnd[t0];
     if (t0 + 1 < nTiles) {
       h.s1 = in.meta[t0 + 1].slot;
       h.n = in.tileIvOff[t0 + 2] - h.dst;
+      if (HIST) h.pe1 = tilePrevEnd[t0 + 1];
     }
     return h;
   };
   auto srcOf = [](const Hdr& h, u32 i) { return i < h.n0 ? h.s0 + i : h.s1 + (i - h.n0); };
   u32 u = blockIdx.x * 4 + wv;
-  Hdr h1{0, 0, 0, 0, 0}, h2{0, 0, 0, 0, 0};
+  Hdr h1{0, 0, 0, 0, 0, 0, 0}, h2{0, 0, 0, 0, 0, 0, 0};
   u32 e1[PP_UNROLL];
   int v1[PP_UNROLL];
 #pragma unroll
@@ -148,6 +160,9 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
   for (; u < nUnits; u += stride) {
     const Hdr h = h1;
     const u32 dst = h.dst, n = h.n;
+    // (HIST: where the pair's first interval starts, and the second tile's -- the end before it, or 0 on a new chromosome)
+    u32 carryPrev = h.pe0;
+    const u32 prevT1 = h.pe1;
     u32 e[PP_UNROLL];
     int v[PP_UNROLL];
 #pragma unroll
@@ -184,6 +199,19 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
           }
           ivEnd[dst + i] = e[k];
           pOut[dst + i] = p;
+        }
+        if (HIST) {  // the interval's length to its pileup's sum (all lanes take part in the shuffles)
+          u32 pe = (u32)__shfl_up((int)e[k], 1, 64);
+          const u32 first = k == 0 ? carryPrev : (u32)__shfl((int)e[k > 0 ? k - 1 : 0], 63, 64);
+          if (lane == 0) pe = first;
+          if (i == h.n0) pe = prevT1;
+          if (i < n && v[k] != V_MARK && (u32)v[k] < PV_LUT) {
+            const u32 len = e[k] - pe;
+            const u32 c = __umulhi((u32)v[k], 0x88888889u) >> 6;
+            if (c * GX_UNIT == (u32)v[k]) atomicAdd(&vh[(lane & 1) * PV_WHOLE + c], len);
+            else atomicAdd((unsigned long long*)&dense[v[k]], (unsigned long long)len);
+          }
+          if (k == PP_UNROLL - 1) carryPrev = (u32)__shfl((int)e[k], 63, 64);   // (the next batch's first interval follows lane 63's)
         }
         if (MASKS) {  // the sweep's significance / skip bit masks, while p is at hand (pre-zeroed words)
           const u64 sg = __ballot(p > thr), sk = __ballot(p == GX_SKIPF);
@@ -223,6 +251,13 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
     }
   }
   if (neg) atomicOr(st, ST_NEG_PILE);
+  if (HIST) {
+    __syncthreads();
+    for (u32 c = threadIdx.x; c < PV_WHOLE; c += 256) {
+      const u64 s2 = (u64)vh[c] + (u64)vh[PV_WHOLE + c];
+      if (s2) atomicAdd((unsigned long long*)&dense[c * GX_UNIT], (unsigned long long)s2);
+    }
+  }
 }
 
 // the intervals of the deep tiles whose pileup lies beyond the table.  k_deep_risky runs while the
@@ -352,6 +387,27 @@ __global__ __launch_bounds__(256) void k_bh_clear(BhTable T, u64* __restrict__ k
     T.keys[h] = EMPTY_KEY;
     T.lens[h] = 0;
     if (kq) kq[h] = ~0ull;
+  }
+}
+
+// k_pack_pval<.., HIST>'s companion: the intervals whose pileup lies beyond the table p(V) (deep tiles: a tower) straight into the
+// hash table, under the p-value k_pval_deep gave them
+__global__ __launch_bounds__(256) void k_deep_hist(PackIn in, const FragFix* __restrict__ ff, const u32* __restrict__ list,
+                                                   const u32* __restrict__ tilePrevEnd, const float* __restrict__ pTight, BhTable T,
+                                                   u32* __restrict__ st) {
+  const u32 nList = ff->nList;
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  for (u32 li = blockIdx.x * 4 + wv; li < nList; li += gridDim.x * 4) {
+    const u32 t = list[li];
+    const u32 src = in.meta[t].slot, dst = in.tileIvOff[t], n = in.tileIvOff[t + 1] - dst;
+    for (u32 i = lane; i < n; i += 64) {
+      const int v = in.looseV[src + i];
+      if (v != V_MARK && (u32)v >= PV_LUT) {
+        const u32 pe = i ? in.looseEnd[src + i - 1] : tilePrevEnd[t];
+        const float p = pTight[dst + i];
+        bh_global_add(T, p == 0.0f ? 0u : __float_as_uint(p), (u64)(in.looseEnd[src + i] - pe), st);
+      }
+    }
   }
 }
 

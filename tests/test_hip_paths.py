@@ -14,7 +14,7 @@ from test_hip_parity import assert_same_run, hip_backend
 pytestmark = pytest.mark.gpu
 
 FUSED, LOOSE, FELL_BACK, PT_GREW, PAIRS, FRAC_PAIRS, PILES_MADE = 1, 2, 4, 8, 16, 128, 256
-MERGE_P = 1024
+MERGE_P, PACK_HIST = 1024, 2048
 
 
 def _case(seed=11, n=90_000, lens=(400_000, 123_457, 16_384, 4_097, 5), **kw):
@@ -568,3 +568,29 @@ def test_control_merge_with_and_without_its_own_p_values(monkeypatch, merge_p, k
         o, h, flags = _run(case, params)
         assert bool(flags & MERGE_P) == merge_p, flags
         assert h.path_info() & PILES_MADE   # (assert_same_run asked for the intervals' pileup floats)
+
+
+# ---- BH's histogram summed by the tight table's kernel (round 6: k_pack_pval<.., HIST> -> k_bh_from_dense) ----
+
+@pytest.mark.parametrize("pack_hist", [True, False])
+@pytest.mark.parametrize("kind", ["plain", "deep", "multimap", "bed", "skipped"])
+def test_q_values_of_a_single_replicate_from_the_pileup_histogram(monkeypatch, pack_hist, kind):
+    """hashPval / computeQval (Genrich.c:300-401) for one replicate without a control: p is a function of the pileup, so the table
+    {p -> bp} is made of "bp at V" sums collected while the tight table is written -- whole pileups in LDS, the pileups beyond the
+    table p(V) (a tower deeper than 2184 reads) straight into the hash table -- or, as until round 5, by a hash insertion per interval
+    (GX_NO_PACK_HIST; also what fractional weights and -E regions take).  The lengths must add up to the genome (377-382: checked on
+    the device), and q, the peaks and their AUC must be the oracle's bits."""
+    if not pack_hist:
+        monkeypatch.setenv("GX_NO_PACK_HIST", "1")
+    lens = [700_000, 250_000, 4_097, 90_000]
+    tr = synth.make_fragments(lens, 140_000, 71, peak_every=20_000, tower_every=300_000, frac_tower=0.2 if kind == "deep" else 0.02)
+    if kind == "multimap":
+        tr = synth.add_multimap(tr, lens, 0.2, seed=72)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=None)])
+    if kind == "bed":
+        case["beds"] = [[0, 5_000, 100_000, 180_500], [10, 11], [], []]
+    if kind == "skipped":
+        case["skip"] = [False, True, False, False]
+    o, h, flags = _run(case, B.make_params(pq=0.05, qval=True, min_auc=20.0))
+    assert h.n_peaks > 0
+    assert bool(flags & PACK_HIST) == (pack_hist and kind in ("plain", "deep", "skipped")), flags
