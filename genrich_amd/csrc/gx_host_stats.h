@@ -548,7 +548,7 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
                        ctx->bhOutKeys.as<u32>(), ctx->bhOutSlot.as<u32>(), ctx->bhLens.as<u64>(), misc + M_BHCOUNT,
                        ctx->pvLut.as<float>(), ctx->bhDense.as<u64>(), (u32)ctx->rank);
     if (int rc__ = allreduce_words(ctx, ctx->bhDense.as<long long>(), words)) return rc__;
-    hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+    hipLaunchKernelGGL(k_bh_clear, dim3(256), dim3(256), 0, s, T);
     HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 4, s));
     hipLaunchKernelGGL(k_bh_from_dense, dim3(256), dim3(256), 0, s, (const u64*)ctx->bhDense.as<u64>(), ctx->pvLut.as<float>(), W, T,
                        misc + M_BHOVF, ctx->dStatus.as<u32>());
@@ -562,7 +562,7 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
     } else {
       // some rank holds more values outside the table than its region takes: every rank saw it, all go back to their own
       // tables and take the general exchange
-      hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T);
+      hipLaunchKernelGGL(k_bh_clear, dim3(256), dim3(256), 0, s, T);
       HIPCHECK(hipMemsetAsync(misc + M_BHCOUNT, 0, 8, s));
       if (int rc__ = launch_hist()) return rc__;
       if (int rc__ = mail_sync(ctx, nullptr, nullptr, nullptr, nullptr, misc + M_BHCOUNT)) return rc__;
@@ -616,7 +616,7 @@ if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     ctx->maskIdx = ctx->finalIdx;
     ctx->maskN = n;
     ctx->maskStride = stride;
-    hipLaunchKernelGGL(k_kq_build, dim3(64), dim3(256), 0, s, T, ctx->bhQ.as<float>(), ctx->bhKQ.as<u64>());
+    hipLaunchKernelGGL(k_kq_build, dim3(256), dim3(256), 0, s, T, ctx->bhQ.as<float>(), ctx->bhKQ.as<u64>());
     const u32 want = std::max(1u, (n + 4095) / 4096);
 #define GX_QLOOKUP(NT, CL, GRID)                                                                                                      \
   do {                                                                                                                                \
@@ -631,7 +631,7 @@ if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     else GX_QLOOKUP(256, 11, 4096);
 #undef GX_QLOOKUP
   }
-  hipLaunchKernelGGL(k_bh_clear, dim3(64), dim3(256), 0, s, T, ctx->bhKQ.as<u64>());
+  hipLaunchKernelGGL(k_bh_clear, dim3(256), dim3(256), 0, s, T, ctx->bhKQ.as<u64>());
   ctx->bhDirty = false;
 if (int rc__ = dbg_sync(ctx, "k_qlookup")) return rc__;
   phase_end(ctx);
