@@ -761,7 +761,7 @@ int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->rangeBhUsed ? GX_PATH_RANGE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u) | (ctx->fusedUsed && ctx->fracPairsUsed ? GX_PATH_FRAC_PAIRS : 0u) |
            (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u) | (ctx->packedUsed ? GX_PATH_PACKED : 0u) | (ctx->mergePUsed ? GX_PATH_MERGE_P : 0u) |
-           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u) | (ctx->fusedUsed && ctx->halfFastUsed ? GX_PATH_HALF2 : 0u);
+           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u);
   return GX_OK;
 }
 

@@ -192,21 +192,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     sbS--;
     nL1 = (nTiles + (1u << sbS) - 1) >> sbS;
   }
-  // The ordinary sample (unit weights, no -E regions) takes half-size bins as well, for another reason: a half bin fits half the
-  // LDS, two workgroups of k_sbtile_half share a CU, and the wavefronts' chains of dependent LDS round trips overlap eight to a
-  // SIMD instead of four (gx_sbtile.h).  Not when the average half bin would crowd its key array (the bins that do not fit are
-  // the second launch's, in the whole LDS).
-  bool halfFast = false;
-  if (pairs && !fracPairs && !ctx->hasBed && sbS == ctx->sbShift && sbS > 0 && !K.noHalf2 && !K.noHalfBins &&
-      ((nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1)) <= (u32)MAX_BINS_P) {
-    const u32 nHalf = (nTiles + (1u << (sbS - 1)) - 1) >> (sbS - 1);
-    if ((size_t)2 * nEv <= (size_t)std::max(1u, nHalf) * (SBT_KEYCAP_HALF - SBT_KEYCAP_HALF / 8)) {
-      halfFast = true;
-      sbS--;
-      nL1 = nHalf;
-    }
-  }
-  ctx->halfFastUsed = halfFast;
 
   // level-2 output: 16-bit tile offsets (S, E) / whole records (F), tile-contiguous
   if (unit32) {
@@ -470,7 +455,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
                             reinterpret_cast<const void*>(k_sbtile<true, false, false, SBT_TR, true>), reinterpret_cast<const void*>(k_sbtile<true, true, false, SBT_TR, true>),
                             reinterpret_cast<const void*>(k_sbtile<true, true, false, SBT_TR_DENSE, true>)})
         HIPCHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SBT_LDS_BYTES));
-      HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sbtile_half), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SBT_LDS_HALF_ASK));
       ctx->sbtLdsSet = true;
     }
     HIPCHECK(ctx->bigBins.ensure((size_t)(MAX_BINS_P + 4) * 4));
@@ -484,7 +468,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     const dim3 gAll(std::max(1u, nL1)), gBig(std::max(1u, std::min(nL1, (u32)ctx->numCU)));
     // a sample so dense that the average bin already holds more keys than the key array (ATAC cut sites of a deep
     // library): every bin takes the rounds of the second launch, the first one would only find that out bin by bin
-    const bool dense = ctx->pairsUsed && !halfFast && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 16);
+    const bool dense = ctx->pairsUsed && (size_t)2 * nEv > (size_t)std::max(1u, nL1) * (SBT_KEYCAP - SBT_KEYCAP / 16);
     if (dense) {
       so2.bigList = nullptr;
       // touched bases per round of the tile passes against keys per round of a bin (they share the LDS, gx_sbtile.h): what
@@ -514,9 +498,6 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
       // a workgroup per bin of the grid, dealt by the dispatcher; the ones beyond the list leave at once)
       hipLaunchKernelGGL((k_sbtile<true, false, false, SBT_TR, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       hipLaunchKernelGGL((k_sbtile<true, true, false, SBT_TR, true>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
-    } else if (ctx->pairsUsed && halfFast) {
-      hipLaunchKernelGGL(k_sbtile_half, gAll, dim3(SBT_NT), SBT_LDS_HALF_ASK, s, si, so2, ctx->dStatus.as<u32>());
-      hipLaunchKernelGGL((k_sbtile<true, true, false>), gBig, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
     } else if (ctx->pairsUsed) {
       hipLaunchKernelGGL((k_sbtile<true, false, false>), gAll, dim3(SBT_NT), SBT_LDS_BYTES, s, si, so2, ctx->dStatus.as<u32>());
       // the bins it left on its list (reads piled up: more keys than the key array holds, a tile with thousands of keys):

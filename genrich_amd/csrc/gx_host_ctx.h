@@ -164,7 +164,6 @@ struct Knobs {
   int noMergeP = 0;       // GX_NO_MERGE_P: the control merge leaves both pileups in its loose slots and k_pack_pairs scores them, as until round 5
   int forceHalfBins = 0;  // GX_FORCE_HALF_BINS: the 128-key level 1 on a small input
   int noHalfBins = 0;     // GX_NO_HALF_BINS
-  int noHalf2 = 0;        // GX_NO_HALF2: the ordinary sample in full-size bins, one workgroup of k_sbtile per CU (as until round 6)
   int fracHalfBins = 0;   // GX_FRAC_HALF_BINS: half-size bins also for a dense sample with fractional weights (measurements)
   int noEarlyColl = 0;    // GX_NO_EARLY_COLL: no all-reduce of the closed form of fragLen ahead of the tile stage
   int noDenseBh = 0;      // GX_NO_DENSE_BH: the range-partitioned exchange also without a control
@@ -185,7 +184,7 @@ const KnobDef KNOBS[] = {
     {"GX_FORCE_REC64", &Knobs::forceRec64, nullptr}, {"GX_FORCE_SLOWFRAG", &Knobs::forceSlowFrag, nullptr},
     {"GX_NO_FUSED", &Knobs::noFused, nullptr}, {"GX_NO_LOOSE", &Knobs::noLoose, nullptr}, {"GX_NO_PAIRS", &Knobs::noPairs, nullptr},
     {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_NO_PACK_HIST", &Knobs::noPackHist, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
-    {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_HALF2", &Knobs::noHalf2, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
+    {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
     {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
     {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
     {"GX_PT_JMAX", &Knobs::ptJmax, nullptr}, {"GX_FAULT", &Knobs::fault, nullptr}, {"GX_SBT_TR", &Knobs::sbtTr, nullptr},
@@ -263,7 +262,6 @@ struct gx_ctx {
                                 // k_sbtile<.., true>); on unit-weight data they give what the unit-weight instances give
   bool fusedOff = false;        // this sample: a super-bucket did not fit k_sbtile (the general chain runs instead)
   bool fusedUsed = false;       // the last build went through k_sbtile
-  bool halfFastUsed = false;    // ... by k_sbtile_half (half-size bins, two workgroups per CU)
   bool pairsUsed = false;       // ... on level 1's pair records (k_sort_a / k_sort_b)
   bool fracPairsUsed = false;   // ... with a weight class per record (fractional weights)
   bool earlyColl = false;       // this build: the ranks exchange the closed form of fragLen ahead of the tile stage

@@ -89,33 +89,16 @@ static_assert((1u << PgCfg<u32>::SHIFT) % SBT_SLOT == 0, "a slot never crosses a
 static_assert(TILE == 4096, "13-bit LDS keys: 12 bits of offset and the stream");
 static_assert((SBT_NW * sbt_tw(64)) % 4 == 0 && (SBT_NW * 96) % 4 == 0, "the scratch is cleared by 16-byte stores (TR: a multiple of 64)");
 constexpr u32 SBT_LDS_BYTES = 160u * 1024u - 512u;    // what a launch asks for (dynamic; the kernel's few static words come on top): one workgroup per CU
-// The HALF instance (round 6): bins of half the size (2^7 tiles; level 1 of the pair mode reaches 64 x 128 of them) in half the
-// LDS, so that TWO workgroups share a CU -- eight wavefronts per SIMD instead of four, one workgroup's loads / histogram /
-// scatter under the other's tile loop.  The tables shrink with the bin, the records in registers to four slots per wavefront
-// (16 K pair records), the scratch to 192 touched bases per round (a tile with a peak takes its rounds).
-constexpr u32 SBT_LDS_HALF = 80u * 1024u - 512u;
-#ifndef GX_SBT_HALF_ASK
-#define GX_SBT_HALF_ASK SBT_LDS_HALF
-#endif
-constexpr u32 SBT_LDS_HALF_ASK = GX_SBT_HALF_ASK;      // (measurements: asking for more than half the LDS keeps one workgroup per CU)
-constexpr int SBT_TILES_HALF = SBT_TILES / 2;
-constexpr int SBT_KP_HALF = 4;
-#ifndef GX_SBT_TR_HALF
-#define GX_SBT_TR_HALF 192
-#endif
-constexpr int SBT_TR_HALF = GX_SBT_TR_HALF;
 
-template <int NTL, int NSL>
-struct SbtLdsT {
-  static constexpr int TILES = NTL;
-  u32 hist[NTL];                           // [15:0] start keys, [31:16] end keys of the tile
-  u32 startC[NTL + 1];                     // keys (both streams) of the bin before the tile
-  int netPref[NTL];                        // start keys - end keys of the bin before the tile
-  u32 cur[2 * NTL];                        // scatter cursors: starts, ends
-  uint4 tinfo[NTL];                        // what a wavefront needs to start a tile, one 16-byte read: pos0, chromosome length,
+struct SbtLds {
+  u32 hist[SBT_TILES];                     // [15:0] start keys, [31:16] end keys of the tile
+  u32 startC[SBT_TILES + 1];               // keys (both streams) of the bin before the tile
+  int netPref[SBT_TILES];                  // start keys - end keys of the bin before the tile
+  u32 cur[2 * SBT_TILES];                  // scatter cursors: starts, ends
+  uint4 tinfo[SBT_TILES];                  // what a wavefront needs to start a tile, one 16-byte read: pos0, chromosome length,
                                            // TM_ flags | keys of the tile << 8, carry-in pileup (1/120)
-  u32 slotOff[NSL];                        // first key of a slot, as an index into its stream's page pool
-  u32 slotCnt[NSL];
+  u32 slotOff[2 * SBT_SLOTS];              // first key of a slot, as an index into its stream's page pool
+  u32 slotCnt[2 * SBT_SLOTS];
   u32 pre[2][NXCD + 1];
   __attribute__((aligned(8))) u32 scratch[40];
   u32 work;
@@ -123,23 +106,17 @@ struct SbtLdsT {
   u32 rnd[SBT_MAXR + 1];                   // pair mode: the tiles of round r are rnd[r] .. rnd[r + 1] - 1 (a bin beyond the key array)
   u32 nRounds;
   u32 nHeavy;                              // tiles of the round that the whole workgroup takes (sbt_heavy)
-  uint16_t heavy[NTL];
-  int netW[NTL];                           // fractional pairs: weight (1/120) a tile hands on (ends it receives count negative)
+  uint16_t heavy[SBT_TILES];
+  int netW[SBT_TILES];                     // fractional pairs: weight (1/120) a tile hands on (ends it receives count negative)
   u32 vsRed[2];                            // loose_vsig's reduction words (its own: tid 0 initialises the others right after)
   // what is left of the 160 KiB, split by TR: k_tile_fast's scratch, one per wavefront -- int [SBT_NW][sbt_tw(TR)] --, then
   // the bin's keys, tile after tile -- uint16_t [sbt_keycap(TR) + 192]: [11:0] offset, [15] end key (+ slack: a tile's
   // first 192 keys are read without a bounds check)
   __attribute__((aligned(16))) int dyn[4];
 };
-using SbtLds = SbtLdsT<SBT_TILES, 2 * (int)SBT_SLOTS>;
-using SbtLdsHalf = SbtLdsT<SBT_TILES_HALF, SBT_KP_HALF * SBT_NW>;
 constexpr u32 SBT_DYN_OFF = (u32)offsetof(SbtLds, dyn);
-constexpr u32 SBT_DYN_OFF_HALF = (u32)offsetof(SbtLdsHalf, dyn);
 // keys of a super-bucket (both streams) that fit the LDS next to the scratch for TR touched bases per round
-__host__ __device__ constexpr u32 sbt_keycap_of(u32 tr, u32 ldsBytes, u32 dynOff) { return ((ldsBytes - dynOff - SBT_NW * sbt_tw(tr) * 4u) / 2u - 192u) / 64u * 64u; }
-__host__ __device__ constexpr u32 sbt_keycap(u32 tr) { return sbt_keycap_of(tr, SBT_LDS_BYTES, SBT_DYN_OFF); }
-constexpr u32 SBT_KEYCAP_HALF = sbt_keycap_of(SBT_TR_HALF, SBT_LDS_HALF, SBT_DYN_OFF_HALF);   // ... of the HALF instance
-static_assert(SBT_KEYCAP_HALF >= 20480, "the HALF instance holds a half bin of the ordinary sample (17 K keys) with room");
+__host__ __device__ constexpr u32 sbt_keycap(u32 tr) { return ((SBT_LDS_BYTES - SBT_DYN_OFF - SBT_NW * sbt_tw(tr) * 4u) / 2u - 192u) / 64u * 64u; }
 constexpr u32 SBT_KEYCAP = sbt_keycap(SBT_TR);        // ... of the ordinary launch
 static_assert(sbt_keycap(192) > sbt_keycap(448) && sbt_keycap(448) >= 40960, "the split of the LDS");
 
@@ -513,18 +490,15 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
 // array holds (worked off in rounds of tiles), a tile with thousands of keys (sbt_heavy: the whole workgroup), more than
 // 32 K pair records.  It keeps no record in registers (every pass reads the bin's slots from global memory: they are
 // in L2), so that none of this costs the first launch -- the one every bin of an ordinary sample takes -- a register.
-template <bool PAIRS, bool BIG, bool FRAC, int TRC, bool BED, typename LT>
-__device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32* __restrict__ st, const u32 seg, LT& L) {
-  constexpr bool HALF = LT::TILES != SBT_TILES;
-  constexpr int NTL = LT::TILES;
-  static_assert(!HALF || (PAIRS && !BIG && !FRAC && !BED), "the HALF instance: unit-weight pair records, first launch");
+template <bool PAIRS, bool BIG, bool FRAC, int TRC, bool BED>
+__device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32* __restrict__ st, const u32 seg, SbtLds& L) {
   static_assert(PAIRS || !BIG, "the second launch exists in pair mode only");
   static_assert(PAIRS || !FRAC, "fractional weights ride pair records only");
   static_assert(!BED || (PAIRS && !FRAC), "-E regions: unit-weight pair records (the tiles with an edge are the second launch's)");
   constexpr u32 LENB = FRAC ? 9u : PAIR_LEN_BITS;      // a pair record's length bits (fractional: [11:9] the weight class)
   const bool fragTerms = FRAC && in.fragAcc != nullptr && (u32)__builtin_amdgcn_readfirstlane((int)in.ff->slow) != 0u;
   long long fhi = 0, flo = 0, bedExcl = 0;
-  constexpr int K = BIG ? 0 : (HALF ? SBT_KP_HALF : PAIRS ? SBT_KP : SBT_K);   // slots per wavefront of the (first) stream held in registers
+  constexpr int K = BIG ? 0 : (PAIRS ? SBT_KP : SBT_K);   // slots per wavefront of the (first) stream held in registers
   constexpr int KX = BIG ? SBT_KX : K;                    // ... and in all
   constexpr int KR = K ? K : 1;                           // (array sizes)
   constexpr u32 NSLOTS = (u32)KX * SBT_NW;
@@ -532,7 +506,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   // how the LDS behind the tables is split: constants of the instance (runtime values cost the rounds launch 12 %: measured)
   static_assert(TRC % 64 == 0 && TRC >= 192 && TRC <= 448, "touched bases per round");
   constexpr u32 trCap = (u32)TRC;
-  constexpr u32 tw = sbt_tw(trCap), scrWords = SBT_NW * tw, keyCap = HALF ? sbt_keycap_of(trCap, SBT_LDS_HALF, SBT_DYN_OFF_HALF) : sbt_keycap(trCap);
+  constexpr u32 tw = sbt_tw(trCap), scrWords = SBT_NW * tw, keyCap = sbt_keycap(trCap);
   int* const scr = L.dyn;
   uint16_t* const keysL = reinterpret_cast<uint16_t*>(L.dyn + scrWords);
   const u32 nSeg = in.nSeg;
@@ -598,7 +572,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   const u32 bedx = loadBed(ti);
   // scratch and tables start at zero
   for (u32 i = (u32)tid * 4; i < scrWords; i += SBT_NT * 4) *reinterpret_cast<int4*>(scr + i) = make_int4(0, 0, 0, 0);
-  if (tid < NTL) {
+  if (tid < SBT_TILES) {
     L.hist[tid] = 0;
     if (FRAC) L.netW[tid] = 0;
   }
@@ -854,7 +828,7 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
     const u32 nS = h & 0xFFFFu, nE = h >> 16;
     const u32 sc = ovf ? 0u : L.startC[tid];
     L.cur[tid] = sc;
-    L.cur[NTL + tid] = sc + nS;
+    L.cur[SBT_TILES + tid] = sc + nS;
     // (a base can only reach the reference's int16 limits where 32,766 starts, or ends, share a tile: the host then
     // replays the events -- gx_saturate.h; a bin worked off in rounds can hold that many)
     if (nS >= HOT16 / GX_UNIT || nE >= HOT16 / GX_UNIT) atomicOr(out.hot, 1u);
@@ -1050,13 +1024,6 @@ __device__ __forceinline__ void sbt_bin(const SbtIn& in, const SbtOut& out, u32*
   // with fractional ones the closed form is not used, FRAG_SLOW_FRAC)
   if (bedExcl && lane == 0) atomicAdd(&in.fragSum[(seg * SBT_NW + (u32)wv) % FRAG_SLOTS], (u64)(-(bedExcl / GX_UNIT)));
   if (bad && lane == 0) atomicOr(st, bad);
-}
-
-// the HALF instance of the first launch: two workgroups per CU (the register budget of eight wavefronts per SIMD: 64)
-__global__ __launch_bounds__(SBT_NT, 2) void k_sbtile_half(SbtIn in, SbtOut out, u32* __restrict__ st) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sbt_raw[];
-  SbtLdsHalf& L = *reinterpret_cast<SbtLdsHalf*>(sbt_raw);
-  sbt_bin<true, false, false, SBT_TR_HALF, false>(in, out, st, blockIdx.x, L);
 }
 
 template <bool PAIRS, bool BIG, bool FRAC, int TRC = SBT_TR, bool BED = false>

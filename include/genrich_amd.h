@@ -321,7 +321,6 @@ int gx_set_knob(gx_ctx* ctx, const char* name, const char* value);
 #define GX_PATH_PILES_MADE 256u /* bit 8: pileup floats (Pileup.cov, printed by -f / -k only) were written since the last gx_reset */
 #define GX_PATH_PACKED 512u  /* bit 9: the last sample's level 1 read 8-byte events in place (k_sort_a<.., PACKED>: gx_push_events_packed) */
 #define GX_PATH_PACK_HIST 2048u /* bit 11: -q on one replicate without control: BH's table was made of the "bp at pileup V" sums that the tight table's kernel left (k_pack_pval<.., HIST>), not by k_bh_hist */
-#define GX_PATH_HALF2 4096u /* bit 12: the last sample's tile stage ran on half-size bins, two workgroups per CU (k_sbtile_half) */
 #define GX_PATH_MERGE_P 1024u /* bit 10: the last control merge scored its intervals itself and left (end, p) in its loose slots (k_merge2<.., true> + k_pack_ep2) */
 #define GX_PATH_FRAC_PAIRS 128u /* bit 7: ... and the pair records carried a weight class (k_sort_a<FRAC> / k_sbtile<.., FRAC>: -s multimapping) */
 int gx_path_info(gx_ctx* ctx, unsigned* flags);
