@@ -561,6 +561,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   if (ctx->par.qval_opt || !masksReady)
     hipLaunchKernelGGL(k_set_misc, dim3(1), dim3(1), 0, s, misc, (u32)M_NIV, (u32)M_GENOME, (u64)g, n);
 
+  ctx->lazyQUsed = false;
   if (ctx->par.qval_opt) {
     if (int rc = bh_qvalues(ctx, fa, n, genomeOpt)) return rc;
   }
@@ -582,6 +583,10 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     src.end = fa.end.as<u32>();
     src.p = fa.p.as<float>();
     src.q = ctx->par.qval_opt ? fa.q.as<float>() : (const float*)nullptr;
+    if (ctx->par.qval_opt && fa.qLazy) {
+      src.kq = ctx->bhKQ.as<u64>();
+      src.kqMask = ctx->bhLiveCap - 1;
+    }
     src.chromOff = fa.chromOff.as<u32>();
     src.nWords = (n + 63) / 64;
     // the masks were filled by the pack kernels (p mode, one replicate) or by k_qlookup (q mode)
@@ -670,8 +675,13 @@ int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* en
     else std::fill(ctrl, ctrl + n, pa->ctrlIsConst ? pa->ctrlConst : 0.0f);
   }
   if (q) {
-    if (pa->q.p && ctx->par.qval_opt) HIPCHECK(hipMemcpy(q, pa->q.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));
-    else std::fill(q, q + n, GX_SKIP);
+    if (pa->q.p && ctx->par.qval_opt) {
+      const int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
+      if (int rc = ensure_q(ctx, ctx->reps[w], w)) return rc;
+      HIPCHECK(hipStreamSynchronize(ctx->stream));
+      HIPCHECK(hipMemcpy(q, pa->q.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));
+    }
+    if (!(pa->q.p && ctx->par.qval_opt)) std::fill(q, q + n, GX_SKIP);
   }
   return GX_OK;
 }
@@ -761,7 +771,7 @@ int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->rangeBhUsed ? GX_PATH_RANGE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u) | (ctx->fusedUsed && ctx->fracPairsUsed ? GX_PATH_FRAC_PAIRS : 0u) |
            (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u) | (ctx->packedUsed ? GX_PATH_PACKED : 0u) | (ctx->mergePUsed ? GX_PATH_MERGE_P : 0u) |
-           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u);
+           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u) | (ctx->lazyQUsed ? GX_PATH_LAZY_Q : 0u);
   return GX_OK;
 }
 

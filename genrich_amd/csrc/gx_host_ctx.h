@@ -131,6 +131,7 @@ struct PArray {  // p-value intervals of one replicate (or the Fisher combinatio
   // exact pileups and tile descriptors, taken out of the context (no copy; the context takes other buffers: pooled)
   DevBuf keptV, keptMeta;
   bool keptLoose = false;
+  bool qLazy = false;     // -q: q[] holds the candidates' intervals only; the rest on request (ensure_q)
   bool hasPiles = false;  // expt/ctrl filled (single-replicate logging)
   bool pilesDropped = false;  // ... deliberately not (gx_set_keep_pileups(0))
   float ctrlConst = 0.0f; // control value when ctrl is not materialised (no -E, no control file)
@@ -160,6 +161,7 @@ struct Knobs {
   int bhVariant = -1;     // GX_BH_VARIANT: the instance of k_bh_hist / k_qlookup (0: 256 threads, 2048-entry LDS tables -- rounds 2-5; 1: 1024 threads,
                           // one workgroup per CU, 8192 / 16384 entries; 2: 512 threads, 4096 / 8192 entries); default: chosen by the run
   int mergeWg = 0;        // GX_MERGE_WG: the control merge by k_merge2 (a workgroup per tile, rounds 2-5) instead of k_merge2w (a wavefront per tile)
+  int noLazyQ = 0;        // GX_NO_LAZY_Q: q of every interval by k_qlookup, as until round 6
   int noPackHist = 0;     // GX_NO_PACK_HIST: BH's histogram by k_bh_hist from the tight table also for a single replicate without control
   int noMergeP = 0;       // GX_NO_MERGE_P: the control merge leaves both pileups in its loose slots and k_pack_pairs scores them, as until round 5
   int forceHalfBins = 0;  // GX_FORCE_HALF_BINS: the 128-key level 1 on a small input
@@ -183,7 +185,7 @@ const KnobDef KNOBS[] = {
     {"GX_DEBUG", &Knobs::debug, nullptr}, {"GX_DEBUG_RETRY", &Knobs::debugRetry, nullptr}, {"GX_NO_SPIN", &Knobs::noSpin, nullptr},
     {"GX_FORCE_REC64", &Knobs::forceRec64, nullptr}, {"GX_FORCE_SLOWFRAG", &Knobs::forceSlowFrag, nullptr},
     {"GX_NO_FUSED", &Knobs::noFused, nullptr}, {"GX_NO_LOOSE", &Knobs::noLoose, nullptr}, {"GX_NO_PAIRS", &Knobs::noPairs, nullptr},
-    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_NO_PACK_HIST", &Knobs::noPackHist, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
+    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_NO_PACK_HIST", &Knobs::noPackHist, nullptr}, {"GX_NO_LAZY_Q", &Knobs::noLazyQ, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
     {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
     {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
     {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
@@ -305,6 +307,10 @@ struct gx_ctx {
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
   long long satDropped = 0;     // ... which dropped this many of them (gx_saturation_dropped)
+  bool lazyQUsed = false;       // the last -q run took k_sig_from_p / k_q_fill_cands (GX_PATH_LAZY_Q)
+  bool bhLive = false;          // the table of the last -q run is still there, with {key, q} of every value (lazy q: ensure_q)
+  u32 bhLiveCap = 0;
+  int bhLiveIdx = -1;           // ... and it belongs to reps[bhLiveIdx]
   bool bhDirty = false;         // the BH table was left with entries (an error path): wipe it before use
   u32 bhCapLog = 22;            // log2 of its slots (grows by 3 after ST_HASH_FULL)
   // sweep
@@ -372,7 +378,7 @@ void recycle(gx_ctx* ctx, DevBuf& b) {
 }
 
 // misc device words (u32 indices into ctx->misc)
-enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_BHOVF = 7, M_GENOME = 10 /* u64 */, M_NMERGED = 15,
+enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_BHOVF = 7, M_GENOME = 10 /* u64 */, M_NMERGED = 15, M_PSTAR = 14,
        // the sweep's counters are contiguous: one memset clears them
        M_TICKET2 = 16, M_SWCOUNT = 17, M_NPEAKS = 18, M_TICKET3 = 19, M_TICKET4 = 20, M_NHEADS = 21, M_PEAKBP = 22 /* u64 */,
        M_SWEEP_FIRST = 16, M_SWEEP_WORDS = 8, M_WORDS = 32 };

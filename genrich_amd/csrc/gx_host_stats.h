@@ -15,8 +15,18 @@ namespace {
 // Infinity-Cache resident for the per-interval look-ups) and grows by 8x, for good, whenever an insertion
 // gives up (ST_HASH_FULL: bh_global_add stops after BH_MAX_PROBE steps instead of crawling through a full
 // table) -- the reference's chained hash (recordPval 277-295) has no limit either.
+BhTable bh_table_of(gx_ctx* ctx, u32 cap);
+// (round 6: the table of the last -q run stays -- the {key, q} pairs answer the q-values nobody has asked for yet, ensure_q -- and is
+// freed here, when the next run wants it)
+void bh_release_live(gx_ctx* ctx) {
+  if (ctx->bhLive && !ctx->bhDirty)
+    hipLaunchKernelGGL(k_bh_clear, dim3(256), dim3(256), 0, ctx->stream, bh_table_of(ctx, ctx->bhLiveCap), ctx->bhKQ.as<u64>());
+  ctx->bhLive = false;
+  ctx->bhLiveIdx = -1;
+}
 int bh_table_prepare(gx_ctx* ctx, u32 c) {
   hipStream_t s = ctx->stream;
+  bh_release_live(ctx);
   const bool fresh = ctx->bhKeys.cap < (size_t)c * 4;
   HIPCHECK(ctx->bhKeys.ensure((size_t)c * 4));
   HIPCHECK(ctx->bhLens.ensure((size_t)c * 8));
@@ -456,6 +466,40 @@ int combine_replicates(gx_ctx* ctx) {
   return GX_OK;
 }
 
+// q of every interval of `fa` from the {key, q} table of the run (lookup 196-206), with the sweep's masks on the way (or without: nullptr)
+int qlookup_all(gx_ctx* ctx, PArray& fa, u32 cap, u64* sigMask, u64* skipMask) {
+  hipStream_t s = ctx->stream;
+  u32* misc = ctx->misc.as<u32>();
+  const int bhv = ctx->knob.bhVariant >= 0 ? ctx->knob.bhVariant : GX_BH_DEFAULT_VARIANT;
+  const u32 want = std::max(1u, (fa.n + 4095) / 4096);
+#define GX_QLOOKUP(NT, CL, GRID)                                                                                                      \
+  do {                                                                                                                                \
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qlookup<NT, CL>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                 (int)(8u << CL)));                                                                                   \
+    hipLaunchKernelGGL((k_qlookup<NT, CL>), dim3(std::min(want, (u32)(GRID))), dim3(NT), (size_t)(8u << CL), s, fa.p.as<float>(),     \
+                       misc + M_NIV, ctx->bhKQ.as<u64>(), cap - 1, fa.q.as<float>(), ctx->par.thr,                                  \
+                       sigMask, skipMask, ctx->dStatus.as<u32>());                              \
+  } while (0)
+  if (bhv == 1) GX_QLOOKUP(1024, 14, ctx->numCU);
+  else if (bhv == 2) GX_QLOOKUP(512, 13, 2 * ctx->numCU);
+  else GX_QLOOKUP(256, 11, 4096);
+#undef GX_QLOOKUP
+  return GX_OK;
+}
+
+// gx_get_intervals' q-values of a -q run whose sweep looked up the candidates' intervals only: the whole array, once
+int ensure_q(gx_ctx* ctx, PArray& pa, int idx) {
+  if (!pa.qLazy) return GX_OK;
+  if (!ctx->bhLive || ctx->bhLiveIdx != idx || !pa.q.p) {
+    ctx->err = "the q-values of this run are gone (another run has taken the table)";
+    return GX_ERR_ORDER;
+  }
+  HIPCHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->misc.as<u32>() + M_NIV), (int)pa.n, 1, ctx->stream));
+  if (int rc = qlookup_all(ctx, pa, ctx->bhLiveCap, nullptr, nullptr)) return rc;
+  pa.qLazy = false;
+  return GX_OK;
+}
+
 // computeQval / saveQval (Genrich.c:352-401, 212-250) for the final p-array `fa` of n intervals: the genome-wide table
 // {p -> bp} (with several ranks: after the exchange, gx_host_coll.h), its sort and suffix scan, q per interval and the
 // sweep's masks on the way.  genomeOpt: the genome length was computed (not -L): the lengths must add up to it
@@ -609,6 +653,7 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
 if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
   }
   HIPCHECK(pooled(ctx, fa.q, (size_t)n * 4 + 16));
+  const bool lazyQ = !ctx->knob.noLazyQ;
   {  // q-values and, on the way, the sweep's significance / SKIP masks
     const size_t stride = (size_t)((n + 63) / 64) + 2;
     HIPCHECK(ctx->swMask.ensure(stride * 8 * 3));
@@ -616,23 +661,24 @@ if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     ctx->maskIdx = ctx->finalIdx;
     ctx->maskN = n;
     ctx->maskStride = stride;
-    hipLaunchKernelGGL(k_kq_build, dim3(256), dim3(256), 0, s, T, ctx->bhQ.as<float>(), ctx->bhKQ.as<u64>());
-    const u32 want = std::max(1u, (n + 4095) / 4096);
-#define GX_QLOOKUP(NT, CL, GRID)                                                                                                      \
-  do {                                                                                                                                \
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qlookup<NT, CL>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                 (int)(8u << CL)));                                                                                   \
-    hipLaunchKernelGGL((k_qlookup<NT, CL>), dim3(std::min(want, (u32)(GRID))), dim3(NT), (size_t)(8u << CL), s, fa.p.as<float>(),     \
-                       misc + M_NIV, ctx->bhKQ.as<u64>(), cap - 1, fa.q.as<float>(), ctx->par.thr,                                  \
-                       ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride, ctx->dStatus.as<u32>());                              \
-  } while (0)
-    if (bhv == 1) GX_QLOOKUP(1024, 14, ctx->numCU);
-    else if (bhv == 2) GX_QLOOKUP(512, 13, 2 * ctx->numCU);
-    else GX_QLOOKUP(256, 11, 4096);
-#undef GX_QLOOKUP
+    HIPCHECK(hipMemsetAsync(misc + M_PSTAR, 0xFF, 4, s));
+    hipLaunchKernelGGL(k_kq_build, dim3(256), dim3(256), 0, s, T, ctx->bhQ.as<float>(), ctx->bhKQ.as<u64>(), ctx->par.thr, misc + M_PSTAR);
+    if (lazyQ) {
+      // q never falls as p grows: the masks from one compare per interval; q itself inside the candidates (run_sweep: k_q_fill_cands)
+      // and for whoever asks for the array (ensure_q)
+      hipLaunchKernelGGL(k_sig_from_p, dim3(std::max(1u, std::min((n + 1023) / 1024, (u32)(8 * ctx->numCU)))), dim3(256), 0, s, fa.p.as<float>(),
+                         misc + M_NIV, misc + M_PSTAR, ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride);
+    } else {
+      if (int rc__ = qlookup_all(ctx, fa, cap, ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride)) return rc__;
+    }
   }
-  hipLaunchKernelGGL(k_bh_clear, dim3(256), dim3(256), 0, s, T, ctx->bhKQ.as<u64>());
+  fa.qLazy = lazyQ;
+  ctx->lazyQUsed = lazyQ;
   ctx->bhDirty = false;
+  ctx->bhLive = true;   // (freed by the next run that wants the table: bh_release_live)
+  ctx->bhLiveCap = cap;
+  ctx->bhLiveIdx = ctx->finalIdx;
+  if (!lazyQ) bh_release_live(ctx);
 if (int rc__ = dbg_sync(ctx, "k_qlookup")) return rc__;
   phase_end(ctx);
   HIPCHECK(hipGetLastError());

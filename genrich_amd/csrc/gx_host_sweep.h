@@ -9,6 +9,9 @@ struct SweepSrc {
   const u32* end = nullptr;
   const float* p = nullptr;
   const float* q = nullptr;
+  // -q with lazy q-values: `q` is written for the candidates' intervals only, by k_q_fill_cands from the run's {key, q} table
+  const u64* kq = nullptr;
+  u32 kqMask = 0;
   // the sweep on the loose slots (LooseCtl): `end` = the loose ends, p = the table p(V) looked up with the slots' exact
   // pileups `V`; the masks are [significant | first of its chromosome], `mStride` apart, and there are no SKIP intervals
   const int* V = nullptr;
@@ -95,6 +98,9 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
       hipLaunchKernelGGL(k_cand_hdr, dim3(std::max(1u, std::min((cap + 255) / 256, 4096u))), dim3(256), 0, s, SM, S.end, runStart,
                          runEnd, misc + M_SWCOUNT, ctx->headPos.as<u32>(), misc + M_NHEADS, ctx->candHdr.as<uint4>(),
                          ctx->longList.as<u32>(), misc + M_TICKET3);
+      if (S.kq)
+        hipLaunchKernelGGL(k_q_fill_cands, dim3(std::max(1u, std::min((cap + 3) / 4, 32768u))), dim3(256), 0, s,
+                           ctx->candHdr.as<uint4>(), misc + M_NHEADS, S.p, S.kq, S.kqMask, const_cast<float*>(S.q), ctx->dStatus.as<u32>());
       {
         const dim3 grid(std::max(1u, std::min((cap + 15) / 16, 16384u)));  // 16 candidates per workgroup and round
         const dim3 gridW(std::max(1u, std::min((cap + 3) / 4, (u32)(8 * ctx->numCU))));

@@ -414,11 +414,95 @@ __global__ __launch_bounds__(256) void k_deep_hist(PackIn in, const FragFix* __r
 // {key, q} of every claimed slot side by side (round 6): k_qlookup's probe of a value that its LDS cache does not hold -- a tenth of
 // the intervals of Fisher-combined replicates, whose p-values are nearly all different around the peaks -- was two dependent 128-byte
 // fetches (the key, then q of the slot); one now.  Free slots hold ~0 (EMPTY_KEY in the low word).
-__global__ __launch_bounds__(256) void k_kq_build(BhTable T, const float* __restrict__ qOfSlot, u64* __restrict__ kq) {
+// (pStar, round 6: the smallest p -- as its bits: the order of non-negative floats -- whose q exceeds the threshold.  q never falls as p
+// grows (computeQval's running minimum, 392-399), so "q > thr" (callPeaks 1015) is "p >= pStar": the sweep's significance bits come from
+// one compare per interval, k_sig_from_p, and q is looked up where somebody reads it -- inside the candidates, k_q_fill_cands)
+__global__ __launch_bounds__(256) void k_kq_build(BhTable T, const float* __restrict__ qOfSlot, u64* __restrict__ kq, float thr,
+                                                  u32* __restrict__ pStar) {
   const u32 n = *T.counter;
+  u32 mn = 0xFFFFFFFFu;
   for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const u32 h = T.outSlot[i];
-    kq[h] = (u64)T.keys[h] | ((u64)__float_as_uint(qOfSlot[h]) << 32);
+    const u32 key = T.keys[h];
+    const float q = qOfSlot[h];
+    kq[h] = (u64)key | ((u64)__float_as_uint(q) << 32);
+    if (q > thr) mn = min(mn, key);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mn = min(mn, (u32)__shfl_xor((int)mn, d, 64));
+  if (lane_id() == 0 && mn != 0xFFFFFFFFu) atomicMin(pStar, mn);
+}
+
+// a value's q from the {key, q} table (lookup 196-206); the probe ends at a free slot (a value that was never inserted: the caller raises
+// the reference's "does not match p-value length")
+__device__ __forceinline__ bool kq_probe(const u64* __restrict__ kq, u32 capMask, u32 key, float* q) {
+  u32 h = bh_hash(key) & capMask;
+  u64 ge;
+  while ((u32)(ge = kq[h]) != key && (u32)ge != EMPTY_KEY) h = (h + 1) & capMask;
+  *q = __uint_as_float((u32)(ge >> 32));
+  return (u32)ge == key;
+}
+
+// the sweep's significance / SKIP masks from the p-values and pStar: whole words, four per iteration and wavefront
+__global__ __launch_bounds__(256) void k_sig_from_p(const float* __restrict__ p, const u32* __restrict__ nPtr, const u32* __restrict__ pStar,
+                                                    u64* __restrict__ sigMask, u64* __restrict__ skipMask) {
+  const u32 n = *nPtr, nw = (n + 63) >> 6, ps = *pStar;
+  for (u32 w0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; w0 < nw; w0 += gridDim.x * 16) {
+    float pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 i = ((w0 + k) << 6) + lane_id();
+      pv[k] = i < n ? p[i] : GX_SKIPF;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 i = ((w0 + k) << 6) + lane_id();
+      const bool skip = pv[k] == GX_SKIPF;
+      const u32 key = pv[k] == 0.0f ? 0u : __float_as_uint(pv[k]);
+      const u64 sg = __ballot(i < n && !skip && key >= ps), sk = __ballot(i < n && skip);
+      if (lane_id() == 0 && w0 + k < nw) {
+        sigMask[w0 + k] = sg;
+        skipMask[w0 + k] = sk;
+      }
+    }
+  }
+}
+
+// q of the intervals inside the candidates (what updatePeak reads, 943-970): one wavefront per candidate, 64 probes per step.  Everything
+// else of q[] stays unwritten until somebody asks for the array (ensure_q: k_qlookup).
+__global__ __launch_bounds__(256) void k_q_fill_cands(const uint4* __restrict__ hdr, const u32* __restrict__ nCands, const float* __restrict__ p,
+                                                      const u64* __restrict__ kq, u32 capMask, float* __restrict__ q, u32* __restrict__ st) {
+  const u32 C = *nCands;
+  for (u32 c = blockIdx.x * 4 + (threadIdx.x >> 6); c < C; c += gridDim.x * 4) {
+    const uint4 h = hdr[c];
+    // (four steps in flight: the p-values, then the four first probes side by side -- a probe is a line of a table that no cache holds)
+    for (u32 i0 = h.x + lane_id(); i0 <= h.y; i0 += 256) {
+      float pv[4];
+      u32 key[4], hs[4];
+      u64 ge[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) pv[k] = i0 + k * 64 <= h.y ? p[i0 + k * 64] : GX_SKIPF;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        key[k] = pv[k] == 0.0f ? 0u : __float_as_uint(pv[k]);
+        hs[k] = bh_hash(key[k]) & capMask;
+        ge[k] = pv[k] != GX_SKIPF ? kq[hs[k]] : 0ull;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (i0 + k * 64 > h.y) continue;
+        float qv = GX_SKIPF;
+        if (pv[k] != GX_SKIPF) {
+          while ((u32)ge[k] != key[k] && (u32)ge[k] != EMPTY_KEY) {
+            hs[k] = (hs[k] + 1) & capMask;
+            ge[k] = kq[hs[k]];
+          }
+          if ((u32)ge[k] == key[k]) qv = __uint_as_float((u32)(ge[k] >> 32));
+          else atomicOr(st, ST_BH_LEN);
+        }
+        q[i0 + k * 64] = qv;
+      }
+    }
   }
 }
 
@@ -904,7 +988,7 @@ __global__ __launch_bounds__(NT) void k_qlookup(const float* __restrict__ p, con
         q[i] = qv;
       }
       const u64 sg = __ballot(i < n && qv > thr), sk = __ballot(i < n && qv == GX_SKIPF);
-      if (lane_id() == 0 && w0 + k < nw) {
+      if (sigMask && lane_id() == 0 && w0 + k < nw) {   // (nullptr: the array alone, for gx_get_intervals -- ensure_q)
         sigMask[w0 + k] = sg;
         skipMask[w0 + k] = sk;
       }

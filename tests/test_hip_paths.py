@@ -14,7 +14,7 @@ from test_hip_parity import assert_same_run, hip_backend
 pytestmark = pytest.mark.gpu
 
 FUSED, LOOSE, FELL_BACK, PT_GREW, PAIRS, FRAC_PAIRS, PILES_MADE = 1, 2, 4, 8, 16, 128, 256
-MERGE_P, PACK_HIST = 1024, 2048
+MERGE_P, PACK_HIST, LAZY_Q = 1024, 2048, 8192
 
 
 def _case(seed=11, n=90_000, lens=(400_000, 123_457, 16_384, 4_097, 5), **kw):
@@ -594,3 +594,39 @@ def test_q_values_of_a_single_replicate_from_the_pileup_histogram(monkeypatch, p
     o, h, flags = _run(case, B.make_params(pq=0.05, qval=True, min_auc=20.0))
     assert h.n_peaks > 0
     assert bool(flags & PACK_HIST) == (pack_hist and kind in ("plain", "deep", "skipped")), flags
+
+
+# ---- q looked up where it is read (round 6: k_sig_from_p + k_q_fill_cands; the whole array on request) ----
+
+@pytest.mark.parametrize("lazy", [True, False])
+@pytest.mark.parametrize("kind", ["single", "ctrl", "reps3", "skipped_ctrl"])
+def test_q_values_inside_the_candidates_only_and_the_whole_array_on_request(monkeypatch, lazy, kind):
+    """computeQval's q never falls as p grows (Genrich.c:392-399: a running minimum over the sorted values), so callPeaks' test
+    `q > threshold` (1015) is `p >= the smallest p whose q passes`: the sweep's bits come from one compare per interval, updatePeak's
+    q-values (943-970) from the run's {p, q} table for the candidates' intervals only, and gx_get_intervals has the whole array looked
+    up when somebody asks (the table of the last run stays until the next one wants it).  GX_NO_LAZY_Q: every interval's q by
+    k_qlookup, as until round 5.  Either way: the oracle's q per interval, peaks and AUC bits."""
+    if not lazy:
+        monkeypatch.setenv("GX_NO_LAZY_Q", "1")
+    lens = [600_000, 200_000, 4_097, 70_000]
+    reps = []
+    for sd in ([81] if kind in ("single", "ctrl", "skipped_ctrl") else [81, 83, 85]):
+        tr = synth.make_fragments(lens, 120_000, sd, peak_every=20_000, tower_every=250_000)
+        ct = synth.make_fragments(lens, 100_000, sd + 100, peak_every=0, tower_every=0) if kind in ("ctrl", "skipped_ctrl") else None
+        reps.append(dict(save=None, treat=tr, ctrl=ct))
+    case = dict(lens=lens, replicates=reps)
+    if kind == "skipped_ctrl":
+        case["skip"] = [False, True, False, False]
+    o, h, flags = _run(case, B.make_params(pq=0.05, qval=True, min_auc=20.0))
+    assert h.n_peaks > 0
+    assert bool(flags & LAZY_Q) == lazy, flags
+    # a second sweep on the same context: the first one's table is released and built again, q asked for AFTER the peaks
+    h.find_peaks()
+    assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
+    for c in range(len(lens)):
+        if case.get("skip", [False] * len(lens))[c]:
+            continue
+        eh, ch = h.get_intervals(-1, c, piles=False)
+        eo, co = o.get_intervals(-1, c)
+        assert np.array_equal(eh, eo)
+        assert np.array_equal(ch["q"].view(np.uint32), co["q"].view(np.uint32))
