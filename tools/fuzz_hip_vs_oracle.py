@@ -79,7 +79,12 @@ def run_paths(seed):
         knobs["GX_NO_PAIRS"] = "1"
     if rng.random() < 0.15:
         knobs["GX_NO_FRAC_PAIRS"] = "1"
-    for k in ("GX_SBSHIFT", "GX_FORCE_HALF_BINS", "GX_NO_PAIRS", "GX_NO_FRAC_PAIRS"):
+    # (round 6's alternatives: q of every interval by k_qlookup, BH's histogram by insertion, the control merge by a workgroup per
+    # tile / leaving both pileups)
+    for k, pr in (("GX_NO_LAZY_Q", 0.25), ("GX_NO_PACK_HIST", 0.2), ("GX_MERGE_WG", 0.15), ("GX_NO_MERGE_P", 0.15)):
+        if rng.random() < pr:
+            knobs[k] = "1"
+    for k in PATH_KNOBS:
         os.environ.pop(k, None)
     os.environ.update(knobs)
     o = B.Oracle(params)
@@ -117,6 +122,7 @@ def describe(case):
     return dict(lens=case["lens"], skip=case.get("skip"), beds=case.get("beds"), reps=reps)
 
 
+PATH_KNOBS = ("GX_SBSHIFT", "GX_FORCE_HALF_BINS", "GX_NO_PAIRS", "GX_NO_FRAC_PAIRS", "GX_NO_LAZY_Q", "GX_NO_PACK_HIST", "GX_MERGE_WG", "GX_NO_MERGE_P")
 mid = "--mid" in sys.argv
 paths = "--paths" in sys.argv
 import time  # noqa: E402
@@ -132,7 +138,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             print("seed", seed, knobs, "pieces", pieces, "path flags", flags, flush=True)
         except Exception as ex:  # noqa: BLE001
             bad += 1
-            print("seed", seed, type(ex).__name__, str(ex)[:300], {k: os.environ.get(k) for k in ("GX_SBSHIFT", "GX_FORCE_HALF_BINS", "GX_NO_PAIRS", "GX_NO_FRAC_PAIRS")}, flush=True)
+            print("seed", seed, type(ex).__name__, str(ex)[:300], {k: os.environ.get(k) for k in PATH_KNOBS}, flush=True)
             print("   ", describe(mid_case(seed)[0]), flush=True)
         continue
     case, params = mid_case(seed) if mid else T._random_case(seed, 50 if "--x50" in sys.argv else 1)
