@@ -211,7 +211,10 @@ int gx_get_peaks(gx_ctx* ctx, gx_peak* out, size_t cap);
  * which: replicate index r (0..n-1) = that replicate's p-value intervals,
  *        GX_IV_FINAL = the intervals peaks were called on (combined when n > 1).
  * Arrays (any may be NULL) receive n_iv entries: end[], expt[] and ctrl[] pileups
- * (only meaningful for a single replicate, as in the reference), p[], q[]. */
+ * (only meaningful for a single replicate, as in the reference), p[], q[].
+ * q (with -q, GX_IV_FINAL only; saveQval 212-250): gx_find_peaks looks q up where updatePeak reads it -- inside the candidate
+ * peaks -- and the whole array is made when it is first asked for here, from the run's {p -> q} table, which stays on the device
+ * until the next gx_find_peaks of the context takes it (then: GX_ERR_ORDER for an array that was never asked for). */
 #define GX_IV_FINAL (-1)
 int gx_interval_count(gx_ctx* ctx, int which, int chrom, size_t* n_iv);
 int gx_total_intervals(gx_ctx* ctx, int which, size_t* n_iv); /* over all chromosomes */
