@@ -86,7 +86,7 @@ def source_hash():
 
 
 PATH_BITS = ((1, "fused"), (16, "pairs"), (128, "frac_pairs"), (2, "loose_sweep"), (4, "fell_back"), (8, "pt_grew"), (32, "dense_bh"),
-             (64, "range_bh"), (1024, "merge_p"), (2048, "pack_hist"), (8192, "lazy_q"))
+             (64, "range_bh"), (1024, "merge_p"), (2048, "pack_hist"), (8192, "lazy_q"), (16384, "late_loose"))
 
 
 def decode_path(flags):

@@ -505,6 +505,7 @@ int gx_pvalues(gx_ctx* ctx) {
     pa.loose = true;
     // (the tile stage wrote the sweep's significance bits, in loose-slot index space: LooseCtl)
     pa.looseSweep = ctx->looseOk && !ctx->par.qval_opt && !ctx->knob.noLoose;
+    pa.latePending = pa.looseSweep && ctx->lateLoose;   // (its bits are still to be written: k_loose_late, by gx_find_peaks)
     pa.looseStride = ctx->looseStride;
     if (pa.looseSweep) pa.chromLooseOff = std::move(ctx->chromLooseOff);
     ctx->looseOk = false;
@@ -571,6 +572,14 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   SweepSrc src{};
   src.nChrom = nChrom;
   if (looseFast) {
+    ctx->lateLooseUsed = fa.lateLoose || fa.latePending;
+    if (fa.latePending) {
+      hipLaunchKernelGGL(k_loose_late, dim3(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s,
+                         ctx->tileSlot.as<u32>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->nTiles,
+                         ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseCtl.as<LooseCtl>(), ctx->swMask.as<u64>());
+      fa.latePending = false;
+      fa.lateLoose = true;
+    }
     src.end = ctx->looseEnd.as<u32>();
     src.V = ctx->looseV.as<int>();
     src.p = ctx->pvLut.as<float>();
@@ -771,7 +780,7 @@ int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->rangeBhUsed ? GX_PATH_RANGE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u) | (ctx->fusedUsed && ctx->fracPairsUsed ? GX_PATH_FRAC_PAIRS : 0u) |
            (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u) | (ctx->packedUsed ? GX_PATH_PACKED : 0u) | (ctx->mergePUsed ? GX_PATH_MERGE_P : 0u) |
-           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u) | (ctx->lazyQUsed ? GX_PATH_LAZY_Q : 0u);
+           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u) | (ctx->lazyQUsed ? GX_PATH_LAZY_Q : 0u) | (ctx->looseSwept && ctx->lateLooseUsed ? GX_PATH_LATE_LOOSE : 0u);
   return GX_OK;
 }
 

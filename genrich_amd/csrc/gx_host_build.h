@@ -209,9 +209,15 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // lambda ahead of the tile stage (closed form of fragLen; LooseCtl): one rank, a treatment sample, -p
   const bool wantEarly = !isCtrl && (!multiRank || earlyColl) && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !forceSlowFrag &&
                          !ctx->sawFrac;  // (fractional weights: the closed form of fragLen is off, lambda only comes with the sample's end)
+  // (round 6) ... and when lambda only comes with the sample's end -- fractional weights: no closed form of fragLen -- the sweep still
+  // walks the loose slots: k_loose_late writes the bits and the fillers once the table p(V) is there (finish_scalars), instead of
+  // k_pack_pval's copy of every interval into the tight table.  One rank, a treatment sample, -p, no -E regions, the fused tile stage.
+  const bool wantLate = !wantEarly && !isCtrl && !multiRank && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !K.noLateLoose &&
+                        fused && !forceSlowFrag;
+  ctx->lateLoose = wantLate;
   const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
   u64* sigMask = nullptr;
-  if (wantEarly) {
+  if (wantEarly || wantLate) {
     // the sweep's masks in loose-slot index space: [significant | first of its chromosome]
     ctx->looseStride = (looseCap + 63) / 64 + 2;
     HIPCHECK(ctx->swMask.ensure(ctx->looseStride * 8 * 3));
@@ -267,15 +273,15 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     base += lbTBytes;
     ctx->lbIv.view(base, lbIBytes);    // k_scan_iv's two
     if (!reuseSort) {
-      const size_t nA = total / 16, nB = wantEarly ? ctx->looseStride * 8 * 2 / 16 : 0;
+      const size_t nA = total / 16, nB = wantEarly || wantLate ? ctx->looseStride * 8 * 2 / 16 : 0;
       static_assert(sizeof(Scalars) / 8 <= 256, "one workgroup clears the scalars");
       hipLaunchKernelGGL(k_build_init, dim3((u32)std::min<size_t>((nA + nB + 1023) / 1024, 4096)), dim3(256), 0, s,
                          ctx->dScal.as<Scalars>(), ctx->beginPending ? 1 : 0, ctx->beginGenome, ctx->zeroArena.as<uint4>(), nA,
-                         wantEarly ? ctx->swMask.as<uint4>() : (uint4*)nullptr, nB);
+                         wantEarly || wantLate ? ctx->swMask.as<uint4>() : (uint4*)nullptr, nB);
       ctx->beginPending = false;
     } else {
       if (int rc__ = flush_begin(ctx)) return rc__;
-      if (wantEarly) HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, ctx->looseStride * 8 * 2, s));
+      if (wantEarly || wantLate) HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, ctx->looseStride * 8 * 2, s));
       // what the tile stage and the scans of the first attempt left: the per-tile tables and look-back arrays (the
       // arena's tail), the loose-sweep block, the correction words of fragLen and the wide-tile count
       char* tail = ctx->tileCnt[0].as<char>();
@@ -418,7 +424,8 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   Scalars* ds = ctx->dScal.as<Scalars>();
   long long* acc = isCtrl ? ds->ctrlAcc : ds->fragAcc;  // zero since gx_sample_begin(treatment)
   TileOut to{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(),
-             ctx->tileDeep.as<u32>(), sigMask, wantEarly ? ctl : (LooseCtl*)nullptr};
+             ctx->tileDeep.as<u32>(), sigMask, wantEarly || wantLate ? ctl : (LooseCtl*)nullptr};   // (late: `enabled` stays 0 -- no bits, no
+                                                                                                    // fillers; a pileup beyond the table still says so)
   BedIn bin{ctx->dBedTileOff.as<u32>(), ctx->dBedEdge.as<u32>(), ctx->dTileSave0.as<uint8_t>()};
   HIPCHECK(pooled(ctx, ctx->tileMeta, (size_t)(nTiles + 1) * sizeof(TileMeta)));
   HIPCHECK(ctx->wideList.ensure((size_t)(nTiles + 1) * 4));
@@ -554,7 +561,7 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
     FragSelect fsel{ff, acc, ctx->world > 1 || ctx->forceColl ? ctx->dColl.as<long long>() : (long long*)nullptr,
                     ctx->nWide.as<u32>() + 1, ctx->dStatus.as<u32>(), ctx->dChrom.as<DChrom>(), nChrom, out.chromIvOff.as<u32>(),
                     ctx->misc.as<u32>() + M_NIV, ds, isCtrl, ctx->chromLooseOff.as<u32>(), ctx->tileSlot.as<u32>(), nTiles, ctl,
-                    wantEarly ? ctx->swMask.as<u64>() + ctx->looseStride : (u64*)nullptr};
+                    wantEarly || wantLate ? ctx->swMask.as<u64>() + ctx->looseStride : (u64*)nullptr};
     ctx->closeSel = fsel;
     ctx->closeSeq = 0;
     if (closeInScan) {
@@ -646,7 +653,10 @@ int finish_scalars(gx_ctx* ctx, int isCtrl) {
     // (when the tile stage had lambda already -- LooseCtl -- and it has not changed, only the deep tiles' part runs)
     hipLaunchKernelGGL(k_pval_lut, dim3(PV_LUT / 256 + DEEP_BLOCKS), dim3(256), 0, s, ds, ctx->pvLut.as<float>(),
                        ctx->dRisk.as<RiskBuf>(), ctx->dDeep.as<DeepTab>(), pin, ctx->fragSum.as<FragFix>(),
-                       ctx->fragList.as<u32>(), ctx->looseCtl.as<LooseCtl>(), 0, ctx->par.thr);
+                       ctx->fragList.as<u32>(), ctx->looseCtl.as<LooseCtl>(), ctx->lateLoose ? 2 : 0, ctx->par.thr);
+    // (lambda came with the sample's end: may the sweep walk the loose slots?  The pass that writes its bits runs when gx_find_peaks
+    // finds the replicate to be the run's only one -- gx_stats.h k_loose_late)
+    if (ctx->lateLoose) hipLaunchKernelGGL(k_loose_verdict, dim3(1), dim3(256), 0, s, ctx->looseCtl.as<LooseCtl>());
   } else {
     hipLaunchKernelGGL(k_pair_tabs, dim3(PAIR_LUT / 256), dim3(256), 0, s, ds, ctx->pairLogE.as<double>(),
                        ctx->pairCtab.as<CtrlEntry>());

@@ -131,6 +131,7 @@ struct PArray {  // p-value intervals of one replicate (or the Fisher combinatio
   // exact pileups and tile descriptors, taken out of the context (no copy; the context takes other buffers: pooled)
   DevBuf keptV, keptMeta;
   bool keptLoose = false;
+  bool latePending = false, lateLoose = false;   // the loose sweep's bits are still to be written (k_loose_late) / were written late
   bool qLazy = false;     // -q: q[] holds the candidates' intervals only; the rest on request (ensure_q)
   bool hasPiles = false;  // expt/ctrl filled (single-replicate logging)
   bool pilesDropped = false;  // ... deliberately not (gx_set_keep_pileups(0))
@@ -161,6 +162,7 @@ struct Knobs {
   int bhVariant = -1;     // GX_BH_VARIANT: the instance of k_bh_hist / k_qlookup (0: 256 threads, 2048-entry LDS tables -- rounds 2-5; 1: 1024 threads,
                           // one workgroup per CU, 8192 / 16384 entries; 2: 512 threads, 4096 / 8192 entries); default: chosen by the run
   int mergeWg = 0;        // GX_MERGE_WG: the control merge by k_merge2 (a workgroup per tile, rounds 2-5) instead of k_merge2w (a wavefront per tile)
+  int noLateLoose = 0;    // GX_NO_LATE_LOOSE: a sample whose lambda comes with its end takes the tight table (k_pack_pval), as until round 6
   int noLazyQ = 0;        // GX_NO_LAZY_Q: q of every interval by k_qlookup, as until round 6
   int noPackHist = 0;     // GX_NO_PACK_HIST: BH's histogram by k_bh_hist from the tight table also for a single replicate without control
   int noMergeP = 0;       // GX_NO_MERGE_P: the control merge leaves both pileups in its loose slots and k_pack_pairs scores them, as until round 5
@@ -185,7 +187,7 @@ const KnobDef KNOBS[] = {
     {"GX_DEBUG", &Knobs::debug, nullptr}, {"GX_DEBUG_RETRY", &Knobs::debugRetry, nullptr}, {"GX_NO_SPIN", &Knobs::noSpin, nullptr},
     {"GX_FORCE_REC64", &Knobs::forceRec64, nullptr}, {"GX_FORCE_SLOWFRAG", &Knobs::forceSlowFrag, nullptr},
     {"GX_NO_FUSED", &Knobs::noFused, nullptr}, {"GX_NO_LOOSE", &Knobs::noLoose, nullptr}, {"GX_NO_PAIRS", &Knobs::noPairs, nullptr},
-    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_NO_PACK_HIST", &Knobs::noPackHist, nullptr}, {"GX_NO_LAZY_Q", &Knobs::noLazyQ, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
+    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_NO_PACK_HIST", &Knobs::noPackHist, nullptr}, {"GX_NO_LAZY_Q", &Knobs::noLazyQ, nullptr}, {"GX_NO_LATE_LOOSE", &Knobs::noLateLoose, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
     {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
     {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
     {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
@@ -307,6 +309,8 @@ struct gx_ctx {
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
   long long satDropped = 0;     // ... which dropped this many of them (gx_saturation_dropped)
+  bool lateLooseUsed = false;   // ... and the replicate the sweep walked was such a sample (GX_PATH_LATE_LOOSE)
+  bool lateLoose = false;       // this sample: the sweep's bits on the loose slots come after the table p(V) (k_loose_late)
   bool lazyQUsed = false;       // the last -q run took k_sig_from_p / k_q_fill_cands (GX_PATH_LAZY_Q)
   bool bhLive = false;          // the table of the last -q run is still there, with {key, q} of every value (lazy q: ensure_q)
   u32 bhLiveCap = 0;

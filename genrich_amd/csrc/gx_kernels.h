@@ -476,8 +476,9 @@ struct LooseCtl {
 };
 // pileups (1/120 units) from which an interval is significant; INT_MAX: the tile kernels write no bits.
 // Call with the whole workgroup (`red`: two words of LDS; contains a barrier).
-__device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporter, u32* __restrict__ red) {
-  if (!c || !c->enabled) return 0x7FFFFFFF;  // (block-uniform)
+// (late: lambda came with the sample's end -- k_loose_late reads the slots the table's second launch left, `enabled` or not)
+__device__ __forceinline__ int loose_vsig(LooseCtl* __restrict__ c, bool reporter, u32* __restrict__ red, bool late = false) {
+  if (!c || (!late && !c->enabled)) return 0x7FFFFFFF;  // (block-uniform)
   u32 a = 0, b = 0;
   for (u32 i = threadIdx.x; i < PV_LUT / 256; i += blockDim.x) {
     a = max(a, c->sigInv[i]);

@@ -68,9 +68,11 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
     return;
   }
   const float lambda = sc->lambda;
+  // (early == 2, round 6: the launch after the tile stage of a sample whose lambda only came with its end -- fractional weights,
+  // several ranks without the early all-reduce --, which leaves LooseCtl's slots as well: k_loose_late writes the sweep's bits from them)
   if (ctl) {
-    if (early && !ctl->enabled) return;                                                // lambda is not known yet
-    if (!early && ctl->enabled && ctl->earlyBits == __float_as_uint(lambda)) return;   // the table is this one already
+    if (early == 1 && !ctl->enabled) return;                                                // lambda is not known yet
+    if (early != 1 && ctl->enabled && ctl->earlyBits == __float_as_uint(lambda)) return;   // the table is this one already
   }
   double ml = 0, sl = 1;
   if (lambda != 0.0f) lnorm_params(lambda, &ml, &sl);
@@ -78,6 +80,63 @@ __global__ __launch_bounds__(256) void k_pval_lut(const Scalars* __restrict__ sc
   for (u32 v = blockIdx.x * 256 + threadIdx.x; v < PV_LUT; v += (PV_LUT / 256) * 256)
     // (the grid covers the table once: v = this wavefront's first entry + lane, one slot per workgroup)
     lut_entry(v, lambda, ml, sl, lutP, risk, early && ctl ? ctl : nullptr, thr, red, threadIdx.x, blockIdx.x);
+}
+
+// The sweep on the loose slots for a sample whose lambda was NOT known before the tile stage (round 6: fractional weights take the
+// closed form of fragLen away; callPeaks 977-1069 on the intervals where savePileupExpt 2197-2273 left them).  The tile stage wrote
+// neither the significance bits nor the zero-length fillers of a tile's unused slots; with the table p(V) and LooseCtl's slots
+// there (k_pval_lut, early == 2) one wavefront per tile does both -- a pass over the pileups (4 bytes per interval) instead of
+// k_pack_pval's copy of everything into the tight table (16 bytes per interval).  The verdict (LooseCtl::ok: no pileup beyond the table,
+// no tile without intervals too long to fill, p(V) > thr a threshold on V) is k_loose_verdict's, with the sample's scalars; the pass
+// itself runs when gx_find_peaks finds this replicate to be the run's only one (a further replicate makes the tight tables anyway).
+__global__ __launch_bounds__(256) void k_loose_verdict(LooseCtl* __restrict__ ctl) {
+  __shared__ u32 red[2];
+  const int vsig = loose_vsig(ctl, threadIdx.x == 0, red, true);
+  if (threadIdx.x == 0) ctl->ok = vsig != 0x7FFFFFFF && ld_agent(&ctl->bad) == 0u ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_loose_late(const u32* __restrict__ tileSlot, const u32* __restrict__ tileCount,
+                                                    const u32* __restrict__ tileLastEnd, u32 nTiles, u32* __restrict__ looseEnd,
+                                                    int* __restrict__ looseV, LooseCtl* __restrict__ ctl, u64* __restrict__ sigMask) {
+  __shared__ u32 red[2];
+  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(ctl, false, red, true));
+  if (vsig == 0x7FFFFFFF) return;  // (k_loose_verdict said so: not reached)
+  const int lane = lane_id();
+  // (a tile is a few hundred slots: what a wavefront waits for is the chain header -> pileups, so the next tile's header is asked for
+  // under this tile's pass, and a tile's pileups 256 at a time)
+  const u32 stride = gridDim.x * 4;
+  u32 tn = blockIdx.x * 4 + (threadIdx.x >> 6);
+  u32 ns0 = 0, ns1 = 0, ncnt = 0, nle = 0;
+  if (tn < nTiles) { ns0 = tileSlot[tn]; ns1 = tileSlot[tn + 1]; ncnt = tileCount[tn]; nle = tileLastEnd[tn]; }
+  while (tn < nTiles) {
+    const u32 s0 = ns0, size = ns1 - ns0, cnt = ncnt, lastEnd = nle;
+    tn += stride;
+    if (tn < nTiles) { ns0 = tileSlot[tn]; ns1 = tileSlot[tn + 1]; ncnt = tileCount[tn]; nle = tileLastEnd[tn]; }
+    if (!cnt) continue;  // (k_scan_iv has filled the slots of a tile without intervals)
+    for (u32 j0 = 0; j0 < size; j0 += 256) {
+      int v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 j = j0 + (u32)k * 64 + (u32)lane;
+        v[k] = j < cnt ? looseV[s0 + j] : (int)0x80000000;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 j = j0 + (u32)k * 64 + (u32)lane;
+        if (j0 + (u32)k * 64 >= size) break;  // wave-uniform
+        const bool sg = j < cnt && v[k] >= vsig;
+        if (j >= cnt && j < size) {
+          looseEnd[s0 + j] = lastEnd;
+          looseV[s0 + j] = 0;
+        }
+        const u64 m = __ballot(sg);
+        if (m && lane == 0) {
+          const u32 b = s0 + j0 + (u32)k * 64, sh = b & 63u;
+          atomicOr((unsigned long long*)&sigMask[b >> 6], m << sh);
+          if (sh && (m >> (64u - sh))) atomicOr((unsigned long long*)&sigMask[(b >> 6) + 1], m >> (64u - sh));
+        }
+      }
+    }
+  }
 }
 
 // p-values against a constant control (no control sample), straight from the tile kernel's
@@ -1224,8 +1283,11 @@ __device__ __forceinline__ void load_whole_lut(float* __restrict__ hot, const fl
   for (u32 i = threadIdx.x; i < PV_WHOLE; i += blockDim.x) hot[i] = lut[PV_LUT + i];
   __syncthreads();
 }
-__device__ __forceinline__ float p_from_v(const float* __restrict__ hot, const int* __restrict__ V, u32 i) {
-  const u32 c = __umulhi((u32)V[i], 0x88888889u) >> 6;  // V / 120
+// (lut: the whole table p(V), V in 1/120 units -- a pileup that is not a whole number, fractional weights, is looked up there)
+__device__ __forceinline__ float p_from_v(const float* __restrict__ hot, const float* __restrict__ lut, const int* __restrict__ V, u32 i) {
+  const u32 v = (u32)V[i];
+  const u32 c = __umulhi(v, 0x88888889u) >> 6;  // V / 120
+  if (v != c * (u32)GX_UNIT) return lut[v < PV_LUT ? v : 0u];
   return hot[c < PV_WHOLE ? c : 0u];
 }
 template <bool USEQ, bool PV>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
@@ -1263,7 +1325,7 @@ __device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, c
         if (in[a]) {
           e[a] = end[i];
           sPrev[a] = i == i0 ? peakStart : end[i - 1];
-          if (PV) pv[a] = p_from_v(hot, reinterpret_cast<const int*>(q), i);
+          if (PV) pv[a] = p_from_v(hot, p, reinterpret_cast<const int*>(q), i);
           else pv[a] = p[i];
           if (USEQ) qv[a] = q[i];
         }
@@ -1350,7 +1412,7 @@ __device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, co
         if (in[a]) {
           e[a] = end[i];
           sPrev[a] = i == i0 ? peakStart : end[i - 1];
-          if (PV) pv[a] = p_from_v(hot, reinterpret_cast<const int*>(qIn), i);
+          if (PV) pv[a] = p_from_v(hot, p, reinterpret_cast<const int*>(qIn), i);
           else pv[a] = p[i];
           if (q) qv[a] = q[i];
         }

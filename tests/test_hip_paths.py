@@ -14,7 +14,7 @@ from test_hip_parity import assert_same_run, hip_backend
 pytestmark = pytest.mark.gpu
 
 FUSED, LOOSE, FELL_BACK, PT_GREW, PAIRS, FRAC_PAIRS, PILES_MADE = 1, 2, 4, 8, 16, 128, 256
-MERGE_P, PACK_HIST, LAZY_Q = 1024, 2048, 8192
+MERGE_P, PACK_HIST, LAZY_Q, LATE_LOOSE = 1024, 2048, 8192, 16384
 
 
 def _case(seed=11, n=90_000, lens=(400_000, 123_457, 16_384, 4_097, 5), **kw):
@@ -170,7 +170,8 @@ def test_what_a_context_has_learned_about_fractions_is_not_the_hints_to_clear():
     params = B.make_params(pq=0.01, min_auc=20.0)
     h = hip_backend(params)
     h.expect_fractional(True)
-    for i, (treat, want_loose) in enumerate(((unit, True), (ev, False), (unit, False))):
+    # (the third run: lambda comes with the sample's end, the loose slots are swept all the same -- k_loose_late, round 6)
+    for i, (treat, want_loose) in enumerate(((unit, True), (ev, False), (unit, True))):
         case = dict(lens=lens, replicates=[dict(save=None, treat=treat, ctrl=None)])
         o = B.Oracle(params)
         so = B.run_case(o, case)
@@ -180,6 +181,7 @@ def test_what_a_context_has_learned_about_fractions_is_not_the_hints_to_clear():
         assert_same_run(o, h, so, sh, case)
         assert flags & FUSED and flags & FRAC_PAIRS and not flags & FELL_BACK
         assert bool(flags & LOOSE) == want_loose, (flags, want_loose)
+        assert bool(flags & LATE_LOOSE) == (i == 2), flags
         if i == 1:
             h.expect_fractional(False)   # (the third run: no hint any more -- what was learned stays)
         o.close()
@@ -630,3 +632,39 @@ def test_q_values_inside_the_candidates_only_and_the_whole_array_on_request(monk
         eo, co = o.get_intervals(-1, c)
         assert np.array_equal(eh, eo)
         assert np.array_equal(ch["q"].view(np.uint32), co["q"].view(np.uint32))
+
+
+# ---- the loose slots swept although lambda came with the sample's end (round 6: k_loose_late) ----
+
+@pytest.mark.parametrize("kind", ["multimap", "deep", "empty_tiles", "knob_off"])
+def test_fractional_weights_sweep_the_loose_slots_once_the_table_is_there(kind):
+    """Fractional weights (-s: addFrac / subFrac, Genrich.c:2300-2376) take the closed form of fragLen away, so lambda -- and with it
+    from which pileup on an interval is significant -- is only known behind the tile stage.  The sweep still walks the intervals where
+    savePileupExpt (2197-2273) left them: one pass over the pileups writes the significance bits and the fillers of the tiles' unused
+    slots, and p comes from the whole table p(V) (a pileup like 7 1/3 has no entry in the compact one).  A pileup beyond the table
+    (`deep`) or the switch send the run to the tight table as before.  Either way the oracle's bits."""
+    lens = [500_000, 150_000, 4_097, 60_000]
+    if kind == "empty_tiles":
+        lens = [2_000_000, 150_000]   # (long stretches without a fragment: tiles without intervals, filled by k_scan_iv)
+    unit = synth.make_fragments(lens, 40_000 if kind == "empty_tiles" else 110_000, 91, peak_every=20_000, tower_every=250_000,
+                                frac_tower=0.2 if kind == "deep" else 0.02)
+    ev = synth.add_multimap(unit, lens, 0.3, 92)
+    params = B.make_params(pq=0.01, min_auc=20.0)
+    h = hip_backend(params)
+    h.expect_fractional(True)
+    if kind == "knob_off":
+        h.set_knob("GX_NO_LATE_LOOSE", 1)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=ev, ctrl=None)])
+    o = B.Oracle(params)
+    so = B.run_case(o, case)
+    for run in range(2):   # (the first run learns that the data holds fractions -- its early lambda does not stand --, the second knows)
+        h.reset()
+        sh = B.run_case(h, case)
+        flags = h.path_info()
+        assert_same_run(o, h, so, sh, case)
+        assert flags & FUSED and flags & FRAC_PAIRS and not flags & FELL_BACK, flags
+        if run == 1:
+            want = kind in ("multimap", "empty_tiles")
+            assert bool(flags & LOOSE) == want and bool(flags & LATE_LOOSE) == want, flags
+    assert h.n_peaks > 0
+    o.close()
