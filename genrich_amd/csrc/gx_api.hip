@@ -504,7 +504,7 @@ int gx_pvalues(gx_ctx* ctx) {
     pa.ctrlConst = ctx->hScal.lambda;
     pa.loose = true;
     // (the tile stage wrote the sweep's significance bits, in loose-slot index space: LooseCtl)
-    pa.looseSweep = ctx->looseOk && !ctx->par.qval_opt && !ctx->knob.noLoose;
+    pa.looseSweep = ctx->looseOk && (!ctx->par.qval_opt || ctx->lateLoose) && !ctx->knob.noLoose;   // (-q: gx_find_peaks' qLoose)
     pa.latePending = pa.looseSweep && ctx->lateLoose;   // (its bits are still to be written: k_loose_late, by gx_find_peaks)
     pa.looseStride = ctx->looseStride;
     if (pa.looseSweep) pa.chromLooseOff = std::move(ctx->chromLooseOff);
@@ -535,8 +535,13 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   // of distinct p-values is made of those sums, not of a hash insertion per interval)
   const bool packHist = ctx->par.qval_opt && ctx->sample == 1 && ctx->reps.size() == 1 && ctx->reps[0].ctrlIsConst && !ctx->sawFrac &&
                         ctx->world <= 1 && !ctx->forceColl && !ctx->knob.noPackHist;
+  // (round 6) ... and with -q as well, where q is a function of the pileup like p: BH's histogram is summed from the loose slots, q
+  // tabulated by whole pileup (k_qv_table), the bits written from "q passes from this pileup on", the sweep as with -p -- no tight table
+  const bool qLoose = packHist && ctx->reps[0].loose && ctx->reps[0].looseSweep && (ctx->reps[0].latePending || ctx->reps[0].lateLoose) &&
+                      !ctx->knob.noQLoose && !ctx->qLooseBad && !ctx->hasBed;
+  ctx->qLooseUsed = false;
   for (size_t r = 0; r < ctx->reps.size(); r++) {
-    if (ctx->reps[r].loose && !looseFast)
+    if (ctx->reps[r].loose && !looseFast && !qLoose)
       if (int rc = materialize_rep(ctx, (int)r, packHist)) return rc;
     // (the Fisher combination of several replicates reuses the loose slots: the last replicate keeps what its pileup
     // floats, if somebody asks for them, are made of)
@@ -563,7 +568,10 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     hipLaunchKernelGGL(k_set_misc, dim3(1), dim3(1), 0, s, misc, (u32)M_NIV, (u32)M_GENOME, (u64)g, n);
 
   ctx->lazyQUsed = false;
-  if (ctx->par.qval_opt) {
+  if (qLoose) {
+    if (int rc = loose_hist(ctx, fa)) return rc;
+    if (int rc = bh_qvalues(ctx, fa, n, genomeOpt, true)) return rc;
+  } else if (ctx->par.qval_opt) {
     if (int rc = bh_qvalues(ctx, fa, n, genomeOpt)) return rc;
   }
 
@@ -571,7 +579,32 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   phase_begin(ctx, "sweep");
   SweepSrc src{};
   src.nChrom = nChrom;
-  if (looseFast) {
+  if (qLoose) {
+    // q by whole pileup and from which pileup on it passes; the bits (and, the first time, the fillers) on the loose slots
+    HIPCHECK(ctx->qLut.ensure((size_t)PV_WHOLE * 4));
+    const u32 vq0[2] = {0xFFFFFFFFu, ctx->knob.fault == 2 ? 0xFFFFFFFFu : 0u};   // (GX_FAULT=2: "q is no threshold on the pileup")
+    HIPCHECK(hipMemcpyAsync(misc + M_VQ, vq0, 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_qv_table, dim3((PV_WHOLE + 255) / 256), dim3(256), 0, s, ctx->pvLut.as<float>(), ctx->bhKQ.as<u64>(),
+                       ctx->bhLiveCap - 1, ctx->par.thr, ctx->qLut.as<float>(), misc + M_VQ);
+    HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, fa.looseStride * 8, s));   // (the significance words: a run before may have left its own)
+    hipLaunchKernelGGL(k_loose_late, dim3(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s,
+                       ctx->tileSlot.as<u32>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->nTiles,
+                       ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->looseCtl.as<LooseCtl>(), ctx->swMask.as<u64>(),
+                       (const u32*)(misc + M_VQ), ctx->dStatus.as<u32>());
+    fa.latePending = false;
+    fa.lateLoose = true;
+    ctx->lateLooseUsed = true;
+    ctx->qLooseUsed = true;
+    src.end = ctx->looseEnd.as<u32>();
+    src.V = ctx->looseV.as<int>();
+    src.p = ctx->pvLut.as<float>();
+    src.qLut = ctx->qLut.as<float>();
+    src.chromOff = fa.chromLooseOff.as<u32>();
+    src.mStride = fa.looseStride;
+    src.nWords = (u32)(fa.looseStride - 2);
+    src.haveMasks = true;
+    src.hasSkip = false;
+  } else if (looseFast) {
     ctx->lateLooseUsed = fa.lateLoose || fa.latePending;
     if (fa.latePending) {
       hipLaunchKernelGGL(k_loose_late, dim3(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s,
@@ -607,10 +640,17 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
     if (!src.haveMasks) HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, src.mStride * 8 * 3, s));
   }
   ctx->maskIdx = -1;
-  ctx->looseSwept = looseFast;
+  ctx->looseSwept = looseFast || qLoose;
   u32 nPeaks = 0;
-  if (int rc = run_sweep(ctx, src, &nPeaks)) return rc;
+  const int rcSweep = run_sweep(ctx, src, &nPeaks);
   phase_end(ctx);
+  if (qLoose && (ctx->mail->status & ST_Q_LOOSE)) {
+    // q turned out to be no threshold on the pileup (a table p(V) that is not monotone): once more, on the tight table -- and from now on
+    HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 4, s));
+    ctx->qLooseBad = true;
+    return gx_find_peaks(ctx, n_peaks, genome_len, peak_bp);
+  }
+  if (rcSweep) return rcSweep;
   if (n_peaks) *n_peaks = nPeaks;
   if (genome_len) *genome_len = g;
   if (peak_bp) *peak_bp = ctx->peakBP;
@@ -684,13 +724,13 @@ int gx_get_intervals(gx_ctx* ctx, int which, int chrom, size_t cap, uint32_t* en
     else std::fill(ctrl, ctrl + n, pa->ctrlIsConst ? pa->ctrlConst : 0.0f);
   }
   if (q) {
-    if (pa->q.p && ctx->par.qval_opt) {
+    if ((pa->q.p || pa->qLazy) && ctx->par.qval_opt) {
       const int w = which == GX_IV_FINAL ? ctx->finalIdx : which;
       if (int rc = ensure_q(ctx, ctx->reps[w], w)) return rc;
       HIPCHECK(hipStreamSynchronize(ctx->stream));
       HIPCHECK(hipMemcpy(q, pa->q.as<float>() + lo, n * 4, hipMemcpyDeviceToHost));
     }
-    if (!(pa->q.p && ctx->par.qval_opt)) std::fill(q, q + n, GX_SKIP);
+    if (!((pa->q.p || pa->qLazy) && ctx->par.qval_opt)) std::fill(q, q + n, GX_SKIP);
   }
   return GX_OK;
 }
@@ -780,7 +820,7 @@ int gx_path_info(gx_ctx* ctx, unsigned* flags) {
   *flags = (ctx->fusedUsed ? GX_PATH_FUSED : 0u) | (ctx->fusedUsed && ctx->pairsUsed ? GX_PATH_PAIRS : 0u) | (ctx->denseBhUsed ? GX_PATH_DENSE_BH : 0u) | (ctx->rangeBhUsed ? GX_PATH_RANGE_BH : 0u) | (ctx->looseSwept ? GX_PATH_LOOSE_SWEEP : 0u) |
            (ctx->fellBack ? GX_PATH_FELL_BACK : 0u) | (ctx->ptGrew ? GX_PATH_PT_GREW : 0u) | (ctx->fusedUsed && ctx->fracPairsUsed ? GX_PATH_FRAC_PAIRS : 0u) |
            (ctx->pilesMade ? GX_PATH_PILES_MADE : 0u) | (ctx->packedUsed ? GX_PATH_PACKED : 0u) | (ctx->mergePUsed ? GX_PATH_MERGE_P : 0u) |
-           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u) | (ctx->lazyQUsed ? GX_PATH_LAZY_Q : 0u) | (ctx->looseSwept && ctx->lateLooseUsed ? GX_PATH_LATE_LOOSE : 0u);
+           (ctx->denseHistUsed ? GX_PATH_PACK_HIST : 0u) | (ctx->lazyQUsed ? GX_PATH_LAZY_Q : 0u) | (ctx->looseSwept && ctx->lateLooseUsed ? GX_PATH_LATE_LOOSE : 0u) | (ctx->qLooseUsed ? GX_PATH_Q_LOOSE : 0u);
   return GX_OK;
 }
 

@@ -212,8 +212,11 @@ int build_pileup(gx_ctx* ctx, Pileup& out, int isCtrl, bool reuseSort = false) {
   // (round 6) ... and when lambda only comes with the sample's end -- fractional weights: no closed form of fragLen -- the sweep still
   // walks the loose slots: k_loose_late writes the bits and the fillers once the table p(V) is there (finish_scalars), instead of
   // k_pack_pval's copy of every interval into the tight table.  One rank, a treatment sample, -p, no -E regions, the fused tile stage.
-  const bool wantLate = !wantEarly && !isCtrl && !multiRank && !ctx->par.qval_opt && !ctx->hasBed && unit32 && !noLoose && !K.noLateLoose &&
-                        fused && !forceSlowFrag;
+  // (-q as well, where q is a function of the pileup: unit weights, no control to come -- gx_find_peaks' qLoose; a control sample
+  // that follows only finds the verdict unused)
+  const bool qLooseMay = ctx->par.qval_opt && !K.noQLoose && !ctx->qLooseBad && !ctx->sawFrac && !ctx->fracHint && !K.noPackHist;
+  const bool wantLate = !wantEarly && !isCtrl && !multiRank && (!ctx->par.qval_opt || qLooseMay) && !ctx->hasBed && unit32 && !noLoose &&
+                        !K.noLateLoose && fused && !forceSlowFrag;
   ctx->lateLoose = wantLate;
   const size_t looseCap = (size_t)2 * nEv + nTiles + ctx->nBedEdges + 16;  // slot t: records before + t (+ edges before)
   u64* sigMask = nullptr;

@@ -162,6 +162,7 @@ struct Knobs {
   int bhVariant = -1;     // GX_BH_VARIANT: the instance of k_bh_hist / k_qlookup (0: 256 threads, 2048-entry LDS tables -- rounds 2-5; 1: 1024 threads,
                           // one workgroup per CU, 8192 / 16384 entries; 2: 512 threads, 4096 / 8192 entries); default: chosen by the run
   int mergeWg = 0;        // GX_MERGE_WG: the control merge by k_merge2 (a workgroup per tile, rounds 2-5) instead of k_merge2w (a wavefront per tile)
+  int noQLoose = 0;       // GX_NO_Q_LOOSE: -q on one replicate without control makes the tight table and sweeps it, as until round 6
   int noLateLoose = 0;    // GX_NO_LATE_LOOSE: a sample whose lambda comes with its end takes the tight table (k_pack_pval), as until round 6
   int noLazyQ = 0;        // GX_NO_LAZY_Q: q of every interval by k_qlookup, as until round 6
   int noPackHist = 0;     // GX_NO_PACK_HIST: BH's histogram by k_bh_hist from the tight table also for a single replicate without control
@@ -187,7 +188,7 @@ const KnobDef KNOBS[] = {
     {"GX_DEBUG", &Knobs::debug, nullptr}, {"GX_DEBUG_RETRY", &Knobs::debugRetry, nullptr}, {"GX_NO_SPIN", &Knobs::noSpin, nullptr},
     {"GX_FORCE_REC64", &Knobs::forceRec64, nullptr}, {"GX_FORCE_SLOWFRAG", &Knobs::forceSlowFrag, nullptr},
     {"GX_NO_FUSED", &Knobs::noFused, nullptr}, {"GX_NO_LOOSE", &Knobs::noLoose, nullptr}, {"GX_NO_PAIRS", &Knobs::noPairs, nullptr},
-    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_NO_PACK_HIST", &Knobs::noPackHist, nullptr}, {"GX_NO_LAZY_Q", &Knobs::noLazyQ, nullptr}, {"GX_NO_LATE_LOOSE", &Knobs::noLateLoose, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
+    {"GX_NO_FRAC_PAIRS", &Knobs::noFracPairs, nullptr}, {"GX_NO_BED_FUSED", &Knobs::noBedFused, nullptr}, {"GX_NO_MERGE_P", &Knobs::noMergeP, nullptr}, {"GX_NO_PACK_HIST", &Knobs::noPackHist, nullptr}, {"GX_NO_LAZY_Q", &Knobs::noLazyQ, nullptr}, {"GX_NO_LATE_LOOSE", &Knobs::noLateLoose, nullptr}, {"GX_NO_Q_LOOSE", &Knobs::noQLoose, nullptr}, {"GX_MERGE_WG", &Knobs::mergeWg, nullptr}, {"GX_BH_VARIANT", &Knobs::bhVariant, nullptr}, {"GX_FORCE_HALF_BINS", &Knobs::forceHalfBins, nullptr},
     {"GX_NO_HALF_BINS", &Knobs::noHalfBins, nullptr}, {"GX_FRAC_HALF_BINS", &Knobs::fracHalfBins, nullptr}, {"GX_NO_EARLY_COLL", &Knobs::noEarlyColl, nullptr},
     {"GX_NO_DENSE_BH", &Knobs::noDenseBh, nullptr}, {"GX_QT_MULTI", &Knobs::qtMulti, nullptr}, {"GX_FORCE_COLL", &Knobs::forceColl, nullptr},
     {"GX_SBSHIFT", &Knobs::sbShift, nullptr}, {"GX_RUN_CAP_MIN", nullptr, &Knobs::runCapMin}, {"GX_BH_CAPLOG", &Knobs::bhCapLog, nullptr},
@@ -309,6 +310,9 @@ struct gx_ctx {
   PinnedBuf hostRecs;           // this rank's BH records for the all-gather
   bool satDone = false;         // this sample's events already went through the saturation filter
   long long satDropped = 0;     // ... which dropped this many of them (gx_saturation_dropped)
+  bool qLooseBad = false;       // -q on the loose slots was called off once (ST_Q_LOOSE): this context takes the tight table from now on
+  bool qLooseUsed = false;      // the last gx_find_peaks: -q, the sweep on the loose slots (GX_PATH_Q_LOOSE)
+  DevBuf qLut;                  // ... its q by whole pileup (k_qv_table)
   bool lateLooseUsed = false;   // ... and the replicate the sweep walked was such a sample (GX_PATH_LATE_LOOSE)
   bool lateLoose = false;       // this sample: the sweep's bits on the loose slots come after the table p(V) (k_loose_late)
   bool lazyQUsed = false;       // the last -q run took k_sig_from_p / k_q_fill_cands (GX_PATH_LAZY_Q)
@@ -382,7 +386,7 @@ void recycle(gx_ctx* ctx, DevBuf& b) {
 }
 
 // misc device words (u32 indices into ctx->misc)
-enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_BHOVF = 7, M_GENOME = 10 /* u64 */, M_NMERGED = 15, M_PSTAR = 14,
+enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_BHOVF = 7, M_GENOME = 10 /* u64 */, M_NMERGED = 15, M_PSTAR = 14, M_VQ = 12 /* two words: k_qv_table */,
        // the sweep's counters are contiguous: one memset clears them
        M_TICKET2 = 16, M_SWCOUNT = 17, M_NPEAKS = 18, M_TICKET3 = 19, M_TICKET4 = 20, M_NHEADS = 21, M_PEAKBP = 22 /* u64 */,
        M_SWEEP_FIRST = 16, M_SWEEP_WORDS = 8, M_WORDS = 32 };

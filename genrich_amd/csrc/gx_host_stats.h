@@ -490,6 +490,7 @@ int qlookup_all(gx_ctx* ctx, PArray& fa, u32 cap, u64* sigMask, u64* skipMask) {
 // gx_get_intervals' q-values of a -q run whose sweep looked up the candidates' intervals only: the whole array, once
 int ensure_q(gx_ctx* ctx, PArray& pa, int idx) {
   if (!pa.qLazy) return GX_OK;
+  if (!pa.q.p && ctx->bhLive && ctx->bhLiveIdx == idx && pa.p.p) HIPCHECK(pooled(ctx, pa.q, (size_t)pa.n * 4 + 16));   // (-q on the loose slots)
   if (!ctx->bhLive || ctx->bhLiveIdx != idx || !pa.q.p) {
     ctx->err = "the q-values of this run are gone (another run has taken the table)";
     return GX_ERR_ORDER;
@@ -500,10 +501,33 @@ int ensure_q(gx_ctx* ctx, PArray& pa, int idx) {
   return GX_OK;
 }
 
+// -q on the loose slots: the "bp at pileup V" histogram that materialize_rep(.., hist) collects while it writes the tight table, without
+// the table (k_pack_pval<.., HIST, false>: reads the loose slots, writes nothing but the sums)
+int loose_hist(gx_ctx* ctx, PArray& pa) {
+  hipStream_t s = ctx->stream;
+  phase_begin(ctx, "pval");
+  const u32 cap = 1u << ctx->bhCapLog;
+  if (int rc = bh_table_prepare(ctx, cap)) return rc;
+  HIPCHECK(hipMemsetAsync(ctx->misc.as<u32>() + M_BHCOUNT, 0, 8, s));
+  HIPCHECK(ctx->bhDense.ensure(bhd_words(1) * 8));
+  HIPCHECK(hipMemsetAsync(ctx->bhDense.p, 0, bhd_words(1) * 8, s));
+  PackIn pin{ctx->looseEnd.as<u32>(), ctx->looseV.as<int>(), ctx->tileMeta.as<TileMeta>(), pa.tileOff.as<u32>()};
+  int nbH = 0;
+  HIPCHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbH, k_pack_pval<false, true, false>, 256, 0));
+  const dim3 gridH(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(std::max(1, std::min(nbH, 8)) * ctx->numCU))));
+  hipLaunchKernelGGL((k_pack_pval<false, true, false>), gridH, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
+                     ctx->pvLut.as<float>(), (u32*)nullptr, (float*)nullptr, ctx->par.thr, (u64*)nullptr, (u64*)nullptr,
+                     ctx->dStatus.as<u32>(), (const u32*)ctx->tilePrevEnd.as<u32>(), ctx->bhDense.as<u64>());
+  ctx->denseHistIdx = ctx->finalIdx;
+  phase_end(ctx);
+  return GX_OK;
+}
+
 // computeQval / saveQval (Genrich.c:352-401, 212-250) for the final p-array `fa` of n intervals: the genome-wide table
 // {p -> bp} (with several ranks: after the exchange, gx_host_coll.h), its sort and suffix scan, q per interval and the
 // sweep's masks on the way.  genomeOpt: the genome length was computed (not -L): the lengths must add up to it
-int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
+// looseQ (round 6): the sweep walks the loose slots -- the table and its {key, q} pairs only (k_qv_table reads them); no interval array here
+int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt, bool looseQ = false) {
   hipStream_t s = ctx->stream;
   u32* misc = ctx->misc.as<u32>();
   const u32 nChrom = ctx->nChrom;
@@ -554,6 +578,10 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
       if (!(ctx->mail->status & ST_HASH_FULL)) break;
       if (ctx->mail->status != ST_HASH_FULL) return status_to_rc(ctx, ctx->mail->status & ~ST_HASH_FULL);
       HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 4, s));   // (a table too small: once more from the tight intervals, into a larger one)
+      if (looseQ) {   // (a few thousand distinct pileups at most against 2^22 slots: not reached; there is no tight table to go back to)
+        ctx->err = "p-value table full";
+        return GX_ERR_MEM;
+      }
       if (int rc = bh_grow()) return rc;
       fromDense = false;
       ctx->denseHistUsed = false;
@@ -652,9 +680,14 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
     }
 if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
   }
+  const bool lazyQ = !ctx->knob.noLazyQ || looseQ;
+  if (looseQ) {
+    HIPCHECK(hipMemsetAsync(misc + M_PSTAR, 0xFF, 4, s));
+    hipLaunchKernelGGL(k_kq_build, dim3(256), dim3(256), 0, s, T, ctx->bhQ.as<float>(), ctx->bhKQ.as<u64>(), ctx->par.thr, misc + M_PSTAR);
+  } else {
   HIPCHECK(pooled(ctx, fa.q, (size_t)n * 4 + 16));
-  const bool lazyQ = !ctx->knob.noLazyQ;
-  {  // q-values and, on the way, the sweep's significance / SKIP masks
+  // q-values and, on the way, the sweep's significance / SKIP masks
+  {
     const size_t stride = (size_t)((n + 63) / 64) + 2;
     HIPCHECK(ctx->swMask.ensure(stride * 8 * 3));
     HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, stride * 8 * 3, s));
@@ -671,6 +704,7 @@ if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     } else {
       if (int rc__ = qlookup_all(ctx, fa, cap, ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride)) return rc__;
     }
+  }
   }
   fa.qLazy = lazyQ;
   ctx->lazyQUsed = lazyQ;

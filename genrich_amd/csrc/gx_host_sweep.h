@@ -15,6 +15,7 @@ struct SweepSrc {
   // the sweep on the loose slots (LooseCtl): `end` = the loose ends, p = the table p(V) looked up with the slots' exact
   // pileups `V`; the masks are [significant | first of its chromosome], `mStride` apart, and there are no SKIP intervals
   const int* V = nullptr;
+  const float* qLut = nullptr;   // ... with -q: q by whole pileup (k_qv_table) -- the AUC and the summits take q from it
   bool haveMasks = false, hasSkip = true;
   const u32* chromOff = nullptr;
   u32 nChrom = 0, nWords = 0;
@@ -109,7 +110,13 @@ int run_sweep(gx_ctx* ctx, const SweepSrc& S, u32* nPeaksOut) {
   hipLaunchKernelGGL((k_peak_both<Q, V>), dim3((NSHORT) + gridW.x), dim3(256), 0, s, (u32)(NSHORT), ctx->candHdr.as<uint4>(), \
                      S.end, S.p, QPTR, S.chromOff, nChrom, misc + M_NHEADS, ctx->longList.as<u32>(), misc + M_TICKET3,       \
                      ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(), ctx->valid.as<u32>())
-        if (S.V) {  // p from the table p(V) (`q` carries the exact pileups); every workgroup copies the table's compact form to LDS
+        if (S.V && S.qLut) {  // ... and q from its own table
+          const u32 nShortV = std::min<u32>(grid.x, (u32)(8 * ctx->numCU));
+          hipLaunchKernelGGL((k_peak_both<false, true, true>), dim3(nShortV + gridW.x), dim3(256), 0, s, nShortV, ctx->candHdr.as<uint4>(),
+                             S.end, S.p, reinterpret_cast<const float*>(S.V), S.chromOff, nChrom, misc + M_NHEADS, ctx->longList.as<u32>(),
+                             misc + M_TICKET3, ctx->par.thr, ctx->par.min_auc, ctx->par.min_len, ctx->cand.as<gx_peak>(),
+                             ctx->valid.as<u32>(), S.qLut);
+        } else if (S.V) {  // p from the table p(V) (`q` carries the exact pileups); every workgroup copies the table's compact form to LDS
           const u32 nShortV = std::min<u32>(grid.x, (u32)(8 * ctx->numCU));
           GX_LAUNCH_PEAKS(false, true, nShortV, reinterpret_cast<const float*>(S.V));
         } else if (S.q)

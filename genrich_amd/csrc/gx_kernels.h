@@ -49,6 +49,7 @@ enum : u32 {
   // (512 / 1024 / 2048: ST_PT_FULL / ST_SB_FULL / ST_SB_FRAC, gx_sort.h -- internal, the host retries)
   ST_END_PILE = 4096u,   // a chromosome's pileup does not return to 0 behind its last base ("finishes at %f (not 0.0)", :2283-2289)
   ST_BH_LEN = 8192u,     // the lengths behind the p-value table do not add up to the genome length (ERRISSUE, :377-382)
+  ST_Q_LOOSE = 16384u,   // (internal) -q on the loose slots: q is no threshold on the pileup -- the host takes the tight table
 };
 
 // ---- "risky" p-values (gx_math.h: round_checked) ------------------------------------------------

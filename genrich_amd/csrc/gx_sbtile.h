@@ -355,7 +355,8 @@ __device__ __forceinline__ void sbt_tile(int* lds, const u32 TR_CAP, const uint1
   if (lane == 0) out.to.tileCount[t] = total;
   // the unused slots of the tile: zero-length intervals behind its last one (a tile without intervals does not
   // know where the previous one ended: k_scan_iv fills its slots)
-  if (total && vsig != 0x7FFFFFFF) {  // wave-uniform
+  // (round 6: also when the sweep's bits come later -- a sample whose lambda is not known yet, LooseCtl handed over all the same)
+  if (total && (vsig != 0x7FFFFFFF || out.to.ctl)) {  // wave-uniform
     const u32 size = n + 1;
     for (u32 j = total + lane; j < size; j += 64) {
       st_u32(out.to.looseEnd, slot + j, lastEnd);
@@ -475,7 +476,7 @@ __device__ __forceinline__ void sbt_heavy(SbtLds& L, const u32 scrWords, const u
   }
   if (tid == 0) out.to.tileCount[t] = total;
   if (FRAC && fragTerms && tid == 0) out.heavyList[atomicAdd(out.nHeavyG, 1u)] = t;
-  if (total && vsig != 0x7FFFFFFF)  // the unused slots: zero-length intervals behind the last one (the sweep walks the loose slots)
+  if (total && (vsig != 0x7FFFFFFF || out.to.ctl))  // the unused slots: zero-length intervals behind the last one (the sweep walks the loose slots)
     for (u32 j = total + tid; j < n + 1; j += SBT_NT) {
       out.to.looseEnd[slot + j] = lastEnd;
       out.to.looseV[slot + j] = 0;

@@ -96,45 +96,69 @@ __global__ __launch_bounds__(256) void k_loose_verdict(LooseCtl* __restrict__ ct
 }
 __global__ __launch_bounds__(256) void k_loose_late(const u32* __restrict__ tileSlot, const u32* __restrict__ tileCount,
                                                     const u32* __restrict__ tileLastEnd, u32 nTiles, u32* __restrict__ looseEnd,
-                                                    int* __restrict__ looseV, LooseCtl* __restrict__ ctl, u64* __restrict__ sigMask) {
+                                                    int* __restrict__ looseV, LooseCtl* __restrict__ ctl, u64* __restrict__ sigMask,
+                                                    const u32* __restrict__ vq = nullptr, u32* __restrict__ st = nullptr) {
   __shared__ u32 red[2];
-  const int vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(ctl, false, red, true));
-  if (vsig == 0x7FFFFFFF) return;  // (k_loose_verdict said so: not reached)
+  int vsig;
+  if (vq) {
+    // -q (k_qv_table): vq[0] = the smallest pileup present whose q passes, vq[1] = 1 + the largest present whose q does not
+    const u32 v0 = vq[0], v1 = vq[1];
+    if (v1 > v0) {  // q is no threshold on the pileup (a table p(V) that is not monotone): the host takes the tight table
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(st, ST_Q_LOOSE);
+      return;
+    }
+    vsig = v0 > 0x7FFFFFFFu ? 0x7FFFFFFF : (int)v0;   // (no pileup passes: no bit, the fillers all the same)
+  } else {
+    vsig = (int)__builtin_amdgcn_readfirstlane(loose_vsig(ctl, false, red, true));
+    if (vsig == 0x7FFFFFFF) return;  // (k_loose_verdict said so: not reached)
+  }
   const int lane = lane_id();
-  // (a tile is a few hundred slots: what a wavefront waits for is the chain header -> pileups, so the next tile's header is asked for
-  // under this tile's pass, and a tile's pileups 256 at a time)
+  // (the fillers of a tile's unused slots are the tile stage's: it writes them whenever LooseCtl is handed to it.  A tile is a few
+  // hundred slots: what a wavefront waits for is the chain header -> pileups, so two tiles ahead the header is asked for, one tile
+  // ahead the first 256 pileups -- k_pack_pval's pipeline)
   const u32 stride = gridDim.x * 4;
-  u32 tn = blockIdx.x * 4 + (threadIdx.x >> 6);
-  u32 ns0 = 0, ns1 = 0, ncnt = 0, nle = 0;
-  if (tn < nTiles) { ns0 = tileSlot[tn]; ns1 = tileSlot[tn + 1]; ncnt = tileCount[tn]; nle = tileLastEnd[tn]; }
-  while (tn < nTiles) {
-    const u32 s0 = ns0, size = ns1 - ns0, cnt = ncnt, lastEnd = nle;
-    tn += stride;
-    if (tn < nTiles) { ns0 = tileSlot[tn]; ns1 = tileSlot[tn + 1]; ncnt = tileCount[tn]; nle = tileLastEnd[tn]; }
-    if (!cnt) continue;  // (k_scan_iv has filled the slots of a tile without intervals)
-    for (u32 j0 = 0; j0 < size; j0 += 256) {
-      int v[4];
+  u32 t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  struct Hdr { u32 s0, cnt; };
+  auto loadHdr = [&](u32 tt) { return tt < nTiles ? Hdr{tileSlot[tt], tileCount[tt]} : Hdr{0u, 0u}; };
+  auto loadV = [&](const Hdr& h, int (&v)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 j = (u32)k * 64 + (u32)lane;
+      v[k] = j < h.cnt ? looseV[h.s0 + j] : (int)0x80000000;
+    }
+  };
+  auto bits = [&](u32 base, const int (&v)[4], u32 left) {   // (left: intervals from `base` on)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if ((u32)k * 64 >= left) break;  // wave-uniform
+      const u64 m = __ballot((u32)k * 64 + (u32)lane < left && v[k] >= vsig);
+      if (m && lane == 0) {
+        const u32 b = base + (u32)k * 64, sh = b & 63u;
+        atomicOr((unsigned long long*)&sigMask[b >> 6], m << sh);
+        if (sh && (m >> (64u - sh))) atomicOr((unsigned long long*)&sigMask[(b >> 6) + 1], m >> (64u - sh));
+      }
+    }
+  };
+  Hdr h1 = loadHdr(t), h2 = loadHdr(t + stride);
+  int v1[4];
+  loadV(h1, v1);
+  for (; t < nTiles; t += stride) {
+    const Hdr h = h1;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = v1[k];
+    h1 = h2;
+    loadV(h1, v1);
+    h2 = loadHdr(t + 2 * stride);
+    bits(h.s0, v, h.cnt);
+    for (u32 j0 = 256; j0 < h.cnt; j0 += 256) {   // (a tile with a peak)
+      int w[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const u32 j = j0 + (u32)k * 64 + (u32)lane;
-        v[k] = j < cnt ? looseV[s0 + j] : (int)0x80000000;
+        w[k] = j < h.cnt ? looseV[h.s0 + j] : (int)0x80000000;
       }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const u32 j = j0 + (u32)k * 64 + (u32)lane;
-        if (j0 + (u32)k * 64 >= size) break;  // wave-uniform
-        const bool sg = j < cnt && v[k] >= vsig;
-        if (j >= cnt && j < size) {
-          looseEnd[s0 + j] = lastEnd;
-          looseV[s0 + j] = 0;
-        }
-        const u64 m = __ballot(sg);
-        if (m && lane == 0) {
-          const u32 b = s0 + j0 + (u32)k * 64, sh = b & 63u;
-          atomicOr((unsigned long long*)&sigMask[b >> 6], m << sh);
-          if (sh && (m >> (64u - sh))) atomicOr((unsigned long long*)&sigMask[(b >> 6) + 1], m >> (64u - sh));
-        }
-      }
+      bits(h.s0 + j0, w, h.cnt - j0);
     }
   }
 }
@@ -159,7 +183,8 @@ constexpr int PP_HOT = 1024;   // whole pileups below this have their p-value in
 // of ~100 sums (k_bh_from_dense) instead of a hash insertion per interval read back from the tight table (k_bh_hist: 0.25 ms at
 // hg38 / 50 M fragments).  Whole pileups inside the table go to an LDS histogram (two copies, by lane parity; 32-bit: a workgroup's
 // share of a genome is far below 2^32 bases), fractional ones to `dense` directly; the pileups beyond the table are k_deep_hist's.
-template <bool MASKS, bool HIST = false>
+// TIGHT = false (round 6, with HIST): the histogram alone -- -q on a replicate whose sweep walks the loose slots makes no tight table.
+template <bool MASKS, bool HIST = false, bool TIGHT = true>
 __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const Scalars* __restrict__ sc,
                                                    const float* __restrict__ lutP, u32* __restrict__ ivEnd,
                                                    float* __restrict__ pOut, float thr, u64* __restrict__ sigMask,
@@ -256,8 +281,10 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
               p = (u32)v[k] < PV_LUT ? lutP[v[k]] : 0.0f;
             }
           }
-          ivEnd[dst + i] = e[k];
-          pOut[dst + i] = p;
+          if (TIGHT) {
+            ivEnd[dst + i] = e[k];
+            pOut[dst + i] = p;
+          }
         }
         if (HIST) {  // the interval's length to its pileup's sum (all lanes take part in the shuffles)
           u32 pe = (u32)__shfl_up((int)e[k], 1, 64);
@@ -562,6 +589,24 @@ __global__ __launch_bounds__(256) void k_q_fill_cands(const uint4* __restrict__ 
         q[i0 + k * 64] = qv;
       }
     }
+  }
+}
+
+// -q on the loose slots (round 6): q as a function of the whole pileup, from the run's {key, q} table -- q(c) = table[p(c)] for every
+// pileup c that occurs (a pileup that does not occur was never inserted: its entry is never read) --, and from which pileup on an
+// interval is significant: vq[0] = min over the present c with q > thr of 120 c, vq[1] = max over the others of 120 c + 1 (both preset
+// by the host: ~0 and 0).  qLut[c]: what k_peak_both's LDS copy is made of.
+__global__ __launch_bounds__(256) void k_qv_table(const float* __restrict__ lutP, const u64* __restrict__ kq, u32 capMask, float thr,
+                                                  float* __restrict__ qLut, u32* __restrict__ vq) {
+  const u32 c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= PV_WHOLE) return;
+  const float pv = lutP[c * (u32)GX_UNIT];   // (the entry k_bh_from_dense made the key of)
+  float qv = 0.0f;
+  const bool present = kq_probe(kq, capMask, pv == 0.0f ? 0u : __float_as_uint(pv), &qv);
+  qLut[c] = present ? qv : 0.0f;
+  if (present) {
+    if (qv > thr) atomicMin(&vq[0], c * (u32)GX_UNIT);
+    else atomicMax(&vq[1], c * (u32)GX_UNIT + 1u);
   }
 }
 
@@ -1290,8 +1335,14 @@ __device__ __forceinline__ float p_from_v(const float* __restrict__ hot, const f
   if (v != c * (u32)GX_UNIT) return lut[v < PV_LUT ? v : 0u];
   return hot[c < PV_WHOLE ? c : 0u];
 }
-template <bool USEQ, bool PV>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
-__device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, const float* __restrict__ hot,
+// (-q on the loose slots: whole pileups within the table only -- unit weights, LooseCtl::bad otherwise)
+__device__ __forceinline__ float q_from_v(const float* __restrict__ hotq, const int* __restrict__ V, u32 i) {
+  const u32 c = __umulhi((u32)V[i], 0x88888889u) >> 6;  // V / 120
+  return hotq[c < PV_WHOLE ? c : 0u];
+}
+// (PVQ, round 6: -q on the loose slots -- q as well is a function of the whole pileup, from a second LDS table, k_qv_table's)
+template <bool USEQ, bool PV, bool PVQ = false>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
+__device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, const float* __restrict__ hot, const float* __restrict__ hotq,
                                                 const uint4* __restrict__ hdr, const u32* __restrict__ end,
                                                 const float* __restrict__ p, const float* __restrict__ q,
                                                 const u32* __restrict__ chromOff, u32 nChrom,
@@ -1328,12 +1379,13 @@ __device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, c
           if (PV) pv[a] = p_from_v(hot, p, reinterpret_cast<const int*>(q), i);
           else pv[a] = p[i];
           if (USEQ) qv[a] = q[i];
+          if (PVQ) qv[a] = q_from_v(hotq, reinterpret_cast<const int*>(q), i);
         }
       }
 #pragma unroll
       for (int a = 0; a < AH; a++) {
         if (st0 + a >= steps) break;  // wave-uniform
-        float pq = USEQ ? qv[a] : pv[a];
+        float pq = USEQ || PVQ ? qv[a] : pv[a];
         const bool sg = in[a] && pq > thr;  // non-significant intervals inside the span only fill gaps
         float term = 0.0f;
         if (sg) term = (float)(e[a] - sPrev[a]) * (pq - thr);  // 949-950: float product ...
@@ -1380,8 +1432,8 @@ __device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, c
 // per step, AH steps of loads in flight; the ordered float sum runs row after row (16 dependent DPP adds
 // each, the running value carried from row to row by a readlane); maxima by DPP rotations inside the rows and
 // readlanes across them: no LDS shuffle anywhere.
-template <bool PV>
-__device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, const float* __restrict__ hot,
+template <bool PV, bool PVQ = false>
+__device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, const float* __restrict__ hot, const float* __restrict__ hotq,
                                                const uint4* __restrict__ hdr, const u32* __restrict__ end,
                                                const float* __restrict__ p, const float* __restrict__ qIn,
                                                const u32* __restrict__ chromOff, u32 nChrom,
@@ -1415,12 +1467,13 @@ __device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, co
           if (PV) pv[a] = p_from_v(hot, p, reinterpret_cast<const int*>(qIn), i);
           else pv[a] = p[i];
           if (q) qv[a] = q[i];
+          if (PVQ) qv[a] = q_from_v(hotq, reinterpret_cast<const int*>(qIn), i);
         }
       }
 #pragma unroll
       for (int a = 0; a < AH; a++) {
         if (base + a * 64 > i1) break;  // wave-uniform
-        float pq = q ? qv[a] : pv[a];
+        float pq = q || PVQ ? qv[a] : pv[a];
         const bool sg = in[a] && pq > thr;       // non-significant intervals inside the span only fill gaps
         float term = 0.0f;
         if (sg) term = (float)(e[a] - sPrev[a]) * (pq - thr);  // 949-950: float product ...
@@ -1464,23 +1517,28 @@ __device__ __forceinline__ void peak_walk_body(const u32 blk, const u32 nBlk, co
 // The two walks in ONE launch (they share nothing but the candidate headers): the first workgroups take the
 // long candidates, the other nShort the short ones -- the few long candidates (one wavefront each, a chain of dependent
 // round trips) run beside the short ones instead of behind them.
-template <bool USEQ, bool PV>
+template <bool USEQ, bool PV, bool PVQ = false>
 __global__ __launch_bounds__(256) void k_peak_both(u32 nShort, const uint4* __restrict__ hdr, const u32* __restrict__ end,
                                                    const float* __restrict__ p, const float* __restrict__ q,
                                                    const u32* __restrict__ chromOff, u32 nChrom,
                                                    const u32* __restrict__ nCands, const u32* __restrict__ longList,
                                                    const u32* __restrict__ nLong, float thr, float minAUC, int minLen,
-                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid) {
+                                                   gx_peak* __restrict__ cand, u32* __restrict__ valid,
+                                                   const float* __restrict__ qLut = nullptr) {
+  static_assert(!PVQ || (PV && !USEQ), "q by pileup rides the sweep on the loose slots");
   __shared__ float hot[PV ? PV_WHOLE : 1];
+  __shared__ float hotq[PVQ ? PV_WHOLE : 1];
   const u32 nWalk = gridDim.x - nShort;  // (the long candidates' workgroups come first in the grid: they are the long pole)
 #ifndef GX_PK_NO_EARLY_EXIT
   if (blockIdx.x < nWalk && blockIdx.x * 4 >= *nLong) return;  // (no long candidate for this workgroup: not even the table)
 #endif
+  if (PVQ)
+    for (u32 i = threadIdx.x; i < PV_WHOLE; i += blockDim.x) hotq[i] = qLut[i];
   if (PV) load_whole_lut(hot, p);
   if (blockIdx.x >= nWalk)
-    peak_short_body<USEQ, PV>(blockIdx.x - nWalk, nShort, hot, hdr, end, p, q, chromOff, nChrom, nCands, thr, minAUC, minLen, cand, valid);
+    peak_short_body<USEQ, PV, PVQ>(blockIdx.x - nWalk, nShort, hot, hotq, hdr, end, p, q, chromOff, nChrom, nCands, thr, minAUC, minLen, cand, valid);
   else
-    peak_walk_body<PV>(blockIdx.x, nWalk, hot, hdr, end, p, q, chromOff, nChrom, longList, nLong, thr, minAUC, minLen, cand, valid);
+    peak_walk_body<PV, PVQ>(blockIdx.x, nWalk, hot, hotq, hdr, end, p, q, chromOff, nChrom, longList, nLong, thr, minAUC, minLen, cand, valid);
 }
 
 // ---- the sweep's three ordered compactions, each in ONE pass -------------------------------------------------

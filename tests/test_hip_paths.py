@@ -14,7 +14,7 @@ from test_hip_parity import assert_same_run, hip_backend
 pytestmark = pytest.mark.gpu
 
 FUSED, LOOSE, FELL_BACK, PT_GREW, PAIRS, FRAC_PAIRS, PILES_MADE = 1, 2, 4, 8, 16, 128, 256
-MERGE_P, PACK_HIST, LAZY_Q, LATE_LOOSE = 1024, 2048, 8192, 16384
+MERGE_P, PACK_HIST, LAZY_Q, LATE_LOOSE, Q_LOOSE = 1024, 2048, 8192, 16384, 32768
 
 
 def _case(seed=11, n=90_000, lens=(400_000, 123_457, 16_384, 4_097, 5), **kw):
@@ -60,9 +60,12 @@ def test_default_run_takes_both_fast_paths_and_a_second_sweep_agrees():
     assert first.tobytes() == again.tobytes() == o.get_peaks().tobytes()
 
 
-def test_q_mode_uses_the_fused_tile_stage_but_the_tight_table():
+@pytest.mark.parametrize("q_loose", [True, False])
+def test_q_mode_uses_the_fused_tile_stage_and_since_round_6_the_loose_slots(monkeypatch, q_loose):
+    if not q_loose:
+        monkeypatch.setenv("GX_NO_Q_LOOSE", "1")
     o, h, flags = _run(_case(seed=3), B.make_params(pq=0.05, qval=True, min_auc=20.0))
-    assert flags & FUSED and not flags & LOOSE
+    assert flags & FUSED and bool(flags & LOOSE) == q_loose and bool(flags & Q_LOOSE) == q_loose, flags
 
 
 def test_a_control_uses_the_fused_tile_stage_for_both_samples():
@@ -621,7 +624,7 @@ def test_q_values_inside_the_candidates_only_and_the_whole_array_on_request(monk
         case["skip"] = [False, True, False, False]
     o, h, flags = _run(case, B.make_params(pq=0.05, qval=True, min_auc=20.0))
     assert h.n_peaks > 0
-    assert bool(flags & LAZY_Q) == lazy, flags
+    assert bool(flags & LAZY_Q) == (lazy or bool(flags & Q_LOOSE)), flags   # (-q on the loose slots never makes the array unasked)
     # a second sweep on the same context: the first one's table is released and built again, q asked for AFTER the peaks
     h.find_peaks()
     assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
@@ -668,3 +671,37 @@ def test_fractional_weights_sweep_the_loose_slots_once_the_table_is_there(kind):
             assert bool(flags & LOOSE) == want and bool(flags & LATE_LOOSE) == want, flags
     assert h.n_peaks > 0
     o.close()
+
+
+# ---- -q on the loose slots (round 6: k_pack_pval<.., HIST, false>, k_qv_table, k_loose_late, k_peak_both<.., PVQ>) ----
+
+@pytest.mark.parametrize("kind", ["plain", "skipped", "fault", "deep", "twice"])
+def test_q_values_on_the_loose_slots_without_a_tight_table(monkeypatch, kind):
+    """One replicate without a control and -q: p is a function of the pileup, and so is q (computeQval 352-401 maps equal p to equal
+    q) -- BH's histogram is summed from the loose slots, q tabulated by whole pileup, callPeaks' test (1015) becomes "from this
+    pileup on", and updatePeak (943-970) takes p and q from two LDS tables.  The tight table is made when gx_get_intervals asks.
+    `fault`: the device is told that q is no threshold on the pileup -- the run is repeated on the tight table, and the context
+    stays there; `deep`: a pileup beyond the table p(V) takes the tight table from the start.  The oracle's bits every time."""
+    if kind == "fault":
+        monkeypatch.setenv("GX_FAULT", "2")
+    lens = [700_000, 250_000, 4_097, 90_000]
+    tr = synth.make_fragments(lens, 140_000, 171, peak_every=20_000, tower_every=300_000, frac_tower=0.2 if kind == "deep" else 0.02)
+    case = dict(lens=lens, replicates=[dict(save=None, treat=tr, ctrl=None)])
+    if kind == "skipped":
+        case["skip"] = [False, True, False, False]
+    params = B.make_params(pq=0.05, qval=True, min_auc=20.0)
+    o, h, flags = _run(case, params)
+    assert h.n_peaks > 0
+    assert bool(flags & Q_LOOSE) == (kind in ("plain", "skipped", "twice")), flags
+    assert flags & PACK_HIST or kind == "fault" or kind == "deep", flags
+    if kind == "twice":   # the same context once more: the intervals were asked for, so the replicate has its tight table now
+        h.find_peaks()
+        assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
+        assert not h.path_info() & Q_LOOSE
+        h.reset()
+        sh = B.run_case(h, case)
+        assert h.path_info() & Q_LOOSE
+        assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
+        h.find_peaks()    # ... and twice in a row on the loose slots
+        assert h.path_info() & Q_LOOSE
+        assert h.get_peaks().tobytes() == o.get_peaks().tobytes()
