@@ -81,7 +81,8 @@ def run_paths(seed):
         knobs["GX_NO_FRAC_PAIRS"] = "1"
     # (round 6's alternatives: q of every interval by k_qlookup, BH's histogram by insertion, the control merge by a workgroup per
     # tile / leaving both pileups)
-    for k, pr in (("GX_NO_LAZY_Q", 0.25), ("GX_NO_PACK_HIST", 0.2), ("GX_MERGE_WG", 0.15), ("GX_NO_MERGE_P", 0.15)):
+    for k, pr in (("GX_NO_LAZY_Q", 0.25), ("GX_NO_PACK_HIST", 0.2), ("GX_MERGE_WG", 0.15), ("GX_NO_MERGE_P", 0.15), ("GX_NO_LATE_LOOSE", 0.2),
+                  ("GX_NO_Q_LOOSE", 0.25)):
         if rng.random() < pr:
             knobs[k] = "1"
     for k in PATH_KNOBS:
@@ -111,8 +112,15 @@ def run_paths(seed):
     h.push_events = in_pieces
     sh = B.run_case(h, case)
     T.assert_same_run(o, h, so, sh, case)
-    knobs = dict(knobs, beds=bool(case.get("beds")), packed=packed)
-    return knobs, pieces, h.path_info()
+    flags = h.path_info()
+    again = rng.random() < 0.4   # the same case once more on the context (what it has learned -- fractions seen -- takes other paths: k_loose_late)
+    if again:
+        h.reset()
+        sh = B.run_case(h, case)
+        T.assert_same_run(o, h, so, sh, case)
+        flags |= h.path_info() << 16
+    knobs = dict(knobs, beds=bool(case.get("beds")), packed=packed, again=again)
+    return knobs, pieces, flags
 
 
 def describe(case):
@@ -122,7 +130,7 @@ def describe(case):
     return dict(lens=case["lens"], skip=case.get("skip"), beds=case.get("beds"), reps=reps)
 
 
-PATH_KNOBS = ("GX_SBSHIFT", "GX_FORCE_HALF_BINS", "GX_NO_PAIRS", "GX_NO_FRAC_PAIRS", "GX_NO_LAZY_Q", "GX_NO_PACK_HIST", "GX_MERGE_WG", "GX_NO_MERGE_P")
+PATH_KNOBS = ("GX_SBSHIFT", "GX_FORCE_HALF_BINS", "GX_NO_PAIRS", "GX_NO_FRAC_PAIRS", "GX_NO_LAZY_Q", "GX_NO_PACK_HIST", "GX_MERGE_WG", "GX_NO_MERGE_P", "GX_NO_LATE_LOOSE", "GX_NO_Q_LOOSE")
 mid = "--mid" in sys.argv
 paths = "--paths" in sys.argv
 import time  # noqa: E402
