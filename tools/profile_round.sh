@@ -8,7 +8,9 @@ tag=$1; cfg=${2:-2}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-cmd="python bench.py --config $cfg --steps 2 --warmup 1 --no-cpu --no-e2e --no-materialised"
+bcfg="--config $cfg"
+[ "$cfg" = "2q" ] && bcfg="--config 2 --qval"   # (the headline with -q: the p + q scan)
+cmd="python bench.py $bcfg --steps 2 --warmup 1 --no-cpu --no-e2e --no-materialised"
 export GX_ROCTX=1   # the library brackets its phases with roctx ranges: the trace pass attributes every kernel to its phase
 passes=" ${GX_PROF_PASSES:-trace fetch write rdsz wrsz sq1 sq2} "
 run() {  # name, rocprofv3 options...
