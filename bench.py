@@ -462,7 +462,7 @@ def main():
         # BASELINE.json's other GPU configs in the same line (the driver runs bench.py once, with defaults)
         detail, brief = {}, {}
         # "2q": the headline workload with -q 0.05 -- north_star's "p + q scan" of one 50 M-fragment sample
-        cfg2q = dict(CONFIGS[2], qval=True, gate_chroms=8, name="configs[1] with -q 0.05",
+        cfg2q = dict(CONFIGS[2], qval=True, gate_chroms=8, name="configs[1] with -q 0.05", profile_as="2q",
                      desc=CONFIGS[2]["desc"].replace("-p 0.01", "-q 0.05"))
         for c, ccfg, cplain in (("2q", cfg2q, False), ("2E", dict(CONFIGS["2E"]), True), (3, dict(CONFIGS[3]), True), (4, dict(CONFIGS[4]), True),
                                 (5, dict(CONFIGS[5]), True)):
@@ -609,7 +609,8 @@ def bench_one(config, cfg, args, env, steps, warmup, plain, want_e2e, want_cpu, 
     # without a matching profile, the tile stage.  Inside the timed region only THAT kernel's phase is bracketed by HIP
     # events on the library's stream (an event record costs the stream a ~5 us bubble); all phases are timed in two extra,
     # untimed steps afterwards.
-    prof = load_profile(config, args.frags, world, plain)
+    # (the headline with -q has a profile of its own: tools/profile_round.sh <tag> 2q)
+    prof = load_profile(cfg.get("profile_as", config), args.frags, world, plain or "profile_as" in cfg)
     dom = prof.get("dominant", {}).get("kernel") if prof else None
     # (the library phase that brackets it -- gx_set_phase_filter -- comes from the profile's own marker trace: the library's roctx
     # ranges, GX_ROCTX; without a profile of this build the tile stage is what is timed)
