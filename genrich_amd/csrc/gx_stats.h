@@ -115,22 +115,21 @@ __global__ __launch_bounds__(256) void k_loose_late(const u32* __restrict__ tile
   const int lane = lane_id();
   // (the fillers of a tile's unused slots are the tile stage's: it writes them whenever LooseCtl is handed to it.  A tile is a few
   // hundred slots: what a wavefront waits for is the chain header -> pileups, so two tiles ahead the header is asked for, one tile
-  // ahead its pileups -- k_pack_pval's pipeline)
+  // ahead the first 256 pileups -- k_pack_pval's pipeline)
   const u32 stride = gridDim.x * 4;
   u32 t = blockIdx.x * 4 + (threadIdx.x >> 6);
   struct Hdr { u32 s0, cnt; };
   auto loadHdr = [&](u32 tt) { return tt < nTiles ? Hdr{tileSlot[tt], tileCount[tt]} : Hdr{0u, 0u}; };
-  constexpr int LV = 8;   // pileups per lane asked for ahead: 512 per tile (an ATAC tile holds ~380 intervals, a tile of config 2 ~110)
-  auto loadV = [&](const Hdr& h, int (&v)[LV]) {
+  auto loadV = [&](const Hdr& h, int (&v)[4]) {
 #pragma unroll
-    for (int k = 0; k < LV; k++) {
+    for (int k = 0; k < 4; k++) {
       const u32 j = (u32)k * 64 + (u32)lane;
       v[k] = j < h.cnt ? looseV[h.s0 + j] : (int)0x80000000;
     }
   };
-  auto bits = [&](u32 base, const int (&v)[LV], u32 left) {   // (left: intervals from `base` on)
+  auto bits = [&](u32 base, const int (&v)[4], u32 left) {   // (left: intervals from `base` on)
 #pragma unroll
-    for (int k = 0; k < LV; k++) {
+    for (int k = 0; k < 4; k++) {
       if ((u32)k * 64 >= left) break;  // wave-uniform
       const u64 m = __ballot((u32)k * 64 + (u32)lane < left && v[k] >= vsig);
       if (m && lane == 0) {
@@ -141,21 +140,21 @@ __global__ __launch_bounds__(256) void k_loose_late(const u32* __restrict__ tile
     }
   };
   Hdr h1 = loadHdr(t), h2 = loadHdr(t + stride);
-  int v1[LV];
+  int v1[4];
   loadV(h1, v1);
   for (; t < nTiles; t += stride) {
     const Hdr h = h1;
-    int v[LV];
+    int v[4];
 #pragma unroll
-    for (int k = 0; k < LV; k++) v[k] = v1[k];
+    for (int k = 0; k < 4; k++) v[k] = v1[k];
     h1 = h2;
     loadV(h1, v1);
     h2 = loadHdr(t + 2 * stride);
     bits(h.s0, v, h.cnt);
-    for (u32 j0 = LV * 64; j0 < h.cnt; j0 += LV * 64) {   // (a tile with a tower on it)
-      int w[LV];
+    for (u32 j0 = 256; j0 < h.cnt; j0 += 256) {   // (a tile with a peak)
+      int w[4];
 #pragma unroll
-      for (int k = 0; k < LV; k++) {
+      for (int k = 0; k < 4; k++) {
         const u32 j = j0 + (u32)k * 64 + (u32)lane;
         w[k] = j < h.cnt ? looseV[h.s0 + j] : (int)0x80000000;
       }
