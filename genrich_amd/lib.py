@@ -364,7 +364,9 @@ class Genrich:
 
     def path_info(self):
         """Which device path the last calls took: GX_PATH_* bits (1 fused tile stage, 2 loose-slot sweep, 4 fell back, 8 page tables grew,
-        16 pair records, 32 dense BH all-reduce, 64 range BH exchange, 128 fractional pair records, 256 pileup floats written)."""
+        16 pair records, 32 dense BH all-reduce, 64 range BH exchange, 128 fractional pair records, 256 pileup floats written, 512 8-byte
+        events read in place, 1024 the control merge scored its intervals, 2048 BH's histogram from the pileup sums, 8192 q looked up
+        where it is read, 16384 the loose slots swept with bits written late, 32768 -q on the loose slots)."""
         f = C.c_uint(0)
         self._check(self.lib.gx_path_info(self.ctx, C.byref(f)))
         return f.value
