@@ -536,7 +536,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   const bool packHist = ctx->par.qval_opt && ctx->sample == 1 && ctx->reps.size() == 1 && ctx->reps[0].ctrlIsConst && !ctx->sawFrac &&
                         ctx->world <= 1 && !ctx->forceColl && !ctx->knob.noPackHist;
   // (round 6) ... and with -q as well, where q is a function of the pileup like p: BH's histogram is summed from the loose slots, q
-  // tabulated by whole pileup (k_qv_table), the bits written from "q passes from this pileup on", the sweep as with -p -- no tight table
+  // tabulated by whole pileup (k_bh_small), the bits written from "q passes from this pileup on", the sweep as with -p -- no tight table
   const bool qLoose = packHist && ctx->reps[0].loose && ctx->reps[0].looseSweep && (ctx->reps[0].latePending || ctx->reps[0].lateLoose) &&
                       !ctx->knob.noQLoose && !ctx->qLooseBad && !ctx->hasBed;
   ctx->qLooseUsed = false;
@@ -569,8 +569,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
 
   ctx->lazyQUsed = false;
   if (qLoose) {
-    if (int rc = loose_hist(ctx, fa)) return rc;
-    if (int rc = bh_qvalues(ctx, fa, n, genomeOpt, true)) return rc;
+    if (int rc = loose_hist(ctx, fa, genomeOpt)) return rc;
   } else if (ctx->par.qval_opt) {
     if (int rc = bh_qvalues(ctx, fa, n, genomeOpt)) return rc;
   }
@@ -580,12 +579,7 @@ int gx_find_peaks(gx_ctx* ctx, size_t* n_peaks, uint64_t* genome_len, uint64_t* 
   SweepSrc src{};
   src.nChrom = nChrom;
   if (qLoose) {
-    // q by whole pileup and from which pileup on it passes; the bits (and, the first time, the fillers) on the loose slots
-    HIPCHECK(ctx->qLut.ensure((size_t)PV_WHOLE * 4));
-    const u32 vq0[2] = {0xFFFFFFFFu, ctx->knob.fault == 2 ? 0xFFFFFFFFu : 0u};   // (GX_FAULT=2: "q is no threshold on the pileup")
-    HIPCHECK(hipMemcpyAsync(misc + M_VQ, vq0, 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_qv_table, dim3((PV_WHOLE + 255) / 256), dim3(256), 0, s, ctx->pvLut.as<float>(), ctx->bhKQ.as<u64>(),
-                       ctx->bhLiveCap - 1, ctx->par.thr, ctx->qLut.as<float>(), misc + M_VQ);
+    // (q by whole pileup and from which pileup on it passes: k_bh_small, above) the bits on the loose slots
     HIPCHECK(hipMemsetAsync(ctx->swMask.p, 0, fa.looseStride * 8, s));   // (the significance words: a run before may have left its own)
     hipLaunchKernelGGL(k_loose_late, dim3(std::max(1u, std::min((ctx->nTiles + 3) / 4, (u32)(8 * ctx->numCU)))), dim3(256), 0, s,
                        ctx->tileSlot.as<u32>(), ctx->tileIvCount.as<u32>(), ctx->tileLastEnd.as<u32>(), ctx->nTiles,

@@ -312,7 +312,7 @@ struct gx_ctx {
   long long satDropped = 0;     // ... which dropped this many of them (gx_saturation_dropped)
   bool qLooseBad = false;       // -q on the loose slots was called off once (ST_Q_LOOSE): this context takes the tight table from now on
   bool qLooseUsed = false;      // the last gx_find_peaks: -q, the sweep on the loose slots (GX_PATH_Q_LOOSE)
-  DevBuf qLut;                  // ... its q by whole pileup (k_qv_table)
+  DevBuf qLut;                  // ... its q by whole pileup (k_bh_small)
   bool lateLooseUsed = false;   // ... and the replicate the sweep walked was such a sample (GX_PATH_LATE_LOOSE)
   bool lateLoose = false;       // this sample: the sweep's bits on the loose slots come after the table p(V) (k_loose_late)
   bool lazyQUsed = false;       // the last -q run took k_sig_from_p / k_q_fill_cands (GX_PATH_LAZY_Q)
@@ -386,7 +386,7 @@ void recycle(gx_ctx* ctx, DevBuf& b) {
 }
 
 // misc device words (u32 indices into ctx->misc)
-enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_BHOVF = 7, M_GENOME = 10 /* u64 */, M_NMERGED = 15, M_PSTAR = 14, M_VQ = 12 /* two words: k_qv_table */,
+enum { M_TICKET = 0, M_NIV = 1, M_BHCOUNT = 5, M_ALLONE = 6, M_BHOVF = 7, M_GENOME = 10 /* u64 */, M_NMERGED = 15, M_PSTAR = 14, M_VQ = 12 /* two words: k_bh_small */,
        // the sweep's counters are contiguous: one memset clears them
        M_TICKET2 = 16, M_SWCOUNT = 17, M_NPEAKS = 18, M_TICKET3 = 19, M_TICKET4 = 20, M_NHEADS = 21, M_PEAKBP = 22 /* u64 */,
        M_SWEEP_FIRST = 16, M_SWEEP_WORDS = 8, M_WORDS = 32 };

@@ -502,8 +502,8 @@ int ensure_q(gx_ctx* ctx, PArray& pa, int idx) {
 }
 
 // -q on the loose slots: the "bp at pileup V" histogram that materialize_rep(.., hist) collects while it writes the tight table, without
-// the table (k_pack_pval<.., HIST, false>: reads the loose slots, writes nothing but the sums)
-int loose_hist(gx_ctx* ctx, PArray& pa) {
+// the table (k_pack_pval<.., HIST, false>: reads the loose slots, writes nothing but the sums), then Benjamini-Hochberg on it
+int loose_hist(gx_ctx* ctx, PArray& pa, bool genomeOpt) {
   hipStream_t s = ctx->stream;
   phase_begin(ctx, "pval");
   const u32 cap = 1u << ctx->bhCapLog;
@@ -518,7 +518,25 @@ int loose_hist(gx_ctx* ctx, PArray& pa) {
   hipLaunchKernelGGL((k_pack_pval<false, true, false>), gridH, dim3(256), 0, s, pin, ctx->nTiles, ctx->dScal.as<Scalars>(),
                      ctx->pvLut.as<float>(), (u32*)nullptr, (float*)nullptr, ctx->par.thr, (u64*)nullptr, (u64*)nullptr,
                      ctx->dStatus.as<u32>(), (const u32*)ctx->tilePrevEnd.as<u32>(), ctx->bhDense.as<u64>());
-  ctx->denseHistIdx = ctx->finalIdx;
+  phase_end(ctx);
+  // computeQval on ~100 distinct values, whole: one workgroup (k_bh_small) -- q by pileup, from which pileup on it passes, the values'
+  // {key, q} in the run's table for whoever asks for the q array later (ensure_q)
+  phase_begin(ctx, "bh");
+  u32* misc = ctx->misc.as<u32>();
+  HIPCHECK(ctx->qLut.ensure((size_t)PV_WHOLE * 4));
+  HIPCHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(misc + M_VQ), (int)0xFFFFFFFFu, 1, s));
+  // (GX_FAULT=2: "q is no threshold on the pileup")
+  HIPCHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(misc + M_VQ + 1), ctx->knob.fault == 2 ? (int)0xFFFFFFFFu : 0, 1, s));
+  hipLaunchKernelGGL(k_bh_small, dim3(1), dim3(1024), 0, s, (const u64*)ctx->bhDense.as<u64>(), ctx->pvLut.as<float>(), bh_table_of(ctx, cap),
+                     ctx->bhKQ.as<u64>(), reinterpret_cast<const u64*>(misc + M_GENOME), ctx->par.thr, ctx->qLut.as<float>(), misc + M_VQ,
+                     misc + M_ALLONE, genomeOpt ? ctx->dStatus.as<u32>() : (u32*)nullptr, ctx->dStatus.as<u32>());
+  ctx->denseHistUsed = true;
+  pa.qLazy = true;
+  ctx->lazyQUsed = true;
+  ctx->bhDirty = false;
+  ctx->bhLive = true;   // (freed by the next run that wants the table: bh_release_live)
+  ctx->bhLiveCap = cap;
+  ctx->bhLiveIdx = ctx->finalIdx;
   phase_end(ctx);
   return GX_OK;
 }
@@ -526,8 +544,7 @@ int loose_hist(gx_ctx* ctx, PArray& pa) {
 // computeQval / saveQval (Genrich.c:352-401, 212-250) for the final p-array `fa` of n intervals: the genome-wide table
 // {p -> bp} (with several ranks: after the exchange, gx_host_coll.h), its sort and suffix scan, q per interval and the
 // sweep's masks on the way.  genomeOpt: the genome length was computed (not -L): the lengths must add up to it
-// looseQ (round 6): the sweep walks the loose slots -- the table and its {key, q} pairs only (k_qv_table reads them); no interval array here
-int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt, bool looseQ = false) {
+int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt) {
   hipStream_t s = ctx->stream;
   u32* misc = ctx->misc.as<u32>();
   const u32 nChrom = ctx->nChrom;
@@ -578,10 +595,6 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt, bool looseQ = fal
       if (!(ctx->mail->status & ST_HASH_FULL)) break;
       if (ctx->mail->status != ST_HASH_FULL) return status_to_rc(ctx, ctx->mail->status & ~ST_HASH_FULL);
       HIPCHECK(hipMemsetAsync(ctx->dStatus.p, 0, 4, s));   // (a table too small: once more from the tight intervals, into a larger one)
-      if (looseQ) {   // (a few thousand distinct pileups at most against 2^22 slots: not reached; there is no tight table to go back to)
-        ctx->err = "p-value table full";
-        return GX_ERR_MEM;
-      }
       if (int rc = bh_grow()) return rc;
       fromDense = false;
       ctx->denseHistUsed = false;
@@ -680,11 +693,7 @@ int bh_qvalues(gx_ctx* ctx, PArray& fa, u32 n, bool genomeOpt, bool looseQ = fal
     }
 if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
   }
-  const bool lazyQ = !ctx->knob.noLazyQ || looseQ;
-  if (looseQ) {
-    HIPCHECK(hipMemsetAsync(misc + M_PSTAR, 0xFF, 4, s));
-    hipLaunchKernelGGL(k_kq_build, dim3(256), dim3(256), 0, s, T, ctx->bhQ.as<float>(), ctx->bhKQ.as<u64>(), ctx->par.thr, misc + M_PSTAR);
-  } else {
+  const bool lazyQ = !ctx->knob.noLazyQ;
   HIPCHECK(pooled(ctx, fa.q, (size_t)n * 4 + 16));
   // q-values and, on the way, the sweep's significance / SKIP masks
   {
@@ -704,7 +713,6 @@ if (int rc__ = dbg_sync(ctx, "k_qtable")) return rc__;
     } else {
       if (int rc__ = qlookup_all(ctx, fa, cap, ctx->swMask.as<u64>(), ctx->swMask.as<u64>() + stride)) return rc__;
     }
-  }
   }
   fa.qLazy = lazyQ;
   ctx->lazyQUsed = lazyQ;

@@ -15,7 +15,7 @@ struct SweepSrc {
   // the sweep on the loose slots (LooseCtl): `end` = the loose ends, p = the table p(V) looked up with the slots' exact
   // pileups `V`; the masks are [significant | first of its chromosome], `mStride` apart, and there are no SKIP intervals
   const int* V = nullptr;
-  const float* qLut = nullptr;   // ... with -q: q by whole pileup (k_qv_table) -- the AUC and the summits take q from it
+  const float* qLut = nullptr;   // ... with -q: q by whole pileup (k_bh_small) -- the AUC and the summits take q from it
   bool haveMasks = false, hasSkip = true;
   const u32* chromOff = nullptr;
   u32 nChrom = 0, nWords = 0;

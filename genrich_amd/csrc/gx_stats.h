@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_loose_late(const u32* __restrict__ tile
   __shared__ u32 red[2];
   int vsig;
   if (vq) {
-    // -q (k_qv_table): vq[0] = the smallest pileup present whose q passes, vq[1] = 1 + the largest present whose q does not
+    // -q (k_bh_small): vq[0] = the smallest pileup present whose q passes, vq[1] = 1 + the largest present whose q does not
     const u32 v0 = vq[0], v1 = vq[1];
     if (v1 > v0) {  // q is no threshold on the pileup (a table p(V) that is not monotone): the host takes the tight table
       if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(st, ST_Q_LOOSE);
@@ -295,7 +295,10 @@ __global__ __launch_bounds__(256) void k_pack_pval(PackIn in, u32 nTiles, const 
             const u32 len = e[k] - pe;
             const u32 c = __umulhi((u32)v[k], 0x88888889u) >> 6;
             if (c * GX_UNIT == (u32)v[k]) atomicAdd(&vh[(lane & 1) * PV_WHOLE + c], len);
-            else atomicAdd((unsigned long long*)&dense[v[k]], (unsigned long long)len);
+            else {
+              atomicAdd((unsigned long long*)&dense[v[k]], (unsigned long long)len);
+              if (!TIGHT) atomicOr(st, ST_Q_LOOSE);   // (a pileup that is no whole number: k_bh_small's table is by whole pileup)
+            }
           }
           if (k == PP_UNROLL - 1) carryPrev = (u32)__shfl((int)e[k], 63, 64);   // (the next batch's first interval follows lane 63's)
         }
@@ -592,24 +595,6 @@ __global__ __launch_bounds__(256) void k_q_fill_cands(const uint4* __restrict__ 
   }
 }
 
-// -q on the loose slots (round 6): q as a function of the whole pileup, from the run's {key, q} table -- q(c) = table[p(c)] for every
-// pileup c that occurs (a pileup that does not occur was never inserted: its entry is never read) --, and from which pileup on an
-// interval is significant: vq[0] = min over the present c with q > thr of 120 c, vq[1] = max over the others of 120 c + 1 (both preset
-// by the host: ~0 and 0).  qLut[c]: what k_peak_both's LDS copy is made of.
-__global__ __launch_bounds__(256) void k_qv_table(const float* __restrict__ lutP, const u64* __restrict__ kq, u32 capMask, float thr,
-                                                  float* __restrict__ qLut, u32* __restrict__ vq) {
-  const u32 c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= PV_WHOLE) return;
-  const float pv = lutP[c * (u32)GX_UNIT];   // (the entry k_bh_from_dense made the key of)
-  float qv = 0.0f;
-  const bool present = kq_probe(kq, capMask, pv == 0.0f ? 0u : __float_as_uint(pv), &qv);
-  qLut[c] = present ? qv : 0.0f;
-  if (present) {
-    if (qv > thr) atomicMin(&vq[0], c * (u32)GX_UNIT);
-    else atomicMax(&vq[1], c * (u32)GX_UNIT + 1u);
-  }
-}
-
 __host__ __device__ constexpr size_t bh_hist_lds(int lt) { return (size_t)lt * 12; }
 template <int NT, int BH_LT, int BH_LPROBE>
 __global__ __launch_bounds__(NT) void k_bh_hist(const u32* __restrict__ end, const float* __restrict__ p,
@@ -838,6 +823,7 @@ __device__ __forceinline__ T block_excl_scan_op(T v, T identity, T* scratch, Op 
 
 struct OpAddU64 { __device__ u64 operator()(u64 a, u64 b) const { return a + b; } };
 struct OpMinF { __device__ float operator()(float a, float b) const { return a < b ? a : b; } };
+struct OpLastU32 { __device__ u32 operator()(u32 a, u32 b) const { return b != 0xFFFFFFFFu ? b : a; } };   // (the later one, if there is one)
 
 __global__ __launch_bounds__(1024) void k_qtable(const u32* __restrict__ keys, const u32* __restrict__ slots,
                                                  const u64* __restrict__ gLens, u32 D, const u64* __restrict__ genomeLenPtr,
@@ -873,6 +859,90 @@ __global__ __launch_bounds__(1024) void k_qtable(const u32* __restrict__ keys, c
     qOfSlot[slots[i]] = q;
     if (r == 0 && allOne) *allOne = q == 0.0f;  // "All q-values are 1" (245)
   }
+}
+
+// -q on the loose slots (round 6): ALL of computeQval (352-401) for a table whose values are a function of the whole pileup, in one
+// workgroup -- no device-wide insertion, no sort, no round trip to the host for the number of distinct values.  dense[120 c] = bp at
+// pileup c (k_pack_pval<.., HIST, false>), p(c) = lutP[120 c].  p never falls as c grows (checked: ST_Q_LOOSE otherwise, the host takes
+// the tight table), so the table sorted by p is the pileups in their own order, equal p lying side by side: the most significant
+// first, as k_qtable walks its sorted values.  A value's rank k = 1 + bp of the strictly more significant ones, raw = p + logN +
+// log10f(k), q = max(min over the values at least as significant, 0).  Of the pileups that share one p the topmost PRESENT one
+// stands for the value (everything above it is strictly more significant); a pileup that does not occur takes no part.
+// Out: qLut[c] (k_peak_both's LDS table), vq[0] / vq[1] (the smallest present pileup whose q passes, 1 + the largest whose q does
+// not, in 1/120 units; preset by the host), {key, q} of every distinct value in the run's table (what k_qlookup probes when
+// gx_get_intervals asks for the q array), "all q-values are 1" (245), the length check (377-382).
+__global__ __launch_bounds__(1024) void k_bh_small(const u64* __restrict__ dense, const float* __restrict__ lutP, BhTable T,
+                                                   u64* __restrict__ kq, const u64* __restrict__ genomeLenPtr, float thr,
+                                                   float* __restrict__ qLut, u32* __restrict__ vq, u32* __restrict__ allOne,
+                                                   u32* __restrict__ lenCheck, u32* __restrict__ st) {
+  __shared__ u64 s64[20];
+  __shared__ float sf[20];
+  __shared__ u32 su[20];
+  __shared__ u32 keyS[PV_WHOLE];
+  __shared__ u64 bpS[PV_WHOLE];
+  for (u32 c = threadIdx.x; c < PV_WHOLE; c += 1024) {
+    const float pv = lutP[c * (u32)GX_UNIT];
+    keyS[c] = pv == 0.0f ? 0u : __float_as_uint(pv);
+    bpS[c] = dense[c * (u32)GX_UNIT];
+  }
+  __syncthreads();
+  const float logN = -log10f_host((float)*genomeLenPtr);
+  constexpr u32 PER = (PV_WHOLE + 1023) / 1024, NONE = 0xFFFFFFFFu;
+  const u32 r0 = min((u32)PV_WHOLE, threadIdx.x * PER), r1 = min((u32)PV_WHOLE, r0 + PER);  // reversed indices: c = PV_WHOLE - 1 - r
+  // bp of the strictly-above entries, and the nearest present entry above (reversed order: "before")
+  u64 sum = 0;
+  u32 lastPresent = NONE;   // (the lowest present c of my run = the latest in reversed order)
+  for (u32 r = r0; r < r1; r++) {
+    const u32 c = PV_WHOLE - 1 - r;
+    sum += bpS[c];
+    if (bpS[c]) lastPresent = c;
+  }
+  u64 above = block_excl_scan_op<u64, 1024>(sum, 0ull, s64, OpAddU64());
+  u32 presAbove = block_excl_scan_op<u32, 1024>(lastPresent, NONE, su, OpLastU32());
+  if (lenCheck && threadIdx.x == 1023 && above + sum != *genomeLenPtr) atomicOr(lenCheck, ST_BH_LEN);
+  float raw[PER], mn = FLT_MAX;
+  u32 bad = 0, firstIdx = NONE;   // (firstIdx: the genome's most significant value is mine)
+  for (u32 r = r0; r < r1; r++) {
+    const u32 c = PV_WHOLE - 1 - r, i = r - r0;
+    raw[i] = FLT_MAX;
+    if (bpS[c]) {
+      if (presAbove == NONE) firstIdx = i;
+      if (presAbove != NONE && keyS[presAbove] < keyS[c]) bad = 1;   // p falls as the pileup grows
+      if (presAbove == NONE || keyS[presAbove] != keyS[c]) raw[i] = __uint_as_float(keyS[c]) + logN + log10f_host((float)(1ull + above));
+      presAbove = c;
+    }
+    above += bpS[c];
+    mn = raw[i] < mn ? raw[i] : mn;
+  }
+  if (bad) atomicOr(st, ST_Q_LOOSE);
+  float run = block_excl_scan_op<float, 1024>(mn, FLT_MAX, sf, OpMinF());
+  u32 vMin = NONE, vMax = 0;
+  for (u32 r = r0; r < r1; r++) {
+    const u32 c = PV_WHOLE - 1 - r, i = r - r0;
+    const bool top = raw[i] != FLT_MAX;
+    run = raw[i] < run ? raw[i] : run;
+    const float q = run > 0.0f ? run : 0.0f;
+    qLut[c] = bpS[c] ? q : 0.0f;
+    if (bpS[c]) {
+      if (q > thr) vMin = min(vMin, c * (u32)GX_UNIT);
+      else vMax = max(vMax, c * (u32)GX_UNIT + 1u);
+    }
+    if (top) {
+      // the value's entry in the run's table (clean at this point: at most PV_WHOLE insertions into >= 2^22 slots)
+      const u32 key = keyS[c];
+      u32 h = bh_hash(key) & T.capMask, old;
+      while ((old = atomicCAS(&T.keys[h], EMPTY_KEY, key)) != EMPTY_KEY && old != key) h = (h + 1) & T.capMask;
+      if (old == EMPTY_KEY) {
+        const u32 j = atomicAdd(T.counter, 1u);
+        T.outKeys[j] = key;
+        T.outSlot[j] = h;
+      }
+      kq[h] = (u64)key | ((u64)__float_as_uint(q) << 32);
+    }
+    if (allOne && i == firstIdx) *allOne = q == 0.0f;  // "All q-values are 1" (245)
+  }
+  if (vMin != NONE) atomicMin(&vq[0], vMin);
+  if (vMax) atomicMax(&vq[1], vMax);
 }
 
 // The same table for many distinct values (Fisher-combined replicates give millions): three launches over
@@ -1340,7 +1410,7 @@ __device__ __forceinline__ float q_from_v(const float* __restrict__ hotq, const 
   const u32 c = __umulhi((u32)V[i], 0x88888889u) >> 6;  // V / 120
   return hotq[c < PV_WHOLE ? c : 0u];
 }
-// (PVQ, round 6: -q on the loose slots -- q as well is a function of the whole pileup, from a second LDS table, k_qv_table's)
+// (PVQ, round 6: -q on the loose slots -- q as well is a function of the whole pileup, from a second LDS table, k_bh_small's)
 template <bool USEQ, bool PV, bool PVQ = false>  // compile-time: a run-time test of `q` inside the loop costs the load scheduling
 __device__ __forceinline__ void peak_short_body(const u32 blk, const u32 nBlk, const float* __restrict__ hot, const float* __restrict__ hotq,
                                                 const uint4* __restrict__ hdr, const u32* __restrict__ end,

@@ -326,7 +326,7 @@ int gx_set_knob(gx_ctx* ctx, const char* name, const char* value);
 #define GX_PATH_PACK_HIST 2048u /* bit 11: -q on one replicate without control: BH's table was made of the "bp at pileup V" sums that the tight table's kernel left (k_pack_pval<.., HIST>), not by k_bh_hist */
 #define GX_PATH_LAZY_Q 8192u /* bit 13: -q: the sweep's significance bits came from one compare per interval against the smallest significant p, q was looked up inside the candidates only (k_sig_from_p + k_q_fill_cands; the whole q array on request) */
 #define GX_PATH_LATE_LOOSE 16384u /* bit 14: ... GX_PATH_LOOSE_SWEEP on a sample whose lambda came with its end (fractional weights): the bits and the fillers were written after the tile stage (k_loose_late) */
-#define GX_PATH_Q_LOOSE 32768u /* bit 15: -q on one replicate without control: no tight table -- BH's histogram from the loose slots, q by pileup, the sweep on the loose slots (k_qv_table, k_loose_late, k_peak_both<.., PVQ>) */
+#define GX_PATH_Q_LOOSE 32768u /* bit 15: -q on one replicate without control: no tight table -- BH's histogram from the loose slots, q by pileup, the sweep on the loose slots (k_bh_small, k_loose_late, k_peak_both<.., PVQ>) */
 #define GX_PATH_MERGE_P 1024u /* bit 10: the last control merge scored its intervals itself and left (end, p) in its loose slots (k_merge2<.., true> + k_pack_ep2) */
 #define GX_PATH_FRAC_PAIRS 128u /* bit 7: ... and the pair records carried a weight class (k_sort_a<FRAC> / k_sbtile<.., FRAC>: -s multimapping) */
 int gx_path_info(gx_ctx* ctx, unsigned* flags);

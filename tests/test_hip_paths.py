@@ -673,7 +673,7 @@ def test_fractional_weights_sweep_the_loose_slots_once_the_table_is_there(kind):
     o.close()
 
 
-# ---- -q on the loose slots (round 6: k_pack_pval<.., HIST, false>, k_qv_table, k_loose_late, k_peak_both<.., PVQ>) ----
+# ---- -q on the loose slots (round 6: k_pack_pval<.., HIST, false>, k_bh_small, k_loose_late, k_peak_both<.., PVQ>) ----
 
 @pytest.mark.parametrize("kind", ["plain", "skipped", "fault", "deep", "twice"])
 def test_q_values_on_the_loose_slots_without_a_tight_table(monkeypatch, kind):
